@@ -1,0 +1,230 @@
+"""Host-side view of a decoded batch: numpy copies of the canonical arena of
+include/etlg.h plus a materialiser that rebuilds the reference's value model.
+
+`materialize()` is the Python analog of the Rust shim a maintainer would add
+(INTEGRATION.md): it walks the arena and yields what
+`Destination::write_events` receives — Event{kind, lsns, ordinal, rows of
+Cells} (crates/etl/src/event.rs:21-267, crates/etl/src/data/cell.rs:19-57).
+"""
+import ctypes as C
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+
+
+def _np_from(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    nbytes = n * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+@dataclass
+class SlotCol:
+    type_oid: int
+    stored_index: int
+    type_class: int
+    nullable: int
+    identity: int
+    off_full: int
+    off_key: int
+    key_index: int
+
+
+@dataclass
+class Slot:
+    table_id: int
+    n_stored: int
+    snapshot_lsn: int
+    n_ident: int
+    row_bytes_full: int
+    row_bytes_key: int
+    state_bytes_full: int
+    state_bytes_key: int
+    cols: list = field(default_factory=list)
+
+    def key_cols(self):
+        return [c for c in self.cols if c.identity]
+
+
+def slots_from_ptr(ptr, n):
+    out = []
+    for k in range(n):
+        d = ptr[k]
+        s = Slot(d.table_id, d.n_stored, d.snapshot_lsn, d.n_ident, d.row_bytes_full,
+                 d.row_bytes_key, d.state_bytes_full, d.state_bytes_key)
+        for i in range(d.n_cols):
+            c = d.cols[i]
+            s.cols.append(SlotCol(c.type_oid, c.stored_index, c.type_class, c.nullable,
+                                  c.identity, c.off_full, c.off_key, c.key_index))
+        out.append(s)
+    return out
+
+
+@dataclass
+class HostBatch:
+    n_events: int
+    n_frames: int
+    payload_bytes: tuple
+    kind: np.ndarray
+    flags: np.ndarray
+    table_id: np.ndarray
+    schema_slot: np.ndarray
+    start_lsn: np.ndarray
+    commit_lsn: np.ndarray
+    tx_ordinal: np.ndarray
+    body_off: np.ndarray
+    fixed: np.ndarray
+    heap: np.ndarray
+    slots: list
+
+    ARRAYS = ("kind", "flags", "table_id", "schema_slot", "start_lsn", "commit_lsn",
+              "tx_ordinal", "body_off", "fixed", "heap")
+
+    @classmethod
+    def from_view(cls, v):
+        """v: abi.BatchView with HOST pointers."""
+        assert not v.on_device, "copy device views with etl_amd.native first"
+        n = v.n_events
+        return cls(
+            n_events=n, n_frames=v.n_frames, payload_bytes=tuple(v.payload_bytes),
+            kind=_np_from(v.ev_kind, n, np.uint8), flags=_np_from(v.ev_flags, n, np.uint8),
+            table_id=_np_from(v.ev_table_id, n, np.uint32),
+            schema_slot=_np_from(v.ev_schema_slot, n, np.uint32),
+            start_lsn=_np_from(v.ev_start_lsn, n, np.uint64),
+            commit_lsn=_np_from(v.ev_commit_lsn, n, np.uint64),
+            tx_ordinal=_np_from(v.ev_tx_ordinal, n, np.uint64),
+            body_off=_np_from(v.ev_body_off, n, np.uint64),
+            fixed=_np_from(v.fixed, v.fixed_bytes, np.uint8),
+            heap=_np_from(v.heap, v.heap_bytes, np.uint8),
+            slots=slots_from_ptr(v.slots, v.n_slots))
+
+    # ---------------------------------------------------------------- parity
+    def diff(self, other):
+        """Byte-for-byte comparison; returns a list of human-readable differences."""
+        out = []
+        if self.n_events != other.n_events:
+            out.append(f"n_events {self.n_events} != {other.n_events}")
+        if self.n_frames != other.n_frames:
+            out.append(f"n_frames {self.n_frames} != {other.n_frames}")
+        if tuple(self.payload_bytes) != tuple(other.payload_bytes):
+            out.append(f"payload_bytes {self.payload_bytes} != {other.payload_bytes}")
+        for name in self.ARRAYS:
+            a, b = getattr(self, name), getattr(other, name)
+            if a.shape != b.shape:
+                out.append(f"{name}: shape {a.shape} != {b.shape}")
+                continue
+            if not np.array_equal(a, b):
+                idx = int(np.flatnonzero(a != b)[0])
+                out.append(f"{name}: first difference at [{idx}]: {a[idx]} != {b[idx]}")
+        if len(self.slots) != len(other.slots):
+            out.append(f"slots: {len(self.slots)} != {len(other.slots)}")
+        else:
+            for k, (a, b) in enumerate(zip(self.slots, other.slots)):
+                if a != b:
+                    out.append(f"slot {k}: {a} != {b}")
+        return out
+
+    # ----------------------------------------------------------- materialise
+    def _heap(self, off, ln):
+        return self.heap[off:off + ln].tobytes()
+
+    def _cell(self, col, state, slot_bytes):
+        tc = col.type_class
+        if state == abi.CELL_NULL:
+            return ("Null",)
+        if state == abi.CELL_MISSING:
+            return ("Missing",)
+        if state == abi.CELL_DEFERRED:
+            off, ln = struct.unpack_from("<II", slot_bytes, 0)
+            return ("Deferred", col.type_oid, self._heap(off, ln))
+        if tc == abi.TC_BOOL:
+            return ("Bool", bool(struct.unpack_from("<I", slot_bytes)[0]))
+        if tc == abi.TC_I16:
+            return ("I16", struct.unpack_from("<i", slot_bytes)[0])
+        if tc == abi.TC_I32:
+            return ("I32", struct.unpack_from("<i", slot_bytes)[0])
+        if tc == abi.TC_U32:
+            return ("U32", struct.unpack_from("<I", slot_bytes)[0])
+        if tc == abi.TC_I64:
+            return ("I64", struct.unpack_from("<q", slot_bytes)[0])
+        if tc == abi.TC_F32:
+            return ("F32", struct.unpack_from("<I", slot_bytes)[0])
+        if tc == abi.TC_F64:
+            return ("F64", struct.unpack_from("<Q", slot_bytes)[0])
+        if tc == abi.TC_DATE:
+            return ("Date", struct.unpack_from("<i", slot_bytes)[0])
+        if tc == abi.TC_TIME:
+            return ("Time",) + struct.unpack_from("<II", slot_bytes)
+        if tc == abi.TC_TIMESTAMP:
+            return ("Timestamp",) + struct.unpack_from("<iII", slot_bytes)
+        if tc == abi.TC_TIMESTAMPTZ:
+            return ("TimestampTz",) + struct.unpack_from("<iII", slot_bytes)
+        if tc == abi.TC_TIMETZ:
+            return ("TimeTz",) + struct.unpack_from("<IIi", slot_bytes)
+        if tc == abi.TC_UUID:
+            return ("Uuid", bytes(slot_bytes[:16]))
+        off, ln = struct.unpack_from("<II", slot_bytes, 0)
+        raw = self._heap(off, ln)
+        if tc == abi.TC_NUMERIC:
+            kind, sign, weight, scale, nd = struct.unpack_from("<BBhHH", raw, 0)
+            digits = struct.unpack_from(f"<{(ln - 8) // 2}h", raw, 8)
+            return ("Numeric", kind, sign, weight, scale, digits)
+        if tc == abi.TC_BYTEA:
+            return ("Bytes", raw)
+        return ("String", raw)
+
+    def _row(self, slot, base, key_layout):
+        cols = slot.key_cols() if key_layout else slot.cols
+        fx = self.fixed
+        cells = []
+        for i, col in enumerate(cols):
+            st = (int(fx[base + i // 4]) >> (2 * (i % 4))) & 3
+            so = base + (col.off_key if key_layout else col.off_full)
+            cells.append(self._cell(col, st, fx[so:so + 16].tobytes()))
+        return cells
+
+    def materialize(self):
+        """List of event dicts mirroring the reference's Event enum."""
+        out = []
+        fx = self.fixed
+        for i in range(self.n_events):
+            k = chr(self.kind[i])
+            e = {"kind": k, "start_lsn": int(self.start_lsn[i]), "commit_lsn": int(self.commit_lsn[i]),
+                 "tx_ordinal": int(self.tx_ordinal[i])}
+            base = int(self.body_off[i])
+            fl = int(self.flags[i])
+            if k == "B":
+                e["xid"] = int(self.table_id[i])
+                e["timestamp"] = struct.unpack_from("<q", fx, base)[0]
+            elif k == "C":
+                e["flags"] = fl - 256 if fl > 127 else fl
+                e["end_lsn"], e["timestamp"] = struct.unpack_from("<Qq", fx, base)
+            elif k == "R":
+                e["table_id"] = int(self.table_id[i])
+                e["schema_slot"] = int(self.schema_slot[i])
+            elif k == "T":
+                e["options"] = fl - 256 if fl > 127 else fl
+                n = int(self.table_id[i])
+                e["tables"] = [struct.unpack_from("<II", fx, base + 8 * j) for j in range(n)]
+            else:
+                e["table_id"] = int(self.table_id[i])
+                e["schema_slot"] = int(self.schema_slot[i])
+                slot = self.slots[e["schema_slot"]]
+                if k == "I":
+                    e["row"] = self._row(slot, base, False)
+                else:
+                    ok = fl & 3
+                    e["old_kind"] = ("None", "Full", "Key")[ok]
+                    old_sz = slot.row_bytes_full if ok == abi.OLD_FULL else slot.row_bytes_key if ok == abi.OLD_KEY else 0
+                    if ok:
+                        e["old_row"] = self._row(slot, base, ok == abi.OLD_KEY)
+                    if k == "U":
+                        e["partial"] = bool(fl & abi.FLAG_PARTIAL)
+                        e["row"] = self._row(slot, base + old_sz, False)
+            out.append(e)
+        return out

@@ -1,0 +1,410 @@
+/*
+ * etlg.h — C ABI of libetl_gfx950.so, the MI355X-native batched pgoutput decode
+ * + CDC event-transform stage that drops in upstream of supabase/etl's
+ * Destination::write_events.
+ *
+ * The reference has no FFI for this path (it is 100 % Rust, monomorphised
+ * generics).  Each entry point below names the reference code it replaces
+ * (paths relative to the supabase/etl checkout):
+ *
+ *   etlg_ctx_create / _destroy   one per apply-loop stream; owns what
+ *                                ApplyLoop keeps in `self.state` + the
+ *                                SharedTableCache
+ *                                (crates/etl/src/replication/apply.rs:942-963,
+ *                                 crates/etl/src/replication/table_cache.rs:88-154)
+ *   etlg_ctx_set_worker          WorkerContext::{Apply,TableSync} ownership rule
+ *                                (apply.rs:2626-2639, 2836-2867, 3514-3519) and the
+ *                                bootstrap snapshot id (apply.rs:2410-2413)
+ *   etlg_schema_put              SchemaStore::store_table_schema /
+ *                                get_table_schema at-or-before lookup
+ *                                (crates/etl/src/store/schema/base.rs:19-69,
+ *                                 crates/etl/src/store/schema/table.rs:61-71)
+ *   etlg_table_state             StateStore::get_table_state for the
+ *                                should_apply_changes filter (apply.rs:2836-2867)
+ *   etlg_table_ready             SharedTableCache::note_ready as done by the
+ *                                table-copy path before streaming starts
+ *                                (table_cache.rs:122)
+ *   etlg_decode                  the body of the hot loop for N messages:
+ *                                ReplicationMessage::parse +
+ *                                LogicalReplicationMessage::parse
+ *                                (postgres-replication 0.6.7, call sites
+ *                                 apply.rs:2037-2125) → handle_*_message
+ *                                (apply.rs:2279-2617) → codec::parse_event_from_*
+ *                                (crates/etl/src/postgres/codec/event.rs:303-547)
+ *                                → parse_cell_from_postgres_text
+ *                                (crates/etl/src/postgres/codec/text.rs:32-153)
+ *   etlg_last_error              EtlError {kind, description, detail}
+ *                                (crates/etl/src/error.rs:27-76, 85-170)
+ *   etlg_batch_*                 the Vec<Event> pushed into EventBatch
+ *                                (apply.rs:1918-1928), as a columnar arena
+ *
+ * Conventions mirrored from the Rust side: callee allocates results, caller
+ * frees through the exported free; a context is NOT re-entrant (the apply
+ * loop is `&mut self`); decode is fail-fast: the first bad frame stops the
+ * batch, all events before it stay valid, and the error carries the
+ * reference's ErrorKind + static description string.
+ *
+ * No torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef ETLG_H
+#define ETLG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ETLG_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------ errors */
+
+/* Subset of crates/etl/src/error.rs:85-170 `ErrorKind` reachable from the
+ * decode path. Values are ours; names are the reference's. */
+typedef enum etlg_error_kind {
+  ETLG_OK = 0,
+  ETLG_ConversionError = 1,        /* error.rs ConversionError */
+  ETLG_InvalidData = 2,            /* error.rs InvalidData */
+  ETLG_ValidationError = 3,        /* error.rs ValidationError */
+  ETLG_InvalidState = 4,           /* error.rs InvalidState */
+  ETLG_MissingTableSchema = 5,     /* error.rs MissingTableSchema */
+  ETLG_CorruptedTableSchema = 6,   /* error.rs CorruptedTableSchema */
+  ETLG_DeserializationError = 7,   /* error.rs DeserializationError */
+  ETLG_SourceConnectionFailed = 8, /* wire-level parse failure: tokio_postgres::Error
+                                      without SQLSTATE (error.rs:947) */
+  ETLG_IoError = 9,                /* io::Error from cstr accessors (error.rs:564) */
+  /* library-level (no reference analog) */
+  ETLG_InvalidArgument = 100,
+  ETLG_DeviceError = 101,
+  ETLG_Unsupported = 102
+} etlg_error_kind;
+
+typedef struct etlg_error {
+  int32_t kind;            /* etlg_error_kind */
+  int32_t code;            /* etlg_err_code: identifies the static description */
+  const char* description; /* the reference's static description string */
+  const char* detail;      /* optional dynamic detail (may be NULL) */
+  int64_t frame_index;     /* index of the offending CopyData frame, -1 if n/a */
+} etlg_error;
+
+/* One code per distinct (kind, static description) pair produced on this
+ * path; the table lives in etlg_err_table() so oracle, kernels and tests
+ * share numbering but not code. */
+typedef enum etlg_err_code {
+  ETLG_E_NONE = 0,
+  ETLG_E_WIRE = 1,                /* SourceConnectionFailed / "PostgreSQL connection failed" */
+  ETLG_E_TXN_STATE = 2,           /* InvalidState / "Invalid transaction state" */
+  ETLG_E_COMMIT_LSN = 3,          /* ValidationError / "Invalid commit LSN" */
+  ETLG_E_MISSING_SHARED_STATE = 4,/* InvalidState / "Missing shared table state" */
+  ETLG_E_WAITING_RELATION = 5,    /* InvalidState / "Waiting for relation state cannot decode row event" */
+  ETLG_E_TUPLE_WIDTH = 6,         /* ConversionError / "Tuple data field count does not match schema" */
+  ETLG_E_FULL_ROW_MISSING = 7,    /* ConversionError / "Tuple missing source value for full row image" */
+  ETLG_E_REQUIRED_NULL = 8,       /* InvalidData / "Required column missing from tuple" */
+  ETLG_E_BINARY_FORMAT = 9,       /* ConversionError / "Binary format not supported in tuple data" */
+  ETLG_E_UTF8 = 10,               /* ConversionError / "UTF-8 conversion failed" */
+  ETLG_E_OLD_ROW_WIDTH = 11,      /* ConversionError / "Old tuple row width does not match schema" */
+  ETLG_E_KEY_SHAPE = 12,          /* ConversionError / "Replica-identity tuple shape does not match schema" */
+  ETLG_E_KEY_MISSING_COLS = 13,   /* ConversionError / "Replica-identity tuple missing key columns" */
+  ETLG_E_KEY_MISSING_VALUE = 14,  /* ConversionError / "Replica-identity tuple missing source value" */
+  ETLG_E_BOOL = 15,               /* InvalidData / "Invalid boolean value" */
+  ETLG_E_INT = 16,                /* ConversionError / "Integer parsing failed" */
+  ETLG_E_FLOAT = 17,              /* ConversionError / "Float parsing failed" */
+  ETLG_E_NUMERIC = 18,            /* ConversionError / "Numeric parsing failed" */
+  ETLG_E_BYTEA = 19,              /* ConversionError / "Bytea hex string conversion failed" */
+  ETLG_E_DATETIME = 20,           /* ConversionError / "Datetime parsing failed" */
+  ETLG_E_UUID = 21,               /* InvalidData / "UUID parsing failed" */
+  ETLG_E_JSON = 22,               /* DeserializationError / "JSON deserialization failed" */
+  ETLG_E_ARRAY_SHORT = 23,        /* ConversionError / "Array input too short" */
+  ETLG_E_ARRAY_BRACES = 24,       /* ConversionError / "Array input missing braces" */
+  ETLG_E_ARRAY_DIMS = 25,         /* ConversionError / "Array input has a malformed dimensions prefix" */
+  ETLG_E_ARRAY_MULTIDIM = 26,     /* ConversionError / "Multidimensional array input is not supported" */
+  ETLG_E_ARRAY_QUOTE = 27,        /* ConversionError / "Array input contains an unterminated quote" */
+  ETLG_E_ARRAY_ESCAPE = 28,       /* ConversionError / "Array input contains an unterminated escape" */
+  ETLG_E_SCHEMA_NOT_FOUND = 29,   /* MissingTableSchema / "Table schema not found" */
+  ETLG_E_UNKNOWN_COLUMNS = 30,    /* CorruptedTableSchema / "Replication stream contains columns missing from the stored table schema" */
+  ETLG_E_DDL_PARSE = 31,          /* ConversionError / "Failed to parse schema change message" */
+  ETLG_E_IO = 32,                 /* IoError / "I/O operation failed" */
+  ETLG_E_BOOTSTRAP_SNAPSHOT = 33, /* InvalidState / "Bootstrap table schema snapshot exceeded requested snapshot" */
+  ETLG_E_SNAPSHOT_MISMATCH = 34,  /* InvalidState / "Table schema snapshot mismatch" */
+  ETLG_E_CTRL_HINT = 35,          /* InvalidArgument / "Control frame found in a batch declared control-free" */
+  ETLG_E__COUNT
+} etlg_err_code;
+
+typedef struct etlg_err_desc {
+  int32_t kind;
+  const char* description;
+} etlg_err_desc;
+
+/* Static (kind, description) for a code; NULL if out of range. */
+const etlg_err_desc* etlg_err_table(int32_t code);
+
+/* ----------------------------------------------------------------- schemas */
+
+/* Value class a column decodes to; determined by the column's *stored* type
+ * OID exactly as parse_cell_from_postgres_text switches on it
+ * (crates/etl/src/postgres/codec/text.rs:32-153; unknown OIDs are TEXT,
+ * crates/etl-postgres/src/type_utils.rs:9-11). */
+typedef enum etlg_type_class {
+  ETLG_TC_STRING = 0, /* everything without a dedicated arm -> Cell::String */
+  ETLG_TC_BOOL = 1,
+  ETLG_TC_I16 = 2,
+  ETLG_TC_I32 = 3,
+  ETLG_TC_I64 = 4,
+  ETLG_TC_U32 = 5, /* oid */
+  ETLG_TC_F32 = 6,
+  ETLG_TC_F64 = 7,
+  ETLG_TC_NUMERIC = 8,
+  ETLG_TC_BYTEA = 9,
+  ETLG_TC_DATE = 10,
+  ETLG_TC_TIME = 11,
+  ETLG_TC_TIMETZ = 12,
+  ETLG_TC_TIMESTAMP = 13,
+  ETLG_TC_TIMESTAMPTZ = 14,
+  ETLG_TC_UUID = 15,
+  ETLG_TC_JSON = 16,
+  ETLG_TC_ARRAY = 17, /* any `_xxx` array type; element class via etlg_array_elem_class */
+  ETLG_TC__COUNT
+} etlg_type_class;
+
+/* OID -> class; never fails (unknown -> STRING). */
+int32_t etlg_type_class_of_oid(uint32_t type_oid);
+/* For an array OID: element class (STRING for arrays without a dedicated arm). */
+int32_t etlg_array_elem_class(uint32_t array_type_oid);
+/* Bytes a column of this class occupies in a row's fixed block (multiple of 4). */
+uint32_t etlg_slot_bytes(int32_t type_class);
+
+/* A stored column, in attnum order — what ColumnSchema carries
+ * (crates/etl-postgres/src/schema.rs:213). */
+typedef struct etlg_col {
+  const char* name; /* NUL-terminated UTF-8; masks are built by name (crates/etl/src/schema.rs:30-61) */
+  uint32_t type_oid;
+  int32_t type_modifier;
+  int32_t attnum;       /* ordinal_position */
+  uint8_t nullable;     /* !attnotnull */
+  uint8_t primary_key;  /* 1 if part of the primary key */
+  uint8_t _pad[2];
+} etlg_col;
+
+/* Table replication state as seen by should_apply_changes
+ * (apply.rs:2844-2850): Ready, SyncDone{lsn}, or anything else. */
+typedef enum etlg_table_state_kind {
+  ETLG_TS_ABSENT = 0,   /* no state stored -> never owned */
+  ETLG_TS_READY = 1,
+  ETLG_TS_SYNC_DONE = 2,/* owned iff lsn <= remote_final_lsn */
+  ETLG_TS_OTHER = 3     /* Init/DataSync/FinishedCopy/SyncWait/Catchup/Errored */
+} etlg_table_state_kind;
+
+typedef enum etlg_worker_kind {
+  ETLG_WORKER_APPLY = 0,
+  ETLG_WORKER_TABLE_SYNC = 1
+} etlg_worker_kind;
+
+/* --------------------------------------------------------------- lifecycle */
+
+typedef struct etlg_ctx etlg_ctx;
+typedef struct etlg_batch etlg_batch;
+
+uint32_t etlg_abi_version(void);
+
+/* hip_device >= 0 selects the GPU. There is no CPU backend: creation fails
+ * with ETLG_DeviceError when no gfx950 device is available. */
+int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out);
+void etlg_ctx_destroy(etlg_ctx* ctx);
+
+/* Run all device work of this context on an existing hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream). NULL = own stream. */
+int32_t etlg_ctx_set_stream(etlg_ctx* ctx, void* hip_stream);
+
+int32_t etlg_ctx_set_worker(etlg_ctx* ctx, int32_t worker_kind,
+                            uint32_t table_sync_table_id,
+                            uint64_t bootstrap_snapshot_lsn);
+
+int32_t etlg_schema_put(etlg_ctx* ctx, uint32_t table_id, uint64_t snapshot_lsn,
+                        const char* schema_name, const char* table_name,
+                        uint32_t ncols, const etlg_col* cols);
+
+int32_t etlg_table_state(etlg_ctx* ctx, uint32_t table_id, int32_t state_kind,
+                         uint64_t lsn);
+
+/* Pre-populate the shared table cache with a Ready replicated schema built
+ * from the stored schema at `snapshot_lsn` (at-or-before) and byte masks over
+ * its columns (1 = replicated / identity). Returns the schema slot id (>= 0)
+ * or a negative etlg_error_kind. */
+int32_t etlg_table_ready(etlg_ctx* ctx, uint32_t table_id, uint64_t snapshot_lsn,
+                         const uint8_t* replication_mask,
+                         const uint8_t* identity_mask, uint32_t nmask);
+
+/* Reset the transaction state (remote_final_lsn = None, next ordinal = 0),
+ * as a fresh ApplyLoop does. */
+int32_t etlg_ctx_reset_stream_state(etlg_ctx* ctx);
+
+/* ------------------------------------------------------------------ decode */
+
+enum {
+  ETLG_F_INPUT_ON_DEVICE = 1u << 0,  /* buf / frame_offsets are device pointers */
+  ETLG_F_OUTPUT_ON_DEVICE = 1u << 1, /* do not copy the arenas to the host; view holds device pointers */
+  ETLG_F_NO_CONTROL = 1u << 2,       /* caller asserts: no R/M/T frame in this batch (skips the
+                                        control-plane round trip; verified on device) */
+  ETLG_F_ASYNC = 1u << 3             /* with OUTPUT_ON_DEVICE: enqueue only, do not synchronize;
+                                        counts become valid after etlg_batch_sync */
+};
+
+/* buf = `nframes` concatenated CopyData frames exactly as on the socket:
+ *   'd' | Int32-BE length (incl. itself) | payload
+ * payload = XLogData 'w' | u64 wal_start | u64 wal_end | i64 ts | pgoutput msg
+ *         | keepalive 'k' | u64 wal_end | i64 ts | u8 reply
+ * frame_offsets: optional sidecar of nframes+1 byte offsets (the host learns
+ * each frame length on receipt); NULL = the device scans record boundaries
+ * itself and nframes is ignored.
+ * Returns 0, or the etlg_error_kind of the first failing frame (the batch is
+ * still returned and holds every event before it). */
+int32_t etlg_decode(etlg_ctx* ctx, const uint8_t* buf, size_t len,
+                    const uint32_t* frame_offsets, size_t nframes,
+                    uint32_t flags, etlg_batch** out);
+
+const etlg_error* etlg_last_error(const etlg_ctx* ctx);
+
+/* ------------------------------------------------------------ batch (arena) */
+
+/* Event kinds: the pgoutput tag of the message that produced the event. */
+enum {
+  ETLG_EV_BEGIN = 'B',
+  ETLG_EV_COMMIT = 'C',
+  ETLG_EV_RELATION = 'R',
+  ETLG_EV_INSERT = 'I',
+  ETLG_EV_UPDATE = 'U',
+  ETLG_EV_DELETE = 'D',
+  ETLG_EV_TRUNCATE = 'T'
+};
+
+/* ev_flags for U/D: bits 0-1 = old row kind, bit 2 = new row is Partial. */
+enum {
+  ETLG_OLD_NONE = 0,
+  ETLG_OLD_FULL = 1, /* OldTableRow::Full */
+  ETLG_OLD_KEY = 2,  /* OldTableRow::Key  */
+  ETLG_FLAG_PARTIAL = 4
+};
+
+/* 2-bit per-cell state stored at the head of every row block. */
+enum {
+  ETLG_CELL_VALUE = 0,
+  ETLG_CELL_NULL = 1,
+  ETLG_CELL_MISSING = 2, /* only inside a Partial new row */
+  ETLG_CELL_DEFERRED = 3 /* slot = (heap_off, len) of the source text; the host finishes
+                            it with the reference's own parse_cell_from_postgres_text */
+};
+
+/* Numeric heap entry header (followed by ndigits little-endian i16 base-10000
+ * digits): mirrors PgNumeric (crates/etl-postgres/src/numeric.rs:75-96). */
+enum { ETLG_NUM_VALUE = 0, ETLG_NUM_NAN = 1, ETLG_NUM_PINF = 2, ETLG_NUM_NINF = 3 };
+typedef struct etlg_numeric_hdr {
+  uint8_t kind; /* ETLG_NUM_* */
+  uint8_t sign; /* 0 positive, 1 negative */
+  int16_t weight;
+  uint16_t scale;
+  uint16_t ndigits;
+} etlg_numeric_hdr;
+
+/* One replicated column of a schema slot. */
+typedef struct etlg_slot_col {
+  uint32_t type_oid;
+  uint16_t stored_index; /* index into the stored (attnum-ordered) schema */
+  uint8_t type_class;    /* etlg_type_class */
+  uint8_t nullable;
+  uint8_t identity;      /* replicated && identity */
+  uint8_t _pad;
+  uint16_t off_full;     /* byte offset of the slot inside a full-layout row block */
+  uint16_t off_key;      /* byte offset inside a key-layout row block (identity cols only) */
+  uint16_t key_index;    /* position among identity columns, 0xFFFF if not identity */
+} etlg_slot_col;
+
+/* A ReplicatedTableSchema instance (crates/etl/src/schema.rs:380-441): the
+ * stored schema at one snapshot + replication/identity masks. */
+typedef struct etlg_slot_desc {
+  uint32_t table_id;
+  uint32_t n_stored;     /* columns in the stored schema */
+  uint64_t snapshot_lsn; /* snapshot id of the stored schema */
+  uint32_t n_cols;       /* replicated columns */
+  uint32_t n_ident;      /* replicated identity columns */
+  uint32_t row_bytes_full; /* state bytes (padded to 4) + slots */
+  uint32_t row_bytes_key;
+  uint32_t state_bytes_full; /* = 4*ceil(n_cols/16) */
+  uint32_t state_bytes_key;  /* = 4*ceil(n_ident/16) */
+  const etlg_slot_col* cols; /* n_cols entries, replicated order */
+} etlg_slot_desc;
+
+/* Columnar view of a decoded batch. Every array has n_events entries.
+ *
+ *   kind 'B': table_id = xid;            body = i64 commit timestamp
+ *   kind 'C': flags    = commit flags;   body = u64 end_lsn, i64 timestamp
+ *   kind 'R': table_id, schema_slot;     no body
+ *   kind 'I': table_id, schema_slot;     body = new row (full layout)
+ *   kind 'U': flags = old kind|partial;  body = [old row][new row]
+ *   kind 'D': flags = old kind;          body = [old row]
+ *   kind 'T': flags = options, table_id = n owned tables;
+ *                                         body = n x {u32 table_id, u32 schema_slot}
+ *
+ * Row block (full layout: all replicated columns; key layout: identity
+ * columns only): 2-bit cell states, column i at bits 2*(i%4) of byte i/4,
+ * padded to 4 bytes; then one slot per column at off_full/off_key.
+ * Slot contents, little-endian, zero for NULL/MISSING cells:
+ *   BOOL u32 0/1 | I16 i32 | I32 i32 | U32 u32 | I64 i64 | F32 u32 bits (8-byte slot)
+ *   F64 u64 bits | DATE i32 days from CE (chrono NaiveDate, 8-byte slot)
+ *   TIME u32 secs-of-day, u32 nanos | TIMESTAMP/TIMESTAMPTZ i32 days, u32 secs, u32 nanos
+ *   TIMETZ u32 secs, u32 nanos, i32 offset seconds east | UUID 16 bytes
+ *   STRING/BYTEA/NUMERIC/JSON/ARRAY and any DEFERRED cell: u32 heap_off, u32 len
+ * Heap entries are 4-byte aligned and zero padded; STRING/DEFERRED hold the
+ * source text verbatim, BYTEA the decoded bytes, NUMERIC an etlg_numeric_hdr
+ * + digits (len = 8 + 2*ndigits). A toast cell resolved from the old row
+ * aliases the old row's heap entry (Cell::clone).
+ * body_off is in bytes into `fixed`; bodies are contiguous in event order.
+ */
+typedef struct etlg_batch_view {
+  uint64_t n_events;
+  uint64_t n_frames;        /* frames consumed (index of the failing frame on error) */
+  uint64_t fixed_bytes;
+  uint64_t heap_bytes;
+  uint64_t payload_bytes[3]; /* insert/update/delete value bytes (codec/event.rs:261-297) */
+  const uint8_t* ev_kind;
+  const uint8_t* ev_flags;
+  const uint32_t* ev_table_id;
+  const uint32_t* ev_schema_slot;
+  const uint64_t* ev_start_lsn;
+  const uint64_t* ev_commit_lsn;
+  const uint64_t* ev_tx_ordinal;
+  const uint64_t* ev_body_off;
+  const uint8_t* fixed;
+  const uint8_t* heap;
+  uint32_t on_device;       /* 1: the pointers above are device pointers */
+  uint32_t n_slots;         /* schema slots known to the context (ids are stable across batches) */
+  const etlg_slot_desc* slots; /* host memory */
+} etlg_batch_view;
+
+int32_t etlg_batch_view_get(const etlg_batch* batch, etlg_batch_view* out);
+/* Wait for an ETLG_F_ASYNC batch and refresh its counts/error. */
+int32_t etlg_batch_sync(etlg_ctx* ctx, etlg_batch* batch);
+void etlg_batch_free(etlg_batch* batch);
+
+/* Schema slots known to the context (also reachable from every batch view). */
+int32_t etlg_ctx_slots(const etlg_ctx* ctx, uint32_t* n_slots,
+                       const etlg_slot_desc** slots);
+
+/* ------------------------------------------------------------- measurement */
+
+/* HIP-event timing of the kernels launched by etlg_decode on the context's
+ * stream (bench.py's roofline leg). */
+typedef struct etlg_kernel_stat {
+  const char* name;
+  uint64_t launches;
+  double total_ms;
+} etlg_kernel_stat;
+
+int32_t etlg_ctx_profile(etlg_ctx* ctx, int32_t enable);
+int32_t etlg_ctx_profile_read(etlg_ctx* ctx, etlg_kernel_stat* out,
+                              uint32_t cap, uint32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ETLG_H */

@@ -1,0 +1,1274 @@
+// TEST INFRASTRUCTURE — CPU oracle for the pgoutput decode + CDC event-transform
+// hot path of supabase/etl. NOT product code.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// build, link or call anything under oracle/. The product library
+// (etl_amd/csrc, libetl_gfx950.so) never includes or links this file.
+//
+// What is restated here, in reference order (paths relative to the
+// supabase/etl checkout):
+//   A0  wire parse              postgres-replication 0.6.7 (un-vendored,
+//                               Cargo.lock:4698-4700) — restated from the public
+//                               PostgreSQL "Logical Replication Message Formats"
+//                               (proto v1) and cross-checked against the
+//                               reference's own encoders at
+//                               crates/etl/src/postgres/codec/event.rs:1076-1172.
+//                               PARITY UNPINNED offline for w/k/B/C/R/T/M/Y/O
+//                               layouts and for malformed-input behaviour.
+//   A1  handle_replication_message          crates/etl/src/replication/apply.rs:2026-2076
+//   A2  handle_*_message + next_tx_ordinal  apply.rs:2279-2617, 942-963
+//   A3  payload byte accounting             codec/event.rs:261-297
+//   A4/A5 convert_tuple_to_row / convert_tuple_data_to_cell  codec/event.rs:554-587, 938-983
+//   A6-A10 value codec                      oracle_codec.hpp
+//   A11 update assembly + OldRowResolver    codec/event.rs:437-484, 605-791
+//   A12 delete + key-tuple normalisation    codec/event.rs:501-527, 795-923
+//   A13 begin/commit/truncate               codec/event.rs:303-336, 533-547
+//   A14 relation + DDL message + cache      apply.rs:2160-2276, 2363-2440, 3643-3734;
+//                                           crates/etl/src/schema.rs:30-61, 99-129, 380-441;
+//                                           crates/etl/src/replication/table_cache.rs:53-154
+//
+// Two decode modes:
+//   FULL      reference semantics for every type (arrays, JSON validation,
+//             chrono fallback shapes, floats). Used for the known-answer
+//             tests and as the timed CPU baseline ("MemoryDestination"
+//             analog: build a Vec<Event>, then drop it).
+//   CONTRACT  the device contract of include/etlg.h: JSON, arrays and the
+//             classes in `defer_mask` are handed back DEFERRED, temporal
+//             values outside the reference's fixed-layout fast paths
+//             (codec/time.rs:89-154) are DEFERRED. Used to produce the
+//             canonical arena the HIP path is compared with byte for byte.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <set>
+#include <unordered_map>
+
+#include "oracle_codec.hpp"
+
+namespace orc {
+
+// ------------------------------------------------------------- error strings
+// (kind, static description) per code — transcribed from the reference:
+// crates/etl/src/error.rs:582-1104, codec/*.rs bail! sites, apply.rs bail! sites.
+struct ErrDesc { int32_t kind; const char* desc; };
+static const ErrDesc kErr[ETLG_E__COUNT] = {
+    {ETLG_OK, ""},
+    {ETLG_SourceConnectionFailed, "PostgreSQL connection failed"},                 // error.rs:947
+    {ETLG_InvalidState, "Invalid transaction state"},                              // apply.rs:2180,2305,2370,2448
+    {ETLG_ValidationError, "Invalid commit LSN"},                                  // apply.rs:2313
+    {ETLG_InvalidState, "Missing shared table state"},                             // apply.rs:3712
+    {ETLG_InvalidState, "Waiting for relation state cannot decode row event"},     // apply.rs:3725
+    {ETLG_ConversionError, "Tuple data field count does not match schema"},        // codec/event.rs:562,614
+    {ETLG_ConversionError, "Tuple missing source value for full row image"},       // codec/event.rs:574
+    {ETLG_InvalidData, "Required column missing from tuple"},                      // codec/event.rs:953
+    {ETLG_ConversionError, "Binary format not supported in tuple data"},           // codec/event.rs:980
+    {ETLG_ConversionError, "UTF-8 conversion failed"},                             // error.rs:605
+    {ETLG_ConversionError, "Old tuple row width does not match schema"},           // codec/event.rs:703,733,775
+    {ETLG_ConversionError, "Replica-identity tuple shape does not match schema"},  // codec/event.rs:753,782,846,913
+    {ETLG_ConversionError, "Replica-identity tuple missing key columns"},          // codec/event.rs:895
+    {ETLG_ConversionError, "Replica-identity tuple missing source value"},         // codec/event.rs:810,855
+    {ETLG_InvalidData, "Invalid boolean value"},                                   // codec/bool.rs:17
+    {ETLG_ConversionError, "Integer parsing failed"},                              // error.rs:647
+    {ETLG_ConversionError, "Float parsing failed"},                                // error.rs:661
+    {ETLG_ConversionError, "Numeric parsing failed"},                              // error.rs:1018
+    {ETLG_ConversionError, "Bytea hex string conversion failed"},                  // codec/hex.rs:15,24,46
+    {ETLG_ConversionError, "Datetime parsing failed"},                             // error.rs:1004,1032
+    {ETLG_InvalidData, "UUID parsing failed"},                                     // error.rs:990
+    {ETLG_DeserializationError, "JSON deserialization failed"},                    // error.rs:589
+    {ETLG_ConversionError, "Array input too short"},                               // codec/text.rs:236
+    {ETLG_ConversionError, "Array input missing braces"},                          // codec/text.rs:240
+    {ETLG_ConversionError, "Array input has a malformed dimensions prefix"},       // codec/text.rs:185
+    {ETLG_ConversionError, "Multidimensional array input is not supported"},       // codec/text.rs:209,273
+    {ETLG_ConversionError, "Array input contains an unterminated quote"},          // codec/text.rs:291
+    {ETLG_ConversionError, "Array input contains an unterminated escape"},         // codec/text.rs:295
+    {ETLG_MissingTableSchema, "Table schema not found"},                           // apply.rs:3656
+    {ETLG_CorruptedTableSchema,
+     "Replication stream contains columns missing from the stored table schema"},  // error.rs:1098
+    {ETLG_ConversionError, "Failed to parse schema change message"},               // codec/event.rs:88
+    {ETLG_IoError, "I/O operation failed"},                                        // error.rs:569
+    {ETLG_InvalidState, "Bootstrap table schema snapshot exceeded requested snapshot"},  // apply.rs:3668
+    {ETLG_InvalidState, "Table schema snapshot mismatch"},                         // apply.rs:3690
+    {ETLG_InvalidArgument, "Control frame found in a batch declared control-free"},
+};
+
+// ----------------------------------------------------------------- byte reader
+struct Rd {
+  const u8* p; size_t n; size_t i = 0; bool ok = true;
+  Rd(const u8* p_, size_t n_) : p(p_), n(n_) {}
+  bool need(size_t k) { if (!ok || n - i < k) { ok = false; return false; } return true; }
+  uint8_t u8_() { if (!need(1)) return 0; return p[i++]; }
+  uint16_t u16() { if (!need(2)) return 0; uint16_t v = (uint16_t)(p[i] << 8 | p[i + 1]); i += 2; return v; }
+  uint32_t u32() { if (!need(4)) return 0; uint32_t v = (uint32_t)p[i] << 24 | (uint32_t)p[i + 1] << 16 | (uint32_t)p[i + 2] << 8 | p[i + 3]; i += 4; return v; }
+  uint64_t u64() { uint64_t h = u32(); uint64_t l = u32(); return h << 32 | l; }
+  sv cstr() {  // NUL-terminated
+    if (!ok) return {};
+    const void* z = memchr(p + i, 0, n - i);
+    if (!z) { ok = false; return {}; }
+    size_t len = (const u8*)z - (p + i);
+    sv r((const char*)p + i, len);
+    i += len + 1;
+    return r;
+  }
+  sv bytes(size_t k) { if (!need(k)) return {}; sv r((const char*)p + i, k); i += k; return r; }
+};
+
+// -------------------------------------------------------------- parsed message
+// postgres-replication's `TupleData` / `Tuple` / `*Body` shapes.
+struct TCell { u8 tag; sv data; };  // 'n' | 'u' | 't' | 'b'
+struct Tuple { std::vector<TCell> cells; bool present = false; };
+
+struct RelCol { int8_t flags; sv name; uint32_t type_oid; int32_t typmod; };
+
+struct Msg {
+  u8 outer = 0;  // 'w' | 'k'
+  uint64_t wal_start = 0, wal_end = 0; int64_t send_ts = 0;
+  u8 tag = 0;    // pgoutput tag for 'w'
+  // B
+  uint64_t final_lsn = 0; int64_t ts = 0; uint32_t xid = 0;
+  // C
+  int8_t flags = 0; uint64_t commit_lsn = 0, end_lsn = 0;
+  // R / I / U / D
+  uint32_t rel_id = 0; u8 replident = 0; std::vector<RelCol> rel_cols;
+  Tuple old_t, key_t, new_t;
+  // T
+  int8_t options = 0; std::vector<uint32_t> rel_ids;
+  // M
+  sv prefix, content;
+};
+
+// Tuple := i16 ncols, ncols x { 'n' | 'u' | 't' i32 len bytes | 'b' i32 len bytes }
+static bool parse_tuple(Rd& r, Tuple& t) {
+  int16_t n = (int16_t)r.u16();
+  if (!r.ok || n < 0) return false;  // negative count: hard error (policy, unpinned)
+  t.present = true;
+  t.cells.clear();
+  t.cells.reserve((size_t)n);
+  for (int k = 0; k < n; k++) {
+    u8 tag = r.u8_();
+    if (!r.ok) return false;
+    if (tag == 'n' || tag == 'u') { t.cells.push_back({tag, {}}); continue; }
+    if (tag == 't' || tag == 'b') {
+      int32_t len = (int32_t)r.u32();
+      if (!r.ok || len < 0) return false;
+      sv d = r.bytes((size_t)len);
+      if (!r.ok) return false;
+      t.cells.push_back({tag, d});
+      continue;
+    }
+    return false;  // unknown tuple data tag
+  }
+  return true;
+}
+
+// ReplicationMessage::parse + LogicalReplicationMessage::parse (A0).
+static bool parse_payload(const u8* p, size_t n, Msg& m) {
+  Rd r(p, n);
+  m.outer = r.u8_();
+  if (!r.ok) return false;
+  if (m.outer == 'k') {
+    m.wal_end = r.u64(); m.send_ts = (int64_t)r.u64(); (void)r.u8_();
+    return r.ok;
+  }
+  if (m.outer != 'w') return false;
+  m.wal_start = r.u64(); m.wal_end = r.u64(); m.send_ts = (int64_t)r.u64();
+  m.tag = r.u8_();
+  if (!r.ok) return false;
+  switch (m.tag) {
+    case 'B': m.final_lsn = r.u64(); m.ts = (int64_t)r.u64(); m.xid = r.u32(); return r.ok;
+    case 'C': m.flags = (int8_t)r.u8_(); m.commit_lsn = r.u64(); m.end_lsn = r.u64(); m.ts = (int64_t)r.u64(); return r.ok;
+    case 'O': (void)r.u64(); (void)r.cstr(); return r.ok;
+    case 'Y': (void)r.u32(); (void)r.cstr(); (void)r.cstr(); return r.ok;
+    case 'R': {
+      m.rel_id = r.u32(); (void)r.cstr(); (void)r.cstr();
+      m.replident = r.u8_();
+      if (!r.ok) return false;
+      if (m.replident != 'd' && m.replident != 'n' && m.replident != 'f' && m.replident != 'i') return false;
+      int16_t nc = (int16_t)r.u16();
+      if (!r.ok || nc < 0) return false;
+      for (int k = 0; k < nc; k++) {
+        RelCol c;
+        c.flags = (int8_t)r.u8_(); c.name = r.cstr(); c.type_oid = r.u32(); c.typmod = (int32_t)r.u32();
+        if (!r.ok) return false;
+        m.rel_cols.push_back(c);
+      }
+      return true;
+    }
+    case 'I': {
+      m.rel_id = r.u32();
+      u8 t = r.u8_();
+      if (!r.ok || t != 'N') return false;
+      return parse_tuple(r, m.new_t);
+    }
+    case 'U': {
+      m.rel_id = r.u32();
+      u8 t = r.u8_();
+      if (!r.ok) return false;
+      if (t == 'K' || t == 'O') {
+        if (!parse_tuple(r, t == 'K' ? m.key_t : m.old_t)) return false;
+        t = r.u8_();
+        if (!r.ok) return false;
+      }
+      if (t != 'N') return false;
+      return parse_tuple(r, m.new_t);
+    }
+    case 'D': {
+      m.rel_id = r.u32();
+      u8 t = r.u8_();
+      if (!r.ok) return false;
+      if (t == 'K') return parse_tuple(r, m.key_t);
+      if (t == 'O') return parse_tuple(r, m.old_t);
+      return false;
+    }
+    case 'T': {
+      int32_t nrel = (int32_t)r.u32();
+      m.options = (int8_t)r.u8_();
+      if (!r.ok || nrel < 0) return false;
+      for (int32_t k = 0; k < nrel; k++) { m.rel_ids.push_back(r.u32()); if (!r.ok) return false; }
+      return true;
+    }
+    case 'M': {
+      (void)r.u8_(); (void)r.u64();
+      m.prefix = r.cstr();
+      int32_t len = (int32_t)r.u32();
+      if (!r.ok || len < 0) return false;
+      m.content = r.bytes((size_t)len);
+      return r.ok;
+    }
+    default: return false;  // unknown logical replication message tag
+  }
+}
+
+// ------------------------------------------------------------------- schemas
+struct StoredCol {
+  std::string name; uint32_t type_oid; int32_t typmod; int32_t attnum; bool nullable; bool pk;
+};
+struct StoredSchema {
+  uint32_t table_id; uint64_t snapshot; std::string nsp, name; std::vector<StoredCol> cols;
+};
+
+struct RCol {  // one replicated column of a ReplicatedTableSchema
+  uint32_t type_oid; int32_t cls; bool nullable; bool identity; uint16_t stored_index;
+  uint16_t off_full = 0, off_key = 0, key_index = 0xFFFF;
+};
+struct Slot {  // ReplicatedTableSchema (schema.rs:380-441)
+  uint32_t table_id; uint64_t snapshot; uint32_t n_stored;
+  std::vector<u8> repl_mask, ident_mask;
+  std::vector<RCol> cols;          // replicated columns in stored order
+  std::vector<uint16_t> ident_idx; // indexes into cols of identity columns
+  uint32_t row_full = 0, row_key = 0, st_full = 0, st_key = 0;
+};
+
+static uint32_t slot_bytes(int32_t cls) {  // layout rule documented in include/etlg.h
+  switch (cls) {
+    case ETLG_TC_BOOL: case ETLG_TC_I16: case ETLG_TC_I32: case ETLG_TC_U32: return 4;
+    case ETLG_TC_I64: case ETLG_TC_F64: case ETLG_TC_F32: case ETLG_TC_DATE: case ETLG_TC_TIME: return 8;
+    case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: case ETLG_TC_TIMETZ: return 12;
+    case ETLG_TC_UUID: return 16;
+    default: return 8;  // (heap_off, len)
+  }
+}
+
+static void layout_slot(Slot& s) {
+  uint32_t n = (uint32_t)s.cols.size();
+  s.ident_idx.clear();
+  for (uint32_t i = 0; i < n; i++)
+    if (s.cols[i].identity) { s.cols[i].key_index = (uint16_t)s.ident_idx.size(); s.ident_idx.push_back((uint16_t)i); }
+  s.st_full = 4 * ((n + 15) / 16);
+  s.st_key = 4 * (((uint32_t)s.ident_idx.size() + 15) / 16);
+  uint32_t off = s.st_full;
+  for (auto& c : s.cols) { c.off_full = (uint16_t)off; off += slot_bytes(c.cls); }
+  s.row_full = off;
+  off = s.st_key;
+  for (auto i : s.ident_idx) { s.cols[i].off_key = (uint16_t)off; off += slot_bytes(s.cols[i].cls); }
+  s.row_key = off;
+}
+
+enum CacheKind { CACHE_WAITING = 1, CACHE_READY = 2 };
+struct CacheEntry { int kind; uint64_t snapshot; int32_t slot; };
+struct TState { int32_t kind; uint64_t lsn; };
+
+// ---------------------------------------------------------------- event model
+constexpr Tag kTagMissing = (Tag)200;   // ConvertedTupleCell::Missing
+constexpr Tag kTagDeferred = (Tag)201;  // CONTRACT mode: raw text view into the input (not owned)
+
+struct Row { std::vector<Cell> cells; };  // TableRow
+
+struct Event {
+  u8 kind = 0, flags = 0;
+  uint32_t table_id = 0; int32_t slot = -1;
+  uint64_t start_lsn = 0, commit_lsn = 0, ord = 0;
+  int64_t ts = 0; uint64_t end_lsn = 0;
+  Row new_row, old_row;
+  std::vector<int32_t> toast_src;  // new-row column -> old-row cell index it was cloned from (-1 none)
+  std::vector<std::pair<uint32_t, int32_t>> trunc;
+};
+
+enum Mode { MODE_FULL = 0, MODE_CONTRACT = 1 };
+
+struct Failure { int32_t code = ETLG_E_NONE; std::string detail; int64_t frame = -1; };
+
+struct Ctx {
+  int32_t worker = ETLG_WORKER_APPLY; uint32_t sync_table = 0; uint64_t bootstrap = 0;
+  int mode = MODE_CONTRACT; uint32_t defer_mask = (1u << ETLG_TC_F32) | (1u << ETLG_TC_F64);
+  std::map<uint32_t, std::map<uint64_t, std::shared_ptr<StoredSchema>>> store;
+  std::unordered_map<uint32_t, TState> states;
+  std::unordered_map<uint32_t, CacheEntry> cache;
+  std::vector<std::unique_ptr<Slot>> slots;
+  bool in_txn = false; uint64_t final_lsn = 0; uint64_t next_ord = 0;
+  Failure last;
+};
+
+struct Batch {
+  std::vector<Event> events;
+  uint64_t n_frames = 0;
+  uint64_t payload[3] = {0, 0, 0};
+  // arena (built on demand)
+  bool arena_built = false;
+  std::vector<u8> kind, flags, fixed, heap;
+  std::vector<uint32_t> table_id, slot;
+  std::vector<uint64_t> start_lsn, commit_lsn, ord, body_off;
+  // slot descriptors exported with the view
+  std::vector<std::vector<etlg_slot_col>> slot_cols;
+  std::vector<etlg_slot_desc> slot_descs;
+};
+
+// --------------------------------------------------------- ownership (A2 tail)
+// should_apply_changes: apply.rs:2626-2639 -> 2836-2867 (apply worker) /
+// 3514-3519 (table-sync worker).
+static bool should_apply(const Ctx& c, uint32_t table_id, uint64_t remote_final_lsn) {
+  if (c.worker == ETLG_WORKER_TABLE_SYNC) return c.sync_table == table_id;
+  auto it = c.states.find(table_id);
+  if (it == c.states.end()) return false;
+  if (it->second.kind == ETLG_TS_READY) return true;
+  if (it->second.kind == ETLG_TS_SYNC_DONE) return it->second.lsn <= remote_final_lsn;
+  return false;
+}
+
+// get_replicated_table_schema: apply.rs:3705-3734
+static int32_t lookup_ready_slot(const Ctx& c, uint32_t table_id, int32_t& err) {
+  auto it = c.cache.find(table_id);
+  if (it == c.cache.end()) { err = ETLG_E_MISSING_SHARED_STATE; return -1; }
+  if (it->second.kind != CACHE_READY) { err = ETLG_E_WAITING_RELATION; return -1; }
+  return it->second.slot;
+}
+
+// ------------------------------------------------------------- cell decoding
+// convert_tuple_data_to_cell, codec/event.rs:938-983. Returns false on error.
+struct CellOut { Cell cell; };
+
+static bool decode_text(const Ctx& c, const RCol& col, sv text, Cell& out, int32_t& err) {
+  // str::from_utf8 first (codec/event.rs:976), for every type.
+  if (!utf8_valid((const u8*)text.data(), text.size())) { err = ETLG_E_UTF8; return false; }
+  if (c.mode == MODE_FULL) {
+    auto r = parse_cell_text(col.type_oid, text);
+    if (!r.ok) { err = r.e.code; return false; }
+    out = std::move(r.v);
+    return true;
+  }
+  // CONTRACT mode (include/etlg.h): which shapes decode on the device.
+  auto defer = [&]() {
+    out.release();
+    out.tag = kTagDeferred;
+    out.u.s.p = const_cast<char*>(text.data());
+    out.u.s.len = text.size();
+    return true;
+  };
+  int32_t cls = col.cls;
+  if (cls == ETLG_TC_JSON || cls == ETLG_TC_ARRAY) return defer();
+  if (c.defer_mask & (1u << cls)) return defer();
+  switch (cls) {
+    case ETLG_TC_DATE: {
+      auto d = iso_date_fast(text);
+      if (!d) return defer();
+      out.tag = Tag::Date; out.u.t.date = *d; return true;
+    }
+    case ETLG_TC_TIME: {
+      auto t = iso_time_fast(text);
+      if (!t) return defer();
+      out.tag = Tag::Time; out.u.t.secs = t->secs; out.u.t.nanos = t->nanos; return true;
+    }
+    case ETLG_TC_TIMESTAMP: {
+      auto t = iso_timestamp_fast(text);
+      if (!t) return defer();
+      out.tag = Tag::Timestamp; out.u.t.date = t->date; out.u.t.secs = t->secs; out.u.t.nanos = t->nanos; return true;
+    }
+    case ETLG_TC_TIMESTAMPTZ: {
+      auto idx = split_offset_index(text, 10);
+      if (!idx) { err = ETLG_E_DATETIME; return false; }
+      auto t = iso_timestamp_fast(text.substr(0, *idx));
+      if (!t) return defer();
+      auto r = parse_pg_timestamptz(text);
+      if (!r.ok) { err = r.e.code; return false; }
+      out.tag = Tag::TimestampTz; out.u.t.date = r.v.date; out.u.t.secs = r.v.secs; out.u.t.nanos = r.v.nanos; return true;
+    }
+    case ETLG_TC_TIMETZ: {
+      auto idx = split_offset_index(text, 0);
+      if (!idx) { err = ETLG_E_DATETIME; return false; }
+      auto t = iso_time_fast(text.substr(0, *idx));
+      if (!t) return defer();
+      auto r = parse_pg_timetz(text);
+      if (!r.ok) { err = r.e.code; return false; }
+      out.tag = Tag::TimeTz; out.u.t.secs = r.v.secs; out.u.t.nanos = r.v.nanos; out.u.t.offset = r.v.offset; return true;
+    }
+    default: {
+      auto r = parse_scalar_text(cls, text);
+      if (!r.ok) { err = r.e.code; return false; }
+      out = std::move(r.v);
+      return true;
+    }
+  }
+}
+
+// old_value: nullptr = None. Returns false on error; `out.tag == kTagMissing`
+// for ConvertedTupleCell::Missing.
+static bool convert_tuple_cell(const Ctx& c, const RCol& col, const TCell& tc, const Cell* old_value,
+                               Cell& out, int32_t& err) {
+  switch (tc.tag) {
+    case 'n':
+      if (col.nullable) { out.release(); return true; }  // Cell::Null
+      err = ETLG_E_REQUIRED_NULL; return false;
+    case 'u':
+      if (old_value) {
+        if (old_value->tag == kTagDeferred) { out.release(); out.tag = kTagDeferred; out.u = old_value->u; }
+        else out = old_value->clone();
+      } else { out.release(); out.tag = kTagMissing; }
+      return true;
+    case 't':
+      return decode_text(c, col, tc.data, out, err);
+    default:  // 'b'
+      err = ETLG_E_BINARY_FORMAT; return false;
+  }
+}
+
+// convert_tuple_to_row, codec/event.rs:554-587
+static bool convert_tuple_to_row(const Ctx& c, const Slot& s, const Tuple& t, Row& row, int32_t& err) {
+  if (t.cells.size() != s.cols.size()) { err = ETLG_E_TUPLE_WIDTH; return false; }
+  row.cells.clear();
+  row.cells.reserve(s.cols.size());
+  for (size_t i = 0; i < s.cols.size(); i++) {
+    Cell cell;
+    if (!convert_tuple_cell(c, s.cols[i], t.cells[i], nullptr, cell, err)) return false;
+    if (cell.tag == kTagMissing) { err = ETLG_E_FULL_ROW_MISSING; return false; }
+    row.cells.push_back(std::move(cell));
+  }
+  return true;
+}
+
+// normalize_key_tuple_to_row (+ dense / full-width variants), codec/event.rs:795-923
+static bool normalize_key_tuple(const Ctx& c, const Slot& s, const Tuple& t, Row& row, int32_t& err) {
+  size_t nid = s.ident_idx.size(), nrep = s.cols.size();
+  if (nid == 0) { err = ETLG_E_KEY_MISSING_COLS; return false; }
+  row.cells.clear();
+  row.cells.reserve(nid);
+  if (t.cells.size() == nid) {
+    for (size_t k = 0; k < nid; k++) {
+      Cell cell;
+      if (!convert_tuple_cell(c, s.cols[s.ident_idx[k]], t.cells[k], nullptr, cell, err)) return false;
+      if (cell.tag == kTagMissing) { err = ETLG_E_KEY_MISSING_VALUE; return false; }
+      row.cells.push_back(std::move(cell));
+    }
+    return true;
+  }
+  if (t.cells.size() == nrep) {
+    size_t next = 0;
+    for (size_t i = 0; i < nrep; i++) {
+      if (!(next < nid && s.ident_idx[next] == i)) continue;  // non-identity position: skipped unread
+      Cell cell;
+      if (!convert_tuple_cell(c, s.cols[i], t.cells[i], nullptr, cell, err)) return false;
+      if (cell.tag == kTagMissing) { err = ETLG_E_KEY_MISSING_VALUE; return false; }
+      row.cells.push_back(std::move(cell));
+      next++;
+    }
+    return true;
+  }
+  err = ETLG_E_KEY_SHAPE;
+  return false;
+}
+
+// convert_update_tuple_to_updated_table_row + OldRowResolver, codec/event.rs:605-791
+static bool convert_update_new_row(const Ctx& c, const Slot& s, const Tuple& t, int old_kind,
+                                   const Row* old_row, Event& ev, int32_t& err) {
+  size_t n = s.cols.size();
+  if (t.cells.size() != n) { err = ETLG_E_TUPLE_WIDTH; return false; }
+  // OldRowResolver::new
+  if (old_kind == ETLG_OLD_FULL && old_row->cells.size() != n) { err = ETLG_E_OLD_ROW_WIDTH; return false; }
+  size_t next_full = 0, next_key = 0;
+  bool partial = false;
+  ev.new_row.cells.clear();
+  ev.new_row.cells.reserve(n);
+  ev.toast_src.clear();
+  size_t ident_next = 0;
+  for (size_t i = 0; i < n; i++) {
+    bool is_identity = ident_next < s.ident_idx.size() && s.ident_idx[ident_next] == i;
+    // value_for_column
+    const Cell* old_value = nullptr;
+    int32_t src = -1;
+    if (old_kind == ETLG_OLD_FULL) {
+      if (next_full >= old_row->cells.size()) { err = ETLG_E_OLD_ROW_WIDTH; return false; }
+      src = (int32_t)next_full;
+      old_value = &old_row->cells[next_full++];
+    } else if (old_kind == ETLG_OLD_KEY && is_identity) {
+      if (next_key >= old_row->cells.size()) { err = ETLG_E_KEY_SHAPE; return false; }
+      src = (int32_t)next_key;
+      old_value = &old_row->cells[next_key++];
+    }
+    if (is_identity) ident_next++;
+    Cell cell;
+    if (!convert_tuple_cell(c, s.cols[i], t.cells[i], old_value, cell, err)) return false;
+    if (cell.tag == kTagMissing) partial = true;
+    if (t.cells[i].tag == 'u' && old_value) {
+      if (ev.toast_src.empty()) ev.toast_src.assign(n, -1);
+      ev.toast_src[i] = src;
+    }
+    ev.new_row.cells.push_back(std::move(cell));
+  }
+  // OldRowResolver::finish
+  if (old_kind == ETLG_OLD_FULL && next_full != old_row->cells.size()) { err = ETLG_E_OLD_ROW_WIDTH; return false; }
+  if (old_kind == ETLG_OLD_KEY && next_key != old_row->cells.size()) { err = ETLG_E_KEY_SHAPE; return false; }
+  if (partial) ev.flags |= ETLG_FLAG_PARTIAL;
+  return true;
+}
+
+// calculate_tuple_bytes, codec/event.rs:261-271
+static uint64_t tuple_bytes(const Tuple& t) {
+  uint64_t s = 0;
+  for (auto& c : t.cells)
+    if (c.tag == 't' || c.tag == 'b') s += c.data.size();
+  return s;
+}
+
+// ------------------------------------------------------------- mini JSON DOM
+// Only what SchemaChangeMessage needs (codec/event.rs:37-56, 96-106, 182-196);
+// serde_json semantics: unknown fields ignored, missing/mistyped/duplicate
+// fields are errors, `null` accepted only for Option.
+struct JV {
+  enum K { Null, Bool, Num, Str, Arr, Obj } k = Null;
+  bool b = false; std::string s;  // Str payload, or the number's literal text
+  std::vector<JV> a; std::vector<std::pair<std::string, JV>> o;
+};
+struct JParse {
+  const char* p; const char* e; int depth = 0;
+  void ws() { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+  static void put_utf8(std::string& out, unsigned cp) {
+    if (cp < 0x80) out.push_back((char)cp);
+    else if (cp < 0x800) { out.push_back((char)(0xC0 | cp >> 6)); out.push_back((char)(0x80 | (cp & 63))); }
+    else if (cp < 0x10000) { out.push_back((char)(0xE0 | cp >> 12)); out.push_back((char)(0x80 | ((cp >> 6) & 63))); out.push_back((char)(0x80 | (cp & 63))); }
+    else { out.push_back((char)(0xF0 | cp >> 18)); out.push_back((char)(0x80 | ((cp >> 12) & 63))); out.push_back((char)(0x80 | ((cp >> 6) & 63))); out.push_back((char)(0x80 | (cp & 63))); }
+  }
+  bool hex4(unsigned& v) {
+    if (e - p < 4) return false;
+    v = 0;
+    for (int i = 0; i < 4; i++) {
+      char h = p[i]; int d;
+      if (h >= '0' && h <= '9') d = h - '0'; else if (h >= 'a' && h <= 'f') d = h - 'a' + 10; else if (h >= 'A' && h <= 'F') d = h - 'A' + 10; else return false;
+      v = v * 16 + d;
+    }
+    p += 4;
+    return true;
+  }
+  bool str(std::string& out) {
+    if (p >= e || *p != '"') return false;
+    p++;
+    while (p < e) {
+      u8 c = (u8)*p;
+      if (c == '"') { p++; return true; }
+      if (c < 0x20) return false;
+      if (c != '\\') { out.push_back((char)c); p++; continue; }
+      p++;
+      if (p >= e) return false;
+      char x = *p++;
+      switch (x) {
+        case '"': out.push_back('"'); break; case '\\': out.push_back('\\'); break; case '/': out.push_back('/'); break;
+        case 'b': out.push_back('\b'); break; case 'f': out.push_back('\f'); break; case 'n': out.push_back('\n'); break;
+        case 'r': out.push_back('\r'); break; case 't': out.push_back('\t'); break;
+        case 'u': {
+          unsigned v;
+          if (!hex4(v)) return false;
+          if (v >= 0xDC00 && v <= 0xDFFF) return false;
+          if (v >= 0xD800 && v <= 0xDBFF) {
+            if (e - p < 2 || p[0] != '\\' || p[1] != 'u') return false;
+            p += 2;
+            unsigned w;
+            if (!hex4(w) || w < 0xDC00 || w > 0xDFFF) return false;
+            v = 0x10000 + ((v - 0xD800) << 10) + (w - 0xDC00);
+          }
+          put_utf8(out, v);
+          break;
+        }
+        default: return false;
+      }
+    }
+    return false;
+  }
+  bool val(JV& v) {
+    ws();
+    if (p >= e) return false;
+    char c = *p;
+    if (c == '{') {
+      if (++depth > 128) return false;
+      v.k = JV::Obj; p++; ws();
+      if (p < e && *p == '}') { p++; depth--; return true; }
+      for (;;) {
+        ws();
+        std::string key;
+        if (!str(key)) return false;
+        ws();
+        if (p >= e || *p != ':') return false;
+        p++;
+        JV x;
+        if (!val(x)) return false;
+        v.o.emplace_back(std::move(key), std::move(x));
+        ws();
+        if (p < e && *p == ',') { p++; continue; }
+        if (p < e && *p == '}') { p++; depth--; return true; }
+        return false;
+      }
+    }
+    if (c == '[') {
+      if (++depth > 128) return false;
+      v.k = JV::Arr; p++; ws();
+      if (p < e && *p == ']') { p++; depth--; return true; }
+      for (;;) {
+        JV x;
+        if (!val(x)) return false;
+        v.a.push_back(std::move(x));
+        ws();
+        if (p < e && *p == ',') { p++; continue; }
+        if (p < e && *p == ']') { p++; depth--; return true; }
+        return false;
+      }
+    }
+    if (c == '"') { v.k = JV::Str; return str(v.s); }
+    if (c == 't') { if (e - p >= 4 && !memcmp(p, "true", 4)) { p += 4; v.k = JV::Bool; v.b = true; return true; } return false; }
+    if (c == 'f') { if (e - p >= 5 && !memcmp(p, "false", 5)) { p += 5; v.k = JV::Bool; v.b = false; return true; } return false; }
+    if (c == 'n') { if (e - p >= 4 && !memcmp(p, "null", 4)) { p += 4; v.k = JV::Null; return true; } return false; }
+    const char* st = p;
+    JsonScan js{p, e};
+    if (!js.number()) return false;
+    p = js.p;
+    v.k = JV::Num; v.s.assign(st, p - st);
+    return true;
+  }
+};
+static bool jv_int(const JV& v, int64_t lo, int64_t hi, int64_t& out) {
+  if (v.k != JV::Num) return false;
+  for (char ch : v.s) if (ch == '.' || ch == 'e' || ch == 'E') return false;
+  errno = 0;
+  char* end = nullptr;
+  long long x = strtoll(v.s.c_str(), &end, 10);
+  if (errno || *end) return false;
+  if (x < lo || x > hi) return false;
+  out = x;
+  return true;
+}
+static const JV* jv_field(const JV& o, const char* name, bool& dup) {
+  const JV* f = nullptr;
+  for (auto& kv : o.o)
+    if (kv.first == name) { if (f) dup = true; f = &kv.second; }
+  return f;
+}
+
+// SchemaChangeMessage::from_str + into_table_schema + build_column_schemas
+// (codec/event.rs:58-93, 204-253).
+static bool parse_ddl_message(sv content, uint64_t snapshot, std::shared_ptr<StoredSchema>& out) {
+  JV root;
+  JParse jp{content.data(), content.data() + content.size()};
+  if (!jp.val(root)) return false;
+  jp.ws();
+  if (jp.p != jp.e || root.k != JV::Obj) return false;
+  bool dup = false;
+  const JV* tag = jv_field(root, "command_tag", dup);
+  const JV* nsp = jv_field(root, "nspname", dup);
+  const JV* rel = jv_field(root, "relname", dup);
+  const JV* oid = jv_field(root, "oid", dup);
+  const JV* ident = jv_field(root, "identity", dup);
+  const JV* cols = jv_field(root, "columns", dup);
+  if (dup || !tag || !nsp || !rel || !oid || !ident || !cols) return false;
+  if (tag->k != JV::Str || nsp->k != JV::Str || rel->k != JV::Str) return false;
+  int64_t oidv;
+  if (!jv_int(*oid, INT64_MIN, INT64_MAX, oidv)) return false;
+  if (ident->k != JV::Obj || cols->k != JV::Arr) return false;
+  const JV* pk = jv_field(*ident, "primary_key_attnums", dup);
+  const JV* rid = jv_field(*ident, "relreplident", dup);
+  const JV* rix = jv_field(*ident, "replica_identity_index_attnums", dup);
+  if (dup || !pk || !rid || !rix || pk->k != JV::Arr || rid->k != JV::Str || rix->k != JV::Arr) return false;
+  std::vector<int32_t> pks;
+  for (auto& x : pk->a) { int64_t v; if (!jv_int(x, INT32_MIN, INT32_MAX, v)) return false; pks.push_back((int32_t)v); }
+  for (auto& x : rix->a) { int64_t v; if (!jv_int(x, INT32_MIN, INT32_MAX, v)) return false; }
+  auto sch = std::make_shared<StoredSchema>();
+  sch->table_id = (uint32_t)oidv;  // `self.oid as u32`
+  sch->snapshot = snapshot;
+  sch->nsp = nsp->s; sch->name = rel->s;
+  for (auto& cj : cols->a) {
+    if (cj.k != JV::Obj) return false;
+    bool d2 = false;
+    const JV* an = jv_field(cj, "attname", d2);
+    const JV* at = jv_field(cj, "atttypid", d2);
+    const JV* am = jv_field(cj, "atttypmod", d2);
+    const JV* au = jv_field(cj, "attnum", d2);
+    const JV* nn = jv_field(cj, "attnotnull", d2);
+    const JV* de = jv_field(cj, "default_expression", d2);
+    if (d2 || !an || !at || !am || !au || !nn) return false;
+    if (an->k != JV::Str || nn->k != JV::Bool) return false;
+    if (de && de->k != JV::Null && de->k != JV::Str) return false;
+    int64_t tv, mv, nv;
+    if (!jv_int(*at, 0, UINT32_MAX, tv) || !jv_int(*am, INT32_MIN, INT32_MAX, mv) || !jv_int(*au, INT32_MIN, INT32_MAX, nv)) return false;
+    StoredCol c;
+    c.name = an->s; c.type_oid = (uint32_t)tv; c.typmod = (int32_t)mv; c.attnum = (int32_t)nv;
+    c.nullable = !nn->b;
+    c.pk = std::find(pks.begin(), pks.end(), c.attnum) != pks.end();
+    sch->cols.push_back(std::move(c));
+  }
+  std::stable_sort(sch->cols.begin(), sch->cols.end(), [](const StoredCol& a, const StoredCol& b) { return a.attnum < b.attnum; });
+  out = std::move(sch);
+  return true;
+}
+
+// ------------------------------------------------------ slot (mask) building
+static int32_t make_slot(Ctx& c, const std::shared_ptr<StoredSchema>& sch, const std::vector<u8>& repl,
+                         const std::vector<u8>& ident) {
+  auto s = std::make_unique<Slot>();
+  s->table_id = sch->table_id; s->snapshot = sch->snapshot; s->n_stored = (uint32_t)sch->cols.size();
+  s->repl_mask = repl; s->ident_mask = ident;
+  for (size_t i = 0; i < sch->cols.size(); i++) {
+    if (repl[i] != 1) continue;
+    RCol rc;
+    rc.type_oid = sch->cols[i].type_oid; rc.cls = class_of_oid(rc.type_oid);
+    rc.nullable = sch->cols[i].nullable; rc.identity = ident[i] == 1; rc.stored_index = (uint16_t)i;
+    s->cols.push_back(rc);
+  }
+  layout_slot(*s);
+  c.slots.push_back(std::move(s));
+  return (int32_t)c.slots.size() - 1;
+}
+
+static std::shared_ptr<StoredSchema> get_at_or_before(const Ctx& c, uint32_t table_id, uint64_t snap) {
+  auto it = c.store.find(table_id);  // store/schema/table.rs:61-71
+  if (it == c.store.end()) return nullptr;
+  auto ub = it->second.upper_bound(snap);
+  if (ub == it->second.begin()) return nullptr;
+  --ub;
+  return ub->second;
+}
+
+// ------------------------------------------------------------ the apply loop
+// One frame = one CopyData message. Returns false when the batch must stop.
+static bool handle_frame(Ctx& c, Batch& b, const u8* payload, size_t plen, int64_t frame_idx) {
+  auto fail = [&](int32_t code, std::string detail = {}) {
+    c.last.code = code; c.last.detail = std::move(detail); c.last.frame = frame_idx;
+    return false;
+  };
+  Msg m;
+  if (!parse_payload(payload, plen, m)) return fail(ETLG_E_WIRE);
+  if (m.outer == 'k') return true;  // keepalive: status update is the host's business (apply.rs:2053-2073)
+  uint64_t start_lsn = m.wal_start;  // apply.rs:2039
+  auto next_ord = [&]() { return c.next_ord++; };  // apply.rs:947-963
+  switch (m.tag) {
+    case 'B': {  // handle_begin_message, apply.rs:2279-2296
+      c.in_txn = true; c.final_lsn = m.final_lsn; c.next_ord = 0;
+      Event e; e.kind = 'B'; e.start_lsn = start_lsn; e.commit_lsn = m.final_lsn; e.ord = next_ord();
+      e.ts = m.ts; e.table_id = m.xid;
+      b.events.push_back(std::move(e));
+      return true;
+    }
+    case 'C': {  // handle_commit_message, apply.rs:2298-2361
+      if (!c.in_txn) return fail(ETLG_E_TXN_STATE);
+      uint64_t remote_final = c.final_lsn;
+      c.in_txn = false;  // `.take()` happens before the LSN check
+      if (m.commit_lsn != remote_final) return fail(ETLG_E_COMMIT_LSN);
+      Event e; e.kind = 'C'; e.start_lsn = start_lsn; e.commit_lsn = m.commit_lsn; e.ord = next_ord();
+      e.flags = (u8)m.flags; e.end_lsn = m.end_lsn; e.ts = m.ts;
+      b.events.push_back(std::move(e));
+      return true;
+    }
+    case 'O': case 'Y': return true;  // apply.rs:2113-2120
+    case 'M': {  // handle_message, apply.rs:2160-2276
+      // prefix()/content() are UTF-8 checked accessors -> io::Error (error.rs:564)
+      if (!utf8_valid((const u8*)m.prefix.data(), m.prefix.size())) return fail(ETLG_E_IO);
+      if (m.prefix != "supabase_etl_ddl") return true;  // codec/event.rs:28
+      if (!c.in_txn) return fail(ETLG_E_TXN_STATE);
+      if (!utf8_valid((const u8*)m.content.data(), m.content.size())) return fail(ETLG_E_IO);
+      std::shared_ptr<StoredSchema> sch;
+      if (!parse_ddl_message(m.content, start_lsn, sch)) return fail(ETLG_E_DDL_PARSE);
+      if (!should_apply(c, sch->table_id, c.final_lsn)) return true;
+      c.store[sch->table_id][sch->snapshot] = sch;                         // store_table_schema
+      c.cache[sch->table_id] = CacheEntry{CACHE_WAITING, start_lsn, -1};   // note_waiting_for_relation
+      return true;
+    }
+    case 'R': {  // handle_relation_message, apply.rs:2363-2440
+      if (!c.in_txn) return fail(ETLG_E_TXN_STATE);
+      uint64_t ord = next_ord();
+      if (!should_apply(c, m.rel_id, c.final_lsn)) return true;
+      // parse_replicated_column_names / parse_replica_identity_column_names
+      // (codec/event.rs:352-396); `column.name()` is a UTF-8 checked accessor.
+      std::set<std::string> repl_names, ident_names;
+      for (auto& rc : m.rel_cols) {
+        if (!utf8_valid((const u8*)rc.name.data(), rc.name.size())) return fail(ETLG_E_IO);
+        repl_names.insert(std::string(rc.name));
+      }
+      for (auto& rc : m.rel_cols)
+        if (m.replident == 'f' || (rc.flags & 1) == 1) ident_names.insert(std::string(rc.name));
+      auto cit = c.cache.find(m.rel_id);
+      bool used_bootstrap = cit == c.cache.end();
+      uint64_t snap = used_bootstrap ? c.bootstrap : cit->second.snapshot;
+      // get_table_schema_for_relation, apply.rs:3643-3697
+      auto sch = get_at_or_before(c, m.rel_id, snap);
+      if (!sch) return fail(ETLG_E_SCHEMA_NOT_FOUND);
+      if (used_bootstrap) { if (sch->snapshot > snap) return fail(ETLG_E_BOOTSTRAP_SNAPSHOT); }
+      else if (sch->snapshot != snap) return fail(ETLG_E_SNAPSHOT_MISMATCH);
+      // ReplicationMask::try_build / IdentityMask::try_build, schema.rs:30-61, 99-129, 220-227
+      std::set<std::string> have;
+      for (auto& sc : sch->cols) have.insert(sc.name);
+      for (auto& nme : repl_names) if (!have.count(nme)) return fail(ETLG_E_UNKNOWN_COLUMNS);
+      for (auto& nme : ident_names) if (!have.count(nme)) return fail(ETLG_E_UNKNOWN_COLUMNS);
+      std::vector<u8> rmask, imask;
+      for (auto& sc : sch->cols) { rmask.push_back(repl_names.count(sc.name) ? 1 : 0); imask.push_back(ident_names.count(sc.name) ? 1 : 0); }
+      int32_t slot = make_slot(c, sch, rmask, imask);
+      c.cache[m.rel_id] = CacheEntry{CACHE_READY, sch->snapshot, slot};  // note_ready
+      Event e; e.kind = 'R'; e.start_lsn = start_lsn; e.commit_lsn = c.final_lsn; e.ord = ord;
+      e.table_id = m.rel_id; e.slot = slot;
+      b.events.push_back(std::move(e));
+      return true;
+    }
+    case 'I': case 'U': case 'D': {  // apply.rs:2443-2573
+      if (!c.in_txn) return fail(ETLG_E_TXN_STATE);
+      uint64_t ord = next_ord();
+      // payload metrics are recorded before the ownership check
+      if (m.tag == 'I') b.payload[0] += tuple_bytes(m.new_t);
+      else if (m.tag == 'U') b.payload[1] += tuple_bytes(m.new_t) + (m.old_t.present ? tuple_bytes(m.old_t) : m.key_t.present ? tuple_bytes(m.key_t) : 0);
+      else b.payload[2] += m.old_t.present ? tuple_bytes(m.old_t) : m.key_t.present ? tuple_bytes(m.key_t) : 0;
+      if (!should_apply(c, m.rel_id, c.final_lsn)) return true;
+      int32_t err = 0;
+      int32_t slot = lookup_ready_slot(c, m.rel_id, err);
+      if (slot < 0) return fail(err);
+      const Slot& s = *c.slots[slot];
+      Event e; e.kind = m.tag; e.start_lsn = start_lsn; e.commit_lsn = c.final_lsn; e.ord = ord;
+      e.table_id = m.rel_id; e.slot = slot;
+      if (m.tag == 'I') {  // parse_event_from_insert_message, codec/event.rs:403-414
+        if (!convert_tuple_to_row(c, s, m.new_t, e.new_row, err)) return fail(err);
+      } else {
+        // old image first (codec/event.rs:450-464, 511-524)
+        int old_kind = ETLG_OLD_NONE;
+        if (m.old_t.present) {
+          old_kind = ETLG_OLD_FULL;
+          if (!convert_tuple_to_row(c, s, m.old_t, e.old_row, err)) return fail(err);
+        } else if (m.key_t.present) {
+          old_kind = ETLG_OLD_KEY;
+          if (!normalize_key_tuple(c, s, m.key_t, e.old_row, err)) return fail(err);
+        }
+        e.flags = (u8)old_kind;
+        if (m.tag == 'U') {
+          if (!convert_update_new_row(c, s, m.new_t, old_kind, &e.old_row, e, err)) return fail(err);
+        }
+      }
+      b.events.push_back(std::move(e));
+      return true;
+    }
+    case 'T': {  // handle_truncate_message, apply.rs:2575-2617
+      if (!c.in_txn) return fail(ETLG_E_TXN_STATE);
+      uint64_t ord = next_ord();
+      Event e; e.kind = 'T'; e.start_lsn = start_lsn; e.commit_lsn = c.final_lsn; e.ord = ord; e.flags = (u8)m.options;
+      for (uint32_t rid : m.rel_ids) {
+        if (!should_apply(c, rid, c.final_lsn)) continue;
+        int32_t err = 0;
+        int32_t slot = lookup_ready_slot(c, rid, err);
+        if (slot < 0) return fail(err);
+        e.trunc.emplace_back(rid, slot);
+      }
+      if (e.trunc.empty()) return true;
+      e.table_id = (uint32_t)e.trunc.size();
+      b.events.push_back(std::move(e));
+      return true;
+    }
+    default: return fail(ETLG_E_WIRE);
+  }
+}
+
+// Record-boundary scan of CopyData frames: 'd' | Int32-BE len (incl. itself) | payload.
+static bool next_frame(const u8* buf, size_t len, size_t pos, size_t& payload_off, size_t& payload_len) {
+  if (len - pos < 5 || buf[pos] != 'd') return false;
+  uint32_t l = (uint32_t)buf[pos + 1] << 24 | (uint32_t)buf[pos + 2] << 16 | (uint32_t)buf[pos + 3] << 8 | buf[pos + 4];
+  if (l < 4 || (size_t)l - 4 > len - pos - 5) return false;
+  payload_off = pos + 5; payload_len = l - 4;
+  return true;
+}
+
+static void decode_stream(Ctx& c, Batch& b, const u8* buf, size_t len, const uint32_t* offs, size_t nframes) {
+  c.last = Failure{};
+  size_t pos = 0;
+  int64_t f = 0;
+  for (;; f++) {
+    if (offs) { if ((size_t)f >= nframes) break; pos = offs[f]; }
+    else if (pos >= len) break;
+    size_t po, pl;
+    bool ok = next_frame(buf, len, pos, po, pl);
+    if (ok && offs && pos + 5 + pl != offs[f + 1]) ok = false;  // sidecar must agree with the length field
+    if (!ok) { c.last.code = ETLG_E_WIRE; c.last.frame = f; break; }
+    if (!handle_frame(c, b, buf + po, pl, f)) break;
+    pos = po + pl;
+  }
+  b.n_frames = (uint64_t)f;
+}
+
+// -------------------------------------------------------------- arena writer
+// Canonical layout of include/etlg.h. CONTRACT mode only.
+static inline void put32(std::vector<u8>& v, size_t off, uint32_t x) { memcpy(v.data() + off, &x, 4); }
+static inline void put64(std::vector<u8>& v, size_t off, uint64_t x) { memcpy(v.data() + off, &x, 8); }
+
+static uint32_t heap_put(std::vector<u8>& heap, const void* p, size_t n) {
+  uint32_t off = (uint32_t)heap.size();
+  heap.insert(heap.end(), (const u8*)p, (const u8*)p + n);
+  while (heap.size() % 4) heap.push_back(0);
+  return off;
+}
+
+static bool write_row(Batch& b, const Slot& s, bool key_layout, const Row& row, size_t base,
+                      const std::vector<int32_t>* toast_src, size_t old_base, bool old_key_layout) {
+  size_t ncols = key_layout ? s.ident_idx.size() : s.cols.size();
+  if (row.cells.size() != ncols) return false;
+  for (size_t i = 0; i < ncols; i++) {
+    const RCol& col = key_layout ? s.cols[s.ident_idx[i]] : s.cols[i];
+    size_t so = base + (key_layout ? col.off_key : col.off_full);
+    const Cell& c = row.cells[i];
+    u8 st = ETLG_CELL_VALUE;
+    if (toast_src && !toast_src->empty() && (*toast_src)[i] >= 0) {
+      // alias the old row's slot verbatim (state + slot bytes)
+      size_t k = (size_t)(*toast_src)[i];
+      const RCol& oc = old_key_layout ? s.cols[s.ident_idx[k]] : s.cols[k];
+      size_t oso = old_base + (old_key_layout ? oc.off_key : oc.off_full);
+      u8 ost = (b.fixed[old_base + k / 4] >> (2 * (k % 4))) & 3;
+      memcpy(b.fixed.data() + so, b.fixed.data() + oso, slot_bytes(col.cls));
+      b.fixed[base + i / 4] |= (u8)(ost << (2 * (i % 4)));
+      continue;
+    }
+    switch ((int)c.tag) {
+      case (int)Tag::Null: st = ETLG_CELL_NULL; break;
+      case (int)kTagMissing: st = ETLG_CELL_MISSING; break;
+      case (int)kTagDeferred: {
+        st = ETLG_CELL_DEFERRED;
+        uint32_t off = heap_put(b.heap, c.u.s.p, c.u.s.len);
+        put32(b.fixed, so, off); put32(b.fixed, so + 4, (uint32_t)c.u.s.len);
+        break;
+      }
+      case (int)Tag::Bool: put32(b.fixed, so, c.u.b ? 1 : 0); break;
+      case (int)Tag::I16: case (int)Tag::I32: put32(b.fixed, so, (uint32_t)(int32_t)c.u.i); break;
+      case (int)Tag::U32: put32(b.fixed, so, (uint32_t)c.u.i); break;
+      case (int)Tag::I64: put64(b.fixed, so, (uint64_t)c.u.i); break;
+      case (int)Tag::F32: put32(b.fixed, so, (uint32_t)c.u.fbits); break;
+      case (int)Tag::F64: put64(b.fixed, so, c.u.fbits); break;
+      case (int)Tag::Date: put32(b.fixed, so, (uint32_t)c.u.t.date); break;
+      case (int)Tag::Time: put32(b.fixed, so, c.u.t.secs); put32(b.fixed, so + 4, c.u.t.nanos); break;
+      case (int)Tag::Timestamp: case (int)Tag::TimestampTz:
+        put32(b.fixed, so, (uint32_t)c.u.t.date); put32(b.fixed, so + 4, c.u.t.secs); put32(b.fixed, so + 8, c.u.t.nanos); break;
+      case (int)Tag::TimeTz:
+        put32(b.fixed, so, c.u.t.secs); put32(b.fixed, so + 4, c.u.t.nanos); put32(b.fixed, so + 8, (uint32_t)c.u.t.offset); break;
+      case (int)Tag::Uuid: memcpy(b.fixed.data() + so, c.u.uuid, 16); break;
+      case (int)Tag::String: case (int)Tag::Bytes: {
+        uint32_t off = heap_put(b.heap, c.u.s.p, c.u.s.len);
+        put32(b.fixed, so, off); put32(b.fixed, so + 4, (uint32_t)c.u.s.len);
+        break;
+      }
+      case (int)Tag::Numeric: {
+        const NumBlock* nb = c.u.num;
+        std::vector<u8> tmp(8 + 2 * (size_t)nb->ndigits);
+        etlg_numeric_hdr h{nb->kind, nb->sign, nb->weight, nb->scale, (uint16_t)nb->ndigits};
+        memcpy(tmp.data(), &h, 8);
+        if (nb->ndigits) memcpy(tmp.data() + 8, nb->digits, 2 * (size_t)nb->ndigits);
+        uint32_t off = heap_put(b.heap, tmp.data(), tmp.size());
+        put32(b.fixed, so, off); put32(b.fixed, so + 4, (uint32_t)tmp.size());
+        break;
+      }
+      default: return false;  // Json/Array values exist only in FULL mode
+    }
+    b.fixed[base + i / 4] |= (u8)(st << (2 * (i % 4)));
+  }
+  return true;
+}
+
+static bool build_arena(const Ctx& c, Batch& b) {
+  if (b.arena_built) return true;
+  size_t n = b.events.size();
+  b.kind.resize(n); b.flags.resize(n); b.table_id.resize(n); b.slot.resize(n);
+  b.start_lsn.resize(n); b.commit_lsn.resize(n); b.ord.resize(n); b.body_off.resize(n);
+  b.fixed.clear(); b.heap.clear();
+  for (size_t i = 0; i < n; i++) {
+    const Event& e = b.events[i];
+    b.kind[i] = e.kind; b.flags[i] = e.flags; b.table_id[i] = e.table_id;
+    b.slot[i] = (uint32_t)e.slot;
+    b.start_lsn[i] = e.start_lsn; b.commit_lsn[i] = e.commit_lsn; b.ord[i] = e.ord;
+    size_t base = b.fixed.size();
+    b.body_off[i] = base;
+    switch (e.kind) {
+      case 'B': b.fixed.resize(base + 8); put64(b.fixed, base, (uint64_t)e.ts); b.slot[i] = 0; break;
+      case 'C': b.fixed.resize(base + 16); put64(b.fixed, base, e.end_lsn); put64(b.fixed, base + 8, (uint64_t)e.ts); b.slot[i] = 0; break;
+      case 'R': break;
+      case 'T':
+        b.slot[i] = 0;
+        b.fixed.resize(base + 8 * e.trunc.size());
+        for (size_t k = 0; k < e.trunc.size(); k++) { put32(b.fixed, base + 8 * k, e.trunc[k].first); put32(b.fixed, base + 8 * k + 4, (uint32_t)e.trunc[k].second); }
+        break;
+      case 'I': {
+        const Slot& s = *c.slots[e.slot];
+        b.fixed.resize(base + s.row_full);
+        if (!write_row(b, s, false, e.new_row, base, nullptr, 0, false)) return false;
+        break;
+      }
+      case 'U': case 'D': {
+        const Slot& s = *c.slots[e.slot];
+        int ok = e.flags & 3;
+        size_t old_sz = ok == ETLG_OLD_FULL ? s.row_full : ok == ETLG_OLD_KEY ? s.row_key : 0;
+        size_t new_sz = e.kind == 'U' ? s.row_full : 0;
+        b.fixed.resize(base + old_sz + new_sz);
+        if (ok != ETLG_OLD_NONE && !write_row(b, s, ok == ETLG_OLD_KEY, e.old_row, base, nullptr, 0, false)) return false;
+        if (e.kind == 'U' && !write_row(b, s, false, e.new_row, base + old_sz, &e.toast_src, base, ok == ETLG_OLD_KEY)) return false;
+        break;
+      }
+      default: return false;
+    }
+  }
+  // slot descriptors
+  b.slot_cols.clear(); b.slot_descs.clear();
+  b.slot_cols.resize(c.slots.size());
+  for (size_t k = 0; k < c.slots.size(); k++) {
+    const Slot& s = *c.slots[k];
+    for (auto& rc : s.cols) {
+      etlg_slot_col sc{};
+      sc.type_oid = rc.type_oid; sc.stored_index = rc.stored_index; sc.type_class = (u8)rc.cls;
+      sc.nullable = rc.nullable; sc.identity = rc.identity; sc.off_full = rc.off_full; sc.off_key = rc.off_key; sc.key_index = rc.key_index;
+      b.slot_cols[k].push_back(sc);
+    }
+  }
+  for (size_t k = 0; k < c.slots.size(); k++) {
+    const Slot& s = *c.slots[k];
+    etlg_slot_desc d{};
+    d.table_id = s.table_id; d.n_stored = s.n_stored; d.snapshot_lsn = s.snapshot;
+    d.n_cols = (uint32_t)s.cols.size(); d.n_ident = (uint32_t)s.ident_idx.size();
+    d.row_bytes_full = s.row_full; d.row_bytes_key = s.row_key; d.state_bytes_full = s.st_full; d.state_bytes_key = s.st_key;
+    d.cols = b.slot_cols[k].data();
+    b.slot_descs.push_back(d);
+  }
+  b.arena_built = true;
+  return true;
+}
+
+// ----------------------------------------------------- text repr (KAT checks)
+static void repr_cell(const Cell& c, std::string& o);
+static void hex_append(std::string& o, const u8* p, size_t n) {
+  static const char* H = "0123456789abcdef";
+  for (size_t i = 0; i < n; i++) { o.push_back(H[p[i] >> 4]); o.push_back(H[p[i] & 15]); }
+}
+static void repr_date(int32_t ce, std::string& o) {
+  int64_t y; unsigned m, d;
+  civil_from_days((int64_t)ce - kCeToUnixDays, y, m, d);
+  char buf[48]; snprintf(buf, sizeof buf, "%04lld-%02u-%02u", (long long)y, m, d); o += buf;
+}
+static void repr_time(uint32_t secs, uint32_t nanos, std::string& o) {
+  char buf[48]; snprintf(buf, sizeof buf, "%02u:%02u:%02u.%09u", secs / 3600, secs / 60 % 60, secs % 60, nanos); o += buf;
+}
+static void repr_cell(const Cell& c, std::string& o) {
+  char buf[96];
+  switch ((int)c.tag) {
+    case (int)Tag::Null: o += "Null"; break;
+    case (int)kTagMissing: o += "Missing"; break;
+    case (int)kTagDeferred: o += "Deferred(\""; o.append(c.u.s.p, c.u.s.len); o += "\")"; break;
+    case (int)Tag::Bool: o += c.u.b ? "Bool(true)" : "Bool(false)"; break;
+    case (int)Tag::I16: snprintf(buf, sizeof buf, "I16(%lld)", (long long)c.u.i); o += buf; break;
+    case (int)Tag::I32: snprintf(buf, sizeof buf, "I32(%lld)", (long long)c.u.i); o += buf; break;
+    case (int)Tag::I64: snprintf(buf, sizeof buf, "I64(%lld)", (long long)c.u.i); o += buf; break;
+    case (int)Tag::U32: snprintf(buf, sizeof buf, "U32(%llu)", (unsigned long long)c.u.i); o += buf; break;
+    case (int)Tag::F32: {
+      uint32_t bits = (uint32_t)c.u.fbits; float f; memcpy(&f, &bits, 4);
+      if (f != f) o += "F32(NaN)"; else { snprintf(buf, sizeof buf, "F32(0x%08x)", bits); o += buf; }
+      break;
+    }
+    case (int)Tag::F64: {
+      double d; memcpy(&d, &c.u.fbits, 8);
+      if (d != d) o += "F64(NaN)"; else { snprintf(buf, sizeof buf, "F64(0x%016llx)", (unsigned long long)c.u.fbits); o += buf; }
+      break;
+    }
+    case (int)Tag::Numeric: {
+      const NumBlock* n = c.u.num;
+      if (n->kind == ETLG_NUM_NAN) o += "Numeric(NaN)";
+      else if (n->kind == ETLG_NUM_PINF) o += "Numeric(+Inf)";
+      else if (n->kind == ETLG_NUM_NINF) o += "Numeric(-Inf)";
+      else {
+        snprintf(buf, sizeof buf, "Numeric(%c,w=%d,s=%u,[", n->sign ? '-' : '+', (int)n->weight, (unsigned)n->scale); o += buf;
+        for (uint32_t i = 0; i < n->ndigits; i++) { snprintf(buf, sizeof buf, i ? ",%d" : "%d", (int)n->digits[i]); o += buf; }
+        o += "])";
+      }
+      break;
+    }
+    case (int)Tag::Date: o += "Date("; repr_date(c.u.t.date, o); o += ")"; break;
+    case (int)Tag::Time: o += "Time("; repr_time(c.u.t.secs, c.u.t.nanos, o); o += ")"; break;
+    case (int)Tag::TimeTz: o += "TimeTz("; repr_time(c.u.t.secs, c.u.t.nanos, o); snprintf(buf, sizeof buf, ",%d)", c.u.t.offset); o += buf; break;
+    case (int)Tag::Timestamp: o += "Timestamp("; repr_date(c.u.t.date, o); o += " "; repr_time(c.u.t.secs, c.u.t.nanos, o); o += ")"; break;
+    case (int)Tag::TimestampTz: o += "TimestampTz("; repr_date(c.u.t.date, o); o += " "; repr_time(c.u.t.secs, c.u.t.nanos, o); o += ")"; break;
+    case (int)Tag::Uuid: o += "Uuid("; hex_append(o, c.u.uuid, 16); o += ")"; break;
+    case (int)Tag::Json: o += "Json("; o.append(c.u.s.p, c.u.s.len); o += ")"; break;
+    case (int)Tag::String: o += "String(\""; o.append(c.u.s.p, c.u.s.len); o += "\")"; break;
+    case (int)Tag::Bytes: o += "Bytes("; hex_append(o, (const u8*)c.u.s.p, c.u.s.len); o += ")"; break;
+    case (int)Tag::Array: {
+      o += "Array[";
+      bool first = true;
+      for (auto& e : c.u.arr->elems) { if (!first) o += ","; first = false; if (e.tag == Tag::Null) o += "NULL"; else repr_cell(e, o); }
+      o += "]";
+      break;
+    }
+    default: o += "?"; break;
+  }
+}
+
+}  // namespace orc
+
+// ===================================================================== C API
+using namespace orc;
+
+extern "C" {
+
+struct oracle_ctx { Ctx c; };
+struct oracle_batch { Batch b; const Ctx* ctx; };
+
+const char* oracle_err_description(int32_t code) { return (code >= 0 && code < ETLG_E__COUNT) ? kErr[code].desc : nullptr; }
+int32_t oracle_err_kind(int32_t code) { return (code >= 0 && code < ETLG_E__COUNT) ? kErr[code].kind : -1; }
+
+oracle_ctx* oracle_ctx_create(void) { return new oracle_ctx(); }
+void oracle_ctx_destroy(oracle_ctx* c) { delete c; }
+
+// mode: 0 FULL, 1 CONTRACT; defer_mask: bit per etlg_type_class deferred wholesale.
+void oracle_ctx_set_mode(oracle_ctx* c, int32_t mode, uint32_t defer_mask) { c->c.mode = mode; c->c.defer_mask = defer_mask; }
+
+void oracle_ctx_set_worker(oracle_ctx* c, int32_t worker, uint32_t table_id, uint64_t bootstrap) {
+  c->c.worker = worker; c->c.sync_table = table_id; c->c.bootstrap = bootstrap;
+}
+
+void oracle_ctx_reset_stream_state(oracle_ctx* c) { c->c.in_txn = false; c->c.final_lsn = 0; c->c.next_ord = 0; }
+
+int32_t oracle_schema_put(oracle_ctx* c, uint32_t table_id, uint64_t snapshot, const char* nsp, const char* name,
+                          uint32_t ncols, const etlg_col* cols) {
+  auto s = std::make_shared<StoredSchema>();
+  s->table_id = table_id; s->snapshot = snapshot; s->nsp = nsp ? nsp : ""; s->name = name ? name : "";
+  for (uint32_t i = 0; i < ncols; i++) {
+    StoredCol sc;
+    sc.name = cols[i].name; sc.type_oid = cols[i].type_oid; sc.typmod = cols[i].type_modifier; sc.attnum = cols[i].attnum;
+    sc.nullable = cols[i].nullable; sc.pk = cols[i].primary_key;
+    s->cols.push_back(std::move(sc));
+  }
+  c->c.store[table_id][snapshot] = s;
+  return 0;
+}
+
+int32_t oracle_table_state(oracle_ctx* c, uint32_t table_id, int32_t kind, uint64_t lsn) {
+  if (kind == ETLG_TS_ABSENT) c->c.states.erase(table_id);
+  else c->c.states[table_id] = TState{kind, lsn};
+  return 0;
+}
+
+int32_t oracle_table_ready(oracle_ctx* c, uint32_t table_id, uint64_t snapshot, const uint8_t* rmask, const uint8_t* imask, uint32_t n) {
+  auto sch = get_at_or_before(c->c, table_id, snapshot);
+  if (!sch || sch->cols.size() != n) return -ETLG_MissingTableSchema;
+  std::vector<u8> r(rmask, rmask + n), i(imask, imask + n);
+  int32_t slot = make_slot(c->c, sch, r, i);
+  c->c.cache[table_id] = CacheEntry{CACHE_READY, sch->snapshot, slot};
+  return slot;
+}
+
+// Decode. offsets may be NULL (record-boundary scan on the CPU).
+// Returns the error *code* (etlg_err_code) of the first failing frame or 0.
+int32_t oracle_decode(oracle_ctx* c, const uint8_t* buf, size_t len, const uint32_t* offsets, size_t nframes, oracle_batch** out) {
+  auto* ob = new oracle_batch();
+  ob->ctx = &c->c;
+  decode_stream(c->c, ob->b, buf, len, offsets, nframes);
+  *out = ob;
+  return c->c.last.code;
+}
+
+// Timed CPU baseline leg: decode into the event object model and drop it
+// (MemoryDestination analog). Returns seconds; writes events/frames decoded.
+double oracle_decode_timed(oracle_ctx* c, const uint8_t* buf, size_t len, const uint32_t* offsets, size_t nframes,
+                           uint64_t* n_events, uint64_t* n_frames, int32_t* err_code) {
+  auto t0 = std::chrono::steady_clock::now();
+  Batch b;
+  decode_stream(c->c, b, buf, len, offsets, nframes);
+  uint64_t ne = b.events.size(), nf = b.n_frames;
+  { Batch drop = std::move(b); }
+  auto t1 = std::chrono::steady_clock::now();
+  if (n_events) *n_events = ne;
+  if (n_frames) *n_frames = nf;
+  if (err_code) *err_code = c->c.last.code;
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+int32_t oracle_last_error(const oracle_ctx* c, int32_t* kind, const char** desc, int64_t* frame) {
+  int32_t code = c->c.last.code;
+  if (kind) *kind = kErr[code].kind;
+  if (desc) *desc = kErr[code].desc;
+  if (frame) *frame = c->c.last.frame;
+  return code;
+}
+
+// Canonical arena view (CONTRACT mode batches only). Returns 0 / -1.
+int32_t oracle_batch_view(oracle_batch* ob, etlg_batch_view* v) {
+  Batch& b = ob->b;
+  if (!build_arena(*ob->ctx, b)) return -1;
+  memset(v, 0, sizeof *v);
+  v->n_events = b.events.size(); v->n_frames = b.n_frames;
+  v->fixed_bytes = b.fixed.size(); v->heap_bytes = b.heap.size();
+  for (int i = 0; i < 3; i++) v->payload_bytes[i] = b.payload[i];
+  v->ev_kind = b.kind.data(); v->ev_flags = b.flags.data(); v->ev_table_id = b.table_id.data(); v->ev_schema_slot = b.slot.data();
+  v->ev_start_lsn = b.start_lsn.data(); v->ev_commit_lsn = b.commit_lsn.data(); v->ev_tx_ordinal = b.ord.data(); v->ev_body_off = b.body_off.data();
+  v->fixed = b.fixed.data(); v->heap = b.heap.data();
+  v->on_device = 0; v->n_slots = (uint32_t)b.slot_descs.size(); v->slots = b.slot_descs.data();
+  return 0;
+}
+
+uint64_t oracle_batch_n_events(const oracle_batch* ob) { return ob->b.events.size(); }
+void oracle_batch_free(oracle_batch* ob) { delete ob; }
+
+// Human-readable dump of one event (both modes) for KAT-style assertions:
+//   "U start=.. commit=.. ord=.. table=.. old=Key[..] new=Partial[..]"
+static std::string g_repr;
+const char* oracle_event_repr(const oracle_batch* ob, uint64_t idx) {
+  const Event& e = ob->b.events[idx];
+  std::string& o = g_repr;
+  o.clear();
+  char buf[160];
+  snprintf(buf, sizeof buf, "%c start=%llu commit=%llu ord=%llu", e.kind, (unsigned long long)e.start_lsn, (unsigned long long)e.commit_lsn, (unsigned long long)e.ord);
+  o += buf;
+  auto row = [&](const Row& r) { o += "["; for (size_t i = 0; i < r.cells.size(); i++) { if (i) o += ", "; repr_cell(r.cells[i], o); } o += "]"; };
+  switch (e.kind) {
+    case 'B': snprintf(buf, sizeof buf, " ts=%lld xid=%u", (long long)e.ts, e.table_id); o += buf; break;
+    case 'C': snprintf(buf, sizeof buf, " flags=%d end=%llu ts=%lld", (int)(int8_t)e.flags, (unsigned long long)e.end_lsn, (long long)e.ts); o += buf; break;
+    case 'R': snprintf(buf, sizeof buf, " table=%u slot=%d", e.table_id, e.slot); o += buf; break;
+    case 'T': snprintf(buf, sizeof buf, " options=%d tables=", (int)(int8_t)e.flags); o += buf; for (auto& t : e.trunc) { snprintf(buf, sizeof buf, "%u/%d ", t.first, t.second); o += buf; } break;
+    default: {
+      snprintf(buf, sizeof buf, " table=%u slot=%d", e.table_id, e.slot); o += buf;
+      if (e.kind != 'I') { int ok = e.flags & 3; o += ok == ETLG_OLD_FULL ? " old=Full" : ok == ETLG_OLD_KEY ? " old=Key" : " old=None"; if (ok) row(e.old_row); }
+      if (e.kind != 'D') { o += (e.flags & ETLG_FLAG_PARTIAL) ? " new=Partial" : " new=Full"; row(e.new_row); }
+    }
+  }
+  return o.c_str();
+}
+
+// KAT entry: parse one text value as `type_oid` with full reference semantics.
+// Writes the repr ("I32(5)" ...) or "Err(<code>)" into out; returns the code.
+int32_t oracle_parse_text_cell(uint32_t type_oid, const char* text, size_t len, int32_t check_utf8, char* out, size_t cap) {
+  std::string o;
+  int32_t code = 0;
+  if (check_utf8 && !utf8_valid((const u8*)text, len)) code = ETLG_E_UTF8;
+  else {
+    auto r = parse_cell_text(type_oid, sv(text, len));
+    if (!r.ok) code = r.e.code; else repr_cell(r.v, o);
+  }
+  if (code) { char b[32]; snprintf(b, sizeof b, "Err(%d)", code); o = b; }
+  if (cap) { size_t n = std::min(cap - 1, o.size()); memcpy(out, o.data(), n); out[n] = 0; }
+  return code;
+}
+
+int32_t oracle_class_of_oid(uint32_t oid) { return class_of_oid(oid); }
+int32_t oracle_array_elem_class(uint32_t oid) { return array_elem_class(oid); }
+uint32_t oracle_slot_bytes(int32_t cls) { return slot_bytes(cls); }
+int32_t oracle_parse_utc_offset(const char* t, size_t n, int32_t* secs) { auto r = parse_utc_offset(sv(t, n)); if (!r) return 0; *secs = *r; return 1; }
+
+}  // extern "C"
