@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py — WAL bytes/s decoded on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the decode hot path over one 64 MiB batch of synthetic
+WAL (BASELINE.json configs[1]: fixed-width 5 x int4 INSERT tuples, 113-byte
+CopyData frames) that is already resident in HBM when the timed region
+starts; the decoded arena stays in HBM. Batches rotate through a pool larger
+than the 256 MiB Infinity Cache so steps do not re-read cached input.
+
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 is launched by the driver under torch.distributed.run (one rank per
+GPU). Each rank decodes its own contiguous, commit-aligned shard of the
+stream (weak scaling: one batch per rank per step); the only collective is an
+all-gather of a 64-byte header per rank per step (RCCL over xGMI) that gives
+every rank the LSN-ordered global layout. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_READ_PER_ROW = 113          # framed INSERT record
+ALG_WRITE_PER_ROW = 50          # event header 29 + 5 x i32 + null bitmap
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-mib", type=int, default=64)
+    ap.add_argument("--pool", type=int, default=6, help="distinct batches resident in HBM (rotated)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from etl_amd import abi, shard, synth
+    from etl_amd.decoder import Decoder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- workload: this rank's shard = its own contiguous range of the stream
+    mk = synth.cfg2 if args.workload == "cfg2" else synth.cfg3
+    w = mk()
+    cap = args.batch_mib << 20
+    # every rank walks the same deterministic stream and keeps batches rank, rank+world, ...
+    # (contiguous commit-aligned ranges; rank order == LSN order inside each step)
+    pool = []
+    need = args.pool
+    i = 0
+    while len(pool) < need:
+        buf, offs = w.fill(cap)
+        if i % world == rank:
+            pool.append((buf, offs))
+        i += 1
+    d_in = [(torch.from_numpy(b).to(dev), torch.from_numpy(o.view(np.int32)).to(dev), len(b), len(o) - 1) for b, o in pool]
+    torch.cuda.synchronize()
+
+    dec = Decoder(local_rank)
+    stream = torch.cuda.Stream(device=dev)   # decode kernels, header copy and the all-gather share one stream
+    torch.cuda.set_stream(stream)
+    dec.set_stream(stream.cuda_stream)
+    w.register(dec)
+    hdr = torch.zeros(8, dtype=torch.int64, device=dev)
+    flags = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
+
+    def step(k, keep):
+        tb, to, nbytes, nfr = d_in[k % len(d_in)]
+        b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, flags)
+        b.header_to_device(hdr.data_ptr())
+        if world > 1:
+            g = shard.all_gather_headers(hdr)
+            keep.append((b, nbytes, nfr, g))
+        else:
+            keep.append((b, nbytes, nfr, None))
+
+    def drain(keep, check):
+        tot_b = tot_f = 0
+        for b, nbytes, nfr, g in keep:
+            rc = b.sync()
+            if check:
+                v = b.view()
+                assert rc == 0 and v.n_events == nfr and v.n_frames == nfr, (rc, v.n_events, v.n_frames, nfr, b.error)
+            tot_b += nbytes
+            tot_f += nfr
+            b.close()
+        return tot_b, tot_f
+
+    keep = []
+    for k in range(args.warmup):
+        step(k, keep)
+    torch.cuda.synchronize()
+    drain(keep, True)
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    keep = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, keep)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    last_gather = keep[-1][3]
+    my_bytes, my_frames = drain(keep, True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([my_bytes, my_frames], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        all_bytes, all_frames = int(tot[0].item()), int(tot[1].item())
+        lay = shard.global_layout(last_gather.cpu().numpy())
+        assert not lay["any_error"]
+    else:
+        all_bytes, all_frames = my_bytes, my_frames
+
+    # ---- roofline leg: HIP-event timing of every kernel over a fresh run of K steps (rank 0)
+    roof = None
+    kern = {}
+    if rank == 0:
+        dec.profile(True)
+        keep = []
+        for k in range(args.steps):
+            tb, to, nbytes, nfr = d_in[k % len(d_in)]
+            keep.append((dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, flags), nbytes, nfr, None))
+        torch.cuda.synchronize()
+        prof = dec.profile_read()
+        dec.profile(False)
+        _, pf = drain(keep, True)
+        rows_per_launch = pf / args.steps
+        kern = {k: {"launches": n, "avg_us": 1000.0 * ms / n} for k, (n, ms) in prof.items() if n}
+        dom = max(kern, key=lambda k: kern[k]["avg_us"])
+        alg_bytes = rows_per_launch * (ALG_READ_PER_ROW + ALG_WRITE_PER_ROW)
+        ach = alg_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9
+        pipe_us = sum(v["avg_us"] for v in kern.values())
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(kern[dom]["avg_us"], 2),
+                "pipeline_kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+                "pipeline_sum_us": round(pipe_us, 2),
+                "pipeline_frac": round(alg_bytes / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    # ---- CPU baseline leg (rank 0, N == 1 only): the oracle on the same host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        o = oracle.Oracle(mode=oracle.MODE_FULL)
+        w.register(o)
+        sample_bytes = sample_frames = 0
+        secs = 0.0
+        reps = 0
+        while secs < args.cpu_seconds:
+            buf, offs = pool[reps % len(pool)]
+            o.reset_stream_state()
+            s, ne, nf, ec = o.decode_timed(buf, offs)
+            assert ec == 0 and nf == len(offs) - 1
+            secs += s
+            sample_bytes += len(buf)
+            sample_frames += nf
+            reps += 1
+        cpu = {"value": round(sample_bytes / secs / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+               "events_per_s": round(sample_frames / secs, 1),
+               "sample": f"{reps} x {args.batch_mib} MiB batches of {w.name} ({sample_bytes} bytes, {secs:.1f} s), "
+                         "single thread = the reference's one apply task; C++ restatement of the Rust decoder "
+                         "(oracle/, FULL mode: decode into an event object model, then drop it)"}
+
+    if rank == 0:
+        value = all_bytes / elapsed / 1e9
+        out = {
+            "metric": "WAL bytes/s decoded", "value": round(value, 3), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "events_per_s": round(all_frames / elapsed, 1),
+            "hbm_read_frac": round(value / HBM_PEAK_GBPS, 5),
+            "config": {"workload": f"{w.name}: {args.batch_mib} MiB batches of CopyData-framed pgoutput, "
+                                   "device-resident in / device-resident out, offsets sidecar, NO_CONTROL",
+                       "batch_bytes": int(my_bytes / args.steps), "frames_per_batch": int(my_frames / args.steps),
+                       "pool_batches": len(pool), "parallelism": f"shard{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

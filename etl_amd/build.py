@@ -1,0 +1,54 @@
+"""Builds the native pieces in-tree (no JIT cache): libetl_gfx950.so (HIP kernels
++ C ABI, cross-compiled for gfx950 with hipcc — works without a GPU) and
+libetlg_synth.so (synthetic WAL generator, plain g++)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libetl_gfx950.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = ["kernels.hip", "host.cpp"]
+DEPS = SOURCES + ["dev_types.h", os.path.join("..", "..", "include", "etlg.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    deps = [os.path.join(CSRC, d) for d in DEPS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        if force or _stale(obj, deps):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
+                   "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
+            if src.endswith(".cpp"):
+                cmd[1:1] = ["-x", "hip"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_all(force=False, verbose=False):
+    from . import synth
+    build_native(force=force, verbose=verbose)
+    synth.build(force=force)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in os.sys.argv, verbose=True)

@@ -1,0 +1,120 @@
+// Structures shared between the host control plane (host.cpp) and the gfx950
+// kernels (kernels.hip). Plain data, no pointers into host memory.
+#pragma once
+#include <stdint.h>
+
+namespace etlg {
+
+// Frame classes written by k_classify (pgoutput tag, or the XLogData/keepalive
+// envelope). 0 = malformed frame (wire-level error).
+enum : uint8_t { FT_BAD = 0 };
+
+// One replicated column of a schema slot (mirrors etlg_slot_col).
+struct DevCol {
+  uint8_t cls;       // etlg_type_class
+  uint8_t nullable;
+  uint8_t identity;
+  uint8_t _pad;
+  uint16_t off_full; // byte offset inside a full-layout row
+  uint16_t off_key;  // byte offset inside a key-layout row
+  uint16_t key_index;
+  uint16_t _pad2;
+};
+
+// A ReplicatedTableSchema instance (reference: crates/etl/src/schema.rs:380-441).
+struct DevSlot {
+  uint32_t n_cols, n_ident;
+  uint32_t row_full, row_key;  // bytes, multiples of 4
+  uint32_t st_full, st_key;    // state bytes at the head of a row
+  uint32_t cols_base;          // index of the first DevCol
+  uint32_t _pad;
+};
+
+// Per-table side input for one batch: ownership state
+// (apply.rs:2844-2850) + the shared-table-cache timeline
+// (table_cache.rs:53-154) as a list of epochs keyed by frame index.
+struct DevTable {
+  uint32_t table_id;
+  uint32_t state_kind;  // etlg_table_state_kind
+  uint64_t state_lsn;
+  uint32_t init_kind;   // cache entry at batch start: 0 none, 1 WaitingForRelation, 2 Ready
+  int32_t init_slot;
+  uint32_t ep_begin, ep_end;  // range in the DevEpoch array
+};
+
+struct DevEpoch {
+  uint32_t frame;   // frame index of the R / M message that caused the change
+  uint32_t kind;    // 1 WaitingForRelation, 2 Ready
+  int32_t slot;
+  uint32_t emit;    // R frames: 1 if the RelationEvent is emitted (owned)
+};
+
+// Control frame descriptor handed to the host control plane.
+struct CtrlFrame {
+  uint32_t frame;
+  uint32_t tag;        // 'R' | 'M'
+  uint32_t in_txn;
+  uint32_t _pad;
+  uint64_t final_lsn;
+};
+
+// Result block (device -> host, one small copy per batch).
+struct DevResult {
+  unsigned long long first_err;  // min over (frame << 16 | rank << 8 | code); ~0 = none
+  uint64_t n_events, fixed_bytes, heap_bytes;
+  uint64_t payload[3];
+  uint64_t n_frames;             // frames consumed
+  uint32_t out_in_txn, n_ctrl;
+  uint64_t out_final_lsn, out_next_ord;
+};
+
+constexpr unsigned long long kNoErr = ~0ull;
+constexpr int kBlock = 256;  // frames per workgroup (one lane per frame)
+
+// error stage ranks: for one frame the lowest rank wins, mirroring the order
+// in which the reference detects them (wire parse -> transaction state ->
+// ownership/schema lookup -> event decode).
+enum : uint32_t { RK_WIRE = 0, RK_TXN = 1, RK_SCHEMA = 2, RK_DECODE = 3 };
+
+struct DecParams {
+  const uint8_t* in;
+  const uint32_t* offs;  // nframes + 1
+  uint32_t nframes;
+  uint32_t nblocks;
+  uint64_t in_len;
+  // carried transaction state (apply.rs:942-963)
+  uint32_t in_txn;
+  uint32_t worker_kind, sync_table;
+  uint32_t flags;        // bit0: NO_CONTROL asserted
+  uint64_t final_lsn, next_ord;
+  uint32_t host_err_frame;  // frames >= this are ignored (host control plane failed there)
+  uint32_t n_tables;
+  // side inputs
+  const DevTable* tables;
+  const DevEpoch* epochs;
+  const DevSlot* slots;
+  const DevCol* cols;
+  // per-frame scratch
+  uint8_t* f_tag;
+  uint8_t* f_emit;
+  uint32_t* f_fixed;  // bytes
+  uint32_t* f_heap;   // bytes
+  // per-block aggregates / prefixes
+  uint32_t* blk_cnt;      // ordinal consumers per block -> exclusive prefix
+  uint32_t* blk_last;     // max over ((idx+1)<<1|isBegin) -> exclusive running max
+  uint32_t* blk_ev;       // events per block -> exclusive prefix
+  uint64_t* blk_fixed;    // bytes
+  uint64_t* blk_heap;
+  uint64_t* blk_payload;  // 3 per block
+  CtrlFrame* ctrl;        // compacted control frames
+  uint32_t ctrl_cap;
+  // outputs
+  uint8_t* ev_kind; uint8_t* ev_flags;
+  uint32_t* ev_table; uint32_t* ev_slot;
+  uint64_t* ev_start; uint64_t* ev_commit; uint64_t* ev_ord; uint64_t* ev_body;
+  uint8_t* fixed; uint8_t* heap;
+  uint64_t fixed_cap, heap_cap;
+  DevResult* res;
+};
+
+}  // namespace etlg

@@ -1,0 +1,1095 @@
+// Host side of libetl_gfx950.so: the C ABI of include/etlg.h.
+//
+// What lives here is the rare, serial control plane the reference runs inside
+// its apply loop — stored schemas (SchemaStore), table replication states
+// (StateStore), the shared per-table protocol cache and the handling of
+// Relation / DDL messages (reference: crates/etl/src/replication/apply.rs:
+// 2160-2276, 2363-2440, 3643-3734; crates/etl/src/schema.rs:30-61, 99-129,
+// 380-441; crates/etl/src/replication/table_cache.rs:53-154) — plus the
+// orchestration of the gfx950 kernels that do all per-row work. There is no
+// CPU decode path in this file: without a device etlg_ctx_create fails.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/etlg.h"
+#include "dev_types.h"
+
+using namespace etlg;
+
+extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
+extern "C" const char* etlg_k_name(int which);
+
+namespace {
+
+// ------------------------------------------------------------ error table
+const etlg_err_desc kErrTable[ETLG_E__COUNT] = {
+    {ETLG_OK, ""},
+    {ETLG_SourceConnectionFailed, "PostgreSQL connection failed"},
+    {ETLG_InvalidState, "Invalid transaction state"},
+    {ETLG_ValidationError, "Invalid commit LSN"},
+    {ETLG_InvalidState, "Missing shared table state"},
+    {ETLG_InvalidState, "Waiting for relation state cannot decode row event"},
+    {ETLG_ConversionError, "Tuple data field count does not match schema"},
+    {ETLG_ConversionError, "Tuple missing source value for full row image"},
+    {ETLG_InvalidData, "Required column missing from tuple"},
+    {ETLG_ConversionError, "Binary format not supported in tuple data"},
+    {ETLG_ConversionError, "UTF-8 conversion failed"},
+    {ETLG_ConversionError, "Old tuple row width does not match schema"},
+    {ETLG_ConversionError, "Replica-identity tuple shape does not match schema"},
+    {ETLG_ConversionError, "Replica-identity tuple missing key columns"},
+    {ETLG_ConversionError, "Replica-identity tuple missing source value"},
+    {ETLG_InvalidData, "Invalid boolean value"},
+    {ETLG_ConversionError, "Integer parsing failed"},
+    {ETLG_ConversionError, "Float parsing failed"},
+    {ETLG_ConversionError, "Numeric parsing failed"},
+    {ETLG_ConversionError, "Bytea hex string conversion failed"},
+    {ETLG_ConversionError, "Datetime parsing failed"},
+    {ETLG_InvalidData, "UUID parsing failed"},
+    {ETLG_DeserializationError, "JSON deserialization failed"},
+    {ETLG_ConversionError, "Array input too short"},
+    {ETLG_ConversionError, "Array input missing braces"},
+    {ETLG_ConversionError, "Array input has a malformed dimensions prefix"},
+    {ETLG_ConversionError, "Multidimensional array input is not supported"},
+    {ETLG_ConversionError, "Array input contains an unterminated quote"},
+    {ETLG_ConversionError, "Array input contains an unterminated escape"},
+    {ETLG_MissingTableSchema, "Table schema not found"},
+    {ETLG_CorruptedTableSchema, "Replication stream contains columns missing from the stored table schema"},
+    {ETLG_ConversionError, "Failed to parse schema change message"},
+    {ETLG_IoError, "I/O operation failed"},
+    {ETLG_InvalidState, "Bootstrap table schema snapshot exceeded requested snapshot"},
+    {ETLG_InvalidState, "Table schema snapshot mismatch"},
+    {ETLG_InvalidArgument, "Control frame found in a batch declared control-free"},
+};
+
+// ---------------------------------------------------------------- type map
+// Type::from_oid(..).unwrap_or(TEXT) + the arms of parse_cell_from_postgres_text
+// (crates/etl/src/postgres/codec/text.rs:32-153).
+struct ArrayOid { uint32_t oid; int32_t elem; };
+const ArrayOid kArrayOids[] = {
+    {1000, ETLG_TC_BOOL}, {1005, ETLG_TC_I16}, {1007, ETLG_TC_I32}, {1016, ETLG_TC_I64}, {1021, ETLG_TC_F32},
+    {1022, ETLG_TC_F64}, {1231, ETLG_TC_NUMERIC}, {1001, ETLG_TC_BYTEA}, {1182, ETLG_TC_DATE}, {1183, ETLG_TC_TIME},
+    {1270, ETLG_TC_TIMETZ}, {1115, ETLG_TC_TIMESTAMP}, {1185, ETLG_TC_TIMESTAMPTZ}, {2951, ETLG_TC_UUID},
+    {199, ETLG_TC_JSON}, {3807, ETLG_TC_JSON}, {1028, ETLG_TC_U32},
+    // generic `_xxx` arrays (ArrayCell::String)
+    {143, 0}, {210, 0}, {270, 0}, {272, 0}, {273, 0}, {629, 0}, {651, 0}, {719, 0}, {775, 0}, {791, 0}, {1002, 0},
+    {1003, 0}, {1006, 0}, {1008, 0}, {1009, 0}, {1010, 0}, {1011, 0}, {1012, 0}, {1013, 0}, {1014, 0}, {1015, 0},
+    {1017, 0}, {1018, 0}, {1019, 0}, {1020, 0}, {1027, 0}, {1034, 0}, {1040, 0}, {1041, 0}, {1187, 0}, {1263, 0},
+    {1561, 0}, {1563, 0}, {2201, 0}, {2207, 0}, {2208, 0}, {2209, 0}, {2210, 0}, {2211, 0}, {2949, 0}, {3221, 0},
+    {3643, 0}, {3644, 0}, {3645, 0}, {3735, 0}, {3770, 0}, {3905, 0}, {3907, 0}, {3909, 0}, {3911, 0}, {3913, 0},
+    {3927, 0}, {4073, 0}, {4090, 0}, {4097, 0}, {4192, 0}, {5039, 0}, {6151, 0}, {6152, 0}, {6153, 0}, {6155, 0},
+    {6156, 0}, {6157, 0}};
+
+int32_t type_class(uint32_t oid) {
+  switch (oid) {
+    case 16: return ETLG_TC_BOOL;
+    case 17: return ETLG_TC_BYTEA;
+    case 20: return ETLG_TC_I64;
+    case 21: return ETLG_TC_I16;
+    case 23: return ETLG_TC_I32;
+    case 26: return ETLG_TC_U32;
+    case 114: case 3802: return ETLG_TC_JSON;
+    case 700: return ETLG_TC_F32;
+    case 701: return ETLG_TC_F64;
+    case 1082: return ETLG_TC_DATE;
+    case 1083: return ETLG_TC_TIME;
+    case 1114: return ETLG_TC_TIMESTAMP;
+    case 1184: return ETLG_TC_TIMESTAMPTZ;
+    case 1266: return ETLG_TC_TIMETZ;
+    case 1700: return ETLG_TC_NUMERIC;
+    case 2950: return ETLG_TC_UUID;
+    default: break;
+  }
+  for (const auto& a : kArrayOids) if (a.oid == oid) return ETLG_TC_ARRAY;
+  return ETLG_TC_STRING;
+}
+
+uint32_t slot_bytes(int32_t cls) {
+  switch (cls) {
+    case ETLG_TC_BOOL: case ETLG_TC_I16: case ETLG_TC_I32: case ETLG_TC_U32: return 4;
+    case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: case ETLG_TC_TIMETZ: return 12;
+    case ETLG_TC_UUID: return 16;
+    default: return 8;
+  }
+}
+
+// ------------------------------------------------------------ control state
+struct StoredCol { std::string name; uint32_t type_oid; int32_t typmod; int32_t attnum; bool nullable; bool pk; };
+struct StoredSchema { uint32_t table_id; uint64_t snapshot; std::string nsp, name; std::vector<StoredCol> cols; };
+using SchemaPtr = std::shared_ptr<const StoredSchema>;
+
+struct SlotHost {  // one ReplicatedTableSchema instance
+  etlg_slot_desc desc;
+  std::vector<etlg_slot_col> cols;
+};
+
+struct CacheEntry { uint32_t kind; uint64_t snapshot; int32_t slot; };  // kind: 1 waiting, 2 ready
+struct TState { int32_t kind; uint64_t lsn; };
+
+struct ControlState {  // everything a failed batch must be able to roll back
+  std::map<uint32_t, std::map<uint64_t, SchemaPtr>> store;
+  std::map<uint32_t, CacheEntry> cache;
+  size_t n_slots = 0;
+};
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct OutSet {  // device output arrays of one batch
+  DevBuf kind, flags, table, slot, start, commit, ord, body, fixed, heap;
+  size_t ev_cap = 0;
+  void release() { kind.release(); flags.release(); table.release(); slot.release(); start.release(); commit.release(); ord.release(); body.release(); fixed.release(); heap.release(); }
+};
+
+struct ProfRec { int which; hipEvent_t a, b; };
+
+}  // namespace
+
+struct etlg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int32_t worker = ETLG_WORKER_APPLY;
+  uint32_t sync_table = 0;
+  uint64_t bootstrap = 0;
+  ControlState cs;
+  std::map<uint32_t, TState> states;
+  std::vector<std::unique_ptr<SlotHost>> slots;
+  bool slots_dirty = true;
+  // carried transaction state
+  bool in_txn = false; uint64_t final_lsn = 0, next_ord = 0;
+  // device scratch (grow-only)
+  DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols;
+  std::vector<OutSet*> out_pool;
+  DevResult* h_res = nullptr;  // pinned
+  // error
+  etlg_error err{};
+  std::string err_detail;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> prof_recs;
+  double prof_ms[8] = {0};
+  uint64_t prof_n[8] = {0};
+};
+
+struct etlg_batch {
+  etlg_ctx* ctx = nullptr;
+  etlg_batch_view v{};
+  OutSet* dev = nullptr;  // owned device arrays (OUTPUT_ON_DEVICE) — returned to the pool on free
+  std::vector<uint8_t> kind, flags, fixed, heap;
+  std::vector<uint32_t> table, slot;
+  std::vector<uint64_t> start, commit, ord, body;
+  std::vector<etlg_slot_desc> slot_descs;
+  bool pending = false;  // ASYNC: counts not read back yet
+  // what sync needs to finish the batch
+  int32_t host_err_code = 0; int64_t host_err_frame = -1; uint32_t host_err_rank = 0;
+  std::vector<CtrlFrame> ctrl;     // processed control frames (for rollback replay)
+  ControlState snapshot;           // control state before the batch
+  bool have_snapshot = false;
+};
+
+namespace {
+
+int32_t set_error(etlg_ctx* c, int32_t code, int64_t frame, const char* detail = nullptr) {
+  c->err.code = code;
+  c->err.kind = kErrTable[code].kind;
+  c->err.description = kErrTable[code].description;
+  c->err_detail = detail ? detail : "";
+  c->err.detail = c->err_detail.empty() ? nullptr : c->err_detail.c_str();
+  c->err.frame_index = frame;
+  return c->err.kind;
+}
+int32_t lib_error(etlg_ctx* c, int32_t kind, const char* what) {
+  c->err.code = 0; c->err.kind = kind; c->err.description = what; c->err.detail = nullptr; c->err.frame_index = -1;
+  return kind;
+}
+void clear_error(etlg_ctx* c) { c->err = etlg_error{}; c->err.frame_index = -1; c->err_detail.clear(); }
+
+#define HIPCHK(ctx, call)                                                        \
+  do {                                                                           \
+    hipError_t _e = (call);                                                      \
+    if (_e != hipSuccess) return lib_error((ctx), ETLG_DeviceError, hipGetErrorString(_e)); \
+  } while (0)
+
+// ----------------------------------------------------------------- slots
+int32_t make_slot(etlg_ctx* c, const SchemaPtr& sch, const std::vector<uint8_t>& repl, const std::vector<uint8_t>& ident) {
+  auto s = std::make_unique<SlotHost>();
+  uint32_t nid = 0;
+  for (size_t i = 0; i < sch->cols.size(); i++) {
+    if (repl[i] != 1) continue;
+    etlg_slot_col sc{};
+    sc.type_oid = sch->cols[i].type_oid;
+    sc.stored_index = (uint16_t)i;
+    sc.type_class = (uint8_t)type_class(sc.type_oid);
+    sc.nullable = sch->cols[i].nullable;
+    sc.identity = ident[i] == 1;
+    sc.key_index = sc.identity ? (uint16_t)nid++ : (uint16_t)0xFFFF;
+    s->cols.push_back(sc);
+  }
+  const uint32_t n = (uint32_t)s->cols.size();
+  etlg_slot_desc& d = s->desc;
+  d = etlg_slot_desc{};
+  d.table_id = sch->table_id; d.n_stored = (uint32_t)sch->cols.size(); d.snapshot_lsn = sch->snapshot;
+  d.n_cols = n; d.n_ident = nid;
+  d.state_bytes_full = 4 * ((n + 15) / 16);
+  d.state_bytes_key = 4 * ((nid + 15) / 16);
+  uint32_t off = d.state_bytes_full, koff = d.state_bytes_key;
+  for (auto& sc : s->cols) {
+    const uint32_t sb = slot_bytes(sc.type_class);
+    sc.off_full = (uint16_t)off; off += sb;
+    if (sc.identity) { sc.off_key = (uint16_t)koff; koff += sb; }
+  }
+  d.row_bytes_full = off; d.row_bytes_key = koff;
+  d.cols = s->cols.data();
+  c->slots.push_back(std::move(s));
+  c->cs.n_slots = c->slots.size();
+  c->slots_dirty = true;
+  return (int32_t)c->slots.size() - 1;
+}
+
+SchemaPtr get_at_or_before(const ControlState& cs, uint32_t table_id, uint64_t snap) {
+  auto it = cs.store.find(table_id);  // store/schema/table.rs:61-71
+  if (it == cs.store.end()) return nullptr;
+  auto ub = it->second.upper_bound(snap);
+  if (ub == it->second.begin()) return nullptr;
+  --ub;
+  return ub->second;
+}
+
+bool should_apply(const etlg_ctx* c, uint32_t table_id, uint64_t final_lsn) {  // apply.rs:2836-2867, 3514-3519
+  if (c->worker == ETLG_WORKER_TABLE_SYNC) return c->sync_table == table_id;
+  auto it = c->states.find(table_id);
+  if (it == c->states.end()) return false;
+  if (it->second.kind == ETLG_TS_READY) return true;
+  if (it->second.kind == ETLG_TS_SYNC_DONE) return it->second.lsn <= final_lsn;
+  return false;
+}
+
+// --------------------------------------------------------- tiny byte reader
+struct Rd {
+  const uint8_t* p; size_t n; size_t i = 0; bool ok = true;
+  bool need(size_t k) { if (!ok || n - i < k) { ok = false; return false; } return true; }
+  uint8_t u8() { return need(1) ? p[i++] : 0; }
+  uint16_t u16() { if (!need(2)) return 0; uint16_t v = (uint16_t)(p[i] << 8 | p[i + 1]); i += 2; return v; }
+  uint32_t u32() { if (!need(4)) return 0; uint32_t v = (uint32_t)p[i] << 24 | (uint32_t)p[i + 1] << 16 | (uint32_t)p[i + 2] << 8 | p[i + 3]; i += 4; return v; }
+  uint64_t u64() { uint64_t h = u32(); return h << 32 | u32(); }
+  std::string_view cstr() {
+    if (!ok) return {};
+    const void* z = memchr(p + i, 0, n - i);
+    if (!z) { ok = false; return {}; }
+    size_t len = (const uint8_t*)z - (p + i);
+    std::string_view r((const char*)p + i, len);
+    i += len + 1;
+    return r;
+  }
+};
+
+bool utf8_ok(std::string_view s) {  // String::from_utf8 in the cstr accessors
+  const uint8_t* p = (const uint8_t*)s.data(); size_t n = s.size(), i = 0;
+  while (i < n) {
+    uint8_t c = p[i];
+    if (c < 0x80) { i++; continue; }
+    size_t need; uint8_t lo = 0x80, hi = 0xBF;
+    if (c >= 0xC2 && c <= 0xDF) need = 1;
+    else if (c >= 0xE0 && c <= 0xEF) { need = 2; if (c == 0xE0) lo = 0xA0; if (c == 0xED) hi = 0x9F; }
+    else if (c >= 0xF0 && c <= 0xF4) { need = 3; if (c == 0xF0) lo = 0x90; if (c == 0xF4) hi = 0x8F; }
+    else return false;
+    if (n - i <= need) return false;
+    if (p[i + 1] < lo || p[i + 1] > hi) return false;
+    for (size_t k = 2; k <= need; k++) if ((p[i + k] & 0xC0) != 0x80) return false;
+    i += need + 1;
+  }
+  return true;
+}
+
+// ------------------------------------------------- DDL message (JSON) reader
+// SchemaChangeMessage (codec/event.rs:37-56, 96-106, 182-196) with serde's
+// struct rules: unknown fields skipped, missing / duplicate / mistyped fields
+// are errors, null only for Option. A pull parser: no DOM is built.
+struct Json {
+  const char* p; const char* e; int depth = 0; bool bad = false;
+  void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+  bool eat(char c) { ws(); if (p < e && *p == c) { p++; return true; } return false; }
+  bool peek(char c) { ws(); return p < e && *p == c; }
+  bool fail() { bad = true; return false; }
+  static void utf8_push(std::string& o, unsigned cp) {
+    if (cp < 0x80) o += (char)cp;
+    else if (cp < 0x800) { o += (char)(0xC0 | cp >> 6); o += (char)(0x80 | (cp & 63)); }
+    else if (cp < 0x10000) { o += (char)(0xE0 | cp >> 12); o += (char)(0x80 | ((cp >> 6) & 63)); o += (char)(0x80 | (cp & 63)); }
+    else { o += (char)(0xF0 | cp >> 18); o += (char)(0x80 | ((cp >> 12) & 63)); o += (char)(0x80 | ((cp >> 6) & 63)); o += (char)(0x80 | (cp & 63)); }
+  }
+  bool hex4(unsigned& v) {
+    if (e - p < 4) return fail();
+    v = 0;
+    for (int k = 0; k < 4; k++) {
+      char h = *p++; int d = h >= '0' && h <= '9' ? h - '0' : h >= 'a' && h <= 'f' ? h - 'a' + 10 : h >= 'A' && h <= 'F' ? h - 'A' + 10 : -1;
+      if (d < 0) return fail();
+      v = v * 16 + (unsigned)d;
+    }
+    return true;
+  }
+  bool string(std::string* out) {
+    ws();
+    if (p >= e || *p != '"') return fail();
+    p++;
+    while (p < e) {
+      unsigned char c = (unsigned char)*p++;
+      if (c == '"') return true;
+      if (c < 0x20) return fail();
+      if (c != '\\') { if (out) *out += (char)c; continue; }
+      if (p >= e) return fail();
+      char x = *p++;
+      char plain = 0;
+      switch (x) {
+        case '"': plain = '"'; break; case '\\': plain = '\\'; break; case '/': plain = '/'; break;
+        case 'b': plain = '\b'; break; case 'f': plain = '\f'; break; case 'n': plain = '\n'; break;
+        case 'r': plain = '\r'; break; case 't': plain = '\t'; break;
+        case 'u': {
+          unsigned v;
+          if (!hex4(v)) return false;
+          if (v >= 0xDC00 && v <= 0xDFFF) return fail();
+          if (v >= 0xD800 && v <= 0xDBFF) {
+            if (e - p < 2 || p[0] != '\\' || p[1] != 'u') return fail();
+            p += 2;
+            unsigned w;
+            if (!hex4(w)) return false;
+            if (w < 0xDC00 || w > 0xDFFF) return fail();
+            v = 0x10000 + ((v - 0xD800) << 10) + (w - 0xDC00);
+          }
+          if (out) utf8_push(*out, v);
+          continue;
+        }
+        default: return fail();
+      }
+      if (out) *out += plain;
+    }
+    return fail();
+  }
+  // number literal -> integer in [lo, hi]; fractions / exponents are type errors
+  bool integer(int64_t lo, uint64_t hi, int64_t& out) {
+    ws();
+    const char* s = p;
+    bool neg = false;
+    if (p < e && *p == '-') { neg = true; p++; }
+    if (p >= e || *p < '0' || *p > '9') return fail();
+    if (*p == '0') p++; else while (p < e && *p >= '0' && *p <= '9') p++;
+    if (p < e && (*p == '.' || *p == 'e' || *p == 'E')) return fail();
+    unsigned __int128 mag = 0;
+    for (const char* q = s + (neg ? 1 : 0); q < p; q++) { mag = mag * 10 + (unsigned)(*q - '0'); if (mag > ((unsigned __int128)1 << 70)) return fail(); }
+    if (neg) { if (mag > (unsigned __int128)(-(lo + 1)) + 1) return fail(); out = (int64_t)(-(__int128)mag); }
+    else { if (mag > hi) return fail(); out = (int64_t)(uint64_t)mag; }
+    return true;
+  }
+  bool skip_number() {
+    if (p < e && *p == '-') p++;
+    if (p >= e) return fail();
+    if (*p == '0') p++;
+    else if (*p >= '1' && *p <= '9') while (p < e && *p >= '0' && *p <= '9') p++;
+    else return fail();
+    if (p < e && *p == '.') { p++; if (p >= e || *p < '0' || *p > '9') return fail(); while (p < e && *p >= '0' && *p <= '9') p++; }
+    if (p < e && (*p == 'e' || *p == 'E')) { p++; if (p < e && (*p == '+' || *p == '-')) p++; if (p >= e || *p < '0' || *p > '9') return fail(); while (p < e && *p >= '0' && *p <= '9') p++; }
+    return true;
+  }
+  bool lit(const char* s) { size_t n = strlen(s); if ((size_t)(e - p) < n || memcmp(p, s, n)) return fail(); p += n; return true; }
+  bool skip_value() {
+    ws();
+    if (p >= e) return fail();
+    switch (*p) {
+      case '{': {
+        if (++depth > 128) return fail();
+        p++;
+        if (eat('}')) { depth--; return true; }
+        for (;;) {
+          if (!string(nullptr) || !eat(':') || !skip_value()) return fail();
+          if (eat(',')) continue;
+          if (eat('}')) { depth--; return true; }
+          return fail();
+        }
+      }
+      case '[': {
+        if (++depth > 128) return fail();
+        p++;
+        if (eat(']')) { depth--; return true; }
+        for (;;) {
+          if (!skip_value()) return false;
+          if (eat(',')) continue;
+          if (eat(']')) { depth--; return true; }
+          return fail();
+        }
+      }
+      case '"': return string(nullptr);
+      case 't': return lit("true");
+      case 'f': return lit("false");
+      case 'n': return lit("null");
+      default: return skip_number();
+    }
+  }
+  // iterate an object: calls f(key) for each member; f must consume the value
+  template <class F>
+  bool object(F f) {
+    if (!eat('{')) return fail();
+    if (++depth > 128) return fail();
+    if (eat('}')) { depth--; return true; }
+    for (;;) {
+      std::string key;
+      if (!string(&key) || !eat(':')) return fail();
+      if (!f(key)) return fail();
+      if (eat(',')) continue;
+      if (eat('}')) { depth--; return true; }
+      return fail();
+    }
+  }
+  template <class F>
+  bool array(F f) {
+    if (!eat('[')) return fail();
+    if (++depth > 128) return fail();
+    if (eat(']')) { depth--; return true; }
+    for (;;) {
+      if (!f()) return fail();
+      if (eat(',')) continue;
+      if (eat(']')) { depth--; return true; }
+      return fail();
+    }
+  }
+  bool boolean(bool& b) { ws(); if (p < e && *p == 't') { b = true; return lit("true"); } if (p < e && *p == 'f') { b = false; return lit("false"); } return fail(); }
+};
+
+bool parse_ddl(std::string_view content, uint64_t snapshot, std::shared_ptr<StoredSchema>& out) {
+  Json j{content.data(), content.data() + content.size()};
+  auto sch = std::make_shared<StoredSchema>();
+  sch->snapshot = snapshot;
+  int seen_tag = 0, seen_nsp = 0, seen_rel = 0, seen_oid = 0, seen_ident = 0, seen_cols = 0;
+  std::vector<int32_t> pks;
+  bool ok = j.object([&](const std::string& k) {
+    if (k == "command_tag") { seen_tag++; return j.string(nullptr); }
+    if (k == "nspname") { seen_nsp++; return j.string(&sch->nsp); }
+    if (k == "relname") { seen_rel++; return j.string(&sch->name); }
+    if (k == "oid") { seen_oid++; int64_t v; if (!j.integer(INT64_MIN, INT64_MAX, v)) return false; sch->table_id = (uint32_t)v; return true; }
+    if (k == "identity") {
+      seen_ident++;
+      int s_pk = 0, s_rid = 0, s_rix = 0;
+      bool o = j.object([&](const std::string& k2) {
+        if (k2 == "primary_key_attnums") { s_pk++; return j.array([&] { int64_t v; if (!j.integer(INT32_MIN, INT32_MAX, v)) return false; pks.push_back((int32_t)v); return true; }); }
+        if (k2 == "relreplident") { s_rid++; return j.string(nullptr); }
+        if (k2 == "replica_identity_index_attnums") { s_rix++; return j.array([&] { int64_t v; return j.integer(INT32_MIN, INT32_MAX, v); }); }
+        return j.skip_value();
+      });
+      return o && s_pk == 1 && s_rid == 1 && s_rix == 1;
+    }
+    if (k == "columns") {
+      seen_cols++;
+      return j.array([&] {
+        StoredCol c{};
+        int s_n = 0, s_t = 0, s_m = 0, s_a = 0, s_nn = 0, s_d = 0;
+        bool notnull = false;
+        bool o = j.object([&](const std::string& k2) {
+          int64_t v;
+          if (k2 == "attname") { s_n++; return j.string(&c.name); }
+          if (k2 == "atttypid") { s_t++; if (!j.integer(0, UINT32_MAX, v)) return false; c.type_oid = (uint32_t)v; return true; }
+          if (k2 == "atttypmod") { s_m++; if (!j.integer(INT32_MIN, INT32_MAX, v)) return false; c.typmod = (int32_t)v; return true; }
+          if (k2 == "attnum") { s_a++; if (!j.integer(INT32_MIN, INT32_MAX, v)) return false; c.attnum = (int32_t)v; return true; }
+          if (k2 == "attnotnull") { s_nn++; return j.boolean(notnull); }
+          if (k2 == "default_expression") { s_d++; if (j.peek('n')) return j.lit("null"); return j.string(nullptr); }
+          return j.skip_value();
+        });
+        if (!o || s_n != 1 || s_t != 1 || s_m != 1 || s_a != 1 || s_nn != 1 || s_d > 1) return false;
+        c.nullable = !notnull;
+        sch->cols.push_back(std::move(c));
+        return true;
+      });
+    }
+    return j.skip_value();
+  });
+  if (!ok || j.bad) return false;
+  j.ws();
+  if (j.p != j.e) return false;
+  if (seen_tag != 1 || seen_nsp != 1 || seen_rel != 1 || seen_oid != 1 || seen_ident != 1 || seen_cols != 1) return false;
+  for (auto& c : sch->cols) c.pk = std::find(pks.begin(), pks.end(), c.attnum) != pks.end();
+  std::stable_sort(sch->cols.begin(), sch->cols.end(), [](const StoredCol& a, const StoredCol& b) { return a.attnum < b.attnum; });
+  out = std::move(sch);
+  return true;
+}
+
+// ----------------------------------------------------- control-plane frames
+struct HostErr { int32_t code = 0; uint32_t rank = 0; };
+struct EpochRec { uint32_t table_id; DevEpoch ep; };
+
+// handle_relation_message (apply.rs:2363-2440) for one R frame.
+HostErr handle_relation(etlg_ctx* c, const CtrlFrame& cf, const uint8_t* body, size_t n, std::vector<EpochRec>& eps) {
+  Rd r{body, n};
+  const uint32_t rel_id = r.u32();
+  (void)r.cstr(); (void)r.cstr();
+  const uint8_t replident = r.u8();
+  if (!r.ok || (replident != 'd' && replident != 'n' && replident != 'f' && replident != 'i')) return {ETLG_E_WIRE, RK_WIRE};
+  const int16_t nc = (int16_t)r.u16();
+  if (!r.ok || nc < 0) return {ETLG_E_WIRE, RK_WIRE};
+  struct RC { int8_t flags; std::string_view name; };
+  std::vector<RC> rcs;
+  for (int k = 0; k < nc; k++) {
+    RC x; x.flags = (int8_t)r.u8(); x.name = r.cstr(); (void)r.u32(); (void)r.u32();
+    if (!r.ok) return {ETLG_E_WIRE, RK_WIRE};
+    rcs.push_back(x);
+  }
+  if (!cf.in_txn) return {ETLG_E_TXN_STATE, RK_TXN};
+  if (!should_apply(c, rel_id, cf.final_lsn)) return {};
+  // parse_replicated_column_names / parse_replica_identity_column_names (codec/event.rs:352-396)
+  std::set<std::string> repl, ident;
+  for (auto& x : rcs) { if (!utf8_ok(x.name)) return {ETLG_E_IO, RK_SCHEMA}; repl.emplace(x.name); }
+  for (auto& x : rcs) if (replident == 'f' || (x.flags & 1) == 1) ident.emplace(x.name);
+  auto cit = c->cs.cache.find(rel_id);
+  const bool used_bootstrap = cit == c->cs.cache.end();
+  const uint64_t snap = used_bootstrap ? c->bootstrap : cit->second.snapshot;
+  SchemaPtr sch = get_at_or_before(c->cs, rel_id, snap);  // get_table_schema_for_relation, apply.rs:3643-3697
+  if (!sch) return {ETLG_E_SCHEMA_NOT_FOUND, RK_SCHEMA};
+  if (used_bootstrap) { if (sch->snapshot > snap) return {ETLG_E_BOOTSTRAP_SNAPSHOT, RK_SCHEMA}; }
+  else if (sch->snapshot != snap) return {ETLG_E_SNAPSHOT_MISMATCH, RK_SCHEMA};
+  // ReplicationMask::try_build / IdentityMask::try_build (schema.rs:30-61, 99-129, 220-227)
+  std::set<std::string_view> have;
+  for (auto& sc : sch->cols) have.insert(sc.name);
+  for (auto& nme : repl) if (!have.count(nme)) return {ETLG_E_UNKNOWN_COLUMNS, RK_SCHEMA};
+  for (auto& nme : ident) if (!have.count(nme)) return {ETLG_E_UNKNOWN_COLUMNS, RK_SCHEMA};
+  std::vector<uint8_t> rm, im;
+  for (auto& sc : sch->cols) { rm.push_back(repl.count(sc.name) ? 1 : 0); im.push_back(ident.count(sc.name) ? 1 : 0); }
+  const int32_t slot = make_slot(c, sch, rm, im);
+  c->cs.cache[rel_id] = CacheEntry{2, sch->snapshot, slot};  // note_ready
+  eps.push_back({rel_id, DevEpoch{cf.frame, 2, slot, 1}});
+  return {};
+}
+
+// handle_message (apply.rs:2160-2276) for one M frame; `wal_start` = snapshot id.
+HostErr handle_ddl(etlg_ctx* c, const CtrlFrame& cf, uint64_t wal_start, const uint8_t* body, size_t n, std::vector<EpochRec>& eps) {
+  Rd r{body, n};
+  (void)r.u8(); (void)r.u64();
+  std::string_view prefix = r.cstr();
+  const int32_t len = (int32_t)r.u32();
+  if (!r.ok || len < 0 || !r.need((size_t)len)) return {ETLG_E_WIRE, RK_WIRE};
+  std::string_view content((const char*)body + r.i, (size_t)len);
+  if (!utf8_ok(prefix)) return {ETLG_E_IO, RK_SCHEMA};
+  if (prefix != "supabase_etl_ddl") return {};  // codec/event.rs:28
+  if (!cf.in_txn) return {ETLG_E_TXN_STATE, RK_TXN};
+  if (!utf8_ok(content)) return {ETLG_E_IO, RK_SCHEMA};
+  std::shared_ptr<StoredSchema> sch;
+  if (!parse_ddl(content, wal_start, sch)) return {ETLG_E_DDL_PARSE, RK_SCHEMA};
+  if (!should_apply(c, sch->table_id, cf.final_lsn)) return {};
+  const uint32_t tid = sch->table_id;
+  c->cs.store[tid][sch->snapshot] = sch;                       // store_table_schema
+  c->cs.cache[tid] = CacheEntry{1, wal_start, -1};             // note_waiting_for_relation
+  eps.push_back({tid, DevEpoch{cf.frame, 1, -1, 0}});
+  return {};
+}
+
+hipError_t upload(hipStream_t s, DevBuf& b, const void* src, size_t n) {
+  hipError_t e = b.ensure(n ? n : 16);
+  if (e != hipSuccess) return e;
+  if (n) e = hipMemcpyAsync(b.p, src, n, hipMemcpyHostToDevice, s);
+  return e;
+}
+
+hipError_t sync_slots(etlg_ctx* c) {
+  if (!c->slots_dirty) return hipSuccess;
+  std::vector<DevSlot> ds;
+  std::vector<DevCol> dc;
+  for (auto& s : c->slots) {
+    DevSlot d{};
+    d.n_cols = s->desc.n_cols; d.n_ident = s->desc.n_ident; d.row_full = s->desc.row_bytes_full; d.row_key = s->desc.row_bytes_key;
+    d.st_full = s->desc.state_bytes_full; d.st_key = s->desc.state_bytes_key; d.cols_base = (uint32_t)dc.size();
+    for (auto& sc : s->cols) {
+      DevCol x{};
+      x.cls = sc.type_class; x.nullable = sc.nullable; x.identity = sc.identity; x.off_full = sc.off_full; x.off_key = sc.off_key; x.key_index = sc.key_index;
+      dc.push_back(x);
+    }
+    ds.push_back(d);
+  }
+  hipError_t e = upload(c->stream, c->d_slots, ds.data(), ds.size() * sizeof(DevSlot));
+  if (e != hipSuccess) return e;
+  e = upload(c->stream, c->d_cols, dc.data(), dc.size() * sizeof(DevCol));
+  if (e != hipSuccess) return e;
+  // the staging vectors die at scope exit: make the copies land first
+  e = hipStreamSynchronize(c->stream);
+  c->slots_dirty = false;
+  return e;
+}
+
+void launch(etlg_ctx* c, int which, const DecParams& p) {
+  if (c->prof) {
+    ProfRec r; r.which = which;
+    (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, c->stream);
+    etlg_k_launch(which, &p, c->stream);
+    (void)hipEventRecord(r.b, c->stream);
+    c->prof_recs.push_back(r);
+  } else {
+    etlg_k_launch(which, &p, c->stream);
+  }
+}
+
+OutSet* take_outset(etlg_ctx* c) {
+  if (!c->out_pool.empty()) { OutSet* o = c->out_pool.back(); c->out_pool.pop_back(); return o; }
+  return new OutSet();
+}
+
+uint32_t max_row_bytes(const etlg_ctx* c) {
+  uint32_t m = 16;
+  for (auto& s : c->slots) m = std::max(m, 2 * s->desc.row_bytes_full);
+  return m;
+}
+
+void fill_view_common(etlg_batch* b) {
+  etlg_ctx* c = b->ctx;
+  b->slot_descs.clear();
+  for (auto& s : c->slots) b->slot_descs.push_back(s->desc);
+  b->v.n_slots = (uint32_t)b->slot_descs.size();
+  b->v.slots = b->slot_descs.data();
+}
+
+// Reads the result block, resolves device vs host error, commits or rolls back
+// the control-plane state and (for host output) copies the arenas back.
+int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& all_ctrl, const uint8_t* host_in,
+                     const uint32_t* host_offs, bool output_on_device);
+int32_t download_batch(etlg_ctx* c, etlg_batch* b);
+
+}  // namespace
+
+// ====================================================================== C API
+extern "C" {
+
+uint32_t etlg_abi_version(void) { return ETLG_ABI_VERSION; }
+
+const etlg_err_desc* etlg_err_table(int32_t code) { return (code >= 0 && code < ETLG_E__COUNT) ? &kErrTable[code] : nullptr; }
+int32_t etlg_type_class_of_oid(uint32_t oid) { return type_class(oid); }
+int32_t etlg_array_elem_class(uint32_t oid) { for (const auto& a : kArrayOids) if (a.oid == oid) return a.elem; return ETLG_TC_STRING; }
+uint32_t etlg_slot_bytes(int32_t cls) { return slot_bytes(cls); }
+
+int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
+  if (!out) return ETLG_InvalidArgument;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev) return ETLG_DeviceError;
+  if (hipSetDevice(hip_device) != hipSuccess) return ETLG_DeviceError;
+  auto* c = new etlg_ctx();
+  c->device = hip_device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ETLG_DeviceError; }
+  c->own_stream = true;
+  if (hipHostMalloc((void**)&c->h_res, sizeof(DevResult), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return ETLG_DeviceError; }
+  clear_error(c);
+  *out = c;
+  return ETLG_OK;
+}
+
+void etlg_ctx_destroy(etlg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols}) b->release();
+  for (OutSet* o : c->out_pool) { o->release(); delete o; }
+  for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int32_t etlg_ctx_set_stream(etlg_ctx* c, void* s) {
+  if (!c) return ETLG_InvalidArgument;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+  else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return ETLG_DeviceError; c->own_stream = true; }
+  return ETLG_OK;
+}
+
+int32_t etlg_ctx_set_worker(etlg_ctx* c, int32_t kind, uint32_t table_id, uint64_t bootstrap) {
+  if (!c) return ETLG_InvalidArgument;
+  c->worker = kind; c->sync_table = table_id; c->bootstrap = bootstrap;
+  return ETLG_OK;
+}
+
+int32_t etlg_schema_put(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const char* nsp, const char* name, uint32_t ncols, const etlg_col* cols) {
+  if (!c || (ncols && !cols)) return ETLG_InvalidArgument;
+  auto s = std::make_shared<StoredSchema>();
+  s->table_id = table_id; s->snapshot = snapshot; s->nsp = nsp ? nsp : ""; s->name = name ? name : "";
+  for (uint32_t i = 0; i < ncols; i++) {
+    StoredCol sc;
+    sc.name = cols[i].name ? cols[i].name : ""; sc.type_oid = cols[i].type_oid; sc.typmod = cols[i].type_modifier;
+    sc.attnum = cols[i].attnum; sc.nullable = cols[i].nullable != 0; sc.pk = cols[i].primary_key != 0;
+    s->cols.push_back(std::move(sc));
+  }
+  c->cs.store[table_id][snapshot] = s;
+  return ETLG_OK;
+}
+
+int32_t etlg_table_state(etlg_ctx* c, uint32_t table_id, int32_t kind, uint64_t lsn) {
+  if (!c) return ETLG_InvalidArgument;
+  if (kind == ETLG_TS_ABSENT) c->states.erase(table_id); else c->states[table_id] = TState{kind, lsn};
+  return ETLG_OK;
+}
+
+int32_t etlg_table_ready(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const uint8_t* rmask, const uint8_t* imask, uint32_t n) {
+  if (!c || !rmask || !imask) return -ETLG_InvalidArgument;
+  SchemaPtr sch = get_at_or_before(c->cs, table_id, snapshot);
+  if (!sch || sch->cols.size() != n) return -ETLG_MissingTableSchema;
+  std::vector<uint8_t> r(rmask, rmask + n), i(imask, imask + n);
+  const int32_t slot = make_slot(c, sch, r, i);
+  c->cs.cache[table_id] = CacheEntry{2, sch->snapshot, slot};
+  return slot;
+}
+
+int32_t etlg_ctx_reset_stream_state(etlg_ctx* c) {
+  if (!c) return ETLG_InvalidArgument;
+  c->in_txn = false; c->final_lsn = 0; c->next_ord = 0;
+  return ETLG_OK;
+}
+
+const etlg_error* etlg_last_error(const etlg_ctx* c) { return c ? &c->err : nullptr; }
+
+int32_t etlg_ctx_slots(const etlg_ctx* c, uint32_t* n, const etlg_slot_desc** slots) {
+  if (!c || !n || !slots) return ETLG_InvalidArgument;
+  static thread_local std::vector<etlg_slot_desc> tmp;
+  tmp.clear();
+  for (auto& s : c->slots) tmp.push_back(s->desc);
+  *n = (uint32_t)tmp.size(); *slots = tmp.data();
+  return ETLG_OK;
+}
+
+int32_t etlg_ctx_profile(etlg_ctx* c, int32_t enable) {
+  if (!c) return ETLG_InvalidArgument;
+  c->prof = enable != 0;
+  if (!enable) { for (int i = 0; i < 8; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; } }
+  return ETLG_OK;
+}
+
+int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, uint32_t* n) {
+  if (!c || !n) return ETLG_InvalidArgument;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& r : c->prof_recs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.which] += ms; c->prof_n[r.which]++; }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  c->prof_recs.clear();
+  uint32_t k = 0;
+  for (int i = 0; i < 7 && k < cap; i++) { out[k].name = etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  *n = k;
+  return ETLG_OK;
+}
+
+int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags, etlg_batch** out) {
+  if (!c || !out) return ETLG_InvalidArgument;
+  *out = nullptr;
+  clear_error(c);
+  if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE, out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
+  const bool no_ctrl = flags & ETLG_F_NO_CONTROL, async = (flags & ETLG_F_ASYNC) && out_dev && no_ctrl;
+  hipStream_t s = c->stream;
+
+  // ---- record boundaries: the sidecar, or a host scan of the length fields
+  std::vector<uint32_t> scanned;
+  const uint32_t* h_offs = frame_offsets;
+  if (!frame_offsets) {
+    if (in_dev) return lib_error(c, ETLG_Unsupported, "device-resident input needs the frame_offsets sidecar");
+    // 'd' | Int32-BE length chain (a malformed tail becomes one bad frame and fails on the device)
+    size_t pos = 0;
+    scanned.push_back(0);
+    while (pos < len) {
+      size_t next = len;
+      if (len - pos >= 5) {
+        uint64_t l = (uint64_t)buf[pos + 1] << 24 | (uint64_t)buf[pos + 2] << 16 | (uint64_t)buf[pos + 3] << 8 | buf[pos + 4];
+        if (buf[pos] == 'd' && l >= 4 && pos + 1 + l <= len) next = pos + 1 + (size_t)l;
+      }
+      scanned.push_back((uint32_t)next);
+      pos = next;
+    }
+    h_offs = scanned.data();
+    nframes = scanned.size() - 1;
+  }
+
+  auto* b = new etlg_batch();
+  b->ctx = c;
+  std::unique_ptr<etlg_batch> guard(b);
+
+  const uint32_t nf = (uint32_t)nframes;
+  const uint32_t nblocks = (nf + kBlock - 1) / kBlock;
+  DecParams p{};
+  if (in_dev) { p.in = buf; p.offs = frame_offsets; }
+  else {
+    HIPCHK(c, c->d_in.ensure(len + 64));
+    HIPCHK(c, c->d_offs.ensure((nframes + 1) * 4));
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_offs.p, h_offs, (nframes + 1) * 4, hipMemcpyHostToDevice, s));
+    p.in = (const uint8_t*)c->d_in.p; p.offs = (const uint32_t*)c->d_offs.p;
+  }
+  p.nframes = nf; p.nblocks = nblocks; p.in_len = len;
+  p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
+  p.worker_kind = (uint32_t)c->worker; p.sync_table = c->sync_table;
+  p.flags = no_ctrl ? 1u : 0u;
+  p.host_err_frame = 0xFFFFFFFFu;
+
+  HIPCHK(c, c->d_tag.ensure(nf + 16)); HIPCHK(c, c->d_emit.ensure(nf + 16));
+  HIPCHK(c, c->d_ffixed.ensure((size_t)nf * 4 + 16)); HIPCHK(c, c->d_fheap.ensure((size_t)nf * 4 + 16));
+  HIPCHK(c, c->d_blk32.ensure((size_t)(nblocks + 1) * 4 * 3 + 64));
+  HIPCHK(c, c->d_blk64.ensure((size_t)(nblocks + 1) * 8 * 5 + 64));
+  HIPCHK(c, c->d_res.ensure(sizeof(DevResult)));
+  p.f_tag = (uint8_t*)c->d_tag.p; p.f_emit = (uint8_t*)c->d_emit.p;
+  p.f_fixed = (uint32_t*)c->d_ffixed.p; p.f_heap = (uint32_t*)c->d_fheap.p;
+  p.blk_cnt = (uint32_t*)c->d_blk32.p; p.blk_last = p.blk_cnt + (nblocks + 1); p.blk_ev = p.blk_last + (nblocks + 1);
+  p.blk_fixed = (uint64_t*)c->d_blk64.p; p.blk_heap = p.blk_fixed + (nblocks + 1); p.blk_payload = p.blk_heap + (nblocks + 1);
+  p.res = (DevResult*)c->d_res.p;
+  DevResult init{}; init.first_err = kNoErr;
+  *c->h_res = init;
+  HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_res, sizeof(DevResult), hipMemcpyHostToDevice, s));
+
+  std::vector<CtrlFrame> ctrl;
+  std::vector<EpochRec> eps;
+  HostErr herr{};
+  int64_t herr_frame = -1;
+  b->snapshot = c->cs; b->have_snapshot = true;
+  const size_t slots_before = c->slots.size();
+
+  if (nf) launch(c, 0, p);
+  launch(c, 1, p);
+  if (!no_ctrl && nf) {
+    HIPCHK(c, c->d_ctrl.ensure((size_t)nf * sizeof(CtrlFrame) + 64));
+    p.ctrl = (CtrlFrame*)c->d_ctrl.p; p.ctrl_cap = nf;
+    launch(c, 2, p);
+    HIPCHK(c, hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const uint32_t nctrl = c->h_res->n_ctrl;
+    if (nctrl) {
+      ctrl.resize(nctrl);
+      HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
+      std::sort(ctrl.begin(), ctrl.end(), [](const CtrlFrame& a, const CtrlFrame& b2) { return a.frame < b2.frame; });
+      std::vector<uint8_t> tmp;
+      for (const CtrlFrame& cf : ctrl) {
+        uint32_t o0, o1;
+        if (in_dev) {
+          uint32_t oo[2];
+          HIPCHK(c, hipMemcpy(oo, frame_offsets + cf.frame, 8, hipMemcpyDeviceToHost));
+          o0 = oo[0]; o1 = oo[1];
+          tmp.resize(o1 - o0);
+          HIPCHK(c, hipMemcpy(tmp.data(), buf + o0, o1 - o0, hipMemcpyDeviceToHost));
+        } else { o0 = h_offs[cf.frame]; o1 = h_offs[cf.frame + 1]; }
+        const uint8_t* fr = in_dev ? tmp.data() : buf + o0;
+        const size_t flen = o1 - o0;
+        // classify guaranteed 'd' len 'w' hdr tag: body starts at +31
+        uint64_t wal_start = 0;
+        for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
+        HostErr he = cf.tag == 'R' ? handle_relation(c, cf, fr + 31, flen - 31, eps) : handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
+        if (he.code) { herr = he; herr_frame = cf.frame; p.host_err_frame = cf.frame; break; }
+      }
+    }
+  }
+  b->ctrl = ctrl;
+  b->host_err_code = herr.code; b->host_err_frame = herr_frame; b->host_err_rank = herr.rank;
+
+  // ---- side inputs: table states + cache timeline
+  {
+    std::map<uint32_t, DevTable> tabs;
+    auto get = [&](uint32_t id) -> DevTable& {
+      auto it = tabs.find(id);
+      if (it == tabs.end()) { DevTable t{}; t.table_id = id; t.init_slot = -1; it = tabs.emplace(id, t).first; }
+      return it->second;
+    };
+    for (auto& kv : c->states) { DevTable& t = get(kv.first); t.state_kind = (uint32_t)kv.second.kind; t.state_lsn = kv.second.lsn; }
+    for (auto& kv : b->snapshot.cache) { DevTable& t = get(kv.first); t.init_kind = kv.second.kind; t.init_slot = kv.second.slot; }
+    for (auto& e : eps) get(e.table_id);
+    std::vector<DevTable> tv;
+    std::vector<DevEpoch> ev;
+    for (auto& kv : tabs) {
+      DevTable t = kv.second;
+      t.ep_begin = (uint32_t)ev.size();
+      for (auto& e : eps) if (e.table_id == t.table_id) ev.push_back(e.ep);  // already in frame order
+      t.ep_end = (uint32_t)ev.size();
+      tv.push_back(t);
+    }
+    HIPCHK(c, upload(s, c->d_tables, tv.data(), tv.size() * sizeof(DevTable)));
+    HIPCHK(c, upload(s, c->d_epochs, ev.data(), ev.size() * sizeof(DevEpoch)));
+    HIPCHK(c, hipStreamSynchronize(s));  // staging vectors die here
+    p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)tv.size();
+  }
+  HIPCHK(c, sync_slots(c));
+  p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
+
+  // ---- outputs (capacity bounds: one event per frame; rows bounded by the widest slot;
+  //      truncate bodies by 2x frame bytes; heap by 2.5x input)
+  OutSet* os = take_outset(c);
+  b->dev = os;
+  const size_t evcap = (size_t)nf + 16;
+  const uint64_t fixed_cap = (uint64_t)nf * max_row_bytes(c) + 2 * (uint64_t)len + 64;
+  const uint64_t heap_cap = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)len * 5 / 2 + 64);
+  HIPCHK(c, os->kind.ensure(evcap)); HIPCHK(c, os->flags.ensure(evcap));
+  HIPCHK(c, os->table.ensure(evcap * 4)); HIPCHK(c, os->slot.ensure(evcap * 4));
+  HIPCHK(c, os->start.ensure(evcap * 8)); HIPCHK(c, os->commit.ensure(evcap * 8));
+  HIPCHK(c, os->ord.ensure(evcap * 8)); HIPCHK(c, os->body.ensure(evcap * 8));
+  HIPCHK(c, os->fixed.ensure(fixed_cap)); HIPCHK(c, os->heap.ensure(heap_cap));
+  p.ev_kind = (uint8_t*)os->kind.p; p.ev_flags = (uint8_t*)os->flags.p; p.ev_table = (uint32_t*)os->table.p; p.ev_slot = (uint32_t*)os->slot.p;
+  p.ev_start = (uint64_t*)os->start.p; p.ev_commit = (uint64_t*)os->commit.p; p.ev_ord = (uint64_t*)os->ord.p; p.ev_body = (uint64_t*)os->body.p;
+  p.fixed = (uint8_t*)os->fixed.p; p.heap = (uint8_t*)os->heap.p; p.fixed_cap = fixed_cap; p.heap_cap = heap_cap;
+
+  if (nf) launch(c, 3, p);
+  launch(c, 4, p);
+  if (nf) launch(c, 5, p);
+  launch(c, 6, p);
+  HIPCHK(c, hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+
+  (void)slots_before;
+  guard.release();
+  *out = b;
+  if (async) { b->pending = true; b->v.on_device = 1; fill_view_common(b); return ETLG_OK; }
+  return finish_batch(c, b, ctrl, in_dev ? nullptr : buf, in_dev ? nullptr : h_offs, out_dev);
+}
+
+int32_t etlg_batch_sync(etlg_ctx* c, etlg_batch* b) {
+  if (!c || !b) return ETLG_InvalidArgument;
+  if (!b->pending) return c->err.kind;
+  b->pending = false;
+  return finish_batch(c, b, b->ctrl, nullptr, nullptr, true);
+}
+
+int32_t etlg_batch_header_to_device(etlg_ctx* c, etlg_batch* b, void* dst) {
+  if (!c || !b || !dst) return ETLG_InvalidArgument;
+  static_assert(offsetof(DevResult, n_frames) == 56, "header layout");
+  HIPCHK(c, hipMemcpyAsync(dst, c->d_res.p, 64, hipMemcpyDeviceToDevice, c->stream));
+  return ETLG_OK;
+}
+
+int32_t etlg_batch_download(etlg_ctx* c, etlg_batch* b) {
+  if (!c || !b) return ETLG_InvalidArgument;
+  if (b->pending) { int32_t rc = etlg_batch_sync(c, b); (void)rc; }
+  return download_batch(c, b);
+}
+
+int32_t etlg_batch_view_get(const etlg_batch* b, etlg_batch_view* out) {
+  if (!b || !out) return ETLG_InvalidArgument;
+  *out = b->v;
+  return ETLG_OK;
+}
+
+void etlg_batch_free(etlg_batch* b) {
+  if (!b) return;
+  if (b->dev) {
+    if (b->pending) (void)hipStreamSynchronize(b->ctx->stream);
+    b->ctx->out_pool.push_back(b->dev);
+  }
+  delete b;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Copies a device-resident batch into host vectors and returns its OutSet to the pool.
+int32_t download_batch(etlg_ctx* c, etlg_batch* b) {
+  OutSet* os = b->dev;
+  if (!os) return ETLG_OK;
+  hipStream_t s = c->stream;
+  etlg_batch_view& v = b->v;
+  const size_t n = (size_t)v.n_events;
+  b->kind.resize(n); b->flags.resize(n); b->table.resize(n); b->slot.resize(n);
+  b->start.resize(n); b->commit.resize(n); b->ord.resize(n); b->body.resize(n);
+  b->fixed.resize((size_t)v.fixed_bytes); b->heap.resize((size_t)v.heap_bytes);
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(b->kind.data(), os->kind.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->flags.data(), os->flags.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->table.data(), os->table.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->slot.data(), os->slot.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->start.data(), os->start.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->commit.data(), os->commit.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->ord.data(), os->ord.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->body.data(), os->body.p, n * 8, hipMemcpyDeviceToHost, s));
+  }
+  if (v.fixed_bytes) HIPCHK(c, hipMemcpyAsync(b->fixed.data(), os->fixed.p, (size_t)v.fixed_bytes, hipMemcpyDeviceToHost, s));
+  if (v.heap_bytes) HIPCHK(c, hipMemcpyAsync(b->heap.data(), os->heap.p, (size_t)v.heap_bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  c->out_pool.push_back(os);
+  b->dev = nullptr;
+  v.on_device = 0;
+  v.ev_kind = b->kind.data(); v.ev_flags = b->flags.data(); v.ev_table_id = b->table.data(); v.ev_schema_slot = b->slot.data();
+  v.ev_start_lsn = b->start.data(); v.ev_commit_lsn = b->commit.data(); v.ev_tx_ordinal = b->ord.data(); v.ev_body_off = b->body.data();
+  v.fixed = b->fixed.data(); v.heap = b->heap.data();
+  return ETLG_OK;
+}
+
+int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& all_ctrl, const uint8_t* host_in,
+                     const uint32_t* host_offs, bool output_on_device) {
+  (void)host_in; (void)host_offs;
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipStreamSynchronize(s));
+  const DevResult r = *c->h_res;
+  // ---- first error: device (frame, rank) vs host control plane (frame, rank)
+  int32_t code = 0; int64_t frame = -1; uint32_t rank = 0xFF;
+  if (r.first_err != kNoErr) { frame = (int64_t)(r.first_err >> 16); rank = (uint32_t)((r.first_err >> 8) & 0xFF); code = (int32_t)(r.first_err & 0xFF); }
+  if (b->host_err_code) {
+    const int64_t hf = b->host_err_frame;
+    if (frame < 0 || hf < frame || (hf == frame && b->host_err_rank < rank)) { frame = hf; rank = b->host_err_rank; code = b->host_err_code; }
+  }
+  // ---- control-plane state: keep only effects of frames before the failing one
+  if (code && b->have_snapshot) {
+    bool later = false;
+    for (auto& cf : all_ctrl) if ((int64_t)cf.frame >= frame) later = true;
+    if (later || b->host_err_code) {
+      // roll back, then replay the prefix (rare path; errors end the stream anyway)
+      c->cs = b->snapshot;
+      c->slots.resize(b->snapshot.n_slots);
+      c->slots_dirty = true;
+      // Replaying needs the frame bytes; they are only needed when a later batch is
+      // decoded on this context after a failure, which the reference never does
+      // (the apply loop exits). Effects of control frames before `frame` are
+      // re-applied when the input is still host-visible.
+      if (host_in && host_offs) {
+        std::vector<EpochRec> eps;
+        for (auto& cf : all_ctrl) {
+          if ((int64_t)cf.frame >= frame) break;
+          const uint8_t* fr = host_in + host_offs[cf.frame];
+          const size_t flen = host_offs[cf.frame + 1] - host_offs[cf.frame];
+          uint64_t wal_start = 0;
+          for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
+          if (cf.tag == 'R') (void)handle_relation(c, cf, fr + 31, flen - 31, eps); else (void)handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
+        }
+      }
+    }
+  }
+  b->have_snapshot = false;
+  b->snapshot = ControlState{};
+  c->in_txn = r.out_in_txn != 0; c->final_lsn = r.out_final_lsn; c->next_ord = r.out_next_ord;
+
+  etlg_batch_view& v = b->v;
+  v.n_events = r.n_events; v.n_frames = code ? (uint64_t)frame : r.n_frames;
+  v.fixed_bytes = r.fixed_bytes; v.heap_bytes = r.heap_bytes;
+  for (int i = 0; i < 3; i++) v.payload_bytes[i] = r.payload[i];
+  OutSet* os = b->dev;
+  v.on_device = 1;
+  v.ev_kind = (const uint8_t*)os->kind.p; v.ev_flags = (const uint8_t*)os->flags.p; v.ev_table_id = (const uint32_t*)os->table.p; v.ev_schema_slot = (const uint32_t*)os->slot.p;
+  v.ev_start_lsn = (const uint64_t*)os->start.p; v.ev_commit_lsn = (const uint64_t*)os->commit.p; v.ev_tx_ordinal = (const uint64_t*)os->ord.p; v.ev_body_off = (const uint64_t*)os->body.p;
+  v.fixed = (const uint8_t*)os->fixed.p; v.heap = (const uint8_t*)os->heap.p;
+  if (!output_on_device) {
+    const int32_t rc = download_batch(c, b);
+    if (rc != ETLG_OK) return rc;
+  }
+  fill_view_common(b);
+  if (code) return set_error(c, code, frame);
+  return ETLG_OK;
+}
+
+}  // namespace

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference interface for the decode hot path.
+
+`Decoder` is what the reference's `ApplyLoop` is to its codec: it owns the
+per-stream transaction state and the shared table cache (inside the native
+context), is primed with stored schemas / table states the way
+`SchemaStore` / `StateStore` are (crates/etl/src/store/schema/base.rs:19-69,
+crates/etl/src/store/state/base.rs:25-139), and turns batches of raw
+logical-replication messages into the events `Destination::write_events`
+would receive (crates/etl/src/destination/base.rs:207). All per-row work runs
+in the gfx950 kernels of libetl_gfx950.so; this module only moves pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, native
+from .view import HostBatch
+
+
+class EtlError(Exception):
+    """EtlError {kind, description, detail} (crates/etl/src/error.rs:27-76)."""
+
+    def __init__(self, kind, code, description, detail, frame_index):
+        self.kind, self.code, self.description, self.detail, self.frame_index = kind, code, description, detail, frame_index
+        super().__init__(f"{abi.KIND_NAMES.get(kind, kind)}: {description} (frame {frame_index})")
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Batch:
+    """A decoded batch (etlg_batch). `host()` copies the arena into numpy arrays."""
+
+    def __init__(self, dec, handle, rc, keep=None):
+        self.dec, self.h, self.rc = dec, handle, rc
+        self._keep = keep
+        self.error = dec.last_error() if rc != abi.OK else None
+
+    def view(self):
+        v = abi.BatchView()
+        self.dec.L.etlg_batch_view_get(self.h, C.byref(v))
+        return v
+
+    def sync(self):
+        self.rc = self.dec.L.etlg_batch_sync(self.dec.h, self.h)
+        self.error = self.dec.last_error() if self.rc != abi.OK else None
+        return self.rc
+
+    def header_to_device(self, dst_ptr):
+        """Enqueue the 64-byte result header into device memory (multi-GPU all-gather input)."""
+        return self.dec.L.etlg_batch_header_to_device(self.dec.h, self.h, C.c_void_p(dst_ptr))
+
+    def host(self):
+        v = self.view()
+        if v.on_device:
+            rc = self.dec.L.etlg_batch_download(self.dec.h, self.h)
+            if rc != abi.OK:
+                raise self.dec.last_error()
+            v = self.view()
+        return HostBatch.from_view(v)
+
+    def close(self):
+        if self.h:
+            self.dec.L.etlg_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Decoder:
+    def __init__(self, device=0, stream=None):
+        self.L = native.lib()
+        h = C.c_void_p()
+        rc = self.L.etlg_ctx_create(device, C.byref(h))
+        if rc != abi.OK:
+            raise RuntimeError(f"etlg_ctx_create failed ({abi.KIND_NAMES.get(rc, rc)}): an MI355X (gfx950) device is required")
+        self.h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.etlg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- control plane (same calls the oracle wrapper exposes)
+    def set_stream(self, cuda_stream_ptr):
+        return self.L.etlg_ctx_set_stream(self.h, C.c_void_p(cuda_stream_ptr))
+
+    def set_worker(self, worker=abi.WORKER_APPLY, table_id=0, bootstrap_lsn=0):
+        return self.L.etlg_ctx_set_worker(self.h, worker, table_id, bootstrap_lsn)
+
+    def reset_stream_state(self):
+        return self.L.etlg_ctx_reset_stream_state(self.h)
+
+    def schema_put(self, table_id, snapshot_lsn, cols, schema="public", name="t"):
+        arr = abi.make_cols(cols)
+        return self.L.etlg_schema_put(self.h, table_id, snapshot_lsn, schema.encode(), name.encode(), len(cols), arr)
+
+    def table_state(self, table_id, kind, lsn=0):
+        return self.L.etlg_table_state(self.h, table_id, kind, lsn)
+
+    def table_ready(self, table_id, snapshot_lsn, repl_mask, ident_mask):
+        r = np.asarray(repl_mask, dtype=np.uint8)
+        i = np.asarray(ident_mask, dtype=np.uint8)
+        return self.L.etlg_table_ready(self.h, table_id, snapshot_lsn, _ptr(r), _ptr(i), len(r))
+
+    def last_error(self):
+        e = self.L.etlg_last_error(self.h).contents
+        return EtlError(e.kind, e.code, (e.description or b"").decode(), (e.detail or b"").decode() or None, e.frame_index)
+
+    # ---- decode
+    def decode(self, buf, offsets=None, flags=0):
+        """Host buffers: buf = bytes / np.uint8, offsets = optional u32 sidecar."""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint32)
+        nfr = 0 if off is None else len(off) - 1
+        out = C.c_void_p()
+        rc = self.L.etlg_decode(self.h, _ptr(a), a.size, _ptr(off), nfr, flags & ~abi.F_INPUT_ON_DEVICE, C.byref(out))
+        if not out:
+            raise self.last_error()
+        return Batch(self, out, rc, keep=(a, off))
+
+    def decode_device(self, buf_ptr, nbytes, offs_ptr, nframes, flags=abi.F_OUTPUT_ON_DEVICE):
+        """Device-resident input (raw device pointers, e.g. torch tensor .data_ptr())."""
+        out = C.c_void_p()
+        rc = self.L.etlg_decode(self.h, C.c_void_p(buf_ptr), nbytes, C.c_void_p(offs_ptr), nframes,
+                                flags | abi.F_INPUT_ON_DEVICE, C.byref(out))
+        if not out:
+            raise self.last_error()
+        return Batch(self, out, rc)
+
+    # ---- measurement
+    def profile(self, enable=True):
+        return self.L.etlg_ctx_profile(self.h, 1 if enable else 0)
+
+    def profile_read(self):
+        arr = (abi.KernelStat * 16)()
+        n = C.c_uint32()
+        self.L.etlg_ctx_profile_read(self.h, arr, 16, C.byref(n))
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}

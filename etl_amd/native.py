@@ -1,0 +1,73 @@
+"""ctypes binding of libetl_gfx950.so — the C ABI declared in include/etlg.h.
+
+Loading fails loudly when the library has not been built (run
+`python -m etl_amd.build` or `__graft_entry__.build()`); there is no Python or
+CPU fallback for the decode path.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libetl_gfx950.so")
+
+# every symbol include/etlg.h declares
+EXPORTS = [
+    "etlg_abi_version", "etlg_err_table", "etlg_type_class_of_oid", "etlg_array_elem_class", "etlg_slot_bytes",
+    "etlg_ctx_create", "etlg_ctx_destroy", "etlg_ctx_set_stream", "etlg_ctx_set_worker", "etlg_schema_put",
+    "etlg_table_state", "etlg_table_ready", "etlg_ctx_reset_stream_state", "etlg_decode", "etlg_last_error",
+    "etlg_batch_view_get", "etlg_batch_sync", "etlg_batch_download", "etlg_batch_header_to_device", "etlg_batch_free", "etlg_ctx_slots", "etlg_ctx_profile",
+    "etlg_ctx_profile_read",
+]
+
+_LIB = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not built — run `python -m etl_amd.build` (needs hipcc); "
+            "the decode path has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.etlg_abi_version.restype = C.c_uint32
+    L.etlg_err_table.argtypes = [C.c_int32]
+    L.etlg_err_table.restype = C.POINTER(abi.ErrDesc)
+    L.etlg_type_class_of_oid.argtypes = [C.c_uint32]
+    L.etlg_array_elem_class.argtypes = [C.c_uint32]
+    L.etlg_slot_bytes.argtypes = [C.c_int32]
+    L.etlg_slot_bytes.restype = C.c_uint32
+    L.etlg_ctx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+    L.etlg_ctx_destroy.argtypes = [C.c_void_p]
+    L.etlg_ctx_destroy.restype = None
+    L.etlg_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.etlg_ctx_set_worker.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64]
+    L.etlg_schema_put.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32,
+                                  C.POINTER(abi.Col)]
+    L.etlg_table_state.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64]
+    L.etlg_table_ready.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.etlg_ctx_reset_stream_state.argtypes = [C.c_void_p]
+    L.etlg_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32,
+                              C.POINTER(C.c_void_p)]
+    L.etlg_last_error.argtypes = [C.c_void_p]
+    L.etlg_last_error.restype = C.POINTER(abi.Error)
+    L.etlg_batch_view_get.argtypes = [C.c_void_p, C.POINTER(abi.BatchView)]
+    L.etlg_batch_sync.argtypes = [C.c_void_p, C.c_void_p]
+    L.etlg_batch_download.argtypes = [C.c_void_p, C.c_void_p]
+    L.etlg_batch_header_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.etlg_batch_free.argtypes = [C.c_void_p]
+    L.etlg_batch_free.restype = None
+    L.etlg_ctx_slots.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(abi.SlotDesc))]
+    L.etlg_ctx_profile.argtypes = [C.c_void_p, C.c_int32]
+    L.etlg_ctx_profile_read.argtypes = [C.c_void_p, C.POINTER(abi.KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]
+    if L.etlg_abi_version() != abi.ABI_VERSION:
+        raise RuntimeError("libetl_gfx950.so ABI version mismatch")
+    _LIB = L
+    return L

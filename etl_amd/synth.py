@@ -1,0 +1,172 @@
+"""Synthetic WAL workloads of SURVEY.md §8(d): ctypes front-end of
+libetlg_synth.so (etl_amd/csrc/synth.cpp) plus the per-config table specs.
+
+A workload is (tables, generator config). `register(target)` installs the
+stored schemas / table states on anything exposing the etlg control-plane
+calls (`schema_put`, `table_state`, `table_ready`) — an etl_amd.Decoder or the
+test-only oracle wrapper — so both sides are primed identically.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+CK_INT4_10D, CK_INT8, CK_INT4, CK_INT2, CK_BOOL, CK_NUMERIC, CK_TEXT, CK_TIMESTAMPTZ, CK_UUID, CK_INT8_SEQ = range(10)
+
+
+class _Col(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("type_oid", C.c_uint32), ("nullable", C.c_uint8), ("pk", C.c_uint8),
+                ("null_pct", C.c_uint8), ("utf8_pct", C.c_uint8), ("min_len", C.c_uint32), ("max_len", C.c_uint32),
+                ("name", C.c_char * 32)]
+
+
+class _Table(C.Structure):
+    _fields_ = [("rel_id", C.c_uint32), ("ncols", C.c_uint32), ("cols", _Col * 32), ("name", C.c_char * 32)]
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("start_lsn", C.c_uint64), ("ntables", C.c_uint32), ("tables", _Table * 4),
+                ("rows_per_txn", C.c_uint32), ("pct_insert", C.c_uint32), ("pct_update", C.c_uint32),
+                ("pct_delete", C.c_uint32), ("upd_pct_key", C.c_uint32), ("upd_pct_toast", C.c_uint32),
+                ("emit_relations", C.c_uint32), ("emit_origin", C.c_uint32), ("ddl_every_txns", C.c_uint32),
+                ("type_msg_pct", C.c_uint32), ("keepalive_every", C.c_uint32)]
+
+
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libetlg_synth.so")
+    src = os.path.join(_HERE, "csrc", "synth.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", so, src])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.synth_cfg_size.restype = C.c_size_t
+        L.synth_state_size.restype = C.c_size_t
+        assert L.synth_cfg_size() == C.sizeof(_Cfg), (L.synth_cfg_size(), C.sizeof(_Cfg))
+        L.synth_init.argtypes = [C.POINTER(_Cfg), C.c_void_p]
+        L.synth_fill.argtypes = [C.POINTER(_Cfg), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                 C.c_uint64, C.POINTER(C.c_size_t)]
+        L.synth_fill.restype = C.c_size_t
+        _LIB = L
+    return _LIB
+
+
+# Postgres OIDs
+INT8, INT2, INT4, TEXT, BOOL, NUMERIC, TIMESTAMPTZ, UUID = 20, 21, 23, 25, 16, 1700, 1184, 2950
+
+
+def col(name, kind, oid, nullable=False, pk=False, null_pct=0, utf8_pct=0, min_len=0, max_len=0):
+    return dict(name=name, kind=kind, oid=oid, nullable=nullable, pk=pk, null_pct=null_pct, utf8_pct=utf8_pct,
+                min_len=min_len, max_len=max_len)
+
+
+def table_fixed(rel_id=16384, name="bench_fixed"):
+    """cfg 1/2: bench_fixed(c0..c4 int4 not null), PK c0; every value exactly 10 digits."""
+    return dict(rel_id=rel_id, name=name,
+                cols=[col(f"c{i}", CK_INT4_10D, INT4, pk=(i == 0)) for i in range(5)])
+
+
+def table_mixed(rel_id=16385, name="bench_mixed"):
+    """cfg 3: 12 columns with TEXT / NUMERIC / timestamptz / uuid."""
+    return dict(rel_id=rel_id, name=name, cols=[
+        col("id", CK_INT8_SEQ, INT8, pk=True), col("a", CK_INT4, INT4), col("b", CK_INT4, INT4),
+        col("c", CK_INT2, INT2), col("f", CK_BOOL, BOOL), col("n1", CK_NUMERIC, NUMERIC), col("n2", CK_NUMERIC, NUMERIC),
+        col("t1", CK_TEXT, TEXT, min_len=8, max_len=64, utf8_pct=10),
+        col("t2", CK_TEXT, TEXT, min_len=0, max_len=256, utf8_pct=10),
+        col("t3", CK_TEXT, TEXT, nullable=True, null_pct=30, min_len=1, max_len=128, utf8_pct=10),
+        col("ts", CK_TIMESTAMPTZ, TIMESTAMPTZ), col("u", CK_UUID, UUID)])
+
+
+def table_w8(rel_id=16386, name="bench_w8"):
+    return dict(rel_id=rel_id, name=name, cols=[
+        col("id", CK_INT8_SEQ, INT8, pk=True), col("a", CK_INT4, INT4), col("f", CK_BOOL, BOOL),
+        col("n", CK_NUMERIC, NUMERIC), col("t", CK_TEXT, TEXT, min_len=4, max_len=48, utf8_pct=5),
+        col("tn", CK_TEXT, TEXT, nullable=True, null_pct=25, min_len=1, max_len=32),
+        col("ts", CK_TIMESTAMPTZ, TIMESTAMPTZ), col("u", CK_UUID, UUID)])
+
+
+class Workload:
+    def __init__(self, tables, seed, rows_per_txn=1000, mix=(100, 0, 0), upd_key=0, upd_toast=0, emit_relations=0,
+                 emit_origin=0, ddl_every=0, type_msg_pct=0, keepalive_every=0, start_lsn=0x1000000, name="custom"):
+        self.name = name
+        self.tables = tables
+        c = _Cfg()
+        c.seed, c.start_lsn, c.ntables = seed, start_lsn, len(tables)
+        for ti, t in enumerate(tables):
+            ct = c.tables[ti]
+            ct.rel_id, ct.ncols, ct.name = t["rel_id"], len(t["cols"]), t["name"].encode()
+            for ci, cc in enumerate(t["cols"]):
+                k = ct.cols[ci]
+                k.kind, k.type_oid, k.nullable, k.pk = cc["kind"], cc["oid"], int(cc["nullable"]), int(cc["pk"])
+                k.null_pct, k.utf8_pct, k.min_len, k.max_len = cc["null_pct"], cc["utf8_pct"], cc["min_len"], cc["max_len"]
+                k.name = cc["name"].encode()
+        c.rows_per_txn = rows_per_txn
+        c.pct_insert, c.pct_update, c.pct_delete = mix
+        c.upd_pct_key, c.upd_pct_toast = upd_key, upd_toast
+        c.emit_relations, c.emit_origin, c.ddl_every_txns = emit_relations, emit_origin, ddl_every
+        c.type_msg_pct, c.keepalive_every = type_msg_pct, keepalive_every
+        self.cfg = c
+        self.state = C.create_string_buffer(_lib().synth_state_size())
+        _lib().synth_init(C.byref(c), self.state)
+
+    def reset(self):
+        _lib().synth_init(C.byref(self.cfg), self.state)
+
+    def fill(self, cap_bytes, max_txns=1 << 62, max_frames=None):
+        """Next batch: whole transactions, at most cap_bytes. Returns (np.uint8 buf, np.uint32 offsets)."""
+        if max_frames is None:
+            max_frames = cap_bytes // 24 + 64
+        buf = np.empty(cap_bytes, dtype=np.uint8)
+        offs = np.empty(max_frames + 1, dtype=np.uint32)
+        nfr = C.c_size_t()
+        n = _lib().synth_fill(C.byref(self.cfg), self.state, buf.ctypes.data, cap_bytes, offs.ctypes.data,
+                              max_frames, max_txns, C.byref(nfr))
+        return buf[:n], offs[:nfr.value + 1].copy()
+
+    def schema_cols(self, t):
+        return [(c["name"], c["oid"], c["nullable"], c["pk"]) for c in t["cols"]]
+
+    def register(self, target, ready=True, snapshot_lsn=0):
+        """Install stored schemas + Ready table state (+ Ready cache entry unless the
+        stream carries its own Relation messages)."""
+        for t in self.tables:
+            target.schema_put(t["rel_id"], snapshot_lsn, self.schema_cols(t), name=t["name"])
+            target.table_state(t["rel_id"], abi.TS_READY)
+            if ready:
+                n = len(t["cols"])
+                target.table_ready(t["rel_id"], snapshot_lsn, [1] * n, [1 if c["pk"] else 0 for c in t["cols"]])
+
+
+def cfg1(seed=0xE710001):
+    """1M-row INSERT-only stream, 1000 txns x 1000 rows (CPU-runnable reference case)."""
+    return Workload([table_fixed()], seed, rows_per_txn=1000, emit_relations=1, name="cfg1_insert_only_1M")
+
+
+def cfg2(seed=0xE710002):
+    """Fixed-width 5 x int4 INSERT tuples, 113-byte frames (coalesced baseline)."""
+    return Workload([table_fixed()], seed, rows_per_txn=1000, name="cfg2_fixed_5xint4")
+
+
+def cfg3(seed=0xE710003):
+    """Mixed I/U/D 60/30/10 on the 12-column TEXT/NUMERIC schema."""
+    return Workload([table_mixed()], seed, rows_per_txn=500, mix=(60, 30, 10), upd_key=10, upd_toast=5,
+                    name="cfg3_mixed_12col")
+
+
+def cfg5(seed=0xE710005):
+    """3 tables round-robin, DDL message -> Relation every 200 txns, Type/Origin noise."""
+    return Workload([table_fixed(), table_w8(), table_mixed()], seed, rows_per_txn=50, mix=(60, 30, 10), upd_key=10,
+                    upd_toast=5, emit_relations=1, emit_origin=1, ddl_every=200, type_msg_pct=10, keepalive_every=997,
+                    name="cfg5_ddl_3tables")

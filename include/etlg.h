@@ -384,6 +384,17 @@ typedef struct etlg_batch_view {
 int32_t etlg_batch_view_get(const etlg_batch* batch, etlg_batch_view* out);
 /* Wait for an ETLG_F_ASYNC batch and refresh its counts/error. */
 int32_t etlg_batch_sync(etlg_ctx* ctx, etlg_batch* batch);
+/* Enqueue (on the context's stream, no synchronisation) a device-to-device copy of
+ * the batch's 64-byte result header into `dst_device_8xu64`:
+ *   {first_err key (~0 = none), n_events, fixed_bytes, heap_bytes,
+ *    payload insert/update/delete bytes, n_frames}
+ * Must be called right after the etlg_decode that produced `batch`. This is the
+ * per-shard record the multi-GPU all-gather exchanges (one fixed-size header per
+ * rank; rank order == LSN order). */
+int32_t etlg_batch_header_to_device(etlg_ctx* ctx, etlg_batch* batch, void* dst_device_8xu64);
+/* Copy a device-resident (ETLG_F_OUTPUT_ON_DEVICE) batch into host memory;
+ * afterwards the view holds host pointers. */
+int32_t etlg_batch_download(etlg_ctx* ctx, etlg_batch* batch);
 void etlg_batch_free(etlg_batch* batch);
 
 /* Schema slots known to the context (also reachable from every batch view). */
