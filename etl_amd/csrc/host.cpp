@@ -682,17 +682,32 @@ int32_t etlg_type_class_of_oid(uint32_t oid) { return type_class(oid); }
 int32_t etlg_array_elem_class(uint32_t oid) { for (const auto& a : kArrayOids) if (a.oid == oid) return a.elem; return ETLG_TC_STRING; }
 uint32_t etlg_slot_bytes(int32_t cls) { return slot_bytes(cls); }
 
+static char g_create_err[256] = "";
+const char* etlg_create_error(void) { return g_create_err; }
+
 int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   if (!out) return ETLG_InvalidArgument;
   *out = nullptr;
+  g_create_err[0] = 0;
+  auto fail = [&](const char* what, hipError_t e) {
+    snprintf(g_create_err, sizeof g_create_err, "%s: %s", what, hipGetErrorString(e));
+    return (int32_t)ETLG_DeviceError;
+  };
+  hipError_t e = hipInit(0);
+  if (e != hipSuccess) return fail("hipInit", e);
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev) return ETLG_DeviceError;
-  if (hipSetDevice(hip_device) != hipSuccess) return ETLG_DeviceError;
+  e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess) return fail("hipGetDeviceCount", e);
+  if (ndev <= 0 || hip_device < 0 || hip_device >= ndev) { snprintf(g_create_err, sizeof g_create_err, "device %d of %d not available", hip_device, ndev); return ETLG_DeviceError; }
+  e = hipSetDevice(hip_device);
+  if (e != hipSuccess) return fail("hipSetDevice", e);
   auto* c = new etlg_ctx();
   c->device = hip_device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ETLG_DeviceError; }
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail("hipStreamCreateWithFlags", e); }
   c->own_stream = true;
-  if (hipHostMalloc((void**)&c->h_res, sizeof(DevResult), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return ETLG_DeviceError; }
+  e = hipHostMalloc((void**)&c->h_res, sizeof(DevResult), hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail("hipHostMalloc", e); }
   clear_error(c);
   *out = c;
   return ETLG_OK;

@@ -504,7 +504,9 @@ DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o) {
   if (!(n && (is_digit(s[0]) || s[0] == '.'))) {
     // parse_special_value; `rest.trim_end()` is a no-op after the outer trim
     if (ieq(s, n, "nan", 3)) { if (explicit_sign) return false; o.kind = ETLG_NUM_NAN; return true; }
-    if (ieq(s, n, "infinity", 8) || ieq(s, n, "inf", 3)) { o.kind = o.sign ? ETLG_NUM_NINF : ETLG_NUM_PINF; return true; }
+    if (ieq(s, n, "infinity", 8) || ieq(s, n, "inf", 3)) {  // the sign lives in the variant, not in a field
+      o.kind = o.sign ? ETLG_NUM_NINF : ETLG_NUM_PINF; o.sign = 0; return true;
+    }
     return false;
   }
   // parse_numeric_value

@@ -78,7 +78,8 @@ class Decoder:
         h = C.c_void_p()
         rc = self.L.etlg_ctx_create(device, C.byref(h))
         if rc != abi.OK:
-            raise RuntimeError(f"etlg_ctx_create failed ({abi.KIND_NAMES.get(rc, rc)}): an MI355X (gfx950) device is required")
+            why = (self.L.etlg_create_error() or b"").decode()
+            raise RuntimeError(f"etlg_ctx_create failed ({abi.KIND_NAMES.get(rc, rc)}: {why}): an MI355X (gfx950) device is required")
         self.h = h
         if stream is not None:
             self.set_stream(stream)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libetl_gfx950.so")
 # every symbol include/etlg.h declares
 EXPORTS = [
     "etlg_abi_version", "etlg_err_table", "etlg_type_class_of_oid", "etlg_array_elem_class", "etlg_slot_bytes",
-    "etlg_ctx_create", "etlg_ctx_destroy", "etlg_ctx_set_stream", "etlg_ctx_set_worker", "etlg_schema_put",
+    "etlg_ctx_create", "etlg_create_error", "etlg_ctx_destroy", "etlg_ctx_set_stream", "etlg_ctx_set_worker", "etlg_schema_put",
     "etlg_table_state", "etlg_table_ready", "etlg_ctx_reset_stream_state", "etlg_decode", "etlg_last_error",
     "etlg_batch_view_get", "etlg_batch_sync", "etlg_batch_download", "etlg_batch_header_to_device", "etlg_batch_free", "etlg_ctx_slots", "etlg_ctx_profile",
     "etlg_ctx_profile_read",
@@ -45,6 +45,7 @@ def lib():
     L.etlg_slot_bytes.argtypes = [C.c_int32]
     L.etlg_slot_bytes.restype = C.c_uint32
     L.etlg_ctx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+    L.etlg_create_error.restype = C.c_char_p
     L.etlg_ctx_destroy.argtypes = [C.c_void_p]
     L.etlg_ctx_destroy.restype = None
     L.etlg_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]

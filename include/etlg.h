@@ -210,6 +210,8 @@ uint32_t etlg_abi_version(void);
 /* hip_device >= 0 selects the GPU. There is no CPU backend: creation fails
  * with ETLG_DeviceError when no gfx950 device is available. */
 int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out);
+/* Human-readable reason of the last failed etlg_ctx_create on this thread's process. */
+const char* etlg_create_error(void);
 void etlg_ctx_destroy(etlg_ctx* ctx);
 
 /* Run all device work of this context on an existing hipStream_t
