@@ -36,6 +36,14 @@ def lib():
         raise NativeLibraryMissing(
             f"{LIB_PATH} not built — run `python -m etl_amd.build` (needs hipcc); "
             "the decode path has no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64. If torch is
+    # imported AFTER this library pulled in /opt/rocm's copy, the process ends up with
+    # two runtimes and the second one finds no device. Importing torch first makes the
+    # dynamic linker bind libetl_gfx950.so to the copy torch already loaded (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.etlg_abi_version.restype = C.c_uint32
     L.etlg_err_table.argtypes = [C.c_int32]
