@@ -66,6 +66,20 @@ struct DevResult {
   uint64_t n_frames;             // frames consumed
   uint32_t out_in_txn, n_ctrl;
   uint64_t out_final_lsn, out_next_ord;
+  uint32_t fused_fail, _pad;     // a look-back spin gave up (never expected; forces the multi-pass path)
+};
+
+// Side arguments of the fused single-pass kernel (fused.hip).
+struct FusedParams {
+  unsigned long long* d_txn;   // [ntiles]  st:2 | seg:30 | mark:32
+  unsigned long long* d_outa;  // [ntiles]  st:2 | events:30 | heap dwords:32
+  unsigned long long* d_outb;  // [ntiles]  st:2 | fixed dwords:62
+  uint32_t* ticket;
+  uint32_t ntiles;
+  uint32_t lds_bytes;          // staging capacity per tile (dynamic LDS)
+  uint32_t in_aligned;         // input pointer is 16-byte aligned
+  uint32_t blk;                // frames per tile (256 or 64)
+  uint32_t dbg, _pad;          // ablation bits (profiling only): 1 no LDS staging, 2 skip writes, 4 skip look-back
 };
 
 constexpr unsigned long long kNoErr = ~0ull;

@@ -30,6 +30,10 @@ using namespace etlg;
 
 extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
 extern "C" const char* etlg_k_name(int which);
+extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
+extern "C" int etlg_k_fused_set_lds(void);
+
+constexpr int kFused = 7;  // profiling slot of the fused kernel
 
 namespace {
 
@@ -181,9 +185,16 @@ struct etlg_ctx {
   // carried transaction state
   bool in_txn = false; uint64_t final_lsn = 0, next_ord = 0;
   // device scratch (grow-only)
-  DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols;
+  DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
+  FusedParams fq{};
+  std::vector<DevTable> last_tables;   // what d_tables / d_epochs currently hold
+  std::vector<DevEpoch> last_epochs;
+  bool side_valid = false;
+  bool force_multipass = false;  // ETLG_FORCE_MULTIPASS=1 (tests exercise both paths)
+  uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
-  DevResult* h_res = nullptr;  // pinned
+  DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
+  std::vector<DevResult*> res_pool;         // pinned result blocks (one per in-flight batch)
   // error
   etlg_error err{};
   std::string err_detail;
@@ -203,6 +214,9 @@ struct etlg_batch {
   std::vector<uint64_t> start, commit, ord, body;
   std::vector<etlg_slot_desc> slot_descs;
   bool pending = false;  // ASYNC: counts not read back yet
+  DevResult* h_res = nullptr;  // pinned, from the context's pool
+  bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
+  DecParams params{};
   // what sync needs to finish the batch
   int32_t host_err_code = 0; int64_t host_err_frame = -1; uint32_t host_err_rank = 0;
   std::vector<CtrlFrame> ctrl;     // processed control frames (for rollback replay)
@@ -632,17 +646,31 @@ hipError_t sync_slots(etlg_ctx* c) {
   return e;
 }
 
+void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
+  if (which == kFused) etlg_k_launch_fused((int)c->fq.blk, &p, &c->fq, c->stream);
+  else etlg_k_launch(which, &p, c->stream);
+}
+
 void launch(etlg_ctx* c, int which, const DecParams& p) {
   if (c->prof) {
     ProfRec r; r.which = which;
     (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, c->stream);
-    etlg_k_launch(which, &p, c->stream);
+    launch_raw(c, which, p);
     (void)hipEventRecord(r.b, c->stream);
     c->prof_recs.push_back(r);
   } else {
-    etlg_k_launch(which, &p, c->stream);
+    launch_raw(c, which, p);
   }
+}
+
+// The multi-pass pipeline (also the exact first-error path).
+void launch_multipass(etlg_ctx* c, const DecParams& p, bool classify_done) {
+  if (!classify_done) { if (p.nframes) launch(c, 0, p); launch(c, 1, p); }
+  if (p.nframes) launch(c, 3, p);
+  launch(c, 4, p);
+  if (p.nframes) launch(c, 5, p);
+  launch(c, 6, p);
 }
 
 OutSet* take_outset(etlg_ctx* c) {
@@ -706,8 +734,12 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail("hipStreamCreateWithFlags", e); }
   c->own_stream = true;
-  e = hipHostMalloc((void**)&c->h_res, sizeof(DevResult), hipHostMallocDefault);
+  e = hipHostMalloc((void**)&c->h_init, sizeof(DevResult), hipHostMallocDefault);
   if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail("hipHostMalloc", e); }
+  { DevResult init{}; init.first_err = kNoErr; *c->h_init = init; }
+  (void)etlg_k_fused_set_lds();
+  { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
+  { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   clear_error(c);
   *out = c;
   return ETLG_OK;
@@ -717,10 +749,11 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols}) b->release();
+  for (DevBuf* b : {&c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_init) (void)hipHostFree(c->h_init);
+  for (DevResult* r : c->res_pool) (void)hipHostFree(r);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -804,7 +837,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < 7 && k < cap; i++) { out[k].name = etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < 8 && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }
@@ -871,26 +904,26 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   p.blk_cnt = (uint32_t*)c->d_blk32.p; p.blk_last = p.blk_cnt + (nblocks + 1); p.blk_ev = p.blk_last + (nblocks + 1);
   p.blk_fixed = (uint64_t*)c->d_blk64.p; p.blk_heap = p.blk_fixed + (nblocks + 1); p.blk_payload = p.blk_heap + (nblocks + 1);
   p.res = (DevResult*)c->d_res.p;
-  DevResult init{}; init.first_err = kNoErr;
-  *c->h_res = init;
-  HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_res, sizeof(DevResult), hipMemcpyHostToDevice, s));
+  if (c->res_pool.empty()) { DevResult* r = nullptr; HIPCHK(c, hipHostMalloc((void**)&r, sizeof(DevResult), hipHostMallocDefault)); c->res_pool.push_back(r); }
+  b->h_res = c->res_pool.back(); c->res_pool.pop_back();
+  HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
 
   std::vector<CtrlFrame> ctrl;
   std::vector<EpochRec> eps;
   HostErr herr{};
   int64_t herr_frame = -1;
-  b->snapshot = c->cs; b->have_snapshot = true;
+  if (!no_ctrl) { b->snapshot = c->cs; b->have_snapshot = true; }
   const size_t slots_before = c->slots.size();
 
-  if (nf) launch(c, 0, p);
-  launch(c, 1, p);
   if (!no_ctrl && nf) {
+    launch(c, 0, p);
+    launch(c, 1, p);
     HIPCHK(c, c->d_ctrl.ensure((size_t)nf * sizeof(CtrlFrame) + 64));
     p.ctrl = (CtrlFrame*)c->d_ctrl.p; p.ctrl_cap = nf;
     launch(c, 2, p);
-    HIPCHK(c, hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    const uint32_t nctrl = c->h_res->n_ctrl;
+    const uint32_t nctrl = b->h_res->n_ctrl;
     if (nctrl) {
       ctrl.resize(nctrl);
       HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
@@ -927,7 +960,8 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
       return it->second;
     };
     for (auto& kv : c->states) { DevTable& t = get(kv.first); t.state_kind = (uint32_t)kv.second.kind; t.state_lsn = kv.second.lsn; }
-    for (auto& kv : b->snapshot.cache) { DevTable& t = get(kv.first); t.init_kind = kv.second.kind; t.init_slot = kv.second.slot; }
+    const ControlState& cs0 = b->have_snapshot ? b->snapshot : c->cs;  // cache as of batch start
+    for (auto& kv : cs0.cache) { DevTable& t = get(kv.first); t.init_kind = kv.second.kind; t.init_slot = kv.second.slot; }
     for (auto& e : eps) get(e.table_id);
     std::vector<DevTable> tv;
     std::vector<DevEpoch> ev;
@@ -938,9 +972,17 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
       t.ep_end = (uint32_t)ev.size();
       tv.push_back(t);
     }
-    HIPCHK(c, upload(s, c->d_tables, tv.data(), tv.size() * sizeof(DevTable)));
-    HIPCHK(c, upload(s, c->d_epochs, ev.data(), ev.size() * sizeof(DevEpoch)));
-    HIPCHK(c, hipStreamSynchronize(s));  // staging vectors die here
+    const bool same = c->side_valid && tv.size() == c->last_tables.size() && ev.size() == c->last_epochs.size() &&
+                      (tv.empty() || !memcmp(tv.data(), c->last_tables.data(), tv.size() * sizeof(DevTable))) &&
+                      (ev.empty() || !memcmp(ev.data(), c->last_epochs.data(), ev.size() * sizeof(DevEpoch)));
+    if (!same) {  // rare: table states or the cache timeline changed; earlier batches may still read the old copy
+      HIPCHK(c, hipStreamSynchronize(s));
+      HIPCHK(c, c->d_tables.ensure(tv.size() * sizeof(DevTable) + 16));
+      HIPCHK(c, c->d_epochs.ensure(ev.size() * sizeof(DevEpoch) + 16));
+      if (!tv.empty()) HIPCHK(c, hipMemcpy(c->d_tables.p, tv.data(), tv.size() * sizeof(DevTable), hipMemcpyHostToDevice));
+      if (!ev.empty()) HIPCHK(c, hipMemcpy(c->d_epochs.p, ev.data(), ev.size() * sizeof(DevEpoch), hipMemcpyHostToDevice));
+      c->last_tables = tv; c->last_epochs = ev; c->side_valid = true;
+    }
     p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)tv.size();
   }
   HIPCHK(c, sync_slots(c));
@@ -962,11 +1004,30 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   p.ev_start = (uint64_t*)os->start.p; p.ev_commit = (uint64_t*)os->commit.p; p.ev_ord = (uint64_t*)os->ord.p; p.ev_body = (uint64_t*)os->body.p;
   p.fixed = (uint8_t*)os->fixed.p; p.heap = (uint8_t*)os->heap.p; p.fixed_cap = fixed_cap; p.heap_cap = heap_cap;
 
-  if (nf) launch(c, 3, p);
-  launch(c, 4, p);
-  if (nf) launch(c, 5, p);
-  launch(c, 6, p);
-  HIPCHK(c, hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  const bool classify_done = !no_ctrl && nf != 0;  // k_classify / k_scan_txn already ran for the control list
+  b->params = p;
+  if (nf && !herr.code && !c->force_multipass) {
+    // ---- fast path: fused single-pass kernel (fused.hip)
+    const uint64_t avg = (len + nf - 1) / nf;
+    FusedParams& q = c->fq;
+    q.blk = avg <= 192 ? 256u : 64u;
+    uint64_t cap = q.blk == 256 ? (uint64_t)q.blk * avg * 9 / 8 + 1024 : (uint64_t)q.blk * avg * 5 / 4 + 2048;
+    cap = std::min<uint64_t>((cap + 255) & ~255ull, 150 * 1024);
+    q.lds_bytes = (uint32_t)cap;
+    q.ntiles = (nf + q.blk - 1) / q.blk;
+    q.in_aligned = ((uintptr_t)p.in & 15) == 0;
+    q.dbg = c->fused_dbg;
+    const size_t dbytes = (size_t)q.ntiles * 8 * 3 + 64;
+    HIPCHK(c, c->d_desc.ensure(dbytes));
+    HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, dbytes, s));
+    q.d_txn = (unsigned long long*)c->d_desc.p; q.d_outa = q.d_txn + q.ntiles; q.d_outb = q.d_outa + q.ntiles;
+    q.ticket = (uint32_t*)(q.d_outb + q.ntiles);
+    launch(c, kFused, p);
+    b->used_fused = true;
+  } else {
+    launch_multipass(c, p, classify_done);
+  }
+  HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
 
   (void)slots_before;
   guard.release();
@@ -1003,10 +1064,9 @@ int32_t etlg_batch_view_get(const etlg_batch* b, etlg_batch_view* out) {
 
 void etlg_batch_free(etlg_batch* b) {
   if (!b) return;
-  if (b->dev) {
-    if (b->pending) (void)hipStreamSynchronize(b->ctx->stream);
-    b->ctx->out_pool.push_back(b->dev);
-  }
+  if (b->pending || b->h_res) (void)hipStreamSynchronize(b->ctx->stream);
+  if (b->dev) b->ctx->out_pool.push_back(b->dev);
+  if (b->h_res) b->ctx->res_pool.push_back(b->h_res);
   delete b;
 }
 
@@ -1051,7 +1111,17 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
   (void)host_in; (void)host_offs;
   hipStream_t s = c->stream;
   HIPCHK(c, hipStreamSynchronize(s));
-  const DevResult r = *c->h_res;
+  if (b->used_fused && (b->h_res->first_err != kNoErr || b->h_res->fused_fail)) {
+    // cold path: recompute with the multi-pass kernels, which know the exact cut at the failing frame
+    HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    launch_multipass(c, b->params, false);
+    HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    b->used_fused = false;
+  }
+  const DevResult r = *b->h_res;
+  c->res_pool.push_back(b->h_res);
+  b->h_res = nullptr;
   // ---- first error: device (frame, rank) vs host control plane (frame, rank)
   int32_t code = 0; int64_t frame = -1; uint32_t rank = 0xFF;
   if (r.first_err != kNoErr) { frame = (int64_t)(r.first_err >> 16); rank = (uint32_t)((r.first_err >> 8) & 0xFF); code = (int32_t)(r.first_err & 0xFF); }

@@ -22,128 +22,9 @@
 //
 // Integer / byte work only: no MFMA. All inter-workgroup data flows through
 // kernel boundaries (no in-kernel hand-offs), so there are no spin waits.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "../../include/etlg.h"
-#include "dev_types.h"
+#include "codec.hip.h"
 
 namespace etlg {
-
-typedef uint8_t u8;
-
-#define DEV __device__ __forceinline__
-
-// ------------------------------------------------------------- byte helpers
-DEV uint32_t ld_be32(const u8* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return __builtin_bswap32(v); }
-DEV uint64_t ld_be64(const u8* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return __builtin_bswap64(v); }
-DEV uint32_t ld_be16(const u8* p) { return ((uint32_t)p[0] << 8) | p[1]; }
-DEV uint32_t pad4(uint32_t n) { return (n + 3u) & ~3u; }
-DEV bool is_digit(uint32_t c) { return c - '0' < 10u; }
-DEV uint32_t lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
-
-DEV void st64(uint32_t* w, uint64_t v) { w[0] = (uint32_t)v; w[1] = (uint32_t)(v >> 32); }
-
-DEV void record_error(const DecParams& p, uint32_t frame, uint32_t rank, uint32_t code) {
-  unsigned long long key = ((unsigned long long)frame << 16) | ((unsigned long long)rank << 8) | code;
-  atomicMin(&p.res->first_err, key);
-}
-
-// ------------------------------------------------------------- block scans
-DEV uint32_t seg_combine(uint32_t a, uint32_t b) {  // bit31 = "a Begin was seen", low bits = count since
-  return (b & 0x80000000u) ? b : ((a & 0x80000000u) | ((a + b) & 0x7FFFFFFFu));
-}
-
-template <int OP>  // 0 sum, 1 max, 2 segmented count
-DEV uint32_t op_apply(uint32_t a, uint32_t b) {
-  if (OP == 0) return a + b;
-  if (OP == 1) return a > b ? a : b;
-  return seg_combine(a, b);
-}
-
-// Inclusive scan across the 256-lane workgroup. `lds` = 4 words of scratch.
-// Returns the inclusive value; *total = workgroup aggregate.
-template <int OP>
-DEV uint32_t block_scan_incl(uint32_t v, uint32_t* lds, uint32_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= d) v = op_apply<OP>(t, v);
-  }
-  if (lane == 63) lds[wave] = v;
-  __syncthreads();
-  uint32_t pre = 0;
-  bool have = false;
-  for (int w = 0; w < wave; w++) { pre = have ? op_apply<OP>(pre, lds[w]) : lds[w]; have = true; }
-  if (have) v = op_apply<OP>(pre, v);
-  if (total) {
-    uint32_t t = lds[0];
-    for (int w = 1; w < kBlock / 64; w++) t = op_apply<OP>(t, lds[w]);
-    *total = t;
-  }
-  __syncthreads();
-  return v;
-}
-
-DEV uint64_t block_sum64(uint64_t v, uint64_t* lds) {  // returns the workgroup total
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  if (lane == 0) lds[wave] = v;
-  __syncthreads();
-  uint64_t t = 0;
-  for (int w = 0; w < kBlock / 64; w++) t += lds[w];
-  __syncthreads();
-  return t;
-}
-
-// Exclusive 64-bit sum scan over the workgroup; *total = aggregate.
-DEV uint64_t block_scan_excl64(uint64_t v, uint64_t* lds, uint64_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint64_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint64_t t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
-  }
-  if (lane == 63) lds[wave] = inc;
-  __syncthreads();
-  uint64_t pre = 0, tot = 0;
-  for (int w = 0; w < kBlock / 64; w++) { if (w < wave) pre += lds[w]; tot += lds[w]; }
-  __syncthreads();
-  if (total) *total = tot;
-  return pre + inc - v;
-}
-
-// --------------------------------------------------------- frame geometry
-// CopyData := 'd' Int32-BE(len incl. itself) payload
-// payload  := 'w' u64 wal_start u64 wal_end i64 ts <pgoutput msg> | 'k' u64 i64 u8
-constexpr uint32_t kHdr = 5;        // 'd' + length
-constexpr uint32_t kTagOff = 30;    // offset of the pgoutput tag inside the frame
-constexpr uint32_t kBodyOff = 31;   // first byte after the tag
-
-DEV bool consumes_ordinal(uint32_t tag) {  // apply.rs:2284-2292, 2339, 2377, 2457, 2501, 2545, 2587
-  return tag == 'B' || tag == 'C' || tag == 'R' || tag == 'I' || tag == 'U' || tag == 'D' || tag == 'T';
-}
-
-DEV uint32_t classify_frame(const DecParams& p, uint32_t f) {
-  const uint32_t o0 = p.offs[f], o1 = p.offs[f + 1];
-  if (o1 <= o0 || o1 > p.in_len) return FT_BAD;
-  const uint32_t flen = o1 - o0;
-  const u8* fr = p.in + o0;
-  if (flen < kHdr + 1 || fr[0] != 'd' || ld_be32(fr + 1) + 1u != flen) return FT_BAD;
-  const uint32_t outer = fr[5];
-  if (outer == 'k') return flen >= kHdr + 18 ? 'k' : FT_BAD;
-  if (outer != 'w' || flen < kBodyOff) return FT_BAD;
-  const uint32_t tag = fr[kTagOff];
-  switch (tag) {
-    case 'B': return flen >= kBodyOff + 20 ? tag : FT_BAD;  // u64 final_lsn, i64 ts, u32 xid
-    case 'C': return flen >= kBodyOff + 25 ? tag : FT_BAD;  // i8 flags, u64, u64, i64
-    case 'O': case 'Y': case 'R': case 'M': case 'I': case 'U': case 'D': case 'T': return tag;
-    default: return FT_BAD;
-  }
-}
 
 // ------------------------------------------------------------ k_classify
 __global__ __launch_bounds__(kBlock) void k_classify(DecParams p) {
@@ -194,13 +75,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_txn(DecParams p) {
   }
 }
 
-// Transaction context of one frame (state BEFORE the frame is applied).
-struct TxnCtx {
-  bool in_txn;         // remote_final_lsn.is_some()
-  uint64_t final_lsn;  // valid when in_txn
-  uint64_t ord;        // ordinal this frame takes if it consumes one
-};
-
 // Per-frame transaction context from the block-local scans + block prefixes.
 DEV TxnCtx txn_context(const DecParams& p, uint32_t f, uint32_t tag, uint32_t* lds) {
   uint32_t cnt = 0, mark = 0;
@@ -249,638 +123,6 @@ __global__ __launch_bounds__(kBlock) void k_ctrl_list(DecParams p) {
   }
 }
 
-// ------------------------------------------------------- side-input lookups
-DEV int find_table(const DecParams& p, uint32_t table_id) {
-  int lo = 0, hi = (int)p.n_tables - 1;
-  while (lo <= hi) {
-    int mid = (lo + hi) >> 1;
-    uint32_t v = p.tables[mid].table_id;
-    if (v == table_id) return mid;
-    if (v < table_id) lo = mid + 1; else hi = mid - 1;
-  }
-  return -1;
-}
-
-// should_apply_changes: apply.rs:2626-2639 -> 2836-2867 / 3514-3519
-DEV bool should_apply(const DecParams& p, int ti, uint32_t table_id, uint64_t remote_final_lsn) {
-  if (p.worker_kind == ETLG_WORKER_TABLE_SYNC) return p.sync_table == table_id;
-  if (ti < 0) return false;
-  const DevTable& t = p.tables[ti];
-  if (t.state_kind == ETLG_TS_READY) return true;
-  if (t.state_kind == ETLG_TS_SYNC_DONE) return t.state_lsn <= remote_final_lsn;
-  return false;
-}
-
-// get_replicated_table_schema (apply.rs:3705-3734) at stream position `f`:
-// the shared-table-cache entry in force just before frame f.
-// returns slot >= 0, or -ETLG_E_MISSING_SHARED_STATE / -ETLG_E_WAITING_RELATION
-DEV int cache_slot_before(const DecParams& p, int ti, uint32_t f) {
-  if (ti < 0) return -(int)ETLG_E_MISSING_SHARED_STATE;
-  const DevTable& t = p.tables[ti];
-  uint32_t kind = t.init_kind;
-  int slot = t.init_slot;
-  // epochs are few (one per R / DDL message of this table in the batch)
-  uint32_t lo = t.ep_begin, hi = t.ep_end;  // first epoch with frame >= f
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (p.epochs[mid].frame < f) lo = mid + 1; else hi = mid;
-  }
-  if (lo > t.ep_begin) { kind = p.epochs[lo - 1].kind; slot = p.epochs[lo - 1].slot; }
-  if (kind == 0) return -(int)ETLG_E_MISSING_SHARED_STATE;
-  if (kind == 1) return -(int)ETLG_E_WAITING_RELATION;
-  return slot;
-}
-
-// The epoch created by the R message at frame f itself (nullptr if the host did not
-// process it, e.g. because it lies behind the host's own error frame).
-DEV const DevEpoch* epoch_at(const DecParams& p, int ti, uint32_t f) {
-  if (ti < 0) return nullptr;
-  const DevTable& t = p.tables[ti];
-  uint32_t lo = t.ep_begin, hi = t.ep_end;
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (p.epochs[mid].frame < f) lo = mid + 1; else hi = mid;
-  }
-  if (lo < t.ep_end && p.epochs[lo].frame == f && p.epochs[lo].kind == 2) return &p.epochs[lo];
-  return nullptr;
-}
-
-// ---------------------------------------------------------- message shapes
-// Tuple := i16 ncols, ncols x { 'n' | 'u' | 't' i32 len bytes | 'b' i32 len bytes }
-// Structural walk: bounds, tags, value bytes (calculate_tuple_bytes, codec/event.rs:261-271).
-DEV bool walk_tuple(const u8*& c, const u8* e, uint32_t& ncols, uint32_t& vbytes) {
-  if (e - c < 2) return false;
-  const uint32_t n = ld_be16(c);
-  c += 2;
-  if (n & 0x8000u) return false;  // negative count
-  ncols = n;
-  for (uint32_t i = 0; i < n; i++) {
-    if (c >= e) return false;
-    const uint32_t t = *c++;
-    if (t == 'n' || t == 'u') continue;
-    if (t != 't' && t != 'b') return false;
-    if (e - c < 4) return false;
-    const uint32_t len = ld_be32(c);
-    c += 4;
-    if ((len & 0x80000000u) || (uint64_t)(e - c) < len) return false;
-    vbytes += len;
-    c += len;
-  }
-  return true;
-}
-
-struct RowMsg {
-  uint32_t rel_id;
-  const u8* old_t;   // at the i16 column count of the old/key tuple (nullptr if none)
-  const u8* new_t;   // likewise for the new tuple (nullptr for D)
-  uint32_t old_kind; // ETLG_OLD_*
-  uint32_t old_n, new_n;
-  uint32_t vbytes;   // payload bytes (A3)
-};
-
-// I := u32 rel 'N' Tuple ; U := u32 rel ['K'|'O' Tuple] 'N' Tuple ; D := u32 rel ('K'|'O') Tuple
-DEV bool parse_row_msg(uint32_t tag, const u8* b, const u8* e, RowMsg& m) {
-  if (e - b < 5) return false;
-  m.rel_id = ld_be32(b);
-  const u8* c = b + 4;
-  m.old_t = nullptr; m.new_t = nullptr; m.old_kind = ETLG_OLD_NONE; m.old_n = m.new_n = 0; m.vbytes = 0;
-  uint32_t t = *c++;
-  if (tag == 'I') {
-    if (t != 'N') return false;
-    m.new_t = c;
-    return walk_tuple(c, e, m.new_n, m.vbytes);
-  }
-  if (tag == 'U') {
-    if (t == 'K' || t == 'O') {
-      m.old_kind = t == 'K' ? ETLG_OLD_KEY : ETLG_OLD_FULL;
-      m.old_t = c;
-      if (!walk_tuple(c, e, m.old_n, m.vbytes)) return false;
-      if (c >= e) return false;
-      t = *c++;
-    }
-    if (t != 'N') return false;
-    m.new_t = c;
-    return walk_tuple(c, e, m.new_n, m.vbytes);
-  }
-  // 'D'
-  if (t != 'K' && t != 'O') return false;
-  m.old_kind = t == 'K' ? ETLG_OLD_KEY : ETLG_OLD_FULL;
-  m.old_t = c;
-  return walk_tuple(c, e, m.old_n, m.vbytes);
-}
-
-DEV bool has_cstr(const u8*& c, const u8* e) {
-  while (c < e) if (*c++ == 0) return true;
-  return false;
-}
-
-// Cell iterator over a structurally valid tuple.
-struct CellIt {
-  const u8* c;
-  DEV void begin(const u8* tuple) { c = tuple + 2; }
-  DEV uint32_t next(const u8*& data, uint32_t& len) {
-    const uint32_t t = *c++;
-    data = nullptr; len = 0;
-    if (t == 't' || t == 'b') { len = ld_be32(c); c += 4; data = c; c += len; }
-    return t;
-  }
-};
-
-// ----------------------------------------------------------------- UTF-8
-// core::str::from_utf8 (strict RFC 3629), call site codec/event.rs:976.
-DEV bool utf8_valid(const u8* s, uint32_t n) {
-  uint32_t i = 0;
-  // ASCII fast path, 8 bytes at a time
-  while (i + 8 <= n) {
-    uint64_t w; __builtin_memcpy(&w, s + i, 8);
-    if (w & 0x8080808080808080ull) break;
-    i += 8;
-  }
-  while (i < n) {
-    const uint32_t c = s[i];
-    if (c < 0x80) { i++; continue; }
-    if (c >= 0xC2 && c <= 0xDF) {
-      if (i + 1 >= n || (s[i + 1] & 0xC0) != 0x80) return false;
-      i += 2;
-    } else if (c >= 0xE0 && c <= 0xEF) {
-      if (i + 2 >= n) return false;
-      const uint32_t c1 = s[i + 1], c2 = s[i + 2];
-      if ((c1 & 0xC0) != 0x80 || (c2 & 0xC0) != 0x80) return false;
-      if (c == 0xE0 && c1 < 0xA0) return false;
-      if (c == 0xED && c1 > 0x9F) return false;
-      i += 3;
-    } else if (c >= 0xF0 && c <= 0xF4) {
-      if (i + 3 >= n) return false;
-      const uint32_t c1 = s[i + 1], c2 = s[i + 2], c3 = s[i + 3];
-      if ((c1 & 0xC0) != 0x80 || (c2 & 0xC0) != 0x80 || (c3 & 0xC0) != 0x80) return false;
-      if (c == 0xF0 && c1 < 0x90) return false;
-      if (c == 0xF4 && c1 > 0x8F) return false;
-      i += 4;
-    } else {
-      return false;
-    }
-  }
-  return true;
-}
-
-// Unicode White_Space (what str::trim strips), numeric.rs:112.
-DEV uint32_t ws_len_at(const u8* p, uint32_t n) {
-  if (n == 0) return 0;
-  const uint32_t c = p[0];
-  if ((c >= 0x09 && c <= 0x0D) || c == 0x20) return 1;
-  if (c == 0xC2 && n >= 2 && (p[1] == 0x85 || p[1] == 0xA0)) return 2;
-  if (c == 0xE1 && n >= 3 && p[1] == 0x9A && p[2] == 0x80) return 3;
-  if (c == 0xE2 && n >= 3) {
-    if (p[1] == 0x80 && ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF)) return 3;
-    if (p[1] == 0x81 && p[2] == 0x9F) return 3;
-  }
-  if (c == 0xE3 && n >= 3 && p[1] == 0x80 && p[2] == 0x80) return 3;
-  return 0;
-}
-DEV void trim_ws(const u8*& s, uint32_t& n) {
-  for (;;) { uint32_t l = ws_len_at(s, n); if (!l) break; s += l; n -= l; }
-  for (;;) {
-    if (!n) break;
-    uint32_t i = n - 1;
-    while (i > 0 && (s[i] & 0xC0) == 0x80) i--;
-    uint32_t l = ws_len_at(s + i, n - i);
-    if (l != n - i || l == 0) break;
-    n = i;
-  }
-}
-DEV bool ieq(const u8* s, uint32_t n, const char* lit, uint32_t ln) {
-  if (n != ln) return false;
-  for (uint32_t i = 0; i < n; i++) if (lower(s[i]) != (uint32_t)lit[i]) return false;
-  return true;
-}
-
-// ------------------------------------------------------------ value codecs
-// Rust `iN::from_str` / `u32::from_str` (codec/text.rs:40-51,135-138).
-// Returns false on error. `bits`: 16/32/64; `is_signed`.
-DEV bool parse_int(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& out) {
-  if (n == 0) return false;
-  bool neg = false;
-  uint32_t i = 0;
-  if (s[0] == '+' || s[0] == '-') {
-    if (n == 1) return false;
-    if (s[0] == '-') { if (!is_signed) return false; neg = true; }
-    i = 1;
-  }
-  uint64_t lim;
-  if (is_signed) lim = neg ? (1ull << (bits - 1)) : (1ull << (bits - 1)) - 1;
-  else lim = bits == 64 ? ~0ull : (1ull << bits) - 1;
-  uint64_t mag = 0;
-  for (; i < n; i++) {
-    const uint32_t d = s[i] - '0';
-    if (d > 9) return false;
-    if (mag > (lim - d) / 10) return false;  // mag*10+d > lim
-    mag = mag * 10 + d;
-  }
-  out = neg ? (int64_t)(0 - mag) : (int64_t)mag;
-  return true;
-}
-
-// PgNumeric::from_str (crates/etl-postgres/src/numeric.rs:108-135, 246-267,
-// 276-396) + the group arithmetic of convert_to_base_10000 (:404-458).
-struct NumShape {
-  uint32_t kind;        // ETLG_NUM_*
-  uint32_t sign;
-  int32_t weight;
-  uint32_t scale;
-  uint32_t ngroups;
-  int32_t offset;       // alignment of decimal digit 0 inside its base-10000 group
-  int32_t first_group, last_group;
-  const u8* mant;       // first mantissa byte (after sign / leading '.')
-  uint32_t mant_len;    // mantissa bytes (digits, '.', '_')
-};
-
-DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o) {
-  trim_ws(s, n);
-  if (n == 0) return false;
-  o.sign = 0; o.kind = ETLG_NUM_VALUE; o.weight = 0; o.scale = 0; o.ngroups = 0;
-  bool explicit_sign = false;
-  if (s[0] == '+') { s++; n--; explicit_sign = true; }
-  else if (s[0] == '-') { o.sign = 1; s++; n--; explicit_sign = true; }
-  if (!(n && (is_digit(s[0]) || s[0] == '.'))) {
-    // parse_special_value; `rest.trim_end()` is a no-op after the outer trim
-    if (ieq(s, n, "nan", 3)) { if (explicit_sign) return false; o.kind = ETLG_NUM_NAN; return true; }
-    if (ieq(s, n, "infinity", 8) || ieq(s, n, "inf", 3)) {  // the sign lives in the variant, not in a field
-      o.kind = o.sign ? ETLG_NUM_NINF : ETLG_NUM_PINF; o.sign = 0; return true;
-    }
-    return false;
-  }
-  // parse_numeric_value
-  uint32_t pos = 0;
-  bool have_dp = false;
-  int32_t dweight = -1;
-  uint32_t dscale = 0;
-  if (s[0] == '.') { have_dp = true; pos = 1; }
-  if (!(pos < n && is_digit(s[pos]))) return false;
-  o.mant = s + pos;
-  int32_t k = 0, first_nz = -1, last_nz = -1;  // decimal digit indexes
-  while (pos < n) {
-    const uint32_t c = s[pos];
-    if (is_digit(c)) {
-      pos++;
-      if (c != '0') { if (first_nz < 0) first_nz = k; last_nz = k; }
-      k++;
-      if (!have_dp) dweight++; else dscale++;
-    } else if (c == '.') {
-      if (have_dp) return false;
-      have_dp = true; pos++;
-      if (pos < n && s[pos] == '_') return false;
-    } else if (c == '_') {
-      pos++;
-      if (!(pos < n && is_digit(s[pos]))) return false;
-    } else break;
-  }
-  o.mant_len = (uint32_t)((s + pos) - o.mant);
-  if (pos < n && (s[pos] == 'e' || s[pos] == 'E')) {
-    pos++;
-    int64_t ex = 0;
-    bool exneg = false;
-    if (pos < n && s[pos] == '+') pos++;
-    else if (pos < n && s[pos] == '-') { exneg = true; pos++; }
-    if (!(pos < n && is_digit(s[pos]))) return false;
-    while (pos < n) {
-      const uint32_t c = s[pos];
-      if (is_digit(c)) {
-        pos++;
-        ex = ex * 10 + (c - '0');
-        if (ex > 0x3FFFFFFF) return false;  // i32::MAX / 2 guard -> ValueOutOfRange
-      } else if (c == '_') {
-        pos++;
-        if (!(pos < n && is_digit(s[pos]))) return false;
-      } else break;
-    }
-    if (exneg) ex = -ex;
-    dweight += (int32_t)ex;
-    int64_t ds = (int64_t)dscale - ex;
-    dscale = ds < 0 ? 0u : (uint32_t)ds;
-  }
-  if (pos != n) return false;
-  if (dscale > 16383) return false;
-  o.scale = dscale;
-  if (first_nz < 0) { o.sign = 0; o.weight = 0; return true; }  // canonical zero
-  const int32_t weight = dweight >= 0 ? (dweight + 4) / 4 - 1 : -((-dweight - 1) / 4 + 1);
-  o.offset = (weight + 1) * 4 - (dweight + 1);
-  o.first_group = (o.offset + first_nz) / 4;
-  o.last_group = (o.offset + last_nz) / 4;
-  const int32_t fw = weight - o.first_group;
-  if (fw < -32768 || fw > 32767) return false;
-  o.weight = fw;
-  o.ngroups = (uint32_t)(o.last_group - o.first_group + 1);
-  return true;
-}
-
-// Writes the etlg_numeric_hdr + digits at `dst` (4-byte aligned); returns bytes incl. padding.
-DEV uint32_t numeric_emit(const NumShape& o, u8* dst) {
-  uint32_t* w = (uint32_t*)dst;
-  w[0] = o.kind | (o.sign << 8) | ((uint32_t)(uint16_t)(int16_t)o.weight << 16);
-  w[1] = o.scale | ((o.ngroups & 0xFFFFu) << 16);
-  uint16_t* dg = (uint16_t*)(dst + 8);
-  if (o.ngroups) {
-    int32_t k = 0;
-    int32_t cur = o.first_group;
-    uint32_t acc = 0;
-    static const uint32_t p10[4] = {1000, 100, 10, 1};
-    for (uint32_t i = 0; i < o.mant_len; i++) {
-      const uint32_t c = o.mant[i];
-      if (!is_digit(c)) continue;
-      const int32_t pos = o.offset + k;
-      k++;
-      const int32_t g = pos >> 2;
-      if (g < o.first_group) continue;
-      if (g > o.last_group) break;
-      while (cur < g) { dg[cur - o.first_group] = (uint16_t)acc; acc = 0; cur++; }
-      acc += (c - '0') * p10[pos & 3];
-    }
-    while (cur <= o.last_group) { dg[cur - o.first_group] = (uint16_t)acc; acc = 0; cur++; }
-    if (o.ngroups & 1) dg[o.ngroups] = 0;  // zero padding up to 4 bytes
-  }
-  return pad4(8 + 2 * o.ngroups);
-}
-
-// chrono NaiveDate::from_ymd_opt + num_days_from_ce for years 0..=9999.
-DEV bool ymd_to_ce_days(uint32_t y, uint32_t m, uint32_t d, int32_t& out) {
-  if (m < 1 || m > 12 || d < 1) return false;
-  const bool leap = (y % 4 == 0 && y % 100 != 0) || y % 400 == 0;
-  static const u8 dim[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
-  uint32_t dm = dim[m - 1] + ((m == 2 && leap) ? 1 : 0);
-  if (d > dm) return false;
-  // days_from_civil (H. Hinnant), shifted to 0001-01-01 = day 1
-  int32_t yy = (int32_t)y - (m <= 2);
-  const int32_t era = (yy >= 0 ? yy : yy - 399) / 400;
-  const uint32_t yoe = (uint32_t)(yy - era * 400);
-  const uint32_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
-  const uint32_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
-  out = era * 146097 + (int32_t)doe - 719468 + 719163;
-  return true;
-}
-DEV bool two_digits(const u8* s, uint32_t& v) {
-  const uint32_t h = s[0] - '0', l = s[1] - '0';
-  if (h > 9 || l > 9) return false;
-  v = h * 10 + l;
-  return true;
-}
-// parse_iso_date_fast, codec/time.rs:89-100
-DEV bool iso_date_fast(const u8* s, uint32_t n, int32_t& days) {
-  if (n != 10 || s[4] != '-' || s[7] != '-') return false;
-  uint32_t y1, y2, m, d;
-  if (!two_digits(s, y1) || !two_digits(s + 2, y2) || !two_digits(s + 5, m) || !two_digits(s + 8, d)) return false;
-  return ymd_to_ce_days(y1 * 100 + y2, m, d, days);
-}
-// parse_iso_time_fast, codec/time.rs:107-141
-DEV bool iso_time_fast(const u8* s, uint32_t n, uint32_t& secs, uint32_t& nanos) {
-  if (n < 8 || s[2] != ':' || s[5] != ':') return false;
-  uint32_t h, m, sec;
-  if (!two_digits(s, h) || !two_digits(s + 3, m) || !two_digits(s + 6, sec)) return false;
-  nanos = 0;
-  if (n != 8) {
-    if (s[8] != '.') return false;
-    const uint32_t fl = n - 9;
-    if (fl == 0 || fl > 9) return false;
-    uint32_t v = 0;
-    for (uint32_t i = 0; i < fl; i++) { const uint32_t d = s[9 + i] - '0'; if (d > 9) return false; v = v * 10 + d; }
-    for (uint32_t i = fl; i < 9; i++) v *= 10;
-    nanos = v;
-  }
-  if (h >= 24 || m >= 60 || sec >= 60) return false;
-  secs = h * 3600 + m * 60 + sec;
-  return true;
-}
-// parse_iso_timestamp_fast, codec/time.rs:145-154
-DEV bool iso_timestamp_fast(const u8* s, uint32_t n, int32_t& days, uint32_t& secs, uint32_t& nanos) {
-  if (n < 19 || s[10] != ' ') return false;
-  return iso_date_fast(s, 10, days) && iso_time_fast(s + 11, n - 11, secs, nanos);
-}
-// parse_postgres_utc_offset, crates/etl-postgres/src/time.rs:143-207
-DEV bool parse_utc_offset(const u8* s, uint32_t n, int32_t& out) {
-  if (n == 0) return false;
-  int32_t sign;
-  if (s[0] == '+') sign = 1; else if (s[0] == '-') sign = -1; else return false;
-  s++; n--;
-  uint32_t h = 0, m = 0, sec = 0;
-  bool colon = false;
-  for (uint32_t i = 0; i < n; i++) if (s[i] == ':') colon = true;
-  if (colon) {
-    if (n == 5) { if (s[2] != ':' || !two_digits(s, h) || !two_digits(s + 3, m)) return false; }
-    else if (n == 8) { if (s[2] != ':' || s[5] != ':' || !two_digits(s, h) || !two_digits(s + 3, m) || !two_digits(s + 6, sec)) return false; }
-    else return false;
-  } else {
-    if (n == 2) { if (!two_digits(s, h)) return false; }
-    else if (n == 4) { if (!two_digits(s, h) || !two_digits(s + 2, m)) return false; }
-    else if (n == 6) { if (!two_digits(s, h) || !two_digits(s + 2, m) || !two_digits(s + 4, sec)) return false; }
-    else return false;
-  }
-  if (m >= 60 || sec >= 60) return false;
-  const uint32_t total = h * 3600 + m * 60 + sec;
-  if (total >= 16 * 3600) return false;
-  out = sign * (int32_t)total;
-  return true;
-}
-// split_utc_offset / split_timestamp_offset: last '+'/'-' with byte index > min_index.
-DEV int32_t split_offset_index(const u8* s, uint32_t n, uint32_t min_index) {
-  for (uint32_t i = n; i-- > 0;) {
-    if (i <= min_index) break;
-    if (s[i] == '+' || s[i] == '-') return (int32_t)i;
-  }
-  return -1;
-}
-DEV int hexv(uint32_t c) {
-  if (c - '0' < 10u) return (int)(c - '0');
-  c = lower(c);
-  if (c - 'a' < 6u) return (int)(c - 'a' + 10);
-  return -1;
-}
-// uuid 1.23 Uuid::parse_str: simple(32) | hyphenated(36) | {braced}(38) | urn:uuid:(45)
-DEV bool parse_uuid(const u8* s, uint32_t n, uint32_t* out4) {
-  u8 b[16];
-  if (n == 32) {
-    for (int i = 0; i < 16; i++) {
-      int h = hexv(s[2 * i]), l = hexv(s[2 * i + 1]);
-      if ((h | l) < 0) return false;
-      b[i] = (u8)((h << 4) | l);
-    }
-  } else {
-    const u8* h;
-    if (n == 36) h = s;
-    else if (n == 38 && s[0] == '{' && s[37] == '}') h = s + 1;
-    else if (n == 45 && s[0] == 'u' && s[1] == 'r' && s[2] == 'n' && s[3] == ':' && s[4] == 'u' && s[5] == 'u' &&
-             s[6] == 'i' && s[7] == 'd' && s[8] == ':') h = s + 9;
-    else return false;
-    if (h[8] != '-' || h[13] != '-' || h[18] != '-' || h[23] != '-') return false;
-    int k = 0;
-    for (int i = 0; i < 16; i++) {
-      if (k == 8 || k == 13 || k == 18 || k == 23) k++;
-      int hi = hexv(h[k]), lo = hexv(h[k + 1]);
-      if ((hi | lo) < 0) return false;
-      b[i] = (u8)((hi << 4) | lo);
-      k += 2;
-    }
-  }
-  for (int i = 0; i < 4; i++) out4[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
-  return true;
-}
-
-// Which classes are handed back DEFERRED wholesale (include/etlg.h contract).
-DEV bool class_always_deferred(uint32_t cls) {
-  return cls == ETLG_TC_JSON || cls == ETLG_TC_ARRAY || cls == ETLG_TC_F32 || cls == ETLG_TC_F64;
-}
-
-// Heap bytes a text cell will occupy (exact for every non-error outcome).
-DEV uint32_t cell_heap_bytes(uint32_t cls, const u8* d, uint32_t len) {
-  if (class_always_deferred(cls) || cls == ETLG_TC_STRING) return pad4(len);
-  switch (cls) {
-    case ETLG_TC_BYTEA: return len >= 2 ? pad4((len - 2) >> 1) : 0;
-    case ETLG_TC_NUMERIC: { NumShape s; return numeric_scan(d, len, s) ? pad4(8 + 2 * s.ngroups) : 0; }
-    case ETLG_TC_DATE: { int32_t x; return iso_date_fast(d, len, x) ? 0 : pad4(len); }
-    case ETLG_TC_TIME: { uint32_t a, b; return iso_time_fast(d, len, a, b) ? 0 : pad4(len); }
-    case ETLG_TC_TIMESTAMP: { int32_t x; uint32_t a, b; return iso_timestamp_fast(d, len, x, a, b) ? 0 : pad4(len); }
-    case ETLG_TC_TIMESTAMPTZ: {
-      int32_t idx = split_offset_index(d, len, 10);
-      if (idx < 0) return 0;
-      int32_t x; uint32_t a, b;
-      return iso_timestamp_fast(d, (uint32_t)idx, x, a, b) ? 0 : pad4(len);
-    }
-    case ETLG_TC_TIMETZ: {
-      int32_t idx = split_offset_index(d, len, 0);
-      if (idx < 0) return 0;
-      uint32_t a, b;
-      return iso_time_fast(d, (uint32_t)idx, a, b) ? 0 : pad4(len);
-    }
-    default: return 0;
-  }
-}
-
-// Copies n bytes to a 4-byte aligned heap position, zero padded to 4.
-DEV void heap_copy(u8* dst, const u8* src, uint32_t n) {
-  uint32_t* w = (uint32_t*)dst;
-  uint32_t i = 0;
-  for (; i + 4 <= n; i += 4) { uint32_t v; __builtin_memcpy(&v, src + i, 4); w[i >> 2] = v; }
-  if (i < n) {
-    uint32_t v = 0;
-    for (uint32_t k = 0; i + k < n; k++) v |= (uint32_t)src[i + k] << (8 * k);
-    w[i >> 2] = v;
-  }
-}
-
-// parse_cell_from_postgres_text for one cell (codec/text.rs:32-153), writing the
-// slot words / heap entry. Returns 0 or an etlg_err_code; `state` = cell state.
-DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t* slot, u8* heap, uint32_t& hcur,
-                              uint32_t& state) {
-  if (!utf8_valid(d, len)) return ETLG_E_UTF8;  // codec/event.rs:976
-  state = ETLG_CELL_VALUE;
-  auto var = [&](uint32_t nbytes) { slot[0] = hcur; slot[1] = nbytes; hcur += pad4(nbytes); };
-  auto defer = [&]() { state = ETLG_CELL_DEFERRED; heap_copy(heap + hcur, d, len); var(len); return 0u; };
-  if (class_always_deferred(cls)) return defer();
-  switch (cls) {
-    case ETLG_TC_STRING: heap_copy(heap + hcur, d, len); var(len); return 0;
-    case ETLG_TC_BOOL:  // parse_bool, codec/bool.rs:11-19
-      if (len == 1 && (d[0] == 't' || d[0] == 'f')) { slot[0] = d[0] == 't'; return 0; }
-      return ETLG_E_BOOL;
-    case ETLG_TC_I16: { int64_t v; if (!parse_int(d, len, true, 16, v)) return ETLG_E_INT; slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_I32: { int64_t v; if (!parse_int(d, len, true, 32, v)) return ETLG_E_INT; slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_U32: { int64_t v; if (!parse_int(d, len, false, 32, v)) return ETLG_E_INT; slot[0] = (uint32_t)v; return 0; }
-    case ETLG_TC_I64: { int64_t v; if (!parse_int(d, len, true, 64, v)) return ETLG_E_INT; st64(slot, (uint64_t)v); return 0; }
-    case ETLG_TC_NUMERIC: {
-      NumShape s;
-      if (!numeric_scan(d, len, s)) return ETLG_E_NUMERIC;
-      numeric_emit(s, heap + hcur);
-      var(8 + 2 * s.ngroups);
-      return 0;
-    }
-    case ETLG_TC_BYTEA: {  // parse_bytea_hex_string, codec/hex.rs:11-52
-      if (len < 2 || d[0] != '\\' || d[1] != 'x') return ETLG_E_BYTEA;
-      if ((len - 2) & 1) return ETLG_E_BYTEA;
-      const uint32_t nb = (len - 2) >> 1;
-      u8* dst = heap + hcur;
-      uint32_t w = 0;
-      for (uint32_t i = 0; i < nb; i++) {
-        int h = hexv(d[2 + 2 * i]);
-        if (h < 0) return ETLG_E_BYTEA;
-        int l = hexv(d[3 + 2 * i]);
-        if (l < 0) return ETLG_E_BYTEA;
-        w |= (uint32_t)((h << 4) | l) << (8 * (i & 3));
-        if ((i & 3) == 3) { ((uint32_t*)dst)[i >> 2] = w; w = 0; }
-      }
-      if (nb & 3) ((uint32_t*)dst)[nb >> 2] = w;
-      var(nb);
-      return 0;
-    }
-    case ETLG_TC_DATE: { int32_t x; if (!iso_date_fast(d, len, x)) return defer(); slot[0] = (uint32_t)x; slot[1] = 0; return 0; }
-    case ETLG_TC_TIME: { uint32_t a, b; if (!iso_time_fast(d, len, a, b)) return defer(); slot[0] = a; slot[1] = b; return 0; }
-    case ETLG_TC_TIMESTAMP: {
-      int32_t x; uint32_t a, b;
-      if (!iso_timestamp_fast(d, len, x, a, b)) return defer();
-      slot[0] = (uint32_t)x; slot[1] = a; slot[2] = b;
-      return 0;
-    }
-    case ETLG_TC_TIMESTAMPTZ: {  // codec/time.rs:63-71 + UTC normalisation codec/text.rs:108-111
-      const int32_t idx = split_offset_index(d, len, 10);
-      if (idx < 0) return ETLG_E_DATETIME;
-      int32_t x; uint32_t a, b;
-      if (!iso_timestamp_fast(d, (uint32_t)idx, x, a, b)) return defer();
-      int32_t off;
-      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return ETLG_E_DATETIME;
-      int32_t sec = (int32_t)a - off;
-      if (sec < 0) { sec += 86400; x -= 1; } else if (sec >= 86400) { sec -= 86400; x += 1; }
-      slot[0] = (uint32_t)x; slot[1] = (uint32_t)sec; slot[2] = b;
-      return 0;
-    }
-    case ETLG_TC_TIMETZ: {  // crates/etl-postgres/src/time.rs:121-127
-      const int32_t idx = split_offset_index(d, len, 0);
-      if (idx < 0) return ETLG_E_DATETIME;
-      uint32_t a, b;
-      if (!iso_time_fast(d, (uint32_t)idx, a, b)) return defer();
-      int32_t off;
-      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return ETLG_E_DATETIME;
-      slot[0] = a; slot[1] = b; slot[2] = (uint32_t)off;
-      return 0;
-    }
-    case ETLG_TC_UUID: return parse_uuid(d, len, slot) ? 0 : ETLG_E_UUID;
-    default: return defer();
-  }
-}
-
-DEV uint32_t slot_bytes(uint32_t cls) {  // layout rule of include/etlg.h
-  switch (cls) {
-    case ETLG_TC_BOOL: case ETLG_TC_I16: case ETLG_TC_I32: case ETLG_TC_U32: return 4;
-    case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: case ETLG_TC_TIMETZ: return 12;
-    case ETLG_TC_UUID: return 16;
-    default: return 8;
-  }
-}
-
-// ---------------------------------------------------------------- k_size
-// Heap bytes of one tuple decoded against `n` schema columns.
-//   mode 0: full row (convert_tuple_to_row); mode 1: dense key tuple;
-//   mode 2: full-width key tuple (non-identity positions skipped unread);
-//   mode 3: update new tuple (u cells never allocate: alias or Missing)
-DEV uint32_t tuple_heap_bytes(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, int mode) {
-  const DevCol* cols = p.cols + s.cols_base;
-  CellIt it; it.begin(tuple);
-  uint32_t h = 0, next_ident = 0;
-  for (uint32_t i = 0; i < ncells; i++) {
-    const u8* d; uint32_t len;
-    const uint32_t t = it.next(d, len);
-    uint32_t ci;
-    if (mode == 1) {
-      // i-th identity column
-      ci = 0xFFFFFFFFu;
-      for (uint32_t c = 0, k = 0; c < s.n_cols; c++) if (cols[c].identity) { if (k == i) { ci = c; break; } k++; }
-      if (ci == 0xFFFFFFFFu) break;
-    } else {
-      if (i >= s.n_cols) break;
-      ci = i;
-      if (mode == 2) { if (!cols[ci].identity) continue; next_ident++; }
-    }
-    if (t == 't') h += cell_heap_bytes(cols[ci].cls, d, len);
-  }
-  (void)next_ident;
-  return h;
-}
-
 __global__ __launch_bounds__(kBlock) void k_size(DecParams p) {
   __shared__ uint32_t lds[8];
   __shared__ uint64_t lds64[4];
@@ -891,85 +133,11 @@ __global__ __launch_bounds__(kBlock) void k_size(DecParams p) {
   uint32_t emit = 0, fixed = 0, heap = 0;
   uint64_t pay[3] = {0, 0, 0};
   if (live) {
-    const u8* fr = p.in + p.offs[f];
-    const u8* b = fr + kBodyOff;
-    const u8* e = p.in + p.offs[f + 1];
-    switch (tag) {
-      case FT_BAD: record_error(p, f, RK_WIRE, ETLG_E_WIRE); break;
-      case 'k': break;
-      case 'B': emit = 1; fixed = 8; break;
-      case 'C':
-        if (!tx.in_txn) record_error(p, f, RK_TXN, ETLG_E_TXN_STATE);
-        else if (ld_be64(b + 1) != tx.final_lsn) record_error(p, f, RK_TXN, ETLG_E_COMMIT_LSN);
-        else { emit = 1; fixed = 16; }
-        break;
-      case 'O': {  // u64 lsn, cstr name
-        const u8* c = b + 8;
-        if (e - b < 9 || !has_cstr(c, e)) record_error(p, f, RK_WIRE, ETLG_E_WIRE);
-        break;
-      }
-      case 'Y': {  // u32 oid, cstr nsp, cstr name
-        const u8* c = b + 4;
-        if (e - b < 6 || !has_cstr(c, e) || !has_cstr(c, e)) record_error(p, f, RK_WIRE, ETLG_E_WIRE);
-        break;
-      }
-      case 'M':
-        if (p.flags & 1u) record_error(p, f, RK_WIRE, ETLG_E_CTRL_HINT);
-        break;  // host control plane (apply.rs:2160-2276)
-      case 'R': {  // handle_relation_message: the event is emitted here, the schema work is the host's
-        if (p.flags & 1u) { record_error(p, f, RK_WIRE, ETLG_E_CTRL_HINT); break; }
-        if (e - b < 4) { record_error(p, f, RK_WIRE, ETLG_E_WIRE); break; }
-        if (!tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
-        const uint32_t rel = ld_be32(b);
-        const int ti = find_table(p, rel);
-        const DevEpoch* ep = epoch_at(p, ti, f);
-        if (ep && ep->emit) emit = 1;
-        break;
-      }
-      case 'I': case 'U': case 'D': {
-        RowMsg m;
-        if (!parse_row_msg(tag, b, e, m)) { record_error(p, f, RK_WIRE, ETLG_E_WIRE); break; }
-        if (!tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
-        pay[tag == 'I' ? 0 : tag == 'U' ? 1 : 2] = m.vbytes;
-        const int ti = find_table(p, m.rel_id);
-        if (!should_apply(p, ti, m.rel_id, tx.final_lsn)) break;
-        const int slot = cache_slot_before(p, ti, f);
-        if (slot < 0) { record_error(p, f, RK_SCHEMA, (uint32_t)(-slot)); break; }
-        const DevSlot& s = p.slots[slot];
-        emit = 1;
-        if (tag == 'I') {
-          fixed = s.row_full;
-          heap = tuple_heap_bytes(p, s, m.new_t, m.new_n, 0);
-        } else {
-          if (m.old_kind == ETLG_OLD_FULL) { fixed = s.row_full; heap = tuple_heap_bytes(p, s, m.old_t, m.old_n, 0); }
-          else if (m.old_kind == ETLG_OLD_KEY) {
-            fixed = s.row_key;
-            if (m.old_n == s.n_ident) heap = tuple_heap_bytes(p, s, m.old_t, m.old_n, 1);
-            else if (m.old_n == s.n_cols) heap = tuple_heap_bytes(p, s, m.old_t, m.old_n, 2);
-          }
-          if (tag == 'U') { fixed += s.row_full; heap += tuple_heap_bytes(p, s, m.new_t, m.new_n, 3); }
-        }
-        break;
-      }
-      case 'T': {  // i32 nrel, i8 options, nrel x u32
-        if (e - b < 5) { record_error(p, f, RK_WIRE, ETLG_E_WIRE); break; }
-        const uint32_t nrel = ld_be32(b);
-        if ((nrel & 0x80000000u) || (uint64_t)(e - b - 5) / 4 < nrel) { record_error(p, f, RK_WIRE, ETLG_E_WIRE); break; }
-        if (!tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
-        uint32_t owned = 0;
-        for (uint32_t i = 0; i < nrel; i++) {
-          const uint32_t rel = ld_be32(b + 5 + 4 * i);
-          const int ti = find_table(p, rel);
-          if (!should_apply(p, ti, rel, tx.final_lsn)) continue;
-          const int slot = cache_slot_before(p, ti, f);
-          if (slot < 0) { record_error(p, f, RK_SCHEMA, (uint32_t)(-slot)); owned = 0; break; }
-          owned++;
-        }
-        if (owned) { emit = 1; fixed = 8 * owned; }
-        break;
-      }
-      default: break;
-    }
+    FrameView v{f, tag, p.in + p.offs[f], p.in + p.offs[f + 1]};
+    RowMsg m;
+    const bool ok = frame_structure(v, m);
+    int row_slot = -1;
+    size_frame(p, v, tx, ok, m, emit, fixed, heap, pay, row_slot);
   }
   if (f < p.nframes) { p.f_emit[f] = (u8)emit; p.f_fixed[f] = fixed; p.f_heap[f] = heap; }
   uint32_t tot_ev;
@@ -1001,127 +169,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_out(DecParams p) {
   if (threadIdx.x == 0) { p.blk_ev[p.nblocks] = (uint32_t)run_ev; p.blk_fixed[p.nblocks] = run_fx; p.blk_heap[p.nblocks] = run_hp; }
 }
 
-// ---------------------------------------------------------------- k_write
-struct RowOut {
-  u8* base;        // row block in the fixed arena (4-byte aligned)
-  uint32_t st_acc; // pending state bits for columns [16*k, 16*k+16)
-};
-
-DEV void row_zero(u8* base, uint32_t nbytes) {
-  uint32_t* w = (uint32_t*)base;
-  for (uint32_t i = 0; i < nbytes / 4; i++) w[i] = 0;
-}
-DEV void set_state(u8* base, uint32_t i, uint32_t st) {  // 2 bits per column
-  if (st) base[i >> 2] |= (u8)(st << (2 * (i & 3)));
-}
-DEV uint32_t get_state(const u8* base, uint32_t i) { return (base[i >> 2] >> (2 * (i & 3))) & 3u; }
-
-// convert_tuple_to_row (codec/event.rs:554-587) into a full-layout row.
-DEV uint32_t write_full_row(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, u8* row,
-                            uint32_t& hcur) {
-  if (ncells != s.n_cols) return ETLG_E_TUPLE_WIDTH;
-  const DevCol* cols = p.cols + s.cols_base;
-  row_zero(row, s.row_full);
-  CellIt it; it.begin(tuple);
-  for (uint32_t i = 0; i < ncells; i++) {
-    const u8* d; uint32_t len;
-    const uint32_t t = it.next(d, len);
-    const DevCol col = cols[i];
-    if (t == 'n') {  // convert_tuple_data_to_cell, codec/event.rs:945-961
-      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
-      set_state(row, i, ETLG_CELL_NULL);
-    } else if (t == 'u') {
-      return ETLG_E_FULL_ROW_MISSING;
-    } else if (t == 't') {
-      uint32_t st;
-      const uint32_t err = decode_text_cell(col.cls, d, len, (uint32_t*)(row + col.off_full), p.heap, hcur, st);
-      if (err) return err;
-      set_state(row, i, st);
-    } else {
-      return ETLG_E_BINARY_FORMAT;
-    }
-  }
-  return 0;
-}
-
-// normalize_key_tuple_to_row (codec/event.rs:795-923) into a key-layout row.
-DEV uint32_t write_key_row(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, u8* row,
-                           uint32_t& hcur) {
-  if (s.n_ident == 0) return ETLG_E_KEY_MISSING_COLS;
-  const bool dense = ncells == s.n_ident;
-  if (!dense && ncells != s.n_cols) return ETLG_E_KEY_SHAPE;
-  const DevCol* cols = p.cols + s.cols_base;
-  row_zero(row, s.row_key);
-  CellIt it; it.begin(tuple);
-  uint32_t ci = 0;  // schema column cursor (dense mode walks identity columns only)
-  for (uint32_t i = 0; i < ncells; i++) {
-    const u8* d; uint32_t len;
-    const uint32_t t = it.next(d, len);
-    if (dense) { while (ci < s.n_cols && !cols[ci].identity) ci++; }
-    else { ci = i; if (!cols[ci].identity) continue; }
-    const DevCol col = cols[ci];
-    const uint32_t k = col.key_index;
-    if (t == 'n') {
-      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
-      set_state(row, k, ETLG_CELL_NULL);
-    } else if (t == 'u') {
-      return ETLG_E_KEY_MISSING_VALUE;
-    } else if (t == 't') {
-      uint32_t st;
-      const uint32_t err = decode_text_cell(col.cls, d, len, (uint32_t*)(row + col.off_key), p.heap, hcur, st);
-      if (err) return err;
-      set_state(row, k, st);
-    } else {
-      return ETLG_E_BINARY_FORMAT;
-    }
-    if (dense) ci++;
-  }
-  return 0;
-}
-
-// convert_update_tuple_to_updated_table_row + OldRowResolver (codec/event.rs:605-791).
-DEV uint32_t write_update_row(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, u8* row,
-                              uint32_t old_kind, const u8* old_row, uint32_t& hcur, bool& partial) {
-  if (ncells != s.n_cols) return ETLG_E_TUPLE_WIDTH;
-  const DevCol* cols = p.cols + s.cols_base;
-  row_zero(row, s.row_full);
-  CellIt it; it.begin(tuple);
-  partial = false;
-  // A decoded old row always has exactly n_cols (Full) / n_ident (Key) cells, so the
-  // resolver's width checks (codec/event.rs:700-710, 730-740, 772-785) cannot fire here.
-  for (uint32_t i = 0; i < ncells; i++) {
-    const u8* d; uint32_t len;
-    const uint32_t t = it.next(d, len);
-    const DevCol col = cols[i];
-    if (t == 'n') {
-      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
-      set_state(row, i, ETLG_CELL_NULL);
-    } else if (t == 'u') {
-      const bool from_full = old_kind == ETLG_OLD_FULL;
-      const bool from_key = old_kind == ETLG_OLD_KEY && col.identity;
-      if (from_full || from_key) {  // Cell::clone of the aligned old value: alias its slot
-        const uint32_t oi = from_full ? i : col.key_index;
-        const uint32_t* src = (const uint32_t*)(old_row + (from_full ? col.off_full : col.off_key));
-        uint32_t* dst = (uint32_t*)(row + col.off_full);
-        const uint32_t nw = slot_bytes(col.cls) / 4;
-        for (uint32_t w = 0; w < nw; w++) dst[w] = src[w];
-        set_state(row, i, get_state(old_row, oi));
-      } else {
-        set_state(row, i, ETLG_CELL_MISSING);
-        partial = true;
-      }
-    } else if (t == 't') {
-      uint32_t st;
-      const uint32_t err = decode_text_cell(col.cls, d, len, (uint32_t*)(row + col.off_full), p.heap, hcur, st);
-      if (err) return err;
-      set_state(row, i, st);
-    } else {
-      return ETLG_E_BINARY_FORMAT;
-    }
-  }
-  return 0;
-}
-
 __global__ __launch_bounds__(kBlock) void k_write(DecParams p) {
   __shared__ uint32_t lds[8];
   __shared__ uint64_t lds64[4];
@@ -1139,80 +186,10 @@ __global__ __launch_bounds__(kBlock) void k_write(DecParams p) {
     record_error(p, f, RK_DECODE, ETLG_E_WIRE);  // capacity guard (cannot happen with the host's bounds)
     return;
   }
-  const u8* fr = p.in + p.offs[f];
-  const u8* b = fr + kBodyOff;
-  const u8* e = p.in + p.offs[f + 1];
-  u8* body = p.fixed + fx_off;
-  uint32_t flags = 0, table = 0, slot_id = 0;
-  uint64_t commit_lsn = tx.final_lsn;
-  switch (tag) {
-    case 'B':  // parse_event_from_begin_message, codec/event.rs:303-316
-      commit_lsn = ld_be64(b);
-      st64((uint32_t*)body, ld_be64(b + 8));
-      table = ld_be32(b + 16);
-      break;
-    case 'C':  // parse_event_from_commit_message, codec/event.rs:322-336
-      flags = b[0];
-      commit_lsn = ld_be64(b + 1);
-      st64((uint32_t*)body, ld_be64(b + 9));
-      st64((uint32_t*)body + 2, ld_be64(b + 17));
-      break;
-    case 'R': {
-      table = ld_be32(b);
-      const DevEpoch* ep = epoch_at(p, find_table(p, table), f);
-      slot_id = ep ? (uint32_t)ep->slot : 0;
-      break;
-    }
-    case 'T': {  // parse_event_from_truncate_message, codec/event.rs:533-547
-      const uint32_t nrel = ld_be32(b);
-      flags = b[4];
-      uint32_t k = 0;
-      for (uint32_t i = 0; i < nrel; i++) {
-        const uint32_t rel = ld_be32(b + 5 + 4 * i);
-        const int ti = find_table(p, rel);
-        if (!should_apply(p, ti, rel, tx.final_lsn)) continue;
-        const int sl = cache_slot_before(p, ti, f);
-        ((uint32_t*)body)[2 * k] = rel; ((uint32_t*)body)[2 * k + 1] = (uint32_t)sl;
-        k++;
-      }
-      table = k;
-      break;
-    }
-    default: {  // I / U / D
-      RowMsg m;
-      parse_row_msg(tag, b, e, m);
-      table = m.rel_id;
-      const int ti = find_table(p, m.rel_id);
-      const int sl = cache_slot_before(p, ti, f);
-      slot_id = (uint32_t)sl;
-      const DevSlot& s = p.slots[sl];
-      uint32_t hcur = (uint32_t)hp_off;
-      uint32_t err = 0;
-      if (tag == 'I') {
-        err = write_full_row(p, s, m.new_t, m.new_n, body, hcur);
-      } else {
-        uint32_t old_sz = 0;
-        if (m.old_kind == ETLG_OLD_FULL) { old_sz = s.row_full; err = write_full_row(p, s, m.old_t, m.old_n, body, hcur); }
-        else if (m.old_kind == ETLG_OLD_KEY) { old_sz = s.row_key; err = write_key_row(p, s, m.old_t, m.old_n, body, hcur); }
-        flags = m.old_kind;
-        if (!err && tag == 'U') {
-          bool partial;
-          err = write_update_row(p, s, m.new_t, m.new_n, body + old_sz, m.old_kind, body, hcur, partial);
-          if (partial) flags |= ETLG_FLAG_PARTIAL;
-        }
-      }
-      if (err) { record_error(p, f, RK_DECODE, err); return; }
-      break;
-    }
-  }
-  p.ev_kind[ev_idx] = (u8)tag;
-  p.ev_flags[ev_idx] = (u8)flags;
-  p.ev_table[ev_idx] = table;
-  p.ev_slot[ev_idx] = slot_id;
-  p.ev_start[ev_idx] = ld_be64(fr + 6);  // wal_start (apply.rs:2039)
-  p.ev_commit[ev_idx] = commit_lsn;
-  p.ev_ord[ev_idx] = tx.ord;
-  p.ev_body[ev_idx] = fx_off;
+  FrameView v{f, tag, p.in + p.offs[f], p.in + p.offs[f + 1]};
+  RowMsg m;
+  (void)frame_structure(v, m);
+  write_frame(p, v, tx, m, -1, ev_idx, fx_off, hp_off);
 }
 
 // --------------------------------------------------------------- k_finalize
