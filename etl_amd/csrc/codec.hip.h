@@ -107,6 +107,56 @@ DEV uint64_t block_scan_excl64(uint64_t v, uint64_t* lds, uint64_t* total) {
   return pre + inc - v;
 }
 
+// Exclusive sum scan of three u32 values at once (one LDS exchange, two barriers).
+// lds: 3 * nwaves words. tot[k] = workgroup totals.
+DEV void block_scan3_excl(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t* lds, uint32_t tot[3]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  uint32_t ia = a, ib = b, ic = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64), tc = __shfl_up(ic, d, 64);
+    if (lane >= d) { ia += ta; ib += tb; ic += tc; }
+  }
+  if (lane == 63) { lds[3 * wave] = ia; lds[3 * wave + 1] = ib; lds[3 * wave + 2] = ic; }
+  __syncthreads();
+  uint32_t pa = 0, pb = 0, pc = 0, ta = 0, tb = 0, tc = 0;
+  for (int w = 0; w < nw; w++) {
+    const uint32_t xa = lds[3 * w], xb = lds[3 * w + 1], xc = lds[3 * w + 2];
+    if (w < wave) { pa += xa; pb += xb; pc += xc; }
+    ta += xa; tb += xb; tc += xc;
+  }
+  __syncthreads();
+  a = pa + ia - a; b = pb + ib - b; c = pc + ic - c;
+  tot[0] = ta; tot[1] = tb; tot[2] = tc;
+}
+
+// Transaction scan: inclusive segmented count + EXCLUSIVE running max in one exchange.
+// lds: 2 * nwaves words.
+DEV void block_scan_txn(uint32_t cnt, uint32_t mark, uint32_t* lds, uint32_t& seg_incl, uint32_t& mark_excl,
+                        uint32_t& tot_cnt, uint32_t& tot_mark) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  uint32_t ic = cnt, im = mark;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t tc = __shfl_up(ic, d, 64), tm = __shfl_up(im, d, 64);
+    if (lane >= d) { ic = seg_combine(tc, ic); im = tm > im ? tm : im; }
+  }
+  uint32_t pm = __shfl_up(im, 1, 64);
+  if (lane == 0) pm = 0;
+  if (lane == 63) { lds[2 * wave] = ic; lds[2 * wave + 1] = im; }
+  __syncthreads();
+  uint32_t pc = 0, pmx = 0, tcn = 0, tmx = 0;
+  for (int w = 0; w < nw; w++) {
+    const uint32_t xc = lds[2 * w], xm = lds[2 * w + 1];
+    if (w < wave) { pc = seg_combine(pc, xc); pmx = pmx > xm ? pmx : xm; }
+    tcn = seg_combine(tcn, xc); tmx = tmx > xm ? tmx : xm;
+  }
+  __syncthreads();
+  seg_incl = seg_combine(pc, ic);
+  mark_excl = pmx > pm ? pmx : pm;
+  tot_cnt = tcn; tot_mark = tmx;
+}
+
 // --------------------------------------------------------- frame geometry
 // CopyData := 'd' Int32-BE(len incl. itself) payload
 // payload  := 'w' u64 wal_start u64 wal_end i64 ts <pgoutput msg> | 'k' u64 i64 u8
@@ -648,42 +698,51 @@ DEV void heap_copy(u8* dst, const u8* src, uint32_t n) {
 DEV uint32_t slot_bytes(uint32_t cls);
 DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t* slot, u8* heap, uint32_t& hcur,
                               uint32_t& state) {
-  if (!utf8_valid(d, len)) return ETLG_E_UTF8;  // codec/event.rs:976
+  // str::from_utf8 precedes the type switch (codec/event.rs:976). Every non-text grammar below
+  // accepts ASCII only, so for those classes validity is only examined when the parse fails
+  // (to pick between the UTF-8 error and the type's own error) or before a cell is deferred.
   state = ETLG_CELL_VALUE;
+  auto bad = [&](uint32_t code) { return utf8_valid(d, len) ? code : (uint32_t)ETLG_E_UTF8; };
   auto var = [&](uint32_t nbytes) { slot[0] = hcur; slot[1] = nbytes; hcur += pad4(nbytes); };
   auto defer = [&]() {
+    if (!utf8_valid(d, len)) return (uint32_t)ETLG_E_UTF8;
     state = ETLG_CELL_DEFERRED; heap_copy(heap + hcur, d, len); var(len);
     if (slot_bytes(cls) == 12) slot[2] = 0;
     return 0u;
   };
   if (class_always_deferred(cls)) return defer();
   switch (cls) {
-    case ETLG_TC_STRING: heap_copy(heap + hcur, d, len); var(len); return 0;
+    case ETLG_TC_STRING:
+      if (!utf8_valid(d, len)) return ETLG_E_UTF8;
+      heap_copy(heap + hcur, d, len); var(len); return 0;
     case ETLG_TC_BOOL:  // parse_bool, codec/bool.rs:11-19
       if (len == 1 && (d[0] == 't' || d[0] == 'f')) { slot[0] = d[0] == 't'; return 0; }
-      return ETLG_E_BOOL;
-    case ETLG_TC_I16: { int64_t v; if (!parse_int(d, len, true, 16, v)) return ETLG_E_INT; slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_I32: { int64_t v; if (!parse_int(d, len, true, 32, v)) return ETLG_E_INT; slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_U32: { int64_t v; if (!parse_int(d, len, false, 32, v)) return ETLG_E_INT; slot[0] = (uint32_t)v; return 0; }
-    case ETLG_TC_I64: { int64_t v; if (!parse_int(d, len, true, 64, v)) return ETLG_E_INT; st64(slot, (uint64_t)v); return 0; }
+      return bad(ETLG_E_BOOL);
+    case ETLG_TC_I16: { int64_t v; if (!parse_int(d, len, true, 16, v)) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
+    case ETLG_TC_I32: { int64_t v; if (!parse_int(d, len, true, 32, v)) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
+    case ETLG_TC_U32: { int64_t v; if (!parse_int(d, len, false, 32, v)) return bad(ETLG_E_INT); slot[0] = (uint32_t)v; return 0; }
+    case ETLG_TC_I64: { int64_t v; if (!parse_int(d, len, true, 64, v)) return bad(ETLG_E_INT); st64(slot, (uint64_t)v); return 0; }
     case ETLG_TC_NUMERIC: {
       NumShape s;
-      if (!numeric_scan(d, len, s)) return ETLG_E_NUMERIC;
+      if (!numeric_scan(d, len, s)) return bad(ETLG_E_NUMERIC);
+      // the numeric grammar strips Unicode whitespace, so a successful scan may still
+      // have seen multi-byte characters: those must be valid UTF-8 too
+      if (!utf8_valid(d, len)) return ETLG_E_UTF8;
       numeric_emit(s, heap + hcur);
       var(8 + 2 * s.ngroups);
       return 0;
     }
     case ETLG_TC_BYTEA: {  // parse_bytea_hex_string, codec/hex.rs:11-52
-      if (len < 2 || d[0] != '\\' || d[1] != 'x') return ETLG_E_BYTEA;
-      if ((len - 2) & 1) return ETLG_E_BYTEA;
+      if (len < 2 || d[0] != '\\' || d[1] != 'x') return bad(ETLG_E_BYTEA);
+      if ((len - 2) & 1) return bad(ETLG_E_BYTEA);
       const uint32_t nb = (len - 2) >> 1;
       u8* dst = heap + hcur;
       uint32_t w = 0;
       for (uint32_t i = 0; i < nb; i++) {
         int h = hexv(d[2 + 2 * i]);
-        if (h < 0) return ETLG_E_BYTEA;
+        if (h < 0) return bad(ETLG_E_BYTEA);
         int l = hexv(d[3 + 2 * i]);
-        if (l < 0) return ETLG_E_BYTEA;
+        if (l < 0) return bad(ETLG_E_BYTEA);
         w |= (uint32_t)((h << 4) | l) << (8 * (i & 3));
         if ((i & 3) == 3) { ((uint32_t*)dst)[i >> 2] = w; w = 0; }
       }
@@ -701,11 +760,11 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
     }
     case ETLG_TC_TIMESTAMPTZ: {  // codec/time.rs:63-71 + UTC normalisation codec/text.rs:108-111
       const int32_t idx = split_offset_index(d, len, 10);
-      if (idx < 0) return ETLG_E_DATETIME;
+      if (idx < 0) return bad(ETLG_E_DATETIME);
       int32_t x; uint32_t a, b;
       if (!iso_timestamp_fast(d, (uint32_t)idx, x, a, b)) return defer();
       int32_t off;
-      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return ETLG_E_DATETIME;
+      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return bad(ETLG_E_DATETIME);
       int32_t sec = (int32_t)a - off;
       if (sec < 0) { sec += 86400; x -= 1; } else if (sec >= 86400) { sec -= 86400; x += 1; }
       slot[0] = (uint32_t)x; slot[1] = (uint32_t)sec; slot[2] = b;
@@ -713,15 +772,15 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
     }
     case ETLG_TC_TIMETZ: {  // crates/etl-postgres/src/time.rs:121-127
       const int32_t idx = split_offset_index(d, len, 0);
-      if (idx < 0) return ETLG_E_DATETIME;
+      if (idx < 0) return bad(ETLG_E_DATETIME);
       uint32_t a, b;
       if (!iso_time_fast(d, (uint32_t)idx, a, b)) return defer();
       int32_t off;
-      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return ETLG_E_DATETIME;
+      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return bad(ETLG_E_DATETIME);
       slot[0] = a; slot[1] = b; slot[2] = (uint32_t)off;
       return 0;
     }
-    case ETLG_TC_UUID: return parse_uuid(d, len, slot) ? 0 : ETLG_E_UUID;
+    case ETLG_TC_UUID: return parse_uuid(d, len, slot) ? 0 : bad(ETLG_E_UUID);
     default: return defer();
   }
 }
@@ -741,6 +800,7 @@ DEV uint32_t slot_bytes(uint32_t cls) {  // layout rule of include/etlg.h
 //   mode 2: full-width key tuple (non-identity positions skipped unread);
 //   mode 3: update new tuple (u cells never allocate: alias or Missing)
 DEV uint32_t tuple_heap_bytes(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, int mode) {
+  if (!s.has_var) return 0;  // fixed-width schema: no cell can reach the heap
   const DevCol* cols = p.cols + s.cols_base;
   CellIt it; it.begin(tuple);
   uint32_t h = 0, next_ident = 0;
@@ -781,91 +841,50 @@ DEV void slot_zero(uint32_t* slot, uint32_t cls) {
 }
 DEV uint32_t get_state(const u8* row, uint32_t i) { return (((const uint32_t*)row)[i >> 4] >> (2 * (i & 15))) & 3u; }
 
-// convert_tuple_to_row (codec/event.rs:554-587) into a full-layout row.
-DEV uint32_t write_full_row(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, u8* row,
-                            uint32_t& hcur) {
-  if (ncells != s.n_cols) return ETLG_E_TUPLE_WIDTH;
-  const DevCol* cols = p.cols + s.cols_base;
-  StateAcc sa{(uint32_t*)row};
-  CellIt it; it.begin(tuple);
-  for (uint32_t i = 0; i < ncells; i++) {
-    const u8* d; uint32_t len;
-    const uint32_t t = it.next(d, len);
-    const DevCol col = cols[i];
-    uint32_t* slot = (uint32_t*)(row + col.off_full);
-    uint32_t st = ETLG_CELL_NULL;
-    if (t == 'n') {  // convert_tuple_data_to_cell, codec/event.rs:945-961
-      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
-      slot_zero(slot, col.cls);
-    } else if (t == 'u') {
-      return ETLG_E_FULL_ROW_MISSING;
-    } else if (t == 't') {
-      const uint32_t err = decode_text_cell(col.cls, d, len, slot, p.heap, hcur, st);
-      if (err) return err;
-    } else {
-      return ETLG_E_BINARY_FORMAT;
-    }
-    sa.put(i, st, i + 1 == ncells);
-  }
-  return 0;
-}
+// One row image out of one tuple. `mode`:
+//   ROW_FULL    convert_tuple_to_row (codec/event.rs:554-587), full layout
+//   ROW_KEY     normalize_key_tuple_to_row (codec/event.rs:795-923), key layout (dense or full-width tuple)
+//   ROW_UPDATE  convert_update_tuple_to_updated_table_row + OldRowResolver (codec/event.rs:605-791):
+//               'u' cells alias the aligned old value (Cell::clone) or become MISSING (Partial)
+// A single body (one inlined copy of the value codec) serves all three.
+enum : uint32_t { ROW_FULL = 0, ROW_KEY = 1, ROW_UPDATE = 2 };
 
-// normalize_key_tuple_to_row (codec/event.rs:795-923) into a key-layout row.
-DEV uint32_t write_key_row(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, u8* row,
-                           uint32_t& hcur) {
-  if (s.n_ident == 0) return ETLG_E_KEY_MISSING_COLS;
-  const bool dense = ncells == s.n_ident;
-  if (!dense && ncells != s.n_cols) return ETLG_E_KEY_SHAPE;
-  const DevCol* cols = p.cols + s.cols_base;
-  StateAcc sa{(uint32_t*)row};
-  CellIt it; it.begin(tuple);
-  uint32_t ci = 0;  // schema column cursor (dense mode walks identity columns only)
-  for (uint32_t i = 0; i < ncells; i++) {
-    const u8* d; uint32_t len;
-    const uint32_t t = it.next(d, len);
-    if (dense) { while (ci < s.n_cols && !cols[ci].identity) ci++; }
-    else { ci = i; if (!cols[ci].identity) continue; }
-    const DevCol col = cols[ci];
-    const uint32_t k = col.key_index;
-    uint32_t* slot = (uint32_t*)(row + col.off_key);
-    uint32_t st = ETLG_CELL_NULL;
-    if (t == 'n') {
-      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
-      slot_zero(slot, col.cls);
-    } else if (t == 'u') {
-      return ETLG_E_KEY_MISSING_VALUE;
-    } else if (t == 't') {
-      const uint32_t err = decode_text_cell(col.cls, d, len, slot, p.heap, hcur, st);
-      if (err) return err;
-    } else {
-      return ETLG_E_BINARY_FORMAT;
-    }
-    sa.put(k, st, k + 1 == s.n_ident);
-    if (dense) ci++;
+DEV uint32_t write_row(const DecParams& p, const DevSlot& s, uint32_t mode, const u8* tuple, uint32_t ncells, u8* row,
+                       uint32_t old_kind, const u8* old_row, uint32_t& hcur, bool& partial) {
+  bool dense = false;
+  if (mode == ROW_KEY) {
+    if (s.n_ident == 0) return ETLG_E_KEY_MISSING_COLS;
+    dense = ncells == s.n_ident;
+    if (!dense && ncells != s.n_cols) return ETLG_E_KEY_SHAPE;
+  } else if (ncells != s.n_cols) {
+    return ETLG_E_TUPLE_WIDTH;
   }
-  return 0;
-}
-
-// convert_update_tuple_to_updated_table_row + OldRowResolver (codec/event.rs:605-791).
-DEV uint32_t write_update_row(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, u8* row,
-                              uint32_t old_kind, const u8* old_row, uint32_t& hcur, bool& partial) {
-  if (ncells != s.n_cols) return ETLG_E_TUPLE_WIDTH;
   const DevCol* cols = p.cols + s.cols_base;
   StateAcc sa{(uint32_t*)row};
   CellIt it; it.begin(tuple);
-  partial = false;
+  uint32_t ci = 0;  // schema column cursor (dense key tuples walk identity columns only)
+  const uint32_t n_out = mode == ROW_KEY ? s.n_ident : s.n_cols;
   // A decoded old row always has exactly n_cols (Full) / n_ident (Key) cells, so the
   // resolver's width checks (codec/event.rs:700-710, 730-740, 772-785) cannot fire here.
   for (uint32_t i = 0; i < ncells; i++) {
     const u8* d; uint32_t len;
     const uint32_t t = it.next(d, len);
-    const DevCol col = cols[i];
-    uint32_t* slot = (uint32_t*)(row + col.off_full);
+    if (mode == ROW_KEY) {
+      if (dense) { while (ci < s.n_cols && !cols[ci].identity) ci++; }
+      else { ci = i; if (!cols[ci].identity) continue; }  // full-width key tuple: other positions are skipped unread
+    } else {
+      ci = i;
+    }
+    const DevCol col = cols[ci];
+    const uint32_t k = mode == ROW_KEY ? col.key_index : i;  // output cell index
+    uint32_t* slot = (uint32_t*)(row + (mode == ROW_KEY ? col.off_key : col.off_full));
     uint32_t st = ETLG_CELL_NULL;
-    if (t == 'n') {
+    if (t == 'n') {  // convert_tuple_data_to_cell, codec/event.rs:945-961
       if (!col.nullable) return ETLG_E_REQUIRED_NULL;
       slot_zero(slot, col.cls);
     } else if (t == 'u') {
+      if (mode == ROW_FULL) return ETLG_E_FULL_ROW_MISSING;
+      if (mode == ROW_KEY) return ETLG_E_KEY_MISSING_VALUE;
       const bool from_full = old_kind == ETLG_OLD_FULL;
       const bool from_key = old_kind == ETLG_OLD_KEY && col.identity;
       if (from_full || from_key) {  // Cell::clone of the aligned old value: alias its slot
@@ -885,7 +904,8 @@ DEV uint32_t write_update_row(const DecParams& p, const DevSlot& s, const u8* tu
     } else {
       return ETLG_E_BINARY_FORMAT;
     }
-    sa.put(i, st, i + 1 == ncells);
+    sa.put(k, st, k + 1 == n_out);
+    if (mode == ROW_KEY && dense) ci++;
   }
   return 0;
 }
@@ -927,8 +947,11 @@ DEV bool frame_structure(const FrameView& v, RowMsg& m) {
 
 // Transaction state machine + ownership + exact output sizes of one frame
 // (apply.rs:2279-2617, 2836-2867). `wire_ok`/`m` come from frame_structure.
+// check_txn = false: the transaction context is not known yet (fused kernel, early
+// sizing); the frame is sized as if inside a transaction and txn_check_frame runs later.
 DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bool wire_ok, const RowMsg& m,
-                    uint32_t& emit, uint32_t& fixed, uint32_t& heap, uint64_t pay[3], int& row_slot) {
+                    uint32_t& emit, uint32_t& fixed, uint32_t& heap, uint64_t pay[3], int& row_slot,
+                    bool check_txn = true) {
   const uint32_t f = v.f, tag = v.tag;
   const u8* b = v.fr + kBodyOff;
   emit = 0; fixed = 0; heap = 0;
@@ -936,8 +959,8 @@ DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bo
   switch (tag) {
     case 'B': emit = 1; fixed = 8; break;
     case 'C':
-      if (!tx.in_txn) record_error(p, f, RK_TXN, ETLG_E_TXN_STATE);
-      else if (ld_be64(b + 1) != tx.final_lsn) record_error(p, f, RK_TXN, ETLG_E_COMMIT_LSN);
+      if (check_txn && !tx.in_txn) record_error(p, f, RK_TXN, ETLG_E_TXN_STATE);
+      else if (check_txn && ld_be64(b + 1) != tx.final_lsn) record_error(p, f, RK_TXN, ETLG_E_COMMIT_LSN);
       else { emit = 1; fixed = 16; }
       break;
     case 'M':
@@ -945,14 +968,14 @@ DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bo
       break;  // host control plane (apply.rs:2160-2276)
     case 'R': {  // handle_relation_message: the event is emitted here, the schema work is the host's
       if (p.flags & 1u) { record_error(p, f, RK_WIRE, ETLG_E_CTRL_HINT); break; }
-      if (!tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
+      if (check_txn && !tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
       const uint32_t rel = ld_be32(b);
       const DevEpoch* ep = epoch_at(p, find_table(p, rel), f);
       if (ep && ep->emit) emit = 1;
       break;
     }
     case 'I': case 'U': case 'D': {
-      if (!tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
+      if (check_txn && !tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
       pay[tag == 'I' ? 0 : tag == 'U' ? 1 : 2] = m.vbytes;  // metrics precede the ownership check
       const int ti = find_table(p, m.rel_id);
       if (!should_apply(p, ti, m.rel_id, tx.final_lsn)) break;
@@ -961,22 +984,18 @@ DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bo
       const DevSlot& s = p.slots[slot];
       row_slot = slot;
       emit = 1;
-      if (tag == 'I') {
-        fixed = s.row_full;
-        heap = tuple_heap_bytes(p, s, m.new_t, m.new_n, 0);
-      } else {
-        if (m.old_kind == ETLG_OLD_FULL) { fixed = s.row_full; heap = tuple_heap_bytes(p, s, m.old_t, m.old_n, 0); }
-        else if (m.old_kind == ETLG_OLD_KEY) {
-          fixed = s.row_key;
-          if (m.old_n == s.n_ident) heap = tuple_heap_bytes(p, s, m.old_t, m.old_n, 1);
-          else if (m.old_n == s.n_cols) heap = tuple_heap_bytes(p, s, m.old_t, m.old_n, 2);
-        }
-        if (tag == 'U') { fixed += s.row_full; heap += tuple_heap_bytes(p, s, m.new_t, m.new_n, 3); }
+      for (uint32_t img = (tag == 'I' || m.old_kind == ETLG_OLD_NONE) ? 1u : 0u; img < (tag == 'D' ? 1u : 2u); img++) {
+        const bool is_new = img == 1;
+        int mode;
+        if (is_new) { fixed += s.row_full; mode = tag == 'U' ? 3 : 0; }
+        else if (m.old_kind == ETLG_OLD_FULL) { fixed += s.row_full; mode = 0; }
+        else { fixed += s.row_key; mode = m.old_n == s.n_ident ? 1 : m.old_n == s.n_cols ? 2 : -1; }
+        if (mode >= 0) heap += tuple_heap_bytes(p, s, is_new ? m.new_t : m.old_t, is_new ? m.new_n : m.old_n, mode);
       }
       break;
     }
     case 'T': {
-      if (!tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
+      if (check_txn && !tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
       const uint32_t nrel = ld_be32(b);
       uint32_t owned = 0;
       for (uint32_t i = 0; i < nrel; i++) {
@@ -991,6 +1010,17 @@ DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bo
       break;
     }
     default: break;  // 'k', 'O', 'Y'
+  }
+}
+
+// The transaction-state checks of size_frame for a frame that was sized early.
+DEV void txn_check_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx) {
+  const uint32_t tag = v.tag;
+  if (tag == 'C') {
+    if (!tx.in_txn) record_error(p, v.f, RK_TXN, ETLG_E_TXN_STATE);
+    else if (ld_be64(v.fr + kBodyOff + 1) != tx.final_lsn) record_error(p, v.f, RK_TXN, ETLG_E_COMMIT_LSN);
+  } else if (tag == 'R' || tag == 'I' || tag == 'U' || tag == 'D' || tag == 'T') {
+    if (!tx.in_txn) record_error(p, v.f, RK_TXN, ETLG_E_TXN_STATE);
   }
 }
 
@@ -1043,19 +1073,18 @@ DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, c
       const DevSlot& s = p.slots[sl];
       uint32_t hcur = (uint32_t)hp_off;
       uint32_t err = 0;
-      if (tag == 'I') {
-        err = write_full_row(p, s, m.new_t, m.new_n, body, hcur);
-      } else {
-        uint32_t old_sz = 0;
-        if (m.old_kind == ETLG_OLD_FULL) { old_sz = s.row_full; err = write_full_row(p, s, m.old_t, m.old_n, body, hcur); }
-        else if (m.old_kind == ETLG_OLD_KEY) { old_sz = s.row_key; err = write_key_row(p, s, m.old_t, m.old_n, body, hcur); }
-        flags = m.old_kind;
-        if (!err && tag == 'U') {
-          bool partial;
-          err = write_update_row(p, s, m.new_t, m.new_n, body + old_sz, m.old_kind, body, hcur, partial);
-          if (partial) flags |= ETLG_FLAG_PARTIAL;
-        }
+      const uint32_t old_sz = m.old_kind == ETLG_OLD_FULL ? s.row_full : m.old_kind == ETLG_OLD_KEY ? s.row_key : 0;
+      if (tag != 'I') flags = m.old_kind;
+      bool partial = false;
+      // image 0 = old / key tuple (U, D), image 1 = new tuple (I, U): one call site for both
+      for (uint32_t img = (tag == 'I' || m.old_kind == ETLG_OLD_NONE) ? 1u : 0u; img < (tag == 'D' ? 1u : 2u) && !err; img++) {
+        const bool is_new = img == 1;
+        const uint32_t mode = is_new ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
+                                     : (m.old_kind == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
+        err = write_row(p, s, mode, is_new ? m.new_t : m.old_t, is_new ? m.new_n : m.old_n,
+                        is_new ? body + old_sz : body, m.old_kind, body, hcur, partial);
       }
+      if (partial) flags |= ETLG_FLAG_PARTIAL;
       if (err) { record_error(p, f, RK_DECODE, err); return; }
       break;
     }

@@ -27,7 +27,7 @@ struct DevSlot {
   uint32_t row_full, row_key;  // bytes, multiples of 4
   uint32_t st_full, st_key;    // state bytes at the head of a row
   uint32_t cols_base;          // index of the first DevCol
-  uint32_t _pad;
+  uint32_t has_var;            // some column may produce a heap entry (var-len / numeric / deferrable class)
 };
 
 // Per-table side input for one batch: ownership state
@@ -67,6 +67,10 @@ struct DevResult {
   uint32_t out_in_txn, n_ctrl;
   uint64_t out_final_lsn, out_next_ord;
   uint32_t fused_fail, _pad;     // a look-back spin gave up (never expected; forces the multi-pass path)
+  unsigned long long dbg_t[12];  // ETLG_FUSED_DBG&8: summed shader-clock cycles per phase (lane 0 of every tile)
+  // fused kernel: payload byte counters sharded by tile id so that no single address
+  // sees more than ntiles/32 atomics; the host folds them into payload[] after the sync
+  unsigned long long pay_shard[32][3];
 };
 
 // Side arguments of the fused single-pass kernel (fused.hip).
@@ -79,7 +83,10 @@ struct FusedParams {
   uint32_t lds_bytes;          // staging capacity per tile (dynamic LDS)
   uint32_t in_aligned;         // input pointer is 16-byte aligned
   uint32_t blk;                // frames per tile (256 or 64)
-  uint32_t dbg, _pad;          // ablation bits (profiling only): 1 no LDS staging, 2 skip writes, 4 skip look-back
+  uint32_t dbg;                // ablation bits (profiling only): 1 no LDS staging, 2 skip writes, 4 skip look-back, 8 phase timers
+  uint32_t seq_lookback;       // 1: ownership needs the transaction's final_lsn (a table is in SyncDone state)
+  uint32_t side_bytes;         // LDS bytes reserved for a copy of the side-input tables (0 = read them from global)
+  uint32_t _pad;
 };
 
 constexpr unsigned long long kNoErr = ~0ull;
@@ -103,6 +110,8 @@ struct DecParams {
   uint64_t final_lsn, next_ord;
   uint32_t host_err_frame;  // frames >= this are ignored (host control plane failed there)
   uint32_t n_tables;
+  uint32_t n_epochs, n_slots, n_cols;  // sizes of the side-input arrays
+  uint32_t _pad0;
   // side inputs
   const DevTable* tables;
   const DevEpoch* epochs;

@@ -25,6 +25,16 @@
 // crates/etl/src/replication/apply.rs:2475-2481), so that path is cold.
 #include "codec.hip.h"
 
+#ifndef ETLG_TICKET
+#define ETLG_TICKET 0      // 1: tile ids from an atomic ticket; 0: blockIdx.x (in-order dispatch; spins are bounded,
+#endif                     //    a give-up falls back to the multi-pass kernels, so correctness never depends on it)
+#ifndef ETLG_MINWAVES
+#define ETLG_MINWAVES 3     // waves per SIMD the register allocator must leave room for
+#endif
+#ifndef ETLG_LB_PARALLEL
+#define ETLG_LB_PARALLEL 1 // run the three independent look-backs on three waves
+#endif
+
 namespace etlg {
 
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_INCL = 2ull << 62, ST_MASK = 3ull << 62;
@@ -51,24 +61,59 @@ struct OpAdd {
   DEV static uint64_t f(uint64_t a, uint64_t b) { return (a + b) & ~ST_MASK; }
 };
 
-// Decoupled look-back executed by ONE wave (all 64 lanes call it). Returns the
-// exclusive prefix of `agg` over tiles [0, tile) combined with `carry`.
+// Two-level decoupled look-back, executed by ONE wave (all 64 lanes call it).
+//
+// Level 0: every tile publishes its aggregate in desc[tile] (status AGG only).
+// Level 1: tiles are grouped by 64; the last tile of a group folds the group's 64
+//          aggregates into gdesc[group] (AGG, then INCL once its own prefix is known).
+// A tile's exclusive prefix = (prefix before its group, from one window over the group
+// descriptors) ⊕ (fold of the earlier tiles of its own group, one window over desc).
+// Both windows are independent of how far the predecessors have progressed beyond
+// publishing their aggregate, so a batch whose tiles all start in lock-step (a grid of a
+// few thousand tiles is only ~3 rounds of the chip) resolves in ~3 memory round trips
+// instead of a 64-tiles-per-round-trip wavefront.
+//
+// Every word carries status + payload in ONE 64-bit value (relaxed agent-scope atomic
+// store / load), so no fence is needed; nothing depends on placement or dispatch order
+// beyond "a tile's predecessors have started" (ticket order); all spins are bounded.
 template <class Op>
-DEV uint64_t lookback(unsigned long long* desc, uint32_t tile, uint64_t agg, uint64_t carry, uint32_t* fail) {
+DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg,
+                      uint64_t carry, uint32_t* fail) {
   const int lane = threadIdx.x & 63;
   if (fail == nullptr) return carry;  // ablation only
-  if (tile == 0) {
-    if (lane == 0) __hip_atomic_store(&desc[0], ST_INCL | Op::f(carry, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return carry;
-  }
+  const uint32_t g = tile >> 6, j = tile & 63;
   if (lane == 0) __hip_atomic_store(&desc[tile], ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint64_t acc = Op::id();  // fold of tiles (base, tile) so far, newest part
-  int64_t base = (int64_t)tile - 1;
   uint32_t polls = 0;
+  // ---- window 0: earlier tiles of this group (lane l <-> tile g*64 + l, l < j)
+  unsigned long long w0 = 0;
+  bool have = (uint32_t)lane >= j;  // lanes >= j have nothing to fetch
+  for (;;) {
+    if (!have) {
+      w0 = __hip_atomic_load(&desc[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      have = (w0 & ST_MASK) != 0;
+    }
+    if (!__ballot(!have)) break;
+    if (++polls > kMaxPolls) { if (lane == 0) atomicOr(fail, 1u); return Op::id(); }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  // ordered fold, lower lane = older: inclusive scan then take lane j-1
+  uint64_t v0 = (uint32_t)lane < j ? (uint64_t)(w0 & ~ST_MASK) : Op::id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(v0, d, 64);
+    if (lane >= d) v0 = Op::f(t, v0);
+  }
+  const uint64_t local = __shfl(v0, 63, 64);  // lanes >= j hold the identity, so lane 63 = fold of [0, j)
+  // the last tile of a full group publishes the group aggregate
+  const uint64_t group_agg = Op::f(local, agg);
+  if (j == 63 && lane == 0) __hip_atomic_store(&gdesc[g], ST_AGG | group_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- window(s) 1: group descriptors before g (lane l <-> group base - l), virtual group -1 = the carry
+  uint64_t acc = Op::id();
+  int64_t base = (int64_t)g - 1;
   for (;;) {
     const int64_t idx = base - lane;
-    unsigned long long w = ST_INCL | carry;  // virtual tile -1: the carried state
-    if (idx >= 0) w = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long w = ST_INCL | carry;
+    if (idx >= 0) w = __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (idx < -1) w = ST_INCL | Op::id();
     const unsigned long long st = w & ST_MASK;
     const unsigned long long m_incl = __ballot(st == ST_INCL);
@@ -80,39 +125,49 @@ DEV uint64_t lookback(unsigned long long* desc, uint32_t tile, uint64_t agg, uin
       __builtin_amdgcn_s_sleep(2);
       continue;
     }
-    // ordered fold of lanes [0, last] (higher lane = older tile): older ⊕ newer
     const int last = first_incl < 64 ? first_incl : 63;
     uint64_t v = lane <= last ? (uint64_t)(w & ~ST_MASK) : Op::id();
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < 64; d <<= 1) {  // higher lane = older group: older ⊕ newer
       const uint64_t t = __shfl_down(v, d, 64);
       if (lane + d < 64) v = Op::f(t, v);
     }
-    const uint64_t window = __shfl(v, 0, 64);
-    acc = Op::f(window, acc);
+    acc = Op::f(__shfl(v, 0, 64), acc);
     if (first_incl < 64) break;
     base -= 64;
   }
-  if (lane == 0) __hip_atomic_store(&desc[tile], ST_INCL | Op::f(acc, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return acc;
+  if (j == 63 && lane == 0) __hip_atomic_store(&gdesc[g], ST_INCL | Op::f(acc, group_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return Op::f(acc, local);
 }
+
+#define TSTAMP(k) do { if ((q.dbg & 8) && threadIdx.x == 0) { const unsigned long long _t = clock64(); atomicAdd(&p.res->dbg_t[k], _t - s64[7]); s64[7] = _t; } } while (0)
 
 DEV uint32_t seg_pack30(uint32_t seg) { return ((seg >> 31) << 29) | (seg & 0x1FFFFFFFu); }
 DEV uint32_t seg_unpack30(uint32_t s30) { return ((s30 >> 29) << 31) | (s30 & 0x1FFFFFFFu); }
+
+// In the fused kernel the transaction mark of a B / C frame carries the frame's BYTE
+// offset ((o0 + 1) << 1 | isBegin, batches < 2 GiB), so the Begin's final_lsn is one load away.
+DEV uint64_t final_lsn_of_mark(const DecParams& p, uint32_t mark) {
+  return mark == 1u ? p.final_lsn : ld_be64(p.in + ((mark >> 1) - 1) + kBodyOff);
+}
 
 // Everything after staging; `base` points at byte `win0` of the input (LDS or global).
 template <int BLK>
 DEV void tile_body(const DecParams& p, const FusedParams& q, uint32_t tile, uint32_t nt, const uint32_t* s_offs,
                    const u8* base, uint32_t win0, uint32_t* s32, uint64_t* s64) {
   const uint32_t tid = threadIdx.x;
+  const int wave = tid >> 6;
   const bool live = tid < nt;
   const uint32_t f = tile * BLK + tid;
-  // ---- phase 1: envelope, tag, structure
+  uint32_t* fail = (q.dbg & 4) ? nullptr : &p.res->fused_fail;
+  // ---- phase 1: envelope, tag, structure (field-length decode of every tuple)
   FrameView v{f, 0, base, base};
   RowMsg m;
   bool wire_ok = true;
+  uint32_t o0 = 0;
   if (live) {
-    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
+    o0 = s_offs[tid];
+    const uint32_t o1 = s_offs[tid + 1];
     if (o1 > o0 && o1 <= p.in_len) {
       v.fr = base + (o0 - win0);
       v.e = base + (o1 - win0);
@@ -120,92 +175,142 @@ DEV void tile_body(const DecParams& p, const FusedParams& q, uint32_t tile, uint
     }
     wire_ok = frame_structure(v, m);
   }
+  TSTAMP(2);
   uint32_t cnt = 0, mark = 0;
   if (live) {
     if (consumes_ordinal(v.tag)) cnt = 1;
-    if (v.tag == 'B') { cnt |= 0x80000000u; mark = ((f + 1) << 1) | 1; }
-    if (v.tag == 'C') mark = (f + 1) << 1;
+    if (v.tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
+    if (v.tag == 'C') mark = (o0 + 1) << 1;
   }
-  uint32_t tot_cnt, tot_mark;
-  const uint32_t ic = block_scan_incl<2>(cnt, s32, &tot_cnt);
-  const uint32_t im = block_scan_incl<1>(mark, s32 + 4, &tot_mark);
-  uint32_t pm = __shfl_up(im, 1, 64);
-  if ((tid & 63) == 63) s32[8 + (tid >> 6)] = im;
-  __syncthreads();
-  if ((tid & 63) == 0) pm = tid ? s32[8 + (tid >> 6) - 1] : 0;
-  // ---- look-back 1: transaction state
-  if (tid < 64) {
-    const uint64_t agg = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark;
-    const uint64_t carry = (uint64_t)(p.in_txn ? 1u : 0u);  // virtual Begin before frame 0; seg identity
-    const uint64_t ex = lookback<OpTxn>(q.d_txn, tile, agg, carry, (q.dbg & 4) ? nullptr : &p.res->fused_fail);
-    if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
-  }
-  __syncthreads();
-  const uint32_t bc = s32[12], bm = s32[13];
-  const uint32_t seg = seg_combine(bc, ic);
-  const uint32_t last = bm > pm ? bm : pm;
-  TxnCtx tx;
-  tx.in_txn = (last & 1u) != 0;
-  tx.final_lsn = 0;
-  if (tx.in_txn) tx.final_lsn = last == 1u ? p.final_lsn : ld_be64(p.in + p.offs[(last >> 1) - 1] + kBodyOff);
-  {
+  uint32_t seg_in, pm, tot_cnt, tot_mark;
+  block_scan_txn(cnt, mark, s32, seg_in, pm, tot_cnt, tot_mark);
+  TSTAMP(3);
+  const uint64_t txn_agg = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark;
+  const uint64_t txn_carry = (uint64_t)(p.in_txn ? 1u : 0u);  // virtual Begin before frame 0; seg identity
+  TxnCtx tx{true, 0, 0};
+  uint32_t bc = 0, bm = 0;
+  auto make_tx = [&]() {
+    bc = s32[12]; bm = s32[13];
+    const uint32_t seg = seg_combine(bc, seg_in);
+    const uint32_t last = bm > pm ? bm : pm;
+    tx.in_txn = (last & 1u) != 0;
+    tx.final_lsn = tx.in_txn ? final_lsn_of_mark(p, last) : 0;
     const uint64_t c = seg & 0x7FFFFFFFu;
     tx.ord = (seg & 0x80000000u) ? c - 1 : p.next_ord + c - 1;
+  };
+  if (q.seq_lookback) {
+    // ownership depends on the transaction's final_lsn (a table is SyncDone): transaction state first
+    if (wave == 0) {
+      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
+      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+    }
+    __syncthreads();
+    make_tx();
   }
-  // ---- phase 2: sizes
+  TSTAMP(4);
+  // ---- phase 2: exact output sizes
   uint32_t emit = 0, fixed = 0, heap = 0;
   uint64_t pay[3] = {0, 0, 0};
   int row_slot = -1;
-  if (live) size_frame(p, v, tx, wire_ok, m, emit, fixed, heap, pay, row_slot);
-  uint64_t tot_ev, tot_fx, tot_hp;
-  const uint64_t x_ev = block_scan_excl64(emit, s64, &tot_ev);
-  const uint64_t x_fx = block_scan_excl64(fixed, s64, &tot_fx);
-  const uint64_t x_hp = block_scan_excl64(heap, s64, &tot_hp);
-  const uint64_t p0 = block_sum64(pay[0], s64), p1 = block_sum64(pay[1], s64), p2 = block_sum64(pay[2], s64);
-  // ---- look-back 2: output positions
-  if (tid < 64) {
-    const uint64_t a = lookback<OpAdd2>(q.d_outa, tile, (tot_ev << 32) | (uint32_t)(tot_hp >> 2), 0, (q.dbg & 4) ? nullptr : &p.res->fused_fail);
-    const uint64_t b = lookback<OpAdd>(q.d_outb, tile, tot_fx >> 2, 0, (q.dbg & 4) ? nullptr : &p.res->fused_fail);
+  if (live) size_frame(p, v, tx, wire_ok, m, emit, fixed, heap, pay, row_slot, q.seq_lookback != 0);
+  TSTAMP(5);
+  uint32_t x_ev = emit, x_fx = fixed >> 2, x_hp = heap >> 2, tot3[3];
+  block_scan3_excl(x_ev, x_fx, x_hp, s32, tot3);
+  {  // payload byte counters (A3): workgroup reduce through LDS, then one atomic per tile and
+     // counter into a shard (a single hot address would serialise thousands of atomics in L2)
+    uint64_t a0 = pay[0], a1 = pay[1], a2 = pay[2];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a0 += __shfl_xor(a0, d, 64); a1 += __shfl_xor(a1, d, 64); a2 += __shfl_xor(a2, d, 64); }
+    if ((tid & 63) == 0) {  // s64[0..3] is free here: block_scan3_excl only used s32
+      if (a0) atomicAdd((unsigned long long*)&s64[0], (unsigned long long)a0);
+      if (a1) atomicAdd((unsigned long long*)&s64[1], (unsigned long long)a1);
+      if (a2) atomicAdd((unsigned long long*)&s64[2], (unsigned long long)a2);
+    }
+  }
+  TSTAMP(6);
+  // ---- look-back: output positions (and the transaction state when it was not needed earlier);
+  //      independent prefixes run on different waves so their latencies overlap
+  const uint64_t agg_a = ((uint64_t)tot3[0] << 32) | tot3[2];
+  const uint64_t agg_b = tot3[1];
+  if (BLK >= 192 && ETLG_LB_PARALLEL) {
+    if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail); if (tid == 0) s64[4] = a; }
+    if (wave == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail); if ((tid & 63) == 0) s64[5] = b; }
+    if (wave == 2 && !q.seq_lookback) {
+      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
+      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+    }
+  } else if (wave == 0) {
+    const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
+    const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
     if (tid == 0) { s64[4] = a; s64[5] = b; }
+    if (!q.seq_lookback) {
+      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
+      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+    }
   }
   __syncthreads();
+  if (tid < 3 && s64[tid]) atomicAdd(&p.res->pay_shard[tile & 31][tid], (unsigned long long)s64[tid]);
+  TSTAMP(7);
+  if (!q.seq_lookback) {
+    make_tx();
+    if (live && wire_ok) txn_check_frame(p, v, tx);
+  }
   const uint64_t pre_ev = s64[4] >> 32, pre_hp = (uint64_t)(uint32_t)s64[4] << 2, pre_fx = s64[5] << 2;
-  if (tid == 0) {
-    if (p0) atomicAdd((unsigned long long*)&p.res->payload[0], (unsigned long long)p0);
-    if (p1) atomicAdd((unsigned long long*)&p.res->payload[1], (unsigned long long)p1);
-    if (p2) atomicAdd((unsigned long long*)&p.res->payload[2], (unsigned long long)p2);
-    if (tile == q.ntiles - 1) {  // the last tile knows the totals and the carried transaction state
-      DevResult* r = p.res;
-      r->n_events = pre_ev + tot_ev; r->fixed_bytes = pre_fx + tot_fx; r->heap_bytes = pre_hp + tot_hp;
-      r->n_frames = p.nframes;
-      const uint32_t sg = seg_combine(bc, tot_cnt);
-      const uint32_t lm = bm > tot_mark ? bm : tot_mark;
-      const bool it = (lm & 1u) != 0;
-      r->out_in_txn = it;
-      r->out_final_lsn = it ? (lm == 1u ? p.final_lsn : ld_be64(p.in + p.offs[(lm >> 1) - 1] + kBodyOff)) : 0;
-      const uint64_t c = sg & 0x7FFFFFFFu;
-      r->out_next_ord = (sg & 0x80000000u) ? c : p.next_ord + c;
-    }
+  if (tid == 0 && tile == q.ntiles - 1) {  // the last tile knows the totals and the carried transaction state
+    DevResult* r = p.res;
+    r->n_events = pre_ev + tot3[0]; r->fixed_bytes = pre_fx + ((uint64_t)tot3[1] << 2); r->heap_bytes = pre_hp + ((uint64_t)tot3[2] << 2);
+    r->n_frames = p.nframes;
+    const uint32_t sg = seg_combine(bc, tot_cnt);
+    const uint32_t lm = bm > tot_mark ? bm : tot_mark;
+    const bool it = (lm & 1u) != 0;
+    r->out_in_txn = it;
+    r->out_final_lsn = it ? final_lsn_of_mark(p, lm) : 0;
+    const uint64_t c = sg & 0x7FFFFFFFu;
+    r->out_next_ord = (sg & 0x80000000u) ? c : p.next_ord + c;
   }
   // ---- phase 3: decode + write
   if (!emit) return;
-  const uint64_t ev_idx = pre_ev + x_ev, fx_off = pre_fx + x_fx, hp_off = pre_hp + x_hp;
+  const uint64_t ev_idx = pre_ev + x_ev, fx_off = pre_fx + ((uint64_t)x_fx << 2), hp_off = pre_hp + ((uint64_t)x_hp << 2);
   if (fx_off + fixed > p.fixed_cap || hp_off + heap > p.heap_cap || hp_off + heap > 0xFFFFFFFFull) {
     record_error(p, f, RK_DECODE, ETLG_E_WIRE);
     return;
   }
   if (q.dbg & 2) return;
   write_frame(p, v, tx, m, row_slot, ev_idx, fx_off, hp_off);
+  TSTAMP(8);
 }
 
 template <int BLK>
-__global__ __launch_bounds__(BLK) void k_fused(DecParams p, FusedParams q) {
+__global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams p, FusedParams q) {
   extern __shared__ __attribute__((aligned(16))) u8 smem[];
   __shared__ uint32_t s_offs[BLK + 1];
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
   const uint32_t tid = threadIdx.x;
+  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
+  if (tid < 3) s64[tid] = 0;  // per-tile payload accumulators
+#if ETLG_TICKET
   if (tid == 0) s32[15] = atomicAdd(q.ticket, 1u);
+#else
+  if (tid == 0) s32[15] = blockIdx.x;
+#endif
+  // copy the (tiny) side-input tables into LDS while the ticket is in flight: every
+  // later lookup is then an LDS read instead of a chain of dependent global loads
+  if (q.side_bytes) {
+    const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
+    const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
+    uint32_t* d = (uint32_t*)smem;
+    for (uint32_t i = tid; i < nt4; i += BLK) d[i] = ((const uint32_t*)p.tables)[i];
+    d += nt4;
+    for (uint32_t i = tid; i < ne4; i += BLK) d[i] = ((const uint32_t*)p.epochs)[i];
+    d += ne4;
+    for (uint32_t i = tid; i < ns4; i += BLK) d[i] = ((const uint32_t*)p.slots)[i];
+    d += ns4;
+    for (uint32_t i = tid; i < nc4; i += BLK) d[i] = ((const uint32_t*)p.cols)[i];
+    uint32_t* b0 = (uint32_t*)smem;
+    p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
+    p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
+  }
   __syncthreads();
   const uint32_t tile = s32[15];
   if (tile >= q.ntiles) return;
@@ -213,6 +318,8 @@ __global__ __launch_bounds__(BLK) void k_fused(DecParams p, FusedParams q) {
   const uint32_t nt = p.nframes - f0 < (uint32_t)BLK ? p.nframes - f0 : (uint32_t)BLK;
   for (uint32_t i = tid; i <= nt; i += BLK) s_offs[i] = p.offs[f0 + i];
   __syncthreads();
+  TSTAMP(0);
+  u8* stage = smem + q.side_bytes;
   const uint32_t span0 = s_offs[0], span1 = s_offs[nt];
   // every well-formed frame of the tile must lie inside [span0, span1) to be staged
   bool lane_ok = true;
@@ -221,16 +328,17 @@ __global__ __launch_bounds__(BLK) void k_fused(DecParams p, FusedParams q) {
     lane_ok = o1 <= o0 || o1 > p.in_len || (o0 >= span0 && o1 <= span1);
   }
   const uint32_t a0 = span0 & ~15u;
-  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 16 <= q.lds_bytes;
+  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 16 <= q.lds_bytes - q.side_bytes;
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok && !(q.dbg & 1);
   if (use_lds) {
     // coalesced staging: 16 B per lane per step; the tail that would cross in_len goes bytewise
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);  // last full 16-byte chunk boundary <= span1
     for (uint32_t c = a0 + 16 * tid; c < full_end; c += 16 * BLK)
-      *(uint4*)(smem + (c - a0)) = *(const uint4*)(p.in + c);
-    for (uint32_t c = full_end + tid; c < span1; c += BLK) smem[c - a0] = p.in[c];
+      *(uint4*)(stage + (c - a0)) = *(const uint4*)(p.in + c);
+    for (uint32_t c = full_end + tid; c < span1; c += BLK) stage[c - a0] = p.in[c];
     __syncthreads();
-    tile_body<BLK>(p, q, tile, nt, s_offs, smem, a0, s32, s64);
+    TSTAMP(1);
+    tile_body<BLK>(p, q, tile, nt, s_offs, stage, a0, s32, s64);
   } else {
     tile_body<BLK>(p, q, tile, nt, s_offs, p.in, 0, s32, s64);
   }

@@ -187,10 +187,12 @@ struct etlg_ctx {
   // device scratch (grow-only)
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
   FusedParams fq{};
+  uint32_t n_dev_slots = 0, n_dev_cols = 0;
   std::vector<DevTable> last_tables;   // what d_tables / d_epochs currently hold
   std::vector<DevEpoch> last_epochs;
   bool side_valid = false;
   bool force_multipass = false;  // ETLG_FORCE_MULTIPASS=1 (tests exercise both paths)
+  unsigned long long last_dbg[12] = {0};
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
   DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
@@ -630,6 +632,10 @@ hipError_t sync_slots(etlg_ctx* c) {
     d.n_cols = s->desc.n_cols; d.n_ident = s->desc.n_ident; d.row_full = s->desc.row_bytes_full; d.row_key = s->desc.row_bytes_key;
     d.st_full = s->desc.state_bytes_full; d.st_key = s->desc.state_bytes_key; d.cols_base = (uint32_t)dc.size();
     for (auto& sc : s->cols) {
+      const int32_t k = sc.type_class;
+      if (!(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32 || k == ETLG_TC_UUID)) d.has_var = 1;
+    }
+    for (auto& sc : s->cols) {
       DevCol x{};
       x.cls = sc.type_class; x.nullable = sc.nullable; x.identity = sc.identity; x.off_full = sc.off_full; x.off_key = sc.off_key; x.key_index = sc.key_index;
       dc.push_back(x);
@@ -643,6 +649,7 @@ hipError_t sync_slots(etlg_ctx* c) {
   // the staging vectors die at scope exit: make the copies land first
   e = hipStreamSynchronize(c->stream);
   c->slots_dirty = false;
+  c->n_dev_slots = (uint32_t)ds.size(); c->n_dev_cols = (uint32_t)dc.size();
   return e;
 }
 
@@ -820,6 +827,13 @@ int32_t etlg_ctx_slots(const etlg_ctx* c, uint32_t* n, const etlg_slot_desc** sl
   return ETLG_OK;
 }
 
+// debugging aid (not part of etlg.h): per-phase cycle sums of the last finished batch
+int32_t etlg_ctx_debug_times(etlg_ctx* c, unsigned long long* out12) {
+  if (!c || !out12) return ETLG_InvalidArgument;
+  for (int i = 0; i < 12; i++) out12[i] = c->last_dbg[i];
+  return ETLG_OK;
+}
+
 int32_t etlg_ctx_profile(etlg_ctx* c, int32_t enable) {
   if (!c) return ETLG_InvalidArgument;
   c->prof = enable != 0;
@@ -952,6 +966,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   b->host_err_code = herr.code; b->host_err_frame = herr_frame; b->host_err_rank = herr.rank;
 
   // ---- side inputs: table states + cache timeline
+  bool any_sync_done = false;
   {
     std::map<uint32_t, DevTable> tabs;
     auto get = [&](uint32_t id) -> DevTable& {
@@ -984,9 +999,13 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
       c->last_tables = tv; c->last_epochs = ev; c->side_valid = true;
     }
     p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)tv.size();
+    p.n_epochs = (uint32_t)ev.size();
+    any_sync_done = false;
+    for (auto& t : tv) if (t.state_kind == ETLG_TS_SYNC_DONE) any_sync_done = true;
   }
   HIPCHK(c, sync_slots(c));
   p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
+  p.n_slots = c->n_dev_slots; p.n_cols = c->n_dev_cols;
 
   // ---- outputs (capacity bounds: one event per frame; rows bounded by the widest slot;
   //      truncate bodies by 2x frame bytes; heap by 2.5x input)
@@ -1006,22 +1025,29 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
 
   const bool classify_done = !no_ctrl && nf != 0;  // k_classify / k_scan_txn already ran for the control list
   b->params = p;
-  if (nf && !herr.code && !c->force_multipass) {
+  if (nf && !herr.code && !c->force_multipass && len < (1ull << 31)) {
     // ---- fast path: fused single-pass kernel (fused.hip)
     const uint64_t avg = (len + nf - 1) / nf;
     FusedParams& q = c->fq;
     q.blk = avg <= 192 ? 256u : 64u;
     uint64_t cap = q.blk == 256 ? (uint64_t)q.blk * avg * 9 / 8 + 1024 : (uint64_t)q.blk * avg * 5 / 4 + 2048;
     cap = std::min<uint64_t>((cap + 255) & ~255ull, 150 * 1024);
+    const uint64_t side = (uint64_t)p.n_tables * sizeof(DevTable) + (uint64_t)p.n_epochs * sizeof(DevEpoch) +
+                          (uint64_t)p.n_slots * sizeof(DevSlot) + (uint64_t)p.n_cols * sizeof(DevCol);
+    q.side_bytes = (side <= 8192 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
+    cap = std::min<uint64_t>(cap + q.side_bytes, 150 * 1024);
     q.lds_bytes = (uint32_t)cap;
+    q.seq_lookback = (any_sync_done || (c->fused_dbg & 32)) ? 1u : 0u;
     q.ntiles = (nf + q.blk - 1) / q.blk;
     q.in_aligned = ((uintptr_t)p.in & 15) == 0;
     q.dbg = c->fused_dbg;
-    const size_t dbytes = (size_t)q.ntiles * 8 * 3 + 64;
+    const size_t ngroups = (q.ntiles + 63) / 64;
+    const size_t per = (size_t)q.ntiles + ngroups;  // tile descriptors followed by group descriptors
+    const size_t dbytes = per * 8 * 3 + 64;
     HIPCHK(c, c->d_desc.ensure(dbytes));
     HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, dbytes, s));
-    q.d_txn = (unsigned long long*)c->d_desc.p; q.d_outa = q.d_txn + q.ntiles; q.d_outb = q.d_outa + q.ntiles;
-    q.ticket = (uint32_t*)(q.d_outb + q.ntiles);
+    q.d_txn = (unsigned long long*)c->d_desc.p; q.d_outa = q.d_txn + per; q.d_outb = q.d_outa + per;
+    q.ticket = (uint32_t*)(q.d_outb + per);
     launch(c, kFused, p);
     b->used_fused = true;
   } else {
@@ -1119,7 +1145,9 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
     HIPCHK(c, hipStreamSynchronize(s));
     b->used_fused = false;
   }
-  const DevResult r = *b->h_res;
+  DevResult r = *b->h_res;
+  if (b->used_fused) for (int k = 0; k < 3; k++) { r.payload[k] = 0; for (int sh = 0; sh < 32; sh++) r.payload[k] += r.pay_shard[sh][k]; }
+  for (int i = 0; i < 12; i++) c->last_dbg[i] = r.dbg_t[i];
   c->res_pool.push_back(b->h_res);
   b->h_res = nullptr;
   // ---- first error: device (frame, rank) vs host control plane (frame, rank)

@@ -10,7 +10,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libetl_gfx950.so")
+LIB_PATH = os.environ.get("ETLG_LIB_PATH") or os.path.join(_HERE, "libetl_gfx950.so")
 
 # every symbol include/etlg.h declares
 EXPORTS = [
