@@ -408,6 +408,49 @@ DEV bool parse_int(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& o
   return true;
 }
 
+// SWAR variant for callers that may read up to 7 bytes past the text (LDS-staged tiles
+// keep 16 bytes of slack): 8 ASCII digits per step, no per-character loop.
+DEV bool swar_digits8(const u8* s, uint32_t n /* 1..8 */, uint32_t& out) {
+  uint64_t x; __builtin_memcpy(&x, s, 8);
+  if (n < 8) x = (x << (8 * (8 - n))) | (0x3030303030303030ull >> (8 * n));  // left-pad with '0'
+  const uint64_t t = x - 0x3030303030303030ull;
+  if (((x + 0x4646464646464646ull) | t) & 0x8080808080808080ull) return false;  // a byte outside '0'..'9'
+  uint64_t v = (t * 10) + (t >> 8);
+  const uint64_t mask = 0x000000FF000000FFull;
+  v = (((v & mask) * 0x000F424000000064ull) + (((v >> 16) & mask) * 0x0000271000000001ull)) >> 32;
+  out = (uint32_t)v;
+  return true;
+}
+DEV bool parse_int_swar(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& out) {
+  if (n == 0) return false;
+  bool neg = false;
+  const uint32_t c0 = s[0];
+  if (c0 == '+' || c0 == '-') {
+    if (n == 1) return false;
+    if (c0 == '-') { if (!is_signed) return false; neg = true; }
+    s++; n--;
+  }
+  if (n > 19) return parse_int(neg || c0 == '+' ? s - 1 : s, neg || c0 == '+' ? n + 1 : n, is_signed, bits, out);  // long (leading zeros)
+  uint32_t lo = 0, mid = 0, hi = 0;
+  uint64_t mag;
+  if (n <= 8) {
+    if (!swar_digits8(s, n, lo)) return false;
+    mag = lo;
+  } else if (n <= 16) {
+    if (!swar_digits8(s, n - 8, mid) || !swar_digits8(s + (n - 8), 8, lo)) return false;
+    mag = (uint64_t)mid * 100000000ull + lo;
+  } else {
+    if (!swar_digits8(s, n - 16, hi) || !swar_digits8(s + (n - 16), 8, mid) || !swar_digits8(s + (n - 8), 8, lo)) return false;
+    mag = ((uint64_t)hi * 100000000ull + mid) * 100000000ull + lo;
+  }
+  uint64_t lim;
+  if (is_signed) lim = neg ? (1ull << (bits - 1)) : (1ull << (bits - 1)) - 1;
+  else lim = bits == 64 ? ~0ull : (1ull << bits) - 1;
+  if (mag > lim) return false;
+  out = neg ? (int64_t)(0 - mag) : (int64_t)mag;
+  return true;
+}
+
 // PgNumeric::from_str (crates/etl-postgres/src/numeric.rs:108-135, 246-267,
 // 276-396) + the group arithmetic of convert_to_base_10000 (:404-458).
 struct NumShape {
@@ -697,7 +740,7 @@ DEV void heap_copy(u8* dst, const u8* src, uint32_t n) {
 // slot words / heap entry. Returns 0 or an etlg_err_code; `state` = cell state.
 DEV uint32_t slot_bytes(uint32_t cls);
 DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t* slot, u8* heap, uint32_t& hcur,
-                              uint32_t& state) {
+                              uint32_t& state, bool over = false) {
   // str::from_utf8 precedes the type switch (codec/event.rs:976). Every non-text grammar below
   // accepts ASCII only, so for those classes validity is only examined when the parse fails
   // (to pick between the UTF-8 error and the type's own error) or before a cell is deferred.
@@ -718,10 +761,10 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
     case ETLG_TC_BOOL:  // parse_bool, codec/bool.rs:11-19
       if (len == 1 && (d[0] == 't' || d[0] == 'f')) { slot[0] = d[0] == 't'; return 0; }
       return bad(ETLG_E_BOOL);
-    case ETLG_TC_I16: { int64_t v; if (!parse_int(d, len, true, 16, v)) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_I32: { int64_t v; if (!parse_int(d, len, true, 32, v)) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_U32: { int64_t v; if (!parse_int(d, len, false, 32, v)) return bad(ETLG_E_INT); slot[0] = (uint32_t)v; return 0; }
-    case ETLG_TC_I64: { int64_t v; if (!parse_int(d, len, true, 64, v)) return bad(ETLG_E_INT); st64(slot, (uint64_t)v); return 0; }
+    case ETLG_TC_I16: { int64_t v; if (!(over ? parse_int_swar(d, len, true, 16, v) : parse_int(d, len, true, 16, v))) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
+    case ETLG_TC_I32: { int64_t v; if (!(over ? parse_int_swar(d, len, true, 32, v) : parse_int(d, len, true, 32, v))) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
+    case ETLG_TC_U32: { int64_t v; if (!(over ? parse_int_swar(d, len, false, 32, v) : parse_int(d, len, false, 32, v))) return bad(ETLG_E_INT); slot[0] = (uint32_t)v; return 0; }
+    case ETLG_TC_I64: { int64_t v; if (!(over ? parse_int_swar(d, len, true, 64, v) : parse_int(d, len, true, 64, v))) return bad(ETLG_E_INT); st64(slot, (uint64_t)v); return 0; }
     case ETLG_TC_NUMERIC: {
       NumShape s;
       if (!numeric_scan(d, len, s)) return bad(ETLG_E_NUMERIC);
@@ -850,7 +893,7 @@ DEV uint32_t get_state(const u8* row, uint32_t i) { return (((const uint32_t*)ro
 enum : uint32_t { ROW_FULL = 0, ROW_KEY = 1, ROW_UPDATE = 2 };
 
 DEV uint32_t write_row(const DecParams& p, const DevSlot& s, uint32_t mode, const u8* tuple, uint32_t ncells, u8* row,
-                       uint32_t old_kind, const u8* old_row, uint32_t& hcur, bool& partial) {
+                       uint32_t old_kind, const u8* old_row, uint32_t& hcur, bool& partial, bool over = false) {
   bool dense = false;
   if (mode == ROW_KEY) {
     if (s.n_ident == 0) return ETLG_E_KEY_MISSING_COLS;
@@ -899,13 +942,52 @@ DEV uint32_t write_row(const DecParams& p, const DevSlot& s, uint32_t mode, cons
         partial = true;
       }
     } else if (t == 't') {
-      const uint32_t err = decode_text_cell(col.cls, d, len, slot, p.heap, hcur, st);
+      const uint32_t err = decode_text_cell(col.cls, d, len, slot, p.heap, hcur, st, over);
       if (err) return err;
     } else {
       return ETLG_E_BINARY_FORMAT;
     }
     sa.put(k, st, k + 1 == n_out);
     if (mode == ROW_KEY && dense) ci++;
+  }
+  return 0;
+}
+
+// convert_tuple_to_row for a wave whose active lanes ALL decode an INSERT of the same
+// schema slot with the same column count (the common case). `slot_u` / `n` are wave-uniform
+// (SGPRs): the column descriptors come through the scalar cache, the loop trip count and
+// the per-column class dispatch are scalar branches, and only the data-dependent work
+// (cell tag, length, characters) stays per lane. `pg` must hold GLOBAL side-table pointers.
+DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const u8* tuple, uint32_t n, u8* row,
+                                    uint32_t& hcur, bool over) {
+  const DevSlot s = pg.slots[slot_u];
+  if (n != s.n_cols) return ETLG_E_TUPLE_WIDTH;
+  const DevCol* cols = pg.cols + s.cols_base;
+  const u8* c = tuple + 2;
+  uint32_t acc = 0;
+  uint32_t* stw = (uint32_t*)row;
+  for (uint32_t i = 0; i < n; i++) {
+    const DevCol col = cols[i];
+    const uint32_t cls = col.cls;
+    uint32_t* slot = (uint32_t*)(row + col.off_full);
+    const uint32_t t = *c++;
+    uint32_t st = ETLG_CELL_NULL;
+    if (t == 't') {
+      const uint32_t len = ld_be32(c);
+      c += 4;
+      const uint32_t err = decode_text_cell(cls, c, len, slot, pg.heap, hcur, st, over);
+      if (err) return err;
+      c += len;
+    } else if (t == 'n') {
+      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
+      slot_zero(slot, cls);
+    } else if (t == 'u') {
+      return ETLG_E_FULL_ROW_MISSING;
+    } else {
+      return ETLG_E_BINARY_FORMAT;
+    }
+    acc |= st << (2 * (i & 15));
+    if ((i & 15) == 15 || i + 1 == n) { stw[i >> 4] = acc; acc = 0; }
   }
   return 0;
 }
@@ -1025,8 +1107,10 @@ DEV void txn_check_frame(const DecParams& p, const FrameView& v, const TxnCtx& t
 }
 
 // Decodes one emitting frame into the arena at (ev_idx, fx_off, hp_off).
+// `pu` (optional): the same parameters with GLOBAL side-table pointers, enabling the
+// wave-uniform INSERT path; `over`: the frame bytes may be over-read by up to 7 bytes.
 DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, const RowMsg& m, int row_slot,
-                     uint64_t ev_idx, uint64_t fx_off, uint64_t hp_off) {
+                     uint64_t ev_idx, uint64_t fx_off, uint64_t hp_off, const DecParams* pu = nullptr, bool over = false) {
   const uint32_t f = v.f, tag = v.tag;
   const u8* fr = v.fr;
   const u8* b = fr + kBodyOff;
@@ -1070,19 +1154,25 @@ DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, c
       table = m.rel_id;
       const int sl = row_slot >= 0 ? row_slot : cache_slot_before(p, find_table(p, m.rel_id), f);
       slot_id = (uint32_t)sl;
-      const DevSlot& s = p.slots[sl];
       uint32_t hcur = (uint32_t)hp_off;
       uint32_t err = 0;
-      const uint32_t old_sz = m.old_kind == ETLG_OLD_FULL ? s.row_full : m.old_kind == ETLG_OLD_KEY ? s.row_key : 0;
-      if (tag != 'I') flags = m.old_kind;
       bool partial = false;
-      // image 0 = old / key tuple (U, D), image 1 = new tuple (I, U): one call site for both
-      for (uint32_t img = (tag == 'I' || m.old_kind == ETLG_OLD_NONE) ? 1u : 0u; img < (tag == 'D' ? 1u : 2u) && !err; img++) {
-        const bool is_new = img == 1;
-        const uint32_t mode = is_new ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
-                                     : (m.old_kind == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
-        err = write_row(p, s, mode, is_new ? m.new_t : m.old_t, is_new ? m.new_n : m.old_n,
-                        is_new ? body + old_sz : body, m.old_kind, body, hcur, partial);
+      const uint32_t sl_u = __builtin_amdgcn_readfirstlane((uint32_t)sl);
+      const uint32_t n_u = __builtin_amdgcn_readfirstlane(m.new_n);
+      if (pu && __all(tag == 'I' && (uint32_t)sl == sl_u && m.new_n == n_u)) {
+        err = write_full_row_uniform(*pu, sl_u, m.new_t, n_u, body, hcur, over);
+      } else {
+        const DevSlot& s = p.slots[sl];
+        const uint32_t old_sz = m.old_kind == ETLG_OLD_FULL ? s.row_full : m.old_kind == ETLG_OLD_KEY ? s.row_key : 0;
+        if (tag != 'I') flags = m.old_kind;
+        // image 0 = old / key tuple (U, D), image 1 = new tuple (I, U): one call site for both
+        for (uint32_t img = (tag == 'I' || m.old_kind == ETLG_OLD_NONE) ? 1u : 0u; img < (tag == 'D' ? 1u : 2u) && !err; img++) {
+          const bool is_new = img == 1;
+          const uint32_t mode = is_new ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
+                                       : (m.old_kind == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
+          err = write_row(p, s, mode, is_new ? m.new_t : m.old_t, is_new ? m.new_n : m.old_n,
+                          is_new ? body + old_sz : body, m.old_kind, body, hcur, partial, over);
+        }
       }
       if (partial) flags |= ETLG_FLAG_PARTIAL;
       if (err) { record_error(p, f, RK_DECODE, err); return; }

@@ -29,7 +29,7 @@
 #define ETLG_TICKET 0      // 1: tile ids from an atomic ticket; 0: blockIdx.x (in-order dispatch; spins are bounded,
 #endif                     //    a give-up falls back to the multi-pass kernels, so correctness never depends on it)
 #ifndef ETLG_MINWAVES
-#define ETLG_MINWAVES 3     // waves per SIMD the register allocator must leave room for
+#define ETLG_MINWAVES 4     // waves per SIMD the register allocator must leave room for (128 VGPRs; measured 108 vs 119 us at 3)
 #endif
 #ifndef ETLG_LB_PARALLEL
 #define ETLG_LB_PARALLEL 1 // run the three independent look-backs on three waves
@@ -152,9 +152,10 @@ DEV uint64_t final_lsn_of_mark(const DecParams& p, uint32_t mark) {
 }
 
 // Everything after staging; `base` points at byte `win0` of the input (LDS or global).
-template <int BLK>
-DEV void tile_body(const DecParams& p, const FusedParams& q, uint32_t tile, uint32_t nt, const uint32_t* s_offs,
-                   const u8* base, uint32_t win0, uint32_t* s32, uint64_t* s64) {
+// `p`: parameters whose side-table pointers may point into LDS; `pg`: the original (global) ones.
+template <int BLK, bool STAGED>
+DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q, uint32_t tile, uint32_t nt,
+                   const uint32_t* s_offs, const u8* base, uint32_t win0, uint32_t* s32, uint64_t* s64) {
   const uint32_t tid = threadIdx.x;
   const int wave = tid >> 6;
   const bool live = tid < nt;
@@ -276,12 +277,13 @@ DEV void tile_body(const DecParams& p, const FusedParams& q, uint32_t tile, uint
     return;
   }
   if (q.dbg & 2) return;
-  write_frame(p, v, tx, m, row_slot, ev_idx, fx_off, hp_off);
+  write_frame(p, v, tx, m, row_slot, ev_idx, fx_off, hp_off, &pg, STAGED);
   TSTAMP(8);
 }
 
 template <int BLK>
-__global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams p, FusedParams q) {
+__global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, FusedParams q) {
+  DecParams p = pg;  // side-table pointers of `p` are redirected to the LDS copy below
   extern __shared__ __attribute__((aligned(16))) u8 smem[];
   __shared__ uint32_t s_offs[BLK + 1];
   __shared__ uint32_t s32[16];
@@ -333,14 +335,24 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams p, Fused
   if (use_lds) {
     // coalesced staging: 16 B per lane per step; the tail that would cross in_len goes bytewise
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);  // last full 16-byte chunk boundary <= span1
-    for (uint32_t c = a0 + 16 * tid; c < full_end; c += 16 * BLK)
-      *(uint4*)(stage + (c - a0)) = *(const uint4*)(p.in + c);
+    // four independent 16-byte loads in flight per lane before the first LDS store
+    for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * BLK) {
+      const uint32_t c1 = c + 16 * BLK, c2 = c + 32 * BLK, c3 = c + 48 * BLK;
+      uint4 v0 = *(const uint4*)(p.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
+      if (c1 < full_end) v1 = *(const uint4*)(p.in + c1);
+      if (c2 < full_end) v2 = *(const uint4*)(p.in + c2);
+      if (c3 < full_end) v3 = *(const uint4*)(p.in + c3);
+      *(uint4*)(stage + (c - a0)) = v0;
+      if (c1 < full_end) *(uint4*)(stage + (c1 - a0)) = v1;
+      if (c2 < full_end) *(uint4*)(stage + (c2 - a0)) = v2;
+      if (c3 < full_end) *(uint4*)(stage + (c3 - a0)) = v3;
+    }
     for (uint32_t c = full_end + tid; c < span1; c += BLK) stage[c - a0] = p.in[c];
     __syncthreads();
     TSTAMP(1);
-    tile_body<BLK>(p, q, tile, nt, s_offs, stage, a0, s32, s64);
+    tile_body<BLK, true>(p, pg, q, tile, nt, s_offs, stage, a0, s32, s64);
   } else {
-    tile_body<BLK>(p, q, tile, nt, s_offs, p.in, 0, s32, s64);
+    tile_body<BLK, false>(p, pg, q, tile, nt, s_offs, p.in, 0, s32, s64);
   }
 }
 

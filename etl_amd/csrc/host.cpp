@@ -1030,6 +1030,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     const uint64_t avg = (len + nf - 1) / nf;
     FusedParams& q = c->fq;
     q.blk = avg <= 192 ? 256u : 64u;
+    if (const char* fb = getenv("ETLG_FUSED_BLK")) { const int v = atoi(fb); if (v == 64 || v == 256) q.blk = (uint32_t)v; }
     uint64_t cap = q.blk == 256 ? (uint64_t)q.blk * avg * 9 / 8 + 1024 : (uint64_t)q.blk * avg * 5 / 4 + 2048;
     cap = std::min<uint64_t>((cap + 255) & ~255ull, 150 * 1024);
     const uint64_t side = (uint64_t)p.n_tables * sizeof(DevTable) + (uint64_t)p.n_epochs * sizeof(DevEpoch) +

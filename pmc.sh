@@ -2,7 +2,3 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc1 -o p -- $B > gpurun_out/pmc1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM --output-format csv -d gpurun_out/pmc2 -o p -- $B > gpurun_out/pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc3 -o p -- $B > gpurun_out/pmc3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc4 -o p -- $B > gpurun_out/pmc4.log 2>&1
-ls gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 gpurun_out/pmc4
-tail -3 gpurun_out/pmc1.log | cut -c1-300
