@@ -1,0 +1,530 @@
+// Column-parallel single-pass decode kernel for gfx950 — the variable-length path.
+//
+// k_fused (fused.hip) gives every frame one lane; with wide rows (hundreds of bytes of
+// TEXT / NUMERIC per frame) that leaves one wave per ~25 KB of staged LDS, i.e. 4 waves
+// per CU, and every per-lane character loop is latency bound. Here a tile is 64 frames
+// and NW waves; after one wave has sliced the tuples into a cell table in LDS, the
+// waves work on different COLUMNS of the same 64 frames:
+//
+//   P0  stage the tile's bytes + side tables into LDS (all waves, coalesced 16-B loads)
+//   P1  wave 0, lane = frame: envelope, tag, tuple walk; cell (offset, length, kind)
+//       records go to LDS as table[virtual column][frame]; transaction scan;
+//       ownership + schema slot per frame
+//   P2  waves over virtual columns (old/key image cells, then new image cells),
+//       lane = frame: exact heap bytes per cell (numeric digit groups, deferred text, ...)
+//   P2b wave 0: tuple-shape checks, per-frame exclusive prefix over its cells' heap bytes,
+//       frame sizes -> wave scan -> two-level look-back (three prefixes on three waves)
+//   P3  waves over virtual columns, lane = frame: decode the cell, write its slot and heap
+//       entry at the final position; 2-bit states are OR-ed into an LDS word per row
+//   P4  wave 0: toast aliasing, row state words, event headers, first error per frame
+//
+// A wave therefore sees ONE column class at a time (scalar dispatch through a waterfall
+// over the distinct classes), all rows of a tile progress in parallel across columns, and
+// occupancy is NW waves per tile instead of one. Schemas wider than MAXC columns, tiles
+// that do not fit LDS and every error fall back to the multi-pass kernels (kernels.hip).
+#include "lookback.hip.h"
+
+namespace etlg {
+
+constexpr int CF = 64;         // frames per tile
+constexpr int MAXC = 16;       // replicated columns per slot this kernel can handle (one state word per row)
+// virtual columns of a tile whose widest slot has maxc columns: [0, maxc) old / key image, [maxc, 2 maxc) new image
+
+enum : uint32_t { CT_N = 0, CT_U = 1, CT_T = 2, CT_B = 3 };  // cell kind in the top 2 bits of ct_len
+
+// frame meta word: tag (8) | old_kind (2) << 8 | wire_ok << 10 | emit << 11 | too_wide << 12
+DEV uint32_t meta_tag(uint32_t m) { return m & 0xFF; }
+DEV uint32_t meta_old(uint32_t m) { return (m >> 8) & 3; }
+
+// Column of the slot that virtual-column cell k of an image with `n` cells decodes against.
+// mode: ROW_FULL / ROW_UPDATE -> k; ROW_KEY dense -> k-th identity column; ROW_KEY
+// full-width -> k if it is an identity column. Returns -1 when the cell is skipped.
+DEV int cell_column(const DevSlot& s, const DevCol* cols, uint32_t mode, uint32_t n, uint32_t k) {
+  if (mode != ROW_KEY) return k < s.n_cols ? (int)k : -1;
+  if (n == s.n_ident) {
+    for (uint32_t c = 0; c < s.n_cols; c++) if (cols[c].identity && cols[c].key_index == k) return (int)c;
+    return -1;
+  }
+  return (k < s.n_cols && cols[k].identity) ? (int)k : -1;
+}
+
+// Is image `img` of this frame well shaped against its slot (tuple-level checks of
+// convert_tuple_to_row / normalize_key_tuple_to_row, codec/event.rs:559-565, 889-922)?
+DEV uint32_t image_shape_error(const DevSlot& s, uint32_t mode, uint32_t n) {
+  if (mode == ROW_KEY) {
+    if (s.n_ident == 0) return ETLG_E_KEY_MISSING_COLS;
+    if (n != s.n_ident && n != s.n_cols) return ETLG_E_KEY_SHAPE;
+    return 0;
+  }
+  return n != s.n_cols ? (uint32_t)ETLG_E_TUPLE_WIDTH : 0u;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams q) {
+  extern __shared__ __attribute__((aligned(16))) u8 smem[];
+  __shared__ uint32_t s_offs[CF + 1];
+  __shared__ int32_t fr_slot[CF];
+  __shared__ uint32_t fr_meta[CF];
+  __shared__ uint32_t fr_n[CF];      // n_old | n_new << 16
+  __shared__ uint64_t fr_fx[CF];     // fixed-arena offset of the frame's body
+  __shared__ uint32_t fr_hp[CF];     // heap offset of the frame's first entry
+  __shared__ uint32_t fr_st[2][CF];  // 2-bit cell states of the old / new row (<= 16 columns)
+  __shared__ uint32_t fr_err[CF];    // min over (order << 8 | code)
+  __shared__ uint32_t fr_toast[CF];  // new-row columns sent as 'u'
+  __shared__ uint32_t s32[16];
+  __shared__ uint64_t s64[8];
+  DecParams p = pg;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
+  if (tid < 3) s64[tid] = 0;
+  // ---- P0: side tables, offsets, staging
+  if (q.side_bytes) {
+    const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
+    const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
+    uint32_t* d = (uint32_t*)smem;
+    for (uint32_t i = tid; i < nt4; i += NW * 64) d[i] = ((const uint32_t*)p.tables)[i];
+    d += nt4;
+    for (uint32_t i = tid; i < ne4; i += NW * 64) d[i] = ((const uint32_t*)p.epochs)[i];
+    d += ne4;
+    for (uint32_t i = tid; i < ns4; i += NW * 64) d[i] = ((const uint32_t*)p.slots)[i];
+    d += ns4;
+    for (uint32_t i = tid; i < nc4; i += NW * 64) d[i] = ((const uint32_t*)p.cols)[i];
+    uint32_t* b0 = (uint32_t*)smem;
+    p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
+    p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
+  }
+  const uint32_t maxc = q.maxc, VC = 2 * maxc;
+  uint32_t* ct_pos = (uint32_t*)(smem + q.side_bytes);
+  uint32_t* ct_len = ct_pos + VC * CF;
+  uint32_t* ct_h = ct_len + VC * CF;
+  u8* stage = (u8*)(ct_h + VC * CF);
+  const uint32_t table_bytes = 3 * VC * CF * 4;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t f0 = tile * CF;
+  uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
+  for (uint32_t i = tid; i <= nt; i += NW * 64) s_offs[i] = pg.offs[f0 + i];
+  __syncthreads();
+  const uint32_t span0 = s_offs[0], span1 = s_offs[nt];
+  bool lane_ok = true;
+  if (tid < nt) {
+    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
+    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
+  }
+  const uint32_t a0 = span0 & ~15u;
+  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
+                         (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
+  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
+  if (!use_lds) {
+    // this kernel only works out of LDS: decode nothing, keep the look-back chain alive, and
+    // let the host redo the batch with the multi-pass kernels
+    if (tid == 0) atomicOr(&pg.res->fused_fail, 2u);
+    nt = 0;
+  } else {
+    const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
+    for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * NW * 64) {
+      const uint32_t c1 = c + 16 * NW * 64, c2 = c + 32 * NW * 64, c3 = c + 48 * NW * 64;
+      uint4 v0 = *(const uint4*)(pg.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
+      if (c1 < full_end) v1 = *(const uint4*)(pg.in + c1);
+      if (c2 < full_end) v2 = *(const uint4*)(pg.in + c2);
+      if (c3 < full_end) v3 = *(const uint4*)(pg.in + c3);
+      *(uint4*)(stage + (c - a0)) = v0;
+      if (c1 < full_end) *(uint4*)(stage + (c1 - a0)) = v1;
+      if (c2 < full_end) *(uint4*)(stage + (c2 - a0)) = v2;
+      if (c3 < full_end) *(uint4*)(stage + (c3 - a0)) = v3;
+    }
+    for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
+  }
+  __syncthreads();
+  uint32_t* fail = &pg.res->fused_fail;
+
+  // ================= P1 (wave 0): slice frames into cells, transaction scan, slots
+  const bool live = wave == 0 && lane < nt;
+  const uint32_t f = f0 + lane;
+  FrameView v{f, 0, stage, stage};
+  uint32_t rel_id = 0, old_kind = ETLG_OLD_NONE, n_old = 0, n_new = 0, vbytes = 0, o0 = 0;
+  bool wire_ok = true, too_wide = false;
+  uint32_t cnt = 0, mark = 0, seg_in = 0, pm = 0, tot_cnt = 0, tot_mark = 0;
+  if (wave == 0) {
+    if (lane < CF) { fr_st[0][lane] = 0; fr_st[1][lane] = 0; fr_err[lane] = 0xFFFFFFFFu; fr_toast[lane] = 0; fr_slot[lane] = -1; fr_meta[lane] = 0; fr_n[lane] = 0; }
+    if (live) {
+      o0 = s_offs[lane];
+      const uint32_t o1 = s_offs[lane + 1];
+      if (o1 > o0 && o1 <= pg.in_len) {
+        v.fr = stage + (o0 - a0);
+        v.e = stage + (o1 - a0);
+        v.tag = classify_ptr(v.fr, o1 - o0);
+      }
+      const uint32_t tag = v.tag;
+      if (tag == 'I' || tag == 'U' || tag == 'D') {
+        // parse_row_msg + walk_tuple, recording every cell
+        const u8* b = v.fr + kBodyOff;
+        const u8* e = v.e;
+        wire_ok = e - b >= 5;
+        if (wire_ok) {
+          rel_id = ld_be32(b);
+          const u8* c = b + 4;
+          // images: 0 = old / key, 1 = new
+          for (int img = 0; img < 2 && wire_ok; img++) {
+            if (img == 0 && tag == 'I') continue;
+            if (img == 1 && tag == 'D') break;
+            if (c >= e) { wire_ok = false; break; }
+            uint32_t t = *c;
+            if (img == 0) {
+              if (t == 'K' || t == 'O') { old_kind = t == 'K' ? ETLG_OLD_KEY : ETLG_OLD_FULL; c++; }
+              else if (tag == 'D') { wire_ok = false; break; }
+              else continue;  // update without an old image
+            } else {
+              if (t != 'N') { wire_ok = false; break; }
+              c++;
+            }
+            if (e - c < 2) { wire_ok = false; break; }
+            const uint32_t n = ld_be16(c);
+            c += 2;
+            if (n & 0x8000u) { wire_ok = false; break; }
+            if (n > maxc) too_wide = true;
+            if (img == 0) n_old = n; else n_new = n;
+            for (uint32_t k = 0; k < n; k++) {
+              if (c >= e) { wire_ok = false; break; }
+              const uint32_t ct = *c++;
+              uint32_t kind, len = 0, pos = 0;
+              if (ct == 'n') kind = CT_N;
+              else if (ct == 'u') kind = CT_U;
+              else if (ct == 't' || ct == 'b') {
+                kind = ct == 't' ? CT_T : CT_B;
+                if (e - c < 4) { wire_ok = false; break; }
+                len = ld_be32(c);
+                c += 4;
+                if ((len & 0x80000000u) || (uint64_t)(e - c) < len) { wire_ok = false; break; }
+                pos = (uint32_t)(c - stage);
+                vbytes += len;
+                c += len;
+              } else { wire_ok = false; break; }
+              if (k < maxc) {
+                const uint32_t vc = (uint32_t)img * maxc + k;
+                ct_pos[vc * CF + lane] = pos;
+                ct_len[vc * CF + lane] = (len & 0x3FFFFFFFu) | (kind << 30);
+                ct_h[vc * CF + lane] = 0;
+                if (len > 0x3FFFFFFFu) too_wide = true;
+              }
+            }
+          }
+        }
+      } else {
+        RowMsg dummy;
+        wire_ok = frame_structure(v, dummy);
+      }
+      if (consumes_ordinal(tag)) cnt = 1;
+      if (tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
+      if (tag == 'C') mark = (o0 + 1) << 1;
+    }
+    // wave-level transaction scan (no barrier: a tile's frames live in one wave)
+    {
+      uint32_t ic = cnt, im = mark;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t tc = __shfl_up(ic, d, 64), tm = __shfl_up(im, d, 64);
+        if ((int)lane >= d) { ic = seg_combine(tc, ic); im = tm > im ? tm : im; }
+      }
+      pm = __shfl_up(im, 1, 64);
+      if (lane == 0) pm = 0;
+      seg_in = ic;
+      tot_cnt = __shfl(ic, 63, 64); tot_mark = __shfl(im, 63, 64);
+    }
+  }
+  const uint64_t txn_agg = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark;  // meaningful on wave 0
+  const uint64_t txn_carry = (uint64_t)(pg.in_txn ? 1u : 0u);
+  TxnCtx tx{true, 0, 0};
+  uint32_t bc = 0, bm = 0;
+  auto make_tx = [&](uint32_t c_in, uint32_t m_in) {
+    bc = c_in; bm = m_in;
+    const uint32_t seg = seg_combine(bc, seg_in);
+    const uint32_t last = bm > pm ? bm : pm;
+    tx.in_txn = (last & 1u) != 0;
+    tx.final_lsn = tx.in_txn ? final_lsn_of_mark(pg, last) : 0;
+    const uint64_t c = seg & 0x7FFFFFFFu;
+    tx.ord = (seg & 0x80000000u) ? c - 1 : pg.next_ord + c - 1;
+  };
+  if (wave == 0) {
+    if (q.seq_lookback) {
+      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
+      make_tx(seg_unpack30((uint32_t)(ex >> 32)), (uint32_t)ex);  // look-back results are wave-uniform
+    }
+    if (live && too_wide) atomicOr(fail, 4u);
+    // ownership + schema slot (size_frame's lookups), per frame
+    if (live && wire_ok && (v.tag == 'I' || v.tag == 'U' || v.tag == 'D')) {
+      const int ti = find_table(p, rel_id);
+      int slot = -1;
+      if (should_apply(p, ti, rel_id, tx.final_lsn)) {
+        slot = cache_slot_before(p, ti, f);
+        if (slot < 0) { record_error(pg, f, RK_SCHEMA, (uint32_t)(-slot)); slot = -1; }
+        else if (p.slots[slot].n_cols > maxc) { atomicOr(fail, 4u); slot = -1; }
+      }
+      fr_slot[lane] = slot;
+    }
+    if (live) {
+      fr_meta[lane] = v.tag | (old_kind << 8) | ((wire_ok ? 1u : 0u) << 10);
+      fr_n[lane] = n_old | (n_new << 16);
+    }
+  }
+  __syncthreads();
+
+  // ================= P2: heap bytes per cell, waves over virtual columns
+  for (uint32_t vc = wave; vc < VC; vc += NW) {
+    const int slot = fr_slot[lane];
+    if (slot < 0) continue;
+    const uint32_t meta = fr_meta[lane];
+    const uint32_t img = vc >= maxc, k = vc - img * maxc;
+    const uint32_t n = img ? (fr_n[lane] >> 16) : (fr_n[lane] & 0xFFFF);
+    if (k >= n) continue;
+    const uint32_t tag = meta_tag(meta);
+    if ((img == 0 && meta_old(meta) == ETLG_OLD_NONE) || (img == 1 && tag == 'D')) continue;
+    const DevSlot& s = p.slots[slot];
+    if (!s.has_var) continue;
+    const uint32_t mode = img ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
+                              : (meta_old(meta) == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
+    if (image_shape_error(s, mode, n)) continue;
+    const DevCol* cols = p.cols + s.cols_base;
+    const int ci = cell_column(s, cols, mode, n, k);
+    if (ci < 0) continue;
+    const uint32_t lw = ct_len[vc * CF + lane];
+    if ((lw >> 30) != CT_T) continue;
+    const uint32_t cls = cols[ci].cls;
+    const u8* d = stage + ct_pos[vc * CF + lane];
+    uint32_t h = 0;
+    // waterfall: one pass per distinct class among the active lanes, scalar dispatch inside
+    bool done = false;
+    while (!done) {
+      const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
+      if (cls == u) { h = cell_heap_bytes(u, d, lw & 0x3FFFFFFFu); done = true; }
+    }
+    ct_h[vc * CF + lane] = h;
+  }
+  __syncthreads();
+
+  // ================= P2b (wave 0): shapes, per-frame heap prefix, sizes, look-back
+  uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_ev = 0, x_fx = 0, x_hp = 0;
+  uint64_t pay[3] = {0, 0, 0};
+  int row_slot = -1;
+  if (wave == 0) {
+    if (live) {
+      const uint32_t tag = v.tag;
+      if (tag == 'I' || tag == 'U' || tag == 'D') {
+        if (!wire_ok) record_error(pg, f, RK_WIRE, ETLG_E_WIRE);
+        else {
+          if (q.seq_lookback && !tx.in_txn) record_error(pg, f, RK_TXN, ETLG_E_TXN_STATE);
+          pay[tag == 'I' ? 0 : tag == 'U' ? 1 : 2] = vbytes;
+          row_slot = fr_slot[lane];
+          if (row_slot >= 0) {
+            const DevSlot& s = p.slots[row_slot];
+            emit = 1;
+            for (uint32_t img = (tag == 'I' || old_kind == ETLG_OLD_NONE) ? 1u : 0u; img < (tag == 'D' ? 1u : 2u); img++) {
+              const uint32_t mode = img ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
+                                        : (old_kind == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
+              const uint32_t n = img ? n_new : n_old;
+              const uint32_t rb = mode == ROW_KEY ? s.row_key : s.row_full;
+              fixed += rb;
+              if (img == 0) old_sz = rb;
+              const uint32_t serr = image_shape_error(s, mode, n);
+              if (serr) { atomicMin(&fr_err[lane], ((img * 32u) << 8) | serr); continue; }
+              for (uint32_t k = 0; k < n && k < maxc; k++) {  // exclusive prefix of the cells' heap bytes
+                const uint32_t idx = (img * maxc + k) * CF + lane;
+                const uint32_t h = ct_h[idx];
+                ct_h[idx] = heap;
+                heap += h;
+              }
+            }
+          }
+        }
+      } else {
+        RowMsg dummy{};
+        size_frame(p, v, tx, wire_ok, dummy, emit, fixed, heap, pay, row_slot, q.seq_lookback != 0);
+      }
+    }
+    // wave scan of (events, fixed dwords, heap dwords)
+    uint32_t ie = emit, ifx = fixed >> 2, ih = heap >> 2;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t te = __shfl_up(ie, d, 64), tf = __shfl_up(ifx, d, 64), th = __shfl_up(ih, d, 64);
+      if ((int)lane >= d) { ie += te; ifx += tf; ih += th; }
+    }
+    const uint32_t tot_e = __shfl(ie, 63, 64), tot_f = __shfl(ifx, 63, 64), tot_h = __shfl(ih, 63, 64);
+    // payload counters
+    uint64_t a0p = pay[0], a1p = pay[1], a2p = pay[2];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a0p += __shfl_xor(a0p, d, 64); a1p += __shfl_xor(a1p, d, 64); a2p += __shfl_xor(a2p, d, 64); }
+    if (lane == 0) {
+      if (a0p) atomicAdd(&pg.res->pay_shard[tile & 31][0], (unsigned long long)a0p);
+      if (a1p) atomicAdd(&pg.res->pay_shard[tile & 31][1], (unsigned long long)a1p);
+      if (a2p) atomicAdd(&pg.res->pay_shard[tile & 31][2], (unsigned long long)a2p);
+      s64[0] = ((uint64_t)tot_e << 32) | tot_h;  // aggregates for the other look-back waves
+      s64[1] = tot_f;
+      s64[2] = txn_agg;
+    }
+    x_ev = ie - emit; x_fx = ifx - (fixed >> 2); x_hp = ih - (heap >> 2);  // exclusive, inside the tile
+  }
+  __syncthreads();
+  if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, s64[0], 0, fail); if (lane == 0) s64[4] = a; }
+  if (wave == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
+  if (wave == 2 % NW && NW > 2 && !q.seq_lookback) {
+    const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
+    if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+  }
+  if (NW <= 2 && wave == 0) {
+    if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
+    if (!q.seq_lookback) {
+      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
+      if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+    }
+  }
+  __syncthreads();
+  const uint64_t pre_ev = s64[4] >> 32, pre_hp = (uint64_t)(uint32_t)s64[4] << 2, pre_fx = s64[5] << 2;
+  uint64_t ev_idx = 0, fx_off = 0, hp_off = 0;
+  if (wave == 0) {
+    if (!q.seq_lookback) {
+      make_tx(s32[12], s32[13]);
+      if (live && wire_ok) txn_check_frame(pg, v, tx);
+    }
+    ev_idx = pre_ev + x_ev;
+    fx_off = pre_fx + ((uint64_t)x_fx << 2);
+    hp_off = pre_hp + ((uint64_t)x_hp << 2);
+    if (lane == 0 && tile == q.ntiles - 1) {
+      DevResult* r = pg.res;
+      r->n_events = pre_ev + (s64[0] >> 32); r->fixed_bytes = pre_fx + (s64[1] << 2); r->heap_bytes = pre_hp + ((uint64_t)(uint32_t)s64[0] << 2);
+      r->n_frames = pg.nframes;
+      const uint32_t sg = seg_combine(bc, tot_cnt);
+      const uint32_t lm = bm > tot_mark ? bm : tot_mark;
+      const bool it = (lm & 1u) != 0;
+      r->out_in_txn = it;
+      r->out_final_lsn = it ? final_lsn_of_mark(pg, lm) : 0;
+      const uint64_t c = sg & 0x7FFFFFFFu;
+      r->out_next_ord = (sg & 0x80000000u) ? c : pg.next_ord + c;
+    }
+    if (emit && (fx_off + fixed > pg.fixed_cap || hp_off + heap > pg.heap_cap || hp_off + heap > 0xFFFFFFFFull)) {
+      record_error(pg, f, RK_DECODE, ETLG_E_WIRE);
+      emit = 0;
+    }
+    fr_fx[lane] = fx_off;
+    fr_hp[lane] = (uint32_t)hp_off;
+    if (live) fr_meta[lane] |= (emit ? 1u : 0u) << 11;
+  }
+  __syncthreads();
+
+  // ================= P3: decode cells, waves over virtual columns
+  for (uint32_t vc = wave; vc < VC; vc += NW) {
+    const uint32_t meta = fr_meta[lane];
+    if (!((meta >> 11) & 1)) continue;
+    const int slot = fr_slot[lane];
+    if (slot < 0) continue;
+    const uint32_t img = vc >= maxc, k = vc - img * maxc;
+    const uint32_t n = img ? (fr_n[lane] >> 16) : (fr_n[lane] & 0xFFFF);
+    if (k >= n) continue;
+    const uint32_t tag = meta_tag(meta), ok = meta_old(meta);
+    if ((img == 0 && ok == ETLG_OLD_NONE) || (img == 1 && tag == 'D')) continue;
+    const DevSlot& s = p.slots[slot];
+    const uint32_t mode = img ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
+                              : (ok == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
+    if (image_shape_error(s, mode, n)) continue;
+    const DevCol* cols = p.cols + s.cols_base;
+    const int ci = cell_column(s, cols, mode, n, k);
+    if (ci < 0) continue;
+    const DevCol col = cols[ci];
+    const uint32_t osz = ok == ETLG_OLD_FULL ? s.row_full : ok == ETLG_OLD_KEY ? s.row_key : 0;
+    u8* row = pg.fixed + fr_fx[lane] + (img ? osz : 0);
+    uint32_t* slotp = (uint32_t*)(row + (mode == ROW_KEY ? col.off_key : col.off_full));
+    const uint32_t kout = mode == ROW_KEY ? col.key_index : (uint32_t)ci;
+    const uint32_t lw = ct_len[vc * CF + lane];
+    const uint32_t kind = lw >> 30, len = lw & 0x3FFFFFFFu;
+    const uint32_t order = img * 32u + 1u + k;
+    uint32_t st = ETLG_CELL_NULL, err = 0;
+    if (kind == CT_T) {
+      const u8* d = stage + ct_pos[vc * CF + lane];
+      uint32_t hcur = fr_hp[lane] + ct_h[vc * CF + lane];
+      const uint32_t cls = col.cls;
+      bool done = false;
+      while (!done) {  // waterfall over the distinct classes of this wave's cells
+        const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
+        if (cls == u) { err = decode_text_cell(u, d, len, slotp, pg.heap, hcur, st, true); done = true; }
+      }
+    } else if (kind == CT_N) {
+      if (!col.nullable) err = ETLG_E_REQUIRED_NULL; else slot_zero(slotp, col.cls);
+    } else if (kind == CT_U) {
+      if (mode == ROW_FULL) err = ETLG_E_FULL_ROW_MISSING;
+      else if (mode == ROW_KEY) err = ETLG_E_KEY_MISSING_VALUE;
+      else { atomicOr(&fr_toast[lane], 1u << k); st = 0; }  // resolved by the frame's lane in P4
+    } else {
+      err = ETLG_E_BINARY_FORMAT;
+    }
+    if (err) atomicMin(&fr_err[lane], (order << 8) | err);
+    else if (st) atomicOr(&fr_st[img][lane], st << (2 * kout));
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ================= P4 (wave 0): finish rows, event headers
+  if (wave != 0 || !emit) return;
+  if (q.dbg & 2) return;
+  const uint32_t tag = v.tag;
+  if (tag == 'I' || tag == 'U' || tag == 'D') {
+    const DevSlot& s = p.slots[row_slot];
+    const DevCol* cols = p.cols + s.cols_base;
+    u8* body = pg.fixed + fx_off;
+    uint32_t flags = tag != 'I' ? old_kind : 0u;
+    uint32_t st_new = fr_st[1][lane];
+    uint32_t toast = fr_toast[lane];
+    const uint32_t e0 = fr_err[lane];
+    // 'u' cells of the new row: alias the aligned old value, else MISSING (codec/event.rs:962-974)
+    while (toast) {
+      const uint32_t k = __builtin_ctz(toast);
+      toast &= toast - 1;
+      const DevCol col = cols[k];
+      uint32_t* dst = (uint32_t*)(body + old_sz + col.off_full);
+      const bool from_full = old_kind == ETLG_OLD_FULL, from_key = old_kind == ETLG_OLD_KEY && col.identity;
+      if (from_full || from_key) {
+        const uint32_t* src = (const uint32_t*)(body + (from_full ? col.off_full : col.off_key));
+        const uint32_t nw = slot_bytes(col.cls) >> 2;
+        for (uint32_t w = 0; w < nw; w++) dst[w] = src[w];
+        const uint32_t ost = (fr_st[0][lane] >> (2 * (from_full ? k : col.key_index))) & 3u;
+        st_new |= ost << (2 * k);
+      } else {
+        slot_zero(dst, col.cls);
+        st_new |= (uint32_t)ETLG_CELL_MISSING << (2 * k);
+        flags |= ETLG_FLAG_PARTIAL;
+      }
+    }
+    if (e0 != 0xFFFFFFFFu) { record_error(pg, f, RK_DECODE, e0 & 0xFF); return; }
+    if (old_kind != ETLG_OLD_NONE && (old_kind == ETLG_OLD_KEY ? s.st_key : s.st_full)) *(uint32_t*)body = fr_st[0][lane];
+    if (tag != 'D' && s.st_full) *(uint32_t*)(body + old_sz) = st_new;
+    pg.ev_kind[ev_idx] = (u8)tag;
+    pg.ev_flags[ev_idx] = (u8)flags;
+    pg.ev_table[ev_idx] = rel_id;
+    pg.ev_slot[ev_idx] = (uint32_t)row_slot;
+    pg.ev_start[ev_idx] = ld_be64(v.fr + 6);
+    pg.ev_commit[ev_idx] = tx.final_lsn;
+    pg.ev_ord[ev_idx] = tx.ord;
+    pg.ev_body[ev_idx] = fx_off;
+  } else {
+    RowMsg dummy{};
+    write_frame(p, v, tx, dummy, -1, ev_idx, fx_off, hp_off, nullptr, true);
+  }
+}
+
+}  // namespace etlg
+
+extern "C" {
+
+using namespace etlg;
+
+void etlg_k_launch_cells(const DecParams* p, const void* qv, hipStream_t s) {
+  const FusedParams* q = (const FusedParams*)qv;
+  hipLaunchKernelGGL(k_cells<4>, dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+}
+
+int etlg_k_cells_set_lds(void) {
+  return hipFuncSetAttribute((const void*)k_cells<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) == hipSuccess ? 0 : 1;
+}
+
+uint32_t etlg_k_cells_table_bytes(uint32_t maxc) { return 3u * 2u * maxc * CF * 4u; }
+uint32_t etlg_k_cells_maxc(void) { return MAXC; }
+
+}  // extern "C"

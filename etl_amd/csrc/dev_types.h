@@ -86,7 +86,7 @@ struct FusedParams {
   uint32_t dbg;                // ablation bits (profiling only): 1 no LDS staging, 2 skip writes, 4 skip look-back, 8 phase timers
   uint32_t seq_lookback;       // 1: ownership needs the transaction's final_lsn (a table is in SyncDone state)
   uint32_t side_bytes;         // LDS bytes reserved for a copy of the side-input tables (0 = read them from global)
-  uint32_t _pad;
+  uint32_t maxc;               // k_cells: widest schema slot of the batch (columns)
 };
 
 constexpr unsigned long long kNoErr = ~0ull;

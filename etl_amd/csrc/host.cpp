@@ -32,8 +32,14 @@ extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
 extern "C" const char* etlg_k_name(int which);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_fused_set_lds(void);
+extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
+extern "C" int etlg_k_cells_set_lds(void);
+extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
+extern "C" uint32_t etlg_k_cells_maxc(void);
 
 constexpr int kFused = 7;  // profiling slot of the fused kernel
+constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
+constexpr int kProfSlots = 9;
 
 namespace {
 
@@ -193,6 +199,7 @@ struct etlg_ctx {
   bool side_valid = false;
   bool force_multipass = false;  // ETLG_FORCE_MULTIPASS=1 (tests exercise both paths)
   unsigned long long last_dbg[12] = {0};
+  int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells (default: by frame size)
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
   DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
@@ -203,8 +210,8 @@ struct etlg_ctx {
   // profiling
   bool prof = false;
   std::vector<ProfRec> prof_recs;
-  double prof_ms[8] = {0};
-  uint64_t prof_n[8] = {0};
+  double prof_ms[kProfSlots] = {0};
+  uint64_t prof_n[kProfSlots] = {0};
 };
 
 struct etlg_batch {
@@ -655,6 +662,7 @@ hipError_t sync_slots(etlg_ctx* c) {
 
 void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
   if (which == kFused) etlg_k_launch_fused((int)c->fq.blk, &p, &c->fq, c->stream);
+  else if (which == kCells) etlg_k_launch_cells(&p, &c->fq, c->stream);
   else etlg_k_launch(which, &p, c->stream);
 }
 
@@ -745,8 +753,11 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail("hipHostMalloc", e); }
   { DevResult init{}; init.first_err = kNoErr; *c->h_init = init; }
   (void)etlg_k_fused_set_lds();
+  (void)etlg_k_cells_set_lds();
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
+  { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
+  if (const char* fb = getenv("ETLG_FUSED_BLK")) { const int v = atoi(fb); if (v == 64) c->fused_kernel = 1; else if (v == 256) c->fused_kernel = 0; }
   clear_error(c);
   *out = c;
   return ETLG_OK;
@@ -837,7 +848,7 @@ int32_t etlg_ctx_debug_times(etlg_ctx* c, unsigned long long* out12) {
 int32_t etlg_ctx_profile(etlg_ctx* c, int32_t enable) {
   if (!c) return ETLG_InvalidArgument;
   c->prof = enable != 0;
-  if (!enable) { for (int i = 0; i < 8; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; } }
+  if (!enable) { for (int i = 0; i < kProfSlots; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; } }
   return ETLG_OK;
 }
 
@@ -851,7 +862,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < 8 && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : i == kCells ? "k_cells" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }
@@ -1025,17 +1036,26 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
 
   const bool classify_done = !no_ctrl && nf != 0;  // k_classify / k_scan_txn already ran for the control list
   b->params = p;
+  bool use_cells = false;
   if (nf && !herr.code && !c->force_multipass && len < (1ull << 31)) {
     // ---- fast path: fused single-pass kernel (fused.hip)
     const uint64_t avg = (len + nf - 1) / nf;
     FusedParams& q = c->fq;
-    q.blk = avg <= 192 ? 256u : 64u;
-    if (const char* fb = getenv("ETLG_FUSED_BLK")) { const int v = atoi(fb); if (v == 64 || v == 256) q.blk = (uint32_t)v; }
-    uint64_t cap = q.blk == 256 ? (uint64_t)q.blk * avg * 9 / 8 + 1024 : (uint64_t)q.blk * avg * 5 / 4 + 2048;
-    cap = std::min<uint64_t>((cap + 255) & ~255ull, 150 * 1024);
     const uint64_t side = (uint64_t)p.n_tables * sizeof(DevTable) + (uint64_t)p.n_epochs * sizeof(DevEpoch) +
                           (uint64_t)p.n_slots * sizeof(DevSlot) + (uint64_t)p.n_cols * sizeof(DevCol);
     q.side_bytes = (side <= 8192 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
+    // kernel choice: narrow frames -> one lane per frame, 256 frames per tile (k_fused); wide frames ->
+    // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 16 columns)
+    uint32_t widest = 1;
+    for (auto& sl : c->slots) widest = std::max<uint32_t>(widest, sl->desc.n_cols);
+    int kernel = avg <= 192 ? 0 : (widest <= etlg_k_cells_maxc() ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
+    if (c->fused_kernel >= 0) kernel = c->fused_kernel == 2 && widest > etlg_k_cells_maxc() ? 1 : c->fused_kernel;
+    use_cells = kernel == 2;
+    q.blk = kernel == 0 ? 256u : 64u;
+    q.maxc = widest;
+    uint64_t cap = kernel == 0 ? (uint64_t)q.blk * avg * 9 / 8 + 1024 : (uint64_t)q.blk * avg * 5 / 4 + 2048;
+    cap = (cap + 255) & ~255ull;
+    if (use_cells) cap += etlg_k_cells_table_bytes(widest);
     cap = std::min<uint64_t>(cap + q.side_bytes, 150 * 1024);
     q.lds_bytes = (uint32_t)cap;
     q.seq_lookback = (any_sync_done || (c->fused_dbg & 32)) ? 1u : 0u;
@@ -1049,7 +1069,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, dbytes, s));
     q.d_txn = (unsigned long long*)c->d_desc.p; q.d_outa = q.d_txn + per; q.d_outb = q.d_outa + per;
     q.ticket = (uint32_t*)(q.d_outb + per);
-    launch(c, kFused, p);
+    launch(c, use_cells ? kCells : kFused, p);
     b->used_fused = true;
   } else {
     launch_multipass(c, p, classify_done);

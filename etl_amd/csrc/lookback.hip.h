@@ -1,0 +1,122 @@
+// Two-level decoupled look-back shared by the single-pass kernels (fused.hip, cells.hip).
+#pragma once
+#include "codec.hip.h"
+
+namespace etlg {
+
+constexpr unsigned long long ST_AGG = 1ull << 62, ST_INCL = 2ull << 62, ST_MASK = 3ull << 62;
+constexpr uint32_t kMaxPolls = 1u << 20;
+
+// payload combiners (62-bit payloads, `a` older than `b`)
+struct OpTxn {
+  DEV static uint64_t id() { return 0; }
+  DEV static uint64_t f(uint64_t a, uint64_t b) {
+    const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);  // flag at bit 29, count in bits 0..28
+    const uint32_t ma = (uint32_t)a, mb = (uint32_t)b;
+    const uint32_t s = (sb & (1u << 29)) ? sb : ((sa & (1u << 29)) | ((sa + sb) & 0x1FFFFFFFu));
+    return ((uint64_t)s << 32) | (ma > mb ? ma : mb);
+  }
+};
+struct OpAdd2 {  // two packed counters: hi 30 bits, lo 32 bits
+  DEV static uint64_t id() { return 0; }
+  DEV static uint64_t f(uint64_t a, uint64_t b) {
+    return ((((a >> 32) + (b >> 32)) & 0x3FFFFFFFull) << 32) | (uint32_t)((uint32_t)a + (uint32_t)b);
+  }
+};
+struct OpAdd {
+  DEV static uint64_t id() { return 0; }
+  DEV static uint64_t f(uint64_t a, uint64_t b) { return (a + b) & ~ST_MASK; }
+};
+
+// Two-level decoupled look-back, executed by ONE wave (all 64 lanes call it).
+//
+// Level 0: every tile publishes its aggregate in desc[tile] (status AGG only).
+// Level 1: tiles are grouped by 64; the last tile of a group folds the group's 64
+//          aggregates into gdesc[group] (AGG, then INCL once its own prefix is known).
+// A tile's exclusive prefix = (prefix before its group, from one window over the group
+// descriptors) ⊕ (fold of the earlier tiles of its own group, one window over desc).
+// Both windows are independent of how far the predecessors have progressed beyond
+// publishing their aggregate, so a batch whose tiles all start in lock-step (a grid of a
+// few thousand tiles is only ~3 rounds of the chip) resolves in ~3 memory round trips
+// instead of a 64-tiles-per-round-trip wavefront.
+//
+// Every word carries status + payload in ONE 64-bit value (relaxed agent-scope atomic
+// store / load), so no fence is needed; nothing depends on placement or dispatch order
+// beyond "a tile's predecessors have started" (ticket order); all spins are bounded.
+template <class Op>
+DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg,
+                      uint64_t carry, uint32_t* fail) {
+  const int lane = threadIdx.x & 63;
+  if (fail == nullptr) return carry;  // ablation only
+  const uint32_t g = tile >> 6, j = tile & 63;
+  if (lane == 0) __hip_atomic_store(&desc[tile], ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t polls = 0;
+  // ---- window 0: earlier tiles of this group (lane l <-> tile g*64 + l, l < j)
+  unsigned long long w0 = 0;
+  bool have = (uint32_t)lane >= j;  // lanes >= j have nothing to fetch
+  for (;;) {
+    if (!have) {
+      w0 = __hip_atomic_load(&desc[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      have = (w0 & ST_MASK) != 0;
+    }
+    if (!__ballot(!have)) break;
+    if (++polls > kMaxPolls) { if (lane == 0) atomicOr(fail, 1u); return Op::id(); }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  // ordered fold, lower lane = older: inclusive scan then take lane j-1
+  uint64_t v0 = (uint32_t)lane < j ? (uint64_t)(w0 & ~ST_MASK) : Op::id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(v0, d, 64);
+    if (lane >= d) v0 = Op::f(t, v0);
+  }
+  const uint64_t local = __shfl(v0, 63, 64);  // lanes >= j hold the identity, so lane 63 = fold of [0, j)
+  // the last tile of a full group publishes the group aggregate
+  const uint64_t group_agg = Op::f(local, agg);
+  if (j == 63 && lane == 0) __hip_atomic_store(&gdesc[g], ST_AGG | group_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- window(s) 1: group descriptors before g (lane l <-> group base - l), virtual group -1 = the carry
+  uint64_t acc = Op::id();
+  int64_t base = (int64_t)g - 1;
+  for (;;) {
+    const int64_t idx = base - lane;
+    unsigned long long w = ST_INCL | carry;
+    if (idx >= 0) w = __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (idx < -1) w = ST_INCL | Op::id();
+    const unsigned long long st = w & ST_MASK;
+    const unsigned long long m_incl = __ballot(st == ST_INCL);
+    const unsigned long long m_empty = __ballot(st == 0);
+    const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
+    const unsigned long long needed = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1);
+    if (m_empty & needed) {
+      if (++polls > kMaxPolls) { if (lane == 0) atomicOr(fail, 1u); return Op::id(); }
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    const int last = first_incl < 64 ? first_incl : 63;
+    uint64_t v = lane <= last ? (uint64_t)(w & ~ST_MASK) : Op::id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {  // higher lane = older group: older ⊕ newer
+      const uint64_t t = __shfl_down(v, d, 64);
+      if (lane + d < 64) v = Op::f(t, v);
+    }
+    acc = Op::f(__shfl(v, 0, 64), acc);
+    if (first_incl < 64) break;
+    base -= 64;
+  }
+  if (j == 63 && lane == 0) __hip_atomic_store(&gdesc[g], ST_INCL | Op::f(acc, group_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return Op::f(acc, local);
+}
+
+#define TSTAMP(k) do { if ((q.dbg & 8) && threadIdx.x == 0) { const unsigned long long _t = clock64(); atomicAdd(&p.res->dbg_t[k], _t - s64[7]); s64[7] = _t; } } while (0)
+
+DEV uint32_t seg_pack30(uint32_t seg) { return ((seg >> 31) << 29) | (seg & 0x1FFFFFFFu); }
+DEV uint32_t seg_unpack30(uint32_t s30) { return ((s30 >> 29) << 31) | (s30 & 0x1FFFFFFFu); }
+
+// In the fused kernel the transaction mark of a B / C frame carries the frame's BYTE
+// offset ((o0 + 1) << 1 | isBegin, batches < 2 GiB), so the Begin's final_lsn is one load away.
+DEV uint64_t final_lsn_of_mark(const DecParams& p, uint32_t mark) {
+  return mark == 1u ? p.final_lsn : ld_be64(p.in + ((mark >> 1) - 1) + kBodyOff);
+}
+
+
+}  // namespace etlg
