@@ -20,9 +20,11 @@
 //
 // A wave therefore sees ONE column class at a time (scalar dispatch through a waterfall
 // over the distinct classes), all rows of a tile progress in parallel across columns, and
-// occupancy is NW waves per tile instead of one. Schemas wider than MAXC columns, tiles
-// that do not fit LDS and every error fall back to the multi-pass kernels (kernels.hip).
+// occupancy is NW waves per tile instead of one. A tile whose bytes do not fit the LDS window
+// reads the input in place. Schemas wider than MAXC columns and every error fall back to the
+// multi-pass kernels (kernels.hip).
 #include "lookback.hip.h"
+#include "utf8_swar.h"
 
 namespace etlg {
 
@@ -59,6 +61,53 @@ DEV uint32_t image_shape_error(const DevSlot& s, uint32_t mode, uint32_t n) {
   return n != s.n_cols ? (uint32_t)ETLG_E_TUPLE_WIDTH : 0u;
 }
 
+// Copies the text of up to 64 cells (lane = frame: source offset `pos`, byte length `clen`, heap
+// offset `hcur`; clen = 0 for lanes without a cell) into the heap, zero padded to 4 bytes, and
+// validates it as UTF-8 on the way. Groups of 2^lgG lanes take one frame at a time, so a frame's
+// dwords leave as one contiguous store. Returns (to the frame's own lane) whether its text is
+// NOT valid UTF-8. over: the source may be read up to 3 bytes past a cell's end.
+DEV bool coop_copy(const u8* base, u8* heap, uint32_t pos, uint32_t clen, uint32_t hcur, uint32_t lane, uint32_t lgG, bool over, uint32_t abl = 0) {
+  const uint32_t G = 1u << lgG, grp = lane >> lgG, gl = lane & (G - 1);
+  const unsigned long long gmask = ((1ull << G) - 1) << (grp << lgG);  // G <= 32
+  bool mine = false;
+  // one dword of one frame: load, store, validate
+  auto step = [&](const u8* src, uint32_t* dst, uint32_t lj, uint32_t w) -> bool {
+    const uint32_t rem = lj - 4 * w;  // >= 1
+    uint32_t x = 0, prev = 0;
+    if (rem >= 4 || over) {
+      __builtin_memcpy(&x, src + 4 * w, 4);
+      if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+    } else {
+      for (uint32_t b2 = 0; b2 < rem; b2++) x |= (uint32_t)src[4 * w + b2] << (8 * b2);
+    }
+    if (w) __builtin_memcpy(&prev, src + 4 * w - 4, 4);
+    if (!(abl & 2)) dst[w] = x;
+    if (abl & 1) return x == 0x12345678u;
+    return ((x | prev) & 0x80808080u) ? utf8_dword_bad(prev, x, rem == 4) : false;
+  };
+  // four frames per trip: their shuffles, LDS reads and stores are independent and overlap
+  for (uint32_t i = 0; i < G; i += 4) {
+    const int j = (int)((grp << lgG) + i);
+    uint32_t pj[4], lj[4], hj[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { pj[u] = __shfl(pos, j + u, 64); lj[u] = __shfl(clen, j + u, 64); hj[u] = __shfl(hcur, j + u, 64); }
+    bool bad[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) bad[u] = gl < ((lj[u] + 3) >> 2) ? step(base + pj[u], (uint32_t*)(heap + hj[u]), lj[u], gl) : false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // texts longer than one group pass (rare when G fits the column)
+      const uint32_t ndw = (lj[u] + 3) >> 2;
+      for (uint32_t w = gl + G; w < ndw; w += G) bad[u] |= step(base + pj[u], (uint32_t*)(heap + hj[u]), lj[u], w);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const unsigned long long bal = __ballot(bad[u]);
+      if (gl == i + u) mine = (bal & gmask) != 0;
+    }
+  }
+  return mine;
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams q) {
   extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -78,6 +127,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
   const int wave = tid >> 6;
   if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;
+  if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
   // ---- P0: side tables, offsets, staging
   if (q.side_bytes) {
     const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
@@ -105,6 +155,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
   uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
   for (uint32_t i = tid; i <= nt; i += NW * 64) s_offs[i] = pg.offs[f0 + i];
   __syncthreads();
+  TSTAMP(0);
   const uint32_t span0 = s_offs[0], span1 = s_offs[nt];
   bool lane_ok = true;
   if (tid < nt) {
@@ -115,12 +166,10 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
                          (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
-  if (!use_lds) {
-    // this kernel only works out of LDS: decode nothing, keep the look-back chain alive, and
-    // let the host redo the batch with the multi-pass kernels
-    if (tid == 0) atomicOr(&pg.res->fused_fail, 2u);
-    nt = 0;
-  } else {
+  // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
+  const u8* base = use_lds ? stage : pg.in;
+  const uint32_t b0 = use_lds ? a0 : 0u;
+  if (use_lds) {
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
     for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * NW * 64) {
       const uint32_t c1 = c + 16 * NW * 64, c2 = c + 32 * NW * 64, c3 = c + 48 * NW * 64;
@@ -136,12 +185,13 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
   }
   __syncthreads();
+  TSTAMP(1);
   uint32_t* fail = &pg.res->fused_fail;
 
   // ================= P1 (wave 0): slice frames into cells, transaction scan, slots
   const bool live = wave == 0 && lane < nt;
   const uint32_t f = f0 + lane;
-  FrameView v{f, 0, stage, stage};
+  FrameView v{f, 0, base, base};
   uint32_t rel_id = 0, old_kind = ETLG_OLD_NONE, n_old = 0, n_new = 0, vbytes = 0, o0 = 0;
   bool wire_ok = true, too_wide = false;
   uint32_t cnt = 0, mark = 0, seg_in = 0, pm = 0, tot_cnt = 0, tot_mark = 0;
@@ -151,8 +201,8 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
       o0 = s_offs[lane];
       const uint32_t o1 = s_offs[lane + 1];
       if (o1 > o0 && o1 <= pg.in_len) {
-        v.fr = stage + (o0 - a0);
-        v.e = stage + (o1 - a0);
+        v.fr = base + (o0 - b0);
+        v.e = base + (o1 - b0);
         v.tag = classify_ptr(v.fr, o1 - o0);
       }
       const uint32_t tag = v.tag;
@@ -186,17 +236,21 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
             if (img == 0) n_old = n; else n_new = n;
             for (uint32_t k = 0; k < n; k++) {
               if (c >= e) { wire_ok = false; break; }
-              const uint32_t ct = *c++;
+              // cell tag and length in one load when the bytes sit in LDS (the window has 16 spare bytes)
+              uint64_t head = *c;
+              if (use_lds) __builtin_memcpy(&head, c, 8);
+              const uint32_t ct = (uint32_t)head & 0xFFu;
+              c++;
               uint32_t kind, len = 0, pos = 0;
               if (ct == 'n') kind = CT_N;
               else if (ct == 'u') kind = CT_U;
               else if (ct == 't' || ct == 'b') {
                 kind = ct == 't' ? CT_T : CT_B;
                 if (e - c < 4) { wire_ok = false; break; }
-                len = ld_be32(c);
+                len = use_lds ? __builtin_bswap32((uint32_t)(head >> 8)) : ld_be32(c);
                 c += 4;
                 if ((len & 0x80000000u) || (uint64_t)(e - c) < len) { wire_ok = false; break; }
-                pos = (uint32_t)(c - stage);
+                pos = (uint32_t)(c - base);
                 vbytes += len;
                 c += len;
               } else { wire_ok = false; break; }
@@ -268,39 +322,41 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     }
   }
   __syncthreads();
+  TSTAMP(2);
 
-  // ================= P2: heap bytes per cell, waves over virtual columns
-  for (uint32_t vc = wave; vc < VC; vc += NW) {
+  // ================= P2: heap bytes per cell; waves pull virtual columns from a queue
+  for (;;) {
+    uint32_t vc = 0;
+    if (lane == 0) vc = atomicAdd(&s32[8], 1u);
+    vc = __builtin_amdgcn_readfirstlane(vc);
+    if (vc >= VC) break;
     const int slot = fr_slot[lane];
-    if (slot < 0) continue;
     const uint32_t meta = fr_meta[lane];
     const uint32_t img = vc >= maxc, k = vc - img * maxc;
     const uint32_t n = img ? (fr_n[lane] >> 16) : (fr_n[lane] & 0xFFFF);
-    if (k >= n) continue;
     const uint32_t tag = meta_tag(meta);
-    if ((img == 0 && meta_old(meta) == ETLG_OLD_NONE) || (img == 1 && tag == 'D')) continue;
-    const DevSlot& s = p.slots[slot];
-    if (!s.has_var) continue;
-    const uint32_t mode = img ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
-                              : (meta_old(meta) == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
-    if (image_shape_error(s, mode, n)) continue;
-    const DevCol* cols = p.cols + s.cols_base;
-    const int ci = cell_column(s, cols, mode, n, k);
-    if (ci < 0) continue;
-    const uint32_t lw = ct_len[vc * CF + lane];
-    if ((lw >> 30) != CT_T) continue;
-    const uint32_t cls = cols[ci].cls;
-    const u8* d = stage + ct_pos[vc * CF + lane];
-    uint32_t h = 0;
-    // waterfall: one pass per distinct class among the active lanes, scalar dispatch inside
-    bool done = false;
-    while (!done) {
-      const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
-      if (cls == u) { h = cell_heap_bytes(u, d, lw & 0x3FFFFFFFu); done = true; }
+    if (slot >= 0 && k < n && !((img == 0 && meta_old(meta) == ETLG_OLD_NONE) || (img == 1 && tag == 'D'))) {
+      const DevSlot& s = p.slots[slot];
+      const uint32_t mode = img ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
+                                : (meta_old(meta) == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
+      const DevCol* cols = p.cols + s.cols_base;
+      const int ci = (!s.has_var || image_shape_error(s, mode, n)) ? -1 : cell_column(s, cols, mode, n, k);
+      const uint32_t lw = ct_len[vc * CF + lane];
+      if (ci >= 0 && (lw >> 30) == CT_T) {
+        const uint32_t cls = cols[ci].cls;
+        const u8* d = base + ct_pos[vc * CF + lane];
+        uint32_t h = 0;
+        bool done = false;
+        while (!done) {  // one pass per distinct class among the active lanes, scalar dispatch inside
+          const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
+          if (cls == u) { h = cell_heap_bytes(u, d, lw & 0x3FFFFFFFu, use_lds); done = true; }
+        }
+        ct_h[vc * CF + lane] = h;
+      }
     }
-    ct_h[vc * CF + lane] = h;
   }
   __syncthreads();
+  TSTAMP(3);
 
   // ================= P2b (wave 0): shapes, per-frame heap prefix, sizes, look-back
   uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_ev = 0, x_fx = 0, x_hp = 0;
@@ -364,6 +420,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     x_ev = ie - emit; x_fx = ifx - (fixed >> 2); x_hp = ih - (heap >> 2);  // exclusive, inside the tile
   }
   __syncthreads();
+  TSTAMP(4);
   if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, s64[0], 0, fail); if (lane == 0) s64[4] = a; }
   if (wave == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
   if (wave == 2 % NW && NW > 2 && !q.seq_lookback) {
@@ -378,6 +435,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     }
   }
   __syncthreads();
+  TSTAMP(5);
   const uint64_t pre_ev = s64[4] >> 32, pre_hp = (uint64_t)(uint32_t)s64[4] << 2, pre_fx = s64[5] << 2;
   uint64_t ev_idx = 0, fx_off = 0, hp_off = 0;
   if (wave == 0) {
@@ -409,57 +467,90 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     if (live) fr_meta[lane] |= (emit ? 1u : 0u) << 11;
   }
   __syncthreads();
+  TSTAMP(6);
 
-  // ================= P3: decode cells, waves over virtual columns
-  for (uint32_t vc = wave; vc < VC; vc += NW) {
-    const uint32_t meta = fr_meta[lane];
-    if (!((meta >> 11) & 1)) continue;
-    const int slot = fr_slot[lane];
-    if (slot < 0) continue;
+  // ================= P3: decode cells; waves pull virtual columns from a queue
+  for (;;) {
+    uint32_t vc = 0;
+    if (lane == 0) vc = atomicAdd(&s32[9], 1u);
+    vc = __builtin_amdgcn_readfirstlane(vc);
+    if (vc >= VC) break;
     const uint32_t img = vc >= maxc, k = vc - img * maxc;
+    const uint32_t meta = fr_meta[lane];
+    const int slot = fr_slot[lane];
     const uint32_t n = img ? (fr_n[lane] >> 16) : (fr_n[lane] & 0xFFFF);
-    if (k >= n) continue;
     const uint32_t tag = meta_tag(meta), ok = meta_old(meta);
-    if ((img == 0 && ok == ETLG_OLD_NONE) || (img == 1 && tag == 'D')) continue;
-    const DevSlot& s = p.slots[slot];
     const uint32_t mode = img ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
                               : (ok == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
-    if (image_shape_error(s, mode, n)) continue;
-    const DevCol* cols = p.cols + s.cols_base;
-    const int ci = cell_column(s, cols, mode, n, k);
-    if (ci < 0) continue;
-    const DevCol col = cols[ci];
-    const uint32_t osz = ok == ETLG_OLD_FULL ? s.row_full : ok == ETLG_OLD_KEY ? s.row_key : 0;
-    u8* row = pg.fixed + fr_fx[lane] + (img ? osz : 0);
-    uint32_t* slotp = (uint32_t*)(row + (mode == ROW_KEY ? col.off_key : col.off_full));
-    const uint32_t kout = mode == ROW_KEY ? col.key_index : (uint32_t)ci;
-    const uint32_t lw = ct_len[vc * CF + lane];
-    const uint32_t kind = lw >> 30, len = lw & 0x3FFFFFFFu;
+    bool act = ((meta >> 11) & 1) && slot >= 0 && k < n && !((img == 0 && ok == ETLG_OLD_NONE) || (img == 1 && tag == 'D'));
+    DevCol col{};
+    uint32_t* slotp = nullptr;
+    uint32_t kout = 0;
+    if (act) {
+      const DevSlot& s = p.slots[slot];
+      const DevCol* cols = p.cols + s.cols_base;
+      const int ci = image_shape_error(s, mode, n) ? -1 : cell_column(s, cols, mode, n, k);
+      if (ci < 0) act = false;
+      else {
+        col = cols[ci];
+        const uint32_t osz = ok == ETLG_OLD_FULL ? s.row_full : ok == ETLG_OLD_KEY ? s.row_key : 0;
+        u8* row = pg.fixed + fr_fx[lane] + (img ? osz : 0);
+        slotp = (uint32_t*)(row + (mode == ROW_KEY ? col.off_key : col.off_full));
+        kout = mode == ROW_KEY ? col.key_index : (uint32_t)ci;
+      }
+    }
+    uint32_t kind = CT_N, len = 0, pos = 0, hcur = 0;
+    if (act) {
+      const uint32_t lw = ct_len[vc * CF + lane];
+      kind = lw >> 30; len = lw & 0x3FFFFFFFu;
+      pos = ct_pos[vc * CF + lane];
+      hcur = fr_hp[lane] + ct_h[vc * CF + lane];
+    }
     const uint32_t order = img * 32u + 1u + k;
+    const uint32_t cls = col.cls;
     uint32_t st = ETLG_CELL_NULL, err = 0;
-    if (kind == CT_T) {
-      const u8* d = stage + ct_pos[vc * CF + lane];
-      uint32_t hcur = fr_hp[lane] + ct_h[vc * CF + lane];
-      const uint32_t cls = col.cls;
+    bool textual = act && kind == CT_T;
+    if (q.dbg >> 6) {  // profiling ablations (results are wrong): skip one family of value codecs
+      const uint32_t fam = cls == ETLG_TC_NUMERIC ? 1u : (cls >= ETLG_TC_DATE && cls <= ETLG_TC_TIMESTAMPTZ) ? 2u : cls == ETLG_TC_UUID ? 4u
+                         : (cls == ETLG_TC_STRING || class_always_deferred(cls)) ? 8u : 16u;
+      if ((q.dbg >> 6) & fam) textual = false;
+    }
+    // text that is copied to the heap verbatim (String cells, cells deferred wholesale): the
+    // whole wave moves the bytes, a group of lanes per frame, with coalesced dword stores
+    const bool coop = textual && (cls == ETLG_TC_STRING || class_always_deferred(cls));
+    if (__ballot(coop)) {
+      const uint32_t clen = coop ? len : 0u;
+      const uint32_t lgG = __ballot(clen > 64u) ? 5u : __ballot(clen > 32u) ? 4u : 3u;
+      const bool bad_utf8 = ((q.dbg >> 11) & 4) ? false : coop_copy(base, pg.heap, pos, clen, hcur, lane, lgG, use_lds, (q.dbg >> 11) & 3);
+      if (coop) {
+        slotp[0] = hcur; slotp[1] = len;
+        st = cls == ETLG_TC_STRING ? (uint32_t)ETLG_CELL_VALUE : (uint32_t)ETLG_CELL_DEFERRED;
+        if (bad_utf8) err = ETLG_E_UTF8;
+      }
+    }
+    if (textual && !coop) {
       bool done = false;
       while (!done) {  // waterfall over the distinct classes of this wave's cells
         const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
-        if (cls == u) { err = decode_text_cell(u, d, len, slotp, pg.heap, hcur, st, true); done = true; }
+        if (cls == u) { err = decode_text_cell(u, base + pos, len, slotp, pg.heap, hcur, st, use_lds); done = true; }
       }
-    } else if (kind == CT_N) {
-      if (!col.nullable) err = ETLG_E_REQUIRED_NULL; else slot_zero(slotp, col.cls);
-    } else if (kind == CT_U) {
+    } else if (act && kind == CT_N) {
+      if (!col.nullable) err = ETLG_E_REQUIRED_NULL; else slot_zero(slotp, cls);
+    } else if (act && kind == CT_U) {
       if (mode == ROW_FULL) err = ETLG_E_FULL_ROW_MISSING;
       else if (mode == ROW_KEY) err = ETLG_E_KEY_MISSING_VALUE;
       else { atomicOr(&fr_toast[lane], 1u << k); st = 0; }  // resolved by the frame's lane in P4
-    } else {
+    } else if (act && kind == CT_B) {
       err = ETLG_E_BINARY_FORMAT;
     }
-    if (err) atomicMin(&fr_err[lane], (order << 8) | err);
-    else if (st) atomicOr(&fr_st[img][lane], st << (2 * kout));
+    if (act) {
+      if (err) atomicMin(&fr_err[lane], (order << 8) | err);
+      else if (st) atomicOr(&fr_st[img][lane], st << (2 * kout));
+    }
   }
   __threadfence_block();
   __syncthreads();
+  TSTAMP(7);
 
   // ================= P4 (wave 0): finish rows, event headers
   if (wave != 0 || !emit) return;
@@ -505,8 +596,9 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     pg.ev_body[ev_idx] = fx_off;
   } else {
     RowMsg dummy{};
-    write_frame(p, v, tx, dummy, -1, ev_idx, fx_off, hp_off, nullptr, true);
+    write_frame(p, v, tx, dummy, -1, ev_idx, fx_off, hp_off, nullptr, use_lds);
   }
+  TSTAMP(8);
 }
 
 }  // namespace etlg

@@ -35,6 +35,25 @@ DEV uint32_t lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
 
 DEV void st64(uint32_t* w, uint64_t v) { w[0] = (uint32_t)v; w[1] = (uint32_t)(v >> 32); }
 
+// Sequential byte reader. With `over` (the caller guarantees 7 readable bytes past any index it
+// asks for: LDS-staged tiles keep 16 bytes of slack) it fetches 8 bytes per load, i.e. one memory
+// round trip per 8 characters instead of one per character; without it every access is a byte load.
+struct ByteWin {
+  const u8* s; bool over;
+  uint32_t base = 0x80000000u; uint64_t w = 0;
+  DEV uint32_t at(uint32_t i) {  // ascending access
+    if (!over) return s[i];
+    uint32_t d = i - base;
+    if (d >= 8u) { base = i; __builtin_memcpy(&w, s + i, 8); d = 0; }
+    return (uint32_t)(w >> (8 * d)) & 0xFFu;
+  }
+  DEV uint32_t at_rev(uint32_t i) {  // descending access
+    if (!over) return s[i];
+    if (i - base >= 8u) { base = i >= 7u ? i - 7u : 0u; __builtin_memcpy(&w, s + base, 8); }
+    return (uint32_t)(w >> (8 * (i - base))) & 0xFFu;
+  }
+};
+
 DEV void record_error(const DecParams& p, uint32_t frame, uint32_t rank, uint32_t code) {
   unsigned long long key = ((unsigned long long)frame << 16) | ((unsigned long long)rank << 8) | code;
   atomicMin(&p.res->first_err, key);
@@ -465,7 +484,7 @@ struct NumShape {
   uint32_t mant_len;    // mantissa bytes (digits, '.', '_')
 };
 
-DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o) {
+DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o, bool over = false) {
   trim_ws(s, n);
   if (n == 0) return false;
   o.sign = 0; o.kind = ETLG_NUM_VALUE; o.weight = 0; o.scale = 0; o.ngroups = 0;
@@ -482,15 +501,16 @@ DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o) {
   }
   // parse_numeric_value
   uint32_t pos = 0;
+  ByteWin bw{s, over};
   bool have_dp = false;
   int32_t dweight = -1;
   uint32_t dscale = 0;
-  if (s[0] == '.') { have_dp = true; pos = 1; }
-  if (!(pos < n && is_digit(s[pos]))) return false;
+  if (bw.at(0) == '.') { have_dp = true; pos = 1; }
+  if (!(pos < n && is_digit(bw.at(pos)))) return false;
   o.mant = s + pos;
   int32_t k = 0, first_nz = -1, last_nz = -1;  // decimal digit indexes
   while (pos < n) {
-    const uint32_t c = s[pos];
+    const uint32_t c = bw.at(pos);
     if (is_digit(c)) {
       pos++;
       if (c != '0') { if (first_nz < 0) first_nz = k; last_nz = k; }
@@ -499,29 +519,29 @@ DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o) {
     } else if (c == '.') {
       if (have_dp) return false;
       have_dp = true; pos++;
-      if (pos < n && s[pos] == '_') return false;
+      if (pos < n && bw.at(pos) == '_') return false;
     } else if (c == '_') {
       pos++;
-      if (!(pos < n && is_digit(s[pos]))) return false;
+      if (!(pos < n && is_digit(bw.at(pos)))) return false;
     } else break;
   }
   o.mant_len = (uint32_t)((s + pos) - o.mant);
-  if (pos < n && (s[pos] == 'e' || s[pos] == 'E')) {
+  if (pos < n && (bw.at(pos) == 'e' || bw.at(pos) == 'E')) {
     pos++;
     int64_t ex = 0;
     bool exneg = false;
-    if (pos < n && s[pos] == '+') pos++;
-    else if (pos < n && s[pos] == '-') { exneg = true; pos++; }
-    if (!(pos < n && is_digit(s[pos]))) return false;
+    if (pos < n && bw.at(pos) == '+') pos++;
+    else if (pos < n && bw.at(pos) == '-') { exneg = true; pos++; }
+    if (!(pos < n && is_digit(bw.at(pos)))) return false;
     while (pos < n) {
-      const uint32_t c = s[pos];
+      const uint32_t c = bw.at(pos);
       if (is_digit(c)) {
         pos++;
         ex = ex * 10 + (c - '0');
         if (ex > 0x3FFFFFFF) return false;  // i32::MAX / 2 guard -> ValueOutOfRange
       } else if (c == '_') {
         pos++;
-        if (!(pos < n && is_digit(s[pos]))) return false;
+        if (!(pos < n && is_digit(bw.at(pos)))) return false;
       } else break;
     }
     if (exneg) ex = -ex;
@@ -545,7 +565,7 @@ DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o) {
 }
 
 // Writes the etlg_numeric_hdr + digits at `dst` (4-byte aligned); returns bytes incl. padding.
-DEV uint32_t numeric_emit(const NumShape& o, u8* dst) {
+DEV uint32_t numeric_emit(const NumShape& o, u8* dst, bool over = false) {
   uint32_t* w = (uint32_t*)dst;
   w[0] = o.kind | (o.sign << 8) | ((uint32_t)(uint16_t)(int16_t)o.weight << 16);
   w[1] = o.scale | ((o.ngroups & 0xFFFFu) << 16);
@@ -555,8 +575,9 @@ DEV uint32_t numeric_emit(const NumShape& o, u8* dst) {
     int32_t cur = o.first_group;
     uint32_t acc = 0;
     static const uint32_t p10[4] = {1000, 100, 10, 1};
+    ByteWin bw{o.mant, over};
     for (uint32_t i = 0; i < o.mant_len; i++) {
-      const uint32_t c = o.mant[i];
+      const uint32_t c = bw.at(i);
       if (!is_digit(c)) continue;
       const int32_t pos = o.offset + k;
       k++;
@@ -602,7 +623,7 @@ DEV bool iso_date_fast(const u8* s, uint32_t n, int32_t& days) {
   return ymd_to_ce_days(y1 * 100 + y2, m, d, days);
 }
 // parse_iso_time_fast, codec/time.rs:107-141
-DEV bool iso_time_fast(const u8* s, uint32_t n, uint32_t& secs, uint32_t& nanos) {
+DEV bool iso_time_fast(const u8* s, uint32_t n, uint32_t& secs, uint32_t& nanos, bool over = false) {
   if (n < 8 || s[2] != ':' || s[5] != ':') return false;
   uint32_t h, m, sec;
   if (!two_digits(s, h) || !two_digits(s + 3, m) || !two_digits(s + 6, sec)) return false;
@@ -612,7 +633,8 @@ DEV bool iso_time_fast(const u8* s, uint32_t n, uint32_t& secs, uint32_t& nanos)
     const uint32_t fl = n - 9;
     if (fl == 0 || fl > 9) return false;
     uint32_t v = 0;
-    for (uint32_t i = 0; i < fl; i++) { const uint32_t d = s[9 + i] - '0'; if (d > 9) return false; v = v * 10 + d; }
+    ByteWin bw{s, over};
+    for (uint32_t i = 0; i < fl; i++) { const uint32_t d = bw.at(9 + i) - '0'; if (d > 9) return false; v = v * 10 + d; }
     for (uint32_t i = fl; i < 9; i++) v *= 10;
     nanos = v;
   }
@@ -621,19 +643,19 @@ DEV bool iso_time_fast(const u8* s, uint32_t n, uint32_t& secs, uint32_t& nanos)
   return true;
 }
 // parse_iso_timestamp_fast, codec/time.rs:145-154
-DEV bool iso_timestamp_fast(const u8* s, uint32_t n, int32_t& days, uint32_t& secs, uint32_t& nanos) {
+DEV bool iso_timestamp_fast(const u8* s, uint32_t n, int32_t& days, uint32_t& secs, uint32_t& nanos, bool over = false) {
   if (n < 19 || s[10] != ' ') return false;
-  return iso_date_fast(s, 10, days) && iso_time_fast(s + 11, n - 11, secs, nanos);
+  return iso_date_fast(s, 10, days) && iso_time_fast(s + 11, n - 11, secs, nanos, over);
 }
 // parse_postgres_utc_offset, crates/etl-postgres/src/time.rs:143-207
-DEV bool parse_utc_offset(const u8* s, uint32_t n, int32_t& out) {
+DEV bool parse_utc_offset(const u8* s, uint32_t n, int32_t& out, bool over = false) {
   if (n == 0) return false;
   int32_t sign;
   if (s[0] == '+') sign = 1; else if (s[0] == '-') sign = -1; else return false;
   s++; n--;
   uint32_t h = 0, m = 0, sec = 0;
   bool colon = false;
-  for (uint32_t i = 0; i < n; i++) if (s[i] == ':') colon = true;
+  { ByteWin bw{s, over}; for (uint32_t i = 0; i < n; i++) if (bw.at(i) == ':') colon = true; }
   if (colon) {
     if (n == 5) { if (s[2] != ':' || !two_digits(s, h) || !two_digits(s + 3, m)) return false; }
     else if (n == 8) { if (s[2] != ':' || s[5] != ':' || !two_digits(s, h) || !two_digits(s + 3, m) || !two_digits(s + 6, sec)) return false; }
@@ -651,10 +673,12 @@ DEV bool parse_utc_offset(const u8* s, uint32_t n, int32_t& out) {
   return true;
 }
 // split_utc_offset / split_timestamp_offset: last '+'/'-' with byte index > min_index.
-DEV int32_t split_offset_index(const u8* s, uint32_t n, uint32_t min_index) {
+DEV int32_t split_offset_index(const u8* s, uint32_t n, uint32_t min_index, bool over = false) {
+  ByteWin bw{s, over};
   for (uint32_t i = n; i-- > 0;) {
     if (i <= min_index) break;
-    if (s[i] == '+' || s[i] == '-') return (int32_t)i;
+    const uint32_t c = bw.at_rev(i);
+    if (c == '+' || c == '-') return (int32_t)i;
   }
   return -1;
 }
@@ -665,11 +689,12 @@ DEV int hexv(uint32_t c) {
   return -1;
 }
 // uuid 1.23 Uuid::parse_str: simple(32) | hyphenated(36) | {braced}(38) | urn:uuid:(45)
-DEV bool parse_uuid(const u8* s, uint32_t n, uint32_t* out4) {
+DEV bool parse_uuid(const u8* s, uint32_t n, uint32_t* out4, bool over = false) {
   u8 b[16];
   if (n == 32) {
+    ByteWin bw{s, over};
     for (int i = 0; i < 16; i++) {
-      int h = hexv(s[2 * i]), l = hexv(s[2 * i + 1]);
+      int h = hexv(bw.at(2 * i)), l = hexv(bw.at(2 * i + 1));
       if ((h | l) < 0) return false;
       b[i] = (u8)((h << 4) | l);
     }
@@ -682,9 +707,10 @@ DEV bool parse_uuid(const u8* s, uint32_t n, uint32_t* out4) {
     else return false;
     if (h[8] != '-' || h[13] != '-' || h[18] != '-' || h[23] != '-') return false;
     int k = 0;
+    ByteWin bw{h, over};
     for (int i = 0; i < 16; i++) {
       if (k == 8 || k == 13 || k == 18 || k == 23) k++;
-      int hi = hexv(h[k]), lo = hexv(h[k + 1]);
+      int hi = hexv(bw.at(k)), lo = hexv(bw.at(k + 1));
       if ((hi | lo) < 0) return false;
       b[i] = (u8)((hi << 4) | lo);
       k += 2;
@@ -700,25 +726,25 @@ DEV bool class_always_deferred(uint32_t cls) {
 }
 
 // Heap bytes a text cell will occupy (exact for every non-error outcome).
-DEV uint32_t cell_heap_bytes(uint32_t cls, const u8* d, uint32_t len) {
+DEV uint32_t cell_heap_bytes(uint32_t cls, const u8* d, uint32_t len, bool over = false) {
   if (class_always_deferred(cls) || cls == ETLG_TC_STRING) return pad4(len);
   switch (cls) {
     case ETLG_TC_BYTEA: return len >= 2 ? pad4((len - 2) >> 1) : 0;
-    case ETLG_TC_NUMERIC: { NumShape s; return numeric_scan(d, len, s) ? pad4(8 + 2 * s.ngroups) : 0; }
+    case ETLG_TC_NUMERIC: { NumShape s; return numeric_scan(d, len, s, over) ? pad4(8 + 2 * s.ngroups) : 0; }
     case ETLG_TC_DATE: { int32_t x; return iso_date_fast(d, len, x) ? 0 : pad4(len); }
-    case ETLG_TC_TIME: { uint32_t a, b; return iso_time_fast(d, len, a, b) ? 0 : pad4(len); }
-    case ETLG_TC_TIMESTAMP: { int32_t x; uint32_t a, b; return iso_timestamp_fast(d, len, x, a, b) ? 0 : pad4(len); }
+    case ETLG_TC_TIME: { uint32_t a, b; return iso_time_fast(d, len, a, b, over) ? 0 : pad4(len); }
+    case ETLG_TC_TIMESTAMP: { int32_t x; uint32_t a, b; return iso_timestamp_fast(d, len, x, a, b, over) ? 0 : pad4(len); }
     case ETLG_TC_TIMESTAMPTZ: {
-      int32_t idx = split_offset_index(d, len, 10);
+      int32_t idx = split_offset_index(d, len, 10, over);
       if (idx < 0) return 0;
       int32_t x; uint32_t a, b;
-      return iso_timestamp_fast(d, (uint32_t)idx, x, a, b) ? 0 : pad4(len);
+      return iso_timestamp_fast(d, (uint32_t)idx, x, a, b, over) ? 0 : pad4(len);
     }
     case ETLG_TC_TIMETZ: {
-      int32_t idx = split_offset_index(d, len, 0);
+      int32_t idx = split_offset_index(d, len, 0, over);
       if (idx < 0) return 0;
       uint32_t a, b;
-      return iso_time_fast(d, (uint32_t)idx, a, b) ? 0 : pad4(len);
+      return iso_time_fast(d, (uint32_t)idx, a, b, over) ? 0 : pad4(len);
     }
     default: return 0;
   }
@@ -767,11 +793,11 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
     case ETLG_TC_I64: { int64_t v; if (!(over ? parse_int_swar(d, len, true, 64, v) : parse_int(d, len, true, 64, v))) return bad(ETLG_E_INT); st64(slot, (uint64_t)v); return 0; }
     case ETLG_TC_NUMERIC: {
       NumShape s;
-      if (!numeric_scan(d, len, s)) return bad(ETLG_E_NUMERIC);
+      if (!numeric_scan(d, len, s, over)) return bad(ETLG_E_NUMERIC);
       // the numeric grammar strips Unicode whitespace, so a successful scan may still
       // have seen multi-byte characters: those must be valid UTF-8 too
       if (!utf8_valid(d, len)) return ETLG_E_UTF8;
-      numeric_emit(s, heap + hcur);
+      numeric_emit(s, heap + hcur, over);
       var(8 + 2 * s.ngroups);
       return 0;
     }
@@ -781,10 +807,11 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
       const uint32_t nb = (len - 2) >> 1;
       u8* dst = heap + hcur;
       uint32_t w = 0;
+      ByteWin bw{d, over};
       for (uint32_t i = 0; i < nb; i++) {
-        int h = hexv(d[2 + 2 * i]);
+        int h = hexv(bw.at(2 + 2 * i));
         if (h < 0) return bad(ETLG_E_BYTEA);
-        int l = hexv(d[3 + 2 * i]);
+        int l = hexv(bw.at(3 + 2 * i));
         if (l < 0) return bad(ETLG_E_BYTEA);
         w |= (uint32_t)((h << 4) | l) << (8 * (i & 3));
         if ((i & 3) == 3) { ((uint32_t*)dst)[i >> 2] = w; w = 0; }
@@ -794,36 +821,36 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
       return 0;
     }
     case ETLG_TC_DATE: { int32_t x; if (!iso_date_fast(d, len, x)) return defer(); slot[0] = (uint32_t)x; slot[1] = 0; return 0; }
-    case ETLG_TC_TIME: { uint32_t a, b; if (!iso_time_fast(d, len, a, b)) return defer(); slot[0] = a; slot[1] = b; return 0; }
+    case ETLG_TC_TIME: { uint32_t a, b; if (!iso_time_fast(d, len, a, b, over)) return defer(); slot[0] = a; slot[1] = b; return 0; }
     case ETLG_TC_TIMESTAMP: {
       int32_t x; uint32_t a, b;
-      if (!iso_timestamp_fast(d, len, x, a, b)) return defer();
+      if (!iso_timestamp_fast(d, len, x, a, b, over)) return defer();
       slot[0] = (uint32_t)x; slot[1] = a; slot[2] = b;
       return 0;
     }
     case ETLG_TC_TIMESTAMPTZ: {  // codec/time.rs:63-71 + UTC normalisation codec/text.rs:108-111
-      const int32_t idx = split_offset_index(d, len, 10);
+      const int32_t idx = split_offset_index(d, len, 10, over);
       if (idx < 0) return bad(ETLG_E_DATETIME);
       int32_t x; uint32_t a, b;
-      if (!iso_timestamp_fast(d, (uint32_t)idx, x, a, b)) return defer();
+      if (!iso_timestamp_fast(d, (uint32_t)idx, x, a, b, over)) return defer();
       int32_t off;
-      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return bad(ETLG_E_DATETIME);
+      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off, over)) return bad(ETLG_E_DATETIME);
       int32_t sec = (int32_t)a - off;
       if (sec < 0) { sec += 86400; x -= 1; } else if (sec >= 86400) { sec -= 86400; x += 1; }
       slot[0] = (uint32_t)x; slot[1] = (uint32_t)sec; slot[2] = b;
       return 0;
     }
     case ETLG_TC_TIMETZ: {  // crates/etl-postgres/src/time.rs:121-127
-      const int32_t idx = split_offset_index(d, len, 0);
+      const int32_t idx = split_offset_index(d, len, 0, over);
       if (idx < 0) return bad(ETLG_E_DATETIME);
       uint32_t a, b;
-      if (!iso_time_fast(d, (uint32_t)idx, a, b)) return defer();
+      if (!iso_time_fast(d, (uint32_t)idx, a, b, over)) return defer();
       int32_t off;
-      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off)) return bad(ETLG_E_DATETIME);
+      if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off, over)) return bad(ETLG_E_DATETIME);
       slot[0] = a; slot[1] = b; slot[2] = (uint32_t)off;
       return 0;
     }
-    case ETLG_TC_UUID: return parse_uuid(d, len, slot) ? 0 : bad(ETLG_E_UUID);
+    case ETLG_TC_UUID: return parse_uuid(d, len, slot, over) ? 0 : bad(ETLG_E_UUID);
     default: return defer();
   }
 }
@@ -842,7 +869,7 @@ DEV uint32_t slot_bytes(uint32_t cls) {  // layout rule of include/etlg.h
 //   mode 0: full row (convert_tuple_to_row); mode 1: dense key tuple;
 //   mode 2: full-width key tuple (non-identity positions skipped unread);
 //   mode 3: update new tuple (u cells never allocate: alias or Missing)
-DEV uint32_t tuple_heap_bytes(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, int mode) {
+DEV uint32_t tuple_heap_bytes(const DecParams& p, const DevSlot& s, const u8* tuple, uint32_t ncells, int mode, bool over = false) {
   if (!s.has_var) return 0;  // fixed-width schema: no cell can reach the heap
   const DevCol* cols = p.cols + s.cols_base;
   CellIt it; it.begin(tuple);
@@ -861,7 +888,7 @@ DEV uint32_t tuple_heap_bytes(const DecParams& p, const DevSlot& s, const u8* tu
       ci = i;
       if (mode == 2) { if (!cols[ci].identity) continue; next_ident++; }
     }
-    if (t == 't') h += cell_heap_bytes(cols[ci].cls, d, len);
+    if (t == 't') h += cell_heap_bytes(cols[ci].cls, d, len, over);
   }
   (void)next_ident;
   return h;
@@ -1033,7 +1060,7 @@ DEV bool frame_structure(const FrameView& v, RowMsg& m) {
 // sizing); the frame is sized as if inside a transaction and txn_check_frame runs later.
 DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bool wire_ok, const RowMsg& m,
                     uint32_t& emit, uint32_t& fixed, uint32_t& heap, uint64_t pay[3], int& row_slot,
-                    bool check_txn = true) {
+                    bool check_txn = true, bool over = false) {
   const uint32_t f = v.f, tag = v.tag;
   const u8* b = v.fr + kBodyOff;
   emit = 0; fixed = 0; heap = 0;
@@ -1072,7 +1099,7 @@ DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bo
         if (is_new) { fixed += s.row_full; mode = tag == 'U' ? 3 : 0; }
         else if (m.old_kind == ETLG_OLD_FULL) { fixed += s.row_full; mode = 0; }
         else { fixed += s.row_key; mode = m.old_n == s.n_ident ? 1 : m.old_n == s.n_cols ? 2 : -1; }
-        if (mode >= 0) heap += tuple_heap_bytes(p, s, is_new ? m.new_t : m.old_t, is_new ? m.new_n : m.old_n, mode);
+        if (mode >= 0) heap += tuple_heap_bytes(p, s, is_new ? m.new_t : m.old_t, is_new ? m.new_n : m.old_n, mode, over);
       }
       break;
     }

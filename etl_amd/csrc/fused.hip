@@ -99,7 +99,7 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
   uint32_t emit = 0, fixed = 0, heap = 0;
   uint64_t pay[3] = {0, 0, 0};
   int row_slot = -1;
-  if (live) size_frame(p, v, tx, wire_ok, m, emit, fixed, heap, pay, row_slot, q.seq_lookback != 0);
+  if (live) size_frame(p, v, tx, wire_ok, m, emit, fixed, heap, pay, row_slot, q.seq_lookback != 0, STAGED);
   TSTAMP(5);
   uint32_t x_ev = emit, x_fx = fixed >> 2, x_hp = heap >> 2, tot3[3];
   block_scan3_excl(x_ev, x_fx, x_hp, s32, tot3);

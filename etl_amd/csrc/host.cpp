@@ -199,6 +199,7 @@ struct etlg_ctx {
   bool side_valid = false;
   bool force_multipass = false;  // ETLG_FORCE_MULTIPASS=1 (tests exercise both paths)
   unsigned long long last_dbg[12] = {0};
+  unsigned long long path_n[4] = {0, 0, 0, 0};
   int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells (default: by frame size)
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
@@ -224,6 +225,7 @@ struct etlg_batch {
   std::vector<etlg_slot_desc> slot_descs;
   bool pending = false;  // ASYNC: counts not read back yet
   DevResult* h_res = nullptr;  // pinned, from the context's pool
+  bool used_cells = false; // ... and it was k_cells
   bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
   DecParams params{};
   // what sync needs to finish the batch
@@ -845,6 +847,14 @@ int32_t etlg_ctx_debug_times(etlg_ctx* c, unsigned long long* out12) {
   return ETLG_OK;
 }
 
+// debugging aid (not part of etlg.h): batches finished per path
+//   [0] k_fused  [1] k_cells  [2] multi-pass directly  [3] single-pass result discarded and redone by the multi-pass kernels
+int32_t etlg_ctx_debug_paths(etlg_ctx* c, unsigned long long* out4) {
+  if (!c || !out4) return ETLG_InvalidArgument;
+  for (int i = 0; i < 4; i++) out4[i] = c->path_n[i];
+  return ETLG_OK;
+}
+
 int32_t etlg_ctx_profile(etlg_ctx* c, int32_t enable) {
   if (!c) return ETLG_InvalidArgument;
   c->prof = enable != 0;
@@ -1053,7 +1063,9 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     use_cells = kernel == 2;
     q.blk = kernel == 0 ? 256u : 64u;
     q.maxc = widest;
-    uint64_t cap = kernel == 0 ? (uint64_t)q.blk * avg * 9 / 8 + 1024 : (uint64_t)q.blk * avg * 5 / 4 + 2048;
+    // LDS window per tile: the average tile plus a margin; a tile that does not fit reads the input in place
+    uint64_t cap = kernel == 1 ? (uint64_t)q.blk * avg * 5 / 4 + 2048 : (uint64_t)q.blk * avg * 9 / 8 + 1024;
+    if (const char* lm = getenv("ETLG_LDS_MARGIN_PCT")) cap = (uint64_t)q.blk * avg * (100 + (uint64_t)atoi(lm)) / 100 + 1024;
     cap = (cap + 255) & ~255ull;
     if (use_cells) cap += etlg_k_cells_table_bytes(widest);
     cap = std::min<uint64_t>(cap + q.side_bytes, 150 * 1024);
@@ -1071,6 +1083,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     q.ticket = (uint32_t*)(q.d_outb + per);
     launch(c, use_cells ? kCells : kFused, p);
     b->used_fused = true;
+    b->used_cells = use_cells;
   } else {
     launch_multipass(c, p, classify_done);
   }
@@ -1165,6 +1178,9 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
     HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     b->used_fused = false;
+    c->path_n[3]++;
+  } else {
+    c->path_n[b->used_fused ? (b->used_cells ? 1 : 0) : 2]++;
   }
   DevResult r = *b->h_res;
   if (b->used_fused) for (int k = 0; k < 3; k++) { r.payload[k] = 0; for (int sh = 0; sh < 32; sh++) r.payload[k] += r.pay_shard[sh][k]; }

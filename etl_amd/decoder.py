@@ -151,3 +151,10 @@ class Decoder:
         n = C.c_uint32()
         self.L.etlg_ctx_profile_read(self.h, arr, 16, C.byref(n))
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
+
+    def debug_paths(self):
+        """Batches finished per kernel path (debugging aid, not in etlg.h):
+        {'fused', 'cells', 'multipass', 'redone'}."""
+        out = (C.c_ulonglong * 4)()
+        self.L.etlg_ctx_debug_paths(self.h, out)
+        return dict(zip(("fused", "cells", "multipass", "redone"), [int(x) for x in out]))

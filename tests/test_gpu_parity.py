@@ -11,6 +11,29 @@ pytestmark = pytest.mark.gpu
 
 ALL = {s.name: s for s in SC.all_scenarios()}
 
+# Every device path must give the oracle's bytes: the default choice (by frame size) and each
+# kernel forced through the environment knobs read by etlg_ctx_create.
+PATHS = {
+    "default": {},
+    "fused256": {"ETLG_FUSED_KERNEL": "0"},   # k_fused, 256 frames per tile
+    "fused64": {"ETLG_FUSED_KERNEL": "1"},    # k_fused, 64 frames per tile
+    "cells": {"ETLG_FUSED_KERNEL": "2"},      # k_cells (column-parallel)
+    "multipass": {"ETLG_FORCE_MULTIPASS": "1"},
+}
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_BLK", "ETLG_FUSED_DBG")
+
+
+@pytest.fixture(params=sorted(PATHS))
+def path(request):
+    import os
+    saved = {k: os.environ.pop(k, None) for k in _KNOBS}
+    os.environ.update(PATHS[request.param])
+    yield request.param
+    for k in _KNOBS:
+        os.environ.pop(k, None)
+        if saved[k] is not None:
+            os.environ[k] = saved[k]
+
 
 def _both(sc):
     from etl_amd.decoder import Decoder
@@ -23,7 +46,7 @@ def _both(sc):
 
 
 @pytest.mark.parametrize("name", sorted(ALL))
-def test_scenario_parity(name):
+def test_scenario_parity(name, path):
     ref, got = _both(ALL[name])
     assert len(ref) == len(got)
     for i, (r, g) in enumerate(zip(ref, got)):
@@ -41,8 +64,10 @@ def test_native_library_is_the_one_in_tree():
 
 
 @pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 8 << 20), (synth.cfg3, 8 << 20), (synth.cfg5, 4 << 20)])
-def test_large_batch_parity(mk, nbytes):
-    """MiB-scale batches, several in a row on one context (state carried across batches)."""
+def test_large_batch_parity(mk, nbytes, path):
+    """MiB-scale batches, several in a row on one context (state carried across batches).
+    These streams decode without error, so the forced kernel must have produced the result
+    itself (no silent redo by the multi-pass kernels)."""
     from etl_amd.decoder import Decoder
     from oracle import oracle
     w = mk()
@@ -56,7 +81,32 @@ def test_large_batch_parity(mk, nbytes):
         assert rb.err_code == 0 and gb.rc == 0
         diff = rb.host_batch().diff(gb.host())
         assert not diff, diff[:6]
+    n = d.debug_paths()
     d.close()
+    assert n["redone"] == 0, n
+    want = {"fused256": "fused", "fused64": "fused", "cells": "cells", "multipass": "multipass"}.get(path)
+    if want:
+        assert n[want] == 2, n
+
+
+@pytest.mark.parametrize("mk", [synth.cfg2, synth.cfg3])
+def test_full_size_parity(mk):
+    """BASELINE batch size (64 MiB) against the oracle, byte for byte, on the default path."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = mk()
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    buf, offs = w.fill(64 << 20)
+    rb = o.decode(buf, offs)
+    gb = d.decode(buf, offs, flags=abi.F_NO_CONTROL)
+    assert rb.err_code == 0 and gb.rc == 0
+    diff = rb.host_batch().diff(gb.host())
+    assert not diff, diff[:6]
+    n = d.debug_paths()
+    d.close()
+    assert n["redone"] == 0 and n["multipass"] == 0, n
 
 
 def test_device_resident_io_and_no_control_flag():
@@ -121,4 +171,59 @@ def test_full_size_properties_cfg2():
         base = int(hb.body_off[i])
         got = hb.fixed[base + 4:base + 24].view(np.int32).tolist()
         assert got == vals
+    d.close()
+
+
+# ---- UTF-8 validation (core::str::from_utf8, call site codec/event.rs:976): the single-pass
+# kernels validate String cells a dword at a time across lanes, so every sequence is tried at
+# every alignment, at the start and at the very end of the text.
+_VALID = [b"", b"a"] + [chr(cp).encode() for cp in (0x80, 0x7FF, 0x800, 0xD7FF, 0xE000, 0xFFFF, 0x10000, 0x10FFFF)] + \
+         [(chr(0xE9) + chr(0x4E2D) + chr(0x1F600)).encode()]
+_INVALID = [bytes.fromhex(h) for h in (
+    "80", "bf", "c080", "c1bf", "e08080", "e09fbf", "f0808080", "f08fbfbf", "eda080", "edbfbf", "f4908080", "f5808080",
+    "ff", "fe", "c2", "e0a0", "f09080", "e180", "f180", "f1", "c241", "e18041", "f1808041", "c28080", "e14180", "f1804180")]
+
+
+def _utf8_texts(seqs):
+    out = []
+    for s in seqs:
+        for p in range(9):
+            for q in (0, 1, 2, 3, 5):
+                out.append(b"a" * p + s + b"b" * q)
+    return out
+
+
+def _text_batch(texts, wide):
+    from tests import pgwire as W
+    cols = [("id", SC.INT8, False, 1), ("t", SC.TEXT, False, 0)] + ([("pad", SC.TEXT, False, 0)] if wide else [])
+    rows = [[str(i), t] + (["x" * 300] if wide else []) for i, t in enumerate(texts)]
+    s = SC.txn([W.insert(42, r) for r in rows])
+    return SC.simple_table(cols), s
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_utf8_matrix(path, wide):
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    # all valid texts in one batch: no error, identical arenas, and no redo by the multi-pass kernels
+    prime, s = _text_batch(_utf8_texts(_VALID), wide)
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+    rb, gb = o.decode(buf, s.offsets), d.decode(buf, s.offsets)
+    assert rb.err_code == 0 and gb.rc == 0
+    assert not rb.host_batch().diff(gb.host())
+    assert d.debug_paths()["redone"] == 0
+    d.close()
+    # invalid texts one per batch: same error, same frame
+    texts = _utf8_texts(_INVALID)
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    for i in range(0, len(texts), 7):
+        _, s = _text_batch([b"ok", texts[i], b"ok"], wide)
+        buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+        rb, gb = o.decode(buf, s.offsets), d.decode(buf, s.offsets)
+        assert rb.err_code == abi.E_UTF8 and rb.err_frame == 2
+        assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), texts[i]
+        o.reset_stream_state(); d.reset_stream_state()
     d.close()
