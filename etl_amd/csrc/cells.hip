@@ -108,84 +108,38 @@ DEV bool coop_copy(const u8* base, u8* heap, uint32_t pos, uint32_t clen, uint32
   return mine;
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams q) {
-  extern __shared__ __attribute__((aligned(16))) u8 smem[];
-  __shared__ uint32_t s_offs[CF + 1];
-  __shared__ int32_t fr_slot[CF];
-  __shared__ uint32_t fr_meta[CF];
-  __shared__ uint32_t fr_n[CF];      // n_old | n_new << 16
-  __shared__ uint64_t fr_fx[CF];     // fixed-arena offset of the frame's body
-  __shared__ uint32_t fr_hp[CF];     // heap offset of the frame's first entry
-  __shared__ uint32_t fr_st[2][CF];  // 2-bit cell states of the old / new row (<= 16 columns)
-  __shared__ uint32_t fr_err[CF];    // min over (order << 8 | code)
-  __shared__ uint32_t fr_toast[CF];  // new-row columns sent as 'u'
-  __shared__ uint32_t s32[16];
-  __shared__ uint64_t s64[8];
-  DecParams p = pg;
+// LDS arrays of one tile (declared by the kernel, shared by both instantiations below).
+struct CellsLds {
+  uint32_t* s_offs;             // CF + 1 frame offsets
+  int32_t* fr_slot;             // schema slot of the frame's table, -1 = nothing to decode
+  uint32_t* fr_meta;
+  uint32_t* fr_n;               // n_old | n_new << 16
+  uint64_t* fr_fx;              // fixed-arena offset of the frame's body
+  uint32_t* fr_hp;              // heap offset of the frame's first entry
+  uint32_t (*fr_st)[CF];        // 2-bit cell states of the old / new row (<= 16 columns)
+  uint32_t* fr_err;             // min over (order << 8 | code)
+  uint32_t* fr_toast;           // new-row columns sent as 'u'
+  uint32_t* s32; uint64_t* s64;
+  uint2* ct_pl;                 // cell table [virtual column][frame]: (offset of the text in `base`, length | kind << 30)
+  uint32_t* ct_h;               // ... heap bytes of the cell, then its heap offset inside the frame
+};
+
+// Everything after staging. STAGED: `base` is the LDS window holding input bytes [b0, ...), reads
+// may run up to 15 bytes past a frame; otherwise `base` is the input itself (b0 = 0).
+// `p`: parameters whose side-table pointers point at the LDS copy; `pg`: the original ones.
+template <int NW, bool STAGED>
+DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& q, const CellsLds& sh, const u8* base,
+                    uint32_t b0, uint32_t tile, uint32_t nt) {
+  uint32_t* const s_offs = sh.s_offs; int32_t* const fr_slot = sh.fr_slot; uint32_t* const fr_meta = sh.fr_meta;
+  uint32_t* const fr_n = sh.fr_n; uint64_t* const fr_fx = sh.fr_fx; uint32_t* const fr_hp = sh.fr_hp;
+  uint32_t (*const fr_st)[CF] = sh.fr_st; uint32_t* const fr_err = sh.fr_err; uint32_t* const fr_toast = sh.fr_toast;
+  uint32_t* const s32 = sh.s32; uint64_t* const s64 = sh.s64;
+  uint2* const ct_pl = sh.ct_pl; uint32_t* const ct_h = sh.ct_h;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
-  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
-  if (tid < 3) s64[tid] = 0;
-  if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
-  // ---- P0: side tables, offsets, staging
-  if (q.side_bytes) {
-    const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
-    const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
-    uint32_t* d = (uint32_t*)smem;
-    for (uint32_t i = tid; i < nt4; i += NW * 64) d[i] = ((const uint32_t*)p.tables)[i];
-    d += nt4;
-    for (uint32_t i = tid; i < ne4; i += NW * 64) d[i] = ((const uint32_t*)p.epochs)[i];
-    d += ne4;
-    for (uint32_t i = tid; i < ns4; i += NW * 64) d[i] = ((const uint32_t*)p.slots)[i];
-    d += ns4;
-    for (uint32_t i = tid; i < nc4; i += NW * 64) d[i] = ((const uint32_t*)p.cols)[i];
-    uint32_t* b0 = (uint32_t*)smem;
-    p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
-    p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
-  }
   const uint32_t maxc = q.maxc, VC = 2 * maxc;
-  uint32_t* ct_pos = (uint32_t*)(smem + q.side_bytes);
-  uint32_t* ct_len = ct_pos + VC * CF;
-  uint32_t* ct_h = ct_len + VC * CF;
-  u8* stage = (u8*)(ct_h + VC * CF);
-  const uint32_t table_bytes = 3 * VC * CF * 4;
-  const uint32_t tile = blockIdx.x;
   const uint32_t f0 = tile * CF;
-  uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
-  for (uint32_t i = tid; i <= nt; i += NW * 64) s_offs[i] = pg.offs[f0 + i];
-  __syncthreads();
-  TSTAMP(0);
-  const uint32_t span0 = s_offs[0], span1 = s_offs[nt];
-  bool lane_ok = true;
-  if (tid < nt) {
-    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
-    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
-  }
-  const uint32_t a0 = span0 & ~15u;
-  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
-                         (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
-  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
-  // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
-  const u8* base = use_lds ? stage : pg.in;
-  const uint32_t b0 = use_lds ? a0 : 0u;
-  if (use_lds) {
-    const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
-    for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * NW * 64) {
-      const uint32_t c1 = c + 16 * NW * 64, c2 = c + 32 * NW * 64, c3 = c + 48 * NW * 64;
-      uint4 v0 = *(const uint4*)(pg.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
-      if (c1 < full_end) v1 = *(const uint4*)(pg.in + c1);
-      if (c2 < full_end) v2 = *(const uint4*)(pg.in + c2);
-      if (c3 < full_end) v3 = *(const uint4*)(pg.in + c3);
-      *(uint4*)(stage + (c - a0)) = v0;
-      if (c1 < full_end) *(uint4*)(stage + (c1 - a0)) = v1;
-      if (c2 < full_end) *(uint4*)(stage + (c2 - a0)) = v2;
-      if (c3 < full_end) *(uint4*)(stage + (c3 - a0)) = v3;
-    }
-    for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
-  }
-  __syncthreads();
-  TSTAMP(1);
+  constexpr bool use_lds = STAGED;
   uint32_t* fail = &pg.res->fused_fail;
 
   // ================= P1 (wave 0): slice frames into cells, transaction scan, slots
@@ -206,65 +160,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
         v.tag = classify_ptr(v.fr, o1 - o0);
       }
       const uint32_t tag = v.tag;
-      if (tag == 'I' || tag == 'U' || tag == 'D') {
-        // parse_row_msg + walk_tuple, recording every cell
-        const u8* b = v.fr + kBodyOff;
-        const u8* e = v.e;
-        wire_ok = e - b >= 5;
-        if (wire_ok) {
-          rel_id = ld_be32(b);
-          const u8* c = b + 4;
-          // images: 0 = old / key, 1 = new
-          for (int img = 0; img < 2 && wire_ok; img++) {
-            if (img == 0 && tag == 'I') continue;
-            if (img == 1 && tag == 'D') break;
-            if (c >= e) { wire_ok = false; break; }
-            uint32_t t = *c;
-            if (img == 0) {
-              if (t == 'K' || t == 'O') { old_kind = t == 'K' ? ETLG_OLD_KEY : ETLG_OLD_FULL; c++; }
-              else if (tag == 'D') { wire_ok = false; break; }
-              else continue;  // update without an old image
-            } else {
-              if (t != 'N') { wire_ok = false; break; }
-              c++;
-            }
-            if (e - c < 2) { wire_ok = false; break; }
-            const uint32_t n = ld_be16(c);
-            c += 2;
-            if (n & 0x8000u) { wire_ok = false; break; }
-            if (n > maxc) too_wide = true;
-            if (img == 0) n_old = n; else n_new = n;
-            for (uint32_t k = 0; k < n; k++) {
-              if (c >= e) { wire_ok = false; break; }
-              // cell tag and length in one load when the bytes sit in LDS (the window has 16 spare bytes)
-              uint64_t head = *c;
-              if (use_lds) __builtin_memcpy(&head, c, 8);
-              const uint32_t ct = (uint32_t)head & 0xFFu;
-              c++;
-              uint32_t kind, len = 0, pos = 0;
-              if (ct == 'n') kind = CT_N;
-              else if (ct == 'u') kind = CT_U;
-              else if (ct == 't' || ct == 'b') {
-                kind = ct == 't' ? CT_T : CT_B;
-                if (e - c < 4) { wire_ok = false; break; }
-                len = use_lds ? __builtin_bswap32((uint32_t)(head >> 8)) : ld_be32(c);
-                c += 4;
-                if ((len & 0x80000000u) || (uint64_t)(e - c) < len) { wire_ok = false; break; }
-                pos = (uint32_t)(c - base);
-                vbytes += len;
-                c += len;
-              } else { wire_ok = false; break; }
-              if (k < maxc) {
-                const uint32_t vc = (uint32_t)img * maxc + k;
-                ct_pos[vc * CF + lane] = pos;
-                ct_len[vc * CF + lane] = (len & 0x3FFFFFFFu) | (kind << 30);
-                ct_h[vc * CF + lane] = 0;
-                if (len > 0x3FFFFFFFu) too_wide = true;
-              }
-            }
-          }
-        }
-      } else {
+      if (!(tag == 'I' || tag == 'U' || tag == 'D')) {
         RowMsg dummy;
         wire_ok = frame_structure(v, dummy);
       }
@@ -272,6 +168,69 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
       if (tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
       if (tag == 'C') mark = (o0 + 1) << 1;
     }
+    // parse_row_msg + walk_tuple for the I / U / D frames, recording every cell. One wave-level loop
+    // over "items" (an image header or a cell) with 32-bit offsets into `base`. This wave runs alone
+    // while the others wait, so the loop body is written without data-dependent branches (bitwise
+    // predicates and selects; every `&&` on lane values would cost an exec-mask round trip): both
+    // interpretations of the next bytes are computed and the lane's state picks one.
+    {
+      const uint32_t tag = v.tag;
+      uint32_t c = 0, e = 0, img = tag == 'I' ? 1u : 0u, k = 0, n = 0;
+      bool run = false, hdr = true;
+      if (live && (tag == 'I' || tag == 'U' || tag == 'D')) {
+        c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
+        wire_ok = e >= c + 5;
+        if (wire_ok) { rel_id = ld_be32(base + c); c += 4; run = true; }
+      }
+      const bool is_upd = tag == 'U';
+      while (__ballot(run)) {
+        // the next 8 bytes: item tag + i16 count (header) or item tag + i32 length (cell)
+        uint64_t head = 0;
+        if (STAGED) {
+          head = ldu64(base + c);  // the window has 16 spare bytes past any frame
+        } else if (run) {
+          for (uint32_t i = 0; i < 5 && c + i < e; i++) head |= (uint64_t)base[c + i] << (8 * i);
+        }
+        const uint32_t t = (uint32_t)head & 0xFFu;
+        const uint32_t room = e - c;  // c <= e holds for a running lane
+        // --- as an image header: 'K' | 'O' | 'N', i16 column count
+        const bool is_old = (t == 'K') | (t == 'O');
+        const uint32_t img_h = (img == 0) & !is_old & is_upd ? 1u : img;  // update without an old image
+        const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
+        const bool hdr_ok = (room >= 3) & (img_h == 0 ? is_old : t == 'N') & !(cnt16 & 0x8000u);
+        // --- as a cell: 'n' | 'u' | ('t' | 'b') i32 len bytes
+        const bool is_val = (t == 't') | (t == 'b');
+        const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
+        const uint32_t kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
+        const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
+        // --- the lane's state picks one
+        const bool in_cell = !hdr;
+        const bool ok = hdr ? hdr_ok : cell_ok;
+        const bool go = run & ok;
+        if (go & in_cell & (k < maxc)) ct_pl[(img * maxc + k) * CF + lane] = make_uint2(c + 5, len | (kind << 30));
+        wire_ok &= !run | ok;
+        too_wide |= go & (hdr ? cnt16 > maxc : len > 0x3FFFFFFFu);
+        vbytes += go & in_cell ? len : 0u;
+        const uint32_t adv = hdr ? 3u : (is_val ? 5u + len : 1u);
+        c += go ? adv : 0u;
+        if (go & hdr) {
+          img = img_h;
+          old_kind = img_h == 0 ? (t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL) : old_kind;
+          n_old = img_h == 0 ? cnt16 : n_old;
+          n_new = img_h == 0 ? n_new : cnt16;
+          n = cnt16;
+        }
+        k = go ? (hdr ? 0u : k + 1u) : k;
+        hdr = go ? false : hdr;
+        // image complete: an update goes on to its new image, everything else is finished
+        const bool done_img = go & (k == n);
+        const bool next_img = done_img & (img == 0) & is_upd;
+        img = next_img ? 1u : img;
+        hdr = next_img ? true : hdr;
+        run = go & (!done_img | next_img);
+      }
+    }
+    TSTAMP(9);
     // wave-level transaction scan (no barrier: a tile's frames live in one wave)
     {
       uint32_t ic = cnt, im = mark;
@@ -304,6 +263,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
       make_tx(seg_unpack30((uint32_t)(ex >> 32)), (uint32_t)ex);  // look-back results are wave-uniform
     }
+    TSTAMP(10);
     if (live && too_wide) atomicOr(fail, 4u);
     // ownership + schema slot (size_frame's lookups), per frame
     if (live && wire_ok && (v.tag == 'I' || v.tag == 'U' || v.tag == 'D')) {
@@ -341,25 +301,25 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
                                 : (meta_old(meta) == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
       const DevCol* cols = p.cols + s.cols_base;
       const int ci = (!s.has_var || image_shape_error(s, mode, n)) ? -1 : cell_column(s, cols, mode, n, k);
-      const uint32_t lw = ct_len[vc * CF + lane];
-      if (ci >= 0 && (lw >> 30) == CT_T) {
+      const uint2 pl = ct_pl[vc * CF + lane];
+      uint32_t h = 0;
+      if (ci >= 0 && (pl.y >> 30) == CT_T) {
         const uint32_t cls = cols[ci].cls;
-        const u8* d = base + ct_pos[vc * CF + lane];
-        uint32_t h = 0;
+        const u8* d = base + pl.x;
         bool done = false;
         while (!done) {  // one pass per distinct class among the active lanes, scalar dispatch inside
           const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
-          if (cls == u) { h = cell_heap_bytes(u, d, lw & 0x3FFFFFFFu, use_lds); done = true; }
+          if (cls == u) { h = cell_heap_bytes(u, d, pl.y & 0x3FFFFFFFu, use_lds); done = true; }
         }
-        ct_h[vc * CF + lane] = h;
       }
+      ct_h[vc * CF + lane] = h;  // every cell of a decodable image gets its entry (P2b sums them blindly)
     }
   }
   __syncthreads();
   TSTAMP(3);
 
   // ================= P2b (wave 0): shapes, per-frame heap prefix, sizes, look-back
-  uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_ev = 0, x_fx = 0, x_hp = 0;
+  uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_ev = 0, x_fx = 0, x_hp = 0, cells = 0;
   uint64_t pay[3] = {0, 0, 0};
   int row_slot = -1;
   if (wave == 0) {
@@ -374,6 +334,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
           if (row_slot >= 0) {
             const DevSlot& s = p.slots[row_slot];
             emit = 1;
+            uint32_t cells_old = 0, cells_new = 0;  // cells of each image that reach the heap walk
             for (uint32_t img = (tag == 'I' || old_kind == ETLG_OLD_NONE) ? 1u : 0u; img < (tag == 'D' ? 1u : 2u); img++) {
               const uint32_t mode = img ? (tag == 'U' ? (uint32_t)ROW_UPDATE : (uint32_t)ROW_FULL)
                                         : (old_kind == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
@@ -382,19 +343,34 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
               fixed += rb;
               if (img == 0) old_sz = rb;
               const uint32_t serr = image_shape_error(s, mode, n);
-              if (serr) { atomicMin(&fr_err[lane], ((img * 32u) << 8) | serr); continue; }
-              for (uint32_t k = 0; k < n && k < maxc; k++) {  // exclusive prefix of the cells' heap bytes
-                const uint32_t idx = (img * maxc + k) * CF + lane;
-                const uint32_t h = ct_h[idx];
-                ct_h[idx] = heap;
-                heap += h;
-              }
+              const uint32_t nc = n < maxc ? n : maxc;
+              if (serr) atomicMin(&fr_err[lane], ((img * 32u) << 8) | serr);
+              else if (img) cells_new = nc; else cells_old = nc;
             }
+            cells = cells_old | (cells_new << 16);
           }
         }
       } else {
         RowMsg dummy{};
         size_frame(p, v, tx, wire_ok, dummy, emit, fixed, heap, pay, row_slot, q.seq_lookback != 0);
+      }
+    }
+    {  // exclusive prefix of the cells' heap bytes in tuple order (old image, then new image): all
+       // loads first (they are independent), then the running sum out of registers. Lanes without
+       // a decodable row have cells = 0 and only rewrite entries nobody reads.
+      const uint32_t cells_old = cells & 0xFFFFu, cells_new = cells >> 16;
+      uint32_t hh[2 * MAXC];
+#pragma unroll
+      for (uint32_t i = 0; i < 2u * MAXC; i++) hh[i] = i < VC ? ct_h[i * CF + lane] : 0u;
+#pragma unroll
+      for (uint32_t i = 0; i < 2u * MAXC; i++) {
+        if (i < VC) {  // uniform
+          const bool in_new = i >= maxc;
+          const uint32_t k = in_new ? i - maxc : i;
+          const bool take = k < (in_new ? cells_new : cells_old);
+          ct_h[i * CF + lane] = heap;
+          heap += take ? hh[i] : 0u;
+        }
       }
     }
     // wave scan of (events, fixed dwords, heap dwords)
@@ -501,9 +477,9 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     }
     uint32_t kind = CT_N, len = 0, pos = 0, hcur = 0;
     if (act) {
-      const uint32_t lw = ct_len[vc * CF + lane];
-      kind = lw >> 30; len = lw & 0x3FFFFFFFu;
-      pos = ct_pos[vc * CF + lane];
+      const uint2 pl = ct_pl[vc * CF + lane];
+      kind = pl.y >> 30; len = pl.y & 0x3FFFFFFFu;
+      pos = pl.x;
       hcur = fr_hp[lane] + ct_h[vc * CF + lane];
     }
     const uint32_t order = img * 32u + 1u + k;
@@ -532,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
       bool done = false;
       while (!done) {  // waterfall over the distinct classes of this wave's cells
         const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
-        if (cls == u) { err = decode_text_cell(u, base + pos, len, slotp, pg.heap, hcur, st, use_lds); done = true; }
+        if (cls == u) { err = decode_text_cell<false>(u, base + pos, len, slotp, pg.heap, hcur, st, use_lds); done = true; }
       }
     } else if (act && kind == CT_N) {
       if (!col.nullable) err = ETLG_E_REQUIRED_NULL; else slot_zero(slotp, cls);
@@ -599,6 +575,86 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     write_frame(p, v, tx, dummy, -1, ev_idx, fx_off, hp_off, nullptr, use_lds);
   }
   TSTAMP(8);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams q) {
+  extern __shared__ __attribute__((aligned(16))) u8 smem[];
+  __shared__ uint32_t s_offs[CF + 1];
+  __shared__ int32_t fr_slot[CF];
+  __shared__ uint32_t fr_meta[CF];
+  __shared__ uint32_t fr_n[CF];      // n_old | n_new << 16
+  __shared__ uint64_t fr_fx[CF];     // fixed-arena offset of the frame's body
+  __shared__ uint32_t fr_hp[CF];     // heap offset of the frame's first entry
+  __shared__ uint32_t fr_st[2][CF];  // 2-bit cell states of the old / new row (<= 16 columns)
+  __shared__ uint32_t fr_err[CF];    // min over (order << 8 | code)
+  __shared__ uint32_t fr_toast[CF];  // new-row columns sent as 'u'
+  __shared__ uint32_t s32[16];
+  __shared__ uint64_t s64[8];
+  DecParams p = pg;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
+  if (tid < 3) s64[tid] = 0;
+  if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
+  // ---- P0: side tables, offsets, staging
+  {  // the side-input tables always live in LDS here (the host picks another kernel when they do not fit)
+    const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
+    const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
+    uint32_t* d = (uint32_t*)smem;
+    for (uint32_t i = tid; i < nt4; i += NW * 64) d[i] = ((const uint32_t*)p.tables)[i];
+    d += nt4;
+    for (uint32_t i = tid; i < ne4; i += NW * 64) d[i] = ((const uint32_t*)p.epochs)[i];
+    d += ne4;
+    for (uint32_t i = tid; i < ns4; i += NW * 64) d[i] = ((const uint32_t*)p.slots)[i];
+    d += ns4;
+    for (uint32_t i = tid; i < nc4; i += NW * 64) d[i] = ((const uint32_t*)p.cols)[i];
+    uint32_t* b0 = (uint32_t*)smem;
+    p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
+    p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
+  }
+  const uint32_t maxc = q.maxc, VC = 2 * maxc;
+  uint2* ct_pl = (uint2*)(smem + q.side_bytes);  // side_bytes is a multiple of 16
+  uint32_t* ct_h = (uint32_t*)(ct_pl + VC * CF);
+  u8* stage = (u8*)(ct_h + VC * CF);
+  const uint32_t table_bytes = 3 * VC * CF * 4;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t f0 = tile * CF;
+  uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
+  for (uint32_t i = tid; i <= nt; i += NW * 64) s_offs[i] = pg.offs[f0 + i];
+  __syncthreads();
+  TSTAMP(0);
+  const uint32_t span0 = s_offs[0], span1 = s_offs[nt];
+  bool lane_ok = true;
+  if (tid < nt) {
+    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
+    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
+  }
+  const uint32_t a0 = span0 & ~15u;
+  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
+                         (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
+  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
+  if (use_lds) {
+    const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
+    for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * NW * 64) {
+      const uint32_t c1 = c + 16 * NW * 64, c2 = c + 32 * NW * 64, c3 = c + 48 * NW * 64;
+      uint4 v0 = *(const uint4*)(pg.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
+      if (c1 < full_end) v1 = *(const uint4*)(pg.in + c1);
+      if (c2 < full_end) v2 = *(const uint4*)(pg.in + c2);
+      if (c3 < full_end) v3 = *(const uint4*)(pg.in + c3);
+      *(uint4*)(stage + (c - a0)) = v0;
+      if (c1 < full_end) *(uint4*)(stage + (c1 - a0)) = v1;
+      if (c2 < full_end) *(uint4*)(stage + (c2 - a0)) = v2;
+      if (c3 < full_end) *(uint4*)(stage + (c3 - a0)) = v3;
+    }
+    for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
+  }
+  __syncthreads();
+  TSTAMP(1);
+  const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_st, fr_err, fr_toast, s32, s64, ct_pl, ct_h};
+  // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
+  if (use_lds) cells_tile<NW, true>(p, pg, q, sh, stage, a0, tile, nt);
+  else cells_tile<NW, false>(p, pg, q, sh, pg.in, 0u, tile, nt);
 }
 
 }  // namespace etlg

@@ -30,6 +30,22 @@ DEV uint32_t ld_be32(const u8* p) { uint32_t v; __builtin_memcpy(&v, p, 4); retu
 DEV uint64_t ld_be64(const u8* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return __builtin_bswap64(v); }
 DEV uint32_t ld_be16(const u8* p) { return ((uint32_t)p[0] << 8) | p[1]; }
 DEV uint32_t pad4(uint32_t n) { return (n + 3u) & ~3u; }
+
+// Unaligned 4 / 8 byte loads built from ALIGNED dword loads + v_alignbyte. LDS serves a misaligned
+// ds_read_b32 / b64 lane by lane (measured: ~1k cycles per wave-wide access with random alignment),
+// while aligned dword reads run at full rate. These read up to the end of the last dword touched,
+// i.e. at most 3 (ldu32) / 3 (ldu64) bytes beyond the value plus the alignment slack below it.
+DEV uint32_t ldu32(const u8* p) {
+  const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;
+  const uint32_t* q = (const uint32_t*)(p - sh);
+  return __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+}
+DEV uint64_t ldu64(const u8* p) {
+  const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;
+  const uint32_t* q = (const uint32_t*)(p - sh);
+  const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+  return __builtin_amdgcn_alignbyte(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+}
 DEV bool is_digit(uint32_t c) { return c - '0' < 10u; }
 DEV uint32_t lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
 
@@ -326,7 +342,7 @@ struct CellIt {
 
 // ----------------------------------------------------------------- UTF-8
 // core::str::from_utf8 (strict RFC 3629), call site codec/event.rs:976.
-DEV bool utf8_valid(const u8* s, uint32_t n) {
+__device__ __attribute__((noinline)) bool utf8_valid(const u8* s, uint32_t n) {
   uint32_t i = 0;
   // ASCII fast path, 8 bytes at a time
   while (i + 8 <= n) {
@@ -395,7 +411,7 @@ DEV bool ieq(const u8* s, uint32_t n, const char* lit, uint32_t ln) {
 // ------------------------------------------------------------ value codecs
 // Rust `iN::from_str` / `u32::from_str` (codec/text.rs:40-51,135-138).
 // Returns false on error. `bits`: 16/32/64; `is_signed`.
-DEV bool parse_int(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& out) {
+__device__ __attribute__((noinline)) bool parse_int(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& out) {
   if (n == 0) return false;
   bool neg = false;
   uint32_t i = 0;
@@ -765,6 +781,9 @@ DEV void heap_copy(u8* dst, const u8* src, uint32_t n) {
 // parse_cell_from_postgres_text for one cell (codec/text.rs:32-153), writing the
 // slot words / heap entry. Returns 0 or an etlg_err_code; `state` = cell state.
 DEV uint32_t slot_bytes(uint32_t cls);
+// COPY_CLASSES = false: the caller moves verbatim text (String cells, wholesale-deferred classes)
+// itself and never passes those classes in (k_cells).
+template <bool COPY_CLASSES = true>
 DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t* slot, u8* heap, uint32_t& hcur,
                               uint32_t& state, bool over = false) {
   // str::from_utf8 precedes the type switch (codec/event.rs:976). Every non-text grammar below
@@ -779,6 +798,7 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
     if (slot_bytes(cls) == 12) slot[2] = 0;
     return 0u;
   };
+  if (!COPY_CLASSES && (cls == ETLG_TC_STRING || class_always_deferred(cls))) return 0;
   if (class_always_deferred(cls)) return defer();
   switch (cls) {
     case ETLG_TC_STRING:
@@ -787,10 +807,14 @@ DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t*
     case ETLG_TC_BOOL:  // parse_bool, codec/bool.rs:11-19
       if (len == 1 && (d[0] == 't' || d[0] == 'f')) { slot[0] = d[0] == 't'; return 0; }
       return bad(ETLG_E_BOOL);
-    case ETLG_TC_I16: { int64_t v; if (!(over ? parse_int_swar(d, len, true, 16, v) : parse_int(d, len, true, 16, v))) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_I32: { int64_t v; if (!(over ? parse_int_swar(d, len, true, 32, v) : parse_int(d, len, true, 32, v))) return bad(ETLG_E_INT); slot[0] = (uint32_t)(int32_t)v; return 0; }
-    case ETLG_TC_U32: { int64_t v; if (!(over ? parse_int_swar(d, len, false, 32, v) : parse_int(d, len, false, 32, v))) return bad(ETLG_E_INT); slot[0] = (uint32_t)v; return 0; }
-    case ETLG_TC_I64: { int64_t v; if (!(over ? parse_int_swar(d, len, true, 64, v) : parse_int(d, len, true, 64, v))) return bad(ETLG_E_INT); st64(slot, (uint64_t)v); return 0; }
+    case ETLG_TC_I16: case ETLG_TC_I32: case ETLG_TC_U32: case ETLG_TC_I64: {  // one copy of the integer parser for all widths
+      const bool sg = cls != ETLG_TC_U32;
+      const int bits = cls == ETLG_TC_I16 ? 16 : cls == ETLG_TC_I64 ? 64 : 32;
+      int64_t v;
+      if (!(over ? parse_int_swar(d, len, sg, bits, v) : parse_int(d, len, sg, bits, v))) return bad(ETLG_E_INT);
+      if (cls == ETLG_TC_I64) st64(slot, (uint64_t)v); else slot[0] = (uint32_t)v;
+      return 0;
+    }
     case ETLG_TC_NUMERIC: {
       NumShape s;
       if (!numeric_scan(d, len, s, over)) return bad(ETLG_E_NUMERIC);

@@ -19,4 +19,4 @@ for buf, offs in bufs:
         names = ["offs", "stage", "P1 walk", "P2 heap size", "P2b sizes", "lookback", "positions", "P3 decode", "P4 finalize"]
     else:
         names = ["ticket+offs", "stage", "structure", "txn scans", "lookback1", "size", "out scans", "lookback2", "write"]
-    print(paths, "tiles", nt, {n: round(out[i] / nt) for i, n in enumerate(names)}, "sum", round(sum(out[:9]) / nt))
+    print(paths, "tiles", nt, {n: round(out[i] / nt) for i, n in enumerate(names)}, "sum", round(sum(out[:12]) / nt), "extra", [round(out[i] / nt) for i in (9, 10, 11)])
