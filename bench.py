@@ -26,8 +26,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALG_READ_PER_ROW = 113          # framed INSERT record
-ALG_WRITE_PER_ROW = 50          # event header 29 + 5 x i32 + null bitmap
+# Algorithmic bytes of one launch: every input byte read once (frames + the 4-byte
+# offsets sidecar per frame) and every arena byte written once (42 bytes of event header columns per
+# event + the fixed row arena + the heap). cfg2: 113 + 4 + 42 + 24 = 183 bytes per row.
+SIDECAR_BYTES_PER_FRAME = 4
+HEADER_BYTES_PER_EVENT = 42     # kind 1, flags 1, table 4, slot 4, start 8, commit 8, ordinal 8, body offset 8
 
 
 def main():
@@ -96,13 +99,16 @@ def main():
         else:
             keep.append((b, nbytes, nfr, None))
 
+    out_bytes = [0]   # arena bytes written by the drained batches (headers + fixed + heap)
+
     def drain(keep, check):
         tot_b = tot_f = 0
         for b, nbytes, nfr, g in keep:
             rc = b.sync()
+            v = b.view()
             if check and not args.no_check:
-                v = b.view()
                 assert rc == 0 and v.n_events == nfr and v.n_frames == nfr, (rc, v.n_events, v.n_frames, nfr, b.error)
+            out_bytes[0] += HEADER_BYTES_PER_EVENT * v.n_events + v.fixed_bytes + v.heap_bytes
             tot_b += nbytes
             tot_f += nfr
             b.close()
@@ -153,15 +159,23 @@ def main():
         torch.cuda.synchronize()
         prof = dec.profile_read()
         dec.profile(False)
-        _, pf = drain(keep, True)
-        rows_per_launch = pf / args.steps
+        out_bytes[0] = 0
+        pb, pf = drain(keep, True)
         kern = {k: {"launches": n, "avg_us": 1000.0 * ms / n} for k, (n, ms) in prof.items() if n}
         dom = max(kern, key=lambda k: kern[k]["avg_us"])
-        alg_bytes = rows_per_launch * (ALG_READ_PER_ROW + ALG_WRITE_PER_ROW)
+        alg_bytes = (pb + SIDECAR_BYTES_PER_FRAME * pf + out_bytes[0]) / args.steps
         ach = alg_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9
         pipe_us = sum(v["avg_us"] for v in kern.values())
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command
+        # (tools/traffic.sh writes the file; FETCH_SIZE doubled per MI355X_MICROARCH.md, gfx950 note)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+        if os.path.exists(tf):
+            t = json.load(open(tf))
+            if t.get("kernel") == dom and t.get("batch_mib") == args.batch_mib:
+                traffic = t["hbm_bytes_per_launch"]
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(kern[dom]["avg_us"], 2),
                 "pipeline_kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
                 "pipeline_sum_us": round(pipe_us, 2),

@@ -195,7 +195,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         const uint32_t room = e - c;  // c <= e holds for a running lane
         // --- as an image header: 'K' | 'O' | 'N', i16 column count
         const bool is_old = (t == 'K') | (t == 'O');
-        const uint32_t img_h = (img == 0) & !is_old & is_upd ? 1u : img;  // update without an old image
+        const uint32_t img_h = ((img == 0) & !is_old & is_upd) ? 1u : img;  // update without an old image
         const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
         const bool hdr_ok = (room >= 3) & (img_h == 0 ? is_old : t == 'N') & !(cnt16 & 0x8000u);
         // --- as a cell: 'n' | 'u' | ('t' | 'b') i32 len bytes
@@ -210,7 +210,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         if (go & in_cell & (k < maxc)) ct_pl[(img * maxc + k) * CF + lane] = make_uint2(c + 5, len | (kind << 30));
         wire_ok &= !run | ok;
         too_wide |= go & (hdr ? cnt16 > maxc : len > 0x3FFFFFFFu);
-        vbytes += go & in_cell ? len : 0u;
+        vbytes += (go & in_cell) ? len : 0u;
         const uint32_t adv = hdr ? 3u : (is_val ? 5u + len : 1u);
         c += go ? adv : 0u;
         if (go & hdr) {
@@ -592,8 +592,7 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
   DecParams p = pg;
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const int wave = tid >> 6;
+  const uint32_t tid = threadIdx.x;
   if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;
   if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3

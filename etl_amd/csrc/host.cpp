@@ -1058,8 +1058,9 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 16 columns)
     uint32_t widest = 1;
     for (auto& sl : c->slots) widest = std::max<uint32_t>(widest, sl->desc.n_cols);
-    int kernel = avg <= 192 ? 0 : (widest <= etlg_k_cells_maxc() ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
-    if (c->fused_kernel >= 0) kernel = c->fused_kernel == 2 && widest > etlg_k_cells_maxc() ? 1 : c->fused_kernel;
+    const bool cells_ok = widest <= etlg_k_cells_maxc() && q.side_bytes != 0;  // k_cells keeps the side tables in LDS
+    int kernel = avg <= 192 ? 0 : (cells_ok ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
+    if (c->fused_kernel >= 0) kernel = c->fused_kernel == 2 && !cells_ok ? 1 : c->fused_kernel;
     use_cells = kernel == 2;
     q.blk = kernel == 0 ? 256u : 64u;
     q.maxc = widest;

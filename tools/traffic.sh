@@ -1,0 +1,30 @@
+# HBM traffic of the dominant kernel for bench.py's roofline.traffic: two rocprofv3 --pmc passes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass) over the bench command, averaged per launch.
+#   bash tools/traffic.sh [cfg2|cfg3]   ->  gpurun_out/traffic_<wl>.json  (copy to profiles/)
+WL=${1:-cfg2}
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+B="python bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/traffic_${WL}_$c -o p -- $B > gpurun_out/traffic_${WL}_$c.log 2>&1
+done
+python - $WL <<'PY'
+import csv, sys, json, collections, glob
+wl = sys.argv[1]
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"gpurun_out/traffic_{wl}_{c}/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "etlg::k_" not in k: continue
+            k = k.split("etlg::")[1].split("<")[0].split("(")[0]
+            tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+best = max(tot, key=lambda k: tot[k].get("FETCH_SIZE", 0))
+fetch_kb = tot[best]["FETCH_SIZE"] / n[(best, "FETCH_SIZE")]
+write_kb = tot[best]["WRITE_SIZE"] / n[(best, "WRITE_SIZE")]
+out = {"workload": wl, "kernel": best, "batch_mib": 64, "launches": n[(best, "FETCH_SIZE")],
+       "FETCH_SIZE_kb_per_launch": round(fetch_kb, 1), "WRITE_SIZE_kb_per_launch": round(write_kb, 1),
+       "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+       "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024)}
+json.dump(out, open(f"gpurun_out/traffic_{wl}.json", "w"), indent=1)
+print(out)
+PY
