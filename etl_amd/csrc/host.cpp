@@ -32,6 +32,9 @@ extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
 extern "C" const char* etlg_k_name(int which);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_fused_set_lds(void);
+extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* vdesc, void* ndesc,
+                                     uint32_t* hints, uint32_t* result, int sequential, hipStream_t s);
+extern "C" uint32_t etlg_k_bounds_tile_bytes(void);
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
@@ -39,7 +42,8 @@ extern "C" uint32_t etlg_k_cells_maxc(void);
 
 constexpr int kFused = 7;  // profiling slot of the fused kernel
 constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
-constexpr int kProfSlots = 9;
+constexpr int kBounds = 9; // ... of the record-boundary scan (scan.hip)
+constexpr int kProfSlots = 10;
 
 namespace {
 
@@ -191,6 +195,9 @@ struct etlg_ctx {
   // carried transaction state
   bool in_txn = false; uint64_t final_lsn = 0, next_ord = 0;
   // device scratch (grow-only)
+  DevBuf d_scan;       // scratch of the record-boundary scan
+  uint32_t* h_scan = nullptr;  // pinned: its 4-word result
+  unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
   FusedParams fq{};
   uint32_t n_dev_slots = 0, n_dev_cols = 0;
@@ -769,7 +776,8 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc}) b->release();
+  if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
+  for (DevBuf* b : {&c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (c->h_init) (void)hipHostFree(c->h_init);
@@ -872,8 +880,85 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : i == kCells ? "k_cells" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
+  return ETLG_OK;
+}
+
+// Record boundaries on the device (scan.hip): fills c->d_offs with nframes + 1 offsets of the frames
+// of `d_in[0, len)` and returns nframes. Optimistic kernel + hint reruns + one-lane fallback.
+hipError_t device_scan(etlg_ctx* c, const uint8_t* d_in, size_t len, size_t* nframes_out) {
+  hipStream_t s = c->stream;
+  *nframes_out = 0;
+  if (len == 0) {
+    hipError_t e = c->d_offs.ensure(64); if (e != hipSuccess) return e;
+    return hipMemsetAsync(c->d_offs.p, 0, 4, s);
+  }
+  const size_t tb = etlg_k_bounds_tile_bytes();
+  const size_t ntiles = (len + tb - 1) / tb, ngroups = (ntiles + 63) / 64;
+  const size_t zero_bytes = (ntiles + ntiles + ngroups) * 8;          // vdesc | ndesc
+  const size_t hints_off = (zero_bytes + 63) & ~(size_t)63, res_off = hints_off + ((ntiles * 4 + 63) & ~(size_t)63);
+  hipError_t e = c->d_scan.ensure(res_off + 64); if (e != hipSuccess) return e;
+  if (!c->h_scan) { e = hipHostMalloc((void**)&c->h_scan, 64); if (e != hipSuccess) return e; }
+  uint8_t* base = (uint8_t*)c->d_scan.p;
+  size_t cap = len / 24 + 1024;  // frames the offsets buffer can take; grown to the worst case (5-byte frames) on demand
+  e = hipMemsetAsync(base + hints_off, 0xFF, ntiles * 4, s); if (e != hipSuccess) return e;
+  bool used_hints = false;
+  for (int run = 0;; run++) {
+    const bool sequential = run >= 4;
+    e = c->d_offs.ensure((cap + 2) * 4); if (e != hipSuccess) return e;
+    e = hipMemsetAsync(base, 0, zero_bytes, s); if (e != hipSuccess) return e;
+    e = hipMemsetAsync(base + res_off, 0, 16, s); if (e != hipSuccess) return e;
+    ProfRec r; r.which = kBounds;
+    if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
+    etlg_k_launch_bounds(d_in, len, (uint32_t*)c->d_offs.p, (uint32_t)std::min<size_t>(cap + 2, 0xFFFFFFFFu), base, base + ntiles * 8,
+                         (uint32_t*)(base + hints_off), (uint32_t*)(base + res_off), sequential ? 1 : 0, s);
+    if (c->prof) { (void)hipEventRecord(r.b, s); c->prof_recs.push_back(r); }
+    e = hipMemcpyAsync(c->h_scan, base + res_off, 16, hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
+    const uint32_t nf = c->h_scan[0], flags = c->h_scan[1], nbad = c->h_scan[2];
+    if (flags & 2u) {  // offsets buffer too small
+      if (cap >= len / 5 + 2) return hipErrorOutOfMemory;
+      cap = len / 5 + 2;
+      run--;
+      continue;
+    }
+    if (sequential || (!(flags & 1u) && nbad == 0)) {
+      if (used_hints) c->scan_reruns++;
+      if (sequential) c->scan_seq++;
+      *nframes_out = nf;
+      return hipSuccess;
+    }
+    used_hints = true;  // some tiles guessed wrong (their hints are set now), or a spin gave up: run again
+  }
+}
+
+int32_t etlg_scan_boundaries(etlg_ctx* c, const uint8_t* buf, size_t len, uint32_t flags, uint32_t* offsets_out, size_t cap,
+                             size_t* nframes_out) {
+  if (!c || !nframes_out || (!offsets_out && cap)) return ETLG_InvalidArgument;
+  clear_error(c);
+  if (len > 0xFFFFFFFFull - 16) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE, out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
+  const uint8_t* d_in_ptr = buf;
+  if (!in_dev) {
+    HIPCHK(c, c->d_in.ensure(len + 64));
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, c->stream));
+    d_in_ptr = (const uint8_t*)c->d_in.p;
+  }
+  size_t nf = 0;
+  HIPCHK(c, device_scan(c, d_in_ptr, len, &nf));
+  *nframes_out = nf;
+  if (nf + 1 > cap) return lib_error(c, ETLG_InvalidArgument, "offsets_out too small for nframes + 1 entries");
+  HIPCHK(c, hipMemcpyAsync(offsets_out, c->d_offs.p, (nf + 1) * 4, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ETLG_OK;
+}
+
+// debugging aid (not part of etlg.h): [0] scans that needed a rerun with hints, [1] scans that fell back to the one-lane walk
+int32_t etlg_ctx_debug_scan(etlg_ctx* c, unsigned long long* out2) {
+  if (!c || !out2) return ETLG_InvalidArgument;
+  out2[0] = c->scan_reruns; out2[1] = c->scan_seq;
   return ETLG_OK;
 }
 
@@ -887,25 +972,18 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   const bool no_ctrl = flags & ETLG_F_NO_CONTROL, async = (flags & ETLG_F_ASYNC) && out_dev && no_ctrl;
   hipStream_t s = c->stream;
 
-  // ---- record boundaries: the sidecar, or a host scan of the length fields
-  std::vector<uint32_t> scanned;
+  // ---- record boundaries: the caller's sidecar, or the device scan (scan.hip)
+  const bool scan = frame_offsets == nullptr;
   const uint32_t* h_offs = frame_offsets;
-  if (!frame_offsets) {
-    if (in_dev) return lib_error(c, ETLG_Unsupported, "device-resident input needs the frame_offsets sidecar");
-    // 'd' | Int32-BE length chain (a malformed tail becomes one bad frame and fails on the device)
-    size_t pos = 0;
-    scanned.push_back(0);
-    while (pos < len) {
-      size_t next = len;
-      if (len - pos >= 5) {
-        uint64_t l = (uint64_t)buf[pos + 1] << 24 | (uint64_t)buf[pos + 2] << 16 | (uint64_t)buf[pos + 3] << 8 | buf[pos + 4];
-        if (buf[pos] == 'd' && l >= 4 && pos + 1 + l <= len) next = pos + 1 + (size_t)l;
-      }
-      scanned.push_back((uint32_t)next);
-      pos = next;
-    }
-    h_offs = scanned.data();
-    nframes = scanned.size() - 1;
+  const uint8_t* d_in_ptr = buf;  // device address of the input
+  if (!in_dev) {
+    HIPCHK(c, c->d_in.ensure(len + 64));
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, s));
+    d_in_ptr = (const uint8_t*)c->d_in.p;
+  }
+  if (scan) {
+    HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes));
+    if (nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   }
 
   auto* b = new etlg_batch();
@@ -915,14 +993,15 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   const uint32_t nf = (uint32_t)nframes;
   const uint32_t nblocks = (nf + kBlock - 1) / kBlock;
   DecParams p{};
-  if (in_dev) { p.in = buf; p.offs = frame_offsets; }
+  p.in = d_in_ptr;
+  if (scan) p.offs = (const uint32_t*)c->d_offs.p;
+  else if (in_dev) p.offs = frame_offsets;
   else {
-    HIPCHK(c, c->d_in.ensure(len + 64));
     HIPCHK(c, c->d_offs.ensure((nframes + 1) * 4));
-    if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_offs.p, h_offs, (nframes + 1) * 4, hipMemcpyHostToDevice, s));
-    p.in = (const uint8_t*)c->d_in.p; p.offs = (const uint32_t*)c->d_offs.p;
+    p.offs = (const uint32_t*)c->d_offs.p;
   }
+  const bool offs_dev_only = in_dev || scan;  // no host copy of the offsets exists
   p.nframes = nf; p.nblocks = nblocks; p.in_len = len;
   p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
   p.worker_kind = (uint32_t)c->worker; p.sync_table = c->sync_table;
@@ -966,12 +1045,14 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
       std::vector<uint8_t> tmp;
       for (const CtrlFrame& cf : ctrl) {
         uint32_t o0, o1;
-        if (in_dev) {
+        if (offs_dev_only) {
           uint32_t oo[2];
-          HIPCHK(c, hipMemcpy(oo, frame_offsets + cf.frame, 8, hipMemcpyDeviceToHost));
+          HIPCHK(c, hipMemcpy(oo, p.offs + cf.frame, 8, hipMemcpyDeviceToHost));
           o0 = oo[0]; o1 = oo[1];
-          tmp.resize(o1 - o0);
-          HIPCHK(c, hipMemcpy(tmp.data(), buf + o0, o1 - o0, hipMemcpyDeviceToHost));
+          if (in_dev) {
+            tmp.resize(o1 - o0);
+            HIPCHK(c, hipMemcpy(tmp.data(), buf + o0, o1 - o0, hipMemcpyDeviceToHost));
+          }
         } else { o0 = h_offs[cf.frame]; o1 = h_offs[cf.frame + 1]; }
         const uint8_t* fr = in_dev ? tmp.data() : buf + o0;
         const size_t flen = o1 - o0;

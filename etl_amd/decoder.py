@@ -158,3 +158,21 @@ class Decoder:
         out = (C.c_ulonglong * 4)()
         self.L.etlg_ctx_debug_paths(self.h, out)
         return dict(zip(("fused", "cells", "multipass", "redone"), [int(x) for x in out]))
+
+    def scan_boundaries(self, buf, max_frames=None):
+        """Record-boundary scan of a host buffer on the device: np.uint32 offsets (nframes + 1)."""
+        import numpy as np
+        a = np.ascontiguousarray(buf, dtype=np.uint8)
+        cap = (len(a) // 5 + 3) if max_frames is None else max_frames + 1
+        out = np.empty(cap, dtype=np.uint32)
+        n = C.c_size_t()
+        rc = self.L.etlg_scan_boundaries(self.h, a.ctypes.data, len(a), 0, out.ctypes.data, cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"etlg_scan_boundaries failed: {rc}")
+        return out[:n.value + 1].copy()
+
+    def debug_scan(self):
+        """(scans that needed a hinted rerun, scans that fell back to the one-lane walk)."""
+        out = (C.c_ulonglong * 2)()
+        self.L.etlg_ctx_debug_scan(self.h, out)
+        return int(out[0]), int(out[1])

@@ -267,6 +267,18 @@ int32_t etlg_decode(etlg_ctx* ctx, const uint8_t* buf, size_t len,
 
 const etlg_error* etlg_last_error(const etlg_ctx* ctx);
 
+/* Record-boundary scan on its own: the frame_offsets sidecar of `buf` (the same scan
+ * etlg_decode runs when it is given none), e.g. to cut a staged stream into shards.
+ * Follows 'd' | Int32-BE length from offset 0; a malformed header turns the rest of
+ * the buffer into one last frame (which then fails in etlg_decode as a wire error).
+ * Replaces the per-message framing the reference gets from its socket codec
+ * (postgres/stream/replication_message.rs:89-230: one CopyData payload per stream item).
+ * flags: ETLG_F_INPUT_ON_DEVICE (buf is a device pointer), ETLG_F_OUTPUT_ON_DEVICE
+ * (offsets_out is a device pointer). offsets_out receives *nframes_out + 1 entries;
+ * cap = entries available. */
+int32_t etlg_scan_boundaries(etlg_ctx* ctx, const uint8_t* buf, size_t len, uint32_t flags,
+                             uint32_t* offsets_out, size_t cap, size_t* nframes_out);
+
 /* ------------------------------------------------------------ batch (arena) */
 
 /* Event kinds: the pgoutput tag of the message that produced the event. */

@@ -1,0 +1,118 @@
+"""Record-boundary scan on the device (etl_amd/csrc/scan.hip) against the sequential rule the
+oracle and the reference's socket framing follow: 'd' | Int32-BE length chains from offset 0, a
+malformed header turns the rest of the buffer into one last frame."""
+import struct
+
+import numpy as np
+import pytest
+
+from etl_amd import abi, synth
+from tests import pgwire as W
+from tests import scenarios as SC
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_scan(buf):
+    b = bytes(buf)
+    n = len(b)
+    offs = [0]
+    p = 0
+    while p < n:
+        nxt = n
+        if n - p >= 5:
+            (L,) = struct.unpack(">I", b[p + 1:p + 5])
+            if b[p] == 0x64 and L >= 4 and p + 1 + L <= n:
+                nxt = p + 1 + L
+        offs.append(nxt)
+        p = nxt
+    return np.array(offs, dtype=np.uint32)
+
+
+def _check(dec, buf):
+    got = dec.scan_boundaries(buf)
+    want = ref_scan(buf)
+    assert len(got) == len(want), (len(got), len(want))
+    assert np.array_equal(got, want)
+
+
+@pytest.fixture()
+def dec():
+    from etl_amd.decoder import Decoder
+    d = Decoder(0)
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 16 << 20), (synth.cfg3, 16 << 20), (synth.cfg5, 4 << 20), (synth.cfg1, 1 << 20)])
+def test_scan_matches_sidecar(dec, mk, nbytes):
+    w = mk()
+    buf, offs = w.fill(nbytes)
+    got = dec.scan_boundaries(buf)
+    assert np.array_equal(got, offs)
+    assert dec.debug_scan() == (0, 0)   # well-formed streams never need a rerun
+
+
+def test_scan_small_and_empty(dec):
+    _check(dec, np.zeros(0, dtype=np.uint8))
+    s = SC.txn([W.insert(42, ["1", "x"])])
+    _check(dec, np.frombuffer(s.bytes(), dtype=np.uint8))
+    _check(dec, np.frombuffer(s.bytes()[:7], dtype=np.uint8))      # cut inside the first header
+    _check(dec, np.frombuffer(b"zzz", dtype=np.uint8))              # no frame at all
+
+
+def test_scan_malformed_tail_and_middle(dec):
+    w = synth.cfg2()
+    buf, offs = w.fill(1 << 20)
+    _check(dec, buf[:len(buf) - 17])                                 # last frame cut short
+    bad = buf.copy()
+    bad[int(offs[len(offs) // 2])] = ord("x")                        # a header in the middle is not 'd'
+    _check(dec, bad)
+    bad = buf.copy()
+    o = int(offs[1000])
+    bad[o + 1:o + 5] = np.frombuffer(struct.pack(">I", 3), dtype=np.uint8)   # length below the minimum
+    _check(dec, bad)
+
+
+def test_scan_frames_longer_than_many_tiles(dec):
+    big = "x" * 300_000
+    rows = [W.insert(42, [str(i), big if i % 3 == 0 else "small"]) for i in range(12)]
+    s = SC.txn(rows)
+    _check(dec, np.frombuffer(s.bytes(), dtype=np.uint8))
+    assert dec.debug_scan() == (0, 0)
+
+
+def test_scan_payload_that_mimics_frames(dec):
+    """Values made of byte-exact fake keepalive frames: tiles that start inside such a value guess a
+    fake entry, fail their check against the real chain, and the hinted rerun repairs them."""
+    fake = b"d" + struct.pack(">I", 22) + b"k" + bytes(17)          # a perfectly plausible 23-byte frame
+    val = fake * 3000                                               # 69 000 bytes: covers several 8 KiB tiles
+    rows = [W.insert(42, ["1", val]), W.insert(42, ["2", "plain"]), W.insert(42, ["3", val]), W.insert(42, ["4", "tail"])]
+    s = SC.txn(rows)
+    buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+    _check(dec, buf)
+    reruns, seq = dec.debug_scan()
+    assert reruns >= 1 and seq == 0
+
+
+def test_decode_without_sidecar_device_input(dec):
+    """etlg_decode(frame_offsets = NULL) on HBM-resident input: boundaries come from the device scan."""
+    import torch
+    from oracle import oracle
+    w = synth.cfg3()
+    o = oracle.Oracle()
+    w.register(o)
+    w.register(dec)
+    buf, offs = w.fill(8 << 20)
+    tb = torch.from_numpy(buf.copy()).cuda()
+    torch.cuda.synchronize()
+    b = dec.decode_device(tb.data_ptr(), tb.numel(), None, 0, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
+    assert b.rc == 0
+    diff = o.decode(buf, offs).host_batch().diff(b.host())
+    assert not diff, diff[:6]
+    # host input, no sidecar
+    o.reset_stream_state(); dec.reset_stream_state()
+    buf2, offs2 = w.fill(4 << 20)
+    g = dec.decode(buf2, None)
+    assert g.rc == 0
+    assert not o.decode(buf2, offs2).host_batch().diff(g.host())

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_scan.py -m gpu -x -q > gpurun_out/scan.log 2>&1; echo "scan rc=$?"; tail -15 gpurun_out/scan.log
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/parity_all.log 2>&1; echo "parity rc=$?" 
 tail -3 gpurun_out/parity_all.log
-for nb in 0 1; do ETLG_NO_ROW_BUFFER_X=$nb; if [ $nb = 1 ]; then export ETLG_NO_ROW_BUFFER=1; fi; timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('nobuf=$nb', d['value'], d['roofline']['kernel_avg_us'], d['roofline']['frac'], d['roofline']['alg_bytes_per_launch'])"; done
