@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true", help="profiling ablations only")
+    ap.add_argument("--no-scan-leg", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -181,6 +182,34 @@ def main():
                 "pipeline_sum_us": round(pipe_us, 2),
                 "pipeline_frac": round(alg_bytes / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
 
+    # ---- no-sidecar leg (rank 0): the same batches with frame_offsets = NULL, i.e. the record-boundary
+    #      scan runs on the device first (scan.hip). Reported beside `value`, never as `value`: the
+    #      reference's host learns every frame length from its socket codec, so a sidecar costs it nothing.
+    scan = None
+    if rank == 0 and not args.no_scan_leg:
+        fl = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL
+        for k in range(2):
+            tb, to, nbytes, nfr = d_in[k % len(d_in)]
+            dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl).close()
+        dec.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = 0
+        for k in range(args.steps):
+            tb, to, nbytes, nfr = d_in[k % len(d_in)]
+            b = dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl)
+            assert args.no_check or (b.rc == 0 and b.view().n_frames == nfr)
+            nb += nbytes
+            b.close()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        prof = dec.profile_read()
+        dec.profile(False)
+        kb = prof.get("k_bounds", (0, 0.0))
+        scan = {"value": round(nb / (t1 - t0) / 1e9, 3), "unit": "GB/s", "k_bounds_avg_us": round(1000.0 * kb[1] / max(kb[0], 1), 2),
+                "k_bounds_launches_per_batch": round(kb[0] / args.steps, 2),
+                "note": "frame_offsets = NULL: device record-boundary scan + decode, synchronous (the host reads the frame count back)"}
+
     # ---- CPU baseline leg (rank 0, N == 1 only): the oracle on the same host cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -218,7 +247,7 @@ def main():
                                    "device-resident in / device-resident out, offsets sidecar, NO_CONTROL",
                        "batch_bytes": int(my_bytes / args.steps), "frames_per_batch": int(my_frames / args.steps),
                        "pool_batches": len(pool), "parallelism": f"shard{world}"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "no_sidecar": scan,
         }
         print(json.dumps(out))
     dec.close()

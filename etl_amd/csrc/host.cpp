@@ -908,15 +908,16 @@ hipError_t device_scan(etlg_ctx* c, const uint8_t* d_in, size_t len, size_t* nfr
     const bool sequential = run >= 4;
     e = c->d_offs.ensure((cap + 2) * 4); if (e != hipSuccess) return e;
     e = hipMemsetAsync(base, 0, zero_bytes, s); if (e != hipSuccess) return e;
-    e = hipMemsetAsync(base + res_off, 0, 16, s); if (e != hipSuccess) return e;
+    e = hipMemsetAsync(base + res_off, 0, 64, s); if (e != hipSuccess) return e;
     ProfRec r; r.which = kBounds;
     if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
     etlg_k_launch_bounds(d_in, len, (uint32_t*)c->d_offs.p, (uint32_t)std::min<size_t>(cap + 2, 0xFFFFFFFFu), base, base + ntiles * 8,
-                         (uint32_t*)(base + hints_off), (uint32_t*)(base + res_off), sequential ? 1 : 0, s);
+                         (uint32_t*)(base + hints_off), (uint32_t*)(base + res_off), (sequential ? 1 : 0) | (getenv("ETLG_SCAN_DBG") ? 2 : 0), s);
     if (c->prof) { (void)hipEventRecord(r.b, s); c->prof_recs.push_back(r); }
-    e = hipMemcpyAsync(c->h_scan, base + res_off, 16, hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(c->h_scan, base + res_off, 64, hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
     const uint32_t nf = c->h_scan[0], flags = c->h_scan[1], nbad = c->h_scan[2];
+    if (getenv("ETLG_SCAN_DBG")) { fprintf(stderr, "k_bounds tiles %zu phase cycles/tile:", ntiles); for (int k = 4; k < 11; k++) fprintf(stderr, " %u", (unsigned)(c->h_scan[k] / std::max<size_t>(1, ntiles / 64))); fprintf(stderr, "\n"); }
     if (flags & 2u) {  // offsets buffer too small
       if (cap >= len / 5 + 2) return hipErrorOutOfMemory;
       cap = len / 5 + 2;

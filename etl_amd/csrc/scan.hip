@@ -7,13 +7,15 @@
 // chain enters it. The kernel is optimistic and verifies itself:
 //
 //   1. one wave stages its tile (TB bytes + a header's worth of halo) into LDS;
-//   2. it GUESSES its entry — the first position of the tile holding a well-formed XLogData /
-//      keepalive frame header whose successor holds one too — and walks the chain from there to
-//      the end of the tile out of LDS, recording the frame starts (tile 0 knows its entry: 0);
-//   3. it publishes (frames, exit offset) and takes part in two look-backs: the usual two-level
-//      decoupled prefix sum of the frame counts (its offsets' base index), and a look at the
-//      nearest older tile that found frames, whose exit must be exactly this tile's guessed
-//      entry (or lie beyond the tile when it found none);
+//   2. every lane GUESSES an entry into its own 128 bytes — the first position holding a
+//      well-formed XLogData / keepalive frame header whose successor holds one too — and walks the
+//      chain to the end of its 128 bytes; the lanes are then stitched (the exit of one must be the
+//      guess of the lane it lands in), which yields the tile's frames and exit offset from the
+//      first guess on (tile 0 knows its entry: offset 0). A tile whose lanes do not stitch walks
+//      the chain with one lane instead;
+//   3. ONE two-level decoupled look-back carries (frames so far: sum, furthest exit so far: max):
+//      the sum is the base index of the tile's offsets, the max must be exactly the tile's
+//      guessed entry (or lie beyond the tile when it found nothing);
 //   4. offsets go straight to their final indexes.
 //
 // If every tile passes its check, the guesses ARE the chain (induction from tile 0). A tile that
@@ -34,7 +36,6 @@ namespace etlg {
 
 constexpr uint32_t TB = 8192;          // bytes per tile
 constexpr uint32_t HALO = 32;          // a header (and the bytes the guess inspects) may straddle the tile end
-constexpr uint32_t MAXN = TB / 5 + 2;  // frames that can start in one tile (a frame is >= 5 bytes)
 constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
 
 struct BoundsParams {
@@ -43,9 +44,10 @@ struct BoundsParams {
   uint32_t* offs;              // out: nframes + 1 offsets
   uint32_t offs_cap;           // entries available in offs
   uint32_t ntiles;
-  unsigned long long* vdesc;   // [ntiles]           st:2 | has:1 | n:15 | exit:32   (zeroed)
-  unsigned long long* ndesc;   // [ntiles + ngroups] frame-count look-back           (zeroed)
+  unsigned long long* vdesc;   // unused
+  unsigned long long* ndesc;   // [ntiles + ngroups] look-back of (frames: sum, exit: max)   (zeroed)
   uint32_t* hints;             // [ntiles] entry to use instead of guessing, NO_ENTRY = guess (kept across reruns)
+  uint32_t dbg;                // 1: per-phase shader-clock sums into result[4..11] (profiling only)
   uint32_t* result;            // [0] nframes  [1] failure flags (1 spin gave up, 2 offs_cap too small)  [2] tiles that failed their check
 };
 
@@ -72,93 +74,168 @@ DEV bool plausible_at(const u8* st, uint32_t lo, uint64_t len, uint32_t p, uint3
   return t == 'B' || t == 'C' || t == 'I' || t == 'U' || t == 'D' || t == 'R' || t == 'T' || t == 'M' || t == 'O' || t == 'Y';
 }
 
-// Walks the chain from `p` to the end of the tile; every lane runs the same walk (uniform control
-// flow, LDS broadcast reads), lane 0 records the frame starts relative to lo.
-DEV void walk(const u8* st, uint16_t* plist, uint32_t lo, uint32_t hi, uint64_t len, uint32_t p, uint32_t& n, uint32_t& exit_off) {
+// Walks the chain from `p` until it reaches `stop` (p < stop on entry): n = frames started, exit_off =
+// where the chain stands then. `out` (optional): the absolute frame starts, written from out[0] on.
+DEV void walk(const u8* st, uint32_t* out, uint32_t lo, uint32_t stop, uint64_t len, uint32_t p, uint32_t& n, uint32_t& exit_off) {
   n = 0;
-  const bool rec = (threadIdx.x & 63) == 0;
-  while (p < hi) {
+  while (p < stop) {
     uint32_t nx;
-    if (rec) plist[n] = (uint16_t)(p - lo);
+    if (out) out[n] = p;
     n++;
     p = header_at(st, lo, len, p, nx) ? nx : (uint32_t)len;  // a malformed header: the rest is one frame
   }
   exit_off = p;
 }
 
+// look-back payload: frames so far (30 bits, summed) | furthest exit so far (32 bits, max)
+struct OpCountExit {
+  DEV static uint64_t id() { return 0; }
+  DEV static uint64_t f(uint64_t a, uint64_t b) {
+    const uint32_t ea = (uint32_t)a, eb = (uint32_t)b;
+    return ((((a >> 32) + (b >> 32)) & 0x3FFFFFFFull) << 32) | (ea > eb ? ea : eb);
+  }
+};
+
+constexpr uint32_t SUB = TB / 64;  // bytes of the tile each lane looks at (128)
+#define STAMP(k) do { if (q.dbg && threadIdx.x == 0 && (blockIdx.x & 63) == 5) { const unsigned long long _t = clock64(); atomicAdd(&q.result[4 + (k)], (uint32_t)(_t - t_prev)); t_prev = _t; } } while (0)
+
 __global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
   __shared__ __attribute__((aligned(16))) u8 st[TB + HALO + 16];
-  __shared__ uint16_t plist[MAXN];
   const uint32_t lane = threadIdx.x;
   const uint32_t tile = blockIdx.x;
   const uint64_t lo64 = (uint64_t)tile * TB;
   const uint32_t lo = (uint32_t)lo64;
   const uint32_t hi = (uint32_t)(lo64 + TB < q.len ? lo64 + TB : q.len);
   uint32_t* fail = &q.result[1];
-  // ---- stage [lo, hi + HALO), zero past the end of the input
+  unsigned long long t_prev = q.dbg ? clock64() : 0;
+  // ---- stage [lo, hi + HALO), zero past the end of the input. A full interior tile takes the fast
+  //      route: all 8 of a lane's 16-byte loads are in flight before the first LDS store.
   {
     const uint32_t want = hi - lo + HALO;
     const bool al = ((uintptr_t)q.in & 15) == 0;  // tile starts are multiples of TB
-    for (uint32_t c = 16 * lane; c < want; c += 16 * 64) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (al && lo64 + c + 16 <= q.len) v = *(const uint4*)(q.in + lo64 + c);
-      else {
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (uint32_t i = 0; i < 16; i++) if (lo64 + c + i < q.len) w[i >> 2] |= (uint32_t)q.in[lo64 + c + i] << (8 * (i & 3));
-        v = make_uint4(w[0], w[1], w[2], w[3]);
+    if (al && lo64 + TB + HALO + 16 <= q.len) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = *(const uint4*)(q.in + lo64 + 16 * lane + 1024 * k);
+      uint4 vh = make_uint4(0, 0, 0, 0);
+      if (lane < (HALO + 15) / 16) vh = *(const uint4*)(q.in + lo64 + TB + 16 * lane);
+#pragma unroll
+      for (int k = 0; k < 8; k++) *(uint4*)(st + 16 * lane + 1024 * k) = v[k];
+      if (lane < (HALO + 15) / 16) *(uint4*)(st + TB + 16 * lane) = vh;
+    } else {
+      for (uint32_t c = 16 * lane; c < want; c += 16 * 64) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (al && lo64 + c + 16 <= q.len) v = *(const uint4*)(q.in + lo64 + c);
+        else {
+          uint32_t w[4] = {0, 0, 0, 0};
+          for (uint32_t i = 0; i < 16; i++) if (lo64 + c + i < q.len) w[i >> 2] |= (uint32_t)q.in[lo64 + c + i] << (8 * (i & 3));
+          v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *(uint4*)(st + c) = v;
       }
-      *(uint4*)(st + c) = v;
     }
   }
   __syncthreads();
-  // ---- entry: known (tile 0), hinted by an earlier run, or guessed
-  uint32_t entry = NO_ENTRY;  // absolute offset
+  STAMP(0);
+  // ---- every lane guesses an entry into ITS 128 bytes: the first position holding a plausible frame
+  //      whose successor is plausible too (or lies outside the tile). 'd' bytes are found 4 at a time.
+  const uint32_t a = lo + lane * SUB, a_end = a + SUB < hi ? a + SUB : hi;
+  uint32_t s_l = NO_ENTRY;
+  if (a < hi) {
+    // all 128 bytes at once (8 independent 16-byte LDS reads): one bit per byte that is 'd', one per
+    // byte that is 0. A guess is only tried where 'd' is followed by a zero byte, i.e. at frames
+    // shorter than 16 MiB (text is full of 'd's; a longer frame is simply never guessed and costs
+    // the tile a hinted rerun).
+    unsigned long long dmask[2] = {0, 0}, zmask[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint4 v = *(const uint4*)(st + (a - lo) + 16 * k);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t x = w[j] ^ 0x64646464u;                                                  // 'd' -> 0
+        const uint32_t zd = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);              // 0x80 where the byte was 'd'
+        const uint32_t y = w[j];
+        const uint32_t zz = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);              // 0x80 where the byte was 0
+        const uint32_t bd = ((zd >> 7) & 1u) | ((zd >> 14) & 2u) | ((zd >> 21) & 4u) | ((zd >> 28) & 8u);
+        const uint32_t bz = ((zz >> 7) & 1u) | ((zz >> 14) & 2u) | ((zz >> 21) & 4u) | ((zz >> 28) & 8u);
+        dmask[k >> 2] |= (unsigned long long)bd << (16 * (k & 3) + 4 * j);
+        zmask[k >> 2] |= (unsigned long long)bz << (16 * (k & 3) + 4 * j);
+      }
+    }
+    const unsigned long long znext = st[(a - lo) + SUB] == 0 ? 1ull : 0ull;  // the byte after this lane's range
+    dmask[0] &= (zmask[0] >> 1) | (zmask[1] << 63);
+    dmask[1] &= (zmask[1] >> 1) | (znext << 63);
+    for (int half = 0; half < 2 && s_l == NO_ENTRY; half++) {
+      unsigned long long m = dmask[half];
+      while (m && s_l == NO_ENTRY) {
+        const uint32_t p = a + 64 * half + (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        uint32_t nx, nx2;
+        if (p < a_end && plausible_at(st, lo, q.len, p, nx) && (nx >= hi || plausible_at(st, lo, q.len, nx, nx2))) s_l = p;
+      }
+    }
+  }
+  STAMP(1);
+  // the tile's own entry: known (tile 0), hinted by an earlier run, or the first lane's guess
   const uint32_t hint = q.hints[tile];
+  uint32_t entry = NO_ENTRY;
   if (tile == 0) entry = 0;
   else if (hint != NO_ENTRY && hint >= lo) entry = hint;  // (a hint below the tile came from a predecessor that was wrong itself)
   else {
-    // first position whose frame looks real and whose successor does too (or cannot be seen from here)
-    for (uint32_t base = lo; base < hi && entry == NO_ENTRY; base += 64) {
-      const uint32_t p = base + lane;
-      bool good = false;
-      uint32_t nx;
-      if (p < hi && plausible_at(st, lo, q.len, p, nx)) {
-        uint32_t nx2;
-        good = nx >= hi || plausible_at(st, lo, q.len, nx, nx2);  // nx < hi: its header is inside the staged window
-      }
-      const unsigned long long m = __ballot(good);
-      if (m) entry = base + (uint32_t)__builtin_ctzll(m);
-    }
+    const unsigned long long m = __ballot(s_l != NO_ENTRY);
+    if (m) entry = (uint32_t)__shfl(s_l, __builtin_ctzll(m), 64);
   }
-  uint32_t n = 0, e = 0;
   const bool has = entry != NO_ENTRY && entry < hi;
-  if (has) walk(st, plist, lo, hi, q.len, entry, n, e);
-  __syncthreads();  // plist (written by lane 0) -> all lanes
-  // ---- publish, prefix-sum the frame counts
-  if (lane == 0) {
-    const unsigned long long w = ST_AGG | ((unsigned long long)(has ? 1u : 0u) << 47) | ((unsigned long long)n << 32) | e;
-    __hip_atomic_store(&q.vdesc[tile], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (has && (entry - lo) / SUB == lane) s_l = entry;  // the lane the chain enters through starts exactly there
+  // local walks: from the lane's guess to the end of its 128 bytes
+  uint32_t n_l = 0, e_l = 0;
+  if (s_l != NO_ENTRY) walk(st, nullptr, lo, a_end, q.len, s_l, n_l, e_l);
+  STAMP(2);
+  // ---- stitch the lanes. The chain passes through every guessing lane from the entry lane on iff each
+  //      of them starts exactly where the furthest walk before it ended (walks of on-chain lanes end
+  //      further and further), and every lane without a guess lies under a frame. One prefix-max scan.
+  uint32_t n = 0, e = 0;
+  bool stitched = has;
+  bool mine = false;  // this lane's walk is part of the tile's chain
+  if (has) {
+    const uint32_t c0 = (entry - lo) / SUB;
+    mine = lane >= c0 && s_l != NO_ENTRY;
+    uint32_t mx = mine ? e_l : 0u;  // inclusive prefix max of the exits
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(mx, d, 64); if ((int)lane >= d && t > mx) mx = t; }
+    uint32_t before = __shfl_up(mx, 1, 64);  // furthest exit of the lanes before this one
+    if (lane == 0) before = 0;
+    bool good = true;
+    if (lane > c0 && a < hi) good = mine ? before == s_l : before >= a_end;
+    stitched = __ballot(!good) == 0;
+    e = (uint32_t)__shfl(mx, 63, 64);
+    uint32_t tot = mine ? n_l : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+    n = tot;
   }
-  const uint64_t N = lookback<OpAdd>(q.ndesc, q.ndesc + q.ntiles, tile, n, 0, fail);
-  // ---- check the guess against the nearest older tile that found frames
+  STAMP(3);
+  uint32_t inc = 0;  // inclusive prefix of the on-chain lanes' frame counts
+  if (has && stitched) {
+    inc = mine ? n_l : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += t; }
+  } else if (has) {
+    // the lanes do not agree (bytes that mimic a frame inside a value, a malformed header ...): one lane
+    // walks the tile; it walks again below to write the offsets once their base index is known
+    if (lane == 0) walk(st, nullptr, lo, hi, q.len, entry, n, e);
+    n = (uint32_t)__shfl(n, 0, 64); e = (uint32_t)__shfl(e, 0, 64);
+  }
+  STAMP(4);
+  // ---- one look-back gives the frames before this tile and how far the chain has come
+  const uint64_t pre = lookback<OpCountExit>(q.ndesc, q.ndesc + q.ntiles, tile, ((uint64_t)n << 32) | e, 0, fail);
+  const uint64_t N = pre >> 32;
+  STAMP(5);
   if (tile > 0) {
-    uint32_t polls = 0, e_prev = 0;
-    int64_t top = (int64_t)tile - 1;
-    for (;;) {
-      const int64_t idx = top - lane;
-      unsigned long long w = ST_AGG | (1ull << 47);  // below tile 0: a virtual tile with frames and exit 0 (never reached: tile 0 has frames)
-      if (idx >= 0) w = __hip_atomic_load(&q.vdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long m_has = __ballot((w & ST_MASK) != 0 && ((w >> 47) & 1)), m_empty = __ballot((w & ST_MASK) == 0);
-      const int first = m_has ? __builtin_ctzll(m_has) : 64;
-      const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1);
-      if (m_empty & need) {
-        if (++polls > kMaxPolls) { if (lane == 0) atomicOr(fail, 1u); return; }
-        __builtin_amdgcn_s_sleep(2);
-        continue;
-      }
-      if (first < 64) { e_prev = (uint32_t)__shfl(w, first, 64); break; }
-      top -= 64;  // 64 tiles inside one frame: keep looking
-    }
+    // If every tile passes this check the guesses are the chain: by induction the exits of the older
+    // tiles are the true ones and grow with the tile index, so their maximum is where the chain enters.
+    const uint32_t e_prev = (uint32_t)pre;
     const bool ok = has ? e_prev == entry : e_prev >= hi;
     if (!ok) {
       if (lane == 0) {
@@ -174,13 +251,20 @@ __global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
       }
     }
   }
-  // ---- offsets at their final indexes
+  // ---- offsets at their final indexes: every on-chain lane repeats its short walk (consecutive lanes
+  //      write consecutive entries)
   if (N + n + 1 > q.offs_cap) { if (lane == 0) atomicOr(fail, 2u); return; }
-  for (uint32_t i = lane; i < n; i += 64) q.offs[N + i] = lo + plist[i];
+  if (has && stitched) {
+    if (mine) { uint32_t n2, e2; walk(st, q.offs + N + (inc - n_l), lo, a_end, q.len, s_l, n2, e2); }
+  } else if (has && lane == 0) {
+    uint32_t n2, e2;
+    walk(st, q.offs + N, lo, hi, q.len, entry, n2, e2);
+  }
   if (tile == q.ntiles - 1 && lane == 0) {
     q.offs[N + n] = (uint32_t)q.len;
     q.result[0] = (uint32_t)(N + n);
   }
+  STAMP(6);
 }
 
 // Cold fallback: one lane follows the whole chain out of global memory.
@@ -217,6 +301,7 @@ uint32_t etlg_k_bounds_tile_bytes(void) { return TB; }
 void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* vdesc, void* ndesc,
                           uint32_t* hints, uint32_t* result, int sequential, hipStream_t s) {
   BoundsParams q;
+  q.dbg = (sequential & 2) ? 1u : 0u; sequential &= 1;
   q.in = in; q.len = len; q.offs = offs; q.offs_cap = offs_cap;
   q.ntiles = (uint32_t)((len + TB - 1) / TB);
   q.vdesc = (unsigned long long*)vdesc; q.ndesc = (unsigned long long*)ndesc; q.hints = hints; q.result = result;
