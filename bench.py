@@ -252,6 +252,7 @@ def main():
         print(json.dumps(out))
     dec.close()
     if world > 1:
+        dist.barrier()   # rank 0 runs the extra legs; everybody leaves together
         dist.destroy_process_group()
 
 

@@ -309,6 +309,17 @@ enum {
                             it with the reference's own parse_cell_from_postgres_text */
 };
 
+/* Which cells come back DEFERRED (the same rule is implemented by the oracle's CONTRACT mode):
+ *  - json / jsonb and every array type: always;
+ *  - date / time / timetz / timestamp / timestamptz: when the text is not in the fixed layout of
+ *    the reference's own fast paths (codec/time.rs:89-154), i.e. what the reference hands to chrono;
+ *  - float4 / float8: the value of "[+-]digits[.digits][e[+-]digits]" is w * 10^q, w = the mantissa
+ *    digits read as an integer with leading and trailing zeros dropped. Decoded on the device when
+ *    w has at most 19 digits, w <= 2^53 and |q| <= 22 (one exact IEEE multiply or divide gives the
+ *    correctly rounded double, as Rust's dec2flt fast path does) — for float4 unless that double
+ *    lies exactly half way between two floats — and for zero, inf / infinity / nan. Every other
+ *    well-formed float text is DEFERRED; malformed text is the reference's "Float parsing failed". */
+
 /* Numeric heap entry header (followed by ndigits little-endian i16 base-10000
  * digits): mirrors PgNumeric (crates/etl-postgres/src/numeric.rs:75-96). */
 enum { ETLG_NUM_VALUE = 0, ETLG_NUM_NAN = 1, ETLG_NUM_PINF = 2, ETLG_NUM_NINF = 3 };

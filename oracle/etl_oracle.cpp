@@ -311,7 +311,7 @@ struct Failure { int32_t code = ETLG_E_NONE; std::string detail; int64_t frame =
 
 struct Ctx {
   int32_t worker = ETLG_WORKER_APPLY; uint32_t sync_table = 0; uint64_t bootstrap = 0;
-  int mode = MODE_CONTRACT; uint32_t defer_mask = (1u << ETLG_TC_F32) | (1u << ETLG_TC_F64);
+  int mode = MODE_CONTRACT; uint32_t defer_mask = 0;  // classes handed back DEFERRED wholesale on top of json / arrays
   std::map<uint32_t, std::map<uint64_t, std::shared_ptr<StoredSchema>>> store;
   std::unordered_map<uint32_t, TState> states;
   std::unordered_map<uint32_t, CacheEntry> cache;
@@ -379,6 +379,14 @@ static bool decode_text(const Ctx& c, const RCol& col, sv text, Cell& out, int32
   if (cls == ETLG_TC_JSON || cls == ETLG_TC_ARRAY) return defer();
   if (c.defer_mask & (1u << cls)) return defer();
   switch (cls) {
+    case ETLG_TC_F32: case ETLG_TC_F64: {
+      const int r = float_device_rule(text, cls == ETLG_TC_F32);
+      if (r == 2) { err = ETLG_E_FLOAT; return false; }
+      if (r == 1) return defer();
+      auto v = cls == ETLG_TC_F32 ? parse_f32_bits(text) : parse_f64_bits(text);
+      out.tag = cls == ETLG_TC_F32 ? Tag::F32 : Tag::F64; out.u.fbits = v.v;
+      return true;
+    }
     case ETLG_TC_DATE: {
       auto d = iso_date_fast(text);
       if (!d) return defer();

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MODE_FULL, MODE_CONTRACT = 0, 1
-DEFAULT_DEFER_MASK = (1 << abi.TC_F32) | (1 << abi.TC_F64)
+DEFAULT_DEFER_MASK = 0   # classes deferred wholesale on top of json / arrays (floats follow the rule in include/etlg.h)
 
 
 def build(force=False):

@@ -440,6 +440,53 @@ inline Res<uint64_t> parse_f32_bits(sv s) {
   return R::Ok((uint64_t)bits);
 }
 
+// Which float texts the DEVICE decodes itself (include/etlg.h, "float cells"): the value is
+// w * 10^q with w the mantissa digits as an integer (leading / trailing zeros dropped) and the
+// rule is  digits(w) <= 19, w <= 2^53, |q| <= 22  (one exact IEEE operation gives the correctly
+// rounded double); f32 additionally not when that double lies exactly on the midpoint of two
+// floats. Specials and zeros always. Everything else is handed back DEFERRED.
+// Returns 0 decode on device, 1 deferred, 2 malformed. Only used in CONTRACT mode; the VALUE
+// itself still comes from strtod / strtof above (an independent computation).
+inline int float_device_rule(sv s, bool is32) {
+  bool special, neg; int k = 0;
+  if (!float_grammar(s, special, k, neg)) return 2;
+  if (special) return 0;
+  size_t i = 0;
+  if (s[0] == '+' || s[0] == '-') i = 1;
+  unsigned __int128 w = 0;
+  long nsig = 0, pending0 = 0, q = 0;
+  bool frac = false, too_long = false;
+  for (; i < s.size(); i++) {
+    char c = s[i];
+    if (c == '.') { frac = true; continue; }
+    if (c < '0' || c > '9') break;
+    if (frac) q--;
+    if (c == '0') { if (nsig) pending0++; continue; }
+    long add = pending0 + 1;
+    if (nsig + add > 19) too_long = true;
+    else { for (long z = 0; z < pending0; z++) w *= 10; w = w * 10 + (unsigned)(c - '0'); }
+    nsig += add; pending0 = 0;
+  }
+  q += pending0;
+  if (i < s.size()) {  // exponent (grammar already checked)
+    i++;
+    bool eneg = false;
+    if (s[i] == '+' || s[i] == '-') { eneg = s[i] == '-'; i++; }
+    long ex = 0;
+    for (; i < s.size(); i++) if (ex < 100000) ex = ex * 10 + (s[i] - '0');
+    q += eneg ? -ex : ex;
+  }
+  if (nsig == 0) return 0;
+  if (too_long || w > ((unsigned __int128)1 << 53) || q < -22 || q > 22) return 1;
+  if (is32) {
+    std::string z(s);
+    double d = strtod(z.c_str(), nullptr);
+    uint64_t bits; memcpy(&bits, &d, 8);
+    if ((bits & 0x1FFFFFFFull) == 0x10000000ull) return 1;
+  }
+  return 0;
+}
+
 // -------------------------------------------------------------------- numeric
 // PgNumeric::from_str            crates/etl-postgres/src/numeric.rs:108-135
 // parse_special_value            :246-267

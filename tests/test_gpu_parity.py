@@ -227,3 +227,71 @@ def test_utf8_matrix(path, wide):
         assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), texts[i]
         o.reset_stream_state(); d.reset_stream_state()
     d.close()
+
+
+# ---- float4 / float8 (Rust dec2flt, codec/text.rs:52-59; KATs :510-578): the device decodes the
+# exactly-representable fast path and defers the rest (include/etlg.h). Bits and the value/deferred
+# decision must match the oracle, whose values come from glibc strtod / strtof.
+def _float_texts():
+    import random
+    rng = random.Random(20260921)
+    t = ["0", "-0", "0.0", "-0.0", "+0", "0e0", "0e999999999", "-0.000e-5", "1", "-1", "1.5", "-7.25", "3.5", "0.1", "0.2", "0.3",
+         "1e22", "1e23", "1e-22", "1e-23", "123456789012345678", "9007199254740992", "9007199254740993", "9007199254740991",
+         "12345678901234567890", "0.000001", "1.7976931348623157e308", "2.2250738585072014e-308", "5e-324", "4.9e-324",
+         "3.4028235e38", "3.4028236e38", "1.17549435e-38", "1e-45", "1.401298464324817e-45", "16777216", "16777217", "16777218",
+         "33554434", "8388608.5", "8388609.5", "0.5", "1.0000000596046448", "1.00000005960464477539", "1.00000011920928955",
+         "inf", "-inf", "Infinity", "-INFINITY", "+inf", "nan", "NaN", "-nan", "1.", ".5", "-.5e1", "+1.25E+2", "1E5", "1e+05",
+         "100000000000000000000000", "1000000000000000000000", "0.00000000000000000000001", "123.456e-2", "00012.500"]
+    for _ in range(3000):
+        nd = rng.randint(1, 21)
+        digs = "".join(rng.choice("0123456789") for _ in range(nd))
+        if rng.random() < 0.6:
+            k = rng.randint(0, nd)
+            digs = digs[:k] + "." + digs[k:]
+            if digs == ".":
+                digs = "0."
+        s = rng.choice(["", "", "-", "+"]) + digs
+        if rng.random() < 0.5:
+            s += rng.choice("eE") + rng.choice(["", "+", "-"]) + str(rng.randint(0, 40))
+        t.append(s)
+    return t
+
+
+def test_float_matrix(path):
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    from tests import pgwire as W
+    cols = [("id", SC.INT8, False, 1), ("f8", SC.FLOAT8, False, 0), ("f4", SC.FLOAT4, False, 0)]
+    texts = _float_texts()
+    s = SC.txn([W.insert(42, [str(i), t, t]) for i, t in enumerate(texts)])
+    prime = SC.simple_table(cols)
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+    rb, gb = o.decode(buf, s.offsets), d.decode(buf, s.offsets)
+    assert rb.err_code == 0 and gb.rc == 0
+    hb = rb.host_batch()
+    diff = hb.diff(gb.host())
+    assert not diff, diff[:6]
+    assert d.debug_paths()["redone"] == 0
+    # the matrix exercises both outcomes for both widths
+    st = [hb.fixed[int(hb.body_off[i + 1])] & 0x3F for i in range(len(texts))]   # state bits of (id, f8, f4)
+    f8 = [(x >> 2) & 3 for x in st]
+    f4 = [(x >> 4) & 3 for x in st]
+    assert abi.CELL_VALUE in f8 and abi.CELL_DEFERRED in f8 and abi.CELL_VALUE in f4 and abi.CELL_DEFERRED in f4
+    assert sum(1 for x in f8 if x == abi.CELL_VALUE) > len(texts) // 3
+    d.close()
+    # malformed texts: the reference's "Float parsing failed" at the right frame
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    for bad in ["", "+", "-", ".", "e5", "1e", "1e+", "1.2.3", "1 ", " 1", "0x10", "1_0", "infinit", "nane", "--1", "1e5.0", "1f", "١"]:
+        for col in (1, 2):
+            row = ["7", "1.0", "1.0"]
+            row[col] = bad
+            s = SC.txn([W.insert(42, ["1", "2.5", "2.5"]), W.insert(42, row)])
+            buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+            rb, gb = o.decode(buf, s.offsets), d.decode(buf, s.offsets)
+            assert rb.err_code == abi.E_FLOAT and rb.err_frame == 2, bad
+            assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), bad
+            o.reset_stream_state(); d.reset_stream_state()
+    d.close()
