@@ -38,7 +38,8 @@ KIND_NAMES = {
  E_KEY_SHAPE, E_KEY_MISSING_COLS, E_KEY_MISSING_VALUE, E_BOOL, E_INT, E_FLOAT, E_NUMERIC,
  E_BYTEA, E_DATETIME, E_UUID, E_JSON, E_ARRAY_SHORT, E_ARRAY_BRACES, E_ARRAY_DIMS,
  E_ARRAY_MULTIDIM, E_ARRAY_QUOTE, E_ARRAY_ESCAPE, E_SCHEMA_NOT_FOUND, E_UNKNOWN_COLUMNS,
- E_DDL_PARSE, E_IO, E_BOOTSTRAP_SNAPSHOT, E_SNAPSHOT_MISMATCH, E_CTRL_HINT, E__COUNT) = range(37)
+ E_DDL_PARSE, E_IO, E_BOOTSTRAP_SNAPSHOT, E_SNAPSHOT_MISMATCH, E_CTRL_HINT, E_COPY_UNTERMINATED,
+ E_COPY_MORE_COLS, E_COPY_FEWER_COLS, E__COUNT) = range(40)
 
 # etlg_type_class
 (TC_STRING, TC_BOOL, TC_I16, TC_I32, TC_I64, TC_U32, TC_F32, TC_F64, TC_NUMERIC, TC_BYTEA,

@@ -85,6 +85,9 @@ const etlg_err_desc kErrTable[ETLG_E__COUNT] = {
     {ETLG_InvalidState, "Bootstrap table schema snapshot exceeded requested snapshot"},
     {ETLG_InvalidState, "Table schema snapshot mismatch"},
     {ETLG_InvalidArgument, "Control frame found in a batch declared control-free"},
+    {ETLG_ConversionError, "Row data not properly terminated"},                                    // table_row.rs:100
+    {ETLG_ConversionError, "Postgres COPY row contains more columns than the table schema"},       // table_row.rs:183
+    {ETLG_ConversionError, "Postgres COPY row contains fewer columns than the table schema"},      // table_row.rs:239
 };
 
 // ---------------------------------------------------------------- type map

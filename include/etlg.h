@@ -128,6 +128,10 @@ typedef enum etlg_err_code {
   ETLG_E_BOOTSTRAP_SNAPSHOT = 33, /* InvalidState / "Bootstrap table schema snapshot exceeded requested snapshot" */
   ETLG_E_SNAPSHOT_MISMATCH = 34,  /* InvalidState / "Table schema snapshot mismatch" */
   ETLG_E_CTRL_HINT = 35,          /* InvalidArgument / "Control frame found in a batch declared control-free" */
+  /* table-copy rows (crates/etl/src/postgres/codec/table_row.rs:57-254) */
+  ETLG_E_COPY_UNTERMINATED = 36,  /* ConversionError / "Row data not properly terminated" */
+  ETLG_E_COPY_MORE_COLS = 37,     /* ConversionError / "Postgres COPY row contains more columns than the table schema" */
+  ETLG_E_COPY_FEWER_COLS = 38,    /* ConversionError / "Postgres COPY row contains fewer columns than the table schema" */
   ETLG_E__COUNT
 } etlg_err_code;
 
@@ -266,6 +270,25 @@ int32_t etlg_decode(etlg_ctx* ctx, const uint8_t* buf, size_t len,
                     uint32_t flags, etlg_batch** out);
 
 const etlg_error* etlg_last_error(const etlg_ctx* ctx);
+
+/* Table-copy rows. Replaces parse_table_row_from_postgres_copy_bytes
+ * (crates/etl/src/postgres/codec/table_row.rs:47-254) applied to every item of the
+ * TableCopyStream (crates/etl/src/postgres/stream/table_copy.rs:54-79).
+ * buf = nrows COPY ... TO STDOUT (text format) row payloads exactly as CopyOutStream
+ * yields them (one row per CopyData message, WITHOUT the 'd' framing), concatenated;
+ * row_offsets = nrows + 1 byte offsets (required; host or device as buf).
+ * schema_slot = the ReplicatedTableSchema to decode against: the value etlg_table_ready
+ * returned (its replicated columns are the reference's `column_schemas`).
+ * The rows come back in the same arena as a batch of Insert events: kind 'I',
+ * table_id / schema_slot of the slot, start_lsn = commit_lsn = 0, tx_ordinal = row index,
+ * one full-layout row per event; payload_bytes[0] = bytes of the rows decoded
+ * (TableCopyPayloadMetadata). NULL fields ("\N") are NULL cells whatever the column's
+ * nullability, as in the reference. Fail-fast: the first bad row ends the batch with the
+ * reference's error; rows before it are valid. The stream state of the context
+ * (transaction carry) is not touched.
+ * flags: ETLG_F_INPUT_ON_DEVICE, ETLG_F_OUTPUT_ON_DEVICE. */
+int32_t etlg_copy_decode(etlg_ctx* ctx, int32_t schema_slot, const uint8_t* buf, size_t len,
+                         const uint32_t* row_offsets, size_t nrows, uint32_t flags, etlg_batch** out);
 
 /* Record-boundary scan on its own: the frame_offsets sidecar of `buf` (the same scan
  * etlg_decode runs when it is given none), e.g. to cut a staged stream into shards.

@@ -40,6 +40,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <deque>
 #include <map>
 #include <memory>
 #include <set>
@@ -91,6 +92,9 @@ static const ErrDesc kErr[ETLG_E__COUNT] = {
     {ETLG_InvalidState, "Bootstrap table schema snapshot exceeded requested snapshot"},  // apply.rs:3668
     {ETLG_InvalidState, "Table schema snapshot mismatch"},                         // apply.rs:3690
     {ETLG_InvalidArgument, "Control frame found in a batch declared control-free"},
+    {ETLG_ConversionError, "Row data not properly terminated"},                                    // table_row.rs:100
+    {ETLG_ConversionError, "Postgres COPY row contains more columns than the table schema"},       // table_row.rs:183
+    {ETLG_ConversionError, "Postgres COPY row contains fewer columns than the table schema"},      // table_row.rs:239
 };
 
 // ----------------------------------------------------------------- byte reader
@@ -322,6 +326,7 @@ struct Ctx {
 
 struct Batch {
   std::vector<Event> events;
+  std::deque<std::string> keep;  // unescaped COPY fields that Deferred cells point into
   uint64_t n_frames = 0;
   uint64_t payload[3] = {0, 0, 0};
   // arena (built on demand)
@@ -922,6 +927,93 @@ static void decode_stream(Ctx& c, Batch& b, const u8* buf, size_t len, const uin
 
 // -------------------------------------------------------------- arena writer
 // Canonical layout of include/etlg.h. CONTRACT mode only.
+// ------------------------------------------------------------- table-copy rows
+// parse_table_row_from_postgres_copy_bytes / _str, crates/etl/src/postgres/codec/table_row.rs:47-254.
+// One COPY ... TO STDOUT (text) row -> TableRow against the slot's replicated columns.
+// KATs: table_row.rs:287-633 (tests/golden/reference_kats.py, COPY_ROW_CASES).
+static bool copy_row_to_row(const Ctx& c, Batch& b, const Slot& s, const u8* row, size_t n, Row& out, int32_t& err) {
+  if (!utf8_valid(row, n)) { err = ETLG_E_UTF8; return false; }            // :51 simdutf8 over the whole row
+  const size_t expected = s.cols.size();
+  std::string field_buffer;
+  size_t pos = 0, column_index = 0;
+  bool row_terminated = false, done = false;
+  out.cells.clear();
+  out.cells.reserve(expected);
+  while (!done) {
+    const size_t field_start = pos;
+    size_t literal_start = field_start, field_end = field_start;
+    bool field_escaped = false;
+    for (;;) {
+      size_t sp = pos;
+      while (sp < n && row[sp] != '\t' && row[sp] != '\n' && row[sp] != '\\') sp++;   // find_next_special :26
+      if (sp == n) {
+        if (field_escaped && n > literal_start) field_buffer.append((const char*)row + literal_start, n - literal_start);
+        if (!row_terminated) { err = ETLG_E_COPY_UNTERMINATED; return false; }          // :99-101
+        done = true;
+        break;
+      }
+      if (field_escaped && sp > literal_start) field_buffer.append((const char*)row + literal_start, sp - literal_start);
+      if (row[sp] == '\t') { field_end = sp; pos = sp + 1; break; }
+      if (row[sp] == '\n') { field_end = sp; pos = sp + 1; row_terminated = true; break; }
+      // backslash: decode the following character, stay in this field (:129-176)
+      if (!field_escaped) { field_buffer.append((const char*)row + field_start, sp - field_start); field_escaped = true; }
+      pos = sp + 1;
+      if (pos < n) {
+        const u8 e = row[pos];
+        if (e < 0x80) {
+          char ch;
+          switch (e) {
+            case 'b': ch = 8; break; case 'f': ch = 12; break; case 'n': ch = '\n'; break;
+            case 'r': ch = '\r'; break; case 't': ch = '\t'; break; case 'v': ch = 11; break;
+            default: ch = (char)e; break;   // strips the backslash, keeps the byte
+          }
+          field_buffer.push_back(ch);
+          pos += 1;
+        } else {  // a whole (validated) multi-byte character
+          const size_t l = e >= 0xF0 ? 4 : e >= 0xE0 ? 3 : 2;
+          field_buffer.append((const char*)row + pos, l);
+          pos += l;
+        }
+      }
+      literal_start = pos;
+    }
+    if (done) break;
+    if (column_index >= expected) { err = ETLG_E_COPY_MORE_COLS; return false; }         // :179-192
+    const RCol& col = s.cols[column_index++];
+    Cell cell;
+    const bool is_null = field_end - field_start == 2 && row[field_start] == '\\' && row[field_start + 1] == 'N';  // raw "\N" :199
+    if (!is_null) {
+      sv text((const char*)row + field_start, field_end - field_start);
+      if (field_escaped) { b.keep.push_back(field_buffer); text = sv(b.keep.back()); }
+      if (!decode_text(c, col, text, cell, err)) return false;                          // :206-220
+    }
+    out.cells.push_back(std::move(cell));
+    field_buffer.clear();
+  }
+  if (column_index < expected) { err = ETLG_E_COPY_FEWER_COLS; return false; }           // :234-249
+  return true;
+}
+
+// The TableCopyStream (postgres/stream/table_copy.rs:54-79) over a buffer of rows: one Insert-shaped
+// event per row (include/etlg.h, etlg_copy_decode), fail-fast at the first bad row.
+static void copy_stream(Ctx& c, Batch& b, int32_t slot, const u8* buf, const uint32_t* offs, size_t nrows) {
+  c.last = Failure{};
+  if (slot < 0 || (size_t)slot >= c.slots.size()) { c.last.code = ETLG_E_SCHEMA_NOT_FOUND; c.last.frame = 0; return; }
+  const Slot& s = *c.slots[slot];
+  for (size_t i = 0; i < nrows; i++) {
+    Event ev;
+    int32_t err = 0;
+    if (!copy_row_to_row(c, b, s, buf + offs[i], offs[i + 1] - offs[i], ev.new_row, err)) {
+      c.last.code = err; c.last.frame = (int64_t)i;
+      return;
+    }
+    ev.kind = 'I'; ev.table_id = s.table_id; ev.slot = slot; ev.ord = i;
+    b.payload[0] += offs[i + 1] - offs[i];
+    b.events.push_back(std::move(ev));
+    b.n_frames = i + 1;
+  }
+}
+
 static inline void put32(std::vector<u8>& v, size_t off, uint32_t x) { memcpy(v.data() + off, &x, 4); }
 static inline void put64(std::vector<u8>& v, size_t off, uint64_t x) { memcpy(v.data() + off, &x, 8); }
 
@@ -1188,6 +1280,17 @@ int32_t oracle_decode(oracle_ctx* c, const uint8_t* buf, size_t len, const uint3
   auto* ob = new oracle_batch();
   ob->ctx = &c->c;
   decode_stream(c->c, ob->b, buf, len, offsets, nframes);
+  *out = ob;
+  return c->c.last.code;
+}
+
+// Table-copy rows (include/etlg.h etlg_copy_decode). Returns the error code of the first failing row or 0.
+int32_t oracle_copy_decode(oracle_ctx* c, int32_t slot, const uint8_t* buf, size_t len, const uint32_t* row_offsets, size_t nrows,
+                           oracle_batch** out) {
+  (void)len;
+  auto* ob = new oracle_batch();
+  ob->ctx = &c->c;
+  copy_stream(c->c, ob->b, slot, buf, row_offsets, nrows);
   *out = ob;
   return c->c.last.code;
 }

@@ -43,6 +43,8 @@ def lib():
         L.oracle_table_ready.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_void_p)]
+        L.oracle_copy_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_void_p)]
         L.oracle_decode_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
         L.oracle_decode_timed.restype = C.c_double
@@ -129,6 +131,15 @@ class Oracle:
         a, off, nfr = self._prep(buf, offsets)
         out = C.c_void_p()
         code = self.L.oracle_decode(self.h, _ptr(a), a.size, _ptr(off), nfr, C.byref(out))
+        kind, desc, frame = C.c_int32(), C.c_char_p(), C.c_int64()
+        self.L.oracle_last_error(self.h, C.byref(kind), C.byref(desc), C.byref(frame))
+        return OracleBatch(self, out, code, kind.value, (desc.value or b"").decode(), frame.value, keep=(a, off, buf))
+
+    def copy_decode(self, slot, buf, row_offsets):
+        """Table-copy rows (COPY text format, one row per offsets interval) against schema slot `slot`."""
+        a, off, nrows = self._prep(buf, row_offsets)
+        out = C.c_void_p()
+        code = self.L.oracle_copy_decode(self.h, slot, _ptr(a), a.size, _ptr(off), nrows, C.byref(out))
         kind, desc, frame = C.c_int32(), C.c_char_p(), C.c_int64()
         self.L.oracle_last_error(self.h, C.byref(kind), C.byref(desc), C.byref(frame))
         return OracleBatch(self, out, code, kind.value, (desc.value or b"").decode(), frame.value, keep=(a, off, buf))
