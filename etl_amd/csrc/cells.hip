@@ -267,9 +267,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     if (live && too_wide) atomicOr(fail, 4u);
     // ownership + schema slot (size_frame's lookups), per frame
     if (live && wire_ok && (v.tag == 'I' || v.tag == 'U' || v.tag == 'D')) {
-      const int ti = find_table(p, rel_id);
+      const int ti = (pg.flags & 2u) ? -1 : find_table(p, rel_id);
       int slot = -1;
-      if (should_apply(p, ti, rel_id, tx.final_lsn)) {
+      if (pg.flags & 2u) slot = pg.copy_slot;  // table-copy rows: the caller named the schema
+      else if (should_apply(p, ti, rel_id, tx.final_lsn)) {
         slot = cache_slot_before(p, ti, f);
         if (slot < 0) { record_error(pg, f, RK_SCHEMA, (uint32_t)(-slot)); slot = -1; }
         else if (p.slots[slot].n_cols > maxc) { atomicOr(fail, 4u); slot = -1; }
@@ -511,7 +512,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         if (cls == u) { err = decode_text_cell<false>(u, base + pos, len, slotp, pg.heap, hcur, st, use_lds); done = true; }
       }
     } else if (act && kind == CT_N) {
-      if (!col.nullable) err = ETLG_E_REQUIRED_NULL; else slot_zero(slotp, cls);
+      if (!col.nullable && !(pg.flags & 2u)) err = ETLG_E_REQUIRED_NULL; else slot_zero(slotp, cls);
     } else if (act && kind == CT_U) {
       if (mode == ROW_FULL) err = ETLG_E_FULL_ROW_MISSING;
       else if (mode == ROW_KEY) err = ETLG_E_KEY_MISSING_VALUE;

@@ -1081,7 +1081,7 @@ DEV uint32_t write_row(const DecParams& p, const DevSlot& s, uint32_t mode, cons
     uint32_t* slot = (uint32_t*)(row + (mode == ROW_KEY ? col.off_key : col.off_full));
     uint32_t st = ETLG_CELL_NULL;
     if (t == 'n') {  // convert_tuple_data_to_cell, codec/event.rs:945-961
-      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
+      if (!col.nullable && !(p.flags & 2u)) return ETLG_E_REQUIRED_NULL;
       slot_zero(slot, col.cls);
     } else if (t == 'u') {
       if (mode == ROW_FULL) return ETLG_E_FULL_ROW_MISSING;
@@ -1137,7 +1137,7 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
       if (err) return err;
       c += len;
     } else if (t == 'n') {
-      if (!col.nullable) return ETLG_E_REQUIRED_NULL;
+      if (!col.nullable && !(pg.flags & 2u)) return ETLG_E_REQUIRED_NULL;
       slot_zero(slot, cls);
     } else if (t == 'u') {
       return ETLG_E_FULL_ROW_MISSING;
@@ -1217,10 +1217,14 @@ DEV void size_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, bo
     case 'I': case 'U': case 'D': {
       if (check_txn && !tx.in_txn) { record_error(p, f, RK_TXN, ETLG_E_TXN_STATE); break; }
       pay[tag == 'I' ? 0 : tag == 'U' ? 1 : 2] = m.vbytes;  // metrics precede the ownership check
-      const int ti = find_table(p, m.rel_id);
-      if (!should_apply(p, ti, m.rel_id, tx.final_lsn)) break;
-      const int slot = cache_slot_before(p, ti, f);
-      if (slot < 0) { record_error(p, f, RK_SCHEMA, (uint32_t)(-slot)); break; }
+      int slot;
+      if (p.flags & 2u) slot = p.copy_slot;  // table-copy rows: the caller named the schema
+      else {
+        const int ti = find_table(p, m.rel_id);
+        if (!should_apply(p, ti, m.rel_id, tx.final_lsn)) break;
+        slot = cache_slot_before(p, ti, f);
+        if (slot < 0) { record_error(p, f, RK_SCHEMA, (uint32_t)(-slot)); break; }
+      }
       const DevSlot& s = p.slots[slot];
       row_slot = slot;
       emit = 1;

@@ -95,7 +95,7 @@ constexpr int kBlock = 256;  // frames per workgroup (one lane per frame)
 // error stage ranks: for one frame the lowest rank wins, mirroring the order
 // in which the reference detects them (wire parse -> transaction state ->
 // ownership/schema lookup -> event decode).
-enum : uint32_t { RK_WIRE = 0, RK_TXN = 1, RK_SCHEMA = 2, RK_DECODE = 3 };
+enum : uint32_t { RK_WIRE = 0, RK_TXN = 1, RK_SCHEMA = 2, RK_DECODE = 3, RK_COPY_SHAPE = 4 };
 
 struct DecParams {
   const uint8_t* in;
@@ -106,12 +106,13 @@ struct DecParams {
   // carried transaction state (apply.rs:942-963)
   uint32_t in_txn;
   uint32_t worker_kind, sync_table;
-  uint32_t flags;        // bit0: NO_CONTROL asserted
+  uint32_t flags;        // bit0: NO_CONTROL asserted; bit1: table-copy rows (synthetic Insert frames: no ownership
+                         // check, NULL allowed in every column — table_row.rs:199-201)
   uint64_t final_lsn, next_ord;
   uint32_t host_err_frame;  // frames >= this are ignored (host control plane failed there)
   uint32_t n_tables;
   uint32_t n_epochs, n_slots, n_cols;  // sizes of the side-input arrays
-  uint32_t _pad0;
+  int32_t copy_slot;     // flags bit1 (table-copy rows): the schema slot every row decodes against
   // side inputs
   const DevTable* tables;
   const DevEpoch* epochs;

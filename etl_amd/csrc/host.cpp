@@ -35,6 +35,10 @@ extern "C" int etlg_k_fused_set_lds(void);
 extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* vdesc, void* ndesc,
                                      uint32_t* hints, uint32_t* result, int sequential, hipStream_t s);
 extern "C" uint32_t etlg_k_bounds_tile_bytes(void);
+extern "C" uint32_t etlg_k_copy_bytes_per_row(uint32_t ncols);
+extern "C" int etlg_k_copy_set_lds(void);
+extern "C" void etlg_k_launch_copy(const uint8_t* rows, const uint32_t* row_offs, uint32_t nrows, uint64_t rows_len, uint32_t ncols,
+                                   uint32_t rel_id, uint8_t* out, uint32_t* out_offs, uint32_t lds_bytes, const DecParams* dec, hipStream_t s);
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
@@ -43,7 +47,8 @@ extern "C" uint32_t etlg_k_cells_maxc(void);
 constexpr int kFused = 7;  // profiling slot of the fused kernel
 constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
 constexpr int kBounds = 9; // ... of the record-boundary scan (scan.hip)
-constexpr int kProfSlots = 10;
+constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
+constexpr int kProfSlots = 11;
 
 namespace {
 
@@ -182,6 +187,16 @@ struct OutSet {  // device output arrays of one batch
 
 struct ProfRec { int which; hipEvent_t a, b; };
 
+// A table-copy batch in flight (etlg_copy_decode): the rows that k_copy_frames turns into Insert frames.
+struct CopyJob {
+  bool active = false;
+  int32_t slot = -1;
+  const uint8_t* d_rows = nullptr; const uint32_t* d_row_offs = nullptr;
+  uint32_t nrows = 0, ncols = 0, rel_id = 0, lds = 0;
+  uint64_t rows_len = 0;
+  uint8_t* d_out = nullptr; uint32_t* d_out_offs = nullptr;
+};
+
 }  // namespace
 
 struct etlg_ctx {
@@ -198,6 +213,8 @@ struct etlg_ctx {
   // carried transaction state
   bool in_txn = false; uint64_t final_lsn = 0, next_ord = 0;
   // device scratch (grow-only)
+  CopyJob copy;        // set while etlg_copy_decode runs etlg_decode over its synthetic frames
+  DevBuf d_copy_in, d_copy_offs, d_copy_out, d_copy_out_offs;
   DevBuf d_scan;       // scratch of the record-boundary scan
   uint32_t* h_scan = nullptr;  // pinned: its 4-word result
   unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
@@ -235,6 +252,7 @@ struct etlg_batch {
   std::vector<etlg_slot_desc> slot_descs;
   bool pending = false;  // ASYNC: counts not read back yet
   DevResult* h_res = nullptr;  // pinned, from the context's pool
+  CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
   bool used_cells = false; // ... and it was k_cells
   bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
   DecParams params{};
@@ -691,6 +709,14 @@ void launch(etlg_ctx* c, int which, const DecParams& p) {
   }
 }
 
+void launch_copy(etlg_ctx* c, const CopyJob& j, const DecParams& p) {
+  if (!j.nrows) return;
+  ProfRec r; r.which = kCopy;
+  if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, c->stream); }
+  etlg_k_launch_copy(j.d_rows, j.d_row_offs, j.nrows, j.rows_len, j.ncols, j.rel_id, j.d_out, j.d_out_offs, j.lds, &p, c->stream);
+  if (c->prof) { (void)hipEventRecord(r.b, c->stream); c->prof_recs.push_back(r); }
+}
+
 // The multi-pass pipeline (also the exact first-error path).
 void launch_multipass(etlg_ctx* c, const DecParams& p, bool classify_done) {
   if (!classify_done) { if (p.nframes) launch(c, 0, p); launch(c, 1, p); }
@@ -766,6 +792,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { DevResult init{}; init.first_err = kNoErr; *c->h_init = init; }
   (void)etlg_k_fused_set_lds();
   (void)etlg_k_cells_set_lds();
+  (void)etlg_k_copy_set_lds();
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
@@ -780,7 +807,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
-  for (DevBuf* b : {&c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc}) b->release();
+  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (c->h_init) (void)hipHostFree(c->h_init);
@@ -883,7 +910,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }
@@ -966,6 +993,56 @@ int32_t etlg_ctx_debug_scan(etlg_ctx* c, unsigned long long* out2) {
   return ETLG_OK;
 }
 
+int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, size_t len, const uint32_t* row_offsets, size_t nrows,
+                         uint32_t flags, etlg_batch** out) {
+  if (!c || !out || !row_offsets) return ETLG_InvalidArgument;
+  *out = nullptr;
+  clear_error(c);
+  if (schema_slot < 0 || (size_t)schema_slot >= c->slots.size()) return lib_error(c, ETLG_InvalidArgument, "unknown schema slot");
+  const SlotHost& sh = *c->slots[(size_t)schema_slot];
+  const uint32_t ncols = sh.desc.n_cols;
+  const uint64_t per_row = etlg_k_copy_bytes_per_row(ncols);
+  const uint64_t syn_len = (uint64_t)len + (uint64_t)nrows * per_row;
+  if (syn_len > 0xFFFFFFFFull - 64 || nrows >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE;
+  hipStream_t s = c->stream;
+  CopyJob j;
+  j.active = true; j.slot = schema_slot; j.nrows = (uint32_t)nrows; j.ncols = ncols; j.rel_id = sh.desc.table_id; j.rows_len = len;
+  if (in_dev) { j.d_rows = buf; j.d_row_offs = row_offsets; }
+  else {
+    HIPCHK(c, c->d_copy_in.ensure(len + 64)); HIPCHK(c, c->d_copy_offs.ensure((nrows + 1) * 4));
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_copy_in.p, buf, len, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_copy_offs.p, row_offsets, (nrows + 1) * 4, hipMemcpyHostToDevice, s));
+    j.d_rows = (const uint8_t*)c->d_copy_in.p; j.d_row_offs = (const uint32_t*)c->d_copy_offs.p;
+  }
+  HIPCHK(c, c->d_copy_out.ensure(syn_len + 64)); HIPCHK(c, c->d_copy_out_offs.ensure((nrows + 1) * 4));
+  j.d_out = (uint8_t*)c->d_copy_out.p; j.d_out_offs = (uint32_t*)c->d_copy_out_offs.p;
+  if (nrows == 0) HIPCHK(c, hipMemsetAsync(j.d_out_offs, 0, 4, s));
+  const uint64_t avg = nrows ? (len + nrows - 1) / nrows : 0;
+  j.lds = (uint32_t)std::min<uint64_t>(((256 * avg * 9 / 8 + 1024) + 255) & ~255ull, 150 * 1024);
+  // the rows decode inside a virtual transaction of their own; the context's stream state is left alone
+  const bool sv_in = c->in_txn; const uint64_t sv_lsn = c->final_lsn, sv_ord = c->next_ord;
+  c->in_txn = true; c->final_lsn = 0; c->next_ord = 0;
+  c->copy = j;
+  const int32_t rc = etlg_decode(c, j.d_out, (size_t)syn_len, j.d_out_offs, nrows,
+                                 (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL, out);
+  c->copy = CopyJob{};
+  c->in_txn = sv_in; c->final_lsn = sv_lsn; c->next_ord = sv_ord;
+  if (*out) {
+    // TableCopyPayloadMetadata: the bytes of the rows that were decoded
+    etlg_batch* b = *out;
+    const uint64_t done = b->v.n_frames;
+    uint32_t o[2] = {0, 0};
+    if (in_dev) {
+      (void)hipMemcpy(&o[0], row_offsets, 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&o[1], row_offsets + done, 4, hipMemcpyDeviceToHost);
+    } else { o[0] = row_offsets[0]; o[1] = row_offsets[done]; }
+    b->v.payload_bytes[0] = o[1] - o[0]; b->v.payload_bytes[1] = 0; b->v.payload_bytes[2] = 0;
+  }
+  return rc;
+}
+
 int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags, etlg_batch** out) {
   if (!c || !out) return ETLG_InvalidArgument;
   *out = nullptr;
@@ -1010,6 +1087,8 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
   p.worker_kind = (uint32_t)c->worker; p.sync_table = c->sync_table;
   p.flags = no_ctrl ? 1u : 0u;
+  p.copy_slot = -1;
+  if (c->copy.active) { p.flags |= 2u; p.copy_slot = c->copy.slot; b->copy = c->copy; }
   p.host_err_frame = 0xFFFFFFFFu;
 
   HIPCHK(c, c->d_tag.ensure(nf + 16)); HIPCHK(c, c->d_emit.ensure(nf + 16));
@@ -1025,6 +1104,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   if (c->res_pool.empty()) { DevResult* r = nullptr; HIPCHK(c, hipHostMalloc((void**)&r, sizeof(DevResult), hipHostMallocDefault)); c->res_pool.push_back(r); }
   b->h_res = c->res_pool.back(); c->res_pool.pop_back();
   HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+  if (b->copy.active) launch_copy(c, b->copy, p);  // rows -> Insert frames (writes p.in / p.offs), row-level errors
 
   std::vector<CtrlFrame> ctrl;
   std::vector<EpochRec> eps;
@@ -1260,6 +1340,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
   if (b->used_fused && (b->h_res->first_err != kNoErr || b->h_res->fused_fail)) {
     // cold path: recompute with the multi-pass kernels, which know the exact cut at the failing frame
     HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    if (b->copy.active) launch_copy(c, b->copy, b->params);
     launch_multipass(c, b->params, false);
     HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

@@ -142,6 +142,25 @@ class Decoder:
             raise self.last_error()
         return Batch(self, out, rc)
 
+    def copy_decode(self, slot, buf, row_offsets, flags=0):
+        """Table-copy rows (COPY text format) from host buffers against schema slot `slot`
+        (the value table_ready returned)."""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf)
+        off = np.ascontiguousarray(row_offsets, dtype=np.uint32)
+        out = C.c_void_p()
+        rc = self.L.etlg_copy_decode(self.h, slot, _ptr(a), a.size, _ptr(off), len(off) - 1, flags & ~abi.F_INPUT_ON_DEVICE, C.byref(out))
+        if not out:
+            raise self.last_error()
+        return Batch(self, out, rc, keep=(a, off))
+
+    def copy_decode_device(self, slot, buf_ptr, nbytes, offs_ptr, nrows, flags=abi.F_OUTPUT_ON_DEVICE):
+        out = C.c_void_p()
+        rc = self.L.etlg_copy_decode(self.h, slot, C.c_void_p(buf_ptr), nbytes, C.c_void_p(offs_ptr), nrows,
+                                     flags | abi.F_INPUT_ON_DEVICE, C.byref(out))
+        if not out:
+            raise self.last_error()
+        return Batch(self, out, rc)
+
     # ---- measurement
     def profile(self, enable=True):
         return self.L.etlg_ctx_profile(self.h, 1 if enable else 0)
