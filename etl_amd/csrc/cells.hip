@@ -597,6 +597,10 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
   if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;
   if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
+  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
+    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
+    for (uint32_t i = tid; i < per; i += NW * 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
+  }
   // ---- P0: side tables, offsets, staging
   {  // the side-input tables always live in LDS here (the host picks another kernel when they do not fit)
     const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);

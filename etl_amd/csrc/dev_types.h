@@ -87,6 +87,8 @@ struct FusedParams {
   uint32_t seq_lookback;       // 1: ownership needs the transaction's final_lsn (a table is in SyncDone state)
   uint32_t side_bytes;         // LDS bytes reserved for a copy of the side-input tables (0 = read them from global)
   uint32_t maxc;               // k_cells: widest schema slot of the batch (columns)
+  uint32_t clear_words;        // 64-bit words of d_clear this launch zeroes (the descriptor buffer of the NEXT batch)
+  unsigned long long* d_clear;
 };
 
 constexpr unsigned long long kNoErr = ~0ull;

@@ -81,7 +81,9 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     const uint32_t seg = seg_combine(bc, seg_in);
     const uint32_t last = bm > pm ? bm : pm;
     tx.in_txn = (last & 1u) != 0;
-    tx.final_lsn = tx.in_txn ? final_lsn_of_mark(p, last) : 0;
+    // the Begin that opened this frame's transaction: carried in from earlier tiles (its final_lsn was
+    // fetched by the wave that ran the transaction look-back) or a frame of this tile (read in place)
+    tx.final_lsn = !tx.in_txn ? 0 : last == bm ? s64[6] : ld_be64(base + (((last >> 1) - 1) - win0) + kBodyOff);
     const uint64_t c = seg & 0x7FFFFFFFu;
     tx.ord = (seg & 0x80000000u) ? c - 1 : p.next_ord + c - 1;
   };
@@ -89,7 +91,7 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     // ownership depends on the transaction's final_lsn (a table is SyncDone): transaction state first
     if (wave == 0) {
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
     }
     __syncthreads();
     make_tx();
@@ -124,7 +126,7 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     if (wave == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail); if ((tid & 63) == 0) s64[5] = b; }
     if (wave == 2 && !q.seq_lookback) {
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
     }
   } else if (wave == 0) {
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
@@ -132,7 +134,7 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     if (tid == 0) { s64[4] = a; s64[5] = b; }
     if (!q.seq_lookback) {
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
     }
   }
   __syncthreads();
@@ -177,6 +179,10 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
   const uint32_t tid = threadIdx.x;
   if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;  // per-tile payload accumulators
+  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
+    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
+    for (uint32_t i = tid; i < per; i += BLK) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
+  }
 #if ETLG_TICKET
   if (tid == 0) s32[15] = atomicAdd(q.ticket, 1u);
 #else
@@ -204,21 +210,16 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
   if (tile >= q.ntiles) return;
   const uint32_t f0 = tile * BLK;
   const uint32_t nt = p.nframes - f0 < (uint32_t)BLK ? p.nframes - f0 : (uint32_t)BLK;
-  for (uint32_t i = tid; i <= nt; i += BLK) s_offs[i] = p.offs[f0 + i];
-  __syncthreads();
-  TSTAMP(0);
+  // The tile's byte span comes from two scalar loads, so staging can start while the per-frame
+  // offsets are still in flight (one global round trip instead of two before the first byte lands).
+  const uint32_t f0u = __builtin_amdgcn_readfirstlane(f0), ntu = __builtin_amdgcn_readfirstlane(nt);
+  const uint32_t span0 = p.offs[f0u], span1 = p.offs[f0u + ntu];
+  const uint32_t my_o = tid <= nt ? p.offs[f0 + tid] : 0u;
+  const uint32_t last_o = (tid == 0 && nt == (uint32_t)BLK) ? p.offs[f0 + BLK] : 0u;
   u8* stage = smem + q.side_bytes;
-  const uint32_t span0 = s_offs[0], span1 = s_offs[nt];
-  // every well-formed frame of the tile must lie inside [span0, span1) to be staged
-  bool lane_ok = true;
-  if (tid < nt) {
-    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
-    lane_ok = o1 <= o0 || o1 > p.in_len || (o0 >= span0 && o1 <= span1);
-  }
   const uint32_t a0 = span0 & ~15u;
-  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 16 <= q.lds_bytes - q.side_bytes;
-  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok && !(q.dbg & 1);
-  if (use_lds) {
+  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 16 <= q.lds_bytes - q.side_bytes && !(q.dbg & 1);
+  if (window_ok) {
     // coalesced staging: 16 B per lane per step; the tail that would cross in_len goes bytewise
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);  // last full 16-byte chunk boundary <= span1
     // four independent 16-byte loads in flight per lane before the first LDS store
@@ -234,7 +235,19 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
       if (c3 < full_end) *(uint4*)(stage + (c3 - a0)) = v3;
     }
     for (uint32_t c = full_end + tid; c < span1; c += BLK) stage[c - a0] = p.in[c];
-    __syncthreads();
+  }
+  if (tid <= nt) s_offs[tid] = my_o;
+  if (tid == 0 && nt == (uint32_t)BLK) s_offs[BLK] = last_o;
+  __syncthreads();
+  TSTAMP(0);
+  // every well-formed frame of the tile must lie inside [span0, span1) for the staged copy to be used
+  bool lane_ok = true;
+  if (tid < nt) {
+    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
+    lane_ok = o1 <= o0 || o1 > p.in_len || (o0 >= span0 && o1 <= span1);
+  }
+  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
+  if (use_lds) {
     TSTAMP(1);
     tile_body<BLK, true>(p, pg, q, tile, nt, s_offs, stage, a0, s32, s64);
   } else {

@@ -213,6 +213,14 @@ struct etlg_ctx {
   // carried transaction state
   bool in_txn = false; uint64_t final_lsn = 0, next_ord = 0;
   // device scratch (grow-only)
+  // look-back descriptors are double buffered: each single-pass launch zeroes the buffer of the next one
+  size_t desc_half = 0;          // bytes per buffer
+  size_t desc_dirty[2] = {0, 0}; // bytes at the head of each buffer that may be non-zero
+  uint32_t desc_cur = 0;
+  // result blocks: a ring re-initialised once per lap with one copy
+  static constexpr uint32_t kResRing = 32;
+  uint32_t res_seq = 0;
+  DevResult* h_init_ring = nullptr;
   CopyJob copy;        // set while etlg_copy_decode runs etlg_decode over its synthetic frames
   DevBuf d_copy_in, d_copy_offs, d_copy_out, d_copy_out_offs;
   DevBuf d_scan;       // scratch of the record-boundary scan
@@ -253,6 +261,7 @@ struct etlg_batch {
   bool pending = false;  // ASYNC: counts not read back yet
   DevResult* h_res = nullptr;  // pinned, from the context's pool
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
+  DevResult* d_res_blk = nullptr;  // this batch's result block on the device
   bool used_cells = false; // ... and it was k_cells
   bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
   DecParams params{};
@@ -790,6 +799,9 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   e = hipHostMalloc((void**)&c->h_init, sizeof(DevResult), hipHostMallocDefault);
   if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail("hipHostMalloc", e); }
   { DevResult init{}; init.first_err = kNoErr; *c->h_init = init; }
+  e = hipHostMalloc((void**)&c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipHostMallocDefault);
+  if (e != hipSuccess) { snprintf(g_create_err, sizeof g_create_err, "hipHostMalloc: %s", hipGetErrorString(e)); delete c; return ETLG_DeviceError; }
+  for (uint32_t i = 0; i < etlg_ctx::kResRing; i++) c->h_init_ring[i] = *c->h_init;
   (void)etlg_k_fused_set_lds();
   (void)etlg_k_cells_set_lds();
   (void)etlg_k_copy_set_lds();
@@ -811,6 +823,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (c->h_init) (void)hipHostFree(c->h_init);
+  if (c->h_init_ring) (void)hipHostFree(c->h_init_ring);
   for (DevResult* r : c->res_pool) (void)hipHostFree(r);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1095,15 +1108,19 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   HIPCHK(c, c->d_ffixed.ensure((size_t)nf * 4 + 16)); HIPCHK(c, c->d_fheap.ensure((size_t)nf * 4 + 16));
   HIPCHK(c, c->d_blk32.ensure((size_t)(nblocks + 1) * 4 * 3 + 64));
   HIPCHK(c, c->d_blk64.ensure((size_t)(nblocks + 1) * 8 * 5 + 64));
-  HIPCHK(c, c->d_res.ensure(sizeof(DevResult)));
+  HIPCHK(c, c->d_res.ensure(sizeof(DevResult) * etlg_ctx::kResRing));
   p.f_tag = (uint8_t*)c->d_tag.p; p.f_emit = (uint8_t*)c->d_emit.p;
   p.f_fixed = (uint32_t*)c->d_ffixed.p; p.f_heap = (uint32_t*)c->d_fheap.p;
   p.blk_cnt = (uint32_t*)c->d_blk32.p; p.blk_last = p.blk_cnt + (nblocks + 1); p.blk_ev = p.blk_last + (nblocks + 1);
   p.blk_fixed = (uint64_t*)c->d_blk64.p; p.blk_heap = p.blk_fixed + (nblocks + 1); p.blk_payload = p.blk_heap + (nblocks + 1);
-  p.res = (DevResult*)c->d_res.p;
+  {  // result block: next slot of the ring; the whole ring is re-initialised by one copy per lap
+    const uint32_t slot = c->res_seq++ % etlg_ctx::kResRing;
+    if (slot == 0) HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice, s));
+    b->d_res_blk = (DevResult*)c->d_res.p + slot;
+  }
+  p.res = b->d_res_blk;
   if (c->res_pool.empty()) { DevResult* r = nullptr; HIPCHK(c, hipHostMalloc((void**)&r, sizeof(DevResult), hipHostMallocDefault)); c->res_pool.push_back(r); }
   b->h_res = c->res_pool.back(); c->res_pool.pop_back();
-  HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
   if (b->copy.active) launch_copy(c, b->copy, p);  // rows -> Insert frames (writes p.in / p.offs), row-level errors
 
   std::vector<CtrlFrame> ctrl;
@@ -1119,7 +1136,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     HIPCHK(c, c->d_ctrl.ensure((size_t)nf * sizeof(CtrlFrame) + 64));
     p.ctrl = (CtrlFrame*)c->d_ctrl.p; p.ctrl_cap = nf;
     launch(c, 2, p);
-    HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const uint32_t nctrl = b->h_res->n_ctrl;
     if (nctrl) {
@@ -1243,17 +1260,31 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     const size_t ngroups = (q.ntiles + 63) / 64;
     const size_t per = (size_t)q.ntiles + ngroups;  // tile descriptors followed by group descriptors
     const size_t dbytes = per * 8 * 3 + 64;
-    HIPCHK(c, c->d_desc.ensure(dbytes));
-    HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, dbytes, s));
-    q.d_txn = (unsigned long long*)c->d_desc.p; q.d_outa = q.d_txn + per; q.d_outb = q.d_outa + per;
+    // two descriptor buffers: this launch uses one and zeroes the head of the other for the next batch,
+    // so the stream carries no memset between kernels (only when a buffer grows or a larger batch left a tail)
+    if (dbytes > c->desc_half) {
+      const size_t half = (dbytes * 2 + 4095) & ~(size_t)4095;
+      HIPCHK(c, c->d_desc.ensure(half * 2));
+      HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, half * 2, s));
+      c->desc_half = half; c->desc_dirty[0] = c->desc_dirty[1] = 0;
+    }
+    const uint32_t cur = c->desc_cur, oth = cur ^ 1u;
+    uint8_t* dcur = (uint8_t*)c->d_desc.p + cur * c->desc_half;
+    uint8_t* doth = (uint8_t*)c->d_desc.p + oth * c->desc_half;
+    if (c->desc_dirty[cur]) { HIPCHK(c, hipMemsetAsync(dcur, 0, c->desc_dirty[cur], s)); c->desc_dirty[cur] = 0; }
+    q.d_txn = (unsigned long long*)dcur; q.d_outa = q.d_txn + per; q.d_outb = q.d_outa + per;
     q.ticket = (uint32_t*)(q.d_outb + per);
+    q.d_clear = (unsigned long long*)doth; q.clear_words = (uint32_t)(dbytes / 8);
+    c->desc_dirty[cur] = dbytes;                                   // this launch writes it
+    if (c->desc_dirty[oth] <= dbytes) c->desc_dirty[oth] = 0;       // ... and clears that much of the other one
+    c->desc_cur = oth;
     launch(c, use_cells ? kCells : kFused, p);
     b->used_fused = true;
     b->used_cells = use_cells;
   } else {
     launch_multipass(c, p, classify_done);
   }
-  HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
 
   (void)slots_before;
   guard.release();
@@ -1272,7 +1303,7 @@ int32_t etlg_batch_sync(etlg_ctx* c, etlg_batch* b) {
 int32_t etlg_batch_header_to_device(etlg_ctx* c, etlg_batch* b, void* dst) {
   if (!c || !b || !dst) return ETLG_InvalidArgument;
   static_assert(offsetof(DevResult, n_frames) == 56, "header layout");
-  HIPCHK(c, hipMemcpyAsync(dst, c->d_res.p, 64, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dst, b->d_res_blk, 64, hipMemcpyDeviceToDevice, c->stream));
   return ETLG_OK;
 }
 
@@ -1339,10 +1370,10 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
   HIPCHK(c, hipStreamSynchronize(s));
   if (b->used_fused && (b->h_res->first_err != kNoErr || b->h_res->fused_fail)) {
     // cold path: recompute with the multi-pass kernels, which know the exact cut at the failing frame
-    HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(b->d_res_blk, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
     if (b->copy.active) launch_copy(c, b->copy, b->params);
     launch_multipass(c, b->params, false);
-    HIPCHK(c, hipMemcpyAsync(b->h_res, c->d_res.p, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     b->used_fused = false;
     c->path_n[3]++;

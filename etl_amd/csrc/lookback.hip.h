@@ -51,6 +51,13 @@ DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint3
   const uint32_t g = tile >> 6, j = tile & 63;
   if (lane == 0) __hip_atomic_store(&desc[tile], ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t polls = 0;
+  // the first window of group descriptors is requested now, so that its round trip overlaps window 0's
+  unsigned long long w1_pre = 0;
+  {
+    const int64_t idx = (int64_t)g - 1 - lane;
+    if (idx >= 0) w1_pre = __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool pre_valid = true;
   // ---- window 0: earlier tiles of this group (lane l <-> tile g*64 + l, l < j)
   unsigned long long w0 = 0;
   bool have = (uint32_t)lane >= j;  // lanes >= j have nothing to fetch
@@ -80,8 +87,9 @@ DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint3
   for (;;) {
     const int64_t idx = base - lane;
     unsigned long long w = ST_INCL | carry;
-    if (idx >= 0) w = __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (idx >= 0) w = pre_valid ? w1_pre : __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (idx < -1) w = ST_INCL | Op::id();
+    pre_valid = false;
     const unsigned long long st = w & ST_MASK;
     const unsigned long long m_incl = __ballot(st == ST_INCL);
     const unsigned long long m_empty = __ballot(st == 0);
