@@ -443,18 +443,28 @@ __device__ __attribute__((noinline)) bool parse_int(const u8* s, uint32_t n, boo
   return true;
 }
 
-// SWAR variant for callers that may read up to 7 bytes past the text (LDS-staged tiles
-// keep 16 bytes of slack): 8 ASCII digits per step, no per-character loop.
+// SWAR variant for callers that may read up to 7 bytes past the text (LDS-staged tiles keep 16
+// bytes of slack): four ASCII digits per 32-bit word, no per-character loop and no 64-bit
+// multiplies (those cost 4-6 VALU instructions each on this hardware; a 10-digit value is three
+// words, ~45 instructions).
+// `w` = 4 bytes, first digit in byte 0. Returns their value; clears `ok` on a non-digit.
+DEV uint32_t digits4(uint32_t w, bool& ok) {
+  const uint32_t t = w - 0x30303030u;
+  ok = ok && ((((w + 0x46464646u) | t) & 0x80808080u) == 0);
+  const uint32_t p = (t * 10u + (t >> 8)) & 0x00FF00FFu;  // two 2-digit numbers (bytes 0 and 2)
+  return (p & 0xFFu) * 100u + (p >> 16);
+}
+// The leading r (1..4) digits of a text, as a 4-digit word left-padded with '0'.
+DEV uint32_t lead_word(const u8* s, uint32_t r) {
+  uint32_t w; __builtin_memcpy(&w, s, 4);
+  return r == 4 ? w : (w << (8 * (4 - r))) | (0x30303030u >> (8 * r));
+}
 DEV bool swar_digits8(const u8* s, uint32_t n /* 1..8 */, uint32_t& out) {
-  uint64_t x; __builtin_memcpy(&x, s, 8);
-  if (n < 8) x = (x << (8 * (8 - n))) | (0x3030303030303030ull >> (8 * n));  // left-pad with '0'
-  const uint64_t t = x - 0x3030303030303030ull;
-  if (((x + 0x4646464646464646ull) | t) & 0x8080808080808080ull) return false;  // a byte outside '0'..'9'
-  uint64_t v = (t * 10) + (t >> 8);
-  const uint64_t mask = 0x000000FF000000FFull;
-  v = (((v & mask) * 0x000F424000000064ull) + (((v >> 16) & mask) * 0x0000271000000001ull)) >> 32;
-  out = (uint32_t)v;
-  return true;
+  bool ok = true;
+  if (n <= 4) { out = digits4(lead_word(s, n), ok); return ok; }
+  uint32_t lo; __builtin_memcpy(&lo, s + (n - 4), 4);
+  out = digits4(lead_word(s, n - 4), ok) * 10000u + digits4(lo, ok);
+  return ok;
 }
 DEV bool parse_int_swar(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& out) {
   if (n == 0) return false;
@@ -466,18 +476,32 @@ DEV bool parse_int_swar(const u8* s, uint32_t n, bool is_signed, int bits, int64
     s++; n--;
   }
   if (n > 19) return parse_int(neg || c0 == '+' ? s - 1 : s, neg || c0 == '+' ? n + 1 : n, is_signed, bits, out);  // long (leading zeros)
-  uint32_t lo = 0, mid = 0, hi = 0;
+  // groups of 4 digits from the right; the leading group has r = 1..4 digits
+  const uint32_t r = ((n - 1) & 3u) + 1u, ng = (n - r) >> 2;  // ng full groups after the leading one (0..4)
+  bool ok = true;
+  const uint32_t lead = digits4(lead_word(s, r), ok);
+  const u8* g = s + r;
   uint64_t mag;
-  if (n <= 8) {
-    if (!swar_digits8(s, n, lo)) return false;
-    mag = lo;
-  } else if (n <= 16) {
-    if (!swar_digits8(s, n - 8, mid) || !swar_digits8(s + (n - 8), 8, lo)) return false;
-    mag = (uint64_t)mid * 100000000ull + lo;
+  if (ng == 0) mag = lead;
+  else if (ng == 1) {  // up to 8 digits: 32-bit arithmetic
+    uint32_t w; __builtin_memcpy(&w, g, 4);
+    mag = lead * 10000u + digits4(w, ok);
   } else {
-    if (!swar_digits8(s, n - 16, hi) || !swar_digits8(s + (n - 16), 8, mid) || !swar_digits8(s + (n - 8), 8, lo)) return false;
-    mag = ((uint64_t)hi * 100000000ull + mid) * 100000000ull + lo;
+    // two groups per 8-byte load; the first accumulate is a 32 x 32 -> 64 multiply-add
+    uint64_t x; __builtin_memcpy(&x, g, 8);
+    mag = (uint64_t)lead * 100000000u + (digits4((uint32_t)x, ok) * 10000u + digits4((uint32_t)(x >> 32), ok));
+    g += 8;
+    if (ng >= 4) {
+      __builtin_memcpy(&x, g, 8);
+      mag = mag * 100000000ull + (digits4((uint32_t)x, ok) * 10000u + digits4((uint32_t)(x >> 32), ok));
+      g += 8;
+    }
+    if (ng & 1u) {
+      uint32_t w; __builtin_memcpy(&w, g, 4);
+      mag = mag * 10000ull + digits4(w, ok);
+    }
   }
+  if (!ok) return false;
   uint64_t lim;
   if (is_signed) lim = neg ? (1ull << (bits - 1)) : (1ull << (bits - 1)) - 1;
   else lim = bits == 64 ? ~0ull : (1ull << bits) - 1;
@@ -1127,7 +1151,8 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
   for (uint32_t i = 0; i < n; i++) {
     const DevCol col = cols[i];
     const uint32_t cls = col.cls;
-    uint32_t* slot = (uint32_t*)(row + col.off_full);
+    uint32_t dummy[4];
+    uint32_t* slot = (pg.flags & 0x100u) ? dummy : (uint32_t*)(row + col.off_full);  // 0x100: profiling ablation (no row stores)
     const uint32_t t = *c++;
     uint32_t st = ETLG_CELL_NULL;
     if (t == 't') {
@@ -1145,7 +1170,7 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
       return ETLG_E_BINARY_FORMAT;
     }
     acc |= st << (2 * (i & 15));
-    if ((i & 15) == 15 || i + 1 == n) { stw[i >> 4] = acc; acc = 0; }
+    if (((i & 15) == 15 || i + 1 == n) && !(pg.flags & 0x100u)) { stw[i >> 4] = acc; acc = 0; }
   }
   return 0;
 }
@@ -1321,7 +1346,9 @@ DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, c
       bool partial = false;
       const uint32_t sl_u = __builtin_amdgcn_readfirstlane((uint32_t)sl);
       const uint32_t n_u = __builtin_amdgcn_readfirstlane(m.new_n);
-      if (pu && __all(tag == 'I' && (uint32_t)sl == sl_u && m.new_n == n_u)) {
+      if (p.flags & 0x400u) { /* profiling ablation: no row decode at all */ }
+      else if (p.flags & 0x800u) { if (pu && __all(tag == 'I' && (uint32_t)sl == sl_u && m.new_n == n_u)) err = write_full_row_uniform(*pu, sl_u, m.new_t, n_u, body, hcur, over); /* ablation: uniform waves only */ }
+      else if (pu && __all(tag == 'I' && (uint32_t)sl == sl_u && m.new_n == n_u)) {
         err = write_full_row_uniform(*pu, sl_u, m.new_t, n_u, body, hcur, over);
       } else {
         const DevSlot& s = p.slots[sl];
@@ -1341,6 +1368,7 @@ DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, c
       break;
     }
   }
+  if (p.flags & 0x200u) return;  // profiling ablation (no header stores)
   p.ev_kind[ev_idx] = (u8)tag;
   p.ev_flags[ev_idx] = (u8)flags;
   p.ev_table[ev_idx] = table;

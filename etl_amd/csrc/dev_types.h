@@ -108,6 +108,8 @@ struct DecParams {
   // carried transaction state (apply.rs:942-963)
   uint32_t in_txn;
   uint32_t worker_kind, sync_table;
+  // bits 8-11 (0x100 no row stores, 0x200 no header stores, 0x400 no row decode, 0x800 uniform waves only) are
+  // profiling ablations set from ETLG_FUSED_DBG; results are wrong with any of them
   uint32_t flags;        // bit0: NO_CONTROL asserted; bit1: table-copy rows (synthetic Insert frames: no ownership
                          // check, NULL allowed in every column — table_row.rs:199-201)
   uint64_t final_lsn, next_ord;

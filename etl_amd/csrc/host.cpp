@@ -1101,6 +1101,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   p.worker_kind = (uint32_t)c->worker; p.sync_table = c->sync_table;
   p.flags = no_ctrl ? 1u : 0u;
   p.copy_slot = -1;
+  p.flags |= c->fused_dbg & 0xF00u;  // profiling ablations (results are wrong)
   if (c->copy.active) { p.flags |= 2u; p.copy_slot = c->copy.slot; b->copy = c->copy; }
   p.host_err_frame = 0xFFFFFFFFu;
 

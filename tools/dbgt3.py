@@ -14,7 +14,7 @@ for buf, offs in bufs:
     out = (C.c_ulonglong * 12)(); d.L.etlg_ctx_debug_times(d.h, out)
     paths = d.debug_paths()
     blk = 256 if paths["fused"] and os.environ.get("ETLG_FUSED_KERNEL", "0") == "0" and wl == "cfg2" else 64
-    nt = (len(offs) - 1 + blk - 1) // blk
+    nt = max(1, ((len(offs) - 1 + blk - 1) // blk) // 16)   # phase clocks are sampled: 1 tile in 16
     if paths["cells"]:
         names = ["offs", "stage", "P1 walk", "P2 heap size", "P2b sizes", "lookback", "positions", "P3 decode", "P4 finalize"]
     else:
