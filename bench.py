@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true", help="profiling ablations only")
     ap.add_argument("--no-scan-leg", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=4, help="N > 1: batches per header all-gather (their 64-byte headers travel together)")
     args = ap.parse_args()
 
     import numpy as np
@@ -57,7 +58,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # ETLG_BENCH_FORCE_GATHER=1 (with torch.distributed.run --nproc-per-node 1) runs the collective path on one GPU
+    gather = world > 1 or (os.environ.get("ETLG_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ)
+    if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -87,18 +90,36 @@ def main():
     torch.cuda.set_stream(stream)
     dec.set_stream(stream.cuda_stream)
     w.register(dec)
-    hdr = torch.zeros(8, dtype=torch.int64, device=dev)
+    # One 64-byte header slot per step. The headers of G consecutive batches travel in ONE asynchronous
+    # all-gather (G x 64 bytes per rank) that overlaps the decode of the following batches and is only
+    # waited for at the end: per-batch collectives made the host the bottleneck (≈ 22 us of c10d / RCCL
+    # enqueue per call against a ≈ 100 us kernel), and nothing consumes the global layout sooner.
+    G = max(1, args.gather_every)
+    nslots = ((args.steps + args.warmup + G - 1) // G + 1) * G
+    hdrs = torch.zeros((nslots, 8), dtype=torch.int64, device=dev)
+    gathered = torch.zeros((nslots // G, world, G * 8), dtype=torch.int64, device=dev) if gather else None
     flags = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
+    works = []
+
+    def gather_group(g):
+        works.append(dist.all_gather_into_tensor(gathered[g], hdrs[g * G:(g + 1) * G].reshape(1, -1), async_op=True))
 
     def step(k, keep):
         tb, to, nbytes, nfr = d_in[k % len(d_in)]
         b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, flags)
-        b.header_to_device(hdr.data_ptr())
-        if world > 1:
-            g = shard.all_gather_headers(hdr)
-            keep.append((b, nbytes, nfr, g))
-        else:
-            keep.append((b, nbytes, nfr, None))
+        b.header_to_device(hdrs[k].data_ptr())
+        keep.append((b, nbytes, nfr, k))
+        if gather and (k + 1) % G == 0:
+            gather_group(k // G)
+
+    def flush_gathers(k_end):
+        """Gathers the last, partial group (k_end = one past the last step issued)."""
+        if gather and k_end % G:
+            gather_group(k_end // G)
+
+    def wait_gathers():
+        while works:
+            works.pop().wait()
 
     out_bytes = [0]   # arena bytes written by the drained batches (headers + fixed + heap)
 
@@ -115,34 +136,56 @@ def main():
             b.close()
         return tot_b, tot_f
 
+    # Arena pool priming (setup, like allocating buffers): the timed loop keeps `steps` batches in flight, each
+    # holding its own output arena; the library grows that pool on demand with hipMalloc, which serialises host
+    # and device, so the pool is grown to its working size here, before warm-up, and only reused afterwards.
+    prime = [dec.decode_device(d_in[k % len(d_in)][0].data_ptr(), d_in[k % len(d_in)][2], d_in[k % len(d_in)][1].data_ptr(),
+                               d_in[k % len(d_in)][3], flags) for k in range(args.steps + 1)]
+    torch.cuda.synchronize()
+    for b in prime:
+        b.sync(); b.close()
+    del prime
+
     keep = []
     for k in range(args.warmup):
         step(k, keep)
+    flush_gathers(args.warmup)
+    wait_gathers()
     torch.cuda.synchronize()
     drain(keep, True)
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     keep = []
-    if world > 1:
+    if gather:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    k0 = ((args.warmup + G - 1) // G) * G   # the timed steps start on a group boundary
     for k in range(args.steps):
-        step(args.warmup + k, keep)
+        step(k0 + k, keep)
+    flush_gathers(k0 + args.steps)
+    ta = time.perf_counter()
+    wait_gathers()
+    tb_ = time.perf_counter()
     torch.cuda.synchronize()
-    if world > 1:
+    tc = time.perf_counter()
+    if gather:
         dist.barrier()
     t1 = time.perf_counter()
+    if os.environ.get("ETLG_BENCH_DEBUG"):
+        print(f"[bench debug] enqueue {1e3 * (ta - t0):.2f} ms, wait gathers {1e3 * (tb_ - ta):.2f} ms, sync {1e3 * (tc - tb_):.2f} ms, "
+              f"barrier {1e3 * (t1 - tc):.2f} ms", file=sys.stderr)
     elapsed = t1 - t0
-    last_gather = keep[-1][3]
+    last_k = keep[-1][3]
     my_bytes, my_frames = drain(keep, True)
-    if world > 1:
+    if gather:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         tot = torch.tensor([my_bytes, my_frames], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         all_bytes, all_frames = int(tot[0].item()), int(tot[1].item())
+        last_gather = gathered[last_k // G][:, (last_k % G) * 8:(last_k % G + 1) * 8]   # the last batch's headers, rank-major
         lay = shard.global_layout(last_gather.cpu().numpy())
         assert args.no_check or not lay["any_error"]
     else:
@@ -251,7 +294,7 @@ def main():
         }
         print(json.dumps(out))
     dec.close()
-    if world > 1:
+    if gather:
         dist.barrier()   # rank 0 runs the extra legs; everybody leaves together
         dist.destroy_process_group()
 
