@@ -75,6 +75,22 @@ DEV void record_error(const DecParams& p, uint32_t frame, uint32_t rank, uint32_
   atomicMin(&p.res->first_err, key);
 }
 
+// ------------------------------------------------------------- wave scans
+// Inclusive scan over the 64 lanes of a wave with DPP (row_shr 1/2/4/8 inside each row of 16, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU instructions, no LDS
+// crossbar round trips (a __shfl_up ladder is six dependent ds_bpermute, ~100 cycles each).
+// op(older, newer); `idn` is its left identity (lanes without a source read it).
+#define ETLG_DPP(ctrl, rmask) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)idn, (int)v, ctrl, rmask, 0xF, false); v = op(t_, v); }
+template <class F>
+DEV uint32_t wave_scan_incl(uint32_t v, F op, uint32_t idn) {
+  ETLG_DPP(0x111, 0xF) ETLG_DPP(0x112, 0xF) ETLG_DPP(0x114, 0xF) ETLG_DPP(0x118, 0xF) ETLG_DPP(0x142, 0xA) ETLG_DPP(0x143, 0xC)
+  return v;
+}
+#undef ETLG_DPP
+DEV uint32_t wave_scan_add(uint32_t v) { return wave_scan_incl(v, [](uint32_t a, uint32_t b) { return a + b; }, 0u); }
+DEV uint32_t wave_scan_max(uint32_t v) { return wave_scan_incl(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }, 0u); }
+DEV uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }  // lane 63 of an inclusive scan = the wave total
+
 // ------------------------------------------------------------- block scans
 DEV uint32_t seg_combine(uint32_t a, uint32_t b) {  // bit31 = "a Begin was seen", low bits = count since
   return (b & 0x80000000u) ? b : ((a & 0x80000000u) | ((a + b) & 0x7FFFFFFFu));
@@ -146,12 +162,7 @@ DEV uint64_t block_scan_excl64(uint64_t v, uint64_t* lds, uint64_t* total) {
 // lds: 3 * nwaves words. tot[k] = workgroup totals.
 DEV void block_scan3_excl(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t* lds, uint32_t tot[3]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
-  uint32_t ia = a, ib = b, ic = c;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64), tc = __shfl_up(ic, d, 64);
-    if (lane >= d) { ia += ta; ib += tb; ic += tc; }
-  }
+  const uint32_t ia = wave_scan_add(a), ib = wave_scan_add(b), ic = wave_scan_add(c);
   if (lane == 63) { lds[3 * wave] = ia; lds[3 * wave + 1] = ib; lds[3 * wave + 2] = ic; }
   __syncthreads();
   uint32_t pa = 0, pb = 0, pc = 0, ta = 0, tb = 0, tc = 0;
@@ -170,14 +181,10 @@ DEV void block_scan3_excl(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t* lds, 
 DEV void block_scan_txn(uint32_t cnt, uint32_t mark, uint32_t* lds, uint32_t& seg_incl, uint32_t& mark_excl,
                         uint32_t& tot_cnt, uint32_t& tot_mark) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
-  uint32_t ic = cnt, im = mark;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t tc = __shfl_up(ic, d, 64), tm = __shfl_up(im, d, 64);
-    if (lane >= d) { ic = seg_combine(tc, ic); im = tm > im ? tm : im; }
-  }
-  uint32_t pm = __shfl_up(im, 1, 64);
-  if (lane == 0) pm = 0;
+  const uint32_t ic = wave_scan_incl(cnt, [](uint32_t a, uint32_t b) { return seg_combine(a, b); }, 0u);
+  const uint32_t im = wave_scan_max(mark);
+  // exclusive running max: the previous lane's inclusive value (wave_shr:1, 0 into lane 0)
+  uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)im, 0x138, 0xF, 0xF, false);
   if (lane == 63) { lds[2 * wave] = ic; lds[2 * wave + 1] = im; }
   __syncthreads();
   uint32_t pc = 0, pmx = 0, tcn = 0, tmx = 0;

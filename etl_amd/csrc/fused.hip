@@ -107,9 +107,9 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
   block_scan3_excl(x_ev, x_fx, x_hp, s32, tot3);
   {  // payload byte counters (A3): workgroup reduce through LDS, then one atomic per tile and
      // counter into a shard (a single hot address would serialise thousands of atomics in L2)
-    uint64_t a0 = pay[0], a1 = pay[1], a2 = pay[2];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { a0 += __shfl_xor(a0, d, 64); a1 += __shfl_xor(a1, d, 64); a2 += __shfl_xor(a2, d, 64); }
+    // (a batch is < 2 GiB on this path, so every partial sum fits 32 bits)
+    const uint32_t a0 = wave_last(wave_scan_add((uint32_t)pay[0])), a1 = wave_last(wave_scan_add((uint32_t)pay[1])),
+                   a2 = wave_last(wave_scan_add((uint32_t)pay[2]));
     if ((tid & 63) == 0) {  // s64[0..3] is free here: block_scan3_excl only used s32
       if (a0) atomicAdd((unsigned long long*)&s64[0], (unsigned long long)a0);
       if (a1) atomicAdd((unsigned long long*)&s64[1], (unsigned long long)a1);

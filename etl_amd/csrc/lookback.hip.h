@@ -72,12 +72,15 @@ DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint3
   }
   // ordered fold, lower lane = older: inclusive scan then take lane j-1
   uint64_t v0 = (uint32_t)lane < j ? (uint64_t)(w0 & ~ST_MASK) : Op::id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint64_t t = __shfl_up(v0, d, 64);
-    if (lane >= d) v0 = Op::f(t, v0);
-  }
-  const uint64_t local = __shfl(v0, 63, 64);  // lanes >= j hold the identity, so lane 63 = fold of [0, j)
+  // DPP ladder (see wave_scan_incl in codec.hip.h) on the two halves of the 64-bit payload; Op::id() == 0
+#define ETLG_LB_DPP(ctrl, rmask) { \
+    const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v0, ctrl, rmask, 0xF, false); \
+    const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v0 >> 32), ctrl, rmask, 0xF, false); \
+    v0 = Op::f(((uint64_t)hi_ << 32) | lo_, v0); }
+  ETLG_LB_DPP(0x111, 0xF) ETLG_LB_DPP(0x112, 0xF) ETLG_LB_DPP(0x114, 0xF) ETLG_LB_DPP(0x118, 0xF) ETLG_LB_DPP(0x142, 0xA) ETLG_LB_DPP(0x143, 0xC)
+#undef ETLG_LB_DPP
+  const uint64_t local = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v0 >> 32), 63) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v0, 63);  // lanes >= j hold the identity, so lane 63 = fold of [0, j)
   // the last tile of a full group publishes the group aggregate
   const uint64_t group_agg = Op::f(local, agg);
   if (j == 63 && lane == 0) __hip_atomic_store(&gdesc[g], ST_AGG | group_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
