@@ -233,16 +233,11 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     TSTAMP(9);
     // wave-level transaction scan (no barrier: a tile's frames live in one wave)
     {
-      uint32_t ic = cnt, im = mark;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t tc = __shfl_up(ic, d, 64), tm = __shfl_up(im, d, 64);
-        if ((int)lane >= d) { ic = seg_combine(tc, ic); im = tm > im ? tm : im; }
-      }
-      pm = __shfl_up(im, 1, 64);
-      if (lane == 0) pm = 0;
+      const uint32_t ic = wave_scan_incl(cnt, [](uint32_t a, uint32_t b) { return seg_combine(a, b); }, 0u);
+      const uint32_t im = wave_scan_max(mark);
+      pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)im, 0x138, 0xF, 0xF, false);  // previous lane's value, 0 into lane 0
       seg_in = ic;
-      tot_cnt = __shfl(ic, 63, 64); tot_mark = __shfl(im, 63, 64);
+      tot_cnt = wave_last(ic); tot_mark = wave_last(im);
     }
   }
   const uint64_t txn_agg = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark;  // meaningful on wave 0
@@ -375,17 +370,11 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       }
     }
     // wave scan of (events, fixed dwords, heap dwords)
-    uint32_t ie = emit, ifx = fixed >> 2, ih = heap >> 2;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t te = __shfl_up(ie, d, 64), tf = __shfl_up(ifx, d, 64), th = __shfl_up(ih, d, 64);
-      if ((int)lane >= d) { ie += te; ifx += tf; ih += th; }
-    }
-    const uint32_t tot_e = __shfl(ie, 63, 64), tot_f = __shfl(ifx, 63, 64), tot_h = __shfl(ih, 63, 64);
-    // payload counters
-    uint64_t a0p = pay[0], a1p = pay[1], a2p = pay[2];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { a0p += __shfl_xor(a0p, d, 64); a1p += __shfl_xor(a1p, d, 64); a2p += __shfl_xor(a2p, d, 64); }
+    const uint32_t ie = wave_scan_add(emit), ifx = wave_scan_add(fixed >> 2), ih = wave_scan_add(heap >> 2);
+    const uint32_t tot_e = wave_last(ie), tot_f = wave_last(ifx), tot_h = wave_last(ih);
+    // payload counters (a batch is < 2 GiB on this path: 32-bit partial sums)
+    const uint32_t a0p = wave_last(wave_scan_add((uint32_t)pay[0])), a1p = wave_last(wave_scan_add((uint32_t)pay[1])),
+                   a2p = wave_last(wave_scan_add((uint32_t)pay[2]));
     if (lane == 0) {
       if (a0p) atomicAdd(&pg.res->pay_shard[tile & 31][0], (unsigned long long)a0p);
       if (a1p) atomicAdd(&pg.res->pay_shard[tile & 31][1], (unsigned long long)a1p);

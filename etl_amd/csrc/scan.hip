@@ -195,33 +195,23 @@ __global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
   // ---- stitch the lanes. The chain passes through every guessing lane from the entry lane on iff each
   //      of them starts exactly where the furthest walk before it ended (walks of on-chain lanes end
   //      further and further), and every lane without a guess lies under a frame. One prefix-max scan.
-  uint32_t n = 0, e = 0;
+  uint32_t n = 0, e = 0, inc = 0;
   bool stitched = has;
   bool mine = false;  // this lane's walk is part of the tile's chain
   if (has) {
     const uint32_t c0 = (entry - lo) / SUB;
     mine = lane >= c0 && s_l != NO_ENTRY;
-    uint32_t mx = mine ? e_l : 0u;  // inclusive prefix max of the exits
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(mx, d, 64); if ((int)lane >= d && t > mx) mx = t; }
-    uint32_t before = __shfl_up(mx, 1, 64);  // furthest exit of the lanes before this one
-    if (lane == 0) before = 0;
+    const uint32_t mx = wave_scan_max(mine ? e_l : 0u);  // inclusive prefix max of the exits
+    const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x138, 0xF, 0xF, false);  // furthest exit of the lanes before this one
     bool good = true;
     if (lane > c0 && a < hi) good = mine ? before == s_l : before >= a_end;
     stitched = __ballot(!good) == 0;
-    e = (uint32_t)__shfl(mx, 63, 64);
-    uint32_t tot = mine ? n_l : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
-    n = tot;
+    e = wave_last(mx);
+    inc = wave_scan_add(mine ? n_l : 0u);  // inclusive prefix of the on-chain lanes' frame counts
+    n = wave_last(inc);
   }
   STAMP(3);
-  uint32_t inc = 0;  // inclusive prefix of the on-chain lanes' frame counts
-  if (has && stitched) {
-    inc = mine ? n_l : 0u;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += t; }
-  } else if (has) {
+  if (has && !stitched) {
     // the lanes do not agree (bytes that mimic a frame inside a value, a malformed header ...): one lane
     // walks the tile; it walks again below to write the offsets once their base index is known
     if (lane == 0) walk(st, nullptr, lo, hi, q.len, entry, n, e);
