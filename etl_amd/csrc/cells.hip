@@ -244,19 +244,20 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   const uint64_t txn_carry = (uint64_t)(pg.in_txn ? 1u : 0u);
   TxnCtx tx{true, 0, 0};
   uint32_t bc = 0, bm = 0;
-  auto make_tx = [&](uint32_t c_in, uint32_t m_in) {
+  auto make_tx = [&](uint32_t c_in, uint32_t m_in, uint64_t carried_lsn) {
     bc = c_in; bm = m_in;
     const uint32_t seg = seg_combine(bc, seg_in);
     const uint32_t last = bm > pm ? bm : pm;
     tx.in_txn = (last & 1u) != 0;
-    tx.final_lsn = tx.in_txn ? final_lsn_of_mark(pg, last) : 0;
+    // carried-in Begin: fetched by the wave that ran the transaction look-back; a Begin of this tile: read in place
+    tx.final_lsn = !tx.in_txn ? 0 : last == bm ? carried_lsn : ld_be64(base + (((last >> 1) - 1) - b0) + kBodyOff);
     const uint64_t c = seg & 0x7FFFFFFFu;
     tx.ord = (seg & 0x80000000u) ? c - 1 : pg.next_ord + c - 1;
   };
   if (wave == 0) {
     if (q.seq_lookback) {
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      make_tx(seg_unpack30((uint32_t)(ex >> 32)), (uint32_t)ex);  // look-back results are wave-uniform
+      make_tx(seg_unpack30((uint32_t)(ex >> 32)), (uint32_t)ex, ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0);  // look-back results are wave-uniform
     }
     TSTAMP(10);
     if (live && too_wide) atomicOr(fail, 4u);
@@ -391,13 +392,13 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   if (wave == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
   if (wave == 2 % NW && NW > 2 && !q.seq_lookback) {
     const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
-    if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+    if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
   }
   if (NW <= 2 && wave == 0) {
     if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
     if (!q.seq_lookback) {
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
-      if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; }
+      if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
     }
   }
   __syncthreads();
@@ -406,7 +407,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   uint64_t ev_idx = 0, fx_off = 0, hp_off = 0;
   if (wave == 0) {
     if (!q.seq_lookback) {
-      make_tx(s32[12], s32[13]);
+      make_tx(s32[12], s32[13], s64[6]);
       if (live && wire_ok) txn_check_frame(pg, v, tx);
     }
     ev_idx = pre_ev + x_ev;
@@ -614,20 +615,13 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
   const uint32_t tile = blockIdx.x;
   const uint32_t f0 = tile * CF;
   uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
-  for (uint32_t i = tid; i <= nt; i += NW * 64) s_offs[i] = pg.offs[f0 + i];
-  __syncthreads();
-  TSTAMP(0);
-  const uint32_t span0 = s_offs[0], span1 = s_offs[nt];
-  bool lane_ok = true;
-  if (tid < nt) {
-    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
-    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
-  }
+  // the tile's byte span from two scalar loads: staging starts while the per-frame offsets are in flight
+  const uint32_t span0 = pg.offs[f0], span1 = pg.offs[f0 + nt];
+  const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
                          (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
-  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
-  if (use_lds) {
+  if (window_ok) {
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
     for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * NW * 64) {
       const uint32_t c1 = c + 16 * NW * 64, c2 = c + 32 * NW * 64, c3 = c + 48 * NW * 64;
@@ -642,7 +636,15 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
     }
     for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
   }
+  if (tid <= nt) s_offs[tid] = my_o;  // CF + 1 <= NW * 64 entries
   __syncthreads();
+  TSTAMP(0);
+  bool lane_ok = true;
+  if (tid < nt) {
+    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
+    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
+  }
+  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
   TSTAMP(1);
   const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_st, fr_err, fr_toast, s32, s64, ct_pl, ct_h};
   // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
