@@ -1,0 +1,15 @@
+"""The device's float4 / float8 text parser (etl_amd/csrc/float_fast.h: exact fast path + deferral rule)
+against glibc strtod / strtof on 6 million texts, through a host build of the same header."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_float_fast_path_matches_strtod(tmp_path):
+    exe = str(tmp_path / "float_fast_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "etl_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "float_fast_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "mismatches 0" in out.stdout
