@@ -285,7 +285,7 @@ def main():
             "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "events_per_s": round(all_frames / elapsed, 1),
-            "hbm_read_frac": round(value / HBM_PEAK_GBPS, 5),
+            "hbm_read_frac": round(value / (HBM_PEAK_GBPS * world), 5),   # input bytes/s per GPU over the 8 TB/s spec
             "config": {"workload": f"{w.name}: {args.batch_mib} MiB batches of CopyData-framed pgoutput, "
                                    "device-resident in / device-resident out, offsets sidecar, NO_CONTROL",
                        "batch_bytes": int(my_bytes / args.steps), "frames_per_batch": int(my_frames / args.steps),
