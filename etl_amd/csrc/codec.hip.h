@@ -352,13 +352,14 @@ struct CellIt {
 // core::str::from_utf8 (strict RFC 3629), call site codec/event.rs:976.
 __device__ __attribute__((noinline)) bool utf8_valid(const u8* s, uint32_t n) {
   uint32_t i = 0;
-  // ASCII fast path, 8 bytes at a time
-  while (i + 8 <= n) {
-    uint64_t w; __builtin_memcpy(&w, s + i, 8);
-    if (w & 0x8080808080808080ull) break;
-    i += 8;
-  }
   while (i < n) {
+    // ASCII runs, 8 bytes at a time (re-entered after every multi-byte character)
+    while (i + 8 <= n) {
+      uint64_t w; __builtin_memcpy(&w, s + i, 8);
+      if (w & 0x8080808080808080ull) break;
+      i += 8;
+    }
+    if (i >= n) break;
     const uint32_t c = s[i];
     if (c < 0x80) { i++; continue; }
     if (c >= 0xC2 && c <= 0xDF) {

@@ -66,6 +66,20 @@ DEV void copy_row(const CopyParams& q, uint32_t r, const u8* row, uint32_t n, u8
       u8* w = o + 5;
       bool ended = false;
       while (pos < n) {
+        if (pos + 8 <= n) {  // eight bytes at a time while there is no tab, newline or backslash among them
+          uint64_t x; __builtin_memcpy(&x, row + pos, 8);
+          auto has = [](uint64_t v, uint64_t c) { const uint64_t t = v ^ (c * 0x0101010101010101ull); return (t - 0x0101010101010101ull) & ~t & 0x8080808080808080ull; };
+          const uint64_t m = has(x, '\t') | has(x, '\n') | has(x, '\\');
+          if (!m) {
+            if (keep) { __builtin_memcpy(w, &x, 8); w += 8; }
+            pos += 8;
+            continue;
+          }
+          const uint32_t k = (uint32_t)__builtin_ctzll(m) >> 3;  // clean bytes before the first special one (exact for the lowest match)
+          if (keep) for (uint32_t j = 0; j < k; j++) w[j] = (u8)(x >> (8 * j));
+          if (keep) w += k;
+          pos += k;
+        }
         const uint32_t c = row[pos];
         if (c == '\t') { pos++; ended = true; break; }
         if (c == '\n') { pos++; ended = true; terminated = true; break; }
