@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <set>
 #include <memory>
 #include <set>
 #include <string>
@@ -240,6 +242,7 @@ struct etlg_ctx {
   std::vector<OutSet*> out_pool;
   DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
   std::vector<DevResult*> res_pool;         // pinned result blocks (one per in-flight batch)
+  std::vector<std::pair<uint8_t*, size_t>> harena_pool;  // pinned host arenas, reused by size
   // error
   etlg_error err{};
   std::string err_detail;
@@ -254,9 +257,8 @@ struct etlg_batch {
   etlg_ctx* ctx = nullptr;
   etlg_batch_view v{};
   OutSet* dev = nullptr;  // owned device arrays (OUTPUT_ON_DEVICE) — returned to the pool on free
-  std::vector<uint8_t> kind, flags, fixed, heap;
-  std::vector<uint32_t> table, slot;
-  std::vector<uint64_t> start, commit, ord, body;
+  // host copy of the arena (etlg_batch_download / host-output decode): one pinned block from the context's pool
+  uint8_t* h_arena = nullptr; size_t h_arena_cap = 0;
   std::vector<etlg_slot_desc> slot_descs;
   bool pending = false;  // ASYNC: counts not read back yet
   DevResult* h_res = nullptr;  // pinned, from the context's pool
@@ -762,6 +764,12 @@ int32_t download_batch(etlg_ctx* c, etlg_batch* b);
 
 }  // namespace
 
+// Live contexts: a batch may be freed after its context (garbage-collected bindings do that), in which case
+// it must not touch the context's pools.
+static std::mutex g_live_mu;
+static std::set<const etlg_ctx*> g_live_ctx;
+static bool ctx_alive(const etlg_ctx* c) { std::lock_guard<std::mutex> l(g_live_mu); return g_live_ctx.count(c) != 0; }
+
 // ====================================================================== C API
 extern "C" {
 
@@ -810,11 +818,14 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
   if (const char* fb = getenv("ETLG_FUSED_BLK")) { const int v = atoi(fb); if (v == 64) c->fused_kernel = 1; else if (v == 256) c->fused_kernel = 0; }
   clear_error(c);
+  { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.insert(c); }
   *out = c;
   return ETLG_OK;
 }
 
 void etlg_ctx_destroy(etlg_ctx* c) {
+  if (!c) return;
+  { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.erase(c); }
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -822,6 +833,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& pr : c->harena_pool) (void)hipHostFree(pr.first);
   if (c->h_init) (void)hipHostFree(c->h_init);
   if (c->h_init_ring) (void)hipHostFree(c->h_init_ring);
   for (DevResult* r : c->res_pool) (void)hipHostFree(r);
@@ -1322,9 +1334,15 @@ int32_t etlg_batch_view_get(const etlg_batch* b, etlg_batch_view* out) {
 
 void etlg_batch_free(etlg_batch* b) {
   if (!b) return;
-  if (b->pending || b->h_res) (void)hipStreamSynchronize(b->ctx->stream);
-  if (b->dev) b->ctx->out_pool.push_back(b->dev);
-  if (b->h_res) b->ctx->res_pool.push_back(b->h_res);
+  if (ctx_alive(b->ctx)) {
+    if (b->pending || b->h_res) (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->dev) b->ctx->out_pool.push_back(b->dev);
+    if (b->h_res) b->ctx->res_pool.push_back(b->h_res);
+    if (b->h_arena) b->ctx->harena_pool.emplace_back(b->h_arena, b->h_arena_cap);
+  } else {  // the context is gone: its device buffers went with it; only what the batch owns outright is released
+    if (b->h_res) (void)hipHostFree(b->h_res);
+    if (b->h_arena) (void)hipHostFree(b->h_arena);
+  }
   delete b;
 }
 
@@ -1339,28 +1357,47 @@ int32_t download_batch(etlg_ctx* c, etlg_batch* b) {
   hipStream_t s = c->stream;
   etlg_batch_view& v = b->v;
   const size_t n = (size_t)v.n_events;
-  b->kind.resize(n); b->flags.resize(n); b->table.resize(n); b->slot.resize(n);
-  b->start.resize(n); b->commit.resize(n); b->ord.resize(n); b->body.resize(n);
-  b->fixed.resize((size_t)v.fixed_bytes); b->heap.resize((size_t)v.heap_bytes);
-  if (n) {
-    HIPCHK(c, hipMemcpyAsync(b->kind.data(), os->kind.p, n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(b->flags.data(), os->flags.p, n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(b->table.data(), os->table.p, n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(b->slot.data(), os->slot.p, n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(b->start.data(), os->start.p, n * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(b->commit.data(), os->commit.p, n * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(b->ord.data(), os->ord.p, n * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(b->body.data(), os->body.p, n * 8, hipMemcpyDeviceToHost, s));
+  // layout of the pinned block: 8-byte arrays first, then 4-byte, then bytes (every part 64-byte aligned)
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t o_start = 0, o_commit = o_start + al(n * 8), o_ord = o_commit + al(n * 8), o_body = o_ord + al(n * 8);
+  const size_t o_table = o_body + al(n * 8), o_slot = o_table + al(n * 4), o_kind = o_slot + al(n * 4), o_flags = o_kind + al(n);
+  const size_t o_fixed = o_flags + al(n), o_heap = o_fixed + al((size_t)v.fixed_bytes), total = o_heap + al((size_t)v.heap_bytes) + 64;
+  if (b->h_arena_cap < total) {
+    if (b->h_arena) { c->harena_pool.emplace_back(b->h_arena, b->h_arena_cap); b->h_arena = nullptr; b->h_arena_cap = 0; }
+    // smallest pooled block that fits, else a new one (rounded up so that similar batches can share it)
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < c->harena_pool.size(); i++)
+      if (c->harena_pool[i].second >= total && (best == (size_t)-1 || c->harena_pool[i].second < c->harena_pool[best].second)) best = i;
+    if (best != (size_t)-1) {
+      b->h_arena = c->harena_pool[best].first; b->h_arena_cap = c->harena_pool[best].second;
+      c->harena_pool.erase(c->harena_pool.begin() + (long)best);
+    } else {
+      const size_t cap = (total + (total >> 2) + 4095) & ~(size_t)4095;
+      HIPCHK(c, hipHostMalloc((void**)&b->h_arena, cap, hipHostMallocDefault));
+      b->h_arena_cap = cap;
+    }
   }
-  if (v.fixed_bytes) HIPCHK(c, hipMemcpyAsync(b->fixed.data(), os->fixed.p, (size_t)v.fixed_bytes, hipMemcpyDeviceToHost, s));
-  if (v.heap_bytes) HIPCHK(c, hipMemcpyAsync(b->heap.data(), os->heap.p, (size_t)v.heap_bytes, hipMemcpyDeviceToHost, s));
+  uint8_t* h = b->h_arena;
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(h + o_kind, os->kind.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h + o_flags, os->flags.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h + o_table, os->table.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h + o_slot, os->slot.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h + o_start, os->start.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h + o_commit, os->commit.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h + o_ord, os->ord.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h + o_body, os->body.p, n * 8, hipMemcpyDeviceToHost, s));
+  }
+  if (v.fixed_bytes) HIPCHK(c, hipMemcpyAsync(h + o_fixed, os->fixed.p, (size_t)v.fixed_bytes, hipMemcpyDeviceToHost, s));
+  if (v.heap_bytes) HIPCHK(c, hipMemcpyAsync(h + o_heap, os->heap.p, (size_t)v.heap_bytes, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   c->out_pool.push_back(os);
   b->dev = nullptr;
   v.on_device = 0;
-  v.ev_kind = b->kind.data(); v.ev_flags = b->flags.data(); v.ev_table_id = b->table.data(); v.ev_schema_slot = b->slot.data();
-  v.ev_start_lsn = b->start.data(); v.ev_commit_lsn = b->commit.data(); v.ev_tx_ordinal = b->ord.data(); v.ev_body_off = b->body.data();
-  v.fixed = b->fixed.data(); v.heap = b->heap.data();
+  v.ev_kind = h + o_kind; v.ev_flags = h + o_flags; v.ev_table_id = (const uint32_t*)(h + o_table); v.ev_schema_slot = (const uint32_t*)(h + o_slot);
+  v.ev_start_lsn = (const uint64_t*)(h + o_start); v.ev_commit_lsn = (const uint64_t*)(h + o_commit);
+  v.ev_tx_ordinal = (const uint64_t*)(h + o_ord); v.ev_body_off = (const uint64_t*)(h + o_body);
+  v.fixed = h + o_fixed; v.heap = h + o_heap;
   return ETLG_OK;
 }
 
