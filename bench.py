@@ -90,36 +90,29 @@ def main():
     torch.cuda.set_stream(stream)
     dec.set_stream(stream.cuda_stream)
     w.register(dec)
-    # One 64-byte header slot per step. The headers of G consecutive batches travel in ONE asynchronous
-    # all-gather (G x 64 bytes per rank) that overlaps the decode of the following batches and is only
-    # waited for at the end: per-batch collectives made the host the bottleneck (≈ 22 us of c10d / RCCL
-    # enqueue per call against a ≈ 100 us kernel), and nothing consumes the global layout sooner.
+    # One 64-byte header slot per step; with N > 1 the headers of G consecutive batches travel in ONE
+    # asynchronous all-gather that overlaps the following decodes (etl_amd/shard.py: HeaderGatherer).
     G = max(1, args.gather_every)
-    nslots = ((args.steps + args.warmup + G - 1) // G + 1) * G
-    hdrs = torch.zeros((nslots, 8), dtype=torch.int64, device=dev)
-    gathered = torch.zeros((nslots // G, world, G * 8), dtype=torch.int64, device=dev) if gather else None
+    nbatches = ((args.warmup + G - 1) // G) * G + args.steps
+    hg = shard.HeaderGatherer(nbatches, G, dev, world=world) if gather else None
+    hdrs = hg.headers if gather else torch.zeros((nbatches + G, 8), dtype=torch.int64, device=dev)
     flags = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
-    works = []
-
-    def gather_group(g):
-        works.append(dist.all_gather_into_tensor(gathered[g], hdrs[g * G:(g + 1) * G].reshape(1, -1), async_op=True))
 
     def step(k, keep):
         tb, to, nbytes, nfr = d_in[k % len(d_in)]
         b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, flags)
         b.header_to_device(hdrs[k].data_ptr())
         keep.append((b, nbytes, nfr, k))
-        if gather and (k + 1) % G == 0:
-            gather_group(k // G)
+        if gather:
+            hg.batch_done(k)
 
     def flush_gathers(k_end):
-        """Gathers the last, partial group (k_end = one past the last step issued)."""
-        if gather and k_end % G:
-            gather_group(k_end // G)
+        if gather:
+            hg.flush(k_end)
 
     def wait_gathers():
-        while works:
-            works.pop().wait()
+        if gather:
+            hg.wait()
 
     out_bytes = [0]   # arena bytes written by the drained batches (headers + fixed + heap)
 
@@ -185,8 +178,7 @@ def main():
         tot = torch.tensor([my_bytes, my_frames], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         all_bytes, all_frames = int(tot[0].item()), int(tot[1].item())
-        last_gather = gathered[last_k // G][:, (last_k % G) * 8:(last_k % G + 1) * 8]   # the last batch's headers, rank-major
-        lay = shard.global_layout(last_gather.cpu().numpy())
+        lay = shard.global_layout(hg.headers_of(last_k).cpu().numpy())   # the last batch's headers, rank-major
         assert args.no_check or not lay["any_error"]
     else:
         all_bytes, all_frames = my_bytes, my_frames

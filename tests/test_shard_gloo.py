@@ -61,6 +61,15 @@ def _worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, f"lay{rank}.npy"),
             np.array([lay["total_events"], lay["total_fixed"], lay["total_heap"], lay["total_frames"],
                       int(lay["event_offsets"][rank]), int(lay["fixed_offsets"][rank]), int(lay["any_error"])]))
+    # the grouped, asynchronous variant bench.py uses: 7 batches, 3 headers per collective (last group partial)
+    hg = shard.HeaderGatherer(7, 3, "cpu")
+    for k in range(7):
+        hg.slot(k).copy_(torch.from_numpy(shard.make_header(n_events=10 * k + rank, fixed_bytes=k, heap_bytes=rank, n_frames=10 * k + rank)))
+        hg.batch_done(k)
+    hg.flush(7)
+    hg.wait()
+    rows = np.stack([hg.headers_of(k).numpy() for k in range(7)])   # [batch, rank, 8]
+    np.save(os.path.join(out_dir, f"grp{rank}.npy"), rows)
     dist.destroy_process_group()
 
 
@@ -73,3 +82,9 @@ def test_header_all_gather_world2_gloo(tmp_path):
     assert list(l0[:4]) == list(l1[:4]) == [2001, 24 * 2001, 4, 2001]
     assert (l0[4], l0[5]) == (0, 0) and (l1[4], l1[5]) == (1000, 24000)  # rank order == LSN order
     assert l0[6] == 0 and l1[6] == 0
+    # grouped asynchronous gather: every rank sees every rank's header of every batch, in rank order
+    g0, g1 = np.load(tmp_path / "grp0.npy"), np.load(tmp_path / "grp1.npy")
+    assert np.array_equal(g0, g1) and g0.shape == (7, 2, 8)
+    for k in range(7):
+        for r in range(2):
+            assert list(g0[k, r, [1, 2, 3, 7]]) == [10 * k + r, k, r, 10 * k + r]
