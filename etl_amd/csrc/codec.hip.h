@@ -270,7 +270,7 @@ DEV const DevEpoch* epoch_at(const DecParams& p, int ti, uint32_t f) {
 // ---------------------------------------------------------- message shapes
 // Tuple := i16 ncols, ncols x { 'n' | 'u' | 't' i32 len bytes | 'b' i32 len bytes }
 // Structural walk: bounds, tags, value bytes (calculate_tuple_bytes, codec/event.rs:261-271).
-DEV bool walk_tuple(const u8*& c, const u8* e, uint32_t& ncols, uint32_t& vbytes) {
+DEV bool walk_tuple(const u8*& c, const u8* e, uint32_t& ncols, uint32_t& vbytes, bool over = false) {
   if (e - c < 2) return false;
   const uint32_t n = ld_be16(c);
   c += 2;
@@ -278,11 +278,15 @@ DEV bool walk_tuple(const u8*& c, const u8* e, uint32_t& ncols, uint32_t& vbytes
   ncols = n;
   for (uint32_t i = 0; i < n; i++) {
     if (c >= e) return false;
-    const uint32_t t = *c++;
+    // cell tag and length in one load where the bytes may be over-read (LDS-staged tiles)
+    uint64_t head = 0;
+    if (over) __builtin_memcpy(&head, c, 8);
+    const uint32_t t = over ? (uint32_t)head & 0xFFu : (uint32_t)*c;
+    c++;
     if (t == 'n' || t == 'u') continue;
     if (t != 't' && t != 'b') return false;
     if (e - c < 4) return false;
-    const uint32_t len = ld_be32(c);
+    const uint32_t len = over ? __builtin_bswap32((uint32_t)(head >> 8)) : ld_be32(c);
     c += 4;
     if ((len & 0x80000000u) || (uint64_t)(e - c) < len) return false;
     vbytes += len;
@@ -301,7 +305,7 @@ struct RowMsg {
 };
 
 // I := u32 rel 'N' Tuple ; U := u32 rel ['K'|'O' Tuple] 'N' Tuple ; D := u32 rel ('K'|'O') Tuple
-DEV bool parse_row_msg(uint32_t tag, const u8* b, const u8* e, RowMsg& m) {
+DEV bool parse_row_msg(uint32_t tag, const u8* b, const u8* e, RowMsg& m, bool over = false) {
   if (e - b < 5) return false;
   m.rel_id = ld_be32(b);
   const u8* c = b + 4;
@@ -310,25 +314,25 @@ DEV bool parse_row_msg(uint32_t tag, const u8* b, const u8* e, RowMsg& m) {
   if (tag == 'I') {
     if (t != 'N') return false;
     m.new_t = c;
-    return walk_tuple(c, e, m.new_n, m.vbytes);
+    return walk_tuple(c, e, m.new_n, m.vbytes, over);
   }
   if (tag == 'U') {
     if (t == 'K' || t == 'O') {
       m.old_kind = t == 'K' ? ETLG_OLD_KEY : ETLG_OLD_FULL;
       m.old_t = c;
-      if (!walk_tuple(c, e, m.old_n, m.vbytes)) return false;
+      if (!walk_tuple(c, e, m.old_n, m.vbytes, over)) return false;
       if (c >= e) return false;
       t = *c++;
     }
     if (t != 'N') return false;
     m.new_t = c;
-    return walk_tuple(c, e, m.new_n, m.vbytes);
+    return walk_tuple(c, e, m.new_n, m.vbytes, over);
   }
   // 'D'
   if (t != 'K' && t != 'O') return false;
   m.old_kind = t == 'K' ? ETLG_OLD_KEY : ETLG_OLD_FULL;
   m.old_t = c;
-  return walk_tuple(c, e, m.old_n, m.vbytes);
+  return walk_tuple(c, e, m.old_n, m.vbytes, over);
 }
 
 DEV bool has_cstr(const u8*& c, const u8* e) {
@@ -1070,10 +1074,13 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
     const uint32_t cls = col.cls;
     uint32_t dummy[4];
     uint32_t* slot = (pg.flags & 0x100u) ? dummy : (uint32_t*)(row + col.off_full);  // 0x100: profiling ablation (no row stores)
-    const uint32_t t = *c++;
+    uint64_t head = 0;
+    if (over) __builtin_memcpy(&head, c, 8);  // tag + length in one load
+    const uint32_t t = over ? (uint32_t)head & 0xFFu : (uint32_t)*c;
+    c++;
     uint32_t st = ETLG_CELL_NULL;
     if (t == 't') {
-      const uint32_t len = ld_be32(c);
+      const uint32_t len = over ? __builtin_bswap32((uint32_t)(head >> 8)) : ld_be32(c);
       c += 4;
       const uint32_t err = decode_text_cell(cls, c, len, slot, pg.heap, hcur, st, over);
       if (err) return err;
@@ -1109,7 +1116,7 @@ struct FrameView {
 
 // Structural validation of the whole message (what the third-party parser does
 // before the reference sees it). For I/U/D fills `m`. Returns false on a wire error.
-DEV bool frame_structure(const FrameView& v, RowMsg& m) {
+DEV bool frame_structure(const FrameView& v, RowMsg& m, bool over = false) {
   const u8* b = v.fr + kBodyOff;
   const u8* e = v.e;
   switch (v.tag) {
@@ -1117,7 +1124,7 @@ DEV bool frame_structure(const FrameView& v, RowMsg& m) {
     case 'O': { const u8* c = b + 8; return e - b >= 9 && has_cstr(c, e); }              // u64 lsn, cstr name
     case 'Y': { const u8* c = b + 4; return e - b >= 6 && has_cstr(c, e) && has_cstr(c, e); }  // u32 oid, cstr, cstr
     case 'R': return e - b >= 4;  // the rest of R is validated by the host control plane
-    case 'I': case 'U': case 'D': return parse_row_msg(v.tag, b, e, m);
+    case 'I': case 'U': case 'D': return parse_row_msg(v.tag, b, e, m, over);
     case 'T': {  // i32 nrel, i8 options, nrel x u32
       if (e - b < 5) return false;
       const uint32_t nrel = ld_be32(b);

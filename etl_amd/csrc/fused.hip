@@ -60,7 +60,7 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
       v.e = base + (o1 - win0);
       v.tag = classify_ptr(v.fr, o1 - o0);
     }
-    wire_ok = frame_structure(v, m);
+    wire_ok = frame_structure(v, m, STAGED);
   }
   TSTAMP(2);
   uint32_t cnt = 0, mark = 0;

@@ -54,7 +54,7 @@ DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint3
   // the first window of group descriptors is requested now, so that its round trip overlaps window 0's
   unsigned long long w1_pre = 0;
   {
-    const int64_t idx = (int64_t)g - 1 - lane;
+    const int64_t idx = (int64_t)g - 1 - 63 + lane;  // same lane mapping as window 1 below
     if (idx >= 0) w1_pre = __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   bool pre_valid = true;
@@ -84,34 +84,38 @@ DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint3
   // the last tile of a full group publishes the group aggregate
   const uint64_t group_agg = Op::f(local, agg);
   if (j == 63 && lane == 0) __hip_atomic_store(&gdesc[g], ST_AGG | group_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- window(s) 1: group descriptors before g (lane l <-> group base - l), virtual group -1 = the carry
+  // ---- window(s) 1: group descriptors before g, 64 at a time, OLDER groups in LOWER lanes (lane 63 <-> group
+  //      `base`, lane l <-> group base - 63 + l), virtual group -1 = the carry. The fold runs from the newest
+  //      inclusive descriptor of the window to lane 63 with the same DPP ladder as above.
   uint64_t acc = Op::id();
   int64_t base = (int64_t)g - 1;
   for (;;) {
-    const int64_t idx = base - lane;
+    const int64_t idx = base - 63 + lane;
     unsigned long long w = ST_INCL | carry;
-    if (idx >= 0) w = pre_valid ? w1_pre : __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (idx >= 0) w = (pre_valid && idx == (int64_t)g - 1 - (63 - lane)) ? w1_pre : __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (idx < -1) w = ST_INCL | Op::id();
     pre_valid = false;
     const unsigned long long st = w & ST_MASK;
     const unsigned long long m_incl = __ballot(st == ST_INCL);
     const unsigned long long m_empty = __ballot(st == 0);
-    const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
-    const unsigned long long needed = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1);
+    const int first_incl = m_incl ? 63 - __builtin_clzll(m_incl) : -1;  // the newest inclusive descriptor of the window
+    const unsigned long long needed = first_incl <= 0 ? ~0ull : (~0ull << first_incl);
     if (m_empty & needed) {
       if (++polls > kMaxPolls) { if (lane == 0) atomicOr(fail, 1u); return Op::id(); }
       __builtin_amdgcn_s_sleep(2);
       continue;
     }
-    const int last = first_incl < 64 ? first_incl : 63;
-    uint64_t v = lane <= last ? (uint64_t)(w & ~ST_MASK) : Op::id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {  // higher lane = older group: older ⊕ newer
-      const uint64_t t = __shfl_down(v, d, 64);
-      if (lane + d < 64) v = Op::f(t, v);
-    }
-    acc = Op::f(__shfl(v, 0, 64), acc);
-    if (first_incl < 64) break;
+    uint64_t v = lane >= (first_incl < 0 ? 0 : first_incl) ? (uint64_t)(w & ~ST_MASK) : Op::id();
+#define ETLG_LB_DPP(ctrl, rmask) { \
+    const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, rmask, 0xF, false); \
+    const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, rmask, 0xF, false); \
+    v = Op::f(((uint64_t)hi_ << 32) | lo_, v); }
+    ETLG_LB_DPP(0x111, 0xF) ETLG_LB_DPP(0x112, 0xF) ETLG_LB_DPP(0x114, 0xF) ETLG_LB_DPP(0x118, 0xF) ETLG_LB_DPP(0x142, 0xA) ETLG_LB_DPP(0x143, 0xC)
+#undef ETLG_LB_DPP
+    const uint64_t wfold = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    acc = Op::f(wfold, acc);
+    if (first_incl >= 0) break;
     base -= 64;
   }
   if (j == 63 && lane == 0) __hip_atomic_store(&gdesc[g], ST_INCL | Op::f(acc, group_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
