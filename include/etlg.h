@@ -252,8 +252,11 @@ enum {
   ETLG_F_OUTPUT_ON_DEVICE = 1u << 1, /* do not copy the arenas to the host; view holds device pointers */
   ETLG_F_NO_CONTROL = 1u << 2,       /* caller asserts: no R/M/T frame in this batch (skips the
                                         control-plane round trip; verified on device) */
-  ETLG_F_ASYNC = 1u << 3             /* with OUTPUT_ON_DEVICE: enqueue only, do not synchronize;
-                                        counts become valid after etlg_batch_sync */
+  ETLG_F_ASYNC = 1u << 3             /* with OUTPUT_ON_DEVICE | NO_CONTROL: enqueue only, do not synchronize;
+                                        counts become valid after etlg_batch_sync. Sync batches in issue
+                                        order and keep fewer than 32 of them in flight per context (their
+                                        result blocks live in a ring of 32; a batch that reports an error is
+                                        decoded again, on the exact-error path, when it is synced) */
 };
 
 /* buf = `nframes` concatenated CopyData frames exactly as on the socket:
