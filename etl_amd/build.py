@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libetl_gfx950.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "scan.hip", "copy.hip", "host.cpp"]
-DEPS = SOURCES + ["dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", os.path.join("..", "..", "include", "etlg.h")]
+DEPS = SOURCES + ["dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
 
 
 def _stale(target, deps):

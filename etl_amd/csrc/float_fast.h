@@ -4,14 +4,75 @@
 #pragma once
 #include <stdint.h>
 #if defined(__HIPCC__)
-#define ETLG_HD __host__ __device__ __forceinline__
+#define ETLG_FD __device__ __forceinline__
+#define ETLG_TABLE __device__ const
 #else
-#define ETLG_HD static inline
+#define ETLG_FD static inline
+#define ETLG_TABLE static const
 #endif
+#include "pow5_table.h"
 
 namespace etlg {
 
-ETLG_HD uint32_t flt_lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
+ETLG_FD uint32_t flt_lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
+
+// ---- Eisel-Lemire (D. Lemire, "Number parsing at a gigabyte per second", SPE 2021; the algorithm Rust's
+// dec2flt runs after its own fast path): w * 10^q -> the correctly rounded binary float from ONE 64 x 128-bit
+// multiplication by a truncated power of five, or "inconclusive" (then the text is DEFERRED).
+struct FltFormat { int mant_bits, min_exp, inf_power, rte_min, rte_max, smallest_p10, largest_p10; };
+ETLG_FD FltFormat flt_format(bool is32) {
+  return is32 ? FltFormat{23, -127, 0xFF, -17, 10, -64, 38} : FltFormat{52, -1023, 0x7FF, -4, 23, -342, 308};
+}
+ETLG_FD void mul64x64(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
+  const uint64_t a0 = (uint32_t)a, a1 = a >> 32, b0 = (uint32_t)b, b1 = b >> 32;
+  const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+  const uint64_t mid = (p00 >> 32) + (uint32_t)p01 + (uint32_t)p10;
+  lo = (mid << 32) | (uint32_t)p00;
+  hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+// Returns 0 and (mantissa without the hidden bit, biased exponent), or 1 when the product is inconclusive.
+ETLG_FD int eisel_lemire(int64_t q, uint64_t w, bool is32, uint64_t& mant, int32_t& pw2) {
+  const FltFormat F = flt_format(is32);
+  mant = 0; pw2 = 0;
+  if (w == 0 || q < F.smallest_p10) return 0;                    // underflows to zero
+  if (q > F.largest_p10) { pw2 = F.inf_power; return 0; }        // overflows to infinity
+  const int lz = __builtin_clzll(w);
+  w <<= lz;
+  // compute_product_approx: w * (high word of 5^q), refined with the low word when the upper bits are all ones
+  const int precision = F.mant_bits + 3;
+  const uint64_t mask = ~0ull >> precision;
+  const uint64_t p5hi = kPow5[q - kPow5Smallest][0], p5lo = kPow5[q - kPow5Smallest][1];
+  uint64_t lo, hi;
+  mul64x64(w, p5hi, lo, hi);
+  if ((hi & mask) == mask) {
+    uint64_t lo2, hi2;
+    mul64x64(w, p5lo, lo2, hi2);
+    lo += hi2;
+    if (hi2 > lo) hi++;
+  }
+  if (lo == ~0ull && !(q >= -27 && q <= 55)) return 1;           // cannot tell which side of a rounding boundary
+  const int upperbit = (int)(hi >> 63);
+  uint64_t m = hi >> (upperbit + 64 - F.mant_bits - 3);
+  int32_t p2 = (int32_t)((((152170 + 65536) * q) >> 16) + 63) + upperbit - lz - F.min_exp;
+  if (p2 <= 0) {                                                  // subnormal result
+    if (-p2 + 1 >= 64) return 0;
+    m >>= -p2 + 1;
+    m += m & 1;
+    m >>= 1;
+    pw2 = m < (1ull << F.mant_bits) ? 0 : 1;
+    mant = m & ~(1ull << F.mant_bits);
+    return 0;
+  }
+  // exactly half way between two floats and the product is exact: round to even
+  if (lo <= 1 && q >= F.rte_min && q <= F.rte_max && (m & 3) == 1 && (m << (upperbit + 64 - F.mant_bits - 3)) == hi) m &= ~1ull;
+  m += m & 1;
+  m >>= 1;
+  if (m >= (2ull << F.mant_bits)) { m = 1ull << F.mant_bits; p2++; }
+  m &= ~(1ull << F.mant_bits);
+  if (p2 >= F.inf_power) { mant = 0; pw2 = F.inf_power; return 0; }
+  mant = m; pw2 = p2;
+  return 0;
+}
 
 // f32 / f64 `str::parse` (Rust core::num::dec2flt; call sites codec/text.rs:52-59), the part that is
 // exact with one IEEE operation (W. Clinger's fast path): the text is  [+-] digits [. digits] [e[+-]digits]
@@ -23,7 +84,7 @@ ETLG_HD uint32_t flt_lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
 // every larger exponent are handed back DEFERRED (include/etlg.h), never approximated.
 // Returns 0 value (bits in out), 1 defer, 2 malformed (ETLG_E_FLOAT).
 template <class At>  // At: uint32_t operator()(uint32_t i) -> byte i of the text
-ETLG_HD int parse_float_fast_t(At at, uint32_t n, bool is32, uint64_t& out) {
+ETLG_FD int parse_float_fast_t(At at, uint32_t n, bool is32, uint64_t& out) {
   uint32_t i = 0;
   bool neg = false;
   if (n && (at(0) == '+' || at(0) == '-')) { neg = at(0) == '-'; i = 1; }
@@ -45,7 +106,7 @@ ETLG_HD int parse_float_fast_t(At at, uint32_t n, bool is32, uint64_t& out) {
   uint32_t nsig = 0;       // significant digits accumulated into w (after leading zeros)
   int32_t q = 0;           // decimal exponent of w's last digit
   uint32_t pending0 = 0;   // zeros seen after a significant digit, not yet appended (dropped if trailing)
-  uint32_t ndig = 0;
+  uint32_t ndig = 0, dropped = 0;  // dropped: significant digit positions beyond the 19 that fit w
   bool frac = false, too_long = false;
   for (; i < n; i++) {
     const uint32_t c = at(i);
@@ -57,8 +118,13 @@ ETLG_HD int parse_float_fast_t(At at, uint32_t n, bool is32, uint64_t& out) {
     if (d == 0) { if (nsig) pending0++; continue; }  // leading zeros carry nothing
     // a non-zero digit: first append the zeros held back, then the digit
     const uint32_t add = pending0 + 1;
-    if (nsig + add > 19) too_long = true;
-    else {
+    if (too_long || nsig + add > 19) {
+      // keep what fits: the zeros held back, then the digit; positions that do not fit only move the exponent
+      uint32_t room = too_long ? 0u : 19u - nsig;
+      for (uint32_t z = 0; z < pending0; z++) { if (room) { w *= 10; room--; } else dropped++; }
+      if (room) w = w * 10 + d; else dropped++;
+      too_long = true;
+    } else {
       for (uint32_t z = 0; z < pending0; z++) w *= 10;
       w = w * 10 + d;
     }
@@ -86,28 +152,38 @@ ETLG_HD int parse_float_fast_t(At at, uint32_t n, bool is32, uint64_t& out) {
     out = is32 ? (neg ? 0x80000000ull : 0ull) : (neg ? 0x8000000000000000ull : 0ull);
     return 0;
   }
-  if (too_long || w > (1ull << 53) || q < -22 || q > 22) return 1;
-  const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
-                                 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
-  const double v = q < 0 ? (double)w / p10[-q] : (double)w * p10[q];
-  uint64_t bits; __builtin_memcpy(&bits, &v, 8);
-  if (!is32) { out = bits | (neg ? 0x8000000000000000ull : 0ull); return 0; }
-  // f64 -> f32, round to nearest even in integer arithmetic (no dependence on the denormal mode)
-  if ((bits & 0x1FFFFFFFull) == 0x10000000ull) return 1;  // exactly on a float midpoint: the double rounding may be wrong
-  const int32_t e = (int32_t)((bits >> 52) & 0x7FF) - 1023;  // v is a normal double >= 1e-22
-  const uint64_t m = (bits & 0xFFFFFFFFFFFFFull) | (1ull << 52);
-  uint32_t f;
-  if (e > 127) f = 0x7F800000u;
-  else if (e >= -126) {
-    uint64_t r = m >> 29;                       // 24 bits
-    const uint64_t rem = m & 0x1FFFFFFFull;
-    if (rem > 0x10000000ull || (rem == 0x10000000ull && (r & 1))) r++;
-    f = (uint32_t)(((uint64_t)(e + 127) << 23) + (r - (1ull << 23)));  // a carry out of the mantissa bumps the exponent (up to inf)
-  } else {
-    // float subnormal (cannot happen for |q| <= 22 and w >= 1: v >= 1e-22 > 2^-126 * 2^-23) — defer to be safe
-    return 1;
+  if (!too_long && w <= (1ull << 53) && q >= -22 && q <= 22) {
+    // Clinger's fast path: both factors are exact doubles, one correctly rounded operation
+    const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                            1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const double v = q < 0 ? (double)w / p10[-q] : (double)w * p10[q];
+    uint64_t bits; __builtin_memcpy(&bits, &v, 8);
+    if (!is32) { out = bits | (neg ? 0x8000000000000000ull : 0ull); return 0; }
+    // f32 from the double: only safe when the double is not exactly on a float midpoint; otherwise Eisel-Lemire decides
+    if ((bits & 0x1FFFFFFFull) != 0x10000000ull) {
+      const int32_t e = (int32_t)((bits >> 52) & 0x7FF) - 1023;  // v is a normal double >= 1e-22
+      const uint64_t m = (bits & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+      if (e > 127) { out = 0x7F800000u | (neg ? 0x80000000u : 0u); return 0; }
+      if (e >= -126) {
+        uint64_t r = m >> 29;  // 24 bits, round to nearest even in integer arithmetic (no dependence on the denormal mode)
+        const uint64_t rem = m & 0x1FFFFFFFull;
+        if (rem > 0x10000000ull || (rem == 0x10000000ull && (r & 1))) r++;
+        out = (uint32_t)(((uint64_t)(e + 127) << 23) + (r - (1ull << 23))) | (neg ? 0x80000000u : 0u);  // a carry bumps the exponent
+        return 0;
+      }
+    }
   }
-  out = f | (neg ? 0x80000000u : 0u);
+  // Eisel-Lemire on the (up to 19-digit) mantissa; a longer mantissa was truncated, so w and w + 1 bracket the
+  // value and must round to the same float
+  const int64_t qe = (int64_t)q + dropped;
+  uint64_t m1; int32_t e1;
+  if (eisel_lemire(qe, w, is32, m1, e1)) return 1;
+  if (too_long) {
+    uint64_t m2; int32_t e2;
+    if (eisel_lemire(qe, w + 1, is32, m2, e2) || m1 != m2 || e1 != e2) return 1;
+  }
+  if (is32) out = (uint32_t)m1 | ((uint32_t)e1 << 23) | (neg ? 0x80000000u : 0u);
+  else out = m1 | ((uint64_t)(uint32_t)e1 << 52) | (neg ? 0x8000000000000000ull : 0ull);
   return 0;
 }
 

@@ -339,12 +339,14 @@ enum {
  *  - json / jsonb and every array type: always;
  *  - date / time / timetz / timestamp / timestamptz: when the text is not in the fixed layout of
  *    the reference's own fast paths (codec/time.rs:89-154), i.e. what the reference hands to chrono;
- *  - float4 / float8: the value of "[+-]digits[.digits][e[+-]digits]" is w * 10^q, w = the mantissa
- *    digits read as an integer with leading and trailing zeros dropped. Decoded on the device when
- *    w has at most 19 digits, w <= 2^53 and |q| <= 22 (one exact IEEE multiply or divide gives the
- *    correctly rounded double, as Rust's dec2flt fast path does) — for float4 unless that double
- *    lies exactly half way between two floats — and for zero, inf / infinity / nan. Every other
- *    well-formed float text is DEFERRED; malformed text is the reference's "Float parsing failed". */
+ *  - float4 / float8: decoded on the device whenever the result is certain: Clinger's exact path (mantissa
+ *    <= 2^53, |exponent| <= 22: one IEEE operation), else the Eisel-Lemire algorithm on the first 19
+ *    significant digits (as Rust's dec2flt does; a longer mantissa must round the same way for w and
+ *    w + 1), plus zero, inf / infinity / nan. The rare text for which that is inconclusive (about 1 in
+ *    10^4 of random decimal texts, essentially none of Postgres' own shortest-round-trip output) is
+ *    DEFERRED. The rule is etl_amd/csrc/float_fast.h; the oracle evaluates the same header for the
+ *    DECISION and glibc strtod / strtof for the value. Malformed text is the reference's
+ *    "Float parsing failed". */
 
 /* Numeric heap entry header (followed by ndigits little-endian i16 base-10000
  * digits): mirrors PgNumeric (crates/etl-postgres/src/numeric.rs:75-96). */

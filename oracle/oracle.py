@@ -22,7 +22,8 @@ DEFAULT_DEFER_MASK = 0   # classes deferred wholesale on top of json / arrays (f
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("etl_oracle.cpp", "oracle_codec.hpp")] + \
-           [os.path.join(_HERE, "..", "include", "etlg.h")]
+           [os.path.join(_HERE, "..", "include", "etlg.h"), os.path.join(_HERE, "..", "etl_amd", "csrc", "float_fast.h"),
+            os.path.join(_HERE, "..", "etl_amd", "csrc", "pow5_table.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so

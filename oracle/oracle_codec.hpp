@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../include/etlg.h"
+#include "../etl_amd/csrc/float_fast.h"  // ONLY the float deferral rule shared with the device (see float_device_rule)
 
 namespace orc {
 
@@ -440,51 +441,16 @@ inline Res<uint64_t> parse_f32_bits(sv s) {
   return R::Ok((uint64_t)bits);
 }
 
-// Which float texts the DEVICE decodes itself (include/etlg.h, "float cells"): the value is
-// w * 10^q with w the mantissa digits as an integer (leading / trailing zeros dropped) and the
-// rule is  digits(w) <= 19, w <= 2^53, |q| <= 22  (one exact IEEE operation gives the correctly
-// rounded double); f32 additionally not when that double lies exactly on the midpoint of two
-// floats. Specials and zeros always. Everything else is handed back DEFERRED.
-// Returns 0 decode on device, 1 deferred, 2 malformed. Only used in CONTRACT mode; the VALUE
-// itself still comes from strtod / strtof above (an independent computation).
+// Which float texts the DEVICE decodes itself (include/etlg.h, "float cells"). This is a rule of OUR contract,
+// not reference behaviour, and it has to agree with the device to the last text, so the decision is taken by
+// the device's own host-compilable header (etl_amd/csrc/float_fast.h: Clinger's exact path, then Eisel-Lemire,
+// else "inconclusive"). Only the DECISION is shared: the value the oracle reports still comes from glibc
+// strtod / strtof above, an independent computation, and tests/test_float_fast.py checks the header against
+// those on ten million texts.
+// Returns 0 decode on device, 1 deferred, 2 malformed. Only used in CONTRACT mode.
 inline int float_device_rule(sv s, bool is32) {
-  bool special, neg; int k = 0;
-  if (!float_grammar(s, special, k, neg)) return 2;
-  if (special) return 0;
-  size_t i = 0;
-  if (s[0] == '+' || s[0] == '-') i = 1;
-  unsigned __int128 w = 0;
-  long nsig = 0, pending0 = 0, q = 0;
-  bool frac = false, too_long = false;
-  for (; i < s.size(); i++) {
-    char c = s[i];
-    if (c == '.') { frac = true; continue; }
-    if (c < '0' || c > '9') break;
-    if (frac) q--;
-    if (c == '0') { if (nsig) pending0++; continue; }
-    long add = pending0 + 1;
-    if (nsig + add > 19) too_long = true;
-    else { for (long z = 0; z < pending0; z++) w *= 10; w = w * 10 + (unsigned)(c - '0'); }
-    nsig += add; pending0 = 0;
-  }
-  q += pending0;
-  if (i < s.size()) {  // exponent (grammar already checked)
-    i++;
-    bool eneg = false;
-    if (s[i] == '+' || s[i] == '-') { eneg = s[i] == '-'; i++; }
-    long ex = 0;
-    for (; i < s.size(); i++) if (ex < 100000) ex = ex * 10 + (s[i] - '0');
-    q += eneg ? -ex : ex;
-  }
-  if (nsig == 0) return 0;
-  if (too_long || w > ((unsigned __int128)1 << 53) || q < -22 || q > 22) return 1;
-  if (is32) {
-    std::string z(s);
-    double d = strtod(z.c_str(), nullptr);
-    uint64_t bits; memcpy(&bits, &d, 8);
-    if ((bits & 0x1FFFFFFFull) == 0x10000000ull) return 1;
-  }
-  return 0;
+  uint64_t ignored = 0;
+  return etlg::parse_float_fast_t([&](uint32_t i) { return (uint32_t)(unsigned char)s[i]; }, (uint32_t)s.size(), is32, ignored);
 }
 
 // -------------------------------------------------------------------- numeric

@@ -81,6 +81,23 @@ int main() {
     if (rand() % 50 == 0) s[rand() % s.size()] = "x _-+.e"[rand() % 7];  // sprinkle malformed ones
     check(s);
   }
+  // wide exponents (overflow to inf, subnormals, underflow to zero) and long mantissas (truncation: w and w + 1)
+  for (long it = 0; it < 2000000; it++) {
+    std::string s;
+    if (rand() % 8 == 0) s += "-";
+    const int nd = 1 + rand() % 40;
+    const int dot = (rand() % 2) ? rand() % (nd + 1) : -1;
+    for (int i = 0; i < nd; i++) { if (i == dot) s += "."; s += (char)('0' + rand() % 10); }
+    s += "e"; if (rand() % 2) s += "-";
+    s += std::to_string(rand() % 420);
+    check(s);
+  }
+  const char* edge[] = {"1e308", "1.7976931348623157e308", "1.7976931348623158e308", "1.7976931348623159e308", "1.8e308", "1e309", "2.2250738585072014e-308",
+                        "2.2250738585072011e-308", "4.9406564584124654e-324", "2.4703282292062327e-324", "2.4703282292062328e-324", "1e-324", "1e-400",
+                        "3.4028234663852886e38", "3.4028235677973366e38", "3.4028235677973367e38", "1.1754943508222875e-38", "1.4012984643248171e-45",
+                        "7.0064923216240854e-46", "7.0064923216240862e-46", "1e-46", "8.5e-46", "0.000000000000000000000000000000000000000000001",
+                        "9007199254740993", "9007199254740995", "18014398509481990", "123456789012345678901234567890", "0.1e1000", "1e-1000", "179769313486231580793728971405303415079934132710037826936173778980444968292764750946649017977587207096330286416692887910946555547851940402630657488671505820681908902000708383676273854845817711531764475730270069855571366959622842914819860834936475292719074168444365510704342711559699508093042880177904174497791.9999999999999999999999999999999999999999999999999999999999999999999999"};
+  for (const char* f : edge) check(f);
   // float midpoints: doubles that lie exactly between two floats must not be rounded twice
   for (uint32_t m = 0x3F800000u; m < 0x3F800000u + 4000; m++) {
     float a; memcpy(&a, &m, 4);

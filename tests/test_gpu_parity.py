@@ -241,7 +241,12 @@ def _float_texts():
          "3.4028235e38", "3.4028236e38", "1.17549435e-38", "1e-45", "1.401298464324817e-45", "16777216", "16777217", "16777218",
          "33554434", "8388608.5", "8388609.5", "0.5", "1.0000000596046448", "1.00000005960464477539", "1.00000011920928955",
          "inf", "-inf", "Infinity", "-INFINITY", "+inf", "nan", "NaN", "-nan", "1.", ".5", "-.5e1", "+1.25E+2", "1E5", "1e+05",
-         "100000000000000000000000", "1000000000000000000000", "0.00000000000000000000001", "123.456e-2", "00012.500"]
+         "100000000000000000000000", "1000000000000000000000", "0.00000000000000000000001", "123.456e-2", "00012.500",
+         # wide exponents, subnormals, overflow, and long mantissas whose truncation is inconclusive (still DEFERRED)
+         "1e308", "1.7976931348623158e308", "1e309", "2.2250738585072011e-308", "4.9406564584124654e-324", "2.4703282292062327e-324",
+         "1e-400", "3.4028235677973366e38", "1.4012984643248171e-45", "7.0064923216240854e-46", "1e-46",
+         "50537618.817359292015891086651596749e82", "107896223265412489690691363e88", "28879636596541978310003766487.741e-212",
+         "679604465747276.5742380775679666e23", "7137255.607280446341269933e14", "5693107746173304490483329377e264"]
     for _ in range(3000):
         nd = rng.randint(1, 21)
         digs = "".join(rng.choice("0123456789") for _ in range(nd))
@@ -252,7 +257,7 @@ def _float_texts():
                 digs = "0."
         s = rng.choice(["", "", "-", "+"]) + digs
         if rng.random() < 0.5:
-            s += rng.choice("eE") + rng.choice(["", "+", "-"]) + str(rng.randint(0, 40))
+            s += rng.choice("eE") + rng.choice(["", "+", "-"]) + str(rng.randint(0, 40) if rng.random() < 0.8 else rng.randint(0, 400))
         t.append(s)
     return t
 
@@ -278,8 +283,8 @@ def test_float_matrix(path):
     st = [hb.fixed[int(hb.body_off[i + 1])] & 0x3F for i in range(len(texts))]   # state bits of (id, f8, f4)
     f8 = [(x >> 2) & 3 for x in st]
     f4 = [(x >> 4) & 3 for x in st]
-    assert abi.CELL_VALUE in f8 and abi.CELL_DEFERRED in f8 and abi.CELL_VALUE in f4 and abi.CELL_DEFERRED in f4
-    assert sum(1 for x in f8 if x == abi.CELL_VALUE) > len(texts) // 3
+    assert abi.CELL_DEFERRED in f8   # the inconclusive long mantissas above
+    assert sum(1 for x in f8 if x == abi.CELL_VALUE) > len(texts) * 0.98 and sum(1 for x in f4 if x == abi.CELL_VALUE) > len(texts) * 0.98
     d.close()
     # malformed texts: the reference's "Float parsing failed" at the right frame
     o, d = oracle.Oracle(), Decoder(0)
