@@ -25,6 +25,11 @@ namespace etlg {
 typedef uint8_t u8;
 
 #define DEV __device__ __forceinline__
+#ifdef ETLG_DECODE_NOINLINE   // experiment: one out-of-line copy of the value codec per kernel (code size / I-cache)
+#define DEV_DECODE __device__ __attribute__((noinline))
+#else
+#define DEV_DECODE DEV
+#endif
 
 // ------------------------------------------------------------- byte helpers
 DEV uint32_t ld_be32(const u8* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return __builtin_bswap32(v); }
@@ -828,7 +833,7 @@ DEV uint32_t slot_bytes(uint32_t cls);
 // COPY_CLASSES = false: the caller moves verbatim text (String cells, wholesale-deferred classes)
 // itself and never passes those classes in (k_cells).
 template <bool COPY_CLASSES = true>
-DEV uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t* slot, u8* heap, uint32_t& hcur,
+DEV_DECODE uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, uint32_t* slot, u8* heap, uint32_t& hcur,
                               uint32_t& state, bool over = false) {
   // str::from_utf8 precedes the type switch (codec/event.rs:976). Every non-text grammar below
   // accepts ASCII only, so for those classes validity is only examined when the parse fails
