@@ -311,6 +311,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       }
       ct_h[vc * CF + lane] = h;  // every cell of a decodable image gets its entry (P2b sums them blindly)
     }
+    ETLG_WAVE_JOIN();
   }
   __syncthreads();
   TSTAMP(3);
@@ -510,6 +511,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     } else if (act && kind == CT_B) {
       err = ETLG_E_BINARY_FORMAT;
     }
+    ETLG_WAVE_JOIN();
     if (act) {
       if (err) atomicMin(&fr_err[lane], (order << 8) | err);
       else if (st) atomicOr(&fr_st[img][lane], st << (2 * kout));
@@ -570,7 +572,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams q) {
-  extern __shared__ __attribute__((aligned(16))) u8 smem[];
+  ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[CF + 1];
   __shared__ int32_t fr_slot[CF];
   __shared__ uint32_t fr_meta[CF];

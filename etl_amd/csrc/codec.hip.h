@@ -25,8 +25,19 @@ namespace etlg {
 typedef uint8_t u8;
 
 #define DEV __device__ __forceinline__
+// The declarations the SIMT test emulator (tests/simt/simt.h) has to substitute: reconvergence markers, out-of-line device
+// functions defined in this header, and the dynamic LDS window of a kernel.
+#ifndef DEV_NOINLINE
+#define DEV_NOINLINE __device__ __attribute__((noinline))
+#endif
+#ifndef ETLG_WAVE_JOIN   // reconvergence point of a divergent region with wave collectives inside: nothing on the GPU
+#define ETLG_WAVE_JOIN() ((void)0)
+#endif
+#ifndef ETLG_DYNAMIC_LDS
+#define ETLG_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) u8 name[]
+#endif
 #ifdef ETLG_DECODE_NOINLINE   // experiment: one out-of-line copy of the value codec per kernel (code size / I-cache)
-#define DEV_DECODE __device__ __attribute__((noinline))
+#define DEV_DECODE DEV_NOINLINE
 #else
 #define DEV_DECODE DEV
 #endif
@@ -359,7 +370,7 @@ struct CellIt {
 
 // ----------------------------------------------------------------- UTF-8
 // core::str::from_utf8 (strict RFC 3629), call site codec/event.rs:976.
-__device__ __attribute__((noinline)) bool utf8_valid(const u8* s, uint32_t n) {
+DEV_NOINLINE bool utf8_valid(const u8* s, uint32_t n) {
   uint32_t i = 0;
   while (i < n) {
     // ASCII runs, 8 bytes at a time (re-entered after every multi-byte character)
@@ -429,7 +440,7 @@ DEV bool ieq(const u8* s, uint32_t n, const char* lit, uint32_t ln) {
 // ------------------------------------------------------------ value codecs
 // Rust `iN::from_str` / `u32::from_str` (codec/text.rs:40-51,135-138).
 // Returns false on error. `bits`: 16/32/64; `is_signed`.
-__device__ __attribute__((noinline)) bool parse_int(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& out) {
+DEV_NOINLINE bool parse_int(const u8* s, uint32_t n, bool is_signed, int bits, int64_t& out) {
   if (n == 0) return false;
   bool neg = false;
   uint32_t i = 0;

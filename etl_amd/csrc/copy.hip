@@ -128,7 +128,7 @@ DEV void copy_row(const CopyParams& q, uint32_t r, const u8* row, uint32_t n, u8
 }
 
 __global__ __launch_bounds__(256) void k_copy_frames(CopyParams q) {
-  extern __shared__ __attribute__((aligned(16))) u8 smem[];
+  ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[257];
   const uint32_t tid = threadIdx.x;
   const uint32_t r0 = blockIdx.x * 256u;

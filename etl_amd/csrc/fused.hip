@@ -63,6 +63,9 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     wire_ok = frame_structure(v, m, STAGED);
   }
   TSTAMP(2);
+#ifdef ETLG_ABLATE  // instruction-count ablations (tools/build_variants.py "ablate"): stop after a phase, keeping its results alive
+  if (q.dbg & 0x2000u) { if (live && wire_ok && m.new_n == 0x7FFFu && v.tag == 0xEE) p.res->fused_fail = 1; return; }
+#endif
   uint32_t cnt = 0, mark = 0;
   if (live) {
     if (consumes_ordinal(v.tag)) cnt = 1;
@@ -117,6 +120,9 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     }
   }
   TSTAMP(6);
+#ifdef ETLG_ABLATE
+  if (q.dbg & 0x4000u) { if (x_ev + x_fx + x_hp + tot3[0] + seg_in + pm == 0xFFFFFFF1u) p.res->fused_fail = 1; return; }
+#endif
   // ---- look-back: output positions (and the transaction state when it was not needed earlier);
   //      independent prefixes run on different waves so their latencies overlap
   const uint64_t agg_a = ((uint64_t)tot3[0] << 32) | tot3[2];
@@ -172,7 +178,7 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
 template <int BLK>
 __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, FusedParams q) {
   DecParams p = pg;  // side-table pointers of `p` are redirected to the LDS copy below
-  extern __shared__ __attribute__((aligned(16))) u8 smem[];
+  ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[BLK + 1];
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
@@ -247,6 +253,9 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     lane_ok = o1 <= o0 || o1 > p.in_len || (o0 >= span0 && o1 <= span1);
   }
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
+#ifdef ETLG_ABLATE
+  if (q.dbg & 0x1000u) { if (use_lds && stage[tid * 7] == 0xEE && stage[tid * 13 + 5] == 0xEF) p.res->fused_fail = 1; return; }
+#endif
   if (use_lds) {
     TSTAMP(1);
     tile_body<BLK, true>(p, pg, q, tile, nt, s_offs, stage, a0, s32, s64);

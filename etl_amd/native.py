@@ -45,6 +45,10 @@ def lib():
     except ImportError:
         pass
     L = C.CDLL(LIB_PATH)
+    # tests/simt builds the kernel sources against a CPU SIMT emulator to check kernel logic without a GPU; that
+    # library is test infrastructure and must never serve a decode outside its own test run
+    if hasattr(L, "etlg_simt_marker") and os.environ.get("ETLG_SIMT_RUN") != "1":
+        raise NativeLibraryMissing(f"{LIB_PATH} is the SIMT test emulator build, not the gfx950 library; the decode path has no CPU fallback")
     L.etlg_abi_version.restype = C.c_uint32
     L.etlg_err_table.argtypes = [C.c_int32]
     L.etlg_err_table.restype = C.POINTER(abi.ErrDesc)

@@ -1,0 +1,160 @@
+// TEST INFRASTRUCTURE — a small SIMT emulator for the kernel sources of etl_amd/csrc.
+//
+// Purpose: run the *same* .hip sources (kernels.hip, fused.hip, cells.hip, scan.hip, copy.hip) and host.cpp on
+// the CPU of a box without a GPU, so that the logic of a kernel change can be checked against the oracle
+// before it costs GPU minutes. The sources are compiled with g++ against this header instead of
+// <hip/hip_runtime.h>; every lane of a workgroup is a fiber (ucontext), workgroups run one after the
+// other in blockIdx order, and wave / workgroup collectives (__syncthreads, __ballot, __shfl*, DPP,
+// readlane, readfirstlane) are rendezvous points resolved by the scheduler in simt.cpp.
+//
+// What it is NOT: it is not a backend of the product. libetl_gfx950.so never contains it,
+// etl_amd/native.py refuses to load a library that exports etlg_simt_marker unless the test harness
+// says so, and nothing here models timing, memory ordering, LDS capacity or data races between
+// waves — the GPU parity suite (-m gpu) stays the gate for every change.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
+#define ETLG_SIMT 1
+
+// ---------------------------------------------------------------- language keywords
+#define __global__ static
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define DEV_NOINLINE static __attribute__((noinline))
+#define ETLG_DYNAMIC_LDS(name) uint8_t* const name = simt::dyn_lds()
+
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct dim3 { uint32_t x, y, z; dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {} };
+
+namespace simt {
+
+enum Op : int { OP_BAR = 1, OP_JOIN, OP_BALLOT, OP_ALL, OP_ANY, OP_READFIRST, OP_READLANE, OP_SHFL, OP_SHFL_UP, OP_SHFL_XOR, OP_DPP, OP_FENCE };
+
+struct Idx { uint32_t x, y, z; };
+struct LaneView { uint32_t tid, bid, bdim, gdim; };
+extern LaneView* g_view;   // the lane that is running
+uint8_t* dyn_lds();
+// rendezvous of the running lane; returns the lane's result
+uint64_t collective(int op, uint64_t a, uint64_t b, uint64_t c, const void* site);
+void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg);
+uint64_t ticks();
+
+static inline Idx tidx() { return Idx{g_view->tid, 0, 0}; }
+static inline Idx bidx() { return Idx{g_view->bid, 0, 0}; }
+static inline Idx bdim() { return Idx{g_view->bdim, 1, 1}; }
+static inline Idx gdim() { return Idx{g_view->gdim, 1, 1}; }
+
+template <class... KArgs, class... Args>
+void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t lds, Args&&... args) {
+  std::tuple<std::decay_t<KArgs>...> tup(std::forward<Args>(args)...);
+  struct Ctx { void (*k)(KArgs...); std::tuple<std::decay_t<KArgs>...>* t; } ctx{k, &tup};
+  run_grid(g.x, b.x, lds, [](void* p) { Ctx* c = (Ctx*)p; std::apply(c->k, *c->t); }, &ctx);
+}
+
+}  // namespace simt
+
+#define threadIdx (simt::tidx())
+#define blockIdx (simt::bidx())
+#define blockDim (simt::bdim())
+#define gridDim (simt::gdim())
+#define hipLaunchKernelGGL(k, g, b, lds, stream, ...) simt::launch(k, g, b, lds, __VA_ARGS__)
+
+// ---------------------------------------------------------------- collectives
+// Every collective is a function-like macro that stamps its expansion with __COUNTER__: the rendezvous is keyed
+// by SOURCE site, which survives whatever the host compiler does to the call (g++ duplicates calls into both
+// arms of a branch, so a return address does not identify a site).
+#define SIMT_ID ((const void*)(((uintptr_t)(__COUNTER__ + 1) << 32) | (uintptr_t)__LINE__))   // order of appearance, source line
+namespace simt {
+static inline void c_bar(const void* id) { collective(OP_BAR, 1, 0, 0, id); }
+static inline int c_bar_and(const void* id, int p) { return (int)collective(OP_BAR, p != 0, 0, 0, id); }
+static inline void c_join(const void* id) { collective(OP_JOIN, 0, 0, 0, id); }
+static inline void c_fence(const void* id) { collective(OP_FENCE, 0, 0, 0, id); }
+static inline unsigned long long c_ballot(const void* id, int p) { return collective(OP_BALLOT, p != 0, 0, 0, id); }
+static inline int c_all(const void* id, int p) { return (int)collective(OP_ALL, p != 0, 0, 0, id); }
+static inline int c_any(const void* id, int p) { return (int)collective(OP_ANY, p != 0, 0, 0, id); }
+static inline int c_readfirstlane(const void* id, int v) { return (int)(uint32_t)collective(OP_READFIRST, (uint32_t)v, 0, 0, id); }
+static inline int c_readlane(const void* id, int v, int lane) { return (int)(uint32_t)collective(OP_READLANE, (uint32_t)v, (uint32_t)lane, 0, id); }
+static inline int c_dpp(const void* id, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  return (int)(uint32_t)collective(OP_DPP, (uint32_t)src, (uint32_t)old,
+                                   (uint32_t)ctrl | ((uint32_t)row_mask << 16) | ((uint32_t)bank_mask << 20) | ((uint32_t)bound_ctrl << 24), id);
+}
+template <class T> static inline T c_shuffle(const void* id, int op, T v, uint32_t arg) {
+  static_assert(sizeof(T) <= 8, "shuffles move at most 8 bytes");
+  uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+  raw = collective(op, raw, arg, 0, id);
+  T out; memcpy(&out, &raw, sizeof(T)); return out;
+}
+template <class T> static inline T c_shfl(const void* id, T v, int src, int = 64) { return c_shuffle(id, OP_SHFL, v, (uint32_t)src); }
+template <class T> static inline T c_shfl_up(const void* id, T v, unsigned d, int = 64) { return c_shuffle(id, OP_SHFL_UP, v, d); }
+template <class T> static inline T c_shfl_xor(const void* id, T v, int m, int = 64) { return c_shuffle(id, OP_SHFL_XOR, v, (uint32_t)m); }
+}  // namespace simt
+#define __syncthreads() simt::c_bar(SIMT_ID)
+#define __syncthreads_and(p) simt::c_bar_and(SIMT_ID, p)
+#define __threadfence_block() simt::c_fence(SIMT_ID)
+// Reconvergence point of a divergent region that contains wave collectives. The hardware reconverges there by
+// itself (the macro is empty in the HIP build); the emulator cannot see the control-flow graph, so lanes that
+// skipped the region wait here for the lanes inside it instead of running ahead to the next collective.
+#define ETLG_WAVE_JOIN() simt::c_join(SIMT_ID)
+#define __ballot(p) simt::c_ballot(SIMT_ID, p)
+#define __all(p) simt::c_all(SIMT_ID, p)
+#define __any(p) simt::c_any(SIMT_ID, p)
+#define __builtin_amdgcn_readfirstlane(v) simt::c_readfirstlane(SIMT_ID, v)
+#define __builtin_amdgcn_readlane(v, l) simt::c_readlane(SIMT_ID, v, l)
+#define __builtin_amdgcn_update_dpp(...) simt::c_dpp(SIMT_ID, __VA_ARGS__)
+#define __shfl(...) simt::c_shfl(SIMT_ID, __VA_ARGS__)
+#define __shfl_up(...) simt::c_shfl_up(SIMT_ID, __VA_ARGS__)
+#define __shfl_xor(...) simt::c_shfl_xor(SIMT_ID, __VA_ARGS__)
+
+// ---------------------------------------------------------------- lane-local intrinsics and atomics (one lane runs at a time)
+static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3u)));
+}
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned long long clock64() { return simt::ticks(); }
+template <class T, class U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class U> static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
+template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+
+// ---------------------------------------------------------------- the slice of the HIP runtime API host.cpp uses ("device" memory = host memory)
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef struct simt_stream* hipStream_t;
+typedef struct simt_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipInit(unsigned) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "simt error"; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = calloc(1, n + 64); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, 8); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

@@ -1,0 +1,63 @@
+"""Kernel logic on a box without a GPU: the kernel sources of etl_amd/csrc and host.cpp are compiled with g++
+against a small SIMT emulator (tests/simt: lanes are fibers, wave / workgroup collectives are rendezvous points)
+and the parity test files run against that build in a subprocess. TEST INFRASTRUCTURE only — the product never
+contains the emulator (etl_amd/native.py refuses to load it outside this run), and the emulator models neither
+timing nor memory ordering nor races between waves: the -m gpu suite on an MI355X stays the gate."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMT = os.path.join(ROOT, "tests", "simt")
+CXXFLAGS = ["-std=c++17", "-O1", "-g", "-fno-strict-aliasing", "-Wno-unknown-pragmas", "-Wno-attributes", "-I", os.path.join(SIMT, "include")]
+
+
+@pytest.fixture(scope="module")
+def simt_lib():
+    sys.path.insert(0, SIMT)
+    try:
+        import build as simt_build
+    finally:
+        sys.path.pop(0)
+    return simt_build.build()
+
+
+def test_emulator_primitives_against_scalar_loops(tmp_path):
+    exe = str(tmp_path / "simt_selftest")
+    subprocess.check_call(["g++"] + CXXFLAGS + [os.path.join(SIMT, "selftest.cpp"), os.path.join(SIMT, "simt.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:]
+
+
+def test_product_loader_refuses_the_emulator_build(simt_lib):
+    code = "from etl_amd import native\ntry:\n    native.lib()\nexcept native.NativeLibraryMissing as e:\n    print('refused')\n"
+    env = dict(os.environ, ETLG_LIB_PATH=simt_lib)
+    env.pop("ETLG_SIMT_RUN", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert "refused" in out.stdout, out.stdout + out.stderr
+
+
+def _run_gpu_file_on_emulator(simt_lib, args, timeout):
+    env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG=str(timeout))
+    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_BLK", "ETLG_FUSED_DBG"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args,
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout + 60)
+    tail = out.stdout[-3000:] + out.stderr[-1000:]
+    assert out.returncode == 0, tail
+    return tail
+
+
+def test_scenarios_on_every_kernel_path(simt_lib):
+    """Every scenario of tests/scenarios.py on the five device paths (default choice, k_fused 256 / 64, k_cells,
+    multi-pass), byte for byte against the oracle — the same test the GPU box runs, on emulated kernels."""
+    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_parity.py", "-k", "scenario_parity"], 600)
+    assert " passed" in tail and "failed" not in tail, tail
+
+
+def test_copy_rows_and_boundary_scan(simt_lib):
+    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k",
+                                                "not device_resident and not device_input and not 16777216"], 600)
+    assert " passed" in tail and "failed" not in tail, tail

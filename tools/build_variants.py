@@ -17,6 +17,7 @@ VARIANTS = {
     "waves5": ["-O3", "-DETLG_MINWAVES=5"],
     "waves3": ["-O3", "-DETLG_MINWAVES=3"],
     "noinl": ["-O3", "-DETLG_DECODE_NOINLINE"],
+    "ablate": ["-Os", "-DETLG_ABLATE"],
 }
 
 
