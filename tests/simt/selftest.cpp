@@ -34,6 +34,67 @@ __global__ void k_misc(uint32_t* out) {
   out[t * 4 + 3] = x + __shfl(t, 63 - lane, 64);
 }
 
+// ---- the two-level look-back with hand-made descriptor states: workgroups run one after the other in the emulator,
+// so the parity files only ever see "every predecessor already inclusive"; this drives the deeper windows.
+template <class Op>
+__global__ void k_lookback(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg, uint64_t carry,
+                           uint32_t* fail, uint64_t* out) {
+  const uint64_t r = lookback<Op>(desc, gdesc, tile, agg, carry, fail);
+  if (threadIdx.x == 0) *out = r;
+}
+
+template <class Op>
+static void check_lookback(const char* name, uint32_t tile, int incl_group /* newest group with an INCLUSIVE descriptor, -1 = none (the carry ends the walk) */,
+                           uint64_t seed) {
+  const uint32_t g = tile >> 6, j = tile & 63, ntiles = (g + 1) * 64;
+  std::vector<unsigned long long> desc(ntiles, 0), gdesc(g + 2, 0);
+  std::vector<uint64_t> agg(ntiles);
+  uint64_t r = seed;
+  auto rnd = [&]() { r ^= r << 13; r ^= r >> 7; r ^= r << 17; return r; };
+  for (auto& a : agg) {
+    const uint64_t x = rnd();
+    // payloads that are valid for every operator: small counts, bit 29 of the high word (the "Begin seen" flag of OpTxn) now and then
+    a = ((uint64_t)(((x >> 40) & 0xFFF) | ((x & 15) == 0 ? (1u << 29) : 0)) << 32) | (uint32_t)((x >> 8) & 0xFFFFF);
+  }
+  const uint64_t carry = ((uint64_t)7 << 32) | 3;
+  // scalar reference: exclusive prefix of `tile`, and the inclusive prefix of every group
+  std::vector<uint64_t> gincl(g + 1);
+  uint64_t run = carry;
+  for (uint32_t t = 0; t < ntiles; t++) { if (t == tile) break; run = Op::f(run, agg[t]); }
+  const uint64_t want = run;
+  run = carry;
+  for (uint32_t t = 0; t < g * 64; t++) { run = Op::f(run, agg[t]); if ((t & 63) == 63) gincl[t >> 6] = run; }
+  for (uint32_t t = g * 64; t < tile; t++) desc[t] = ST_AGG | agg[t];   // earlier tiles of the own group: aggregates only
+  for (uint32_t k = 0; k < g; k++) {
+    uint64_t ga = agg[k * 64];
+    for (uint32_t t = k * 64 + 1; t < (k + 1) * 64; t++) ga = Op::f(ga, agg[t]);
+    gdesc[k] = ((int)k <= incl_group) ? (ST_INCL | gincl[k]) : (ST_AGG | ga);
+  }
+  uint32_t fail = 0; uint64_t out = ~0ull;
+  hipLaunchKernelGGL(k_lookback<Op>, dim3(1), dim3(64), 0, 0, desc.data(), gdesc.data(), tile, agg[tile], carry, &fail, &out);
+  CHECK(fail == 0, "%s tile %u: gave up", name, tile);
+  CHECK(out == want, "%s tile %u incl_group %d: %llx != %llx", name, tile, incl_group, (unsigned long long)out, (unsigned long long)want);
+  CHECK(desc[tile] == (ST_AGG | agg[tile]), "%s tile %u: own aggregate not published", name, tile);
+  if (j == 63) CHECK(gdesc[g] == (ST_INCL | Op::f(want, agg[tile])), "%s tile %u: group descriptor", name, tile);
+  (void)j;
+}
+
+static void lookback_tests() {
+  uint64_t seed = 0x9E3779B97F4A7C15ull;
+  const uint32_t tiles[] = {0, 1, 5, 63, 64, 65, 100, 127, 128, 64 * 63 + 9, 64 * 64, 64 * 64 + 63, 64 * 65 + 1, 64 * 130 + 17, 64 * 200 + 63};
+  for (uint32_t tile : tiles) {
+    const int g = (int)(tile >> 6);
+    const int incls[] = {g - 1, g - 2, g - 40, g - 64, g - 65, g - 130, -1};
+    for (int ig : incls) {
+      if (ig < -1 || ig >= g) { if (ig != -1) continue; }
+      seed += 0x1234567;
+      check_lookback<OpAdd>("OpAdd", tile, ig, seed);
+      check_lookback<OpAdd2>("OpAdd2", tile, ig, seed);
+      check_lookback<OpTxn>("OpTxn", tile, ig, seed);
+    }
+  }
+}
+
 int main() {
   const uint32_t B = 256, G = 3, N = B * G;
   std::vector<uint32_t> in(N), a(N), m(N), s(N), blk(N), tot(G);
@@ -68,6 +129,7 @@ int main() {
     const uint32_t x = (lane >= 10 && lane < 40) ? (uint32_t)pm + (uint32_t)(pm >> 32) : 0;
     CHECK(o[t * 4 + 3] == x + (w0 + 63 - lane), "partial ballot / shfl t%u: %u", t, o[t * 4 + 3]);
   }
+  lookback_tests();
   printf(g_fail ? "simt selftest: %d failures\n" : "simt selftest ok\n", g_fail);
   return g_fail != 0;
 }
