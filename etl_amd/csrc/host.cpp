@@ -270,6 +270,7 @@ struct etlg_batch {
   // what sync needs to finish the batch
   int32_t host_err_code = 0; int64_t host_err_frame = -1; uint32_t host_err_rank = 0;
   std::vector<CtrlFrame> ctrl;     // processed control frames (for rollback replay)
+  std::vector<std::vector<uint8_t>> ctrl_raw;  // their bytes, same order (the input may be device-resident or come without a sidecar)
   ControlState snapshot;           // control state before the batch
   bool have_snapshot = false;
 };
@@ -1170,6 +1171,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
         } else { o0 = h_offs[cf.frame]; o1 = h_offs[cf.frame + 1]; }
         const uint8_t* fr = in_dev ? tmp.data() : buf + o0;
         const size_t flen = o1 - o0;
+        b->ctrl_raw.emplace_back(fr, fr + flen);
         // classify guaranteed 'd' len 'w' hdr tag: body starts at +31
         uint64_t wal_start = 0;
         for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
@@ -1439,25 +1441,23 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
       c->cs = b->snapshot;
       c->slots.resize(b->snapshot.n_slots);
       c->slots_dirty = true;
-      // Replaying needs the frame bytes; they are only needed when a later batch is
-      // decoded on this context after a failure, which the reference never does
-      // (the apply loop exits). Effects of control frames before `frame` are
-      // re-applied when the input is still host-visible.
-      if (host_in && host_offs) {
-        std::vector<EpochRec> eps;
-        for (auto& cf : all_ctrl) {
-          if ((int64_t)cf.frame >= frame) break;
-          const uint8_t* fr = host_in + host_offs[cf.frame];
-          const size_t flen = host_offs[cf.frame + 1] - host_offs[cf.frame];
-          uint64_t wal_start = 0;
-          for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
-          if (cf.tag == 'R') (void)handle_relation(c, cf, fr + 31, flen - 31, eps); else (void)handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
-        }
+      // Effects of the control frames before `frame` are re-applied from the copies of their bytes kept
+      // by the first pass (the input itself may be device-resident, or have come without a sidecar).
+      std::vector<EpochRec> eps;
+      for (size_t i = 0; i < all_ctrl.size() && i < b->ctrl_raw.size(); i++) {
+        const CtrlFrame& cf = all_ctrl[i];
+        if ((int64_t)cf.frame >= frame) break;
+        const uint8_t* fr = b->ctrl_raw[i].data();
+        const size_t flen = b->ctrl_raw[i].size();
+        uint64_t wal_start = 0;
+        for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
+        if (cf.tag == 'R') (void)handle_relation(c, cf, fr + 31, flen - 31, eps); else (void)handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
       }
     }
   }
   b->have_snapshot = false;
   b->snapshot = ControlState{};
+  b->ctrl_raw.clear();
   c->in_txn = r.out_in_txn != 0; c->final_lsn = r.out_final_lsn; c->next_ord = r.out_next_ord;
 
   etlg_batch_view& v = b->v;

@@ -116,3 +116,35 @@ def test_decode_without_sidecar_device_input(dec):
     g = dec.decode(buf2, None)
     assert g.rc == 0
     assert not o.decode(buf2, offs2).host_batch().diff(g.host())
+
+
+@pytest.mark.parametrize("sidecar", [False, True])
+def test_error_after_in_batch_relation_keeps_the_schema_slots(sidecar):
+    """A batch that carries its own Relation messages and fails later: the events before the failing frame
+    still name schema slots created by those Relation messages, so the view must list them — also when the
+    batch came without a sidecar (the host replays the control frames from the copies it kept of their bytes;
+    found by tools/simt_fuzz.py: the replay used to need host-visible offsets)."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.cfg5()
+    buf, offs = w.fill(48 << 10)
+    b = bytearray(buf.tobytes())
+    tags = [b[int(o) + 30] if int(offs[i + 1]) - int(o) > 31 else 0 for i, o in enumerate(offs[:-1])]
+    rels = [i for i, t in enumerate(tags) if t == ord("R")]
+    assert len(rels) >= 2
+    # a row between two Relation messages: the failure rolls the second one back, the first one must survive
+    victim = max(i for i, t in enumerate(tags) if t == ord("I") and rels[0] < i < rels[-1])
+    b[int(offs[victim + 1]) - 1] = ord("x")      # the last character of the row's last value: a decode error
+    mb = np.frombuffer(bytes(b), dtype=np.uint8)
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o, ready=False)
+    w.register(d, ready=False)
+    rb, gb = o.decode(mb, offs if sidecar else None), d.decode(mb, offs if sidecar else None)
+    e = gb.error
+    assert rb.err_code != 0 and e is not None and (rb.err_code, rb.err_frame) == (e.code, e.frame_index)
+    assert rb.err_frame == victim
+    hb = rb.host_batch()
+    assert len(hb.slots) > 0
+    diff = hb.diff(gb.host())
+    d.close()
+    assert not diff, diff[:4]

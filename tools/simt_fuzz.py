@@ -1,0 +1,87 @@
+"""Long mutation fuzz of the EMULATED kernels (tests/simt) against the oracle: the GPU fuzz test is bounded by GPU
+minutes, this one only by CPU time. usage: python tools/simt_fuzz.py [seconds=600] [seed0=1]
+Prints one line per disagreement (seed, path, workload, iteration) and a summary; exit code 1 if any."""
+import os
+import random
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "simt"))
+
+WORKER = r'''
+import os, sys, random, time
+sys.path.insert(0, %(root)r)
+from etl_amd import synth
+from etl_amd.decoder import Decoder
+from oracle import oracle
+from tests.test_gpu_fuzz import _mutate
+seed, budget = int(sys.argv[1]), float(sys.argv[2])
+rng = random.Random(seed)
+mk = rng.choice([synth.cfg2, synth.cfg3, synth.cfg5])
+w = mk()
+for _ in range(rng.randrange(4)):
+    w.fill(rng.randrange(8 << 10, 64 << 10))       # start somewhere else in the stream
+buf, offs = w.fill(rng.randrange(16 << 10, 80 << 10))
+t0 = time.time(); it = 0; bad = 0
+while time.time() - t0 < budget:
+    mb, mo = buf, offs
+    for _ in range(rng.choice([1, 1, 2, 3])):
+        if len(mo) < 3:
+            break
+        mb, mo = _mutate(rng, mb, mo)
+    sidecar = rng.random() < 0.8
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o, ready=not w.cfg.emit_relations); w.register(d, ready=not w.cfg.emit_relations)
+    rb = o.decode(mb, mo if sidecar else None); gb = d.decode(mb, mo if sidecar else None)
+    e = gb.error
+    got = (e.code, e.kind, e.description, e.frame_index) if e else (0, 0, "", -1)
+    want = (rb.err_code, rb.err_kind, rb.err_desc, rb.err_frame)
+    diff = [] if want != got else rb.host_batch().diff(gb.host())
+    if want != got or diff:
+        bad += 1
+        print("MISMATCH seed", seed, "it", it, mk.__name__, os.environ.get("ETLG_FUSED_KERNEL"), os.environ.get("ETLG_FORCE_MULTIPASS"), "sidecar", sidecar, want, got, diff[:3], flush=True)
+    d.close(); it += 1
+print("DONE seed", seed, mk.__name__, "iterations", it, "mismatches", bad, flush=True)
+'''
+
+PATHS = [{}, {"ETLG_FUSED_KERNEL": "0"}, {"ETLG_FUSED_KERNEL": "1"}, {"ETLG_FUSED_KERNEL": "2"}, {"ETLG_FORCE_MULTIPASS": "1"}]
+
+
+def main():
+    import build as simt_build
+    lib = simt_build.build()
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t_end = time.time() + seconds
+    total = bad = 0
+    procs = []
+    nproc = max(1, (os.cpu_count() or 2) - 1)
+    while time.time() < t_end or procs:
+        while time.time() < t_end and len(procs) < nproc:
+            env = dict(os.environ, ETLG_LIB_PATH=lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="120", **PATHS[seed % len(PATHS)])
+            procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT}, str(seed), "20"], env=env, cwd=ROOT,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+            seed += 1
+        for p in list(procs):
+            if p.poll() is not None:
+                out = p.stdout.read()
+                procs.remove(p)
+                for line in out.splitlines():
+                    if line.startswith("MISMATCH") or "watchdog" in line or "Error" in line or "Traceback" in line:
+                        print(line, flush=True)
+                        bad += 1
+                    if line.startswith("DONE"):
+                        total += int(line.split("iterations")[1].split()[0])
+                if p.returncode != 0:
+                    print("worker exit", p.returncode, out[-400:], flush=True)
+                    bad += 1
+        time.sleep(0.2)
+    print(f"simt fuzz: {total} mutated batches, {bad} problems, seeds up to {seed - 1}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
