@@ -47,6 +47,42 @@ while time.time() - t0 < budget:
 print("DONE seed", seed, mk.__name__, "iterations", it, "mismatches", bad, flush=True)
 '''
 
+COPY_WORKER = r'''
+import os, sys, random, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+from tests.test_gpu_copy import _gen_rows, GEN_COLS, both
+seed, budget = int(sys.argv[1]), float(sys.argv[2])
+rng = random.Random(seed)
+t0 = time.time(); it = 0; bad = 0
+while time.time() - t0 < budget:
+    rows = [bytearray(r) for r in _gen_rows(rng.randrange(1, 300), rng.randrange(1 << 30))]
+    for _ in range(rng.choice([0, 1, 1, 2, 4])):       # byte-level damage: flips, dropped / doubled separators, cut rows, raw bytes
+        r = rows[rng.randrange(len(rows))]
+        if not r: continue
+        k = rng.choice(["flip", "tab", "untab", "cut", "raw", "nl", "bs"])
+        i = rng.randrange(len(r))
+        if k == "flip": r[i] ^= 1 << rng.randrange(8)
+        elif k == "tab": r[i:i] = b"\t"
+        elif k == "untab":
+            j = r.find(b"\t")
+            if j >= 0: del r[j]
+        elif k == "cut": del r[i:]
+        elif k == "raw": r[i] = rng.choice(b"\x00\xff\xc3\x80\\N")
+        elif k == "nl": r[i:i] = b"\n"
+        elif k == "bs": r[i:i] = b"\\"
+    o, d, rb, gb = both(GEN_COLS, [bytes(r) for r in rows])
+    e = gb.error
+    got = (e.code, e.kind, e.description, e.frame_index) if e else (0, 0, "", -1)
+    want = (rb.err_code, rb.err_kind, rb.err_desc, rb.err_frame)
+    diff = [] if want != got else rb.host_batch().diff(gb.host())
+    if want != got or diff:
+        bad += 1
+        print("MISMATCH copy seed", seed, "it", it, os.environ.get("ETLG_FUSED_KERNEL"), os.environ.get("ETLG_FORCE_MULTIPASS"), want, got, diff[:3], flush=True)
+    d.close(); it += 1
+print("DONE seed", seed, "copy", "iterations", it, "mismatches", bad, flush=True)
+'''
+
 PATHS = [{}, {"ETLG_FUSED_KERNEL": "0"}, {"ETLG_FUSED_KERNEL": "1"}, {"ETLG_FUSED_KERNEL": "2"}, {"ETLG_FORCE_MULTIPASS": "1"}]
 
 
@@ -62,7 +98,8 @@ def main():
     while time.time() < t_end or procs:
         while time.time() < t_end and len(procs) < nproc:
             env = dict(os.environ, ETLG_LIB_PATH=lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="120", **PATHS[seed % len(PATHS)])
-            procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT}, str(seed), "20"], env=env, cwd=ROOT,
+            worker = COPY_WORKER if seed % 3 == 0 else WORKER      # a third of the workers fuzz the table-copy path
+            procs.append(subprocess.Popen([sys.executable, "-c", worker % {"root": ROOT}, str(seed), "20"], env=env, cwd=ROOT,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
             seed += 1
         for p in list(procs):
