@@ -31,7 +31,10 @@ while time.time() - t0 < budget:
     for _ in range(rng.choice([1, 1, 2, 3])):
         if len(mo) < 3:
             break
-        mb, mo = _mutate(rng, mb, mo)
+        try:
+            mb, mo = _mutate(rng, mb, mo)
+        except Exception:      # a second mutation can hit a frame the first one cut short
+            break
     sidecar = rng.random() < 0.8
     o, d = oracle.Oracle(), Decoder(0)
     w.register(o, ready=not w.cfg.emit_relations); w.register(d, ready=not w.cfg.emit_relations)
@@ -83,6 +86,45 @@ while time.time() - t0 < budget:
 print("DONE seed", seed, "copy", "iterations", it, "mismatches", bad, flush=True)
 '''
 
+SCAN_WORKER = r'''
+import os, sys, random, struct, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+from etl_amd.decoder import Decoder
+from tests.test_gpu_scan import ref_scan
+seed, budget = int(sys.argv[1]), float(sys.argv[2])
+rng = random.Random(seed)
+dec = Decoder(0)
+t0 = time.time(); it = 0; bad = 0
+def payload(n):
+    k = rng.random()
+    if k < 0.3: return bytes(rng.getrandbits(8) for _ in range(n))
+    if k < 0.6: return bytes(rng.choice(b"d\x00\x00\x01\x10w") for _ in range(n))      # header look-alikes everywhere
+    return (b"d" + struct.pack(">I", rng.choice([4, 5, 17, 60, 200, 4000])) + b"w") * (n // 6 + 1)
+while time.time() - t0 < budget:
+    parts = []
+    total = rng.choice([0, 1, 4, 5, 300, 5000, 9000, 40000, 150000])
+    size = 0
+    while size < total:
+        n = rng.choice([0, 1, 20, 108, 108, 108, 500, 3000, 9000, 20000, 70000])
+        body = payload(n)[:n]
+        fr = b"d" + struct.pack(">I", len(body) + 4) + body
+        k = rng.random()
+        if k < 0.03: fr = fr[:rng.randrange(1, len(fr) + 1)]                       # truncated frame in the middle
+        elif k < 0.05: fr = bytes([rng.getrandbits(8)]) + fr[1:]                    # not a 'd'
+        elif k < 0.07: fr = fr[:1] + struct.pack(">I", rng.choice([0, 3, 2**31, 2**32 - 1, len(body) + 5])) + fr[5:]
+        parts.append(fr); size += len(fr)
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    if rng.random() < 0.3 and len(buf) > 3: buf = buf[:rng.randrange(len(buf))]
+    got = dec.scan_boundaries(buf); want = ref_scan(buf)
+    if len(got) != len(want) or not np.array_equal(got, want):
+        bad += 1
+        print("MISMATCH scan seed", seed, "it", it, "len", len(buf), "frames", len(want) - 1, len(got) - 1, flush=True)
+    it += 1
+dec.close()
+print("DONE seed", seed, "scan", "iterations", it, "mismatches", bad, flush=True)
+'''
+
 PATHS = [{}, {"ETLG_FUSED_KERNEL": "0"}, {"ETLG_FUSED_KERNEL": "1"}, {"ETLG_FUSED_KERNEL": "2"}, {"ETLG_FORCE_MULTIPASS": "1"}]
 
 
@@ -98,7 +140,7 @@ def main():
     while time.time() < t_end or procs:
         while time.time() < t_end and len(procs) < nproc:
             env = dict(os.environ, ETLG_LIB_PATH=lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="120", **PATHS[seed % len(PATHS)])
-            worker = COPY_WORKER if seed % 3 == 0 else WORKER      # a third of the workers fuzz the table-copy path
+            worker = COPY_WORKER if seed % 4 == 0 else SCAN_WORKER if seed % 4 == 2 else WORKER   # stream / table-copy / boundary-scan
             procs.append(subprocess.Popen([sys.executable, "-c", worker % {"root": ROOT}, str(seed), "20"], env=env, cwd=ROOT,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
             seed += 1
