@@ -625,6 +625,10 @@ __global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams 
                          (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
   if (window_ok) {
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
+#ifdef ETLG_STAGE_WIDE
+    stage_chunks<NW * 64>(pg.in, stage, a0, full_end, tid);
+    if (false)
+#endif
     for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * NW * 64) {
       const uint32_t c1 = c + 16 * NW * 64, c2 = c + 32 * NW * 64, c3 = c + 48 * NW * 64;
       uint4 v0 = *(const uint4*)(pg.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;

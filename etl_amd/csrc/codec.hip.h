@@ -42,6 +42,30 @@ typedef uint8_t u8;
 #define DEV_DECODE DEV
 #endif
 
+// ------------------------------------------------------------- staging (experiment)
+// ETLG_STAGE_WIDE=<W> (tools/build_variants.py "stage8"): W independent 16-byte loads per lane in flight
+// before the first LDS store instead of 4, i.e. one HBM round trip for a 113-byte-per-lane tile instead of two.
+#ifdef ETLG_STAGE_WIDE
+template <int NT>
+DEV void stage_chunks(const uint8_t* in, uint8_t* stage, uint32_t a0, uint32_t full_end, uint32_t tid) {
+  constexpr int W = ETLG_STAGE_WIDE;
+  for (uint32_t c = a0 + 16 * tid; c < full_end; c += 16 * NT * W) {
+    uint4 v[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const uint32_t ck = c + 16 * NT * k;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (ck < full_end) v[k] = *(const uint4*)(in + ck);
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const uint32_t ck = c + 16 * NT * k;
+      if (ck < full_end) *(uint4*)(stage + (ck - a0)) = v[k];
+    }
+  }
+}
+#endif
+
 // ------------------------------------------------------------- byte helpers
 DEV uint32_t ld_be32(const u8* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return __builtin_bswap32(v); }
 DEV uint64_t ld_be64(const u8* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return __builtin_bswap64(v); }

@@ -229,6 +229,10 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     // coalesced staging: 16 B per lane per step; the tail that would cross in_len goes bytewise
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);  // last full 16-byte chunk boundary <= span1
     // four independent 16-byte loads in flight per lane before the first LDS store
+#ifdef ETLG_STAGE_WIDE
+    stage_chunks<BLK>(p.in, stage, a0, full_end, tid);
+    if (false)
+#endif
     for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * BLK) {
       const uint32_t c1 = c + 16 * BLK, c2 = c + 32 * BLK, c3 = c + 48 * BLK;
       uint4 v0 = *(const uint4*)(p.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;

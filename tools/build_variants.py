@@ -6,18 +6,25 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from etl_amd.build import OPT as PRODUCT_OPT  # noqa: E402
 CSRC = os.path.join(ROOT, "etl_amd", "csrc")
 OUT = os.path.join(ROOT, "etl_amd", "variants")
 SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "scan.hip", "copy.hip", "host.cpp"]
+# A variant is a list of extra flags. Unless it names an optimisation level itself, every source is built at the
+# level the product uses for it (etl_amd/build.py: OPT, -O3 otherwise), so "product" IS the shipped library and
+# every other variant differs from it by exactly its flags.
 VARIANTS = {
+    "product": [],
     "base": ["-O3"],
-    "nounroll": ["-O3", "-fno-unroll-loops"],
     "os": ["-Os"],
-    "maxilp": ["-O3", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-    "waves5": ["-O3", "-DETLG_MINWAVES=5"],
-    "waves3": ["-O3", "-DETLG_MINWAVES=3"],
-    "noinl": ["-O3", "-DETLG_DECODE_NOINLINE"],
-    "ablate": ["-Os", "-DETLG_ABLATE"],
+    "nounroll": ["-fno-unroll-loops"],
+    "maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "waves5": ["-DETLG_MINWAVES=5"],
+    "waves3": ["-DETLG_MINWAVES=3"],
+    "noinl": ["-DETLG_DECODE_NOINLINE"],
+    "ablate": ["-DETLG_ABLATE"],          # early-exit ablations for tools/run_pmc_split.sh
+    "stage8": ["-DETLG_STAGE_WIDE=8"],    # 8 staging loads in flight per lane instead of 4
 }
 
 
@@ -28,6 +35,8 @@ def build(name, flags):
     for src in SOURCES:
         obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-function"] + flags
+        if not any(f.startswith("-O") for f in flags):
+            cmd.append(PRODUCT_OPT.get(src, "-O3"))
         if src.endswith(".cpp"):
             cmd += ["-x", "hip"]
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
