@@ -528,7 +528,17 @@ DEV bool parse_int_swar(const u8* s, uint32_t n, bool is_signed, int bits, int64
     if (c0 == '-') { if (!is_signed) return false; neg = true; }
     s++; n--;
   }
+#ifdef ETLG_HOT_FIXES
+  if (n > 19) {  // long (leading zeros): the out-of-line parser gets its own result slot, so that `out` never has its
+                 // address taken and stays in registers on the fast path (it lived in scratch: one memory round trip per cell)
+    int64_t slow = 0;
+    const bool ok_slow = parse_int(neg || c0 == '+' ? s - 1 : s, neg || c0 == '+' ? n + 1 : n, is_signed, bits, slow);
+    out = slow;
+    return ok_slow;
+  }
+#else
   if (n > 19) return parse_int(neg || c0 == '+' ? s - 1 : s, neg || c0 == '+' ? n + 1 : n, is_signed, bits, out);  // long (leading zeros)
+#endif
   // groups of 4 digits from the right; the leading group has r = 1..4 digits
   const uint32_t r = ((n - 1) & 3u) + 1u, ng = (n - r) >> 2;  // ng full groups after the leading one (0..4)
   bool ok = true;
@@ -895,7 +905,14 @@ DEV_DECODE uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, ui
       const bool sg = cls != ETLG_TC_U32;
       const int bits = cls == ETLG_TC_I16 ? 16 : cls == ETLG_TC_I64 ? 64 : 32;
       int64_t v;
+#ifdef ETLG_HOT_FIXES
+      bool int_ok;
+      if (over) int_ok = parse_int_swar(d, len, sg, bits, v);
+      else { int64_t slow = 0; int_ok = parse_int(d, len, sg, bits, slow); v = slow; }  // `v` never has its address taken by an out-of-line call
+      if (!int_ok) return bad(ETLG_E_INT);
+#else
       if (!(over ? parse_int_swar(d, len, sg, bits, v) : parse_int(d, len, sg, bits, v))) return bad(ETLG_E_INT);
+#endif
       if (cls == ETLG_TC_I64) st64(slot, (uint64_t)v); else slot[0] = (uint32_t)v;
       return 0;
     }
@@ -1112,8 +1129,12 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
   for (uint32_t i = 0; i < n; i++) {
     const DevCol col = cols[i];
     const uint32_t cls = col.cls;
+#ifdef ETLG_HOT_FIXES
+    uint32_t* slot = (uint32_t*)(row + col.off_full);  // always the arena: a pointer that may also name private memory turns every row store into a flat store
+#else
     uint32_t dummy[4];
     uint32_t* slot = (pg.flags & 0x100u) ? dummy : (uint32_t*)(row + col.off_full);  // 0x100: profiling ablation (no row stores)
+#endif
     uint64_t head = 0;
     if (over) __builtin_memcpy(&head, c, 8);  // tag + length in one load
     const uint32_t t = over ? (uint32_t)head & 0xFFu : (uint32_t)*c;

@@ -260,9 +260,23 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
 #ifdef ETLG_ABLATE
   if (q.dbg & 0x1000u) { if (use_lds && stage[tid * 7] == 0xEE && stage[tid * 13 + 5] == 0xEF) p.res->fused_fail = 1; return; }
 #endif
+#ifdef ETLG_HOT_FIXES
+  // the staged instance reads its side tables through pointers that can only name LDS (ds_read instead of flat
+  // loads that must first find out which memory they address); a tile without them takes the global instance
+  if (use_lds && q.side_bytes) {
+    TSTAMP(1);
+    const uint32_t nt4 = pg.n_tables * (sizeof(DevTable) / 4), ne4 = pg.n_epochs * (sizeof(DevEpoch) / 4), ns4 = pg.n_slots * (sizeof(DevSlot) / 4);
+    DecParams pl = pg;
+    uint32_t* b0 = (uint32_t*)smem;
+    pl.tables = (const DevTable*)b0; pl.epochs = (const DevEpoch*)(b0 + nt4);
+    pl.slots = (const DevSlot*)(b0 + nt4 + ne4); pl.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
+    tile_body<BLK, true>(pl, pg, q, tile, nt, s_offs, stage, a0, s32, s64);
+  } else if (false) {
+#else
   if (use_lds) {
     TSTAMP(1);
     tile_body<BLK, true>(p, pg, q, tile, nt, s_offs, stage, a0, s32, s64);
+#endif
   } else {
     tile_body<BLK, false>(p, pg, q, tile, nt, s_offs, p.in, 0, s32, s64);
   }

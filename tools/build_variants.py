@@ -25,6 +25,8 @@ VARIANTS = {
     "noinl": ["-DETLG_DECODE_NOINLINE"],
     "ablate": ["-DETLG_ABLATE"],          # early-exit ablations for tools/run_pmc_split.sh
     "stage8": ["-DETLG_STAGE_WIDE=8"],    # 8 staging loads in flight per lane instead of 4
+    "hotfix": ["-DETLG_HOT_FIXES"],       # parsed integers stay in registers, row stores are global (not flat) stores, side tables are read with ds_read
+    "hotfix_stage8": ["-DETLG_HOT_FIXES", "-DETLG_STAGE_WIDE=8"],
 }
 
 

@@ -130,7 +130,7 @@ PATHS = [{}, {"ETLG_FUSED_KERNEL": "0"}, {"ETLG_FUSED_KERNEL": "1"}, {"ETLG_FUSE
 
 def main():
     import build as simt_build
-    lib = simt_build.build()
+    lib = os.environ.get("ETLG_SIMT_FUZZ_LIB") or simt_build.build()   # a variant build of the emulator library (tests/simt/build.py: extra_flags)
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t_end = time.time() + seconds
