@@ -570,8 +570,12 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   TSTAMP(8);
 }
 
+#ifndef ETLG_CELLS_MINBLOCKS
+#define ETLG_CELLS_MINBLOCKS 3   // workgroups per CU the register allocator leaves room for: 168 VGPRs. 4 would mean 128 VGPRs and 176 bytes of
+                                 // spills per lane, for nothing while the ~45 KB LDS window of a tile caps a CU at 3 workgroups anyway
+#endif
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 3) void k_cells(DecParams pg, FusedParams q) {
+__global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecParams pg, FusedParams q) {
   ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[CF + 1];
   __shared__ int32_t fr_slot[CF];
