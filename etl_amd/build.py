@@ -13,7 +13,7 @@ SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "scan.hip", "copy.hip", "hos
 # per-source optimisation level: k_fused is measurably faster built for size (88 vs 93 us on cfg2, tools/variants.sh);
 # k_cells and the rest are not
 OPT = {"fused.hip": "-Os"}
-DEPS = SOURCES + ["dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
+DEPS = SOURCES + ["dev_types.h", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
 
 
 def _stale(target, deps):

@@ -33,6 +33,9 @@ typedef uint8_t u8;
 #ifndef ETLG_WAVE_JOIN   // reconvergence point of a divergent region with wave collectives inside: nothing on the GPU
 #define ETLG_WAVE_JOIN() ((void)0)
 #endif
+#ifndef ETLG_CONST_AS      // constant address space (scalar loads of wave-uniform descriptors); the emulator has one address space
+#define ETLG_CONST_AS __attribute__((address_space(4)))
+#endif
 #ifndef ETLG_DYNAMIC_LDS
 #define ETLG_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) u8 name[]
 #endif
@@ -1120,14 +1123,30 @@ DEV uint32_t write_row(const DecParams& p, const DevSlot& s, uint32_t mode, cons
 // (cell tag, length, characters) stays per lane. `pg` must hold GLOBAL side-table pointers.
 DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const u8* tuple, uint32_t n, u8* row,
                                     uint32_t& hcur, bool over) {
+#ifdef ETLG_SCALAR_COLS
+  // The descriptors are read as whole dwords through constant-address-space pointers: the address is wave-uniform
+  // and the memory is never written by a kernel, so these are s_load (scalar cache, results in SGPRs). As byte /
+  // halfword fields of a plain global struct they compiled to global_load_ubyte / _ushort + s_waitcnt vmcnt(0) +
+  // v_readfirstlane — one dependent vector-memory round trip per column (gfx950 has no sub-dword scalar loads).
+  const ETLG_CONST_AS uint32_t* sw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.slots + slot_u);
+  static_assert(sizeof(DevSlot) == 32 && sizeof(DevCol) == 12, "descriptor words below");
+  if (n != sw[0]) return ETLG_E_TUPLE_WIDTH;                      // DevSlot.n_cols
+  const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + sw[6]);  // DevSlot.cols_base
+  struct { uint32_t cls, nullable, off_full; } col;
+#else
   const DevSlot s = pg.slots[slot_u];
   if (n != s.n_cols) return ETLG_E_TUPLE_WIDTH;
   const DevCol* cols = pg.cols + s.cols_base;
+#endif
   const u8* c = tuple + 2;
   uint32_t acc = 0;
   uint32_t* stw = (uint32_t*)row;
   for (uint32_t i = 0; i < n; i++) {
+#ifdef ETLG_SCALAR_COLS
+    { const uint32_t w0 = cw[3 * i], w1 = cw[3 * i + 1]; col.cls = w0 & 0xFFu; col.nullable = (w0 >> 8) & 0xFFu; col.off_full = w1 & 0xFFFFu; }
+#else
     const DevCol col = cols[i];
+#endif
     const uint32_t cls = col.cls;
 #ifdef ETLG_HOT_FIXES
     uint32_t* slot = (uint32_t*)(row + col.off_full);  // always the arena: a pointer that may also name private memory turns every row store into a flat store

@@ -34,6 +34,9 @@
 #ifndef ETLG_LB_PARALLEL
 #define ETLG_LB_PARALLEL 1 // run the three independent look-backs on three waves
 #endif
+#ifdef ETLG_FIXED_TILE
+#include "fixed_tile.hip.h"  // variant: schema-constant sizing for tiles of Begin / Commit / fixed-width Insert frames
+#endif
 
 namespace etlg {
 
@@ -259,6 +262,19 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
 #ifdef ETLG_ABLATE
   if (q.dbg & 0x1000u) { if (use_lds && stage[tid * 7] == 0xEE && stage[tid * 13 + 5] == 0xEF) p.res->fused_fail = 1; return; }
+#endif
+#ifdef ETLG_FIXED_TILE
+  if (use_lds && q.side_bytes && !q.seq_lookback && (q.dbg & ~64u) == 0 && !(pg.flags & 0xF02u) && pg.worker_kind == ETLG_WORKER_APPLY) {
+    const uint32_t nt4 = pg.n_tables * (sizeof(DevTable) / 4), ne4 = pg.n_epochs * (sizeof(DevEpoch) / 4), ns4 = pg.n_slots * (sizeof(DevSlot) / 4);
+    DecParams pl = pg;  // side tables through pointers that can only name LDS
+    uint32_t* b0 = (uint32_t*)smem;
+    pl.tables = (const DevTable*)b0; pl.epochs = (const DevEpoch*)(b0 + nt4);
+    pl.slots = (const DevSlot*)(b0 + nt4 + ne4); pl.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
+    if (tile_fixed<BLK>(pl, pg, q, tile, nt, s_offs, stage, a0, s32, s64)) {
+      if ((q.dbg & 64u) && tid == 0) atomicAdd(&pg.res->dbg_t[11], 1ull);  // ETLG_FUSED_DBG=64: tiles that took the fixed-width plan (tests)
+      return;
+    }
+  }
 #endif
 #ifdef ETLG_HOT_FIXES
   // the staged instance reads its side tables through pointers that can only name LDS (ds_read instead of flat

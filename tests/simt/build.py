@@ -11,7 +11,7 @@ CSRC = os.path.join(ROOT, "etl_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libetlg_simt.so")
 KERNEL_SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "scan.hip", "copy.hip", "host.cpp"]
-DEPS = KERNEL_SOURCES + ["dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h"]
+DEPS = KERNEL_SOURCES + ["dev_types.h", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h"]
 CXX = os.environ.get("CXX", "g++")
 FLAGS = ["-std=c++17", "-O1", "-g", "-fPIC", "-fno-strict-aliasing", "-Wno-unknown-pragmas", "-Wno-attributes",
          "-I", os.path.join(HERE, "include"), "-x", "c++"]

@@ -32,6 +32,7 @@
 #define __shared__ static
 #define DEV_NOINLINE static __attribute__((noinline))
 #define ETLG_DYNAMIC_LDS(name) uint8_t* const name = simt::dyn_lds()
+#define ETLG_CONST_AS   /* one address space on the host */
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };

@@ -27,6 +27,17 @@ VARIANTS = {
     "stage8": ["-DETLG_STAGE_WIDE=8"],    # 8 staging loads in flight per lane instead of 4
     "hotfix": ["-DETLG_HOT_FIXES"],       # parsed integers stay in registers, row stores are global (not flat) stores, side tables are read with ds_read
     "hotfix_stage8": ["-DETLG_HOT_FIXES", "-DETLG_STAGE_WIDE=8"],
+    # fixed-width plan (csrc/fixed_tile.hip.h): tiles of Begin / Commit / Insert-into-a-fixed-width-table frames are sized from
+    # schema constants (one scan instead of three, no generic size_frame); everything else takes the generic body
+    "fixed": ["-DETLG_FIXED_TILE"],
+    "fixed_hotfix": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES"],
+    "fixed_hotfix_stage8": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_STAGE_WIDE=8"],
+    # wave-uniform row writer reads its slot / column descriptors with s_load (whole dwords through constant-address-space
+    # pointers) instead of one global_load_ubyte/_ushort + vmcnt(0) + v_readfirstlane round trip per column
+    "scols": ["-DETLG_SCALAR_COLS"],
+    "hotfix_scols": ["-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS"],
+    "fixed_hotfix_scols": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS"],
+    "all": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_STAGE_WIDE=8"],
 }
 
 
