@@ -598,6 +598,11 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
     for (uint32_t i = tid; i < per; i += NW * 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
   // ---- P0: side tables, offsets, staging
+#ifdef ETLG_EARLY_SPAN
+  SideRegs side;  // variant head (lookback.hip.h): one round trip for all four tables, LDS stores after the staging loads
+  side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
+  if (false)
+#endif
   {  // the side-input tables always live in LDS here (the host picks another kernel when they do not fit)
     const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
     const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
@@ -622,7 +627,12 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   const uint32_t f0 = tile * CF;
   uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
   // the tile's byte span from two scalar loads: staging starts while the per-frame offsets are in flight
+#ifdef ETLG_EARLY_SPAN
+  const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)pg.offs;  // real scalar loads (see k_fused)
+  const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
+#else
   const uint32_t span0 = pg.offs[f0], span1 = pg.offs[f0 + nt];
+#endif
   const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
@@ -646,6 +656,9 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
     }
     for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
   }
+#ifdef ETLG_EARLY_SPAN
+  side_store<NW * 64>((uint32_t*)smem, tid, side);
+#endif
   if (tid <= nt) s_offs[tid] = my_o;  // CF + 1 <= NW * 64 entries
   __syncthreads();
   TSTAMP(0);

@@ -192,14 +192,37 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
     for (uint32_t i = tid; i < per; i += BLK) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
-#if ETLG_TICKET
+#if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
+  // Variant (kernel head with fewer dependent global round trips). The default head runs, one after the other: three side-table
+  // copy loops (load, wait, LDS store — per table), a barrier, the loads of the tile's byte span (vector loads of a uniform
+  // address, waited for on the spot), and two rounds of staging loads: six round trips before a tile can start parsing.
+  // Here the tile id is blockIdx.x (nothing to broadcast through LDS first); the four side tables are read as ONE
+  // concatenation, up to four dwords per lane, and only stored to LDS after the staging loads have been issued; the span
+  // comes through real scalar loads (constant address space) that overlap the side-table loads; with ETLG_STAGE_WIDE=8 the
+  // tile's bytes are one more round trip. The barrier after staging covers the side tables too.
+  const uint32_t tile = blockIdx.x;
+  if (tile >= q.ntiles) return;
+  const uint32_t f0 = tile * BLK;
+  const uint32_t nt = p.nframes - f0 < (uint32_t)BLK ? p.nframes - f0 : (uint32_t)BLK;
+  const uint32_t f0u = __builtin_amdgcn_readfirstlane(f0), ntu = __builtin_amdgcn_readfirstlane(nt);
+  SideRegs side;
+  side_load<BLK>(p, q.side_bytes != 0, (uint32_t*)smem, tid, side);
+  const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)p.offs;
+  const uint32_t span0 = offs_c[f0u], span1 = offs_c[f0u + ntu];
+  const uint32_t my_o = tid <= nt ? p.offs[f0 + tid] : 0u;
+  const uint32_t last_o = (tid == 0 && nt == (uint32_t)BLK) ? p.offs[f0 + BLK] : 0u;
+#elif ETLG_TICKET
   if (tid == 0) s32[15] = atomicAdd(q.ticket, 1u);
 #else
   if (tid == 0) s32[15] = blockIdx.x;
 #endif
   // copy the (tiny) side-input tables into LDS while the ticket is in flight: every
   // later lookup is then an LDS read instead of a chain of dependent global loads
+#if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
+  if (false) {
+#else
   if (q.side_bytes) {
+#endif
     const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
     const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
     uint32_t* d = (uint32_t*)smem;
@@ -214,6 +237,7 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
     p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
   }
+#if !(defined(ETLG_EARLY_SPAN) && !ETLG_TICKET)
   __syncthreads();
   const uint32_t tile = s32[15];
   if (tile >= q.ntiles) return;
@@ -225,6 +249,7 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
   const uint32_t span0 = p.offs[f0u], span1 = p.offs[f0u + ntu];
   const uint32_t my_o = tid <= nt ? p.offs[f0 + tid] : 0u;
   const uint32_t last_o = (tid == 0 && nt == (uint32_t)BLK) ? p.offs[f0 + BLK] : 0u;
+#endif
   u8* stage = smem + q.side_bytes;
   const uint32_t a0 = span0 & ~15u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 16 <= q.lds_bytes - q.side_bytes && !(q.dbg & 1);
@@ -249,6 +274,9 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     }
     for (uint32_t c = full_end + tid; c < span1; c += BLK) stage[c - a0] = p.in[c];
   }
+#if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
+  side_store<BLK>((uint32_t*)smem, tid, side);
+#endif
   if (tid <= nt) s_offs[tid] = my_o;
   if (tid == 0 && nt == (uint32_t)BLK) s_offs[BLK] = last_o;
   __syncthreads();

@@ -134,5 +134,37 @@ DEV uint64_t final_lsn_of_mark(const DecParams& p, uint32_t mark) {
   return mark == 1u ? p.final_lsn : ld_be64(p.in + ((mark >> 1) - 1) + kBodyOff);
 }
 
+#ifdef ETLG_EARLY_SPAN
+// Variant kernel head (k_fused, k_cells): the four side tables are read as ONE concatenation, up to four dwords per lane held in
+// registers (`side_load`), and stored to LDS only after the tile's staging loads have been issued (`side_store`), so the whole
+// copy costs one global round trip that overlaps the span loads instead of one round trip per table before anything else starts.
+// NT = threads per workgroup. `side_load` also redirects the side-table pointers of `p` to the LDS copy.
+struct SideRegs { uint32_t v0, v1, v2, v3, tot4; };
+template <int NT>
+DEV void side_load(DecParams& p, bool have_side, uint32_t* side_lds, uint32_t tid, SideRegs& r) {
+  const uint32_t e1 = p.n_tables * (sizeof(DevTable) / 4), e2 = e1 + p.n_epochs * (sizeof(DevEpoch) / 4);
+  const uint32_t e3 = e2 + p.n_slots * (sizeof(DevSlot) / 4), tot4 = have_side ? e3 + p.n_cols * (sizeof(DevCol) / 4) : 0u;
+  const uint32_t* t0 = (const uint32_t*)p.tables; const uint32_t* t1 = (const uint32_t*)p.epochs;
+  const uint32_t* t2 = (const uint32_t*)p.slots; const uint32_t* t3 = (const uint32_t*)p.cols;
+  auto ld = [&](uint32_t j) { return j < e1 ? t0[j] : j < e2 ? t1[j - e1] : j < e3 ? t2[j - e2] : t3[j - e3]; };
+  r.v0 = r.v1 = r.v2 = r.v3 = 0; r.tot4 = tot4;
+  if (tid < tot4) r.v0 = ld(tid);
+  if (tid + NT < tot4) r.v1 = ld(tid + NT);
+  if (tid + 2 * NT < tot4) r.v2 = ld(tid + 2 * NT);
+  if (tid + 3 * NT < tot4) r.v3 = ld(tid + 3 * NT);
+  for (uint32_t j = tid + 4 * NT; j < tot4; j += NT) side_lds[j] = ld(j);  // side tables beyond four dwords per lane: the simple way
+  if (have_side) {
+    p.tables = (const DevTable*)side_lds; p.epochs = (const DevEpoch*)(side_lds + e1);
+    p.slots = (const DevSlot*)(side_lds + e2); p.cols = (const DevCol*)(side_lds + e3);
+  }
+}
+template <int NT>
+DEV void side_store(uint32_t* side_lds, uint32_t tid, const SideRegs& r) {
+  if (tid < r.tot4) side_lds[tid] = r.v0;
+  if (tid + NT < r.tot4) side_lds[tid + NT] = r.v1;
+  if (tid + 2 * NT < r.tot4) side_lds[tid + 2 * NT] = r.v2;
+  if (tid + 3 * NT < r.tot4) side_lds[tid + 3 * NT] = r.v3;
+}
+#endif
 
 }  // namespace etlg

@@ -167,3 +167,31 @@ def test_errors_and_odd_frames_inside_conforming_tiles(what, fused):
     if what not in ("keepalive_tag", "update_tag", "int_overflow"):   # legal shapes (keepalive; Update without an old tuple); a short value cannot overflow
         assert err != 0
     d.close()
+
+
+def test_many_registered_tables(fused):
+    """~6 KiB of side tables (30 registered tables of 12 columns): more than four dwords per lane, so the kernel head's
+    side-table copy needs its remainder loop on top of the in-register part (ETLG_EARLY_SPAN variant), and the generic
+    head its full loops; the stream itself only touches two of the tables."""
+    from etl_amd import abi
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    wa = synth.Workload([synth.table_fixed()], 0xF1D0003, rows_per_txn=300, name="fixed_runs")
+    wb = synth.Workload([synth.table_mixed()], 0xF1D0004, rows_per_txn=100, mix=(70, 20, 10), upd_key=10, start_lsn=0x9000000,
+                        name="mixed_runs")
+    d, o = Decoder(0), oracle.Oracle()
+    extra = synth.table_mixed()
+    for t in (d, o):
+        for k in range(30):   # ids on both sides of the two real tables
+            rel = 100 + 7 * k if k % 2 else 900000 + 11 * k
+            t.schema_put(rel, 0, wb.schema_cols(extra), name="extra_%d" % k)
+            t.table_state(rel, abi.TS_READY)
+            n = len(extra["cols"])
+            t.table_ready(rel, 0, [1] * n, [1 if c["pk"] else 0 for c in extra["cols"]])
+    for w in (wa, wb):
+        w.register(d, ready=True)
+        w.register(o, ready=True)
+    buf, offs = _concat([wa.fill(120 << 10), wb.fill(50 << 10), wa.fill(90 << 10)])
+    assert _agree(d, o, buf, offs) == 0
+    assert d.debug_paths()["redone"] == 0
+    d.close()

@@ -65,7 +65,7 @@ def test_copy_rows_and_boundary_scan(simt_lib):
 
 def test_fixed_width_plan_variant(simt_lib):
     """The ETLG_FIXED_TILE variant of k_fused (csrc/fixed_tile.hip.h, not in the default build; built here together with
-    the other prepared flags, ETLG_HOT_FIXES and ETLG_SCALAR_COLS): its own parity file
+    the other prepared flags: ETLG_HOT_FIXES, ETLG_SCALAR_COLS, ETLG_EARLY_SPAN, ETLG_STAGE_WIDE=8 — tools/build_variants.py "all"): its own parity file
     with the demand that conforming tiles really take the plan, and the cfg2 mutation fuzz, on an emulator build
     of the variant; the same parity file on the default build (generic body only)."""
     sys.path.insert(0, SIMT)
@@ -73,8 +73,8 @@ def test_fixed_width_plan_variant(simt_lib):
         import build as simt_build
     finally:
         sys.path.pop(0)
-    lib = simt_build.build(extra_flags=["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS"],
-                           lib=os.path.join(simt_build.OUT, "libetlg_simt_fixed.so"))
+    lib = simt_build.build(extra_flags=["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
+                           lib=os.path.join(simt_build.OUT, "libetlg_simt_all.so"))
     os.environ["ETLG_EXPECT_FIXED_TILE"] = "1"
     try:
         tail = _run_gpu_file_on_emulator(lib, ["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or (cfg2 and (default or fused))"], 600)

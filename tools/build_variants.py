@@ -37,7 +37,11 @@ VARIANTS = {
     "scols": ["-DETLG_SCALAR_COLS"],
     "hotfix_scols": ["-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS"],
     "fixed_hotfix_scols": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS"],
-    "all": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_STAGE_WIDE=8"],
+    # kernel head with two dependent global round trips instead of six (side tables read as one concatenation and stored to LDS
+    # after the staging loads were issued, span through real scalar loads, no barrier before the span loads)
+    "early": ["-DETLG_EARLY_SPAN"],
+    "early_stage8": ["-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
+    "all": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
 }
 
 
