@@ -1,5 +1,5 @@
-// "Fixed-width plan" of the fused kernel (variant ETLG_FIXED_TILE; included by fused.hip only under that flag,
-// so the default device code does not contain it).
+// "Fixed-width plan" of the fused kernel (flag ETLG_FIXED_TILE, part of the product's flags for fused.hip —
+// etl_amd/build.py DEFS; without the flag fused.hip does not include this file).
 //
 // DESIGN.md §6 prices k_fused at 1 949 VALU instructions per wave of 64 rows on cfg2, 473 of them between the
 // structure walk and the look-back: the generic sizing (`size_frame`: any tag, ownership by transaction LSN,

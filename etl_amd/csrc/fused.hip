@@ -35,7 +35,7 @@
 #define ETLG_LB_PARALLEL 1 // run the three independent look-backs on three waves
 #endif
 #ifdef ETLG_FIXED_TILE
-#include "fixed_tile.hip.h"  // variant: schema-constant sizing for tiles of Begin / Commit / fixed-width Insert frames
+#include "fixed_tile.hip.h"  // fixed-width plan: schema-constant sizing for tiles of Begin / Commit / fixed-width Insert frames
 #endif
 
 namespace etlg {

@@ -13,6 +13,8 @@ LIB = os.path.join(OUT, "libetlg_simt.so")
 KERNEL_SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "scan.hip", "copy.hip", "host.cpp"]
 DEPS = KERNEL_SOURCES + ["dev_types.h", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h"]
 CXX = os.environ.get("CXX", "g++")
+sys.path.insert(0, ROOT)
+from etl_amd.build import DEFS as PRODUCT_DEFS  # noqa: E402
 FLAGS = ["-std=c++17", "-O1", "-g", "-fPIC", "-fno-strict-aliasing", "-Wno-unknown-pragmas", "-Wno-attributes",
          "-I", os.path.join(HERE, "include"), "-x", "c++"]
 
@@ -26,7 +28,8 @@ def _stale(target, deps):
 
 def build(force=False, extra_flags=(), lib=LIB):
     deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.join(ROOT, "include", "etlg.h"), os.path.join(HERE, "simt.h"),
-                                                   os.path.join(HERE, "simt.cpp"), os.path.abspath(__file__)]
+                                                   os.path.join(HERE, "simt.cpp"), os.path.abspath(__file__),
+                                                   os.path.join(ROOT, "etl_amd", "build.py")]
     if not force and not _stale(lib, deps):
         return lib
     os.makedirs(OUT, exist_ok=True)
@@ -35,7 +38,9 @@ def build(force=False, extra_flags=(), lib=LIB):
     def one(src):
         path = os.path.join(CSRC, src) if src != "simt.cpp" else os.path.join(HERE, src)
         obj = os.path.join(OUT, f"{tag}_{os.path.splitext(src)[0]}.o")
-        subprocess.check_call([CXX] + FLAGS + list(extra_flags) + ["-c", path, "-o", obj])
+        # the default emulator build mirrors the product's per-source feature flags (etl_amd/build.py: DEFS)
+        defs = [] if extra_flags else PRODUCT_DEFS.get(src, [])
+        subprocess.check_call([CXX] + FLAGS + defs + list(extra_flags) + ["-c", path, "-o", obj])
         return obj
 
     with ThreadPoolExecutor(4) as ex:

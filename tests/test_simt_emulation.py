@@ -64,10 +64,10 @@ def test_copy_rows_and_boundary_scan(simt_lib):
 
 
 def test_fixed_width_plan_variant(simt_lib):
-    """The ETLG_FIXED_TILE variant of k_fused (csrc/fixed_tile.hip.h, not in the default build; built here together with
+    """The fixed-width plan of k_fused (csrc/fixed_tile.hip.h; in the product for fused.hip only; built here on every source together with
     the other prepared flags: ETLG_HOT_FIXES, ETLG_SCALAR_COLS, ETLG_EARLY_SPAN, ETLG_STAGE_WIDE=8 — tools/build_variants.py "all"): its own parity file
     with the demand that conforming tiles really take the plan, and the cfg2 mutation fuzz, on an emulator build
-    of the variant; the same parity file on the default build (generic body only)."""
+    with every flag on every source (k_cells' variant head included); the same parity file on the default emulator build."""
     sys.path.insert(0, SIMT)
     try:
         import build as simt_build
@@ -78,8 +78,9 @@ def test_fixed_width_plan_variant(simt_lib):
     os.environ["ETLG_EXPECT_FIXED_TILE"] = "1"
     try:
         tail = _run_gpu_file_on_emulator(lib, ["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or (cfg2 and (default or fused))"], 600)
+        assert " passed" in tail and "failed" not in tail, tail
+        # the default emulator build mirrors the product's per-source flags (etl_amd/build.py: DEFS — k_fused carries the plan)
+        tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_fixed_plan.py"], 600)
+        assert " passed" in tail and "failed" not in tail, tail
     finally:
         os.environ.pop("ETLG_EXPECT_FIXED_TILE", None)
-    assert " passed" in tail and "failed" not in tail, tail
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_fixed_plan.py"], 600)
-    assert " passed" in tail and "failed" not in tail, tail

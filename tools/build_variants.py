@@ -7,15 +7,16 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from etl_amd.build import OPT as PRODUCT_OPT  # noqa: E402
+from etl_amd.build import OPT as PRODUCT_OPT, DEFS as PRODUCT_DEFS  # noqa: E402
 CSRC = os.path.join(ROOT, "etl_amd", "csrc")
 OUT = os.path.join(ROOT, "etl_amd", "variants")
 SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "scan.hip", "copy.hip", "host.cpp"]
 # A variant is a list of extra flags. Unless it names an optimisation level itself, every source is built at the
-# level the product uses for it (etl_amd/build.py: OPT, -O3 otherwise), so "product" IS the shipped library and
-# every other variant differs from it by exactly its flags.
+# level the product uses for it (etl_amd/build.py: OPT, -O3 otherwise). "product" IS the shipped library (it alone also gets the
+# product's per-source feature flags, DEFS); every other variant is the plain sources plus exactly its flags, on every source.
 VARIANTS = {
-    "product": [],
+    "product": [],                       # per-source flags of etl_amd/build.py (DEFS): the shipped library
+    "plain": [],                         # no feature flags anywhere (what shipped up to r01i)
     "base": ["-O3"],
     "os": ["-Os"],
     "nounroll": ["-fno-unroll-loops"],
@@ -52,6 +53,8 @@ def build(name, flags):
     for src in SOURCES:
         obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-function"] + flags
+        if name == "product":
+            cmd += PRODUCT_DEFS.get(src, [])
         if not any(f.startswith("-O") for f in flags):
             cmd.append(PRODUCT_OPT.get(src, "-O3"))
         if src.endswith(".cpp"):

@@ -8,7 +8,7 @@ T=$(mktemp -d)
 mkdir -p $T/new $T/old $T/src
 git -C $ROOT archive $REV etl_amd/csrc include | tar -x -C $T/src
 for f in fused cells copy kernels scan; do
-  O=-O3; [ $f = fused ] && O=-Os
+  O=-O3; [ $f = fused ] && O="-Os $(cd $ROOT && python -c 'from etl_amd.build import DEFS; print(" ".join(DEFS.get("fused.hip", [])))')"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $O -std=c++17 --cuda-device-only -S $ROOT/etl_amd/csrc/$f.hip -o $T/new/$f.s 2>/dev/null &
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $O -std=c++17 --cuda-device-only -S $T/src/etl_amd/csrc/$f.hip -o $T/old/$f.s 2>/dev/null &
   wait
