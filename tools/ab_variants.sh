@@ -1,15 +1,15 @@
 # First GPU call of a round: parity, then timing, of the prepared k_fused variants (tools/build_variants.py), one box.
-#   here (no GPU):  python tools/build_variants.py product hotfix stage8 early_stage8 fixed_hotfix_scols all
-#   GPU box:        gpurun --timeout 1500 -- 'bash tools/ab_variants.sh "product hotfix stage8 early_stage8 fixed_hotfix_scols all"'
+#   here (no GPU):  python tools/build_variants.py product plain hotfix stage8 early_stage8 fixed_hotfix_scols all
+#   GPU box:        gpurun --timeout 1500 -- 'bash tools/ab_variants.sh "product plain hotfix stage8 early_stage8 fixed_hotfix_scols all"'
 # For every variant: the parity files that exercise what the flags touch (fixed-width plan cases, cfg2 mutation fuzz, MiB-scale
-# cfg2 / cfg3 batches on every kernel path) through ETLG_LIB_PATH, then bench.py on cfg2 (kernel average from the library's HIP
+# cfg2 / cfg3 batches on every kernel path) through ETLG_LIB_PATH, then bench.py on cfg2 and cfg3 (kernel average from the library's HIP
 # events). A variant whose parity run fails is not timed. Output: gpurun_out/ab/<variant>.{parity.log,json} and one table.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab
-for v in ${1:-product hotfix stage8 early_stage8 fixed_hotfix_scols all}; do
+for v in ${1:-product plain hotfix stage8 early_stage8 fixed_hotfix_scols all}; do
   lib=$GRAFT_REPO_ROOT/etl_amd/variants/libetl_gfx950_$v.so
   [ -f $lib ] || { echo "$v: not built"; continue; }
-  expect=0; case $v in fixed*|all) expect=1;; esac
+  expect=0; case $v in fixed*|all|product) expect=1;; esac
   ETLG_LIB_PATH=$lib ETLG_EXPECT_FIXED_TILE=$expect timeout 400 python -m pytest -q -x -m gpu -p no:cacheprovider \
     tests/test_gpu_fixed_plan.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py \
     -k "fixed_plan or (mutations and cfg2) or large_batch or full_size" --deselect tests/test_gpu_parity.py::test_native_library_is_the_one_in_tree \
@@ -17,7 +17,7 @@ for v in ${1:-product hotfix stage8 early_stage8 fixed_hotfix_scols all}; do
   rc=$?
   echo "$v parity rc=$rc  $(tail -1 gpurun_out/ab/$v.parity.log)"
   [ $rc = 0 ] || continue
-  for wl in cfg2 ${2:-}; do
+  for wl in ${2:-cfg2 cfg3}; do
     ETLG_LIB_PATH=$lib timeout 120 python bench.py --workload $wl --steps 40 --warmup 5 --pool 4 --no-cpu-baseline --no-scan-leg \
       > gpurun_out/ab/${v}_$wl.json 2> gpurun_out/ab/${v}_$wl.err
     python - $v $wl <<'PY'
