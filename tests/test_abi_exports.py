@@ -50,3 +50,17 @@ def test_host_only_entry_points_match_the_oracle():
         assert L.etlg_array_elem_class(oid) == o.L.oracle_array_elem_class(oid), oid
     for cls in range(18):
         assert L.etlg_slot_bytes(cls) == o.L.oracle_slot_bytes(cls), cls
+
+
+def test_shipped_fused_flags_are_the_measured_variant():
+    """k_fused ships with the flag set that was timed on the MI355X as variant "all" (profiles/r01j_ab_quick_all.json):
+    etl_amd/build.py DEFS for fused.hip and tools/build_variants.py "all" must stay the same list."""
+    import importlib.util
+    import os
+    from etl_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("build_variants", os.path.join(root, "tools", "build_variants.py"))
+    bv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bv)
+    assert sorted(build.DEFS["fused.hip"]) == sorted(bv.VARIANTS["all"])
+    assert bv.VARIANTS["plain"] == [] and bv.VARIANTS["product"] == []
