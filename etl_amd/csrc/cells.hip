@@ -601,8 +601,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
 #ifdef ETLG_EARLY_SPAN
   SideRegs side;  // variant head (lookback.hip.h): one round trip for all four tables, LDS stores after the staging loads
   side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
-  if (false)
-#endif
+#else
   {  // the side-input tables always live in LDS here (the host picks another kernel when they do not fit)
     const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
     const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
@@ -618,6 +617,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
     p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
     p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
   }
+#endif
   const uint32_t maxc = q.maxc, VC = 2 * maxc;
   uint2* ct_pl = (uint2*)(smem + q.side_bytes);  // side_bytes is a multiple of 16
   uint32_t* ct_h = (uint32_t*)(ct_pl + VC * CF);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     for (uint32_t i = tid; i < per; i += BLK) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
 #if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
-  // Variant (kernel head with fewer dependent global round trips). The default head runs, one after the other: three side-table
+  // Kernel head with few dependent global round trips (ETLG_EARLY_SPAN; in the product). The plain head below runs, one after the other: three side-table
   // copy loops (load, wait, LDS store — per table), a barrier, the loads of the tile's byte span (vector loads of a uniform
   // address, waited for on the spot), and two rounds of staging loads: six round trips before a tile can start parsing.
   // Here the tile id is blockIdx.x (nothing to broadcast through LDS first); the four side tables are read as ONE
@@ -211,18 +211,16 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
   const uint32_t span0 = offs_c[f0u], span1 = offs_c[f0u + ntu];
   const uint32_t my_o = tid <= nt ? p.offs[f0 + tid] : 0u;
   const uint32_t last_o = (tid == 0 && nt == (uint32_t)BLK) ? p.offs[f0 + BLK] : 0u;
-#elif ETLG_TICKET
+#else
+  // Plain head (tools/build_variants.py "plain"; the only one when tile ids come from the atomic ticket).
+#if ETLG_TICKET
   if (tid == 0) s32[15] = atomicAdd(q.ticket, 1u);
 #else
   if (tid == 0) s32[15] = blockIdx.x;
 #endif
   // copy the (tiny) side-input tables into LDS while the ticket is in flight: every
   // later lookup is then an LDS read instead of a chain of dependent global loads
-#if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
-  if (false) {
-#else
   if (q.side_bytes) {
-#endif
     const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
     const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
     uint32_t* d = (uint32_t*)smem;
@@ -237,7 +235,6 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
     p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
   }
-#if !(defined(ETLG_EARLY_SPAN) && !ETLG_TICKET)
   __syncthreads();
   const uint32_t tile = s32[15];
   if (tile >= q.ntiles) return;
