@@ -1,12 +1,12 @@
 # First GPU call of a round: parity, then timing, of the prepared k_fused variants (tools/build_variants.py), one box.
-#   here (no GPU):  python tools/build_variants.py product plain hotfix stage8 early_stage8 fixed_hotfix_scols all
-#   GPU box:        gpurun --timeout 1500 -- 'bash tools/ab_variants.sh "product plain hotfix stage8 early_stage8 fixed_hotfix_scols all"'
+#   here (no GPU):  python tools/build_variants.py product plain hotfix stage8 early_stage8 early_hotfix fixed_hotfix_scols all
+#   GPU box:        gpurun --timeout 1500 -- 'bash tools/ab_variants.sh "product plain hotfix stage8 early_stage8 early_hotfix fixed_hotfix_scols all"'
 # For every variant: the parity files that exercise what the flags touch (fixed-width plan cases, cfg2 mutation fuzz, MiB-scale
 # cfg2 / cfg3 batches on every kernel path) through ETLG_LIB_PATH, then bench.py on cfg2 and cfg3 (kernel average from the library's HIP
 # events). A variant whose parity run fails is not timed. Output: gpurun_out/ab/<variant>.{parity.log,json} and one table.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab
-for v in ${1:-product plain hotfix stage8 early_stage8 fixed_hotfix_scols all}; do
+for v in ${1:-product plain hotfix stage8 early_stage8 early_hotfix fixed_hotfix_scols all}; do
   lib=$GRAFT_REPO_ROOT/etl_amd/variants/libetl_gfx950_$v.so
   [ -f $lib ] || { echo "$v: not built"; continue; }
   expect=0; case $v in fixed*|all|product) expect=1;; esac

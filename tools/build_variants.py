@@ -42,6 +42,7 @@ VARIANTS = {
     # after the staging loads were issued, span through real scalar loads, no barrier before the span loads)
     "early": ["-DETLG_EARLY_SPAN"],
     "early_stage8": ["-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
+    "early_hotfix": ["-DETLG_EARLY_SPAN", "-DETLG_HOT_FIXES"],   # the candidate for k_cells: 8-deep staging costs it VGPR spills (12-14 vs 6-8)
     "all": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
 }
 
