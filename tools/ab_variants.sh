@@ -32,3 +32,19 @@ except Exception as e:
 PY
   done
 done
+# tile size: k_fused with 64 frames per tile on cfg2 (the product instantiates 256 and 64; 512 was slower than 256, 128 has never
+# been built) — if 64 is close to 256 a 128-frame instance with the look-backs on two waves is worth building
+lib=$GRAFT_REPO_ROOT/etl_amd/variants/libetl_gfx950_product.so
+if [ -f $lib ]; then
+  ETLG_FUSED_KERNEL=1 ETLG_LIB_PATH=$lib timeout 120 python bench.py --workload cfg2 --steps 40 --warmup 5 --pool 4 --no-cpu-baseline --no-scan-leg \
+    > gpurun_out/ab/product_blk64_cfg2.json 2> gpurun_out/ab/product_blk64_cfg2.err
+  python - <<'PY'
+import json
+try:
+    j = json.loads(open("gpurun_out/ab/product_blk64_cfg2.json").read().strip().splitlines()[-1])
+    r = j["roofline"]
+    print(f"product, 64-frame tiles cfg2 value {j['value']:8.1f} GB/s  {r['kernel']} {r['kernel_avg_us']:.1f} us  frac {r['frac']}")
+except Exception as e:
+    print("product blk64 FAILED", e)
+PY
+fi
