@@ -106,6 +106,18 @@ DEV bool tile_fixed(const DecParams& p, const DecParams& pg, const FusedParams& 
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
       if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
     }
+#ifdef ETLG_BLK128
+  } else if (BLK == 128 && ETLG_LB_PARALLEL) {  // two waves: the output prefixes on one, the transaction state on the other
+    if (wave == 0) {
+      const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
+      const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
+      if (tid == 0) { s64[4] = a; s64[5] = b; }
+    }
+    if (wave == 1) {
+      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
+      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
+    }
+#endif
   } else if (wave == 0) {
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
     const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);

@@ -137,6 +137,18 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
       if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
     }
+#ifdef ETLG_BLK128
+  } else if (BLK == 128 && ETLG_LB_PARALLEL) {  // two waves: the output prefixes on one, the transaction state on the other
+    if (wave == 0) {
+      const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
+      const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
+      if (tid == 0) { s64[4] = a; s64[5] = b; }
+    }
+    if (wave == 1 && !q.seq_lookback) {
+      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
+      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
+    }
+#endif
   } else if (wave == 0) {
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
     const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
@@ -333,13 +345,28 @@ using namespace etlg;
 void etlg_k_launch_fused(int blk, const DecParams* p, const void* qv, hipStream_t s) {
   const FusedParams* q = (const FusedParams*)qv;
   if (blk == 256) hipLaunchKernelGGL(k_fused<256>, dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+#ifdef ETLG_BLK128
+  else if (blk == 128) hipLaunchKernelGGL(k_fused<128>, dim3(q->ntiles), dim3(128), q->lds_bytes, s, *p, *q);
+#endif
   else hipLaunchKernelGGL(k_fused<64>, dim3(q->ntiles), dim3(64), q->lds_bytes, s, *p, *q);
+}
+
+// 1 when this build carries the 128-frame-tile instance (variant ETLG_BLK128; ETLG_FUSED_BLK=128 selects it at run time)
+int etlg_k_fused_has_blk128(void) {
+#ifdef ETLG_BLK128
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 int etlg_k_fused_set_lds(void) {
   // allow the full 160 KiB of LDS as dynamic shared memory
   hipError_t e1 = hipFuncSetAttribute((const void*)k_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
   hipError_t e2 = hipFuncSetAttribute((const void*)k_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+#ifdef ETLG_BLK128
+  if (hipFuncSetAttribute((const void*)k_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess) return 1;
+#endif
   return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
 }
 

@@ -33,6 +33,7 @@ using namespace etlg;
 extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
 extern "C" const char* etlg_k_name(int which);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
+extern "C" int etlg_k_fused_has_blk128(void);
 extern "C" int etlg_k_fused_set_lds(void);
 extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* vdesc, void* ndesc,
                                      uint32_t* hints, uint32_t* result, int sequential, hipStream_t s);
@@ -238,6 +239,7 @@ struct etlg_ctx {
   unsigned long long last_dbg[12] = {0};
   unsigned long long path_n[4] = {0, 0, 0, 0};
   int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells (default: by frame size)
+  bool fused_blk128 = false;     // ETLG_FUSED_BLK=128 on a build that carries the 128-frame-tile instance (variant ETLG_BLK128)
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
   DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
@@ -817,7 +819,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
-  if (const char* fb = getenv("ETLG_FUSED_BLK")) { const int v = atoi(fb); if (v == 64) c->fused_kernel = 1; else if (v == 256) c->fused_kernel = 0; }
+  if (const char* fb = getenv("ETLG_FUSED_BLK")) { const int v = atoi(fb); if (v == 64) c->fused_kernel = 1; else if (v == 256) c->fused_kernel = 0; else if (v == 128 && etlg_k_fused_has_blk128()) { c->fused_kernel = 0; c->fused_blk128 = true; } }
   clear_error(c);
   { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.insert(c); }
   *out = c;
@@ -1259,7 +1261,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     int kernel = avg <= 192 ? 0 : (cells_ok ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
     if (c->fused_kernel >= 0) kernel = c->fused_kernel == 2 && !cells_ok ? 1 : c->fused_kernel;
     use_cells = kernel == 2;
-    q.blk = kernel == 0 ? 256u : 64u;
+    q.blk = kernel == 0 ? (c->fused_blk128 ? 128u : 256u) : 64u;
     q.maxc = widest;
     // LDS window per tile: the average tile plus a margin; a tile that does not fit reads the input in place
     uint64_t cap = kernel == 1 ? (uint64_t)q.blk * avg * 5 / 4 + 2048 : (uint64_t)q.blk * avg * 9 / 8 + 1024;

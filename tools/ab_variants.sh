@@ -32,8 +32,22 @@ except Exception as e:
 PY
   done
 done
-# tile size: k_fused with 64 frames per tile on cfg2 (the product instantiates 256 and 64; 512 was slower than 256, 128 has never
-# been built) — if 64 is close to 256 a 128-frame instance with the look-backs on two waves is worth building
+# tile size: 128 frames per tile (variant all_blk128, emulator parity only so far: every scenario, cfg2 fuzz, 2 MiB cfg2 / cfg5)
+lib=$GRAFT_REPO_ROOT/etl_amd/variants/libetl_gfx950_all_blk128.so
+if [ -f $lib ]; then
+  ETLG_FUSED_BLK=128 ETLG_LIB_PATH=$lib timeout 120 python bench.py --workload cfg2 --steps 40 --warmup 5 --pool 4 --no-cpu-baseline --no-scan-leg \
+    > gpurun_out/ab/all_blk128_cfg2.json 2> gpurun_out/ab/all_blk128_cfg2.err
+  python - <<'PY'
+import json
+try:
+    j = json.loads(open("gpurun_out/ab/all_blk128_cfg2.json").read().strip().splitlines()[-1])
+    r = j["roofline"]
+    print(f"all_blk128, 128-frame tiles cfg2 value {j['value']:8.1f} GB/s  {r['kernel']} {r['kernel_avg_us']:.1f} us  frac {r['frac']}")
+except Exception as e:
+    print("all_blk128 FAILED", e)
+PY
+fi
+# tile size: k_fused with 64 frames per tile on cfg2 (the product instantiates 256 and 64; 512 was slower than 256)
 lib=$GRAFT_REPO_ROOT/etl_amd/variants/libetl_gfx950_product.so
 if [ -f $lib ]; then
   ETLG_FUSED_KERNEL=1 ETLG_LIB_PATH=$lib timeout 120 python bench.py --workload cfg2 --steps 40 --warmup 5 --pool 4 --no-cpu-baseline --no-scan-leg \

@@ -44,6 +44,9 @@ VARIANTS = {
     "early_stage8": ["-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
     "early_hotfix": ["-DETLG_EARLY_SPAN", "-DETLG_HOT_FIXES"],   # the candidate for k_cells: 8-deep staging costs it VGPR spills (12-14 vs 6-8)
     "all": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
+    # "all" plus a k_fused instance with 128 frames per tile (two waves: output look-backs on one, transaction look-back on the
+    # other); selected at run time with ETLG_FUSED_BLK=128 (without it the library behaves like "all")
+    "all_blk128": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8", "-DETLG_BLK128"],
 }
 
 
