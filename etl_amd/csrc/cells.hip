@@ -588,15 +588,16 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   __shared__ uint32_t fr_toast[CF];  // new-row columns sent as 'u'
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
-  DecParams p = pg;
   const uint32_t tid = threadIdx.x;
-  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
-  if (tid < 3) s64[tid] = 0;
-  if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
   if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
     for (uint32_t i = tid; i < per; i += NW * 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
+  if (!load_carry(pg)) return;  // ASYNC chain: the batch before this one left no state to start from
+  DecParams p = pg;
+  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
+  if (tid < 3) s64[tid] = 0;
+  if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
   // ---- P0: side tables, offsets, staging
 #ifdef ETLG_EARLY_SPAN
   SideRegs side;  // variant head (lookback.hip.h): one round trip for all four tables, LDS stores after the staging loads

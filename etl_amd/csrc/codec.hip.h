@@ -39,6 +39,19 @@ typedef uint8_t u8;
 #ifndef ETLG_DYNAMIC_LDS
 #define ETLG_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) u8 name[]
 #endif
+// LDS-DMA (plan.hip): every lane moves 16 bytes from its own global address to (wave-uniform LDS base) + 16 * lane; the data
+// never passes through VGPRs. The wave waits for its pieces with ETLG_VMEM_WAIT before it reads the window.
+#ifndef ETLG_GLDS16
+#define ETLG_GLDS16(g, l) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(g), (void __attribute__((address_space(3)))*)(l), 16, 0, 0)
+#define ETLG_VMEM_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// One aligned ds_read_b32. Volatile keeps the compiler from fusing neighbouring dwords into a ds_read_b64 / b128 with 4-byte
+// alignment, which the LDS serves at the misaligned rate (tools/ubench/lds_align.hip: 3.3x the cycles of an aligned read).
+#define ETLG_LDS_AS __attribute__((address_space(3)))
+#define ETLG_LDS_LD32(p) (*(volatile const ETLG_LDS_AS uint32_t*)(p))
+#endif
+#ifndef ETLG_PLAN_MINWAVES
+#define ETLG_PLAN_MINWAVES 5   // k_plan: waves per SIMD the register allocator leaves room for (96 VGPRs; the ~8 KB LDS window per wave allows ~5)
+#endif
 #ifdef ETLG_DECODE_NOINLINE   // experiment: one out-of-line copy of the value codec per kernel (code size / I-cache)
 #define DEV_DECODE DEV_NOINLINE
 #else
@@ -117,6 +130,18 @@ struct ByteWin {
 DEV void record_error(const DecParams& p, uint32_t frame, uint32_t rank, uint32_t code) {
   unsigned long long key = ((unsigned long long)frame << 16) | ((unsigned long long)rank << 8) | code;
   atomicMin(&p.res->first_err, key);
+}
+
+// ETLG_F_ASYNC batches are chained on the device: the transaction state a batch starts from is what the batch before it
+// left in its result block (stream order), not what the host knew when it enqueued this one.
+// Returns false when that batch did not produce a result (an error, a plan that did not hold, a predecessor that failed in turn):
+// this one must not run either — the host decodes both again, in order, when they are synced (DevResult.fused_fail bit 3).
+DEV bool load_carry(DecParams& p) {
+  if (!p.carry) return true;
+  const bool ok = p.carry->fused_fail == 0 && p.carry->first_err == kNoErr;
+  p.in_txn = p.carry->out_in_txn; p.final_lsn = p.carry->out_final_lsn; p.next_ord = p.carry->out_next_ord;
+  if (!ok && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&p.res->fused_fail, 8u);
+  return ok;
 }
 
 // ------------------------------------------------------------- wave scans

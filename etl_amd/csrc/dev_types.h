@@ -66,7 +66,8 @@ struct DevResult {
   uint64_t n_frames;             // frames consumed
   uint32_t out_in_txn, n_ctrl;
   uint64_t out_final_lsn, out_next_ord;
-  uint32_t fused_fail, _pad;     // a look-back spin gave up (never expected; forces the multi-pass path)
+  uint32_t fused_fail, _pad;     // single-pass result not usable: 1 a look-back spin gave up (never expected), 2 the fixed-width plan did not
+                                 // cover the batch (plan.hip), 4 a schema too wide for k_cells, 8 the ASYNC predecessor of this batch failed
   unsigned long long dbg_t[12];  // ETLG_FUSED_DBG&8: summed shader-clock cycles per phase (lane 0 of every tile)
   // fused kernel: payload byte counters sharded by tile id so that no single address
   // sees more than ntiles/32 atomics; the host folds them into payload[] after the sync
@@ -143,6 +144,34 @@ struct DecParams {
   uint8_t* fixed; uint8_t* heap;
   uint64_t fixed_cap, heap_cap;
   DevResult* res;
+  // ETLG_F_ASYNC chains batches on the device: when set, the carried transaction state (in_txn / final_lsn / next_ord above)
+  // is read from the result block of the batch issued just before this one on the same stream, not from these host values
+  const DevResult* carry;
+};
+
+// The fixed-width decode plan (plan.hip): the eligible tables of a batch, sorted by rel_id, and their columns.
+struct PlanTab {
+  uint32_t rel_id;
+  uint32_t slot;        // schema slot id
+  uint32_t n_cols;
+  uint32_t row_dwords;  // full-layout row block, dwords
+  uint32_t cols_base;   // index of the table's first column word
+};
+// one word per column: cls | nullable << 8 | off_full << 16
+
+struct PlanParams {
+  unsigned long long* desc;    // look-back words (plan.hip): desc[ntiles] | gdesc[ceil(ntiles / 64)] | dlsn[ntiles]
+  unsigned long long* d_clear; // descriptor buffer of the NEXT batch, zeroed by this launch
+  uint32_t clear_words;
+  uint32_t ntiles;             // tiles of 64 frames (one wave each)
+  uint32_t lds_bytes;          // dynamic LDS per tile: the staging window [0, rows_off) + the tile's image of the fixed arena (64 rows)
+  uint32_t rows_off;
+  uint32_t n_tabs;
+  const PlanTab* tabs;
+  const uint32_t* cols;
+  uint32_t dbg;                // ETLG_PLAN_DBG. bit 0: no LDS staging (tests: the in-place reader). Profiling ablations, results are WRONG:
+                               // bit 1 stop after staging, bit 2 stop after the message heads, bit 3 no cell decode / row stores, bit 4 no event header stores
+                               // bit 5: phase clocks into DevResult.dbg_t
 };
 
 }  // namespace etlg

@@ -192,18 +192,19 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
 
 template <int BLK>
 __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, FusedParams q) {
-  DecParams p = pg;  // side-table pointers of `p` are redirected to the LDS copy below
   ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[BLK + 1];
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
   const uint32_t tid = threadIdx.x;
-  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
-  if (tid < 3) s64[tid] = 0;  // per-tile payload accumulators
   if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
     for (uint32_t i = tid; i < per; i += BLK) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
+  if (!load_carry(pg)) return;  // ASYNC chain: the batch before this one left no state to start from
+  DecParams p = pg;  // side-table pointers of `p` are redirected to the LDS copy below
+  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
+  if (tid < 3) s64[tid] = 0;  // per-tile payload accumulators
 #if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
   // Kernel head with few dependent global round trips (ETLG_EARLY_SPAN; in the product). The plain head below runs, one after the other: three side-table
   // copy loops (load, wait, LDS store — per table), a barrier, the loads of the tile's byte span (vector loads of a uniform

@@ -43,6 +43,8 @@ extern "C" int etlg_k_copy_set_lds(void);
 extern "C" void etlg_k_launch_copy(const uint8_t* rows, const uint32_t* row_offs, uint32_t nrows, uint64_t rows_len, uint32_t ncols,
                                    uint32_t rel_id, uint8_t* out, uint32_t* out_offs, uint32_t lds_bytes, const DecParams* dec, hipStream_t s);
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
+extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_t s);
+extern "C" int etlg_k_plan_set_lds(void);
 extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_maxc(void);
@@ -51,7 +53,8 @@ constexpr int kFused = 7;  // profiling slot of the fused kernel
 constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
 constexpr int kBounds = 9; // ... of the record-boundary scan (scan.hip)
 constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
-constexpr int kProfSlots = 11;
+constexpr int kPlan = 11;  // ... of the fixed-width plan (plan.hip)
+constexpr int kProfSlots = 12;
 
 namespace {
 
@@ -189,6 +192,8 @@ struct OutSet {  // device output arrays of one batch
 };
 
 struct ProfRec { int which; hipEvent_t a, b; };
+struct HostErr { int32_t code = 0; uint32_t rank = 0; };
+struct EpochRec { uint32_t table_id; DevEpoch ep; };
 
 // A table-copy batch in flight (etlg_copy_decode): the rows that k_copy_frames turns into Insert frames.
 struct CopyJob {
@@ -204,6 +209,7 @@ struct CopyJob {
 
 struct etlg_ctx {
   int device = 0;
+  uint64_t gen = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int32_t worker = ETLG_WORKER_APPLY;
@@ -231,15 +237,25 @@ struct etlg_ctx {
   unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
   FusedParams fq{};
+  PlanParams pq{};
   uint32_t n_dev_slots = 0, n_dev_cols = 0;
+  // the fixed-width plan (plan.hip): eligible tables of the current side inputs, and the back-off after a batch that did not conform
+  DevBuf d_ptabs, d_pcols;
+  uint32_t n_plan_tabs = 0, plan_max_row = 16;
+  bool plan_covers_all = false;
+  int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
+  uint32_t plan_margin_pct = 4;  // ETLG_PLAN_MARGIN: LDS window per tile = 64 average frames + this margin (a tile that does not fit is read in place)
+  uint32_t plan_dbg = 0;         // ETLG_PLAN_DBG: bit 0 = no LDS staging (tests of the in-place reader)
+  int n_cus = 256;
+  uint32_t plan_skip = 0, plan_penalty = 4, plan_streak = 0;
+  std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order
   std::vector<DevTable> last_tables;   // what d_tables / d_epochs currently hold
   std::vector<DevEpoch> last_epochs;
   bool side_valid = false;
   bool force_multipass = false;  // ETLG_FORCE_MULTIPASS=1 (tests exercise both paths)
   unsigned long long last_dbg[12] = {0};
-  unsigned long long path_n[4] = {0, 0, 0, 0};
-  int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells (default: by frame size)
-  bool fused_blk128 = false;     // ETLG_FUSED_BLK=128 on a build that carries the 128-frame-tile instance (variant ETLG_BLK128)
+  unsigned long long path_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells, 3 k_plan whenever eligible (default: plan, else by frame size)
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
   DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
@@ -263,6 +279,14 @@ struct etlg_batch {
   uint8_t* h_arena = nullptr; size_t h_arena_cap = 0;
   std::vector<etlg_slot_desc> slot_descs;
   bool pending = false;  // ASYNC: counts not read back yet
+  bool finished = false;
+  int32_t rc = 0;        // result of the batch once finished (what etlg_decode / etlg_batch_sync return)
+  etlg_error err{}; std::string err_detail;
+  int level = 1;         // which kernels produced the result: 0 fixed-width plan, 1 generic single pass, 2 multi-pass
+  bool user_no_ctrl = false, ctrl_done = false, out_dev = false, in_dev = false, scan = false, any_sync_done = false;
+  size_t len = 0;
+  const uint8_t* host_in = nullptr; const uint32_t* host_offs = nullptr; const uint8_t* dev_in = nullptr;
+  uint64_t ctx_gen = 0;
   DevResult* h_res = nullptr;  // pinned, from the context's pool
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
   DevResult* d_res_blk = nullptr;  // this batch's result block on the device
@@ -271,6 +295,7 @@ struct etlg_batch {
   DecParams params{};
   // what sync needs to finish the batch
   int32_t host_err_code = 0; int64_t host_err_frame = -1; uint32_t host_err_rank = 0;
+  std::vector<EpochRec> eps_saved; // epochs of the batch's own control frames (a multi-pass redo needs the same side inputs)
   std::vector<CtrlFrame> ctrl;     // processed control frames (for rollback replay)
   std::vector<std::vector<uint8_t>> ctrl_raw;  // their bytes, same order (the input may be device-resident or come without a sidecar)
   ControlState snapshot;           // control state before the batch
@@ -600,8 +625,6 @@ bool parse_ddl(std::string_view content, uint64_t snapshot, std::shared_ptr<Stor
 }
 
 // ----------------------------------------------------- control-plane frames
-struct HostErr { int32_t code = 0; uint32_t rank = 0; };
-struct EpochRec { uint32_t table_id; DevEpoch ep; };
 
 // handle_relation_message (apply.rs:2363-2440) for one R frame.
 HostErr handle_relation(etlg_ctx* c, const CtrlFrame& cf, const uint8_t* body, size_t n, std::vector<EpochRec>& eps) {
@@ -706,6 +729,7 @@ hipError_t sync_slots(etlg_ctx* c) {
 
 void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
   if (which == kFused) etlg_k_launch_fused((int)c->fq.blk, &p, &c->fq, c->stream);
+  else if (which == kPlan) etlg_k_launch_plan(&p, &c->pq, c->stream);
   else if (which == kCells) etlg_k_launch_cells(&p, &c->fq, c->stream);
   else etlg_k_launch(which, &p, c->stream);
 }
@@ -761,17 +785,28 @@ void fill_view_common(etlg_batch* b) {
 
 // Reads the result block, resolves device vs host error, commits or rolls back
 // the control-plane state and (for host output) copies the arenas back.
-int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& all_ctrl, const uint8_t* host_in,
-                     const uint32_t* host_offs, bool output_on_device);
+int32_t finish_batch(etlg_ctx* c, etlg_batch* b);
+int32_t drain_pending(etlg_ctx* c);
 int32_t download_batch(etlg_ctx* c, etlg_batch* b);
+struct BatchGuard {  // an etlg_decode that fails half way returns what the batch took from the context's pools
+  etlg_batch* b;
+  ~BatchGuard() { if (b) etlg_batch_free(b); }
+};
+int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec>& eps);
+int32_t setup_outputs(etlg_ctx* c, etlg_batch* b);
+int32_t setup_scratch(etlg_ctx* c, DecParams& p);
+bool plan_wanted(etlg_ctx* c, const etlg_batch* b);
+int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level);
+int32_t standard_path(etlg_ctx* c, etlg_batch* b);
 
 }  // namespace
 
 // Live contexts: a batch may be freed after its context (garbage-collected bindings do that), in which case
 // it must not touch the context's pools.
 static std::mutex g_live_mu;
-static std::set<const etlg_ctx*> g_live_ctx;
-static bool ctx_alive(const etlg_ctx* c) { std::lock_guard<std::mutex> l(g_live_mu); return g_live_ctx.count(c) != 0; }
+static std::map<const etlg_ctx*, uint64_t> g_live_ctx;  // context -> generation (an address can be reused by a later context)
+static uint64_t g_ctx_gen = 0;
+static bool ctx_alive(const etlg_ctx* c, uint64_t gen) { std::lock_guard<std::mutex> l(g_live_mu); auto it = g_live_ctx.find(c); return it != g_live_ctx.end() && it->second == gen; }
 
 // ====================================================================== C API
 extern "C" {
@@ -819,21 +854,25 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
-  if (const char* fb = getenv("ETLG_FUSED_BLK")) { const int v = atoi(fb); if (v == 64) c->fused_kernel = 1; else if (v == 256) c->fused_kernel = 0; else if (v == 128 && etlg_k_fused_has_blk128()) { c->fused_kernel = 0; c->fused_blk128 = true; } }
   clear_error(c);
-  { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.insert(c); }
+  (void)etlg_k_plan_set_lds();
+  if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
+  if (const char* pm = getenv("ETLG_PLAN_MARGIN")) c->plan_margin_pct = (uint32_t)atoi(pm);
+  if (const char* pm = getenv("ETLG_PLAN_DBG")) c->plan_dbg = (uint32_t)atoi(pm);
+  { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && ncu > 0) c->n_cus = ncu; }
+  { std::lock_guard<std::mutex> l(g_live_mu); c->gen = ++g_ctx_gen; g_live_ctx[c] = c->gen; }
   *out = c;
   return ETLG_OK;
 }
 
 void etlg_ctx_destroy(etlg_ctx* c) {
   if (!c) return;
-  { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.erase(c); }
-  if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)drain_pending(c);
+  { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.erase(c); }
   (void)hipStreamSynchronize(c->stream);
   if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
-  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc}) b->release();
+  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& pr : c->harena_pool) (void)hipHostFree(pr.first);
@@ -846,6 +885,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
 
 int32_t etlg_ctx_set_stream(etlg_ctx* c, void* s) {
   if (!c) return ETLG_InvalidArgument;
+  (void)drain_pending(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
@@ -855,12 +895,14 @@ int32_t etlg_ctx_set_stream(etlg_ctx* c, void* s) {
 
 int32_t etlg_ctx_set_worker(etlg_ctx* c, int32_t kind, uint32_t table_id, uint64_t bootstrap) {
   if (!c) return ETLG_InvalidArgument;
-  c->worker = kind; c->sync_table = table_id; c->bootstrap = bootstrap;
+  (void)drain_pending(c);
+  c->worker = kind; c->sync_table = table_id; c->bootstrap = bootstrap; c->side_valid = false;
   return ETLG_OK;
 }
 
 int32_t etlg_schema_put(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const char* nsp, const char* name, uint32_t ncols, const etlg_col* cols) {
   if (!c || (ncols && !cols)) return ETLG_InvalidArgument;
+  (void)drain_pending(c);
   auto s = std::make_shared<StoredSchema>();
   s->table_id = table_id; s->snapshot = snapshot; s->nsp = nsp ? nsp : ""; s->name = name ? name : "";
   for (uint32_t i = 0; i < ncols; i++) {
@@ -875,12 +917,14 @@ int32_t etlg_schema_put(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const
 
 int32_t etlg_table_state(etlg_ctx* c, uint32_t table_id, int32_t kind, uint64_t lsn) {
   if (!c) return ETLG_InvalidArgument;
+  (void)drain_pending(c);
   if (kind == ETLG_TS_ABSENT) c->states.erase(table_id); else c->states[table_id] = TState{kind, lsn};
   return ETLG_OK;
 }
 
 int32_t etlg_table_ready(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const uint8_t* rmask, const uint8_t* imask, uint32_t n) {
   if (!c || !rmask || !imask) return -ETLG_InvalidArgument;
+  (void)drain_pending(c);
   SchemaPtr sch = get_at_or_before(c->cs, table_id, snapshot);
   if (!sch || sch->cols.size() != n) return -ETLG_MissingTableSchema;
   std::vector<uint8_t> r(rmask, rmask + n), i(imask, imask + n);
@@ -891,6 +935,7 @@ int32_t etlg_table_ready(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, cons
 
 int32_t etlg_ctx_reset_stream_state(etlg_ctx* c) {
   if (!c) return ETLG_InvalidArgument;
+  (void)drain_pending(c);
   c->in_txn = false; c->final_lsn = 0; c->next_ord = 0;
   return ETLG_OK;
 }
@@ -920,6 +965,13 @@ int32_t etlg_ctx_debug_paths(etlg_ctx* c, unsigned long long* out4) {
   for (int i = 0; i < 4; i++) out4[i] = c->path_n[i];
   return ETLG_OK;
 }
+//   [4] k_plan  [5] plan result discarded and redone by the generic single-pass kernel  [6] batches that took the control path
+//   (a Relation / DDL frame, or a caller without ETLG_F_NO_CONTROL on the multi-pass path)  [7] ASYNC batches re-run because their predecessor failed
+int32_t etlg_ctx_debug_paths8(etlg_ctx* c, unsigned long long* out8) {
+  if (!c || !out8) return ETLG_InvalidArgument;
+  for (int i = 0; i < 8; i++) out8[i] = c->path_n[i];
+  return ETLG_OK;
+}
 
 int32_t etlg_ctx_profile(etlg_ctx* c, int32_t enable) {
   if (!c) return ETLG_InvalidArgument;
@@ -938,7 +990,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }
@@ -1078,11 +1130,16 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   HIPCHK(c, hipSetDevice(c->device));
   const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE, out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
-  const bool no_ctrl = flags & ETLG_F_NO_CONTROL, async = (flags & ETLG_F_ASYNC) && out_dev && no_ctrl;
+  const bool no_ctrl = flags & ETLG_F_NO_CONTROL;
+  const bool scan = frame_offsets == nullptr;
+  // ASYNC batches are chained on the device (DecParams.carry) and may be decoded again when they are synced, so everything
+  // they read must still be there then: device-resident input AND sidecar (the context's staging and scan buffers are shared
+  // by all batches). Anything else is decoded synchronously; etlg_batch_sync on such a batch returns its stored result.
+  const bool async = (flags & ETLG_F_ASYNC) && out_dev && no_ctrl && in_dev && !scan && !c->copy.active && !c->force_multipass && len < (1ull << 31);
   hipStream_t s = c->stream;
+  if (!async) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
 
   // ---- record boundaries: the caller's sidecar, or the device scan (scan.hip)
-  const bool scan = frame_offsets == nullptr;
   const uint32_t* h_offs = frame_offsets;
   const uint8_t* d_in_ptr = buf;  // device address of the input
   if (!in_dev) {
@@ -1096,12 +1153,14 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   }
 
   auto* b = new etlg_batch();
-  b->ctx = c;
-  std::unique_ptr<etlg_batch> guard(b);
+  b->ctx = c; b->ctx_gen = c->gen;
+  BatchGuard guard{b};
+  b->user_no_ctrl = no_ctrl; b->out_dev = out_dev; b->in_dev = in_dev; b->scan = scan; b->len = len;
+  b->host_in = in_dev ? nullptr : buf; b->host_offs = (in_dev || scan) ? nullptr : h_offs; b->dev_in = in_dev ? buf : nullptr;
 
   const uint32_t nf = (uint32_t)nframes;
-  const uint32_t nblocks = (nf + kBlock - 1) / kBlock;
-  DecParams p{};
+  DecParams& p = b->params;
+  p = DecParams{};
   p.in = d_in_ptr;
   if (scan) p.offs = (const uint32_t*)c->d_offs.p;
   else if (in_dev) p.offs = frame_offsets;
@@ -1110,211 +1169,64 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     HIPCHK(c, hipMemcpyAsync(c->d_offs.p, h_offs, (nframes + 1) * 4, hipMemcpyHostToDevice, s));
     p.offs = (const uint32_t*)c->d_offs.p;
   }
-  const bool offs_dev_only = in_dev || scan;  // no host copy of the offsets exists
-  p.nframes = nf; p.nblocks = nblocks; p.in_len = len;
-  p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
+  p.nframes = nf; p.nblocks = (nf + kBlock - 1) / kBlock; p.in_len = len;
   p.worker_kind = (uint32_t)c->worker; p.sync_table = c->sync_table;
-  p.flags = no_ctrl ? 1u : 0u;
+  p.flags = c->fused_dbg & 0xF00u;  // profiling ablations (results are wrong)
   p.copy_slot = -1;
-  p.flags |= c->fused_dbg & 0xF00u;  // profiling ablations (results are wrong)
   if (c->copy.active) { p.flags |= 2u; p.copy_slot = c->copy.slot; b->copy = c->copy; }
   p.host_err_frame = 0xFFFFFFFFu;
+  // carried transaction state: the host's (every earlier batch is finished), or — behind pending ASYNC batches — whatever the
+  // batch issued just before this one leaves in its result block
+  p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
+  p.carry = (async && !c->pending.empty()) ? c->pending.back()->d_res_blk : nullptr;
 
-  HIPCHK(c, c->d_tag.ensure(nf + 16)); HIPCHK(c, c->d_emit.ensure(nf + 16));
-  HIPCHK(c, c->d_ffixed.ensure((size_t)nf * 4 + 16)); HIPCHK(c, c->d_fheap.ensure((size_t)nf * 4 + 16));
-  HIPCHK(c, c->d_blk32.ensure((size_t)(nblocks + 1) * 4 * 3 + 64));
-  HIPCHK(c, c->d_blk64.ensure((size_t)(nblocks + 1) * 8 * 5 + 64));
   HIPCHK(c, c->d_res.ensure(sizeof(DevResult) * etlg_ctx::kResRing));
-  p.f_tag = (uint8_t*)c->d_tag.p; p.f_emit = (uint8_t*)c->d_emit.p;
-  p.f_fixed = (uint32_t*)c->d_ffixed.p; p.f_heap = (uint32_t*)c->d_fheap.p;
-  p.blk_cnt = (uint32_t*)c->d_blk32.p; p.blk_last = p.blk_cnt + (nblocks + 1); p.blk_ev = p.blk_last + (nblocks + 1);
-  p.blk_fixed = (uint64_t*)c->d_blk64.p; p.blk_heap = p.blk_fixed + (nblocks + 1); p.blk_payload = p.blk_heap + (nblocks + 1);
-  {  // result block: next slot of the ring; the whole ring is re-initialised by one copy per lap
-    const uint32_t slot = c->res_seq++ % etlg_ctx::kResRing;
-    if (slot == 0) HIPCHK(c, hipMemcpyAsync(c->d_res.p, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice, s));
-    b->d_res_blk = (DevResult*)c->d_res.p + slot;
+  {  // result block: next slot of a ring that is re-initialised once per lap. Slot 31 is the carry source of the batch in
+     // slot 0, so it is re-initialised one batch later than the others.
+    const uint32_t seq = c->res_seq++;
+    const uint32_t slot = seq % etlg_ctx::kResRing;
+    DevResult* ring = (DevResult*)c->d_res.p;
+    if (seq == 0) HIPCHK(c, hipMemcpyAsync(ring, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice, s));
+    else if (slot == 0) HIPCHK(c, hipMemcpyAsync(ring, c->h_init_ring, sizeof(DevResult) * (etlg_ctx::kResRing - 1), hipMemcpyHostToDevice, s));
+    else if (slot == 1) HIPCHK(c, hipMemcpyAsync(ring + (etlg_ctx::kResRing - 1), c->h_init_ring, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    b->d_res_blk = ring + slot;
   }
   p.res = b->d_res_blk;
   if (c->res_pool.empty()) { DevResult* r = nullptr; HIPCHK(c, hipHostMalloc((void**)&r, sizeof(DevResult), hipHostMallocDefault)); c->res_pool.push_back(r); }
   b->h_res = c->res_pool.back(); c->res_pool.pop_back();
   if (b->copy.active) launch_copy(c, b->copy, p);  // rows -> Insert frames (writes p.in / p.offs), row-level errors
 
-  std::vector<CtrlFrame> ctrl;
-  std::vector<EpochRec> eps;
-  HostErr herr{};
-  int64_t herr_frame = -1;
-  if (!no_ctrl) { b->snapshot = c->cs; b->have_snapshot = true; }
-  const size_t slots_before = c->slots.size();
-
-  if (!no_ctrl && nf) {
-    launch(c, 0, p);
-    launch(c, 1, p);
-    HIPCHK(c, c->d_ctrl.ensure((size_t)nf * sizeof(CtrlFrame) + 64));
-    p.ctrl = (CtrlFrame*)c->d_ctrl.p; p.ctrl_cap = nf;
-    launch(c, 2, p);
-    HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const uint32_t nctrl = b->h_res->n_ctrl;
-    if (nctrl) {
-      ctrl.resize(nctrl);
-      HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
-      std::sort(ctrl.begin(), ctrl.end(), [](const CtrlFrame& a, const CtrlFrame& b2) { return a.frame < b2.frame; });
-      std::vector<uint8_t> tmp;
-      for (const CtrlFrame& cf : ctrl) {
-        uint32_t o0, o1;
-        if (offs_dev_only) {
-          uint32_t oo[2];
-          HIPCHK(c, hipMemcpy(oo, p.offs + cf.frame, 8, hipMemcpyDeviceToHost));
-          o0 = oo[0]; o1 = oo[1];
-          if (in_dev) {
-            tmp.resize(o1 - o0);
-            HIPCHK(c, hipMemcpy(tmp.data(), buf + o0, o1 - o0, hipMemcpyDeviceToHost));
-          }
-        } else { o0 = h_offs[cf.frame]; o1 = h_offs[cf.frame + 1]; }
-        const uint8_t* fr = in_dev ? tmp.data() : buf + o0;
-        const size_t flen = o1 - o0;
-        b->ctrl_raw.emplace_back(fr, fr + flen);
-        // classify guaranteed 'd' len 'w' hdr tag: body starts at +31
-        uint64_t wal_start = 0;
-        for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
-        HostErr he = cf.tag == 'R' ? handle_relation(c, cf, fr + 31, flen - 31, eps) : handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
-        if (he.code) { herr = he; herr_frame = cf.frame; p.host_err_frame = cf.frame; break; }
-      }
-    }
-  }
-  b->ctrl = ctrl;
-  b->host_err_code = herr.code; b->host_err_frame = herr_frame; b->host_err_rank = herr.rank;
-
-  // ---- side inputs: table states + cache timeline
-  bool any_sync_done = false;
-  {
-    std::map<uint32_t, DevTable> tabs;
-    auto get = [&](uint32_t id) -> DevTable& {
-      auto it = tabs.find(id);
-      if (it == tabs.end()) { DevTable t{}; t.table_id = id; t.init_slot = -1; it = tabs.emplace(id, t).first; }
-      return it->second;
-    };
-    for (auto& kv : c->states) { DevTable& t = get(kv.first); t.state_kind = (uint32_t)kv.second.kind; t.state_lsn = kv.second.lsn; }
-    const ControlState& cs0 = b->have_snapshot ? b->snapshot : c->cs;  // cache as of batch start
-    for (auto& kv : cs0.cache) { DevTable& t = get(kv.first); t.init_kind = kv.second.kind; t.init_slot = kv.second.slot; }
-    for (auto& e : eps) get(e.table_id);
-    std::vector<DevTable> tv;
-    std::vector<DevEpoch> ev;
-    for (auto& kv : tabs) {
-      DevTable t = kv.second;
-      t.ep_begin = (uint32_t)ev.size();
-      for (auto& e : eps) if (e.table_id == t.table_id) ev.push_back(e.ep);  // already in frame order
-      t.ep_end = (uint32_t)ev.size();
-      tv.push_back(t);
-    }
-    const bool same = c->side_valid && tv.size() == c->last_tables.size() && ev.size() == c->last_epochs.size() &&
-                      (tv.empty() || !memcmp(tv.data(), c->last_tables.data(), tv.size() * sizeof(DevTable))) &&
-                      (ev.empty() || !memcmp(ev.data(), c->last_epochs.data(), ev.size() * sizeof(DevEpoch)));
-    if (!same) {  // rare: table states or the cache timeline changed; earlier batches may still read the old copy
-      HIPCHK(c, hipStreamSynchronize(s));
-      HIPCHK(c, c->d_tables.ensure(tv.size() * sizeof(DevTable) + 16));
-      HIPCHK(c, c->d_epochs.ensure(ev.size() * sizeof(DevEpoch) + 16));
-      if (!tv.empty()) HIPCHK(c, hipMemcpy(c->d_tables.p, tv.data(), tv.size() * sizeof(DevTable), hipMemcpyHostToDevice));
-      if (!ev.empty()) HIPCHK(c, hipMemcpy(c->d_epochs.p, ev.data(), ev.size() * sizeof(DevEpoch), hipMemcpyHostToDevice));
-      c->last_tables = tv; c->last_epochs = ev; c->side_valid = true;
-    }
-    p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)tv.size();
-    p.n_epochs = (uint32_t)ev.size();
-    any_sync_done = false;
-    for (auto& t : tv) if (t.state_kind == ETLG_TS_SYNC_DONE) any_sync_done = true;
-  }
-  HIPCHK(c, sync_slots(c));
-  p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
-  p.n_slots = c->n_dev_slots; p.n_cols = c->n_dev_cols;
-
-  // ---- outputs (capacity bounds: one event per frame; rows bounded by the widest slot;
-  //      truncate bodies by 2x frame bytes; heap by 2.5x input)
-  OutSet* os = take_outset(c);
-  b->dev = os;
-  const size_t evcap = (size_t)nf + 16;
-  const uint64_t fixed_cap = (uint64_t)nf * max_row_bytes(c) + 2 * (uint64_t)len + 64;
-  const uint64_t heap_cap = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)len * 5 / 2 + 64);
-  HIPCHK(c, os->kind.ensure(evcap)); HIPCHK(c, os->flags.ensure(evcap));
-  HIPCHK(c, os->table.ensure(evcap * 4)); HIPCHK(c, os->slot.ensure(evcap * 4));
-  HIPCHK(c, os->start.ensure(evcap * 8)); HIPCHK(c, os->commit.ensure(evcap * 8));
-  HIPCHK(c, os->ord.ensure(evcap * 8)); HIPCHK(c, os->body.ensure(evcap * 8));
-  HIPCHK(c, os->fixed.ensure(fixed_cap)); HIPCHK(c, os->heap.ensure(heap_cap));
-  p.ev_kind = (uint8_t*)os->kind.p; p.ev_flags = (uint8_t*)os->flags.p; p.ev_table = (uint32_t*)os->table.p; p.ev_slot = (uint32_t*)os->slot.p;
-  p.ev_start = (uint64_t*)os->start.p; p.ev_commit = (uint64_t*)os->commit.p; p.ev_ord = (uint64_t*)os->ord.p; p.ev_body = (uint64_t*)os->body.p;
-  p.fixed = (uint8_t*)os->fixed.p; p.heap = (uint8_t*)os->heap.p; p.fixed_cap = fixed_cap; p.heap_cap = heap_cap;
-
-  const bool classify_done = !no_ctrl && nf != 0;  // k_classify / k_scan_txn already ran for the control list
-  b->params = p;
-  bool use_cells = false;
-  if (nf && !herr.code && !c->force_multipass && len < (1ull << 31)) {
-    // ---- fast path: fused single-pass kernel (fused.hip)
-    const uint64_t avg = (len + nf - 1) / nf;
-    FusedParams& q = c->fq;
-    const uint64_t side = (uint64_t)p.n_tables * sizeof(DevTable) + (uint64_t)p.n_epochs * sizeof(DevEpoch) +
-                          (uint64_t)p.n_slots * sizeof(DevSlot) + (uint64_t)p.n_cols * sizeof(DevCol);
-    q.side_bytes = (side <= 8192 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
-    // kernel choice: narrow frames -> one lane per frame, 256 frames per tile (k_fused); wide frames ->
-    // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 16 columns)
-    uint32_t widest = 1;
-    for (auto& sl : c->slots) widest = std::max<uint32_t>(widest, sl->desc.n_cols);
-    const bool cells_ok = widest <= etlg_k_cells_maxc() && q.side_bytes != 0;  // k_cells keeps the side tables in LDS
-    int kernel = avg <= 192 ? 0 : (cells_ok ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
-    if (c->fused_kernel >= 0) kernel = c->fused_kernel == 2 && !cells_ok ? 1 : c->fused_kernel;
-    use_cells = kernel == 2;
-    q.blk = kernel == 0 ? (c->fused_blk128 ? 128u : 256u) : 64u;
-    q.maxc = widest;
-    // LDS window per tile: the average tile plus a margin; a tile that does not fit reads the input in place
-    uint64_t cap = kernel == 1 ? (uint64_t)q.blk * avg * 5 / 4 + 2048 : (uint64_t)q.blk * avg * 9 / 8 + 1024;
-    if (const char* lm = getenv("ETLG_LDS_MARGIN_PCT")) cap = (uint64_t)q.blk * avg * (100 + (uint64_t)atoi(lm)) / 100 + 1024;
-    cap = (cap + 255) & ~255ull;
-    if (use_cells) cap += etlg_k_cells_table_bytes(widest);
-    cap = std::min<uint64_t>(cap + q.side_bytes, 150 * 1024);
-    q.lds_bytes = (uint32_t)cap;
-    q.seq_lookback = (any_sync_done || (c->fused_dbg & 32)) ? 1u : 0u;
-    q.ntiles = (nf + q.blk - 1) / q.blk;
-    q.in_aligned = ((uintptr_t)p.in & 15) == 0;
-    q.dbg = c->fused_dbg;
-    const size_t ngroups = (q.ntiles + 63) / 64;
-    const size_t per = (size_t)q.ntiles + ngroups;  // tile descriptors followed by group descriptors
-    const size_t dbytes = per * 8 * 3 + 64;
-    // two descriptor buffers: this launch uses one and zeroes the head of the other for the next batch,
-    // so the stream carries no memset between kernels (only when a buffer grows or a larger batch left a tail)
-    if (dbytes > c->desc_half) {
-      const size_t half = (dbytes * 2 + 4095) & ~(size_t)4095;
-      HIPCHK(c, c->d_desc.ensure(half * 2));
-      HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, half * 2, s));
-      c->desc_half = half; c->desc_dirty[0] = c->desc_dirty[1] = 0;
-    }
-    const uint32_t cur = c->desc_cur, oth = cur ^ 1u;
-    uint8_t* dcur = (uint8_t*)c->d_desc.p + cur * c->desc_half;
-    uint8_t* doth = (uint8_t*)c->d_desc.p + oth * c->desc_half;
-    if (c->desc_dirty[cur]) { HIPCHK(c, hipMemsetAsync(dcur, 0, c->desc_dirty[cur], s)); c->desc_dirty[cur] = 0; }
-    q.d_txn = (unsigned long long*)dcur; q.d_outa = q.d_txn + per; q.d_outb = q.d_outa + per;
-    q.ticket = (uint32_t*)(q.d_outb + per);
-    q.d_clear = (unsigned long long*)doth; q.clear_words = (uint32_t)(dbytes / 8);
-    c->desc_dirty[cur] = dbytes;                                   // this launch writes it
-    if (c->desc_dirty[oth] <= dbytes) c->desc_dirty[oth] = 0;       // ... and clears that much of the other one
-    c->desc_cur = oth;
-    launch(c, use_cells ? kCells : kFused, p);
-    b->used_fused = true;
-    b->used_cells = use_cells;
+  // ---- first attempt. A single-pass kernel runs OPTIMISTICALLY as if the batch held no Relation / DDL frame (they are
+  //      <0.1 % of frames and absent from almost every batch): no classify / control-list kernels, no host round trip. A
+  //      control frame makes that kernel report ETLG_E_CTRL_HINT and the batch takes the control path then (finish_batch).
+  const bool single_pass = nf && !c->force_multipass && len < (1ull << 31);
+  if (single_pass) {
+    p.flags |= 1u;
+    const std::vector<EpochRec> no_eps;
+    { const int32_t rc = build_side_inputs(c, b, no_eps); if (rc != ETLG_OK) return rc; }
+    { const int32_t rc = setup_outputs(c, b); if (rc != ETLG_OK) return rc; }
+    { const int32_t rc = enqueue_single(c, b, plan_wanted(c, b) ? 0 : 1); if (rc != ETLG_OK) return rc; }
   } else {
-    launch_multipass(c, p, classify_done);
+    const int32_t rc = standard_path(c, b);
+    if (rc != ETLG_OK) return rc;
   }
   HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
 
-  (void)slots_before;
-  guard.release();
+  guard.b = nullptr;
   *out = b;
-  if (async) { b->pending = true; b->v.on_device = 1; fill_view_common(b); return ETLG_OK; }
-  return finish_batch(c, b, ctrl, in_dev ? nullptr : buf, in_dev ? nullptr : h_offs, out_dev);
+  if (async) { b->pending = true; b->v.on_device = 1; fill_view_common(b); c->pending.push_back(b); return ETLG_OK; }
+  return finish_batch(c, b);
 }
 
 int32_t etlg_batch_sync(etlg_ctx* c, etlg_batch* b) {
   if (!c || !b) return ETLG_InvalidArgument;
-  if (!b->pending) return c->err.kind;
-  b->pending = false;
-  return finish_batch(c, b, b->ctrl, nullptr, nullptr, true);
+  if (b->pending) {
+    // batches finish in issue order: the carried transaction state of the context is the state after the LAST finished one
+    while (b->pending && !c->pending.empty()) { const int32_t rc = finish_batch(c, c->pending.front()); (void)rc; }
+  }
+  // the context's last error becomes this batch's (the reference returns the error of the call that hit it)
+  c->err = b->err; c->err_detail = b->err_detail; c->err.detail = c->err_detail.empty() ? nullptr : c->err_detail.c_str();
+  return b->rc;
 }
 
 int32_t etlg_batch_header_to_device(etlg_ctx* c, etlg_batch* b, void* dst) {
@@ -1338,12 +1250,18 @@ int32_t etlg_batch_view_get(const etlg_batch* b, etlg_batch_view* out) {
 
 void etlg_batch_free(etlg_batch* b) {
   if (!b) return;
-  if (ctx_alive(b->ctx)) {
-    if (b->pending || b->h_res) (void)hipStreamSynchronize(b->ctx->stream);
-    if (b->dev) b->ctx->out_pool.push_back(b->dev);
-    if (b->h_res) b->ctx->res_pool.push_back(b->h_res);
-    if (b->h_arena) b->ctx->harena_pool.emplace_back(b->h_arena, b->h_arena_cap);
-  } else {  // the context is gone: its device buffers went with it; only what the batch owns outright is released
+  if (b->ctx && ctx_alive(b->ctx, b->ctx_gen)) {
+    etlg_ctx* c = b->ctx;
+    if (b->pending) {  // freed without a sync: it still has to finish, in order, for the context's carried state to be right
+      while (b->pending && !c->pending.empty()) { const int32_t rc = finish_batch(c, c->pending.front()); (void)rc; }
+      b->pending = false;
+    }
+    if (b->h_res) (void)hipStreamSynchronize(c->stream);
+    if (b->dev) c->out_pool.push_back(b->dev);
+    if (b->h_res) c->res_pool.push_back(b->h_res);
+    if (b->h_arena) c->harena_pool.emplace_back(b->h_arena, b->h_arena_cap);
+  } else {  // the context is gone (its pools with it): release what the batch owns outright
+    if (b->dev) { b->dev->release(); delete b->dev; }
     if (b->h_res) (void)hipHostFree(b->h_res);
     if (b->h_arena) (void)hipHostFree(b->h_arena);
   }
@@ -1405,23 +1323,356 @@ int32_t download_batch(etlg_ctx* c, etlg_batch* b) {
   return ETLG_OK;
 }
 
-int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& all_ctrl, const uint8_t* host_in,
-                     const uint32_t* host_offs, bool output_on_device) {
-  (void)host_in; (void)host_offs;
+// ------------------------------------------------------------ decode orchestration
+// Per-frame scratch of the multi-pass kernels (context-shared, grow-only): (re)binds the pointers of `p`.
+int32_t setup_scratch(etlg_ctx* c, DecParams& p) {
+  const uint32_t nf = p.nframes, nblocks = p.nblocks;
+  HIPCHK(c, c->d_tag.ensure(nf + 16)); HIPCHK(c, c->d_emit.ensure(nf + 16));
+  HIPCHK(c, c->d_ffixed.ensure((size_t)nf * 4 + 16)); HIPCHK(c, c->d_fheap.ensure((size_t)nf * 4 + 16));
+  HIPCHK(c, c->d_blk32.ensure((size_t)(nblocks + 1) * 4 * 3 + 64));
+  HIPCHK(c, c->d_blk64.ensure((size_t)(nblocks + 1) * 8 * 5 + 64));
+  p.f_tag = (uint8_t*)c->d_tag.p; p.f_emit = (uint8_t*)c->d_emit.p;
+  p.f_fixed = (uint32_t*)c->d_ffixed.p; p.f_heap = (uint32_t*)c->d_fheap.p;
+  p.blk_cnt = (uint32_t*)c->d_blk32.p; p.blk_last = p.blk_cnt + (nblocks + 1); p.blk_ev = p.blk_last + (nblocks + 1);
+  p.blk_fixed = (uint64_t*)c->d_blk64.p; p.blk_heap = p.blk_fixed + (nblocks + 1); p.blk_payload = p.blk_heap + (nblocks + 1);
+  return ETLG_OK;
+}
+
+// Side inputs of one batch: table states + the shared-table-cache timeline (`eps`: the epochs its own Relation / DDL frames
+// create) + schema slots + the fixed-width plan's tables. Re-uploaded only when they change; a change behind pending ASYNC
+// batches finishes those first (their kernels read the old copy).
+int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec>& eps) {
+  DecParams& p = b->params;
   hipStream_t s = c->stream;
-  HIPCHK(c, hipStreamSynchronize(s));
-  if (b->used_fused && (b->h_res->first_err != kNoErr || b->h_res->fused_fail)) {
-    // cold path: recompute with the multi-pass kernels, which know the exact cut at the failing frame
-    HIPCHK(c, hipMemcpyAsync(b->d_res_blk, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
-    if (b->copy.active) launch_copy(c, b->copy, b->params);
-    launch_multipass(c, b->params, false);
-    HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    b->used_fused = false;
-    c->path_n[3]++;
-  } else {
-    c->path_n[b->used_fused ? (b->used_cells ? 1 : 0) : 2]++;
+  std::map<uint32_t, DevTable> tabs;
+  auto get = [&](uint32_t id) -> DevTable& {
+    auto it = tabs.find(id);
+    if (it == tabs.end()) { DevTable t{}; t.table_id = id; t.init_slot = -1; it = tabs.emplace(id, t).first; }
+    return it->second;
+  };
+  for (auto& kv : c->states) { DevTable& t = get(kv.first); t.state_kind = (uint32_t)kv.second.kind; t.state_lsn = kv.second.lsn; }
+  const ControlState& cs0 = b->have_snapshot ? b->snapshot : c->cs;  // cache as of batch start
+  for (auto& kv : cs0.cache) { DevTable& t = get(kv.first); t.init_kind = kv.second.kind; t.init_slot = kv.second.slot; }
+  for (auto& e : eps) get(e.table_id);
+  std::vector<DevTable> tv;
+  std::vector<DevEpoch> ev;
+  for (auto& kv : tabs) {
+    DevTable t = kv.second;
+    t.ep_begin = (uint32_t)ev.size();
+    for (auto& e : eps) if (e.table_id == t.table_id) ev.push_back(e.ep);  // already in frame order
+    t.ep_end = (uint32_t)ev.size();
+    tv.push_back(t);
   }
+  const bool same = c->side_valid && !c->slots_dirty && tv.size() == c->last_tables.size() && ev.size() == c->last_epochs.size() &&
+                    (tv.empty() || !memcmp(tv.data(), c->last_tables.data(), tv.size() * sizeof(DevTable))) &&
+                    (ev.empty() || !memcmp(ev.data(), c->last_epochs.data(), ev.size() * sizeof(DevEpoch)));
+  if (!same) {  // rare: table states, the cache timeline or the slots changed
+    if (!b->pending) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; }
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, c->d_tables.ensure(tv.size() * sizeof(DevTable) + 16));
+    HIPCHK(c, c->d_epochs.ensure(ev.size() * sizeof(DevEpoch) + 16));
+    if (!tv.empty()) HIPCHK(c, hipMemcpy(c->d_tables.p, tv.data(), tv.size() * sizeof(DevTable), hipMemcpyHostToDevice));
+    if (!ev.empty()) HIPCHK(c, hipMemcpy(c->d_epochs.p, ev.data(), ev.size() * sizeof(DevEpoch), hipMemcpyHostToDevice));
+    c->last_tables = tv; c->last_epochs = ev; c->side_valid = true;
+    HIPCHK(c, sync_slots(c));
+    // ---- the fixed-width plan (plan.hip): tables the apply worker owns outright, Ready for the whole batch, whose
+    //      replicated columns are all bool / int2 / int4 / int8 / oid
+    std::vector<PlanTab> pt;
+    std::vector<uint32_t> pc;
+    if (ev.empty() && c->worker == ETLG_WORKER_APPLY) {
+      for (const DevTable& t : tv) {  // tv is sorted by table id
+        if (t.state_kind != ETLG_TS_READY || t.init_kind != 2u || t.init_slot < 0 || (size_t)t.init_slot >= c->slots.size()) continue;
+        const SlotHost& sh = *c->slots[(size_t)t.init_slot];
+        bool ok = sh.desc.n_cols > 0;
+        for (auto& sc : sh.cols) {
+          const int32_t k = sc.type_class;
+          if (!(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32)) ok = false;
+        }
+        if (!ok) continue;
+        PlanTab e{};
+        e.rel_id = t.table_id; e.slot = (uint32_t)t.init_slot; e.n_cols = sh.desc.n_cols; e.row_dwords = sh.desc.row_bytes_full / 4;
+        e.cols_base = (uint32_t)pc.size();
+        for (auto& sc : sh.cols) pc.push_back((uint32_t)sc.type_class | ((uint32_t)(sc.nullable ? 1 : 0) << 8) | ((uint32_t)sc.off_full << 16));
+        pt.push_back(e);
+      }
+    }
+    HIPCHK(c, c->d_ptabs.ensure(pt.size() * sizeof(PlanTab) + 16)); HIPCHK(c, c->d_pcols.ensure(pc.size() * 4 + 16));
+    if (!pt.empty()) HIPCHK(c, hipMemcpy(c->d_ptabs.p, pt.data(), pt.size() * sizeof(PlanTab), hipMemcpyHostToDevice));
+    if (!pc.empty()) HIPCHK(c, hipMemcpy(c->d_pcols.p, pc.data(), pc.size() * 4, hipMemcpyHostToDevice));
+    c->n_plan_tabs = (uint32_t)pt.size();
+    c->plan_max_row = 16;
+    for (auto& e : pt) c->plan_max_row = std::max<uint32_t>(c->plan_max_row, e.row_dwords * 4);
+    // every table state the batch can meet must be covered by the plan for it to be worth trying: a table that is not
+    // eligible but owned (a TEXT column, say) would fail every batch that carries its rows
+    c->plan_covers_all = !pt.empty();
+    for (const DevTable& t : tv) if (t.state_kind != ETLG_TS_ABSENT && t.state_kind != ETLG_TS_OTHER) {
+      bool found = false;
+      for (auto& e : pt) if (e.rel_id == t.table_id) found = true;
+      if (!found) c->plan_covers_all = false;
+    }
+  }
+  p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)tv.size();
+  p.n_epochs = (uint32_t)ev.size();
+  b->any_sync_done = false;
+  for (auto& t : tv) if (t.state_kind == ETLG_TS_SYNC_DONE) b->any_sync_done = true;
+  p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
+  p.n_slots = c->n_dev_slots; p.n_cols = c->n_dev_cols;
+  return ETLG_OK;
+}
+
+// Output arrays (capacity bounds: one event per frame; rows bounded by the widest slot; truncate bodies by 2x frame bytes;
+// heap by 2.5x input). Called again when the control path created wider slots.
+int32_t setup_outputs(etlg_ctx* c, etlg_batch* b) {
+  DecParams& p = b->params;
+  if (!b->dev) b->dev = take_outset(c);
+  OutSet* os = b->dev;
+  const uint32_t nf = p.nframes;
+  const size_t evcap = (size_t)nf + 16;
+  const uint64_t fixed_cap = (uint64_t)nf * max_row_bytes(c) + 2 * (uint64_t)b->len + 64;
+  const uint64_t heap_cap = std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)b->len * 5 / 2 + 64);
+  HIPCHK(c, os->kind.ensure(evcap)); HIPCHK(c, os->flags.ensure(evcap));
+  HIPCHK(c, os->table.ensure(evcap * 4)); HIPCHK(c, os->slot.ensure(evcap * 4));
+  HIPCHK(c, os->start.ensure(evcap * 8)); HIPCHK(c, os->commit.ensure(evcap * 8));
+  HIPCHK(c, os->ord.ensure(evcap * 8)); HIPCHK(c, os->body.ensure(evcap * 8));
+  HIPCHK(c, os->fixed.ensure(fixed_cap)); HIPCHK(c, os->heap.ensure(heap_cap));
+  p.ev_kind = (uint8_t*)os->kind.p; p.ev_flags = (uint8_t*)os->flags.p; p.ev_table = (uint32_t*)os->table.p; p.ev_slot = (uint32_t*)os->slot.p;
+  p.ev_start = (uint64_t*)os->start.p; p.ev_commit = (uint64_t*)os->commit.p; p.ev_ord = (uint64_t*)os->ord.p; p.ev_body = (uint64_t*)os->body.p;
+  p.fixed = (uint8_t*)os->fixed.p; p.heap = (uint8_t*)os->heap.p; p.fixed_cap = fixed_cap; p.heap_cap = heap_cap;
+  return ETLG_OK;
+}
+
+// Should this batch try the fixed-width plan first?
+bool plan_wanted(etlg_ctx* c, const etlg_batch* b) {
+  const DecParams& p = b->params;
+  if (c->plan_mode == 0 || (c->fused_kernel >= 0 && c->fused_kernel != 3)) return false;  // ETLG_PLAN=0 / a forced generic kernel
+  if (!c->n_plan_tabs || !c->plan_covers_all || p.n_epochs || (p.flags & 2u) || c->worker != ETLG_WORKER_APPLY) return false;
+  if (p.nframes >= (1u << 29) || p.fixed_cap >= (1ull << 34) || c->fused_dbg) return false;   // descriptor: mark 30 bits, fixed dwords 32 bits
+  if (c->plan_max_row > 512) return false;   // 64 rows of the widest table sit in LDS beside the staging window
+  if (c->fused_kernel == 3) return true;
+  if (c->plan_skip) { c->plan_skip--; return false; }  // backing off after a batch that did not conform
+  return true;
+}
+
+// Look-back descriptor buffers: two, each single-pass launch uses one and zeroes the head of the other for the next batch,
+// so the stream carries no memset between kernels (only when a buffer grows or a larger batch left a tail).
+int32_t take_descriptors(etlg_ctx* c, size_t dbytes, uint8_t** cur_out, uint8_t** oth_out) {
+  hipStream_t s = c->stream;
+  if (dbytes > c->desc_half) {
+    const size_t half = (dbytes * 2 + 4095) & ~(size_t)4095;
+    HIPCHK(c, hipStreamSynchronize(s));   // earlier launches may still be using the old buffer
+    HIPCHK(c, c->d_desc.ensure(half * 2));
+    HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, half * 2, s));
+    c->desc_half = half; c->desc_dirty[0] = c->desc_dirty[1] = 0;
+  }
+  const uint32_t cur = c->desc_cur, oth = cur ^ 1u;
+  uint8_t* dcur = (uint8_t*)c->d_desc.p + cur * c->desc_half;
+  uint8_t* doth = (uint8_t*)c->d_desc.p + oth * c->desc_half;
+  if (c->desc_dirty[cur]) { HIPCHK(c, hipMemsetAsync(dcur, 0, c->desc_dirty[cur], s)); c->desc_dirty[cur] = 0; }
+  c->desc_dirty[cur] = dbytes;                                   // this launch writes it
+  if (c->desc_dirty[oth] <= dbytes) c->desc_dirty[oth] = 0;       // ... and clears that much of the other one
+  c->desc_cur = oth;
+  *cur_out = dcur; *oth_out = doth;
+  return ETLG_OK;
+}
+
+// Enqueues ONE single-pass kernel over the batch: level 0 = the fixed-width plan (plan.hip), level 1 = the generic fused
+// kernel (fused.hip) or, for wide frames, the column-parallel one (cells.hip).
+int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
+  const DecParams& p = b->params;
+  const uint32_t nf = p.nframes;
+  const uint64_t avg = (b->len + nf - 1) / nf;
+  b->level = level;
+  if (level == 0) {
+    PlanParams& q = c->pq;
+    q.ntiles = (nf + 63) / 64;
+    uint64_t cap = 64 * avg * (100 + (uint64_t)c->plan_margin_pct) / 100 + 128;
+    cap = std::min<uint64_t>((cap + 127) & ~127ull, 48 * 1024);
+    q.rows_off = (uint32_t)std::max<uint64_t>(cap, 2048 + 64);        // the staging window (a tile read in place parks 64 x 32-byte bodies there)
+    // rows of up to 8 dwords wait for the look-back inside their own frame's staged head; wider tables get a region of 64 rows
+    q.lds_bytes = q.rows_off + (c->plan_max_row > 32 ? (uint32_t)(64ull * c->plan_max_row + 64) : 0u);
+    q.n_tabs = c->n_plan_tabs; q.tabs = (const PlanTab*)c->d_ptabs.p; q.cols = (const uint32_t*)c->d_pcols.p;
+    q.dbg = c->plan_dbg;
+    const size_t per = 2 * (size_t)q.ntiles + ((size_t)q.ntiles + 63) / 64;   // desc[ntiles] | gdesc[ngroups] | dlsn[ntiles]
+    const size_t dbytes = per * 8 + 64;
+    uint8_t *dcur, *doth;
+    { const int32_t rc = take_descriptors(c, dbytes, &dcur, &doth); if (rc != ETLG_OK) return rc; }
+    q.desc = (unsigned long long*)dcur;
+    q.d_clear = (unsigned long long*)doth; q.clear_words = (uint32_t)(dbytes / 8);
+    launch(c, kPlan, p);
+    b->used_fused = true; b->used_cells = false;
+    return ETLG_OK;
+  }
+  FusedParams& q = c->fq;
+  const uint64_t side = (uint64_t)p.n_tables * sizeof(DevTable) + (uint64_t)p.n_epochs * sizeof(DevEpoch) +
+                        (uint64_t)p.n_slots * sizeof(DevSlot) + (uint64_t)p.n_cols * sizeof(DevCol);
+  q.side_bytes = (side <= 8192 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
+  // kernel choice: narrow frames -> one lane per frame, 256 frames per tile (k_fused); wide frames ->
+  // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 16 columns)
+  uint32_t widest = 1;
+  for (auto& sl : c->slots) widest = std::max<uint32_t>(widest, sl->desc.n_cols);
+  const bool cells_ok = widest <= etlg_k_cells_maxc() && q.side_bytes != 0;  // k_cells keeps the side tables in LDS
+  int kernel = avg <= 192 ? 0 : (cells_ok ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
+  if (c->fused_kernel >= 0 && c->fused_kernel <= 2) kernel = c->fused_kernel == 2 && !cells_ok ? 1 : c->fused_kernel;
+  const bool use_cells = kernel == 2;
+  q.blk = kernel == 0 ? 256u : 64u;
+  q.maxc = widest;
+  // LDS window per tile: the average tile plus a margin; a tile that does not fit reads the input in place
+  uint64_t cap = kernel == 1 ? (uint64_t)q.blk * avg * 5 / 4 + 2048 : (uint64_t)q.blk * avg * 9 / 8 + 1024;
+  if (const char* lm = getenv("ETLG_LDS_MARGIN_PCT")) cap = (uint64_t)q.blk * avg * (100 + (uint64_t)atoi(lm)) / 100 + 1024;
+  cap = (cap + 255) & ~255ull;
+  if (use_cells) cap += etlg_k_cells_table_bytes(widest);
+  cap = std::min<uint64_t>(cap + q.side_bytes, 150 * 1024);
+  q.lds_bytes = (uint32_t)cap;
+  q.seq_lookback = (b->any_sync_done || (c->fused_dbg & 32)) ? 1u : 0u;
+  q.ntiles = (nf + q.blk - 1) / q.blk;
+  q.in_aligned = ((uintptr_t)p.in & 15) == 0;
+  q.dbg = c->fused_dbg;
+  const size_t ngroups = (q.ntiles + 63) / 64;
+  const size_t per = (size_t)q.ntiles + ngroups;  // tile descriptors followed by group descriptors
+  const size_t dbytes = per * 8 * 3 + 64;
+  uint8_t *dcur, *doth;
+  { const int32_t rc = take_descriptors(c, dbytes, &dcur, &doth); if (rc != ETLG_OK) return rc; }
+  q.d_txn = (unsigned long long*)dcur; q.d_outa = q.d_txn + per; q.d_outb = q.d_outa + per;
+  q.ticket = (uint32_t*)(q.d_outb + per);
+  q.d_clear = (unsigned long long*)doth; q.clear_words = (uint32_t)(dbytes / 8);
+  launch(c, use_cells ? kCells : kFused, p);
+  b->used_fused = true;
+  b->used_cells = use_cells;
+  return ETLG_OK;
+}
+
+// The control pre-pass: classify + transaction scan + compaction of the R / M frames, one host round trip, then the host
+// control plane (handle_relation / handle_ddl) in frame order. Fills b->ctrl / ctrl_raw, `eps`, the host error of the batch.
+int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps) {
+  DecParams& p = b->params;
+  hipStream_t s = c->stream;
+  const uint32_t nf = p.nframes;
+  b->snapshot = c->cs; b->have_snapshot = true;
+  b->ctrl.clear(); b->ctrl_raw.clear();
+  b->host_err_code = 0; b->host_err_frame = -1; b->host_err_rank = 0;
+  b->ctrl_done = true;
+  if (!nf) return ETLG_OK;
+  { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
+  launch(c, 0, p);
+  launch(c, 1, p);
+  HIPCHK(c, c->d_ctrl.ensure((size_t)nf * sizeof(CtrlFrame) + 64));
+  p.ctrl = (CtrlFrame*)c->d_ctrl.p; p.ctrl_cap = nf;
+  launch(c, 2, p);
+  HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  const uint32_t nctrl = b->h_res->n_ctrl;
+  if (!nctrl) return ETLG_OK;
+  std::vector<CtrlFrame>& ctrl = b->ctrl;
+  ctrl.resize(nctrl);
+  HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
+  std::sort(ctrl.begin(), ctrl.end(), [](const CtrlFrame& a, const CtrlFrame& b2) { return a.frame < b2.frame; });
+  const bool offs_dev_only = b->host_offs == nullptr;  // no host copy of the offsets exists
+  std::vector<uint8_t> tmp;
+  for (const CtrlFrame& cf : ctrl) {
+    uint32_t o0, o1;
+    if (offs_dev_only) {
+      uint32_t oo[2];
+      HIPCHK(c, hipMemcpy(oo, p.offs + cf.frame, 8, hipMemcpyDeviceToHost));
+      o0 = oo[0]; o1 = oo[1];
+    } else { o0 = b->host_offs[cf.frame]; o1 = b->host_offs[cf.frame + 1]; }
+    if (b->in_dev) {
+      tmp.resize(o1 - o0);
+      HIPCHK(c, hipMemcpy(tmp.data(), b->dev_in + o0, o1 - o0, hipMemcpyDeviceToHost));
+    }
+    const uint8_t* fr = b->in_dev ? tmp.data() : b->host_in + o0;
+    const size_t flen = o1 - o0;
+    b->ctrl_raw.emplace_back(fr, fr + flen);
+    // classify guaranteed 'd' len 'w' hdr tag: body starts at +31
+    uint64_t wal_start = 0;
+    for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
+    HostErr he = cf.tag == 'R' ? handle_relation(c, cf, fr + 31, flen - 31, eps) : handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
+    if (he.code) { b->host_err_code = he.code; b->host_err_frame = cf.frame; b->host_err_rank = he.rank; p.host_err_frame = cf.frame; break; }
+  }
+  return ETLG_OK;
+}
+
+// The path that knows about control frames: control pre-pass (unless the caller asserted there are none), side inputs with
+// the batch's own epochs, then the generic single-pass kernel or — forced, oversized, or behind a host error — the
+// multi-pass kernels. Synchronous callers only (immediate carry).
+int32_t standard_path(etlg_ctx* c, etlg_batch* b) {
+  DecParams& p = b->params;
+  const uint32_t nf = p.nframes;
+  std::vector<EpochRec> eps;
+  p.flags &= ~1u;
+  if (b->user_no_ctrl) p.flags |= 1u;
+  else { const int32_t rc = run_control_pass(c, b, eps); if (rc != ETLG_OK) return rc; c->path_n[6]++; }
+  b->eps_saved = eps;
+  { const int32_t rc = build_side_inputs(c, b, eps); if (rc != ETLG_OK) return rc; }
+  { const int32_t rc = setup_outputs(c, b); if (rc != ETLG_OK) return rc; }
+  if (nf && !b->host_err_code && !c->force_multipass && b->len < (1ull << 31)) return enqueue_single(c, b, 1);
+  { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
+  launch_multipass(c, p, b->ctrl_done && nf != 0);
+  b->level = 2; b->used_fused = false; b->used_cells = false;
+  return ETLG_OK;
+}
+
+// Finishes every pending ASYNC batch, oldest first.
+int32_t drain_pending(etlg_ctx* c) {
+  while (!c->pending.empty()) { const int32_t rc = finish_batch(c, c->pending.front()); (void)rc; }
+  return ETLG_OK;
+}
+
+// Finishes one batch: waits for its result block; when the optimistic attempt did not hold, decodes the batch again on
+// the next path (plan -> generic single pass -> control path / multi-pass exact error cut); resolves device vs host
+// error, commits or rolls back the control-plane state, updates the carried transaction state of the context and (for
+// host output) copies the arenas back. Batches finish in issue order.
+int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
+  hipStream_t s = c->stream;
+  if (b->pending) {  // must be the oldest pending batch
+    if (c->pending.empty() || c->pending.front() != b) return lib_error(c, ETLG_InvalidArgument, "ASYNC batches must be synced in issue order");
+    c->pending.erase(c->pending.begin());
+  }
+  auto fail_hip = [&](hipError_t e) {
+    b->pending = false; b->finished = true;
+    b->rc = lib_error(c, ETLG_DeviceError, hipGetErrorString(e));
+    b->err = c->err; b->err_detail.clear();
+    return b->rc;
+  };
+#define FB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip(e_); } while (0)
+#define FB_RC(call) do { const int32_t rc_ = (call); if (rc_ != ETLG_OK) { b->pending = false; b->finished = true; b->rc = rc_; b->err = c->err; return rc_; } } while (0)
+  FB_HIP(hipStreamSynchronize(s));
+  bool redone_mp = false;
+  for (int guard = 0; guard < 8; guard++) {
+    const DevResult& r0 = *b->h_res;
+    const bool failed = r0.first_err != kNoErr || r0.fused_fail;
+    const bool ctrl_hint = r0.first_err != kNoErr && (uint32_t)(r0.first_err & 0xFF) == ETLG_E_CTRL_HINT && !b->user_no_ctrl && !b->ctrl_done;
+    if (!failed || (b->level == 2 && !ctrl_hint)) break;
+    // ---- decode again. Every earlier batch is finished, so the host's carried state is exact: no device chaining.
+    DecParams& p = b->params;
+    p.carry = nullptr;
+    p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
+    const uint32_t ff = r0.fused_fail;
+    FB_HIP(hipMemcpyAsync(b->d_res_blk, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    if (b->copy.active) launch_copy(c, b->copy, p);
+    if (ff & 8u) {  // the batch before this one failed, so this one never ran: same path again, now from the right state
+      c->path_n[7]++;
+      FB_RC(build_side_inputs(c, b, std::vector<EpochRec>()));
+      FB_RC(enqueue_single(c, b, b->level));
+    } else if (b->level == 0) {  // the fixed-width plan did not cover the batch: generic kernel, and back off
+      c->path_n[5]++;
+      c->plan_skip = c->plan_penalty; c->plan_penalty = std::min<uint32_t>(c->plan_penalty * 2, 4096); c->plan_streak = 0;
+      FB_RC(build_side_inputs(c, b, std::vector<EpochRec>()));
+      FB_RC(enqueue_single(c, b, 1));
+    } else if (ctrl_hint && !(ff & 1u)) {
+      FB_RC(standard_path(c, b));  // a Relation / DDL frame: the control path
+    } else {  // an error (or a look-back give-up): the multi-pass kernels know the exact cut at the failing frame
+      FB_RC(build_side_inputs(c, b, b->eps_saved));
+      FB_RC(setup_scratch(c, p));
+      launch_multipass(c, p, false);
+      b->level = 2; b->used_fused = false;
+      c->path_n[3]++; redone_mp = true;
+    }
+    FB_HIP(hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+    FB_HIP(hipStreamSynchronize(s));
+  }
+  if (b->level == 0) { c->path_n[4]++; if (++c->plan_streak >= 16) c->plan_penalty = 4; }
+  else if (b->used_fused) c->path_n[b->used_cells ? 1 : 0]++;
+  else if (!redone_mp) c->path_n[2]++;
   DevResult r = *b->h_res;
   if (b->used_fused) for (int k = 0; k < 3; k++) { r.payload[k] = 0; for (int sh = 0; sh < 32; sh++) r.payload[k] += r.pay_shard[sh][k]; }
   for (int i = 0; i < 12; i++) c->last_dbg[i] = r.dbg_t[i];
@@ -1437,7 +1688,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
   // ---- control-plane state: keep only effects of frames before the failing one
   if (code && b->have_snapshot) {
     bool later = false;
-    for (auto& cf : all_ctrl) if ((int64_t)cf.frame >= frame) later = true;
+    for (auto& cf : b->ctrl) if ((int64_t)cf.frame >= frame) later = true;
     if (later || b->host_err_code) {
       // roll back, then replay the prefix (rare path; errors end the stream anyway)
       c->cs = b->snapshot;
@@ -1446,8 +1697,8 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
       // Effects of the control frames before `frame` are re-applied from the copies of their bytes kept
       // by the first pass (the input itself may be device-resident, or have come without a sidecar).
       std::vector<EpochRec> eps;
-      for (size_t i = 0; i < all_ctrl.size() && i < b->ctrl_raw.size(); i++) {
-        const CtrlFrame& cf = all_ctrl[i];
+      for (size_t i = 0; i < b->ctrl.size() && i < b->ctrl_raw.size(); i++) {
+        const CtrlFrame& cf = b->ctrl[i];
         if ((int64_t)cf.frame >= frame) break;
         const uint8_t* fr = b->ctrl_raw[i].data();
         const size_t flen = b->ctrl_raw[i].size();
@@ -1460,6 +1711,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
   b->have_snapshot = false;
   b->snapshot = ControlState{};
   b->ctrl_raw.clear();
+  b->eps_saved.clear();
   c->in_txn = r.out_in_txn != 0; c->final_lsn = r.out_final_lsn; c->next_ord = r.out_next_ord;
 
   etlg_batch_view& v = b->v;
@@ -1471,13 +1723,15 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b, const std::vector<CtrlFrame>& a
   v.ev_kind = (const uint8_t*)os->kind.p; v.ev_flags = (const uint8_t*)os->flags.p; v.ev_table_id = (const uint32_t*)os->table.p; v.ev_schema_slot = (const uint32_t*)os->slot.p;
   v.ev_start_lsn = (const uint64_t*)os->start.p; v.ev_commit_lsn = (const uint64_t*)os->commit.p; v.ev_tx_ordinal = (const uint64_t*)os->ord.p; v.ev_body_off = (const uint64_t*)os->body.p;
   v.fixed = (const uint8_t*)os->fixed.p; v.heap = (const uint8_t*)os->heap.p;
-  if (!output_on_device) {
-    const int32_t rc = download_batch(c, b);
-    if (rc != ETLG_OK) return rc;
-  }
+  b->pending = false; b->finished = true;
+  if (!b->out_dev) FB_RC(download_batch(c, b));
   fill_view_common(b);
-  if (code) return set_error(c, code, frame);
-  return ETLG_OK;
+  clear_error(c);
+  b->rc = code ? set_error(c, code, frame) : (int32_t)ETLG_OK;
+  b->err = c->err; b->err_detail = c->err_detail;
+  return b->rc;
+#undef FB_HIP
+#undef FB_RC
 }
 
 }  // namespace

@@ -43,13 +43,27 @@ struct OpAdd {
 // Every word carries status + payload in ONE 64-bit value (relaxed agent-scope atomic
 // store / load), so no fence is needed; nothing depends on placement or dispatch order
 // beyond "a tile's predecessors have started" (ticket order); all spins are bounded.
+// The two halves can be called apart (plan.hip): a tile publishes its aggregate as soon as it knows it, does work that
+// does not need the prefix, and resolves afterwards — by then its predecessors' words have usually arrived.
+DEV void lookback_publish(unsigned long long* desc, uint32_t tile, uint64_t agg) {
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&desc[tile], ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class Op>
+DEV uint64_t lookback_resolve(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg, uint64_t carry, uint32_t* fail);
+
 template <class Op>
 DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg,
                       uint64_t carry, uint32_t* fail) {
-  const int lane = threadIdx.x & 63;
   if (fail == nullptr) return carry;  // ablation only
+  lookback_publish(desc, tile, agg);
+  return lookback_resolve<Op>(desc, gdesc, tile, agg, carry, fail);
+}
+
+template <class Op>
+DEV uint64_t lookback_resolve(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg,
+                              uint64_t carry, uint32_t* fail) {
+  const int lane = threadIdx.x & 63;
   const uint32_t g = tile >> 6, j = tile & 63;
-  if (lane == 0) __hip_atomic_store(&desc[tile], ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t polls = 0;
   // the first window of group descriptors is requested now, so that its round trip overlaps window 0's
   unsigned long long w1_pre = 0;

@@ -1,0 +1,437 @@
+// k_plan — the fixed-width decode plan for gfx950 (MI355X, wave64): the hot path of BASELINE cfg2.
+//
+// A batch is eligible (host.cpp, "plan") when the apply worker owns every table outright (state Ready, cache entry
+// Ready for the whole batch) and the eligible tables' schemas only hold integer / oid / bool columns. The kernel then
+// decodes Begin / Commit / Insert frames and nothing else: one WAVE per tile of 64 consecutive frames, one lane per
+// frame, no workgroup barrier anywhere.
+//
+//   1. the tile's bytes go HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA: no staging VGPRs, 1 KiB per
+//      wave-instruction, every input byte leaves HBM once); occupancy (5-8 waves per SIMD at <= 64 VGPRs and
+//      ~8 KB of LDS per wave) overlaps one wave's load with the others' parsing,
+//   2. every LDS access is an ALIGNED dword read + v_alignbyte: lanes sit at arbitrary byte offsets (113-byte
+//      frames) and a misaligned ds_read costs 3.3x an aligned one on this chip (tools/ubench/lds_align.hip;
+//      70 % of k_fused's LDS cycles were SQ_LDS_UNALIGNED_STALL),
+//   3. sizes are schema constants, so ONE 64-bit look-back descriptor per tile carries everything a tile needs from
+//      its predecessors: {last Begin/Commit mark : 30, fixed-arena dwords : 32}. Events are one per frame (the event
+//      prefix is the frame index), the heap is empty, ordinals follow from frame indexes (every frame of a
+//      conforming batch consumes one: apply.rs:2284-2292, 2339, 2457),
+//   4. integers are parsed from a right-aligned 12- or 20-byte field, four digits per 32-bit word (SWAR).
+//
+// Anything else — another tag, a table that is not eligible, a NULL in a NOT NULL column, text the lean parser does
+// not take (a long run of leading zeros), a malformed frame, a transaction-state violation — sets
+// DevResult.fused_fail bit 1: nothing of the batch is trusted and the host decodes it again with the generic
+// kernels (fused.hip / cells.hip, then kernels.hip for the exact error cut). Errors end the stream in the reference
+// (apply.rs:2475-2481), so that path is cold.
+//
+// Reference work replaced per row: LogicalReplicationMessage::parse (postgres-replication 0.6.7), handle_insert_message
+// (apply.rs:2443-2491), convert_tuple_to_row (codec/event.rs:554-587), parse_cell_from_postgres_text for
+// INT2/INT4/INT8/OID/BOOL (codec/text.rs:35-51,135-138, codec/bool.rs:11-19), payload accounting (codec/event.rs:261-297).
+#include "lookback.hip.h"
+
+namespace etlg {
+
+// ---- aligned readers: `off` is a byte offset into the tile's window
+struct WinLds {  // the staged tile; window byte 0 sits at a 16-byte aligned LDS address
+  const ETLG_LDS_AS u8* base;
+  DEV uint32_t w(uint32_t aoff) const { return ETLG_LDS_LD32(base + aoff); }
+};
+struct WinGlb {  // a tile that does not fit its LDS window reads the input in place (window byte 0 = input byte 0)
+  const u8* base; uint32_t lim;
+  DEV uint32_t w(uint32_t aoff) const {
+    uint32_t v = 0;
+    if (aoff + 4 <= lim) __builtin_memcpy(&v, base + aoff, 4);
+    else for (uint32_t k = 0; aoff + k < lim; k++) v |= (uint32_t)base[aoff + k] << (8 * k);
+    return v;
+  }
+};
+template <class M> DEV uint32_t rd32(const M& m, uint32_t off) {
+  const uint32_t a = off & ~3u, s = off & 3u;
+  return __builtin_amdgcn_alignbyte(m.w(a + 4), m.w(a), s);
+}
+template <class M> DEV uint64_t rd64(const M& m, uint32_t off) {
+  const uint32_t a = off & ~3u, s = off & 3u;
+  const uint32_t w0 = m.w(a), w1 = m.w(a + 4), w2 = m.w(a + 8);
+  return __builtin_amdgcn_alignbyte(w1, w0, s) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, s) << 32);
+}
+DEV uint64_t bswap64(uint64_t v) { return __builtin_bswap64(v); }
+
+// Four ASCII digits, most significant in byte 0 (codec.hip.h digits4 without the flag plumbing): value, and a
+// non-zero `bad` accumulator when a byte is not a digit.
+DEV uint32_t dig4(uint32_t w, uint32_t& bad) {
+  const uint32_t t = w - 0x30303030u;
+  bad |= ((w + 0x46464646u) | t) & 0x80808080u;
+  const uint32_t p = (t * 10u + (t >> 8)) & 0x00FF00FFu;
+  return (p & 0xFFu) * 100u + (p >> 16);
+}
+// Word j of a field whose first k bytes are replaced by '0' (the text is right-aligned in the field). Branch-free.
+DEV uint32_t pad_word(uint32_t w, uint32_t k, uint32_t j) {
+  const int32_t sh = (int32_t)k - (int32_t)(4 * j);  // bytes of this word to replace, from byte 0
+  const uint32_t part = 0xFFFFFFFFu << (8 * ((uint32_t)sh & 3u));
+  const uint32_t keep = sh <= 0 ? 0xFFFFFFFFu : sh >= 4 ? 0u : part;
+  return (w & keep) | (0x30303030u & ~keep);
+}
+
+// Rust iN::from_str / u32::from_str (codec/text.rs:40-51, 135-138) on the text [cs, cs + n) of the window, first
+// character c0 already in hand. Straight-line code (every lane of the wave runs it, whatever its cell holds): takes
+// what fits a 12-byte (32-bit classes) / 20-byte (int8) field and returns ok = 0 for everything else, INCLUDING every
+// error — the generic kernels decide what a rejected text means. `cls` is wave-uniform.
+template <class M>
+DEV uint64_t plan_int(const M& m, uint32_t cs, uint32_t n, uint32_t c0, uint32_t cls, uint32_t& ok) {
+  const uint32_t neg = c0 == '-' ? 1u : 0u;
+  const uint32_t sg = (c0 == '-' || c0 == '+') ? 1u : 0u;
+  const uint32_t nd = n - sg;  // digits
+  uint32_t bad = 0;
+  uint64_t mag;
+  if (cls == ETLG_TC_I64) {
+    const uint32_t nn = n < 20u ? n : 20u;   // the field never leaves the window, whatever the length says
+    const uint32_t s0 = cs + nn - 20u, a = s0 & ~3u, s = s0 & 3u, k = 20u - (nd < 20u ? nd : 20u);
+    const uint32_t w0 = m.w(a), w1 = m.w(a + 4), w2 = m.w(a + 8), w3 = m.w(a + 12), w4 = m.w(a + 16), w5 = m.w(a + 20);
+    const uint32_t d0 = dig4(pad_word(__builtin_amdgcn_alignbyte(w1, w0, s), k, 0), bad);
+    const uint32_t d1 = dig4(pad_word(__builtin_amdgcn_alignbyte(w2, w1, s), k, 1), bad);
+    const uint32_t d2 = dig4(pad_word(__builtin_amdgcn_alignbyte(w3, w2, s), k, 2), bad);
+    const uint32_t d3 = dig4(pad_word(__builtin_amdgcn_alignbyte(w4, w3, s), k, 3), bad);
+    const uint32_t d4 = dig4(pad_word(__builtin_amdgcn_alignbyte(w5, w4, s), k, 4), bad);
+    mag = (uint64_t)(d0 * 10000u + d1) * 1000000000000ull + (uint64_t)(d2 * 10000u + d3) * 10000ull + d4;  // nd <= 19: d0 <= 999, < 10^19
+    const uint64_t lim = neg ? (1ull << 63) : (1ull << 63) - 1;
+    ok = (n != 0u) & (nd != 0u) & (n <= 20u) & (nd <= 19u) & (bad == 0u) & (mag <= lim);
+  } else {
+    const uint32_t nn = n < 12u ? n : 12u;
+    const uint32_t s0 = cs + nn - 12u, a = s0 & ~3u, s = s0 & 3u, k = 12u - (nd < 12u ? nd : 12u);
+    const uint32_t w0 = m.w(a), w1 = m.w(a + 4), w2 = m.w(a + 8), w3 = m.w(a + 12);
+    const uint32_t d0 = dig4(pad_word(__builtin_amdgcn_alignbyte(w1, w0, s), k, 0), bad);
+    const uint32_t d1 = dig4(pad_word(__builtin_amdgcn_alignbyte(w2, w1, s), k, 1), bad);
+    const uint32_t d2 = dig4(pad_word(__builtin_amdgcn_alignbyte(w3, w2, s), k, 2), bad);
+    mag = (uint64_t)d0 * 100000000ull + (d1 * 10000u + d2);   // nd <= 11: d0 <= 999
+    uint64_t lim;
+    if (cls == ETLG_TC_U32) lim = 0xFFFFFFFFull;              // a '-' is rejected below: "-0" is an error for u32::from_str
+    else if (cls == ETLG_TC_I16) lim = neg ? 0x8000ull : 0x7FFFull;
+    else lim = neg ? 0x80000000ull : 0x7FFFFFFFull;
+    ok = (n != 0u) & (nd != 0u) & (n <= 12u) & (nd <= 11u) & (bad == 0u) & (mag <= lim) & ((cls != ETLG_TC_U32) | (neg ^ 1u));
+  }
+  return neg ? 0 - mag : mag;
+}
+
+// Binary search of the (rel_id-sorted) plan tables with a wave-uniform key: scalar loads only.
+DEV int plan_find(const PlanParams& q, uint32_t rel_u) {
+  const ETLG_CONST_AS uint32_t* t = (const ETLG_CONST_AS uint32_t*)(uintptr_t)q.tabs;
+  int lo = 0, hi = (int)q.n_tabs - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const uint32_t v = t[mid * (int)(sizeof(PlanTab) / 4)];
+    if (v == rel_u) return mid;
+    if (v < rel_u) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+// ETLG_PLAN_DBG bit 5: per-phase shader-clock sums of one tile in 16 (lane 0), in DevResult.dbg_t[k]
+// ETLG_PLAN_DBG bit 6: wall-clock (100 MHz, chip-wide) timeline of EVERY tile into the (otherwise unused) heap arena: 8 x u64 per tile
+#define WSTAMP(k) do { if ((q.dbg & 64u) && threadIdx.x == 0) ((unsigned long long*)p.heap)[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+// ETLG_PLAN_DBG bit 5: per-phase shader-clock sums of one tile in 16 (lane 0), in DevResult.dbg_t[k]
+#define PSTAMP(k) do { if ((q.dbg & 32u) && threadIdx.x == 0 && (blockIdx.x & 15u) == 3u) { const unsigned long long t_ = clock64(); atomicAdd(&p.res->dbg_t[k], t_ - tprev); tprev = t_; } } while (0)
+
+// ---- the plan's look-back --------------------------------------------------------------------------------------------
+// What a tile needs from the tiles before it: the sum of their fixed-arena dwords and the last Begin / Commit mark, ONE
+// 64-bit descriptor {mark : 30 | fixed dwords : 32} in the two-level decoupled look-back of lookback.hip.h, plus the LSN
+// of the Begin that is open when the tile starts: dlsn[t] = VALID | LSN:62 of tile t's last Begin, a second self-validating
+// word per tile, read with one dependent load once the mark says which tile holds that Begin.
+// A round trip to another CU's words costs 1.5-2 us on this chip (agent-scope loads are served past the per-XCD L2s), so
+// the order of work matters more than the instruction count: a tile PUBLISHES as soon as it has read its message heads,
+// decodes its rows into LDS while its predecessors' words travel, and only then resolves. The last tile of a group of 64
+// resolves right away instead: it is the one that folds the group descriptor the groups behind it are waiting for.
+struct OpPlan {  // payload: hi 30 bits = running max of transaction marks, lo 32 bits = sum of fixed-arena dwords
+  DEV static uint64_t id() { return 0; }
+  DEV static uint64_t f(uint64_t a, uint64_t b) {
+    const uint32_t ma = (uint32_t)(a >> 32), mb = (uint32_t)(b >> 32);
+    return ((uint64_t)(ma > mb ? ma : mb) << 32) | (uint32_t)((uint32_t)a + (uint32_t)b);
+  }
+};
+constexpr unsigned long long kValid = 1ull << 62;
+constexpr uint32_t kPlanMaxPolls = 1u << 15;   // bounded spin (tens of milliseconds): a give-up sends the batch to the generic kernels
+
+template <class M>
+DEV void plan_tile(const DecParams& p, const PlanParams& q, const M& m, u8* rows, bool stage_own, uint32_t a0, uint32_t tile, uint32_t nt, uint32_t my_o,
+                   uint32_t span0, uint32_t span1, unsigned long long tprev) {
+  const uint32_t lane = threadIdx.x;
+  const bool live = lane < nt;
+  const uint32_t f = tile * 64u + lane;
+  uint32_t* failp = &p.res->fused_fail;
+  uint32_t bad = 0;  // non-zero: this lane saw something the plan does not cover (accumulated bitwise: straight-line code)
+
+  // ---- (1) what the look-back needs, as early as possible: tag + table of every frame -> tile aggregate -> publish
+  const uint32_t o0 = my_o;
+  const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp((int)span1, (int)my_o, 0x130, 0xF, 0xF, false);  // wave_shl:1 — the next lane's offset
+  const uint32_t flen = o1 - o0;
+  const uint32_t sane = (live ? 1u : 0u) & (o1 > o0) & (o0 >= span0) & (o1 <= span1) & (flen >= 38u);
+  bad |= (live ? 1u : 0u) & (sane ^ 1u);
+  const uint32_t fr = sane ? o0 - a0 : 0u;  // window offset of the frame (a lane without a sane frame reads offset 0)
+  const uint64_t h30 = rd64(m, fr + 30);    // tag | rel:4 | 'N' | ncols:2  (Insert)
+  const uint32_t tag = (uint32_t)(h30 & 0xFF);
+  const uint32_t rel = __builtin_bswap32((uint32_t)(h30 >> 8));
+  const uint32_t ncols = ((uint32_t)(h30 >> 48) & 0xFFu) << 8 | (uint32_t)(h30 >> 56);
+  bad |= sane & (uint32_t)(tag != 'I' && tag != 'B' && tag != 'C');
+  const bool isI = sane && tag == 'I', isB = sane && tag == 'B', isC = sane && tag == 'C';
+  // table of every Insert lane: one scalar lookup per distinct table of the wave (descriptors through the scalar cache)
+  int ti = -1;
+  uint32_t row_dw = 0, slot_id = 0, want_cols = 0;
+  {
+    unsigned long long todo = __ballot(isI);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t rel_u = (uint32_t)__builtin_amdgcn_readlane((int)rel, leader);
+      const int t_u = plan_find(q, rel_u);
+      const bool mine = isI && rel == rel_u;
+      if (t_u >= 0) {
+        const ETLG_CONST_AS uint32_t* tw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(q.tabs + t_u);
+        const uint32_t s_u = tw[1], n_u = tw[2], r_u = tw[3];
+        if (mine) { ti = t_u; slot_id = s_u; want_cols = n_u; row_dw = r_u; }
+      }
+      todo &= ~__ballot(mine);
+    }
+  }
+  bad |= (uint32_t)(isI && (ti < 0 || ncols != want_cols));  // "Tuple data field count does not match schema" is the generic path's to report
+  uint64_t b_lsn = 0;  // Begin: final_lsn; Commit: commit_lsn
+  if (isB) b_lsn = bswap64(rd64(m, fr + 31));
+  if (isC) b_lsn = bswap64(rd64(m, fr + 32));
+  const uint32_t fixed_dw = isI ? row_dw : isB ? 2u : isC ? 4u : 0u;
+  const uint32_t mark = isB ? (((f + 1) << 1) | 1u) : isC ? ((f + 1) << 1) : 0u;
+  const uint32_t im = wave_scan_max(mark);
+  const uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)im, 0x138, 0xF, 0xF, false);  // wave_shr:1: exclusive running max
+  const uint32_t ifx = wave_scan_add(fixed_dw);
+  const uint32_t tot_mark = wave_last(im), tot_fx = wave_last(ifx);
+  const uint32_t x_fx = ifx - fixed_dw;
+  uint64_t tile_lsn = 0;  // LSN of the tile's last Begin, when its last mark is one
+  if (tot_mark & 1u) {
+    const int src = (int)((tot_mark >> 1) - 1u - tile * 64u);
+    tile_lsn = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b_lsn >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b_lsn, src);
+    bad |= (uint32_t)((tile_lsn >> 62) != 0);   // the LSN word keeps two bits for its own validity: such an LSN goes the generic way
+    tile_lsn &= ~(3ull << 62);
+  }
+  PSTAMP(2);
+  WSTAMP(2);
+  if (q.dbg & 4u) { if (tot_mark + tot_fx == 0xFFFFFFF1u) atomicOr(failp, 2u); return; }  // profiling: stop after the message heads
+
+  // ---- (2) publish, and while the predecessors' words travel: envelope checks, the rest of the heads, the rows into LDS
+  //      (a row only needs the tile-local offset x_fx; where the tile's block goes in the arena is the look-back's answer)
+  const uint64_t agg = ((uint64_t)tot_mark << 32) | tot_fx;
+  const uint64_t carry = (uint64_t)(p.in_txn ? 1u : 0u) << 32;  // virtual Begin before frame 0
+  if (lane == 0) {
+    unsigned long long* dlsn = q.desc + q.ntiles + ((q.ntiles + 63u) >> 6);
+    __hip_atomic_store(&dlsn[tile], kValid | tile_lsn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  lookback_publish(q.desc, tile, agg);
+  const bool early = (tile & 63u) == 63u;   // the group's folder: the groups behind it wait for what it publishes next
+  uint64_t ex = 0;
+  if (early) ex = lookback_resolve<OpPlan>(q.desc, q.desc + q.ntiles, tile, agg, carry, failp);
+  {
+    const uint64_t h0 = rd64(m, fr);        // 'd' | len:4 | 'w' | 2 bytes of wal_start
+    const uint32_t len = __builtin_bswap32((uint32_t)(h0 >> 8));
+    const uint32_t env = ((uint32_t)(h0 & 0xFF) == 'd') & (len + 1u == flen) & ((uint32_t)((h0 >> 40) & 0xFF) == 'w');
+    const uint32_t shape = tag == 'I' ? (uint32_t)((uint32_t)((h30 >> 40) & 0xFF) == 'N')
+                         : tag == 'B' ? (uint32_t)(flen >= kBodyOff + 20) : (uint32_t)(flen >= kBodyOff + 25);
+    bad |= sane & ((env & shape) ^ 1u);
+  }
+  const uint64_t wal_start = bswap64(rd64(m, fr + 6));
+  uint64_t b_ts = 0, c_end = 0;
+  uint32_t b_xid = 0, c_flags = 0;
+  if (isB) { b_ts = bswap64(rd64(m, fr + 39)); b_xid = __builtin_bswap32(rd32(m, fr + 47)); }
+  if (isC) { c_flags = (uint32_t)(h30 >> 8) & 0xFFu; c_end = bswap64(rd64(m, fr + 40)); b_ts = bswap64(rd64(m, fr + 48)); }
+  // Where a frame's body (its row; a Begin / Commit body) waits for the look-back. Up to 8 dwords fit the first 38 bytes of the
+  // frame's OWN staged bytes — the message head, which is in registers by now — so narrow tables need no LDS beyond the window
+  // (occupancy: ~20 waves per CU instead of 17). Wider rows take a separate region, at the tile-local arena offset.
+  uint32_t* rimg = q.lds_bytes > q.rows_off ? (uint32_t*)(rows + q.rows_off) + x_fx : (uint32_t*)(rows + (stage_own ? ((fr + 3u) & ~3u) : lane * 32u));
+  if (isB && !bad) { rimg[0] = (uint32_t)b_ts; rimg[1] = (uint32_t)(b_ts >> 32); }
+  if (isC && !bad) { rimg[0] = (uint32_t)c_end; rimg[1] = (uint32_t)(c_end >> 32); rimg[2] = (uint32_t)b_ts; rimg[3] = (uint32_t)(b_ts >> 32); }
+  uint32_t vbytes = 0;
+  if (!(q.dbg & 8u)) {  // profiling: bit 3 skips the cell decode
+    unsigned long long todo = __ballot(isI && !bad);
+    while (todo) {  // one pass per distinct table of the wave (one, normally): column descriptors in SGPRs
+      const int leader = __builtin_ctzll(todo);
+      const int t_u = __builtin_amdgcn_readlane(ti, leader);
+      const bool mine = isI && !bad && ti == t_u;
+      const ETLG_CONST_AS uint32_t* tw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(q.tabs + t_u);
+      const uint32_t n_u = tw[2], cb_u = tw[4];
+      const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(q.cols + cb_u);
+      if (mine) {  // ONE divergent region; inside it the loop is wave-uniform and the cell code straight-line
+        uint32_t cur = fr + 38;              // window offset of the cell being read
+        const uint32_t e = fr + flen;
+        uint32_t acc = 0, cbad = 0;
+        uint32_t cd_next = cw[0];
+        for (uint32_t i = 0; i < n_u; i++) {
+          const uint32_t cd = cd_next;  // cls | nullable << 8 | off_full << 16
+          cd_next = cw[i + 1 < n_u ? i + 1 : i];   // the next column's word travels while this cell is parsed
+          const uint32_t cls = cd & 0xFFu;
+          uint32_t* slot = rimg + (cd >> 18);
+          const uint32_t rc = cur < e ? cur : fr;   // a cursor that ran off the frame is an error below; keep the reads inside the window
+          const uint64_t ch = rd64(m, rc);          // kind | len:4 | first three characters
+          const uint32_t kind = (uint32_t)(ch & 0xFF);
+          const uint32_t len = __builtin_bswap32((uint32_t)(ch >> 8));
+          const uint32_t c0 = (uint32_t)(ch >> 40) & 0xFFu;
+          const uint32_t is_t = kind == 't', is_n = kind == 'n';
+          const uint32_t fits = (cur < e) & (is_n | (is_t & (rc + 5 <= e) & (len <= e - rc - 5)));
+          const uint32_t tl = (is_t & fits) ? len : 0u;   // text length the parsers may look at
+          uint32_t okv;
+          uint64_t v;
+          if (cls == ETLG_TC_BOOL) {  // parse_bool, codec/bool.rs:11-19
+            okv = (tl == 1u) & ((c0 == 't') | (c0 == 'f'));
+            v = c0 == 't';
+          } else {
+            v = plan_int(m, rc + 5, tl, c0, cls, okv);
+          }
+          // NULL: convert_tuple_data_to_cell, codec/event.rs:945-961; anything but 't' / 'n' ('u' in a full row, 'b', garbage) is not the plan's
+          const uint32_t good = fits & ((is_n & ((cd >> 8) & 1u)) | (is_t & okv));
+          cbad |= good ^ 1u;
+          const uint64_t val = is_t ? v : 0ull;
+          slot[0] = (uint32_t)val;
+          if (cls == ETLG_TC_I64) slot[1] = (uint32_t)(val >> 32);
+          acc |= (is_n ? (uint32_t)ETLG_CELL_NULL : (uint32_t)ETLG_CELL_VALUE) << (2 * (i & 15));
+          if ((i & 15) == 15 || i + 1 == n_u) { rimg[i >> 4] = acc; acc = 0; }
+          vbytes += tl;
+          cur = rc + (is_t ? 5u + tl : 1u);
+        }
+        bad |= cbad;
+      }
+      todo &= ~__ballot(mine);
+    }
+  }
+  PSTAMP(3);
+  WSTAMP(3);
+
+  // ---- (3) the look-back's answer
+  if (!early) ex = lookback_resolve<OpPlan>(q.desc, q.desc + q.ntiles, tile, agg, carry, failp);
+  const uint32_t pre_mark = (uint32_t)(ex >> 32);
+  const uint64_t pre_fx = (uint64_t)(uint32_t)ex << 2;  // bytes
+  uint64_t pre_lsn = p.final_lsn;   // LSN of the Begin that is open when this tile starts
+  if ((pre_mark & 1u) && (pre_mark >> 1) != 0) {  // wave-uniform: that Begin lives in an earlier tile, which published its LSN word with its descriptor
+    unsigned long long* dlsn = q.desc + q.ntiles + ((q.ntiles + 63u) >> 6);
+    const uint32_t bt = ((pre_mark >> 1) - 1u) >> 6;
+    unsigned long long ll = 0;
+    for (uint32_t polls = 0;; polls++) {
+      ll = __hip_atomic_load(&dlsn[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ll & kValid) break;
+      if (polls > kPlanMaxPolls) { if (lane == 0) atomicOr(failp, 1u); return; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    pre_lsn = ll & ~(3ull << 62);
+  }
+  PSTAMP(4);
+  WSTAMP(4);
+
+  // ---- transaction context of every frame (A2: apply.rs:2279-2617, ordinals :942-963)
+  const uint32_t last = pre_mark > pm ? pre_mark : pm;  // last Begin / Commit strictly before this frame
+  const bool in_txn = (last & 1u) != 0;
+  const uint32_t fb1 = last >> 1;                       // frame index of that Begin + 1; 0 = carried in from an earlier batch
+  uint64_t final_lsn = 0;
+  {
+    // a Begin inside this tile: its lane holds the LSN; one from an earlier tile came with the look-back (wave-uniform)
+    const bool here = in_txn && fb1 != 0 && fb1 - 1 >= tile * 64u;
+    const uint32_t src = here ? fb1 - 1 - tile * 64u : 0u;
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b_lsn, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(b_lsn >> 32), (int)src, 64);
+    if (in_txn) final_lsn = here ? (((uint64_t)hi << 32) | lo) : pre_lsn;
+  }
+  uint64_t ord = 0;
+  if (!isB && in_txn) ord = fb1 == 0 ? p.next_ord + f : (uint64_t)(f - (fb1 - 1));
+  bad |= (uint32_t)((isI || isC) && !in_txn);               // "Invalid transaction state"
+  bad |= (uint32_t)(isC && in_txn && b_lsn != final_lsn);   // "Invalid commit LSN"
+
+  // ---- totals and the carried transaction state (last tile)
+  if (tile == q.ntiles - 1 && lane == 0) {
+    DevResult* r = p.res;
+    r->n_events = p.nframes; r->fixed_bytes = pre_fx + ((uint64_t)tot_fx << 2); r->heap_bytes = 0; r->n_frames = p.nframes;
+    const uint32_t lm = pre_mark > tot_mark ? pre_mark : tot_mark;
+    const bool it = (lm & 1u) != 0;
+    r->out_in_txn = it;
+    uint64_t fl = 0, no = 0;
+    if (it) {
+      const uint32_t lb1 = lm >> 1;
+      fl = tot_mark ? tile_lsn : pre_lsn;   // marks grow with the frame index: a mark of this tile is the last one
+      no = lb1 == 0 ? p.next_ord + p.nframes : (uint64_t)(p.nframes - (lb1 - 1));
+    }
+    r->out_final_lsn = fl; r->out_next_ord = no;
+  }
+
+  // ---- (4) rows and Begin / Commit bodies: LDS -> their final place in the fixed arena
+  const uint64_t fx_off = pre_fx + ((uint64_t)x_fx << 2);
+  const uint32_t any_bad = __any(bad != 0u) ? 1u : 0u;
+  const bool cap_ok = pre_fx + ((uint64_t)tot_fx << 2) <= p.fixed_cap;
+  if (!any_bad && cap_ok && !(q.dbg & 8u)) {
+    uint32_t* dst = (uint32_t*)(p.fixed + fx_off);
+    for (uint32_t d = 0; d < fixed_dw; d++) dst[d] = rimg[d];
+  }
+  PSTAMP(5);
+  // ---- event headers (A13/A15)
+  if (live && !any_bad && cap_ok && !(q.dbg & 16u)) {  // profiling: bit 4 skips the event header stores
+    p.ev_kind[f] = (u8)tag;
+    p.ev_flags[f] = (u8)c_flags;
+    p.ev_table[f] = isB ? b_xid : isI ? rel : 0u;
+    p.ev_slot[f] = isI ? slot_id : 0u;
+    p.ev_start[f] = wal_start;
+    p.ev_commit[f] = isI ? final_lsn : b_lsn;
+    p.ev_ord[f] = ord;
+    p.ev_body[f] = fx_off;
+  }
+  PSTAMP(6);
+  WSTAMP(5);
+  // payload bytes of the tile's inserts (A3), one atomic per wave into a shard
+  const uint32_t pay = wave_last(wave_scan_add(vbytes));
+  if (lane == 0 && pay) atomicAdd(&p.res->pay_shard[tile & 31][0], (unsigned long long)pay);
+  if ((any_bad || !cap_ok) && lane == 0) atomicOr(failp, 2u);
+}
+
+__global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan(DecParams p, PlanParams q) {
+  ETLG_DYNAMIC_LDS(smem);
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tile = blockIdx.x;
+  unsigned long long tprev = (q.dbg & 32u) ? clock64() : 0ull;
+  WSTAMP(0);
+  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
+    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
+    for (uint32_t i = lane; i < per; i += 64) { const uint32_t w = tile * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
+  }
+  if (!load_carry(p)) return;  // ASYNC chain: the batch before this one left no state to start from
+  const uint32_t f0 = tile * 64u;
+  const uint32_t nt = p.nframes - f0 < 64u ? p.nframes - f0 : 64u;
+  const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)p.offs;
+  const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
+  const uint32_t my_o = lane < nt ? p.offs[f0 + lane] : span1;
+  PSTAMP(0);
+  const uint32_t a0 = span0 & ~15u;
+  const bool staged = span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 64 <= q.rows_off && !(q.dbg & 1u);
+  if (staged) {
+    // LDS-DMA: piece k of the window = 1 KiB, lane l moves bytes [a0 + 1024 k + 16 l, +16) to LDS offset 1024 k + 16 l.
+    // A 16-byte piece that would cross the end of the input is moved bytewise by the first lanes instead.
+    const uint32_t npieces = (span1 - a0 + 1023u) >> 10;
+    for (uint32_t k = 0; k < npieces; k++) {
+      const uint32_t c = a0 + (k << 10) + (lane << 4);
+      if (c < span1 && (uint64_t)c + 16 <= p.in_len) ETLG_GLDS16(p.in + c, smem + (k << 10));
+    }
+    const uint32_t tail = a0 + (((uint32_t)p.in_len - a0) & ~15u);  // the piece holding the last input byte, if partial
+    if (tail < span1 && (uint64_t)tail + 16 > p.in_len && tail + lane < p.in_len && lane < 16) smem[tail - a0 + lane] = p.in[tail + lane];
+    ETLG_VMEM_WAIT();
+    PSTAMP(1);
+    WSTAMP(1);
+    if (q.dbg & 2u) { if (smem[lane * 97u] == 0xEE && smem[lane * 13u + 5u] == 0xEF && my_o == 0xFFFFFFF1u) atomicOr(&p.res->fused_fail, 2u); return; }  // profiling: staging only
+    const WinLds m{(const ETLG_LDS_AS u8*)smem};
+    plan_tile(p, q, m, smem, true, a0, tile, nt, my_o, span0, span1, tprev);
+  } else {
+    const WinGlb m{p.in, (uint32_t)p.in_len};
+    plan_tile(p, q, m, smem, false, 0u, tile, nt, my_o, span0, span1, tprev);
+  }
+}
+
+}  // namespace etlg
+
+extern "C" {
+
+using namespace etlg;
+
+void etlg_k_launch_plan(const DecParams* p, const void* qv, hipStream_t s) {
+  const PlanParams* q = (const PlanParams*)qv;
+  hipLaunchKernelGGL(k_plan, dim3(q->ntiles), dim3(64), q->lds_bytes, s, *p, *q);
+}
+
+int etlg_k_plan_set_lds(void) {
+  return hipFuncSetAttribute((const void*)k_plan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
+}
+
+}  // extern "C"

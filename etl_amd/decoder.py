@@ -172,11 +172,14 @@ class Decoder:
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
 
     def debug_paths(self):
-        """Batches finished per kernel path (debugging aid, not in etlg.h):
-        {'fused', 'cells', 'multipass', 'redone'}."""
-        out = (C.c_ulonglong * 4)()
-        self.L.etlg_ctx_debug_paths(self.h, out)
-        return dict(zip(("fused", "cells", "multipass", "redone"), [int(x) for x in out]))
+        """Batches finished per kernel path (debugging aid, not in etlg.h): 'fused' / 'cells' / 'plan' = produced by that
+        single-pass kernel, 'multipass' = decoded by the multi-pass kernels directly, 'redone' = a single-pass result thrown
+        away and redone by the multi-pass kernels (errors), 'plan_redone' = a fixed-width-plan result redone by the generic
+        kernel, 'control' = batches that took the control path (a Relation / DDL frame), 'chain_rerun' = ASYNC batches run
+        again because their predecessor failed."""
+        out = (C.c_ulonglong * 8)()
+        self.L.etlg_ctx_debug_paths8(self.h, out)
+        return dict(zip(("fused", "cells", "multipass", "redone", "plan", "plan_redone", "control", "chain_rerun"), [int(x) for x in out]))
 
     def scan_boundaries(self, buf, max_frames=None):
         """Record-boundary scan of a host buffer on the device: np.uint32 offsets (nframes + 1)."""

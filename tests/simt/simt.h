@@ -33,6 +33,11 @@
 #define DEV_NOINLINE static __attribute__((noinline))
 #define ETLG_DYNAMIC_LDS(name) uint8_t* const name = simt::dyn_lds()
 #define ETLG_CONST_AS   /* one address space on the host */
+// LDS-DMA: lane l of the wave copies 16 bytes to (base + 16 l); nothing to wait for afterwards
+#define ETLG_GLDS16(g, l) memcpy((uint8_t*)(l) + 16 * (simt::g_view->tid & 63u), (const void*)(g), 16)
+#define ETLG_VMEM_WAIT() ((void)0)
+#define ETLG_LDS_AS
+#define ETLG_LDS_LD32(p) (*(const uint32_t*)(p))
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
@@ -125,6 +130,7 @@ static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint
 }
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline unsigned long long clock64() { return simt::ticks(); }
+static inline unsigned long long wall_clock64() { return simt::ticks(); }
 template <class T, class U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
 template <class T, class U> static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
 template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
@@ -143,6 +149,8 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipInit(unsigned) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "simt error"; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }

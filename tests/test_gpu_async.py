@@ -1,0 +1,130 @@
+"""ETLG_F_ASYNC pipelining: batches enqueued back to back, before any of them is synced, must start from the transaction
+state their predecessor LEFT ON THE DEVICE (DecParams.carry), not from what the host knew when it enqueued them — the
+apply loop carries remote_final_lsn / the next ordinal from message to message (crates/etl/src/replication/apply.rs:942-963,
+2284-2292). The batches here are cut at arbitrary frame boundaries, so transactions span them.
+
+Also: a batch that cannot be produced by its first kernel (an error; a frame the fixed-width plan does not cover) poisons the
+batches queued behind it; they are decoded again, in order, when they are synced, and must still match the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from etl_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
+
+
+class DevBufs:
+    """Device copies of (bytes, offsets). On the CPU emulator build "device memory" is host memory."""
+
+    def __init__(self, pieces):
+        self.keep = []
+        self.items = []
+        emu = os.environ.get("ETLG_SIMT_RUN") == "1"
+        if not emu:
+            import torch
+        for buf, offs in pieces:
+            o32 = np.ascontiguousarray(offs.astype(np.uint32))
+            if emu:
+                b = np.ascontiguousarray(buf)
+                self.keep += [b, o32]
+                self.items.append((b.ctypes.data, len(b), o32.ctypes.data, len(o32) - 1))
+            else:
+                tb = torch.from_numpy(np.ascontiguousarray(buf).copy()).cuda()
+                to = torch.from_numpy(o32.view(np.int32).copy()).cuda()
+                self.keep += [tb, to]
+                self.items.append((tb.data_ptr(), tb.numel(), to.data_ptr(), len(o32) - 1))
+        if not emu:
+            torch.cuda.synchronize()
+
+
+def _cut(buf, offs, nparts, seed):
+    """Cuts one framed stream into `nparts` consecutive batches at pseudo-random FRAME boundaries (not commit aligned)."""
+    rng = np.random.default_rng(seed)
+    nf = len(offs) - 1
+    cuts = sorted(set(int(x) for x in rng.integers(1, nf, nparts - 1)))
+    edges = [0] + cuts + [nf]
+    out = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        o = offs[a:b + 1].astype(np.int64)
+        out.append((buf[int(o[0]):int(o[-1])].copy(), (o - o[0]).astype(np.uint32)))
+    return out
+
+
+def _run_chain(w, pieces, expect_path=None):
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    dev = DevBufs(pieces)
+    inflight = [d.decode_device(p, n, po, nf, FLAGS) for (p, n, po, nf) in dev.items]   # nothing synced yet
+    res = []
+    for (buf, offs), b in zip(pieces, inflight):
+        rb = o.decode(buf, offs)
+        rc = b.sync()
+        res.append((rb, rc, b))
+    paths = d.debug_paths()
+    for i, (rb, rc, b) in enumerate(res):
+        assert (rb.err_code != 0) == (rc != 0), f"batch {i}: oracle error {rb.err_code} vs rc {rc} ({b.error})"
+        if rb.err_code:
+            assert (b.error.code, b.error.frame_index) == (rb.err_code, rb.err_frame), f"batch {i}"
+        diff = rb.host_batch().diff(b.host())
+        assert not diff, f"batch {i}: {diff[:6]}"
+        b.close()
+    d.close()
+    return paths
+
+
+@pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 3 << 20), (synth.cfg3, 3 << 20)])
+def test_async_chain_carries_transaction_state(mk, nbytes):
+    w = mk()
+    buf, offs = w.fill(nbytes)
+    pieces = _cut(buf, offs, 7, seed=11)
+    paths = _run_chain(w, pieces)
+    assert paths["redone"] == 0 and paths["chain_rerun"] == 0 and paths["plan_redone"] == 0, paths
+    if mk is synth.cfg2:
+        assert paths["plan"] == 7, paths
+
+
+def test_async_chain_survives_an_error_in_the_middle():
+    """Batch 2 holds a malformed integer: its error must be the oracle's, and the batches queued behind it — which the device
+    refused to run from a failed predecessor — are decoded when they are synced, from the state the failed batch left."""
+    w = synth.cfg2()
+    buf, offs = w.fill(2 << 20)
+    pieces = _cut(buf, offs, 6, seed=5)
+    b2, o2 = pieces[2]
+    fr = int(o2[len(o2) // 2])          # some frame in the middle of batch 2
+    k = fr
+    while b2[k + 30] != ord("I"):       # find an Insert at or after it
+        k = int(o2[np.searchsorted(o2, k, side="right")])
+    b2[k + 43 + 3] = ord("x")           # a letter inside the first int4 text
+    paths = _run_chain(w, pieces)
+    assert paths["chain_rerun"] >= 1, paths
+
+
+def test_async_chain_when_the_plan_does_not_cover_a_batch():
+    """An UPDATE in a stream of fixed-width inserts: k_plan gives the batch up, the generic kernel decodes it, and the
+    batches queued behind it run again from the right state."""
+    from tests import pgwire as W
+    w = synth.cfg2()
+    buf, offs = w.fill(1 << 20)
+    pieces = _cut(buf, offs, 5, seed=3)
+    # splice an Update of the same table in front of a frame of batch 1 that sits inside a transaction
+    b1, o1 = pieces[1]
+    nf = len(o1) - 1
+    at = nf // 2
+    while b1[int(o1[at]) + 30] != ord("I") or b1[int(o1[at - 1]) + 30] != ord("I"):
+        at += 1
+    rel = int.from_bytes(b1[int(o1[at]) + 31:int(o1[at]) + 35].tobytes(), "big")
+    lsn = int.from_bytes(b1[int(o1[at]) + 6:int(o1[at]) + 14].tobytes(), "big")
+    upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"])))
+    cut = int(o1[at])
+    nb = np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]])
+    no = np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32)
+    pieces[1] = (nb, no)
+    paths = _run_chain(w, pieces)
+    assert paths["plan_redone"] >= 1 and paths["redone"] == 0, paths
