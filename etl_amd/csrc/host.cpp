@@ -1066,6 +1066,32 @@ int32_t etlg_scan_boundaries(etlg_ctx* c, const uint8_t* buf, size_t len, uint32
   return ETLG_OK;
 }
 
+int32_t etlg_frame_tags(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags,
+                        uint8_t* tags_out) {
+  if (!c || !frame_offsets || (!tags_out && nframes)) return ETLG_InvalidArgument;
+  clear_error(c);
+  if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  if (!nframes) return ETLG_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; }
+  const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE, out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
+  hipStream_t s = c->stream;
+  DecParams p{};
+  p.in = buf; p.offs = frame_offsets;
+  if (!in_dev) {
+    HIPCHK(c, c->d_in.ensure(len + 64)); HIPCHK(c, c->d_offs.ensure((nframes + 1) * 4));
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_offs.p, frame_offsets, (nframes + 1) * 4, hipMemcpyHostToDevice, s));
+    p.in = (const uint8_t*)c->d_in.p; p.offs = (const uint32_t*)c->d_offs.p;
+  }
+  p.nframes = (uint32_t)nframes; p.nblocks = (p.nframes + kBlock - 1) / kBlock; p.in_len = len;
+  { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
+  launch(c, 0, p);   // k_classify: envelope + tag of every frame
+  HIPCHK(c, hipMemcpyAsync(tags_out, p.f_tag, nframes, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  return ETLG_OK;
+}
+
 // debugging aid (not part of etlg.h): [0] scans that needed a rerun with hints, [1] scans that fell back to the one-lane walk
 int32_t etlg_ctx_debug_scan(etlg_ctx* c, unsigned long long* out2) {
   if (!c || !out2) return ETLG_InvalidArgument;

@@ -181,6 +181,24 @@ class Decoder:
         self.L.etlg_ctx_debug_paths8(self.h, out)
         return dict(zip(("fused", "cells", "multipass", "redone", "plan", "plan_redone", "control", "chain_rerun"), [int(x) for x in out]))
 
+    def frame_tags(self, buf, offsets):
+        """pgoutput tag of every frame (np.uint8; 0 = malformed), classified on the device (etlg_frame_tags)."""
+        import numpy as np
+        a = np.ascontiguousarray(buf, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint32)
+        out = np.zeros(len(o) - 1, dtype=np.uint8)
+        rc = self.L.etlg_frame_tags(self.h, a.ctypes.data, len(a), o.ctypes.data, len(o) - 1, 0, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"etlg_frame_tags failed: {rc}")
+        return out
+
+    def frame_tags_device(self, buf_ptr, nbytes, offs_ptr, nframes, out_ptr):
+        """Device-resident variant: raw device pointers in and out."""
+        rc = self.L.etlg_frame_tags(self.h, C.c_void_p(buf_ptr), nbytes, C.c_void_p(offs_ptr), nframes,
+                                    abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE, C.c_void_p(out_ptr))
+        if rc != 0:
+            raise RuntimeError(f"etlg_frame_tags failed: {rc}")
+
     def scan_boundaries(self, buf, max_frames=None):
         """Record-boundary scan of a host buffer on the device: np.uint32 offsets (nframes + 1)."""
         import numpy as np

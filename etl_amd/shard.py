@@ -1,13 +1,19 @@
 """Multi-GPU partitioning of a WAL stream.
 
-The decode path shards by contiguous, commit-aligned ranges of CopyData frames:
-every rank decodes its own range with its own context (transaction state is
-shard-local because a cut is only made after a Commit), schemas are replicated
-to every rank by the host, and there is no data-path collective. The single
-collective is an all-gather of one fixed-size header per rank; because rank
-order == LSN order, the exclusive prefix of the gathered counts is each
-shard's position in the global, LSN-ordered event sequence (reassembly is
-concatenation, no merge).
+The reference decodes ONE ordered stream in one task (crates/etl/src/replication/apply.rs:1210-1336); what a frame
+decodes to depends on two pieces of running state: the open transaction (commit_lsn, next ordinal: apply.rs:942-963) and
+the shared table cache that Relation / DDL-message frames update (apply.rs:2160-2276, 2363-2440). The decode path shards by
+contiguous ranges of CopyData frames and removes both dependencies:
+
+  * cuts are only made right after a Commit ('C') frame (`plan_shards`), so the transaction state is shard-local;
+  * the rare control frames are BROADCAST: every shard extracts the transactions of its range that carry a Relation or a
+    DDL message, reduced to {Begin, control frames, Commit} (`control_stream`, a few hundred bytes), the ranks all-gather
+    them, and every rank replays those of the ranks before it on its own context before it decodes (`replay_control`) —
+    same schema slots in the same order on every rank, so the arenas reference identical slot ids;
+  * rank order == LSN order: one all-gather of a 64-byte header per rank gives every rank the exclusive prefix of
+    (events, fixed bytes, heap bytes) of its shard in the LSN-ordered result (`global_layout`), and — optionally — one
+    padded all-gather per arena array puts the whole result on every rank (`ArenaGatherer`); reassembly is concatenation
+    plus that prefix on body offsets and heap references (`etl_amd.view.HostBatch.concat`), never a merge.
 """
 import numpy as np
 
@@ -17,21 +23,35 @@ HEADER_FIELDS = ("first_err", "n_events", "fixed_bytes", "heap_bytes", "pay_inse
 NO_ERR = -1  # first_err == ~0 read as int64
 
 
-def plan_shards(buf, offsets, n_shards):
+def frame_tags(buf, offsets):
+    """pgoutput tag of every frame, on the host (numpy gather). Streams that are already in HBM use the device
+    classification instead (Decoder.frame_tags / etlg_frame_tags): same values for well-formed frames."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    nfr = len(offsets) - 1
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    tags = np.zeros(nfr, dtype=np.uint8)
+    if nfr == 0:
+        return tags
+    starts = offsets[:-1]
+    lens = offsets[1:] - starts
+    outer = a[np.minimum(starts + 5, len(a) - 1)]
+    idx = np.flatnonzero((lens >= 31) & (outer == ord("w")))
+    tags[idx] = a[starts[idx] + 30]
+    tags[(lens >= 23) & (outer == ord("k"))] = ord("k")
+    return tags
+
+
+def plan_shards(buf, offsets, n_shards, tags=None):
     """Cut frames [0, nframes) into n_shards contiguous ranges that end right after a
-    Commit ('C') frame, balanced by bytes. Returns [(f0, f1)] (f1 exclusive)."""
+    Commit ('C') frame, balanced by bytes. Returns [(f0, f1)] (f1 exclusive).
+    `tags`: the frames' pgoutput tags if the caller already has them (etlg_frame_tags); `buf` may then be None."""
     offsets = np.asarray(offsets, dtype=np.int64)
     nfr = len(offsets) - 1
     if nfr == 0:
         return [(0, 0)] * n_shards
-    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
-    starts = offsets[:-1]
-    lens = offsets[1:] - starts
-    tag_ok = lens >= 31
-    tags = np.zeros(nfr, dtype=np.uint8)
-    idx = np.flatnonzero(tag_ok & (a[np.minimum(starts + 5, len(a) - 1)] == ord("w")))
-    tags[idx] = a[starts[idx] + 30]
-    commit_ends = np.flatnonzero(tags == ord("C")) + 1  # candidate cut points (frame index after a Commit)
+    if tags is None:
+        tags = frame_tags(buf, offsets)
+    commit_ends = np.flatnonzero(np.asarray(tags) == ord("C")) + 1  # candidate cut points (frame index after a Commit)
     total = int(offsets[-1])
     cuts = [0]
     for k in range(1, n_shards):
@@ -52,6 +72,135 @@ def slice_shard(buf, offsets, f0, f1):
     a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
     b0, b1 = int(offsets[f0]), int(offsets[f1])
     return a[b0:b1], (offsets[f0:f1 + 1] - b0).astype(np.uint32)
+
+
+def control_stream(buf, offsets, f0=0, f1=None, tags=None):
+    """The control frames of frames [f0, f1) as a tiny stream of their own: for every transaction that holds a Relation
+    ('R') or logical-decoding Message ('M') frame, its Begin, those frames in order, and its Commit (frames outside any
+    transaction are kept as they are: the decoder reports them exactly as it would in place). Decoding it on a fresh
+    context has the same effect on the schema store and the shared table cache as decoding the whole range
+    (apply.rs:2160-2276, 2363-2440 are the only writers), at none of the cost. Returns (bytes as np.uint8, offsets as
+    np.uint32) — possibly empty."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    nfr = len(offsets) - 1
+    f1 = nfr if f1 is None else f1
+    if tags is None:
+        tags = frame_tags(a, offsets)
+    t = np.asarray(tags)[f0:f1]
+    ctrl = np.flatnonzero((t == ord("R")) | (t == ord("M")))
+    if len(ctrl) == 0:
+        return np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint32)
+    begins = np.flatnonzero(t == ord("B"))
+    commits = np.flatnonzero(t == ord("C"))
+    keep = set(int(i) for i in ctrl)
+    for i in ctrl:
+        b = np.searchsorted(begins, i, side="right") - 1
+        if b < 0:
+            continue                                  # before the first Begin of the range: not in a transaction here
+        bi = int(begins[b])
+        c = np.searchsorted(commits, bi, side="left")
+        ci = int(commits[c]) if c < len(commits) else None
+        if ci is not None and ci < i:
+            continue                                  # that transaction was closed before the control frame
+        keep.add(bi)
+        if ci is not None:
+            keep.add(ci)
+    frames = sorted(keep)
+    pieces = [a[int(offsets[f0 + i]):int(offsets[f0 + i + 1])] for i in frames]
+    lens = np.array([len(p) for p in pieces], dtype=np.int64)
+    return np.concatenate(pieces), np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+
+
+def replay_control(decoder, streams):
+    """Applies the control streams of the shards BEFORE this one (in rank order) to `decoder` — a Decoder or anything with
+    its decode() — and drops the events. Raises if a replay fails: the shard that owns those frames reports the error."""
+    for buf, offs in streams:
+        if len(offs) <= 1:
+            continue
+        b = decoder.decode(buf, offs)
+        rc = getattr(b, "rc", None)
+        if rc is None:
+            rc = getattr(b, "err_code", 0)
+        if rc != 0:
+            raise RuntimeError(f"control replay failed: {getattr(b, 'error', None) or rc}")
+        if hasattr(b, "close"):
+            b.close()
+
+
+def all_gather_control(stream, group=None):
+    """All-gathers every rank's control stream (padded uint8 + lengths; they are tiny) and returns them in rank order."""
+    import torch
+    import torch.distributed as dist
+    buf, offs = stream
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    sizes = torch.tensor([len(buf), len(offs)], dtype=torch.int64, device=dev)
+    all_sizes = torch.empty((world, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_sizes, sizes.reshape(1, 2), group=group)
+    all_sizes = all_sizes.cpu().numpy()
+    mb, mo = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+    pb = torch.zeros(max(mb, 1), dtype=torch.uint8, device=dev)
+    po = torch.zeros(max(mo, 1), dtype=torch.int64, device=dev)
+    if len(buf):
+        pb[:len(buf)] = torch.from_numpy(np.ascontiguousarray(buf)).to(dev)
+    po[:len(offs)] = torch.from_numpy(np.asarray(offs, dtype=np.int64)).to(dev)
+    gb = torch.empty((world, pb.numel()), dtype=torch.uint8, device=dev)
+    go = torch.empty((world, po.numel()), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gb, pb.reshape(1, -1), group=group)
+    dist.all_gather_into_tensor(go, po.reshape(1, -1), group=group)
+    gb, go = gb.cpu().numpy(), go.cpu().numpy()
+    return [(gb[r, :all_sizes[r, 0]].copy(), go[r, :all_sizes[r, 1]].astype(np.uint32)) for r in range(world)]
+
+
+ARENA_ARRAYS = (("kind", np.uint8), ("flags", np.uint8), ("table_id", np.uint32), ("schema_slot", np.uint32),
+                ("start_lsn", np.uint64), ("commit_lsn", np.uint64), ("tx_ordinal", np.uint64), ("body_off", np.uint64),
+                ("fixed", np.uint8), ("heap", np.uint8))
+
+
+def all_gather_arenas(arrays, group=None):
+    """The optional data-path collective of north_star: every rank ends up with every shard's arena arrays.
+    `arrays`: dict name -> 1-D torch tensor of this rank's shard (device tensors under nccl, CPU tensors under gloo),
+    names as in ARENA_ARRAYS. One all-gather of the lengths, then one padded all_gather_into_tensor per array (RCCL moves
+    world x max-shard bytes per array over xGMI). Returns (gathered: name -> [world, pad] tensor, lengths [world, n_arrays])."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    names = [n for n, _ in ARENA_ARRAYS]
+    dev = arrays[names[0]].device
+    lens = torch.tensor([arrays[n].numel() for n in names], dtype=torch.int64, device=dev)
+    all_lens = torch.empty((world, len(names)), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_lens, lens.reshape(1, -1), group=group)
+    pads = all_lens.max(dim=0).values.cpu().tolist()
+    out = {}
+    for k, n in enumerate(names):
+        t = arrays[n]
+        item = t.element_size()
+        pad = max(int(pads[k]), 1) * item
+        raw = t.contiguous().view(torch.uint8)           # the collective moves bytes: every backend takes uint8
+        src = raw if raw.numel() == pad else torch.cat([raw, torch.zeros(pad - raw.numel(), dtype=torch.uint8, device=dev)])
+        g = torch.empty((world, pad), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(g, src.reshape(1, -1), group=group)
+        out[n] = g.view(t.dtype)
+    return out, all_lens
+
+
+def decode_sharded(make_context, buf, offsets, n_shards, tags=None):
+    """The whole multi-GPU recipe in one process (tests, and the reference for what N ranks do): cut, broadcast the control
+    streams, decode every shard on its OWN context. `make_context()` returns a primed Decoder (or oracle wrapper).
+    Returns the list of per-shard batches, in LSN order."""
+    if tags is None:
+        tags = frame_tags(buf, offsets)
+    ranges = plan_shards(buf, offsets, n_shards, tags=tags)
+    ctrl = [control_stream(buf, offsets, f0, f1, tags=tags) for f0, f1 in ranges]
+    out = []
+    for k, (f0, f1) in enumerate(ranges):
+        ctx = make_context()
+        replay_control(ctx, ctrl[:k])
+        ctx.reset_stream_state()
+        b, o = slice_shard(buf, offsets, f0, f1)
+        out.append((ctx, ctx.decode(np.ascontiguousarray(b), o)))
+    return out
 
 
 def make_header(n_events, fixed_bytes, heap_bytes, n_frames, payload=(0, 0, 0), first_err=NO_ERR):

@@ -129,6 +129,68 @@ class HostBatch:
                     out.append(f"slot {k}: {a} != {b}")
         return out
 
+    # ------------------------------------------------------ shard reassembly
+    _HEAP_CLASSES = (abi.TC_STRING, abi.TC_BYTEA, abi.TC_NUMERIC, abi.TC_JSON, abi.TC_ARRAY)
+
+    def _rebase_heap_refs(self, delta):
+        """Adds `delta` to every heap reference held in this batch's fixed arena (String / Bytes / Numeric / Json / Array
+        cells and every DEFERRED cell keep {u32 heap_off, u32 len} in their slot)."""
+        if not delta or self.n_events == 0:
+            return
+        fx32 = self.fixed.view(np.uint32) if len(self.fixed) % 4 == 0 else None
+        assert fx32 is not None
+        body = self.body_off.astype(np.int64)
+        for si, slot in enumerate(self.slots):
+            for kind in (ord("I"), ord("U"), ord("D")):
+                base_sel = (self.kind == kind) & (self.schema_slot == si)
+                if not base_sel.any():
+                    continue
+                for ok in (abi.OLD_NONE, abi.OLD_FULL, abi.OLD_KEY):
+                    sel = base_sel if kind == ord("I") else base_sel & ((self.flags & 3) == ok)
+                    if kind == ord("I") and ok != abi.OLD_NONE:
+                        continue
+                    ev = np.flatnonzero(sel)
+                    if len(ev) == 0:
+                        continue
+                    images = []   # (row base offsets, key layout?)
+                    old_sz = slot.row_bytes_full if ok == abi.OLD_FULL else slot.row_bytes_key if ok == abi.OLD_KEY else 0
+                    if kind != ord("I") and ok != abi.OLD_NONE:
+                        images.append((body[ev], ok == abi.OLD_KEY))
+                    if kind in (ord("I"), ord("U")):
+                        images.append((body[ev] + old_sz, False))
+                    for bases, key_layout in images:
+                        cols = slot.key_cols() if key_layout else slot.cols
+                        for i, col in enumerate(cols):
+                            st = (self.fixed[bases + i // 4] >> (2 * (i % 4))) & 3
+                            is_ref = (st == abi.CELL_DEFERRED) | ((st == abi.CELL_VALUE) & (col.type_class in self._HEAP_CLASSES))
+                            at = (bases[is_ref] + (col.off_key if key_layout else col.off_full)) // 4
+                            fx32[at] += np.uint32(delta)
+
+    @classmethod
+    def concat(cls, parts):
+        """Reassembles the batches of consecutive, commit-aligned shards of one stream (rank order == LSN order) into the
+        batch a single decode of the whole stream produces: arrays concatenated, body offsets and heap references moved
+        by each shard's exclusive prefix (etl_amd/shard.py: global_layout). Every part must come from a context that had
+        seen the same schema slots (shard.replay_control gives later shards the earlier shards' Relation / DDL frames)."""
+        parts = list(parts)
+        fx_off = np.concatenate([[0], np.cumsum([len(p.fixed) for p in parts])])
+        hp_off = np.concatenate([[0], np.cumsum([len(p.heap) for p in parts])])
+        moved = []
+        for k, p in enumerate(parts):
+            q = cls(p.n_events, p.n_frames, p.payload_bytes, p.kind, p.flags, p.table_id, p.schema_slot, p.start_lsn, p.commit_lsn,
+                    p.tx_ordinal, p.body_off + np.uint64(fx_off[k]), p.fixed.copy(), p.heap, p.slots)
+            hold = cls(p.n_events, p.n_frames, p.payload_bytes, p.kind, p.flags, p.table_id, p.schema_slot, p.start_lsn,
+                       p.commit_lsn, p.tx_ordinal, p.body_off, q.fixed, p.heap, p.slots)   # shard-local offsets, shared fixed copy
+            hold._rebase_heap_refs(int(hp_off[k]))
+            moved.append(q)
+        cat = lambda name: np.concatenate([getattr(m, name) for m in moved]) if moved else np.zeros(0)
+        return cls(
+            n_events=sum(p.n_events for p in parts), n_frames=sum(p.n_frames for p in parts),
+            payload_bytes=tuple(sum(p.payload_bytes[i] for p in parts) for i in range(3)),
+            kind=cat("kind"), flags=cat("flags"), table_id=cat("table_id"), schema_slot=cat("schema_slot"),
+            start_lsn=cat("start_lsn"), commit_lsn=cat("commit_lsn"), tx_ordinal=cat("tx_ordinal"), body_off=cat("body_off"),
+            fixed=cat("fixed"), heap=cat("heap"), slots=max((p.slots for p in parts), key=len))
+
     # ----------------------------------------------------------- materialise
     def _heap(self, off, ln):
         return self.heap[off:off + ln].tobytes()

@@ -305,6 +305,16 @@ int32_t etlg_copy_decode(etlg_ctx* ctx, int32_t schema_slot, const uint8_t* buf,
 int32_t etlg_scan_boundaries(etlg_ctx* ctx, const uint8_t* buf, size_t len, uint32_t flags,
                              uint32_t* offsets_out, size_t cap, size_t* nframes_out);
 
+/* The pgoutput tag of every frame of a staged stream (the same classification etlg_decode runs first): tags_out[i] is
+ * 'B' 'C' 'R' 'I' 'U' 'D' 'T' 'M' 'Y' 'O', 'k' for a keepalive, 0 for a malformed frame. It is what a host needs to cut
+ * a stream into commit-aligned shards (cuts go after a 'C') and to find the rare Relation / DDL-message frames whose effects
+ * every later shard must see (etl_amd/shard.py: plan_shards, control_stream) without reading the stream back.
+ * Replaces, as a pre-pass, the message-kind dispatch of the apply loop (crates/etl/src/replication/apply.rs:2087-2125).
+ * frame_offsets: nframes + 1 entries (required; e.g. from etlg_scan_boundaries).
+ * flags: ETLG_F_INPUT_ON_DEVICE (buf / frame_offsets are device pointers), ETLG_F_OUTPUT_ON_DEVICE (tags_out is one). */
+int32_t etlg_frame_tags(etlg_ctx* ctx, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes,
+                        uint32_t flags, uint8_t* tags_out);
+
 /* ------------------------------------------------------------ batch (arena) */
 
 /* Event kinds: the pgoutput tag of the message that produced the event. */

@@ -57,6 +57,13 @@ def test_scenarios_on_every_kernel_path(simt_lib):
     assert " passed" in tail and "failed" not in tail, tail
 
 
+def test_sharded_decode_and_async_chain(simt_lib):
+    """The multi-GPU recipe (cut after Commit, broadcast control frames, decode per shard, concatenate) and the ASYNC batch
+    chain (device-side carried transaction state, poisoned successors), through the C ABI and the emulated kernels."""
+    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_shard_decode.py", "tests/test_gpu_async.py", "-k", "not 8-"], 900)
+    assert " passed" in tail and "failed" not in tail, tail
+
+
 def test_copy_rows_and_boundary_scan(simt_lib):
     tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k",
                                                 "not device_resident and not device_input and not 16777216"], 600)
