@@ -1,19 +1,24 @@
 #!/usr/bin/env python
 """bench.py — WAL bytes/s decoded on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the decode hot path over one 64 MiB batch of synthetic
-WAL (BASELINE.json configs[1]: fixed-width 5 x int4 INSERT tuples, 113-byte
-CopyData frames) that is already resident in HBM when the timed region
-starts; the decoded arena stays in HBM. Batches rotate through a pool larger
-than the 256 MiB Infinity Cache so steps do not re-read cached input.
+A "step" is one pass of the decode hot path over `--inner` (10) consecutive 64 MiB batches of synthetic WAL
+(BASELINE.json configs[1]: fixed-width 5 x int4 INSERT tuples, 113-byte CopyData frames) that are already resident in HBM
+when the timed region starts; the decoded arenas stay in HBM. Batches rotate through a pool larger than the 256 MiB
+Infinity Cache so steps do not re-read cached input. The driver's `--steps 20` is therefore 200 decodes (the timed region
+of round 1 was 20 decodes, 1.6 ms).
 
   python bench.py [--gpus N --steps K --warmup W]
 
-N > 1 is launched by the driver under torch.distributed.run (one rank per
-GPU). Each rank decodes its own contiguous, commit-aligned shard of the
-stream (weak scaling: one batch per rank per step); the only collective is an
-all-gather of a 64-byte header per rank per step (RCCL over xGMI) that gives
-every rank the LSN-ordered global layout. Rank 0 prints ONE JSON line.
+N > 1 is launched by the driver under torch.distributed.run (one rank per GPU). Each rank decodes its own contiguous,
+commit-aligned shard of the stream (weak scaling: `--inner` batches per rank per step); the collective of the path is an
+all-gather of a 64-byte header per rank per batch (RCCL over xGMI) that gives every rank the LSN-ordered global layout.
+`--workload cfg4` is BASELINE configs[3]: ONE 8 GiB stream cut into N commit-aligned shards, device-side boundary scan,
+control-frame broadcast, header all-gather and (`--gather-arenas`) the padded arena all-gather.
+
+Rank 0 prints ONE JSON line. Beside the headline it carries one object per other BASELINE config, each with its own
+algorithmic bytes and kernel times: `cfg3` (mixed I/U/D, TEXT / NUMERIC), `cfg5` (Relation / DDL messages in the stream,
+default flags: the control path), `copy` (table-copy rows), `no_sidecar` (record-boundary scan on the device first),
+`cfg4` (with --workload cfg4 or --cfg4-leg).
 """
 import argparse
 import json
@@ -26,11 +31,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Algorithmic bytes of one launch: every input byte read once (frames + the 4-byte
-# offsets sidecar per frame) and every arena byte written once (42 bytes of event header columns per
-# event + the fixed row arena + the heap). cfg2: 113 + 4 + 42 + 24 = 183 bytes per row.
+# Algorithmic bytes of one launch: every input byte read once (frames + the 4-byte offsets sidecar per
+# frame) and every arena byte written once (42 bytes of event header columns per event + the fixed row arena + the heap).
+# cfg2: 113 + 4 + 42 + 24 = 183 bytes per row.
 SIDECAR_BYTES_PER_FRAME = 4
 HEADER_BYTES_PER_EVENT = 42     # kind 1, flags 1, table 4, slot 4, start 8, commit 8, ordinal 8, body offset 8
+WINDOW = 24                     # ASYNC batches in flight per context (the library's result ring holds 32)
 
 
 def cpu_threads(requested):
@@ -106,14 +112,382 @@ def cpu_baseline_threads(w, pool, nthreads, seconds):
                       "commit-aligned shards, one oracle context per thread"}
 
 
+class Pipeline:
+    """ASYNC decodes of device-resident batches on one context, at most WINDOW in flight (the oldest is synced — its
+    own completion event, not the stream — checked and freed before the next one is issued)."""
+
+    def __init__(self, dec, items, flags, check=True):
+        self.dec, self.items, self.flags, self.check = dec, items, flags, check
+        self.inflight = []
+        self.bytes = self.frames = self.out_bytes = self.events = 0
+        self.k = 0
+
+    def _retire(self):
+        b, nbytes, nfr = self.inflight.pop(0)
+        rc = b.sync()
+        v = b.view()
+        if self.check:
+            assert rc == 0 and v.n_frames == nfr, (rc, v.n_events, v.n_frames, nfr, b.error)
+        self.out_bytes += HEADER_BYTES_PER_EVENT * v.n_events + v.fixed_bytes + v.heap_bytes
+        self.events += v.n_events
+        self.bytes += nbytes
+        self.frames += nfr
+        b.close()
+
+    def issue(self, hdr_ptr=None):
+        tb, to, nbytes, nfr = self.items[self.k % len(self.items)]
+        self.k += 1
+        if len(self.inflight) >= WINDOW:
+            self._retire()
+        b = self.dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, self.flags)
+        if hdr_ptr is not None:
+            b.header_to_device(hdr_ptr)
+        self.inflight.append((b, nbytes, nfr))
+
+    def drain(self):
+        while self.inflight:
+            self._retire()
+
+
+def kernel_table(prof):
+    return {k: {"launches": n, "avg_us": 1000.0 * ms / n} for k, (n, ms) in prof.items() if n}
+
+
+def roofline_of(kern, alg_bytes_per_launch, traffic=None):
+    dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+    ach = alg_bytes_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
+    per_batch = {k: v["avg_us"] * v["launches"] / kern[dom]["launches"] for k, v in kern.items()}
+    pipe_us = sum(per_batch.values())
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "alg_bytes_per_launch": int(alg_bytes_per_launch), "kernel_avg_us": round(kern[dom]["avg_us"], 2),
+            "pipeline_kernels_us": {k: round(v, 2) for k, v in per_batch.items()},
+            "pipeline_sum_us": round(pipe_us, 2),
+            "pipeline_frac": round(alg_bytes_per_launch / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+def to_device(pool, dev):
+    import numpy as np
+    import torch
+    d = [(torch.from_numpy(b).to(dev), torch.from_numpy(o.view(np.int32)).to(dev), len(b), len(o) - 1) for b, o in pool]
+    torch.cuda.synchronize()
+    return d
+
+
+def leg_async(mk, dev_id, dev, cap, npool, nbatches, flags, check, traffic_file=None):
+    """One BASELINE config as an ASYNC pipeline on a fresh context: wall-clock rate, then the same again under the
+    library's HIP-event profiler for the kernel times."""
+    import torch
+
+    from etl_amd.decoder import Decoder
+    w = mk()
+    pool = [w.fill(cap) for _ in range(npool)]
+    items = to_device(pool, dev)
+    dec = Decoder(dev_id)
+    w.register(dec)
+    p = Pipeline(dec, items, flags, check)
+    for _ in range(WINDOW + 2):       # arena pool priming + warm-up
+        p.issue()
+    p.drain()
+    torch.cuda.synchronize()
+    p = Pipeline(dec, items, flags, check)
+    t0 = time.perf_counter()
+    for _ in range(nbatches):
+        p.issue()
+    p.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dec.profile(True)
+    q = Pipeline(dec, items, flags, check)
+    for _ in range(nbatches):
+        q.issue()
+    q.drain()
+    torch.cuda.synchronize()
+    kern = kernel_table(dec.profile_read())
+    dec.profile(False)
+    alg = (q.bytes + SIDECAR_BYTES_PER_FRAME * q.frames + q.out_bytes) / nbatches
+    traffic = None
+    if traffic_file and os.path.exists(traffic_file):
+        t = json.load(open(traffic_file))
+        traffic = t.get("hbm_bytes_per_launch")
+    out = {"value": round(p.bytes / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(p.events / dt, 1),
+           "hbm_read_frac": round(p.bytes / dt / 1e9 / HBM_PEAK_GBPS, 5),
+           "workload": f"{w.name}: {cap >> 20} MiB batches, device-resident in / out, offsets sidecar, NO_CONTROL | ASYNC",
+           "batches": nbatches, "frames_per_batch": int(p.frames / nbatches), "paths": dec.debug_paths(),
+           "roofline": roofline_of(kern, alg, traffic)}
+    dec.close()
+    return out, pool, w
+
+
+def leg_cfg5(dev_id, dev, cap, npool, passes):
+    """BASELINE configs[4]: Relation / DDL messages interleaved with rows of 3 tables, DEFAULT flags (the caller asserts
+    nothing: a batch with a control frame takes the control path). The stream is decoded in order by a fresh context
+    per pass (its schemas evolve with the DDL messages)."""
+    import torch
+
+    from etl_amd import abi, synth
+    from etl_amd.decoder import Decoder
+    w = synth.cfg5()
+    pool = [w.fill(cap) for _ in range(npool)]
+    items = to_device(pool, dev)
+    best = None
+    kern = {}
+    tot_bytes = sum(len(b) for b, _ in pool)
+    tot_frames = sum(len(o) - 1 for _, o in pool)
+    out_bytes = events = 0
+    paths = {}
+    for rep in range(passes + 1):
+        dec = Decoder(dev_id)
+        w.register(dec, ready=False)
+        if rep == passes:
+            dec.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ob = ev = 0
+        for tb, to, nbytes, nfr in items:
+            b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, abi.F_OUTPUT_ON_DEVICE)
+            v = b.view()
+            assert b.rc == 0 and v.n_frames == nfr, (b.rc, b.error)
+            ob += HEADER_BYTES_PER_EVENT * v.n_events + v.fixed_bytes + v.heap_bytes
+            ev += v.n_events
+            b.close()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rep == passes:
+            kern = kernel_table(dec.profile_read())
+            paths = dec.debug_paths()
+        elif rep > 0 or passes == 1:
+            best = dt if best is None else min(best, dt)
+        out_bytes, events = ob, ev
+        dec.close()
+    alg = (tot_bytes + SIDECAR_BYTES_PER_FRAME * tot_frames + out_bytes) / npool
+    # kernel table per BATCH: the control path launches classify / scan / ctrl_list only for batches with control frames
+    return {"value": round(tot_bytes / best / 1e9, 3), "unit": "GB/s", "events_per_s": round(events / best, 1),
+            "hbm_read_frac": round(tot_bytes / best / 1e9 / HBM_PEAK_GBPS, 5),
+            "workload": f"{w.name}: {npool} consecutive {cap >> 20} MiB batches of one stream, device-resident in / out, offsets sidecar, "
+                        "default flags (synchronous decode; Relation / DDL frames handled by the host control plane)",
+            "batches": npool, "paths": paths, "roofline": roofline_of(kern, alg)}
+
+
+def leg_copy(dev_id, dev, nrows, reps):
+    """SURVEY §8(f)#1: table-copy rows (COPY text format) -> the Insert arena."""
+    import numpy as np
+    import torch
+
+    from etl_amd import synth
+    from etl_amd.decoder import Decoder
+    base = synth.copy_rows(20000, 1)
+    rows = base * max(1, nrows // len(base))
+    buf = np.frombuffer(b"".join(rows), dtype=np.uint8)
+    offs = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint32)
+    d = Decoder(dev_id)
+    d.schema_put(42, 0, synth.COPY_COLS)
+    slot = d.table_ready(42, 0, [1] * 10, [1] + [0] * 9)
+    tb = torch.from_numpy(buf.copy()).to(dev)
+    to = torch.from_numpy(offs.view(np.int32).copy()).to(dev)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        d.copy_decode_device(slot, tb.data_ptr(), tb.numel(), to.data_ptr(), len(rows)).close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b = d.copy_decode_device(slot, tb.data_ptr(), tb.numel(), to.data_ptr(), len(rows))
+        assert b.rc == 0
+        b.close()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    d.profile(True)
+    ob = 0
+    for _ in range(reps):
+        b = d.copy_decode_device(slot, tb.data_ptr(), tb.numel(), to.data_ptr(), len(rows))
+        v = b.view()
+        ob += HEADER_BYTES_PER_EVENT * v.n_events + v.fixed_bytes + v.heap_bytes
+        b.close()
+    torch.cuda.synchronize()
+    kern = kernel_table(d.profile_read())
+    d.profile(False)
+    d.close()
+    # the splitter reads the rows + row offsets and writes the synthetic frames, which the decode kernel reads again
+    syn = len(buf) + len(rows) * (38 + 5 * 10)
+    alg = len(buf) + 4 * len(rows) + 2 * syn + ob / reps
+    return {"value": round(reps * len(buf) / dt / 1e9, 3), "unit": "GB/s", "rows_per_s": round(reps * len(rows) / dt, 1),
+            "workload": f"{len(rows)} COPY text rows of a 10-column mixed table ({len(buf)} bytes), device-resident, synchronous",
+            "roofline": roofline_of(kern, alg)}
+
+
+def leg_no_sidecar(dec, items, steps, check):
+    """The same cfg2 batches with frame_offsets = NULL: the record-boundary scan runs on the device first (scan.hip).
+    Reported beside `value`, never as `value`: the reference's host learns every frame length from its socket codec."""
+    import torch
+
+    from etl_amd import abi
+    fl = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL
+    for k in range(2):
+        tb, to, nbytes, nfr = items[k % len(items)]
+        dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl).close()
+    dec.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nb = 0
+    for k in range(steps):
+        tb, to, nbytes, nfr = items[k % len(items)]
+        b = dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl)
+        assert not check or (b.rc == 0 and b.view().n_frames == nfr)
+        nb += nbytes
+        b.close()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    kern = kernel_table(dec.profile_read())
+    dec.profile(False)
+    kb = kern.get("k_bounds", {"launches": 0, "avg_us": 0.0})
+    return {"value": round(nb / (t1 - t0) / 1e9, 3), "unit": "GB/s", "k_bounds_avg_us": round(kb["avg_us"], 2),
+            "k_bounds_launches_per_batch": round(kb["launches"] / steps, 2),
+            "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+            "note": "frame_offsets = NULL: device record-boundary scan + decode, synchronous (the host reads the frame count back)"}
+
+
+def _gen_segment(args):
+    """One ~1 GiB segment of the cfg4 stream (worker process): the cfg3 generator with its own seed and LSN base."""
+    import numpy as np
+
+    from etl_amd import synth
+    k, nbytes = args
+    w = synth.Workload([synth.table_mixed()], 0xE710004 + k, rows_per_txn=500, mix=(60, 30, 10), upd_key=10, upd_toast=5,
+                       start_lsn=0x1000000 + (k << 36), name="cfg4_segment")
+    parts, got = [], 0
+    while got < nbytes:
+        b, _ = w.fill(min(256 << 20, nbytes - got + (1 << 20)))
+        if len(b) == 0:
+            break
+        parts.append(b)
+        got += len(b)
+    return np.concatenate(parts)
+
+
+def leg_cfg4(dev_id, dev, world, rank, total_gib, seg_mib, gather_arenas, dist):
+    """BASELINE configs[3]: ONE stream of `total_gib` GiB (8 segments of the cfg3 generator, consecutive LSN ranges) cut into
+    `world` commit-aligned shards. Per rank, timed: device record-boundary scan of the shard, device frame tags, control-frame
+    broadcast, decode in <= 1 GiB batches, header all-gather (+ the padded arena all-gather with --gather-arenas)."""
+    import multiprocessing as mp
+
+    import numpy as np
+    import torch
+
+    from etl_amd import abi, shard, synth
+    from etl_amd.decoder import Decoder
+    nseg = max(world, (total_gib << 10) // seg_mib)
+    mine = [k for k in range(nseg) if k * world // nseg == rank]    # contiguous segments of this rank
+    t_gen = time.perf_counter()
+    with mp.get_context("fork").Pool(min(len(mine), max(1, (os.cpu_count() or 8) // max(world, 1)))) as pool:
+        segs = pool.map(_gen_segment, [(k, seg_mib << 20) for k in mine])
+    t_gen = time.perf_counter() - t_gen
+    w = synth.Workload([synth.table_mixed()], 0xE710004, name="cfg4")
+    dec = Decoder(dev_id)
+    w.register(dec)
+    d_segs = [torch.from_numpy(s).to(dev) for s in segs]
+    nbytes = sum(len(s) for s in segs)
+    cap_frames = max(len(s) for s in segs) // 24 + 1024
+    d_offs = [torch.empty(cap_frames + 2, dtype=torch.int32, device=dev) for _ in segs]
+    d_tags = [torch.empty(cap_frames + 2, dtype=torch.uint8, device=dev) for _ in segs]
+    torch.cuda.synchronize()
+
+    def run(check):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames, keep, ctrl = 0, [], []
+        for s, o, t in zip(d_segs, d_offs, d_tags):   # (1) boundaries + tags on the device, cut points on the host
+            nf = dec.scan_boundaries_device(s.data_ptr(), s.numel(), o.data_ptr(), o.numel())
+            dec.frame_tags_device(s.data_ptr(), s.numel(), o.data_ptr(), nf, t.data_ptr())
+            tags = t[:nf].cpu().numpy()
+            assert tags[nf - 1] == ord("C"), "a segment ends after a Commit"
+            has_ctrl = np.flatnonzero((tags == ord("R")) | (tags == ord("M")))
+            if len(has_ctrl):   # rare: pull those transactions back and extract the control stream
+                ctrl.append(shard.control_stream(s.cpu().numpy(), o[:nf + 1].cpu().numpy().view(np.uint32), tags=tags))
+            frames += nf
+            keep.append((s, o, nf))
+        if dist is not None:   # (2) control frames of earlier ranks (cfg4 has none after the schemas are primed: an empty exchange)
+            mine_ctrl = (np.concatenate([c[0] for c in ctrl]) if ctrl else np.zeros(0, np.uint8), np.zeros(1, np.uint32))
+            shard.replay_control(dec, [x for x in shard.all_gather_control(mine_ctrl)[:rank] if len(x[1]) > 1])
+        dec.reset_stream_state()
+        batches = []
+        fl = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
+        hdrs = torch.zeros((len(keep), 8), dtype=torch.int64, device=dev)
+        for i, (s, o, nf) in enumerate(keep):          # (3) decode, one batch per segment (<= 1 GiB)
+            b = dec.decode_device(s.data_ptr(), s.numel(), o.data_ptr(), nf, fl)
+            b.header_to_device(hdrs[i].data_ptr())
+            batches.append((b, nf))
+        lay = None
+        if dist is not None:                           # (4) one all-gather of the 64-byte headers: the global layout
+            g = torch.empty((world, hdrs.numel()), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(g, hdrs.reshape(1, -1))
+        ev = ob = 0
+        for b, nf in batches:
+            rc = b.sync()
+            v = b.view()
+            assert not check or (rc == 0 and v.n_frames == nf), (rc, b.error)
+            ev += v.n_events
+            ob += HEADER_BYTES_PER_EVENT * v.n_events + v.fixed_bytes + v.heap_bytes
+        gathered = 0
+        if dist is not None and gather_arenas:         # (5) optional: the arenas themselves, padded, to every rank
+            import ctypes as C
+            for b, nf in batches:
+                v = b.view()
+                arrs = {}
+                for name, ptr, n, item in (("kind", v.ev_kind, v.n_events, 1), ("flags", v.ev_flags, v.n_events, 1),
+                                           ("table_id", v.ev_table_id, v.n_events, 4), ("schema_slot", v.ev_schema_slot, v.n_events, 4),
+                                           ("start_lsn", v.ev_start_lsn, v.n_events, 8), ("commit_lsn", v.ev_commit_lsn, v.n_events, 8),
+                                           ("tx_ordinal", v.ev_tx_ordinal, v.n_events, 8), ("body_off", v.ev_body_off, v.n_events, 8),
+                                           ("fixed", v.fixed, v.fixed_bytes, 1), ("heap", v.heap, v.heap_bytes, 1)):
+                    arrs[name] = abi.device_tensor(C.cast(ptr, C.c_void_p).value or 0, int(n) * item, dev)
+                g2, lens = shard.all_gather_arenas(arrs)
+                gathered += sum(int(x.numel()) for x in g2.values())
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        for b, _ in batches:
+            b.close()
+        return dt, frames, ev, ob, gathered
+
+    run(True)
+    dt, frames, ev, ob, gathered = min((run(True) for _ in range(2)), key=lambda r: r[0])
+    tot = torch.tensor([nbytes, frames, ev], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tot)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dec.profile(True)
+    run(False)
+    kern = kernel_table(dec.profile_read())
+    dec.profile(False)
+    dec.close()
+    dt = float(tmax.item())
+    return {"value": round(int(tot[0]) / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(int(tot[2]) / dt, 1), "n_gpus": world,
+            "hbm_read_frac": round(int(tot[0]) / dt / 1e9 / (HBM_PEAK_GBPS * world), 5), "seconds": round(dt, 4),
+            "stream_bytes": int(tot[0]), "frames": int(tot[1]), "shard_bytes_rank0": nbytes, "segments_per_rank": len(mine),
+            "generation_s_rank0": round(t_gen, 1), "arena_bytes_gathered_rank0": gathered,
+            "kernels_us_rank0": {k: round(v["avg_us"], 1) for k, v in kern.items()},
+            "workload": f"cfg4: one {total_gib} GiB stream (cfg3 generator, {nseg} segments of {seg_mib} MiB with consecutive LSN ranges) cut into "
+                        f"{world} commit-aligned shard(s); per rank: device boundary scan + frame tags, control broadcast, decode in "
+                        f"{seg_mib} MiB batches, header all-gather" + (", padded arena all-gather" if gather_arenas else "")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--inner", type=int, default=10, help="64 MiB batches decoded per step")
     ap.add_argument("--batch-mib", type=int, default=64)
     ap.add_argument("--pool", type=int, default=6, help="distinct batches resident in HBM (rotated)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar", help="extra legs on rank 0 (comma separated; empty = none)")
+    ap.add_argument("--cfg4-leg", action="store_true", help="add the cfg4 leg to a cfg2 / cfg3 run")
+    ap.add_argument("--cfg4-gib", type=int, default=8)
+    ap.add_argument("--cfg4-seg-mib", type=int, default=1024)
+    ap.add_argument("--gather-arenas", action="store_true", help="cfg4: also all-gather the arenas (padded) to every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = the cores available, at most 64; 1 = skip)")
@@ -122,8 +496,10 @@ def main():
     ap.add_argument("--no-scan-leg", action="store_true")
     ap.add_argument("--gather-every", type=int, default=4, help="N > 1: batches per header all-gather (their 64-byte headers travel together)")
     args = ap.parse_args()
+    legs = [x for x in args.legs.split(",") if x]
+    if args.no_scan_leg and "no_sidecar" in legs:
+        legs.remove("no_sidecar")
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -142,110 +518,92 @@ def main():
     assert world == args.gpus or world == 1, (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    check = not args.no_check
 
-    # ---- workload: this rank's shard = its own contiguous range of the stream
+    if args.workload == "cfg4":
+        r = leg_cfg4(local_rank, dev, world, rank, args.cfg4_gib, args.cfg4_seg_mib, args.gather_arenas, dist if gather else None)
+        if rank == 0:
+            out = {"metric": "WAL bytes/s decoded", "value": r["value"], "unit": "GB/s", "n_gpus": world, "steps": 1, "warmup": 1,
+                   "ms_per_step": round(1000.0 * r["seconds"], 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "u8", "data": "synthetic", "events_per_s": r["events_per_s"], "hbm_read_frac": r["hbm_read_frac"],
+                   "config": {"workload": r["workload"], "parallelism": f"shard{world}"}, "cfg4": r}
+            print(json.dumps(out))
+        if gather:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- headline workload: this rank's shard = its own contiguous range of the stream
     mk = synth.cfg2 if args.workload == "cfg2" else synth.cfg3
     w = mk()
     cap = args.batch_mib << 20
     # every rank walks the same deterministic stream and keeps batches rank, rank+world, ...
     # (contiguous commit-aligned ranges; rank order == LSN order inside each step)
     pool = []
-    need = args.pool
     i = 0
-    while len(pool) < need:
+    while len(pool) < args.pool:
         buf, offs = w.fill(cap)
         if i % world == rank:
             pool.append((buf, offs))
         i += 1
-    d_in = [(torch.from_numpy(b).to(dev), torch.from_numpy(o.view(np.int32)).to(dev), len(b), len(o) - 1) for b, o in pool]
-    torch.cuda.synchronize()
+    items = to_device(pool, dev)
 
     dec = Decoder(local_rank)
     stream = torch.cuda.Stream(device=dev)   # decode kernels, header copy and the all-gather share one stream
     torch.cuda.set_stream(stream)
     dec.set_stream(stream.cuda_stream)
     w.register(dec)
-    # One 64-byte header slot per step; with N > 1 the headers of G consecutive batches travel in ONE
+    # One 64-byte header slot per batch; with N > 1 the headers of G consecutive batches travel in ONE
     # asynchronous all-gather that overlaps the following decodes (etl_amd/shard.py: HeaderGatherer).
     G = max(1, args.gather_every)
-    nbatches = ((args.warmup + G - 1) // G) * G + args.steps
+    inner = max(1, args.inner)
+    nwarm = ((args.warmup * inner + G - 1) // G) * G
+    nbatches = nwarm + args.steps * inner
     hg = shard.HeaderGatherer(nbatches, G, dev, world=world) if gather else None
     hdrs = hg.headers if gather else torch.zeros((nbatches + G, 8), dtype=torch.int64, device=dev)
     flags = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
 
-    def step(k, keep):
-        tb, to, nbytes, nfr = d_in[k % len(d_in)]
-        b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, flags)
-        b.header_to_device(hdrs[k].data_ptr())
-        keep.append((b, nbytes, nfr, k))
+    # Arena pool priming (setup, like allocating buffers): the timed loop keeps WINDOW batches in flight, each holding its
+    # own output arena; the library grows that pool on demand with hipMalloc, which serialises host and device.
+    p = Pipeline(dec, items, flags, check)
+    for _ in range(WINDOW + 2):
+        p.issue()
+    p.drain()
+    p = Pipeline(dec, items, flags, check)
+    for k in range(nwarm):
+        p.issue(hdrs[k].data_ptr())
         if gather:
             hg.batch_done(k)
-
-    def flush_gathers(k_end):
-        if gather:
-            hg.flush(k_end)
-
-    def wait_gathers():
-        if gather:
-            hg.wait()
-
-    out_bytes = [0]   # arena bytes written by the drained batches (headers + fixed + heap)
-
-    def drain(keep, check):
-        tot_b = tot_f = 0
-        for b, nbytes, nfr, g in keep:
-            rc = b.sync()
-            v = b.view()
-            if check and not args.no_check:
-                assert rc == 0 and v.n_events == nfr and v.n_frames == nfr, (rc, v.n_events, v.n_frames, nfr, b.error)
-            out_bytes[0] += HEADER_BYTES_PER_EVENT * v.n_events + v.fixed_bytes + v.heap_bytes
-            tot_b += nbytes
-            tot_f += nfr
-            b.close()
-        return tot_b, tot_f
-
-    # Arena pool priming (setup, like allocating buffers): the timed loop keeps `steps` batches in flight, each
-    # holding its own output arena; the library grows that pool on demand with hipMalloc, which serialises host
-    # and device, so the pool is grown to its working size here, before warm-up, and only reused afterwards.
-    prime = [dec.decode_device(d_in[k % len(d_in)][0].data_ptr(), d_in[k % len(d_in)][2], d_in[k % len(d_in)][1].data_ptr(),
-                               d_in[k % len(d_in)][3], flags) for k in range(args.steps + 1)]
+    p.drain()
+    if gather:
+        hg.flush(nwarm)
+        hg.wait()
     torch.cuda.synchronize()
-    for b in prime:
-        b.sync(); b.close()
-    del prime
 
-    keep = []
-    for k in range(args.warmup):
-        step(k, keep)
-    flush_gathers(args.warmup)
-    wait_gathers()
-    torch.cuda.synchronize()
-    drain(keep, True)
-
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    keep = []
+    # ---- timed region: exactly K steps (K x inner batches), barrier + synchronize on both sides
+    p = Pipeline(dec, items, flags, check)
     if gather:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k0 = ((args.warmup + G - 1) // G) * G   # the timed steps start on a group boundary
-    for k in range(args.steps):
-        step(k0 + k, keep)
-    flush_gathers(k0 + args.steps)
+    for k in range(args.steps * inner):
+        p.issue(hdrs[nwarm + k].data_ptr())
+        if gather:
+            hg.batch_done(nwarm + k)
+    if gather:
+        hg.flush(nbatches)
+    p.drain()
     ta = time.perf_counter()
-    wait_gathers()
-    tb_ = time.perf_counter()
+    if gather:
+        hg.wait()
     torch.cuda.synchronize()
-    tc = time.perf_counter()
     if gather:
         dist.barrier()
     t1 = time.perf_counter()
     if os.environ.get("ETLG_BENCH_DEBUG"):
-        print(f"[bench debug] enqueue {1e3 * (ta - t0):.2f} ms, wait gathers {1e3 * (tb_ - ta):.2f} ms, sync {1e3 * (tc - tb_):.2f} ms, "
-              f"barrier {1e3 * (t1 - tc):.2f} ms", file=sys.stderr)
+        print(f"[bench debug] enqueue+drain {1e3 * (ta - t0):.2f} ms, gathers+sync+barrier {1e3 * (t1 - ta):.2f} ms", file=sys.stderr)
     elapsed = t1 - t0
-    last_k = keep[-1][3]
-    my_bytes, my_frames = drain(keep, True)
+    my_bytes, my_frames = p.bytes, p.frames
     if gather:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,72 +611,50 @@ def main():
         tot = torch.tensor([my_bytes, my_frames], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         all_bytes, all_frames = int(tot[0].item()), int(tot[1].item())
-        lay = shard.global_layout(hg.headers_of(last_k).cpu().numpy())   # the last batch's headers, rank-major
+        lay = shard.global_layout(hg.headers_of(nbatches - 1).cpu().numpy())   # the last batch's headers, rank-major
         assert args.no_check or not lay["any_error"]
     else:
         all_bytes, all_frames = my_bytes, my_frames
 
-    # ---- roofline leg: HIP-event timing of every kernel over a fresh run of K steps (rank 0)
+    # ---- roofline leg: HIP-event timing of every kernel over a fresh run of 4 x inner batches (rank 0)
     roof = None
-    kern = {}
+    paths = None
     if rank == 0:
         dec.profile(True)
-        keep = []
-        for k in range(args.steps):
-            tb, to, nbytes, nfr = d_in[k % len(d_in)]
-            keep.append((dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, flags), nbytes, nfr, None))
+        q = Pipeline(dec, items, flags, check)
+        nprof = max(4 * inner, 20)
+        for _ in range(nprof):
+            q.issue()
+        q.drain()
         torch.cuda.synchronize()
-        prof = dec.profile_read()
+        kern = kernel_table(dec.profile_read())
         dec.profile(False)
-        out_bytes[0] = 0
-        pb, pf = drain(keep, True)
-        kern = {k: {"launches": n, "avg_us": 1000.0 * ms / n} for k, (n, ms) in prof.items() if n}
-        dom = max(kern, key=lambda k: kern[k]["avg_us"])
-        alg_bytes = (pb + SIDECAR_BYTES_PER_FRAME * pf + out_bytes[0]) / args.steps
-        ach = alg_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9
-        pipe_us = sum(v["avg_us"] for v in kern.values())
+        alg_bytes = (q.bytes + SIDECAR_BYTES_PER_FRAME * q.frames + q.out_bytes) / nprof
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command
         # (tools/traffic.sh writes the file; FETCH_SIZE doubled per MI355X_MICROARCH.md, gfx950 note)
         traffic = None
         tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+        dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
         if os.path.exists(tf):
             t = json.load(open(tf))
             if t.get("kernel") == dom and t.get("batch_mib") == args.batch_mib:
                 traffic = t["hbm_bytes_per_launch"]
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(kern[dom]["avg_us"], 2),
-                "pipeline_kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
-                "pipeline_sum_us": round(pipe_us, 2),
-                "pipeline_frac": round(alg_bytes / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+        roof = roofline_of(kern, alg_bytes, traffic)
+        paths = dec.debug_paths()
 
-    # ---- no-sidecar leg (rank 0): the same batches with frame_offsets = NULL, i.e. the record-boundary
-    #      scan runs on the device first (scan.hip). Reported beside `value`, never as `value`: the
-    #      reference's host learns every frame length from its socket codec, so a sidecar costs it nothing.
-    scan = None
-    if rank == 0 and not args.no_scan_leg:
-        fl = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL
-        for k in range(2):
-            tb, to, nbytes, nfr = d_in[k % len(d_in)]
-            dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl).close()
-        dec.profile(True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nb = 0
-        for k in range(args.steps):
-            tb, to, nbytes, nfr = d_in[k % len(d_in)]
-            b = dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl)
-            assert args.no_check or (b.rc == 0 and b.view().n_frames == nfr)
-            nb += nbytes
-            b.close()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        prof = dec.profile_read()
-        dec.profile(False)
-        kb = prof.get("k_bounds", (0, 0.0))
-        scan = {"value": round(nb / (t1 - t0) / 1e9, 3), "unit": "GB/s", "k_bounds_avg_us": round(1000.0 * kb[1] / max(kb[0], 1), 2),
-                "k_bounds_launches_per_batch": round(kb[0] / args.steps, 2),
-                "note": "frame_offsets = NULL: device record-boundary scan + decode, synchronous (the host reads the frame count back)"}
+    extra = {}
+    if rank == 0:
+        if "no_sidecar" in legs and args.workload == "cfg2":
+            extra["no_sidecar"] = leg_no_sidecar(dec, items, 20, check)
+        if "cfg3" in legs and args.workload != "cfg3":
+            extra["cfg3"] = leg_async(synth.cfg3, local_rank, dev, cap, 4, 60, flags, check,
+                                      os.path.join(ROOT, "profiles", "traffic_cfg3.json"))[0]
+        if "cfg5" in legs:
+            extra["cfg5"] = leg_cfg5(local_rank, dev, cap, 4, 2)
+        if "copy" in legs:
+            extra["copy"] = leg_copy(local_rank, dev, 400000, 8)
+    if args.cfg4_leg and world == 1:
+        extra["cfg4"] = leg_cfg4(local_rank, dev, 1, 0, args.cfg4_gib, args.cfg4_seg_mib, False, None)
 
     # ---- CPU baseline leg (rank 0, N == 1 only): the oracle on the same host cores
     cpu = None
@@ -357,11 +693,13 @@ def main():
             "events_per_s": round(all_frames / elapsed, 1),
             "hbm_read_frac": round(value / (HBM_PEAK_GBPS * world), 5),   # input bytes/s per GPU over the 8 TB/s spec
             "config": {"workload": f"{w.name}: {args.batch_mib} MiB batches of CopyData-framed pgoutput, "
-                                   "device-resident in / device-resident out, offsets sidecar, NO_CONTROL",
-                       "batch_bytes": int(my_bytes / args.steps), "frames_per_batch": int(my_frames / args.steps),
-                       "pool_batches": len(pool), "parallelism": f"shard{world}"},
-            "roofline": roof, "cpu_baseline": cpu, "no_sidecar": scan,
+                                   "device-resident in / device-resident out, offsets sidecar, NO_CONTROL | ASYNC",
+                       "batches_per_step": inner, "batch_bytes": int(my_bytes / (args.steps * inner)),
+                       "frames_per_batch": int(my_frames / (args.steps * inner)),
+                       "pool_batches": len(pool), "parallelism": f"shard{world}", "kernel_paths": paths},
+            "roofline": roof, "cpu_baseline": cpu,
         }
+        out.update(extra)
         print(json.dumps(out))
     dec.close()
     if gather:

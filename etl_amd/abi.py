@@ -118,3 +118,18 @@ def make_cols(cols):
         arr[i].primary_key = 1 if pk else 0
     arr._keep = keep
     return arr
+
+
+class _DevArray:
+    """Raw device memory as a __cuda_array_interface__ object (what torch.as_tensor needs to wrap a pointer)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, nbytes, device):
+    """A uint8 torch tensor over `nbytes` of device memory at `ptr` (no copy; the owner must outlive it)."""
+    import torch
+    if not nbytes:
+        return torch.zeros(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_DevArray(ptr, nbytes), device=device)

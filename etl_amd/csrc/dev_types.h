@@ -56,6 +56,7 @@ struct CtrlFrame {
   uint32_t in_txn;
   uint32_t _pad;
   uint64_t final_lsn;
+  uint32_t o0, o1;     // byte range of the frame in the input (so the host fetches its bytes without another round trip)
 };
 
 // Result block (device -> host, one small copy per batch).

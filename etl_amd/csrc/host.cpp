@@ -248,7 +248,11 @@ struct etlg_ctx {
   uint32_t plan_dbg = 0;         // ETLG_PLAN_DBG: bit 0 = no LDS staging (tests of the in-place reader)
   int n_cus = 256;
   uint32_t plan_skip = 0, plan_penalty = 4, plan_streak = 0;
+  bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
+  bool last_any_sync_done = false;
+  bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
   std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order
+  std::vector<hipEvent_t> ev_pool;   // "result block copied back" events of finished batches
   std::vector<DevTable> last_tables;   // what d_tables / d_epochs currently hold
   std::vector<DevEpoch> last_epochs;
   bool side_valid = false;
@@ -287,6 +291,7 @@ struct etlg_batch {
   size_t len = 0;
   const uint8_t* host_in = nullptr; const uint32_t* host_offs = nullptr; const uint8_t* dev_in = nullptr;
   uint64_t ctx_gen = 0;
+  hipEvent_t done = nullptr;  // recorded behind the copy of the result block: syncing a batch waits for IT, not for the whole stream
   DevResult* h_res = nullptr;  // pinned, from the context's pool
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
   DevResult* d_res_blk = nullptr;  // this batch's result block on the device
@@ -664,6 +669,7 @@ HostErr handle_relation(etlg_ctx* c, const CtrlFrame& cf, const uint8_t* body, s
   for (auto& sc : sch->cols) { rm.push_back(repl.count(sc.name) ? 1 : 0); im.push_back(ident.count(sc.name) ? 1 : 0); }
   const int32_t slot = make_slot(c, sch, rm, im);
   c->cs.cache[rel_id] = CacheEntry{2, sch->snapshot, slot};  // note_ready
+  c->side_dirty = true;
   eps.push_back({rel_id, DevEpoch{cf.frame, 2, slot, 1}});
   return {};
 }
@@ -686,6 +692,7 @@ HostErr handle_ddl(etlg_ctx* c, const CtrlFrame& cf, uint64_t wal_start, const u
   const uint32_t tid = sch->table_id;
   c->cs.store[tid][sch->snapshot] = sch;                       // store_table_schema
   c->cs.cache[tid] = CacheEntry{1, wal_start, -1};             // note_waiting_for_relation
+  c->side_dirty = true;
   eps.push_back({tid, DevEpoch{cf.frame, 1, -1, 0}});
   return {};
 }
@@ -875,6 +882,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& pr : c->harena_pool) (void)hipHostFree(pr.first);
   if (c->h_init) (void)hipHostFree(c->h_init);
   if (c->h_init_ring) (void)hipHostFree(c->h_init_ring);
@@ -896,7 +904,7 @@ int32_t etlg_ctx_set_stream(etlg_ctx* c, void* s) {
 int32_t etlg_ctx_set_worker(etlg_ctx* c, int32_t kind, uint32_t table_id, uint64_t bootstrap) {
   if (!c) return ETLG_InvalidArgument;
   (void)drain_pending(c);
-  c->worker = kind; c->sync_table = table_id; c->bootstrap = bootstrap; c->side_valid = false;
+  c->worker = kind; c->sync_table = table_id; c->bootstrap = bootstrap; c->side_valid = false; c->side_dirty = true;
   return ETLG_OK;
 }
 
@@ -919,6 +927,7 @@ int32_t etlg_table_state(etlg_ctx* c, uint32_t table_id, int32_t kind, uint64_t 
   if (!c) return ETLG_InvalidArgument;
   (void)drain_pending(c);
   if (kind == ETLG_TS_ABSENT) c->states.erase(table_id); else c->states[table_id] = TState{kind, lsn};
+  c->side_dirty = true;
   return ETLG_OK;
 }
 
@@ -930,6 +939,7 @@ int32_t etlg_table_ready(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, cons
   std::vector<uint8_t> r(rmask, rmask + n), i(imask, imask + n);
   const int32_t slot = make_slot(c, sch, r, i);
   c->cs.cache[table_id] = CacheEntry{2, sch->snapshot, slot};
+  c->side_dirty = true;
   return slot;
 }
 
@@ -1226,7 +1236,9 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   //      <0.1 % of frames and absent from almost every batch): no classify / control-list kernels, no host round trip. A
   //      control frame makes that kernel report ETLG_E_CTRL_HINT and the batch takes the control path then (finish_batch).
   const bool single_pass = nf && !c->force_multipass && len < (1ull << 31);
-  if (single_pass) {
+  // ... unless the batch before this one held control frames and the caller asserts nothing: streams that change schemas often
+  // (DDL messages every few hundred transactions) would pay for a wasted kernel on every batch
+  if (single_pass && (no_ctrl || !c->last_had_ctrl)) {
     p.flags |= 1u;
     const std::vector<EpochRec> no_eps;
     { const int32_t rc = build_side_inputs(c, b, no_eps); if (rc != ETLG_OK) return rc; }
@@ -1237,6 +1249,11 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     if (rc != ETLG_OK) return rc;
   }
   HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  if (async) {
+    if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
+    b->done = c->ev_pool.back(); c->ev_pool.pop_back();
+    HIPCHK(c, hipEventRecord(b->done, s));
+  }
 
   guard.b = nullptr;
   *out = b;
@@ -1283,11 +1300,13 @@ void etlg_batch_free(etlg_batch* b) {
       b->pending = false;
     }
     if (b->h_res) (void)hipStreamSynchronize(c->stream);
+    if (b->done) c->ev_pool.push_back(b->done);
     if (b->dev) c->out_pool.push_back(b->dev);
     if (b->h_res) c->res_pool.push_back(b->h_res);
     if (b->h_arena) c->harena_pool.emplace_back(b->h_arena, b->h_arena_cap);
   } else {  // the context is gone (its pools with it): release what the batch owns outright
     if (b->dev) { b->dev->release(); delete b->dev; }
+    if (b->done) (void)hipEventDestroy(b->done);
     if (b->h_res) (void)hipHostFree(b->h_res);
     if (b->h_arena) (void)hipHostFree(b->h_arena);
   }
@@ -1370,6 +1389,15 @@ int32_t setup_scratch(etlg_ctx* c, DecParams& p) {
 int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec>& eps) {
   DecParams& p = b->params;
   hipStream_t s = c->stream;
+  if (eps.empty() && c->side_valid && !c->side_dirty && !c->slots_dirty && c->last_epochs.empty() && !b->have_snapshot) {
+    // nothing the side inputs are built from has changed since the last upload (the common case: one call per batch)
+    p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)c->last_tables.size();
+    p.n_epochs = 0;
+    b->any_sync_done = c->last_any_sync_done;
+    p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
+    p.n_slots = c->n_dev_slots; p.n_cols = c->n_dev_cols;
+    return ETLG_OK;
+  }
   std::map<uint32_t, DevTable> tabs;
   auto get = [&](uint32_t id) -> DevTable& {
     auto it = tabs.find(id);
@@ -1441,6 +1469,8 @@ int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec
   p.n_epochs = (uint32_t)ev.size();
   b->any_sync_done = false;
   for (auto& t : tv) if (t.state_kind == ETLG_TS_SYNC_DONE) b->any_sync_done = true;
+  c->last_any_sync_done = b->any_sync_done;
+  if (!b->have_snapshot) c->side_dirty = false;   // built from the live control state
   p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
   p.n_slots = c->n_dev_slots; p.n_cols = c->n_dev_cols;
   return ETLG_OK;
@@ -1537,7 +1567,12 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
   uint32_t widest = 1;
   for (auto& sl : c->slots) widest = std::max<uint32_t>(widest, sl->desc.n_cols);
   const bool cells_ok = widest <= etlg_k_cells_maxc() && q.side_bytes != 0;  // k_cells keeps the side tables in LDS
-  int kernel = avg <= 192 ? 0 : (cells_ok ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
+  bool any_var = false;   // a table the batch may carry has TEXT / NUMERIC / ... columns: one lane per frame crawls on those
+  for (auto& sl : c->slots) for (auto& sc : sl->cols) {
+    const int32_t k = sc.type_class;
+    if (!(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32 || k == ETLG_TC_UUID)) any_var = true;
+  }
+  int kernel = (avg <= 192 && !(any_var && cells_ok && avg > 96)) ? 0 : (cells_ok ? 2 : 1);  // 0 fused/256, 1 fused/64, 2 cells
   if (c->fused_kernel >= 0 && c->fused_kernel <= 2) kernel = c->fused_kernel == 2 && !cells_ok ? 1 : c->fused_kernel;
   const bool use_cells = kernel == 2;
   q.blk = kernel == 0 ? 256u : 64u;
@@ -1592,21 +1627,20 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
   ctrl.resize(nctrl);
   HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
   std::sort(ctrl.begin(), ctrl.end(), [](const CtrlFrame& a, const CtrlFrame& b2) { return a.frame < b2.frame; });
-  const bool offs_dev_only = b->host_offs == nullptr;  // no host copy of the offsets exists
-  std::vector<uint8_t> tmp;
-  for (const CtrlFrame& cf : ctrl) {
-    uint32_t o0, o1;
-    if (offs_dev_only) {
-      uint32_t oo[2];
-      HIPCHK(c, hipMemcpy(oo, p.offs + cf.frame, 8, hipMemcpyDeviceToHost));
-      o0 = oo[0]; o1 = oo[1];
-    } else { o0 = b->host_offs[cf.frame]; o1 = b->host_offs[cf.frame + 1]; }
-    if (b->in_dev) {
-      tmp.resize(o1 - o0);
-      HIPCHK(c, hipMemcpy(tmp.data(), b->dev_in + o0, o1 - o0, hipMemcpyDeviceToHost));
-    }
-    const uint8_t* fr = b->in_dev ? tmp.data() : b->host_in + o0;
-    const size_t flen = o1 - o0;
+  // the frames' bytes: already on the host, or fetched from the device with ONE synchronisation for all of them
+  std::vector<uint8_t> stage;
+  std::vector<size_t> at(nctrl + 1, 0);
+  for (uint32_t i = 0; i < nctrl; i++) at[i + 1] = at[i] + (ctrl[i].o1 - ctrl[i].o0);
+  if (b->in_dev) {
+    stage.resize(at[nctrl] + 16);
+    for (uint32_t i = 0; i < nctrl; i++)
+      if (ctrl[i].o1 > ctrl[i].o0) HIPCHK(c, hipMemcpyAsync(stage.data() + at[i], b->dev_in + ctrl[i].o0, ctrl[i].o1 - ctrl[i].o0, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  for (uint32_t i = 0; i < nctrl; i++) {
+    const CtrlFrame& cf = ctrl[i];
+    const uint8_t* fr = b->in_dev ? stage.data() + at[i] : b->host_in + cf.o0;
+    const size_t flen = cf.o1 - cf.o0;
     b->ctrl_raw.emplace_back(fr, fr + flen);
     // classify guaranteed 'd' len 'w' hdr tag: body starts at +31
     uint64_t wal_start = 0;
@@ -1661,7 +1695,8 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
   };
 #define FB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip(e_); } while (0)
 #define FB_RC(call) do { const int32_t rc_ = (call); if (rc_ != ETLG_OK) { b->pending = false; b->finished = true; b->rc = rc_; b->err = c->err; return rc_; } } while (0)
-  FB_HIP(hipStreamSynchronize(s));
+  if (b->done) FB_HIP(hipEventSynchronize(b->done));   // batches queued behind this one keep running
+  else FB_HIP(hipStreamSynchronize(s));
   bool redone_mp = false;
   for (int guard = 0; guard < 8; guard++) {
     const DevResult& r0 = *b->h_res;
@@ -1719,7 +1754,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
       // roll back, then replay the prefix (rare path; errors end the stream anyway)
       c->cs = b->snapshot;
       c->slots.resize(b->snapshot.n_slots);
-      c->slots_dirty = true;
+      c->slots_dirty = true; c->side_dirty = true;
       // Effects of the control frames before `frame` are re-applied from the copies of their bytes kept
       // by the first pass (the input itself may be device-resident, or have come without a sidecar).
       std::vector<EpochRec> eps;
@@ -1734,6 +1769,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
       }
     }
   }
+  if (!b->user_no_ctrl) c->last_had_ctrl = b->ctrl_done && !b->ctrl.empty();
   b->have_snapshot = false;
   b->snapshot = ControlState{};
   b->ctrl_raw.clear();

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kBlock) void k_ctrl_list(DecParams p) {
     if (i < p.ctrl_cap) {
       CtrlFrame c;
       c.frame = f; c.tag = tag; c.in_txn = t.in_txn; c._pad = 0; c.final_lsn = t.final_lsn;
+      c.o0 = p.offs[f]; c.o1 = p.offs[f + 1];
       p.ctrl[i] = c;
     }
   }

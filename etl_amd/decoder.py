@@ -199,6 +199,15 @@ class Decoder:
         if rc != 0:
             raise RuntimeError(f"etlg_frame_tags failed: {rc}")
 
+    def scan_boundaries_device(self, buf_ptr, nbytes, out_ptr, cap):
+        """Record-boundary scan of a device-resident stream into a device array of `cap` u32 entries; returns nframes."""
+        n = C.c_size_t()
+        rc = self.L.etlg_scan_boundaries(self.h, C.c_void_p(buf_ptr), nbytes, abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE,
+                                         C.c_void_p(out_ptr), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"etlg_scan_boundaries failed: {rc}")
+        return int(n.value)
+
     def scan_boundaries(self, buf, max_frames=None):
         """Record-boundary scan of a host buffer on the device: np.uint32 offsets (nframes + 1)."""
         import numpy as np

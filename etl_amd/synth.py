@@ -170,3 +170,35 @@ def cfg5(seed=0xE710005):
     return Workload([table_fixed(), table_w8(), table_mixed()], seed, rows_per_txn=50, mix=(60, 30, 10), upd_key=10,
                     upd_toast=5, emit_relations=1, emit_origin=1, ddl_every=200, type_msg_pct=10, keepalive_every=997,
                     name="cfg5_ddl_3tables")
+
+
+# ---- table-copy rows (COPY ... TO STDOUT, text format: what etlg_copy_decode takes) -----------------------------------
+BYTEA, FLOAT8 = 17, 701
+COPY_COLS = [("id", INT8, False, 1), ("a", INT4, False, 0), ("b", BOOL, False, 0), ("n", NUMERIC, False, 0),
+             ("t", TEXT, False, 0), ("tn", TEXT, True, 0), ("ts", TIMESTAMPTZ, False, 0), ("u", UUID, False, 0),
+             ("f", FLOAT8, False, 0), ("by", BYTEA, False, 0)]
+
+
+def copy_rows(n, seed):
+    """n COPY text rows for COPY_COLS (int8, int4, bool, numeric, text, text NULLable, timestamptz, uuid, float8, bytea),
+    every backslash escape of the format included."""
+    import random
+    rng = random.Random(seed)
+    alphabet = "abcdefghij XYZ\t\n\\\r\x08\x0c\x0b\u00e9\u4e2d\U0001F600,;{}\"'"
+    esc_map = {"\t": "\\t", "\n": "\\n", "\\": "\\\\", "\r": "\\r", "\x08": "\\b", "\x0c": "\\f", "\x0b": "\\v"}
+
+    def esc(s):
+        return "".join(esc_map.get(ch, ch) for ch in s)
+
+    rows = []
+    for i in range(n):
+        txt = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 80)))
+        f = [str(i), str(rng.randint(-2**31, 2**31 - 1)), rng.choice("tf"),
+             rng.choice(["0", "-12.5", "123456789.000100", "NaN", "1e5", "0.000012"]),
+             esc(txt), "\\N" if rng.random() < 0.3 else esc(txt[:10]),
+             "2024-0%d-1%d 0%d:30:15.%06d+0%d" % (rng.randint(1, 9), rng.randint(0, 9), rng.randint(0, 9), rng.randint(0, 999999), rng.randint(0, 9)),
+             "%08x-1111-2222-3333-%012x" % (rng.getrandbits(32), rng.getrandbits(48)),
+             rng.choice(["1.5", "-0.25", "1e300", "3.141592653589793", "12345678901234567890123", "nan"]),
+             "\\\\x" + "".join("%02x" % rng.getrandbits(8) for _ in range(rng.randint(0, 20)))]
+        rows.append(("\t".join(f) + "\n").encode())
+    return rows

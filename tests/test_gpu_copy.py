@@ -63,34 +63,7 @@ def test_copy_kat_errors(cols, row, code, path):
     d.close()
 
 
-def _gen_rows(n, seed):
-    """Rows for (int8, int4, bool, numeric, text, text NULLable, timestamptz, uuid, float8, bytea) with escapes."""
-    rng = random.Random(seed)
-    alphabet = "abcdefghij XYZ\t\n\\\r\x08\x0c\x0bé中\U0001F600,;{}\"'"
-
-    def esc(s):
-        out = []
-        for ch in s:
-            out.append({"\t": "\\t", "\n": "\\n", "\\": "\\\\", "\r": "\\r", "\x08": "\\b", "\x0c": "\\f", "\x0b": "\\v"}.get(ch, ch))
-        return "".join(out)
-
-    rows = []
-    for i in range(n):
-        txt = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 80)))
-        f = [str(i), str(rng.randint(-2**31, 2**31 - 1)), rng.choice("tf"),
-             rng.choice(["0", "-12.5", "123456789.000100", "NaN", "1e5", "0.000012"]),
-             esc(txt), "\\N" if rng.random() < 0.3 else esc(txt[:10]),
-             "2024-0%d-1%d 0%d:30:15.%06d+0%d" % (rng.randint(1, 9), rng.randint(0, 9), rng.randint(0, 9), rng.randint(0, 999999), rng.randint(0, 9)),
-             "%08x-1111-2222-3333-%012x" % (rng.getrandbits(32), rng.getrandbits(48)),
-             rng.choice(["1.5", "-0.25", "1e300", "3.141592653589793", "12345678901234567890123", "nan"]),
-             "\\\\x" + "".join("%02x" % rng.getrandbits(8) for _ in range(rng.randint(0, 20)))]
-        rows.append(("\t".join(f) + "\n").encode())
-    return rows
-
-
-GEN_COLS = [("id", SC.INT8, False, 1), ("a", SC.INT4, False, 0), ("b", SC.BOOL, False, 0), ("n", SC.NUMERIC, False, 0),
-            ("t", SC.TEXT, False, 0), ("tn", SC.TEXT, True, 0), ("ts", SC.TIMESTAMPTZ, False, 0), ("u", SC.UUID, False, 0),
-            ("f", SC.FLOAT8, False, 0), ("by", SC.BYTEA, False, 0)]
+from etl_amd.synth import copy_rows as _gen_rows, COPY_COLS as GEN_COLS   # the generator bench.py's copy leg uses
 
 
 def test_copy_generated_rows(path):
