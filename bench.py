@@ -494,6 +494,7 @@ def main():
     ap.add_argument("--cpu-threads-seconds", type=float, default=6.0)
     ap.add_argument("--no-check", action="store_true", help="profiling ablations only")
     ap.add_argument("--no-scan-leg", action="store_true")
+    ap.add_argument("--prime", type=int, default=WINDOW + 2, help="decodes that grow the arena pool before warm-up (profiling runs under rocprofv3 --pmc use 2)")
     ap.add_argument("--gather-every", type=int, default=4, help="N > 1: batches per header all-gather (their 64-byte headers travel together)")
     args = ap.parse_args()
     legs = [x for x in args.legs.split(",") if x]
@@ -566,7 +567,7 @@ def main():
     # Arena pool priming (setup, like allocating buffers): the timed loop keeps WINDOW batches in flight, each holding its
     # own output arena; the library grows that pool on demand with hipMalloc, which serialises host and device.
     p = Pipeline(dec, items, flags, check)
-    for _ in range(WINDOW + 2):
+    for _ in range(args.prime):
         p.issue()
     p.drain()
     p = Pipeline(dec, items, flags, check)
@@ -622,7 +623,7 @@ def main():
     if rank == 0:
         dec.profile(True)
         q = Pipeline(dec, items, flags, check)
-        nprof = max(4 * inner, 20)
+        nprof = max(4 * inner, 20) if args.prime > 2 else 4
         for _ in range(nprof):
             q.issue()
         q.drain()

@@ -253,6 +253,7 @@ struct etlg_ctx {
   bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
   std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order
   std::vector<hipEvent_t> ev_pool;   // "result block copied back" events of finished batches
+  std::vector<int32_t> last_live;      // slots whose columns d_cols currently holds
   std::vector<DevTable> last_tables;   // what d_tables / d_epochs currently hold
   std::vector<DevEpoch> last_epochs;
   bool side_valid = false;
@@ -704,11 +705,17 @@ hipError_t upload(hipStream_t s, DevBuf& b, const void* src, size_t n) {
   return e;
 }
 
-hipError_t sync_slots(etlg_ctx* c) {
-  if (!c->slots_dirty) return hipSuccess;
+// Uploads the schema slots. Slot ids are stable for the life of the context (the arenas name them), but a stream that changes
+// schemas often leaves most of them dead: only slots in `live` (what the table cache, this batch's epochs or a table copy can
+// reach) get their column descriptors uploaded; the rest are empty entries. The side tables then stay small enough for the
+// LDS copy the single-pass kernels want (k_cells needs it) after hundreds of DDL messages.
+hipError_t sync_slots(etlg_ctx* c, const std::vector<int32_t>& live) {
+  if (!c->slots_dirty && live == c->last_live) return hipSuccess;
   std::vector<DevSlot> ds;
   std::vector<DevCol> dc;
+  size_t si = 0;
   for (auto& s : c->slots) {
+    if (!std::binary_search(live.begin(), live.end(), (int32_t)si++)) { DevSlot dead{}; dead.cols_base = (uint32_t)dc.size(); ds.push_back(dead); continue; }
     DevSlot d{};
     d.n_cols = s->desc.n_cols; d.n_ident = s->desc.n_ident; d.row_full = s->desc.row_bytes_full; d.row_key = s->desc.row_bytes_key;
     d.st_full = s->desc.state_bytes_full; d.st_key = s->desc.state_bytes_key; d.cols_base = (uint32_t)dc.size();
@@ -730,6 +737,7 @@ hipError_t sync_slots(etlg_ctx* c) {
   // the staging vectors die at scope exit: make the copies land first
   e = hipStreamSynchronize(c->stream);
   c->slots_dirty = false;
+  c->last_live = live;
   c->n_dev_slots = (uint32_t)ds.size(); c->n_dev_cols = (uint32_t)dc.size();
   return e;
 }
@@ -1389,7 +1397,7 @@ int32_t setup_scratch(etlg_ctx* c, DecParams& p) {
 int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec>& eps) {
   DecParams& p = b->params;
   hipStream_t s = c->stream;
-  if (eps.empty() && c->side_valid && !c->side_dirty && !c->slots_dirty && c->last_epochs.empty() && !b->have_snapshot) {
+  if (eps.empty() && c->side_valid && !c->side_dirty && !c->slots_dirty && c->last_epochs.empty() && !b->have_snapshot && !b->copy.active) {
     // nothing the side inputs are built from has changed since the last upload (the common case: one call per batch)
     p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)c->last_tables.size();
     p.n_epochs = 0;
@@ -1417,7 +1425,13 @@ int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec
     t.ep_end = (uint32_t)ev.size();
     tv.push_back(t);
   }
-  const bool same = c->side_valid && !c->slots_dirty && tv.size() == c->last_tables.size() && ev.size() == c->last_epochs.size() &&
+  std::vector<int32_t> live;   // slots a frame of this batch can decode against
+  for (auto& t : tv) if (t.init_kind == 2u && t.init_slot >= 0) live.push_back(t.init_slot);
+  for (auto& e : ev) if (e.kind == 2u && e.slot >= 0) live.push_back(e.slot);
+  if (b->copy.active && b->copy.slot >= 0) live.push_back(b->copy.slot);
+  std::sort(live.begin(), live.end());
+  live.erase(std::unique(live.begin(), live.end()), live.end());
+  const bool same = c->side_valid && !c->slots_dirty && live == c->last_live && tv.size() == c->last_tables.size() && ev.size() == c->last_epochs.size() &&
                     (tv.empty() || !memcmp(tv.data(), c->last_tables.data(), tv.size() * sizeof(DevTable))) &&
                     (ev.empty() || !memcmp(ev.data(), c->last_epochs.data(), ev.size() * sizeof(DevEpoch)));
   if (!same) {  // rare: table states, the cache timeline or the slots changed
@@ -1428,7 +1442,7 @@ int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec
     if (!tv.empty()) HIPCHK(c, hipMemcpy(c->d_tables.p, tv.data(), tv.size() * sizeof(DevTable), hipMemcpyHostToDevice));
     if (!ev.empty()) HIPCHK(c, hipMemcpy(c->d_epochs.p, ev.data(), ev.size() * sizeof(DevEpoch), hipMemcpyHostToDevice));
     c->last_tables = tv; c->last_epochs = ev; c->side_valid = true;
-    HIPCHK(c, sync_slots(c));
+    HIPCHK(c, sync_slots(c, live));
     // ---- the fixed-width plan (plan.hip): tables the apply worker owns outright, Ready for the whole batch, whose
     //      replicated columns are all bool / int2 / int4 / int8 / oid
     std::vector<PlanTab> pt;
@@ -1561,14 +1575,14 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
   FusedParams& q = c->fq;
   const uint64_t side = (uint64_t)p.n_tables * sizeof(DevTable) + (uint64_t)p.n_epochs * sizeof(DevEpoch) +
                         (uint64_t)p.n_slots * sizeof(DevSlot) + (uint64_t)p.n_cols * sizeof(DevCol);
-  q.side_bytes = (side <= 8192 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
+  q.side_bytes = (side <= 16384 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
   // kernel choice: narrow frames -> one lane per frame, 256 frames per tile (k_fused); wide frames ->
   // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 16 columns)
   uint32_t widest = 1;
-  for (auto& sl : c->slots) widest = std::max<uint32_t>(widest, sl->desc.n_cols);
+  for (int32_t li : c->last_live) widest = std::max<uint32_t>(widest, c->slots[(size_t)li]->desc.n_cols);
   const bool cells_ok = widest <= etlg_k_cells_maxc() && q.side_bytes != 0;  // k_cells keeps the side tables in LDS
   bool any_var = false;   // a table the batch may carry has TEXT / NUMERIC / ... columns: one lane per frame crawls on those
-  for (auto& sl : c->slots) for (auto& sc : sl->cols) {
+  for (int32_t li : c->last_live) for (auto& sc : c->slots[(size_t)li]->cols) {
     const int32_t k = sc.type_class;
     if (!(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32 || k == ETLG_TC_UUID)) any_var = true;
   }

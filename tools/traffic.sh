@@ -1,11 +1,11 @@
 # HBM traffic of the dominant kernel for bench.py's roofline.traffic: two rocprofv3 --pmc passes
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass) over the bench command, averaged per launch.
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass) over a SHORT bench command, averaged per launch.
 #   bash tools/traffic.sh [cfg2|cfg3]   ->  gpurun_out/traffic_<wl>.json  (copy to profiles/)
 WL=${1:-cfg2}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B="python bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline"
+B="python bench.py --workload $WL --steps 1 --warmup 1 --inner 4 --prime 2 --legs= --no-cpu-baseline"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/traffic_${WL}_$c -o p -- $B > gpurun_out/traffic_${WL}_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/traffic_${WL}_$c -o p -- $B > gpurun_out/traffic_${WL}_$c.log 2>&1
 done
 python - $WL <<'PY'
 import csv, sys, json, collections, glob
