@@ -13,12 +13,8 @@ SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "plan.hip", "scan.hip", "cop
 # per-source optimisation level: k_fused is measurably faster built for size (88 vs 93 us on cfg2, tools/variants.sh);
 # k_cells and the rest are not
 OPT = {"fused.hip": "-Os"}
-# per-source feature flags. k_fused is built with the fixed-width plan, the register / address-space fixes, scalar descriptor
-# loads, the short kernel head and 8-deep staging: 78.2 us against 87.8 us for the plain build on cfg2, both timed in one run
-# (profiles/r01j_ab_quick_*.json; tools/build_variants.py "all" vs "plain"). The other kernels keep the plain build until the
-# same flags have been measured on them (tools/ab_variants.sh).
-DEFS = {"fused.hip": ["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"]}
-DEPS = SOURCES + ["../build.py", "dev_types.h", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
+DEFS = {}   # no per-source feature flags: one code path per kernel
+DEPS = SOURCES + ["../build.py", "dev_types.h", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "plan.hip", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
 
 
 def _stale(target, deps):

@@ -599,26 +599,8 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   if (tid < 3) s64[tid] = 0;
   if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
   // ---- P0: side tables, offsets, staging
-#ifdef ETLG_EARLY_SPAN
   SideRegs side;  // variant head (lookback.hip.h): one round trip for all four tables, LDS stores after the staging loads
   side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
-#else
-  {  // the side-input tables always live in LDS here (the host picks another kernel when they do not fit)
-    const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
-    const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
-    uint32_t* d = (uint32_t*)smem;
-    for (uint32_t i = tid; i < nt4; i += NW * 64) d[i] = ((const uint32_t*)p.tables)[i];
-    d += nt4;
-    for (uint32_t i = tid; i < ne4; i += NW * 64) d[i] = ((const uint32_t*)p.epochs)[i];
-    d += ne4;
-    for (uint32_t i = tid; i < ns4; i += NW * 64) d[i] = ((const uint32_t*)p.slots)[i];
-    d += ns4;
-    for (uint32_t i = tid; i < nc4; i += NW * 64) d[i] = ((const uint32_t*)p.cols)[i];
-    uint32_t* b0 = (uint32_t*)smem;
-    p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
-    p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
-  }
-#endif
   const uint32_t maxc = q.maxc, VC = 2 * maxc;
   uint2* ct_pl = (uint2*)(smem + q.side_bytes);  // side_bytes is a multiple of 16
   uint32_t* ct_h = (uint32_t*)(ct_pl + VC * CF);
@@ -628,38 +610,18 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   const uint32_t f0 = tile * CF;
   uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
   // the tile's byte span from two scalar loads: staging starts while the per-frame offsets are in flight
-#ifdef ETLG_EARLY_SPAN
   const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)pg.offs;  // real scalar loads (see k_fused)
   const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
-#else
-  const uint32_t span0 = pg.offs[f0], span1 = pg.offs[f0 + nt];
-#endif
   const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
                          (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
   if (window_ok) {
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
-#ifdef ETLG_STAGE_WIDE
     stage_chunks<NW * 64>(pg.in, stage, a0, full_end, tid);
-    if (false)
-#endif
-    for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * NW * 64) {
-      const uint32_t c1 = c + 16 * NW * 64, c2 = c + 32 * NW * 64, c3 = c + 48 * NW * 64;
-      uint4 v0 = *(const uint4*)(pg.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
-      if (c1 < full_end) v1 = *(const uint4*)(pg.in + c1);
-      if (c2 < full_end) v2 = *(const uint4*)(pg.in + c2);
-      if (c3 < full_end) v3 = *(const uint4*)(pg.in + c3);
-      *(uint4*)(stage + (c - a0)) = v0;
-      if (c1 < full_end) *(uint4*)(stage + (c1 - a0)) = v1;
-      if (c2 < full_end) *(uint4*)(stage + (c2 - a0)) = v2;
-      if (c3 < full_end) *(uint4*)(stage + (c3 - a0)) = v3;
-    }
     for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
   }
-#ifdef ETLG_EARLY_SPAN
   side_store<NW * 64>((uint32_t*)smem, tid, side);
-#endif
   if (tid <= nt) s_offs[tid] = my_o;  // CF + 1 <= NW * 64 entries
   __syncthreads();
   TSTAMP(0);

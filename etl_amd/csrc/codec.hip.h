@@ -52,19 +52,14 @@ typedef uint8_t u8;
 #ifndef ETLG_PLAN_MINWAVES
 #define ETLG_PLAN_MINWAVES 5   // k_plan: waves per SIMD the register allocator leaves room for (96 VGPRs; the ~8 KB LDS window per wave allows ~5)
 #endif
-#ifdef ETLG_DECODE_NOINLINE   // experiment: one out-of-line copy of the value codec per kernel (code size / I-cache)
-#define DEV_DECODE DEV_NOINLINE
-#else
 #define DEV_DECODE DEV
-#endif
 
-// ------------------------------------------------------------- staging (experiment)
-// ETLG_STAGE_WIDE=<W> (tools/build_variants.py "stage8"): W independent 16-byte loads per lane in flight
-// before the first LDS store instead of 4, i.e. one HBM round trip for a 113-byte-per-lane tile instead of two.
-#ifdef ETLG_STAGE_WIDE
+// ------------------------------------------------------------- staging (k_fused, k_cells)
+// Eight independent 16-byte loads per lane in flight before the first LDS store: one HBM round trip for a
+// 113-byte-per-lane tile.
 template <int NT>
 DEV void stage_chunks(const uint8_t* in, uint8_t* stage, uint32_t a0, uint32_t full_end, uint32_t tid) {
-  constexpr int W = ETLG_STAGE_WIDE;
+  constexpr int W = 8;
   for (uint32_t c = a0 + 16 * tid; c < full_end; c += 16 * NT * W) {
     uint4 v[W];
 #pragma unroll
@@ -80,7 +75,6 @@ DEV void stage_chunks(const uint8_t* in, uint8_t* stage, uint32_t a0, uint32_t f
     }
   }
 }
-#endif
 
 // ------------------------------------------------------------- byte helpers
 DEV uint32_t ld_be32(const u8* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return __builtin_bswap32(v); }
@@ -556,7 +550,6 @@ DEV bool parse_int_swar(const u8* s, uint32_t n, bool is_signed, int bits, int64
     if (c0 == '-') { if (!is_signed) return false; neg = true; }
     s++; n--;
   }
-#ifdef ETLG_HOT_FIXES
   if (n > 19) {  // long (leading zeros): the out-of-line parser gets its own result slot, so that `out` never has its
                  // address taken and stays in registers on the fast path (it lived in scratch: one memory round trip per cell)
     int64_t slow = 0;
@@ -564,9 +557,6 @@ DEV bool parse_int_swar(const u8* s, uint32_t n, bool is_signed, int bits, int64
     out = slow;
     return ok_slow;
   }
-#else
-  if (n > 19) return parse_int(neg || c0 == '+' ? s - 1 : s, neg || c0 == '+' ? n + 1 : n, is_signed, bits, out);  // long (leading zeros)
-#endif
   // groups of 4 digits from the right; the leading group has r = 1..4 digits
   const uint32_t r = ((n - 1) & 3u) + 1u, ng = (n - r) >> 2;  // ng full groups after the leading one (0..4)
   bool ok = true;
@@ -933,14 +923,10 @@ DEV_DECODE uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, ui
       const bool sg = cls != ETLG_TC_U32;
       const int bits = cls == ETLG_TC_I16 ? 16 : cls == ETLG_TC_I64 ? 64 : 32;
       int64_t v;
-#ifdef ETLG_HOT_FIXES
       bool int_ok;
       if (over) int_ok = parse_int_swar(d, len, sg, bits, v);
       else { int64_t slow = 0; int_ok = parse_int(d, len, sg, bits, slow); v = slow; }  // `v` never has its address taken by an out-of-line call
       if (!int_ok) return bad(ETLG_E_INT);
-#else
-      if (!(over ? parse_int_swar(d, len, sg, bits, v) : parse_int(d, len, sg, bits, v))) return bad(ETLG_E_INT);
-#endif
       if (cls == ETLG_TC_I64) st64(slot, (uint64_t)v); else slot[0] = (uint32_t)v;
       return 0;
     }
@@ -1148,7 +1134,6 @@ DEV uint32_t write_row(const DecParams& p, const DevSlot& s, uint32_t mode, cons
 // (cell tag, length, characters) stays per lane. `pg` must hold GLOBAL side-table pointers.
 DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const u8* tuple, uint32_t n, u8* row,
                                     uint32_t& hcur, bool over) {
-#ifdef ETLG_SCALAR_COLS
   // The descriptors are read as whole dwords through constant-address-space pointers: the address is wave-uniform
   // and the memory is never written by a kernel, so these are s_load (scalar cache, results in SGPRs). As byte /
   // halfword fields of a plain global struct they compiled to global_load_ubyte / _ushort + s_waitcnt vmcnt(0) +
@@ -1158,27 +1143,13 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
   if (n != sw[0]) return ETLG_E_TUPLE_WIDTH;                      // DevSlot.n_cols
   const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + sw[6]);  // DevSlot.cols_base
   struct { uint32_t cls, nullable, off_full; } col;
-#else
-  const DevSlot s = pg.slots[slot_u];
-  if (n != s.n_cols) return ETLG_E_TUPLE_WIDTH;
-  const DevCol* cols = pg.cols + s.cols_base;
-#endif
   const u8* c = tuple + 2;
   uint32_t acc = 0;
   uint32_t* stw = (uint32_t*)row;
   for (uint32_t i = 0; i < n; i++) {
-#ifdef ETLG_SCALAR_COLS
     { const uint32_t w0 = cw[3 * i], w1 = cw[3 * i + 1]; col.cls = w0 & 0xFFu; col.nullable = (w0 >> 8) & 0xFFu; col.off_full = w1 & 0xFFFFu; }
-#else
-    const DevCol col = cols[i];
-#endif
     const uint32_t cls = col.cls;
-#ifdef ETLG_HOT_FIXES
     uint32_t* slot = (uint32_t*)(row + col.off_full);  // always the arena: a pointer that may also name private memory turns every row store into a flat store
-#else
-    uint32_t dummy[4];
-    uint32_t* slot = (pg.flags & 0x100u) ? dummy : (uint32_t*)(row + col.off_full);  // 0x100: profiling ablation (no row stores)
-#endif
     uint64_t head = 0;
     if (over) __builtin_memcpy(&head, c, 8);  // tag + length in one load
     const uint32_t t = over ? (uint32_t)head & 0xFFu : (uint32_t)*c;

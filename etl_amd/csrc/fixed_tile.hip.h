@@ -1,7 +1,8 @@
-// "Fixed-width plan" of the fused kernel (flag ETLG_FIXED_TILE, part of the product's flags for fused.hip —
-// etl_amd/build.py DEFS; without the flag fused.hip does not include this file).
+// "Fixed-width plan" of the generic fused kernel. Whole batches of such frames go to k_plan (plan.hip, the lean kernel);
+// this body serves the tiles of k_fused launches that conform anyway: tables with uuid columns (not in k_plan's class set),
+// batches k_plan gave up because ONE tile did not conform, runs of a fixed-width table between runs of another one.
 //
-// DESIGN.md §6 prices k_fused at 1 949 VALU instructions per wave of 64 rows on cfg2, 473 of them between the
+// Round 1 priced k_fused at 1 949 VALU instructions per wave of 64 rows on cfg2, 473 of them between the
 // structure walk and the look-back: the generic sizing (`size_frame`: any tag, ownership by transaction LSN,
 // cache epochs, heap bytes of either tuple image), three workgroup scans and three payload reductions — for
 // frames whose sizes are constants of their schema. A tile takes this body instead when, after the structure
@@ -106,18 +107,6 @@ DEV bool tile_fixed(const DecParams& p, const DecParams& pg, const FusedParams& 
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
       if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
     }
-#ifdef ETLG_BLK128
-  } else if (BLK == 128 && ETLG_LB_PARALLEL) {  // two waves: the output prefixes on one, the transaction state on the other
-    if (wave == 0) {
-      const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
-      const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
-      if (tid == 0) { s64[4] = a; s64[5] = b; }
-    }
-    if (wave == 1) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
-    }
-#endif
   } else if (wave == 0) {
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
     const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);

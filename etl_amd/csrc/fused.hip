@@ -25,18 +25,13 @@
 // crates/etl/src/replication/apply.rs:2475-2481), so that path is cold.
 #include "lookback.hip.h"
 
-#ifndef ETLG_TICKET
-#define ETLG_TICKET 0      // 1: tile ids from an atomic ticket; 0: blockIdx.x (in-order dispatch; spins are bounded,
-#endif                     //    a give-up falls back to the multi-pass kernels, so correctness never depends on it)
 #ifndef ETLG_MINWAVES
 #define ETLG_MINWAVES 4     // waves per SIMD the register allocator must leave room for (128 VGPRs; measured 108 vs 119 us at 3)
 #endif
 #ifndef ETLG_LB_PARALLEL
 #define ETLG_LB_PARALLEL 1 // run the three independent look-backs on three waves
 #endif
-#ifdef ETLG_FIXED_TILE
 #include "fixed_tile.hip.h"  // fixed-width plan: schema-constant sizing for tiles of Begin / Commit / fixed-width Insert frames
-#endif
 
 namespace etlg {
 
@@ -66,9 +61,6 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     wire_ok = frame_structure(v, m, STAGED);
   }
   TSTAMP(2);
-#ifdef ETLG_ABLATE  // instruction-count ablations (tools/build_variants.py "ablate"): stop after a phase, keeping its results alive
-  if (q.dbg & 0x2000u) { if (live && wire_ok && m.new_n == 0x7FFFu && v.tag == 0xEE) p.res->fused_fail = 1; return; }
-#endif
   uint32_t cnt = 0, mark = 0;
   if (live) {
     if (consumes_ordinal(v.tag)) cnt = 1;
@@ -123,9 +115,6 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     }
   }
   TSTAMP(6);
-#ifdef ETLG_ABLATE
-  if (q.dbg & 0x4000u) { if (x_ev + x_fx + x_hp + tot3[0] + seg_in + pm == 0xFFFFFFF1u) p.res->fused_fail = 1; return; }
-#endif
   // ---- look-back: output positions (and the transaction state when it was not needed earlier);
   //      independent prefixes run on different waves so their latencies overlap
   const uint64_t agg_a = ((uint64_t)tot3[0] << 32) | tot3[2];
@@ -137,18 +126,6 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
       if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
     }
-#ifdef ETLG_BLK128
-  } else if (BLK == 128 && ETLG_LB_PARALLEL) {  // two waves: the output prefixes on one, the transaction state on the other
-    if (wave == 0) {
-      const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
-      const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
-      if (tid == 0) { s64[4] = a; s64[5] = b; }
-    }
-    if (wave == 1 && !q.seq_lookback) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
-    }
-#endif
   } else if (wave == 0) {
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
     const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
@@ -205,14 +182,12 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
   DecParams p = pg;  // side-table pointers of `p` are redirected to the LDS copy below
   if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;  // per-tile payload accumulators
-#if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
-  // Kernel head with few dependent global round trips (ETLG_EARLY_SPAN; in the product). The plain head below runs, one after the other: three side-table
-  // copy loops (load, wait, LDS store — per table), a barrier, the loads of the tile's byte span (vector loads of a uniform
-  // address, waited for on the spot), and two rounds of staging loads: six round trips before a tile can start parsing.
-  // Here the tile id is blockIdx.x (nothing to broadcast through LDS first); the four side tables are read as ONE
-  // concatenation, up to four dwords per lane, and only stored to LDS after the staging loads have been issued; the span
-  // comes through real scalar loads (constant address space) that overlap the side-table loads; with ETLG_STAGE_WIDE=8 the
-  // tile's bytes are one more round trip. The barrier after staging covers the side tables too.
+  // Kernel head with two dependent global round trips: the tile id is blockIdx.x (nothing to broadcast through LDS first); the
+  // four side tables are read as ONE concatenation, up to four dwords per lane, and only stored to LDS after the staging loads
+  // have been issued; the span comes through real scalar loads (constant address space) that overlap the side-table loads; the
+  // tile's bytes are one more round trip (eight 16-byte loads in flight per lane). The barrier after staging covers the side
+  // tables too. (Round 1 measured this head, the fixed-width plan and the register / address-space fixes together: 78.2 us
+  // against 87.8 us for the head with one round trip per table, profiles/r01j_ab_quick_*.json.)
   const uint32_t tile = blockIdx.x;
   if (tile >= q.ntiles) return;
   const uint32_t f0 = tile * BLK;
@@ -224,69 +199,17 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
   const uint32_t span0 = offs_c[f0u], span1 = offs_c[f0u + ntu];
   const uint32_t my_o = tid <= nt ? p.offs[f0 + tid] : 0u;
   const uint32_t last_o = (tid == 0 && nt == (uint32_t)BLK) ? p.offs[f0 + BLK] : 0u;
-#else
-  // Plain head (tools/build_variants.py "plain"; the only one when tile ids come from the atomic ticket).
-#if ETLG_TICKET
-  if (tid == 0) s32[15] = atomicAdd(q.ticket, 1u);
-#else
-  if (tid == 0) s32[15] = blockIdx.x;
-#endif
-  // copy the (tiny) side-input tables into LDS while the ticket is in flight: every
-  // later lookup is then an LDS read instead of a chain of dependent global loads
-  if (q.side_bytes) {
-    const uint32_t nt4 = p.n_tables * (sizeof(DevTable) / 4), ne4 = p.n_epochs * (sizeof(DevEpoch) / 4);
-    const uint32_t ns4 = p.n_slots * (sizeof(DevSlot) / 4), nc4 = p.n_cols * (sizeof(DevCol) / 4);
-    uint32_t* d = (uint32_t*)smem;
-    for (uint32_t i = tid; i < nt4; i += BLK) d[i] = ((const uint32_t*)p.tables)[i];
-    d += nt4;
-    for (uint32_t i = tid; i < ne4; i += BLK) d[i] = ((const uint32_t*)p.epochs)[i];
-    d += ne4;
-    for (uint32_t i = tid; i < ns4; i += BLK) d[i] = ((const uint32_t*)p.slots)[i];
-    d += ns4;
-    for (uint32_t i = tid; i < nc4; i += BLK) d[i] = ((const uint32_t*)p.cols)[i];
-    uint32_t* b0 = (uint32_t*)smem;
-    p.tables = (const DevTable*)b0; p.epochs = (const DevEpoch*)(b0 + nt4);
-    p.slots = (const DevSlot*)(b0 + nt4 + ne4); p.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
-  }
-  __syncthreads();
-  const uint32_t tile = s32[15];
-  if (tile >= q.ntiles) return;
-  const uint32_t f0 = tile * BLK;
-  const uint32_t nt = p.nframes - f0 < (uint32_t)BLK ? p.nframes - f0 : (uint32_t)BLK;
-  // The tile's byte span comes from two scalar loads, so staging can start while the per-frame
-  // offsets are still in flight (one global round trip instead of two before the first byte lands).
-  const uint32_t f0u = __builtin_amdgcn_readfirstlane(f0), ntu = __builtin_amdgcn_readfirstlane(nt);
-  const uint32_t span0 = p.offs[f0u], span1 = p.offs[f0u + ntu];
-  const uint32_t my_o = tid <= nt ? p.offs[f0 + tid] : 0u;
-  const uint32_t last_o = (tid == 0 && nt == (uint32_t)BLK) ? p.offs[f0 + BLK] : 0u;
-#endif
   u8* stage = smem + q.side_bytes;
   const uint32_t a0 = span0 & ~15u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 16 <= q.lds_bytes - q.side_bytes && !(q.dbg & 1);
   if (window_ok) {
     // coalesced staging: 16 B per lane per step; the tail that would cross in_len goes bytewise
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);  // last full 16-byte chunk boundary <= span1
-    // four independent 16-byte loads in flight per lane before the first LDS store
-#ifdef ETLG_STAGE_WIDE
+    // eight independent 16-byte loads in flight per lane before the first LDS store: one HBM round trip for a 29 KB tile
     stage_chunks<BLK>(p.in, stage, a0, full_end, tid);
-    if (false)
-#endif
-    for (uint32_t c = a0 + 16 * tid; c < full_end; c += 64 * BLK) {
-      const uint32_t c1 = c + 16 * BLK, c2 = c + 32 * BLK, c3 = c + 48 * BLK;
-      uint4 v0 = *(const uint4*)(p.in + c), v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
-      if (c1 < full_end) v1 = *(const uint4*)(p.in + c1);
-      if (c2 < full_end) v2 = *(const uint4*)(p.in + c2);
-      if (c3 < full_end) v3 = *(const uint4*)(p.in + c3);
-      *(uint4*)(stage + (c - a0)) = v0;
-      if (c1 < full_end) *(uint4*)(stage + (c1 - a0)) = v1;
-      if (c2 < full_end) *(uint4*)(stage + (c2 - a0)) = v2;
-      if (c3 < full_end) *(uint4*)(stage + (c3 - a0)) = v3;
-    }
     for (uint32_t c = full_end + tid; c < span1; c += BLK) stage[c - a0] = p.in[c];
   }
-#if defined(ETLG_EARLY_SPAN) && !ETLG_TICKET
   side_store<BLK>((uint32_t*)smem, tid, side);
-#endif
   if (tid <= nt) s_offs[tid] = my_o;
   if (tid == 0 && nt == (uint32_t)BLK) s_offs[BLK] = last_o;
   __syncthreads();
@@ -298,10 +221,6 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     lane_ok = o1 <= o0 || o1 > p.in_len || (o0 >= span0 && o1 <= span1);
   }
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
-#ifdef ETLG_ABLATE
-  if (q.dbg & 0x1000u) { if (use_lds && stage[tid * 7] == 0xEE && stage[tid * 13 + 5] == 0xEF) p.res->fused_fail = 1; return; }
-#endif
-#ifdef ETLG_FIXED_TILE
   if (use_lds && q.side_bytes && !q.seq_lookback && (q.dbg & ~64u) == 0 && !(pg.flags & 0xF02u) && pg.worker_kind == ETLG_WORKER_APPLY) {
     const uint32_t nt4 = pg.n_tables * (sizeof(DevTable) / 4), ne4 = pg.n_epochs * (sizeof(DevEpoch) / 4), ns4 = pg.n_slots * (sizeof(DevSlot) / 4);
     DecParams pl = pg;  // side tables through pointers that can only name LDS
@@ -313,8 +232,6 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
       return;
     }
   }
-#endif
-#ifdef ETLG_HOT_FIXES
   // the staged instance reads its side tables through pointers that can only name LDS (ds_read instead of flat
   // loads that must first find out which memory they address); a tile without them takes the global instance
   if (use_lds && q.side_bytes) {
@@ -325,12 +242,6 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     pl.tables = (const DevTable*)b0; pl.epochs = (const DevEpoch*)(b0 + nt4);
     pl.slots = (const DevSlot*)(b0 + nt4 + ne4); pl.cols = (const DevCol*)(b0 + nt4 + ne4 + ns4);
     tile_body<BLK, true>(pl, pg, q, tile, nt, s_offs, stage, a0, s32, s64);
-  } else if (false) {
-#else
-  if (use_lds) {
-    TSTAMP(1);
-    tile_body<BLK, true>(p, pg, q, tile, nt, s_offs, stage, a0, s32, s64);
-#endif
   } else {
     tile_body<BLK, false>(p, pg, q, tile, nt, s_offs, p.in, 0, s32, s64);
   }
@@ -346,28 +257,13 @@ using namespace etlg;
 void etlg_k_launch_fused(int blk, const DecParams* p, const void* qv, hipStream_t s) {
   const FusedParams* q = (const FusedParams*)qv;
   if (blk == 256) hipLaunchKernelGGL(k_fused<256>, dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
-#ifdef ETLG_BLK128
-  else if (blk == 128) hipLaunchKernelGGL(k_fused<128>, dim3(q->ntiles), dim3(128), q->lds_bytes, s, *p, *q);
-#endif
   else hipLaunchKernelGGL(k_fused<64>, dim3(q->ntiles), dim3(64), q->lds_bytes, s, *p, *q);
-}
-
-// 1 when this build carries the 128-frame-tile instance (variant ETLG_BLK128; ETLG_FUSED_BLK=128 selects it at run time)
-int etlg_k_fused_has_blk128(void) {
-#ifdef ETLG_BLK128
-  return 1;
-#else
-  return 0;
-#endif
 }
 
 int etlg_k_fused_set_lds(void) {
   // allow the full 160 KiB of LDS as dynamic shared memory
   hipError_t e1 = hipFuncSetAttribute((const void*)k_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
   hipError_t e2 = hipFuncSetAttribute((const void*)k_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-#ifdef ETLG_BLK128
-  if (hipFuncSetAttribute((const void*)k_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess) return 1;
-#endif
   return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
 }
 

@@ -33,7 +33,6 @@ using namespace etlg;
 extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
 extern "C" const char* etlg_k_name(int which);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
-extern "C" int etlg_k_fused_has_blk128(void);
 extern "C" int etlg_k_fused_set_lds(void);
 extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* vdesc, void* ndesc,
                                      uint32_t* hints, uint32_t* result, int sequential, hipStream_t s);

@@ -148,7 +148,6 @@ DEV uint64_t final_lsn_of_mark(const DecParams& p, uint32_t mark) {
   return mark == 1u ? p.final_lsn : ld_be64(p.in + ((mark >> 1) - 1) + kBodyOff);
 }
 
-#ifdef ETLG_EARLY_SPAN
 // Variant kernel head (k_fused, k_cells): the four side tables are read as ONE concatenation, up to four dwords per lane held in
 // registers (`side_load`), and stored to LDS only after the tile's staging loads have been issued (`side_store`), so the whole
 // copy costs one global round trip that overlaps the span loads instead of one round trip per table before anything else starts.
@@ -179,6 +178,5 @@ DEV void side_store(uint32_t* side_lds, uint32_t tid, const SideRegs& r) {
   if (tid + 2 * NT < r.tot4) side_lds[tid + 2 * NT] = r.v2;
   if (tid + 3 * NT < r.tot4) side_lds[tid + 3 * NT] = r.v3;
 }
-#endif
 
 }  // namespace etlg

@@ -1,9 +1,11 @@
-"""The fixed-width plan of the fused kernel (variant ETLG_FIXED_TILE, etl_amd/csrc/fixed_tile.hip.h) against the
-oracle, through the C ABI: tiles that conform (Begin / Commit / Insert into a Ready fixed-width table) take
-schema-constant sizing, every other tile of the same launch takes the generic body, and the arena must not show
-the seam. On a library built without the variant the same cases run through the generic body alone (still a
-parity test); ETLG_EXPECT_FIXED_TILE=1 (set by the run that loads a variant build) additionally demands that the
-plan was really taken."""
+"""Fixed-width decode plans against the oracle, through the C ABI.
+
+k_plan (etl_amd/csrc/plan.hip): whole batches of Begin / Commit / Insert frames into Ready tables of bool / integer
+columns, one wave per tile; anything else makes the kernel give the batch up and the generic kernel decodes it.
+The plan of k_fused (etl_amd/csrc/fixed_tile.hip.h): tiles that conform take schema-constant sizing, every other tile
+of the same launch takes the generic body, and the arena must not show the seam.
+Every case runs on both (`fused` fixture: k_fused with 256 / 64 frames per tile forced, k_plan forced, k_plan reading the
+input in place instead of its LDS window), with the demand that the plan was really taken where a stream conforms."""
 import ctypes as C
 import os
 import struct
@@ -15,16 +17,22 @@ from etl_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-EXPECT = os.environ.get("ETLG_EXPECT_FIXED_TILE") == "1"
-_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_BLK", "ETLG_FUSED_DBG")
+EXPECT = True
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG")
 
 
-@pytest.fixture(params=["fused256", "fused64"])
+@pytest.fixture(params=["fused256", "fused64", "plan", "plan_inplace"])
 def fused(request):
+    """Yields the frames per tile of the forced k_fused instance, or 0 when k_plan is forced."""
     saved = {k: os.environ.pop(k, None) for k in _KNOBS}
-    os.environ["ETLG_FUSED_KERNEL"] = "0" if request.param == "fused256" else "1"
-    os.environ["ETLG_FUSED_DBG"] = "64"   # k_fused only: count the tiles that took the plan (DevResult.dbg_t[11])
-    yield 256 if request.param == "fused256" else 64
+    if request.param.startswith("plan"):
+        os.environ["ETLG_FUSED_KERNEL"] = "3"
+        if request.param == "plan_inplace":
+            os.environ["ETLG_PLAN_DBG"] = "1"
+    else:
+        os.environ["ETLG_FUSED_KERNEL"] = "0" if request.param == "fused256" else "1"
+        os.environ["ETLG_FUSED_DBG"] = "64"   # k_fused only: count the tiles that took the plan (DevResult.dbg_t[11])
+    yield {"fused256": 256, "fused64": 64}.get(request.param, 0)
     for k in _KNOBS:
         os.environ.pop(k, None)
         if saved[k] is not None:
@@ -61,13 +69,14 @@ def test_conforming_stream_takes_the_plan_and_matches(fused):
     batches, so the carried transaction state crosses plan tiles in both directions."""
     w = synth.cfg2()
     d, o = _pair(w)
-    for nbytes in (300 << 10, 64 << 10, 1 << 20):
+    for k, nbytes in enumerate((300 << 10, 64 << 10, 1 << 20)):
         buf, offs = w.fill(nbytes)
         assert _agree(d, o, buf, offs) == 0
-        ntiles = (len(offs) - 1 + fused - 1) // fused
-        if EXPECT:
-            assert _plan_tiles(d) == ntiles
-        assert d.debug_paths()["redone"] == 0
+        if fused:
+            assert _plan_tiles(d) == (len(offs) - 1 + fused - 1) // fused
+        else:
+            assert d.debug_paths()["plan"] == k + 1, d.debug_paths()
+        assert d.debug_paths()["redone"] == 0 and d.debug_paths()["plan_redone"] == 0
     d.close()
 
 
@@ -97,11 +106,14 @@ def test_plan_and_generic_tiles_mix_in_one_launch(fused):
     for sizes in ((200, 60, 150, 40, 100), (90, 30, 250)):
         buf, offs = _concat([(wa if i % 2 == 0 else wb).fill(kb << 10) for i, kb in enumerate(sizes)])
         assert _agree(d, o, buf, offs) == 0
-        ntiles = (len(offs) - 1 + fused - 1) // fused
-        seen += _plan_tiles(d)
-        assert _plan_tiles(d) < ntiles          # the var-len table's tiles are generic
-    if EXPECT:
+        if fused:
+            ntiles = (len(offs) - 1 + fused - 1) // fused
+            seen += _plan_tiles(d)
+            assert _plan_tiles(d) < ntiles          # the var-len table's tiles are generic
+    if fused:
         assert seen > 0
+    else:
+        assert d.debug_paths()["plan"] == 0         # a table with TEXT columns is owned: k_plan is not even tried
     assert d.debug_paths()["redone"] == 0
     d.close()
 
@@ -195,3 +207,141 @@ def test_many_registered_tables(fused):
     assert _agree(d, o, buf, offs) == 0
     assert d.debug_paths()["redone"] == 0
     d.close()
+
+
+# ---- k_plan's own cases -------------------------------------------------------------------------------------------------
+from tests import pgwire as W   # noqa: E402
+from tests import scenarios as SC   # noqa: E402
+
+WIDE = [("id", SC.INT8, False, 1)] + [("c%d" % i, (SC.INT4, SC.INT8, SC.INT2, SC.BOOL, SC.OID)[i % 5], i % 3 == 0, 0) for i in range(1, 14)]
+NARROW = [("k", SC.INT4, False, 1), ("v", SC.INT8, True, 0)]
+
+
+def _two_tables(t):
+    for rel, cols in ((42, WIDE), (43, NARROW)):
+        t.schema_put(rel, 0, cols, name="t%d" % rel)
+        t.table_state(rel, 1)
+        t.table_ready(rel, 0, [1] * len(cols), [1 if c[3] else 0 for c in cols])
+
+
+def _wide_row(rng, i):
+    vals = [str(i)]
+    for k in range(1, 14):
+        oid = WIDE[k][1]
+        if WIDE[k][2] and rng.random() < 0.3:
+            vals.append(W.NULL)
+        elif oid == SC.BOOL:
+            vals.append(rng.choice("tf"))
+        elif oid == SC.INT2:
+            vals.append(str(rng.choice([-32768, 32767, 0, -1, 7, 12345])))
+        elif oid == SC.INT8:
+            vals.append(rng.choice(["-9223372036854775808", "9223372036854775807", "0", "+17", "-0", str(rng.randint(-10**18, 10**18))]))
+        elif oid == SC.OID:
+            vals.append(rng.choice(["0", "4294967295", "+12", str(rng.randint(0, 2**32 - 1))]))
+        else:
+            vals.append(rng.choice(["-2147483648", "2147483647", "+5", "-0", "0007", str(rng.randint(-2**31, 2**31 - 1))]))
+    return vals
+
+
+def _plan_stream(seed, ntx, rows, odd=None):
+    import random
+    rng = random.Random(seed)
+    s = W.Stream()
+    lsn = 0x5000
+    n = 0
+    for t in range(ntx):
+        lsn += 0x100
+        s.add(W.begin(lsn, ts=1000 + t, xid=70 + t))
+        for r in range(rows):
+            if rng.random() < 0.5:
+                s.add(W.insert(42, _wide_row(rng, n)))
+            else:
+                s.add(W.insert(43, [str(n), W.NULL if rng.random() < 0.2 else str(rng.randint(-10**12, 10**12))]))
+            if odd and n == odd[0]:
+                s.add(odd[1])
+            n += 1
+        s.add(W.commit(lsn, lsn + 8, ts=2000 + t, flags=0))
+    return s
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_k_plan_two_tables_wide_rows_nulls_and_boundary_values(inplace):
+    """A 14-column table (60-byte rows: they wait for the look-back in the separate LDS region, not in the frame's own
+    head) interleaved frame by frame with a 2-column one (waves hold both tables: one pass per table), NULLs in nullable
+    columns, every integer width at its limits, explicit signs, leading zeros; transactions of 37 rows span tiles."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    saved = {k: os.environ.pop(k, None) for k in _KNOBS}
+    os.environ["ETLG_FUSED_KERNEL"] = "3"
+    if inplace:
+        os.environ["ETLG_PLAN_DBG"] = "1"
+    try:
+        d, o = Decoder(0), oracle.Oracle()
+        _two_tables(d); _two_tables(o)
+        for seed in (1, 2):
+            s = _plan_stream(seed, 40, 37)
+            buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+            assert _agree(d, o, buf, s.offsets) == 0
+        p = d.debug_paths()
+        assert p["plan"] == 2 and p["plan_redone"] == 0 and p["redone"] == 0, p
+        d.close()
+    finally:
+        for k in _KNOBS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("what", ["long_leading_zeros", "null_in_required", "oid_minus_zero", "int2_overflow", "update", "delete",
+                                  "truncate", "keepalive", "unknown_table", "lsn_top_bits"])
+def test_k_plan_gives_up_and_the_generic_kernel_answers(what):
+    """Shapes k_plan does not take. Legal ones (a value with twenty leading zeros, an Update, a keepalive ...) must come out
+    exactly as the oracle has them, produced by the generic kernel ('plan_redone'); illegal ones must report the oracle's error."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    saved = {k: os.environ.pop(k, None) for k in _KNOBS}
+    os.environ["ETLG_FUSED_KERNEL"] = "3"
+    try:
+        d, o = Decoder(0), oracle.Oracle()
+        _two_tables(d); _two_tables(o)
+        odd = {
+            "long_leading_zeros": W.insert(43, ["00000000000000000000042", "1"]),
+            "null_in_required": W.insert(43, [W.NULL, "1"]),
+            "oid_minus_zero": W.insert(42, ["1"] + ["0", "0", "0", "t", "-0"] + ["0", "0", "0", "t", "0", "0", "0", "0"]),
+            "int2_overflow": W.insert(42, ["1"] + ["0", "0", "32768", "t", "0"] + ["0", "0", "0", "t", "0", "0", "0", "0"]),
+            "update": W.update(43, ["5", "6"]),
+            "delete": W.delete(43, key=["5"]),
+            "truncate": W.truncate([43], 1),
+            "keepalive": None,
+            "unknown_table": W.insert(4242, ["1"]),
+            "lsn_top_bits": None,
+        }[what]
+        s = _plan_stream(7, 6, 90, odd=(251, odd) if odd is not None else None)
+        if what == "keepalive":
+            s2 = W.Stream()
+            for i in range(len(s.offsets) - 1):
+                s2.add_payload(bytes(s.buf[s.offsets[i] + 5:s.offsets[i + 1]]))
+                if i == 200:
+                    s2.add_payload(W.keepalive(0x9999))
+            s = s2
+        buf = np.frombuffer(s.bytes(), dtype=np.uint8).copy()
+        if what == "lsn_top_bits":   # a Begin whose final_lsn does not fit the 62 bits of k_plan's LSN word (and its Commit)
+            offs = s.offsets
+            tags = [buf[int(offs[i]) + 30] for i in range(len(offs) - 1)]
+            bi = [i for i, t in enumerate(tags) if t == ord("B")][2]
+            ci = [i for i, t in enumerate(tags) if t == ord("C") and i > bi][0]
+            buf[int(offs[bi]) + 31] |= 0xC0
+            buf[int(offs[ci]) + 32] |= 0xC0
+        err = _agree(d, o, buf, s.offsets)
+        p = d.debug_paths()
+        assert p["plan"] == 0 and p["plan_redone"] == 1, p
+        legal = what in ("long_leading_zeros", "update", "delete", "truncate", "keepalive", "lsn_top_bits", "unknown_table")   # a table without a state is not owned: its rows are skipped
+        assert (err == 0) == legal, (what, err)
+        if not legal:
+            assert p["redone"] == 1, p
+        d.close()
+    finally:
+        for k in _KNOBS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]

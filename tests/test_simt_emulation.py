@@ -70,24 +70,9 @@ def test_copy_rows_and_boundary_scan(simt_lib):
     assert " passed" in tail and "failed" not in tail, tail
 
 
-def test_fixed_width_plan_variant(simt_lib):
-    """The fixed-width plan of k_fused (csrc/fixed_tile.hip.h; in the product for fused.hip only; built here on every source together with
-    the other prepared flags: ETLG_HOT_FIXES, ETLG_SCALAR_COLS, ETLG_EARLY_SPAN, ETLG_STAGE_WIDE=8 — tools/build_variants.py "all"): its own parity file
-    with the demand that conforming tiles really take the plan, and the cfg2 mutation fuzz, on an emulator build
-    with every flag on every source (k_cells' variant head included); the same parity file on the default emulator build."""
-    sys.path.insert(0, SIMT)
-    try:
-        import build as simt_build
-    finally:
-        sys.path.pop(0)
-    lib = simt_build.build(extra_flags=["-DETLG_FIXED_TILE", "-DETLG_HOT_FIXES", "-DETLG_SCALAR_COLS", "-DETLG_EARLY_SPAN", "-DETLG_STAGE_WIDE=8"],
-                           lib=os.path.join(simt_build.OUT, "libetlg_simt_all.so"))
-    os.environ["ETLG_EXPECT_FIXED_TILE"] = "1"
-    try:
-        tail = _run_gpu_file_on_emulator(lib, ["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or (cfg2 and (default or fused))"], 600)
-        assert " passed" in tail and "failed" not in tail, tail
-        # the default emulator build mirrors the product's per-source flags (etl_amd/build.py: DEFS — k_fused carries the plan)
-        tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_fixed_plan.py"], 600)
-        assert " passed" in tail and "failed" not in tail, tail
-    finally:
-        os.environ.pop("ETLG_EXPECT_FIXED_TILE", None)
+def test_fixed_width_plans(simt_lib):
+    """k_plan (plan.hip) and the fixed-width plan of k_fused (fixed_tile.hip.h): their own parity file with the demand that
+    conforming streams really take the plan, and the cfg2 mutation fuzz on the default path (k_plan first, the generic kernel
+    behind it)."""
+    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or k_plan or (cfg2 and default)"], 900)
+    assert " passed" in tail and "failed" not in tail, tail
