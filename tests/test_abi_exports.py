@@ -52,15 +52,17 @@ def test_host_only_entry_points_match_the_oracle():
         assert L.etlg_slot_bytes(cls) == o.L.oracle_slot_bytes(cls), cls
 
 
-def test_shipped_fused_flags_are_the_measured_variant():
-    """k_fused ships with the flag set that was timed on the MI355X as variant "all" (profiles/r01j_ab_quick_all.json):
-    etl_amd/build.py DEFS for fused.hip and tools/build_variants.py "all" must stay the same list."""
-    import importlib.util
+def test_one_code_path_per_kernel():
+    """The flag variants of round 1 are gone: no per-source feature flags in the build, none of their names in the kernel
+    sources ("collapse the variant matrix")."""
     import os
+    import re
     from etl_amd import build
+    assert build.DEFS == {}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("build_variants", os.path.join(root, "tools", "build_variants.py"))
-    bv = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bv)
-    assert sorted(build.DEFS["fused.hip"]) == sorted(bv.VARIANTS["all"])
-    assert bv.VARIANTS["plain"] == [] and bv.VARIANTS["product"] == []
+    pat = re.compile(r"ETLG_(FIXED_TILE|HOT_FIXES|SCALAR_COLS|EARLY_SPAN|STAGE_WIDE|BLK128|TICKET|ABLATE|DECODE_NOINLINE)\b|if \(false\)")
+    csrc = os.path.join(root, "etl_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".cpp")):
+            hits = [ln for ln in open(os.path.join(csrc, f)).read().split("\n") if pat.search(ln)]
+            assert not hits, (f, hits[:3])
