@@ -950,6 +950,22 @@ int32_t etlg_table_ready(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, cons
   return slot;
 }
 
+int32_t etlg_table_forget(etlg_ctx* c, uint32_t table_id) {
+  if (!c) return ETLG_InvalidArgument;
+  (void)drain_pending(c);
+  c->cs.cache.erase(table_id);
+  c->side_dirty = true;
+  return ETLG_OK;
+}
+
+int32_t etlg_table_cache_get(const etlg_ctx* c, uint32_t table_id, int32_t* kind, uint64_t* snapshot, int32_t* slot) {
+  if (!c || !kind || !snapshot || !slot) return 0;
+  auto it = c->cs.cache.find(table_id);
+  if (it == c->cs.cache.end()) return 0;
+  *kind = (int32_t)it->second.kind; *snapshot = it->second.snapshot; *slot = it->second.slot;
+  return 1;
+}
+
 int32_t etlg_ctx_reset_stream_state(etlg_ctx* c) {
   if (!c) return ETLG_InvalidArgument;
   (void)drain_pending(c);

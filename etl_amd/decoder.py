@@ -117,6 +117,17 @@ class Decoder:
         i = np.asarray(ident_mask, dtype=np.uint8)
         return self.L.etlg_table_ready(self.h, table_id, snapshot_lsn, _ptr(r), _ptr(i), len(r))
 
+    def table_forget(self, table_id):
+        """SharedTableCache::remove_table (table_cache.rs:131-145)."""
+        return self.L.etlg_table_forget(self.h, table_id)
+
+    def cache_state(self, table_id):
+        """SharedTableCache::get (table_cache.rs:99-102): None, or (kind 1 WaitingForRelation | 2 Ready, snapshot id, schema slot)."""
+        k, sn, sl = C.c_int32(), C.c_uint64(), C.c_int32()
+        if not self.L.etlg_table_cache_get(self.h, table_id, C.byref(k), C.byref(sn), C.byref(sl)):
+            return None
+        return k.value, sn.value, sl.value
+
     def last_error(self):
         e = self.L.etlg_last_error(self.h).contents
         return EtlError(e.kind, e.code, (e.description or b"").decode(), (e.detail or b"").decode() or None, e.frame_index)

@@ -241,6 +241,16 @@ int32_t etlg_table_ready(etlg_ctx* ctx, uint32_t table_id, uint64_t snapshot_lsn
                          const uint8_t* replication_mask,
                          const uint8_t* identity_mask, uint32_t nmask);
 
+/* Drop the shared-table-cache entry of a table (idempotent): SharedTableCache::remove_table
+ * (crates/etl/src/replication/table_cache.rs:131-145), as the table-sync worker does before it restarts a table
+ * (crates/etl/src/replication/table_sync/mod.rs:233). Rows of that table then fail with "Missing shared table state"
+ * until a Relation message or etlg_table_ready installs a schema again. Stored schemas and slot ids are untouched. */
+int32_t etlg_table_forget(etlg_ctx* ctx, uint32_t table_id);
+
+/* The shared-table-cache entry of a table (SharedTableCache::get, table_cache.rs:99-102): returns 0 if there is none, else 1
+ * with *kind = 1 WaitingForRelation | 2 Ready, *snapshot_lsn = the entry's snapshot id, *schema_slot = the Ready schema (-1 while waiting). */
+int32_t etlg_table_cache_get(const etlg_ctx* ctx, uint32_t table_id, int32_t* kind, uint64_t* snapshot_lsn, int32_t* schema_slot);
+
 /* Reset the transaction state (remote_final_lsn = None, next ordinal = 0),
  * as a fresh ApplyLoop does. */
 int32_t etlg_ctx_reset_stream_state(etlg_ctx* ctx);

@@ -1276,6 +1276,22 @@ int32_t oracle_table_ready(oracle_ctx* c, uint32_t table_id, uint64_t snapshot, 
 
 // Decode. offsets may be NULL (record-boundary scan on the CPU).
 // Returns the error *code* (etlg_err_code) of the first failing frame or 0.
+// SharedTableCache accessors (crates/etl/src/replication/table_cache.rs:88-154): get / remove_table / active_table_ids.
+int32_t oracle_cache_state(const oracle_ctx* c, uint32_t table_id, int32_t* kind, uint64_t* snapshot, int32_t* slot) {
+  auto it = c->c.cache.find(table_id);
+  if (it == c->c.cache.end()) return 0;
+  *kind = (int32_t)it->second.kind; *snapshot = it->second.snapshot; *slot = it->second.slot;
+  return 1;
+}
+void oracle_table_forget(oracle_ctx* c, uint32_t table_id) { c->c.cache.erase(table_id); }
+uint32_t oracle_cache_tables(const oracle_ctx* c, uint32_t* out, uint32_t cap) {
+  std::vector<uint32_t> ids;
+  for (auto& kv : c->c.cache) ids.push_back(kv.first);
+  std::sort(ids.begin(), ids.end());
+  for (uint32_t i = 0; i < ids.size() && i < cap; i++) out[i] = ids[i];
+  return (uint32_t)ids.size();
+}
+
 int32_t oracle_decode(oracle_ctx* c, const uint8_t* buf, size_t len, const uint32_t* offsets, size_t nframes, oracle_batch** out) {
   auto* ob = new oracle_batch();
   ob->ctx = &c->c;

@@ -120,6 +120,26 @@ class Oracle:
         i = np.asarray(ident_mask, dtype=np.uint8)
         return self.L.oracle_table_ready(self.h, table_id, snapshot_lsn, _ptr(r), _ptr(i), len(r))
 
+    def cache_state(self, table_id):
+        """SharedTableCache::get (table_cache.rs:99-102): None, or (kind 1 WaitingForRelation | 2 Ready, snapshot id, schema slot)."""
+        k, sn, sl = C.c_int32(), C.c_uint64(), C.c_int32()
+        self.L.oracle_cache_state.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+        if not self.L.oracle_cache_state(self.h, table_id, C.byref(k), C.byref(sn), C.byref(sl)):
+            return None
+        return k.value, sn.value, sl.value
+
+    def table_forget(self, table_id):
+        self.L.oracle_table_forget.argtypes = [C.c_void_p, C.c_uint32]
+        self.L.oracle_table_forget.restype = None
+        self.L.oracle_table_forget(self.h, table_id)
+
+    def cache_tables(self):
+        out = (C.c_uint32 * 256)()
+        self.L.oracle_cache_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        self.L.oracle_cache_tables.restype = C.c_uint32
+        n = self.L.oracle_cache_tables(self.h, out, 256)
+        return [int(out[i]) for i in range(n)]
+
     @staticmethod
     def _prep(buf, offsets):
         a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf

@@ -22,7 +22,6 @@
 #include <vector>
 
 #include "../include/etlg.h"
-#include "../etl_amd/csrc/float_fast.h"  // ONLY the float deferral rule shared with the device (see float_device_rule)
 
 namespace orc {
 
@@ -441,16 +440,64 @@ inline Res<uint64_t> parse_f32_bits(sv s) {
   return R::Ok((uint64_t)bits);
 }
 
-// Which float texts the DEVICE decodes itself (include/etlg.h, "float cells"). This is a rule of OUR contract,
-// not reference behaviour, and it has to agree with the device to the last text, so the decision is taken by
-// the device's own host-compilable header (etl_amd/csrc/float_fast.h: Clinger's exact path, then Eisel-Lemire,
-// else "inconclusive"). Only the DECISION is shared: the value the oracle reports still comes from glibc
-// strtod / strtof above, an independent computation, and tests/test_float_fast.py checks the header against
-// those on ten million texts.
+// Which float texts the DEVICE decodes itself (include/etlg.h, "float cells"). This is a rule of OUR contract, not
+// reference behaviour. It is STATED here independently of the device's implementation (etl_amd/csrc/float_fast.h is not
+// included): a text is decoded on the device iff its value is already determined by its first 19 significant digits, i.e.
+//   * zero, inf / infinity / nan, or at most 19 significant digits: always;
+//   * more than 19 significant digits (a non-zero digit was cut off): iff w x 10^q and (w + 1) x 10^q — the two decimals
+//     that bracket the text, w = the first 19 significant digits — round to the SAME float. Both roundings are taken with
+//     glibc strtod / strtof on the synthesised decimals, exact and unrelated to the device's arithmetic.
+// The device reaches the same verdict with Clinger's exact path and the Eisel-Lemire algorithm; the one place where the two
+// could part is a text on which Eisel-Lemire itself is inconclusive (the device then defers although the value is
+// determined): none is known, tests/native/float_rule_check.cpp compares the two verdicts on millions of texts, and a
+// parity failure on such a text would name it.
 // Returns 0 decode on device, 1 deferred, 2 malformed. Only used in CONTRACT mode.
 inline int float_device_rule(sv s, bool is32) {
-  uint64_t ignored = 0;
-  return etlg::parse_float_fast_t([&](uint32_t i) { return (uint32_t)(unsigned char)s[i]; }, (uint32_t)s.size(), is32, ignored);
+  bool special, neg; int k = 0;
+  if (!float_grammar(s, special, k, neg)) return 2;
+  if (special) return 0;
+  size_t i = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+  std::string w;            // first 19 significant digits
+  long long q = 0;          // decimal exponent of the last digit position read so far
+  bool frac = false, cut = false;
+  size_t zeros = 0;         // zeros after a significant digit, not yet appended
+  for (; i < s.size(); i++) {
+    const char c = s[i];
+    if (c == '.') { frac = true; continue; }
+    if (c < '0' || c > '9') break;
+    if (frac) q--;
+    if (c == '0') { if (!w.empty() || cut) zeros++; continue; }
+    // a non-zero digit: the zeros held back, then the digit; whatever does not fit 19 digits only moves the exponent
+    for (size_t z = 0; z <= zeros; z++) {
+      const char d = z < zeros ? '0' : c;
+      if (w.size() < 19 && !cut) w.push_back(d);
+      else { cut = true; q++; }
+    }
+    zeros = 0;
+  }
+  q += (long long)zeros;    // trailing zeros are not part of w
+  if (i < s.size()) {       // exponent (the grammar was checked above)
+    i++;
+    bool eneg = false;
+    if (s[i] == '+' || s[i] == '-') { eneg = s[i] == '-'; i++; }
+    long long ex = 0;
+    for (; i < s.size(); i++) if (ex < 100000) ex = ex * 10 + (s[i] - '0');
+    q += eneg ? -ex : ex;
+  }
+  if (w.empty()) return 0;  // zero, whatever the exponent
+  if (!cut) return 0;
+  // w + 1 as a decimal string
+  std::string w1 = w;
+  int p = (int)w1.size() - 1;
+  while (p >= 0 && w1[(size_t)p] == '9') { w1[(size_t)p] = '0'; p--; }
+  if (p >= 0) w1[(size_t)p]++; else w1.insert(w1.begin(), '1');
+  const std::string lo = w + "e" + std::to_string(q), hi = w1 + "e" + std::to_string(q);
+  if (is32) {
+    const float a = strtof(lo.c_str(), nullptr), b = strtof(hi.c_str(), nullptr);
+    return memcmp(&a, &b, 4) == 0 ? 0 : 1;
+  }
+  const double a = strtod(lo.c_str(), nullptr), b = strtod(hi.c_str(), nullptr);
+  return memcmp(&a, &b, 8) == 0 ? 0 : 1;
 }
 
 // -------------------------------------------------------------------- numeric

@@ -342,3 +342,63 @@ ERR_TABLE = {
     A.E_BOOTSTRAP_SNAPSHOT: (A.InvalidState, "Bootstrap table schema snapshot exceeded requested snapshot"),
     A.E_SNAPSHOT_MISMATCH: (A.InvalidState, "Table schema snapshot mismatch"),
 }
+
+
+# ---- replication / identity masks and the shared table cache (A14) ---------------------------------------------------
+# The stored schema of crates/etl/src/schema.rs:790-800 and crates/etl/src/replication/table_cache.rs:165-177:
+# test_table(id int4 PK, name text NULL, age int4 NULL). A stored column here is (name, oid, nullable, primary_key_ordinal).
+TEST_TABLE = [("id", 23, False, 1), ("name", 25, True, 0), ("age", 23, True, 0)]
+
+# crates/etl/src/schema.rs:802-898 — (test name, replicated column names, expected mask | ("unknown", sorted names))
+SCHEMA_RS_REPLICATION_MASK = [
+    ("replication_mask_try_build_all_columns_replicated:802", ["id", "name", "age"], [1, 1, 1]),
+    ("replication_mask_try_build_partial_columns_replicated:813", ["id", "age"], [1, 0, 1]),
+    ("replication_mask_try_build_no_columns_replicated:824", [], [0, 0, 0]),
+    ("replication_mask_try_build_unknown_column_error:834", ["id", "unknown_column"], ("unknown", ["unknown_column"])),
+    ("replication_mask_try_build_multiple_unknown_columns_error:852", ["id", "foo", "bar"], ("unknown", ["bar", "foo"])),
+]
+# crates/etl/src/schema.rs:871-898 — build_or_all / all
+SCHEMA_RS_BUILD_OR_ALL = [
+    ("replication_mask_build_or_all_success:871", ["id", "age"], [1, 0, 1]),
+    ("replication_mask_build_or_all_falls_back_to_all:882", ["id", "unknown_column"], [1, 1, 1]),
+]
+# crates/etl/src/schema.rs:913-951 — (test, replication mask, identity mask | None = from_mask's default, expected IdentityType)
+SCHEMA_RS_IDENTITY_TYPE = [
+    ("identity_type_primary_key:913", [1, 1, 1], None, "PrimaryKey"),
+    ("identity_type_alternative_key:922", [1, 1, 1], [0, 1, 1], "AlternativeKey"),
+    ("identity_type_full:933", [1, 1, 1], [1, 1, 1], "Full"),
+    ("identity_type_missing:944", [1, 1, 1], [0, 0, 0], "Missing"),
+]
+# crates/etl/src/schema.rs:955-988 — (test, stored columns, replication mask, identity mask, omitted primary-key columns)
+SCHEMA_RS_PK_REPLICATED = [
+    ("all_primary_key_columns_replicated_returns_true_for_complete_primary_key:955", TEST_TABLE, [1, 1, 1], None, []),
+    ("all_primary_key_columns_replicated_returns_false_for_partial_primary_key:965",
+     [("tenant_id", 23, False, 1), ("id", 23, False, 2), ("name", 25, True, 0)], [0, 1, 1], [0, 1, 0], ["tenant_id"]),
+]
+
+# crates/etl/src/postgres/codec/event.rs:1232-1354 — IdentityMessage::build_identity_mask
+# (test, stored columns, replication mask, primary_key_attnums, relreplident, replica_identity_index_attnums, expected mask | None, expected IdentityType | None)
+_T2 = [("id", 20, False, 1), ("email", 25, False, 0)]
+_T3 = [("id", 20, False, 1), ("name", 25, False, 2), ("email", 25, False, 0)]
+_T3B = [("id", 20, False, 1), ("name", 25, False, 0), ("email", 25, False, 0)]
+EVENT_RS_BUILD_IDENTITY = [
+    ("build_identity_classifies_using_index_with_primary_key_columns_as_primary_key:1233", _T2, [1, 1], [1], "i", [1], None, "PrimaryKey"),
+    ("build_identity_classifies_using_index_with_distinct_columns_as_alternative_key:1260", _T2, [1, 1], [1], "i", [2], None, "AlternativeKey"),
+    ("build_identity_for_default_filters_to_replicated_columns:1287", _T3, [1, 0, 1], [1, 2], "d", [], [1, 0, 0], None),
+    ("build_identity_for_using_index_filters_to_replicated_columns:1310", _T3B, [0, 1, 0], [1], "i", [2, 3], [0, 1, 0], None),
+    ("build_identity_for_full_uses_all_replicated_columns:1333", _T2, [1, 0], [1], "f", [], [1, 0], None),
+]
+
+# crates/etl/src/replication/table_cache.rs:165-302 — the Ready schema of create_test_schema(): TEST_TABLE stored at snapshot 10,
+# replication mask [1, 0, 1] ("id", "age"), identity mask [1, 0, 1]. Steps: ("ready", snapshot) = note_ready with that schema,
+# ("waiting", table, snapshot) = note_waiting_for_relation, ("forget", table) = remove_table; expected = table -> None | (state, snapshot).
+TABLE_CACHE_RS = [
+    ("note_ready_and_get:185", [("ready", 123)], {123: ("Ready", 10)}),
+    ("note_waiting_for_relation_invalidates_ready_schema:206", [("ready", 123), ("waiting", 123, 11)], {123: ("WaitingForRelation", 11)}),
+    ("older_snapshot_rewinds_to_waiting_relation:220", [("ready", 123), ("waiting", 123, 9)], {123: ("WaitingForRelation", 9)}),
+    ("waiting_state_exposes_snapshot_without_schema:256", [("waiting", 123, 10)], {123: ("WaitingForRelation", 10)}),
+    ("active_table_ids_returns_current_tables:269", [("ready", 123), ("waiting", 456, 20)], {123: ("Ready", 10), 456: ("WaitingForRelation", 20)}),
+    ("remove_table_is_idempotent:286", [("forget", 123), ("ready", 123), ("forget", 123), ("forget", 123)], {123: None}),
+]
+# clone_shares_state (:234) checks that two handles of one Arc see the same entry: a context IS the one shared cache here
+# (etlg_ctx_create: "owns ... the SharedTableCache"), so there is nothing to transcribe.

@@ -13,3 +13,16 @@ def test_float_fast_path_matches_strtod(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "mismatches 0" in out.stdout
+
+
+def test_oracle_states_the_deferral_rule_independently(tmp_path):
+    """The oracle decides "decoded on the device or DEFERRED" without the device's header (two glibc roundings of the decimals
+    that bracket a long mantissa); the device decides with Clinger + Eisel-Lemire. Same verdict on 3.6 million texts x 2 widths."""
+    src = open(os.path.join(ROOT, "oracle", "oracle_codec.hpp")).read()
+    assert "float_fast.h\"" not in src.replace("etl_amd/csrc/float_fast.h is not", ""), "the oracle must not include the product's float header"
+    exe = str(tmp_path / "float_rule_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "etl_amd", "csrc"), "-I", os.path.join(ROOT, "oracle"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "float_rule_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "mismatches 0" in out.stdout

@@ -115,6 +115,46 @@ def test_full_size_parity(mk):
     assert n["redone"] == 0 and n["multipass"] == 0, n
 
 
+def test_full_size_parity_cfg5_control_path():
+    """BASELINE configs[4] at the BASELINE batch size: 64 MiB of the cfg5 stream (Relation / DDL messages, Type / Origin noise,
+    keepalives, 3 tables) with DEFAULT flags — the optimistic kernel, then the control path — byte for byte, two batches in a
+    row (the second starts from the schemas the first one's DDL messages left)."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.cfg5()
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o, ready=False)
+    w.register(d, ready=False)
+    for _ in range(2):
+        buf, offs = w.fill(64 << 20)
+        rb = o.decode(buf, offs)
+        gb = d.decode(buf, offs)
+        assert rb.err_code == 0 and gb.rc == 0, gb.error
+        diff = rb.host_batch().diff(gb.host())
+        assert not diff, diff[:6]
+    n = d.debug_paths()
+    d.close()
+    assert n["redone"] == 0 and n["control"] == 2, n
+
+
+@pytest.mark.parametrize("mk", [synth.cfg2, synth.cfg3])
+def test_full_size_parity_without_sidecar(mk):
+    """64 MiB with frame_offsets = NULL: the device finds the record boundaries itself (scan.hip) before it decodes."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = mk()
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    buf, offs = w.fill(64 << 20)
+    rb = o.decode(buf, offs)
+    gb = d.decode(buf, None, flags=abi.F_NO_CONTROL)
+    assert rb.err_code == 0 and gb.rc == 0
+    diff = rb.host_batch().diff(gb.host())
+    assert not diff, diff[:6]
+    d.close()
+
+
 def test_device_resident_io_and_no_control_flag():
     """Input already in HBM, output left in HBM, control-plane round trip skipped."""
     import torch
