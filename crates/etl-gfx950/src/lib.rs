@@ -1,0 +1,133 @@
+//! etl-gfx950 — the Rust side of the MI355X-native decode stage for supabase/etl.
+//!
+//! ```text
+//! ReplicationMessageStream ──bytes──▶ StagingBatcher ──64 MiB + sidecar──▶ GpuDecoder::decode ──arena──▶ materialize::events ──▶ EventBatch
+//! ```
+//! * [`ffi`]         raw binding of `include/etlg.h` (checked against the header by the etl-gfx950 test suite);
+//! * [`batcher`]     frames + offsets sidecar accumulation, flush policy (apply.rs:1910-1967);
+//! * [`materialize`] arena → `Event` / `TableRow` / `Cell`, DEFERRED cells finished with the reference's own parser;
+//! * [`GpuDecoder`]  safe wrapper of one context: side inputs mirror `SchemaStore` / `StateStore` / `SharedTableCache`
+//!                   (crates/etl/src/store/schema/base.rs:19-69, store/state/base.rs:25-139, replication/table_cache.rs:88-154).
+pub mod batcher;
+pub mod ffi;
+pub mod materialize;
+
+use std::ffi::{CStr, CString};
+use std::ptr;
+
+use etl::error::{ErrorKind, EtlError, EtlResult};
+use etl::etl_error;
+use etl::event::Event;
+
+use crate::batcher::StagedBatch;
+use crate::ffi::*;
+
+/// `etlg_error_kind` → the reference's `ErrorKind` (crates/etl/src/error.rs:85-170). Descriptions are the reference's own
+/// static strings (`etlg_err_table`), so `EtlError::kind()` / `description()` read as if the CPU decoder had failed.
+fn kind_of(k: i32) -> ErrorKind {
+    match k {
+        ETLG_ConversionError => ErrorKind::ConversionError,
+        ETLG_InvalidData => ErrorKind::InvalidData,
+        ETLG_ValidationError => ErrorKind::ValidationError,
+        ETLG_InvalidState => ErrorKind::InvalidState,
+        ETLG_MissingTableSchema => ErrorKind::MissingTableSchema,
+        ETLG_CorruptedTableSchema => ErrorKind::CorruptedTableSchema,
+        ETLG_DeserializationError => ErrorKind::DeserializationError,
+        ETLG_SourceConnectionFailed => ErrorKind::SourceConnectionFailed,
+        ETLG_IoError => ErrorKind::IoError,
+        _ => ErrorKind::Unknown,
+    }
+}
+
+pub struct GpuDecoder {
+    ctx: *mut etlg_ctx,
+}
+
+// One context per apply-loop stream, used from one task at a time (`&mut self`), like the loop's own state.
+unsafe impl Send for GpuDecoder {}
+
+impl GpuDecoder {
+    pub fn new(hip_device: i32) -> EtlResult<Self> {
+        let mut ctx = ptr::null_mut();
+        let rc = unsafe { etlg_ctx_create(hip_device, &mut ctx) };
+        if rc != ETLG_OK {
+            let why = unsafe { CStr::from_ptr(etlg_create_error()) }.to_string_lossy().into_owned();
+            return Err(etl_error!(ErrorKind::ConfigError, "MI355X decode context could not be created", why));
+        }
+        debug_assert_eq!(unsafe { etlg_abi_version() }, ETLG_ABI_VERSION);
+        Ok(Self { ctx })
+    }
+
+    fn last_error(&self) -> EtlError {
+        let e = unsafe { &*etlg_last_error(self.ctx) };
+        let desc: &'static str = if e.description.is_null() { "GPU decode failed" } else { unsafe { CStr::from_ptr(e.description) }.to_str().unwrap_or("GPU decode failed") };
+        let detail = if e.detail.is_null() { format!("frame {}", e.frame_index) } else { format!("{} (frame {})", unsafe { CStr::from_ptr(e.detail) }.to_string_lossy(), e.frame_index) };
+        etl_error!(kind_of(e.kind), desc, detail)
+    }
+
+    /// `SchemaStore::store_table_schema` mirror: stored columns in attnum order.
+    pub fn put_schema(&mut self, table_id: u32, snapshot_lsn: u64, schema: &str, table: &str, cols: &[(String, u32, i32, i32, bool, bool)]) -> EtlResult<()> {
+        let names: Vec<CString> = cols.iter().map(|c| CString::new(c.0.as_str()).unwrap()).collect();
+        let raw: Vec<etlg_col> = cols
+            .iter()
+            .zip(&names)
+            .map(|(c, n)| etlg_col { name: n.as_ptr(), type_oid: c.1, type_modifier: c.2, attnum: c.3, nullable: c.4 as u8, primary_key: c.5 as u8, _pad: [0; 2] })
+            .collect();
+        let (s, t) = (CString::new(schema).unwrap(), CString::new(table).unwrap());
+        match unsafe { etlg_schema_put(self.ctx, table_id, snapshot_lsn, s.as_ptr(), t.as_ptr(), raw.len() as u32, raw.as_ptr()) } {
+            ETLG_OK => Ok(()),
+            _ => Err(self.last_error()),
+        }
+    }
+
+    /// Table replication state as `should_apply_changes` sees it (apply.rs:2836-2867).
+    pub fn set_table_state(&mut self, table_id: u32, state_kind: i32, lsn: u64) {
+        unsafe { etlg_table_state(self.ctx, table_id, state_kind, lsn) };
+    }
+
+    /// `SharedTableCache::note_ready` after a table copy (table_cache.rs:122); returns the schema slot.
+    pub fn table_ready(&mut self, table_id: u32, snapshot_lsn: u64, replication_mask: &[u8], identity_mask: &[u8]) -> EtlResult<u32> {
+        debug_assert_eq!(replication_mask.len(), identity_mask.len());
+        let slot = unsafe { etlg_table_ready(self.ctx, table_id, snapshot_lsn, replication_mask.as_ptr(), identity_mask.as_ptr(), replication_mask.len() as u32) };
+        if slot < 0 { Err(self.last_error()) } else { Ok(slot as u32) }
+    }
+
+    /// `SharedTableCache::remove_table` (table_cache.rs:131-145).
+    pub fn forget_table(&mut self, table_id: u32) {
+        unsafe { etlg_table_forget(self.ctx, table_id) };
+    }
+
+    pub fn set_worker(&mut self, table_sync_table: Option<u32>, bootstrap_snapshot_lsn: u64) {
+        let (kind, id) = match table_sync_table { Some(t) => (ETLG_WORKER_TABLE_SYNC, t), None => (ETLG_WORKER_APPLY, 0) };
+        unsafe { etlg_ctx_set_worker(self.ctx, kind, id, bootstrap_snapshot_lsn) };
+    }
+
+    /// Decodes one staged batch into the events the apply loop would have produced message by message. On a decode error
+    /// (fail-fast, apply.rs:2475-2481) the events BEFORE the failing frame are returned with the error.
+    pub fn decode(&mut self, staged: &StagedBatch, schemas: &mut dyn materialize::SlotSchemas) -> (Vec<Event>, EtlResult<()>) {
+        let mut batch = ptr::null_mut();
+        let flags = if staged.control_free { ETLG_F_NO_CONTROL } else { 0 };
+        let rc = unsafe {
+            etlg_decode(self.ctx, staged.frames.as_ptr(), staged.frames.len(), staged.offsets.as_ptr(), staged.meta.len(), flags, &mut batch)
+        };
+        if batch.is_null() {
+            return (Vec::new(), Err(self.last_error()));
+        }
+        let status = if rc == ETLG_OK { Ok(()) } else { Err(self.last_error()) };
+        let mut view = std::mem::MaybeUninit::<etlg_batch_view>::uninit();
+        unsafe { etlg_batch_view_get(batch, view.as_mut_ptr()) };
+        let view = unsafe { view.assume_init() };
+        let events = unsafe { materialize::events(&view, schemas) };
+        unsafe { etlg_batch_free(batch) };
+        match events {
+            Ok(ev) => (ev, status),
+            Err(e) => (Vec::new(), Err(e)),
+        }
+    }
+}
+
+impl Drop for GpuDecoder {
+    fn drop(&mut self) {
+        unsafe { etlg_ctx_destroy(self.ctx) };
+    }
+}
