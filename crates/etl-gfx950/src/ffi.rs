@@ -170,6 +170,62 @@ pub struct etlg_batch_view {
 }
 
 #[repr(C)]
+pub struct etlg_column {
+    pub type_class: u32,
+    pub arrow_kind: u32,
+    pub value_bytes: u32,
+    pub nullable: u32,
+    pub null_count: u64,
+    pub deferred_count: u64,
+    pub validity: *const u8,
+    pub deferred: *const u8,
+    pub values: *const u8,
+    pub offsets: *const i64,
+    pub values_bytes: u64,
+}
+
+#[repr(C)]
+pub struct etlg_columns_view {
+    pub n_rows: u64,
+    pub n_cols: u32,
+    pub on_device: u32,
+    pub cols: *const etlg_column,
+    pub row_event: *const u64,
+}
+
+#[repr(C)]
+pub struct etlg_rowbinary_view {
+    pub n_rows: u64,
+    pub n_bytes: u64,
+    pub n_host_rows: u64,
+    pub status: u32,
+    pub on_device: u32,
+    pub host_event: u64,
+    pub host_column: u32,
+    pub _pad: u32,
+    pub bytes: *const u8,
+    pub row_offsets: *const i64,
+    pub row_event: *const u64,
+}
+
+#[repr(C)]
+pub struct etlg_columns {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct etlg_rowbinary {
+    _private: [u8; 0],
+}
+
+pub const ETLG_ROWS_INSERT: u32 = 1;
+pub const ETLG_ROWS_UPDATE: u32 = 2;
+pub const ETLG_CH_MERGE_TREE: i32 = 0;
+pub const ETLG_CH_REPLACING_MERGE_TREE: i32 = 1;
+pub const ETLG_RB_OK: u32 = 0;
+pub const ETLG_RB_NEEDS_HOST: u32 = 3;
+
+#[repr(C)]
 pub struct etlg_kernel_stat {
     pub name: *const c_char,
     pub launches: u64,
@@ -254,6 +310,21 @@ extern "C" {
     pub fn etlg_batch_header_to_device(ctx: *mut etlg_ctx, batch: *mut etlg_batch, dst_device_8xu64: *mut c_void) -> i32;
     pub fn etlg_batch_download(ctx: *mut etlg_ctx, batch: *mut etlg_batch) -> i32;
     pub fn etlg_batch_free(batch: *mut etlg_batch);
+    pub fn etlg_batch_columns(ctx: *mut etlg_ctx, batch: *mut etlg_batch, schema_slot: i32, row_kinds: u32, flags: u32, out: *mut *mut etlg_columns) -> i32;
+    pub fn etlg_columns_view_get(cols: *const etlg_columns, out: *mut etlg_columns_view) -> i32;
+    pub fn etlg_columns_free(cols: *mut etlg_columns);
+    pub fn etlg_batch_rowbinary(
+        ctx: *mut etlg_ctx,
+        batch: *mut etlg_batch,
+        schema_slot: i32,
+        nullable_flags: *const u8,
+        n_flags: u32,
+        engine: i32,
+        flags: u32,
+        out: *mut *mut etlg_rowbinary,
+    ) -> i32;
+    pub fn etlg_rowbinary_view_get(rb: *const etlg_rowbinary, out: *mut etlg_rowbinary_view) -> i32;
+    pub fn etlg_rowbinary_free(rb: *mut etlg_rowbinary);
     pub fn etlg_ctx_slots(ctx: *const etlg_ctx, n_slots: *mut u32, slots: *mut *const etlg_slot_desc) -> i32;
 
     pub fn etlg_ctx_profile(ctx: *mut etlg_ctx, enable: i32) -> i32;

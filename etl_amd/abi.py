@@ -96,6 +96,31 @@ class BatchView(C.Structure):
                 ("on_device", C.c_uint32), ("n_slots", C.c_uint32), ("slots", C.POINTER(SlotDesc))]
 
 
+class Column(C.Structure):   # etlg_column
+    _fields_ = [("type_class", C.c_uint32), ("arrow_kind", C.c_uint32), ("value_bytes", C.c_uint32), ("nullable", C.c_uint32),
+                ("null_count", C.c_uint64), ("deferred_count", C.c_uint64), ("validity", C.c_void_p), ("deferred", C.c_void_p),
+                ("values", C.c_void_p), ("offsets", C.c_void_p), ("values_bytes", C.c_uint64)]
+
+
+class ColumnsView(C.Structure):   # etlg_columns_view
+    _fields_ = [("n_rows", C.c_uint64), ("n_cols", C.c_uint32), ("on_device", C.c_uint32), ("cols", C.POINTER(Column)),
+                ("row_event", C.c_void_p)]
+
+
+class RowBinaryView(C.Structure):   # etlg_rowbinary_view
+    _fields_ = [("n_rows", C.c_uint64), ("n_bytes", C.c_uint64), ("n_host_rows", C.c_uint64), ("status", C.c_uint32),
+                ("on_device", C.c_uint32), ("host_event", C.c_uint64), ("host_column", C.c_uint32), ("_pad", C.c_uint32),
+                ("bytes", C.c_void_p), ("row_offsets", C.c_void_p), ("row_event", C.c_void_p)]
+
+
+CH_MERGE_TREE, CH_REPLACING_MERGE_TREE = 0, 1
+RB_OK, RB_NEEDS_HOST = 0, 3
+(AK_BOOLEAN, AK_INT32, AK_INT64, AK_FLOAT32, AK_FLOAT64, AK_DATE32, AK_TIME64_US, AK_TIMESTAMP_US, AK_TIMESTAMP_US_UTC, AK_FIXED16,
+ AK_LARGE_UTF8, AK_LARGE_BINARY, AK_TEXT_FORM) = range(13)
+AK_NONE = 255
+ROWS_INSERT, ROWS_UPDATE = 1, 2
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 

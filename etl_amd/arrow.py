@@ -91,13 +91,49 @@ def rows_to_record_batch(hb, slot_index, names=None, kinds=("I",), on_text="rais
         elif tc == abi.TC_STRING or tc == abi.TC_BYTEA:
             offsets, data = _var(hb, fx, so, valid)
             if tc == abi.TC_STRING:
-                arr = pa.StringArray.from_buffers(n, pa.py_buffer(offsets.astype(np.int32)), pa.py_buffer(data), _validity(pa, valid))
+                if len(data) >= 1 << 31:   # Utf8 has 32-bit offsets: a bigger hand-off goes out as LargeUtf8
+                    arr = pa.Array.from_buffers(pa.large_utf8(), n, [_validity(pa, valid), pa.py_buffer(offsets), pa.py_buffer(data)])
+                else:
+                    arr = pa.StringArray.from_buffers(n, pa.py_buffer(offsets.astype(np.int32)), pa.py_buffer(data), _validity(pa, valid))
             else:
                 arr = pa.LargeBinaryArray.from_buffers(pa.large_binary(), n, [_validity(pa, valid), pa.py_buffer(offsets), pa.py_buffer(data)])
         else:
             arr = _FIXED[tc](pa, fx, so, mask)
         arrays.append(arr)
         fields.append(pa.field(name, arr.type, nullable=bool(col.nullable)))
+    return pa.RecordBatch.from_arrays(arrays, schema=pa.schema(fields))
+
+
+def columns_to_record_batch(cols, names=None, columns=None, on_text="raise"):
+    """pyarrow.RecordBatch over the buffers `Batch.columns(slot, ...)` built on the device (host-resident `Columns`): the
+    buffers are wrapped, not converted — no per-row or per-column arithmetic happens here. Same field types as
+    `rows_to_record_batch`, except that String is LargeUtf8 (64-bit offsets: one hand-off can hold more than 2 GiB of text)."""
+    import pyarrow as pa
+    n = cols.n_rows
+    types = {abi.AK_BOOLEAN: pa.bool_(), abi.AK_INT32: pa.int32(), abi.AK_INT64: pa.int64(), abi.AK_FLOAT32: pa.float32(),
+             abi.AK_FLOAT64: pa.float64(), abi.AK_DATE32: pa.date32(), abi.AK_TIME64_US: pa.time64("us"),
+             abi.AK_TIMESTAMP_US: pa.timestamp("us"), abi.AK_TIMESTAMP_US_UTC: pa.timestamp("us", tz="UTC"),
+             abi.AK_FIXED16: pa.binary(16), abi.AK_LARGE_UTF8: pa.large_utf8(), abi.AK_LARGE_BINARY: pa.large_binary(),
+             abi.AK_TEXT_FORM: pa.large_binary()}
+    arrays, fields = [], []
+    for i in range(cols.view.n_cols):
+        if columns is not None and i not in columns:
+            continue
+        k = cols.column(i)
+        name = names[i] if names else f"c{i}"
+        if k.arrow_kind == abi.AK_NONE:
+            raise NotImplementedError(f"column {name}: timetz values are not handed off (select other columns with columns=)")
+        if (k.arrow_kind == abi.AK_TEXT_FORM or k.deferred_count) and on_text != "binary":
+            raise NotImplementedError(f"column {name} (type class {k.type_class}): text-form cells (numeric / json / arrays / deferred) "
+                                      "have no fixed-width Arrow form; pass on_text='binary' (deferred cells of a fixed-width "
+                                      "column come back null, flagged in the column's `deferred` bitmap)")
+        validity, _deferred, values, offsets = cols.host_arrays(i)
+        vbuf = None if k.null_count == 0 else pa.py_buffer(validity)
+        t = types[k.arrow_kind]
+        bufs = [vbuf, pa.py_buffer(values)] if offsets is None else [vbuf, pa.py_buffer(offsets), pa.py_buffer(values)]
+        arr = pa.Array.from_buffers(t, n, bufs, null_count=int(k.null_count))
+        arrays.append(arr)
+        fields.append(pa.field(name, t, nullable=bool(k.nullable)))
     return pa.RecordBatch.from_arrays(arrays, schema=pa.schema(fields))
 
 

@@ -1,0 +1,364 @@
+// Columnar hand-off on the device: the rows of ONE schema slot out of a decoded batch, as Arrow-layout
+// column buffers — validity bitmap + values (+ 64-bit offsets for var-len columns) — built by kernels over the arena that
+// is already in HBM. Replaces the per-Cell builders of the reference's sinks (rows_to_record_batch / build_array_for_field,
+// crates/etl-destinations/src/iceberg/encoding.rs:34-84; cell_to_* converters :150-360) with one strided gather per column:
+//
+//   Bool -> Boolean (bit-packed) | I16, I32 -> Int32 | I64, U32 -> Int64 (cell_to_i32 / cell_to_i64, :157-171)
+//   F32 -> Float32 | F64 -> Float64 | Date -> Date32 (days since 1970-01-01, :194) | Time -> Time64(us) (:201)
+//   Timestamp -> Timestamp(us) (:208) | TimestampTz -> Timestamp(us, UTC) (:215) | Uuid -> FixedSizeBinary(16)
+//   String -> LargeUtf8 | Bytes -> LargeBinary | numeric / json / arrays -> their heap entries (LargeBinary, the host finishes them)
+//
+// A cell the decode kernels handed back DEFERRED is null in `validity` and set in the column's `deferred` bitmap: the consumer
+// finishes it from the arena (row_event names the event). Integer / byte work, HBM-bound: no MFMA.
+#include "codec.hip.h"
+
+namespace etlg {
+
+DEV bool col_selected(const ColSel& s, uint64_t i, uint64_t& base) {
+  if (i >= s.n_events || s.ev_slot[i] != s.slot) return false;
+  const uint32_t k = s.ev_kind[i], fl = s.ev_flags[i];
+  base = s.ev_body[i];
+  if (k == 'I') return (s.kinds & 1u) != 0;
+  if (k == 'U' && (s.kinds & 2u) && !(fl & ETLG_FLAG_PARTIAL)) {
+    const uint32_t ok = fl & 3u;
+    base += ok == ETLG_OLD_FULL ? s.row_full : ok == ETLG_OLD_KEY ? s.row_key : 0u;
+    return true;
+  }
+  if (k == 'D' && (s.kinds & 4u) && (fl & 3u) == ETLG_OLD_FULL) return true;
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_col_count(ColSel s) {
+  __shared__ uint32_t lds[8];
+  uint64_t base;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t sel = col_selected(s, i, base) ? 1u : 0u;
+  if (s.host_rows) {  // row events of the slot that are not handed off
+    bool left = false;
+    if (!sel && i < s.n_events && s.ev_slot[i] == s.slot) { const uint32_t k = s.ev_kind[i]; left = k == 'I' || k == 'U' || k == 'D'; }
+    const unsigned long long m = __ballot(left);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(s.host_rows, (unsigned long long)__builtin_popcountll(m));
+  }
+  uint32_t tot;
+  block_scan_incl<0>(sel, lds, &tot);
+  if (threadIdx.x == 0) s.blk[blockIdx.x] = tot;
+}
+
+// exclusive scan of n u32 counts in place (single workgroup, chunks of 256); total at [n]
+__global__ __launch_bounds__(256) void k_col_scan(uint32_t* v, uint32_t n) {
+  __shared__ uint32_t lds[8];
+  uint32_t run = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t x = i < n ? v[i] : 0u;
+    uint32_t tot;
+    const uint32_t inc = block_scan_incl<0>(x, lds, &tot);
+    if (i < n) v[i] = run + inc - x;
+    run += tot;
+  }
+  if (threadIdx.x == 0) v[n] = run;
+}
+
+__global__ __launch_bounds__(256) void k_col_rows(ColSel s) {
+  __shared__ uint32_t lds[8];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t base = 0;
+  const uint32_t sel = col_selected(s, i, base) ? 1u : 0u;
+  const uint32_t inc = block_scan_incl<0>(sel, lds, nullptr);
+  if (sel) { const uint32_t r = s.blk[blockIdx.x] + inc - 1; s.row_event[r] = i; s.row_base[r] = base; }
+}
+
+enum : uint32_t { AK_BOOL = 0, AK_I32 = 1, AK_I64 = 2, AK_F32 = 3, AK_F64 = 4, AK_DATE32 = 5, AK_TIME64 = 6, AK_TS = 7, AK_TSTZ = 8, AK_FIXED16 = 9,
+                  AK_UTF8 = 10, AK_BINARY = 11, AK_TEXT_FORM = 12, AK_NONE = 255 };
+constexpr int32_t kCeDays1970 = 719163;  // chrono num_days_from_ce of 1970-01-01
+
+DEV uint32_t col_state(const ColJob& j, uint64_t base) { return (j.fixed[base + j.col_index / 4] >> (2 * (j.col_index % 4))) & 3u; }
+DEV uint32_t ld32a(const u8* p) { return *(const uint32_t*)p; }   // row slots are 4-byte aligned
+
+// One thread per row: state, value, validity / deferred words through wave ballots.
+__global__ __launch_bounds__(256) void k_col_fixed(ColJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < j.n_rows;
+  uint32_t st = ETLG_CELL_NULL;
+  const u8* slot = nullptr;
+  if (live) { const uint64_t b = j.row_base[r]; st = col_state(j, b); slot = j.fixed + b + j.off_full; }
+  const bool valid = live && st == ETLG_CELL_VALUE, defer = live && st == ETLG_CELL_DEFERRED;
+  const unsigned long long vm = __ballot(valid), dm = __ballot(defer), lm = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && lm) {
+    j.validity[r >> 6] = vm; j.deferred[r >> 6] = dm;
+    const uint32_t nulls = (uint32_t)__builtin_popcountll(lm & ~vm), nd = (uint32_t)__builtin_popcountll(dm);
+    if (nulls) atomicAdd(j.null_count, (unsigned long long)nulls);
+    if (nd) atomicAdd(j.deferred_count, (unsigned long long)nd);
+  }
+  if (j.kind == AK_BOOL) {  // values are bit-packed like the validity
+    const unsigned long long bits = __ballot(valid && ld32a(slot) != 0);
+    if ((threadIdx.x & 63) == 0 && lm) ((unsigned long long*)j.values)[r >> 6] = bits;
+    return;
+  }
+  if (!live) return;
+  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+  if (valid) { w0 = ld32a(slot); if (j.kind != AK_I32 && j.kind != AK_F32 && j.kind != AK_DATE32) w1 = ld32a(slot + 4); }
+  switch (j.kind) {
+    case AK_I32: case AK_F32: ((uint32_t*)j.values)[r] = w0; break;
+    case AK_DATE32: ((int32_t*)j.values)[r] = valid ? (int32_t)w0 - kCeDays1970 : 0; break;
+    case AK_I64: {  // I64 as is; U32 widens (cell_to_i64)
+      const uint64_t v = j.cls == ETLG_TC_U32 ? (uint64_t)w0 : ((uint64_t)w1 << 32) | w0;
+      ((uint64_t*)j.values)[r] = v; break;
+    }
+    case AK_F64: ((uint64_t*)j.values)[r] = ((uint64_t)w1 << 32) | w0; break;
+    case AK_TIME64: ((int64_t*)j.values)[r] = valid ? (int64_t)w0 * 1000000 + (int64_t)(w1 / 1000u) : 0; break;
+    case AK_TS: case AK_TSTZ: {
+      if (valid) w2 = ld32a(slot + 8);
+      const int64_t days = (int64_t)(int32_t)w0 - kCeDays1970;
+      ((int64_t*)j.values)[r] = valid ? (days * 86400 + (int64_t)w1) * 1000000 + (int64_t)(w2 / 1000u) : 0; break;
+    }
+    case AK_FIXED16: {
+      if (valid) { w2 = ld32a(slot + 8); w3 = ld32a(slot + 12); }
+      ((uint4*)j.values)[r] = make_uint4(w0, w1, w2, w3); break;
+    }
+    default: break;
+  }
+}
+
+// var-len columns, pass 1: validity / deferred words + the byte length of every row's entry
+__global__ __launch_bounds__(256) void k_col_lens(ColJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < j.n_rows;
+  uint32_t st = ETLG_CELL_NULL, len = 0;
+  if (live) {
+    const uint64_t b = j.row_base[r];
+    st = col_state(j, b);
+    // text-form columns hand over DEFERRED entries too (their heap entry is the source text)
+    const bool has = st == ETLG_CELL_VALUE || (j.kind == AK_TEXT_FORM && st == ETLG_CELL_DEFERRED);
+    if (has) len = ld32a(j.fixed + b + j.off_full + 4);
+    j.lens[r] = len;
+  }
+  const bool valid = live && (st == ETLG_CELL_VALUE || (j.kind == AK_TEXT_FORM && st == ETLG_CELL_DEFERRED));
+  const bool defer = live && st == ETLG_CELL_DEFERRED;
+  const unsigned long long vm = __ballot(valid), dm = __ballot(defer), lm = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && lm) {
+    j.validity[r >> 6] = vm; j.deferred[r >> 6] = dm;
+    const uint32_t nulls = (uint32_t)__builtin_popcountll(lm & ~vm), nd = (uint32_t)__builtin_popcountll(dm);
+    if (nulls) atomicAdd(j.null_count, (unsigned long long)nulls);
+    if (nd) atomicAdd(j.deferred_count, (unsigned long long)nd);
+  }
+}
+
+// lens (u32) -> offsets (i64), three steps like k_col_count / k_col_scan / k_col_rows
+__global__ __launch_bounds__(256) void k_col_len_blocks(const uint32_t* lens, uint64_t n, unsigned long long* blk) {
+  __shared__ uint64_t lds[4];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t t = block_sum64(i < n ? lens[i] : 0u, lds);
+  if (threadIdx.x == 0) blk[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void k_col_len_scan(unsigned long long* blk, uint32_t n) {
+  __shared__ uint64_t lds[4];
+  uint64_t run = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint64_t tot;
+    const uint64_t ex = block_scan_excl64(i < n ? blk[i] : 0ull, lds, &tot);
+    if (i < n) blk[i] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) blk[n] = run;
+}
+__global__ __launch_bounds__(256) void k_col_offsets(const uint32_t* lens, uint64_t n, const unsigned long long* blk, int64_t* offsets) {
+  __shared__ uint64_t lds[4];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t ex = block_scan_excl64(i < n ? lens[i] : 0u, lds, nullptr);
+  if (i < n) offsets[i] = (int64_t)(blk[blockIdx.x] + ex);
+  if (i == n - 1) offsets[n] = (int64_t)(blk[blockIdx.x] + ex + lens[i]);
+}
+
+// var-len columns, pass 2: one wave per 64 rows; the wave moves one row at a time, 4 bytes per lane per step where both ends
+// allow it (heap entries start 4-byte aligned; the destination is wherever the previous row ended)
+__global__ __launch_bounds__(256) void k_col_copy(ColJob j) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (r0 >= j.n_rows) return;
+  const uint64_t r = r0 + lane;
+  uint32_t len = 0, src = 0; int64_t dst = 0;
+  if (r < j.n_rows) { len = j.lens[r]; dst = j.offsets[r]; if (len) src = ld32a(j.fixed + j.row_base[r] + j.off_full); }
+  const uint32_t nrow = j.n_rows - r0 < 64 ? (uint32_t)(j.n_rows - r0) : 64u;
+  for (uint32_t k = 0; k < nrow; k++) {
+    const uint32_t l_u = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)k);
+    if (!l_u) continue;
+    const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)k);
+    const uint64_t d_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)dst >> 32), (int)k) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dst, (int)k);
+    const u8* sp = j.heap + s_u;
+    u8* dp = j.values + d_u;
+    for (uint32_t b = lane; b < l_u; b += 64) dp[b] = sp[b];
+  }
+}
+
+
+// ---- ClickHouse RowBinary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83 which wire type a Cell becomes,
+// :188-283 the byte format; core.rs:96-114 the trailing CDC columns). One thread per row, run twice: lengths, then bytes.
+enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3 };
+constexpr int32_t kDate32Min = -25567, kDate32Max = 120529;   // 1900-01-01 .. 2299-12-31 (encoding.rs:147-173)
+
+struct RbCount {
+  uint32_t n = 0;
+  DEV void put(u8) { n++; }
+  DEV void put32(uint32_t) { n += 4; }
+  DEV void put64(uint64_t) { n += 8; }
+  DEV void bytes(const u8*, uint32_t len) { n += len; }
+  DEV void hex(const u8*, uint32_t len) { n += 2 * len; }
+};
+struct RbWrite {
+  u8* p;
+  DEV void put(u8 b) { *p++ = b; }
+  DEV void put32(uint32_t v) { for (int k = 0; k < 4; k++) *p++ = (u8)(v >> (8 * k)); }
+  DEV void put64(uint64_t v) { for (int k = 0; k < 8; k++) *p++ = (u8)(v >> (8 * k)); }
+  DEV void bytes(const u8* s, uint32_t len) { for (uint32_t k = 0; k < len; k++) *p++ = s[k]; }
+  DEV void hex(const u8* s, uint32_t len) {   // bytes_to_hex, lowercase (:176-185)
+    for (uint32_t k = 0; k < len; k++) { const uint32_t b = s[k], h = b >> 4, l = b & 15; *p++ = (u8)(h < 10 ? '0' + h : 'a' + h - 10); *p++ = (u8)(l < 10 ? '0' + l : 'a' + l - 10); }
+  }
+};
+
+template <class S>
+DEV void rb_varint(S& s, uint32_t v) {   // LEB128 (:188-199)
+  while (v >= 0x80) { s.put((u8)(v | 0x80)); v >>= 7; }
+  s.put((u8)v);
+}
+
+template <class S>
+DEV void rb_2d(S& s, uint32_t v) { s.put((u8)('0' + v / 10)); s.put((u8)('0' + v % 10)); }
+
+template <class S>
+DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or column << 8 | code of the first cell that cannot be encoded
+  const uint64_t base = j.row_base[r];
+  for (uint32_t i = 0; i < j.n_cols; i++) {
+    const uint32_t cd = j.cols[i], cls = cd & 0xFF, off = cd >> 16;
+    const bool nullable = (cd >> 8) & 1;
+    const uint32_t st = (j.fixed[base + i / 4] >> (2 * (i % 4))) & 3u;
+    if (st == ETLG_CELL_NULL) {
+      if (!nullable) return (i << 8) | RB_E_NULL;   // "NULL value for non-nullable ClickHouse column" (:217-225)
+      s.put(1);
+      continue;
+    }
+    if (st != ETLG_CELL_VALUE) return (i << 8) | RB_E_HOST_CELL;
+    if (nullable) s.put(0);
+    const u8* slot = j.fixed + base + off;
+    const uint32_t w0 = ld32a(slot);
+    switch (cls) {
+      case ETLG_TC_BOOL: s.put(w0 ? 1 : 0); break;
+      case ETLG_TC_I16: s.put((u8)w0); s.put((u8)(w0 >> 8)); break;
+      case ETLG_TC_I32: case ETLG_TC_U32: case ETLG_TC_F32: s.put32(w0); break;
+      case ETLG_TC_I64: case ETLG_TC_F64: s.put64(((uint64_t)ld32a(slot + 4) << 32) | w0); break;
+      case ETLG_TC_DATE: {
+        const int32_t days = (int32_t)w0 - kCeDays1970;
+        if (days < kDate32Min || days > kDate32Max) return (i << 8) | RB_E_DATE_RANGE;
+        s.put32((uint32_t)days); break;
+      }
+      case ETLG_TC_TIME: {  // String(t.to_string()): chrono NaiveTime Display
+        const uint32_t secs = w0, nanos = ld32a(slot + 4);
+        const uint32_t frac = nanos == 0 ? 0u : nanos % 1000000u == 0 ? 4u : nanos % 1000u == 0 ? 7u : 10u;
+        rb_varint(s, 8 + frac);
+        rb_2d(s, secs / 3600); s.put(':'); rb_2d(s, secs / 60 % 60); s.put(':'); rb_2d(s, secs % 60);
+        if (frac) {
+          s.put('.');
+          uint32_t v = frac == 4 ? nanos / 1000000u : frac == 7 ? nanos / 1000u : nanos, div = frac == 4 ? 100u : frac == 7 ? 100000u : 100000000u;
+          for (; div; div /= 10) s.put((u8)('0' + v / div % 10));
+        }
+        break;
+      }
+      case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: {
+        const int64_t days = (int64_t)(int32_t)w0 - kCeDays1970;
+        s.put64((uint64_t)((days * 86400 + (int64_t)ld32a(slot + 4)) * 1000000 + (int64_t)(ld32a(slot + 8) / 1000u))); break;
+      }
+      case ETLG_TC_UUID:  // high u64 LE then low u64 LE of the big-endian 16 bytes (:240-247)
+        for (int h = 0; h < 2; h++) for (int k = 7; k >= 0; k--) s.put(slot[8 * h + k]);
+        break;
+      case ETLG_TC_STRING: { const uint32_t len = ld32a(slot + 4); rb_varint(s, len); s.bytes(j.heap + w0, len); break; }
+      case ETLG_TC_BYTEA: { const uint32_t len = ld32a(slot + 4); rb_varint(s, 2 * len); s.hex(j.heap + w0, len); break; }
+      default: return (i << 8) | RB_E_HOST_CELL;   // numeric / timetz / json / arrays: Display strings the host writes
+    }
+  }
+  // trailing CDC columns (core.rs:96-114); never NULL, a Nullable() destination column still takes its marker byte
+  const uint64_t ev = j.row_event[r];
+  const uint32_t kind = j.ev_kind[ev];
+  const uint64_t lsn = j.ev_commit[ev], ord = j.ev_ord[ev];
+  if (j.cdc_nullable & 1u) s.put(0);
+  if (j.engine == 0) {
+    s.put(6);
+    const char* op = kind == 'I' ? "INSERT" : kind == 'U' ? "UPDATE" : "DELETE";
+    for (int k = 0; k < 6; k++) s.put((u8)op[k]);
+    if (j.cdc_nullable & 2u) s.put(0);
+    s.put64(lsn);
+  } else {
+    s.put64(ord); s.put64(lsn);   // u128 = commit_lsn << 64 | tx_ordinal, little endian
+    if (j.cdc_nullable & 2u) s.put(0);
+    s.put(kind == 'D' ? 1 : 0);
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_rb_lens(RbJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= j.n_rows) return;
+  RbCount c;
+  const uint32_t e = rb_row(j, r, c);
+  if (e) { atomicMin(j.err, (unsigned long long)((r << 24) | e)); c.n = 0; }
+  j.lens[r] = c.n;
+}
+
+__global__ __launch_bounds__(256) void k_rb_rows(RbJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= j.n_rows || !j.lens[r]) return;
+  RbWrite w{j.out + j.offsets[r]};
+  (void)rb_row(j, r, w);
+}
+
+}  // namespace etlg
+
+extern "C" {
+
+using namespace etlg;
+
+void etlg_k_col_select(const void* selv, hipStream_t st) {
+  const ColSel s = *(const ColSel*)selv;
+  if (!s.nblocks) return;
+  hipLaunchKernelGGL(k_col_count, dim3(s.nblocks), dim3(256), 0, st, s);
+  hipLaunchKernelGGL(k_col_scan, dim3(1), dim3(256), 0, st, s.blk, s.nblocks);
+  hipLaunchKernelGGL(k_col_rows, dim3(s.nblocks), dim3(256), 0, st, s);
+}
+
+void etlg_k_col_fixed(const void* jv, hipStream_t st) {
+  const ColJob j = *(const ColJob*)jv;
+  if (j.n_rows) hipLaunchKernelGGL(k_col_fixed, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
+}
+
+// blk: (nblocks + 1) x u64 scratch
+void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st) {
+  const ColJob j = *(const ColJob*)jv;
+  if (!j.n_rows) return;
+  const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
+  if (step == 0) {
+    hipLaunchKernelGGL(k_col_lens, dim3(nb), dim3(256), 0, st, j);
+    hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, blk);
+    hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
+    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
+  } else {
+    hipLaunchKernelGGL(k_col_copy, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
+  }
+}
+
+// step 0: lengths + offsets (blk: (nblocks + 1) x u64 scratch); step 1: the bytes
+void etlg_k_rowbinary(const void* jv, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st) {
+  const RbJob j = *(const RbJob*)jv;
+  if (!j.n_rows) return;
+  const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
+  if (step == 0) {
+    hipLaunchKernelGGL(k_rb_lens, dim3(nb), dim3(256), 0, st, j);
+    hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, blk);
+    hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
+    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
+  } else {
+    hipLaunchKernelGGL(k_rb_rows, dim3(nb), dim3(256), 0, st, j);
+  }
+}
+
+}  // extern "C"

@@ -175,4 +175,37 @@ struct PlanParams {
                                // bit 5: phase clocks into DevResult.dbg_t
 };
 
+// ---- columnar hand-off (columns.hip)
+struct ColSel {            // which events are rows of the hand-off
+  const uint8_t* ev_kind; const uint8_t* ev_flags; const uint32_t* ev_slot; const uint64_t* ev_body;
+  uint64_t n_events;
+  uint32_t slot, kinds;    // kinds: bit 0 inserts, bit 1 new rows of non-partial updates, bit 2 full old rows of deletes
+  unsigned long long* host_rows;  // optional: I/U/D events of the slot the selection leaves out (partial updates, key-only deletes)
+  uint32_t row_full, row_key;
+  uint32_t* blk;           // per-block counts -> exclusive prefix; blk[nblocks] = total
+  uint32_t nblocks;
+  uint64_t* row_event; uint64_t* row_base;   // outputs of k_col_rows
+};
+
+struct ColJob {
+  const uint8_t* fixed; const uint8_t* heap; const uint64_t* row_base;
+  uint64_t n_rows;
+  uint32_t col_index, off_full, cls, kind;
+  unsigned long long* validity; unsigned long long* deferred; uint8_t* values;
+  unsigned long long* null_count; unsigned long long* deferred_count;
+  uint32_t* lens; const int64_t* offsets;   // var-len
+};
+
+struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
+  const uint8_t* fixed; const uint8_t* heap; const uint64_t* row_event; const uint64_t* row_base;
+  const uint8_t* ev_kind; const uint64_t* ev_commit; const uint64_t* ev_ord;
+  uint64_t n_rows;
+  uint32_t n_cols, engine;         // engine: 0 MergeTree, 1 ReplacingMergeTree
+  uint32_t cdc_nullable, _pad;     // bit 0 / 1: the first / second trailing CDC column is Nullable() in the destination
+  const uint32_t* cols;            // per replicated column: cls | nullable << 8 | off_full << 16
+  uint32_t* lens; const int64_t* offsets; uint8_t* out;
+  unsigned long long* err;         // min over failing cells of (row << 24 | column << 8 | code); ~0 = none
+};
+
+
 }  // namespace etlg

@@ -44,6 +44,10 @@ extern "C" void etlg_k_launch_copy(const uint8_t* rows, const uint32_t* row_offs
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_plan_set_lds(void);
+extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
+extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
+extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
+extern "C" void etlg_k_col_var(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_maxc(void);
@@ -250,6 +254,7 @@ struct etlg_ctx {
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
   bool last_any_sync_done = false;
   bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
+  DevBuf d_colsel;                   // etlg_batch_columns: block counts of the row selection
   std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order
   std::vector<hipEvent_t> ev_pool;   // "result block copied back" events of finished batches
   std::vector<int32_t> last_live;      // slots whose columns d_cols currently holds
@@ -305,6 +310,17 @@ struct etlg_batch {
   std::vector<std::vector<uint8_t>> ctrl_raw;  // their bytes, same order (the input may be device-resident or come without a sidecar)
   ControlState snapshot;           // control state before the batch
   bool have_snapshot = false;
+};
+
+struct etlg_columns {  // etlg_batch_columns: the buffers live in two device blocks (+ one host block when downloaded)
+  etlg_columns_view v{};
+  std::vector<etlg_column> cols;
+  void* d_a = nullptr; void* d_b = nullptr; uint8_t* h = nullptr;
+};
+
+struct etlg_rowbinary {
+  etlg_rowbinary_view v{};
+  void* d_a = nullptr; void* d_b = nullptr; uint8_t* h = nullptr;
 };
 
 namespace {
@@ -886,7 +902,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.erase(c); }
   (void)hipStreamSynchronize(c->stream);
   if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
-  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols}) b->release();
+  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols, &c->d_colsel}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1334,6 +1350,282 @@ void etlg_batch_free(etlg_batch* b) {
     if (b->h_arena) (void)hipHostFree(b->h_arena);
   }
   delete b;
+}
+
+// ---- columnar hand-off (columns.hip)
+namespace {
+struct ColPlan { uint32_t kind, vbytes; bool var; };
+ColPlan col_plan(uint32_t cls) {
+  switch (cls) {
+    case ETLG_TC_BOOL: return {ETLG_AK_BOOLEAN, 0, false};
+    case ETLG_TC_I16: case ETLG_TC_I32: return {ETLG_AK_INT32, 4, false};
+    case ETLG_TC_I64: case ETLG_TC_U32: return {ETLG_AK_INT64, 8, false};
+    case ETLG_TC_F32: return {ETLG_AK_FLOAT32, 4, false};
+    case ETLG_TC_F64: return {ETLG_AK_FLOAT64, 8, false};
+    case ETLG_TC_DATE: return {ETLG_AK_DATE32, 4, false};
+    case ETLG_TC_TIME: return {ETLG_AK_TIME64_US, 8, false};
+    case ETLG_TC_TIMESTAMP: return {ETLG_AK_TIMESTAMP_US, 8, false};
+    case ETLG_TC_TIMESTAMPTZ: return {ETLG_AK_TIMESTAMP_US_UTC, 8, false};
+    case ETLG_TC_UUID: return {ETLG_AK_FIXED16, 16, false};
+    case ETLG_TC_STRING: return {ETLG_AK_LARGE_UTF8, 0, true};
+    case ETLG_TC_BYTEA: return {ETLG_AK_LARGE_BINARY, 0, true};
+    case ETLG_TC_TIMETZ: return {ETLG_AK_NONE, 0, false};
+    default: return {ETLG_AK_TEXT_FORM, 0, true};
+  }
+}
+}  // namespace
+
+int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t row_kinds, uint32_t flags, etlg_columns** out) {
+  if (!c || !b || !out || b->ctx != c) return ETLG_InvalidArgument;
+  *out = nullptr;
+  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
+  if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_columns needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
+  if (slot < 0 || (size_t)slot >= c->slots.size() || !(row_kinds & 3u)) return ETLG_InvalidArgument;
+  const SlotHost& sh = *c->slots[(size_t)slot];
+  hipStream_t s = c->stream;
+  const etlg_batch_view& bv = b->v;
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  std::unique_ptr<etlg_columns, void (*)(etlg_columns*)> cs(new etlg_columns, etlg_columns_free);
+  const uint64_t ne = bv.n_events;
+  const uint32_t nblk = (uint32_t)((ne + 255) / 256);
+  // ---- 1. which events are rows (count -> scan -> scatter); row_event / row_base are sized for every event
+  HIPCHK(c, c->d_colsel.ensure(al((size_t)(nblk + 1) * 4) + 64));
+  uint32_t* d_blk = (uint32_t*)c->d_colsel.p;
+  void* d_rows = nullptr;
+  if (ne) HIPCHK(c, hipMalloc(&d_rows, al(ne * 8) * 2));
+  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } free_rows{d_rows};
+  uint64_t* d_row_event = (uint64_t*)d_rows;
+  uint64_t* d_row_base = (uint64_t*)((uint8_t*)d_rows + al(ne * 8));
+  uint32_t n_rows32 = 0;
+  if (ne) {
+    ColSel q{};
+    q.ev_kind = bv.ev_kind; q.ev_flags = bv.ev_flags; q.ev_slot = bv.ev_schema_slot; q.ev_body = bv.ev_body_off;
+    q.n_events = ne; q.slot = (uint32_t)slot; q.kinds = row_kinds & 3u;
+    q.row_full = sh.desc.row_bytes_full; q.row_key = sh.desc.row_bytes_key;
+    q.blk = d_blk; q.nblocks = nblk; q.row_event = d_row_event; q.row_base = d_row_base;
+    etlg_k_col_select(&q, s);
+    HIPCHK(c, hipMemcpyAsync(&n_rows32, d_blk + nblk, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  const uint64_t n = n_rows32;
+  // ---- 2. block A: row_event | per column {validity, deferred, values or (lens, offsets)} | counters
+  const uint32_t nc = sh.desc.n_cols;
+  const size_t bm = al(((size_t)n + 63) / 64 * 8);
+  struct Lay { ColPlan pl; size_t validity, deferred, values, lens, offsets; };
+  std::vector<Lay> lay(nc);
+  size_t off = al(n * 8);
+  for (uint32_t i = 0; i < nc; i++) {
+    Lay& l = lay[i];
+    l.pl = col_plan(sh.cols[i].type_class);
+    l.validity = l.deferred = l.values = l.lens = l.offsets = 0;
+    if (l.pl.kind == ETLG_AK_NONE) continue;
+    l.validity = off; off += bm; l.deferred = off; off += bm;
+    if (l.pl.var) { l.offsets = off; off += al((n + 1) * 8); l.lens = off; off += al(n * 4); }
+    else { l.values = off; off += l.pl.kind == ETLG_AK_BOOLEAN ? bm : al(n * l.pl.vbytes); }
+  }
+  const size_t o_cnt = off; off += al((size_t)nc * 16);
+  const uint32_t nrb = (uint32_t)((n + 255) / 256);
+  const size_t o_scan = off; off += al((size_t)(nrb + 1) * 8);   // one scan scratch: var-len columns run one after another on the stream
+  const size_t a_bytes = off + 64;
+  HIPCHK(c, hipMalloc(&cs->d_a, a_bytes));
+  uint8_t* A = (uint8_t*)cs->d_a;
+  HIPCHK(c, hipMemsetAsync(A + o_cnt, 0, (size_t)nc * 16, s));
+  if (n) HIPCHK(c, hipMemcpyAsync(A, d_row_event, n * 8, hipMemcpyDeviceToDevice, s));
+  std::vector<ColJob> jobs(nc);
+  std::vector<int64_t> var_total(nc, 0);
+  for (uint32_t i = 0; i < nc; i++) {
+    const Lay& l = lay[i];
+    if (l.pl.kind == ETLG_AK_NONE) continue;
+    ColJob& j = jobs[i];
+    j = ColJob{};
+    j.fixed = bv.fixed; j.heap = bv.heap; j.row_base = d_row_base; j.n_rows = n;
+    j.col_index = i; j.off_full = sh.cols[i].off_full; j.cls = sh.cols[i].type_class; j.kind = l.pl.kind;
+    j.validity = (unsigned long long*)(A + l.validity); j.deferred = (unsigned long long*)(A + l.deferred);
+    j.null_count = (unsigned long long*)(A + o_cnt + (size_t)i * 16); j.deferred_count = j.null_count + 1;
+    if (l.pl.var) {
+      j.lens = (uint32_t*)(A + l.lens); j.offsets = (const int64_t*)(A + l.offsets);
+      if (n) {
+        etlg_k_col_var(&j, (unsigned long long*)(A + o_scan), (int64_t*)(A + l.offsets), 0, s);
+        HIPCHK(c, hipMemcpyAsync(&var_total[i], A + l.offsets + n * 8, 8, hipMemcpyDeviceToHost, s));
+      } else {
+        HIPCHK(c, hipMemsetAsync(A + l.offsets, 0, 8, s));
+      }
+    } else {
+      j.values = A + l.values;
+      etlg_k_col_fixed(&j, s);
+    }
+  }
+  std::vector<uint64_t> cnt((size_t)nc * 2, 0);
+  if (nc) HIPCHK(c, hipMemcpyAsync(cnt.data(), A + o_cnt, (size_t)nc * 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  // ---- 3. block B: the bytes of the var-len columns
+  std::vector<size_t> vb(nc, 0);
+  size_t b_bytes = 0;
+  for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.var) { vb[i] = b_bytes; b_bytes += al((size_t)var_total[i]); }
+  if (b_bytes) HIPCHK(c, hipMalloc(&cs->d_b, b_bytes + 64));
+  uint8_t* B = (uint8_t*)cs->d_b;
+  for (uint32_t i = 0; i < nc; i++)
+    if (lay[i].pl.var && var_total[i] > 0) { jobs[i].values = B + vb[i]; etlg_k_col_var(&jobs[i], nullptr, nullptr, 1, s); }
+  // ---- 4. the view (device pointers, or a host copy of both blocks)
+  const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
+  const uint8_t* base_a = A; const uint8_t* base_b = B;
+  if (!on_dev) {
+    HIPCHK(c, hipHostMalloc((void**)&cs->h, al(o_cnt) + b_bytes + 64, hipHostMallocDefault));
+    if (o_cnt) HIPCHK(c, hipMemcpyAsync(cs->h, A, o_cnt, hipMemcpyDeviceToHost, s));
+    if (b_bytes) HIPCHK(c, hipMemcpyAsync(cs->h + al(o_cnt), B, b_bytes, hipMemcpyDeviceToHost, s));
+    base_a = cs->h; base_b = cs->h + al(o_cnt);
+  }
+  HIPCHK(c, hipStreamSynchronize(s));   // row_base (freed on return) is read by the kernels above
+  if (!on_dev) { (void)hipFree(cs->d_a); cs->d_a = nullptr; if (cs->d_b) (void)hipFree(cs->d_b); cs->d_b = nullptr; }
+  cs->cols.resize(nc);
+  for (uint32_t i = 0; i < nc; i++) {
+    etlg_column& k = cs->cols[i];
+    const Lay& l = lay[i];
+    k = etlg_column{};
+    k.type_class = sh.cols[i].type_class; k.arrow_kind = l.pl.kind; k.value_bytes = l.pl.vbytes; k.nullable = sh.cols[i].nullable;
+    if (l.pl.kind == ETLG_AK_NONE) continue;
+    k.null_count = cnt[(size_t)i * 2]; k.deferred_count = cnt[(size_t)i * 2 + 1];
+    k.validity = base_a + l.validity; k.deferred = base_a + l.deferred;
+    if (l.pl.var) { k.offsets = (const int64_t*)(base_a + l.offsets); k.values = base_b ? base_b + vb[i] : nullptr; k.values_bytes = (uint64_t)var_total[i]; }
+    else { k.values = base_a + l.values; k.values_bytes = l.pl.kind == ETLG_AK_BOOLEAN ? ((n + 63) / 64) * 8 : n * l.pl.vbytes; }
+  }
+  cs->v.n_rows = n; cs->v.n_cols = nc; cs->v.on_device = on_dev ? 1u : 0u; cs->v.cols = cs->cols.data();
+  cs->v.row_event = (const uint64_t*)base_a;
+  *out = cs.release();
+  return ETLG_OK;
+}
+
+int32_t etlg_columns_view_get(const etlg_columns* cs, etlg_columns_view* out) {
+  if (!cs || !out) return ETLG_InvalidArgument;
+  *out = cs->v;
+  return ETLG_OK;
+}
+
+void etlg_columns_free(etlg_columns* cs) {
+  if (!cs) return;
+  if (cs->d_a) (void)hipFree(cs->d_a);
+  if (cs->d_b) (void)hipFree(cs->d_b);
+  if (cs->h) (void)hipHostFree(cs->h);
+  delete cs;
+}
+
+int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint8_t* nullable_flags, uint32_t n_flags, int32_t engine,
+                             uint32_t flags, etlg_rowbinary** out) {
+  if (!c || !b || !out || b->ctx != c || !nullable_flags) return ETLG_InvalidArgument;
+  *out = nullptr;
+  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
+  if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_rowbinary needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
+  if (slot < 0 || (size_t)slot >= c->slots.size() || (engine != ETLG_CH_MERGE_TREE && engine != ETLG_CH_REPLACING_MERGE_TREE)) return ETLG_InvalidArgument;
+  const SlotHost& sh = *c->slots[(size_t)slot];
+  const uint32_t nc = sh.desc.n_cols;
+  if (n_flags != nc + 2) return lib_error(c, ETLG_ConversionError, "ClickHouse RowBinary row width mismatch");
+  std::unique_ptr<etlg_rowbinary, void (*)(etlg_rowbinary*)> rb(new etlg_rowbinary, etlg_rowbinary_free);
+  const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
+  rb->v.on_device = on_dev ? 1u : 0u; rb->v.host_event = ~0ull;
+  std::vector<uint32_t> cols(nc);
+  for (uint32_t i = 0; i < nc; i++) {
+    const uint32_t cls = sh.cols[i].type_class;
+    if (col_plan(cls).kind == ETLG_AK_TEXT_FORM || cls == ETLG_TC_TIMETZ) {  // a Display string in the reference: the host writes it
+      rb->v.status = ETLG_RB_NEEDS_HOST; rb->v.host_column = i;
+      *out = rb.release();
+      return ETLG_OK;
+    }
+    cols[i] = cls | (nullable_flags[i] ? 1u << 8 : 0u) | ((uint32_t)sh.cols[i].off_full << 16);
+  }
+  hipStream_t s = c->stream;
+  const etlg_batch_view& bv = b->v;
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const uint64_t ne = bv.n_events;
+  const uint32_t nblk = (uint32_t)((ne + 255) / 256);
+  // block S (freed on return): block counts | host-row counter | error word | column words | row_base
+  const size_t o_cnt = al((size_t)(nblk + 1) * 4), o_cols = o_cnt + 64, o_base = o_cols + al((size_t)nc * 4 + 4), s_bytes = o_base + al(ne * 8) + 64;
+  void* d_s = nullptr;
+  HIPCHK(c, hipMalloc(&d_s, s_bytes));
+  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } free_s{d_s};
+  uint8_t* S = (uint8_t*)d_s;
+  const unsigned long long init[2] = {0ull, ~0ull};
+  HIPCHK(c, hipMemcpyAsync(S + o_cnt, init, 16, hipMemcpyHostToDevice, s));
+  if (nc) HIPCHK(c, hipMemcpyAsync(S + o_cols, cols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s));
+  // block A: row_event | row_offsets | lens | scan scratch (sized for every event being a row)
+  const size_t o_off = al(ne * 8), o_len = o_off + al((ne + 1) * 8), o_scan = o_len + al(ne * 4), a_bytes = o_scan + al((size_t)(nblk + 1) * 8) + 64;
+  HIPCHK(c, hipMalloc(&rb->d_a, a_bytes));
+  uint8_t* A = (uint8_t*)rb->d_a;
+  uint32_t n32 = 0;
+  unsigned long long cnt[2] = {0, ~0ull};
+  if (ne) {
+    ColSel q{};
+    q.ev_kind = bv.ev_kind; q.ev_flags = bv.ev_flags; q.ev_slot = bv.ev_schema_slot; q.ev_body = bv.ev_body_off;
+    q.n_events = ne; q.slot = (uint32_t)slot; q.kinds = 7u; q.host_rows = (unsigned long long*)(S + o_cnt);
+    q.row_full = sh.desc.row_bytes_full; q.row_key = sh.desc.row_bytes_key;
+    q.blk = (uint32_t*)S; q.nblocks = nblk; q.row_event = (uint64_t*)A; q.row_base = (uint64_t*)(S + o_base);
+    etlg_k_col_select(&q, s);
+    HIPCHK(c, hipMemcpyAsync(&n32, S + (size_t)nblk * 4, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  const uint64_t n = n32;
+  RbJob j{};
+  j.fixed = bv.fixed; j.heap = bv.heap; j.row_event = (const uint64_t*)A; j.row_base = (const uint64_t*)(S + o_base);
+  j.ev_kind = bv.ev_kind; j.ev_commit = bv.ev_commit_lsn; j.ev_ord = bv.ev_tx_ordinal;
+  j.n_rows = n; j.n_cols = nc; j.engine = (uint32_t)engine;
+  j.cdc_nullable = (nullable_flags[nc] ? 1u : 0u) | (nullable_flags[nc + 1] ? 2u : 0u);
+  j.cols = (const uint32_t*)(S + o_cols); j.lens = (uint32_t*)(A + o_len); j.offsets = (const int64_t*)(A + o_off);
+  j.err = (unsigned long long*)(S + o_cnt) + 1;
+  int64_t total = 0;
+  if (n) {
+    etlg_k_rowbinary(&j, (unsigned long long*)(A + o_scan), (int64_t*)(A + o_off), 0, s);
+    HIPCHK(c, hipMemcpyAsync(&total, A + o_off + n * 8, 8, hipMemcpyDeviceToHost, s));
+  } else {
+    HIPCHK(c, hipMemsetAsync(A + o_off, 0, 8, s));
+  }
+  HIPCHK(c, hipMemcpyAsync(cnt, S + o_cnt, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  rb->v.n_host_rows = cnt[0];
+  if (cnt[1] != ~0ull) {  // the first row (event order) with a cell that has no encoding
+    const uint32_t code = (uint32_t)(cnt[1] & 0xFF), col = (uint32_t)((cnt[1] >> 8) & 0xFFFF);
+    uint64_t ev = 0;
+    HIPCHK(c, hipMemcpy(&ev, A + (cnt[1] >> 24) * 8, 8, hipMemcpyDeviceToHost));
+    if (code == 3) {
+      rb->v.status = ETLG_RB_NEEDS_HOST; rb->v.host_event = ev; rb->v.host_column = col;
+      (void)hipFree(rb->d_a); rb->d_a = nullptr;
+      *out = rb.release();
+      return ETLG_OK;
+    }
+    const int32_t k = lib_error(c, ETLG_ConversionError, code == 1 ? "NULL value for non-nullable ClickHouse column" : "Date out of ClickHouse Date32 range");
+    c->err.frame_index = (int64_t)ev;
+    return k;
+  }
+  if (total) {
+    HIPCHK(c, hipMalloc(&rb->d_b, (size_t)total + 64));
+    j.out = (uint8_t*)rb->d_b;
+    etlg_k_rowbinary(&j, nullptr, nullptr, 1, s);
+  }
+  const uint8_t* base_a = A; const uint8_t* base_b = (const uint8_t*)rb->d_b;
+  if (!on_dev) {
+    HIPCHK(c, hipHostMalloc((void**)&rb->h, o_len + al((size_t)total) + 64, hipHostMallocDefault));
+    HIPCHK(c, hipMemcpyAsync(rb->h, A, o_off + (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (total) HIPCHK(c, hipMemcpyAsync(rb->h + o_len, rb->d_b, (size_t)total, hipMemcpyDeviceToHost, s));
+    base_a = rb->h; base_b = rb->h + o_len;
+  }
+  HIPCHK(c, hipStreamSynchronize(s));   // block S is freed on return
+  if (!on_dev) { (void)hipFree(rb->d_a); rb->d_a = nullptr; if (rb->d_b) (void)hipFree(rb->d_b); rb->d_b = nullptr; }
+  rb->v.n_rows = n; rb->v.n_bytes = (uint64_t)total;
+  rb->v.row_event = (const uint64_t*)base_a; rb->v.row_offsets = (const int64_t*)(base_a + o_off); rb->v.bytes = total ? base_b : nullptr;
+  *out = rb.release();
+  return ETLG_OK;
+}
+
+int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out) {
+  if (!rb || !out) return ETLG_InvalidArgument;
+  *out = rb->v;
+  return ETLG_OK;
+}
+
+void etlg_rowbinary_free(etlg_rowbinary* rb) {
+  if (!rb) return;
+  if (rb->d_a) (void)hipFree(rb->d_a);
+  if (rb->d_b) (void)hipFree(rb->d_b);
+  if (rb->h) (void)hipHostFree(rb->h);
+  delete rb;
 }
 
 }  // extern "C"

@@ -60,9 +60,113 @@ class Batch:
             v = self.view()
         return HostBatch.from_view(v)
 
+    def columns(self, slot, kinds=("I",), on_device=False):
+        """Arrow-layout column buffers of the rows decoded against schema slot `slot`, built on the device
+        (etlg_batch_columns). The batch must still be device-resident."""
+        rk = (abi.ROWS_INSERT if "I" in kinds else 0) | (abi.ROWS_UPDATE if "U" in kinds else 0)
+        out = C.c_void_p()
+        rc = self.dec.L.etlg_batch_columns(self.dec.h, self.h, slot, rk, abi.F_OUTPUT_ON_DEVICE if on_device else 0, C.byref(out))
+        if rc != abi.OK or not out:
+            raise self.dec.last_error()
+        return Columns(self.dec, out)
+
+    def rowbinary(self, slot, nullable_flags, engine=abi.CH_MERGE_TREE, on_device=False):
+        """ClickHouse RowBinary rows of schema slot `slot`, encoded on the device (etlg_batch_rowbinary). Raises EtlError for
+        the reference's ConversionErrors; `RowBinary.status == abi.RB_NEEDS_HOST` when a cell has no device encoding."""
+        nf = np.ascontiguousarray(nullable_flags, dtype=np.uint8)
+        out = C.c_void_p()
+        rc = self.dec.L.etlg_batch_rowbinary(self.dec.h, self.h, slot, nf.ctypes.data, len(nf), engine,
+                                             abi.F_OUTPUT_ON_DEVICE if on_device else 0, C.byref(out))
+        if rc != abi.OK or not out:
+            raise self.dec.last_error()
+        return RowBinary(self.dec, out)
+
     def close(self):
         if self.h:
             self.dec.L.etlg_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Columns:
+    """etlg_columns: `view` = etlg_columns_view; `host_arrays()` wraps host-resident buffers as numpy arrays."""
+
+    def __init__(self, dec, handle):
+        self.dec, self.h = dec, handle
+        self.view = abi.ColumnsView()
+        dec.L.etlg_columns_view_get(handle, C.byref(self.view))
+
+    @property
+    def n_rows(self):
+        return int(self.view.n_rows)
+
+    def column(self, i):
+        return self.view.cols[i]
+
+    def _np(self, ptr, nbytes, dtype):
+        if not nbytes:
+            return np.zeros(0, dtype=dtype)
+        assert not self.view.on_device, "device-resident buffers: read them through abi.device_tensor"
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dtype)
+
+    def host_arrays(self, i):
+        """(validity bits u8[], deferred bits u8[], values u8[], offsets i64[] | None) of column i (views into the block)."""
+        k, n = self.view.cols[i], self.n_rows
+        if k.arrow_kind == abi.AK_NONE:
+            return None
+        bm = (n + 63) // 64 * 8
+        offs = self._np(k.offsets, (n + 1) * 8, np.int64) if k.offsets else None
+        return self._np(k.validity, bm, np.uint8), self._np(k.deferred, bm, np.uint8), self._np(k.values, int(k.values_bytes), np.uint8), offs
+
+    def row_event(self):
+        return self._np(self.view.row_event, self.n_rows * 8, np.uint64)
+
+    def close(self):
+        if self.h:
+            self.dec.L.etlg_columns_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RowBinary:
+    """etlg_rowbinary: `view` = etlg_rowbinary_view; the accessors below wrap host-resident buffers."""
+
+    def __init__(self, dec, handle):
+        self.dec, self.h = dec, handle
+        self.view = abi.RowBinaryView()
+        dec.L.etlg_rowbinary_view_get(handle, C.byref(self.view))
+
+    status = property(lambda self: int(self.view.status))
+    n_rows = property(lambda self: int(self.view.n_rows))
+
+    def _np(self, ptr, nbytes, dtype):
+        if not nbytes or not ptr:
+            return np.zeros(0, dtype=dtype)
+        assert not self.view.on_device
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dtype)
+
+    def bytes(self):
+        return self._np(self.view.bytes, int(self.view.n_bytes), np.uint8)
+
+    def row_offsets(self):
+        return self._np(self.view.row_offsets, (self.n_rows + 1) * 8, np.int64)
+
+    def row_event(self):
+        return self._np(self.view.row_event, self.n_rows * 8, np.uint64)
+
+    def close(self):
+        if self.h:
+            self.dec.L.etlg_rowbinary_free(self.h)
             self.h = None
 
     def __del__(self):

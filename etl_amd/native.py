@@ -20,6 +20,8 @@ EXPORTS = [
     "etlg_batch_view_get", "etlg_batch_sync", "etlg_batch_download", "etlg_batch_header_to_device", "etlg_batch_free", "etlg_ctx_slots", "etlg_ctx_profile",
     "etlg_ctx_profile_read", "etlg_scan_boundaries", "etlg_copy_decode", "etlg_frame_tags",
     "etlg_table_forget", "etlg_table_cache_get",
+    "etlg_batch_columns", "etlg_columns_view_get", "etlg_columns_free",
+    "etlg_batch_rowbinary", "etlg_rowbinary_view_get", "etlg_rowbinary_free",
 ]
 
 _LIB = None
@@ -88,6 +90,14 @@ def lib():
     L.etlg_frame_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
     L.etlg_frame_tags.restype = C.c_int32
     L.etlg_table_forget.argtypes = [C.c_void_p, C.c_uint32]
+    L.etlg_batch_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.etlg_columns_view_get.argtypes = [C.c_void_p, C.c_void_p]
+    L.etlg_columns_free.argtypes = [C.c_void_p]
+    L.etlg_columns_free.restype = None
+    L.etlg_batch_rowbinary.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.etlg_rowbinary_view_get.argtypes = [C.c_void_p, C.c_void_p]
+    L.etlg_rowbinary_free.argtypes = [C.c_void_p]
+    L.etlg_rowbinary_free.restype = None
     L.etlg_table_cache_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     if L.etlg_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("libetl_gfx950.so ABI version mismatch")

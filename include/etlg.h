@@ -470,6 +470,108 @@ int32_t etlg_batch_header_to_device(etlg_ctx* ctx, etlg_batch* batch, void* dst_
 int32_t etlg_batch_download(etlg_ctx* ctx, etlg_batch* batch);
 void etlg_batch_free(etlg_batch* batch);
 
+/* ------------------------------------------------------ columnar hand-off */
+
+/* Arrow-layout column buffers for the rows of ONE schema slot of a decoded batch,
+ * built on the device from the arena (no Cell objects, no per-row host work).
+ * Replaces rows_to_record_batch / build_array_for_field and the cell_to_*
+ * converters of the reference's Arrow sinks
+ * (crates/etl-destinations/src/iceberg/encoding.rs:34-84, :150-360). */
+typedef enum etlg_arrow_kind {
+  ETLG_AK_BOOLEAN = 0,      /* values bit-packed, LSB first */
+  ETLG_AK_INT32 = 1,        /* I16, I32 (cell_to_i32, encoding.rs:157) */
+  ETLG_AK_INT64 = 2,        /* I64, U32 (cell_to_i64, encoding.rs:164) */
+  ETLG_AK_FLOAT32 = 3,
+  ETLG_AK_FLOAT64 = 4,
+  ETLG_AK_DATE32 = 5,       /* days since 1970-01-01 (encoding.rs:194) */
+  ETLG_AK_TIME64_US = 6,    /* encoding.rs:201 */
+  ETLG_AK_TIMESTAMP_US = 7, /* encoding.rs:208 */
+  ETLG_AK_TIMESTAMP_US_UTC = 8, /* encoding.rs:215 */
+  ETLG_AK_FIXED16 = 9,      /* uuid: FixedSizeBinary(16) */
+  ETLG_AK_LARGE_UTF8 = 10,  /* i64 offsets + bytes */
+  ETLG_AK_LARGE_BINARY = 11,
+  ETLG_AK_TEXT_FORM = 12,   /* numeric / json / arrays: the cell's heap entry (etlg_numeric_hdr + digits, or
+                             * the source text), i64 offsets + bytes; the host finishes it */
+  ETLG_AK_NONE = 255        /* not handed off (timetz: a display string in the reference) - no buffers */
+} etlg_arrow_kind;
+
+typedef struct etlg_column {
+  uint32_t type_class;      /* etlg_type_class of the replicated column */
+  uint32_t arrow_kind;      /* etlg_arrow_kind */
+  uint32_t value_bytes;     /* bytes per row in `values` (0: bit-packed or var-len) */
+  uint32_t nullable;
+  uint64_t null_count;      /* rows whose validity bit is 0 */
+  uint64_t deferred_count;  /* rows set in `deferred` */
+  const uint8_t* validity;  /* n_rows bits, LSB first, padded to 8 bytes */
+  const uint8_t* deferred;  /* same shape: cells the kernels handed back ETLG_CELL_DEFERRED. In a fixed-width
+                             * column they are null in `validity`; in a TEXT_FORM column their entry is the source text */
+  const uint8_t* values;
+  const int64_t* offsets;   /* var-len kinds: n_rows + 1 entries, else NULL */
+  uint64_t values_bytes;    /* bytes behind `values` */
+} etlg_column;
+
+typedef struct etlg_columns_view {
+  uint64_t n_rows;
+  uint32_t n_cols;          /* replicated columns of the slot, slot order */
+  uint32_t on_device;       /* 1: buffer pointers are device pointers */
+  const etlg_column* cols;  /* host memory */
+  const uint64_t* row_event; /* n_rows: index of the event each row came from (event order) */
+} etlg_columns_view;
+
+typedef struct etlg_columns etlg_columns;
+
+#define ETLG_ROWS_INSERT 1u  /* Insert rows */
+#define ETLG_ROWS_UPDATE 2u  /* the new row of non-partial Updates */
+
+/* `batch` must be device-resident (decoded with ETLG_F_OUTPUT_ON_DEVICE, not downloaded) and finished
+ * (an ETLG_F_ASYNC batch is synced first). flags: ETLG_F_OUTPUT_ON_DEVICE keeps the buffers in HBM, otherwise
+ * they are copied to host memory. An unchanged-toast cell cannot occur (partial rows are not selected). */
+int32_t etlg_batch_columns(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t row_kinds,
+                           uint32_t flags, etlg_columns** out);
+int32_t etlg_columns_view_get(const etlg_columns* cols, etlg_columns_view* out);
+void etlg_columns_free(etlg_columns* cols);
+
+/* ClickHouse RowBinary rows for ONE schema slot of a decoded batch, encoded on the device: what
+ * cell_to_clickhouse_value + encode_to_row_binary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83,
+ * :188-283) and append_cdc_columns (clickhouse/core.rs:96-114) produce for the rows core.rs:1078-1127 collects:
+ * Insert -> the row; Update -> the new row; Delete -> the old row. Rows the reference builds with extra host
+ * logic (a Partial update, a Delete that carries only the key) are left out and counted in n_host_rows.
+ * Columns of class numeric / timetz / json / array / interval are Display strings in the reference; a slot that
+ * has one, or a DEFERRED cell in a row, makes the call return status ETLG_RB_NEEDS_HOST (no bytes). */
+typedef enum etlg_ch_engine {
+  ETLG_CH_MERGE_TREE = 0,           /* + cdc_operation String, cdc_lsn UInt64 */
+  ETLG_CH_REPLACING_MERGE_TREE = 1  /* + _etl_version UInt128 (commit_lsn << 64 | tx_ordinal), _etl_deleted UInt8 */
+} etlg_ch_engine;
+
+#define ETLG_RB_OK 0u
+#define ETLG_RB_NEEDS_HOST 3u
+
+typedef struct etlg_rowbinary_view {
+  uint64_t n_rows;
+  uint64_t n_bytes;
+  uint64_t n_host_rows;       /* Insert/Update/Delete events of the slot that are not among the rows */
+  uint32_t status;            /* ETLG_RB_OK | ETLG_RB_NEEDS_HOST */
+  uint32_t on_device;
+  uint64_t host_event;        /* NEEDS_HOST: the first event (and column) the device cannot encode; ~0 = the slot's classes */
+  uint32_t host_column;
+  uint32_t _pad;
+  const uint8_t* bytes;       /* rows back to back, event order */
+  const int64_t* row_offsets; /* n_rows + 1 (the client cuts inserts at max_bytes_per_insert, client.rs:566-600) */
+  const uint64_t* row_event;  /* n_rows */
+} etlg_rowbinary_view;
+
+typedef struct etlg_rowbinary etlg_rowbinary;
+
+/* nullable_flags: one byte per destination column = the slot's replicated columns, then the engine's two CDC
+ * columns (nullable_flags_from_clickhouse_columns, clickhouse/core.rs:162-209); n_flags must be n_cols + 2
+ * ("ClickHouse RowBinary row width mismatch", encoding.rs:263-274, otherwise). A NULL in a non-nullable column and a
+ * date outside 1900-01-01..=2299-12-31 fail the call with ETLG_ConversionError like the reference (etlg_last_error:
+ * the description, frame_index = the event index). Same batch requirements as etlg_batch_columns. */
+int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, const uint8_t* nullable_flags,
+                             uint32_t n_flags, int32_t engine, uint32_t flags, etlg_rowbinary** out);
+int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out);
+void etlg_rowbinary_free(etlg_rowbinary* rb);
+
 /* Schema slots known to the context (also reachable from every batch view). */
 int32_t etlg_ctx_slots(const etlg_ctx* ctx, uint32_t* n_slots,
                        const etlg_slot_desc** slots);

@@ -1,0 +1,168 @@
+"""Device-side columnar hand-off (etlg_batch_columns, etl_amd/csrc/columns.hip) against the host hand-off of the oracle's
+arena (etl_amd.arrow.rows_to_record_batch — itself pinned to the reference's Cell -> Arrow mapping,
+crates/etl-destinations/src/iceberg/encoding.rs:61-360, by tests/test_arrow_handoff.py): same rows, same order, same
+values, validity and types, for every class; plus the raw buffers (offsets, bit-packed validity, row_event)."""
+import os
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from etl_amd import abi, synth
+from etl_amd.arrow import columns_to_record_batch, rows_to_record_batch
+from tests import pgwire as W
+from tests import scenarios as SC
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(prime, buf, offs):
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o)
+    prime(d)
+    rb = o.decode(buf, offs)
+    assert rb.err_code == 0, rb.err_desc
+    b = d.decode(buf, offs, flags=abi.F_OUTPUT_ON_DEVICE)
+    assert b.rc == 0, b.error
+    return rb.host_batch(), b, d
+
+
+def _same(want, got):
+    assert want.num_rows == got.num_rows and want.schema.names == got.schema.names
+    for name in want.schema.names:
+        a, g = want.column(name), got.column(name)
+        if pa.types.is_string(a.type):
+            a = a.cast(pa.large_utf8())
+        assert a.type == g.type, (name, a.type, g.type)
+        assert want.schema.field(name).nullable == got.schema.field(name).nullable, name
+        assert a.null_count == g.null_count, name
+        assert a.equals(g), name
+
+
+def _stream(msgs):
+    s = SC.txn(msgs)
+    return np.frombuffer(s.bytes(), dtype=np.uint8), s.offsets
+
+
+def test_every_class_known_answers():
+    rows = [SC.alltypes_row(), SC.alltypes_row(id="2", b="f", i2="7", i4="-2147483648", o="4294967295", d="1969-12-31",
+                                               t="00:00:00", ts="1969-12-31 23:59:59.5", tstz="2026-01-02 03:04:05+02",
+                                               f8="1e300", f4="-0.5", s="", by="\\x"),
+            [("3" if c[0] == "id" else W.NULL) for c in SC.ALLTYPES]]
+    rows += [SC.alltypes_row(id=str(10 + i), s="x" * (i * 7 % 90), i4=str(i * 1001)) for i in range(150)]   # > 2 waves of rows
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
+    names = [c[0] for c in SC.ALLTYPES]
+    keep = [i for i, n in enumerate(names) if n != "tz"]
+    cols = b.columns(0)
+    assert cols.n_rows == len(rows) and cols.view.n_cols == len(names) and not cols.view.on_device
+    assert cols.column(names.index("tz")).arrow_kind == abi.AK_NONE
+    with pytest.raises(NotImplementedError):
+        columns_to_record_batch(cols, names=names)                       # text-form columns need on_text="binary"
+    with pytest.raises(NotImplementedError):
+        columns_to_record_batch(cols, names=names, on_text="binary")     # timetz is not handed off
+    got = columns_to_record_batch(cols, names=names, columns=keep, on_text="binary")
+    want = rows_to_record_batch(hb, 0, names=names, on_text="binary", columns=keep)
+    _same(want, got)
+    assert got.column("id").to_pylist()[:3] == [1, 2, 3] and got.column("b").to_pylist()[:3] == [True, False, None]
+    assert got.column("s").to_pylist()[:3] == ["hello wörld", "", None]
+    assert np.array_equal(cols.row_event(), np.flatnonzero(hb.kind == ord("I")).astype(np.uint64))
+    cols.close(); b.close(); d.close()
+
+
+@pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 1 << 20), (synth.cfg3, 2 << 20)])
+@pytest.mark.parametrize("kinds", [("I",), ("I", "U"), ("U",)])
+def test_synthetic_streams(mk, nbytes, kinds):
+    if os.environ.get("ETLG_SIMT_RUN") == "1":
+        nbytes = 192 << 10
+    w = mk()
+    buf, offs = w.fill(nbytes)
+    hb, b, d = _both(w.register, buf, offs)
+    cols = b.columns(0, kinds=kinds)
+    want = rows_to_record_batch(hb, 0, kinds=kinds, on_text="binary")
+    got = columns_to_record_batch(cols, on_text="binary", names=want.schema.names)
+    _same(want, got)
+    if mk is synth.cfg3 and "U" in kinds:
+        assert want.num_rows > 100
+    sel = cols.row_event()
+    assert np.all(np.diff(sel.astype(np.int64)) > 0)          # event order
+    cols.close(); b.close(); d.close()
+
+
+def test_empty_and_foreign_slots():
+    prime = SC.simple_table(SC.COLS2)
+    buf, offs = _stream([])
+    hb, b, d = _both(prime, buf, offs)
+    cols = b.columns(0)
+    rb = columns_to_record_batch(cols, names=["id", "payload"])
+    assert rb.num_rows == 0 and rb.schema.names == ["id", "payload"]
+    with pytest.raises(Exception):
+        b.columns(7)                                           # no such slot
+    hb2 = b.host()                                             # downloaded: the arena left the device
+    with pytest.raises(Exception):
+        b.columns(0)
+    assert hb2.n_events == hb.n_events
+    cols.close(); b.close(); d.close()
+
+
+def test_deferred_cells_are_flagged():
+    """Cells the kernels hand back DEFERRED (here: float8 texts the device rule does not settle): null in the validity of a
+    fixed-width column and set in its `deferred` bitmap, exactly where the oracle's arena has state 3."""
+    cols3 = [("id", 20, False, True), ("x", 701, True, False), ("y", 700, True, False)]
+    vals = ["1.5", "0.1000000000000000055511151231257827021181583404541015625", "NaN", "3.141592653589793238462643383279",
+            "1e-320", "2.5", "1.7976931348623157e308", "4.9e-324", "50537618.817359292015891086651596749e82",
+            "107896223265412489690691363e88", "28879636596541978310003766487.741e-212", "5693107746173304490483329377e264"]
+    msgs = [W.insert(42, [str(i), vals[i % len(vals)], vals[(i + 3) % len(vals)]]) for i in range(200)]
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(cols3), buf, offs)
+    c = b.columns(0)
+    slot = hb.slots[0]
+    base = hb.body_off[hb.kind == ord("I")].astype(np.int64)
+    total_deferred = 0
+    for i in (1, 2):
+        st = (hb.fixed[base + i // 4] >> np.uint8(2 * (i % 4))) & 3
+        validity, deferred, values, _ = c.host_arrays(i)
+        vbits = np.unpackbits(validity, bitorder="little")[:len(base)].astype(bool)
+        dbits = np.unpackbits(deferred, bitorder="little")[:len(base)].astype(bool)
+        assert np.array_equal(vbits, st == abi.CELL_VALUE) and np.array_equal(dbits, st == abi.CELL_DEFERRED)
+        assert c.column(i).deferred_count == int((st == abi.CELL_DEFERRED).sum())
+        assert c.column(i).null_count == int((st != abi.CELL_VALUE).sum())
+        total_deferred += int(c.column(i).deferred_count)
+        w = 8 if i == 1 else 4
+        so = base + slot.cols[i].off_full
+        raw = hb.fixed[so[:, None] + np.arange(w)[None, :]]
+        got = values.reshape(len(base), w)
+        assert np.array_equal(got[vbits], raw[vbits])
+    assert total_deferred > 0
+    c.close(); b.close(); d.close()
+
+
+def test_buffers_can_stay_on_the_device():
+    w = synth.cfg3()
+    buf, offs = w.fill(256 << 10)
+    hb, b, d = _both(w.register, buf, offs)
+    host = b.columns(0, kinds=("I", "U"))
+    dev = b.columns(0, kinds=("I", "U"), on_device=True)
+    assert dev.view.on_device == 1 and dev.n_rows == host.n_rows > 0
+    emu = os.environ.get("ETLG_SIMT_RUN") == "1"
+
+    def read(ptr, nbytes):
+        if not nbytes:
+            return np.zeros(0, np.uint8)
+        if emu:
+            import ctypes as C
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=np.uint8).copy()
+        return abi.device_tensor(ptr, nbytes, 0).cpu().numpy()
+
+    n = host.n_rows
+    for i in range(host.view.n_cols):
+        hk, dk = host.column(i), dev.column(i)
+        assert (hk.arrow_kind, hk.null_count, hk.deferred_count, hk.values_bytes) == (dk.arrow_kind, dk.null_count, dk.deferred_count, dk.values_bytes)
+        hv = host.host_arrays(i)
+        assert np.array_equal(read(dk.validity, (n + 63) // 64 * 8), hv[0])
+        assert np.array_equal(read(dk.values, int(dk.values_bytes)), hv[2])
+        if hv[3] is not None:
+            assert np.array_equal(read(dk.offsets, (n + 1) * 8).view(np.int64), hv[3])
+    host.close(); dev.close(); b.close(); d.close()

@@ -1,0 +1,145 @@
+"""Device-side ClickHouse RowBinary (etlg_batch_rowbinary, etl_amd/csrc/columns.hip) byte for byte against oracle/rowbinary.py
+(the restatement of crates/etl-destinations/src/clickhouse/encoding.rs + core.rs:96-114, pinned to the reference's own
+vectors by tests/test_oracle_rowbinary.py): every class the device encodes, both engines, nullable and non-nullable
+destinations, the reference's two ConversionErrors, and the rows / cells that stay with the host."""
+import os
+
+import numpy as np
+import pytest
+
+from etl_amd import abi, synth
+from tests import pgwire as W
+from tests import scenarios as SC
+
+pytestmark = pytest.mark.gpu
+
+RB_COLS = [c for c in SC.ALLTYPES if c[0] not in ("n", "tz", "j", "arr")]   # the classes the device encodes
+
+
+def _both(prime, buf, offs):
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o)
+    prime(d)
+    rb = o.decode(buf, offs)
+    assert rb.err_code == 0, rb.err_desc
+    b = d.decode(buf, offs, flags=abi.F_OUTPUT_ON_DEVICE)
+    assert b.rc == 0, b.error
+    return rb.host_batch(), b, d
+
+
+def _stream(msgs):
+    s = SC.txn(msgs)
+    return np.frombuffer(s.bytes(), dtype=np.uint8), s.offsets
+
+
+def _check(hb, b, flags, engine):
+    from oracle import rowbinary as RB
+    slot = hb.slots[0]
+    rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in slot.cols], list(flags), engine)
+    r = b.rowbinary(0, flags, engine)
+    assert r.status == abi.RB_OK
+    assert r.n_rows == len(rows) and int(r.view.n_host_rows) == host
+    assert np.array_equal(r.row_event(), np.array(idx, dtype=np.uint64))
+    offs = r.row_offsets()
+    assert offs[0] == 0 and np.array_equal(np.diff(offs), np.array([len(x) for x in rows], dtype=np.int64))
+    assert r.bytes().tobytes() == b"".join(rows)
+    r.close()
+    return len(rows)
+
+
+def _row(**kw):
+    full = dict(zip([c[0] for c in SC.ALLTYPES], SC.alltypes_row(**kw)))
+    return [full[c[0]] for c in RB_COLS]
+
+
+@pytest.mark.parametrize("engine", [abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE])
+def test_every_encodable_class(engine):
+    names = [c[0] for c in RB_COLS]
+    rows = [_row(), _row(id="2", b="f", i2="-7", i4="-2147483648", o="4294967295", d="1900-01-01", t="00:00:00",
+                         ts="1969-12-31 23:59:59.5", tstz="2026-01-02 03:04:05+02", f8="1e300", f4="-0.5", s="", by="\\x"),
+            _row(id="3", d="2299-12-31", t="23:59:59.12", s="x" * 300, by="\\x" + "ab" * 200),
+            [("4" if n == "id" else W.NULL) for n in names]]
+    rows += [_row(id=str(10 + i), s="y" * (i * 13 % 200), t=f"01:02:{i % 60:02}.{i:06}") for i in range(130)]
+    msgs = [W.insert(42, r) for r in rows] + [W.update(42, rows[1]), W.delete(42, old=rows[0])]
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(RB_COLS), buf, offs)
+    n = len(names)
+    nullable = [0 if nm == "id" else 1 for nm in names]
+    assert _check(hb, b, nullable + [0, 0], engine) >= len(rows)
+    assert _check(hb, b, nullable + [1, 1], engine) >= len(rows)     # Nullable() CDC columns take their marker byte
+    # NULL in a non-nullable destination column: the reference's ConversionError, at the first such row
+    from etl_amd.decoder import EtlError
+    with pytest.raises(EtlError) as ei:
+        b.rowbinary(0, [0] * n + [0, 0], engine)
+    assert ei.value.kind == abi.ConversionError
+    assert ei.value.description == "NULL value for non-nullable ClickHouse column" and ei.value.frame_index == 1 + 3
+    with pytest.raises(EtlError) as ei:
+        b.rowbinary(0, nullable + [0], engine)
+    assert ei.value.description == "ClickHouse RowBinary row width mismatch"
+    b.close(); d.close()
+
+
+def test_date_out_of_range_fails_like_the_reference():
+    from etl_amd.decoder import EtlError
+    cols = [("id", SC.INT8, False, 1), ("d", 1082, True, 0)]
+    for bad in ("1899-12-31", "2300-01-01"):
+        buf, offs = _stream([W.insert(42, ["1", "2000-01-01"]), W.insert(42, ["2", bad])])
+        hb, b, d = _both(SC.simple_table(cols), buf, offs)
+        with pytest.raises(EtlError) as ei:
+            b.rowbinary(0, [0, 1, 0, 0])
+        assert ei.value.description == "Date out of ClickHouse Date32 range" and ei.value.frame_index == 2
+        b.close(); d.close()
+
+
+def test_cells_and_rows_that_stay_with_the_host():
+    # a numeric column: the whole slot is the host's
+    buf, offs = _stream([W.insert(42, SC.alltypes_row())])
+    hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
+    r = b.rowbinary(0, [1] * len(SC.ALLTYPES) + [0, 0])
+    assert r.status == abi.RB_NEEDS_HOST and r.n_rows == 0 and r.view.host_column == [c[0] for c in SC.ALLTYPES].index("n")
+    r.close(); b.close(); d.close()
+    # a DEFERRED float: reported with its event and column
+    cols = [("id", SC.INT8, False, 1), ("x", SC.FLOAT8, True, 0)]
+    buf, offs = _stream([W.insert(42, ["1", "1.5"]), W.insert(42, ["2", "50537618.817359292015891086651596749e82"])])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    r = b.rowbinary(0, [0, 1, 0, 0])
+    assert r.status == abi.RB_NEEDS_HOST and (int(r.view.host_event), r.view.host_column) == (2, 1)
+    r.close(); b.close(); d.close()
+
+
+@pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 1 << 20)])
+@pytest.mark.parametrize("engine", [abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE])
+def test_synthetic_stream(mk, nbytes, engine):
+    if os.environ.get("ETLG_SIMT_RUN") == "1":
+        nbytes = 128 << 10
+    w = mk()
+    buf, offs = w.fill(nbytes)
+    hb, b, d = _both(w.register, buf, offs)
+    nc = len(hb.slots[0].cols)
+    assert _check(hb, b, [0] * nc + [0, 0], engine) > 100
+    b.close(); d.close()
+
+
+def test_updates_deletes_and_host_rows():
+    """cfg3-like traffic on a table the device encodes: updates (new row), deletes with a full old row; key-only deletes and
+    partial updates are counted, not encoded."""
+    cols = [("id", SC.INT8, False, 1), ("v", SC.INT4, True, 0), ("s", 25, True, 0)]
+    msgs = []
+    for i in range(300):
+        r = [str(i), str(i * 3), "t" * (i % 50)]
+        msgs.append(W.insert(42, r))
+        if i % 3 == 0:
+            msgs.append(W.update(42, [str(i), W.NULL, "u"]))
+        if i % 5 == 0:
+            msgs.append(W.update(42, [str(i), "1", W.TOAST]))                   # partial: host
+        if i % 7 == 0:
+            msgs.append(W.delete(42, key=[str(i), W.NULL, W.NULL]))              # key only: host
+        if i % 11 == 0:
+            msgs.append(W.delete(42, old=r))                                     # full old row
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    for engine in (abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE):
+        _check(hb, b, [0, 1, 1, 0, 0], engine)
+    b.close(); d.close()
