@@ -315,35 +315,97 @@ def leg_copy(dev_id, dev, nrows, reps):
             "roofline": roofline_of(kern, alg)}
 
 
+def leg_handoff(dev_id, dev, cap, reps):
+    """the decoded cfg2 arena (device-resident) -> Arrow-layout column buffers (etlg_batch_columns) and
+    ClickHouse RowBinary rows (etlg_batch_rowbinary), both left in HBM. Rates are quoted in WAL input bytes per second so
+    that they compare with `value`; the host-side hand-off of the same arena (etl_amd/arrow.py, numpy) is timed beside."""
+    import numpy as np
+    import torch
+
+    from etl_amd import abi, synth
+    from etl_amd.decoder import Decoder
+    w = synth.cfg2()
+    d = Decoder(dev_id)
+    w.register(d)
+    buf, offs = w.fill(cap)
+    tb = torch.from_numpy(buf.copy()).to(dev)
+    to = torch.from_numpy(offs.astype(np.uint32).view(np.int32).copy()).to(dev)
+    b = d.decode_device(tb.data_ptr(), tb.numel(), to.data_ptr(), len(offs) - 1, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
+    assert b.rc == 0
+    nc = 5
+    out = {"workload": f"one {cap >> 20} MiB cfg2 batch ({len(offs) - 1} frames), arena device-resident, outputs left in HBM"}
+    for name, fn in (("arrow_columns", lambda: b.columns(0, on_device=True)),
+                     ("rowbinary", lambda: b.rowbinary(0, [0] * nc + [0, 0], abi.CH_REPLACING_MERGE_TREE, on_device=True))):
+        fn().close()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+            nrows = r.n_rows
+            nbytes = int(r.view.n_bytes) if name == "rowbinary" else sum(int(r.column(i).values_bytes) for i in range(nc))
+            r.close()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"value": round(len(buf) / dt / 1e9, 3), "unit": "GB/s", "ms": round(dt * 1e3, 3), "rows": nrows,
+                     "rows_per_s": round(nrows / dt, 1), "out_bytes": nbytes}
+    # the host path the device one replaces: download the arena, numpy gathers per column
+    from etl_amd.arrow import rows_to_record_batch
+    t0 = time.perf_counter()
+    hb = b.host()
+    t1 = time.perf_counter()
+    rb = rows_to_record_batch(hb, 0)
+    t2 = time.perf_counter()
+    out["host_numpy"] = {"value": round(len(buf) / (t2 - t0) / 1e9, 3), "unit": "GB/s", "download_ms": round((t1 - t0) * 1e3, 2),
+                         "gather_ms": round((t2 - t1) * 1e3, 2), "rows": rb.num_rows}
+    b.close()
+    d.close()
+    return out
+
+
 def leg_no_sidecar(dec, items, steps, check):
     """The same cfg2 batches with frame_offsets = NULL: the record-boundary scan runs on the device first (scan.hip).
-    Reported beside `value`, never as `value`: the reference's host learns every frame length from its socket codec."""
+    Reported beside `value`, never as `value`: the reference's host learns every frame length from its socket codec.
+    `value`: ASYNC — the scan of batch k+1 runs on its own stream while batch k is decoded, the host only waits for the frame
+    count; `sync_value`: one batch at a time, every call returns a finished batch."""
     import torch
 
     from etl_amd import abi
-    fl = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL
-    for k in range(2):
-        tb, to, nbytes, nfr = items[k % len(items)]
-        dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl).close()
-    dec.profile(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nb = 0
-    for k in range(steps):
-        tb, to, nbytes, nfr = items[k % len(items)]
-        b = dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl)
-        assert not check or (b.rc == 0 and b.view().n_frames == nfr)
-        nb += nbytes
-        b.close()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    kern = kernel_table(dec.profile_read())
-    dec.profile(False)
+    out = {}
+    for mode, fl in (("sync", abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL), ("async", abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC)):
+        for k in range(2):
+            tb, to, nbytes, nfr = items[k % len(items)]
+            dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl).close()
+        dec.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = 0
+        window = []
+        for k in range(steps):
+            tb, to, nbytes, nfr = items[k % len(items)]
+            b = dec.decode_device(tb.data_ptr(), nbytes, None, 0, fl)
+            window.append((b, nfr))
+            nb += nbytes
+            if len(window) >= (8 if mode == "async" else 1):
+                ob, onf = window.pop(0)
+                rc = ob.sync() if mode == "async" else ob.rc
+                assert not check or (rc == 0 and ob.view().n_frames == onf)
+                ob.close()
+        for ob, onf in window:
+            rc = ob.sync() if mode == "async" else ob.rc
+            assert not check or (rc == 0 and ob.view().n_frames == onf)
+            ob.close()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        kern = kernel_table(dec.profile_read())
+        dec.profile(False)
+        out[mode] = (nb / (t1 - t0) / 1e9, kern)
+    kern = out["async"][1]
     kb = kern.get("k_bounds", {"launches": 0, "avg_us": 0.0})
-    return {"value": round(nb / (t1 - t0) / 1e9, 3), "unit": "GB/s", "k_bounds_avg_us": round(kb["avg_us"], 2),
-            "k_bounds_launches_per_batch": round(kb["launches"] / steps, 2),
+    return {"value": round(out["async"][0], 3), "unit": "GB/s", "sync_value": round(out["sync"][0], 3),
+            "k_bounds_avg_us": round(kb["avg_us"], 2), "k_bounds_launches_per_batch": round(kb["launches"] / steps, 2),
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
-            "note": "frame_offsets = NULL: device record-boundary scan + decode, synchronous (the host reads the frame count back)"}
+            "note": "frame_offsets = NULL: device record-boundary scan + decode. value = ASYNC (scan of the next batch beside the decode of "
+                    "this one, the host waits for the frame count only); sync_value = one finished batch per call"}
 
 
 def _gen_segment(args):
@@ -483,7 +545,7 @@ def main():
     ap.add_argument("--batch-mib", type=int, default=64)
     ap.add_argument("--pool", type=int, default=6, help="distinct batches resident in HBM (rotated)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar", help="extra legs on rank 0 (comma separated; empty = none)")
+    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar,handoff", help="extra legs on rank 0 (comma separated; empty = none)")
     ap.add_argument("--cfg4-leg", action="store_true", help="add the cfg4 leg to a cfg2 / cfg3 run")
     ap.add_argument("--cfg4-gib", type=int, default=8)
     ap.add_argument("--cfg4-seg-mib", type=int, default=1024)
@@ -646,7 +708,7 @@ def main():
     extra = {}
     if rank == 0:
         if "no_sidecar" in legs and args.workload == "cfg2":
-            extra["no_sidecar"] = leg_no_sidecar(dec, items, 20, check)
+            extra["no_sidecar"] = leg_no_sidecar(dec, items, 40, check)
         if "cfg3" in legs and args.workload != "cfg3":
             extra["cfg3"] = leg_async(synth.cfg3, local_rank, dev, cap, 4, 60, flags, check,
                                       os.path.join(ROOT, "profiles", "traffic_cfg3.json"))[0]
@@ -654,6 +716,8 @@ def main():
             extra["cfg5"] = leg_cfg5(local_rank, dev, cap, 4, 2)
         if "copy" in legs:
             extra["copy"] = leg_copy(local_rank, dev, 400000, 8)
+        if "handoff" in legs:
+            extra["handoff"] = leg_handoff(local_rank, dev, cap, 5)
     if args.cfg4_leg and world == 1:
         extra["cfg4"] = leg_cfg4(local_rank, dev, 1, 0, args.cfg4_gib, args.cfg4_seg_mib, False, None)
 

@@ -209,6 +209,23 @@ pub struct etlg_rowbinary_view {
 }
 
 #[repr(C)]
+pub struct etlg_size_model {
+    pub begin_event: u32,
+    pub commit_event: u32,
+    pub insert_event: u32,
+    pub update_event: u32,
+    pub delete_event: u32,
+    pub truncate_event: u32,
+    pub relation_event: u32,
+    pub replicated_table_schema: u32,
+    pub table_row: u32,
+    pub cell: u32,
+    pub _reserved: [u32; 2],
+}
+
+pub const ETLG_SIZE_HINT_INCOMPLETE: u64 = 1 << 63;
+
+#[repr(C)]
 pub struct etlg_columns {
     _private: [u8; 0],
 }
@@ -325,6 +342,7 @@ extern "C" {
     ) -> i32;
     pub fn etlg_rowbinary_view_get(rb: *const etlg_rowbinary, out: *mut etlg_rowbinary_view) -> i32;
     pub fn etlg_rowbinary_free(rb: *mut etlg_rowbinary);
+    pub fn etlg_batch_size_hints(ctx: *mut etlg_ctx, batch: *mut etlg_batch, model: *const etlg_size_model, flags: u32, out: *mut u64) -> i32;
     pub fn etlg_ctx_slots(ctx: *const etlg_ctx, n_slots: *mut u32, slots: *mut *const etlg_slot_desc) -> i32;
 
     pub fn etlg_ctx_profile(ctx: *mut etlg_ctx, enable: i32) -> i32;

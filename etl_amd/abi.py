@@ -113,6 +113,12 @@ class RowBinaryView(C.Structure):   # etlg_rowbinary_view
                 ("bytes", C.c_void_p), ("row_offsets", C.c_void_p), ("row_event", C.c_void_p)]
 
 
+class SizeModel(C.Structure):   # etlg_size_model
+    _fields_ = [(n, C.c_uint32) for n in ("begin_event", "commit_event", "insert_event", "update_event", "delete_event", "truncate_event",
+                                          "relation_event", "replicated_table_schema", "table_row", "cell")] + [("_reserved", C.c_uint32 * 2)]
+
+
+SIZE_HINT_INCOMPLETE = 1 << 63
 CH_MERGE_TREE, CH_REPLACING_MERGE_TREE = 0, 1
 RB_OK, RB_NEEDS_HOST = 0, 3
 (AK_BOOLEAN, AK_INT32, AK_INT64, AK_FLOAT32, AK_FLOAT64, AK_DATE32, AK_TIME64_US, AK_TIMESTAMP_US, AK_TIMESTAMP_US_UTC, AK_FIXED16,

@@ -312,6 +312,60 @@ __global__ __launch_bounds__(256) void k_rb_rows(RbJob j) {
   (void)rb_row(j, r, w);
 }
 
+
+// ---- Event::size_hint (crates/etl/src/event.rs:295-320; data/table_row.rs:248-299)
+DEV uint64_t hint_row(const HintJob& j, const uint32_t* sl, uint64_t base, bool key, bool& incomplete) {
+  const uint32_t n_cols = sl[0], n_ident = sl[1], cb = sl[4];
+  uint64_t total = (uint64_t)j.m_row + (uint64_t)(key ? n_ident : n_cols) * j.m_cell;   // TableRow + Vec<Cell> capacity
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n_cols; i++) {
+    const uint32_t cd = j.cols[2 * (cb + i)], cls = cd & 0xFF;
+    if (key && !((cd >> 8) & 1)) continue;
+    const uint32_t pos = key ? k : i, off = key ? j.cols[2 * (cb + i) + 1] : cd >> 16;
+    k++;
+    const uint32_t st = (j.fixed[base + pos / 4] >> (2 * (pos % 4))) & 3u;
+    if (st == ETLG_CELL_NULL) continue;
+    if (st == ETLG_CELL_MISSING) { incomplete = true; continue; }
+    const bool text_form = cls == ETLG_TC_JSON || cls == ETLG_TC_ARRAY || cls == ETLG_TC_NUMERIC;
+    if (st == ETLG_CELL_DEFERRED) { if (text_form) incomplete = true; continue; }   // a deferred fixed-width cell owns no heap
+    const u8* slot = j.fixed + base + off;
+    if (cls == ETLG_TC_STRING || cls == ETLG_TC_BYTEA) total += ld32a(slot + 4);
+    else if (cls == ETLG_TC_NUMERIC) { const u8* h = j.heap + ld32a(slot); if (h[0] == ETLG_NUM_VALUE) total += 2u * (uint32_t)(h[6] | (h[7] << 8)); }
+    else if (cls == ETLG_TC_JSON || cls == ETLG_TC_ARRAY) incomplete = true;
+  }
+  return total;
+}
+
+__global__ __launch_bounds__(256) void k_size_hints(HintJob j) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= j.n_events) return;
+  const uint32_t kind = j.ev_kind[i], fl = j.ev_flags[i];
+  uint64_t v = 0;
+  bool inc = false;
+  if (kind == 'B') v = j.m_begin;
+  else if (kind == 'C') v = j.m_commit;
+  else if (kind == 'R') v = j.m_relation;
+  else if (kind == 'T') v = (uint64_t)j.m_truncate + (uint64_t)j.ev_table[i] * j.m_rts;
+  else if (kind == 'I' || kind == 'U' || kind == 'D') {
+    const uint32_t s = j.ev_slot[i];
+    if (s >= j.n_slots) { inc = true; }
+    else {
+      const uint32_t* sl = j.slots + 5 * s;
+      uint64_t base = j.ev_body[i];
+      v = kind == 'I' ? j.m_insert : kind == 'U' ? j.m_update : j.m_delete;
+      if (kind != 'I') {
+        const uint32_t ok = fl & 3u;
+        if (ok) { v += hint_row(j, sl, base, ok == ETLG_OLD_KEY, inc); base += ok == ETLG_OLD_KEY ? sl[3] : sl[2]; }
+      }
+      if (kind != 'D') {
+        if (fl & ETLG_FLAG_PARTIAL) inc = true;
+        v += hint_row(j, sl, base, false, inc);
+      }
+    }
+  }
+  j.out[i] = v | (inc ? (1ull << 63) : 0ull);
+}
+
 }  // namespace etlg
 
 extern "C" {
@@ -359,6 +413,11 @@ void etlg_k_rowbinary(const void* jv, unsigned long long* blk, int64_t* offsets,
   } else {
     hipLaunchKernelGGL(k_rb_rows, dim3(nb), dim3(256), 0, st, j);
   }
+}
+
+void etlg_k_size_hints(const void* jv, hipStream_t st) {
+  const HintJob j = *(const HintJob*)jv;
+  if (j.n_events) hipLaunchKernelGGL(k_size_hints, dim3((uint32_t)((j.n_events + 255) / 256)), dim3(256), 0, st, j);
 }
 
 }  // extern "C"

@@ -196,6 +196,17 @@ struct ColJob {
   uint32_t* lens; const int64_t* offsets;   // var-len
 };
 
+struct HintJob {           // Event::size_hint per event (k_size_hints)
+  const uint8_t* ev_kind; const uint8_t* ev_flags; const uint32_t* ev_table; const uint32_t* ev_slot; const uint64_t* ev_body;
+  const uint8_t* fixed; const uint8_t* heap;
+  uint64_t n_events;
+  const uint32_t* slots;   // per slot: n_cols, n_ident, row_full, row_key, cols_base
+  const uint32_t* cols;    // per column: cls | identity << 8 | off_full << 16, then off_key
+  uint32_t n_slots;
+  uint32_t m_begin, m_commit, m_insert, m_update, m_delete, m_truncate, m_relation, m_rts, m_row, m_cell;
+  unsigned long long* out;
+};
+
 struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
   const uint8_t* fixed; const uint8_t* heap; const uint64_t* row_event; const uint64_t* row_base;
   const uint8_t* ev_kind; const uint64_t* ev_commit; const uint64_t* ev_ord;

@@ -46,6 +46,7 @@ extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_
 extern "C" int etlg_k_plan_set_lds(void);
 extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
 extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
+extern "C" void etlg_k_size_hints(const void* job, hipStream_t s);
 extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" void etlg_k_col_var(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" int etlg_k_cells_set_lds(void);
@@ -254,6 +255,8 @@ struct etlg_ctx {
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
   bool last_any_sync_done = false;
   bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
+  hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
+  std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
   DevBuf d_colsel;                   // etlg_batch_columns: block counts of the row selection
   std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order
   std::vector<hipEvent_t> ev_pool;   // "result block copied back" events of finished batches
@@ -296,6 +299,7 @@ struct etlg_batch {
   size_t len = 0;
   const uint8_t* host_in = nullptr; const uint32_t* host_offs = nullptr; const uint8_t* dev_in = nullptr;
   uint64_t ctx_gen = 0;
+  DevBuf* scan_offs = nullptr;  // ASYNC without a sidecar: the batch's own offsets (from the context's pool)
   hipEvent_t done = nullptr;  // recorded behind the copy of the result block: syncing a batch waits for IT, not for the whole stream
   DevResult* h_res = nullptr;  // pinned, from the context's pool
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
@@ -904,6 +908,8 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
   for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols, &c->d_colsel}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
+  for (DevBuf* o : c->offs_pool) { o->release(); delete o; }
+  if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& pr : c->harena_pool) (void)hipHostFree(pr.first);
@@ -1046,12 +1052,11 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
 
 // Record boundaries on the device (scan.hip): fills c->d_offs with nframes + 1 offsets of the frames
 // of `d_in[0, len)` and returns nframes. Optimistic kernel + hint reruns + one-lane fallback.
-hipError_t device_scan(etlg_ctx* c, const uint8_t* d_in, size_t len, size_t* nframes_out) {
-  hipStream_t s = c->stream;
+hipError_t device_scan(etlg_ctx* c, const uint8_t* d_in, size_t len, size_t* nframes_out, hipStream_t s, DevBuf& offs) {
   *nframes_out = 0;
   if (len == 0) {
-    hipError_t e = c->d_offs.ensure(64); if (e != hipSuccess) return e;
-    return hipMemsetAsync(c->d_offs.p, 0, 4, s);
+    hipError_t e = offs.ensure(64); if (e != hipSuccess) return e;
+    return hipMemsetAsync(offs.p, 0, 4, s);
   }
   const size_t tb = etlg_k_bounds_tile_bytes();
   const size_t ntiles = (len + tb - 1) / tb, ngroups = (ntiles + 63) / 64;
@@ -1065,12 +1070,12 @@ hipError_t device_scan(etlg_ctx* c, const uint8_t* d_in, size_t len, size_t* nfr
   bool used_hints = false;
   for (int run = 0;; run++) {
     const bool sequential = run >= 4;
-    e = c->d_offs.ensure((cap + 2) * 4); if (e != hipSuccess) return e;
+    e = offs.ensure((cap + 2) * 4); if (e != hipSuccess) return e;
     e = hipMemsetAsync(base, 0, zero_bytes, s); if (e != hipSuccess) return e;
     e = hipMemsetAsync(base + res_off, 0, 64, s); if (e != hipSuccess) return e;
     ProfRec r; r.which = kBounds;
     if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
-    etlg_k_launch_bounds(d_in, len, (uint32_t*)c->d_offs.p, (uint32_t)std::min<size_t>(cap + 2, 0xFFFFFFFFu), base, base + ntiles * 8,
+    etlg_k_launch_bounds(d_in, len, (uint32_t*)offs.p, (uint32_t)std::min<size_t>(cap + 2, 0xFFFFFFFFu), base, base + ntiles * 8,
                          (uint32_t*)(base + hints_off), (uint32_t*)(base + res_off), (sequential ? 1 : 0) | (getenv("ETLG_SCAN_DBG") ? 2 : 0), s);
     if (c->prof) { (void)hipEventRecord(r.b, s); c->prof_recs.push_back(r); }
     e = hipMemcpyAsync(c->h_scan, base + res_off, 64, hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
@@ -1107,7 +1112,7 @@ int32_t etlg_scan_boundaries(etlg_ctx* c, const uint8_t* buf, size_t len, uint32
     d_in_ptr = (const uint8_t*)c->d_in.p;
   }
   size_t nf = 0;
-  HIPCHK(c, device_scan(c, d_in_ptr, len, &nf));
+  HIPCHK(c, device_scan(c, d_in_ptr, len, &nf, c->stream, c->d_offs));
   *nframes_out = nf;
   if (nf + 1 > cap) return lib_error(c, ETLG_InvalidArgument, "offsets_out too small for nframes + 1 entries");
   HIPCHK(c, hipMemcpyAsync(offsets_out, c->d_offs.p, (nf + 1) * 4, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
@@ -1210,7 +1215,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   // ASYNC batches are chained on the device (DecParams.carry) and may be decoded again when they are synced, so everything
   // they read must still be there then: device-resident input AND sidecar (the context's staging and scan buffers are shared
   // by all batches). Anything else is decoded synchronously; etlg_batch_sync on such a batch returns its stored result.
-  const bool async = (flags & ETLG_F_ASYNC) && out_dev && no_ctrl && in_dev && !scan && !c->copy.active && !c->force_multipass && len < (1ull << 31);
+  const bool async = (flags & ETLG_F_ASYNC) && out_dev && no_ctrl && in_dev && !c->copy.active && !c->force_multipass && len < (1ull << 31);
   hipStream_t s = c->stream;
   if (!async) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
 
@@ -1222,14 +1227,23 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, s));
     d_in_ptr = (const uint8_t*)c->d_in.p;
   }
-  if (scan) {
-    HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes));
-    if (nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
-  }
-
   auto* b = new etlg_batch();
   b->ctx = c; b->ctx_gen = c->gen;
   BatchGuard guard{b};
+  if (scan) {
+    if (async) {
+      // the scan of THIS batch runs on its own stream while the previous batch is still being decoded on the context's; the
+      // host waits for the frame count (it sizes the decode launch), the device does not go idle. The input must be
+      // complete when the call is made (include/etlg.h).
+      if (!c->scan_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
+      if (c->offs_pool.empty()) c->offs_pool.push_back(new DevBuf());
+      b->scan_offs = c->offs_pool.back(); c->offs_pool.pop_back();
+      HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes, c->scan_stream, *b->scan_offs));
+    } else {
+      HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes, s, c->d_offs));
+    }
+    if (nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  }
   b->user_no_ctrl = no_ctrl; b->out_dev = out_dev; b->in_dev = in_dev; b->scan = scan; b->len = len;
   b->host_in = in_dev ? nullptr : buf; b->host_offs = (in_dev || scan) ? nullptr : h_offs; b->dev_in = in_dev ? buf : nullptr;
 
@@ -1237,7 +1251,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   DecParams& p = b->params;
   p = DecParams{};
   p.in = d_in_ptr;
-  if (scan) p.offs = (const uint32_t*)c->d_offs.p;
+  if (scan) p.offs = (const uint32_t*)(b->scan_offs ? b->scan_offs->p : c->d_offs.p);
   else if (in_dev) p.offs = frame_offsets;
   else {
     HIPCHK(c, c->d_offs.ensure((nframes + 1) * 4));
@@ -1341,10 +1355,12 @@ void etlg_batch_free(etlg_batch* b) {
     if (b->h_res) (void)hipStreamSynchronize(c->stream);
     if (b->done) c->ev_pool.push_back(b->done);
     if (b->dev) c->out_pool.push_back(b->dev);
+    if (b->scan_offs) c->offs_pool.push_back(b->scan_offs);
     if (b->h_res) c->res_pool.push_back(b->h_res);
     if (b->h_arena) c->harena_pool.emplace_back(b->h_arena, b->h_arena_cap);
   } else {  // the context is gone (its pools with it): release what the batch owns outright
     if (b->dev) { b->dev->release(); delete b->dev; }
+    if (b->scan_offs) { b->scan_offs->release(); delete b->scan_offs; }
     if (b->done) (void)hipEventDestroy(b->done);
     if (b->h_res) (void)hipHostFree(b->h_res);
     if (b->h_arena) (void)hipHostFree(b->h_arena);
@@ -1492,6 +1508,48 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   cs->v.n_rows = n; cs->v.n_cols = nc; cs->v.on_device = on_dev ? 1u : 0u; cs->v.cols = cs->cols.data();
   cs->v.row_event = (const uint64_t*)base_a;
   *out = cs.release();
+  return ETLG_OK;
+}
+
+int32_t etlg_batch_size_hints(etlg_ctx* c, etlg_batch* b, const etlg_size_model* m, uint32_t flags, uint64_t* out) {
+  if (!c || !b || !m || b->ctx != c) return ETLG_InvalidArgument;
+  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
+  if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_size_hints needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
+  const etlg_batch_view& bv = b->v;
+  const uint64_t ne = bv.n_events;
+  if (!ne) return ETLG_OK;
+  if (!out) return ETLG_InvalidArgument;
+  hipStream_t s = c->stream;
+  std::vector<uint32_t> tab;
+  const uint32_t ns = (uint32_t)c->slots.size();
+  tab.resize((size_t)ns * 5);
+  uint32_t ncols = 0;
+  for (uint32_t i = 0; i < ns; i++) {
+    const SlotHost& sh = *c->slots[i];
+    uint32_t* t = &tab[(size_t)i * 5];
+    t[0] = sh.desc.n_cols; t[1] = sh.desc.n_ident; t[2] = sh.desc.row_bytes_full; t[3] = sh.desc.row_bytes_key; t[4] = ncols;
+    ncols += sh.desc.n_cols;
+  }
+  const size_t o_cols = tab.size();
+  tab.resize(o_cols + (size_t)ncols * 2);
+  for (uint32_t i = 0, k = 0; i < ns; i++)
+    for (const etlg_slot_col& col : c->slots[i]->cols) { tab[o_cols + 2 * k] = col.type_class | (col.identity ? 1u << 8 : 0u) | ((uint32_t)col.off_full << 16); tab[o_cols + 2 * k + 1] = col.off_key; k++; }
+  const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
+  const size_t tab_bytes = (tab.size() * 4 + 63) & ~(size_t)63;
+  void* d = nullptr;
+  HIPCHK(c, hipMalloc(&d, tab_bytes + (on_dev ? 0 : ne * 8) + 64));
+  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } free_d{d};
+  HIPCHK(c, hipMemcpyAsync(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+  HintJob j{};
+  j.ev_kind = bv.ev_kind; j.ev_flags = bv.ev_flags; j.ev_table = bv.ev_table_id; j.ev_slot = bv.ev_schema_slot; j.ev_body = bv.ev_body_off;
+  j.fixed = bv.fixed; j.heap = bv.heap; j.n_events = ne;
+  j.slots = (const uint32_t*)d; j.cols = (const uint32_t*)d + o_cols; j.n_slots = ns;
+  j.m_begin = m->begin_event; j.m_commit = m->commit_event; j.m_insert = m->insert_event; j.m_update = m->update_event; j.m_delete = m->delete_event;
+  j.m_truncate = m->truncate_event; j.m_relation = m->relation_event; j.m_rts = m->replicated_table_schema; j.m_row = m->table_row; j.m_cell = m->cell;
+  j.out = on_dev ? (unsigned long long*)out : (unsigned long long*)((uint8_t*)d + tab_bytes);
+  etlg_k_size_hints(&j, s);
+  if (!on_dev) HIPCHK(c, hipMemcpyAsync(out, j.out, ne * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));   // the tables are freed on return
   return ETLG_OK;
 }
 

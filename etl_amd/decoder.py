@@ -70,6 +70,15 @@ class Batch:
             raise self.dec.last_error()
         return Columns(self.dec, out)
 
+    def size_hints(self, model):
+        """Event::size_hint per event (np.uint64; bit 63 = abi.SIZE_HINT_INCOMPLETE), computed on the device
+        (etlg_batch_size_hints). `model`: abi.SizeModel — the reference's size_of constants."""
+        out = np.zeros(int(self.view().n_events), dtype=np.uint64)
+        rc = self.dec.L.etlg_batch_size_hints(self.dec.h, self.h, C.byref(model), 0, out.ctypes.data)
+        if rc != abi.OK:
+            raise self.dec.last_error()
+        return out
+
     def rowbinary(self, slot, nullable_flags, engine=abi.CH_MERGE_TREE, on_device=False):
         """ClickHouse RowBinary rows of schema slot `slot`, encoded on the device (etlg_batch_rowbinary). Raises EtlError for
         the reference's ConversionErrors; `RowBinary.status == abi.RB_NEEDS_HOST` when a cell has no device encoding."""

@@ -266,7 +266,11 @@ enum {
                                         counts become valid after etlg_batch_sync. Sync batches in issue
                                         order and keep fewer than 32 of them in flight per context (their
                                         result blocks live in a ring of 32; a batch that reports an error is
-                                        decoded again, on the exact-error path, when it is synced) */
+                                        decoded again, on the exact-error path, when it is synced).
+                                        With frame_offsets = NULL the record-boundary scan of the batch runs on a
+                                        private stream beside the previous batch's decode and the call returns once
+                                        the frame count is known: the input must be COMPLETE in device memory when
+                                        the call is made (not merely enqueued on the context's stream) */
 };
 
 /* buf = `nframes` concatenated CopyData frames exactly as on the socket:
@@ -571,6 +575,39 @@ int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_sl
                              uint32_t n_flags, int32_t engine, uint32_t flags, etlg_rowbinary** out);
 int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out);
 void etlg_rowbinary_free(etlg_rowbinary* rb);
+
+/* --------------------------------------------------------------- size hints */
+
+/* Event::size_hint (crates/etl/src/event.rs:295-320) for every event of a batch, computed on the device from the
+ * arena: what EventBatch::push adds up to decide batch cut points (replication/apply.rs:656-657, 1932-1935).
+ * The estimate is built from `size_of::<T>()` of the reference's own types (data/table_row.rs:248-384), whose
+ * layouts are not ABI-stable: the Rust shim fills this model once (crates/etl-gfx950/src/lib.rs). */
+typedef struct etlg_size_model {
+  uint32_t begin_event;             /* size_of::<BeginEvent>() ... (event.rs:297-316) */
+  uint32_t commit_event;
+  uint32_t insert_event;
+  uint32_t update_event;
+  uint32_t delete_event;
+  uint32_t truncate_event;
+  uint32_t relation_event;
+  uint32_t replicated_table_schema; /* per truncated table (event.rs:311-314) */
+  uint32_t table_row;               /* size_of::<TableRow>()  (table_row.rs:249-251) */
+  uint32_t cell;                    /* size_of::<Cell>(), times the row's Vec capacity: n_cols (codec/event.rs:567),
+                                       n_ident for key rows (:800, :831) */
+  uint32_t _reserved[2];
+} etlg_size_model;
+
+/* The event has a part only the host can size: a DEFERRED json / array / numeric cell (estimate_json_allocated_bytes /
+ * estimate_array_allocated_bytes need the parsed value) or a Partial updated row (its Vec capacities depend on the
+ * reserve/append sequence of codec/event.rs:636-660). The low bits hold everything else of the event. */
+#define ETLG_SIZE_HINT_INCOMPLETE (1ull << 63)
+
+/* out: n_events u64 entries; device memory when flags has ETLG_F_OUTPUT_ON_DEVICE, else host memory.
+ * Same batch requirements as etlg_batch_columns. Per cell (estimate_cell_allocated_bytes, table_row.rs:276-299):
+ * String -> len (str::to_owned), Bytes -> len (Vec::with_capacity(hex / 2), codec/hex.rs:21), Numeric::Value ->
+ * 2 * ndigits (Vec::with_capacity(retained_groups), numeric.rs:444), everything fixed-width -> 0. */
+int32_t etlg_batch_size_hints(etlg_ctx* ctx, etlg_batch* batch, const etlg_size_model* model, uint32_t flags,
+                              uint64_t* out);
 
 /* Schema slots known to the context (also reachable from every batch view). */
 int32_t etlg_ctx_slots(const etlg_ctx* ctx, uint32_t* n_slots,

@@ -54,14 +54,14 @@ def _cut(buf, offs, nparts, seed):
     return out
 
 
-def _run_chain(w, pieces, expect_path=None):
+def _run_chain(w, pieces, expect_path=None, sidecar=True):
     from etl_amd.decoder import Decoder
     from oracle import oracle
     o, d = oracle.Oracle(), Decoder(0)
     w.register(o)
     w.register(d)
     dev = DevBufs(pieces)
-    inflight = [d.decode_device(p, n, po, nf, FLAGS) for (p, n, po, nf) in dev.items]   # nothing synced yet
+    inflight = [d.decode_device(p, n, po if sidecar else None, nf if sidecar else 0, FLAGS) for (p, n, po, nf) in dev.items]   # nothing synced yet
     res = []
     for (buf, offs), b in zip(pieces, inflight):
         rb = o.decode(buf, offs)
@@ -128,3 +128,22 @@ def test_async_chain_when_the_plan_does_not_cover_a_batch():
     pieces[1] = (nb, no)
     paths = _run_chain(w, pieces)
     assert paths["plan_redone"] >= 1 and paths["redone"] == 0, paths
+
+
+def test_async_chain_without_a_sidecar():
+    """frame_offsets = NULL + ASYNC: every batch scans its own record boundaries (on the scan stream, into an offsets buffer the
+    batch owns) and is chained on the device like the others; an error in the middle still re-runs the batches behind it."""
+    w = synth.cfg2()
+    buf, offs = w.fill(2 << 20)
+    pieces = _cut(buf, offs, 6, seed=17)
+    paths = _run_chain(w, pieces, sidecar=False)
+    assert paths["redone"] == 0 and paths["chain_rerun"] == 0 and paths["plan"] == 6, paths
+    w = synth.cfg3()
+    buf, offs = w.fill(2 << 20)
+    pieces = _cut(buf, offs, 5, seed=23)
+    b2, o2 = pieces[2]
+    k = int(o2[len(o2) // 2])
+    while b2[k + 30] != ord("I"):
+        k = int(o2[np.searchsorted(o2, k, side="right")])
+    b2[k + 31:k + 35] = 0xEE     # an Insert for a relation id nobody registered
+    paths = _run_chain(w, pieces, sidecar=False)

@@ -134,6 +134,8 @@ def test_constants_match_the_header():
                 pass
     for m in re.finditer(r"#define (ETLG_[A-Z0-9_]+) (\d+)u", HDR):
         vals[m.group(1)] = int(m.group(2))
+    for m in re.finditer(r"#define (ETLG_[A-Z0-9_]+) \((\d+)ull << (\d+)\)", HDR):
+        vals[m.group(1)] = int(m.group(2)) << int(m.group(3))
     seen = 0
     for m in re.finditer(r"pub const (ETLG_[A-Za-z0-9_]+): [a-z0-9]+ = ([^;]+);", FFI):
         name, v = m.group(1), m.group(2).strip()
