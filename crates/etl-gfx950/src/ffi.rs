@@ -182,6 +182,11 @@ pub struct etlg_column {
     pub values: *const u8,
     pub offsets: *const i64,
     pub values_bytes: u64,
+    pub child_kind: u32,
+    pub _pad: u32,
+    pub child_count: u64,
+    pub child_null_count: u64,
+    pub child_validity: *const u8,
 }
 
 #[repr(C)]
@@ -237,6 +242,7 @@ pub struct etlg_rowbinary {
 
 pub const ETLG_ROWS_INSERT: u32 = 1;
 pub const ETLG_ROWS_UPDATE: u32 = 2;
+pub const ETLG_ROWS_PARSE_ARRAYS: u32 = 4;
 pub const ETLG_CH_MERGE_TREE: i32 = 0;
 pub const ETLG_CH_REPLACING_MERGE_TREE: i32 = 1;
 pub const ETLG_RB_OK: u32 = 0;

@@ -126,6 +126,40 @@ impl GpuDecoder {
     }
 }
 
+/// The reference's own type sizes for `etlg_batch_size_hints` (the device evaluates Event::size_hint, event.rs:295-320, with
+/// them): layouts are not ABI-stable, so they are taken from THIS build of the `etl` crate, once.
+pub fn reference_size_model() -> etlg_size_model {
+    use etl::data::{Cell, TableRow};
+    use etl::event::{BeginEvent, CommitEvent, DeleteEvent, InsertEvent, RelationEvent, TruncateEvent, UpdateEvent};
+    use etl::schema::ReplicatedTableSchema;
+    use std::mem::size_of;
+    etlg_size_model {
+        begin_event: size_of::<BeginEvent>() as u32,
+        commit_event: size_of::<CommitEvent>() as u32,
+        insert_event: size_of::<InsertEvent>() as u32,
+        update_event: size_of::<UpdateEvent>() as u32,
+        delete_event: size_of::<DeleteEvent>() as u32,
+        truncate_event: size_of::<TruncateEvent>() as u32,
+        relation_event: size_of::<RelationEvent>() as u32,
+        replicated_table_schema: size_of::<ReplicatedTableSchema>() as u32,
+        table_row: size_of::<TableRow>() as u32,
+        cell: size_of::<Cell>() as u32,
+        _reserved: [0; 2],
+    }
+}
+
+impl GpuDecoder {
+    /// Device-resident decode + per-event size hints, for a batcher that wants the reference's cut points
+    /// (EventBatch::push, apply.rs:656-657; flush rule :1932-1935) without materialising `Event`s first. Entries with
+    /// ETLG_SIZE_HINT_INCOMPLETE set hold everything but the parts only the host can size (json / array cells, partial rows).
+    pub fn size_hints(&mut self, batch: *mut etlg_batch, n_events: usize) -> EtlResult<Vec<u64>> {
+        let model = reference_size_model();
+        let mut out = vec![0u64; n_events];
+        let rc = unsafe { etlg_batch_size_hints(self.ctx, batch, &model, 0, out.as_mut_ptr()) };
+        if rc == ETLG_OK { Ok(out) } else { Err(self.last_error()) }
+    }
+}
+
 impl Drop for GpuDecoder {
     fn drop(&mut self) {
         unsafe { etlg_ctx_destroy(self.ctx) };

@@ -99,7 +99,9 @@ class BatchView(C.Structure):
 class Column(C.Structure):   # etlg_column
     _fields_ = [("type_class", C.c_uint32), ("arrow_kind", C.c_uint32), ("value_bytes", C.c_uint32), ("nullable", C.c_uint32),
                 ("null_count", C.c_uint64), ("deferred_count", C.c_uint64), ("validity", C.c_void_p), ("deferred", C.c_void_p),
-                ("values", C.c_void_p), ("offsets", C.c_void_p), ("values_bytes", C.c_uint64)]
+                ("values", C.c_void_p), ("offsets", C.c_void_p), ("values_bytes", C.c_uint64),
+                ("child_kind", C.c_uint32), ("_pad", C.c_uint32), ("child_count", C.c_uint64), ("child_null_count", C.c_uint64),
+                ("child_validity", C.c_void_p)]
 
 
 class ColumnsView(C.Structure):   # etlg_columns_view
@@ -122,9 +124,9 @@ SIZE_HINT_INCOMPLETE = 1 << 63
 CH_MERGE_TREE, CH_REPLACING_MERGE_TREE = 0, 1
 RB_OK, RB_NEEDS_HOST = 0, 3
 (AK_BOOLEAN, AK_INT32, AK_INT64, AK_FLOAT32, AK_FLOAT64, AK_DATE32, AK_TIME64_US, AK_TIMESTAMP_US, AK_TIMESTAMP_US_UTC, AK_FIXED16,
- AK_LARGE_UTF8, AK_LARGE_BINARY, AK_TEXT_FORM) = range(13)
+ AK_LARGE_UTF8, AK_LARGE_BINARY, AK_TEXT_FORM, AK_LIST) = range(14)
 AK_NONE = 255
-ROWS_INSERT, ROWS_UPDATE = 1, 2
+ROWS_INSERT, ROWS_UPDATE, ROWS_PARSE_ARRAYS = 1, 2, 4
 
 
 class KernelStat(C.Structure):

@@ -123,12 +123,20 @@ def columns_to_record_batch(cols, names=None, columns=None, on_text="raise"):
         name = names[i] if names else f"c{i}"
         if k.arrow_kind == abi.AK_NONE:
             raise NotImplementedError(f"column {name}: timetz values are not handed off (select other columns with columns=)")
-        if (k.arrow_kind == abi.AK_TEXT_FORM or k.deferred_count) and on_text != "binary":
+        if (k.arrow_kind == abi.AK_TEXT_FORM or (k.deferred_count and k.arrow_kind != abi.AK_LIST)) and on_text != "binary":
             raise NotImplementedError(f"column {name} (type class {k.type_class}): text-form cells (numeric / json / arrays / deferred) "
                                       "have no fixed-width Arrow form; pass on_text='binary' (deferred cells of a fixed-width "
                                       "column come back null, flagged in the column's `deferred` bitmap)")
         validity, _deferred, values, offsets = cols.host_arrays(i)
         vbuf = None if k.null_count == 0 else pa.py_buffer(validity)
+        if k.arrow_kind == abi.AK_LIST:   # array literal parsed on the device: LargeList<child>
+            ct = types[k.child_kind]
+            cv = None if k.child_null_count == 0 else pa.py_buffer(cols.child_validity(i))
+            child = pa.Array.from_buffers(ct, int(k.child_count), [cv, pa.py_buffer(values)], null_count=int(k.child_null_count))
+            t = pa.large_list(ct)
+            arrays.append(pa.Array.from_buffers(t, n, [vbuf, pa.py_buffer(offsets)], null_count=int(k.null_count), children=[child]))
+            fields.append(pa.field(name, t, nullable=bool(k.nullable)))
+            continue
         t = types[k.arrow_kind]
         bufs = [vbuf, pa.py_buffer(values)] if offsets is None else [vbuf, pa.py_buffer(offsets), pa.py_buffer(values)]
         arr = pa.Array.from_buffers(t, n, bufs, null_count=int(k.null_count))

@@ -194,6 +194,126 @@ __global__ __launch_bounds__(256) void k_col_copy(ColJob j) {
 }
 
 
+// ---- array literals (parse_cell_from_postgres_text_array, crates/etl/src/postgres/codec/text.rs:228-312; the dimensions
+// prefix :163-214) for the element classes with a fixed-width value: bool, int2, int4, int8, oid. One thread per row walks its
+// text twice: k_arr_count (shape errors, element parse errors, element count), then k_arr_fill behind the offsets scan.
+constexpr uint32_t kArrElemMax = 40;   // an element text longer than this is left to the host (Rust accepts any number of leading zeros)
+enum : uint32_t { ARR_HOST = 0x100 };  // not an error: the row is handed back deferred
+
+DEV uint32_t arr_strip_dims(const u8* s, uint32_t n, uint32_t& start) {   // strip_array_dimensions_prefix
+  auto at = [&](uint32_t i) -> int { return i < n ? (int)s[i] : -1; };
+  start = 0;
+  if (at(0) != '[') return 0;
+  uint32_t groups = 0, idx = 0;
+  auto skip_int = [&](uint32_t i, uint32_t& out) { if (at(i) == '-') i++; const uint32_t st = i; while (at(i) >= '0' && at(i) <= '9') i++; out = i; return i > st; };
+  while (at(idx) == '[') {
+    uint32_t a, b;
+    if (!skip_int(idx + 1, a) || at(a) != ':') return ETLG_E_ARRAY_DIMS;
+    if (!skip_int(a + 1, b) || at(b) != ']') return ETLG_E_ARRAY_DIMS;
+    idx = b + 1; groups++;
+  }
+  if (at(idx) != '=') return ETLG_E_ARRAY_DIMS;
+  if (groups > 1) return ETLG_E_ARRAY_MULTIDIM;
+  start = idx + 1;
+  return 0;
+}
+
+// Calls elem(k, is_null, value words) per element in text order; returns 0, an etlg_err_code, or ARR_HOST.
+template <class F>
+DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& count, F&& elem) {
+  uint32_t start;
+  count = 0;
+  if (const uint32_t e = arr_strip_dims(s0, n0, start)) return e;
+  const u8* s = s0 + start;
+  const uint32_t n = n0 - start;
+  if (n < 2) return ETLG_E_ARRAY_SHORT;
+  if (s[0] != '{' || s[n - 1] != '}') return ETLG_E_ARRAY_BRACES;
+  const u8* body = s + 1;
+  const uint32_t bn = n - 2;
+  u8 val[kArrElemMax];
+  uint32_t vl = 0, pos = 0;
+  bool in_quotes = false, in_escape = false, val_quoted = false, done = bn == 0, too_long = false;
+  while (!done) {
+    for (;;) {
+      if (pos >= bn) { done = true; break; }
+      const u8 c = body[pos++];
+      bool push = false;
+      if (in_escape) { push = true; in_escape = false; }
+      else if (c == '"') { if (!in_quotes) val_quoted = true; in_quotes = !in_quotes; }
+      else if (c == '\\') in_escape = true;
+      else if ((c == '{' || c == '}') && !in_quotes) return ETLG_E_ARRAY_MULTIDIM;
+      else if (c == ',' && !in_quotes) break;
+      else push = true;
+      if (push) { if (vl < kArrElemMax) val[vl] = c; else too_long = true; vl++; }
+    }
+    if (in_quotes) return ETLG_E_ARRAY_QUOTE;
+    if (in_escape) return ETLG_E_ARRAY_ESCAPE;
+    if (too_long) return ARR_HOST;
+    const bool is_null = !val_quoted && vl == 4 && (val[0] | 0x20) == 'n' && (val[1] | 0x20) == 'u' && (val[2] | 0x20) == 'l' && (val[3] | 0x20) == 'l';
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (!is_null) {
+      uint32_t hcur = 0, st = 0;
+      if (const uint32_t e = decode_text_cell<true>(elem_cls, val, vl, w, nullptr, hcur, st, false)) return e;
+    }
+    elem(count, is_null, w);
+    count++;
+    vl = 0; val_quoted = false;
+  }
+  return 0;
+}
+
+DEV bool arr_text(const ColJob& j, uint64_t r, const u8*& s, uint32_t& n, uint32_t& st) {
+  const uint64_t b = j.row_base[r];
+  st = col_state(j, b);
+  if (st != ETLG_CELL_VALUE && st != ETLG_CELL_DEFERRED) return false;
+  const u8* slot = j.fixed + b + j.off_full;
+  s = j.heap + ld32a(slot); n = ld32a(slot + 4);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_arr_count(ColJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < j.n_rows;
+  bool valid = false, defer = false;
+  if (live) {
+    const u8* s; uint32_t n, st, cnt = 0;
+    if (arr_text(j, r, s, n, st)) {
+      const uint32_t e = arr_walk(s, n, j.elem_cls, cnt, [](uint32_t, bool, const uint32_t*) {});
+      if (e == ARR_HOST) { defer = true; cnt = 0; }
+      else if (e) { atomicMin(j.err, (unsigned long long)((r << 8) | e)); cnt = 0; }
+      else valid = true;
+    }
+    j.lens[r] = cnt;
+  }
+  const unsigned long long vm = __ballot(valid), dm = __ballot(defer), lm = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && lm) {
+    j.validity[r >> 6] = vm; j.deferred[r >> 6] = dm;
+    const uint32_t nulls = (uint32_t)__builtin_popcountll(lm & ~vm), nd = (uint32_t)__builtin_popcountll(dm);
+    if (nulls) atomicAdd(j.null_count, (unsigned long long)nulls);
+    if (nd) atomicAdd(j.deferred_count, (unsigned long long)nd);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= j.n_rows || !j.lens[r]) return;
+  const u8* s; uint32_t n, st, cnt;
+  if (!arr_text(j, r, s, n, st)) return;
+  const uint64_t o = (uint64_t)j.offsets[r];
+  uint32_t nulls = 0;
+  (void)arr_walk(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w) {
+    const uint64_t e = o + k;
+    if (is_null) { nulls++; }
+    else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
+    switch (j.kind) {   // child layout
+      case AK_BOOL: if (!is_null && w[0]) atomicOr(&((uint32_t*)j.values)[e >> 5], 1u << (e & 31)); break;
+      case AK_I32: ((uint32_t*)j.values)[e] = w[0]; break;
+      default: ((uint64_t*)j.values)[e] = j.elem_cls == ETLG_TC_U32 ? (uint64_t)w[0] : ((uint64_t)w[1] << 32) | w[0]; break;
+    }
+  });
+  if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
+}
+
 // ---- ClickHouse RowBinary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83 which wire type a Cell becomes,
 // :188-283 the byte format; core.rs:96-114 the trailing CDC columns). One thread per row, run twice: lengths, then bytes.
 enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3 };
@@ -397,6 +517,21 @@ void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, i
     hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
   } else {
     hipLaunchKernelGGL(k_col_copy, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
+  }
+}
+
+// list columns: step 0 = element counts + list offsets, step 1 = child values / validity
+void etlg_k_col_list(const void* jv, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st) {
+  const ColJob j = *(const ColJob*)jv;
+  if (!j.n_rows) return;
+  const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
+  if (step == 0) {
+    hipLaunchKernelGGL(k_arr_count, dim3(nb), dim3(256), 0, st, j);
+    hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, blk);
+    hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
+    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
+  } else {
+    hipLaunchKernelGGL(k_arr_fill, dim3(nb), dim3(256), 0, st, j);
   }
 }
 

@@ -194,6 +194,9 @@ struct ColJob {
   unsigned long long* validity; unsigned long long* deferred; uint8_t* values;
   unsigned long long* null_count; unsigned long long* deferred_count;
   uint32_t* lens; const int64_t* offsets;   // var-len
+  // list columns (array literals parsed on the device): element class, child validity words, child null counter, first error
+  uint32_t elem_cls, _pad;
+  uint32_t* child_validity; unsigned long long* child_nulls; unsigned long long* err;
 };
 
 struct HintJob {           // Event::size_hint per event (k_size_hints)

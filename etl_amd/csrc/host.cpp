@@ -46,6 +46,7 @@ extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_
 extern "C" int etlg_k_plan_set_lds(void);
 extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
 extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
+extern "C" void etlg_k_col_list(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" void etlg_k_size_hints(const void* job, hipStream_t s);
 extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" void etlg_k_col_var(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
@@ -1368,9 +1369,18 @@ void etlg_batch_free(etlg_batch* b) {
   delete b;
 }
 
+extern "C++" {
 // ---- columnar hand-off (columns.hip)
 namespace {
-struct ColPlan { uint32_t kind, vbytes; bool var; };
+struct ColPlan { uint32_t kind, vbytes; bool var; uint32_t child = 0, child_bytes = 0, elem = 0; };
+ColPlan list_plan(uint32_t elem) {  // array literals the device parses: element classes with a fixed-width value
+  switch (elem) {
+    case ETLG_TC_BOOL: return {ETLG_AK_LIST, 0, true, ETLG_AK_BOOLEAN, 0, elem};
+    case ETLG_TC_I16: case ETLG_TC_I32: return {ETLG_AK_LIST, 0, true, ETLG_AK_INT32, 4, elem};
+    case ETLG_TC_I64: case ETLG_TC_U32: return {ETLG_AK_LIST, 0, true, ETLG_AK_INT64, 8, elem};
+    default: return {ETLG_AK_TEXT_FORM, 0, true};
+  }
+}
 ColPlan col_plan(uint32_t cls) {
   switch (cls) {
     case ETLG_TC_BOOL: return {ETLG_AK_BOOLEAN, 0, false};
@@ -1390,6 +1400,7 @@ ColPlan col_plan(uint32_t cls) {
   }
 }
 }  // namespace
+}  // extern "C++"
 
 int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t row_kinds, uint32_t flags, etlg_columns** out) {
   if (!c || !b || !out || b->ctx != c) return ETLG_InvalidArgument;
@@ -1397,6 +1408,7 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
   if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_columns needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
   if (slot < 0 || (size_t)slot >= c->slots.size() || !(row_kinds & 3u)) return ETLG_InvalidArgument;
+  const bool parse_arrays = (row_kinds & ETLG_ROWS_PARSE_ARRAYS) != 0;
   const SlotHost& sh = *c->slots[(size_t)slot];
   hipStream_t s = c->stream;
   const etlg_batch_view& bv = b->v;
@@ -1433,19 +1445,24 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   for (uint32_t i = 0; i < nc; i++) {
     Lay& l = lay[i];
     l.pl = col_plan(sh.cols[i].type_class);
+    if (parse_arrays && sh.cols[i].type_class == ETLG_TC_ARRAY) l.pl = list_plan((uint32_t)etlg_array_elem_class(sh.cols[i].type_oid));
     l.validity = l.deferred = l.values = l.lens = l.offsets = 0;
     if (l.pl.kind == ETLG_AK_NONE) continue;
     l.validity = off; off += bm; l.deferred = off; off += bm;
     if (l.pl.var) { l.offsets = off; off += al((n + 1) * 8); l.lens = off; off += al(n * 4); }
     else { l.values = off; off += l.pl.kind == ETLG_AK_BOOLEAN ? bm : al(n * l.pl.vbytes); }
   }
-  const size_t o_cnt = off; off += al((size_t)nc * 16);
+  const size_t o_cnt = off; off += al((size_t)nc * 32);   // per column: nulls, deferred, child nulls, first list error
   const uint32_t nrb = (uint32_t)((n + 255) / 256);
   const size_t o_scan = off; off += al((size_t)(nrb + 1) * 8);   // one scan scratch: var-len columns run one after another on the stream
   const size_t a_bytes = off + 64;
   HIPCHK(c, hipMalloc(&cs->d_a, a_bytes));
   uint8_t* A = (uint8_t*)cs->d_a;
-  HIPCHK(c, hipMemsetAsync(A + o_cnt, 0, (size_t)nc * 16, s));
+  {
+    std::vector<unsigned long long> init((size_t)nc * 4, 0ull);
+    for (uint32_t i = 0; i < nc; i++) init[(size_t)i * 4 + 3] = ~0ull;
+    if (nc) HIPCHK(c, hipMemcpy(A + o_cnt, init.data(), (size_t)nc * 32, hipMemcpyHostToDevice));
+  }
   if (n) HIPCHK(c, hipMemcpyAsync(A, d_row_event, n * 8, hipMemcpyDeviceToDevice, s));
   std::vector<ColJob> jobs(nc);
   std::vector<int64_t> var_total(nc, 0);
@@ -1457,11 +1474,13 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
     j.fixed = bv.fixed; j.heap = bv.heap; j.row_base = d_row_base; j.n_rows = n;
     j.col_index = i; j.off_full = sh.cols[i].off_full; j.cls = sh.cols[i].type_class; j.kind = l.pl.kind;
     j.validity = (unsigned long long*)(A + l.validity); j.deferred = (unsigned long long*)(A + l.deferred);
-    j.null_count = (unsigned long long*)(A + o_cnt + (size_t)i * 16); j.deferred_count = j.null_count + 1;
+    j.null_count = (unsigned long long*)(A + o_cnt + (size_t)i * 32); j.deferred_count = j.null_count + 1;
+    j.child_nulls = j.null_count + 2; j.err = j.null_count + 3; j.elem_cls = l.pl.elem;
     if (l.pl.var) {
       j.lens = (uint32_t*)(A + l.lens); j.offsets = (const int64_t*)(A + l.offsets);
       if (n) {
-        etlg_k_col_var(&j, (unsigned long long*)(A + o_scan), (int64_t*)(A + l.offsets), 0, s);
+        if (l.pl.kind == ETLG_AK_LIST) { j.kind = l.pl.child; etlg_k_col_list(&j, (unsigned long long*)(A + o_scan), (int64_t*)(A + l.offsets), 0, s); }
+        else etlg_k_col_var(&j, (unsigned long long*)(A + o_scan), (int64_t*)(A + l.offsets), 0, s);
         HIPCHK(c, hipMemcpyAsync(&var_total[i], A + l.offsets + n * 8, 8, hipMemcpyDeviceToHost, s));
       } else {
         HIPCHK(c, hipMemsetAsync(A + l.offsets, 0, 8, s));
@@ -1471,17 +1490,44 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
       etlg_k_col_fixed(&j, s);
     }
   }
-  std::vector<uint64_t> cnt((size_t)nc * 2, 0);
-  if (nc) HIPCHK(c, hipMemcpyAsync(cnt.data(), A + o_cnt, (size_t)nc * 16, hipMemcpyDeviceToHost, s));
+  std::vector<uint64_t> cnt((size_t)nc * 4, 0);
+  if (nc) HIPCHK(c, hipMemcpyAsync(cnt.data(), A + o_cnt, (size_t)nc * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  {  // a malformed array literal: the reference's error, for the first such row in event order
+    uint64_t first = ~0ull;
+    for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.kind == ETLG_AK_LIST) first = std::min(first, cnt[(size_t)i * 4 + 3]);
+    if (first != ~0ull) {
+      uint64_t ev = 0;
+      HIPCHK(c, hipMemcpy(&ev, d_row_event + (first >> 8), 8, hipMemcpyDeviceToHost));
+      return set_error(c, (int32_t)(first & 0xFF), (int64_t)ev);
+    }
+  }
   // ---- 3. block B: the bytes of the var-len columns
   std::vector<size_t> vb(nc, 0);
   size_t b_bytes = 0;
-  for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.var) { vb[i] = b_bytes; b_bytes += al((size_t)var_total[i]); }
+  std::vector<size_t> cvb(nc, 0), vbytes(nc, 0);   // list columns: child validity offset; bytes behind `values`
+  for (uint32_t i = 0; i < nc; i++) {
+    if (!lay[i].pl.var) continue;
+    const size_t tot = (size_t)var_total[i];
+    vb[i] = b_bytes;
+    if (lay[i].pl.kind == ETLG_AK_LIST) {
+      const size_t bits = (tot + 63) / 64 * 8;
+      vbytes[i] = lay[i].pl.child == ETLG_AK_BOOLEAN ? bits : tot * lay[i].pl.child_bytes;
+      b_bytes += al(vbytes[i]); cvb[i] = b_bytes; b_bytes += al(bits);
+    } else { vbytes[i] = tot; b_bytes += al(tot); }
+  }
   if (b_bytes) HIPCHK(c, hipMalloc(&cs->d_b, b_bytes + 64));
   uint8_t* B = (uint8_t*)cs->d_b;
-  for (uint32_t i = 0; i < nc; i++)
-    if (lay[i].pl.var && var_total[i] > 0) { jobs[i].values = B + vb[i]; etlg_k_col_var(&jobs[i], nullptr, nullptr, 1, s); }
+  for (uint32_t i = 0; i < nc; i++) {
+    if (!lay[i].pl.var || var_total[i] <= 0) continue;
+    jobs[i].values = B + vb[i];
+    if (lay[i].pl.kind == ETLG_AK_LIST) {
+      jobs[i].child_validity = (uint32_t*)(B + cvb[i]);
+      HIPCHK(c, hipMemsetAsync(B + vb[i], 0, cvb[i] - vb[i] + al(((size_t)var_total[i] + 63) / 64 * 8), s));   // bitmaps are OR-ed into
+      etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s);
+    } else etlg_k_col_var(&jobs[i], nullptr, nullptr, 1, s);
+  }
+  if (nc) HIPCHK(c, hipMemcpyAsync(cnt.data(), A + o_cnt, (size_t)nc * 32, hipMemcpyDeviceToHost, s));   // again: the child null counts
   // ---- 4. the view (device pointers, or a host copy of both blocks)
   const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
   const uint8_t* base_a = A; const uint8_t* base_b = B;
@@ -1500,10 +1546,14 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
     k = etlg_column{};
     k.type_class = sh.cols[i].type_class; k.arrow_kind = l.pl.kind; k.value_bytes = l.pl.vbytes; k.nullable = sh.cols[i].nullable;
     if (l.pl.kind == ETLG_AK_NONE) continue;
-    k.null_count = cnt[(size_t)i * 2]; k.deferred_count = cnt[(size_t)i * 2 + 1];
+    k.null_count = cnt[(size_t)i * 4]; k.deferred_count = cnt[(size_t)i * 4 + 1];
     k.validity = base_a + l.validity; k.deferred = base_a + l.deferred;
-    if (l.pl.var) { k.offsets = (const int64_t*)(base_a + l.offsets); k.values = base_b ? base_b + vb[i] : nullptr; k.values_bytes = (uint64_t)var_total[i]; }
-    else { k.values = base_a + l.values; k.values_bytes = l.pl.kind == ETLG_AK_BOOLEAN ? ((n + 63) / 64) * 8 : n * l.pl.vbytes; }
+    if (l.pl.var) { k.offsets = (const int64_t*)(base_a + l.offsets); k.values = base_b ? base_b + vb[i] : nullptr; k.values_bytes = (uint64_t)vbytes[i]; }
+    if (l.pl.kind == ETLG_AK_LIST) {
+      k.child_kind = l.pl.child; k.child_count = (uint64_t)var_total[i]; k.child_null_count = cnt[(size_t)i * 4 + 2];
+      k.child_validity = base_b ? base_b + cvb[i] : nullptr;
+    }
+    if (!l.pl.var) { k.values = base_a + l.values; k.values_bytes = l.pl.kind == ETLG_AK_BOOLEAN ? ((n + 63) / 64) * 8 : n * l.pl.vbytes; }
   }
   cs->v.n_rows = n; cs->v.n_cols = nc; cs->v.on_device = on_dev ? 1u : 0u; cs->v.cols = cs->cols.data();
   cs->v.row_event = (const uint64_t*)base_a;

@@ -60,10 +60,11 @@ class Batch:
             v = self.view()
         return HostBatch.from_view(v)
 
-    def columns(self, slot, kinds=("I",), on_device=False):
+    def columns(self, slot, kinds=("I",), on_device=False, parse_arrays=False):
         """Arrow-layout column buffers of the rows decoded against schema slot `slot`, built on the device
-        (etlg_batch_columns). The batch must still be device-resident."""
-        rk = (abi.ROWS_INSERT if "I" in kinds else 0) | (abi.ROWS_UPDATE if "U" in kinds else 0)
+        (etlg_batch_columns). The batch must still be device-resident. parse_arrays: bool / int2 / int4 / int8 / oid array
+        columns are parsed on the device into list columns (abi.AK_LIST); a malformed literal raises the reference's error."""
+        rk = (abi.ROWS_INSERT if "I" in kinds else 0) | (abi.ROWS_UPDATE if "U" in kinds else 0) | (abi.ROWS_PARSE_ARRAYS if parse_arrays else 0)
         out = C.c_void_p()
         rc = self.dec.L.etlg_batch_columns(self.dec.h, self.h, slot, rk, abi.F_OUTPUT_ON_DEVICE if on_device else 0, C.byref(out))
         if rc != abi.OK or not out:
@@ -131,6 +132,10 @@ class Columns:
         bm = (n + 63) // 64 * 8
         offs = self._np(k.offsets, (n + 1) * 8, np.int64) if k.offsets else None
         return self._np(k.validity, bm, np.uint8), self._np(k.deferred, bm, np.uint8), self._np(k.values, int(k.values_bytes), np.uint8), offs
+
+    def child_validity(self, i):
+        k = self.view.cols[i]
+        return self._np(k.child_validity, (int(k.child_count) + 63) // 64 * 8, np.uint8)
 
     def row_event(self):
         return self._np(self.view.row_event, self.n_rows * 8, np.uint64)

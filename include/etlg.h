@@ -496,6 +496,9 @@ typedef enum etlg_arrow_kind {
   ETLG_AK_LARGE_BINARY = 11,
   ETLG_AK_TEXT_FORM = 12,   /* numeric / json / arrays: the cell's heap entry (etlg_numeric_hdr + digits, or
                              * the source text), i64 offsets + bytes; the host finishes it */
+  ETLG_AK_LIST = 13,        /* only with ETLG_ROWS_PARSE_ARRAYS: bool[] / int2[] / int4[] / int8[] / oid[] parsed on the device
+                             * (parse_cell_from_postgres_text_array, codec/text.rs:228-312): i64 list offsets in `offsets`,
+                             * child values in `values` (child_kind layout), child validity in `child_validity` */
   ETLG_AK_NONE = 255        /* not handed off (timetz: a display string in the reference) - no buffers */
 } etlg_arrow_kind;
 
@@ -512,6 +515,12 @@ typedef struct etlg_column {
   const uint8_t* values;
   const int64_t* offsets;   /* var-len kinds: n_rows + 1 entries, else NULL */
   uint64_t values_bytes;    /* bytes behind `values` */
+  /* ETLG_AK_LIST only */
+  uint32_t child_kind;      /* ETLG_AK_BOOLEAN | ETLG_AK_INT32 (int2, int4) | ETLG_AK_INT64 (int8, oid) */
+  uint32_t _pad;
+  uint64_t child_count;     /* elements of all rows = offsets[n_rows] */
+  uint64_t child_null_count;
+  const uint8_t* child_validity; /* child_count bits */
 } etlg_column;
 
 typedef struct etlg_columns_view {
@@ -526,6 +535,9 @@ typedef struct etlg_columns etlg_columns;
 
 #define ETLG_ROWS_INSERT 1u  /* Insert rows */
 #define ETLG_ROWS_UPDATE 2u  /* the new row of non-partial Updates */
+#define ETLG_ROWS_PARSE_ARRAYS 4u /* array columns of a fixed-width element class become ETLG_AK_LIST; a malformed literal
+                                   * fails the call with the reference's error (ETLG_E_ARRAY_* / the element's parse error,
+                                   * frame_index = the event index), as parse_cell_from_postgres_text does at decode time */
 
 /* `batch` must be device-resident (decoded with ETLG_F_OUTPUT_ON_DEVICE, not downloaded) and finished
  * (an ETLG_F_ASYNC batch is synced first). flags: ETLG_F_OUTPUT_ON_DEVICE keeps the buffers in HBM, otherwise

@@ -166,3 +166,76 @@ def test_buffers_can_stay_on_the_device():
         if hv[3] is not None:
             assert np.array_equal(read(dk.offsets, (n + 1) * 8).view(np.int64), hv[3])
     host.close(); dev.close(); b.close(); d.close()
+
+
+ARR_COLS = [("id", SC.INT8, False, 1), ("a4", 1007, True, 0), ("a8", 1016, True, 0), ("a2", 1005, True, 0), ("ab", 1000, True, 0),
+            ("ao", 1028, True, 0), ("at", 1009, True, 0)]
+
+
+def _oracle_list(oid, text):
+    """The oracle's parse of one array literal (parse_array_text, oracle_codec.hpp — text.rs:228-312) as a Python list."""
+    from oracle import oracle
+    r = oracle.parse_text_cell(oid, text)
+    assert r.startswith("Array["), r
+    body = r[6:-1]
+    out = []
+    for e in ([] if not body else body.split(",")):
+        if e == "NULL":
+            out.append(None)
+        elif e.startswith("Bool("):
+            out.append(e == "Bool(true)")
+        else:
+            out.append(int(e[e.index("(") + 1:-1]))
+    return out
+
+
+def test_array_literals_are_parsed_on_the_device():
+    """bool[] / int2[] / int4[] / int8[] / oid[] columns come back as list columns whose rows equal the oracle's parse of the same
+    literal: dimension prefixes, quotes, escapes, NULL (any case, unquoted only), empty arrays, NULL cells; text[] stays text."""
+    lits4 = ["{1,NULL,3}", "{}", "[1:2]={1,2}", '{"1",2}', "{+5,-0}", "{-2147483648,2147483647}", '{"\\1",null,NuLl}', "[-1:0]={7,8}", "{0}"]
+    lits8 = ["{9223372036854775807,-9223372036854775808}", "{}", "{NULL}", "{1}", '{"12"}']
+    lits2 = ["{-32768,32767}", "{1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40}", "{}"]
+    litsb = ["{t,f,NULL}", "{}", '{"t"}', "{f}"]
+    litso = ["{0,4294967295}", "{NULL,7}", "{}"]
+    rows = []
+    for i in range(90):
+        rows.append([str(i), lits4[i % len(lits4)], lits8[i % len(lits8)], lits2[i % len(lits2)], litsb[i % len(litsb)],
+                     litso[i % len(litso)], '{a,"b c",NULL}'])
+    rows.append(["900"] + [W.NULL] * 6)
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(ARR_COLS), buf, offs)
+    names = [c[0] for c in ARR_COLS]
+    cols = b.columns(0, parse_arrays=True)
+    assert [cols.column(i).arrow_kind for i in range(1, 7)] == [abi.AK_LIST] * 5 + [abi.AK_TEXT_FORM]
+    rb = columns_to_record_batch(cols, names=names, on_text="binary")
+    assert rb.schema.field("a4").type == pa.large_list(pa.int32()) and rb.schema.field("a8").type == pa.large_list(pa.int64())
+    assert rb.schema.field("a2").type == pa.large_list(pa.int32()) and rb.schema.field("ab").type == pa.large_list(pa.bool_())
+    assert rb.schema.field("ao").type == pa.large_list(pa.int64())
+    for ci, oid in ((1, 1007), (2, 1016), (3, 1005), (4, 1000), (5, 1028)):
+        want = [None if r[ci] is W.NULL else _oracle_list(oid, r[ci]) for r in rows]
+        assert rb.column(ci).to_pylist() == want, names[ci]
+    assert rb.column(6).to_pylist()[0] == b'{a,"b c",NULL}'
+    # without the flag the same columns are their source text, as before
+    plain = b.columns(0)
+    assert plain.column(1).arrow_kind == abi.AK_TEXT_FORM
+    plain.close(); cols.close(); b.close(); d.close()
+
+
+@pytest.mark.parametrize("lit,col", [("{1,{2}}", 1), ("{1,2", 1), ("{a}", 1), ("[1:2={1}", 1), ("[1:1][1:1]={{1}}", 1), ('{"1}', 1), ("{1\\}", 1),
+                                     ("{2}", 4), ("{99999}", 3), ("{-1}", 5), ("}", 2), ("{ 1}", 2)])
+def test_malformed_array_literals_fail_like_the_reference(lit, col):
+    from etl_amd.decoder import EtlError
+    from oracle import oracle
+    good = ["1", "{1}", "{1}", "{1}", "{t}", "{1}", "{x}"]
+    bad = list(good)
+    bad[0], bad[col] = "2", lit
+    buf, offs = _stream([W.insert(42, good), W.insert(42, bad), W.insert(42, good)])
+    hb, b, d = _both(SC.simple_table(ARR_COLS), buf, offs)
+    want = oracle.parse_text_cell(ARR_COLS[col][1], lit)
+    assert want.startswith("Err("), want
+    with pytest.raises(EtlError) as ei:
+        b.columns(0, parse_arrays=True)
+    assert ei.value.code == int(want[4:-1]) and ei.value.frame_index == 2
+    o = oracle.Oracle()
+    assert ei.value.description == o.L.oracle_err_description(ei.value.code).decode()
+    b.close(); d.close()
