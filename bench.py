@@ -174,6 +174,33 @@ def to_device(pool, dev):
     return d
 
 
+def deferred_cells(dec, item):
+    """Share of the row cells of one batch that the kernels hand back DEFERRED (the host finishes them: json, arrays, the
+    float / temporal texts the device rule does not settle) — counted from the arena's 2-bit cell states, outside any timed
+    region (VERDICT r01 #9: "the deferred fraction is reported in the bench line")."""
+    import numpy as np
+
+    from etl_amd import abi
+    tb, to, nbytes, nfr = item
+    b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
+    hb = b.host()
+    b.close()
+    cells = deferred = 0
+    for si, slot in enumerate(hb.slots):
+        n = len(slot.cols)
+        for kind, full in ((ord("I"), True), (ord("U"), True)):
+            sel = (hb.kind == kind) & (hb.schema_slot == si)
+            base = hb.body_off[sel].astype(np.int64)
+            if kind == ord("U"):
+                ok = hb.flags[sel] & 3
+                base = base + np.where(ok == abi.OLD_FULL, slot.row_bytes_full, np.where(ok == abi.OLD_KEY, slot.row_bytes_key, 0))
+            for i in range(n):
+                st = (hb.fixed[base + i // 4] >> np.uint8(2 * (i % 4))) & 3
+                cells += len(st)
+                deferred += int((st == abi.CELL_DEFERRED).sum())
+    return {"cells": cells, "deferred": deferred, "frac": round(deferred / cells, 8) if cells else 0.0}
+
+
 def leg_async(mk, dev_id, dev, cap, npool, nbatches, flags, check, traffic_file=None):
     """One BASELINE config as an ASYNC pipeline on a fresh context: wall-clock rate, then the same again under the
     library's HIP-event profiler for the kernel times."""
@@ -214,7 +241,7 @@ def leg_async(mk, dev_id, dev, cap, npool, nbatches, flags, check, traffic_file=
            "hbm_read_frac": round(p.bytes / dt / 1e9 / HBM_PEAK_GBPS, 5),
            "workload": f"{w.name}: {cap >> 20} MiB batches, device-resident in / out, offsets sidecar, NO_CONTROL | ASYNC",
            "batches": nbatches, "frames_per_batch": int(p.frames / nbatches), "paths": dec.debug_paths(),
-           "roofline": roofline_of(kern, alg, traffic)}
+           "roofline": roofline_of(kern, alg, traffic), "deferred_cells": deferred_cells(dec, items[0])}
     dec.close()
     return out, pool, w
 
@@ -707,6 +734,7 @@ def main():
 
     extra = {}
     if rank == 0:
+        extra["deferred_cells"] = deferred_cells(dec, items[0])
         if "no_sidecar" in legs and args.workload == "cfg2":
             extra["no_sidecar"] = leg_no_sidecar(dec, items, 40, check)
         if "cfg3" in legs and args.workload != "cfg3":

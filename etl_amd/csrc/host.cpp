@@ -256,6 +256,7 @@ struct etlg_ctx {
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
   bool last_any_sync_done = false;
   bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
+  hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
   std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
   DevBuf d_colsel;                   // etlg_batch_columns: block counts of the row selection
@@ -301,6 +302,7 @@ struct etlg_batch {
   const uint8_t* host_in = nullptr; const uint32_t* host_offs = nullptr; const uint8_t* dev_in = nullptr;
   uint64_t ctx_gen = 0;
   DevBuf* scan_offs = nullptr;  // ASYNC without a sidecar: the batch's own offsets (from the context's pool)
+  hipEvent_t kdone = nullptr; // ASYNC: recorded behind the batch's kernels on the context's stream (the result copy waits for it)
   hipEvent_t done = nullptr;  // recorded behind the copy of the result block: syncing a batch waits for IT, not for the whole stream
   DevResult* h_res = nullptr;  // pinned, from the context's pool
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
@@ -911,6 +913,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (DevBuf* o : c->offs_pool) { o->release(); delete o; }
   if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
+  if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& pr : c->harena_pool) (void)hipHostFree(pr.first);
@@ -1302,11 +1305,20 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     const int32_t rc = standard_path(c, b);
     if (rc != ETLG_OK) return rc;
   }
-  HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
   if (async) {
-    if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
-    b->done = c->ev_pool.back(); c->ev_pool.pop_back();
-    HIPCHK(c, hipEventRecord(b->done, s));
+    // the result block is copied on a second stream: on the context's stream the next batch's kernel follows this one
+    // directly (a 200-byte device-to-host copy is a 4 us blit kernel plus two dispatch gaps when it sits between them)
+    for (int k = 0; k < 2; k++) {
+      if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
+      (k ? b->done : b->kdone) = c->ev_pool.back(); c->ev_pool.pop_back();
+    }
+    if (!c->res_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventRecord(b->kdone, s));
+    HIPCHK(c, hipStreamWaitEvent(c->res_stream, b->kdone, 0));
+    HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, c->res_stream));
+    HIPCHK(c, hipEventRecord(b->done, c->res_stream));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
   }
 
   guard.b = nullptr;
@@ -1355,6 +1367,7 @@ void etlg_batch_free(etlg_batch* b) {
     }
     if (b->h_res) (void)hipStreamSynchronize(c->stream);
     if (b->done) c->ev_pool.push_back(b->done);
+    if (b->kdone) c->ev_pool.push_back(b->kdone);
     if (b->dev) c->out_pool.push_back(b->dev);
     if (b->scan_offs) c->offs_pool.push_back(b->scan_offs);
     if (b->h_res) c->res_pool.push_back(b->h_res);
@@ -1363,6 +1376,7 @@ void etlg_batch_free(etlg_batch* b) {
     if (b->dev) { b->dev->release(); delete b->dev; }
     if (b->scan_offs) { b->scan_offs->release(); delete b->scan_offs; }
     if (b->done) (void)hipEventDestroy(b->done);
+    if (b->kdone) (void)hipEventDestroy(b->kdone);
     if (b->h_res) (void)hipHostFree(b->h_res);
     if (b->h_arena) (void)hipHostFree(b->h_arena);
   }
