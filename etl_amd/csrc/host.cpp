@@ -259,6 +259,7 @@ struct etlg_ctx {
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
   std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
+  std::vector<std::pair<void*, size_t>> blk_dev, blk_host;  // hand-off calls (columns / RowBinary / size hints): pooled device and pinned blocks
   DevBuf d_colsel;                   // etlg_batch_columns: block counts of the row selection
   std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order
   std::vector<hipEvent_t> ev_pool;   // "result block copied back" events of finished batches
@@ -319,15 +320,20 @@ struct etlg_batch {
   bool have_snapshot = false;
 };
 
-struct etlg_columns {  // etlg_batch_columns: the buffers live in two device blocks (+ one host block when downloaded)
+struct HandoffBlocks {  // two device blocks (+ one pinned block when downloaded), taken from / returned to the context's pool
+  etlg_ctx* ctx = nullptr; uint64_t ctx_gen = 0;
+  void* d_a = nullptr; void* d_b = nullptr; uint8_t* h = nullptr;
+  size_t cap_a = 0, cap_b = 0, cap_h = 0;
+};
+struct etlg_columns {  // etlg_batch_columns
   etlg_columns_view v{};
   std::vector<etlg_column> cols;
-  void* d_a = nullptr; void* d_b = nullptr; uint8_t* h = nullptr;
+  HandoffBlocks m;
 };
 
 struct etlg_rowbinary {
   etlg_rowbinary_view v{};
-  void* d_a = nullptr; void* d_b = nullptr; uint8_t* h = nullptr;
+  HandoffBlocks m;
 };
 
 namespace {
@@ -846,6 +852,36 @@ static uint64_t g_ctx_gen = 0;
 static bool ctx_alive(const etlg_ctx* c, uint64_t gen) { std::lock_guard<std::mutex> l(g_live_mu); auto it = g_live_ctx.find(c); return it != g_live_ctx.end() && it->second == gen; }
 
 // ====================================================================== C API
+// Pooled blocks of the hand-off calls: hipMalloc / hipFree synchronise the device and cost ~100 us each.
+static hipError_t blk_take(etlg_ctx* c, size_t bytes, bool host, void** out, size_t* cap) {
+  auto& pool = host ? c->blk_host : c->blk_dev;
+  size_t best = (size_t)-1;
+  for (size_t i = 0; i < pool.size(); i++)
+    if (pool[i].second >= bytes && (best == (size_t)-1 || pool[i].second < pool[best].second)) best = i;
+  if (best != (size_t)-1 && pool[best].second <= 4 * bytes + (1u << 20)) {
+    *out = pool[best].first; *cap = pool[best].second;
+    pool.erase(pool.begin() + (long)best);
+    return hipSuccess;
+  }
+  const size_t want = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+  const hipError_t e = host ? hipHostMalloc(out, want, hipHostMallocDefault) : hipMalloc(out, want);
+  if (e == hipSuccess) *cap = want;
+  return e;
+}
+static void blk_give(etlg_ctx* c, uint64_t gen, void* p, size_t cap, bool host) {
+  if (!p) return;
+  if (c && ctx_alive(c, gen)) { (host ? c->blk_host : c->blk_dev).emplace_back(p, cap); return; }
+  if (host) (void)hipHostFree(p); else (void)hipFree(p);
+}
+static void handoff_release(HandoffBlocks& m) {
+  blk_give(m.ctx, m.ctx_gen, m.d_a, m.cap_a, false); blk_give(m.ctx, m.ctx_gen, m.d_b, m.cap_b, false); blk_give(m.ctx, m.ctx_gen, m.h, m.cap_h, true);
+  m.d_a = m.d_b = nullptr; m.h = nullptr;
+}
+struct ScratchBlk {  // a device block for the duration of one call
+  etlg_ctx* c; void* p = nullptr; size_t cap = 0;
+  ~ScratchBlk() { if (p) blk_give(c, c->gen, p, cap, false); }
+};
+
 extern "C" {
 
 uint32_t etlg_abi_version(void) { return ETLG_ABI_VERSION; }
@@ -912,6 +948,8 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols, &c->d_colsel}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (DevBuf* o : c->offs_pool) { o->release(); delete o; }
+  for (auto& b : c->blk_dev) (void)hipFree(b.first);
+  for (auto& b : c->blk_host) (void)hipHostFree(b.first);
   if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
   if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1433,9 +1471,10 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   // ---- 1. which events are rows (count -> scan -> scatter); row_event / row_base are sized for every event
   HIPCHK(c, c->d_colsel.ensure(al((size_t)(nblk + 1) * 4) + 64));
   uint32_t* d_blk = (uint32_t*)c->d_colsel.p;
-  void* d_rows = nullptr;
-  if (ne) HIPCHK(c, hipMalloc(&d_rows, al(ne * 8) * 2));
-  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } free_rows{d_rows};
+  cs->m.ctx = c; cs->m.ctx_gen = c->gen;
+  ScratchBlk rows_blk{c};
+  if (ne) HIPCHK(c, blk_take(c, al(ne * 8) * 2, false, &rows_blk.p, &rows_blk.cap));
+  void* d_rows = rows_blk.p;
   uint64_t* d_row_event = (uint64_t*)d_rows;
   uint64_t* d_row_base = (uint64_t*)((uint8_t*)d_rows + al(ne * 8));
   uint32_t n_rows32 = 0;
@@ -1470,8 +1509,8 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   const uint32_t nrb = (uint32_t)((n + 255) / 256);
   const size_t o_scan = off; off += al((size_t)(nrb + 1) * 8);   // one scan scratch: var-len columns run one after another on the stream
   const size_t a_bytes = off + 64;
-  HIPCHK(c, hipMalloc(&cs->d_a, a_bytes));
-  uint8_t* A = (uint8_t*)cs->d_a;
+  HIPCHK(c, blk_take(c, a_bytes, false, &cs->m.d_a, &cs->m.cap_a));
+  uint8_t* A = (uint8_t*)cs->m.d_a;
   {
     std::vector<unsigned long long> init((size_t)nc * 4, 0ull);
     for (uint32_t i = 0; i < nc; i++) init[(size_t)i * 4 + 3] = ~0ull;
@@ -1530,8 +1569,8 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
       b_bytes += al(vbytes[i]); cvb[i] = b_bytes; b_bytes += al(bits);
     } else { vbytes[i] = tot; b_bytes += al(tot); }
   }
-  if (b_bytes) HIPCHK(c, hipMalloc(&cs->d_b, b_bytes + 64));
-  uint8_t* B = (uint8_t*)cs->d_b;
+  if (b_bytes) HIPCHK(c, blk_take(c, b_bytes + 64, false, &cs->m.d_b, &cs->m.cap_b));
+  uint8_t* B = (uint8_t*)cs->m.d_b;
   for (uint32_t i = 0; i < nc; i++) {
     if (!lay[i].pl.var || var_total[i] <= 0) continue;
     jobs[i].values = B + vb[i];
@@ -1546,13 +1585,13 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
   const uint8_t* base_a = A; const uint8_t* base_b = B;
   if (!on_dev) {
-    HIPCHK(c, hipHostMalloc((void**)&cs->h, al(o_cnt) + b_bytes + 64, hipHostMallocDefault));
-    if (o_cnt) HIPCHK(c, hipMemcpyAsync(cs->h, A, o_cnt, hipMemcpyDeviceToHost, s));
-    if (b_bytes) HIPCHK(c, hipMemcpyAsync(cs->h + al(o_cnt), B, b_bytes, hipMemcpyDeviceToHost, s));
-    base_a = cs->h; base_b = cs->h + al(o_cnt);
+    HIPCHK(c, blk_take(c, al(o_cnt) + b_bytes + 64, true, (void**)&cs->m.h, &cs->m.cap_h));
+    if (o_cnt) HIPCHK(c, hipMemcpyAsync(cs->m.h, A, o_cnt, hipMemcpyDeviceToHost, s));
+    if (b_bytes) HIPCHK(c, hipMemcpyAsync(cs->m.h + al(o_cnt), B, b_bytes, hipMemcpyDeviceToHost, s));
+    base_a = cs->m.h; base_b = cs->m.h + al(o_cnt);
   }
   HIPCHK(c, hipStreamSynchronize(s));   // row_base (freed on return) is read by the kernels above
-  if (!on_dev) { (void)hipFree(cs->d_a); cs->d_a = nullptr; if (cs->d_b) (void)hipFree(cs->d_b); cs->d_b = nullptr; }
+  if (!on_dev) { blk_give(c, c->gen, cs->m.d_a, cs->m.cap_a, false); blk_give(c, c->gen, cs->m.d_b, cs->m.cap_b, false); cs->m.d_a = cs->m.d_b = nullptr; }
   cs->cols.resize(nc);
   for (uint32_t i = 0; i < nc; i++) {
     etlg_column& k = cs->cols[i];
@@ -1600,9 +1639,9 @@ int32_t etlg_batch_size_hints(etlg_ctx* c, etlg_batch* b, const etlg_size_model*
     for (const etlg_slot_col& col : c->slots[i]->cols) { tab[o_cols + 2 * k] = col.type_class | (col.identity ? 1u << 8 : 0u) | ((uint32_t)col.off_full << 16); tab[o_cols + 2 * k + 1] = col.off_key; k++; }
   const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
   const size_t tab_bytes = (tab.size() * 4 + 63) & ~(size_t)63;
-  void* d = nullptr;
-  HIPCHK(c, hipMalloc(&d, tab_bytes + (on_dev ? 0 : ne * 8) + 64));
-  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } free_d{d};
+  ScratchBlk dblk{c};
+  HIPCHK(c, blk_take(c, tab_bytes + (on_dev ? 0 : ne * 8) + 64, false, &dblk.p, &dblk.cap));
+  void* d = dblk.p;
   HIPCHK(c, hipMemcpyAsync(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
   HintJob j{};
   j.ev_kind = bv.ev_kind; j.ev_flags = bv.ev_flags; j.ev_table = bv.ev_table_id; j.ev_slot = bv.ev_schema_slot; j.ev_body = bv.ev_body_off;
@@ -1625,9 +1664,7 @@ int32_t etlg_columns_view_get(const etlg_columns* cs, etlg_columns_view* out) {
 
 void etlg_columns_free(etlg_columns* cs) {
   if (!cs) return;
-  if (cs->d_a) (void)hipFree(cs->d_a);
-  if (cs->d_b) (void)hipFree(cs->d_b);
-  if (cs->h) (void)hipHostFree(cs->h);
+  handoff_release(cs->m);
   delete cs;
 }
 
@@ -1661,17 +1698,18 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
   const uint32_t nblk = (uint32_t)((ne + 255) / 256);
   // block S (freed on return): block counts | host-row counter | error word | column words | row_base
   const size_t o_cnt = al((size_t)(nblk + 1) * 4), o_cols = o_cnt + 64, o_base = o_cols + al((size_t)nc * 4 + 4), s_bytes = o_base + al(ne * 8) + 64;
-  void* d_s = nullptr;
-  HIPCHK(c, hipMalloc(&d_s, s_bytes));
-  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } free_s{d_s};
+  rb->m.ctx = c; rb->m.ctx_gen = c->gen;
+  ScratchBlk sblk{c};
+  HIPCHK(c, blk_take(c, s_bytes, false, &sblk.p, &sblk.cap));
+  void* d_s = sblk.p;
   uint8_t* S = (uint8_t*)d_s;
   const unsigned long long init[2] = {0ull, ~0ull};
   HIPCHK(c, hipMemcpyAsync(S + o_cnt, init, 16, hipMemcpyHostToDevice, s));
   if (nc) HIPCHK(c, hipMemcpyAsync(S + o_cols, cols.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s));
   // block A: row_event | row_offsets | lens | scan scratch (sized for every event being a row)
   const size_t o_off = al(ne * 8), o_len = o_off + al((ne + 1) * 8), o_scan = o_len + al(ne * 4), a_bytes = o_scan + al((size_t)(nblk + 1) * 8) + 64;
-  HIPCHK(c, hipMalloc(&rb->d_a, a_bytes));
-  uint8_t* A = (uint8_t*)rb->d_a;
+  HIPCHK(c, blk_take(c, a_bytes, false, &rb->m.d_a, &rb->m.cap_a));
+  uint8_t* A = (uint8_t*)rb->m.d_a;
   uint32_t n32 = 0;
   unsigned long long cnt[2] = {0, ~0ull};
   if (ne) {
@@ -1708,7 +1746,7 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
     HIPCHK(c, hipMemcpy(&ev, A + (cnt[1] >> 24) * 8, 8, hipMemcpyDeviceToHost));
     if (code == 3) {
       rb->v.status = ETLG_RB_NEEDS_HOST; rb->v.host_event = ev; rb->v.host_column = col;
-      (void)hipFree(rb->d_a); rb->d_a = nullptr;
+      blk_give(c, c->gen, rb->m.d_a, rb->m.cap_a, false); rb->m.d_a = nullptr;
       *out = rb.release();
       return ETLG_OK;
     }
@@ -1717,19 +1755,19 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
     return k;
   }
   if (total) {
-    HIPCHK(c, hipMalloc(&rb->d_b, (size_t)total + 64));
-    j.out = (uint8_t*)rb->d_b;
+    HIPCHK(c, blk_take(c, (size_t)total + 64, false, &rb->m.d_b, &rb->m.cap_b));
+    j.out = (uint8_t*)rb->m.d_b;
     etlg_k_rowbinary(&j, nullptr, nullptr, 1, s);
   }
-  const uint8_t* base_a = A; const uint8_t* base_b = (const uint8_t*)rb->d_b;
+  const uint8_t* base_a = A; const uint8_t* base_b = (const uint8_t*)rb->m.d_b;
   if (!on_dev) {
-    HIPCHK(c, hipHostMalloc((void**)&rb->h, o_len + al((size_t)total) + 64, hipHostMallocDefault));
-    HIPCHK(c, hipMemcpyAsync(rb->h, A, o_off + (n + 1) * 8, hipMemcpyDeviceToHost, s));
-    if (total) HIPCHK(c, hipMemcpyAsync(rb->h + o_len, rb->d_b, (size_t)total, hipMemcpyDeviceToHost, s));
-    base_a = rb->h; base_b = rb->h + o_len;
+    HIPCHK(c, blk_take(c, o_len + al((size_t)total) + 64, true, (void**)&rb->m.h, &rb->m.cap_h));
+    HIPCHK(c, hipMemcpyAsync(rb->m.h, A, o_off + (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (total) HIPCHK(c, hipMemcpyAsync(rb->m.h + o_len, rb->m.d_b, (size_t)total, hipMemcpyDeviceToHost, s));
+    base_a = rb->m.h; base_b = rb->m.h + o_len;
   }
   HIPCHK(c, hipStreamSynchronize(s));   // block S is freed on return
-  if (!on_dev) { (void)hipFree(rb->d_a); rb->d_a = nullptr; if (rb->d_b) (void)hipFree(rb->d_b); rb->d_b = nullptr; }
+  if (!on_dev) { blk_give(c, c->gen, rb->m.d_a, rb->m.cap_a, false); blk_give(c, c->gen, rb->m.d_b, rb->m.cap_b, false); rb->m.d_a = rb->m.d_b = nullptr; }
   rb->v.n_rows = n; rb->v.n_bytes = (uint64_t)total;
   rb->v.row_event = (const uint64_t*)base_a; rb->v.row_offsets = (const int64_t*)(base_a + o_off); rb->v.bytes = total ? base_b : nullptr;
   *out = rb.release();
@@ -1744,9 +1782,7 @@ int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* o
 
 void etlg_rowbinary_free(etlg_rowbinary* rb) {
   if (!rb) return;
-  if (rb->d_a) (void)hipFree(rb->d_a);
-  if (rb->d_b) (void)hipFree(rb->d_b);
-  if (rb->h) (void)hipHostFree(rb->h);
+  handoff_release(rb->m);
   delete rb;
 }
 

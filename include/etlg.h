@@ -545,6 +545,7 @@ typedef struct etlg_columns etlg_columns;
 int32_t etlg_batch_columns(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t row_kinds,
                            uint32_t flags, etlg_columns** out);
 int32_t etlg_columns_view_get(const etlg_columns* cols, etlg_columns_view* out);
+/* Returns the buffers to the context's pool (no device synchronisation): work the caller enqueued on them must be complete. */
 void etlg_columns_free(etlg_columns* cols);
 
 /* ClickHouse RowBinary rows for ONE schema slot of a decoded batch, encoded on the device: what
