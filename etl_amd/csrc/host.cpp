@@ -34,7 +34,7 @@ extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
 extern "C" const char* etlg_k_name(int which);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_fused_set_lds(void);
-extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* vdesc, void* ndesc,
+extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* cur, void* clear, uint32_t clear_words,
                                      uint32_t* hints, uint32_t* result, int sequential, hipStream_t s);
 extern "C" uint32_t etlg_k_bounds_tile_bytes(void);
 extern "C" uint32_t etlg_k_copy_bytes_per_row(uint32_t ncols);
@@ -197,6 +197,7 @@ struct OutSet {  // device output arrays of one batch
 };
 
 struct ProfRec { int which; hipEvent_t a, b; };
+struct ScanJob { const uint8_t* d_in = nullptr; size_t len = 0; hipStream_t s = nullptr; DevBuf* offs = nullptr; size_t cap = 0; uint8_t* cur = nullptr; };
 struct HostErr { int32_t code = 0; uint32_t rank = 0; };
 struct EpochRec { uint32_t table_id; DevEpoch ep; };
 
@@ -239,6 +240,7 @@ struct etlg_ctx {
   DevBuf d_copy_in, d_copy_offs, d_copy_out, d_copy_out_offs;
   DevBuf d_scan;       // scratch of the record-boundary scan
   uint32_t* h_scan = nullptr;  // pinned: its 4-word result
+  size_t scan_half = 0, scan_tiles_cap = 0, scan_dirty[2] = {0, 0}; int scan_cur = 0;  // double-buffered scan descriptors: bytes per buffer, dirty 8-byte words, the one the next run uses
   unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
   FusedParams fq{};
@@ -256,6 +258,8 @@ struct etlg_ctx {
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
   bool last_any_sync_done = false;
   bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
+  etlg_batch* deferred = nullptr;     // ASYNC batch without a sidecar whose boundary scan is in flight: its decode is enqueued by the next call
+  ScanJob scan_job;                   // ... and that scan
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
   std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
@@ -302,6 +306,8 @@ struct etlg_batch {
   size_t len = 0;
   const uint8_t* host_in = nullptr; const uint32_t* host_offs = nullptr; const uint8_t* dev_in = nullptr;
   uint64_t ctx_gen = 0;
+  bool deferred = false;        // ASYNC without a sidecar: scan in flight, decode not enqueued yet (etlg_ctx::deferred)
+  const uint8_t* d_in_ptr = nullptr; const uint32_t* user_offs = nullptr;
   DevBuf* scan_offs = nullptr;  // ASYNC without a sidecar: the batch's own offsets (from the context's pool)
   hipEvent_t kdone = nullptr; // ASYNC: recorded behind the batch's kernels on the context's stream (the result copy waits for it)
   hipEvent_t done = nullptr;  // recorded behind the copy of the result block: syncing a batch waits for IT, not for the whole stream
@@ -841,6 +847,8 @@ int32_t setup_scratch(etlg_ctx* c, DecParams& p);
 bool plan_wanted(etlg_ctx* c, const etlg_batch* b);
 int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level);
 int32_t standard_path(etlg_ctx* c, etlg_batch* b);
+int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev);
+int32_t flush_deferred(etlg_ctx* c);
 
 }  // namespace
 
@@ -964,6 +972,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
 
 int32_t etlg_ctx_set_stream(etlg_ctx* c, void* s) {
   if (!c) return ETLG_InvalidArgument;
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   (void)drain_pending(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -973,6 +982,7 @@ int32_t etlg_ctx_set_stream(etlg_ctx* c, void* s) {
 }
 
 int32_t etlg_ctx_set_worker(etlg_ctx* c, int32_t kind, uint32_t table_id, uint64_t bootstrap) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c) return ETLG_InvalidArgument;
   (void)drain_pending(c);
   c->worker = kind; c->sync_table = table_id; c->bootstrap = bootstrap; c->side_valid = false; c->side_dirty = true;
@@ -980,6 +990,7 @@ int32_t etlg_ctx_set_worker(etlg_ctx* c, int32_t kind, uint32_t table_id, uint64
 }
 
 int32_t etlg_schema_put(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const char* nsp, const char* name, uint32_t ncols, const etlg_col* cols) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c || (ncols && !cols)) return ETLG_InvalidArgument;
   (void)drain_pending(c);
   auto s = std::make_shared<StoredSchema>();
@@ -995,6 +1006,7 @@ int32_t etlg_schema_put(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const
 }
 
 int32_t etlg_table_state(etlg_ctx* c, uint32_t table_id, int32_t kind, uint64_t lsn) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c) return ETLG_InvalidArgument;
   (void)drain_pending(c);
   if (kind == ETLG_TS_ABSENT) c->states.erase(table_id); else c->states[table_id] = TState{kind, lsn};
@@ -1003,6 +1015,7 @@ int32_t etlg_table_state(etlg_ctx* c, uint32_t table_id, int32_t kind, uint64_t 
 }
 
 int32_t etlg_table_ready(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, const uint8_t* rmask, const uint8_t* imask, uint32_t n) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c || !rmask || !imask) return -ETLG_InvalidArgument;
   (void)drain_pending(c);
   SchemaPtr sch = get_at_or_before(c->cs, table_id, snapshot);
@@ -1015,6 +1028,7 @@ int32_t etlg_table_ready(etlg_ctx* c, uint32_t table_id, uint64_t snapshot, cons
 }
 
 int32_t etlg_table_forget(etlg_ctx* c, uint32_t table_id) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c) return ETLG_InvalidArgument;
   (void)drain_pending(c);
   c->cs.cache.erase(table_id);
@@ -1031,6 +1045,7 @@ int32_t etlg_table_cache_get(const etlg_ctx* c, uint32_t table_id, int32_t* kind
 }
 
 int32_t etlg_ctx_reset_stream_state(etlg_ctx* c) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c) return ETLG_InvalidArgument;
   (void)drain_pending(c);
   c->in_txn = false; c->final_lsn = 0; c->next_ord = 0;
@@ -1094,54 +1109,105 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
 
 // Record boundaries on the device (scan.hip): fills c->d_offs with nframes + 1 offsets of the frames
 // of `d_in[0, len)` and returns nframes. Optimistic kernel + hint reruns + one-lane fallback.
-hipError_t device_scan(etlg_ctx* c, const uint8_t* d_in, size_t len, size_t* nframes_out, hipStream_t s, DevBuf& offs) {
-  *nframes_out = 0;
+// One record-boundary scan in flight (scan.hip). scan_launch enqueues a run and returns; scan_collect waits for it, reruns it
+// with hints / on one lane when tiles guessed wrong, and returns the frame count.
+hipError_t scan_launch(etlg_ctx* c, ScanJob& j, bool sequential) {
+  const size_t len = j.len;
+  hipStream_t s = j.s;
+  const size_t tb = etlg_k_bounds_tile_bytes();
+  const size_t ntiles = (len + tb - 1) / tb, ngroups = (ntiles + 63) / 64;
+  // scratch: two descriptor buffers (result block of 64 bytes + look-back words) | hints. Each run zeroes the buffer the next
+  // run will use, the result travels through pinned host memory: a scan is ONE kernel on the stream, no memset, no copy.
+  const size_t words = 8 + ntiles + ngroups;                       // 8-byte words of one descriptor buffer that this run dirties
+  if (!c->h_scan) { hipError_t e = hipHostMalloc((void**)&c->h_scan, 64); if (e != hipSuccess) return e; }
+  if (ntiles > c->scan_tiles_cap) {  // (re)allocation: the layout is by capacity, everything is initialised once
+    const size_t tcap = ntiles + ntiles / 4 + 64;
+    const size_t half = ((8 + tcap + tcap / 64 + 2) * 8 + 63) & ~(size_t)63;
+    const size_t need = 2 * half + ((tcap * 4 + 63) & ~(size_t)63) + 64;
+    hipError_t e = c->d_scan.ensure(need); if (e != hipSuccess) return e;
+    e = hipMemsetAsync(c->d_scan.p, 0, 2 * half, s); if (e != hipSuccess) return e;
+    e = hipMemsetAsync((uint8_t*)c->d_scan.p + 2 * half, 0xFF, tcap * 4, s); if (e != hipSuccess) return e;
+    c->scan_tiles_cap = tcap; c->scan_half = half; c->scan_cur = 0; c->scan_dirty[0] = c->scan_dirty[1] = 0;
+  }
+  const size_t half = c->scan_half;
+  uint8_t* base = (uint8_t*)c->d_scan.p;
+  hipError_t e = j.offs->ensure((j.cap + 2) * 4); if (e != hipSuccess) return e;
+  j.cur = base + (size_t)c->scan_cur * half;
+  uint8_t* oth = base + (size_t)(c->scan_cur ^ 1) * half;
+  c->h_scan[0] = 0; c->h_scan[1] = 0;
+  const bool dbg = getenv("ETLG_SCAN_DBG") != nullptr;
+  ProfRec r; r.which = kBounds;
+  if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
+  etlg_k_launch_bounds(j.d_in, len, (uint32_t*)j.offs->p, (uint32_t)std::min<size_t>(j.cap + 2, 0xFFFFFFFFu), j.cur, oth, (uint32_t)c->scan_dirty[c->scan_cur ^ 1],
+                       (uint32_t*)(base + 2 * half), c->h_scan, (sequential ? 1 : 0) | (dbg ? 2 : 0), s);
+  if (c->prof) { (void)hipEventRecord(r.b, s); c->prof_recs.push_back(r); }
+  c->scan_dirty[c->scan_cur] = words; c->scan_dirty[c->scan_cur ^ 1] = 0;
+  c->scan_cur ^= 1;
+  return hipSuccess;
+}
+
+hipError_t scan_begin(etlg_ctx* c, ScanJob& j, const uint8_t* d_in, size_t len, hipStream_t s, DevBuf& offs) {
+  j = ScanJob{};
+  j.d_in = d_in; j.len = len; j.s = s; j.offs = &offs;
+  j.cap = len / 24 + 1024;  // frames the offsets buffer can take; grown to the worst case (5-byte frames) on demand
   if (len == 0) {
     hipError_t e = offs.ensure(64); if (e != hipSuccess) return e;
     return hipMemsetAsync(offs.p, 0, 4, s);
   }
+  return scan_launch(c, j, false);
+}
+
+hipError_t scan_collect(etlg_ctx* c, ScanJob& j, size_t* nframes_out) {
+  *nframes_out = 0;
+  if (j.len == 0) return hipSuccess;
+  const size_t len = j.len;
+  hipStream_t s = j.s;
   const size_t tb = etlg_k_bounds_tile_bytes();
-  const size_t ntiles = (len + tb - 1) / tb, ngroups = (ntiles + 63) / 64;
-  const size_t zero_bytes = (ntiles + ntiles + ngroups) * 8;          // vdesc | ndesc
-  const size_t hints_off = (zero_bytes + 63) & ~(size_t)63, res_off = hints_off + ((ntiles * 4 + 63) & ~(size_t)63);
-  hipError_t e = c->d_scan.ensure(res_off + 64); if (e != hipSuccess) return e;
-  if (!c->h_scan) { e = hipHostMalloc((void**)&c->h_scan, 64); if (e != hipSuccess) return e; }
-  uint8_t* base = (uint8_t*)c->d_scan.p;
-  size_t cap = len / 24 + 1024;  // frames the offsets buffer can take; grown to the worst case (5-byte frames) on demand
-  e = hipMemsetAsync(base + hints_off, 0xFF, ntiles * 4, s); if (e != hipSuccess) return e;
-  bool used_hints = false;
+  const size_t ntiles = (len + tb - 1) / tb;
+  const bool dbg = getenv("ETLG_SCAN_DBG") != nullptr;
+  bool used_hints = false, hints_set = false;
+  hipError_t rc = hipSuccess;
   for (int run = 0;; run++) {
     const bool sequential = run >= 4;
-    e = offs.ensure((cap + 2) * 4); if (e != hipSuccess) return e;
-    e = hipMemsetAsync(base, 0, zero_bytes, s); if (e != hipSuccess) return e;
-    e = hipMemsetAsync(base + res_off, 0, 64, s); if (e != hipSuccess) return e;
-    ProfRec r; r.which = kBounds;
-    if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
-    etlg_k_launch_bounds(d_in, len, (uint32_t*)offs.p, (uint32_t)std::min<size_t>(cap + 2, 0xFFFFFFFFu), base, base + ntiles * 8,
-                         (uint32_t*)(base + hints_off), (uint32_t*)(base + res_off), (sequential ? 1 : 0) | (getenv("ETLG_SCAN_DBG") ? 2 : 0), s);
-    if (c->prof) { (void)hipEventRecord(r.b, s); c->prof_recs.push_back(r); }
-    e = hipMemcpyAsync(c->h_scan, base + res_off, 64, hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
-    const uint32_t nf = c->h_scan[0], flags = c->h_scan[1], nbad = c->h_scan[2];
-    if (getenv("ETLG_SCAN_DBG")) { fprintf(stderr, "k_bounds tiles %zu phase cycles/tile:", ntiles); for (int k = 4; k < 11; k++) fprintf(stderr, " %u", (unsigned)(c->h_scan[k] / std::max<size_t>(1, ntiles / 64))); fprintf(stderr, "\n"); }
-    if (flags & 2u) {  // offsets buffer too small
-      if (cap >= len / 5 + 2) return hipErrorOutOfMemory;
-      cap = len / 5 + 2;
-      run--;
-      continue;
+    hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
+    uint32_t nf = c->h_scan[0], flags = 0, nbad = 0;
+    if (c->h_scan[1] || dbg) {  // some tile failed: the details are in the device result block
+      uint32_t res[16];
+      e = hipMemcpy(res, j.cur, 64, hipMemcpyDeviceToHost); if (e != hipSuccess) return e;
+      nf = res[0]; flags = res[1]; nbad = res[2];
+      if (dbg) { fprintf(stderr, "k_bounds tiles %zu phase cycles/tile:", ntiles); for (int k = 4; k < 11; k++) fprintf(stderr, " %u", (unsigned)(res[k] / std::max<size_t>(1, ntiles / 64))); fprintf(stderr, "\n"); }
+      if (nbad) hints_set = true;
     }
-    if (sequential || (!(flags & 1u) && nbad == 0)) {
+    bool again_same = false;
+    if (flags & 2u) {  // offsets buffer too small
+      if (j.cap >= len / 5 + 2) { rc = hipErrorOutOfMemory; break; }
+      j.cap = len / 5 + 2;
+      run--; again_same = true;
+    } else if (sequential || (!(flags & 1u) && nbad == 0)) {
       if (used_hints) c->scan_reruns++;
       if (sequential) c->scan_seq++;
       *nframes_out = nf;
-      return hipSuccess;
+      break;
+    } else {
+      used_hints = true;  // some tiles guessed wrong (their hints are set now), or a spin gave up: run again
     }
-    used_hints = true;  // some tiles guessed wrong (their hints are set now), or a spin gave up: run again
+    e = scan_launch(c, j, again_same ? sequential : run + 1 >= 4); if (e != hipSuccess) return e;
   }
+  if (hints_set) { const hipError_t e = hipMemsetAsync((uint8_t*)c->d_scan.p + 2 * c->scan_half, 0xFF, ntiles * 4, s); if (e != hipSuccess) return e; }   // rare: leave the hints clean for the next scan
+  return rc;
 }
+
+// Record boundaries on the device: fills `offs` with nframes + 1 offsets of the frames of `d_in[0, len)` and returns nframes.
+hipError_t device_scan(etlg_ctx* c, const uint8_t* d_in, size_t len, size_t* nframes_out, hipStream_t s, DevBuf& offs) {
+  ScanJob j;
+  hipError_t e = scan_begin(c, j, d_in, len, s, offs); if (e != hipSuccess) return e;
+  return scan_collect(c, j, nframes_out);
+}
+
 
 int32_t etlg_scan_boundaries(etlg_ctx* c, const uint8_t* buf, size_t len, uint32_t flags, uint32_t* offsets_out, size_t cap,
                              size_t* nframes_out) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c || !nframes_out || (!offsets_out && cap)) return ETLG_InvalidArgument;
   clear_error(c);
   if (len > 0xFFFFFFFFull - 16) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
@@ -1164,6 +1230,7 @@ int32_t etlg_scan_boundaries(etlg_ctx* c, const uint8_t* buf, size_t len, uint32
 
 int32_t etlg_frame_tags(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags,
                         uint8_t* tags_out) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c || !frame_offsets || (!tags_out && nframes)) return ETLG_InvalidArgument;
   clear_error(c);
   if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
@@ -1197,6 +1264,7 @@ int32_t etlg_ctx_debug_scan(etlg_ctx* c, unsigned long long* out2) {
 
 int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, size_t len, const uint32_t* row_offsets, size_t nrows,
                          uint32_t flags, etlg_batch** out) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c || !out || !row_offsets) return ETLG_InvalidArgument;
   *out = nullptr;
   clear_error(c);
@@ -1251,6 +1319,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   clear_error(c);
   if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   HIPCHK(c, hipSetDevice(c->device));
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE, out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
   const bool no_ctrl = flags & ETLG_F_NO_CONTROL;
   const bool scan = frame_offsets == nullptr;
@@ -1272,23 +1341,76 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   auto* b = new etlg_batch();
   b->ctx = c; b->ctx_gen = c->gen;
   BatchGuard guard{b};
+  b->user_no_ctrl = no_ctrl; b->out_dev = out_dev; b->in_dev = in_dev; b->scan = scan; b->len = len;
+  b->host_in = in_dev ? nullptr : buf; b->host_offs = (in_dev || scan) ? nullptr : h_offs; b->dev_in = in_dev ? buf : nullptr;
+  b->d_in_ptr = d_in_ptr; b->user_offs = frame_offsets;
   if (scan) {
     if (async) {
-      // the scan of THIS batch runs on its own stream while the previous batch is still being decoded on the context's; the
-      // host waits for the frame count (it sizes the decode launch), the device does not go idle. The input must be
-      // complete when the call is made (include/etlg.h).
+      // The scan of THIS batch runs on its own stream while the previous batch is still being decoded on the context's, and
+      // nobody waits for it here: the call returns with the scan in flight and the NEXT call (or the batch's sync) collects
+      // the frame count and enqueues the decode. The input must be complete when the call is made (include/etlg.h).
       if (!c->scan_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
       if (c->offs_pool.empty()) c->offs_pool.push_back(new DevBuf());
       b->scan_offs = c->offs_pool.back(); c->offs_pool.pop_back();
-      HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes, c->scan_stream, *b->scan_offs));
-    } else {
-      HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes, s, c->d_offs));
+      HIPCHK(c, scan_begin(c, c->scan_job, d_in_ptr, len, c->scan_stream, *b->scan_offs));
+      b->deferred = true; b->pending = true; b->v.on_device = 1;
+      c->deferred = b; c->pending.push_back(b);
+      guard.b = nullptr;
+      *out = b;
+      return ETLG_OK;
     }
+    HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes, s, c->d_offs));
     if (nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   }
-  b->user_no_ctrl = no_ctrl; b->out_dev = out_dev; b->in_dev = in_dev; b->scan = scan; b->len = len;
-  b->host_in = in_dev ? nullptr : buf; b->host_offs = (in_dev || scan) ? nullptr : h_offs; b->dev_in = in_dev ? buf : nullptr;
+  {
+    const int32_t rc = decode_tail(c, b, nframes, async, (async && !c->pending.empty()) ? c->pending.back() : nullptr);
+    if (rc != ETLG_OK) return rc;
+  }
+  guard.b = nullptr;
+  *out = b;
+  if (async) { b->pending = true; b->v.on_device = 1; fill_view_common(b); c->pending.push_back(b); return ETLG_OK; }
+  return finish_batch(c, b);
+}
 
+}  // extern "C"
+
+namespace {
+
+// The decode of a batch whose boundary scan was left in flight by etlg_decode: collect the frame count, enqueue the kernels.
+// A failure here belongs to THAT batch (its sync reports it), not to the call that happens to run this.
+int32_t flush_deferred(etlg_ctx* c) {
+  etlg_batch* b = c ? c->deferred : nullptr;
+  if (!b) return ETLG_OK;
+  c->deferred = nullptr;
+  b->deferred = false;
+  size_t nframes = 0;
+  int32_t rc = ETLG_OK;
+  const hipError_t e = scan_collect(c, c->scan_job, &nframes);
+  if (e != hipSuccess) rc = lib_error(c, ETLG_DeviceError, hipGetErrorString(e));
+  else if (nframes >= (1u << 30)) rc = lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  if (rc == ETLG_OK) {
+    etlg_batch* prev = nullptr;   // the batch issued just before this one, if it is still in flight
+    for (size_t i = 0; i < c->pending.size(); i++) if (c->pending[i] == b && i > 0) prev = c->pending[i - 1];
+    rc = decode_tail(c, b, nframes, true, prev);
+  }
+  if (rc != ETLG_OK) {  // nothing was enqueued for it: it is finished, with this error
+    for (size_t i = 0; i < c->pending.size(); i++) if (c->pending[i] == b) { c->pending.erase(c->pending.begin() + (long)i); break; }
+    b->pending = false; b->finished = true; b->rc = rc; b->err = c->err; b->err_detail = c->err_detail;
+    b->err.detail = b->err_detail.empty() ? nullptr : b->err_detail.c_str();
+    return rc;
+  }
+  fill_view_common(b);
+  return ETLG_OK;
+}
+
+// Everything of etlg_decode that needs the frame count: parameters, result block, side inputs, outputs, the first kernel.
+int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev) {
+  hipStream_t s = c->stream;
+  const bool scan = b->scan, in_dev = b->in_dev, no_ctrl = b->user_no_ctrl;
+  const size_t len = b->len;
+  const uint8_t* d_in_ptr = b->d_in_ptr;
+  const uint32_t* frame_offsets = b->user_offs;
+  const uint32_t* h_offs = b->user_offs;
   const uint32_t nf = (uint32_t)nframes;
   DecParams& p = b->params;
   p = DecParams{};
@@ -1309,7 +1431,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   // carried transaction state: the host's (every earlier batch is finished), or — behind pending ASYNC batches — whatever the
   // batch issued just before this one leaves in its result block
   p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
-  p.carry = (async && !c->pending.empty()) ? c->pending.back()->d_res_blk : nullptr;
+  p.carry = (async && prev) ? prev->d_res_blk : nullptr;
 
   HIPCHK(c, c->d_res.ensure(sizeof(DevResult) * etlg_ctx::kResRing));
   {  // result block: next slot of a ring that is re-initialised once per lap. Slot 31 is the carry source of the batch in
@@ -1359,11 +1481,12 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
   }
 
-  guard.b = nullptr;
-  *out = b;
-  if (async) { b->pending = true; b->v.on_device = 1; fill_view_common(b); c->pending.push_back(b); return ETLG_OK; }
-  return finish_batch(c, b);
+  return ETLG_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int32_t etlg_batch_sync(etlg_ctx* c, etlg_batch* b) {
   if (!c || !b) return ETLG_InvalidArgument;
@@ -1379,6 +1502,7 @@ int32_t etlg_batch_sync(etlg_ctx* c, etlg_batch* b) {
 int32_t etlg_batch_header_to_device(etlg_ctx* c, etlg_batch* b, void* dst) {
   if (!c || !b || !dst) return ETLG_InvalidArgument;
   static_assert(offsetof(DevResult, n_frames) == 56, "header layout");
+  if (b->deferred) { const int32_t rc = flush_deferred(c); if (rc != ETLG_OK) return rc; }
   HIPCHK(c, hipMemcpyAsync(dst, b->d_res_blk, 64, hipMemcpyDeviceToDevice, c->stream));
   return ETLG_OK;
 }
@@ -2162,6 +2286,10 @@ int32_t drain_pending(etlg_ctx* c) {
 // host output) copies the arenas back. Batches finish in issue order.
 int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
   hipStream_t s = c->stream;
+  if (b->deferred) {  // its boundary scan is still in flight: collect it and enqueue the decode first
+    const int32_t rc = flush_deferred(c);
+    if (rc != ETLG_OK) return rc;   // the batch is finished, with that error
+  }
   if (b->pending) {  // must be the oldest pending batch
     if (c->pending.empty() || c->pending.front() != b) return lib_error(c, ETLG_InvalidArgument, "ASYNC batches must be synced in issue order");
     c->pending.erase(c->pending.begin());

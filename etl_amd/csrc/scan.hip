@@ -44,7 +44,10 @@ struct BoundsParams {
   uint32_t* offs;              // out: nframes + 1 offsets
   uint32_t offs_cap;           // entries available in offs
   uint32_t ntiles;
-  unsigned long long* vdesc;   // unused
+  unsigned long long* d_clear; // the OTHER descriptor buffer (result block + look-back words of the next run), zeroed by this launch
+  uint32_t clear_words;        // ... its extent in 8-byte words
+  uint32_t* hflag;             // pinned host memory: [0] nframes (last tile), [1] set to 1 by any tile that fails — the host reads the device
+                               // result block only then
   unsigned long long* ndesc;   // [ntiles + ngroups] look-back of (frames: sum, exit: max)   (zeroed)
   uint32_t* hints;             // [ntiles] entry to use instead of guessing, NO_ENTRY = guess (kept across reruns)
   uint32_t dbg;                // 1: per-phase shader-clock sums into result[4..11] (profiling only)
@@ -97,17 +100,23 @@ struct OpCountExit {
 };
 
 constexpr uint32_t SUB = TB / 64;  // bytes of the tile each lane looks at (128)
-#define STAMP(k) do { if (q.dbg && threadIdx.x == 0 && (blockIdx.x & 63) == 5) { const unsigned long long _t = clock64(); atomicAdd(&q.result[4 + (k)], (uint32_t)(_t - t_prev)); t_prev = _t; } } while (0)
+#define STAMP(k) do { if (q.dbg && threadIdx.x == 0 && (blockIdx.x & 31) == 5) { const unsigned long long _t = clock64(); atomicAdd(&q.result[4 + (k)], (uint32_t)(_t - t_prev)); t_prev = _t; } } while (0)
 
-__global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
-  __shared__ __attribute__((aligned(16))) u8 st[TB + HALO + 16];
+// What a tile knows after its local phase (registers; the LDS window is free again)
+struct TileLocal {
+  uint32_t lo, hi, a_end;      // the tile's bytes, the end of this lane's 128
+  uint32_t entry, n, e;        // guessed entry, frames and exit offset of the tile's chain
+  uint32_t s_l, n_l, inc;      // this lane: its guess, the frames of its walk, inclusive prefix of the on-chain lanes' counts
+  bool has, stitched, mine;
+};
+
+// ---- local phase of one tile: stage, guess, walk, stitch. Ends with the tile's aggregate published to the look-back.
+DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t, unsigned long long& t_prev) {
   const uint32_t lane = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
   const uint64_t lo64 = (uint64_t)tile * TB;
   const uint32_t lo = (uint32_t)lo64;
   const uint32_t hi = (uint32_t)(lo64 + TB < q.len ? lo64 + TB : q.len);
-  uint32_t* fail = &q.result[1];
-  unsigned long long t_prev = q.dbg ? clock64() : 0;
+  t.lo = lo; t.hi = hi;
   // ---- stage [lo, hi + HALO), zero past the end of the input. A full interior tile takes the fast
   //      route: all 8 of a lane's 16-byte loads are in flight before the first LDS store.
   {
@@ -140,6 +149,7 @@ __global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
   // ---- every lane guesses an entry into ITS 128 bytes: the first position holding a plausible frame
   //      whose successor is plausible too (or lies outside the tile). 'd' bytes are found 4 at a time.
   const uint32_t a = lo + lane * SUB, a_end = a + SUB < hi ? a + SUB : hi;
+  t.a_end = a_end;
   uint32_t s_l = NO_ENTRY;
   if (a < hi) {
     // all 128 bytes at once (8 independent 16-byte LDS reads): one bit per byte that is 'd', one per
@@ -213,14 +223,26 @@ __global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
   STAMP(3);
   if (has && !stitched) {
     // the lanes do not agree (bytes that mimic a frame inside a value, a malformed header ...): one lane
-    // walks the tile; it walks again below to write the offsets once their base index is known
+    // walks the tile; it walks again (out of global memory) to write the offsets once their base index is known
     if (lane == 0) walk(st, nullptr, lo, hi, q.len, entry, n, e);
     n = (uint32_t)__shfl(n, 0, 64); e = (uint32_t)__shfl(e, 0, 64);
   }
   STAMP(4);
-  // ---- one look-back gives the frames before this tile and how far the chain has come
-  const uint64_t pre = lookback<OpCountExit>(q.ndesc, q.ndesc + q.ntiles, tile, ((uint64_t)n << 32) | e, 0, fail);
+  t.entry = entry; t.n = n; t.e = e; t.s_l = s_l; t.n_l = n_l; t.inc = inc; t.has = has; t.stitched = stitched; t.mine = mine;
+  // the aggregate is published NOW; the prefix is fetched after the wave's second tile has done its local work, so the look-back's
+  // round trips (half of a tile's time when waited for at once) are covered by work
+  lookback_publish(q.ndesc, tile, ((uint64_t)n << 32) | e);
+}
+
+// ---- second phase: the look-back gives the frames before this tile and how far the chain has come; check the guess, write the
+//      offsets. The LDS window may hold another tile by now: the short re-walks read the input itself.
+DEV void bounds_finish(const BoundsParams& q, uint32_t tile, const TileLocal& t, uint32_t* lfail, unsigned long long& t_prev) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t hi = t.hi, n = t.n, entry = t.entry;
+  const bool has = t.has;
+  const uint64_t pre = lookback_resolve<OpCountExit>(q.ndesc, q.ndesc + q.ntiles, tile, ((uint64_t)n << 32) | t.e, 0, lfail);
   const uint64_t N = pre >> 32;
+  if (*lfail) { if (lane == 0) { atomicOr(&q.result[1], 1u); q.hflag[1] = 1u; } }
   STAMP(5);
   if (tile > 0) {
     // If every tile passes this check the guesses are the chain: by induction the exits of the older
@@ -231,30 +253,60 @@ __global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
       if (lane == 0) {
         q.hints[tile] = e_prev;  // what this tile should have started from (>= hi: nothing starts here)
         atomicAdd(&q.result[2], 1u);
+        q.hflag[1] = 1u;
       }
       // a frame that runs past this tile also covers every tile up to its end: tell them all now (tiles
       // inside one long value that mimics frames agree with each other and would otherwise be found
       // one per run)
       if (e_prev >= hi) {
         const uint64_t last = (uint64_t)e_prev / TB;  // tiles tile+1 .. last-1 end at or before e_prev
-        for (uint64_t t = (uint64_t)tile + 1 + lane; t < last && t < q.ntiles; t += 64) q.hints[t] = e_prev;
+        for (uint64_t tt = (uint64_t)tile + 1 + lane; tt < last && tt < q.ntiles; tt += 64) q.hints[tt] = e_prev;
       }
     }
   }
   // ---- offsets at their final indexes: every on-chain lane repeats its short walk (consecutive lanes
   //      write consecutive entries)
-  if (N + n + 1 > q.offs_cap) { if (lane == 0) atomicOr(fail, 2u); return; }
-  if (has && stitched) {
-    if (mine) { uint32_t n2, e2; walk(st, q.offs + N + (inc - n_l), lo, a_end, q.len, s_l, n2, e2); }
+  if (N + n + 1 > q.offs_cap) { if (lane == 0) { atomicOr(&q.result[1], 2u); q.hflag[1] = 1u; } return; }
+  if (has && t.stitched) {
+    if (t.mine) { uint32_t n2, e2; walk(q.in, q.offs + N + (t.inc - t.n_l), 0u, t.a_end, q.len, t.s_l, n2, e2); }
   } else if (has && lane == 0) {
     uint32_t n2, e2;
-    walk(st, q.offs + N, lo, hi, q.len, entry, n2, e2);
+    walk(q.in, q.offs + N, 0u, hi, q.len, entry, n2, e2);
   }
   if (tile == q.ntiles - 1 && lane == 0) {
     q.offs[N + n] = (uint32_t)q.len;
     q.result[0] = (uint32_t)(N + n);
+    q.hflag[0] = (uint32_t)(N + n);
   }
   STAMP(6);
+}
+
+// One wave = TWO consecutive tiles through ONE LDS window: local(A), local(B), finish(A), finish(B). Half as many waves as tiles:
+// a 64 MiB batch (8 192 tiles) is one round of the chip instead of 1.7, and each look-back is resolved a tile's work after it
+// was published.
+__global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
+  __shared__ __attribute__((aligned(16))) u8 st[TB + HALO + 16];
+  __shared__ uint32_t lfail;   // failure bit of THIS wave's look-backs (1 spin gave up)
+  const uint32_t lane = threadIdx.x;
+  if (lane == 0) lfail = 0;
+  unsigned long long t_prev = q.dbg ? clock64() : 0;
+  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next run will use
+    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
+    for (uint32_t i = lane; i < per; i += 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
+  }
+  const uint32_t t0 = 2 * blockIdx.x, t1 = t0 + 1;
+  TileLocal A, B;
+  bounds_local(q, st, t0, A, t_prev);
+  const bool two = t1 < q.ntiles;
+  if (two) {
+    __syncthreads();   // every lane is done with tile A's bytes
+    bounds_local(q, st, t1, B, t_prev);
+  }
+  // B first: the last tile of a group (always a B) publishes the group's aggregate as soon as it has folded the group's tile words,
+  // before it waits for the older groups itself — resolving A first would put A's wait for the older groups in front of that
+  // publication and chain the groups one round trip after the other
+  if (two) bounds_finish(q, t1, B, &lfail, t_prev);
+  bounds_finish(q, t0, A, &lfail, t_prev);
 }
 
 // Cold fallback: one lane follows the whole chain out of global memory.
@@ -264,7 +316,7 @@ __global__ void k_bounds_seq(BoundsParams q) {
   uint32_t n = 0;
   q.result[1] = 0; q.result[2] = 0;
   while (p < q.len) {
-    if (n + 2 > q.offs_cap) { q.result[1] = 2u; return; }
+    if (n + 2 > q.offs_cap) { q.result[1] = 2u; q.hflag[1] = 1u; return; }
     q.offs[n++] = (uint32_t)p;
     uint64_t next = q.len;
     if (q.len - p >= 5) {
@@ -276,6 +328,7 @@ __global__ void k_bounds_seq(BoundsParams q) {
   }
   q.offs[n] = (uint32_t)q.len;
   q.result[0] = n;
+  q.hflag[0] = n;
 }
 
 }  // namespace etlg
@@ -286,17 +339,19 @@ using namespace etlg;
 
 uint32_t etlg_k_bounds_tile_bytes(void) { return TB; }
 
-// Scratch layout (device, caller-owned): vdesc [ntiles] u64 | ndesc [ntiles + ngroups] u64 (both zeroed
-// before every run) | hints [ntiles] u32 (0xFF-filled before the first run only) | result [4] u32 (zeroed).
-void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* vdesc, void* ndesc,
-                          uint32_t* hints, uint32_t* result, int sequential, hipStream_t s) {
+// Scratch (device, caller-owned): two descriptor buffers, each = result block (16 u32, first) | ndesc [ntiles + ngroups] u64, zero when a
+// run starts — every run zeroes the OTHER buffer (`clear`, `clear_words`) — and hints [ntiles] u32, 0xFF-filled (refilled by the
+// caller after a run that set any). hflag: 2 u32 of pinned host memory, zeroed by the caller.
+void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* cur, void* clear, uint32_t clear_words,
+                          uint32_t* hints, uint32_t* hflag, int sequential, hipStream_t s) {
   BoundsParams q;
   q.dbg = (sequential & 2) ? 1u : 0u; sequential &= 1;
   q.in = in; q.len = len; q.offs = offs; q.offs_cap = offs_cap;
   q.ntiles = (uint32_t)((len + TB - 1) / TB);
-  q.vdesc = (unsigned long long*)vdesc; q.ndesc = (unsigned long long*)ndesc; q.hints = hints; q.result = result;
+  q.result = (uint32_t*)cur; q.ndesc = (unsigned long long*)cur + 8; q.hints = hints; q.hflag = hflag;
+  q.d_clear = (unsigned long long*)clear; q.clear_words = clear_words;
   if (sequential) hipLaunchKernelGGL(k_bounds_seq, dim3(1), dim3(64), 0, s, q);
-  else hipLaunchKernelGGL(k_bounds, dim3(q.ntiles), dim3(64), 0, s, q);
+  else hipLaunchKernelGGL(k_bounds, dim3((q.ntiles + 1) / 2), dim3(64), 0, s, q);
 }
 
 }  // extern "C"
