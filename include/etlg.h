@@ -268,9 +268,10 @@ enum {
                                         result blocks live in a ring of 32; a batch that reports an error is
                                         decoded again, on the exact-error path, when it is synced).
                                         With frame_offsets = NULL the record-boundary scan of the batch runs on a
-                                        private stream beside the previous batch's decode and the call returns once
-                                        the frame count is known: the input must be COMPLETE in device memory when
-                                        the call is made (not merely enqueued on the context's stream) */
+                                        private stream beside the previous batch's decode and the call returns with
+                                        that scan in flight (the next call on the context, or the batch's sync,
+                                        enqueues the decode): the input must be COMPLETE in device memory when the
+                                        call is made (not merely enqueued on the context's stream) */
 };
 
 /* buf = `nframes` concatenated CopyData frames exactly as on the socket:
