@@ -172,7 +172,8 @@ struct PlanParams {
   const uint32_t* cols;
   uint32_t dbg;                // ETLG_PLAN_DBG. bit 0: no LDS staging (tests: the in-place reader). Profiling ablations, results are WRONG:
                                // bit 1 stop after staging, bit 2 stop after the message heads, bit 3 no cell decode / row stores, bit 4 no event header stores
-                               // bit 5: phase clocks into DevResult.dbg_t
+                               // bit 5: phase clocks into DevResult.dbg_t; bit 9: one tile per wave (k_plan) even when two would do
+  uint32_t max_row_dw;         // dwords of the widest planned row (k_plan2 keeps a row of up to 6 / 8 dwords in registers)
 };
 
 // ---- columnar hand-off (columns.hip)

@@ -2151,6 +2151,7 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
     q.lds_bytes = q.rows_off + (c->plan_max_row > 32 ? (uint32_t)(64ull * c->plan_max_row + 64) : 0u);
     q.n_tabs = c->n_plan_tabs; q.tabs = (const PlanTab*)c->d_ptabs.p; q.cols = (const uint32_t*)c->d_pcols.p;
     q.dbg = c->plan_dbg;
+    q.max_row_dw = (c->plan_max_row + 3) / 4;
     const size_t per = 2 * (size_t)q.ntiles + ((size_t)q.ntiles + 63) / 64;   // desc[ntiles] | gdesc[ngroups] | dlsn[ntiles]
     const size_t dbytes = per * 8 + 64;
     uint8_t *dcur, *doth;

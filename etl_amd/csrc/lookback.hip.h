@@ -48,8 +48,22 @@ struct OpAdd {
 DEV void lookback_publish(unsigned long long* desc, uint32_t tile, uint64_t agg) {
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(&desc[tile], ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The first words a resolve looks at, requested ahead of time (a wave that resolves two tiles back to back asks for both tiles'
+// words before it waits for the first: their round trips overlap). A word that has not been published yet is simply polled again.
+struct LookbackPre { unsigned long long w0 = 0, w1 = 0; bool valid = false; };
+DEV LookbackPre lookback_prefetch(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t g = tile >> 6, j = tile & 63;
+  LookbackPre r;
+  r.valid = true;
+  if ((uint32_t)lane < j) r.w0 = __hip_atomic_load(&desc[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t idx = (int64_t)g - 1 - 63 + lane;
+  if (idx >= 0) r.w1 = __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
 template <class Op>
-DEV uint64_t lookback_resolve(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg, uint64_t carry, uint32_t* fail);
+DEV uint64_t lookback_resolve(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg, uint64_t carry, uint32_t* fail,
+                              const LookbackPre& pre = LookbackPre());
 
 template <class Op>
 DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg,
@@ -61,20 +75,20 @@ DEV uint64_t lookback(unsigned long long* desc, unsigned long long* gdesc, uint3
 
 template <class Op>
 DEV uint64_t lookback_resolve(unsigned long long* desc, unsigned long long* gdesc, uint32_t tile, uint64_t agg,
-                              uint64_t carry, uint32_t* fail) {
+                              uint64_t carry, uint32_t* fail, const LookbackPre& pre) {
   const int lane = threadIdx.x & 63;
   const uint32_t g = tile >> 6, j = tile & 63;
   uint32_t polls = 0;
   // the first window of group descriptors is requested now, so that its round trip overlaps window 0's
-  unsigned long long w1_pre = 0;
-  {
+  unsigned long long w1_pre = pre.w1;
+  if (!pre.valid) {
     const int64_t idx = (int64_t)g - 1 - 63 + lane;  // same lane mapping as window 1 below
     if (idx >= 0) w1_pre = __hip_atomic_load(&gdesc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   bool pre_valid = true;
   // ---- window 0: earlier tiles of this group (lane l <-> tile g*64 + l, l < j)
-  unsigned long long w0 = 0;
-  bool have = (uint32_t)lane >= j;  // lanes >= j have nothing to fetch
+  unsigned long long w0 = pre.valid ? pre.w0 : 0ull;
+  bool have = (uint32_t)lane >= j || (w0 & ST_MASK) != 0;  // lanes >= j have nothing to fetch
   for (;;) {
     if (!have) {
       w0 = __hip_atomic_load(&desc[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

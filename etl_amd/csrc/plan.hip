@@ -149,9 +149,25 @@ struct OpPlan {  // payload: hi 30 bits = running max of transaction marks, lo 3
 constexpr unsigned long long kValid = 1ull << 62;
 constexpr uint32_t kPlanMaxPolls = 1u << 15;   // bounded spin (tens of milliseconds): a give-up sends the batch to the generic kernels
 
-template <class M>
-DEV void plan_tile(const DecParams& p, const PlanParams& q, const M& m, u8* rows, bool stage_own, uint32_t a0, uint32_t tile, uint32_t nt, uint32_t my_o,
-                   uint32_t span0, uint32_t span1, unsigned long long tprev) {
+// What a tile carries from its local phase (heads, publish, rows) to its finish (resolve, context, stores). A wave runs TWO tiles
+// through one LDS window — local(A), local(B), finish(A), finish(B) — so A's state, its row image included, lives in registers.
+template <int RD>
+struct PlanLocal {
+  uint32_t tbl, slot_id, pm, x_fx, fixed_dw, vbytes, bad;
+  uint32_t tagf;           // tag | c_flags << 8 | isI << 16 | isB << 17 | isC << 18 | live << 19
+  uint64_t wal_start, b_lsn;
+  uint32_t* rimg;          // where the frame's body waits in LDS, or (the wave's first tile: the window is reused) ...
+  uint32_t row[RD];        // ... the body itself (RD dwords: 6 or 8)
+  uint64_t ord;            // written by plan_resolve (as is b_lsn: the commit_lsn column from then on)
+  uint64_t agg, carry, tile_lsn, ex, tile_pre_lsn;   // wave-uniform from here on
+  uint32_t tot_mark, tot_fx;
+  bool early, done;
+};
+
+template <class M, int RD>
+DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* rows, bool stage_own, uint32_t a0, uint32_t tile, uint32_t nt, uint32_t my_o,
+                    uint32_t span0, uint32_t span1, unsigned long long& tprev, PlanLocal<RD>& L, bool keep) {
+  L.done = true;   // until the local phase has run to its end
   const uint32_t lane = threadIdx.x;
   const bool live = lane < nt;
   const uint32_t f = tile * 64u + lane;
@@ -296,11 +312,38 @@ DEV void plan_tile(const DecParams& p, const PlanParams& q, const M& m, u8* rows
   }
   PSTAMP(3);
   WSTAMP(3);
+  // (storing the header columns that do not depend on the look-back here, early, was tried: the descriptor loads of the finish
+  // phase then queue behind those stores — memory operations of a wave return in order — and the kernel got 4 us slower)
+  L.tbl = isB ? b_xid : isI ? rel : 0u; L.slot_id = isI ? slot_id : 0u; L.pm = pm; L.x_fx = x_fx; L.fixed_dw = fixed_dw; L.vbytes = vbytes; L.bad = bad;
+  L.tagf = tag | (c_flags << 8) | ((isI ? 1u : 0u) << 16) | ((isB ? 1u : 0u) << 17) | ((isC ? 1u : 0u) << 18) | ((live ? 1u : 0u) << 19);
+  L.wal_start = wal_start; L.b_lsn = b_lsn; L.rimg = rimg;
+  if (keep) {
+#pragma unroll
+    for (int d = 0; d < RD; d++) L.row[d] = rimg[d];   // inside the frame's own 38-byte head (or the lane's 32 bytes): always readable
+  }
+  L.agg = agg; L.carry = carry; L.tile_lsn = tile_lsn; L.ex = ex; L.tot_mark = tot_mark; L.tot_fx = tot_fx; L.early = early; L.done = false;
+}
+
+// Finish, part 1: everything that LOADS — the look-back's answer, the open Begin's LSN word — and the transaction context. A wave runs
+// this for both of its tiles before it stores anything: memory operations of a wave return in order, so a descriptor load issued
+// behind a tile's row / header stores waits for those stores to be acknowledged first.
+template <int RD>
+DEV void plan_resolve(const DecParams& p, const PlanParams& q, uint32_t tile, PlanLocal<RD>& L, unsigned long long& tprev,
+                      const LookbackPre& pre = LookbackPre()) {
+  if (L.done) return;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t f = tile * 64u + lane;
+  uint32_t* failp = &p.res->fused_fail;
+  uint32_t bad = L.bad;
+  const bool isI = (L.tagf >> 16) & 1u, isB = (L.tagf >> 17) & 1u, isC = (L.tagf >> 18) & 1u;
+  const uint32_t pm = L.pm;
+  const uint64_t b_lsn = L.b_lsn;
+  uint64_t ex = L.ex;
 
   // ---- (3) the look-back's answer
-  if (!early) ex = lookback_resolve<OpPlan>(q.desc, q.desc + q.ntiles, tile, agg, carry, failp);
+  if (!L.early) ex = lookback_resolve<OpPlan>(q.desc, q.desc + q.ntiles, tile, L.agg, L.carry, failp, pre);
+  PSTAMP(7);
   const uint32_t pre_mark = (uint32_t)(ex >> 32);
-  const uint64_t pre_fx = (uint64_t)(uint32_t)ex << 2;  // bytes
   uint64_t pre_lsn = p.final_lsn;   // LSN of the Begin that is open when this tile starts
   if ((pre_mark & 1u) && (pre_mark >> 1) != 0) {  // wave-uniform: that Begin lives in an earlier tile, which published its LSN word with its descriptor
     unsigned long long* dlsn = q.desc + q.ntiles + ((q.ntiles + 63u) >> 6);
@@ -309,7 +352,7 @@ DEV void plan_tile(const DecParams& p, const PlanParams& q, const M& m, u8* rows
     for (uint32_t polls = 0;; polls++) {
       ll = __hip_atomic_load(&dlsn[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ll & kValid) break;
-      if (polls > kPlanMaxPolls) { if (lane == 0) atomicOr(failp, 1u); return; }
+      if (polls > kPlanMaxPolls) { if (lane == 0) atomicOr(failp, 1u); L.done = true; return; }
       __builtin_amdgcn_s_sleep(2);
     }
     pre_lsn = ll & ~(3ull << 62);
@@ -333,6 +376,25 @@ DEV void plan_tile(const DecParams& p, const PlanParams& q, const M& m, u8* rows
   if (!isB && in_txn) ord = fb1 == 0 ? p.next_ord + f : (uint64_t)(f - (fb1 - 1));
   bad |= (uint32_t)((isI || isC) && !in_txn);               // "Invalid transaction state"
   bad |= (uint32_t)(isC && in_txn && b_lsn != final_lsn);   // "Invalid commit LSN"
+  L.bad = bad; L.ex = ex; L.tile_pre_lsn = pre_lsn;
+  L.b_lsn = isI ? final_lsn : b_lsn;   // from here on: the event's commit_lsn column
+  L.ord = ord;
+}
+
+// Finish, part 2: everything that STORES.
+template <bool REGS, int RD>
+DEV void plan_store(const DecParams& p, const PlanParams& q, uint32_t tile, const PlanLocal<RD>& L, unsigned long long& tprev) {
+  if (L.done) return;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t f = tile * 64u + lane;
+  uint32_t* failp = &p.res->fused_fail;
+  const uint32_t bad = L.bad;
+  const uint32_t tag = L.tagf & 0xFFu, c_flags = (L.tagf >> 8) & 0xFFu;
+  const bool live = (L.tagf >> 19) & 1u;
+  const uint32_t x_fx = L.x_fx, fixed_dw = L.fixed_dw, vbytes = L.vbytes, tot_mark = L.tot_mark, tot_fx = L.tot_fx;
+  const uint64_t tile_lsn = L.tile_lsn, pre_lsn = L.tile_pre_lsn;
+  const uint32_t pre_mark = (uint32_t)(L.ex >> 32);
+  const uint64_t pre_fx = (uint64_t)(uint32_t)L.ex << 2;  // bytes
 
   // ---- totals and the carried transaction state (last tile)
   if (tile == q.ntiles - 1 && lane == 0) {
@@ -356,18 +418,24 @@ DEV void plan_tile(const DecParams& p, const PlanParams& q, const M& m, u8* rows
   const bool cap_ok = pre_fx + ((uint64_t)tot_fx << 2) <= p.fixed_cap;
   if (!any_bad && cap_ok && !(q.dbg & 8u)) {
     uint32_t* dst = (uint32_t*)(p.fixed + fx_off);
-    for (uint32_t d = 0; d < fixed_dw; d++) dst[d] = rimg[d];
+    if (REGS) {
+#pragma unroll
+      for (uint32_t d = 0; d < (uint32_t)RD; d++) if (d < fixed_dw) dst[d] = L.row[d];
+    } else {
+      const uint32_t* rimg = L.rimg;
+      for (uint32_t d = 0; d < fixed_dw; d++) dst[d] = rimg[d];
+    }
   }
   PSTAMP(5);
   // ---- event headers (A13/A15)
   if (live && !any_bad && cap_ok && !(q.dbg & 16u)) {  // profiling: bit 4 skips the event header stores
     p.ev_kind[f] = (u8)tag;
     p.ev_flags[f] = (u8)c_flags;
-    p.ev_table[f] = isB ? b_xid : isI ? rel : 0u;
-    p.ev_slot[f] = isI ? slot_id : 0u;
-    p.ev_start[f] = wal_start;
-    p.ev_commit[f] = isI ? final_lsn : b_lsn;
-    p.ev_ord[f] = ord;
+    p.ev_table[f] = L.tbl;
+    p.ev_slot[f] = L.slot_id;
+    p.ev_start[f] = L.wal_start;
+    p.ev_commit[f] = L.b_lsn;
+    p.ev_ord[f] = L.ord;
     p.ev_body[f] = fx_off;
   }
   PSTAMP(6);
@@ -378,22 +446,25 @@ DEV void plan_tile(const DecParams& p, const PlanParams& q, const M& m, u8* rows
   if ((any_bad || !cap_ok) && lane == 0) atomicOr(failp, 2u);
 }
 
-__global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan(DecParams p, PlanParams q) {
-  ETLG_DYNAMIC_LDS(smem);
+// A tile's frames: their count, the byte span (two scalar loads) and this lane's offset
+struct TileSpan { uint32_t nt, span0, span1, my_o; };
+DEV TileSpan plan_span(const DecParams& p, uint32_t tile) {
   const uint32_t lane = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
-  unsigned long long tprev = (q.dbg & 32u) ? clock64() : 0ull;
-  WSTAMP(0);
-  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
-    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
-    for (uint32_t i = lane; i < per; i += 64) { const uint32_t w = tile * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
-  }
-  if (!load_carry(p)) return;  // ASYNC chain: the batch before this one left no state to start from
+  TileSpan t;
   const uint32_t f0 = tile * 64u;
-  const uint32_t nt = p.nframes - f0 < 64u ? p.nframes - f0 : 64u;
+  t.nt = p.nframes - f0 < 64u ? p.nframes - f0 : 64u;
   const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)p.offs;
-  const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
-  const uint32_t my_o = lane < nt ? p.offs[f0 + lane] : span1;
+  t.span0 = offs_c[f0]; t.span1 = offs_c[f0 + t.nt];
+  t.my_o = lane < t.nt ? p.offs[f0 + lane] : t.span1;
+  return t;
+}
+
+// Stages one tile (LDS-DMA) and runs its local phase.
+template <int RD>
+DEV void plan_stage_local(const DecParams& p, const PlanParams& q, u8* smem, uint32_t tile, const TileSpan& ts, unsigned long long& tprev, PlanLocal<RD>& L, bool keep) {
+  const uint32_t lane = threadIdx.x;
+  L.done = true;
+  const uint32_t nt = ts.nt, span0 = ts.span0, span1 = ts.span1, my_o = ts.my_o;
   PSTAMP(0);
   const uint32_t a0 = span0 & ~15u;
   const bool staged = span1 > span0 && span1 <= p.in_len && (uint64_t)(span1 - a0) + 64 <= q.rows_off && !(q.dbg & 1u);
@@ -412,11 +483,64 @@ __global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan(DecParams p, Pl
     WSTAMP(1);
     if (q.dbg & 2u) { if (smem[lane * 97u] == 0xEE && smem[lane * 13u + 5u] == 0xEF && my_o == 0xFFFFFFF1u) atomicOr(&p.res->fused_fail, 2u); return; }  // profiling: staging only
     const WinLds m{(const ETLG_LDS_AS u8*)smem};
-    plan_tile(p, q, m, smem, true, a0, tile, nt, my_o, span0, span1, tprev);
+    plan_local(p, q, m, smem, true, a0, tile, nt, my_o, span0, span1, tprev, L, keep);
   } else {
     const WinGlb m{p.in, (uint32_t)p.in_len};
-    plan_tile(p, q, m, smem, false, 0u, tile, nt, my_o, span0, span1, tprev);
+    plan_local(p, q, m, smem, false, 0u, tile, nt, my_o, span0, span1, tprev, L, keep);
   }
+}
+
+// TWO: a wave takes two consecutive tiles through ONE LDS window — local(A), local(B), finish(A), finish(B): half as many waves
+// as tiles (a 64 MiB cfg2 batch is 4 645 waves: one round of the chip's ~5 100 slots instead of 1.8), and A's look-back is resolved
+// a whole tile's work after it was published. Only for rows of up to 8 dwords (A's image waits in registers).
+template <bool TWO, int RD>
+DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
+  const uint32_t lane = threadIdx.x;
+  unsigned long long tprev = (q.dbg & 32u) ? clock64() : 0ull;
+  WSTAMP(0);
+  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
+    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
+    for (uint32_t i = lane; i < per; i += 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
+  }
+  if (!load_carry(p)) return;  // ASYNC chain: the batch before this one left no state to start from
+  const uint32_t t0 = TWO ? 2u * blockIdx.x : blockIdx.x;
+  const TileSpan sa = plan_span(p, t0);
+  TileSpan sb = sa;
+  if (TWO && t0 + 1u < q.ntiles) sb = plan_span(p, t0 + 1u);   // B's offsets travel while A is worked on
+  PlanLocal<RD> A;
+  plan_stage_local(p, q, smem, t0, sa, tprev, A, TWO);
+  if (TWO) {
+    const uint32_t t1 = t0 + 1u;
+    PlanLocal<RD> B;
+    B.done = true;
+    if (t1 < q.ntiles) {
+      __threadfence_block();
+      __syncthreads();   // every read of A's window has returned before B's bytes land in it
+      plan_stage_local(p, q, smem, t1, sb, tprev, B, false);
+    }
+    // both tiles' first look-back words are requested before the first wait: one round trip instead of two
+    LookbackPre preA, preB;
+    if (!A.done && !A.early) preA = lookback_prefetch(q.desc, q.desc + q.ntiles, t0);
+    if (!B.done && !B.early) preB = lookback_prefetch(q.desc, q.desc + q.ntiles, t1);
+    plan_resolve(p, q, t0, A, tprev, preA);
+    plan_resolve(p, q, t1, B, tprev, preB);
+    plan_store<true>(p, q, t0, A, tprev);
+    plan_store<false>(p, q, t1, B, tprev);
+  } else {
+    plan_resolve(p, q, t0, A, tprev);
+    plan_store<false>(p, q, t0, A, tprev);
+  }
+}
+
+__global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan(DecParams p, PlanParams q) {
+  ETLG_DYNAMIC_LDS(smem);
+  plan_kernel<false, 1>(p, q, smem);
+}
+
+template <int RD>
+__global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan2(DecParams p, PlanParams q) {
+  ETLG_DYNAMIC_LDS(smem);
+  plan_kernel<true, RD>(p, q, smem);
 }
 
 }  // namespace etlg
@@ -427,11 +551,18 @@ using namespace etlg;
 
 void etlg_k_launch_plan(const DecParams* p, const void* qv, hipStream_t s) {
   const PlanParams* q = (const PlanParams*)qv;
-  hipLaunchKernelGGL(k_plan, dim3(q->ntiles), dim3(64), q->lds_bytes, s, *p, *q);
+  // two tiles per wave whenever a row fits 8 dwords (its image then needs no LDS beyond the window); ETLG_PLAN_DBG bit 9 = one tile per wave
+  if (q->lds_bytes == q->rows_off && q->max_row_dw <= 8u && !(q->dbg & 512u)) {
+    if (q->max_row_dw <= 6u) hipLaunchKernelGGL(k_plan2<6>, dim3((q->ntiles + 1) / 2), dim3(64), q->lds_bytes, s, *p, *q);
+    else hipLaunchKernelGGL(k_plan2<8>, dim3((q->ntiles + 1) / 2), dim3(64), q->lds_bytes, s, *p, *q);
+  } else hipLaunchKernelGGL(k_plan, dim3(q->ntiles), dim3(64), q->lds_bytes, s, *p, *q);
 }
 
 int etlg_k_plan_set_lds(void) {
-  return hipFuncSetAttribute((const void*)k_plan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
+  const int a = hipFuncSetAttribute((const void*)k_plan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
+  const int b = hipFuncSetAttribute((const void*)k_plan2<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
+  const int c = hipFuncSetAttribute((const void*)k_plan2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
+  return a | b | c;
 }
 
 }  // extern "C"
