@@ -17,6 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r["Kernel_Name"]
             if "etlg::k_" not in k: continue
             k = k.split("etlg::")[1].split("<")[0].split("(")[0]
+            if k == "k_plan2": k = "k_plan"   # the library's profiler reports both instantiations of the plan kernel under one name
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 best = max(tot, key=lambda k: tot[k].get("FETCH_SIZE", 0))
 fetch_kb = tot[best]["FETCH_SIZE"] / n[(best, "FETCH_SIZE")]
