@@ -239,3 +239,37 @@ def test_malformed_array_literals_fail_like_the_reference(lit, col):
     o = oracle.Oracle()
     assert ei.value.description == o.L.oracle_err_description(ei.value.code).decode()
     b.close(); d.close()
+
+
+def test_full_size_batch_columns_and_rowbinary():
+    """BASELINE-size (64 MiB) cfg2 batch: the device-built columns equal the host gather over the SAME arena (whose parity with
+    the oracle is test_gpu_parity's job), and the RowBinary buffer equals a vectorised restatement of the reference's row
+    (5 x Int32 LE, _etl_version = tx_ordinal | commit_lsn << 64 as UInt128 LE, _etl_deleted UInt8)."""
+    if os.environ.get("ETLG_SIMT_RUN") == "1":
+        pytest.skip("full size: MI355X only")
+    from etl_amd.decoder import Decoder
+    w = synth.cfg2()
+    d = Decoder(0)
+    w.register(d)
+    buf, offs = w.fill(64 << 20)
+    b = d.decode(buf, offs, flags=abi.F_OUTPUT_ON_DEVICE)
+    assert b.rc == 0
+    cols = b.columns(0)
+    rb = b.rowbinary(0, [0] * 5 + [0, 0], abi.CH_REPLACING_MERGE_TREE)
+    got = columns_to_record_batch(cols)
+    rows_ev = cols.row_event().copy()
+    rb_bytes, rb_offs, rb_ev = rb.bytes().copy(), rb.row_offsets().copy(), rb.row_event().copy()
+    hb = b.host()                                    # downloads the arena: the batch leaves the device here
+    want = rows_to_record_batch(hb, 0)
+    _same(want, got)
+    ins = np.flatnonzero(hb.kind == ord("I"))
+    assert len(ins) > 500_000 and np.array_equal(rows_ev, ins.astype(np.uint64)) and np.array_equal(rb_ev, rows_ev)
+    n = len(ins)
+    exp = np.zeros((n, 37), dtype=np.uint8)
+    for c in range(5):
+        exp[:, 4 * c:4 * c + 4] = np.ascontiguousarray(want.column(c).to_numpy().astype("<i4")).view(np.uint8).reshape(n, 4)
+    exp[:, 20:28] = np.ascontiguousarray(hb.tx_ordinal[ins].astype("<u8")).view(np.uint8).reshape(n, 8)
+    exp[:, 28:36] = np.ascontiguousarray(hb.commit_lsn[ins].astype("<u8")).view(np.uint8).reshape(n, 8)
+    assert np.array_equal(rb_offs, np.arange(n + 1, dtype=np.int64) * 37)
+    assert np.array_equal(rb_bytes.reshape(n, 37), exp)
+    cols.close(); rb.close(); b.close(); d.close()
