@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void k_col_copy(ColJob j) {
 
 
 // ---- array literals (parse_cell_from_postgres_text_array, crates/etl/src/postgres/codec/text.rs:228-312; the dimensions
-// prefix :163-214) for the element classes with a fixed-width value: bool, int2, int4, int8, oid. One thread per row walks its
+// prefix :163-214) for the element classes with a fixed-width value: bool, int2, int4, int8, oid, float4, float8, date, time,
+// timestamp, timestamptz, uuid. One thread per row walks its
 // text twice: k_arr_count (shape errors, element parse errors, element count), then k_arr_fill behind the offsets scan.
 constexpr uint32_t kArrElemMax = 40;   // an element text longer than this is left to the host (Rust accepts any number of leading zeros)
 enum : uint32_t { ARR_HOST = 0x100 };  // not an error: the row is handed back deferred
@@ -253,7 +254,9 @@ DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& co
     uint32_t w[4] = {0, 0, 0, 0};
     if (!is_null) {
       uint32_t hcur = 0, st = 0;
-      if (const uint32_t e = decode_text_cell<true>(elem_cls, val, vl, w, nullptr, hcur, st, false)) return e;
+      uint32_t scratch[(kArrElemMax + 7) / 4];   // where a DEFERRED element's text would go: the row is handed back whole instead
+      if (const uint32_t e = decode_text_cell<true>(elem_cls, val, vl, w, (u8*)scratch, hcur, st, false)) return e;
+      if (st != ETLG_CELL_VALUE) return ARR_HOST;   // a float text the device rule does not settle, a temporal shape outside the fast path
     }
     elem(count, is_null, w);
     count++;
@@ -305,10 +308,15 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
     const uint64_t e = o + k;
     if (is_null) { nulls++; }
     else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
-    switch (j.kind) {   // child layout
+    switch (j.kind) {   // child layout: the same conversions as k_col_fixed
       case AK_BOOL: if (!is_null && w[0]) atomicOr(&((uint32_t*)j.values)[e >> 5], 1u << (e & 31)); break;
-      case AK_I32: ((uint32_t*)j.values)[e] = w[0]; break;
-      default: ((uint64_t*)j.values)[e] = j.elem_cls == ETLG_TC_U32 ? (uint64_t)w[0] : ((uint64_t)w[1] << 32) | w[0]; break;
+      case AK_I32: case AK_F32: ((uint32_t*)j.values)[e] = w[0]; break;
+      case AK_DATE32: ((int32_t*)j.values)[e] = is_null ? 0 : (int32_t)w[0] - kCeDays1970; break;
+      case AK_TIME64: ((int64_t*)j.values)[e] = is_null ? 0 : (int64_t)w[0] * 1000000 + (int64_t)(w[1] / 1000u); break;
+      case AK_TS: case AK_TSTZ:
+        ((int64_t*)j.values)[e] = is_null ? 0 : (((int64_t)(int32_t)w[0] - kCeDays1970) * 86400 + (int64_t)w[1]) * 1000000 + (int64_t)(w[2] / 1000u); break;
+      case AK_FIXED16: ((uint4*)j.values)[e] = make_uint4(w[0], w[1], w[2], w[3]); break;
+      default: ((uint64_t*)j.values)[e] = j.elem_cls == ETLG_TC_U32 ? (uint64_t)w[0] : ((uint64_t)w[1] << 32) | w[0]; break;   // I64, U32, F64
     }
   });
   if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);

@@ -1554,7 +1554,14 @@ ColPlan list_plan(uint32_t elem) {  // array literals the device parses: element
     case ETLG_TC_BOOL: return {ETLG_AK_LIST, 0, true, ETLG_AK_BOOLEAN, 0, elem};
     case ETLG_TC_I16: case ETLG_TC_I32: return {ETLG_AK_LIST, 0, true, ETLG_AK_INT32, 4, elem};
     case ETLG_TC_I64: case ETLG_TC_U32: return {ETLG_AK_LIST, 0, true, ETLG_AK_INT64, 8, elem};
-    default: return {ETLG_AK_TEXT_FORM, 0, true};
+    case ETLG_TC_F32: return {ETLG_AK_LIST, 0, true, ETLG_AK_FLOAT32, 4, elem};
+    case ETLG_TC_F64: return {ETLG_AK_LIST, 0, true, ETLG_AK_FLOAT64, 8, elem};
+    case ETLG_TC_DATE: return {ETLG_AK_LIST, 0, true, ETLG_AK_DATE32, 4, elem};
+    case ETLG_TC_TIME: return {ETLG_AK_LIST, 0, true, ETLG_AK_TIME64_US, 8, elem};
+    case ETLG_TC_TIMESTAMP: return {ETLG_AK_LIST, 0, true, ETLG_AK_TIMESTAMP_US, 8, elem};
+    case ETLG_TC_TIMESTAMPTZ: return {ETLG_AK_LIST, 0, true, ETLG_AK_TIMESTAMP_US_UTC, 8, elem};
+    case ETLG_TC_UUID: return {ETLG_AK_LIST, 0, true, ETLG_AK_FIXED16, 16, elem};
+    default: return {ETLG_AK_TEXT_FORM, 0, true};   // text / numeric / bytea / json / timetz elements: the host's
   }
 }
 ColPlan col_plan(uint32_t cls) {

@@ -273,3 +273,100 @@ def test_full_size_batch_columns_and_rowbinary():
     assert np.array_equal(rb_offs, np.arange(n + 1, dtype=np.int64) * 37)
     assert np.array_equal(rb_bytes.reshape(n, 37), exp)
     cols.close(); rb.close(); b.close(); d.close()
+
+
+ARR2_COLS = [("id", SC.INT8, False, 1), ("f8", 1022, True, 0), ("f4", 1021, True, 0), ("d", 1182, True, 0), ("t", 1183, True, 0),
+             ("ts", 1115, True, 0), ("tz", 1185, True, 0), ("u", 2951, True, 0), ("n", 1231, True, 0)]
+
+
+def _oracle_elems(oid, text):
+    """The oracle's parse of one array literal as Python values comparable with pyarrow's to_pylist()."""
+    import datetime as dt
+    import struct
+    from oracle import oracle
+    r = oracle.parse_text_cell(oid, text)
+    assert r.startswith("Array["), r
+    out = []
+    body = r[6:-1]
+    for e in ([] if not body else body.split(",")):
+        k, _, v = e.partition("(")
+        v = v[:-1]
+        if e == "NULL":
+            out.append(None)
+        elif k in ("F64", "F32") and v == "NaN":
+            out.append(float("nan"))
+        elif k == "F64":
+            out.append(struct.unpack("<d", struct.pack("<Q", int(v, 16)))[0])
+        elif k == "F32":
+            out.append(struct.unpack("<f", struct.pack("<I", int(v, 16)))[0])
+        elif k == "Date":
+            out.append(dt.date.fromisoformat(v))
+        elif k == "Time":
+            out.append(dt.time.fromisoformat(v[:15]))            # microseconds
+        elif k == "Timestamp":
+            out.append(dt.datetime.fromisoformat(v[:26]))
+        elif k == "TimestampTz":
+            out.append(dt.datetime.fromisoformat(v[:26]).replace(tzinfo=dt.timezone.utc))
+        elif k == "Uuid":
+            out.append(bytes.fromhex(v))
+        else:
+            raise AssertionError(e)
+    return out
+
+
+def test_float_temporal_and_uuid_arrays_on_the_device():
+    import math
+    lits = {
+        1: ["{1.5,NULL,-0.25,1e300}", "{}", "{NaN,inf,-Infinity}", '{"3.141592653589793",0}'],
+        2: ["{1.5,3.4028235e38}", "{NULL}", "{-0.5}"],
+        3: ["{2026-01-02,1969-12-31}", "{}", "{NULL,0001-01-01}"],
+        4: ["{12:30:45.123456,00:00:00}", "{23:59:59.5}"],
+        5: ['{"2026-01-02 03:04:05.123456"}', '{"1969-12-31 23:59:59.5",NULL}'],
+        6: ['{"2026-01-02 03:04:05+02","2026-01-02 03:04:05.123456+00"}', "{}"],
+        7: ["{123e4567-e89b-12d3-a456-426614174000,NULL}", "{123E4567E89B12D3A456426614174000}"],
+    }
+    rows = []
+    for i in range(70):
+        rows.append([str(i)] + [lits[c][i % len(lits[c])] for c in range(1, 8)] + ["{1.5,NaN}"])
+    rows.append(["700"] + [W.NULL] * 8)
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(ARR2_COLS), buf, offs)
+    names = [c[0] for c in ARR2_COLS]
+    cols = b.columns(0, parse_arrays=True)
+    assert [cols.column(i).arrow_kind for i in range(1, 9)] == [abi.AK_LIST] * 7 + [abi.AK_TEXT_FORM]     # numeric[] stays text
+    rb = columns_to_record_batch(cols, names=names, on_text="binary")
+    kinds = [pa.float64(), pa.float32(), pa.date32(), pa.time64("us"), pa.timestamp("us"), pa.timestamp("us", tz="UTC"), pa.binary(16)]
+    for ci in range(1, 8):
+        assert rb.schema.field(names[ci]).type == pa.large_list(kinds[ci - 1]), names[ci]
+        want = [None if r[ci] is W.NULL else _oracle_elems(ARR2_COLS[ci][1], r[ci]) for r in rows]
+        got = rb.column(ci).to_pylist()
+        assert len(got) == len(want)
+        for g, w_ in zip(got, want):
+            if w_ is None or g is None:
+                assert g is None and w_ is None, names[ci]
+                continue
+            assert len(g) == len(w_), names[ci]
+            for x, y in zip(g, w_):
+                if isinstance(y, float) and math.isnan(y):
+                    assert math.isnan(x)
+                else:
+                    assert x == y, (names[ci], x, y)
+    cols.close(); b.close(); d.close()
+
+
+def test_array_elements_outside_the_fast_paths_hand_the_row_back():
+    """An element the scalar decoder would hand back DEFERRED (a float text the device rule does not settle, a temporal shape
+    only chrono parses) makes its ROW deferred: null in the list column, set in `deferred`, the rest of the column intact."""
+    rows = [["1", "{1.5}", "{2026-01-02}"], ["2", "{50537618.817359292015891086651596749e82,2}", "{2023-1-01}"], ["3", "{2.5}", "{1999-12-31}"]]
+    cols3 = [("id", SC.INT8, False, 1), ("f8", 1022, True, 0), ("d", 1182, True, 0)]
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(cols3), buf, offs)
+    c = b.columns(0, parse_arrays=True)
+    rb = columns_to_record_batch(c, names=["id", "f8", "d"])
+    assert rb.column(1).to_pylist() == [[1.5], None, [2.5]]
+    import datetime as dt
+    assert rb.column(2).to_pylist() == [[dt.date(2026, 1, 2)], None, [dt.date(1999, 12, 31)]]
+    for i in (1, 2):
+        deferred = np.unpackbits(c.host_arrays(i)[1], bitorder="little")[:3]
+        assert list(deferred) == [0, 1, 0] and c.column(i).deferred_count == 1
+    c.close(); b.close(); d.close()
