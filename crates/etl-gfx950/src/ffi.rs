@@ -187,6 +187,7 @@ pub struct etlg_column {
     pub child_count: u64,
     pub child_null_count: u64,
     pub child_validity: *const u8,
+    pub child_offsets: *const i64,
 }
 
 #[repr(C)]

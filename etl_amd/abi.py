@@ -101,7 +101,7 @@ class Column(C.Structure):   # etlg_column
                 ("null_count", C.c_uint64), ("deferred_count", C.c_uint64), ("validity", C.c_void_p), ("deferred", C.c_void_p),
                 ("values", C.c_void_p), ("offsets", C.c_void_p), ("values_bytes", C.c_uint64),
                 ("child_kind", C.c_uint32), ("_pad", C.c_uint32), ("child_count", C.c_uint64), ("child_null_count", C.c_uint64),
-                ("child_validity", C.c_void_p)]
+                ("child_validity", C.c_void_p), ("child_offsets", C.c_void_p)]
 
 
 class ColumnsView(C.Structure):   # etlg_columns_view

@@ -132,7 +132,11 @@ def columns_to_record_batch(cols, names=None, columns=None, on_text="raise"):
         if k.arrow_kind == abi.AK_LIST:   # array literal parsed on the device: LargeList<child>
             ct = types[k.child_kind]
             cv = None if k.child_null_count == 0 else pa.py_buffer(cols.child_validity(i))
-            child = pa.Array.from_buffers(ct, int(k.child_count), [cv, pa.py_buffer(values)], null_count=int(k.child_null_count))
+            co = cols.child_offsets(i)
+            if k.child_kind == abi.AK_LARGE_UTF8 and co is None:   # no element at all
+                co = np.zeros(1, dtype=np.int64)
+            cbufs = [cv, pa.py_buffer(values)] if co is None else [cv, pa.py_buffer(co), pa.py_buffer(values)]
+            child = pa.Array.from_buffers(ct, int(k.child_count), cbufs, null_count=int(k.child_null_count))
             t = pa.large_list(ct)
             arrays.append(pa.Array.from_buffers(t, n, [vbuf, pa.py_buffer(offsets)], null_count=int(k.null_count), children=[child]))
             fields.append(pa.field(name, t, nullable=bool(k.nullable)))

@@ -220,8 +220,10 @@ DEV uint32_t arr_strip_dims(const u8* s, uint32_t n, uint32_t& start) {   // str
 }
 
 // Calls elem(k, is_null, value words) per element in text order; returns 0, an etlg_err_code, or ARR_HOST.
-template <class F>
-DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& count, F&& elem) {
+// TEXT: string elements (ArrayCell::String: text[], varchar[], and every array type without a dedicated arm) are the unescaped
+// bytes themselves; `dst(k)` says where element k's bytes go (nullptr: they are only counted).
+template <bool TEXT, class F, class D>
+DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& count, F&& elem, D&& dst) {
   uint32_t start;
   count = 0;
   if (const uint32_t e = arr_strip_dims(s0, n0, start)) return e;
@@ -234,6 +236,7 @@ DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& co
   u8 val[kArrElemMax];
   uint32_t vl = 0, pos = 0;
   bool in_quotes = false, in_escape = false, val_quoted = false, done = bn == 0, too_long = false;
+  u8* out = TEXT ? dst(0u) : nullptr;
   while (!done) {
     for (;;) {
       if (pos >= bn) { done = true; break; }
@@ -245,14 +248,22 @@ DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& co
       else if ((c == '{' || c == '}') && !in_quotes) return ETLG_E_ARRAY_MULTIDIM;
       else if (c == ',' && !in_quotes) break;
       else push = true;
-      if (push) { if (vl < kArrElemMax) val[vl] = c; else too_long = true; vl++; }
+      if (push) {
+        if (vl < kArrElemMax) val[vl] = c; else too_long = true;
+        // a text element's bytes leave as they come, except the first four: an unquoted "null" is not text at all
+        if (TEXT && out && vl >= 4) { if (vl == 4) { out[0] = val[0]; out[1] = val[1]; out[2] = val[2]; out[3] = val[3]; } out[vl] = c; }
+        vl++;
+      }
     }
     if (in_quotes) return ETLG_E_ARRAY_QUOTE;
     if (in_escape) return ETLG_E_ARRAY_ESCAPE;
-    if (too_long) return ARR_HOST;
+    if (!TEXT && too_long) return ARR_HOST;
     const bool is_null = !val_quoted && vl == 4 && (val[0] | 0x20) == 'n' && (val[1] | 0x20) == 'u' && (val[2] | 0x20) == 'l' && (val[3] | 0x20) == 'l';
     uint32_t w[4] = {0, 0, 0, 0};
-    if (!is_null) {
+    if (TEXT) {
+      if (out && !is_null && vl <= 4) for (uint32_t b = 0; b < vl; b++) out[b] = val[b];
+      w[0] = is_null ? 0u : vl;
+    } else if (!is_null) {
       uint32_t hcur = 0, st = 0;
       uint32_t scratch[(kArrElemMax + 7) / 4];   // where a DEFERRED element's text would go: the row is handed back whole instead
       if (const uint32_t e = decode_text_cell<true>(elem_cls, val, vl, w, (u8*)scratch, hcur, st, false)) return e;
@@ -261,6 +272,7 @@ DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& co
     elem(count, is_null, w);
     count++;
     vl = 0; val_quoted = false;
+    if (TEXT) out = dst(count);
   }
   return 0;
 }
@@ -281,7 +293,9 @@ __global__ __launch_bounds__(256) void k_arr_count(ColJob j) {
   if (live) {
     const u8* s; uint32_t n, st, cnt = 0;
     if (arr_text(j, r, s, n, st)) {
-      const uint32_t e = arr_walk(s, n, j.elem_cls, cnt, [](uint32_t, bool, const uint32_t*) {});
+      auto none = [](uint32_t) -> u8* { return nullptr; };
+      auto skip = [](uint32_t, bool, const uint32_t*) {};
+      const uint32_t e = j.elem_cls == ETLG_TC_STRING ? arr_walk<true>(s, n, j.elem_cls, cnt, skip, none) : arr_walk<false>(s, n, j.elem_cls, cnt, skip, none);
       if (e == ARR_HOST) { defer = true; cnt = 0; }
       else if (e) { atomicMin(j.err, (unsigned long long)((r << 8) | e)); cnt = 0; }
       else valid = true;
@@ -304,7 +318,22 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
   if (!arr_text(j, r, s, n, st)) return;
   const uint64_t o = (uint64_t)j.offsets[r];
   uint32_t nulls = 0;
-  (void)arr_walk(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w) {
+  if (j.elem_cls == ETLG_TC_STRING) {
+    // pass A (child_lens set, values not): the byte length and validity of every element; pass B (values set): the bytes
+    if (!j.values) {
+      (void)arr_walk<true>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w) {
+        const uint64_t e = o + k;
+        j.child_lens[e] = w[0];
+        if (is_null) nulls++; else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
+      }, [](uint32_t) -> u8* { return nullptr; });
+      if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
+    } else {
+      (void)arr_walk<true>(s, n, j.elem_cls, cnt, [](uint32_t, bool, const uint32_t*) {},
+                           [&](uint32_t k) -> u8* { return k < j.lens[r] ? j.values + j.child_offsets[o + k] : nullptr; });
+    }
+    return;
+  }
+  (void)arr_walk<false>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w) {
     const uint64_t e = o + k;
     if (is_null) { nulls++; }
     else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
@@ -318,7 +347,7 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
       case AK_FIXED16: ((uint4*)j.values)[e] = make_uint4(w[0], w[1], w[2], w[3]); break;
       default: ((uint64_t*)j.values)[e] = j.elem_cls == ETLG_TC_U32 ? (uint64_t)w[0] : ((uint64_t)w[1] << 32) | w[0]; break;   // I64, U32, F64
     }
-  });
+  }, [](uint32_t) -> u8* { return nullptr; });
   if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
 }
 
@@ -526,6 +555,15 @@ void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, i
   } else {
     hipLaunchKernelGGL(k_col_copy, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
   }
+}
+
+// lens (u32, n entries) -> offsets (i64, n + 1 entries); blk: (ceil(n / 256) + 1) x u64 scratch
+void etlg_k_scan_lens(const uint32_t* lens, uint64_t n, unsigned long long* blk, int64_t* offsets, hipStream_t st) {
+  if (!n) return;
+  const uint32_t nb = (uint32_t)((n + 255) / 256);
+  hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, lens, n, blk);
+  hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
+  hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, lens, n, (const unsigned long long*)blk, offsets);
 }
 
 // list columns: step 0 = element counts + list offsets, step 1 = child values / validity

@@ -198,6 +198,7 @@ struct ColJob {
   // list columns (array literals parsed on the device): element class, child validity words, child null counter, first error
   uint32_t elem_cls, _pad;
   uint32_t* child_validity; unsigned long long* child_nulls; unsigned long long* err;
+  uint32_t* child_lens; const int64_t* child_offsets;   // lists of strings: byte length / start of every element
 };
 
 struct HintJob {           // Event::size_hint per event (k_size_hints)

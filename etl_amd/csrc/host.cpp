@@ -46,6 +46,7 @@ extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_
 extern "C" int etlg_k_plan_set_lds(void);
 extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
 extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
+extern "C" void etlg_k_scan_lens(const uint32_t* lens, uint64_t n, unsigned long long* blk, int64_t* offsets, hipStream_t s);
 extern "C" void etlg_k_col_list(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" void etlg_k_size_hints(const void* job, hipStream_t s);
 extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
@@ -328,8 +329,8 @@ struct etlg_batch {
 
 struct HandoffBlocks {  // two device blocks (+ one pinned block when downloaded), taken from / returned to the context's pool
   etlg_ctx* ctx = nullptr; uint64_t ctx_gen = 0;
-  void* d_a = nullptr; void* d_b = nullptr; uint8_t* h = nullptr;
-  size_t cap_a = 0, cap_b = 0, cap_h = 0;
+  void* d_a = nullptr; void* d_b = nullptr; void* d_c = nullptr; uint8_t* h = nullptr;
+  size_t cap_a = 0, cap_b = 0, cap_c = 0, cap_h = 0;
 };
 struct etlg_columns {  // etlg_batch_columns
   etlg_columns_view v{};
@@ -882,8 +883,9 @@ static void blk_give(etlg_ctx* c, uint64_t gen, void* p, size_t cap, bool host) 
   if (host) (void)hipHostFree(p); else (void)hipFree(p);
 }
 static void handoff_release(HandoffBlocks& m) {
-  blk_give(m.ctx, m.ctx_gen, m.d_a, m.cap_a, false); blk_give(m.ctx, m.ctx_gen, m.d_b, m.cap_b, false); blk_give(m.ctx, m.ctx_gen, m.h, m.cap_h, true);
-  m.d_a = m.d_b = nullptr; m.h = nullptr;
+  blk_give(m.ctx, m.ctx_gen, m.d_a, m.cap_a, false); blk_give(m.ctx, m.ctx_gen, m.d_b, m.cap_b, false); blk_give(m.ctx, m.ctx_gen, m.d_c, m.cap_c, false);
+  blk_give(m.ctx, m.ctx_gen, m.h, m.cap_h, true);
+  m.d_a = m.d_b = m.d_c = nullptr; m.h = nullptr;
 }
 struct ScratchBlk {  // a device block for the duration of one call
   etlg_ctx* c; void* p = nullptr; size_t cap = 0;
@@ -1561,7 +1563,8 @@ ColPlan list_plan(uint32_t elem) {  // array literals the device parses: element
     case ETLG_TC_TIMESTAMP: return {ETLG_AK_LIST, 0, true, ETLG_AK_TIMESTAMP_US, 8, elem};
     case ETLG_TC_TIMESTAMPTZ: return {ETLG_AK_LIST, 0, true, ETLG_AK_TIMESTAMP_US_UTC, 8, elem};
     case ETLG_TC_UUID: return {ETLG_AK_LIST, 0, true, ETLG_AK_FIXED16, 16, elem};
-    default: return {ETLG_AK_TEXT_FORM, 0, true};   // text / numeric / bytea / json / timetz elements: the host's
+    case ETLG_TC_STRING: return {ETLG_AK_LIST, 0, true, ETLG_AK_LARGE_UTF8, 0, elem};   // text[], varchar[], and every array type without a dedicated arm
+    default: return {ETLG_AK_TEXT_FORM, 0, true};   // numeric / bytea / json / timetz elements: the host's
   }
 }
 ColPlan col_plan(uint32_t cls) {
@@ -1686,43 +1689,75 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
       return set_error(c, (int32_t)(first & 0xFF), (int64_t)ev);
     }
   }
-  // ---- 3. block B: the bytes of the var-len columns
+  // ---- 3. block B: the bytes of the var-len columns; list columns: child values (or, for lists of strings, child offsets +
+  //      lengths) and child validity
   std::vector<size_t> vb(nc, 0);
   size_t b_bytes = 0;
-  std::vector<size_t> cvb(nc, 0), vbytes(nc, 0);   // list columns: child validity offset; bytes behind `values`
+  std::vector<size_t> cvb(nc, 0), vbytes(nc, 0), clen(nc, 0), cscan(nc, 0);   // list columns: child validity offset; bytes behind `values`; child lens; scan scratch
+  bool any_text_list = false;
   for (uint32_t i = 0; i < nc; i++) {
     if (!lay[i].pl.var) continue;
     const size_t tot = (size_t)var_total[i];
     vb[i] = b_bytes;
     if (lay[i].pl.kind == ETLG_AK_LIST) {
       const size_t bits = (tot + 63) / 64 * 8;
-      vbytes[i] = lay[i].pl.child == ETLG_AK_BOOLEAN ? bits : tot * lay[i].pl.child_bytes;
-      b_bytes += al(vbytes[i]); cvb[i] = b_bytes; b_bytes += al(bits);
+      if (lay[i].pl.child == ETLG_AK_LARGE_UTF8) {   // child offsets first (i64), then lengths, scan scratch, validity
+        any_text_list = true;
+        b_bytes += al((tot + 1) * 8); clen[i] = b_bytes; b_bytes += al(tot * 4); cscan[i] = b_bytes; b_bytes += al((tot / 256 + 2) * 8);
+        cvb[i] = b_bytes; b_bytes += al(bits);
+      } else {
+        vbytes[i] = lay[i].pl.child == ETLG_AK_BOOLEAN ? bits : tot * lay[i].pl.child_bytes;
+        b_bytes += al(vbytes[i]); cvb[i] = b_bytes; b_bytes += al(bits);
+      }
     } else { vbytes[i] = tot; b_bytes += al(tot); }
   }
   if (b_bytes) HIPCHK(c, blk_take(c, b_bytes + 64, false, &cs->m.d_b, &cs->m.cap_b));
   uint8_t* B = (uint8_t*)cs->m.d_b;
+  std::vector<int64_t> text_total(nc, 0);
   for (uint32_t i = 0; i < nc; i++) {
     if (!lay[i].pl.var || var_total[i] <= 0) continue;
-    jobs[i].values = B + vb[i];
     if (lay[i].pl.kind == ETLG_AK_LIST) {
       jobs[i].child_validity = (uint32_t*)(B + cvb[i]);
-      HIPCHK(c, hipMemsetAsync(B + vb[i], 0, cvb[i] - vb[i] + al(((size_t)var_total[i] + 63) / 64 * 8), s));   // bitmaps are OR-ed into
-      etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s);
-    } else etlg_k_col_var(&jobs[i], nullptr, nullptr, 1, s);
+      if (lay[i].pl.child == ETLG_AK_LARGE_UTF8) {   // pass A: byte length + validity of every element, then their offsets
+        jobs[i].values = nullptr; jobs[i].child_lens = (uint32_t*)(B + clen[i]); jobs[i].child_offsets = (const int64_t*)(B + vb[i]);
+        HIPCHK(c, hipMemsetAsync(B + cvb[i], 0, al(((size_t)var_total[i] + 63) / 64 * 8), s));
+        etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s);
+        etlg_k_scan_lens(jobs[i].child_lens, (uint64_t)var_total[i], (unsigned long long*)(B + cscan[i]), (int64_t*)(B + vb[i]), s);
+        HIPCHK(c, hipMemcpyAsync(&text_total[i], B + vb[i] + (size_t)var_total[i] * 8, 8, hipMemcpyDeviceToHost, s));
+      } else {
+        jobs[i].values = B + vb[i];
+        HIPCHK(c, hipMemsetAsync(B + vb[i], 0, cvb[i] - vb[i] + al(((size_t)var_total[i] + 63) / 64 * 8), s));   // bitmaps are OR-ed into
+        etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s);
+      }
+    } else { jobs[i].values = B + vb[i]; etlg_k_col_var(&jobs[i], nullptr, nullptr, 1, s); }
   }
+  // ---- 3b. block C: the element bytes of lists of strings
+  std::vector<size_t> vc(nc, 0);
+  size_t c_bytes = 0;
+  if (any_text_list) {
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.kind == ETLG_AK_LIST && lay[i].pl.child == ETLG_AK_LARGE_UTF8) { vc[i] = c_bytes; vbytes[i] = (size_t)text_total[i]; c_bytes += al((size_t)text_total[i]) + 64; }
+    if (c_bytes) HIPCHK(c, blk_take(c, c_bytes + 64, false, &cs->m.d_c, &cs->m.cap_c));
+    for (uint32_t i = 0; i < nc; i++)
+      if (lay[i].pl.kind == ETLG_AK_LIST && lay[i].pl.child == ETLG_AK_LARGE_UTF8 && var_total[i] > 0) { jobs[i].values = (uint8_t*)cs->m.d_c + vc[i]; etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s); }
+  }
+  uint8_t* Cb = (uint8_t*)cs->m.d_c;
   if (nc) HIPCHK(c, hipMemcpyAsync(cnt.data(), A + o_cnt, (size_t)nc * 32, hipMemcpyDeviceToHost, s));   // again: the child null counts
-  // ---- 4. the view (device pointers, or a host copy of both blocks)
+  // ---- 4. the view (device pointers, or a host copy of the blocks)
   const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
-  const uint8_t* base_a = A; const uint8_t* base_b = B;
+  const uint8_t* base_a = A; const uint8_t* base_b = B; const uint8_t* base_c = Cb;
   if (!on_dev) {
-    HIPCHK(c, blk_take(c, al(o_cnt) + b_bytes + 64, true, (void**)&cs->m.h, &cs->m.cap_h));
+    HIPCHK(c, blk_take(c, al(o_cnt) + al(b_bytes) + c_bytes + 64, true, (void**)&cs->m.h, &cs->m.cap_h));
     if (o_cnt) HIPCHK(c, hipMemcpyAsync(cs->m.h, A, o_cnt, hipMemcpyDeviceToHost, s));
     if (b_bytes) HIPCHK(c, hipMemcpyAsync(cs->m.h + al(o_cnt), B, b_bytes, hipMemcpyDeviceToHost, s));
-    base_a = cs->m.h; base_b = cs->m.h + al(o_cnt);
+    if (c_bytes) HIPCHK(c, hipMemcpyAsync(cs->m.h + al(o_cnt) + al(b_bytes), Cb, c_bytes, hipMemcpyDeviceToHost, s));
+    base_a = cs->m.h; base_b = cs->m.h + al(o_cnt); base_c = cs->m.h + al(o_cnt) + al(b_bytes);
   }
   HIPCHK(c, hipStreamSynchronize(s));   // row_base (freed on return) is read by the kernels above
-  if (!on_dev) { blk_give(c, c->gen, cs->m.d_a, cs->m.cap_a, false); blk_give(c, c->gen, cs->m.d_b, cs->m.cap_b, false); cs->m.d_a = cs->m.d_b = nullptr; }
+  if (!on_dev) {
+    blk_give(c, c->gen, cs->m.d_a, cs->m.cap_a, false); blk_give(c, c->gen, cs->m.d_b, cs->m.cap_b, false); blk_give(c, c->gen, cs->m.d_c, cs->m.cap_c, false);
+    cs->m.d_a = cs->m.d_b = cs->m.d_c = nullptr;
+  }
   cs->cols.resize(nc);
   for (uint32_t i = 0; i < nc; i++) {
     etlg_column& k = cs->cols[i];
@@ -1736,6 +1771,10 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
     if (l.pl.kind == ETLG_AK_LIST) {
       k.child_kind = l.pl.child; k.child_count = (uint64_t)var_total[i]; k.child_null_count = cnt[(size_t)i * 4 + 2];
       k.child_validity = base_b ? base_b + cvb[i] : nullptr;
+      if (l.pl.child == ETLG_AK_LARGE_UTF8) {   // element texts: offsets in block B, bytes in block C
+        k.child_offsets = base_b ? (const int64_t*)(base_b + vb[i]) : nullptr;
+        k.values = base_c ? base_c + vc[i] : nullptr;
+      }
     }
     if (!l.pl.var) { k.values = base_a + l.values; k.values_bytes = l.pl.kind == ETLG_AK_BOOLEAN ? ((n + 63) / 64) * 8 : n * l.pl.vbytes; }
   }

@@ -137,6 +137,10 @@ class Columns:
         k = self.view.cols[i]
         return self._np(k.child_validity, (int(k.child_count) + 63) // 64 * 8, np.uint8)
 
+    def child_offsets(self, i):
+        k = self.view.cols[i]
+        return self._np(k.child_offsets, (int(k.child_count) + 1) * 8, np.int64) if k.child_offsets else None
+
     def row_event(self):
         return self._np(self.view.row_event, self.n_rows * 8, np.uint64)
 

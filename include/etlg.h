@@ -498,7 +498,7 @@ typedef enum etlg_arrow_kind {
   ETLG_AK_TEXT_FORM = 12,   /* numeric / json / arrays: the cell's heap entry (etlg_numeric_hdr + digits, or
                              * the source text), i64 offsets + bytes; the host finishes it */
   ETLG_AK_LIST = 13,        /* only with ETLG_ROWS_PARSE_ARRAYS: arrays of bool / int2 / int4 / int8 / oid / float4 / float8 / date / time /
-                             * timestamp / timestamptz / uuid elements parsed on the device
+                             * timestamp / timestamptz / uuid / text elements parsed on the device
                              * (parse_cell_from_postgres_text_array, codec/text.rs:228-312): i64 list offsets in `offsets`,
                              * child values in `values` (child_kind layout), child validity in `child_validity` */
   ETLG_AK_NONE = 255        /* not handed off (timetz: a display string in the reference) - no buffers */
@@ -518,11 +518,14 @@ typedef struct etlg_column {
   const int64_t* offsets;   /* var-len kinds: n_rows + 1 entries, else NULL */
   uint64_t values_bytes;    /* bytes behind `values` */
   /* ETLG_AK_LIST only */
-  uint32_t child_kind;      /* the element column's etlg_arrow_kind (BOOLEAN, INT32, INT64, FLOAT32/64, DATE32, TIME64_US, TIMESTAMP_US[_UTC], FIXED16) */
+  uint32_t child_kind;      /* the element column's etlg_arrow_kind (BOOLEAN, INT32, INT64, FLOAT32/64, DATE32, TIME64_US, TIMESTAMP_US[_UTC], FIXED16,
+                             * LARGE_UTF8) */
   uint32_t _pad;
   uint64_t child_count;     /* elements of all rows = offsets[n_rows] */
   uint64_t child_null_count;
   const uint8_t* child_validity; /* child_count bits */
+  const int64_t* child_offsets;  /* child_kind ETLG_AK_LARGE_UTF8 (text[] and every array without a dedicated element type): child_count + 1
+                                  * byte offsets into `values`, the unescaped element texts back to back */
 } etlg_column;
 
 typedef struct etlg_columns_view {
