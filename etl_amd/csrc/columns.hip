@@ -384,6 +384,46 @@ DEV void rb_varint(S& s, uint32_t v) {   // LEB128 (:188-199)
 template <class S>
 DEV void rb_2d(S& s, uint32_t v) { s.put((u8)('0' + v / 10)); s.put((u8)('0' + v % 10)); }
 
+// One non-null value of class `cls` whose arena slot words start at `slot` (a row's slot, or the words decode_text_cell produced for
+// an array element). Returns 0, RB_E_DATE_RANGE or RB_E_HOST_CELL.
+template <class S>
+DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
+  const uint32_t w0 = ld32a(slot);
+  switch (cls) {
+    case ETLG_TC_BOOL: s.put(w0 ? 1 : 0); return 0;
+    case ETLG_TC_I16: s.put((u8)w0); s.put((u8)(w0 >> 8)); return 0;
+    case ETLG_TC_I32: case ETLG_TC_U32: case ETLG_TC_F32: s.put32(w0); return 0;
+    case ETLG_TC_I64: case ETLG_TC_F64: s.put64(((uint64_t)ld32a(slot + 4) << 32) | w0); return 0;
+    case ETLG_TC_DATE: {
+      const int32_t days = (int32_t)w0 - kCeDays1970;
+      if (days < kDate32Min || days > kDate32Max) return RB_E_DATE_RANGE;
+      s.put32((uint32_t)days); return 0;
+    }
+    case ETLG_TC_TIME: {  // String(t.to_string()): chrono NaiveTime Display
+      const uint32_t secs = w0, nanos = ld32a(slot + 4);
+      const uint32_t frac = nanos == 0 ? 0u : nanos % 1000000u == 0 ? 4u : nanos % 1000u == 0 ? 7u : 10u;
+      rb_varint(s, 8 + frac);
+      rb_2d(s, secs / 3600); s.put(':'); rb_2d(s, secs / 60 % 60); s.put(':'); rb_2d(s, secs % 60);
+      if (frac) {
+        s.put('.');
+        uint32_t v = frac == 4 ? nanos / 1000000u : frac == 7 ? nanos / 1000u : nanos, div = frac == 4 ? 100u : frac == 7 ? 100000u : 100000000u;
+        for (; div; div /= 10) s.put((u8)('0' + v / div % 10));
+      }
+      return 0;
+    }
+    case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: {
+      const int64_t days = (int64_t)(int32_t)w0 - kCeDays1970;
+      s.put64((uint64_t)((days * 86400 + (int64_t)ld32a(slot + 4)) * 1000000 + (int64_t)(ld32a(slot + 8) / 1000u))); return 0;
+    }
+    case ETLG_TC_UUID:  // high u64 LE then low u64 LE of the big-endian 16 bytes (:240-247)
+      for (int h = 0; h < 2; h++) for (int k = 7; k >= 0; k--) s.put(slot[8 * h + k]);
+      return 0;
+    case ETLG_TC_STRING: if (!heap) return RB_E_HOST_CELL; { const uint32_t len = ld32a(slot + 4); rb_varint(s, len); s.bytes(heap + w0, len); return 0; }
+    case ETLG_TC_BYTEA: if (!heap) return RB_E_HOST_CELL; { const uint32_t len = ld32a(slot + 4); rb_varint(s, 2 * len); s.hex(heap + w0, len); return 0; }
+    default: return RB_E_HOST_CELL;   // numeric / timetz / json: Display strings the host writes
+  }
+}
+
 template <class S>
 DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or column << 8 | code of the first cell that cannot be encoded
   const uint64_t base = j.row_base[r];
@@ -396,43 +436,32 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
       s.put(1);
       continue;
     }
+    const u8* slot = j.fixed + base + off;
+    if (cls == ETLG_TC_ARRAY && st != ETLG_CELL_MISSING) {
+      // Array(Nullable(T)) (:249-254): varint count, then every element with its null marker. The literal (kept as text in the
+      // arena) is walked twice: count, then encode. A literal the device cannot take apart is the host's (it raises the exact error).
+      const uint32_t elem = (cd >> 9) & 0x7Fu;
+      if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA || elem == ETLG_TC_NUMERIC || elem == ETLG_TC_JSON || elem == ETLG_TC_TIMETZ) return (i << 8) | RB_E_HOST_CELL;
+      const u8* txt = j.heap + ld32a(slot);
+      const uint32_t tn = ld32a(slot + 4);
+      uint32_t cnt = 0;
+      auto none = [](uint32_t) -> u8* { return nullptr; };
+      if (arr_walk<false>(txt, tn, elem, cnt, [](uint32_t, bool, const uint32_t*) {}, none)) return (i << 8) | RB_E_HOST_CELL;
+      if (nullable) s.put(0);
+      rb_varint(s, cnt);
+      uint32_t ee = 0;
+      (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w) {
+        if (is_null) { s.put(1); return; }
+        s.put(0);
+        const uint32_t e1 = rb_scalar(s, elem, (const u8*)w, nullptr);
+        if (e1 && !ee) ee = e1;
+      }, none);
+      if (ee) return (i << 8) | ee;
+      continue;
+    }
     if (st != ETLG_CELL_VALUE) return (i << 8) | RB_E_HOST_CELL;
     if (nullable) s.put(0);
-    const u8* slot = j.fixed + base + off;
-    const uint32_t w0 = ld32a(slot);
-    switch (cls) {
-      case ETLG_TC_BOOL: s.put(w0 ? 1 : 0); break;
-      case ETLG_TC_I16: s.put((u8)w0); s.put((u8)(w0 >> 8)); break;
-      case ETLG_TC_I32: case ETLG_TC_U32: case ETLG_TC_F32: s.put32(w0); break;
-      case ETLG_TC_I64: case ETLG_TC_F64: s.put64(((uint64_t)ld32a(slot + 4) << 32) | w0); break;
-      case ETLG_TC_DATE: {
-        const int32_t days = (int32_t)w0 - kCeDays1970;
-        if (days < kDate32Min || days > kDate32Max) return (i << 8) | RB_E_DATE_RANGE;
-        s.put32((uint32_t)days); break;
-      }
-      case ETLG_TC_TIME: {  // String(t.to_string()): chrono NaiveTime Display
-        const uint32_t secs = w0, nanos = ld32a(slot + 4);
-        const uint32_t frac = nanos == 0 ? 0u : nanos % 1000000u == 0 ? 4u : nanos % 1000u == 0 ? 7u : 10u;
-        rb_varint(s, 8 + frac);
-        rb_2d(s, secs / 3600); s.put(':'); rb_2d(s, secs / 60 % 60); s.put(':'); rb_2d(s, secs % 60);
-        if (frac) {
-          s.put('.');
-          uint32_t v = frac == 4 ? nanos / 1000000u : frac == 7 ? nanos / 1000u : nanos, div = frac == 4 ? 100u : frac == 7 ? 100000u : 100000000u;
-          for (; div; div /= 10) s.put((u8)('0' + v / div % 10));
-        }
-        break;
-      }
-      case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: {
-        const int64_t days = (int64_t)(int32_t)w0 - kCeDays1970;
-        s.put64((uint64_t)((days * 86400 + (int64_t)ld32a(slot + 4)) * 1000000 + (int64_t)(ld32a(slot + 8) / 1000u))); break;
-      }
-      case ETLG_TC_UUID:  // high u64 LE then low u64 LE of the big-endian 16 bytes (:240-247)
-        for (int h = 0; h < 2; h++) for (int k = 7; k >= 0; k--) s.put(slot[8 * h + k]);
-        break;
-      case ETLG_TC_STRING: { const uint32_t len = ld32a(slot + 4); rb_varint(s, len); s.bytes(j.heap + w0, len); break; }
-      case ETLG_TC_BYTEA: { const uint32_t len = ld32a(slot + 4); rb_varint(s, 2 * len); s.hex(j.heap + w0, len); break; }
-      default: return (i << 8) | RB_E_HOST_CELL;   // numeric / timetz / json / arrays: Display strings the host writes
-    }
+    if (const uint32_t e = rb_scalar(s, cls, slot, j.heap)) return (i << 8) | e;
   }
   // trailing CDC columns (core.rs:96-114); never NULL, a Nullable() destination column still takes its marker byte
   const uint64_t ev = j.row_event[r];

@@ -1854,12 +1854,19 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
   std::vector<uint32_t> cols(nc);
   for (uint32_t i = 0; i < nc; i++) {
     const uint32_t cls = sh.cols[i].type_class;
-    if (col_plan(cls).kind == ETLG_AK_TEXT_FORM || cls == ETLG_TC_TIMETZ) {  // a Display string in the reference: the host writes it
+    uint32_t elem = 0;
+    bool host_class = col_plan(cls).kind == ETLG_AK_TEXT_FORM || cls == ETLG_TC_TIMETZ;   // a Display string in the reference: the host writes it
+    if (cls == ETLG_TC_ARRAY) {  // arrays of fixed-width elements are encoded on the device (Array(Nullable(T)))
+      elem = (uint32_t)etlg_array_elem_class(sh.cols[i].type_oid);
+      const ColPlan lp = list_plan(elem);
+      host_class = lp.kind != ETLG_AK_LIST || lp.child == ETLG_AK_LARGE_UTF8;
+    }
+    if (host_class) {
       rb->v.status = ETLG_RB_NEEDS_HOST; rb->v.host_column = i;
       *out = rb.release();
       return ETLG_OK;
     }
-    cols[i] = cls | (nullable_flags[i] ? 1u << 8 : 0u) | ((uint32_t)sh.cols[i].off_full << 16);
+    cols[i] = cls | (nullable_flags[i] ? 1u << 8 : 0u) | (elem << 9) | ((uint32_t)sh.cols[i].off_full << 16);
   }
   hipStream_t s = c->stream;
   const etlg_batch_view& bv = b->v;

@@ -558,8 +558,9 @@ void etlg_columns_free(etlg_columns* cols);
  * :188-283) and append_cdc_columns (clickhouse/core.rs:96-114) produce for the rows core.rs:1078-1127 collects:
  * Insert -> the row; Update -> the new row; Delete -> the old row. Rows the reference builds with extra host
  * logic (a Partial update, a Delete that carries only the key) are left out and counted in n_host_rows.
- * Columns of class numeric / timetz / json / array / interval are Display strings in the reference; a slot that
- * has one, or a DEFERRED cell in a row, makes the call return status ETLG_RB_NEEDS_HOST (no bytes). */
+ * Columns of class numeric / timetz / json are Display strings in the reference; a slot that has one (or an array of
+ * those, or of text), or a DEFERRED scalar cell / an array literal the device cannot take apart in a row, makes the call
+ * return status ETLG_RB_NEEDS_HOST (no bytes). Arrays of fixed-width elements are encoded as Array(Nullable(T)). */
 typedef enum etlg_ch_engine {
   ETLG_CH_MERGE_TREE = 0,           /* + cdc_operation String, cdc_lsn UInt64 */
   ETLG_CH_REPLACING_MERGE_TREE = 1  /* + _etl_version UInt128 (commit_lsn << 64 | tx_ordinal), _etl_deleted UInt8 */

@@ -17,6 +17,8 @@ Works on the per-cell tuples of etl_amd.view.HostBatch.materialize()."""
 import struct
 
 MERGE_TREE, REPLACING_MERGE_TREE = 0, 1
+# array types whose element class the device encodes: bool int2 int4 int8 oid float4 float8 date time timestamp timestamptz uuid
+ARRAY_OIDS = {1000, 1005, 1007, 1016, 1028, 1021, 1022, 1182, 1183, 1115, 1185, 2951}
 CE_DAYS_1970 = 719163
 DATE32_MIN, DATE32_MAX = -25567, 120529        # 1900-01-01, 2299-12-31 as days since 1970-01-01
 
@@ -90,7 +92,57 @@ def value(cell):
         return string(cell[1].hex().encode())
     if k == "String":
         return string(cell[1])
+    if k == "Deferred" and cell[1] in ARRAY_OIDS:   # array columns keep their literal in the arena
+        return array(cell[1], cell[2])
     raise NeedsHost(k)
+
+
+def array_elements(type_oid, text):
+    """The elements of an array literal as the cell tuples value() takes, through the C++ oracle's parser
+    (parse_array_text, oracle_codec.hpp — codec/text.rs:228-312) and its repr. Only for element classes whose repr is unambiguous
+    (no strings)."""
+    import datetime as dt
+    from oracle import oracle
+    r = oracle.parse_text_cell(type_oid, text)
+    if not r.startswith("Array["):
+        raise NeedsHost(r)
+    out = []
+    body = r[6:-1]
+    for e in ([] if not body else body.split(",")):
+        k, _, v = e.partition("(")
+        v = v[:-1]
+        if e == "NULL":
+            out.append(("Null",))
+        elif k == "Bool":
+            out.append(("Bool", v == "true"))
+        elif k in ("I16", "I32", "I64", "U32"):
+            out.append((k, int(v)))
+        elif k in ("F32", "F64"):
+            if v == "NaN":
+                raise NeedsHost("NaN bits are not in the repr")
+            out.append((k, int(v, 16)))
+        elif k == "Date":
+            out.append(("Date", dt.date.fromisoformat(v).toordinal()))
+        elif k == "Time":
+            h, m, rest = v.split(":")
+            sec, ns = rest.split(".")
+            out.append(("Time", int(h) * 3600 + int(m) * 60 + int(sec), int(ns)))
+        elif k in ("Timestamp", "TimestampTz"):
+            d, t = v.split(" ")
+            h, m, rest = t.split(":")
+            sec, ns = rest.split(".")
+            out.append((k, dt.date.fromisoformat(d).toordinal(), int(h) * 3600 + int(m) * 60 + int(sec), int(ns)))
+        elif k == "Uuid":
+            out.append(("Uuid", bytes.fromhex(v)))
+        else:
+            raise NeedsHost(e)
+    return out
+
+
+def array(type_oid, text):
+    """rb_encode_value(ClickHouseValue::Array) (encoding.rs:249-254): varint count, every element through rb_encode_nullable."""
+    items = array_elements(type_oid, text)
+    return varint(len(items)) + b"".join(nullable(c) for c in items)
 
 
 def nullable(cell):
