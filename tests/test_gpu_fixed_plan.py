@@ -21,7 +21,7 @@ EXPECT = True
 _KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG")
 
 
-@pytest.fixture(params=["fused256", "fused64", "plan", "plan_inplace"])
+@pytest.fixture(params=["fused256", "fused64", "plan", "plan_one", "plan_inplace"])
 def fused(request):
     """Yields the frames per tile of the forced k_fused instance, or 0 when k_plan is forced."""
     saved = {k: os.environ.pop(k, None) for k in _KNOBS}
@@ -29,6 +29,8 @@ def fused(request):
         os.environ["ETLG_FUSED_KERNEL"] = "3"
         if request.param == "plan_inplace":
             os.environ["ETLG_PLAN_DBG"] = "1"
+        if request.param == "plan_one":
+            os.environ["ETLG_PLAN_DBG"] = "512"   # one tile per wave (k_plan) instead of two (k_plan2)
     else:
         os.environ["ETLG_FUSED_KERNEL"] = "0" if request.param == "fused256" else "1"
         os.environ["ETLG_FUSED_DBG"] = "64"   # k_fused only: count the tiles that took the plan (DevResult.dbg_t[11])
