@@ -147,3 +147,53 @@ def test_async_chain_without_a_sidecar():
         k = int(o2[np.searchsorted(o2, k, side="right")])
     b2[k + 31:k + 35] = 0xEE     # an Insert for a relation id nobody registered
     paths = _run_chain(w, pieces, sidecar=False)
+
+
+def test_deferred_scan_is_collected_by_whatever_comes_next():
+    """An ASYNC batch without a sidecar returns with its boundary scan in flight; the decode is enqueued by the next call on the
+    context — another decode, a control-plane call, a frame-tag query, the batch's own sync, its free, or the context's destroy —
+    and the result is the oracle's every time."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.cfg2()
+    buf, offs = w.fill(1 << 20)
+    pieces = _cut(buf, offs, 4, seed=29)
+    dev = DevBufs(pieces)
+    for what in ("sync", "control_call", "frame_tags", "free", "destroy", "sync_decode"):
+        o, d = oracle.Oracle(), Decoder(0)
+        w.register(o)
+        w.register(d)
+        want = [o.decode(b, f) for b, f in pieces]
+        p0, n0, _, nf0 = dev.items[0]
+        b0 = d.decode_device(p0, n0, None, 0, FLAGS)            # scan in flight, decode not enqueued
+        if what == "sync":
+            pass
+        elif what == "control_call":
+            assert d.table_state(999, abi.TS_READY, 0) == 0     # any call that may change what a batch decodes against
+        elif what == "frame_tags":
+            t = d.frame_tags(pieces[1][0], pieces[1][1])
+            assert len(t) == len(pieces[1][1]) - 1
+        elif what == "free":
+            b0.close()
+            b0 = None
+        elif what == "destroy":
+            d.close()
+            d = None
+            b0 = None
+        elif what == "sync_decode":                              # a synchronous decode behind it: both are decoded, in order
+            p1, n1, po1, nf1 = dev.items[1]
+            b1 = d.decode_device(p1, n1, po1, nf1, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
+            assert b1.rc == 0 and not want[1].host_batch().diff(b1.host())
+            b1.close()
+        if b0 is not None:
+            assert b0.sync() == 0
+            assert b0.view().n_frames == nf0 and not want[0].host_batch().diff(b0.host())
+            b0.close()
+        if d is not None:
+            # the context carries on from the right state
+            if what != "sync_decode":
+                p1, n1, _, nf1 = dev.items[1]
+                b1 = d.decode_device(p1, n1, None, 0, FLAGS)
+                assert b1.sync() == 0 and not want[1].host_batch().diff(b1.host())
+                b1.close()
+            d.close()
