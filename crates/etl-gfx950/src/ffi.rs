@@ -347,6 +347,7 @@ extern "C" {
         flags: u32,
         out: *mut *mut etlg_rowbinary,
     ) -> i32;
+    pub fn etlg_batch_protobuf(ctx: *mut etlg_ctx, batch: *mut etlg_batch, schema_slot: i32, flags: u32, out: *mut *mut etlg_rowbinary) -> i32;
     pub fn etlg_rowbinary_view_get(rb: *const etlg_rowbinary, out: *mut etlg_rowbinary_view) -> i32;
     pub fn etlg_rowbinary_free(rb: *mut etlg_rowbinary);
     pub fn etlg_batch_size_hints(ctx: *mut etlg_ctx, batch: *mut etlg_batch, model: *const etlg_size_model, flags: u32, out: *mut u64) -> i32;

@@ -359,6 +359,7 @@ constexpr int32_t kDate32Min = -25567, kDate32Max = 120529;   // 1900-01-01 .. 2
 struct RbCount {
   uint32_t n = 0;
   DEV void put(u8) { n++; }
+  DEV void varint64(uint64_t v) { do { n++; v >>= 7; } while (v); }
   DEV void put32(uint32_t) { n += 4; }
   DEV void put64(uint64_t) { n += 8; }
   DEV void bytes(const u8*, uint32_t len) { n += len; }
@@ -367,6 +368,7 @@ struct RbCount {
 struct RbWrite {
   u8* p;
   DEV void put(u8 b) { *p++ = b; }
+  DEV void varint64(uint64_t v) { while (v >= 0x80) { *p++ = (u8)(v | 0x80); v >>= 7; } *p++ = (u8)v; }
   DEV void put32(uint32_t v) { for (int k = 0; k < 4; k++) *p++ = (u8)(v >> (8 * k)); }
   DEV void put64(uint64_t v) { for (int k = 0; k < 8; k++) *p++ = (u8)(v >> (8 * k)); }
   DEV void bytes(const u8* s, uint32_t len) { for (uint32_t k = 0; k < len; k++) *p++ = s[k]; }
@@ -482,11 +484,91 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
   return 0;
 }
 
+
+// ---- BigQuery protobuf rows (cell_encode_prost, crates/etl-destinations/src/bigquery/encoding.rs:120-190; the wire format is
+// prost's = protobuf's: key = varint(tag << 3 | wire type), wire types 0 varint, 1 fixed64, 2 length-delimited, 5 fixed32; int32 /
+// int64 as sign-extended 64-bit varints). Insert rows only: the row's cells with tags 1..n (NULL cells leave nothing), then
+// _CHANGE_TYPE = "UPSERT" and _CHANGE_SEQUENCE_NUMBER = "{commit_lsn:016x}/{tx_ordinal:016x}/{0:016x}" (bigquery/core.rs:978-996,
+// 1404-1406; EventSequenceKey Display, crates/etl/src/event.rs:346-351).
+template <class S> DEV void pb_key(S& s, uint32_t tag, uint32_t wt) { s.varint64(((uint64_t)tag << 3) | wt); }
+template <class S> DEV void pb_4d(S& s, uint32_t v) { s.put((u8)('0' + v / 1000 % 10)); s.put((u8)('0' + v / 100 % 10)); s.put((u8)('0' + v / 10 % 10)); s.put((u8)('0' + v % 10)); }
+template <class S> DEV void pb_hex16(S& s, uint64_t v) { for (int k = 15; k >= 0; k--) { const uint32_t d = (uint32_t)(v >> (4 * k)) & 15u; s.put((u8)(d < 10 ? '0' + d : 'a' + d - 10)); } }
+// days from CE (chrono) -> civil date: "%Y-%m-%d" (DATE_FORMAT, etl-postgres/src/time.rs:13); years 0000-9999 (the others are DEFERRED)
+template <class S> DEV void pb_date(S& s, int32_t days_ce) {
+  const int64_t z = (int64_t)days_ce - kCeDays1970 + 719468;
+  const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  const uint32_t doe = (uint32_t)(z - era * 146097);
+  const uint32_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const uint32_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const uint32_t mp = (5 * doy + 2) / 153;
+  const uint32_t d = doy - (153 * mp + 2) / 5 + 1, m = mp < 10 ? mp + 3 : mp - 9;
+  const int64_t y = (int64_t)yoe + era * 400 + (m <= 2 ? 1 : 0);
+  pb_4d(s, (uint32_t)y); s.put('-'); rb_2d(s, m); s.put('-'); rb_2d(s, d);
+}
+DEV uint32_t pb_frac_len(uint32_t nanos) { return nanos == 0 ? 0u : nanos % 1000000u == 0 ? 4u : nanos % 1000u == 0 ? 7u : 10u; }
+// "%H:%M:%S%.f" (TIME_FORMAT :17): chrono prints no fraction, or 3 / 6 / 9 digits
+template <class S> DEV void pb_time(S& s, uint32_t secs, uint32_t nanos) {
+  rb_2d(s, secs / 3600); s.put(':'); rb_2d(s, secs / 60 % 60); s.put(':'); rb_2d(s, secs % 60);
+  const uint32_t frac = pb_frac_len(nanos);
+  if (frac) {
+    s.put('.');
+    uint32_t v = frac == 4 ? nanos / 1000000u : frac == 7 ? nanos / 1000u : nanos, div = frac == 4 ? 100u : frac == 7 ? 100000u : 100000000u;
+    for (; div; div /= 10) s.put((u8)('0' + v / div % 10));
+  }
+}
+
+template <class S>
+DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
+  const uint64_t base = j.row_base[r];
+  for (uint32_t i = 0; i < j.n_cols; i++) {
+    const uint32_t cd = j.cols[i], cls = cd & 0xFF, off = cd >> 16, tag = i + 1;
+    const uint32_t st = (j.fixed[base + i / 4] >> (2 * (i % 4))) & 3u;
+    if (st == ETLG_CELL_NULL) continue;                       // Cell::Null => {}
+    if (st != ETLG_CELL_VALUE) return (i << 8) | RB_E_HOST_CELL;
+    const u8* slot = j.fixed + base + off;
+    const uint32_t w0 = ld32a(slot);
+    switch (cls) {
+      case ETLG_TC_BOOL: pb_key(s, tag, 0); s.put(w0 ? 1 : 0); break;
+      case ETLG_TC_I16: case ETLG_TC_I32: pb_key(s, tag, 0); s.varint64((uint64_t)(int64_t)(int32_t)w0); break;
+      case ETLG_TC_I64: pb_key(s, tag, 0); s.varint64(((uint64_t)ld32a(slot + 4) << 32) | w0); break;
+      case ETLG_TC_U32: pb_key(s, tag, 0); s.varint64((uint64_t)w0); break;
+      case ETLG_TC_F32: pb_key(s, tag, 5); s.put32(w0); break;
+      case ETLG_TC_F64: pb_key(s, tag, 1); s.put64(((uint64_t)ld32a(slot + 4) << 32) | w0); break;
+      case ETLG_TC_STRING: case ETLG_TC_BYTEA: { const uint32_t len = ld32a(slot + 4); pb_key(s, tag, 2); s.varint64(len); s.bytes(j.heap + w0, len); break; }
+      case ETLG_TC_DATE: pb_key(s, tag, 2); s.varint64(10); pb_date(s, (int32_t)w0); break;
+      case ETLG_TC_TIME: { const uint32_t ns = ld32a(slot + 4); pb_key(s, tag, 2); s.varint64(8 + pb_frac_len(ns)); pb_time(s, w0, ns); break; }
+      case ETLG_TC_TIMESTAMP: {  // "%Y-%m-%d %H:%M:%S%.f" (TIMESTAMP_FORMAT :21)
+        const uint32_t secs = ld32a(slot + 4), ns = ld32a(slot + 8);
+        pb_key(s, tag, 2); s.varint64(19 + pb_frac_len(ns)); pb_date(s, (int32_t)w0); s.put(' '); pb_time(s, secs, ns); break;
+      }
+      case ETLG_TC_TIMESTAMPTZ: {  // epoch microseconds as int64 (:176-179)
+        const int64_t days = (int64_t)(int32_t)w0 - kCeDays1970;
+        pb_key(s, tag, 0); s.varint64((uint64_t)((days * 86400 + (int64_t)ld32a(slot + 4)) * 1000000 + (int64_t)(ld32a(slot + 8) / 1000u))); break;
+      }
+      case ETLG_TC_UUID:  // Uuid Display: hyphenated lowercase
+        pb_key(s, tag, 2); s.varint64(36);
+        for (int k = 0; k < 16; k++) {
+          const uint32_t b = slot[k], h = b >> 4, l = b & 15;
+          if (k == 4 || k == 6 || k == 8 || k == 10) s.put('-');
+          s.put((u8)(h < 10 ? '0' + h : 'a' + h - 10)); s.put((u8)(l < 10 ? '0' + l : 'a' + l - 10));
+        }
+        break;
+      default: return (i << 8) | RB_E_HOST_CELL;   // numeric / timetz / json / arrays: host-formatted strings, host-side validation
+    }
+  }
+  const uint64_t ev = j.row_event[r];
+  pb_key(s, j.n_cols + 1, 2); s.varint64(6);
+  { const char* op = "UPSERT"; for (int k = 0; k < 6; k++) s.put((u8)op[k]); }
+  pb_key(s, j.n_cols + 2, 2); s.varint64(50);
+  pb_hex16(s, j.ev_commit[ev]); s.put('/'); pb_hex16(s, j.ev_ord[ev]); s.put('/'); pb_hex16(s, 0);
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void k_rb_lens(RbJob j) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= j.n_rows) return;
   RbCount c;
-  const uint32_t e = rb_row(j, r, c);
+  const uint32_t e = j.format ? pb_row(j, r, c) : rb_row(j, r, c);
   if (e) { atomicMin(j.err, (unsigned long long)((r << 24) | e)); c.n = 0; }
   j.lens[r] = c.n;
 }
@@ -495,7 +577,7 @@ __global__ __launch_bounds__(256) void k_rb_rows(RbJob j) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= j.n_rows || !j.lens[r]) return;
   RbWrite w{j.out + j.offsets[r]};
-  (void)rb_row(j, r, w);
+  if (j.format) (void)pb_row(j, r, w); else (void)rb_row(j, r, w);
 }
 
 

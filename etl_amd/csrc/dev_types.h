@@ -217,7 +217,8 @@ struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
   const uint8_t* ev_kind; const uint64_t* ev_commit; const uint64_t* ev_ord;
   uint64_t n_rows;
   uint32_t n_cols, engine;         // engine: 0 MergeTree, 1 ReplacingMergeTree
-  uint32_t cdc_nullable, _pad;     // bit 0 / 1: the first / second trailing CDC column is Nullable() in the destination
+  uint32_t cdc_nullable;           // bit 0 / 1: the first / second trailing CDC column is Nullable() in the destination
+  uint32_t format;                 // 0 ClickHouse RowBinary, 1 BigQuery protobuf (Insert rows, prost wire format)
   const uint32_t* cols;            // per replicated column: cls | nullable << 8 | off_full << 16
   uint32_t* lens; const int64_t* offsets; uint8_t* out;
   unsigned long long* err;         // min over failing cells of (row << 24 | column << 8 | code); ~0 = none

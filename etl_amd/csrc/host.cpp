@@ -1838,16 +1838,30 @@ void etlg_columns_free(etlg_columns* cs) {
   delete cs;
 }
 
+static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint8_t* nullable_flags, uint32_t n_flags, int32_t engine,
+                            uint32_t flags, uint32_t format, etlg_rowbinary** out);
+
 int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint8_t* nullable_flags, uint32_t n_flags, int32_t engine,
                              uint32_t flags, etlg_rowbinary** out) {
   if (!c || !b || !out || b->ctx != c || !nullable_flags) return ETLG_InvalidArgument;
+  return handoff_rows(c, b, slot, nullable_flags, n_flags, engine, flags, 0u, out);
+}
+
+int32_t etlg_batch_protobuf(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t flags, etlg_rowbinary** out) {
+  if (!c || !b || !out || b->ctx != c) return ETLG_InvalidArgument;
+  return handoff_rows(c, b, slot, nullptr, 0u, ETLG_CH_MERGE_TREE, flags, 1u, out);
+}
+
+// format 0: ClickHouse RowBinary (Insert / Update / Delete rows + the engine's CDC columns); 1: BigQuery protobuf (Insert rows)
+static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint8_t* nullable_flags, uint32_t n_flags, int32_t engine,
+                            uint32_t flags, uint32_t format, etlg_rowbinary** out) {
   *out = nullptr;
   if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
   if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_rowbinary needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
   if (slot < 0 || (size_t)slot >= c->slots.size() || (engine != ETLG_CH_MERGE_TREE && engine != ETLG_CH_REPLACING_MERGE_TREE)) return ETLG_InvalidArgument;
   const SlotHost& sh = *c->slots[(size_t)slot];
   const uint32_t nc = sh.desc.n_cols;
-  if (n_flags != nc + 2) return lib_error(c, ETLG_ConversionError, "ClickHouse RowBinary row width mismatch");
+  if (format == 0 && n_flags != nc + 2) return lib_error(c, ETLG_ConversionError, "ClickHouse RowBinary row width mismatch");
   std::unique_ptr<etlg_rowbinary, void (*)(etlg_rowbinary*)> rb(new etlg_rowbinary, etlg_rowbinary_free);
   const bool on_dev = (flags & ETLG_F_OUTPUT_ON_DEVICE) != 0;
   rb->v.on_device = on_dev ? 1u : 0u; rb->v.host_event = ~0ull;
@@ -1856,7 +1870,8 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
     const uint32_t cls = sh.cols[i].type_class;
     uint32_t elem = 0;
     bool host_class = col_plan(cls).kind == ETLG_AK_TEXT_FORM || cls == ETLG_TC_TIMETZ;   // a Display string in the reference: the host writes it
-    if (cls == ETLG_TC_ARRAY) {  // arrays of fixed-width elements are encoded on the device (Array(Nullable(T)))
+    if (format == 1 && cls == ETLG_TC_ARRAY) host_class = true;   // packed / repeated array fields + NULL-element validation: the host's
+    else if (cls == ETLG_TC_ARRAY) {  // arrays of fixed-width elements are encoded on the device (Array(Nullable(T)))
       elem = (uint32_t)etlg_array_elem_class(sh.cols[i].type_oid);
       const ColPlan lp = list_plan(elem);
       host_class = lp.kind != ETLG_AK_LIST || lp.child == ETLG_AK_LARGE_UTF8;
@@ -1866,7 +1881,7 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
       *out = rb.release();
       return ETLG_OK;
     }
-    cols[i] = cls | (nullable_flags[i] ? 1u << 8 : 0u) | (elem << 9) | ((uint32_t)sh.cols[i].off_full << 16);
+    cols[i] = cls | ((nullable_flags && nullable_flags[i]) ? 1u << 8 : 0u) | (elem << 9) | ((uint32_t)sh.cols[i].off_full << 16);
   }
   hipStream_t s = c->stream;
   const etlg_batch_view& bv = b->v;
@@ -1892,7 +1907,7 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
   if (ne) {
     ColSel q{};
     q.ev_kind = bv.ev_kind; q.ev_flags = bv.ev_flags; q.ev_slot = bv.ev_schema_slot; q.ev_body = bv.ev_body_off;
-    q.n_events = ne; q.slot = (uint32_t)slot; q.kinds = 7u; q.host_rows = (unsigned long long*)(S + o_cnt);
+    q.n_events = ne; q.slot = (uint32_t)slot; q.kinds = format ? 1u : 7u; q.host_rows = (unsigned long long*)(S + o_cnt);
     q.row_full = sh.desc.row_bytes_full; q.row_key = sh.desc.row_bytes_key;
     q.blk = (uint32_t*)S; q.nblocks = nblk; q.row_event = (uint64_t*)A; q.row_base = (uint64_t*)(S + o_base);
     etlg_k_col_select(&q, s);
@@ -1904,7 +1919,8 @@ int32_t etlg_batch_rowbinary(etlg_ctx* c, etlg_batch* b, int32_t slot, const uin
   j.fixed = bv.fixed; j.heap = bv.heap; j.row_event = (const uint64_t*)A; j.row_base = (const uint64_t*)(S + o_base);
   j.ev_kind = bv.ev_kind; j.ev_commit = bv.ev_commit_lsn; j.ev_ord = bv.ev_tx_ordinal;
   j.n_rows = n; j.n_cols = nc; j.engine = (uint32_t)engine;
-  j.cdc_nullable = (nullable_flags[nc] ? 1u : 0u) | (nullable_flags[nc + 1] ? 2u : 0u);
+  j.cdc_nullable = nullable_flags ? (nullable_flags[nc] ? 1u : 0u) | (nullable_flags[nc + 1] ? 2u : 0u) : 0u;
+  j.format = format;
   j.cols = (const uint32_t*)(S + o_cols); j.lens = (uint32_t*)(A + o_len); j.offsets = (const int64_t*)(A + o_off);
   j.err = (unsigned long long*)(S + o_cnt) + 1;
   int64_t total = 0;

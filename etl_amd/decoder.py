@@ -91,6 +91,14 @@ class Batch:
             raise self.dec.last_error()
         return RowBinary(self.dec, out)
 
+    def protobuf(self, slot, on_device=False):
+        """BigQuery protobuf rows (one per Insert event) of schema slot `slot`, encoded on the device (etlg_batch_protobuf)."""
+        out = C.c_void_p()
+        rc = self.dec.L.etlg_batch_protobuf(self.dec.h, self.h, slot, abi.F_OUTPUT_ON_DEVICE if on_device else 0, C.byref(out))
+        if rc != abi.OK or not out:
+            raise self.dec.last_error()
+        return RowBinary(self.dec, out)
+
     def close(self):
         if self.h:
             self.dec.L.etlg_batch_free(self.h)

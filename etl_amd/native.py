@@ -21,7 +21,7 @@ EXPORTS = [
     "etlg_ctx_profile_read", "etlg_scan_boundaries", "etlg_copy_decode", "etlg_frame_tags",
     "etlg_table_forget", "etlg_table_cache_get",
     "etlg_batch_columns", "etlg_columns_view_get", "etlg_columns_free",
-    "etlg_batch_rowbinary", "etlg_rowbinary_view_get", "etlg_rowbinary_free", "etlg_batch_size_hints",
+    "etlg_batch_rowbinary", "etlg_batch_protobuf", "etlg_rowbinary_view_get", "etlg_rowbinary_free", "etlg_batch_size_hints",
 ]
 
 _LIB = None
@@ -95,6 +95,7 @@ def lib():
     L.etlg_columns_free.argtypes = [C.c_void_p]
     L.etlg_columns_free.restype = None
     L.etlg_batch_rowbinary.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.etlg_batch_protobuf.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.etlg_rowbinary_view_get.argtypes = [C.c_void_p, C.c_void_p]
     L.etlg_rowbinary_free.argtypes = [C.c_void_p]
     L.etlg_rowbinary_free.restype = None

@@ -592,6 +592,13 @@ typedef struct etlg_rowbinary etlg_rowbinary;
  * the description, frame_index = the event index). Same batch requirements as etlg_batch_columns. */
 int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, const uint8_t* nullable_flags,
                              uint32_t n_flags, int32_t engine, uint32_t flags, etlg_rowbinary** out);
+/* BigQuery Storage Write rows for ONE schema slot: the protobuf bytes BigQueryTableRow holds for every Insert event
+ * (cell_encode_prost, crates/etl-destinations/src/bigquery/encoding.rs:120-190: field tag = column position + 1, NULL cells
+ * leave nothing; then _CHANGE_TYPE = "UPSERT" and _CHANGE_SEQUENCE_NUMBER = "{commit_lsn:016x}/{tx_ordinal:016x}/{0:016x}",
+ * bigquery/core.rs:978-996, 1404-1406). Updates and deletes need the reference's key-change logic (core.rs:1431-1754): they are
+ * counted in n_host_rows. numeric / timetz / json / array columns (host-formatted strings, host-side validation,
+ * bigquery/validation.rs) and DEFERRED cells return ETLG_RB_NEEDS_HOST. The result is an etlg_rowbinary (same view). */
+int32_t etlg_batch_protobuf(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t flags, etlg_rowbinary** out);
 int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out);
 void etlg_rowbinary_free(etlg_rowbinary* rb);
 
