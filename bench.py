@@ -344,7 +344,7 @@ def leg_copy(dev_id, dev, nrows, reps):
 
 def leg_handoff(dev_id, dev, cap, reps):
     """the decoded cfg2 arena (device-resident) -> Arrow-layout column buffers (etlg_batch_columns) and
-    ClickHouse RowBinary rows (etlg_batch_rowbinary), both left in HBM. Rates are quoted in WAL input bytes per second so
+    ClickHouse RowBinary rows (etlg_batch_rowbinary) and BigQuery protobuf rows (etlg_batch_protobuf), all left in HBM. Rates are quoted in WAL input bytes per second so
     that they compare with `value`; the host-side hand-off of the same arena (etl_amd/arrow.py, numpy) is timed beside."""
     import numpy as np
     import torch
@@ -362,14 +362,15 @@ def leg_handoff(dev_id, dev, cap, reps):
     nc = 5
     out = {"workload": f"one {cap >> 20} MiB cfg2 batch ({len(offs) - 1} frames), arena device-resident, outputs left in HBM"}
     for name, fn in (("arrow_columns", lambda: b.columns(0, on_device=True)),
-                     ("rowbinary", lambda: b.rowbinary(0, [0] * nc + [0, 0], abi.CH_REPLACING_MERGE_TREE, on_device=True))):
+                     ("rowbinary", lambda: b.rowbinary(0, [0] * nc + [0, 0], abi.CH_REPLACING_MERGE_TREE, on_device=True)),
+                     ("protobuf", lambda: b.protobuf(0, on_device=True))):
         fn().close()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             r = fn()
             nrows = r.n_rows
-            nbytes = int(r.view.n_bytes) if name == "rowbinary" else sum(int(r.column(i).values_bytes) for i in range(nc))
+            nbytes = int(r.view.n_bytes) if name != "arrow_columns" else sum(int(r.column(i).values_bytes) for i in range(nc))
             r.close()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
