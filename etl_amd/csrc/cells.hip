@@ -168,66 +168,77 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       if (tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
       if (tag == 'C') mark = (o0 + 1) << 1;
     }
-    // parse_row_msg + walk_tuple for the I / U / D frames, recording every cell. One wave-level loop
-    // over "items" (an image header or a cell) with 32-bit offsets into `base`. This wave runs alone
-    // while the others wait, so the loop body is written without data-dependent branches (bitwise
-    // predicates and selects; every `&&` on lane values would cost an exec-mask round trip): both
-    // interpretations of the next bytes are computed and the lane's state picks one.
+    // parse_row_msg + walk_tuple for the I / U / D frames, recording every cell, with 32-bit offsets into `base`.
+    // This wave runs alone while the others wait and a lone wave issues an instruction every 5-8 cycles, so the
+    // walk is priced per instruction: a frame is at most (image header, cells) twice, and the two kinds of item
+    // get their own wave-level steps — one header step per pass, then a cell loop whose body is a dozen VALU
+    // operations (no data-dependent branches: bitwise predicates and selects).
     {
       const uint32_t tag = v.tag;
+      const bool is_upd = tag == 'U';
       uint32_t c = 0, e = 0, img = tag == 'I' ? 1u : 0u, k = 0, n = 0;
-      bool run = false, hdr = true;
+      bool want_hdr = false, in_cells = false;
       if (live && (tag == 'I' || tag == 'U' || tag == 'D')) {
         c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
         wire_ok = e >= c + 5;
-        if (wire_ok) { rel_id = ld_be32(base + c); c += 4; run = true; }
+        if (wire_ok) { rel_id = ld_be32(base + c); c += 4; want_hdr = true; }
       }
-      const bool is_upd = tag == 'U';
-      while (__ballot(run)) {
-        // the next 8 bytes: item tag + i16 count (header) or item tag + i32 length (cell)
+      // the next 8 bytes of a lane: item tag + i16 count (header) or item tag + i32 length (cell)
+      auto next8 = [&](bool on) -> uint64_t {
+        if (STAGED) return ldu64(base + c);  // the window has 16 spare bytes past any frame
         uint64_t head = 0;
-        if (STAGED) {
-          head = ldu64(base + c);  // the window has 16 spare bytes past any frame
-        } else if (run) {
-          for (uint32_t i = 0; i < 5 && c + i < e; i++) head |= (uint64_t)base[c + i] << (8 * i);
+        if (on) for (uint32_t i = 0; i < 5 && c + i < e; i++) head |= (uint64_t)base[c + i] << (8 * i);
+        return head;
+      };
+      for (int pass = 0; pass < 2; pass++) {  // pass 0: every frame's first image; pass 1: the new image of updates that sent an old one
+        if (!__ballot(want_hdr)) break;
+        {  // image header: 'K' | 'O' | 'N', i16 column count
+          const uint64_t head = next8(want_hdr);
+          const uint32_t t = (uint32_t)head & 0xFFu;
+          const uint32_t room = e - c;  // c <= e holds for a lane that is still going
+          const bool is_old = (t == 'K') | (t == 'O');
+          const uint32_t img_h = ((img == 0) & !is_old & is_upd) ? 1u : img;  // update without an old image
+          const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
+          const bool hdr_ok = (room >= 3) & (img_h == 0 ? is_old : t == 'N') & !(cnt16 & 0x8000u);
+          const bool go = want_hdr & hdr_ok;
+          wire_ok &= !want_hdr | hdr_ok;
+          too_wide |= go & (cnt16 > maxc);
+          c += go ? 3u : 0u;
+          if (go) {
+            img = img_h;
+            old_kind = img_h == 0 ? (t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL) : old_kind;
+            n_old = img_h == 0 ? cnt16 : n_old;
+            n_new = img_h == 0 ? n_new : cnt16;
+            n = cnt16; k = 0;
+          }
+          const bool empty = go & (n == 0);  // an image without cells is complete at once
+          const bool again = empty & (img == 0) & is_upd;
+          in_cells = go & !empty;
+          img = again ? 1u : img;
+          want_hdr = again;
         }
-        const uint32_t t = (uint32_t)head & 0xFFu;
-        const uint32_t room = e - c;  // c <= e holds for a running lane
-        // --- as an image header: 'K' | 'O' | 'N', i16 column count
-        const bool is_old = (t == 'K') | (t == 'O');
-        const uint32_t img_h = ((img == 0) & !is_old & is_upd) ? 1u : img;  // update without an old image
-        const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
-        const bool hdr_ok = (room >= 3) & (img_h == 0 ? is_old : t == 'N') & !(cnt16 & 0x8000u);
-        // --- as a cell: 'n' | 'u' | ('t' | 'b') i32 len bytes
-        const bool is_val = (t == 't') | (t == 'b');
-        const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
-        const uint32_t kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
-        const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
-        // --- the lane's state picks one
-        const bool in_cell = !hdr;
-        const bool ok = hdr ? hdr_ok : cell_ok;
-        const bool go = run & ok;
-        if (go & in_cell & (k < maxc)) ct_pl[(img * maxc + k) * CF + lane] = make_uint2(c + 5, len | (kind << 30));
-        wire_ok &= !run | ok;
-        too_wide |= go & (hdr ? cnt16 > maxc : len > 0x3FFFFFFFu);
-        vbytes += (go & in_cell) ? len : 0u;
-        const uint32_t adv = hdr ? 3u : (is_val ? 5u + len : 1u);
-        c += go ? adv : 0u;
-        if (go & hdr) {
-          img = img_h;
-          old_kind = img_h == 0 ? (t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL) : old_kind;
-          n_old = img_h == 0 ? cnt16 : n_old;
-          n_new = img_h == 0 ? n_new : cnt16;
-          n = cnt16;
+        while (__ballot(in_cells)) {  // cells: 'n' | 'u' | ('t' | 'b') i32 len bytes
+          const uint64_t head = next8(in_cells);
+          const uint32_t t = (uint32_t)head & 0xFFu;
+          const uint32_t room = e - c;
+          const bool is_val = (t == 't') | (t == 'b');
+          const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
+          const uint32_t kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
+          const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
+          const bool go = in_cells & cell_ok;
+          if (go & (k < maxc)) ct_pl[(img * maxc + k) * CF + lane] = make_uint2(c + 5, len | (kind << 30));
+          wire_ok &= !in_cells | cell_ok;
+          too_wide |= go & (len > 0x3FFFFFFFu);
+          vbytes += go ? len : 0u;
+          c += go ? (is_val ? 5u + len : 1u) : 0u;
+          k += go ? 1u : 0u;
+          // image complete: an update goes on to its new image (next pass), everything else is finished
+          const bool done_img = go & (k == n);
+          const bool again = done_img & (img == 0) & is_upd;
+          img = again ? 1u : img;
+          want_hdr |= again;
+          in_cells = go & !done_img;
         }
-        k = go ? (hdr ? 0u : k + 1u) : k;
-        hdr = go ? false : hdr;
-        // image complete: an update goes on to its new image, everything else is finished
-        const bool done_img = go & (k == n);
-        const bool next_img = done_img & (img == 0) & is_upd;
-        img = next_img ? 1u : img;
-        hdr = next_img ? true : hdr;
-        run = go & (!done_img | next_img);
       }
     }
     TSTAMP(9);
