@@ -23,6 +23,7 @@
 // occupancy is NW waves per tile instead of one. A tile whose bytes do not fit the LDS window
 // reads the input in place. Schemas wider than MAXC columns and every error fall back to the
 // multi-pass kernels (kernels.hip).
+#define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
 #include "lookback.hip.h"
 #include "utf8_swar.h"
 
@@ -32,7 +33,50 @@ constexpr int CF = 64;         // frames per tile
 constexpr int MAXC = 16;       // replicated columns per slot this kernel can handle (one state word per row)
 // virtual columns of a tile whose widest slot has maxc columns: [0, maxc) old / key image, [maxc, 2 maxc) new image
 
-enum : uint32_t { CT_N = 0, CT_U = 1, CT_T = 2, CT_B = 3 };  // cell kind in the top 2 bits of ct_len
+enum : uint32_t { CT_N = 0, CT_U = 1, CT_T = 2, CT_B = 3 };  // cell kind
+// classes whose heap bytes depend on the text, not only on its length (cell_heap_bytes): float, numeric, bytea, date / time
+constexpr uint32_t kScanClasses = (1u << ETLG_TC_F32) | (1u << ETLG_TC_F64) | (1u << ETLG_TC_NUMERIC) | (1u << ETLG_TC_BYTEA) | (1u << ETLG_TC_DATE) |
+                                  (1u << ETLG_TC_TIME) | (1u << ETLG_TC_TIMETZ) | (1u << ETLG_TC_TIMESTAMP) | (1u << ETLG_TC_TIMESTAMPTZ);
+
+// The cell table of a tile, [virtual column][frame], written by the tuple walk (P1), sized by P2 / P2b, read by P3.
+// STAGED tiles keep ONE dword per cell — where the cell's tag byte sits in the LDS window (17 bits) and the cell's heap
+// bytes, later its heap offset inside the frame, in dwords (15 bits) — and read kind and length back from the staged bytes:
+// at 12 bytes per cell the table of a 12-column schema was 18 KB of a 47 KB tile and capped a CU at three workgroups.
+// A tile read in place has no window; it keeps (32-bit offset, length | kind << 30, heap bytes) per cell in the space the
+// window would have taken.
+constexpr uint32_t kWinMax = 120u * 1024u;   // staged bytes of a tile: tag positions fit 17 bits, a frame's heap bytes fit 15 bits of dwords
+template <bool STAGED> struct CellTab;
+template <> struct CellTab<true> {
+  uint32_t* e;
+  // the heap field starts out as what a class that copies its text takes (String, wholesale-deferred): pad4(len)
+  DEV void put(uint32_t i, uint32_t tagpos, uint32_t len, uint32_t kind) const { e[i] = (tagpos << 15) | (kind == CT_T ? (len + 3u) >> 2 : 0u); }
+  // -> offset of the cell's text, its length and kind; returns the raw entry (heap field)
+  DEV uint32_t get(uint32_t i, const u8* base, uint32_t& pos, uint32_t& len, uint32_t& kind) const {
+    const uint32_t w = e[i], c = w >> 15;
+    const uint64_t head = ldu64(base + c);  // the window has 16 spare bytes past any frame
+    const uint32_t t = (uint32_t)head & 0xFFu;
+    const bool is_val = (t == 't') | (t == 'b');
+    len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
+    kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
+    pos = c + 5;
+    return w;
+  }
+  DEV uint32_t heap_of(uint32_t w) const { return (w & 0x7FFFu) << 2; }
+  DEV uint32_t raw(uint32_t i) const { return e[i]; }
+  DEV void set_heap_of(uint32_t i, uint32_t w, uint32_t h) const { e[i] = (w & ~0x7FFFu) | (h >> 2); }  // w: what get() / raw() returned; h: a multiple of 4 below 128 KiB
+};
+template <> struct CellTab<false> {
+  uint2* pl; uint32_t* h;
+  DEV void put(uint32_t i, uint32_t tagpos, uint32_t len, uint32_t kind) const { pl[i] = make_uint2(tagpos + 5, len | (kind << 30)); h[i] = kind == CT_T ? pad4(len) : 0u; }
+  DEV uint32_t get(uint32_t i, const u8*, uint32_t& pos, uint32_t& len, uint32_t& kind) const {
+    const uint2 v = pl[i];
+    pos = v.x; len = v.y & 0x3FFFFFFFu; kind = v.y >> 30;
+    return h[i];
+  }
+  DEV uint32_t heap_of(uint32_t w) const { return w; }
+  DEV uint32_t raw(uint32_t i) const { return h[i]; }
+  DEV void set_heap_of(uint32_t i, uint32_t, uint32_t v) const { h[i] = v; }
+};
 
 // frame meta word: tag (8) | old_kind (2) << 8 | wire_ok << 10 | emit << 11 | too_wide << 12
 DEV uint32_t meta_tag(uint32_t m) { return m & 0xFF; }
@@ -120,8 +164,8 @@ struct CellsLds {
   uint32_t* fr_err;             // min over (order << 8 | code)
   uint32_t* fr_toast;           // new-row columns sent as 'u'
   uint32_t* s32; uint64_t* s64;
-  uint2* ct_pl;                 // cell table [virtual column][frame]: (offset of the text in `base`, length | kind << 30)
-  uint32_t* ct_h;               // ... heap bytes of the cell, then its heap offset inside the frame
+  uint32_t* ct;                 // cell table region (CellTab)
+  uint8_t (*vlist)[32];         // virtual columns P2 ([0]) and P3 ([1]) visit
 };
 
 // Everything after staging. STAGED: `base` is the LDS window holding input bytes [b0, ...), reads
@@ -134,12 +178,14 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   uint32_t* const fr_n = sh.fr_n; uint64_t* const fr_fx = sh.fr_fx; uint32_t* const fr_hp = sh.fr_hp;
   uint32_t (*const fr_st)[CF] = sh.fr_st; uint32_t* const fr_err = sh.fr_err; uint32_t* const fr_toast = sh.fr_toast;
   uint32_t* const s32 = sh.s32; uint64_t* const s64 = sh.s64;
-  uint2* const ct_pl = sh.ct_pl; uint32_t* const ct_h = sh.ct_h;
+  uint8_t (*const vlist)[32] = sh.vlist;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
   const uint32_t maxc = q.maxc, VC = 2 * maxc;
   const uint32_t f0 = tile * CF;
   constexpr bool use_lds = STAGED;
+  CellTab<STAGED> tab;
+  if constexpr (STAGED) tab.e = sh.ct; else { tab.pl = (uint2*)sh.ct; tab.h = sh.ct + 2 * VC * CF; }
   uint32_t* fail = &pg.res->fused_fail;
 
   // ================= P1 (wave 0): slice frames into cells, transaction scan, slots
@@ -149,7 +195,12 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   uint32_t rel_id = 0, old_kind = ETLG_OLD_NONE, n_old = 0, n_new = 0, vbytes = 0, o0 = 0;
   bool wire_ok = true, too_wide = false;
   uint32_t cnt = 0, mark = 0, seg_in = 0, pm = 0, tot_cnt = 0, tot_mark = 0;
+  int my_slot = -1;
+  uint32_t heap_cols = 0;  // virtual columns of this frame whose cells reach the heap (wave 0)
+  // The single-wave phases (P1, P2b, the look-backs, P4) are the spine of a tile: every other wave of the workgroup waits
+  // for them at a barrier, while the cell phases of the other tiles on this SIMD have slack. They run at a raised issue priority.
   if (wave == 0) {
+    ETLG_WAVE_PRIO(3);
     if (lane < CF) { fr_st[0][lane] = 0; fr_st[1][lane] = 0; fr_err[lane] = 0xFFFFFFFFu; fr_toast[lane] = 0; fr_slot[lane] = -1; fr_meta[lane] = 0; fr_n[lane] = 0; }
     if (live) {
       o0 = s_offs[lane];
@@ -168,6 +219,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       if (tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
       if (tag == 'C') mark = (o0 + 1) << 1;
     }
+    TSTAMP(11);
     // parse_row_msg + walk_tuple for the I / U / D frames, recording every cell, with 32-bit offsets into `base`.
     // This wave runs alone while the others wait and a lone wave issues an instruction every 5-8 cycles, so the
     // walk is priced per instruction: a frame is at most (image header, cells) twice, and the two kinds of item
@@ -190,9 +242,13 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         if (on) for (uint32_t i = 0; i < 5 && c + i < e; i++) head |= (uint64_t)base[c + i] << (8 * i);
         return head;
       };
-      for (int pass = 0; pass < 2; pass++) {  // pass 0: every frame's first image; pass 1: the new image of updates that sent an old one
-        if (!__ballot(want_hdr)) break;
-        {  // image header: 'K' | 'O' | 'N', i16 column count
+      // One loop over "steps": a header step whenever some lane stands in front of an image header (the first trip for
+      // everybody, later the frames that go on from an old / key image to the new one), then a cell step for every lane
+      // inside an image. A tile finishes in (cells of its longest frame) + 1 or 2 trips.
+      for (;;) {
+        const unsigned long long wh = __ballot(want_hdr);
+        if (!(wh | __ballot(in_cells))) break;
+        if (wh) {  // image header: 'K' | 'O' | 'N', i16 column count
           const uint64_t head = next8(want_hdr);
           const uint32_t t = (uint32_t)head & 0xFFu;
           const uint32_t room = e - c;  // c <= e holds for a lane that is still going
@@ -213,11 +269,12 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
           }
           const bool empty = go & (n == 0);  // an image without cells is complete at once
           const bool again = empty & (img == 0) & is_upd;
-          in_cells = go & !empty;
+          in_cells |= go & !empty;
           img = again ? 1u : img;
           want_hdr = again;
+          if (!__ballot(in_cells)) continue;
         }
-        while (__ballot(in_cells)) {  // cells: 'n' | 'u' | ('t' | 'b') i32 len bytes
+        {  // cells: 'n' | 'u' | ('t' | 'b') i32 len bytes
           const uint64_t head = next8(in_cells);
           const uint32_t t = (uint32_t)head & 0xFFu;
           const uint32_t room = e - c;
@@ -226,13 +283,13 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
           const uint32_t kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
           const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
           const bool go = in_cells & cell_ok;
-          if (go & (k < maxc)) ct_pl[(img * maxc + k) * CF + lane] = make_uint2(c + 5, len | (kind << 30));
+          if (go & (k < maxc)) tab.put((img * maxc + k) * CF + lane, c, len, kind);
           wire_ok &= !in_cells | cell_ok;
           too_wide |= go & (len > 0x3FFFFFFFu);
           vbytes += go ? len : 0u;
           c += go ? (is_val ? 5u + len : 1u) : 0u;
           k += go ? 1u : 0u;
-          // image complete: an update goes on to its new image (next pass), everything else is finished
+          // image complete: an update goes on to its new image (a header step), everything else is finished
           const bool done_img = go & (k == n);
           const bool again = done_img & (img == 0) & is_upd;
           img = again ? 1u : img;
@@ -283,21 +340,57 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         else if (p.slots[slot].n_cols > maxc) { atomicOr(fail, 4u); slot = -1; }
       }
       fr_slot[lane] = slot;
+      my_slot = slot;
     }
     if (live) {
       fr_meta[lane] = v.tag | (old_kind << 8) | ((wire_ok ? 1u : 0u) << 10);
       fr_n[lane] = n_old | (n_new << 16);
     }
+    // Which virtual columns hold cells of a decodable image at all (P3 visits those), and which of them belong to a class
+    // whose heap bytes depend on the text (P2 visits those; every other cell keeps the walk's pad4(len), counted in P2b
+    // only where the column's class reaches the heap). Bits 0..15: old / key image, 16..31: new image.
+    uint32_t present = 0, scan = 0;
+    if (my_slot >= 0) {
+      const DevSlot& s = p.slots[my_slot];
+      const uint32_t full = s.has_var, tag = v.tag;
+      const uint32_t po = old_kind != ETLG_OLD_NONE ? (1u << (n_old < maxc ? n_old : maxc)) - 1u : 0u;
+      const uint32_t pn = tag != 'D' ? (1u << (n_new < maxc ? n_new : maxc)) - 1u : 0u;
+      uint32_t oh = full & 0xFFFFu, os = full >> 16;                       // old image of a full row
+      if (old_kind == ETLG_OLD_KEY) {
+        if (n_old == s.n_ident) { oh = s.key_masks & 0xFFFFu; os = s.key_masks >> 16; }   // dense key tuple: cell j = identity column j
+        else { oh &= s.ident_mask; os &= s.ident_mask; }                                   // full-width key tuple: the other cells are skipped unread
+      }
+      present = po | (pn << 16);
+      heap_cols = (oh & po) | ((full & 0xFFFFu & pn) << 16);
+      scan = (os & po) | (((full >> 16) & pn) << 16);
+    }
+    present = wave_last(wave_scan_incl(present, [](uint32_t a, uint32_t b) { return a | b; }, 0u));
+    scan = wave_last(wave_scan_incl(scan, [](uint32_t a, uint32_t b) { return a | b; }, 0u));
+    const uint32_t heapy = wave_last(wave_scan_incl(heap_cols, [](uint32_t a, uint32_t b) { return a | b; }, 0u));
+    if (lane < 32) {  // the two visiting lists; P3's starts with the columns that cost most (text to copy, then text to scan),
+                      // so that the waves pulling from it finish close to each other
+      const uint32_t below = (1u << lane) - 1u, vc_of = lane < 16 ? lane : maxc + (lane - 16);
+      if ((scan >> lane) & 1u) vlist[0][__builtin_popcount(scan & below)] = (uint8_t)vc_of;
+      const uint32_t t1 = present & heapy & ~scan, t2 = present & scan, t3 = present & ~(heapy | scan);
+      const uint32_t rank = ((t1 >> lane) & 1u) ? __builtin_popcount(t1 & below)
+                          : ((t2 >> lane) & 1u) ? __builtin_popcount(t1) + __builtin_popcount(t2 & below)
+                                                : __builtin_popcount(t1 | t2) + __builtin_popcount(t3 & below);
+      if ((present >> lane) & 1u) vlist[1][rank] = (uint8_t)vc_of;
+    }
+    if (lane == 0) { s32[10] = (uint32_t)__builtin_popcount(scan); s32[11] = (uint32_t)__builtin_popcount(present); }
+    ETLG_WAVE_PRIO(0);
   }
   __syncthreads();
   TSTAMP(2);
 
   // ================= P2: heap bytes per cell; waves pull virtual columns from a queue
+  const uint32_t n_scan = s32[10], n_present = s32[11];
   for (;;) {
-    uint32_t vc = 0;
-    if (lane == 0) vc = atomicAdd(&s32[8], 1u);
-    vc = __builtin_amdgcn_readfirstlane(vc);
-    if (vc >= VC) break;
+    uint32_t vj = 0;
+    if (lane == 0) vj = atomicAdd(&s32[8], 1u);
+    vj = __builtin_amdgcn_readfirstlane(vj);
+    if (vj >= n_scan) break;
+    const uint32_t vc = vlist[0][vj];
     const int slot = fr_slot[lane];
     const uint32_t meta = fr_meta[lane];
     const uint32_t img = vc >= maxc, k = vc - img * maxc;
@@ -309,23 +402,25 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
                                 : (meta_old(meta) == ETLG_OLD_KEY ? (uint32_t)ROW_KEY : (uint32_t)ROW_FULL);
       const DevCol* cols = p.cols + s.cols_base;
       const int ci = (!s.has_var || image_shape_error(s, mode, n)) ? -1 : cell_column(s, cols, mode, n, k);
-      const uint2 pl = ct_pl[vc * CF + lane];
-      uint32_t h = 0;
-      if (ci >= 0 && (pl.y >> 30) == CT_T) {
-        const uint32_t cls = cols[ci].cls;
-        const u8* d = base + pl.x;
+      uint32_t pos, len, kind;
+      const uint32_t ent = tab.get(vc * CF + lane, base, pos, len, kind);
+      const uint32_t cls = ci >= 0 ? (uint32_t)cols[ci].cls : 0u;
+      if (ci >= 0 && kind == CT_T && ((kScanClasses >> cls) & 1u)) {
+        const u8* d = base + pos;
+        uint32_t h = 0;
         bool done = false;
         while (!done) {  // one pass per distinct class among the active lanes, scalar dispatch inside
           const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
-          if (cls == u) { h = cell_heap_bytes(u, d, pl.y & 0x3FFFFFFFu, use_lds); done = true; }
+          if (cls == u) { h = cell_heap_bytes(u, d, len, use_lds); done = true; }
         }
+        tab.set_heap_of(vc * CF + lane, ent, h);
       }
-      ct_h[vc * CF + lane] = h;  // every cell of a decodable image gets its entry (P2b sums them blindly)
     }
     ETLG_WAVE_JOIN();
   }
   __syncthreads();
   TSTAMP(3);
+  ETLG_WAVE_PRIO(3);   // P2b on wave 0, then one look-back per wave
 
   // ================= P2b (wave 0): shapes, per-frame heap prefix, sizes, look-back
   uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_ev = 0, x_fx = 0, x_hp = 0, cells = 0;
@@ -370,15 +465,15 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       const uint32_t cells_old = cells & 0xFFFFu, cells_new = cells >> 16;
       uint32_t hh[2 * MAXC];
 #pragma unroll
-      for (uint32_t i = 0; i < 2u * MAXC; i++) hh[i] = i < VC ? ct_h[i * CF + lane] : 0u;
+      for (uint32_t i = 0; i < 2u * MAXC; i++) hh[i] = i < VC ? tab.raw(i * CF + lane) : 0u;
 #pragma unroll
       for (uint32_t i = 0; i < 2u * MAXC; i++) {
         if (i < VC) {  // uniform
           const bool in_new = i >= maxc;
           const uint32_t k = in_new ? i - maxc : i;
-          const bool take = k < (in_new ? cells_new : cells_old);
-          ct_h[i * CF + lane] = heap;
-          heap += take ? hh[i] : 0u;
+          const bool take = (k < (in_new ? cells_new : cells_old)) & (((heap_cols >> (in_new ? 16u + k : k)) & 1u) != 0);
+          tab.set_heap_of(i * CF + lane, hh[i], heap);
+          heap += take ? tab.heap_of(hh[i]) : 0u;
         }
       }
     }
@@ -445,15 +540,17 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     fr_hp[lane] = (uint32_t)hp_off;
     if (live) fr_meta[lane] |= (emit ? 1u : 0u) << 11;
   }
+  ETLG_WAVE_PRIO(0);
   __syncthreads();
   TSTAMP(6);
 
   // ================= P3: decode cells; waves pull virtual columns from a queue
   for (;;) {
-    uint32_t vc = 0;
-    if (lane == 0) vc = atomicAdd(&s32[9], 1u);
-    vc = __builtin_amdgcn_readfirstlane(vc);
-    if (vc >= VC) break;
+    uint32_t vj = 0;
+    if (lane == 0) vj = atomicAdd(&s32[9], 1u);
+    vj = __builtin_amdgcn_readfirstlane(vj);
+    if (vj >= n_present) break;
+    const uint32_t vc = vlist[1][vj];
     const uint32_t img = vc >= maxc, k = vc - img * maxc;
     const uint32_t meta = fr_meta[lane];
     const int slot = fr_slot[lane];
@@ -479,12 +576,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       }
     }
     uint32_t kind = CT_N, len = 0, pos = 0, hcur = 0;
-    if (act) {
-      const uint2 pl = ct_pl[vc * CF + lane];
-      kind = pl.y >> 30; len = pl.y & 0x3FFFFFFFu;
-      pos = pl.x;
-      hcur = fr_hp[lane] + ct_h[vc * CF + lane];
-    }
+    if (act) hcur = fr_hp[lane] + tab.heap_of(tab.get(vc * CF + lane, base, pos, len, kind));
     const uint32_t order = img * 32u + 1u + k;
     const uint32_t cls = col.cls;
     uint32_t st = ETLG_CELL_NULL, err = 0;
@@ -535,6 +627,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   // ================= P4 (wave 0): finish rows, event headers
   if (wave != 0 || !emit) return;
   if (q.dbg & 2) return;
+  ETLG_WAVE_PRIO(3);
   const uint32_t tag = v.tag;
   if (tag == 'I' || tag == 'U' || tag == 'D') {
     const DevSlot& s = p.slots[row_slot];
@@ -582,8 +675,9 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
 }
 
 #ifndef ETLG_CELLS_MINBLOCKS
-#define ETLG_CELLS_MINBLOCKS 3   // workgroups per CU the register allocator leaves room for: 168 VGPRs. 4 would mean 128 VGPRs and 176 bytes of
-                                 // spills per lane, for nothing while the ~45 KB LDS window of a tile caps a CU at 3 workgroups anyway
+#define ETLG_CELLS_MINBLOCKS 4   // workgroups per CU the register allocator leaves room for: 4 x 4 waves = 128 VGPRs (24 spilled). With the
+                                 // one-dword cell table a 12-column tile is ~38 KB of LDS, so four fit; measured on cfg3: 281 us at three
+                                 // workgroups (168 VGPRs, no spills), 238 us at four (profiles/r02u_cells_variants.json)
 #endif
 template <int NW>
 __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecParams pg, FusedParams q) {
@@ -599,6 +693,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   __shared__ uint32_t fr_toast[CF];  // new-row columns sent as 'u'
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
+  __shared__ uint8_t vlist[2][32];
   const uint32_t tid = threadIdx.x;
   if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
@@ -613,10 +708,11 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   SideRegs side;  // variant head (lookback.hip.h): one round trip for all four tables, LDS stores after the staging loads
   side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
   const uint32_t maxc = q.maxc, VC = 2 * maxc;
-  uint2* ct_pl = (uint2*)(smem + q.side_bytes);  // side_bytes is a multiple of 16
-  uint32_t* ct_h = (uint32_t*)(ct_pl + VC * CF);
-  u8* stage = (u8*)(ct_h + VC * CF);
-  const uint32_t table_bytes = 3 * VC * CF * 4;
+  // dynamic LDS: side tables | cell table (one dword per cell) | staging window; a tile read in place spreads its
+  // three-dword cells over table + window (the host sizes the allocation for that, etlg_k_cells_lds_floor)
+  uint32_t* ct = (uint32_t*)(smem + q.side_bytes);  // side_bytes is a multiple of 16
+  u8* stage = (u8*)(ct + VC * CF);
+  const uint32_t table_bytes = VC * CF * 4;
   const uint32_t tile = blockIdx.x;
   const uint32_t f0 = tile * CF;
   uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
@@ -625,7 +721,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
   const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
-  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len &&
+  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len && span1 - a0 + 16 <= kWinMax &&
                          (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
   if (window_ok) {
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
@@ -643,7 +739,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   }
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
   TSTAMP(1);
-  const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_st, fr_err, fr_toast, s32, s64, ct_pl, ct_h};
+  const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_st, fr_err, fr_toast, s32, s64, ct, vlist};
   // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
   if (use_lds) cells_tile<NW, true>(p, pg, q, sh, stage, a0, tile, nt);
   else cells_tile<NW, false>(p, pg, q, sh, pg.in, 0u, tile, nt);
@@ -664,7 +760,9 @@ int etlg_k_cells_set_lds(void) {
   return hipFuncSetAttribute((const void*)k_cells<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) == hipSuccess ? 0 : 1;
 }
 
-uint32_t etlg_k_cells_table_bytes(uint32_t maxc) { return 3u * 2u * maxc * CF * 4u; }
+uint32_t etlg_k_cells_table_bytes(uint32_t maxc) { return 2u * maxc * CF * 4u; }       // next to the window of a staged tile
+uint32_t etlg_k_cells_lds_floor(uint32_t maxc) { return 3u * 2u * maxc * CF * 4u; }    // table + window together: what a tile read in place needs
+uint32_t etlg_k_cells_static_lds(void) { return 3584; }  // the kernel's __shared__ arrays (3 216 bytes in the gfx950 build) + slack
 uint32_t etlg_k_cells_maxc(void) { return MAXC; }
 
 }  // extern "C"

@@ -30,6 +30,9 @@ typedef uint8_t u8;
 #ifndef DEV_NOINLINE
 #define DEV_NOINLINE __device__ __attribute__((noinline))
 #endif
+#ifndef ETLG_WAVE_PRIO   // s_setprio: the issue arbiter of a SIMD prefers the wave with the higher value (0..3)
+#define ETLG_WAVE_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
 #ifndef ETLG_WAVE_JOIN   // reconvergence point of a divergent region with wave collectives inside: nothing on the GPU
 #define ETLG_WAVE_JOIN() ((void)0)
 #endif
@@ -603,7 +606,22 @@ struct NumShape {
   int32_t first_group, last_group;
   const u8* mant;       // first mantissa byte (after sign / leading '.')
   uint32_t mant_len;    // mantissa bytes (digits, '.', '_')
+  uint32_t dot_at;      // numeric_plain only: index of the '.' inside the mantissa, mant_len when there is none
 };
+
+// weight / first and last base-10000 group from the decimal weight of the first digit and the first / last non-zero digit
+DEV bool numeric_groups(NumShape& o, int32_t dweight, int32_t first_nz, int32_t last_nz) {
+  if (first_nz < 0) { o.sign = 0; o.weight = 0; return true; }  // canonical zero
+  const int32_t weight = dweight >= 0 ? (dweight + 4) / 4 - 1 : -((-dweight - 1) / 4 + 1);
+  o.offset = (weight + 1) * 4 - (dweight + 1);
+  o.first_group = (o.offset + first_nz) / 4;
+  o.last_group = (o.offset + last_nz) / 4;
+  const int32_t fw = weight - o.first_group;
+  if (fw < -32768 || fw > 32767) return false;
+  o.weight = fw;
+  o.ngroups = (uint32_t)(o.last_group - o.first_group + 1);
+  return true;
+}
 
 DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o, bool over = false) {
   trim_ws(s, n);
@@ -673,16 +691,54 @@ DEV bool numeric_scan(const u8* s, uint32_t n, NumShape& o, bool over = false) {
   if (pos != n) return false;
   if (dscale > 16383) return false;
   o.scale = dscale;
-  if (first_nz < 0) { o.sign = 0; o.weight = 0; return true; }  // canonical zero
-  const int32_t weight = dweight >= 0 ? (dweight + 4) / 4 - 1 : -((-dweight - 1) / 4 + 1);
-  o.offset = (weight + 1) * 4 - (dweight + 1);
-  o.first_group = (o.offset + first_nz) / 4;
-  o.last_group = (o.offset + last_nz) / 4;
-  const int32_t fw = weight - o.first_group;
-  if (fw < -32768 || fw > 32767) return false;
-  o.weight = fw;
-  o.ngroups = (uint32_t)(o.last_group - o.first_group + 1);
-  return true;
+  return numeric_groups(o, dweight, first_nz, last_nz);
+}
+
+// The same result for the texts Postgres itself prints for ordinary values — [+-] digits [. digits], at most 24 characters
+// after the sign, nothing else (no exponent, '_', whitespace, NaN / Infinity) — without a character loop: the characters are
+// classified four at a time and the positions of the '.' and of the first / last non-zero digit come out of bit masks.
+// Returns false for every other text, valid or not: the caller then runs numeric_scan. Staged (LDS) text only: the loads
+// may run up to 7 bytes past the text.
+DEV bool numeric_plain(const u8* s, uint32_t n, NumShape& o) {
+  if (n == 0) return false;
+  const uint32_t c0 = s[0];
+  const uint32_t start = (c0 == '+' || c0 == '-') ? 1u : 0u;
+  const uint32_t m = n - start;
+  if (m - 1u > 23u) return false;
+  const u8* p = s + start;
+  uint32_t dm = 0, pm = 0, nz = 0;  // bit i: character i is a digit / the '.' / a digit other than '0'
+#pragma unroll
+  for (uint32_t j = 0; j < 6; j++) {
+    if (4 * j < m) {
+      uint32_t x; __builtin_memcpy(&x, p + 4 * j, 4);
+      const uint32_t t = (x & 0x7F7F7F7Fu) ^ 0x30303030u;                 // '0'..'9' -> 0..9
+      const uint32_t dig = ~(t + 0x76767676u) & ~x & 0x80808080u;          // bit 7 of a byte: it is an ASCII digit
+      const uint32_t z = x ^ 0x2E2E2E2Eu;
+      const uint32_t dot = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;   // ... it is '.'
+      const uint32_t nzd = dig & ((t + 0x7F7F7F7Fu) | t);                   // ... a digit and t != 0
+      // the four bit-7 flags of a word -> 4 adjacent bits (the partial products of the multiply never collide)
+      dm |= (((dig >> 7) * 0x00204081u) >> 21 & 0xFu) << (4 * j);
+      pm |= (((dot >> 7) * 0x00204081u) >> 21 & 0xFu) << (4 * j);
+      nz |= (((nzd >> 7) * 0x00204081u) >> 21 & 0xFu) << (4 * j);
+    }
+  }
+  const uint32_t vm = (1u << m) - 1u;   // m <= 24
+  dm &= vm; pm &= vm; nz &= vm;
+  if ((dm | pm) != vm || (pm & (pm - 1u)) != 0 || (pm == 1u && m < 2)) return false;
+  const uint32_t dp = pm ? (uint32_t)__builtin_ctz(pm) : m;   // digits in front of the '.'
+  const bool lead_dot = dp == 0;
+  o.sign = c0 == '-' ? 1u : 0u; o.kind = ETLG_NUM_VALUE; o.weight = 0; o.ngroups = 0;
+  o.scale = pm ? m - dp - 1 : 0u;
+  o.mant = p + (lead_dot ? 1 : 0);
+  o.mant_len = m - (lead_dot ? 1u : 0u);
+  o.dot_at = (pm && !lead_dot) ? dp : o.mant_len;
+  int32_t first_nz = -1, last_nz = -1;   // as indexes of decimal digits
+  if (nz) {
+    const uint32_t fb = (uint32_t)__builtin_ctz(nz), lb = 31u - (uint32_t)__builtin_clz(nz);
+    first_nz = (int32_t)(fb - (fb > dp ? 1u : 0u));
+    last_nz = (int32_t)(lb - (lb > dp ? 1u : 0u));
+  }
+  return numeric_groups(o, (int32_t)dp - 1, first_nz, last_nz);
 }
 
 // Writes the etlg_numeric_hdr + digits at `dst` (4-byte aligned); returns bytes incl. padding.
@@ -710,6 +766,32 @@ DEV uint32_t numeric_emit(const NumShape& o, u8* dst, bool over = false) {
     }
     while (cur <= o.last_group) { dg[cur - o.first_group] = (uint16_t)acc; acc = 0; cur++; }
     if (o.ngroups & 1) dg[o.ngroups] = 0;  // zero padding up to 4 bytes
+  }
+  return pad4(8 + 2 * o.ngroups);
+}
+
+// numeric_emit for a shape numeric_plain produced: digit k of the mantissa is byte k (+ 1 behind the '.'), so every group is
+// four independent byte reads; two groups leave as one dword.
+DEV uint32_t numeric_emit_plain(const NumShape& o, u8* dst) {
+  uint32_t* w = (uint32_t*)dst;
+  w[0] = o.kind | (o.sign << 8) | ((uint32_t)(uint16_t)(int16_t)o.weight << 16);
+  w[1] = o.scale | ((o.ngroups & 0xFFFFu) << 16);
+  const int32_t nd = (int32_t)(o.mant_len - (o.dot_at < o.mant_len ? 1u : 0u));
+  auto group = [&](int32_t g) -> uint32_t {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int32_t k = 4 * g + i - o.offset;
+      uint32_t d = 0;
+      if (k >= 0 && k < nd) d = (uint32_t)o.mant[(uint32_t)k + ((uint32_t)k >= o.dot_at ? 1u : 0u)] - '0';
+      v = v * 10u + d;
+    }
+    return v;
+  };
+  for (uint32_t j = 0; 2 * j < o.ngroups; j++) {
+    const int32_t g = o.first_group + 2 * (int32_t)j;
+    const uint32_t lo = group(g), hi = g + 1 <= o.last_group ? group(g + 1) : 0u;  // an odd count is zero padded to 4 bytes
+    w[2 + j] = lo | (hi << 16);
   }
   return pad4(8 + 2 * o.ngroups);
 }
@@ -810,39 +892,70 @@ DEV int hexv(uint32_t c) {
   return -1;
 }
 // uuid 1.23 Uuid::parse_str: simple(32) | hyphenated(36) | {braced}(38) | urn:uuid:(45)
+// Four ASCII hex characters per 32-bit word (character i in byte i): validity of all four at once, then their two bytes.
+DEV bool hex4_ok(uint32_t x) {
+  const uint32_t x7 = x & 0x7F7F7F7Fu;
+  const uint32_t t = x7 ^ 0x30303030u;                       // '0'..'9' -> 0..9
+  const uint32_t dig = ~(t + 0x76767676u);                   // bit 7 of a byte set <=> t < 10
+  const uint32_t a = (x7 | 0x20202020u) ^ 0x60606060u;       // 'A'..'F', 'a'..'f' -> 1..6
+  const uint32_t alp = (a + 0x7F7F7F7Fu) & ~(a + 0x79797979u);  // bit 7 set <=> 1 <= a <= 6
+  return (((dig | alp) & ~x) & 0x80808080u) == 0x80808080u;  // ... and the character itself is ASCII
+}
+DEV uint32_t hex4_bytes(uint32_t x) {  // valid input only: 2 bytes, first character pair in bits 0..7
+  const uint32_t n = (x & 0x0F0F0F0Fu) + 9u * ((x >> 6) & 0x01010101u);
+  const uint32_t p = (n << 4) | (n >> 8);
+  return (p & 0xFFu) | ((p >> 8) & 0xFF00u);
+}
 DEV bool parse_uuid(const u8* s, uint32_t n, uint32_t* out4, bool over = false) {
-  u8 b[16];
-  if (n == 32) {
-    ByteWin bw{s, over};
-    for (int i = 0; i < 16; i++) {
-      int h = hexv(bw.at(2 * i)), l = hexv(bw.at(2 * i + 1));
-      if ((h | l) < 0) return false;
-      b[i] = (u8)((h << 4) | l);
+  uint32_t skip;  // bytes in front of the 32 / 36 characters
+  if (n == 32 || n == 36) skip = 0;
+  else if (n == 38) { if (s[0] != '{' || s[37] != '}') return false; skip = 1; }
+  else if (n == 45) {
+    if (!(s[0] == 'u' && s[1] == 'r' && s[2] == 'n' && s[3] == ':' && s[4] == 'u' && s[5] == 'u' && s[6] == 'i' && s[7] == 'd' && s[8] == ':')) return false;
+    skip = 9;
+  } else return false;
+  const u8* h = s + skip;
+  const uint32_t nw = n == 32 ? 8u : 9u;
+  uint32_t w[9];
+  if (over) {  // staged bytes: aligned dwords + v_alignbyte (reads end inside the dword after the last character)
+    const uint32_t sh = (uint32_t)(uintptr_t)h & 3u;
+    const uint32_t* q = (const uint32_t*)(h - sh);
+    uint32_t prev = q[0];
+#pragma unroll
+    for (uint32_t i = 0; i < 9; i++) {
+      uint32_t nx = 0;
+      if (i < nw) nx = q[i + 1];
+      w[i] = __builtin_amdgcn_alignbyte(nx, prev, sh);
+      prev = nx;
     }
   } else {
-    const u8* h;
-    if (n == 36) h = s;
-    else if (n == 38 && s[0] == '{' && s[37] == '}') h = s + 1;
-    else if (n == 45 && s[0] == 'u' && s[1] == 'r' && s[2] == 'n' && s[3] == ':' && s[4] == 'u' && s[5] == 'u' &&
-             s[6] == 'i' && s[7] == 'd' && s[8] == ':') h = s + 9;
-    else return false;
-    if (h[8] != '-' || h[13] != '-' || h[18] != '-' || h[23] != '-') return false;
-    int k = 0;
-    ByteWin bw{h, over};
-    for (int i = 0; i < 16; i++) {
-      if (k == 8 || k == 13 || k == 18 || k == 23) k++;
-      int hi = hexv(bw.at(k)), lo = hexv(bw.at(k + 1));
-      if ((hi | lo) < 0) return false;
-      b[i] = (u8)((hi << 4) | lo);
-      k += 2;
+#pragma unroll
+    for (uint32_t i = 0; i < 9; i++) {
+      w[i] = 0;
+      if (i < nw) w[i] = (uint32_t)h[4 * i] | ((uint32_t)h[4 * i + 1] << 8) | ((uint32_t)h[4 * i + 2] << 16) | ((uint32_t)h[4 * i + 3] << 24);
     }
   }
-  for (int i = 0; i < 4; i++) out4[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+  if (n != 32) {  // 8-4-4-4-12: check the hyphens, close the gaps
+    if ((w[2] & 0xFFu) != '-' || ((w[3] >> 8) & 0xFFu) != '-' || ((w[4] >> 16) & 0xFFu) != '-' || (w[5] >> 24) != '-') return false;
+    w[2] = __builtin_amdgcn_alignbyte(w[3], w[2], 1);
+    w[3] = __builtin_amdgcn_alignbyte(w[4], w[3], 2);
+    w[4] = __builtin_amdgcn_alignbyte(w[5], w[4], 3);
+    w[5] = w[6]; w[6] = w[7]; w[7] = w[8];
+  }
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 8; i++) ok &= hex4_ok(w[i]);
+  if (!ok) return false;
+#pragma unroll
+  for (int i = 0; i < 4; i++) out4[i] = hex4_bytes(w[2 * i]) | (hex4_bytes(w[2 * i + 1]) << 16);
   return true;
 }
 
 // f32 / f64 `str::parse`: the exact fast path lives in float_fast.h (host-testable); here it reads through ByteWin.
-DEV int parse_float_fast(const u8* s, uint32_t n, bool is32, uint64_t& out, bool over) {
+#ifndef ETLG_FLOAT_CALL   // k_cells calls it out of line: inlined, its two call sites (sizing, decode) cost the kernel ~25 VGPRs, i.e. a workgroup per CU
+#define ETLG_FLOAT_CALL DEV
+#endif
+ETLG_FLOAT_CALL int parse_float_fast(const u8* s, uint32_t n, bool is32, uint64_t& out, bool over) {
   ByteWin bw{s, over};
   return parse_float_fast_t([&](uint32_t i) { return bw.at(i); }, n, is32, out);
 }
@@ -858,7 +971,7 @@ DEV uint32_t cell_heap_bytes(uint32_t cls, const u8* d, uint32_t len, bool over 
   switch (cls) {
     case ETLG_TC_BYTEA: return len >= 2 ? pad4((len - 2) >> 1) : 0;
     case ETLG_TC_F32: case ETLG_TC_F64: { uint64_t b; return parse_float_fast(d, len, cls == ETLG_TC_F32, b, over) == 1 ? pad4(len) : 0; }
-    case ETLG_TC_NUMERIC: { NumShape s; return numeric_scan(d, len, s, over) ? pad4(8 + 2 * s.ngroups) : 0; }
+    case ETLG_TC_NUMERIC: { NumShape s; return ((over && numeric_plain(d, len, s)) || numeric_scan(d, len, s, over)) ? pad4(8 + 2 * s.ngroups) : 0; }
     case ETLG_TC_DATE: { int32_t x; return iso_date_fast(d, len, x) ? 0 : pad4(len); }
     case ETLG_TC_TIME: { uint32_t a, b; return iso_time_fast(d, len, a, b, over) ? 0 : pad4(len); }
     case ETLG_TC_TIMESTAMP: { int32_t x; uint32_t a, b; return iso_timestamp_fast(d, len, x, a, b, over) ? 0 : pad4(len); }
@@ -940,6 +1053,11 @@ DEV_DECODE uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, ui
     }
     case ETLG_TC_NUMERIC: {
       NumShape s;
+      if (over && numeric_plain(d, len, s)) {  // digits, one '.', a sign: ASCII by construction
+        numeric_emit_plain(s, heap + hcur);
+        var(8 + 2 * s.ngroups);
+        return 0;
+      }
       if (!numeric_scan(d, len, s, over)) return bad(ETLG_E_NUMERIC);
       // the numeric grammar strips Unicode whitespace, so a successful scan may still
       // have seen multi-byte characters: those must be valid UTF-8 too
@@ -1139,7 +1257,7 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
   // halfword fields of a plain global struct they compiled to global_load_ubyte / _ushort + s_waitcnt vmcnt(0) +
   // v_readfirstlane — one dependent vector-memory round trip per column (gfx950 has no sub-dword scalar loads).
   const ETLG_CONST_AS uint32_t* sw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.slots + slot_u);
-  static_assert(sizeof(DevSlot) == 32 && sizeof(DevCol) == 12, "descriptor words below");
+  static_assert(sizeof(DevSlot) == 40 && sizeof(DevCol) == 12, "descriptor words below");
   if (n != sw[0]) return ETLG_E_TUPLE_WIDTH;                      // DevSlot.n_cols
   const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + sw[6]);  // DevSlot.cols_base
   struct { uint32_t cls, nullable, off_full; } col;

@@ -27,7 +27,11 @@ struct DevSlot {
   uint32_t row_full, row_key;  // bytes, multiples of 4
   uint32_t st_full, st_key;    // state bytes at the head of a row
   uint32_t cols_base;          // index of the first DevCol
-  uint32_t has_var;            // some column may produce a heap entry (var-len / numeric / deferrable class)
+  uint32_t has_var;            // != 0: some column may produce a heap entry (var-len / numeric / deferrable class). For slots of
+                               // up to 16 columns, bit k: column k may; bit 16 + k: ... and how many bytes depends on the text
+                               // (numeric, float, date / time, bytea), not on its length alone. Wider slots: all ones.
+  uint32_t key_masks;          // the same two masks for a dense key tuple: bit j = the identity column with key_index j
+  uint32_t ident_mask;         // bit k: column k is an identity column (<= 16 columns)
 };
 
 // Per-table side input for one batch: ownership state

@@ -54,6 +54,8 @@ extern "C" void etlg_k_col_var(const void* job, unsigned long long* blk, int64_t
 extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_maxc(void);
+extern "C" uint32_t etlg_k_cells_lds_floor(uint32_t maxc);
+extern "C" uint32_t etlg_k_cells_static_lds(void);
 
 constexpr int kFused = 7;  // profiling slot of the fused kernel
 constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
@@ -754,9 +756,24 @@ hipError_t sync_slots(etlg_ctx* c, const std::vector<int32_t>& live) {
     DevSlot d{};
     d.n_cols = s->desc.n_cols; d.n_ident = s->desc.n_ident; d.row_full = s->desc.row_bytes_full; d.row_key = s->desc.row_bytes_key;
     d.st_full = s->desc.state_bytes_full; d.st_key = s->desc.state_bytes_key; d.cols_base = (uint32_t)dc.size();
-    for (auto& sc : s->cols) {
-      const int32_t k = sc.type_class;
-      if (!(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32 || k == ETLG_TC_UUID)) d.has_var = 1;
+    {  // which columns can reach the heap, and for which of them the byte count depends on the text (DevSlot.has_var)
+      const bool narrow = s->cols.size() <= 16;
+      uint32_t ci = 0;
+      for (auto& sc : s->cols) {
+        const int32_t k = sc.type_class;
+        const bool heap = !(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32 || k == ETLG_TC_UUID);
+        const bool scan = heap && !(k == ETLG_TC_STRING || k == ETLG_TC_JSON || k == ETLG_TC_ARRAY);
+        if (!narrow) { if (heap) d.has_var = 0xFFFFFFFFu; }
+        else {
+          if (heap) d.has_var |= 1u << ci;
+          if (scan) d.has_var |= 1u << (16 + ci);
+          if (sc.identity) {
+            d.ident_mask |= 1u << ci;
+            if (sc.key_index < 16) { if (heap) d.key_masks |= 1u << sc.key_index; if (scan) d.key_masks |= 1u << (16 + sc.key_index); }
+          }
+        }
+        ci++;
+      }
     }
     for (auto& sc : s->cols) {
       DevCol x{};
@@ -2254,7 +2271,14 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
   uint64_t cap = kernel == 1 ? (uint64_t)q.blk * avg * 5 / 4 + 2048 : (uint64_t)q.blk * avg * 9 / 8 + 1024;
   if (const char* lm = getenv("ETLG_LDS_MARGIN_PCT")) cap = (uint64_t)q.blk * avg * (100 + (uint64_t)atoi(lm)) / 100 + 1024;
   cap = (cap + 255) & ~255ull;
-  if (use_cells) cap += etlg_k_cells_table_bytes(widest);
+  if (use_cells) {
+    cap = std::max<uint64_t>(cap + etlg_k_cells_table_bytes(widest), etlg_k_cells_lds_floor(widest));
+    // LDS decides how many workgroups share a CU (160 KB; the register file allows four): the window takes whatever the
+    // allocation can grow by without losing one, so fewer tiles overflow it
+    const uint64_t stat = etlg_k_cells_static_lds();
+    const uint64_t wgs = std::max<uint64_t>(1, std::min<uint64_t>(4, (160 * 1024) / (cap + q.side_bytes + stat)));
+    cap = std::max<uint64_t>(cap, ((160 * 1024) / wgs - 512 - stat - q.side_bytes) & ~255ull);
+  }
   cap = std::min<uint64_t>(cap + q.side_bytes, 150 * 1024);
   q.lds_bytes = (uint32_t)cap;
   q.seq_lookback = (b->any_sync_done || (c->fused_dbg & 32)) ? 1u : 0u;

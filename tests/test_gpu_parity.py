@@ -347,3 +347,111 @@ def test_float_matrix(path):
             assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), bad
             o.reset_stream_state(); d.reset_stream_state()
     d.close()
+
+
+def _numeric_texts(seed=20260922, n=5000):
+    """Decimal texts around the device's loop-free path (sign, digits, one '.', at most 24 characters) and just outside it:
+    leading / trailing zeros, every position of the '.', lengths up to 30, exponents, '_', blanks, special values."""
+    import random
+    rng = random.Random(seed)
+    t = ["0", "-0", "+0", "0.0", "-0.00", ".5", "-.5", "+.5", "5.", "-5.", "00.00", "0.0001", "0.00010", "100", "1000", "10000", "100000000",
+         "9999", "9999.9999", "10000.0001", "0000120.00", "1200000", "000000000000000000000000", "0000000000000000000000001",
+         "999999999999999999999999", "9999999999999999999999999", "1" + "0" * 23, "1" + "0" * 24, "." + "0" * 22 + "1", "." + "0" * 23 + "1",
+         "12345678901.2345678901234", "123456789012.345678901234", "NaN", "Infinity", "-Infinity", "1e5", "1.5e-3", "1_000", " 1.5", "1.5 "]
+    for _ in range(n):
+        nd = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20, 22, 23, 24, 25, 26, 30])
+        kind = rng.random()
+        if kind < 0.25:
+            digs = "".join(rng.choice("0000123456789") for _ in range(nd))
+        elif kind < 0.5:
+            z1, z2 = rng.randint(0, nd), rng.randint(0, nd)
+            digs = ("0" * z1 + "".join(rng.choice("0123456789") for _ in range(nd)) + "0" * z2)[:nd]
+        else:
+            digs = "".join(rng.choice("0123456789") for _ in range(nd))
+        if rng.random() < 0.7:
+            k = rng.randint(0, len(digs))
+            digs = digs[:k] + "." + digs[k:]
+            if digs == ".":
+                digs = "0."
+        s = rng.choice(["", "", "-", "+"]) + digs
+        r = rng.random()
+        if r < 0.05:
+            s += rng.choice("eE") + rng.choice(["", "+", "-"]) + str(rng.randint(0, 30))
+        elif r < 0.08 and len(s) > 3 and s[-2].isdigit() and s[-1].isdigit():
+            s = s[:-1] + "_" + s[-1]
+        t.append(s)
+    return t
+
+
+def test_numeric_matrix(path):
+    """PgNumeric::from_str on the device, with and without the loop-free path for plain decimals (k_cells / k_fused staged
+    tiles take it, the multi-pass kernels do not): header, weight, scale and base-10000 digits byte for byte against the oracle."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    from tests import pgwire as W
+    cols = [("id", SC.INT8, False, 1), ("n", SC.NUMERIC, False, 0), ("s", SC.TEXT, False, 0), ("m", SC.NUMERIC, True, 0)]
+    texts = _numeric_texts()
+    s = SC.txn([W.insert(42, [str(i), t, "x" * (i % 7), texts[-1 - i] if i % 3 else SC.N]) for i, t in enumerate(texts)])
+    prime = SC.simple_table(cols)
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+    rb, gb = o.decode(buf, s.offsets), d.decode(buf, s.offsets)
+    assert rb.err_code == 0 and gb.rc == 0, (rb.err_code, rb.err_frame, gb.rc)
+    diff = rb.host_batch().diff(gb.host())
+    assert not diff, diff[:6]
+    assert d.debug_paths()["redone"] == 0
+    d.close()
+    # malformed texts: "invalid numeric" at the right frame, whatever path looked at them first
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    for bad in ["", "+", "-", ".", "-.", "..", "1..2", "1.2.3", ".1.", "--1", "+-1", "1-", "12a", "1e", "1e+", "e5", "1__0", "_1", "1_", "1._5", "0x10", "١", "1.5é"]:
+        sb = SC.txn([W.insert(42, ["1", "2.5", "a", "2.5"]), W.insert(42, ["7", bad, "b", SC.N])])
+        buf = np.frombuffer(sb.bytes(), dtype=np.uint8)
+        rb, gb = o.decode(buf, sb.offsets), d.decode(buf, sb.offsets)
+        assert rb.err_code != 0 and rb.err_frame == 2, bad
+        assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), bad
+        o.reset_stream_state(); d.reset_stream_state()
+    d.close()
+
+
+def test_uuid_matrix(path):
+    """Uuid::parse_str forms (simple, hyphenated, braced, urn) in both cases at every alignment the preceding text column
+    produces, and every malformed neighbour of them (wrong hyphen, non-hex character, one character short / long)."""
+    import random
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    from tests import pgwire as W
+    rng = random.Random(7)
+    cols = [("id", SC.INT8, False, 1), ("s", SC.TEXT, False, 0), ("u", SC.UUID, False, 0)]
+    prime = SC.simple_table(cols)
+    good = []
+    for i in range(600):
+        h = "%032x" % rng.getrandbits(128)
+        if rng.random() < 0.5:
+            h = h.upper() if rng.random() < 0.5 else "".join(c.upper() if rng.random() < 0.5 else c for c in h)
+        hy = "-".join([h[:8], h[8:12], h[12:16], h[16:20], h[20:]])
+        good.append(rng.choice([h, hy, hy, "{" + hy + "}", "urn:uuid:" + hy]))
+    s = SC.txn([W.insert(42, [str(i), "p" * (i % 9), u]) for i, u in enumerate(good)])
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+    rb, gb = o.decode(buf, s.offsets), d.decode(buf, s.offsets)
+    assert rb.err_code == 0 and gb.rc == 0
+    diff = rb.host_batch().diff(gb.host())
+    assert not diff, diff[:6]
+    d.close()
+    hy = "123e4567-e89b-12d3-a456-426614174000"
+    bad = [hy[:-1], hy + "0", hy.replace("-", "", 1), hy[:8] + "_" + hy[9:], hy[:13] + "0" + hy[14:], "g" + hy[1:], hy[:35] + "G", hy[:20] + "é" + hy[22:],
+           "{" + hy, hy + "}", "{" + hy + ")", "urn:uuid:" + hy[:-1], "urn-uuid:" + hy, "URN:UUID:" + hy, hy.replace("-", "")[:-1], hy.replace("-", "") + "0",
+           hy.replace("-", "")[:31] + "x", "{" + hy.replace("-", "") + "}", hy[:8] + hy[9:13] + "-" + hy[13:], "@" * 36, "`" * 32, "/" * 36, ":" * 36]
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    for k, b in enumerate(bad):
+        sb = SC.txn([W.insert(42, ["1", "q" * (k % 5), hy]), W.insert(42, ["2", "r" * (k % 4), b])])
+        buf = np.frombuffer(sb.bytes(), dtype=np.uint8)
+        rb, gb = o.decode(buf, sb.offsets), d.decode(buf, sb.offsets)
+        assert rb.err_code != 0 and rb.err_frame == 2, b
+        assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), b
+        o.reset_stream_state(); d.reset_stream_state()
+    d.close()

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from etl_amd import abi, synth
 from etl_amd.decoder import Decoder
 
-NAMES = {0: "P0 stage", 1: "vote", 9: "P1 walk", 10: "P1 txn scan", 2: "P1 slot+barrier", 3: "P2 sizing", 4: "P2b prefix/scan",
+NAMES = {0: "P0 stage", 1: "vote", 11: "P1 classify", 9: "P1 walk", 10: "P1 txn scan", 2: "P1 slot+barrier", 3: "P2 sizing", 4: "P2b prefix/scan",
          5: "look-back", 6: "ctx distribute", 7: "P3 decode", 8: "P4 headers"}
 masks = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 8, 16, 31]
 w = synth.cfg3()
@@ -34,7 +34,10 @@ for phases in (False, True):
         w2.register(d)
         d.profile(True)
         t = None
-        for it in range(6):
+        n0 = ms0 = 0
+        for it in range(4 + 16):
+            if it == 4:  # the first launches of a context are slower (code load, arena growth): not timed
+                n0, ms0 = d.profile_read().get("k_cells", (0, 0.0))
             b = d.decode_device(tb.data_ptr(), tb.numel(), to.data_ptr(), nf, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
             if phases:
                 o = (C.c_ulonglong * 12)()
@@ -43,6 +46,7 @@ for phases in (False, True):
             b.close()
         prof = d.profile_read()
         n, ms = prof.get("k_cells", (0, 0.0))
+        n, ms = n - n0, ms - ms0
         row = {"dbg": dbg, "ablate": m, "k_cells_us": round(1e3 * ms / max(n, 1), 1), "launches": n, "paths": d.debug_paths()}
         if t:
             tot = sum(t)
