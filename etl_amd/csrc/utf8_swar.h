@@ -20,6 +20,17 @@ namespace etlg {
 ETLG_HD bool utf8_dword_bad(uint32_t prev, uint32_t cur, bool at_end) {
   // four positions at once: every predicate lives in bit 7 of its byte (other bits are garbage
   // until the final mask). bit k of a byte is brought to bit 7 by a left shift of 7 - k.
+  if ((((cur & (cur << 1) & (cur << 2)) | (prev & (prev << 1) & (prev << 2))) & 0x80808080u) == 0) {
+    // nothing in E0..FF here or just before (text of one- and two-byte characters, the common case): the only
+    // sequences are C2..DF + one continuation byte, and the range rules of the longer ones cannot apply
+    const uint32_t b6 = cur << 1;
+    const uint32_t ge_c0 = cur & b6, is_cont = cur & ~b6;
+    const uint32_t p1 = (prev >> 24) | (cur << 8);       // the byte before each position
+    uint32_t bad = ((p1 & (p1 << 1)) ^ is_cont) | (ge_c0 & ~((cur << 2) | (cur << 3) | (cur << 4) | (cur << 5) | (cur << 6)));  // ... | C0, C1
+    bad &= 0x80808080u;
+    if (at_end) bad |= ge_c0 & 0x80000000u;
+    return bad != 0;
+  }
   const uint64_t W = prev | ((uint64_t)cur << 32);
   const uint32_t p1 = (uint32_t)(W >> 24), p2 = (uint32_t)(W >> 16), p3 = (uint32_t)(W >> 8);  // the 1st/2nd/3rd byte before
   const uint32_t b6 = cur << 1, b5 = cur << 2, b4 = cur << 3, b3 = cur << 4, b2 = cur << 5, b1 = cur << 6, b0 = cur << 7;
