@@ -226,14 +226,17 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     // get their own wave-level steps — one header step per pass, then a cell loop whose body is a dozen VALU
     // operations (no data-dependent branches: bitwise predicates and selects).
     {
+      // Loop-carried state is kept in integers (st: 0 idle, 1 in front of an image header, 2 inside an image; bad / wide:
+      // error flags): as `bool`s they live in lane-mask SGPR pairs and every trip paid ~30 scalar instructions merging them.
       const uint32_t tag = v.tag;
-      const bool is_upd = tag == 'U';
-      uint32_t c = 0, e = 0, img = tag == 'I' ? 1u : 0u, k = 0, n = 0;
-      bool want_hdr = false, in_cells = false;
+      const uint32_t upd = tag == 'U' ? 1u : 0u;
+      uint32_t maxc_u;  // a scalar of its own: q's fields sit in an 8-register tuple that is spilled, and every use inside the loop reloaded all eight
+      ETLG_SCALAR_COPY(maxc_u, maxc);
+      uint32_t c = 0, e = 0, img = tag == 'I' ? 1u : 0u, k = 0, n = 0, st = 0, bad = 0, wide = 0;
       if (live && (tag == 'I' || tag == 'U' || tag == 'D')) {
         c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
         wire_ok = e >= c + 5;
-        if (wire_ok) { rel_id = ld_be32(base + c); c += 4; want_hdr = true; }
+        if (wire_ok) { rel_id = ld_be32(base + c); c += 4; st = 1; }
       }
       // the next 8 bytes of a lane: item tag + i16 count (header) or item tag + i32 length (cell)
       auto next8 = [&](bool on) -> uint64_t {
@@ -246,57 +249,57 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       // everybody, later the frames that go on from an old / key image to the new one), then a cell step for every lane
       // inside an image. A tile finishes in (cells of its longest frame) + 1 or 2 trips.
       for (;;) {
-        const unsigned long long wh = __ballot(want_hdr);
-        if (!(wh | __ballot(in_cells))) break;
+        const unsigned long long wh = __ballot(st == 1);
+        if (!(wh | __ballot(st == 2))) break;
         if (wh) {  // image header: 'K' | 'O' | 'N', i16 column count
-          const uint64_t head = next8(want_hdr);
+          const bool on = st == 1;
+          const uint64_t head = next8(on);
           const uint32_t t = (uint32_t)head & 0xFFu;
           const uint32_t room = e - c;  // c <= e holds for a lane that is still going
           const bool is_old = (t == 'K') | (t == 'O');
-          const uint32_t img_h = ((img == 0) & !is_old & is_upd) ? 1u : img;  // update without an old image
+          const uint32_t img_h = ((img == 0) & !is_old & (upd != 0)) ? 1u : img;  // update without an old image
           const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
           const bool hdr_ok = (room >= 3) & (img_h == 0 ? is_old : t == 'N') & !(cnt16 & 0x8000u);
-          const bool go = want_hdr & hdr_ok;
-          wire_ok &= !want_hdr | hdr_ok;
-          too_wide |= go & (cnt16 > maxc);
+          const bool go = on & hdr_ok;
+          bad |= (on & !hdr_ok) ? 1u : 0u;
+          wide |= (go & (cnt16 > maxc_u)) ? 1u : 0u;
           c += go ? 3u : 0u;
-          if (go) {
-            img = img_h;
-            old_kind = img_h == 0 ? (t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL) : old_kind;
-            n_old = img_h == 0 ? cnt16 : n_old;
-            n_new = img_h == 0 ? n_new : cnt16;
-            n = cnt16; k = 0;
-          }
-          const bool empty = go & (n == 0);  // an image without cells is complete at once
-          const bool again = empty & (img == 0) & is_upd;
-          in_cells |= go & !empty;
-          img = again ? 1u : img;
-          want_hdr = again;
-          if (!__ballot(in_cells)) continue;
+          const bool first = go & (img_h == 0);
+          old_kind = first ? (t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL) : old_kind;
+          n_old = first ? cnt16 : n_old;
+          n_new = (go & (img_h != 0)) ? cnt16 : n_new;
+          n = go ? cnt16 : n;
+          k = go ? 0u : k;
+          const bool again = go & (cnt16 == 0) & (img_h == 0) & (upd != 0);  // an image without cells is complete at once
+          img = go ? (again ? 1u : img_h) : img;
+          st = on ? (go ? (cnt16 == 0 ? (again ? 1u : 0u) : 2u) : 0u) : st;
+          if (!__ballot(st == 2)) continue;
         }
         {  // cells: 'n' | 'u' | ('t' | 'b') i32 len bytes
-          const uint64_t head = next8(in_cells);
+          const bool on = st == 2;
+          const uint64_t head = next8(on);
           const uint32_t t = (uint32_t)head & 0xFFu;
           const uint32_t room = e - c;
           const bool is_val = (t == 't') | (t == 'b');
           const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
           const uint32_t kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
           const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
-          const bool go = in_cells & cell_ok;
-          if (go & (k < maxc)) tab.put((img * maxc + k) * CF + lane, c, len, kind);
-          wire_ok &= !in_cells | cell_ok;
-          too_wide |= go & (len > 0x3FFFFFFFu);
+          const bool go = on & cell_ok;
+          if (go & (k < maxc_u)) tab.put((img * maxc_u + k) * CF + lane, c, len, kind);
+          bad |= (on & !cell_ok) ? 1u : 0u;
+          wide |= (go & (len > 0x3FFFFFFFu)) ? 1u : 0u;
           vbytes += go ? len : 0u;
           c += go ? (is_val ? 5u + len : 1u) : 0u;
           k += go ? 1u : 0u;
           // image complete: an update goes on to its new image (a header step), everything else is finished
           const bool done_img = go & (k == n);
-          const bool again = done_img & (img == 0) & is_upd;
+          const bool again = done_img & (img == 0) & (upd != 0);
           img = again ? 1u : img;
-          want_hdr |= again;
-          in_cells = go & !done_img;
+          st = on ? (go ? (done_img ? (again ? 1u : 0u) : 2u) : 0u) : st;
         }
       }
+      wire_ok = wire_ok & (bad == 0);
+      too_wide |= wide != 0;
     }
     TSTAMP(9);
     // wave-level transaction scan (no barrier: a tile's frames live in one wave)

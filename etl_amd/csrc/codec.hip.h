@@ -30,6 +30,9 @@ typedef uint8_t u8;
 #ifndef DEV_NOINLINE
 #define DEV_NOINLINE __device__ __attribute__((noinline))
 #endif
+#ifndef ETLG_SCALAR_COPY   // a wave-uniform value in a scalar register of its own (not a member of a spilled register tuple)
+#define ETLG_SCALAR_COPY(dst, src) asm volatile("s_mov_b32 %0, %1" : "=s"(dst) : "s"(src))
+#endif
 #ifndef ETLG_WAVE_PRIO   // s_setprio: the issue arbiter of a SIMD prefers the wave with the higher value (0..3)
 #define ETLG_WAVE_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif

@@ -115,6 +115,7 @@ template <class T> static inline T c_shfl_xor(const void* id, T v, int m, int = 
 // skipped the region wait here for the lanes inside it instead of running ahead to the next collective.
 #define ETLG_WAVE_JOIN() simt::c_join(SIMT_ID)
 #define ETLG_WAVE_PRIO(n) ((void)0)   // issue priority: timing only
+#define ETLG_SCALAR_COPY(dst, src) ((dst) = (src))
 #define __ballot(p) simt::c_ballot(SIMT_ID, p)
 #define __all(p) simt::c_all(SIMT_ID, p)
 #define __any(p) simt::c_any(SIMT_ID, p)
