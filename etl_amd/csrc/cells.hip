@@ -24,6 +24,7 @@
 // reads the input in place. Schemas wider than MAXC columns and every error fall back to the
 // multi-pass kernels (kernels.hip).
 #define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
+#define ETLG_DBG_WORD dbg_u   // cells_tile / k_cells keep the debug word in a scalar register of its own
 #include "lookback.hip.h"
 #include "utf8_swar.h"
 
@@ -181,7 +182,11 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   uint8_t (*const vlist)[32] = sh.vlist;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
-  const uint32_t maxc = q.maxc, VC = 2 * maxc;
+  // The launch parameters the phases keep asking for, each in a scalar register of its own: as members of q they sit in an
+  // eight-register tuple that is spilled, and every use reloaded all eight (v_readlane x 8, ~250 of them in P3 alone).
+  uint32_t maxc, dbg_u, seq_lb;
+  ETLG_SCALAR_COPY(maxc, q.maxc); ETLG_SCALAR_COPY(dbg_u, q.dbg); ETLG_SCALAR_COPY(seq_lb, q.seq_lookback);
+  const uint32_t VC = 2 * maxc;
   const uint32_t f0 = tile * CF;
   constexpr bool use_lds = STAGED;
   CellTab<STAGED> tab;
@@ -230,8 +235,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       // error flags): as `bool`s they live in lane-mask SGPR pairs and every trip paid ~30 scalar instructions merging them.
       const uint32_t tag = v.tag;
       const uint32_t upd = tag == 'U' ? 1u : 0u;
-      uint32_t maxc_u;  // a scalar of its own: q's fields sit in an 8-register tuple that is spilled, and every use inside the loop reloaded all eight
-      ETLG_SCALAR_COPY(maxc_u, maxc);
+      const uint32_t maxc_u = maxc;
       uint32_t c = 0, e = 0, img = tag == 'I' ? 1u : 0u, k = 0, n = 0, st = 0, bad = 0, wide = 0;
       if (live && (tag == 'I' || tag == 'U' || tag == 'D')) {
         c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
@@ -326,7 +330,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     tx.ord = (seg & 0x80000000u) ? c - 1 : pg.next_ord + c - 1;
   };
   if (wave == 0) {
-    if (q.seq_lookback) {
+    if (seq_lb) {
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
       make_tx(seg_unpack30((uint32_t)(ex >> 32)), (uint32_t)ex, ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0);  // look-back results are wave-uniform
     }
@@ -435,7 +439,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       if (tag == 'I' || tag == 'U' || tag == 'D') {
         if (!wire_ok) record_error(pg, f, RK_WIRE, ETLG_E_WIRE);
         else {
-          if (q.seq_lookback && !tx.in_txn) record_error(pg, f, RK_TXN, ETLG_E_TXN_STATE);
+          if (seq_lb && !tx.in_txn) record_error(pg, f, RK_TXN, ETLG_E_TXN_STATE);
           pay[tag == 'I' ? 0 : tag == 'U' ? 1 : 2] = vbytes;
           row_slot = fr_slot[lane];
           if (row_slot >= 0) {
@@ -459,7 +463,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         }
       } else {
         RowMsg dummy{};
-        size_frame(p, v, tx, wire_ok, dummy, emit, fixed, heap, pay, row_slot, q.seq_lookback != 0);
+        size_frame(p, v, tx, wire_ok, dummy, emit, fixed, heap, pay, row_slot, seq_lb != 0);
       }
     }
     {  // exclusive prefix of the cells' heap bytes in tuple order (old image, then new image): all
@@ -500,13 +504,13 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   TSTAMP(4);
   if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, s64[0], 0, fail); if (lane == 0) s64[4] = a; }
   if (wave == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
-  if (wave == 2 % NW && NW > 2 && !q.seq_lookback) {
+  if (wave == 2 % NW && NW > 2 && !seq_lb) {
     const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
     if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
   }
   if (NW <= 2 && wave == 0) {
     if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
-    if (!q.seq_lookback) {
+    if (!seq_lb) {
       const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
       if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
     }
@@ -516,7 +520,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   const uint64_t pre_ev = s64[4] >> 32, pre_hp = (uint64_t)(uint32_t)s64[4] << 2, pre_fx = s64[5] << 2;
   uint64_t ev_idx = 0, fx_off = 0, hp_off = 0;
   if (wave == 0) {
-    if (!q.seq_lookback) {
+    if (!seq_lb) {
       make_tx(s32[12], s32[13], s64[6]);
       if (live && wire_ok) txn_check_frame(pg, v, tx);
     }
@@ -584,10 +588,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     const uint32_t cls = col.cls;
     uint32_t st = ETLG_CELL_NULL, err = 0;
     bool textual = act && kind == CT_T;
-    if (q.dbg >> 6) {  // profiling ablations (results are wrong): skip one family of value codecs
+    if (dbg_u >> 6) {  // profiling ablations (results are wrong): skip one family of value codecs
       const uint32_t fam = cls == ETLG_TC_NUMERIC ? 1u : (cls >= ETLG_TC_DATE && cls <= ETLG_TC_TIMESTAMPTZ) ? 2u : cls == ETLG_TC_UUID ? 4u
                          : (cls == ETLG_TC_STRING || class_always_deferred(cls)) ? 8u : 16u;
-      if ((q.dbg >> 6) & fam) textual = false;
+      if ((dbg_u >> 6) & fam) textual = false;
     }
     // text that is copied to the heap verbatim (String cells, cells deferred wholesale): the
     // whole wave moves the bytes, a group of lanes per frame, with coalesced dword stores
@@ -595,7 +599,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     if (__ballot(coop)) {
       const uint32_t clen = coop ? len : 0u;
       const uint32_t lgG = __ballot(clen > 64u) ? 5u : __ballot(clen > 32u) ? 4u : 3u;
-      const bool bad_utf8 = ((q.dbg >> 11) & 4) ? false : coop_copy(base, pg.heap, pos, clen, hcur, lane, lgG, use_lds, (q.dbg >> 11) & 3);
+      const bool bad_utf8 = ((dbg_u >> 11) & 4) ? false : coop_copy(base, pg.heap, pos, clen, hcur, lane, lgG, use_lds, (dbg_u >> 11) & 3);
       if (coop) {
         slotp[0] = hcur; slotp[1] = len;
         st = cls == ETLG_TC_STRING ? (uint32_t)ETLG_CELL_VALUE : (uint32_t)ETLG_CELL_DEFERRED;
@@ -629,7 +633,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
 
   // ================= P4 (wave 0): finish rows, event headers
   if (wave != 0 || !emit) return;
-  if (q.dbg & 2) return;
+  if (dbg_u & 2) return;
   ETLG_WAVE_PRIO(3);
   const uint32_t tag = v.tag;
   if (tag == 'I' || tag == 'U' || tag == 'D') {
@@ -704,7 +708,9 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   }
   if (!load_carry(pg)) return;  // ASYNC chain: the batch before this one left no state to start from
   DecParams p = pg;
-  if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
+  uint32_t dbg_u;
+  ETLG_SCALAR_COPY(dbg_u, q.dbg);
+  if ((dbg_u & 8) && tid == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;
   if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
   // ---- P0: side tables, offsets, staging
