@@ -161,6 +161,7 @@ struct CellsLds {
   uint32_t* fr_n;               // n_old | n_new << 16
   uint64_t* fr_fx;              // fixed-arena offset of the frame's body
   uint32_t* fr_hp;              // heap offset of the frame's first entry
+  uint32_t* fr_ev;              // index of the frame's event
   uint32_t (*fr_st)[CF];        // 2-bit cell states of the old / new row (<= 16 columns)
   uint32_t* fr_err;             // min over (order << 8 | code)
   uint32_t* fr_toast;           // new-row columns sent as 'u'
@@ -176,7 +177,7 @@ template <int NW, bool STAGED>
 DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& q, const CellsLds& sh, const u8* base,
                     uint32_t b0, uint32_t tile, uint32_t nt) {
   uint32_t* const s_offs = sh.s_offs; int32_t* const fr_slot = sh.fr_slot; uint32_t* const fr_meta = sh.fr_meta;
-  uint32_t* const fr_n = sh.fr_n; uint64_t* const fr_fx = sh.fr_fx; uint32_t* const fr_hp = sh.fr_hp;
+  uint32_t* const fr_n = sh.fr_n; uint64_t* const fr_fx = sh.fr_fx; uint32_t* const fr_hp = sh.fr_hp; uint32_t* const fr_ev = sh.fr_ev;
   uint32_t (*const fr_st)[CF] = sh.fr_st; uint32_t* const fr_err = sh.fr_err; uint32_t* const fr_toast = sh.fr_toast;
   uint32_t* const s32 = sh.s32; uint64_t* const s64 = sh.s64;
   uint8_t (*const vlist)[32] = sh.vlist;
@@ -518,15 +519,16 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   __syncthreads();
   TSTAMP(5);
   const uint64_t pre_ev = s64[4] >> 32, pre_hp = (uint64_t)(uint32_t)s64[4] << 2, pre_fx = s64[5] << 2;
-  uint64_t ev_idx = 0, fx_off = 0, hp_off = 0;
+  // (event index and arena offsets of the frame go to LDS here and come back in P4: kept in registers across P3 they were
+  // the 64-bit values the allocator spilled to scratch)
   if (wave == 0) {
     if (!seq_lb) {
       make_tx(s32[12], s32[13], s64[6]);
       if (live && wire_ok) txn_check_frame(pg, v, tx);
     }
-    ev_idx = pre_ev + x_ev;
-    fx_off = pre_fx + ((uint64_t)x_fx << 2);
-    hp_off = pre_hp + ((uint64_t)x_hp << 2);
+    const uint64_t ev_idx = pre_ev + x_ev;
+    const uint64_t fx_off = pre_fx + ((uint64_t)x_fx << 2);
+    const uint64_t hp_off = pre_hp + ((uint64_t)x_hp << 2);
     if (lane == 0 && tile == q.ntiles - 1) {
       DevResult* r = pg.res;
       r->n_events = pre_ev + (s64[0] >> 32); r->fixed_bytes = pre_fx + (s64[1] << 2); r->heap_bytes = pre_hp + ((uint64_t)(uint32_t)s64[0] << 2);
@@ -545,6 +547,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     }
     fr_fx[lane] = fx_off;
     fr_hp[lane] = (uint32_t)hp_off;
+    fr_ev[lane] = (uint32_t)ev_idx;  // a batch has fewer than 2^32 frames
     if (live) fr_meta[lane] |= (emit ? 1u : 0u) << 11;
   }
   ETLG_WAVE_PRIO(0);
@@ -636,6 +639,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   if (dbg_u & 2) return;
   ETLG_WAVE_PRIO(3);
   const uint32_t tag = v.tag;
+  const uint64_t ev_idx = fr_ev[lane], fx_off = fr_fx[lane], hp_off = fr_hp[lane];
   if (tag == 'I' || tag == 'U' || tag == 'D') {
     const DevSlot& s = p.slots[row_slot];
     const DevCol* cols = p.cols + s.cols_base;
@@ -695,6 +699,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   __shared__ uint32_t fr_n[CF];      // n_old | n_new << 16
   __shared__ uint64_t fr_fx[CF];     // fixed-arena offset of the frame's body
   __shared__ uint32_t fr_hp[CF];     // heap offset of the frame's first entry
+  __shared__ uint32_t fr_ev[CF];     // index of the frame's event
   __shared__ uint32_t fr_st[2][CF];  // 2-bit cell states of the old / new row (<= 16 columns)
   __shared__ uint32_t fr_err[CF];    // min over (order << 8 | code)
   __shared__ uint32_t fr_toast[CF];  // new-row columns sent as 'u'
@@ -748,7 +753,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   }
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
   TSTAMP(1);
-  const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_st, fr_err, fr_toast, s32, s64, ct, vlist};
+  const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist};
   // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
   if (use_lds) cells_tile<NW, true>(p, pg, q, sh, stage, a0, tile, nt);
   else cells_tile<NW, false>(p, pg, q, sh, pg.in, 0u, tile, nt);

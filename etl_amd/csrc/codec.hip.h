@@ -918,40 +918,44 @@ DEV bool parse_uuid(const u8* s, uint32_t n, uint32_t* out4, bool over = false) 
     skip = 9;
   } else return false;
   const u8* h = s + skip;
-  const uint32_t nw = n == 32 ? 8u : 9u;
-  uint32_t w[9];
-  if (over) {  // staged bytes: aligned dwords + v_alignbyte (reads end inside the dword after the last character)
-    const uint32_t sh = (uint32_t)(uintptr_t)h & 3u;
-    const uint32_t* q = (const uint32_t*)(h - sh);
-    uint32_t prev = q[0];
-#pragma unroll
-    for (uint32_t i = 0; i < 9; i++) {
-      uint32_t nx = 0;
-      if (i < nw) nx = q[i + 1];
-      w[i] = __builtin_amdgcn_alignbyte(nx, prev, sh);
-      prev = nx;
-    }
-  } else {
-#pragma unroll
-    for (uint32_t i = 0; i < 9; i++) {
-      w[i] = 0;
-      if (i < nw) w[i] = (uint32_t)h[4 * i] | ((uint32_t)h[4 * i + 1] << 8) | ((uint32_t)h[4 * i + 2] << 16) | ((uint32_t)h[4 * i + 3] << 24);
-    }
-  }
-  if (n != 32) {  // 8-4-4-4-12: check the hyphens, close the gaps
-    if ((w[2] & 0xFFu) != '-' || ((w[3] >> 8) & 0xFFu) != '-' || ((w[4] >> 16) & 0xFFu) != '-' || (w[5] >> 24) != '-') return false;
-    w[2] = __builtin_amdgcn_alignbyte(w[3], w[2], 1);
-    w[3] = __builtin_amdgcn_alignbyte(w[4], w[3], 2);
-    w[4] = __builtin_amdgcn_alignbyte(w[5], w[4], 3);
-    w[5] = w[6]; w[6] = w[7]; w[7] = w[8];
-  }
+  const uint32_t sh = (uint32_t)(uintptr_t)h & 3u;
+  const uint32_t* q = (const uint32_t*)(h - sh);
+  // characters [4 i, 4 i + 4) of the text. Staged bytes: aligned dwords + v_alignbyte (reads end inside the dword after the last character)
+  auto word = [&](uint32_t i) -> uint32_t {
+    if (over) return __builtin_amdgcn_alignbyte(q[i + 1], q[i], sh);
+    return (uint32_t)h[4 * i] | ((uint32_t)h[4 * i + 1] << 8) | ((uint32_t)h[4 * i + 2] << 16) | ((uint32_t)h[4 * i + 3] << 24);
+  };
+  // two halves of sixteen digits each, so that at most five words of text are live at a time (all nine at once cost k_cells
+  // its fourth workgroup per CU without spills)
   bool ok = true;
-#pragma unroll
-  for (int i = 0; i < 8; i++) ok &= hex4_ok(w[i]);
-  if (!ok) return false;
-#pragma unroll
-  for (int i = 0; i < 4; i++) out4[i] = hex4_bytes(w[2 * i]) | (hex4_bytes(w[2 * i + 1]) << 16);
-  return true;
+  if (n == 32) {
+    {
+      const uint32_t a = word(0), b = word(1), c = word(2), d = word(3);
+      ok = hex4_ok(a) & hex4_ok(b) & hex4_ok(c) & hex4_ok(d);
+      out4[0] = hex4_bytes(a) | (hex4_bytes(b) << 16); out4[1] = hex4_bytes(c) | (hex4_bytes(d) << 16);
+    }
+    {
+      const uint32_t a = word(4), b = word(5), c = word(6), d = word(7);
+      ok &= hex4_ok(a) & hex4_ok(b) & hex4_ok(c) & hex4_ok(d);
+      out4[2] = hex4_bytes(a) | (hex4_bytes(b) << 16); out4[3] = hex4_bytes(c) | (hex4_bytes(d) << 16);
+    }
+    return ok;
+  }
+  {  // 8-4-4-4-12: "xxxxxxxx-xxxx-xxxx-" are characters 0..18
+    const uint32_t a = word(0), b = word(1), w2 = word(2), w3 = word(3), w4 = word(4);
+    ok = (w2 & 0xFFu) == '-' && ((w3 >> 8) & 0xFFu) == '-' && ((w4 >> 16) & 0xFFu) == '-';
+    const uint32_t c = __builtin_amdgcn_alignbyte(w3, w2, 1), d = __builtin_amdgcn_alignbyte(w4, w3, 2);
+    ok &= hex4_ok(a) & hex4_ok(b) & hex4_ok(c) & hex4_ok(d);
+    out4[0] = hex4_bytes(a) | (hex4_bytes(b) << 16); out4[1] = hex4_bytes(c) | (hex4_bytes(d) << 16);
+  }
+  {  // "xxxx-xxxxxxxxxxxx" are characters 19..35
+    const uint32_t w4 = word(4), w5 = word(5), b = word(6), c = word(7), d = word(8);
+    ok &= (w5 >> 24) == '-';
+    const uint32_t a = __builtin_amdgcn_alignbyte(w5, w4, 3);
+    ok &= hex4_ok(a) & hex4_ok(b) & hex4_ok(c) & hex4_ok(d);
+    out4[2] = hex4_bytes(a) | (hex4_bytes(b) << 16); out4[3] = hex4_bytes(c) | (hex4_bytes(d) << 16);
+  }
+  return ok;
 }
 
 // f32 / f64 `str::parse`: the exact fast path lives in float_fast.h (host-testable); here it reads through ByteWin.

@@ -1,8 +1,8 @@
 #!/bin/bash
 # end-of-round evidence for the shipped build: full GPU suite, the default bench line, rocprofv3 kernel stats of the bench command
-# (cfg2 headline; cfg3 workload), HBM traffic passes. Everything under gpurun_out/r02t; copy the summaries to profiles/.
-O=gpurun_out/r02t; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+# (cfg2 headline; cfg3 workload), HBM traffic passes. Everything under gpurun_out/r02u; copy the summaries to profiles/.
+O=gpurun_out/r02u; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -q -x ) > $O/tests.log 2>&1; tail -6 $O/tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 bash tools/traffic.sh cfg2 > $O/traffic_cfg2.log 2>&1; bash tools/traffic.sh cfg3 > $O/traffic_cfg3.log 2>&1
