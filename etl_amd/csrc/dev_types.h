@@ -58,9 +58,9 @@ struct CtrlFrame {
   uint32_t frame;
   uint32_t tag;        // 'R' | 'M'
   uint32_t in_txn;
-  uint32_t _pad;
+  uint32_t stage_off;  // where k_ctrl_list put a copy of the frame's bytes in DecParams.ctrl_stage; ~0: it did not fit, fetch [o0, o1) of the input
   uint64_t final_lsn;
-  uint32_t o0, o1;     // byte range of the frame in the input (so the host fetches its bytes without another round trip)
+  uint32_t o0, o1;     // byte range of the frame in the input
 };
 
 // Result block (device -> host, one small copy per batch).
@@ -71,7 +71,7 @@ struct DevResult {
   uint64_t n_frames;             // frames consumed
   uint32_t out_in_txn, n_ctrl;
   uint64_t out_final_lsn, out_next_ord;
-  uint32_t fused_fail, _pad;     // single-pass result not usable: 1 a look-back spin gave up (never expected), 2 the fixed-width plan did not
+  uint32_t fused_fail, ctrl_bytes;  // ctrl_bytes: bytes of R / M frames k_ctrl_list gathered into DecParams.ctrl_stage (4-byte granules). fused_fail: single-pass result not usable: 1 a look-back spin gave up (never expected), 2 the fixed-width plan did not
                                  // cover the batch (plan.hip), 4 a schema too wide for k_cells, 8 the ASYNC predecessor of this batch failed
   unsigned long long dbg_t[12];  // ETLG_FUSED_DBG&8: summed shader-clock cycles per phase (lane 0 of every tile)
   // fused kernel: payload byte counters sharded by tile id so that no single address
@@ -142,6 +142,8 @@ struct DecParams {
   uint64_t* blk_payload;  // 3 per block
   CtrlFrame* ctrl;        // compacted control frames
   uint32_t ctrl_cap;
+  uint32_t ctrl_stage_cap;  // bytes of ctrl_stage
+  uint8_t* ctrl_stage;    // the control frames' bytes, gathered so that the host fetches them with one copy
   // outputs
   uint8_t* ev_kind; uint8_t* ev_flags;
   uint32_t* ev_table; uint32_t* ev_slot;

@@ -245,6 +245,7 @@ struct etlg_ctx {
   uint32_t* h_scan = nullptr;  // pinned: its 4-word result
   size_t scan_half = 0, scan_tiles_cap = 0, scan_dirty[2] = {0, 0}; int scan_cur = 0;  // double-buffered scan descriptors: bytes per buffer, dirty 8-byte words, the one the next run uses
   unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
+  DevBuf d_ctrl_stage;   // bytes of a batch's Relation / DDL frames (k_ctrl_list gathers them)
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
   FusedParams fq{};
   PlanParams pq{};
@@ -972,7 +973,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.erase(c); }
   (void)hipStreamSynchronize(c->stream);
   if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
-  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols, &c->d_colsel}) b->release();
+  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_ctrl_stage, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols, &c->d_colsel}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (DevBuf* o : c->offs_pool) { o->release(); delete o; }
   for (auto& b : c->blk_dev) (void)hipFree(b.first);
@@ -2315,6 +2316,11 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
   launch(c, 1, p);
   HIPCHK(c, c->d_ctrl.ensure((size_t)nf * sizeof(CtrlFrame) + 64));
   p.ctrl = (CtrlFrame*)c->d_ctrl.p; p.ctrl_cap = nf;
+  {  // room for the control frames' bytes: a batch rarely carries more than a few hundred KB of them
+    const size_t want = std::min<size_t>(std::max<size_t>(b->len / 16, 64 << 10), 8 << 20);
+    HIPCHK(c, c->d_ctrl_stage.ensure(want));
+    p.ctrl_stage = (uint8_t*)c->d_ctrl_stage.p; p.ctrl_stage_cap = (uint32_t)want;
+  }
   launch(c, 2, p);
   HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -2324,19 +2330,24 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
   ctrl.resize(nctrl);
   HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
   std::sort(ctrl.begin(), ctrl.end(), [](const CtrlFrame& a, const CtrlFrame& b2) { return a.frame < b2.frame; });
-  // the frames' bytes: already on the host, or fetched from the device with ONE synchronisation for all of them
-  std::vector<uint8_t> stage;
+  // the frames' bytes: already on the host, or the gathered copy k_ctrl_list left in the staging buffer (one transfer);
+  // a frame that did not fit there is fetched from the input by itself
+  std::vector<uint8_t> stage, extra;
   std::vector<size_t> at(nctrl + 1, 0);
-  for (uint32_t i = 0; i < nctrl; i++) at[i + 1] = at[i] + (ctrl[i].o1 - ctrl[i].o0);
+  for (uint32_t i = 0; i < nctrl; i++) at[i + 1] = at[i] + (ctrl[i].stage_off == 0xFFFFFFFFu ? ctrl[i].o1 - ctrl[i].o0 : 0u);
   if (b->in_dev) {
-    stage.resize(at[nctrl] + 16);
+    const uint32_t staged = std::min<uint32_t>(b->h_res->ctrl_bytes, p.ctrl_stage_cap);
+    stage.resize((size_t)staged + 16);
+    if (staged) HIPCHK(c, hipMemcpyAsync(stage.data(), c->d_ctrl_stage.p, staged, hipMemcpyDeviceToHost, s));
+    extra.resize(at[nctrl] + 16);
     for (uint32_t i = 0; i < nctrl; i++)
-      if (ctrl[i].o1 > ctrl[i].o0) HIPCHK(c, hipMemcpyAsync(stage.data() + at[i], b->dev_in + ctrl[i].o0, ctrl[i].o1 - ctrl[i].o0, hipMemcpyDeviceToHost, s));
+      if (ctrl[i].stage_off == 0xFFFFFFFFu && ctrl[i].o1 > ctrl[i].o0)
+        HIPCHK(c, hipMemcpyAsync(extra.data() + at[i], b->dev_in + ctrl[i].o0, ctrl[i].o1 - ctrl[i].o0, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
   }
   for (uint32_t i = 0; i < nctrl; i++) {
     const CtrlFrame& cf = ctrl[i];
-    const uint8_t* fr = b->in_dev ? stage.data() + at[i] : b->host_in + cf.o0;
+    const uint8_t* fr = !b->in_dev ? b->host_in + cf.o0 : cf.stage_off != 0xFFFFFFFFu ? stage.data() + cf.stage_off : extra.data() + at[i];
     const size_t flen = cf.o1 - cf.o0;
     b->ctrl_raw.emplace_back(fr, fr + flen);
     // classify guaranteed 'd' len 'w' hdr tag: body starts at +31
