@@ -126,7 +126,7 @@ struct Gen {
   void gen_value(const synth_col& c, uint64_t row_id, bool allow_null = true) {
     Rng& r = st.rng;
     if (allow_null && c.nullable && c.null_pct && r.pct(c.null_pct)) { msg.u8('n'); return; }
-    char b[640];
+    char b[8256];   // one value: texts up to 8 KiB (wide-row tiles of k_cells)
     int n = 0;
     switch (c.kind) {
       case CK_INT4_10D: n = snprintf(b, sizeof b, "%llu", (unsigned long long)r.range(1000000000ull, 2147483647ull)); break;
@@ -145,7 +145,7 @@ struct Gen {
       }
       case CK_TEXT: {
         unsigned len = (unsigned)r.range(c.min_len, c.max_len);
-        if (len > 600) len = 600;
+        if (len > 8192) len = 8192;
         while ((unsigned)n < len) {
           if (c.utf8_pct && (unsigned)n + 2 <= len && r.pct(c.utf8_pct)) {
             // a 2-byte UTF-8 char U+00A1..U+00FF / U+0100..U+017F

@@ -455,3 +455,39 @@ def test_uuid_matrix(path):
         assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), b
         o.reset_stream_state(); d.reset_stream_state()
     d.close()
+
+
+@pytest.mark.parametrize("max_len", [40, 700, 1500, 2600, 5000])
+def test_cells_tile_sizes(max_len):
+    """k_cells across its tile regimes: small frames (the LDS allocation holds the three-dword table of a tile read in place),
+    windows of tens of KB (one-dword cell table, four workgroups per CU), windows near the 120 KB the one-dword entries
+    can address, and frames so long that every tile is read in place — all byte for byte against the oracle, with updates,
+    key images, NULLs and multi-byte text in the mix."""
+    import os
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    t = dict(rel_id=16500, name="wide_text", cols=[
+        synth.col("id", synth.CK_INT8_SEQ, synth.INT8, pk=True), synth.col("n", synth.CK_NUMERIC, synth.NUMERIC),
+        synth.col("t", synth.CK_TEXT, synth.TEXT, min_len=max_len // 3, max_len=max_len, utf8_pct=10),
+        synth.col("u", synth.CK_UUID, synth.UUID), synth.col("tn", synth.CK_TEXT, synth.TEXT, nullable=True, null_pct=30, min_len=0, max_len=max_len // 2),
+        synth.col("ts", synth.CK_TIMESTAMPTZ, synth.TIMESTAMPTZ)])
+    w = synth.Workload([t], 0xC0FFEE + max_len, rows_per_txn=37, mix=(60, 30, 10), upd_key=20, upd_toast=10, name="wide_text")
+    saved = os.environ.get("ETLG_FUSED_KERNEL")
+    os.environ["ETLG_FUSED_KERNEL"] = "2"
+    try:
+        o, d = oracle.Oracle(), Decoder(0)
+        w.register(o); w.register(d)
+        for _ in range(2):
+            buf, offs = w.fill(3 << 20)
+            rb, gb = o.decode(buf, offs), d.decode(buf, offs)
+            assert rb.err_code == 0 and gb.rc == 0
+            diff = rb.host_batch().diff(gb.host())
+            assert not diff, diff[:6]
+        n = d.debug_paths()
+        d.close()
+        assert n["cells"] == 2 and n["redone"] == 0, n
+    finally:
+        if saved is None:
+            os.environ.pop("ETLG_FUSED_KERNEL", None)
+        else:
+            os.environ["ETLG_FUSED_KERNEL"] = saved
