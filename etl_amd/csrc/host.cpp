@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <set>
@@ -246,6 +247,9 @@ struct etlg_ctx {
   size_t scan_half = 0, scan_tiles_cap = 0, scan_dirty[2] = {0, 0}; int scan_cur = 0;  // double-buffered scan descriptors: bytes per buffer, dirty 8-byte words, the one the next run uses
   unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
   DevBuf d_ctrl_stage;   // bytes of a batch's Relation / DDL frames (k_ctrl_list gathers them)
+  // ETLG_HOST_TIMES=1: wall-clock microseconds the host spends between marks of the control path, printed when the context goes
+  bool host_times = false; double host_us[12] = {0}; uint64_t host_n[12] = {0};
+  std::chrono::steady_clock::time_point host_mark;
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
   FusedParams fq{};
   PlanParams pq{};
@@ -866,6 +870,13 @@ int32_t setup_scratch(etlg_ctx* c, DecParams& p);
 bool plan_wanted(etlg_ctx* c, const etlg_batch* b);
 int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level);
 int32_t standard_path(etlg_ctx* c, etlg_batch* b);
+static inline void ht_start(etlg_ctx* c) { if (c->host_times) c->host_mark = std::chrono::steady_clock::now(); }
+static inline void ht_mark(etlg_ctx* c, int i) {
+  if (!c->host_times) return;
+  const auto t = std::chrono::steady_clock::now();
+  c->host_us[i] += std::chrono::duration<double, std::micro>(t - c->host_mark).count(); c->host_n[i]++;
+  c->host_mark = t;
+}
 int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev);
 int32_t flush_deferred(etlg_ctx* c);
 
@@ -953,6 +964,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   (void)etlg_k_cells_set_lds();
   (void)etlg_k_copy_set_lds();
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
+  { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && ht[0] == '1'; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
   clear_error(c);
@@ -972,6 +984,10 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   (void)drain_pending(c);
   { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.erase(c); }
   (void)hipStreamSynchronize(c->stream);
+  if (c->host_times) {
+    static const char* names[8] = {"pre-pass kernels + result", "control list", "control bytes", "host control plane", "side inputs", "outputs", "enqueue decode", "wait for the batch"};
+    for (int i = 0; i < 8; i++) if (c->host_n[i]) fprintf(stderr, "etlg host times: %-26s %8.1f us x %llu\n", names[i], c->host_us[i] / (double)c->host_n[i], (unsigned long long)c->host_n[i]);
+  }
   if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
   for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_ctrl_stage, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols, &c->d_colsel}) b->release();
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
@@ -2306,6 +2322,7 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
   DecParams& p = b->params;
   hipStream_t s = c->stream;
   const uint32_t nf = p.nframes;
+  ht_start(c);
   b->snapshot = c->cs; b->have_snapshot = true;
   b->ctrl.clear(); b->ctrl_raw.clear();
   b->host_err_code = 0; b->host_err_frame = -1; b->host_err_rank = 0;
@@ -2324,12 +2341,14 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
   launch(c, 2, p);
   HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  ht_mark(c, 0);
   const uint32_t nctrl = b->h_res->n_ctrl;
   if (!nctrl) return ETLG_OK;
   std::vector<CtrlFrame>& ctrl = b->ctrl;
   ctrl.resize(nctrl);
   HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
   std::sort(ctrl.begin(), ctrl.end(), [](const CtrlFrame& a, const CtrlFrame& b2) { return a.frame < b2.frame; });
+  ht_mark(c, 1);
   // the frames' bytes: already on the host, or the gathered copy k_ctrl_list left in the staging buffer (one transfer);
   // a frame that did not fit there is fetched from the input by itself
   std::vector<uint8_t> stage, extra;
@@ -2345,6 +2364,7 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
         HIPCHK(c, hipMemcpyAsync(extra.data() + at[i], b->dev_in + ctrl[i].o0, ctrl[i].o1 - ctrl[i].o0, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
   }
+  ht_mark(c, 2);
   for (uint32_t i = 0; i < nctrl; i++) {
     const CtrlFrame& cf = ctrl[i];
     const uint8_t* fr = !b->in_dev ? b->host_in + cf.o0 : cf.stage_off != 0xFFFFFFFFu ? stage.data() + cf.stage_off : extra.data() + at[i];
@@ -2356,6 +2376,7 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
     HostErr he = cf.tag == 'R' ? handle_relation(c, cf, fr + 31, flen - 31, eps) : handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
     if (he.code) { b->host_err_code = he.code; b->host_err_frame = cf.frame; b->host_err_rank = he.rank; p.host_err_frame = cf.frame; break; }
   }
+  ht_mark(c, 3);
   return ETLG_OK;
 }
 
@@ -2370,9 +2391,12 @@ int32_t standard_path(etlg_ctx* c, etlg_batch* b) {
   if (b->user_no_ctrl) p.flags |= 1u;
   else { const int32_t rc = run_control_pass(c, b, eps); if (rc != ETLG_OK) return rc; c->path_n[6]++; }
   b->eps_saved = eps;
+  ht_start(c);
   { const int32_t rc = build_side_inputs(c, b, eps); if (rc != ETLG_OK) return rc; }
+  ht_mark(c, 4);
   { const int32_t rc = setup_outputs(c, b); if (rc != ETLG_OK) return rc; }
-  if (nf && !b->host_err_code && !c->force_multipass && b->len < (1ull << 31)) return enqueue_single(c, b, 1);
+  ht_mark(c, 5);
+  if (nf && !b->host_err_code && !c->force_multipass && b->len < (1ull << 31)) { const int32_t rc = enqueue_single(c, b, 1); ht_mark(c, 6); return rc; }
   { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
   launch_multipass(c, p, b->ctrl_done && nf != 0);
   b->level = 2; b->used_fused = false; b->used_cells = false;
@@ -2407,8 +2431,10 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
   };
 #define FB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip(e_); } while (0)
 #define FB_RC(call) do { const int32_t rc_ = (call); if (rc_ != ETLG_OK) { b->pending = false; b->finished = true; b->rc = rc_; b->err = c->err; return rc_; } } while (0)
+  ht_start(c);
   if (b->done) FB_HIP(hipEventSynchronize(b->done));   // batches queued behind this one keep running
   else FB_HIP(hipStreamSynchronize(s));
+  ht_mark(c, 7);
   bool redone_mp = false;
   for (int guard = 0; guard < 8; guard++) {
     const DevResult& r0 = *b->h_res;
