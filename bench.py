@@ -17,8 +17,9 @@ control-frame broadcast, header all-gather and (`--gather-arenas`) the padded ar
 
 Rank 0 prints ONE JSON line. Beside the headline it carries one object per other BASELINE config, each with its own
 algorithmic bytes and kernel times: `cfg3` (mixed I/U/D, TEXT / NUMERIC), `cfg5` (Relation / DDL messages in the stream,
-default flags: the control path), `copy` (table-copy rows), `no_sidecar` (record-boundary scan on the device first),
-`cfg4` (with --workload cfg4 or --cfg4-leg).
+default flags: the control path), `copy` (table-copy rows), `no_sidecar` (record-boundary scan on the device first), `default_flags` (the headline workload
+without the caller's no-control assertion: the optimistic control path), `handoff` (columns / RowBinary / protobuf of a decoded
+batch), `cfg4` (with --workload cfg4 or --cfg4-leg).
 """
 import argparse
 import json
@@ -206,6 +207,7 @@ def leg_async(mk, dev_id, dev, cap, npool, nbatches, flags, check, traffic_file=
     library's HIP-event profiler for the kernel times."""
     import torch
 
+    from etl_amd import abi
     from etl_amd.decoder import Decoder
     w = mk()
     pool = [w.fill(cap) for _ in range(npool)]
@@ -239,7 +241,7 @@ def leg_async(mk, dev_id, dev, cap, npool, nbatches, flags, check, traffic_file=
         traffic = t.get("hbm_bytes_per_launch")
     out = {"value": round(p.bytes / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(p.events / dt, 1),
            "hbm_read_frac": round(p.bytes / dt / 1e9 / HBM_PEAK_GBPS, 5),
-           "workload": f"{w.name}: {cap >> 20} MiB batches, device-resident in / out, offsets sidecar, NO_CONTROL | ASYNC",
+           "workload": f"{w.name}: {cap >> 20} MiB batches, device-resident in / out, offsets sidecar, " + ("NO_CONTROL | ASYNC" if flags & abi.F_NO_CONTROL else "ASYNC, default control flags (the caller asserts nothing about Relation / DDL frames)"),
            "batches": nbatches, "frames_per_batch": int(p.frames / nbatches), "paths": dec.debug_paths(),
            "roofline": roofline_of(kern, alg, traffic), "deferred_cells": deferred_cells(dec, items[0])}
     dec.close()
@@ -576,7 +578,7 @@ def main():
     ap.add_argument("--batch-mib", type=int, default=64)
     ap.add_argument("--pool", type=int, default=6, help="distinct batches resident in HBM (rotated)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar,handoff", help="extra legs on rank 0 (comma separated; empty = none)")
+    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar,handoff,default_flags", help="extra legs on rank 0 (comma separated; empty = none)")
     ap.add_argument("--cfg4-leg", action="store_true", help="add the cfg4 leg to a cfg2 / cfg3 run")
     ap.add_argument("--cfg4-gib", type=int, default=8)
     ap.add_argument("--cfg4-seg-mib", type=int, default=1024)
@@ -744,6 +746,12 @@ def main():
         if "cfg3" in legs and args.workload != "cfg3":
             extra["cfg3"] = leg_async(synth.cfg3, local_rank, dev, cap, 4, 60, flags, check,
                                       os.path.join(ROOT, "profiles", "traffic_cfg3.json"))[0]
+        if "default_flags" in legs and args.workload == "cfg2":
+            # the headline workload WITHOUT the caller's no-control assertion: the optimistic path (first kernel as if there were
+            # no Relation / DDL frame, ETLG_E_CTRL_HINT otherwise) has to stay within a few percent of `value`
+            d = leg_async(synth.cfg2, local_rank, dev, cap, 4, 60, abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC, check)[0]
+            extra["default_flags"] = {k: d[k] for k in ("value", "unit", "workload", "batches", "paths")}
+            extra["default_flags"]["kernels_us"] = d["roofline"]["pipeline_kernels_us"]
         if "cfg5" in legs:
             extra["cfg5"] = leg_cfg5(local_rank, dev, cap, 4, 2)
         if "copy" in legs:
