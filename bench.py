@@ -749,7 +749,7 @@ def main():
         if "default_flags" in legs and args.workload == "cfg2":
             # the headline workload WITHOUT the caller's no-control assertion: the optimistic path (first kernel as if there were
             # no Relation / DDL frame, ETLG_E_CTRL_HINT otherwise) has to stay within a few percent of `value`
-            d = leg_async(synth.cfg2, local_rank, dev, cap, 4, 60, abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC, check)[0]
+            d = leg_async(synth.cfg2, local_rank, dev, cap, 6, 200, abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC, check)[0]   # the headline's pool and batch count
             extra["default_flags"] = {k: d[k] for k in ("value", "unit", "workload", "batches", "paths")}
             extra["default_flags"]["kernels_us"] = d["roofline"]["pipeline_kernels_us"]
         if "cfg5" in legs:
