@@ -241,7 +241,7 @@ def leg_async(mk, dev_id, dev, cap, npool, nbatches, flags, check, traffic_file=
         traffic = t.get("hbm_bytes_per_launch")
     out = {"value": round(p.bytes / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(p.events / dt, 1),
            "hbm_read_frac": round(p.bytes / dt / 1e9 / HBM_PEAK_GBPS, 5),
-           "workload": f"{w.name}: {cap >> 20} MiB batches, device-resident in / out, offsets sidecar, " + ("NO_CONTROL | ASYNC" if flags & abi.F_NO_CONTROL else "ASYNC, default control flags (the caller asserts nothing about Relation / DDL frames)"),
+           "workload": f"{w.name}: {cap >> 20} MiB batches, device-resident in / out, offsets sidecar, " + ("NO_CONTROL | ASYNC" if flags & abi.F_NO_CONTROL else "default control flags (the caller asserts nothing about Relation / DDL frames; the library honours ASYNC only with that assertion, so every batch is finished before the call returns)"),
            "batches": nbatches, "frames_per_batch": int(p.frames / nbatches), "paths": dec.debug_paths(),
            "roofline": roofline_of(kern, alg, traffic), "deferred_cells": deferred_cells(dec, items[0])}
     dec.close()
@@ -748,7 +748,7 @@ def main():
                                       os.path.join(ROOT, "profiles", "traffic_cfg3.json"))[0]
         if "default_flags" in legs and args.workload == "cfg2":
             # the headline workload WITHOUT the caller's no-control assertion: the optimistic path (first kernel as if there were
-            # no Relation / DDL frame, ETLG_E_CTRL_HINT otherwise) has to stay within a few percent of `value`
+            # no Relation / DDL frame, ETLG_E_CTRL_HINT otherwise), one finished batch per call (no ASYNC without the assertion)
             d = leg_async(synth.cfg2, local_rank, dev, cap, 6, 200, abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC, check)[0]   # the headline's pool and batch count
             extra["default_flags"] = {k: d[k] for k in ("value", "unit", "workload", "batches", "paths")}
             extra["default_flags"]["kernels_us"] = d["roofline"]["pipeline_kernels_us"]
