@@ -249,6 +249,7 @@ struct etlg_ctx {
   DevBuf d_ctrl_stage;   // bytes of a batch's Relation / DDL frames (k_ctrl_list gathers them)
   // ETLG_HOST_TIMES=1: wall-clock microseconds the host spends between marks of the control path, printed when the context goes
   bool host_times = false; double host_us[12] = {0}; uint64_t host_n[12] = {0};
+  size_t ctrl_stage_cap_test = 0;
   std::chrono::steady_clock::time_point host_mark;
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
   FusedParams fq{};
@@ -965,6 +966,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   (void)etlg_k_copy_set_lds();
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
   { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && ht[0] == '1'; }
+  { const char* sc = getenv("ETLG_CTRL_STAGE_CAP"); c->ctrl_stage_cap_test = sc ? (size_t)atol(sc) : 0; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
   clear_error(c);
@@ -2334,7 +2336,8 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
   HIPCHK(c, c->d_ctrl.ensure((size_t)nf * sizeof(CtrlFrame) + 64));
   p.ctrl = (CtrlFrame*)c->d_ctrl.p; p.ctrl_cap = nf;
   {  // room for the control frames' bytes: a batch rarely carries more than a few hundred KB of them
-    const size_t want = std::min<size_t>(std::max<size_t>(b->len / 16, 64 << 10), 8 << 20);
+    size_t want = std::min<size_t>(std::max<size_t>(b->len / 16, 64 << 10), 8 << 20);
+    if (c->ctrl_stage_cap_test) want = c->ctrl_stage_cap_test;   // ETLG_CTRL_STAGE_CAP (tests): a staging buffer too small for the batch's control frames
     HIPCHK(c, c->d_ctrl_stage.ensure(want));
     p.ctrl_stage = (uint8_t*)c->d_ctrl_stage.p; p.ctrl_stage_cap = (uint32_t)want;
   }

@@ -491,3 +491,48 @@ def test_cells_tile_sizes(max_len):
             os.environ.pop("ETLG_FUSED_KERNEL", None)
         else:
             os.environ["ETLG_FUSED_KERNEL"] = saved
+
+
+@pytest.mark.parametrize("cap", [1, 150, 400, 4096])
+def test_control_frames_that_do_not_fit_the_staging_buffer(cap):
+    """The control pre-pass gathers the Relation / DDL frames' bytes into one staging buffer for a single device-to-host
+    copy; a frame that does not fit is fetched from the input by itself. With the buffer forced down to a few hundred
+    bytes both routes serve the same batch, device-resident input or not, and the decode stays byte-identical."""
+    import os
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    saved = os.environ.get("ETLG_CTRL_STAGE_CAP")
+    os.environ["ETLG_CTRL_STAGE_CAP"] = str(cap)
+    try:
+        w = synth.cfg5()
+        o, d = oracle.Oracle(), Decoder(0)
+        w.register(o, ready=False); w.register(d, ready=False)
+        import torch
+        on_gpu = torch.cuda.is_available()   # the SIMT emulator build (CPU suite) takes host pointers as device pointers
+        for k in range(4):
+            buf, offs = w.fill(600 << 10)
+            rb = o.decode(buf, offs)
+            if k % 2 == 0:
+                gb = d.decode(buf, offs)
+                got = gb.host()
+            else:
+                o32 = np.ascontiguousarray(offs, dtype=np.uint32)
+                if on_gpu:
+                    tb, to = torch.from_numpy(buf.copy()).cuda(), torch.from_numpy(o32.view(np.int32).copy()).cuda()
+                    bp, op = tb.data_ptr(), to.data_ptr()
+                else:
+                    keep = (np.ascontiguousarray(buf), o32)
+                    bp, op = keep[0].ctypes.data, keep[1].ctypes.data
+                gb = d.decode_device(bp, len(buf), op, len(offs) - 1, 0)
+                got = gb.host()
+            assert rb.err_code == 0 and gb.rc == 0
+            diff = rb.host_batch().diff(got)
+            assert not diff, diff[:6]
+        n = d.debug_paths()
+        d.close()
+        assert n["control"] >= 3, n   # the first batch of a context starts on the optimistic path
+    finally:
+        if saved is None:
+            os.environ.pop("ETLG_CTRL_STAGE_CAP", None)
+        else:
+            os.environ["ETLG_CTRL_STAGE_CAP"] = saved
