@@ -777,7 +777,7 @@ int etlg_k_cells_set_lds(void) {
 
 uint32_t etlg_k_cells_table_bytes(uint32_t maxc) { return 2u * maxc * CF * 4u; }       // next to the window of a staged tile
 uint32_t etlg_k_cells_lds_floor(uint32_t maxc) { return 3u * 2u * maxc * CF * 4u; }    // table + window together: what a tile read in place needs
-uint32_t etlg_k_cells_static_lds(void) { return 3584; }  // the kernel's __shared__ arrays (3 216 bytes in the gfx950 build) + slack
+uint32_t etlg_k_cells_static_lds(void) { return 3584; }  // the kernel's __shared__ arrays (3 536 bytes in the gfx950 build) + slack
 uint32_t etlg_k_cells_maxc(void) { return MAXC; }
 
 }  // extern "C"
