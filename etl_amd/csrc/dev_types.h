@@ -179,7 +179,10 @@ struct PlanParams {
   uint32_t dbg;                // ETLG_PLAN_DBG. bit 0: no LDS staging (tests: the in-place reader). Profiling ablations, results are WRONG:
                                // bit 1 stop after staging, bit 2 stop after the message heads, bit 3 no cell decode / row stores, bit 4 no event header stores
                                // bit 5: phase clocks into DevResult.dbg_t; bit 9: one tile per wave (k_plan) even when two would do
-  uint32_t max_row_dw;         // dwords of the widest planned row (k_plan2 keeps a row of up to 6 / 8 dwords in registers)
+  uint32_t max_row_dw;         // dwords of the widest planned row (k_plan2 / k_plan3 keep a row of up to 6 / 8 dwords in registers)
+  uint32_t tiles_per_wave;     // != 0: k_plan3 — persistent waves, this many tiles each, two LDS windows of rows_off bytes per wave and look-back
+                               // words in pairs: desc = {agg, lsn}[ntiles] | {agg, lsn}[ceil(ntiles / 64)]
+  uint32_t stagger;            // k_plan3: waves sharing a SIMD start this many x 64 cycles apart (ETLG_PLAN_STAGGER)
 };
 
 // ---- columnar hand-off (columns.hip)

@@ -45,6 +45,7 @@ extern "C" void etlg_k_launch_copy(const uint8_t* rows, const uint32_t* row_offs
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_plan_set_lds(void);
+extern "C" uint32_t etlg_k_plan3_window_max(void);
 extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
 extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
 extern "C" void etlg_k_scan_lens(const uint32_t* lens, uint64_t n, unsigned long long* blk, int64_t* offsets, hipStream_t s);
@@ -63,7 +64,8 @@ constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
 constexpr int kBounds = 9; // ... of the record-boundary scan (scan.hip)
 constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
 constexpr int kPlan = 11;  // ... of the fixed-width plan (plan.hip)
-constexpr int kProfSlots = 12;
+constexpr int kPlan3 = 12; // ... of its persistent-wave form (k_plan3): same launch entry, told apart by PlanParams.tiles_per_wave
+constexpr int kProfSlots = 13;
 
 namespace {
 
@@ -262,6 +264,8 @@ struct etlg_ctx {
   int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
   uint32_t plan_margin_pct = 4;  // ETLG_PLAN_MARGIN: LDS window per tile = 64 average frames + this margin (a tile that does not fit is read in place)
   uint32_t plan_dbg = 0;         // ETLG_PLAN_DBG: bit 0 = no LDS staging (tests of the in-place reader)
+  uint32_t plan_stagger = 0;     // ETLG_PLAN_STAGGER: k_plan3 start stagger of the waves of a SIMD, x 64 cycles
+  int plan_nt = 0;               // ETLG_PLAN_NT: tiles per persistent wave of k_plan3 (0: sized from the batch; small batches take k_plan2)
   int n_cus = 256;
   uint32_t plan_skip = 0, plan_penalty = 4, plan_streak = 0;
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
@@ -809,7 +813,7 @@ void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
 
 void launch(etlg_ctx* c, int which, const DecParams& p) {
   if (c->prof) {
-    ProfRec r; r.which = which;
+    ProfRec r; r.which = (which == kPlan && c->pq.tiles_per_wave) ? kPlan3 : which;
     (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, c->stream);
     launch_raw(c, which, p);
@@ -974,6 +978,8 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_MARGIN")) c->plan_margin_pct = (uint32_t)atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_DBG")) c->plan_dbg = (uint32_t)atoi(pm);
+  if (const char* pm = getenv("ETLG_PLAN_NT")) c->plan_nt = atoi(pm);
+  if (const char* pm = getenv("ETLG_PLAN_STAGGER")) c->plan_stagger = (uint32_t)atoi(pm);
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && ncu > 0) c->n_cus = ncu; }
   { std::lock_guard<std::mutex> l(g_live_mu); c->gen = ++g_ctx_gen; g_live_ctx[c] = c->gen; }
   *out = c;
@@ -1140,7 +1146,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kPlan3 ? "k_plan3" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }
@@ -2257,7 +2263,17 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
     q.n_tabs = c->n_plan_tabs; q.tabs = (const PlanTab*)c->d_ptabs.p; q.cols = (const uint32_t*)c->d_pcols.p;
     q.dbg = c->plan_dbg;
     q.max_row_dw = (c->plan_max_row + 3) / 4;
-    const size_t per = 2 * (size_t)q.ntiles + ((size_t)q.ntiles + 63) / 64;   // desc[ntiles] | gdesc[ngroups] | dlsn[ntiles]
+    // k_plan3 (persistent waves, two windows each) when the batch is more than one round of such waves; k_plan2 / k_plan below that.
+    // ETLG_PLAN_NT=n forces n tiles per wave (tests, small batches); ETLG_PLAN_DBG bit 10 keeps k_plan2.
+    q.tiles_per_wave = 0; q.stagger = c->plan_stagger;
+    if (q.lds_bytes == q.rows_off && q.max_row_dw <= 8u && !(q.dbg & (512u | 1024u)) && q.rows_off <= etlg_k_plan3_window_max()) {
+      const uint32_t per_cu = std::min<uint32_t>(16u, (160u * 1024u) / q.rows_off);   // 16: the kernel's 128 VGPRs
+      const uint32_t resident = std::max<uint32_t>(1u, (uint32_t)c->n_cus * per_cu);
+      const uint32_t need = (q.ntiles + resident - 1) / resident;   // fewer tiles per wave than this and the grid is not resident at once: its waves would poll for tiles that cannot start
+      if (c->plan_nt > 0) q.tiles_per_wave = std::max<uint32_t>((uint32_t)c->plan_nt, need);
+      else if (q.ntiles > resident) q.tiles_per_wave = need;
+    }
+    const size_t per = 2 * ((size_t)q.ntiles + ((size_t)q.ntiles + 63) / 64);   // desc[ntiles] | gdesc[ngroups] | dlsn[ntiles], or (k_plan3) pairs: {agg, lsn}[ntiles] | {agg, lsn}[ngroups]
     const size_t dbytes = per * 8 + 64;
     uint8_t *dcur, *doth;
     { const int32_t rc = take_descriptors(c, dbytes, &dcur, &doth); if (rc != ETLG_OK) return rc; }

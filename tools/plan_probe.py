@@ -1,0 +1,60 @@
+"""k_plan variants on cfg2: kernel time (library HIP events on the decode stream) per 64 MiB batch for the persistent-wave
+kernel (k_plan3) at several tiles-per-wave settings and for k_plan2 / k_plan, all in ONE process on one box (boxes differ by
+up to 10 %, so only numbers of the same call compare). Batches rotate through a pool larger than the Infinity Cache.
+usage: python tools/plan_probe.py [variant ...]     variant = name:ENV=val,ENV=val   (default: a standard ladder)"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from etl_amd import abi, synth
+from etl_amd.decoder import Decoder
+
+DEFAULT = ["plan3_auto:", "plan2:ETLG_PLAN_DBG=1024", "plan1:ETLG_PLAN_DBG=512", "plan3_nt2:ETLG_PLAN_NT=2", "plan3_nt3:ETLG_PLAN_NT=3",
+           "plan3_nt5:ETLG_PLAN_NT=5", "plan3_nt6:ETLG_PLAN_NT=6", "plan3_nt8:ETLG_PLAN_NT=8", "plan3_auto_again:"]
+variants = sys.argv[1:] or DEFAULT
+KNOBS = ("ETLG_PLAN_DBG", "ETLG_PLAN_NT", "ETLG_PLAN_MARGIN")
+w = synth.cfg2()
+pool = []
+for k in range(6):
+    buf, offs = w.fill(64 << 20)
+    pool.append((torch.from_numpy(buf.copy()).cuda(), torch.from_numpy(offs.astype(np.uint32).view(np.int32).copy()).cuda(), len(buf), len(offs) - 1))
+torch.cuda.synchronize()
+rows = []
+for v in variants:
+    name, _, envs = v.partition(":")
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    for kv in filter(None, envs.split(",")):
+        a, b = kv.split("=")
+        os.environ[a] = b
+    d = Decoder(0)
+    synth.cfg2().register(d)
+    d.profile(True)
+    base = {}
+    for it in range(6 + 24):
+        if it == 6:
+            base = d.profile_read()
+        keep = []
+        for k in range(6):
+            tb, to, nb, nf = pool[k]
+            keep.append(d.decode_device(tb.data_ptr(), nb, to.data_ptr(), nf, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC))
+        for b in keep:
+            b.sync()
+            assert b.rc == 0, b.error
+            b.close()
+    prof = d.profile_read()
+    row = {"variant": name, "env": envs, "paths": d.debug_paths()}
+    for kn in ("k_plan", "k_plan3"):
+        n, ms = prof[kn][0] - base.get(kn, (0, 0))[0], prof[kn][1] - base.get(kn, (0, 0.0))[1]
+        if n:
+            row[kn + "_us"] = round(1e3 * ms / n, 2)
+            row[kn + "_launches"] = n
+    print(json.dumps(row), flush=True)
+    rows.append(row)
+    d.close()
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(rows, open("gpurun_out/plan_probe.json", "w"), indent=1)
