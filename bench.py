@@ -655,7 +655,7 @@ def main():
     inner = max(1, args.inner)
     nwarm = ((args.warmup * inner + G - 1) // G) * G
     nbatches = nwarm + args.steps * inner
-    hg = shard.HeaderGatherer(nbatches, G, dev, world=world) if gather else None
+    hg = shard.HeaderGatherer(nbatches, G, dev, world=world, fence=dec.fence) if gather else None
     hdrs = hg.headers if gather else torch.zeros((nbatches + G, 8), dtype=torch.int64, device=dev)
     flags = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
 

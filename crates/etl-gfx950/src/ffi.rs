@@ -332,6 +332,7 @@ extern "C" {
     pub fn etlg_batch_view_get(batch: *const etlg_batch, out: *mut etlg_batch_view) -> i32;
     pub fn etlg_batch_sync(ctx: *mut etlg_ctx, batch: *mut etlg_batch) -> i32;
     pub fn etlg_batch_header_to_device(ctx: *mut etlg_ctx, batch: *mut etlg_batch, dst_device_8xu64: *mut c_void) -> i32;
+    pub fn etlg_ctx_fence(ctx: *mut etlg_ctx) -> i32;
     pub fn etlg_batch_download(ctx: *mut etlg_ctx, batch: *mut etlg_batch) -> i32;
     pub fn etlg_batch_free(batch: *mut etlg_batch);
     pub fn etlg_batch_columns(ctx: *mut etlg_ctx, batch: *mut etlg_batch, schema_slot: i32, row_kinds: u32, flags: u32, out: *mut *mut etlg_columns) -> i32;

@@ -55,7 +55,7 @@ typedef uint8_t u8;
 #define ETLG_LDS_AS __attribute__((address_space(3)))
 #define ETLG_LDS_LD32(p) (*(volatile const ETLG_LDS_AS uint32_t*)(p))
 #endif
-// A pair of look-back words (k_plan3): ONE 16-byte load / store that bypasses the non-coherent caches (volatile: sc0 sc1), tracked by
+// A pair of look-back words (plan.hip): ONE 16-byte load / store that bypasses the non-coherent caches (volatile: sc0 sc1), tracked by
 // the compiler's own s_waitcnt bookkeeping (an inline-asm load would not be). Each 8-byte half validates itself (status bits),
 // so nothing depends on the 16 bytes arriving as one.
 #ifndef ETLG_LD_PAIR
@@ -64,16 +64,6 @@ typedef unsigned int etlg_v4u __attribute__((ext_vector_type(4)));
     (a) = ((unsigned long long)t_.y << 32) | t_.x; (l) = ((unsigned long long)t_.w << 32) | t_.z; } while (0)
 #define ETLG_ST_PAIR(ptr, a, l) do { etlg_v4u t_; t_.x = (unsigned int)(a); t_.y = (unsigned int)((unsigned long long)(a) >> 32); t_.z = (unsigned int)(l); \
     t_.w = (unsigned int)((unsigned long long)(l) >> 32); *(volatile __attribute__((address_space(1))) etlg_v4u*)(ptr) = t_; } while (0)
-#define ETLG_LD_V4(ptr) (*(const __attribute__((address_space(1))) etlg_v4u*)(ptr))                       // global_load_dwordx4 (the address is 16-byte aligned)
-#define ETLG_ST_V4_LDS(ptr, v) (*(__attribute__((address_space(3))) etlg_v4u*)(ptr) = (v))                   // ds_write_b128
-// tile i of persistent wave w (k_plan3): wave w of W takes tiles w, w + W, w + 2W, ... — every iteration works on one contiguous range of the batch
-// The waves that share a SIMD start `units` x 64 cycles apart (by their wave slot, HW_ID bits 0..3, modulo 3): persistent waves that
-// start together stay in step — all parsing, then all waiting — and a SIMD overlaps one wave's memory phase with another's VALU phase
-// only when they are out of step.
-#define ETLG_PLAN3_STAGGER(units) do { if (units) { uint32_t hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); \
-    for (uint32_t k_ = (hw_ & 15u) % 3u; k_; k_--) for (uint32_t u_ = (units); u_; u_ = u_ > 100u ? u_ - 100u : 0u) __builtin_amdgcn_s_sleep(100); } } while (0)
-#define ETLG_PERSIST_FIRST(w, nt) (w)
-#define ETLG_PERSIST_STRIDE(W) (W)
 #endif
 #ifndef ETLG_PLAN_MINWAVES
 #define ETLG_PLAN_MINWAVES 5   // k_plan: waves per SIMD the register allocator leaves room for (96 VGPRs; the ~8 KB LDS window per wave allows ~5)

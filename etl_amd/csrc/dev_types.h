@@ -77,6 +77,9 @@ struct DevResult {
   // fused kernel: payload byte counters sharded by tile id so that no single address
   // sees more than ntiles/32 atomics; the host folds them into payload[] after the sync
   unsigned long long pay_shard[32][3];
+  // plan.hip: set (release) by the batch's last tile once out_in_txn / out_final_lsn / out_next_ord above are written: a batch that runs
+  // beside this one on the second stream (DecParams.flags bit 4) polls it before it reads them
+  uint32_t carry_ready, _pad_ready;
 };
 
 // Side arguments of the fused single-pass kernel (fused.hip).
@@ -117,7 +120,8 @@ struct DecParams {
   // bits 8-11 (0x100 no row stores, 0x200 no header stores, 0x400 no row decode, 0x800 uniform waves only) are
   // profiling ablations set from ETLG_FUSED_DBG; results are wrong with any of them
   uint32_t flags;        // bit0: NO_CONTROL asserted; bit1: table-copy rows (synthetic Insert frames: no ownership
-                         // check, NULL allowed in every column — table_row.rs:199-201)
+                         // check, NULL allowed in every column — table_row.rs:199-201); bit4: `carry` belongs to a batch that may still
+                         // be running on the other stream: poll its carry_ready before reading it (plan.hip only)
   uint64_t final_lsn, next_ord;
   uint32_t host_err_frame;  // frames >= this are ignored (host control plane failed there)
   uint32_t n_tables;
@@ -180,9 +184,6 @@ struct PlanParams {
                                // bit 1 stop after staging, bit 2 stop after the message heads, bit 3 no cell decode / row stores, bit 4 no event header stores
                                // bit 5: phase clocks into DevResult.dbg_t; bit 9: one tile per wave (k_plan) even when two would do
   uint32_t max_row_dw;         // dwords of the widest planned row (k_plan2 / k_plan3 keep a row of up to 6 / 8 dwords in registers)
-  uint32_t tiles_per_wave;     // != 0: k_plan3 — persistent waves, this many tiles each, two LDS windows of rows_off bytes per wave and look-back
-                               // words in pairs: desc = {agg, lsn}[ntiles] | {agg, lsn}[ceil(ntiles / 64)]
-  uint32_t stagger;            // k_plan3: waves sharing a SIMD start this many x 64 cycles apart (ETLG_PLAN_STAGGER)
 };
 
 // ---- columnar hand-off (columns.hip)

@@ -45,7 +45,6 @@ extern "C" void etlg_k_launch_copy(const uint8_t* rows, const uint32_t* row_offs
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_plan_set_lds(void);
-extern "C" uint32_t etlg_k_plan3_window_max(void);
 extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
 extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
 extern "C" void etlg_k_scan_lens(const uint32_t* lens, uint64_t n, unsigned long long* blk, int64_t* offsets, hipStream_t s);
@@ -64,8 +63,7 @@ constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
 constexpr int kBounds = 9; // ... of the record-boundary scan (scan.hip)
 constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
 constexpr int kPlan = 11;  // ... of the fixed-width plan (plan.hip)
-constexpr int kPlan3 = 12; // ... of its persistent-wave form (k_plan3): same launch entry, told apart by PlanParams.tiles_per_wave
-constexpr int kProfSlots = 13;
+constexpr int kProfSlots = 12;
 
 namespace {
 
@@ -236,8 +234,19 @@ struct etlg_ctx {
   // device scratch (grow-only)
   // look-back descriptors are double buffered: each single-pass launch zeroes the buffer of the next one
   size_t desc_half = 0;          // bytes per buffer
-  size_t desc_dirty[2] = {0, 0}; // bytes at the head of each buffer that may be non-zero
+  size_t desc_dirty[4] = {0, 0, 0, 0}; // bytes at the head of each buffer that may be non-zero
   uint32_t desc_cur = 0;
+  // Two decode streams: consecutive ASYNC batches of the fixed-width plan alternate between them, so the tail of batch k (its last
+  // waves, the write-back, the dispatch gap) overlaps the head of batch k+1 (decode_tail, "two streams"). Everything else runs on
+  // `stream`; `stream2` is created on first use.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t tail2 = nullptr;    // recorded behind the last kernel enqueued on stream2
+  bool tail2_set = false;
+  hipEvent_t fence_ev = nullptr; // etlg_ctx_fence: recorded behind the header copies on res_stream
+  bool hdr_in_flight = false;
+  int overlap_mode = 1;          // ETLG_OVERLAP=0: one stream, as in round 2
+  bool prof_serial = false;      // etlg_ctx_profile(ctx, 2): kernels timed one at a time (no second stream), for per-kernel durations
+  unsigned long long overlapped = 0;   // debugging aid: batches launched beside their predecessor
   // result blocks: a ring re-initialised once per lap with one copy
   static constexpr uint32_t kResRing = 32;
   uint32_t res_seq = 0;
@@ -264,8 +273,6 @@ struct etlg_ctx {
   int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
   uint32_t plan_margin_pct = 4;  // ETLG_PLAN_MARGIN: LDS window per tile = 64 average frames + this margin (a tile that does not fit is read in place)
   uint32_t plan_dbg = 0;         // ETLG_PLAN_DBG: bit 0 = no LDS staging (tests of the in-place reader)
-  uint32_t plan_stagger = 0;     // ETLG_PLAN_STAGGER: k_plan3 start stagger of the waves of a SIMD, x 64 cycles
-  int plan_nt = 0;               // ETLG_PLAN_NT: tiles per persistent wave of k_plan3 (0: sized from the batch; small batches take k_plan2)
   int n_cus = 256;
   uint32_t plan_skip = 0, plan_penalty = 4, plan_streak = 0;
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
@@ -322,7 +329,10 @@ struct etlg_batch {
   bool deferred = false;        // ASYNC without a sidecar: scan in flight, decode not enqueued yet (etlg_ctx::deferred)
   const uint8_t* d_in_ptr = nullptr; const uint32_t* user_offs = nullptr;
   DevBuf* scan_offs = nullptr;  // ASYNC without a sidecar: the batch's own offsets (from the context's pool)
-  hipEvent_t kdone = nullptr; // ASYNC: recorded behind the batch's kernels on the context's stream (the result copy waits for it)
+  int plan_decided = -1;      // decode_tail: -1 not decided yet, 0 / 1 = the first attempt is the generic kernel / the fixed-width plan
+  int sidx = 0;               // decode stream the batch's first attempt was enqueued on (0: etlg_ctx::stream, 1: stream2)
+  bool force_rerun = false;   // a batch of the chain before this one had to be decoded again: whatever this one produced started from the wrong state
+  hipEvent_t kdone = nullptr; // ASYNC: recorded behind the batch's kernels on its decode stream (the result copy waits for it)
   hipEvent_t done = nullptr;  // recorded behind the copy of the result block: syncing a batch waits for IT, not for the whole stream
   DevResult* h_res = nullptr;  // pinned, from the context's pool
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
@@ -813,7 +823,7 @@ void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
 
 void launch(etlg_ctx* c, int which, const DecParams& p) {
   if (c->prof) {
-    ProfRec r; r.which = (which == kPlan && c->pq.tiles_per_wave) ? kPlan3 : which;
+    ProfRec r; r.which = which;
     (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, c->stream);
     launch_raw(c, which, p);
@@ -884,6 +894,7 @@ static inline void ht_mark(etlg_ctx* c, int i) {
 }
 int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev);
 int32_t flush_deferred(etlg_ctx* c);
+hipError_t sync_decode_streams(etlg_ctx* c);
 
 }  // namespace
 
@@ -978,8 +989,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_MARGIN")) c->plan_margin_pct = (uint32_t)atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_DBG")) c->plan_dbg = (uint32_t)atoi(pm);
-  if (const char* pm = getenv("ETLG_PLAN_NT")) c->plan_nt = atoi(pm);
-  if (const char* pm = getenv("ETLG_PLAN_STAGGER")) c->plan_stagger = (uint32_t)atoi(pm);
+  if (const char* pm = getenv("ETLG_OVERLAP")) c->overlap_mode = atoi(pm);
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && ncu > 0) c->n_cus = ncu; }
   { std::lock_guard<std::mutex> l(g_live_mu); c->gen = ++g_ctx_gen; g_live_ctx[c] = c->gen; }
   *out = c;
@@ -991,7 +1001,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)drain_pending(c);
   { std::lock_guard<std::mutex> l(g_live_mu); g_live_ctx.erase(c); }
-  (void)hipStreamSynchronize(c->stream);
+  (void)sync_decode_streams(c);
   if (c->host_times) {
     static const char* names[8] = {"pre-pass kernels + result", "control list", "control bytes", "host control plane", "side inputs", "outputs", "enqueue decode", "wait for the batch"};
     for (int i = 0; i < 8; i++) if (c->host_n[i]) fprintf(stderr, "etlg host times: %-26s %8.1f us x %llu\n", names[i], c->host_us[i] / (double)c->host_n[i], (unsigned long long)c->host_n[i]);
@@ -1004,6 +1014,9 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (auto& b : c->blk_host) (void)hipHostFree(b.first);
   if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
   if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->tail2) (void)hipEventDestroy(c->tail2);
+  if (c->fence_ev) (void)hipEventDestroy(c->fence_ev);
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& pr : c->harena_pool) (void)hipHostFree(pr.first);
@@ -1123,6 +1136,8 @@ int32_t etlg_ctx_debug_paths(etlg_ctx* c, unsigned long long* out4) {
 }
 //   [4] k_plan  [5] plan result discarded and redone by the generic single-pass kernel  [6] batches that took the control path
 //   (a Relation / DDL frame, or a caller without ETLG_F_NO_CONTROL on the multi-pass path)  [7] ASYNC batches re-run because their predecessor failed
+// debugging aid (not part of etlg.h): ASYNC batches that were enqueued beside their predecessor on the second decode stream
+unsigned long long etlg_ctx_debug_overlapped(etlg_ctx* c) { return c ? c->overlapped : 0; }
 int32_t etlg_ctx_debug_paths8(etlg_ctx* c, unsigned long long* out8) {
   if (!c || !out8) return ETLG_InvalidArgument;
   for (int i = 0; i < 8; i++) out8[i] = c->path_n[i];
@@ -1132,6 +1147,7 @@ int32_t etlg_ctx_debug_paths8(etlg_ctx* c, unsigned long long* out8) {
 int32_t etlg_ctx_profile(etlg_ctx* c, int32_t enable) {
   if (!c) return ETLG_InvalidArgument;
   c->prof = enable != 0;
+  c->prof_serial = enable == 2;   // 2: time kernels one at a time (ASYNC batches stay on one stream), for per-kernel durations that do not overlap
   if (!enable) { for (int i = 0; i < kProfSlots; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; } }
   return ETLG_OK;
 }
@@ -1146,7 +1162,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kPlan3 ? "k_plan3" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }
@@ -1450,6 +1466,7 @@ int32_t flush_deferred(etlg_ctx* c) {
 // Everything of etlg_decode that needs the frame count: parameters, result block, side inputs, outputs, the first kernel.
 int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev) {
   hipStream_t s = c->stream;
+  b->plan_decided = -1;
   const bool scan = b->scan, in_dev = b->in_dev, no_ctrl = b->user_no_ctrl;
   const size_t len = b->len;
   const uint8_t* d_in_ptr = b->d_in_ptr;
@@ -1478,6 +1495,48 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   p.carry = (async && prev) ? prev->d_res_blk : nullptr;
 
   HIPCHK(c, c->d_res.ensure(sizeof(DevResult) * etlg_ctx::kResRing));
+  const uint32_t res_slot = c->res_seq % etlg_ctx::kResRing;
+  // ---- two streams. A batch of the fixed-width plan whose predecessor in the chain is one too, and still in flight, is enqueued
+  //      on the OTHER decode stream and told (flags bit 4) that the state it starts from arrives late: its kernel does not read
+  //      the predecessor's result block at its start; the few tiles without a Begin / Commit before them in the batch poll for it
+  //      (plan.hip, plan_late_carry). So the tail of batch k — its last waves, the write-back of its dirty lines, the dispatch of
+  //      the next kernel — overlaps the staging and parsing of batch k+1: 63.9 -> 50.1 us per 64 MiB cfg2 batch measured with two
+  //      independent chains (profiles/r03_plan_development.json). Ordering kept: k+1 starts after k-1 has completed (look-back
+  //      buffers rotate with distance two; k's waves are all dispatched by then, so a tile of k+1 that polls cannot hold a slot k
+  //      needs), side inputs unchanged (a change drains the chain), no lap boundary of the result ring. Decided before anything is
+  //      enqueued for the batch; everything below then runs on the chosen stream.
+  struct StreamSwitch { etlg_ctx* c; hipStream_t saved; ~StreamSwitch() { c->stream = saved; } } sw{c, c->stream};
+  bool beside = false;
+  const bool first_try_single = p.nframes && !c->force_multipass && len < (1ull << 31) && (no_ctrl || !c->last_had_ctrl);
+  if (async && prev && prev->pending && prev->level == 0 && !prev->force_rerun && c->overlap_mode && first_try_single && c->res_seq != 0 && res_slot >= 2 &&
+      c->side_valid && !c->side_dirty && !c->slots_dirty && c->last_epochs.empty() && !b->copy.active && !c->prof_serial) {
+    p.flags |= 1u;
+    const std::vector<EpochRec> no_eps;
+    { const int32_t rc = build_side_inputs(c, b, no_eps); if (rc != ETLG_OK) return rc; }   // the unchanged-inputs path: no stream work
+    { const int32_t rc = setup_outputs(c, b); if (rc != ETLG_OK) return rc; }
+    const size_t ntl = ((size_t)nf + 63) / 64;
+    const bool pw = plan_wanted(c, b);
+    b->plan_decided = pw ? 1 : 0;
+    beside = pw && (2 * (ntl + (ntl + 63) / 64) * 8 + 64) <= c->desc_half;   // (a descriptor buffer that has to grow synchronises both streams)
+  }
+  if (beside) {
+    if (!c->stream2) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->tail2, hipEventDisableTiming));
+    }
+    b->sidx = prev->sidx ^ 1;
+    c->stream = b->sidx ? c->stream2 : sw.saved;
+    // the batch before the predecessor must be complete; it is, when it ran on this stream — otherwise wait for its event
+    etlg_batch* pp = nullptr;
+    for (size_t i = 0; i + 1 < c->pending.size(); i++) if (c->pending[i + 1] == prev) pp = c->pending[i];
+    if (pp && pp->pending && pp->kdone && pp->sidx != b->sidx) HIPCHK(c, hipStreamWaitEvent(c->stream, pp->kdone, 0));
+    p.flags |= 16u;
+    c->overlapped++;
+  } else {
+    b->sidx = 0;
+    if (c->tail2_set) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->tail2, 0)); c->tail2_set = false; }   // join: everything enqueued on stream2 so far
+  }
+  s = c->stream;
   {  // result block: next slot of a ring that is re-initialised once per lap. Slot 31 is the carry source of the batch in
      // slot 0, so it is re-initialised one batch later than the others.
     const uint32_t seq = c->res_seq++;
@@ -1499,7 +1558,9 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   const bool single_pass = nf && !c->force_multipass && len < (1ull << 31);
   // ... unless the batch before this one held control frames and the caller asserts nothing: streams that change schemas often
   // (DDL messages every few hundred transactions) would pay for a wasted kernel on every batch
-  if (single_pass && (no_ctrl || !c->last_had_ctrl)) {
+  if (b->plan_decided >= 0) {   // side inputs and outputs were set up for the stream decision above
+    { const int32_t rc = enqueue_single(c, b, b->plan_decided ? 0 : 1); if (rc != ETLG_OK) return rc; }
+  } else if (single_pass && (no_ctrl || !c->last_had_ctrl)) {
     p.flags |= 1u;
     const std::vector<EpochRec> no_eps;
     { const int32_t rc = build_side_inputs(c, b, no_eps); if (rc != ETLG_OK) return rc; }
@@ -1518,6 +1579,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     }
     if (!c->res_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventRecord(b->kdone, s));
+    if (b->sidx) { HIPCHK(c, hipEventRecord(c->tail2, s)); c->tail2_set = true; }
     HIPCHK(c, hipStreamWaitEvent(c->res_stream, b->kdone, 0));
     HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, c->res_stream));
     HIPCHK(c, hipEventRecord(b->done, c->res_stream));
@@ -1547,7 +1609,25 @@ int32_t etlg_batch_header_to_device(etlg_ctx* c, etlg_batch* b, void* dst) {
   if (!c || !b || !dst) return ETLG_InvalidArgument;
   static_assert(offsetof(DevResult, n_frames) == 56, "header layout");
   if (b->deferred) { const int32_t rc = flush_deferred(c); if (rc != ETLG_OK) return rc; }
+  if (b->pending && b->kdone && c->res_stream) {   // in flight: behind its kernels on the stream its result block travels on (etlg_ctx_fence joins)
+    HIPCHK(c, hipMemcpyAsync(dst, b->d_res_blk, 64, hipMemcpyDeviceToDevice, c->res_stream));
+    c->hdr_in_flight = true;
+    return ETLG_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(dst, b->d_res_blk, 64, hipMemcpyDeviceToDevice, c->stream));
+  return ETLG_OK;
+}
+
+int32_t etlg_ctx_fence(etlg_ctx* c) {
+  if (!c) return ETLG_InvalidArgument;
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
+  if (c->tail2_set) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->tail2, 0)); c->tail2_set = false; }
+  if (c->hdr_in_flight && c->res_stream) {
+    if (!c->fence_ev) HIPCHK(c, hipEventCreateWithFlags(&c->fence_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->fence_ev, c->res_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->fence_ev, 0));
+    c->hdr_in_flight = false;
+  }
   return ETLG_OK;
 }
 
@@ -2223,24 +2303,32 @@ bool plan_wanted(etlg_ctx* c, const etlg_batch* b) {
   return true;
 }
 
-// Look-back descriptor buffers: two, each single-pass launch uses one and zeroes the head of the other for the next batch,
-// so the stream carries no memset between kernels (only when a buffer grows or a larger batch left a tail).
+// Look-back descriptor buffers: four in rotation. The launch of batch k uses buffer k mod 4 and zeroes the head of buffer
+// (k + 2) mod 4, so the stream carries no memset between kernels (only when a buffer grows or a larger batch left a tail).
+// Distance two, not one: batch k+1 may run BESIDE batch k on the second stream (it uses a buffer batch k-1 cleared, which
+// completed before k+1 started), and the buffer k clears was last used by batch k-2, which completed before k started.
+hipError_t sync_decode_streams(etlg_ctx* c) {
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && c->stream2) e = hipStreamSynchronize(c->stream2);
+  return e;
+}
 int32_t take_descriptors(etlg_ctx* c, size_t dbytes, uint8_t** cur_out, uint8_t** oth_out) {
   hipStream_t s = c->stream;
   if (dbytes > c->desc_half) {
     const size_t half = (dbytes * 2 + 4095) & ~(size_t)4095;
-    HIPCHK(c, hipStreamSynchronize(s));   // earlier launches may still be using the old buffer
-    HIPCHK(c, c->d_desc.ensure(half * 2));
-    HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, half * 2, s));
-    c->desc_half = half; c->desc_dirty[0] = c->desc_dirty[1] = 0;
+    HIPCHK(c, sync_decode_streams(c));   // earlier launches may still be using the old buffer
+    HIPCHK(c, c->d_desc.ensure(half * 4));
+    HIPCHK(c, hipMemsetAsync(c->d_desc.p, 0, half * 4, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->desc_half = half; for (size_t& d : c->desc_dirty) d = 0;
   }
-  const uint32_t cur = c->desc_cur, oth = cur ^ 1u;
+  const uint32_t cur = c->desc_cur & 3u, oth = (cur + 2u) & 3u;
   uint8_t* dcur = (uint8_t*)c->d_desc.p + cur * c->desc_half;
   uint8_t* doth = (uint8_t*)c->d_desc.p + oth * c->desc_half;
   if (c->desc_dirty[cur]) { HIPCHK(c, hipMemsetAsync(dcur, 0, c->desc_dirty[cur], s)); c->desc_dirty[cur] = 0; }
   c->desc_dirty[cur] = dbytes;                                   // this launch writes it
-  if (c->desc_dirty[oth] <= dbytes) c->desc_dirty[oth] = 0;       // ... and clears that much of the other one
-  c->desc_cur = oth;
+  if (c->desc_dirty[oth] <= dbytes) c->desc_dirty[oth] = 0;       // ... and clears that much of the one after next
+  c->desc_cur = (cur + 1u) & 3u;
   *cur_out = dcur; *oth_out = doth;
   return ETLG_OK;
 }
@@ -2263,17 +2351,7 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
     q.n_tabs = c->n_plan_tabs; q.tabs = (const PlanTab*)c->d_ptabs.p; q.cols = (const uint32_t*)c->d_pcols.p;
     q.dbg = c->plan_dbg;
     q.max_row_dw = (c->plan_max_row + 3) / 4;
-    // k_plan3 (persistent waves, two windows each) when the batch is more than one round of such waves; k_plan2 / k_plan below that.
-    // ETLG_PLAN_NT=n forces n tiles per wave (tests, small batches); ETLG_PLAN_DBG bit 10 keeps k_plan2.
-    q.tiles_per_wave = 0; q.stagger = c->plan_stagger;
-    if (q.lds_bytes == q.rows_off && q.max_row_dw <= 8u && !(q.dbg & (512u | 1024u)) && q.rows_off <= etlg_k_plan3_window_max()) {
-      const uint32_t per_cu = std::min<uint32_t>(16u, (160u * 1024u) / q.rows_off);   // 16: the kernel's 128 VGPRs
-      const uint32_t resident = std::max<uint32_t>(1u, (uint32_t)c->n_cus * per_cu);
-      const uint32_t need = (q.ntiles + resident - 1) / resident;   // fewer tiles per wave than this and the grid is not resident at once: its waves would poll for tiles that cannot start
-      if (c->plan_nt > 0) q.tiles_per_wave = std::max<uint32_t>((uint32_t)c->plan_nt, need);
-      else if (q.ntiles > resident) q.tiles_per_wave = need;
-    }
-    const size_t per = 2 * ((size_t)q.ntiles + ((size_t)q.ntiles + 63) / 64);   // desc[ntiles] | gdesc[ngroups] | dlsn[ntiles], or (k_plan3) pairs: {agg, lsn}[ntiles] | {agg, lsn}[ngroups]
+    const size_t per = 2 * ((size_t)q.ntiles + ((size_t)q.ntiles + 63) / 64);   // pairs: {agg, lsn}[ntiles] | {agg, lsn}[ngroups]
     const size_t dbytes = per * 8 + 64;
     uint8_t *dcur, *doth;
     { const int32_t rc = take_descriptors(c, dbytes, &dcur, &doth); if (rc != ETLG_OK) return rc; }
@@ -2455,16 +2533,24 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
   else FB_HIP(hipStreamSynchronize(s));
   ht_mark(c, 7);
   bool redone_mp = false;
+  bool forced = b->force_rerun;   // a batch before this one in the chain was decoded again: this one started from a state that was not final
+  b->force_rerun = false;
   for (int guard = 0; guard < 8; guard++) {
     const DevResult& r0 = *b->h_res;
-    const bool failed = r0.first_err != kNoErr || r0.fused_fail;
+    const bool failed = forced || r0.first_err != kNoErr || r0.fused_fail;
     const bool ctrl_hint = r0.first_err != kNoErr && (uint32_t)(r0.first_err & 0xFF) == ETLG_E_CTRL_HINT && !b->user_no_ctrl && !b->ctrl_done;
     if (!failed || (b->level == 2 && !ctrl_hint)) break;
     // ---- decode again. Every earlier batch is finished, so the host's carried state is exact: no device chaining.
     DecParams& p = b->params;
     p.carry = nullptr;
+    p.flags &= ~16u;
     p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
-    const uint32_t ff = r0.fused_fail;
+    const uint32_t ff = forced ? 8u : r0.fused_fail;
+    forced = false;
+    if (!c->pending.empty()) {   // batches behind this one may be running beside it (second stream) and chained to a result that is being replaced
+      FB_HIP(sync_decode_streams(c));
+      for (etlg_batch* pb : c->pending) pb->force_rerun = true;
+    }
     FB_HIP(hipMemcpyAsync(b->d_res_blk, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
     if (b->copy.active) launch_copy(c, b->copy, p);
     if (ff & 8u) {  // the batch before this one failed, so this one never ran: same path again, now from the right state

@@ -126,35 +126,28 @@ DEV int plan_find(const PlanParams& q, uint32_t rel_u) {
 
 // ETLG_PLAN_DBG bit 5: per-phase shader-clock sums of one tile in 16 (lane 0), in DevResult.dbg_t[k]
 // ETLG_PLAN_DBG bit 6: wall-clock (100 MHz, chip-wide) timeline of EVERY tile into the (otherwise unused) heap arena: 8 x u64 per tile
-#define WSTAMP(k) do { if ((q.dbg & 64u) && threadIdx.x == 0) ((unsigned long long*)p.heap)[(size_t)(q.tiles_per_wave ? tile : blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#define WSTAMP(k) do { if ((q.dbg & 64u) && threadIdx.x == 0) ((unsigned long long*)p.heap)[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 // ETLG_PLAN_DBG bit 5: per-phase shader-clock sums of one tile in 16 (lane 0), in DevResult.dbg_t[k]
 #define PSTAMP(k) do { if ((q.dbg & 32u) && threadIdx.x == 0 && (blockIdx.x & 15u) == 3u) { const unsigned long long t_ = clock64(); atomicAdd(&p.res->dbg_t[k], t_ - tprev); tprev = t_; } } while (0)
 
 // ---- the plan's look-back --------------------------------------------------------------------------------------------
-// What a tile needs from the tiles before it: the sum of their fixed-arena dwords and the last Begin / Commit mark, ONE
-// 64-bit descriptor {mark : 30 | fixed dwords : 32} in the two-level decoupled look-back of lookback.hip.h, plus the LSN
-// of the Begin that is open when the tile starts: dlsn[t] = VALID | LSN:62 of tile t's last Begin, a second self-validating
-// word per tile, read with one dependent load once the mark says which tile holds that Begin.
-// A round trip to another CU's words costs 1.5-2 us on this chip (agent-scope loads are served past the per-XCD L2s), so
+// What a tile needs from the tiles before it: the sum of their fixed-arena dwords, the last Begin / Commit mark, and the LSN
+// of the Begin that is open when the tile starts. One 16-byte descriptor per tile and per group of 64 tiles in the two-level
+// decoupled look-back of lookback.hip.h: {status | mark : 30 | fixed dwords : 32, status | LSN : 62} — LSN of the range's last
+// Begin when its last mark is one — read with ONE 16-byte load per lane and window; the fold carries the LSN along:
+// f(older, newer) = {max mark, sum of dwords, newer has a mark ? newer's LSN : older's}. (Round 2 kept the LSN in a second
+// array, read with a dependent load once the mark said which tile held the Begin: a third round trip per tile, ~5 us of the
+// kernel.) Both halves carry the status, so a reader that catches a group descriptor between its AGG and INCL stores sees two
+// different statuses and polls again; each half is written and read as one 8-byte unit at least.
+// A round trip to another CU's words costs 1.5-2 us on this chip (such loads are served past the per-XCD L2s), so
 // the order of work matters more than the instruction count: a tile PUBLISHES as soon as it has read its message heads,
 // decodes its rows into LDS while its predecessors' words travel, and only then resolves. The last tile of a group of 64
 // resolves right away instead: it is the one that folds the group descriptor the groups behind it are waiting for.
-struct OpPlan {  // payload: hi 30 bits = running max of transaction marks, lo 32 bits = sum of fixed-arena dwords
-  DEV static uint64_t id() { return 0; }
-  DEV static uint64_t f(uint64_t a, uint64_t b) {
-    const uint32_t ma = (uint32_t)(a >> 32), mb = (uint32_t)(b >> 32);
-    return ((uint64_t)(ma > mb ? ma : mb) << 32) | (uint32_t)((uint32_t)a + (uint32_t)b);
-  }
-};
-constexpr unsigned long long kValid = 1ull << 62;
+// The transaction state carried into the batch is NOT part of the fold (virtual group -1 holds the identity): a tile whose
+// prefix holds no mark patches it in afterwards (plan_resolve) — so only the first tiles of a batch depend on the batch before
+// it, and consecutive ASYNC batches can run side by side (DecParams.flags bit 4, host.cpp "two streams").
 constexpr uint32_t kPlanMaxPolls = 1u << 15;   // bounded spin (tens of milliseconds): a give-up sends the batch to the generic kernels
 
-// ---- the same look-back with the words in PAIRS (k_plan3) -----------------------------------------------------------------
-// The LSN word above costs a third dependent round trip per tile (the mark must be known before the word can be asked for).
-// Here every descriptor is 16 bytes {status | mark : 30 | fixed dwords : 32, status | LSN : 62} — LSN of the range's last Begin
-// when its last mark is one — read with ONE 16-byte load per lane and window, and the fold carries the LSN along:
-// f(older, newer) = {max mark, sum of dwords, newer has a mark ? newer's LSN : older's}. Both halves carry the status, so a
-// reader that catches a group descriptor between its AGG and INCL stores sees two different statuses and polls again.
 struct PlanPre2 { unsigned long long a0 = 0, l0 = 0, a1 = 0, l1 = 0; bool valid = false; };
 struct PlanFold { uint32_t fx, mk, l0, l1; };   // fixed dwords, mark, LSN (low, high 30 bits)
 DEV PlanFold fold_id() { return PlanFold{0u, 0u, 0u, 0u}; }
@@ -194,9 +187,9 @@ DEV PlanPre2 plan_prefetch2(unsigned long long* d2, unsigned long long* g2, uint
   if (idx >= 0) ETLG_LD_PAIR(g2 + 2 * idx, r.a1, r.l1);
   return r;
 }
-// lookback_resolve (lookback.hip.h) on pairs: the exclusive prefix of `tile` = {mark, fixed dwords} in `ex`, the open Begin's LSN in `ex_lsn`
-DEV void plan_resolve2(unsigned long long* d2, unsigned long long* g2, uint32_t tile, uint64_t agg, uint64_t tile_lsn, uint64_t carry_agg,
-                       uint64_t carry_lsn, uint32_t* fail, const PlanPre2& pre, uint64_t& ex, uint64_t& ex_lsn) {
+// lookback_resolve (lookback.hip.h) on pairs, without a carry: the exclusive prefix of `tile` = {mark, fixed dwords} in `ex`, the open Begin's LSN in `ex_lsn`
+DEV void plan_resolve2(unsigned long long* d2, unsigned long long* g2, uint32_t tile, uint64_t agg, uint64_t tile_lsn, uint32_t* fail,
+                       const PlanPre2& pre, uint64_t& ex, uint64_t& ex_lsn) {
   const uint32_t lane = threadIdx.x, g = tile >> 6, j = tile & 63u;
   uint32_t polls = 0;
   ex = 0; ex_lsn = 0;
@@ -222,16 +215,16 @@ DEV void plan_resolve2(unsigned long long* d2, unsigned long long* g2, uint32_t 
   const PlanFold own = fold_of(agg, tile_lsn);
   const PlanFold group_agg = fold_f(local, own);
   if (j == 63u && lane == 0) ETLG_ST_PAIR(g2 + 2 * (size_t)g, ST_AGG | fold_agg(group_agg), ST_AGG | fold_lsn(group_agg));
-  // ---- window(s) 1: group descriptors before g, older groups in lower lanes, virtual group -1 = the carry
+  // ---- window(s) 1: group descriptors before g, older groups in lower lanes
   PlanFold acc = fold_id();
   int64_t base = (int64_t)g - 1;
   for (;;) {
     const int64_t idx = base - 63 + (int64_t)lane;
-    unsigned long long wa = ST_INCL | carry_agg, wl = ST_INCL | carry_lsn;
+    unsigned long long wa = ST_INCL, wl = ST_INCL;   // before group 0: the identity (the carried state is patched in by the caller)
     if (idx >= 0) {
       if (pre_valid) { wa = a1p; wl = l1p; }
       else ETLG_LD_PAIR(g2 + 2 * idx, wa, wl);
-    } else if (idx < -1) { wa = ST_INCL; wl = ST_INCL; }
+    }
     pre_valid = false;
     const unsigned long long st = pair_state(wa, wl);
     const unsigned long long m_incl = __ballot(st == ST_INCL);
@@ -263,17 +256,14 @@ struct PlanLocal {
   uint32_t* rimg;          // where the frame's body waits in LDS, or (the wave's first tile: the window is reused) ...
   uint32_t row[RD];        // ... the body itself (RD dwords: 6 or 8)
   uint64_t ord;            // written by plan_resolve (as is b_lsn: the commit_lsn column from then on)
-  uint64_t agg, carry, tile_lsn, ex, ex_lsn, tile_pre_lsn;   // wave-uniform from here on
+  uint64_t agg, tile_lsn, ex, ex_lsn, tile_pre_lsn;   // wave-uniform from here on
   uint32_t tot_mark, tot_fx;
   bool early, done;
 };
 
-// PAIR (k_plan3): look-back words in pairs. `mid()` runs between the message heads (publish) and the rows: k_plan3 finishes the
-// tile of its previous iteration there, so that tile's state is dead before the row parser needs its registers.
-struct PlanNoMid { DEV void operator()() const {} };
-template <class M, int RD, bool PAIR, class Mid>
+template <class M, int RD>
 DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* rows, bool stage_own, uint32_t a0, uint32_t tile, uint32_t nt, uint32_t my_o,
-                    uint32_t span0, uint32_t span1, unsigned long long& tprev, PlanLocal<RD>& L, bool keep, const Mid& mid) {
+                    uint32_t span0, uint32_t span1, unsigned long long& tprev, PlanLocal<RD>& L, bool keep) {
   L.done = true;   // until the local phase has run to its end
   const uint32_t lane = threadIdx.x;
   const bool live = lane < nt;
@@ -337,20 +327,10 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
   // ---- (2) publish, and while the predecessors' words travel: envelope checks, the rest of the heads, the rows into LDS
   //      (a row only needs the tile-local offset x_fx; where the tile's block goes in the arena is the look-back's answer)
   const uint64_t agg = ((uint64_t)tot_mark << 32) | tot_fx;
-  const uint64_t carry = (uint64_t)(p.in_txn ? 1u : 0u) << 32;  // virtual Begin before frame 0
   const bool early = (tile & 63u) == 63u;   // the group's folder: the groups behind it wait for what it publishes next
   uint64_t ex = 0, ex_lsn = 0;
-  if (PAIR) {
-    plan_publish2(q.desc, tile, agg, tile_lsn);
-    if (early) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, agg, tile_lsn, carry, 0ull, failp, PlanPre2(), ex, ex_lsn);
-  } else {
-    if (lane == 0) {
-      unsigned long long* dlsn = q.desc + q.ntiles + ((q.ntiles + 63u) >> 6);
-      __hip_atomic_store(&dlsn[tile], kValid | tile_lsn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    lookback_publish(q.desc, tile, agg);
-    if (early) ex = lookback_resolve<OpPlan>(q.desc, q.desc + q.ntiles, tile, agg, carry, failp);
-  }
+  plan_publish2(q.desc, tile, agg, tile_lsn);
+  if (early) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, agg, tile_lsn, failp, PlanPre2(), ex, ex_lsn);
   {
     const uint64_t h0 = rd64(m, fr);        // 'd' | len:4 | 'w' | 2 bytes of wal_start
     const uint32_t len = __builtin_bswap32((uint32_t)(h0 >> 8));
@@ -371,7 +351,6 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
   if (isB && !bad) { rimg[0] = (uint32_t)b_ts; rimg[1] = (uint32_t)(b_ts >> 32); }
   if (isC && !bad) { rimg[0] = (uint32_t)c_end; rimg[1] = (uint32_t)(c_end >> 32); rimg[2] = (uint32_t)b_ts; rimg[3] = (uint32_t)(b_ts >> 32); }
   uint32_t vbytes = 0;
-  mid();
   if (!(q.dbg & 8u)) {  // profiling: bit 3 skips the cell decode
     unsigned long long todo = __ballot(isI && !bad);
     while (todo) {  // one pass per distinct table of the wave (one, normally): column descriptors in SGPRs
@@ -434,15 +413,30 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
 #pragma unroll
     for (int d = 0; d < RD; d++) L.row[d] = rimg[d];   // inside the frame's own 38-byte head (or the lane's 32 bytes): always readable
   }
-  L.agg = agg; L.carry = carry; L.tile_lsn = tile_lsn; L.ex = ex; L.ex_lsn = ex_lsn; L.tot_mark = tot_mark; L.tot_fx = tot_fx; L.early = early; L.done = false;
+  L.agg = agg; L.tile_lsn = tile_lsn; L.ex = ex; L.ex_lsn = ex_lsn; L.tot_mark = tot_mark; L.tot_fx = tot_fx; L.early = early; L.done = false;
 }
 
-// Finish, part 1: everything that LOADS — the look-back's answer, the open Begin's LSN word — and the transaction context. A wave runs
-// this for both of its tiles before it stores anything: memory operations of a wave return in order, so a descriptor load issued
+// The transaction state a batch starts from when the batch before it may still be running (DecParams.flags bit 4, set by the
+// host for batches it puts on the second stream): wait for that batch's last tile to have written its totals, then read them.
+// Wave-uniform; once per wave. No poison check here: when a batch of a chain fails, the host decodes its successors again.
+DEV void plan_late_carry(DecParams& p, uint32_t* failp) {
+  if (!(p.flags & 16u) || !p.carry) return;
+  for (uint32_t polls = 0;; polls++) {
+    if (__hip_atomic_load(&p.carry->carry_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
+    if (polls > kPlanMaxPolls) { if (threadIdx.x == 0) atomicOr(failp, 1u); break; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  p.in_txn = __hip_atomic_load(&p.carry->out_in_txn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  p.final_lsn = __hip_atomic_load(&p.carry->out_final_lsn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  p.next_ord = __hip_atomic_load(&p.carry->out_next_ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  p.flags &= ~16u;
+}
+
+// Finish, part 1: everything that LOADS — the look-back's answer, with it the open Begin's LSN — and the transaction context. A wave
+// runs this for both of its tiles before it stores anything: memory operations of a wave return in order, so a descriptor load issued
 // behind a tile's row / header stores waits for those stores to be acknowledged first.
-template <int RD, bool PAIR = false>
-DEV void plan_resolve(const DecParams& p, const PlanParams& q, uint32_t tile, PlanLocal<RD>& L, unsigned long long& tprev,
-                      const LookbackPre& pre = LookbackPre(), const PlanPre2& pre2 = PlanPre2()) {
+template <int RD>
+DEV void plan_resolve(DecParams& p, const PlanParams& q, uint32_t tile, PlanLocal<RD>& L, unsigned long long& tprev, const PlanPre2& pre = PlanPre2()) {
   if (L.done) return;
   const uint32_t lane = threadIdx.x;
   const uint32_t f = tile * 64u + lane;
@@ -451,31 +445,18 @@ DEV void plan_resolve(const DecParams& p, const PlanParams& q, uint32_t tile, Pl
   const bool isI = (L.tagf >> 16) & 1u, isB = (L.tagf >> 17) & 1u, isC = (L.tagf >> 18) & 1u;
   const uint32_t pm = L.pm;
   const uint64_t b_lsn = L.b_lsn;
-  uint64_t ex = L.ex;
+  uint64_t ex = L.ex, ex_lsn = L.ex_lsn;
 
   // ---- (3) the look-back's answer
-  uint64_t ex_lsn = L.ex_lsn;
-  if (!L.early) {
-    if (PAIR) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, L.agg, L.tile_lsn, L.carry, 0ull, failp, pre2, ex, ex_lsn);
-    else ex = lookback_resolve<OpPlan>(q.desc, q.desc + q.ntiles, tile, L.agg, L.carry, failp, pre);
-  }
+  if (!L.early) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, L.agg, L.tile_lsn, failp, pre, ex, ex_lsn);
   PSTAMP(7);
-  const uint32_t pre_mark = (uint32_t)(ex >> 32);
-  uint64_t pre_lsn = p.final_lsn;   // LSN of the Begin that is open when this tile starts
-  if (PAIR) {
-    if ((pre_mark & 1u) && (pre_mark >> 1) != 0) pre_lsn = ex_lsn;   // it came with the fold
-  } else if ((pre_mark & 1u) && (pre_mark >> 1) != 0) {  // wave-uniform: that Begin lives in an earlier tile, which published its LSN word with its descriptor
-    unsigned long long* dlsn = q.desc + q.ntiles + ((q.ntiles + 63u) >> 6);
-    const uint32_t bt = ((pre_mark >> 1) - 1u) >> 6;
-    unsigned long long ll = 0;
-    for (uint32_t polls = 0;; polls++) {
-      ll = __hip_atomic_load(&dlsn[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ll & kValid) break;
-      if (polls > kPlanMaxPolls) { if (lane == 0) atomicOr(failp, 1u); L.done = true; return; }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    pre_lsn = ll & ~(3ull << 62);
+  uint32_t pre_mark = (uint32_t)(ex >> 32);
+  if (pre_mark == 0) {   // no Begin / Commit before this tile in the batch: the state the batch started from decides (virtual Begin before frame 0)
+    plan_late_carry(p, failp);
+    if (p.in_txn) { pre_mark = 1u; ex |= 1ull << 32; }
   }
+  // LSN of the Begin that is open when this tile starts: carried in, or (it lives in an earlier tile) it came with the fold
+  const uint64_t pre_lsn = (pre_mark & 1u) && (pre_mark >> 1) != 0 ? ex_lsn : p.final_lsn;
   PSTAMP(4);
   WSTAMP(4);
 
@@ -502,7 +483,7 @@ DEV void plan_resolve(const DecParams& p, const PlanParams& q, uint32_t tile, Pl
 
 // Finish, part 2: everything that STORES.
 template <bool REGS, int RD>
-DEV void plan_store(const DecParams& p, const PlanParams& q, uint32_t tile, const PlanLocal<RD>& L, unsigned long long& tprev) {
+DEV void plan_store(DecParams& p, const PlanParams& q, uint32_t tile, const PlanLocal<RD>& L, unsigned long long& tprev) {
   if (L.done) return;
   const uint32_t lane = threadIdx.x;
   const uint32_t f = tile * 64u + lane;
@@ -529,6 +510,7 @@ DEV void plan_store(const DecParams& p, const PlanParams& q, uint32_t tile, cons
       no = lb1 == 0 ? p.next_ord + p.nframes : (uint64_t)(p.nframes - (lb1 - 1));
     }
     r->out_final_lsn = fl; r->out_next_ord = no;
+    __hip_atomic_store(&r->carry_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the batch behind this one may be waiting for exactly these three words (plan_late_carry)
   }
 
   // ---- (4) rows and Begin / Commit bodies: LDS -> their final place in the fixed arena
@@ -580,7 +562,7 @@ DEV TileSpan plan_span(const DecParams& p, uint32_t tile) {
 
 // Stages one tile (LDS-DMA) and runs its local phase.
 template <int RD>
-DEV void plan_stage_local(const DecParams& p, const PlanParams& q, u8* smem, uint32_t tile, const TileSpan& ts, unsigned long long& tprev, PlanLocal<RD>& L, bool keep) {
+DEV void plan_stage_local(DecParams& p, const PlanParams& q, u8* smem, uint32_t tile, const TileSpan& ts, unsigned long long& tprev, PlanLocal<RD>& L, bool keep) {
   const uint32_t lane = threadIdx.x;
   L.done = true;
   const uint32_t nt = ts.nt, span0 = ts.span0, span1 = ts.span1, my_o = ts.my_o;
@@ -602,140 +584,10 @@ DEV void plan_stage_local(const DecParams& p, const PlanParams& q, u8* smem, uin
     WSTAMP(1);
     if (q.dbg & 2u) { if (smem[lane * 97u] == 0xEE && smem[lane * 13u + 5u] == 0xEF && my_o == 0xFFFFFFF1u) atomicOr(&p.res->fused_fail, 2u); return; }  // profiling: staging only
     const WinLds m{(const ETLG_LDS_AS u8*)smem};
-    plan_local<WinLds, RD, false>(p, q, m, smem, true, a0, tile, nt, my_o, span0, span1, tprev, L, keep, PlanNoMid());
+    plan_local(p, q, m, smem, true, a0, tile, nt, my_o, span0, span1, tprev, L, keep);
   } else {
     const WinGlb m{p.in, (uint32_t)p.in_len};
-    plan_local<WinGlb, RD, false>(p, q, m, smem, false, 0u, tile, nt, my_o, span0, span1, tprev, L, keep, PlanNoMid());
-  }
-}
-
-// ---- k_plan3: persistent waves ---------------------------------------------------------------------------------------------
-// k_plan2 holds a whole 64 MiB batch on the chip at once, so the kernel is one wave's chain of phases and every phase is run by
-// all waves together: HBM idles while the chip parses, the VALUs idle while it stages or waits for look-back words. Here a wave
-// takes `tiles_per_wave` tiles through its ONE LDS window and the phases of consecutive tiles overlap:
-//
-//   iteration i:  global loads of tile i+1 into REGISTERS (NP x 16 bytes per lane; its offsets came an iteration ago)
-//                 heads of tile i, publish
-//                 resolve tile i-1 (its look-back words were asked for at the end of iteration i-1; no dependent second round
-//                 trip: the Begin's LSN comes with the fold), store tile i-1 — its state is dead before the rows need registers
-//                 rows of tile i -> registers                 <- the loads travel under this
-//                 registers -> the window (ds_write_b128: the window is free, tile i's rows are in registers)
-//                 ask for the look-back words of tile i (published a row phase ago: they have landed)
-//
-// The next tile waits in registers, not in a second LDS window (measured first, profiles/r03_plan_development.json: two windows
-// per wave leave 9-10 waves per CU, and at that occupancy the row parser — a dependent chain of ~230 instructions per column —
-// ran the VALUs half empty: 62 us against k_plan2's 58). One window per wave and <= 128 VGPRs keep 16 waves per CU.
-// Tiles are dealt round robin (tile = wave + i * waves), so iteration i of all waves covers one contiguous range and the look-back
-// sees its predecessors in the same phase; the grid is sized to be resident at once, and a wave whose predecessors are not
-// (another kernel holds their slots) polls — bounded, like every spin here.
-template <int NP> struct PlanRegs { etlg_v4u r[NP]; };
-// The wave-uniform members of a tile's state, pinned to scalar registers: carried around the loop they would otherwise be merged into
-// vector registers (sixteen of them per tile in flight).
-DEV uint64_t uni64(uint64_t v) {
-  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-}
-template <int RD>
-DEV void plan_uniform(PlanLocal<RD>& L) {
-  L.agg = uni64(L.agg); L.carry = uni64(L.carry); L.tile_lsn = uni64(L.tile_lsn); L.ex = uni64(L.ex); L.ex_lsn = uni64(L.ex_lsn);
-  L.tot_mark = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tot_mark); L.tot_fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tot_fx);
-  L.early = __builtin_amdgcn_readfirstlane(L.early ? 1 : 0) != 0; L.done = __builtin_amdgcn_readfirstlane(L.done ? 1 : 0) != 0;
-}
-
-template <int NP>
-DEV bool plan3_fits(const DecParams& p, const PlanParams& q, const TileSpan& ts) {
-  const uint32_t a0 = ts.span0 & ~15u;
-  return ts.span1 > ts.span0 && ts.span1 <= p.in_len && (uint64_t)(ts.span1 - a0) + 64 <= q.rows_off && ts.span1 - a0 <= (uint32_t)NP * 1024u && !(q.dbg & 1u);
-}
-// piece k of the window = 1 KiB, lane l holds bytes [a0 + 1024 k + 16 l, +16)
-template <int NP>
-DEV void plan3_load(const DecParams& p, const TileSpan& ts, PlanRegs<NP>& R) {
-  const uint32_t lane = threadIdx.x;
-  const uint32_t a0 = ts.span0 & ~15u;
-#pragma unroll
-  for (int k = 0; k < NP; k++) {
-    const uint32_t c = a0 + ((uint32_t)k << 10) + (lane << 4);
-    etlg_v4u v = {0u, 0u, 0u, 0u};
-    if (c < ts.span1) {
-      if ((uint64_t)c + 16 <= p.in_len) v = ETLG_LD_V4(p.in + c);
-      else { uint32_t w[4] = {0u, 0u, 0u, 0u}; for (uint32_t b = 0; c + b < p.in_len; b++) w[b >> 2] |= (uint32_t)p.in[c + b] << (8 * (b & 3u)); v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3]; }
-    }
-    R.r[k] = v;
-  }
-}
-template <int NP>
-DEV void plan3_park(const TileSpan& ts, const PlanRegs<NP>& R, u8* win) {
-  const uint32_t lane = threadIdx.x;
-  const uint32_t a0 = ts.span0 & ~15u;
-#pragma unroll
-  for (int k = 0; k < NP; k++) {
-    const uint32_t c = a0 + ((uint32_t)k << 10) + (lane << 4);
-    if (c < ts.span1) ETLG_ST_V4_LDS(win + ((uint32_t)k << 10) + (lane << 4), R.r[k]);
-  }
-}
-
-template <int RD, int NP>
-DEV void plan_kernel3(DecParams& p, const PlanParams& q, u8* smem) {
-  const uint32_t lane = threadIdx.x;
-  unsigned long long tprev = (q.dbg & 32u) ? clock64() : 0ull;
-  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
-    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
-    for (uint32_t i = lane; i < per; i += 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
-  }
-  if (!load_carry(p)) return;  // ASYNC chain: the batch before this one left no state to start from
-  ETLG_PLAN3_STAGGER(q.stagger);
-  const uint32_t first = ETLG_PERSIST_FIRST(blockIdx.x, q.tiles_per_wave), stride = ETLG_PERSIST_STRIDE(gridDim.x);
-  if (first >= q.ntiles) return;
-  uint32_t n = (q.ntiles - first + stride - 1u) / stride;
-  if (n > q.tiles_per_wave) n = q.tiles_per_wave;
-  PlanRegs<NP> R;
-  TileSpan s_cur = plan_span(p, first);
-  bool st_cur = plan3_fits<NP>(p, q, s_cur);
-  if (st_cur) { plan3_load<NP>(p, s_cur, R); plan3_park<NP>(s_cur, R, smem); }
-  ETLG_WAVE_JOIN();
-  TileSpan s_nxt = s_cur;
-  if (n > 1u) s_nxt = plan_span(p, first + stride);
-  PlanLocal<RD> P;
-  P.done = true;
-  PlanPre2 preP;
-  uint32_t tP = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t tile = first + i * stride;
-    WSTAMP(0);
-    bool st_nxt = false;
-    TileSpan s_nn = s_nxt;
-    if (i + 1u < n) {
-      st_nxt = plan3_fits<NP>(p, q, s_nxt);
-      if (st_nxt) plan3_load<NP>(p, s_nxt, R);                     // the next tile's bytes travel during this iteration
-      if (i + 2u < n) s_nn = plan_span(p, tile + 2u * stride);     // ... and the offsets of the one after
-    }
-    PlanLocal<RD> C;
-    WSTAMP(6);
-    PSTAMP(1);
-    auto finish_prev = [&]() {   // the previous iteration's tile: its look-back words were asked for when its rows were done
-      if (!P.done) {
-        plan_resolve<RD, true>(p, q, tP, P, tprev, LookbackPre(), preP);
-        plan_store<true>(p, q, tP, P, tprev);
-      }
-    };
-    if (st_cur) {
-      const WinLds m{(const ETLG_LDS_AS u8*)smem};
-      plan_local<WinLds, RD, true>(p, q, m, smem, true, s_cur.span0 & ~15u, tile, s_cur.nt, s_cur.my_o, s_cur.span0, s_cur.span1, tprev, C, true, finish_prev);
-    } else {
-      const WinGlb m{p.in, (uint32_t)p.in_len};
-      plan_local<WinGlb, RD, true>(p, q, m, smem, false, 0u, tile, s_cur.nt, s_cur.my_o, s_cur.span0, s_cur.span1, tprev, C, true, finish_prev);
-    }
-    ETLG_WAVE_JOIN();   // (a wave's LDS operations execute in program order: nothing to wait for on the GPU)
-    if (st_nxt) plan3_park<NP>(s_nxt, R, smem);   // tile i's rows are in registers: the window is free
-    ETLG_WAVE_JOIN();
-    WSTAMP(1);
-    P = C; tP = tile;
-    plan_uniform(P);
-    if (!P.done && !P.early) preP = plan_prefetch2(q.desc, q.desc + 2 * (size_t)q.ntiles, tP);   // published a row phase ago; used after the next tile's heads
-    s_cur = s_nxt; st_cur = st_nxt; s_nxt = s_nn;
-  }
-  if (!P.done) {
-    plan_resolve<RD, true>(p, q, tP, P, tprev, LookbackPre(), preP);
-    plan_store<true>(p, q, tP, P, tprev);
+    plan_local(p, q, m, smem, false, 0u, tile, nt, my_o, span0, span1, tprev, L, keep);
   }
 }
 
@@ -752,7 +604,9 @@ DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
     for (uint32_t i = lane; i < per; i += 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
-  if (!load_carry(p)) return;  // ASYNC chain: the batch before this one left no state to start from
+  // ASYNC chain: the state the batch before this one left on the device — read now (that batch has finished: same stream), or, for
+  // a batch the host put on the second stream, by the few tiles that need it, when they need it (plan_late_carry)
+  if (!(p.flags & 16u) && !load_carry(p)) return;
   const uint32_t t0 = TWO ? 2u * blockIdx.x : blockIdx.x;
   const TileSpan sa = plan_span(p, t0);
   TileSpan sb = sa;
@@ -769,9 +623,9 @@ DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
       plan_stage_local(p, q, smem, t1, sb, tprev, B, false);
     }
     // both tiles' first look-back words are requested before the first wait: one round trip instead of two
-    LookbackPre preA, preB;
-    if (!A.done && !A.early) preA = lookback_prefetch(q.desc, q.desc + q.ntiles, t0);
-    if (!B.done && !B.early) preB = lookback_prefetch(q.desc, q.desc + q.ntiles, t1);
+    PlanPre2 preA, preB;
+    if (!A.done && !A.early) preA = plan_prefetch2(q.desc, q.desc + 2 * (size_t)q.ntiles, t0);
+    if (!B.done && !B.early) preB = plan_prefetch2(q.desc, q.desc + 2 * (size_t)q.ntiles, t1);
     plan_resolve(p, q, t0, A, tprev, preA);
     plan_resolve(p, q, t1, B, tprev, preB);
     plan_store<true>(p, q, t0, A, tprev);
@@ -793,19 +647,6 @@ __global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan2(DecParams p, P
   plan_kernel<true, RD>(p, q, smem);
 }
 
-#ifndef ETLG_PLAN3_MINWAVES
-#define ETLG_PLAN3_MINWAVES 4   // 128 VGPRs: the next tile's bytes wait in 32 of them
-#endif
-#ifndef ETLG_PLAN3_PIECES
-#define ETLG_PLAN3_PIECES 8
-#endif
-constexpr int kPlan3Pieces = ETLG_PLAN3_PIECES;   // KiB of window a wave can hold in registers (k_plan3 takes batches whose tiles fit; host.cpp)
-template <int RD>
-__global__ __launch_bounds__(64, ETLG_PLAN3_MINWAVES) void k_plan3(DecParams p, PlanParams q) {
-  ETLG_DYNAMIC_LDS(smem);
-  plan_kernel3<RD, kPlan3Pieces>(p, q, smem);
-}
-
 }  // namespace etlg
 
 extern "C" {
@@ -814,12 +655,6 @@ using namespace etlg;
 
 void etlg_k_launch_plan(const DecParams* p, const void* qv, hipStream_t s) {
   const PlanParams* q = (const PlanParams*)qv;
-  if (q->tiles_per_wave) {   // persistent waves (the host checked that a row fits 8 dwords and the window the registers)
-    const uint32_t waves = (q->ntiles + q->tiles_per_wave - 1) / q->tiles_per_wave;
-    if (q->max_row_dw <= 6u) hipLaunchKernelGGL(k_plan3<6>, dim3(waves), dim3(64), q->rows_off, s, *p, *q);
-    else hipLaunchKernelGGL(k_plan3<8>, dim3(waves), dim3(64), q->rows_off, s, *p, *q);
-    return;
-  }
   // two tiles per wave whenever a row fits 8 dwords (its image then needs no LDS beyond the window); ETLG_PLAN_DBG bit 9 = one tile per wave
   if (q->lds_bytes == q->rows_off && q->max_row_dw <= 8u && !(q->dbg & 512u)) {
     if (q->max_row_dw <= 6u) hipLaunchKernelGGL(k_plan2<6>, dim3((q->ntiles + 1) / 2), dim3(64), q->lds_bytes, s, *p, *q);
@@ -827,15 +662,11 @@ void etlg_k_launch_plan(const DecParams* p, const void* qv, hipStream_t s) {
   } else hipLaunchKernelGGL(k_plan, dim3(q->ntiles), dim3(64), q->lds_bytes, s, *p, *q);
 }
 
-uint32_t etlg_k_plan3_window_max(void) { return (uint32_t)kPlan3Pieces * 1024u; }
-
 int etlg_k_plan_set_lds(void) {
   const int a = hipFuncSetAttribute((const void*)k_plan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
   const int b = hipFuncSetAttribute((const void*)k_plan2<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
   const int c = hipFuncSetAttribute((const void*)k_plan2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
-  const int d = hipFuncSetAttribute((const void*)k_plan3<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
-  const int e = hipFuncSetAttribute((const void*)k_plan3<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess ? 0 : 1;
-  return a | b | c | d | e;
+  return a | b | c;
 }
 
 }  // extern "C"

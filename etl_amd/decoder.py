@@ -232,6 +232,17 @@ class Decoder:
     def set_worker(self, worker=abi.WORKER_APPLY, table_id=0, bootstrap_lsn=0):
         return self.L.etlg_ctx_set_worker(self.h, worker, table_id, bootstrap_lsn)
 
+    def debug_overlapped(self):
+        """ASYNC batches enqueued beside their predecessor on the second decode stream (debugging aid, not in etlg.h)."""
+        self.L.etlg_ctx_debug_overlapped.restype = C.c_ulonglong
+        self.L.etlg_ctx_debug_overlapped.argtypes = [C.c_void_p]
+        return int(self.L.etlg_ctx_debug_overlapped(self.h))
+
+    def fence(self):
+        """The context's stream waits (device side) for every ASYNC batch enqueued so far — decode kernels on the library's two
+        decode streams and header copies (etlg_ctx_fence); call before enqueuing a consumer of their arenas / headers on it."""
+        return self.L.etlg_ctx_fence(self.h)
+
     def reset_stream_state(self):
         return self.L.etlg_ctx_reset_stream_state(self.h)
 

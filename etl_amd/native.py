@@ -17,7 +17,7 @@ EXPORTS = [
     "etlg_abi_version", "etlg_err_table", "etlg_type_class_of_oid", "etlg_array_elem_class", "etlg_slot_bytes",
     "etlg_ctx_create", "etlg_create_error", "etlg_ctx_destroy", "etlg_ctx_set_stream", "etlg_ctx_set_worker", "etlg_schema_put",
     "etlg_table_state", "etlg_table_ready", "etlg_ctx_reset_stream_state", "etlg_decode", "etlg_last_error",
-    "etlg_batch_view_get", "etlg_batch_sync", "etlg_batch_download", "etlg_batch_header_to_device", "etlg_batch_free", "etlg_ctx_slots", "etlg_ctx_profile",
+    "etlg_batch_view_get", "etlg_batch_sync", "etlg_batch_download", "etlg_batch_header_to_device", "etlg_ctx_fence", "etlg_batch_free", "etlg_ctx_slots", "etlg_ctx_profile",
     "etlg_ctx_profile_read", "etlg_scan_boundaries", "etlg_copy_decode", "etlg_frame_tags",
     "etlg_table_forget", "etlg_table_cache_get",
     "etlg_batch_columns", "etlg_columns_view_get", "etlg_columns_free",
@@ -78,6 +78,8 @@ def lib():
     L.etlg_batch_sync.argtypes = [C.c_void_p, C.c_void_p]
     L.etlg_batch_download.argtypes = [C.c_void_p, C.c_void_p]
     L.etlg_batch_header_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.etlg_ctx_fence.argtypes = [C.c_void_p]
+    L.etlg_ctx_fence.restype = C.c_int32
     L.etlg_batch_free.argtypes = [C.c_void_p]
     L.etlg_batch_free.restype = None
     L.etlg_ctx_slots.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(abi.SlotDesc))]

@@ -239,11 +239,12 @@ class HeaderGatherer:
     at the end. (One collective per batch made the host the bottleneck: ~22 us of c10d / RCCL enqueue per
     call against a ~100 us kernel, and nothing consumes the global layout sooner.)"""
 
-    def __init__(self, nbatches, group, device, world=None, pg=None):
+    def __init__(self, nbatches, group, device, world=None, pg=None, fence=None):
         import torch
         import torch.distributed as dist
         self.G = max(1, int(group))
         self.pg = pg
+        self.fence = fence   # Decoder.fence: ASYNC header copies travel on a private stream; the collective's stream waits for them here
         self.world = dist.get_world_size(pg) if world is None else world
         self.nslots = ((nbatches + self.G - 1) // self.G + 1) * self.G
         self.headers = torch.zeros((self.nslots, 8), dtype=torch.int64, device=device)
@@ -256,6 +257,8 @@ class HeaderGatherer:
 
     def _gather_group(self, g):
         import torch.distributed as dist
+        if self.fence is not None:
+            self.fence()
         self.works.append(dist.all_gather_into_tensor(self.gathered[g], self.headers[g * self.G:(g + 1) * self.G].reshape(1, -1),
                                                       group=self.pg, async_op=True))
 

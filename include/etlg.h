@@ -263,7 +263,10 @@ enum {
   ETLG_F_NO_CONTROL = 1u << 2,       /* caller asserts: no R/M/T frame in this batch (skips the
                                         control-plane round trip; verified on device) */
   ETLG_F_ASYNC = 1u << 3             /* with OUTPUT_ON_DEVICE | NO_CONTROL: enqueue only, do not synchronize;
-                                        counts become valid after etlg_batch_sync. Sync batches in issue
+                                        counts become valid after etlg_batch_sync. The input must be COMPLETE in
+                                        device memory when the call is made: the batch may be decoded on a private
+                                        stream beside its predecessor, not behind work enqueued on the context's
+                                        stream (etlg_ctx_fence orders the other direction). Sync batches in issue
                                         order and keep fewer than 32 of them in flight per context (their
                                         result blocks live in a ring of 32; a batch that reports an error is
                                         decoded again, on the exact-error path, when it is synced).
@@ -462,14 +465,22 @@ typedef struct etlg_batch_view {
 int32_t etlg_batch_view_get(const etlg_batch* batch, etlg_batch_view* out);
 /* Wait for an ETLG_F_ASYNC batch and refresh its counts/error. */
 int32_t etlg_batch_sync(etlg_ctx* ctx, etlg_batch* batch);
-/* Enqueue (on the context's stream, no synchronisation) a device-to-device copy of
- * the batch's 64-byte result header into `dst_device_8xu64`:
+/* Enqueue (no synchronisation) a device-to-device copy of the batch's 64-byte
+ * result header into `dst_device_8xu64`:
  *   {first_err key (~0 = none), n_events, fixed_bytes, heap_bytes,
  *    payload insert/update/delete bytes, n_frames}
  * Must be called right after the etlg_decode that produced `batch`. This is the
  * per-shard record the multi-GPU all-gather exchanges (one fixed-size header per
- * rank; rank order == LSN order). */
+ * rank; rank order == LSN order). For a finished batch the copy is enqueued on the
+ * context's stream; for an ETLG_F_ASYNC batch in flight it travels on a private
+ * stream behind the batch's kernels (a copy between two decode kernels costs a
+ * dispatch gap): call etlg_ctx_fence before work on the context's stream reads it. */
 int32_t etlg_batch_header_to_device(etlg_ctx* ctx, etlg_batch* batch, void* dst_device_8xu64);
+/* Makes the context's stream wait (on the device; the host does not block) for every
+ * ETLG_F_ASYNC batch enqueued so far: their decode kernels — consecutive batches may
+ * run on two private streams side by side — and their header copies. Device work the
+ * caller enqueues on the context's stream afterwards sees their arenas and headers. */
+int32_t etlg_ctx_fence(etlg_ctx* ctx);
 /* Copy a device-resident (ETLG_F_OUTPUT_ON_DEVICE) batch into host memory;
  * afterwards the view holds host pointers. */
 int32_t etlg_batch_download(etlg_ctx* ctx, etlg_batch* batch);

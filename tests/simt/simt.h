@@ -37,19 +37,10 @@
 #define ETLG_GLDS16(g, l) memcpy((uint8_t*)(l) + 16 * (simt::g_view->tid & 63u), (const void*)(g), 16)
 #define ETLG_VMEM_WAIT() ((void)0)
 #define ETLG_LDS_AS
+#define ETLG_LDS_LD32(p) (*(const uint32_t*)(p))
 // pairs of look-back words: two plain loads / stores (one lane runs at a time)
 #define ETLG_LD_PAIR(ptr, a, l) do { (a) = ((const unsigned long long*)(ptr))[0]; (l) = ((const unsigned long long*)(ptr))[1]; } while (0)
 #define ETLG_ST_PAIR(ptr, a, l) do { ((unsigned long long*)(ptr))[0] = (a); ((unsigned long long*)(ptr))[1] = (l); } while (0)
-struct etlg_v4u { uint32_t x, y, z, w; };
-static inline etlg_v4u etlg_ld_v4(const void* p) { etlg_v4u v; memcpy(&v, p, 16); return v; }
-#define ETLG_LD_V4(ptr) etlg_ld_v4(ptr)
-#define ETLG_ST_V4_LDS(ptr, v) memcpy((void*)(ptr), &(v), 16)
-// persistent waves (k_plan3): workgroups run one after the other here, so a wave takes CONSECUTIVE tiles — every tile's predecessors
-// then belong to workgroups that have already run (the GPU build strides by the grid size instead)
-#define ETLG_PLAN3_STAGGER(units) ((void)(units))   // timing only
-#define ETLG_PERSIST_FIRST(w, nt) ((w) * (nt))
-#define ETLG_PERSIST_STRIDE(W) 1u
-#define ETLG_LDS_LD32(p) (*(const uint32_t*)(p))
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };

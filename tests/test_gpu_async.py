@@ -68,6 +68,7 @@ def _run_chain(w, pieces, expect_path=None, sidecar=True):
         rc = b.sync()
         res.append((rb, rc, b))
     paths = d.debug_paths()
+    paths["overlapped"] = d.debug_overlapped()
     for i, (rb, rc, b) in enumerate(res):
         assert (rb.err_code != 0) == (rc != 0), f"batch {i}: oracle error {rb.err_code} vs rc {rc} ({b.error})"
         if rb.err_code:
@@ -88,6 +89,39 @@ def test_async_chain_carries_transaction_state(mk, nbytes):
     assert paths["redone"] == 0 and paths["chain_rerun"] == 0 and paths["plan_redone"] == 0, paths
     if mk is synth.cfg2:
         assert paths["plan"] == 7, paths
+        # consecutive plan batches run side by side on two streams; the transactions span the cuts, so the first tiles of every
+        # batch had to wait for the state their predecessor left (plan.hip: plan_late_carry)
+        assert paths["overlapped"] >= 4, paths
+
+
+def test_async_chain_long_two_streams_and_ring_laps():
+    """70 cfg2 batches cut at arbitrary frames, up to 20 in flight: the result ring (32 blocks) laps twice, the look-back
+    buffers rotate, and every batch but the first of a lap runs beside its predecessor on the other decode stream."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.cfg2()
+    buf, offs = w.fill(6 << 20)
+    pieces = _cut(buf, offs, 70, seed=23)
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    dev = DevBufs(pieces)
+    inflight = []
+    done = 0
+    for k, (p, n, po, nf) in enumerate(dev.items):
+        inflight.append(d.decode_device(p, n, po, nf, FLAGS))
+        while len(inflight) - done > 20 or (k == len(dev.items) - 1 and done < len(inflight)):
+            b = inflight[done]
+            rb = o.decode(*pieces[done])
+            assert b.sync() == 0 and rb.err_code == 0
+            diff = rb.host_batch().diff(b.host())
+            assert not diff, f"batch {done}: {diff[:6]}"
+            b.close()
+            done += 1
+    paths = d.debug_paths()
+    assert paths["plan"] == 70 and paths["chain_rerun"] == 0 and paths["plan_redone"] == 0, paths
+    assert d.debug_overlapped() >= 60, d.debug_overlapped()
+    d.close()
 
 
 def test_async_chain_survives_an_error_in_the_middle():

@@ -5,7 +5,7 @@ columns, one wave per tile; anything else makes the kernel give the batch up and
 The plan of k_fused (etl_amd/csrc/fixed_tile.hip.h): tiles that conform take schema-constant sizing, every other tile
 of the same launch takes the generic body, and the arena must not show the seam.
 Every case runs on both (`fused` fixture: k_fused with 256 / 64 frames per tile forced, k_plan forced, k_plan reading the
-input in place instead of its LDS window, k_plan3 — persistent waves — with 3 and 5 tiles per wave and in place), with the demand that the plan was really taken where a stream conforms."""
+input in place instead of its LDS window), with the demand that the plan was really taken where a stream conforms."""
 import ctypes as C
 import os
 import struct
@@ -18,10 +18,10 @@ from etl_amd import synth
 pytestmark = pytest.mark.gpu
 
 EXPECT = True
-_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_NT")
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG")
 
 
-@pytest.fixture(params=["fused256", "fused64", "plan", "plan_one", "plan_inplace", "plan3", "plan3_nt5", "plan3_inplace"])
+@pytest.fixture(params=["fused256", "fused64", "plan", "plan_one", "plan_inplace"])
 def fused(request):
     """Yields the frames per tile of the forced k_fused instance, or 0 when k_plan is forced."""
     saved = {k: os.environ.pop(k, None) for k in _KNOBS}
@@ -31,10 +31,6 @@ def fused(request):
             os.environ["ETLG_PLAN_DBG"] = "1"
         if request.param == "plan_one":
             os.environ["ETLG_PLAN_DBG"] = "512"   # one tile per wave (k_plan) instead of two (k_plan2)
-        if request.param.startswith("plan3"):      # k_plan3: persistent waves (batches this small would take k_plan2 otherwise)
-            os.environ["ETLG_PLAN_NT"] = "5" if request.param == "plan3_nt5" else "3"
-            if request.param == "plan3_inplace":
-                os.environ["ETLG_PLAN_DBG"] = "1"
     else:
         os.environ["ETLG_FUSED_KERNEL"] = "0" if request.param == "fused256" else "1"
         os.environ["ETLG_FUSED_DBG"] = "64"   # k_fused only: count the tiles that took the plan (DevResult.dbg_t[11])
@@ -83,12 +79,6 @@ def test_conforming_stream_takes_the_plan_and_matches(fused):
         else:
             assert d.debug_paths()["plan"] == k + 1, d.debug_paths()
         assert d.debug_paths()["redone"] == 0 and d.debug_paths()["plan_redone"] == 0
-    if os.environ.get("ETLG_PLAN_NT"):   # the persistent-wave kernel really ran (its own profiling slot)
-        d.profile(True)
-        buf, offs = w.fill(200 << 10)
-        assert _agree(d, o, buf, offs) == 0
-        prof = d.profile_read()
-        assert prof["k_plan3"][0] == 1 and prof["k_plan"][0] == 0, prof
     d.close()
 
 

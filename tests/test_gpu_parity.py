@@ -21,11 +21,10 @@ PATHS = {
     "plan": {"ETLG_FUSED_KERNEL": "3"},       # the fixed-width plan whenever the batch is eligible, no back-off (k_plan2: two tiles per wave)
     "plan_one": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_DBG": "512"},     # ... one tile per wave (k_plan, the kernel wide rows take)
     "plan_inplace": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_DBG": "1"},   # ... reading the input in place instead of the LDS window
-    "plan3": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_NT": "3"},          # ... persistent waves, three tiles each through two LDS windows (k_plan3: what a 64 MiB batch takes)
     "noplan": {"ETLG_PLAN": "0"},             # the default choice without the plan
     "multipass": {"ETLG_FORCE_MULTIPASS": "1"},
 }
-_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_NT")
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG")
 
 
 @pytest.fixture(params=sorted(PATHS))
@@ -90,7 +89,7 @@ def test_large_batch_parity(mk, nbytes, path):
     d.close()
     assert n["redone"] == 0, n
     want = {"fused256": "fused", "fused64": "fused", "cells": "cells", "multipass": "multipass"}.get(path)
-    if path in ("plan", "plan_one", "plan_inplace", "plan3", "default") and mk is synth.cfg2:
+    if path in ("plan", "plan_one", "plan_inplace", "default") and mk is synth.cfg2:
         want = "plan"   # cfg2 is what the fixed-width plan is for
     if want:
         assert n[want] == 2, n

@@ -41,7 +41,7 @@ def test_product_loader_refuses_the_emulator_build(simt_lib):
 
 def _run_gpu_file_on_emulator(simt_lib, args, timeout):
     env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG=str(timeout))
-    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_NT"):
+    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args,
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout + 60)

@@ -1,6 +1,7 @@
-"""k_plan variants on cfg2: kernel time (library HIP events on the decode stream) per 64 MiB batch for the persistent-wave
-kernel (k_plan3) at several tiles-per-wave settings and for k_plan2 / k_plan, all in ONE process on one box (boxes differ by
-up to 10 %, so only numbers of the same call compare). Batches rotate through a pool larger than the Infinity Cache.
+"""k_plan variants on cfg2: per 64 MiB batch, kernel time (library HIP events on the stream of each launch — with two decode
+streams consecutive kernels overlap, so their durations add up to more than the wall clock) and wall-clock time per batch of an
+ASYNC chain, all in ONE process on one box (boxes differ by up to 10 %, so only numbers of the same call compare). Batches
+rotate through a pool larger than the Infinity Cache.
 usage: python tools/plan_probe.py [variant ...]     variant = name:ENV=val,ENV=val   (default: a standard ladder)"""
 import json
 import os
@@ -13,10 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from etl_amd import abi, synth
 from etl_amd.decoder import Decoder
 
-DEFAULT = ["plan3_auto:", "plan2:ETLG_PLAN_DBG=1024", "plan1:ETLG_PLAN_DBG=512", "plan3_nt2:ETLG_PLAN_NT=2", "plan3_nt3:ETLG_PLAN_NT=3",
-           "plan3_nt5:ETLG_PLAN_NT=5", "plan3_nt6:ETLG_PLAN_NT=6", "plan3_nt8:ETLG_PLAN_NT=8", "plan3_auto_again:"]
+DEFAULT = ["two_streams:", "one_stream:ETLG_OVERLAP=0", "one_tile_per_wave:ETLG_PLAN_DBG=512", "two_streams_again:"]
 variants = sys.argv[1:] or DEFAULT
-KNOBS = ("ETLG_PLAN_DBG", "ETLG_PLAN_NT", "ETLG_PLAN_MARGIN")
+KNOBS = ("ETLG_PLAN_DBG", "ETLG_OVERLAP", "ETLG_PLAN_MARGIN")
 w = synth.cfg2()
 pool = []
 for k in range(6):
@@ -35,9 +35,13 @@ for v in variants:
     synth.cfg2().register(d)
     d.profile(True)
     base = {}
+    import time
+    t0 = 0.0
     for it in range(6 + 24):
         if it == 6:
             base = d.profile_read()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         keep = []
         for k in range(6):
             tb, to, nb, nf = pool[k]
@@ -46,9 +50,12 @@ for v in variants:
             b.sync()
             assert b.rc == 0, b.error
             b.close()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
     prof = d.profile_read()
-    row = {"variant": name, "env": envs, "paths": d.debug_paths()}
-    for kn in ("k_plan", "k_plan3"):
+    row = {"variant": name, "env": envs, "paths": d.debug_paths(), "overlapped": d.debug_overlapped(), "wall_us_per_batch": round(1e6 * wall / (24 * 6), 2),
+           "GBps": round(24 * 6 * (64 << 20) / wall / 1e9, 1)}
+    for kn in ("k_plan",):
         n, ms = prof[kn][0] - base.get(kn, (0, 0))[0], prof[kn][1] - base.get(kn, (0, 0.0))[1]
         if n:
             row[kn + "_us"] = round(1e3 * ms / n, 2)
