@@ -1542,6 +1542,10 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     const uint32_t seq = c->res_seq++;
     const uint32_t slot = seq % etlg_ctx::kResRing;
     DevResult* ring = (DevResult*)c->d_res.p;
+    // the blocks about to be re-initialised belong to batches whose result copies travel on res_stream: with two decode streams a
+    // batch completes within microseconds of its predecessor, so "the copy of the batch before last is long done" no longer holds —
+    // wait (on the device) for the copy of the latest batch, which is behind all the others
+    if ((slot == 0 || slot == 1) && prev && prev->pending && prev->done) HIPCHK(c, hipStreamWaitEvent(s, prev->done, 0));
     if (seq == 0) HIPCHK(c, hipMemcpyAsync(ring, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice, s));
     else if (slot == 0) HIPCHK(c, hipMemcpyAsync(ring, c->h_init_ring, sizeof(DevResult) * (etlg_ctx::kResRing - 1), hipMemcpyHostToDevice, s));
     else if (slot == 1) HIPCHK(c, hipMemcpyAsync(ring + (etlg_ctx::kResRing - 1), c->h_init_ring, sizeof(DevResult), hipMemcpyHostToDevice, s));
@@ -1577,7 +1581,11 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
       if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
       (k ? b->done : b->kdone) = c->ev_pool.back(); c->ev_pool.pop_back();
     }
-    if (!c->res_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
+    if (!c->res_stream) {   // highest priority: its small copies are blit kernels, and the decode streams keep every wave slot of the chip taken
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIPCHK(c, hipStreamCreateWithPriority(&c->res_stream, hipStreamNonBlocking, hi));
+    }
     HIPCHK(c, hipEventRecord(b->kdone, s));
     if (b->sidx) { HIPCHK(c, hipEventRecord(c->tail2, s)); c->tail2_set = true; }
     HIPCHK(c, hipStreamWaitEvent(c->res_stream, b->kdone, 0));

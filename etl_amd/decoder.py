@@ -315,7 +315,9 @@ class Decoder:
 
     # ---- measurement
     def profile(self, enable=True):
-        return self.L.etlg_ctx_profile(self.h, 1 if enable else 0)
+        """HIP-event timing of every kernel launch (etlg_ctx_profile). enable=2: additionally keep ASYNC batches on ONE decode stream,
+        so that the durations are those of a kernel running alone (with two streams consecutive kernels overlap)."""
+        return self.L.etlg_ctx_profile(self.h, 2 if enable == 2 else 1 if enable else 0)
 
     def profile_read(self):
         arr = (abi.KernelStat * 16)()

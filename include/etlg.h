@@ -652,8 +652,11 @@ int32_t etlg_ctx_slots(const etlg_ctx* ctx, uint32_t* n_slots,
 
 /* ------------------------------------------------------------- measurement */
 
-/* HIP-event timing of the kernels launched by etlg_decode on the context's
- * stream (bench.py's roofline leg). */
+/* HIP-event timing of the kernels launched by etlg_decode, each on the stream
+ * it is launched on (bench.py's roofline leg). enable = 1: as the chain runs —
+ * consecutive ETLG_F_ASYNC batches side by side on two decode streams, so their
+ * durations overlap; enable = 2: the chain kept on one stream, i.e. every
+ * kernel timed alone; 0: off (resets the counters). */
 typedef struct etlg_kernel_stat {
   const char* name;
   uint64_t launches;

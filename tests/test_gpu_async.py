@@ -231,3 +231,36 @@ def test_deferred_scan_is_collected_by_whatever_comes_next():
                 assert b1.sync() == 0 and not want[1].host_batch().diff(b1.host())
                 b1.close()
             d.close()
+
+
+@pytest.mark.skipif(os.environ.get("ETLG_SIMT_RUN") == "1", reason="full-size batches: MI355X only")
+def test_async_chain_full_size_two_streams():
+    """BASELINE-size (64 MiB) cfg2 batches, 40 of them back to back with 12 in flight, every arena byte for byte against the
+    oracle. At this size two consecutive kernels really are on the chip together for tens of microseconds (the 70-batch test
+    above finishes each kernel before the next starts to matter): what the look-back buffers' rotation, the late carried state
+    and the ordering of the result ring's re-initialisation behind the result copies have to get right."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.cfg2()
+    pieces = [w.fill(64 << 20) for _ in range(4)]
+    dev = DevBufs(pieces)
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    inflight, done, n = [], 0, 40
+    for k in range(n + 1):
+        if k < n:
+            p, nb, po, nf = dev.items[k % 4]
+            inflight.append(d.decode_device(p, nb, po, nf, FLAGS))
+        while done < len(inflight) and (len(inflight) - done > 12 or k == n):
+            b = inflight[done]
+            rb = o.decode(*pieces[done % 4])
+            assert b.sync() == 0 and rb.err_code == 0, (done, b.error, rb.err_desc)
+            diff = rb.host_batch().diff(b.host())
+            assert not diff, f"batch {done}: {diff[:6]}"
+            b.close()
+            done += 1
+    paths = d.debug_paths()
+    assert paths["plan"] == n and paths["chain_rerun"] == 0 and paths["plan_redone"] == 0, paths
+    assert d.debug_overlapped() >= n - 6, d.debug_overlapped()
+    d.close()
