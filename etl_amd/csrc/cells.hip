@@ -317,23 +317,23 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     }
   }
   const uint64_t txn_agg = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark;  // meaningful on wave 0
-  const uint64_t txn_carry = (uint64_t)(pg.in_txn ? 1u : 0u);
   TxnCtx tx{true, 0, 0};
   uint32_t bc = 0, bm = 0;
-  auto make_tx = [&](uint32_t c_in, uint32_t m_in, uint64_t carried_lsn) {
-    bc = c_in; bm = m_in;
+  uint64_t carried_lsn = 0, start_ord = 0;   // wave 0, from the transaction look-back: final_lsn of the Begin `bm` names, the ordinal the batch starts from
+  auto make_tx = [&]() {
+    bc = s32[12]; bm = s32[13]; carried_lsn = s64[6]; start_ord = s64[3];
     const uint32_t seg = seg_combine(bc, seg_in);
     const uint32_t last = bm > pm ? bm : pm;
     tx.in_txn = (last & 1u) != 0;
     // carried-in Begin: fetched by the wave that ran the transaction look-back; a Begin of this tile: read in place
     tx.final_lsn = !tx.in_txn ? 0 : last == bm ? carried_lsn : ld_be64(base + (((last >> 1) - 1) - b0) + kBodyOff);
     const uint64_t c = seg & 0x7FFFFFFFu;
-    tx.ord = (seg & 0x80000000u) ? c - 1 : pg.next_ord + c - 1;
+    tx.ord = (seg & 0x80000000u) ? c - 1 : start_ord + c - 1;
   };
   if (wave == 0) {
     if (seq_lb) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      make_tx(seg_unpack30((uint32_t)(ex >> 32)), (uint32_t)ex, ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0);  // look-back results are wave-uniform
+      txn_lookback(pg, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64);
+      make_tx();   // (the wave reads back what its first lane just wrote: LDS operations of a wave are ordered)
     }
     TSTAMP(10);
     if (live && too_wide) atomicOr(fail, 4u);
@@ -505,16 +505,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   TSTAMP(4);
   if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, s64[0], 0, fail); if (lane == 0) s64[4] = a; }
   if (wave == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
-  if (wave == 2 % NW && NW > 2 && !seq_lb) {
-    const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
-    if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
-  }
+  if (wave == 2 % NW && NW > 2 && !seq_lb) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
   if (NW <= 2 && wave == 0) {
     if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
-    if (!seq_lb) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], txn_carry, fail);
-      if (lane == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
-    }
+    if (!seq_lb) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
   }
   __syncthreads();
   TSTAMP(5);
@@ -523,7 +517,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   // the 64-bit values the allocator spilled to scratch)
   if (wave == 0) {
     if (!seq_lb) {
-      make_tx(s32[12], s32[13], s64[6]);
+      make_tx();
       if (live && wire_ok) txn_check_frame(pg, v, tx);
     }
     const uint64_t ev_idx = pre_ev + x_ev;
@@ -537,9 +531,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       const uint32_t lm = bm > tot_mark ? bm : tot_mark;
       const bool it = (lm & 1u) != 0;
       r->out_in_txn = it;
-      r->out_final_lsn = it ? final_lsn_of_mark(pg, lm) : 0;
+      r->out_final_lsn = it ? (lm == bm ? carried_lsn : final_lsn_of_mark(pg, lm)) : 0;
       const uint64_t c = sg & 0x7FFFFFFFu;
-      r->out_next_ord = (sg & 0x80000000u) ? c : pg.next_ord + c;
+      r->out_next_ord = (sg & 0x80000000u) ? c : start_ord + c;
+      carry_publish(r);
     }
     if (emit && (fx_off + fixed > pg.fixed_cap || hp_off + heap > pg.heap_cap || hp_off + heap > 0xFFFFFFFFull)) {
       record_error(pg, f, RK_DECODE, ETLG_E_WIRE);
@@ -712,7 +707,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
     for (uint32_t i = tid; i < per; i += NW * 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
-  if (!load_carry(pg)) return;  // ASYNC chain: the batch before this one left no state to start from
+  if (!(pg.flags & 16u) && !load_carry(pg)) return;  // ASYNC chain: the state the batch before this one left (flags bit 4: read late, by the tiles that need it — txn_lookback)
   DecParams p = pg;
   uint32_t dbg_u;
   ETLG_SCALAR_COPY(dbg_u, q.dbg);

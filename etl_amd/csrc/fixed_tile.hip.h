@@ -89,7 +89,6 @@ DEV bool tile_fixed(const DecParams& p, const DecParams& pg, const FusedParams& 
   uint32_t seg_in, pm, tot_cnt, tot_mark;
   block_scan_txn(cnt, mark, s32, seg_in, pm, tot_cnt, tot_mark);
   const uint64_t txn_agg = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark;
-  const uint64_t txn_carry = (uint64_t)(p.in_txn ? 1u : 0u);
   // ---- sizes: one event per live frame, no heap; only the fixed-arena prefix needs a scan
   uint32_t tot_fx;
   const uint32_t x_fx = block_scan1_excl(fixed >> 2, s32, tot_fx);
@@ -103,15 +102,12 @@ DEV bool tile_fixed(const DecParams& p, const DecParams& pg, const FusedParams& 
   if (BLK >= 192 && ETLG_LB_PARALLEL) {
     if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail); if (tid == 0) s64[4] = a; }
     if (wave == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail); if ((tid & 63) == 0) s64[5] = b; }
-    if (wave == 2) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
-    }
+    if (wave == 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64);
   } else if (wave == 0) {
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
     const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
-    const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-    if (tid == 0) { s64[4] = a; s64[5] = b; s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(pg, (uint32_t)ex) : 0; }
+    txn_lookback(pg, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64);
+    if (tid == 0) { s64[4] = a; s64[5] = b; }
   }
   __syncthreads();
   if (tid == 0 && s64[0]) atomicAdd(&p.res->pay_shard[tile & 31][0], (unsigned long long)s64[0]);
@@ -124,7 +120,7 @@ DEV bool tile_fixed(const DecParams& p, const DecParams& pg, const FusedParams& 
     tx.in_txn = (last & 1u) != 0;
     tx.final_lsn = !tx.in_txn ? 0 : last == bm ? s64[6] : ld_be64(base + (((last >> 1) - 1) - win0) + kBodyOff);
     const uint64_t c = seg & 0x7FFFFFFFu;
-    tx.ord = (seg & 0x80000000u) ? c - 1 : p.next_ord + c - 1;
+    tx.ord = (seg & 0x80000000u) ? c - 1 : s64[3] + c - 1;
   }
   if (live) txn_check_frame(p, v, tx);
   const uint64_t pre_ev = s64[4] >> 32, pre_hp = (uint64_t)(uint32_t)s64[4] << 2, pre_fx = s64[5] << 2;
@@ -136,9 +132,10 @@ DEV bool tile_fixed(const DecParams& p, const DecParams& pg, const FusedParams& 
     const uint32_t lm = bm > tot_mark ? bm : tot_mark;
     const bool it = (lm & 1u) != 0;
     r->out_in_txn = it;
-    r->out_final_lsn = it ? final_lsn_of_mark(pg, lm) : 0;
+    r->out_final_lsn = it ? (lm == bm ? s64[6] : final_lsn_of_mark(pg, lm)) : 0;
     const uint64_t c = sg & 0x7FFFFFFFu;
-    r->out_next_ord = (sg & 0x80000000u) ? c : p.next_ord + c;
+    r->out_next_ord = (sg & 0x80000000u) ? c : s64[3] + c;
+    carry_publish(r);
   }
   // ---- decode + write (the shared row writer; conforming INSERT waves of one table take its wave-uniform path)
   if (!live) return true;

@@ -71,7 +71,6 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
   block_scan_txn(cnt, mark, s32, seg_in, pm, tot_cnt, tot_mark);
   TSTAMP(3);
   const uint64_t txn_agg = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark;
-  const uint64_t txn_carry = (uint64_t)(p.in_txn ? 1u : 0u);  // virtual Begin before frame 0; seg identity
   TxnCtx tx{true, 0, 0};
   uint32_t bc = 0, bm = 0;
   auto make_tx = [&]() {
@@ -83,14 +82,11 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     // fetched by the wave that ran the transaction look-back) or a frame of this tile (read in place)
     tx.final_lsn = !tx.in_txn ? 0 : last == bm ? s64[6] : ld_be64(base + (((last >> 1) - 1) - win0) + kBodyOff);
     const uint64_t c = seg & 0x7FFFFFFFu;
-    tx.ord = (seg & 0x80000000u) ? c - 1 : p.next_ord + c - 1;
+    tx.ord = (seg & 0x80000000u) ? c - 1 : s64[3] + c - 1;
   };
   if (q.seq_lookback) {
     // ownership depends on the transaction's final_lsn (a table is SyncDone): transaction state first
-    if (wave == 0) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
-    }
+    if (wave == 0) txn_lookback(p, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64);
     __syncthreads();
     make_tx();
   }
@@ -122,18 +118,12 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
   if (BLK >= 192 && ETLG_LB_PARALLEL) {
     if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail); if (tid == 0) s64[4] = a; }
     if (wave == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail); if ((tid & 63) == 0) s64[5] = b; }
-    if (wave == 2 && !q.seq_lookback) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if ((tid & 63) == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
-    }
+    if (wave == 2 && !q.seq_lookback) txn_lookback(p, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64);
   } else if (wave == 0) {
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg_a, 0, fail);
     const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, agg_b, 0, fail);
     if (tid == 0) { s64[4] = a; s64[5] = b; }
-    if (!q.seq_lookback) {
-      const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, txn_agg, txn_carry, fail);
-      if (tid == 0) { s32[12] = seg_unpack30((uint32_t)(ex >> 32)); s32[13] = (uint32_t)ex; s64[6] = ((uint32_t)ex & 1u) ? final_lsn_of_mark(p, (uint32_t)ex) : 0; }
-    }
+    if (!q.seq_lookback) txn_lookback(p, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64);
   }
   __syncthreads();
   if (tid < 3 && s64[tid]) atomicAdd(&p.res->pay_shard[tile & 31][tid], (unsigned long long)s64[tid]);
@@ -151,9 +141,10 @@ DEV void tile_body(const DecParams& p, const DecParams& pg, const FusedParams& q
     const uint32_t lm = bm > tot_mark ? bm : tot_mark;
     const bool it = (lm & 1u) != 0;
     r->out_in_txn = it;
-    r->out_final_lsn = it ? final_lsn_of_mark(p, lm) : 0;
+    r->out_final_lsn = it ? (lm == bm ? s64[6] : final_lsn_of_mark(p, lm)) : 0;
     const uint64_t c = sg & 0x7FFFFFFFu;
-    r->out_next_ord = (sg & 0x80000000u) ? c : p.next_ord + c;
+    r->out_next_ord = (sg & 0x80000000u) ? c : s64[3] + c;
+    carry_publish(r);
   }
   // ---- phase 3: decode + write
   if (!emit) return;
@@ -178,7 +169,7 @@ __global__ __launch_bounds__(BLK, ETLG_MINWAVES) void k_fused(DecParams pg, Fuse
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
     for (uint32_t i = tid; i < per; i += BLK) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
-  if (!load_carry(pg)) return;  // ASYNC chain: the batch before this one left no state to start from
+  if (!(pg.flags & 16u) && !load_carry(pg)) return;  // ASYNC chain: the state the batch before this one left (flags bit 4: read late, by the tiles that need it — txn_lookback)
   DecParams p = pg;  // side-table pointers of `p` are redirected to the LDS copy below
   if ((q.dbg & 8) && tid == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;  // per-tile payload accumulators

@@ -1496,10 +1496,10 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
 
   HIPCHK(c, c->d_res.ensure(sizeof(DevResult) * etlg_ctx::kResRing));
   const uint32_t res_slot = c->res_seq % etlg_ctx::kResRing;
-  // ---- two streams. A batch of the fixed-width plan whose predecessor in the chain is one too, and still in flight, is enqueued
-  //      on the OTHER decode stream and told (flags bit 4) that the state it starts from arrives late: its kernel does not read
-  //      the predecessor's result block at its start; the few tiles without a Begin / Commit before them in the batch poll for it
-  //      (plan.hip, plan_late_carry). So the tail of batch k — its last waves, the write-back of its dirty lines, the dispatch of
+  // ---- two streams. A batch whose first attempt is a single-pass kernel (k_plan, k_fused, k_cells) and whose predecessor in the
+  //      chain is one too, and still in flight, is enqueued on the OTHER decode stream and told (flags bit 4) that the state it
+  //      starts from arrives late: its kernel does not read the predecessor's result block at its start; the few tiles without a
+  //      Begin before them in the batch poll for it (plan.hip plan_late_carry, lookback.hip.h txn_lookback). So the tail of batch k — its last waves, the write-back of its dirty lines, the dispatch of
   //      the next kernel — overlaps the staging and parsing of batch k+1: 63.9 -> 50.1 us per 64 MiB cfg2 batch measured with two
   //      independent chains (profiles/r03_plan_development.json). Ordering kept: k+1 starts after k-1 has completed (look-back
   //      buffers rotate with distance two; k's waves are all dispatched by then, so a tile of k+1 that polls cannot hold a slot k
@@ -1508,16 +1508,14 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   struct StreamSwitch { etlg_ctx* c; hipStream_t saved; ~StreamSwitch() { c->stream = saved; } } sw{c, c->stream};
   bool beside = false;
   const bool first_try_single = p.nframes && !c->force_multipass && len < (1ull << 31) && (no_ctrl || !c->last_had_ctrl);
-  if (async && prev && prev->pending && prev->level == 0 && !prev->force_rerun && c->overlap_mode && first_try_single && c->res_seq != 0 && res_slot >= 2 &&
+  if (async && prev && prev->pending && prev->level <= 1 && prev->used_fused && !prev->force_rerun && c->overlap_mode && first_try_single && c->res_seq != 0 && res_slot >= 2 &&
       c->side_valid && !c->side_dirty && !c->slots_dirty && c->last_epochs.empty() && !b->copy.active && !c->prof_serial) {
     p.flags |= 1u;
     const std::vector<EpochRec> no_eps;
     { const int32_t rc = build_side_inputs(c, b, no_eps); if (rc != ETLG_OK) return rc; }   // the unchanged-inputs path: no stream work
     { const int32_t rc = setup_outputs(c, b); if (rc != ETLG_OK) return rc; }
-    const size_t ntl = ((size_t)nf + 63) / 64;
-    const bool pw = plan_wanted(c, b);
-    b->plan_decided = pw ? 1 : 0;
-    beside = pw && (2 * (ntl + (ntl + 63) / 64) * 8 + 64) <= c->desc_half;   // (a descriptor buffer that has to grow synchronises both streams)
+    b->plan_decided = plan_wanted(c, b) ? 1 : 0;
+    beside = true;   // (a look-back buffer that has to grow synchronises both streams: take_descriptors)
   }
   if (beside) {
     if (!c->stream2) {

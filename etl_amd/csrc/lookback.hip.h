@@ -165,6 +165,41 @@ DEV uint64_t final_lsn_of_mark(const DecParams& p, uint32_t mark) {
   return mark == 1u ? p.final_lsn : ld_be64(p.in + ((mark >> 1) - 1) + kBodyOff);
 }
 
+// The transaction look-back of the generic kernels (k_fused, k_cells), one wave. The state carried into the batch is NOT part of
+// the fold (virtual group -1 holds the identity): it is patched in afterwards, and only a tile whose prefix needs it — no Begin /
+// Commit before the tile in this batch, or no Begin (ordinals then continue the carried count) — reads it. With DecParams.flags
+// bit 4 the batch before this one may still be running on the other decode stream: such a tile then waits for that batch's last
+// tile to have written its totals (carry_ready); every other tile of the batch never looks at the predecessor at all. Results
+// for the workgroup, written by the wave's first lane: s32[12] segment count, s32[13] mark, s64[6] final_lsn of the Begin the
+// mark names (0 when it names none), s64[3] the ordinal the batch starts from.
+DEV void txn_lookback(const DecParams& pg, unsigned long long* d_txn, uint32_t ntiles, uint32_t tile, uint64_t txn_agg, uint32_t* fail,
+                      uint32_t* s32, uint64_t* s64) {
+  const uint64_t ex = lookback<OpTxn>(d_txn, d_txn + ntiles, tile, txn_agg, 0ull, fail);
+  const uint32_t seg = seg_unpack30((uint32_t)(ex >> 32));
+  uint32_t mark = (uint32_t)ex;
+  uint32_t in_txn = pg.in_txn;
+  uint64_t final_lsn = pg.final_lsn, next_ord = pg.next_ord;
+  if ((pg.flags & 16u) && pg.carry && (mark == 0u || !(seg & 0x80000000u))) {   // wave-uniform
+    for (uint32_t polls = 0;; polls++) {
+      if (__hip_atomic_load(&pg.carry->carry_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (polls > (1u << 15)) { if ((threadIdx.x & 63) == 0) atomicOr(fail, 1u); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    in_txn = __hip_atomic_load(&pg.carry->out_in_txn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    final_lsn = __hip_atomic_load(&pg.carry->out_final_lsn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    next_ord = __hip_atomic_load(&pg.carry->out_next_ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (mark == 0u && in_txn) mark = 1u;   // virtual Begin before frame 0
+  if ((threadIdx.x & 63) == 0) {
+    s32[12] = seg; s32[13] = mark;
+    s64[6] = (mark & 1u) ? (mark == 1u ? final_lsn : ld_be64(pg.in + ((mark >> 1) - 1) + kBodyOff)) : 0ull;
+    s64[3] = next_ord;
+  }
+  ETLG_WAVE_JOIN();   // (the wave may read these back at once: its LDS operations are ordered)
+}
+// the last tile of a single-pass kernel has written the batch's totals: the batch behind it may be waiting for them
+DEV void carry_publish(DevResult* r) { __hip_atomic_store(&r->carry_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Variant kernel head (k_fused, k_cells): the four side tables are read as ONE concatenation, up to four dwords per lane held in
 // registers (`side_load`), and stored to LDS only after the tile's staging loads have been issued (`side_store`), so the whole
 // copy costs one global round trip that overlaps the span loads instead of one round trip per table before anything else starts.

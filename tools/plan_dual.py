@@ -13,10 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from etl_amd import abi, synth
 from etl_amd.decoder import Decoder
 
-variants = sys.argv[1:] or ["plan2:ETLG_PLAN_DBG=1024", "plan3:"]
-KNOBS = ("ETLG_PLAN_DBG", "ETLG_PLAN_NT", "ETLG_PLAN_MARGIN")
+variants = [a for a in sys.argv[1:] if not a.startswith("wl=")] or ["default:"]
+WL = ([a[3:] for a in sys.argv[1:] if a.startswith("wl=")] or ["cfg2"])[0]
+MK = {"cfg2": synth.cfg2, "cfg3": synth.cfg3}[WL]
+KNOBS = ("ETLG_PLAN_DBG", "ETLG_OVERLAP", "ETLG_PLAN_MARGIN")
 NCTX = 3
-ws = [synth.cfg2(seed=0xE710002 + 97 * k) for k in range(NCTX)]
+ws = [MK(seed=0xE710002 + 97 * k) for k in range(NCTX)]
 pools = []
 for w in ws:
     pool = []
@@ -63,7 +65,7 @@ for v in variants:
                 nb += run(6)
             dt = time.perf_counter() - t0
             best = max(best, nb / dt / 1e9)
-        row = {"variant": name, "contexts": nctx, "GBps": round(best, 1), "us_per_batch": round((64 << 20) / best / 1e3, 1), "paths": decs[0].debug_paths()}
+        row = {"workload": WL, "variant": name, "contexts": nctx, "GBps": round(best, 1), "us_per_batch": round((64 << 20) / best / 1e3, 1), "paths": decs[0].debug_paths()}
         print(json.dumps(row), flush=True)
         rows.append(row)
         for d in decs:
