@@ -25,6 +25,7 @@
 // multi-pass kernels (kernels.hip).
 #define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
 #define ETLG_DBG_WORD dbg_u   // cells_tile / k_cells keep the debug word in a scalar register of its own
+#define ETLG_TSTAMP_WHO (wave == 0 && lane == 0)   // phase clocks are taken by the tile's spine wave (its role rotates, see cells_tile)
 #include "lookback.hip.h"
 #include "utf8_swar.h"
 
@@ -182,11 +183,15 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   uint32_t* const s32 = sh.s32; uint64_t* const s64 = sh.s64;
   uint8_t (*const vlist)[32] = sh.vlist;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const int wave = tid >> 6;
+  // `wave` is a ROLE, not a position: role 0 is the tile's spine (P1, P2b, a look-back, P4 — about twice the instructions of
+  // the other roles). The dispatcher places wave w of every 256-thread workgroup on SIMD w of its CU
+  // (tools/ubench/simd_place.hip), so with role = position the spine waves of all four resident tiles shared SIMD 0 while
+  // the other three SIMDs idled through the single-wave phases. The role rotates with the tile index instead.
   // The launch parameters the phases keep asking for, each in a scalar register of its own: as members of q they sit in an
   // eight-register tuple that is spilled, and every use reloaded all eight (v_readlane x 8, ~250 of them in P3 alone).
   uint32_t maxc, dbg_u, seq_lb;
   ETLG_SCALAR_COPY(maxc, q.maxc); ETLG_SCALAR_COPY(dbg_u, q.dbg); ETLG_SCALAR_COPY(seq_lb, q.seq_lookback);
+  const int wave = (int)(((tid >> 6) + ((dbg_u & 0x10000u) ? 0u : tile)) & (uint32_t)(NW - 1));
   const uint32_t VC = 2 * maxc;
   const uint32_t f0 = tile * CF;
   constexpr bool use_lds = STAGED;
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   DecParams p = pg;
   uint32_t dbg_u;
   ETLG_SCALAR_COPY(dbg_u, q.dbg);
-  if ((dbg_u & 8) && tid == 0) s64[7] = clock64();
+  if ((dbg_u & 8) && ((tid >> 6) + ((dbg_u & 0x10000u) ? 0u : blockIdx.x)) % NW == 0 && (tid & 63) == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;
   if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
   // ---- P0: side tables, offsets, staging
@@ -724,6 +729,8 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   u8* stage = (u8*)(ct + VC * CF);
   const uint32_t table_bytes = VC * CF * 4;
   const uint32_t tile = blockIdx.x;
+  const uint32_t lane = tid & 63;
+  const int wave = (int)(((tid >> 6) + ((dbg_u & 0x10000u) ? 0u : tile)) & (uint32_t)(NW - 1));   // role of this wave in the tile (cells_tile)
   const uint32_t f0 = tile * CF;
   uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
   // the tile's byte span from two scalar loads: staging starts while the per-frame offsets are in flight

@@ -427,14 +427,18 @@ DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
 }
 
 template <class S>
-DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or column << 8 | code of the first cell that cannot be encoded
+DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or column << 8 | code of the cell that fails the row
+  // The reference converts every cell of every pending row first (cell_to_clickhouse_value, clickhouse/core.rs:1193-1203: Date32
+  // range errors) and only then encodes the rows (NULL in a non-nullable column): a range error anywhere beats a NULL error. So a
+  // row that meets a cell without an encoding goes on looking for a date out of range; k_rb_lens ranks range errors first across rows.
   const uint64_t base = j.row_base[r];
+  uint32_t err0 = 0;
   for (uint32_t i = 0; i < j.n_cols; i++) {
     const uint32_t cd = j.cols[i], cls = cd & 0xFF, off = cd >> 16;
     const bool nullable = (cd >> 8) & 1;
     const uint32_t st = (j.fixed[base + i / 4] >> (2 * (i % 4))) & 3u;
     if (st == ETLG_CELL_NULL) {
-      if (!nullable) return (i << 8) | RB_E_NULL;   // "NULL value for non-nullable ClickHouse column" (:217-225)
+      if (!nullable) { if (!err0) err0 = (i << 8) | RB_E_NULL; continue; }   // "NULL value for non-nullable ClickHouse column" (:217-225)
       s.put(1);
       continue;
     }
@@ -443,12 +447,12 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
       // Array(Nullable(T)) (:249-254): varint count, then every element with its null marker. The literal (kept as text in the
       // arena) is walked twice: count, then encode. A literal the device cannot take apart is the host's (it raises the exact error).
       const uint32_t elem = (cd >> 9) & 0x7Fu;
-      if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA || elem == ETLG_TC_NUMERIC || elem == ETLG_TC_JSON || elem == ETLG_TC_TIMETZ) return (i << 8) | RB_E_HOST_CELL;
+      if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA || elem == ETLG_TC_NUMERIC || elem == ETLG_TC_JSON || elem == ETLG_TC_TIMETZ) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
       const u8* txt = j.heap + ld32a(slot);
       const uint32_t tn = ld32a(slot + 4);
       uint32_t cnt = 0;
       auto none = [](uint32_t) -> u8* { return nullptr; };
-      if (arr_walk<false>(txt, tn, elem, cnt, [](uint32_t, bool, const uint32_t*) {}, none)) return (i << 8) | RB_E_HOST_CELL;
+      if (arr_walk<false>(txt, tn, elem, cnt, [](uint32_t, bool, const uint32_t*) {}, none)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
       if (nullable) s.put(0);
       rb_varint(s, cnt);
       uint32_t ee = 0;
@@ -458,13 +462,18 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
         const uint32_t e1 = rb_scalar(s, elem, (const u8*)w, nullptr);
         if (e1 && !ee) ee = e1;
       }, none);
-      if (ee) return (i << 8) | ee;
+      if (ee == RB_E_DATE_RANGE) return (i << 8) | ee;
+      if (ee && !err0) err0 = (i << 8) | ee;
       continue;
     }
-    if (st != ETLG_CELL_VALUE) return (i << 8) | RB_E_HOST_CELL;
+    if (st != ETLG_CELL_VALUE) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
     if (nullable) s.put(0);
-    if (const uint32_t e = rb_scalar(s, cls, slot, j.heap)) return (i << 8) | e;
+    if (const uint32_t e = rb_scalar(s, cls, slot, j.heap)) {
+      if (e == RB_E_DATE_RANGE) return (i << 8) | e;
+      if (!err0) err0 = (i << 8) | e;
+    }
   }
+  if (err0) return err0;
   // trailing CDC columns (core.rs:96-114); never NULL, a Nullable() destination column still takes its marker byte
   const uint64_t ev = j.row_event[r];
   const uint32_t kind = j.ev_kind[ev];
@@ -569,7 +578,8 @@ __global__ __launch_bounds__(256) void k_rb_lens(RbJob j) {
   if (r >= j.n_rows) return;
   RbCount c;
   const uint32_t e = j.format ? pb_row(j, r, c) : rb_row(j, r, c);
-  if (e) { atomicMin(j.err, (unsigned long long)((r << 24) | e)); c.n = 0; }
+  // first failing row in event order, rows with a date out of range before all others (bit 62 clear)
+  if (e) { atomicMin(j.err, (((e & 0xFFu) == RB_E_DATE_RANGE || j.format) ? 0ull : 1ull << 62) | (unsigned long long)((r << 24) | e)); c.n = 0; }
   j.lens[r] = c.n;
 }
 

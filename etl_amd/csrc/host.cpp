@@ -169,6 +169,7 @@ using SchemaPtr = std::shared_ptr<const StoredSchema>;
 struct SlotHost {  // one ReplicatedTableSchema instance
   etlg_slot_desc desc;
   std::vector<etlg_slot_col> cols;
+  int identity_type = 0;   // ReplicatedTableSchema::infer_identity_type (schema.rs:686-721): 0 Missing, 1 PrimaryKey, 2 Full, 3 AlternativeKey
 };
 
 struct CacheEntry { uint32_t kind; uint64_t snapshot; int32_t slot; };  // kind: 1 waiting, 2 ready
@@ -402,6 +403,16 @@ int32_t make_slot(etlg_ctx* c, const SchemaPtr& sch, const std::vector<uint8_t>&
     sc.identity = ident[i] == 1;
     sc.key_index = sc.identity ? (uint16_t)nid++ : (uint16_t)0xFFFF;
     s->cols.push_back(sc);
+  }
+  {  // identity type over the stored columns, as the reference infers it from the two masks
+    bool has = false, m_pk = true, m_full = true;
+    for (size_t i = 0; i < sch->cols.size(); i++) {
+      const bool r = repl[i] == 1, id = ident[i] == 1;
+      has |= id;
+      if (id != (r && sch->cols[i].pk)) m_pk = false;
+      if (id != r) m_full = false;
+    }
+    s->identity_type = !has ? 0 : m_pk ? 1 : m_full ? 2 : 3;
   }
   const uint32_t n = (uint32_t)s->cols.size();
   etlg_slot_desc& d = s->desc;
@@ -1327,6 +1338,9 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
   { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c || !out || !row_offsets) return ETLG_InvalidArgument;
   *out = nullptr;
+  // ASYNC batches still in flight finish first: finish_batch writes the stream state they leave into the context, and the
+  // rows below decode inside a virtual transaction that must neither see that state nor be overwritten by it
+  { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; }
   clear_error(c);
   if (schema_slot < 0 || (size_t)schema_slot >= c->slots.size()) return lib_error(c, ETLG_InvalidArgument, "unknown schema slot");
   const SlotHost& sh = *c->slots[(size_t)schema_slot];
@@ -1719,7 +1733,7 @@ ColPlan col_plan(uint32_t cls) {
 int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t row_kinds, uint32_t flags, etlg_columns** out) {
   if (!c || !b || !out || b->ctx != c) return ETLG_InvalidArgument;
   *out = nullptr;
-  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
+  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); if (rc != ETLG_OK) return rc; }   // an ASYNC batch that ended in a decode error: the caller gets that error (fail-fast, as the reference), not a hand-off of the prefix
   if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_columns needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
   if (slot < 0 || (size_t)slot >= c->slots.size() || !(row_kinds & 3u)) return ETLG_InvalidArgument;
   const bool parse_arrays = (row_kinds & ETLG_ROWS_PARSE_ARRAYS) != 0;
@@ -1914,7 +1928,7 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
 
 int32_t etlg_batch_size_hints(etlg_ctx* c, etlg_batch* b, const etlg_size_model* m, uint32_t flags, uint64_t* out) {
   if (!c || !b || !m || b->ctx != c) return ETLG_InvalidArgument;
-  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
+  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); if (rc != ETLG_OK) return rc; }   // an ASYNC batch that ended in a decode error: the caller gets that error (fail-fast, as the reference), not a hand-off of the prefix
   if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_size_hints needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
   const etlg_batch_view& bv = b->v;
   const uint64_t ne = bv.n_events;
@@ -1984,7 +1998,7 @@ int32_t etlg_batch_protobuf(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t f
 static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint8_t* nullable_flags, uint32_t n_flags, int32_t engine,
                             uint32_t flags, uint32_t format, etlg_rowbinary** out) {
   *out = nullptr;
-  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); (void)rc; }
+  if (b->pending) { const int32_t rc = etlg_batch_sync(c, b); if (rc != ETLG_OK) return rc; }   // an ASYNC batch that ended in a decode error: the caller gets that error (fail-fast, as the reference), not a hand-off of the prefix
   if (!b->v.on_device || !b->dev) return lib_error(c, ETLG_InvalidState, "etlg_batch_rowbinary needs a device-resident batch (ETLG_F_OUTPUT_ON_DEVICE, not downloaded)");
   if (slot < 0 || (size_t)slot >= c->slots.size() || (engine != ETLG_CH_MERGE_TREE && engine != ETLG_CH_REPLACING_MERGE_TREE)) return ETLG_InvalidArgument;
   const SlotHost& sh = *c->slots[(size_t)slot];
@@ -2035,7 +2049,12 @@ static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint
   if (ne) {
     ColSel q{};
     q.ev_kind = bv.ev_kind; q.ev_flags = bv.ev_flags; q.ev_slot = bv.ev_schema_slot; q.ev_body = bv.ev_body_off;
-    q.n_events = ne; q.slot = (uint32_t)slot; q.kinds = format ? 1u : 7u; q.host_rows = (unsigned long long*)(S + o_cnt);
+    // ReplacingMergeTree keys its dedup on the source primary key: the reference refuses Update events of a table whose replica
+    // identity is neither PrimaryKey nor Full (clickhouse_update_row -> ensure_clickhouse_key_identity_is_primary_key,
+    // clickhouse/core.rs:1359-1427). Such Updates are not encoded here: they are left to the host (n_host_rows), which raises
+    // the reference's SourceReplicaIdentityError when it meets the first of them.
+    const bool upd_ok = format != 0 || engine != ETLG_CH_REPLACING_MERGE_TREE || sh.identity_type == 1 || sh.identity_type == 2;
+    q.n_events = ne; q.slot = (uint32_t)slot; q.kinds = format ? 1u : (upd_ok ? 7u : 5u); q.host_rows = (unsigned long long*)(S + o_cnt);
     q.row_full = sh.desc.row_bytes_full; q.row_key = sh.desc.row_bytes_key;
     q.blk = (uint32_t*)S; q.nblocks = nblk; q.row_event = (uint64_t*)A; q.row_base = (uint64_t*)(S + o_base);
     etlg_k_col_select(&q, s);
@@ -2064,7 +2083,7 @@ static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint
   if (cnt[1] != ~0ull) {  // the first row (event order) with a cell that has no encoding
     const uint32_t code = (uint32_t)(cnt[1] & 0xFF), col = (uint32_t)((cnt[1] >> 8) & 0xFFFF);
     uint64_t ev = 0;
-    HIPCHK(c, hipMemcpy(&ev, A + (cnt[1] >> 24) * 8, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&ev, A + ((cnt[1] & ~(1ull << 62)) >> 24) * 8, 8, hipMemcpyDeviceToHost));   // (bit 62: not a date-range error, k_rb_lens)
     if (code == 3) {
       rb->v.status = ETLG_RB_NEEDS_HOST; rb->v.host_event = ev; rb->v.host_column = col;
       blk_give(c, c->gen, rb->m.d_a, rb->m.cap_a, false); rb->m.d_a = nullptr;

@@ -154,7 +154,10 @@ DEV uint64_t lookback_resolve(unsigned long long* desc, unsigned long long* gdes
 #ifndef ETLG_DBG_WORD
 #define ETLG_DBG_WORD q.dbg
 #endif
-#define TSTAMP(k) do { if ((ETLG_DBG_WORD & 8) && threadIdx.x == 0 && (blockIdx.x & 15) == 3) { const unsigned long long _t = clock64(); atomicAdd(&p.res->dbg_t[k], _t - s64[7]); s64[7] = _t; } } while (0)
+#ifndef ETLG_TSTAMP_WHO
+#define ETLG_TSTAMP_WHO (threadIdx.x == 0)
+#endif
+#define TSTAMP(k) do { if ((ETLG_DBG_WORD & 8) && ETLG_TSTAMP_WHO && (blockIdx.x & 15) == 3) { const unsigned long long _t = clock64(); atomicAdd(&p.res->dbg_t[k], _t - s64[7]); s64[7] = _t; } } while (0)
 
 DEV uint32_t seg_pack30(uint32_t seg) { return ((seg >> 31) << 29) | (seg & 0x1FFFFFFFu); }
 DEV uint32_t seg_unpack30(uint32_t s30) { return ((s30 >> 29) << 31) | (s30 & 0x1FFFFFFFu); }

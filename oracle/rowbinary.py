@@ -169,19 +169,40 @@ def cdc_columns(op, commit_lsn, tx_ordinal, engine):
     return struct.pack("<QQ", tx_ordinal, commit_lsn) + bytes([1 if op == "D" else 0])   # u128 LE: low half first
 
 
-def encode_events(events, slot_index, types_by_col, nullable_flags, engine):
+def encode_events(events, slot_index, types_by_col, nullable_flags, engine, identity_type="PrimaryKey"):
     """Rows of the events the device emitter takes (Insert; non-partial Update -> new row; Delete with a full old row).
     `types_by_col`: type classes (only their count is used here: text-form classes raise NeedsHost from value()).
+    `identity_type`: ReplicatedTableSchema::identity_type of the slot; under ReplacingMergeTree the reference refuses Update
+    events unless it is PrimaryKey or Full (clickhouse_update_row, clickhouse/core.rs:1359-1382) — the emitter leaves those
+    Updates to the host, which raises that error.
     Returns (list of row bytes, list of event indices, n events of the slot left to the host)."""
+    updates_ok = engine == MERGE_TREE or identity_type in ("PrimaryKey", "Full")
     n_user = len(types_by_col)
     rows, idx, host = [], [], 0
+    # the sink converts every cell of every pending row first (cell_to_clickhouse_value, core.rs:1193-1203: Date32 range errors)
+    # and encodes afterwards (NULL in a non-nullable column, client.rs): a date out of range anywhere comes first
+    for e in events:
+        if e["kind"] not in "IUD" or e.get("schema_slot") != slot_index:
+            continue
+        if e["kind"] == "U" and (e["partial"] or not updates_ok) or e["kind"] == "D" and e["old_kind"] != "Full":
+            continue
+        for c in (e["old_row"] if e["kind"] == "D" else e["row"]):
+            try:
+                if c[0] == "Date":
+                    value(c)
+                elif c[0] == "Deferred" and c[1] in ARRAY_OIDS:
+                    for el in array_elements(c[1], c[2]):
+                        if el[0] == "Date":
+                            value(el)
+            except NeedsHost:
+                pass
     for i, e in enumerate(events):
         if e["kind"] not in "IUD" or e.get("schema_slot") != slot_index:
             continue
         if e["kind"] == "I":
             cells = e["row"]
         elif e["kind"] == "U":
-            if e["partial"]:
+            if e["partial"] or not updates_ok:
                 host += 1
                 continue
             cells = e["row"]

@@ -264,3 +264,44 @@ def test_async_chain_full_size_two_streams():
     assert paths["plan"] == n and paths["chain_rerun"] == 0 and paths["plan_redone"] == 0, paths
     assert d.debug_overlapped() >= n - 6, d.debug_overlapped()
     d.close()
+
+
+def test_copy_decode_behind_batches_in_flight():
+    """etlg_copy_decode with ASYNC stream batches still pending on the context: they are finished first (their carried
+    transaction state reaches the context), the copy rows decode inside their own virtual transaction, and the stream goes on
+    afterwards from the state the pending batches left — all three against the oracle."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.cfg2()
+    buf, offs = w.fill(1 << 20)
+    pieces = _cut(buf, offs, 5, seed=41)          # transactions span the cuts
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    cols = [("id", 20, False, 1), ("t", 25, True, 0)]
+    for t in (o, d):
+        t.schema_put(4242, 0, cols)
+    so, sd = o.table_ready(4242, 0, [1, 1], [1, 0]), d.table_ready(4242, 0, [1, 1], [1, 0])
+    rows = [b"%d\trow %d\n" % (i, i) for i in range(300)]
+    rbuf = np.frombuffer(b"".join(rows), dtype=np.uint8)
+    roffs = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint32)
+    dev = DevBufs(pieces)
+    inflight = [d.decode_device(p, n, po, nf, FLAGS) for (p, n, po, nf) in dev.items[:3]]   # nothing synced
+    want = [o.decode(*pieces[k]) for k in range(3)]
+    gc, rc = d.copy_decode(sd, rbuf, roffs), o.copy_decode(so, rbuf, roffs)
+    assert gc.rc == 0 and rc.err_code == 0
+    assert not rc.host_batch().diff(gc.host())
+    for k, b in enumerate(inflight):
+        assert b.sync() == 0
+        diff = want[k].host_batch().diff(b.host())
+        assert not diff, f"batch {k}: {diff[:6]}"
+        b.close()
+    for k in (3, 4):                               # the stream continues from the state batch 2 left
+        p, n, po, nf = dev.items[k]
+        b = d.decode_device(p, n, po, nf, FLAGS)
+        rb = o.decode(*pieces[k])
+        assert b.sync() == 0 and rb.err_code == 0
+        diff = rb.host_batch().diff(b.host())
+        assert not diff, f"batch {k}: {diff[:6]}"
+        b.close()
+    d.close()

@@ -34,10 +34,10 @@ def _stream(msgs):
     return np.frombuffer(s.bytes(), dtype=np.uint8), s.offsets
 
 
-def _check(hb, b, flags, engine):
+def _check(hb, b, flags, engine, identity_type="PrimaryKey"):
     from oracle import rowbinary as RB
     slot = hb.slots[0]
-    rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in slot.cols], list(flags), engine)
+    rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in slot.cols], list(flags), engine, identity_type)
     r = b.rowbinary(0, flags, engine)
     assert r.status == abi.RB_OK
     assert r.n_rows == len(rows) and int(r.view.n_host_rows) == host
@@ -177,3 +177,53 @@ def test_arrays_of_fixed_width_elements():
     r = b.rowbinary(0, [0, 1, 0, 0])
     assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == 1
     r.close(); b.close(); d.close()
+
+
+def test_replacing_merge_tree_leaves_updates_of_other_identities_to_the_host():
+    """REPLICA IDENTITY USING INDEX on a non-PK column (AlternativeKey): clickhouse_update_row refuses Update events under
+    ReplacingMergeTree (clickhouse/core.rs:1359-1427, 'ClickHouse requires primary-key or full replica identity'), so the device
+    does not encode them there — they are counted as host rows; MergeTree takes them; REPLICA IDENTITY FULL is accepted by both."""
+    from etl_amd.schema import infer_identity_type
+    cols = [("id", SC.INT8, False, 1), ("k", SC.INT4, False, 0), ("s", 25, True, 0)]
+    msgs = []
+    for i in range(100):
+        r = [str(i), str(i * 2), "t%d" % i]
+        msgs.append(W.insert(42, r))
+        if i % 3 == 0:
+            msgs.append(W.update(42, [str(i), str(i * 2), "u"]))
+    buf, offs = _stream(msgs)
+    for ident, want in (([0, 1, 0], "AlternativeKey"), ([1, 1, 1], "Full"), ([1, 0, 0], "PrimaryKey")):
+        assert infer_identity_type(cols, [1, 1, 1], ident) == want
+        hb, b, d = _both(SC.simple_table(cols, ident=ident), buf, offs)
+        n_mt = _check(hb, b, [0, 0, 1, 0, 0], abi.CH_MERGE_TREE, want)
+        n_rmt = _check(hb, b, [0, 0, 1, 0, 0], abi.CH_REPLACING_MERGE_TREE, want)
+        assert n_mt == 134 and n_rmt == (100 if want == "AlternativeKey" else 134)
+        b.close(); d.close()
+
+
+def test_date_range_error_comes_before_a_null_error():
+    """cell_to_clickhouse_value runs over every pending row before any row is encoded (clickhouse/core.rs:1193-1203), so a date
+    outside Date32's range in a LATER row is reported instead of a NULL in a non-nullable column of an earlier one; inside one
+    row a range error behind a NULL cell wins too."""
+    from etl_amd.decoder import EtlError
+    from oracle import rowbinary as RB
+    cols = [("id", SC.INT8, False, 1), ("v", SC.INT4, True, 0), ("d", 1082, True, 0)]
+    buf, offs = _stream([W.insert(42, ["1", "5", "2000-01-01"]), W.insert(42, ["2", W.NULL, "2000-01-01"]),
+                         W.insert(42, ["3", "7", "2000-01-02"]), W.insert(42, ["4", W.NULL, "1899-12-31"])])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    with pytest.raises(RB.ConversionError) as oi:
+        RB.encode_events(hb.materialize(), 0, [c.type_class for c in hb.slots[0].cols], [0, 0, 1, 0, 0], abi.CH_MERGE_TREE)
+    assert str(oi.value) == "Date out of ClickHouse Date32 range"
+    with pytest.raises(EtlError) as ei:
+        b.rowbinary(0, [0, 0, 1, 0, 0])
+    assert ei.value.description == "Date out of ClickHouse Date32 range" and ei.value.frame_index == 4
+    with pytest.raises(EtlError) as ei:      # without the bad date the NULL error is the first row's that has one
+        b.rowbinary(0, [0, 0, 0, 0, 0])
+    assert ei.value.description == "Date out of ClickHouse Date32 range"
+    b.close(); d.close()
+    buf, offs = _stream([W.insert(42, ["1", W.NULL, "2000-01-01"]), W.insert(42, ["2", W.NULL, "2000-01-01"])])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    with pytest.raises(EtlError) as ei:
+        b.rowbinary(0, [0, 0, 1, 0, 0])
+    assert ei.value.description == "NULL value for non-nullable ClickHouse column" and ei.value.frame_index == 1
+    b.close(); d.close()
