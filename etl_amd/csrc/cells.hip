@@ -674,7 +674,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     pg.ev_kind[ev_idx] = (u8)tag;
     pg.ev_flags[ev_idx] = (u8)flags;
     pg.ev_table[ev_idx] = rel_id;
-    pg.ev_slot[ev_idx] = (uint32_t)row_slot;
+    pg.ev_slot[ev_idx] = s.host_id;
     pg.ev_start[ev_idx] = ld_be64(v.fr + 6);
     pg.ev_commit[ev_idx] = tx.final_lsn;
     pg.ev_ord[ev_idx] = tx.ord;

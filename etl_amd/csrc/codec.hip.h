@@ -154,6 +154,9 @@ DEV bool load_carry(DecParams& p) {
   return ok;
 }
 
+// device slot index -> the slot id the arenas name (DevSlot.host_id); negative values (lookup failures) pass through
+DEV uint32_t slot_host_id(const DecParams& p, int sl) { return sl >= 0 ? p.slots[sl].host_id : (uint32_t)sl; }
+
 // ------------------------------------------------------------- wave scans
 // Inclusive scan over the 64 lanes of a wave with DPP (row_shr 1/2/4/8 inside each row of 16, then
 // row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU instructions, no LDS
@@ -1274,7 +1277,7 @@ DEV uint32_t write_full_row_uniform(const DecParams& pg, uint32_t slot_u, const 
   // halfword fields of a plain global struct they compiled to global_load_ubyte / _ushort + s_waitcnt vmcnt(0) +
   // v_readfirstlane — one dependent vector-memory round trip per column (gfx950 has no sub-dword scalar loads).
   const ETLG_CONST_AS uint32_t* sw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.slots + slot_u);
-  static_assert(sizeof(DevSlot) == 40 && sizeof(DevCol) == 12, "descriptor words below");
+  static_assert(sizeof(DevSlot) == 44 && sizeof(DevCol) == 12, "descriptor words below");
   if (n != sw[0]) return ETLG_E_TUPLE_WIDTH;                      // DevSlot.n_cols
   const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + sw[6]);  // DevSlot.cols_base
   struct { uint32_t cls, nullable, off_full; } col;
@@ -1454,7 +1457,7 @@ DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, c
     case 'R': {
       table = ld_be32(b);
       const DevEpoch* ep = epoch_at(p, find_table(p, table), f);
-      slot_id = ep ? (uint32_t)ep->slot : 0;
+      slot_id = ep ? slot_host_id(p, ep->slot) : 0;
       break;
     }
     case 'T': {  // parse_event_from_truncate_message, codec/event.rs:533-547
@@ -1466,7 +1469,7 @@ DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, c
         const int ti = find_table(p, rel);
         if (!should_apply(p, ti, rel, tx.final_lsn)) continue;
         const int sl = cache_slot_before(p, ti, f);
-        ((uint32_t*)body)[2 * k] = rel; ((uint32_t*)body)[2 * k + 1] = (uint32_t)sl;
+        ((uint32_t*)body)[2 * k] = rel; ((uint32_t*)body)[2 * k + 1] = slot_host_id(p, sl);
         k++;
       }
       table = k;
@@ -1475,7 +1478,7 @@ DEV void write_frame(const DecParams& p, const FrameView& v, const TxnCtx& tx, c
     default: {  // I / U / D
       table = m.rel_id;
       const int sl = row_slot >= 0 ? row_slot : cache_slot_before(p, find_table(p, m.rel_id), f);
-      slot_id = (uint32_t)sl;
+      slot_id = slot_host_id(p, sl);
       uint32_t hcur = (uint32_t)hp_off;
       uint32_t err = 0;
       bool partial = false;

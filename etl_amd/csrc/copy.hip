@@ -41,16 +41,19 @@ constexpr uint32_t kCopyHdr = 38;  // 'd' len(4) 'w' 24 x 0 'I' rel(4) 'N' ncols
 
 template <bool STAGED>
 DEV void copy_row(const CopyParams& q, uint32_t r, const u8* row, uint32_t n, u8* fr, uint32_t slot_bytes) {
-  // frame header
-  fr[0] = 'd';
-  const uint32_t L = slot_bytes - 1;
-  fr[1] = (u8)(L >> 24); fr[2] = (u8)(L >> 16); fr[3] = (u8)(L >> 8); fr[4] = (u8)L;
-  fr[5] = 'w';
-  for (uint32_t i = 6; i < 30; i++) fr[i] = 0;
-  fr[30] = 'I';
-  fr[31] = (u8)(q.rel_id >> 24); fr[32] = (u8)(q.rel_id >> 16); fr[33] = (u8)(q.rel_id >> 8); fr[34] = (u8)q.rel_id;
-  fr[35] = 'N';
-  fr[36] = (u8)(q.ncols >> 8); fr[37] = (u8)q.ncols;
+  // frame header: 38 bytes as four 8-byte stores and three 2-byte ones (a frame starts at any byte; one byte at a time it was 38 store
+  // instructions per row)
+  {
+    const uint32_t L = slot_bytes - 1;
+    const uint64_t w0 = (uint64_t)'d' | ((uint64_t)__builtin_bswap32(L) << 8) | ((uint64_t)'w' << 40);   // bytes 0..7: 'd' len 'w' 0 0
+    const uint64_t zero = 0;
+    const uint64_t w3 = ((uint64_t)'I' << 48) | ((uint64_t)(q.rel_id >> 24) << 56);                      // bytes 24..31: 0 x 6, 'I', rel[0]
+    const uint16_t h0 = (uint16_t)(((q.rel_id >> 16) & 0xFFu) | (((q.rel_id >> 8) & 0xFFu) << 8));         // bytes 32..33
+    const uint16_t h1 = (uint16_t)((q.rel_id & 0xFFu) | ((uint32_t)'N' << 8));                            // bytes 34..35
+    const uint16_t h2 = (uint16_t)(((q.ncols >> 8) & 0xFFu) | ((q.ncols & 0xFFu) << 8));                  // bytes 36..37
+    __builtin_memcpy(fr, &w0, 8); __builtin_memcpy(fr + 8, &zero, 8); __builtin_memcpy(fr + 16, &zero, 8); __builtin_memcpy(fr + 24, &w3, 8);
+    __builtin_memcpy(fr + 32, &h0, 2); __builtin_memcpy(fr + 34, &h1, 2); __builtin_memcpy(fr + 36, &h2, 2);
+  }
   u8* o = fr + kCopyHdr;
   uint32_t col = 0;
   uint32_t err = 0;
@@ -116,7 +119,7 @@ DEV void copy_row(const CopyParams& q, uint32_t r, const u8* row, uint32_t n, u8
       } else {
         const uint32_t ulen = (uint32_t)(w - (cell + 5));
         cell[0] = 't';
-        cell[1] = (u8)(ulen >> 24); cell[2] = (u8)(ulen >> 16); cell[3] = (u8)(ulen >> 8); cell[4] = (u8)ulen;
+        { const uint32_t be = __builtin_bswap32(ulen); __builtin_memcpy(cell + 1, &be, 4); }
         o = w;
       }
       col++;

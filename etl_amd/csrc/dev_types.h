@@ -32,6 +32,9 @@ struct DevSlot {
                                // (numeric, float, date / time, bytea), not on its length alone. Wider slots: all ones.
   uint32_t key_masks;          // the same two masks for a dense key tuple: bit j = the identity column with key_index j
   uint32_t ident_mask;         // bit k: column k is an identity column (<= 16 columns)
+  uint32_t host_id;            // the schema slot id the arenas name (etlg_slot_desc index). The device table holds only the slots a frame
+                               // of the batch can decode against, in ascending id order: DevTable.init_slot / DevEpoch.slot /
+                               // DecParams.copy_slot index THIS table, and what reaches ev_slot / Truncate bodies is host_id
 };
 
 // Per-table side input for one batch: ownership state

@@ -216,6 +216,20 @@ struct CopyJob {
   uint8_t* d_out = nullptr; uint32_t* d_out_offs = nullptr;
 };
 
+// One uploaded copy of the side inputs (table states + cache timeline, schema slots + columns, the fixed-width plan's tables):
+// ONE device block filled by ONE asynchronous copy from a pinned staging block of its own. A batch keeps the set its kernels
+// read (`users`) until it is finished, so a change of the side inputs never has to wait for the batches in flight: it goes
+// to a set nobody uses.
+struct SideSet {
+  DevBuf dev;
+  uint8_t* h = nullptr; size_t h_cap = 0;
+  size_t o_tables = 0, o_epochs = 0, o_slots = 0, o_cols = 0, o_ptabs = 0, o_pcols = 0;
+  uint32_t n_slots = 0, n_cols = 0;
+  int users = 0;
+  hipEvent_t ready = nullptr;   // recorded behind the upload
+  uint32_t synced = 0;          // decode streams (bit = etlg_batch::sidx) that are ordered behind the upload
+};
+
 }  // namespace
 
 struct etlg_ctx {
@@ -263,12 +277,13 @@ struct etlg_ctx {
   bool host_times = false; double host_us[12] = {0}; uint64_t host_n[12] = {0};
   size_t ctrl_stage_cap_test = 0;
   std::chrono::steady_clock::time_point host_mark;
-  DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_tables, d_epochs, d_slots, d_cols, d_desc;
+  DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_desc;
+  std::vector<SideSet*> side_sets;   // every set ever built (a handful)
+  SideSet* side_cur = nullptr;       // the latest upload: what last_tables / last_epochs / last_live describe
   FusedParams fq{};
   PlanParams pq{};
   uint32_t n_dev_slots = 0, n_dev_cols = 0;
   // the fixed-width plan (plan.hip): eligible tables of the current side inputs, and the back-off after a batch that did not conform
-  DevBuf d_ptabs, d_pcols;
   uint32_t n_plan_tabs = 0, plan_max_row = 16;
   bool plan_covers_all = false;
   int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
@@ -279,7 +294,21 @@ struct etlg_ctx {
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
   bool last_any_sync_done = false;
   bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
-  etlg_batch* deferred = nullptr;     // ASYNC batch without a sidecar whose boundary scan is in flight: its decode is enqueued by the next call
+  // ASYNC without the caller's no-control assertion on a stream that carries Relation / DDL frames (last_had_ctrl): the control
+  // pre-pass of batch k+1 (classify, transaction scan, control list + the frames' bytes to pinned memory) runs on its own stream
+  // while batch k is decoded; the host control plane of k+1 then runs — still beside k's kernels — when the next call comes in
+  // (flush_deferred), and k+1's decode is enqueued behind k's with the device-side carry. One pre-pass in flight at a time.
+  hipStream_t ctl_stream = nullptr;
+  DevBuf d_ctl_res;                   // ring of kCtlRing pre-pass result blocks (the pre-passes chain their transaction state through them)
+  static constexpr uint32_t kCtlRing = 4, kCtlListCap = 4096, kCtlStageCap = 512u << 10;
+  uint32_t ctl_seq = 0;
+  CtrlFrame* h_ctl_list = nullptr;    // pinned: the first kCtlListCap entries of the control list ...
+  uint8_t* h_ctl_stage = nullptr;     // ... and the first kCtlStageCap gathered bytes, copied behind the pre-pass without asking for their sizes
+  hipEvent_t mp_tail = nullptr; bool mp_tail_set = false;   // behind the last multi-pass launch (it shares the per-frame scratch with the pre-pass)
+  int ctl_async_mode = 1;             // ETLG_CTL_ASYNC=0: control batches are decoded synchronously, as in round 2
+  uint64_t cs_gen = 0;                // bumped by every rollback of the control state
+  unsigned long long ctl_ahead_n = 0; // debugging aid: batches whose pre-pass ran ahead
+  etlg_batch* deferred = nullptr;     // ASYNC batch whose boundary scan (no sidecar) or control pre-pass is in flight: its decode is enqueued by the next call
   ScanJob scan_job;                   // ... and that scan
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
@@ -299,6 +328,7 @@ struct etlg_ctx {
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
   DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
+  DevResult* h_poison = nullptr;            // pinned, constant: "this batch did not run" (fused_fail bit 3)
   std::vector<DevResult*> res_pool;         // pinned result blocks (one per in-flight batch)
   std::vector<std::pair<uint8_t*, size_t>> harena_pool;  // pinned host arenas, reused by size
   // error
@@ -341,6 +371,8 @@ struct etlg_batch {
   bool used_cells = false; // ... and it was k_cells
   bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
   DecParams params{};
+  SideSet* side = nullptr;   // the side inputs its kernels read (released when the batch is finished)
+  size_t n_slots_view = ~(size_t)0;   // schema slots the batch's view lists (fill_view_common)
   // what sync needs to finish the batch
   int32_t host_err_code = 0; int64_t host_err_frame = -1; uint32_t host_err_rank = 0;
   std::vector<EpochRec> eps_saved; // epochs of the batch's own control frames (a multi-pass redo needs the same side inputs)
@@ -348,6 +380,15 @@ struct etlg_batch {
   std::vector<std::vector<uint8_t>> ctrl_raw;  // their bytes, same order (the input may be device-resident or come without a sidecar)
   ControlState snapshot;           // control state before the batch
   bool have_snapshot = false;
+  uint64_t snap_gen = 0;           // etlg_ctx::cs_gen when the snapshot was taken
+  // pipelined control path (etlg_ctx::ctl_stream)
+  bool defer_ctl = false;          // deferred because its control pre-pass is in flight (not a boundary scan)
+  bool ctl_started = false;        // pre-pass enqueued ahead (ctl_params / h_ctl / ctl_ev are valid)
+  bool ctl_async = false;          // took the pipelined control path: a forced re-run redoes its control pass
+  size_t nframes_in = 0;
+  DecParams ctl_params{};
+  DevResult* h_ctl = nullptr;      // pinned copy of the pre-pass result block
+  hipEvent_t ctl_ev = nullptr;     // behind the pre-pass and its copies
 };
 
 struct HandoffBlocks {  // two device blocks (+ one pinned block when downloaded), taken from / returned to the context's pool
@@ -766,25 +807,16 @@ HostErr handle_ddl(etlg_ctx* c, const CtrlFrame& cf, uint64_t wal_start, const u
   return {};
 }
 
-hipError_t upload(hipStream_t s, DevBuf& b, const void* src, size_t n) {
-  hipError_t e = b.ensure(n ? n : 16);
-  if (e != hipSuccess) return e;
-  if (n) e = hipMemcpyAsync(b.p, src, n, hipMemcpyHostToDevice, s);
-  return e;
-}
-
-// Uploads the schema slots. Slot ids are stable for the life of the context (the arenas name them), but a stream that changes
-// schemas often leaves most of them dead: only slots in `live` (what the table cache, this batch's epochs or a table copy can
-// reach) get their column descriptors uploaded; the rest are empty entries. The side tables then stay small enough for the
-// LDS copy the single-pass kernels want (k_cells needs it) after hundreds of DDL messages.
-hipError_t sync_slots(etlg_ctx* c, const std::vector<int32_t>& live) {
-  if (!c->slots_dirty && live == c->last_live) return hipSuccess;
-  std::vector<DevSlot> ds;
-  std::vector<DevCol> dc;
-  size_t si = 0;
-  for (auto& s : c->slots) {
-    if (!std::binary_search(live.begin(), live.end(), (int32_t)si++)) { DevSlot dead{}; dead.cols_base = (uint32_t)dc.size(); ds.push_back(dead); continue; }
+// The schema slots as the kernels read them. Slot ids are stable for the life of the context (the arenas name them), but a stream
+// that changes schemas often leaves most of them dead: the device table holds only the slots in `live` (what the table cache, this
+// batch's epochs or a table copy can reach), addressed by their position in it (DevSlot.host_id names the arena's id). The side
+// tables then stay small enough for the LDS copy the single-pass kernels want (k_cells needs it) after thousands of DDL messages.
+void build_slots(etlg_ctx* c, const std::vector<int32_t>& live, std::vector<DevSlot>& ds, std::vector<DevCol>& dc) {
+  for (int32_t li : live) {   // ascending host ids: the device index of a slot is its position in `live`
+    if (li < 0 || (size_t)li >= c->slots.size()) { DevSlot dead{}; dead.cols_base = (uint32_t)dc.size(); dead.host_id = (uint32_t)li; ds.push_back(dead); continue; }
+    auto& s = c->slots[(size_t)li];
     DevSlot d{};
+    d.host_id = (uint32_t)li;
     d.n_cols = s->desc.n_cols; d.n_ident = s->desc.n_ident; d.row_full = s->desc.row_bytes_full; d.row_key = s->desc.row_bytes_key;
     d.st_full = s->desc.state_bytes_full; d.st_key = s->desc.state_bytes_key; d.cols_base = (uint32_t)dc.size();
     {  // which columns can reach the heap, and for which of them the byte count depends on the text (DevSlot.has_var)
@@ -813,17 +845,10 @@ hipError_t sync_slots(etlg_ctx* c, const std::vector<int32_t>& live) {
     }
     ds.push_back(d);
   }
-  hipError_t e = upload(c->stream, c->d_slots, ds.data(), ds.size() * sizeof(DevSlot));
-  if (e != hipSuccess) return e;
-  e = upload(c->stream, c->d_cols, dc.data(), dc.size() * sizeof(DevCol));
-  if (e != hipSuccess) return e;
-  // the staging vectors die at scope exit: make the copies land first
-  e = hipStreamSynchronize(c->stream);
-  c->slots_dirty = false;
-  c->last_live = live;
-  c->n_dev_slots = (uint32_t)ds.size(); c->n_dev_cols = (uint32_t)dc.size();
-  return e;
 }
+
+void side_release(etlg_batch* b) { if (b->side) { b->side->users--; b->side = nullptr; } }
+void side_use(etlg_batch* b, SideSet* ss) { if (b->side == ss) return; side_release(b); b->side = ss; ss->users++; }
 
 void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
   if (which == kFused) etlg_k_launch_fused((int)c->fq.blk, &p, &c->fq, c->stream);
@@ -860,6 +885,7 @@ void launch_multipass(etlg_ctx* c, const DecParams& p, bool classify_done) {
   launch(c, 4, p);
   if (p.nframes) launch(c, 5, p);
   launch(c, 6, p);
+  if (c->mp_tail) { (void)hipEventRecord(c->mp_tail, c->stream); c->mp_tail_set = true; }   // a pre-pass that runs ahead waits for it (shared scratch)
 }
 
 OutSet* take_outset(etlg_ctx* c) {
@@ -876,7 +902,10 @@ uint32_t max_row_bytes(const etlg_ctx* c) {
 void fill_view_common(etlg_batch* b) {
   etlg_ctx* c = b->ctx;
   b->slot_descs.clear();
-  for (auto& s : c->slots) b->slot_descs.push_back(s->desc);
+  // the slots that existed when the batch's own control frames had been applied — not the ones a LATER batch's control plane has
+  // created meanwhile (the control pre-pass runs ahead of the decode: etlg_ctx::ctl_stream)
+  const size_t n = std::min(c->slots.size(), b->n_slots_view);
+  for (size_t i = 0; i < n; i++) b->slot_descs.push_back(c->slots[i]->desc);
   b->v.n_slots = (uint32_t)b->slot_descs.size();
   b->v.slots = b->slot_descs.data();
 }
@@ -896,6 +925,7 @@ int32_t setup_scratch(etlg_ctx* c, DecParams& p);
 bool plan_wanted(etlg_ctx* c, const etlg_batch* b);
 int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level);
 int32_t standard_path(etlg_ctx* c, etlg_batch* b);
+int32_t ctl_begin(etlg_ctx* c, etlg_batch* b, DecParams& p, hipStream_t s, bool ahead);
 static inline void ht_start(etlg_ctx* c) { if (c->host_times) c->host_mark = std::chrono::steady_clock::now(); }
 static inline void ht_mark(etlg_ctx* c, int i) {
   if (!c->host_times) return;
@@ -1001,6 +1031,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   if (const char* pm = getenv("ETLG_PLAN_MARGIN")) c->plan_margin_pct = (uint32_t)atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_DBG")) c->plan_dbg = (uint32_t)atoi(pm);
   if (const char* pm = getenv("ETLG_OVERLAP")) c->overlap_mode = atoi(pm);
+  if (const char* pm = getenv("ETLG_CTL_ASYNC")) c->ctl_async_mode = atoi(pm);
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && ncu > 0) c->n_cus = ncu; }
   { std::lock_guard<std::mutex> l(g_live_mu); c->gen = ++g_ctx_gen; g_live_ctx[c] = c->gen; }
   *out = c;
@@ -1018,11 +1049,17 @@ void etlg_ctx_destroy(etlg_ctx* c) {
     for (int i = 0; i < 8; i++) if (c->host_n[i]) fprintf(stderr, "etlg host times: %-26s %8.1f us x %llu\n", names[i], c->host_us[i] / (double)c->host_n[i], (unsigned long long)c->host_n[i]);
   }
   if (c->h_scan) { (void)hipHostFree(c->h_scan); c->h_scan = nullptr; }
-  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_ctrl_stage, &c->d_res, &c->d_tables, &c->d_epochs, &c->d_slots, &c->d_cols, &c->d_desc, &c->d_ptabs, &c->d_pcols, &c->d_colsel}) b->release();
+  for (DevBuf* b : {&c->d_copy_in, &c->d_copy_offs, &c->d_copy_out, &c->d_copy_out_offs, &c->d_scan, &c->d_in, &c->d_offs, &c->d_tag, &c->d_emit, &c->d_ffixed, &c->d_fheap, &c->d_blk32, &c->d_blk64, &c->d_ctrl, &c->d_ctrl_stage, &c->d_res, &c->d_desc, &c->d_colsel}) b->release();
+  for (SideSet* ss : c->side_sets) { ss->dev.release(); if (ss->h) (void)hipHostFree(ss->h); if (ss->ready) (void)hipEventDestroy(ss->ready); delete ss; }
   for (OutSet* o : c->out_pool) { o->release(); delete o; }
   for (DevBuf* o : c->offs_pool) { o->release(); delete o; }
   for (auto& b : c->blk_dev) (void)hipFree(b.first);
   for (auto& b : c->blk_host) (void)hipHostFree(b.first);
+  if (c->ctl_stream) (void)hipStreamDestroy(c->ctl_stream);
+  if (c->mp_tail) (void)hipEventDestroy(c->mp_tail);
+  if (c->h_ctl_list) (void)hipHostFree(c->h_ctl_list);
+  if (c->h_ctl_stage) (void)hipHostFree(c->h_ctl_stage);
+  c->d_ctl_res.release();
   if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
   if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1032,6 +1069,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& pr : c->harena_pool) (void)hipHostFree(pr.first);
   if (c->h_init) (void)hipHostFree(c->h_init);
+  if (c->h_poison) (void)hipHostFree(c->h_poison);
   if (c->h_init_ring) (void)hipHostFree(c->h_init_ring);
   for (DevResult* r : c->res_pool) (void)hipHostFree(r);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1149,6 +1187,7 @@ int32_t etlg_ctx_debug_paths(etlg_ctx* c, unsigned long long* out4) {
 //   (a Relation / DDL frame, or a caller without ETLG_F_NO_CONTROL on the multi-pass path)  [7] ASYNC batches re-run because their predecessor failed
 // debugging aid (not part of etlg.h): ASYNC batches that were enqueued beside their predecessor on the second decode stream
 unsigned long long etlg_ctx_debug_overlapped(etlg_ctx* c) { return c ? c->overlapped : 0; }
+unsigned long long etlg_ctx_debug_ctl_ahead(etlg_ctx* c) { return c ? c->ctl_ahead_n : 0; }   // batches whose control pre-pass ran ahead of their decode
 int32_t etlg_ctx_debug_paths8(etlg_ctx* c, unsigned long long* out8) {
   if (!c || !out8) return ETLG_InvalidArgument;
   for (int i = 0; i < 8; i++) out8[i] = c->path_n[i];
@@ -1400,7 +1439,12 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   // ASYNC batches are chained on the device (DecParams.carry) and may be decoded again when they are synced, so everything
   // they read must still be there then: device-resident input AND sidecar (the context's staging and scan buffers are shared
   // by all batches). Anything else is decoded synchronously; etlg_batch_sync on such a batch returns its stored result.
-  const bool async = (flags & ETLG_F_ASYNC) && out_dev && no_ctrl && in_dev && !c->copy.active && !c->force_multipass && len < (1ull << 31);
+  // Without the caller's no-control assertion the first attempt is optimistic as long as the stream has not been carrying Relation /
+  // DDL frames (a control frame then fails the batch with a hint and finish_batch takes the control path); on a stream that does
+  // carry them (last_had_ctrl) the control pre-pass runs ahead on its own stream (ctl_begin) — that needs the sidecar.
+  const bool async_ok = (flags & ETLG_F_ASYNC) && out_dev && in_dev && !c->copy.active && !c->force_multipass && len < (1ull << 31);
+  const bool ctl_ahead = async_ok && !no_ctrl && c->last_had_ctrl && !scan && nframes && c->ctl_async_mode;
+  const bool async = async_ok && (no_ctrl || !c->last_had_ctrl || ctl_ahead);
   hipStream_t s = c->stream;
   if (!async) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
 
@@ -1436,6 +1480,36 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     HIPCHK(c, device_scan(c, d_in_ptr, len, &nframes, s, c->d_offs));
     if (nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   }
+  if (ctl_ahead) {
+    // the pre-pass goes out now, on the control stream; the host control plane and the decode follow when the next call comes in
+    if (!c->ctl_stream) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->ctl_stream, hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->mp_tail, hipEventDisableTiming));
+      HIPCHK(c, c->d_ctl_res.ensure(sizeof(DevResult) * etlg_ctx::kCtlRing));
+    }
+    b->nframes_in = nframes;
+    b->ctl_async = true;
+    DecParams& cp = b->ctl_params;
+    cp = DecParams{};
+    cp.in = d_in_ptr; cp.offs = frame_offsets; cp.nframes = (uint32_t)nframes; cp.nblocks = ((uint32_t)nframes + kBlock - 1) / kBlock; cp.in_len = len;
+    cp.worker_kind = (uint32_t)c->worker; cp.sync_table = c->sync_table; cp.copy_slot = -1; cp.host_err_frame = 0xFFFFFFFFu;
+    cp.in_txn = c->in_txn; cp.final_lsn = c->final_lsn; cp.next_ord = c->next_ord;
+    cp.flags = 32u;
+    etlg_batch* prev = c->pending.empty() ? nullptr : c->pending.back();
+    if (prev && prev->pending) {
+      if (prev->ctl_async && prev->ctl_params.res) cp.carry = prev->ctl_params.res;   // the pre-passes chain among themselves (control stream order)
+      else if (prev->kdone) { HIPCHK(c, hipStreamWaitEvent(c->ctl_stream, prev->kdone, 0)); cp.carry = prev->d_res_blk; }   // an optimistic batch: its decode result
+      else { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; cp.in_txn = c->in_txn; cp.final_lsn = c->final_lsn; cp.next_ord = c->next_ord; }
+    }
+    cp.res = (DevResult*)c->d_ctl_res.p + (c->ctl_seq++ % etlg_ctx::kCtlRing);
+    { const int32_t rc = ctl_begin(c, b, cp, c->ctl_stream, true); if (rc != ETLG_OK) return rc; }
+    b->deferred = true; b->defer_ctl = true; b->pending = true; b->v.on_device = 1;
+    c->deferred = b; c->pending.push_back(b);
+    c->ctl_ahead_n++;
+    guard.b = nullptr;
+    *out = b;
+    return ETLG_OK;
+  }
   {
     const int32_t rc = decode_tail(c, b, nframes, async, (async && !c->pending.empty()) ? c->pending.back() : nullptr);
     if (rc != ETLG_OK) return rc;
@@ -1459,9 +1533,12 @@ int32_t flush_deferred(etlg_ctx* c) {
   b->deferred = false;
   size_t nframes = 0;
   int32_t rc = ETLG_OK;
-  const hipError_t e = scan_collect(c, c->scan_job, &nframes);
-  if (e != hipSuccess) rc = lib_error(c, ETLG_DeviceError, hipGetErrorString(e));
-  else if (nframes >= (1u << 30)) rc = lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  if (b->defer_ctl) { b->defer_ctl = false; nframes = b->nframes_in; }   // its control pre-pass ran ahead: decode_tail collects it (standard_path -> ctl_finish)
+  else {
+    const hipError_t e = scan_collect(c, c->scan_job, &nframes);
+    if (e != hipSuccess) rc = lib_error(c, ETLG_DeviceError, hipGetErrorString(e));
+    else if (nframes >= (1u << 30)) rc = lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  }
   if (rc == ETLG_OK) {
     etlg_batch* prev = nullptr;   // the batch issued just before this one, if it is still in flight
     for (size_t i = 0; i < c->pending.size(); i++) if (c->pending[i] == b && i > 0) prev = c->pending[i - 1];
@@ -1521,7 +1598,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   //      enqueued for the batch; everything below then runs on the chosen stream.
   struct StreamSwitch { etlg_ctx* c; hipStream_t saved; ~StreamSwitch() { c->stream = saved; } } sw{c, c->stream};
   bool beside = false;
-  const bool first_try_single = p.nframes && !c->force_multipass && len < (1ull << 31) && (no_ctrl || !c->last_had_ctrl);
+  const bool first_try_single = p.nframes && !c->force_multipass && len < (1ull << 31) && (no_ctrl || !c->last_had_ctrl) && !b->ctl_async;
   if (async && prev && prev->pending && prev->level <= 1 && prev->used_fused && !prev->force_rerun && c->overlap_mode && first_try_single && c->res_seq != 0 && res_slot >= 2 &&
       c->side_valid && !c->side_dirty && !c->slots_dirty && c->last_epochs.empty() && !b->copy.active && !c->prof_serial) {
     p.flags |= 1u;
@@ -1549,6 +1626,10 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     if (c->tail2_set) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->tail2, 0)); c->tail2_set = false; }   // join: everything enqueued on stream2 so far
   }
   s = c->stream;
+  if (b->side && !(b->side->synced & (1u << b->sidx))) {   // the set was uploaded on the other decode stream: the first batch over here waits for it
+    HIPCHK(c, hipStreamWaitEvent(s, b->side->ready, 0));
+    b->side->synced |= 1u << b->sidx;
+  }
   {  // result block: next slot of a ring that is re-initialised once per lap. Slot 31 is the carry source of the batch in
      // slot 0, so it is re-initialised one batch later than the others.
     const uint32_t seq = c->res_seq++;
@@ -1576,7 +1657,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   // (DDL messages every few hundred transactions) would pay for a wasted kernel on every batch
   if (b->plan_decided >= 0) {   // side inputs and outputs were set up for the stream decision above
     { const int32_t rc = enqueue_single(c, b, b->plan_decided ? 0 : 1); if (rc != ETLG_OK) return rc; }
-  } else if (single_pass && (no_ctrl || !c->last_had_ctrl)) {
+  } else if (single_pass && (no_ctrl || !c->last_had_ctrl) && !b->ctl_async) {
     p.flags |= 1u;
     const std::vector<EpochRec> no_eps;
     { const int32_t rc = build_side_inputs(c, b, no_eps); if (rc != ETLG_OK) return rc; }
@@ -1586,6 +1667,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     const int32_t rc = standard_path(c, b);
     if (rc != ETLG_OK) return rc;
   }
+  if (b->n_slots_view == ~(size_t)0) b->n_slots_view = c->slots.size();
   if (async) {
     // the result block is copied on a second stream: on the context's stream the next batch's kernel follows this one
     // directly (a 200-byte device-to-host copy is a 4 us blit kernel plus two dispatch gaps when it sits between them)
@@ -1672,6 +1754,9 @@ void etlg_batch_free(etlg_batch* b) {
       b->pending = false;
     }
     if (b->h_res) (void)hipStreamSynchronize(c->stream);
+    side_release(b);
+    if (b->ctl_ev) { if (b->ctl_started && c->ctl_stream) (void)hipStreamSynchronize(c->ctl_stream); c->ev_pool.push_back(b->ctl_ev); }
+    if (b->h_ctl) c->res_pool.push_back(b->h_ctl);
     if (b->done) c->ev_pool.push_back(b->done);
     if (b->kdone) c->ev_pool.push_back(b->kdone);
     if (b->dev) c->out_pool.push_back(b->dev);
@@ -1683,6 +1768,8 @@ void etlg_batch_free(etlg_batch* b) {
     if (b->scan_offs) { b->scan_offs->release(); delete b->scan_offs; }
     if (b->done) (void)hipEventDestroy(b->done);
     if (b->kdone) (void)hipEventDestroy(b->kdone);
+    if (b->ctl_ev) (void)hipEventDestroy(b->ctl_ev);
+    if (b->h_ctl) (void)hipHostFree(b->h_ctl);
     if (b->h_res) (void)hipHostFree(b->h_res);
     if (b->h_arena) (void)hipHostFree(b->h_arena);
   }
@@ -2202,13 +2289,18 @@ int32_t setup_scratch(etlg_ctx* c, DecParams& p) {
 int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec>& eps) {
   DecParams& p = b->params;
   hipStream_t s = c->stream;
+  auto point = [&](SideSet* ss, uint32_t n_tables, uint32_t n_epochs) {
+    const uint8_t* d = (const uint8_t*)ss->dev.p;
+    p.tables = (const DevTable*)(d + ss->o_tables); p.epochs = (const DevEpoch*)(d + ss->o_epochs); p.n_tables = n_tables; p.n_epochs = n_epochs;
+    p.slots = (const DevSlot*)(d + ss->o_slots); p.cols = (const DevCol*)(d + ss->o_cols);
+    p.n_slots = ss->n_slots; p.n_cols = ss->n_cols;
+    if (p.flags & 2u) p.copy_slot = (int32_t)(std::lower_bound(c->last_live.begin(), c->last_live.end(), b->copy.slot) - c->last_live.begin());   // device index of the caller's slot
+    side_use(b, ss);
+  };
   if (eps.empty() && c->side_valid && !c->side_dirty && !c->slots_dirty && c->last_epochs.empty() && !b->have_snapshot && !b->copy.active) {
     // nothing the side inputs are built from has changed since the last upload (the common case: one call per batch)
-    p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)c->last_tables.size();
-    p.n_epochs = 0;
+    point(c->side_cur, (uint32_t)c->last_tables.size(), 0u);
     b->any_sync_done = c->last_any_sync_done;
-    p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
-    p.n_slots = c->n_dev_slots; p.n_cols = c->n_dev_cols;
     return ETLG_OK;
   }
   std::map<uint32_t, DevTable> tabs;
@@ -2236,26 +2328,29 @@ int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec
   if (b->copy.active && b->copy.slot >= 0) live.push_back(b->copy.slot);
   std::sort(live.begin(), live.end());
   live.erase(std::unique(live.begin(), live.end()), live.end());
+  auto dev_index = [&](int32_t host_slot) -> int32_t {   // position in `live`; -1 stays -1
+    if (host_slot < 0) return host_slot;
+    return (int32_t)(std::lower_bound(live.begin(), live.end(), host_slot) - live.begin());
+  };
+  for (auto& t : tv) if (t.init_kind == 2u) t.init_slot = dev_index(t.init_slot);
+  for (auto& e : ev) if (e.kind == 2u) e.slot = dev_index(e.slot);
   const bool same = c->side_valid && !c->slots_dirty && live == c->last_live && tv.size() == c->last_tables.size() && ev.size() == c->last_epochs.size() &&
                     (tv.empty() || !memcmp(tv.data(), c->last_tables.data(), tv.size() * sizeof(DevTable))) &&
                     (ev.empty() || !memcmp(ev.data(), c->last_epochs.data(), ev.size() * sizeof(DevEpoch)));
-  if (!same) {  // rare: table states, the cache timeline or the slots changed
-    if (!b->pending) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; }
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, c->d_tables.ensure(tv.size() * sizeof(DevTable) + 16));
-    HIPCHK(c, c->d_epochs.ensure(ev.size() * sizeof(DevEpoch) + 16));
-    if (!tv.empty()) HIPCHK(c, hipMemcpy(c->d_tables.p, tv.data(), tv.size() * sizeof(DevTable), hipMemcpyHostToDevice));
-    if (!ev.empty()) HIPCHK(c, hipMemcpy(c->d_epochs.p, ev.data(), ev.size() * sizeof(DevEpoch), hipMemcpyHostToDevice));
-    c->last_tables = tv; c->last_epochs = ev; c->side_valid = true;
-    HIPCHK(c, sync_slots(c, live));
+  if (!same) {  // table states, the cache timeline or the slots changed: a new upload, into a set no unfinished batch reads
+    std::vector<DevSlot> ds;
+    std::vector<DevCol> dc;
+    build_slots(c, live, ds, dc);
     // ---- the fixed-width plan (plan.hip): tables the apply worker owns outright, Ready for the whole batch, whose
     //      replicated columns are all bool / int2 / int4 / int8 / oid
     std::vector<PlanTab> pt;
     std::vector<uint32_t> pc;
     if (ev.empty() && c->worker == ETLG_WORKER_APPLY) {
       for (const DevTable& t : tv) {  // tv is sorted by table id
-        if (t.state_kind != ETLG_TS_READY || t.init_kind != 2u || t.init_slot < 0 || (size_t)t.init_slot >= c->slots.size()) continue;
-        const SlotHost& sh = *c->slots[(size_t)t.init_slot];
+        if (t.state_kind != ETLG_TS_READY || t.init_kind != 2u || t.init_slot < 0 || (size_t)t.init_slot >= live.size()) continue;
+        const int32_t host_slot = live[(size_t)t.init_slot];   // (t.init_slot is the device index by now)
+        if (host_slot < 0 || (size_t)host_slot >= c->slots.size()) continue;
+        const SlotHost& sh = *c->slots[(size_t)host_slot];
         bool ok = sh.desc.n_cols > 0;
         for (auto& sc : sh.cols) {
           const int32_t k = sc.type_class;
@@ -2263,15 +2358,45 @@ int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec
         }
         if (!ok) continue;
         PlanTab e{};
-        e.rel_id = t.table_id; e.slot = (uint32_t)t.init_slot; e.n_cols = sh.desc.n_cols; e.row_dwords = sh.desc.row_bytes_full / 4;
+        e.rel_id = t.table_id; e.slot = (uint32_t)host_slot; e.n_cols = sh.desc.n_cols; e.row_dwords = sh.desc.row_bytes_full / 4;   // (the plan writes the arena's id, it does not index the slot table)
         e.cols_base = (uint32_t)pc.size();
         for (auto& sc : sh.cols) pc.push_back((uint32_t)sc.type_class | ((uint32_t)(sc.nullable ? 1 : 0) << 8) | ((uint32_t)sc.off_full << 16));
         pt.push_back(e);
       }
     }
-    HIPCHK(c, c->d_ptabs.ensure(pt.size() * sizeof(PlanTab) + 16)); HIPCHK(c, c->d_pcols.ensure(pc.size() * 4 + 16));
-    if (!pt.empty()) HIPCHK(c, hipMemcpy(c->d_ptabs.p, pt.data(), pt.size() * sizeof(PlanTab), hipMemcpyHostToDevice));
-    if (!pc.empty()) HIPCHK(c, hipMemcpy(c->d_pcols.p, pc.data(), pc.size() * 4, hipMemcpyHostToDevice));
+    SideSet* ss = nullptr;
+    side_release(b);   // (a batch that is decoded again lets go of the set its first attempt read)
+    for (SideSet* x : c->side_sets) if (x->users == 0) { ss = x; break; }
+    if (!ss) { ss = new SideSet(); c->side_sets.push_back(ss); HIPCHK(c, hipEventCreateWithFlags(&ss->ready, hipEventDisableTiming)); }
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    ss->o_tables = 0;
+    ss->o_epochs = al(tv.size() * sizeof(DevTable) + 16);
+    ss->o_slots = ss->o_epochs + al(ev.size() * sizeof(DevEpoch) + 16);
+    ss->o_cols = ss->o_slots + al(ds.size() * sizeof(DevSlot) + 16);
+    ss->o_ptabs = ss->o_cols + al(dc.size() * sizeof(DevCol) + 16);
+    ss->o_pcols = ss->o_ptabs + al(pt.size() * sizeof(PlanTab) + 16);
+    const size_t total = ss->o_pcols + al(pc.size() * 4 + 16);
+    if (total > ss->h_cap) {
+      if (ss->h) (void)hipHostFree(ss->h);
+      ss->h = nullptr; ss->h_cap = 0;
+      const size_t want = total + total / 2 + 4096;
+      HIPCHK(c, hipHostMalloc((void**)&ss->h, want, hipHostMallocDefault));
+      ss->h_cap = want;
+    }
+    HIPCHK(c, ss->dev.ensure(ss->h_cap));
+    if (!tv.empty()) memcpy(ss->h + ss->o_tables, tv.data(), tv.size() * sizeof(DevTable));
+    if (!ev.empty()) memcpy(ss->h + ss->o_epochs, ev.data(), ev.size() * sizeof(DevEpoch));
+    if (!ds.empty()) memcpy(ss->h + ss->o_slots, ds.data(), ds.size() * sizeof(DevSlot));
+    if (!dc.empty()) memcpy(ss->h + ss->o_cols, dc.data(), dc.size() * sizeof(DevCol));
+    if (!pt.empty()) memcpy(ss->h + ss->o_ptabs, pt.data(), pt.size() * sizeof(PlanTab));
+    if (!pc.empty()) memcpy(ss->h + ss->o_pcols, pc.data(), pc.size() * 4);
+    HIPCHK(c, hipMemcpyAsync(ss->dev.p, ss->h, total, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(ss->ready, s));
+    ss->synced = 1u << (s == c->stream2 && c->stream2 ? 1 : 0);
+    ss->n_slots = (uint32_t)ds.size(); ss->n_cols = (uint32_t)dc.size();
+    c->side_cur = ss;
+    c->last_tables = tv; c->last_epochs = ev; c->side_valid = true;
+    c->slots_dirty = false; c->last_live = live;
     c->n_plan_tabs = (uint32_t)pt.size();
     c->plan_max_row = 16;
     for (auto& e : pt) c->plan_max_row = std::max<uint32_t>(c->plan_max_row, e.row_dwords * 4);
@@ -2284,14 +2409,11 @@ int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec
       if (!found) c->plan_covers_all = false;
     }
   }
-  p.tables = (const DevTable*)c->d_tables.p; p.epochs = (const DevEpoch*)c->d_epochs.p; p.n_tables = (uint32_t)tv.size();
-  p.n_epochs = (uint32_t)ev.size();
+  point(c->side_cur, (uint32_t)tv.size(), (uint32_t)ev.size());
   b->any_sync_done = false;
   for (auto& t : tv) if (t.state_kind == ETLG_TS_SYNC_DONE) b->any_sync_done = true;
   c->last_any_sync_done = b->any_sync_done;
   if (!b->have_snapshot) c->side_dirty = false;   // built from the live control state
-  p.slots = (const DevSlot*)c->d_slots.p; p.cols = (const DevCol*)c->d_cols.p;
-  p.n_slots = c->n_dev_slots; p.n_cols = c->n_dev_cols;
   return ETLG_OK;
 }
 
@@ -2373,7 +2495,7 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
     q.rows_off = (uint32_t)std::max<uint64_t>(cap, 2048 + 64);        // the staging window (a tile read in place parks 64 x 32-byte bodies there)
     // rows of up to 8 dwords wait for the look-back inside their own frame's staged head; wider tables get a region of 64 rows
     q.lds_bytes = q.rows_off + (c->plan_max_row > 32 ? (uint32_t)(64ull * c->plan_max_row + 64) : 0u);
-    q.n_tabs = c->n_plan_tabs; q.tabs = (const PlanTab*)c->d_ptabs.p; q.cols = (const uint32_t*)c->d_pcols.p;
+    q.n_tabs = c->n_plan_tabs; q.tabs = (const PlanTab*)((const uint8_t*)b->side->dev.p + b->side->o_ptabs); q.cols = (const uint32_t*)((const uint8_t*)b->side->dev.p + b->side->o_pcols);
     q.dbg = c->plan_dbg;
     q.max_row_dw = (c->plan_max_row + 3) / 4;
     const size_t per = 2 * ((size_t)q.ntiles + ((size_t)q.ntiles + 63) / 64);   // pairs: {agg, lsn}[ntiles] | {agg, lsn}[ngroups]
@@ -2389,7 +2511,7 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
   FusedParams& q = c->fq;
   const uint64_t side = (uint64_t)p.n_tables * sizeof(DevTable) + (uint64_t)p.n_epochs * sizeof(DevEpoch) +
                         (uint64_t)p.n_slots * sizeof(DevSlot) + (uint64_t)p.n_cols * sizeof(DevCol);
-  q.side_bytes = (side <= 16384 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
+  q.side_bytes = (side <= 32768 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
   // kernel choice: narrow frames -> one lane per frame, 256 frames per tile (k_fused); wide frames ->
   // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 16 columns)
   uint32_t widest = 1;
@@ -2437,18 +2559,26 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
   return ETLG_OK;
 }
 
-// The control pre-pass: classify + transaction scan + compaction of the R / M frames, one host round trip, then the host
-// control plane (handle_relation / handle_ddl) in frame order. Fills b->ctrl / ctrl_raw, `eps`, the host error of the batch.
-int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps) {
-  DecParams& p = b->params;
-  hipStream_t s = c->stream;
+// The control pre-pass, device half: classify + transaction scan + compaction of the R / M frames (k_ctrl_list also gathers their
+// bytes), then the result block, the head of the list and the head of the gathered bytes to pinned memory WITHOUT asking for their
+// sizes first (one round trip instead of three; what does not fit is fetched afterwards). `ahead`: on the control stream, beside the
+// decode of the batch before (etlg_decode); otherwise on the context's stream, collected at once (run_control_pass).
+int32_t ctl_begin(etlg_ctx* c, etlg_batch* b, DecParams& p, hipStream_t s, bool ahead) {
+  struct StreamSwitch { etlg_ctx* c; hipStream_t saved; ~StreamSwitch() { c->stream = saved; } } sw{c, c->stream};
+  c->stream = s;
   const uint32_t nf = p.nframes;
-  ht_start(c);
-  b->snapshot = c->cs; b->have_snapshot = true;
-  b->ctrl.clear(); b->ctrl_raw.clear();
-  b->host_err_code = 0; b->host_err_frame = -1; b->host_err_rank = 0;
-  b->ctrl_done = true;
-  if (!nf) return ETLG_OK;
+  if (!c->h_ctl_list) {
+    HIPCHK(c, hipHostMalloc((void**)&c->h_ctl_list, sizeof(CtrlFrame) * etlg_ctx::kCtlListCap, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_ctl_stage, etlg_ctx::kCtlStageCap, hipHostMallocDefault));
+  }
+  if (ahead) {
+    if (c->mp_tail_set) { HIPCHK(c, hipStreamWaitEvent(s, c->mp_tail, 0)); c->mp_tail_set = false; }   // the multi-pass kernels share the per-frame scratch
+    if (c->res_pool.empty()) { DevResult* r = nullptr; HIPCHK(c, hipHostMalloc((void**)&r, sizeof(DevResult), hipHostMallocDefault)); c->res_pool.push_back(r); }
+    b->h_ctl = c->res_pool.back(); c->res_pool.pop_back();
+    if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
+    b->ctl_ev = c->ev_pool.back(); c->ev_pool.pop_back();
+    HIPCHK(c, hipMemcpyAsync(p.res, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+  }
   { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
   launch(c, 0, p);
   launch(c, 1, p);
@@ -2461,42 +2591,77 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
     p.ctrl_stage = (uint8_t*)c->d_ctrl_stage.p; p.ctrl_stage_cap = (uint32_t)want;
   }
   launch(c, 2, p);
-  HIPCHK(c, hipMemcpyAsync(b->h_res, b->d_res_blk, sizeof(DevResult), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipMemcpyAsync(ahead ? b->h_ctl : b->h_res, p.res, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_ctl_list, c->d_ctrl.p, (size_t)std::min<uint32_t>(nf, etlg_ctx::kCtlListCap) * sizeof(CtrlFrame), hipMemcpyDeviceToHost, s));
+  if (b->in_dev) HIPCHK(c, hipMemcpyAsync(c->h_ctl_stage, c->d_ctrl_stage.p, std::min<size_t>(p.ctrl_stage_cap, etlg_ctx::kCtlStageCap), hipMemcpyDeviceToHost, s));
+  if (ahead) { HIPCHK(c, hipEventRecord(b->ctl_ev, s)); b->ctl_started = true; }
+  return ETLG_OK;
+}
+
+// The control pre-pass of one batch (device half above, unless it ran ahead), then the host control plane (handle_relation /
+// handle_ddl) in frame order. Fills b->ctrl / ctrl_raw, `eps`, the host error of the batch.
+int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps) {
+  hipStream_t s = c->stream;
+  const uint32_t nf = b->params.nframes;
+  ht_start(c);
+  b->snapshot = c->cs; b->have_snapshot = true; b->snap_gen = c->cs_gen;
+  b->ctrl.clear(); b->ctrl_raw.clear();
+  b->host_err_code = 0; b->host_err_frame = -1; b->host_err_rank = 0;
+  b->ctrl_done = true;
+  if (!nf) return ETLG_OK;
+  const bool ahead = b->ctl_started;
+  DecParams& p = ahead ? b->ctl_params : b->params;
+  if (ahead) {
+    HIPCHK(c, hipEventSynchronize(b->ctl_ev));
+    s = c->ctl_stream;   // what did not fit the pinned heads is fetched on the stream the pre-pass ran on
+  } else {
+    { const int32_t rc = ctl_begin(c, b, p, s, false); if (rc != ETLG_OK) return rc; }
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
   ht_mark(c, 0);
-  const uint32_t nctrl = b->h_res->n_ctrl;
+  const DevResult& cr = ahead ? *b->h_ctl : *b->h_res;
+  const uint32_t nctrl = std::min<uint32_t>(cr.n_ctrl, p.ctrl_cap);
   if (!nctrl) return ETLG_OK;
   std::vector<CtrlFrame>& ctrl = b->ctrl;
   ctrl.resize(nctrl);
-  HIPCHK(c, hipMemcpy(ctrl.data(), c->d_ctrl.p, (size_t)nctrl * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
+  const uint32_t nhead = std::min<uint32_t>(nctrl, etlg_ctx::kCtlListCap);
+  memcpy(ctrl.data(), c->h_ctl_list, (size_t)nhead * sizeof(CtrlFrame));
+  if (nctrl > nhead) HIPCHK(c, hipMemcpy(ctrl.data() + nhead, (const CtrlFrame*)c->d_ctrl.p + nhead, (size_t)(nctrl - nhead) * sizeof(CtrlFrame), hipMemcpyDeviceToHost));
   std::sort(ctrl.begin(), ctrl.end(), [](const CtrlFrame& a, const CtrlFrame& b2) { return a.frame < b2.frame; });
   ht_mark(c, 1);
-  // the frames' bytes: already on the host, or the gathered copy k_ctrl_list left in the staging buffer (one transfer);
-  // a frame that did not fit there is fetched from the input by itself
+  // the frames' bytes: already on the host, or the gathered copy k_ctrl_list left in the staging buffer (its head is in pinned
+  // memory already); a frame that did not fit there is fetched from the input by itself
   std::vector<uint8_t> stage, extra;
   std::vector<size_t> at(nctrl + 1, 0);
   for (uint32_t i = 0; i < nctrl; i++) at[i + 1] = at[i] + (ctrl[i].stage_off == 0xFFFFFFFFu ? ctrl[i].o1 - ctrl[i].o0 : 0u);
+  const uint8_t* staged_bytes = c->h_ctl_stage;
   if (b->in_dev) {
-    const uint32_t staged = std::min<uint32_t>(b->h_res->ctrl_bytes, p.ctrl_stage_cap);
-    stage.resize((size_t)staged + 16);
-    if (staged) HIPCHK(c, hipMemcpyAsync(stage.data(), c->d_ctrl_stage.p, staged, hipMemcpyDeviceToHost, s));
+    const uint32_t staged = std::min<uint32_t>(cr.ctrl_bytes, p.ctrl_stage_cap);
+    bool wait = false;
+    if (staged > etlg_ctx::kCtlStageCap) {   // more gathered bytes than the pinned head holds: one copy of everything
+      stage.resize((size_t)staged + 16);
+      HIPCHK(c, hipMemcpyAsync(stage.data(), c->d_ctrl_stage.p, staged, hipMemcpyDeviceToHost, s));
+      staged_bytes = stage.data(); wait = true;
+    }
     extra.resize(at[nctrl] + 16);
     for (uint32_t i = 0; i < nctrl; i++)
-      if (ctrl[i].stage_off == 0xFFFFFFFFu && ctrl[i].o1 > ctrl[i].o0)
+      if (ctrl[i].stage_off == 0xFFFFFFFFu && ctrl[i].o1 > ctrl[i].o0) {
         HIPCHK(c, hipMemcpyAsync(extra.data() + at[i], b->dev_in + ctrl[i].o0, ctrl[i].o1 - ctrl[i].o0, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+        wait = true;
+      }
+    if (wait) HIPCHK(c, hipStreamSynchronize(s));
   }
   ht_mark(c, 2);
   for (uint32_t i = 0; i < nctrl; i++) {
     const CtrlFrame& cf = ctrl[i];
-    const uint8_t* fr = !b->in_dev ? b->host_in + cf.o0 : cf.stage_off != 0xFFFFFFFFu ? stage.data() + cf.stage_off : extra.data() + at[i];
+    const uint8_t* fr = !b->in_dev ? b->host_in + cf.o0 : cf.stage_off != 0xFFFFFFFFu ? staged_bytes + cf.stage_off : extra.data() + at[i];
     const size_t flen = cf.o1 - cf.o0;
     b->ctrl_raw.emplace_back(fr, fr + flen);
     // classify guaranteed 'd' len 'w' hdr tag: body starts at +31
     uint64_t wal_start = 0;
     for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
     HostErr he = cf.tag == 'R' ? handle_relation(c, cf, fr + 31, flen - 31, eps) : handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
-    if (he.code) { b->host_err_code = he.code; b->host_err_frame = cf.frame; b->host_err_rank = he.rank; p.host_err_frame = cf.frame; break; }
+    if (he.code) { b->host_err_code = he.code; b->host_err_frame = cf.frame; b->host_err_rank = he.rank; b->params.host_err_frame = cf.frame; break; }
   }
   ht_mark(c, 3);
   return ETLG_OK;
@@ -2511,7 +2676,7 @@ int32_t standard_path(etlg_ctx* c, etlg_batch* b) {
   std::vector<EpochRec> eps;
   p.flags &= ~1u;
   if (b->user_no_ctrl) p.flags |= 1u;
-  else { const int32_t rc = run_control_pass(c, b, eps); if (rc != ETLG_OK) return rc; c->path_n[6]++; }
+  else { const int32_t rc = run_control_pass(c, b, eps); if (rc != ETLG_OK) return rc; c->path_n[6]++; b->n_slots_view = c->slots.size(); }
   b->eps_saved = eps;
   ht_start(c);
   { const int32_t rc = build_side_inputs(c, b, eps); if (rc != ETLG_OK) return rc; }
@@ -2519,8 +2684,18 @@ int32_t standard_path(etlg_ctx* c, etlg_batch* b) {
   { const int32_t rc = setup_outputs(c, b); if (rc != ETLG_OK) return rc; }
   ht_mark(c, 5);
   if (nf && !b->host_err_code && !c->force_multipass && b->len < (1ull << 31)) { const int32_t rc = enqueue_single(c, b, 1); ht_mark(c, 6); return rc; }
+  if (p.carry) {
+    // chained to a batch in flight and in need of the multi-pass kernels (the host control plane failed on one of its frames): they
+    // take the carried state from the host. The batch is marked "did not run" — the batches behind it stop at that — and is decoded
+    // when it is synced, from the exact state (finish_batch, the forced re-run).
+    DevResult poison = *c->h_init; poison.fused_fail = 8u;
+    if (!c->h_poison) { HIPCHK(c, hipHostMalloc((void**)&c->h_poison, sizeof(DevResult), hipHostMallocDefault)); *c->h_poison = poison; }
+    HIPCHK(c, hipMemcpyAsync(b->d_res_blk, c->h_poison, sizeof(DevResult), hipMemcpyHostToDevice, c->stream));
+    b->level = 1; b->used_fused = true; b->used_cells = false;
+    return ETLG_OK;
+  }
   { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
-  launch_multipass(c, p, b->ctrl_done && nf != 0);
+  launch_multipass(c, p, b->ctrl_done && nf != 0 && !b->ctl_started);
   b->level = 2; b->used_fused = false; b->used_cells = false;
   return ETLG_OK;
 }
@@ -2572,16 +2747,25 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
     p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
     const uint32_t ff = forced ? 8u : r0.fused_fail;
     forced = false;
+    if (c->ctl_stream) FB_HIP(hipStreamSynchronize(c->ctl_stream));   // (a pre-pass running ahead shares the scratch and the pinned heads with what follows)
     if (!c->pending.empty()) {   // batches behind this one may be running beside it (second stream) and chained to a result that is being replaced
       FB_HIP(sync_decode_streams(c));
-      for (etlg_batch* pb : c->pending) pb->force_rerun = true;
+      for (etlg_batch* pb : c->pending) { pb->force_rerun = true; if (pb->deferred) pb->ctl_started = false; }   // (a pre-pass that ran ahead started from a state that was not final)
     }
     FB_HIP(hipMemcpyAsync(b->d_res_blk, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
     if (b->copy.active) launch_copy(c, b->copy, p);
     if (ff & 8u) {  // the batch before this one failed, so this one never ran: same path again, now from the right state
       c->path_n[7]++;
-      FB_RC(build_side_inputs(c, b, std::vector<EpochRec>()));
-      FB_RC(enqueue_single(c, b, b->level));
+      if (b->ctl_async) {
+        // it took the control path: its control pass ran against a history that has changed. Back to the state before the batch —
+        // its own snapshot, unless a rollback since then has already discarded everything behind the failed batch — and again.
+        if (b->have_snapshot && b->snap_gen == c->cs_gen) { c->cs = b->snapshot; c->slots.resize(b->snapshot.n_slots); c->slots_dirty = true; c->side_dirty = true; }
+        b->ctrl_done = false; b->ctl_started = false; b->have_snapshot = false;
+        FB_RC(standard_path(c, b));
+      } else {
+        FB_RC(build_side_inputs(c, b, std::vector<EpochRec>()));
+        FB_RC(enqueue_single(c, b, b->level));
+      }
     } else if (b->level == 0) {  // the fixed-width plan did not cover the batch: generic kernel, and back off
       c->path_n[5]++;
       c->plan_skip = c->plan_penalty; c->plan_penalty = std::min<uint32_t>(c->plan_penalty * 2, 4096); c->plan_streak = 0;
@@ -2621,6 +2805,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
     if (later || b->host_err_code) {
       // roll back, then replay the prefix (rare path; errors end the stream anyway)
       c->cs = b->snapshot;
+      c->cs_gen++;
       c->slots.resize(b->snapshot.n_slots);
       c->slots_dirty = true; c->side_dirty = true;
       // Effects of the control frames before `frame` are re-applied from the copies of their bytes kept
@@ -2635,6 +2820,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
         for (int k = 0; k < 8; k++) wal_start = wal_start << 8 | fr[6 + k];
         if (cf.tag == 'R') (void)handle_relation(c, cf, fr + 31, flen - 31, eps); else (void)handle_ddl(c, cf, wal_start, fr + 31, flen - 31, eps);
       }
+      b->n_slots_view = c->slots.size();
     }
   }
   if (!b->user_no_ctrl) c->last_had_ctrl = b->ctrl_done && !b->ctrl.empty();
@@ -2654,6 +2840,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
   v.ev_start_lsn = (const uint64_t*)os->start.p; v.ev_commit_lsn = (const uint64_t*)os->commit.p; v.ev_tx_ordinal = (const uint64_t*)os->ord.p; v.ev_body_off = (const uint64_t*)os->body.p;
   v.fixed = (const uint8_t*)os->fixed.p; v.heap = (const uint8_t*)os->heap.p;
   b->pending = false; b->finished = true;
+  side_release(b);   // its kernels are done: the set may take the next change of the side inputs
   if (!b->out_dev) FB_RC(download_batch(c, b));
   fill_view_common(b);
   clear_error(c);

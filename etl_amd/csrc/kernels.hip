@@ -49,7 +49,12 @@ __global__ __launch_bounds__(kBlock) void k_classify(DecParams p) {
 __global__ __launch_bounds__(kBlock) void k_scan_txn(DecParams p) {
   __shared__ uint32_t lds[8];
   uint32_t run_cnt = 0;                 // (flag=0, count=0): identity for seg_combine
-  uint32_t run_mark = p.in_txn ? 1u : 0u;  // carried state: virtual Begin before frame 0
+  // carried state: virtual Begin before frame 0. flags bit 5 (the pre-pass of a pipelined control batch, host.cpp ctl_begin): the
+  // state is whatever the batch before this one left in ITS block (`carry`: a pre-pass block or a decode result block, complete by
+  // stream order), and this pre-pass leaves the state at its own end in `res` for the next one
+  const bool chained = (p.flags & 32u) && p.carry;
+  const uint32_t in0 = chained ? p.carry->out_in_txn : p.in_txn;
+  uint32_t run_mark = in0 ? 1u : 0u;
   for (uint32_t base = 0; base < p.nblocks; base += kBlock) {
     const uint32_t b = base + threadIdx.x;
     uint32_t c = b < p.nblocks ? p.blk_cnt[b] : 0, m = b < p.nblocks ? p.blk_last[b] : 0;
@@ -72,6 +77,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_txn(DecParams p) {
   if (threadIdx.x == 0) {  // totals at [nblocks]
     p.blk_cnt[p.nblocks] = run_cnt;
     p.blk_last[p.nblocks] = run_mark;
+    if (p.flags & 32u) {
+      const uint64_t lsn0 = chained ? p.carry->out_final_lsn : p.final_lsn;
+      p.res->out_in_txn = run_mark & 1u;
+      p.res->out_final_lsn = !(run_mark & 1u) ? 0ull : run_mark == 1u ? lsn0 : ld_be64(p.in + p.offs[(run_mark >> 1) - 1] + kBodyOff);
+    }
   }
 }
 
@@ -99,7 +109,7 @@ DEV TxnCtx txn_context(const DecParams& p, uint32_t f, uint32_t tag, uint32_t* l
   t.in_txn = (last & 1u) != 0;
   t.final_lsn = 0;
   if (t.in_txn) {
-    if (last == 1u) t.final_lsn = p.final_lsn;  // Begin came in a previous batch
+    if (last == 1u) t.final_lsn = ((p.flags & 32u) && p.carry) ? p.carry->out_final_lsn : p.final_lsn;  // Begin came in a previous batch
     else t.final_lsn = ld_be64(p.in + p.offs[(last >> 1) - 1] + kBodyOff);
   }
   const uint64_t c = seg & 0x7FFFFFFFu;

@@ -238,6 +238,12 @@ class Decoder:
         self.L.etlg_ctx_debug_overlapped.argtypes = [C.c_void_p]
         return int(self.L.etlg_ctx_debug_overlapped(self.h))
 
+    def debug_ctl_ahead(self):
+        """Batches whose control pre-pass ran ahead of their decode (ASYNC without NO_CONTROL on a stream with Relation / DDL frames)."""
+        self.L.etlg_ctx_debug_ctl_ahead.restype = C.c_ulonglong
+        self.L.etlg_ctx_debug_ctl_ahead.argtypes = [C.c_void_p]
+        return int(self.L.etlg_ctx_debug_ctl_ahead(self.h))
+
     def fence(self):
         """The context's stream waits (device side) for every ASYNC batch enqueued so far — decode kernels on the library's two
         decode streams and header copies (etlg_ctx_fence); call before enqueuing a consumer of their arenas / headers on it."""

@@ -305,3 +305,106 @@ def test_copy_decode_behind_batches_in_flight():
         assert not diff, f"batch {k}: {diff[:6]}"
         b.close()
     d.close()
+
+
+FLAGS_DEFAULT = abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC     # no NO_CONTROL assertion
+
+
+def _chain_default_flags(w, pieces, warm, ready=True):
+    """`warm` batches one at a time (each synced: the context learns whether the stream carries control frames), the rest
+    enqueued back to back and synced afterwards; every batch against the oracle."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o, ready=ready)
+    w.register(d, ready=ready)
+    dev = DevBufs(pieces)
+    want = []
+    for bb, ff in pieces:
+        rb = o.decode(bb, ff)
+        want.append((rb, rb.host_batch()))    # (the view lists the schema slots that exist NOW)
+
+    def check(k, b):
+        rc = b.sync()
+        rb, hb = want[k]
+        assert (rb.err_code != 0) == (rc != 0), f"batch {k}: oracle error {rb.err_code} vs rc {rc} ({b.error})"
+        if rb.err_code:
+            assert (b.error.code, b.error.frame_index) == (rb.err_code, rb.err_frame), f"batch {k}"
+        diff = hb.diff(b.host())
+        assert not diff, f"batch {k}: {diff[:6]}"
+        b.close()
+
+    for k in range(warm):
+        p, n, po, nf = dev.items[k]
+        check(k, d.decode_device(p, n, po, nf, FLAGS_DEFAULT))
+    infl = [d.decode_device(p, n, po, nf, FLAGS_DEFAULT) for (p, n, po, nf) in dev.items[warm:]]
+    for k, b in enumerate(infl):
+        check(warm + k, b)
+    paths = d.debug_paths()
+    paths["overlapped"] = d.debug_overlapped()
+    paths["ctl_ahead"] = d.debug_ctl_ahead()
+    d.close()
+    return paths
+
+
+def test_async_is_honoured_without_the_no_control_assertion():
+    """Default flags + ASYNC on a stream without Relation / DDL frames: the batches are chained on the device exactly like
+    NO_CONTROL ones (optimistic first attempt), none takes the control path."""
+    w = synth.cfg2()
+    buf, offs = w.fill(3 << 20)
+    paths = _chain_default_flags(w, _cut(buf, offs, 8, seed=7), warm=0)
+    assert paths["plan"] == 8 and paths["control"] == 0 and paths["chain_rerun"] == 0 and paths["overlapped"] >= 5, paths
+
+
+def test_async_control_stream_runs_its_pre_pass_ahead():
+    """cfg5 (Relation / DDL frames in every batch) with default flags + ASYNC: once the context has seen control frames, the
+    control pre-pass of batch k+1 runs ahead on the control stream and its host control plane while batch k is decoded; the
+    arenas, the schema slots the Relation messages create and the carried transaction state are the oracle's."""
+    w = synth.cfg5()
+    buf, offs = w.fill(3 << 20)
+    pieces = _cut(buf, offs, 9, seed=13)
+    paths = _chain_default_flags(w, pieces, warm=1, ready=False)
+    assert paths["ctl_ahead"] == 8 and paths["control"] >= 9 and paths["chain_rerun"] == 0, paths
+
+
+def test_async_control_stream_with_an_error_in_the_middle():
+    """... and with a malformed integer in batch 4: its error is the oracle's, its control-plane effects end at the failing
+    frame, and the batches behind it — whose pre-pass and control plane had already run — are decoded again from that state."""
+    w = synth.cfg5()
+    buf, offs = w.fill(3 << 20)
+    pieces = _cut(buf, offs, 9, seed=19)
+    b4, o4 = pieces[4]
+    k = int(o4[len(o4) // 2])
+    while not (b4[k + 30] == ord("I") and b4[k + 31 + 4] == ord("N") and b4[k + 31 + 7] == ord("t")):   # an Insert whose first cell is text-form
+        k = int(o4[np.searchsorted(o4, k, side="right")])
+    ln = int.from_bytes(b4[k + 39:k + 43].tobytes(), "big")
+    assert ln >= 1
+    b4[k + 43] = ord("x")       # first byte of the first cell (an integer key in every cfg5 table)
+    paths = _chain_default_flags(w, pieces, warm=1, ready=False)
+    assert paths["ctl_ahead"] >= 4 and paths["chain_rerun"] >= 1, paths
+
+
+def test_async_control_stream_with_a_ddl_message_the_host_rejects():
+    """A DDL message whose JSON does not parse, in a batch whose pre-pass ran ahead: the host control plane fails on that frame, the
+    batch is not run in the chain (it needs the multi-pass kernels with the exact carried state), the batches behind it stop, and
+    everything is decoded in order at sync time — error, frame and the events before it as the oracle has them."""
+    w = synth.cfg5()
+    buf, offs = w.fill(3 << 20)
+    pieces = _cut(buf, offs, 7, seed=31)
+    hit = False
+    for bi in (3, 4, 5):
+        bb, oo = pieces[bi]
+        for fi in range(len(oo) - 1):
+            k = int(oo[fi])
+            if bb[k + 30] == ord("M"):
+                body = bytes(bb[k:int(oo[fi + 1])])
+                j = body.find(b"{")
+                assert j > 0
+                bb[k + j] = ord("x")
+                hit = True
+                break
+        if hit:
+            break
+    assert hit
+    paths = _chain_default_flags(w, pieces, warm=1, ready=False)
+    assert paths["ctl_ahead"] >= 3 and paths["chain_rerun"] >= 1, paths
