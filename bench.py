@@ -355,50 +355,63 @@ def leg_copy(dev_id, dev, nrows, reps):
 
 
 def leg_handoff(dev_id, dev, cap, reps):
-    """the decoded cfg2 arena (device-resident) -> Arrow-layout column buffers (etlg_batch_columns) and
-    ClickHouse RowBinary rows (etlg_batch_rowbinary) and BigQuery protobuf rows (etlg_batch_protobuf), all left in HBM. Rates are quoted in WAL input bytes per second so
-    that they compare with `value`; the host-side hand-off of the same arena (etl_amd/arrow.py, numpy) is timed beside."""
+    """a decoded arena (device-resident) -> Arrow-layout column buffers (etlg_batch_columns), ClickHouse RowBinary rows
+    (etlg_batch_rowbinary) and BigQuery protobuf rows (etlg_batch_protobuf), all left in HBM — for a cfg2 batch (5 x int4) and, under
+    "cfg3", for BASELINE's var-len schema (TEXT, NUMERIC as its Display string, timestamptz, uuid; inserts + updates + deletes).
+    Rates are quoted in WAL input bytes per second so that they compare with `value`; the host-side hand-off of the same cfg2 arena
+    (etl_amd/arrow.py, numpy) is timed beside."""
     import numpy as np
     import torch
 
     from etl_amd import abi, synth
     from etl_amd.decoder import Decoder
-    w = synth.cfg2()
-    d = Decoder(dev_id)
-    w.register(d)
-    buf, offs = w.fill(cap)
-    tb = torch.from_numpy(buf.copy()).to(dev)
-    to = torch.from_numpy(offs.astype(np.uint32).view(np.int32).copy()).to(dev)
-    b = d.decode_device(tb.data_ptr(), tb.numel(), to.data_ptr(), len(offs) - 1, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
-    assert b.rc == 0
-    nc = 5
-    out = {"workload": f"one {cap >> 20} MiB cfg2 batch ({len(offs) - 1} frames), arena device-resident, outputs left in HBM"}
-    for name, fn in (("arrow_columns", lambda: b.columns(0, on_device=True)),
-                     ("rowbinary", lambda: b.rowbinary(0, [0] * nc + [0, 0], abi.CH_REPLACING_MERGE_TREE, on_device=True)),
-                     ("protobuf", lambda: b.protobuf(0, on_device=True))):
-        fn().close()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+
+    def one(mk, host_leg):
+        w = mk()
+        d = Decoder(dev_id)
+        w.register(d)
+        buf, offs = w.fill(cap)
+        tb = torch.from_numpy(buf.copy()).to(dev)
+        to = torch.from_numpy(offs.astype(np.uint32).view(np.int32).copy()).to(dev)
+        b = d.decode_device(tb.data_ptr(), tb.numel(), to.data_ptr(), len(offs) - 1, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
+        assert b.rc == 0
+        c0 = b.columns(0, on_device=True)
+        nc = int(c0.view.n_cols)
+        nullable = [1 if c0.column(i).nullable else 0 for i in range(nc)]   # Nullable() destination columns where the source column is
+        c0.close()
+        out = {"workload": f"one {cap >> 20} MiB {w.name} batch ({len(offs) - 1} frames), arena device-resident, outputs left in HBM"}
+        for name, fn in (("arrow_columns", lambda: b.columns(0, kinds=("I", "U"), on_device=True)),
+                         ("rowbinary", lambda: b.rowbinary(0, nullable + [0, 0], abi.CH_REPLACING_MERGE_TREE, on_device=True)),
+                         ("protobuf", lambda: b.protobuf(0, on_device=True))):
             r = fn()
-            nrows = r.n_rows
-            nbytes = int(r.view.n_bytes) if name != "arrow_columns" else sum(int(r.column(i).values_bytes) for i in range(nc))
+            assert name == "arrow_columns" or r.status == abi.RB_OK, "the slot must be encoded on the device"
             r.close()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        out[name] = {"value": round(len(buf) / dt / 1e9, 3), "unit": "GB/s", "ms": round(dt * 1e3, 3), "rows": nrows,
-                     "rows_per_s": round(nrows / dt, 1), "out_bytes": nbytes}
-    # the host path the device one replaces: download the arena, numpy gathers per column
-    from etl_amd.arrow import rows_to_record_batch
-    t0 = time.perf_counter()
-    hb = b.host()
-    t1 = time.perf_counter()
-    rb = rows_to_record_batch(hb, 0)
-    t2 = time.perf_counter()
-    out["host_numpy"] = {"value": round(len(buf) / (t2 - t0) / 1e9, 3), "unit": "GB/s", "download_ms": round((t1 - t0) * 1e3, 2),
-                         "gather_ms": round((t2 - t1) * 1e3, 2), "rows": rb.num_rows}
-    b.close()
-    d.close()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+                nrows = r.n_rows
+                nbytes = int(r.view.n_bytes) if name != "arrow_columns" else sum(int(r.column(i).values_bytes) for i in range(nc))
+                r.close()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            out[name] = {"value": round(len(buf) / dt / 1e9, 3), "unit": "GB/s", "ms": round(dt * 1e3, 3), "rows": nrows,
+                         "rows_per_s": round(nrows / dt, 1), "out_bytes": nbytes}
+        if host_leg:   # the host path the device one replaces: download the arena, numpy gathers per column
+            from etl_amd.arrow import rows_to_record_batch
+            t0 = time.perf_counter()
+            hb = b.host()
+            t1 = time.perf_counter()
+            rb = rows_to_record_batch(hb, 0)
+            t2 = time.perf_counter()
+            out["host_numpy"] = {"value": round(len(buf) / (t2 - t0) / 1e9, 3), "unit": "GB/s", "download_ms": round((t1 - t0) * 1e3, 2),
+                                 "gather_ms": round((t2 - t1) * 1e3, 2), "rows": rb.num_rows}
+        b.close()
+        d.close()
+        return out
+
+    out = one(synth.cfg2, True)
+    out["cfg3"] = one(synth.cfg3, False)
     return out
 
 

@@ -35,6 +35,7 @@ fn kind_of(k: i32) -> ErrorKind {
         ETLG_DeserializationError => ErrorKind::DeserializationError,
         ETLG_SourceConnectionFailed => ErrorKind::SourceConnectionFailed,
         ETLG_IoError => ErrorKind::IoError,
+        ETLG_UnsupportedValueInDestination => ErrorKind::UnsupportedValueInDestination,
         _ => ErrorKind::Unknown,
     }
 }

@@ -19,6 +19,7 @@ CorruptedTableSchema = 6
 DeserializationError = 7
 SourceConnectionFailed = 8
 IoError = 9
+UnsupportedValueInDestination = 10
 InvalidArgument = 100
 DeviceError = 101
 Unsupported = 102
@@ -28,7 +29,7 @@ KIND_NAMES = {
     ValidationError: "ValidationError", InvalidState: "InvalidState",
     MissingTableSchema: "MissingTableSchema", CorruptedTableSchema: "CorruptedTableSchema",
     DeserializationError: "DeserializationError", SourceConnectionFailed: "SourceConnectionFailed",
-    IoError: "IoError", InvalidArgument: "InvalidArgument", DeviceError: "DeviceError",
+    IoError: "IoError", UnsupportedValueInDestination: "UnsupportedValueInDestination", InvalidArgument: "InvalidArgument", DeviceError: "DeviceError",
     Unsupported: "Unsupported",
 }
 

@@ -12,9 +12,11 @@ Python. This module does that with numpy and hands the buffers to pyarrow, follo
     Date -> Date32 (days since 1970-01-01, :194) | Time -> Time64(us) (:201)
     Timestamp -> Timestamp(us) (:208) | TimestampTz -> Timestamp(us, "UTC") (:215) | Uuid -> FixedSizeBinary(16)
 
-Columns whose class the device hands back as text (numeric digits, json, arrays, DEFERRED cells) have no
-fixed-width Arrow form here: `on_text="binary"` emits their heap entries as LargeBinary for the host to finish,
-the default raises; timetz values (decoded in the arena, a display string in the reference) always raise. Works on any `HostBatch` (the HIP path's or the oracle's — they are byte-identical).
+    Numeric, TimeTz -> Utf8 of their Display strings (cell_to_string, :349-352: `n.to_string()`, `t.to_string()`)
+
+Columns whose class the device hands back as text (json, arrays, DEFERRED cells) have no fixed-width Arrow form here:
+`on_text="binary"` emits their heap entries as LargeBinary for the host to finish, the default raises. Works on any `HostBatch`
+(the HIP path's or the oracle's — they are byte-identical).
 """
 import numpy as np
 
@@ -77,11 +79,14 @@ def rows_to_record_batch(hb, slot_index, names=None, kinds=("I",), on_text="rais
         mask = ~valid
         so = base + col.off_full
         tc = col.type_class
-        if tc == abi.TC_TIMETZ and np.any(valid):
-            # the reference hands TimeTz to Arrow as its display string (cell_to_string :352); the arena holds it decoded
-            # (second of day, nanos, utc offset) and formatting is per-row work this module does not do
-            raise NotImplementedError(f"column {name}: timetz values are not handed off (select other columns with columns=)")
-        textual = tc not in _FIXED and tc not in (abi.TC_STRING, abi.TC_BYTEA)   # numeric digits, json, arrays, ...
+        if tc in (abi.TC_TIMETZ, abi.TC_NUMERIC) and not np.any(deferred):
+            # Display strings in the reference (cell_to_string :349-352); per-row formatting on this host path
+            # (etlg_batch_columns formats them on the device)
+            arr = pa.array(_display_strings(hb, fx, so, valid, tc), type=pa.string())
+            arrays.append(arr)
+            fields.append(pa.field(name, arr.type, nullable=bool(col.nullable)))
+            continue
+        textual = tc not in _FIXED and tc not in (abi.TC_STRING, abi.TC_BYTEA)   # json, arrays, ...
         if np.any(deferred) or textual:
             if on_text != "binary":
                 raise NotImplementedError(f"column {name} (type class {tc}): text-form cells (numeric / json / arrays / deferred) "
@@ -122,7 +127,7 @@ def columns_to_record_batch(cols, names=None, columns=None, on_text="raise"):
         k = cols.column(i)
         name = names[i] if names else f"c{i}"
         if k.arrow_kind == abi.AK_NONE:
-            raise NotImplementedError(f"column {name}: timetz values are not handed off (select other columns with columns=)")
+            raise NotImplementedError(f"column {name}: not handed off (select other columns with columns=)")
         if (k.arrow_kind == abi.AK_TEXT_FORM or (k.deferred_count and k.arrow_kind != abi.AK_LIST)) and on_text != "binary":
             raise NotImplementedError(f"column {name} (type class {k.type_class}): text-form cells (numeric / json / arrays / deferred) "
                                       "have no fixed-width Arrow form; pass on_text='binary' (deferred cells of a fixed-width "
@@ -147,6 +152,23 @@ def columns_to_record_batch(cols, names=None, columns=None, on_text="raise"):
         arrays.append(arr)
         fields.append(pa.field(name, t, nullable=bool(k.nullable)))
     return pa.RecordBatch.from_arrays(arrays, schema=pa.schema(fields))
+
+
+def _display_strings(hb, fx, so, valid, tc):
+    import struct
+    from .view import numeric_to_string, timetz_to_string
+    out = []
+    for i in range(len(so)):
+        if not valid[i]:
+            out.append(None)
+        elif tc == abi.TC_TIMETZ:
+            out.append(timetz_to_string(*struct.unpack_from("<IIi", fx, int(so[i]))))
+        else:
+            off, ln = struct.unpack_from("<II", fx, int(so[i]))
+            raw = hb.heap[off:off + ln].tobytes()
+            kind, sign, weight, scale, _nd = struct.unpack_from("<BBhHH", raw, 0)
+            out.append(numeric_to_string(kind, sign, weight, scale, struct.unpack_from(f"<{(ln - 8) // 2}h", raw, 8)))
+    return out
 
 
 def _validity(pa, valid):

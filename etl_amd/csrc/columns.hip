@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_col_rows(ColSel s) {
 }
 
 enum : uint32_t { AK_BOOL = 0, AK_I32 = 1, AK_I64 = 2, AK_F32 = 3, AK_F64 = 4, AK_DATE32 = 5, AK_TIME64 = 6, AK_TS = 7, AK_TSTZ = 8, AK_FIXED16 = 9,
-                  AK_UTF8 = 10, AK_BINARY = 11, AK_TEXT_FORM = 12, AK_NONE = 255 };
+                  AK_UTF8 = 10, AK_BINARY = 11, AK_TEXT_FORM = 12, AK_NUMERIC_STR = 14, AK_TIMETZ_STR = 15, AK_NONE = 255 };   // 14 / 15: internal (host.cpp ColPlan.fmt), LargeUtf8 to the caller
 constexpr int32_t kCeDays1970 = 719163;  // chrono num_days_from_ce of 1970-01-01
 
 DEV uint32_t col_state(const ColJob& j, uint64_t base) { return (j.fixed[base + j.col_index / 4] >> (2 * (j.col_index % 4))) & 3u; }
@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void k_col_fixed(ColJob j) {
   }
 }
 
+DEV uint32_t numeric_str_len(const u8* ent);
+DEV uint32_t timetz_str_len(const u8* slot);
 // var-len columns, pass 1: validity / deferred words + the byte length of every row's entry
 __global__ __launch_bounds__(256) void k_col_lens(ColJob j) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -130,7 +132,10 @@ __global__ __launch_bounds__(256) void k_col_lens(ColJob j) {
     st = col_state(j, b);
     // text-form columns hand over DEFERRED entries too (their heap entry is the source text)
     const bool has = st == ETLG_CELL_VALUE || (j.kind == AK_TEXT_FORM && st == ETLG_CELL_DEFERRED);
-    if (has) len = ld32a(j.fixed + b + j.off_full + 4);
+    if (has) {
+      const u8* slot = j.fixed + b + j.off_full;
+      len = j.kind == AK_NUMERIC_STR ? numeric_str_len(j.heap + ld32a(slot)) : j.kind == AK_TIMETZ_STR ? timetz_str_len(slot) : ld32a(slot + 4);
+    }
     j.lens[r] = len;
   }
   const bool valid = live && (st == ETLG_CELL_VALUE || (j.kind == AK_TEXT_FORM && st == ETLG_CELL_DEFERRED));
@@ -351,9 +356,107 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
   if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
 }
 
+// ---- Display strings of the classes every sink writes as text: PgNumeric (format_numeric_value,
+// crates/etl-postgres/src/numeric.rs:460-560), PgTimeTz (etl-postgres/src/time.rs:113-117 + write_utc_offset :210-225) and
+// chrono's "%H:%M:%S%.f" (TIME_FORMAT, time.rs:17). `ent`: the numeric's heap entry (etlg_numeric_hdr + i16 digits, 4-byte aligned).
+// All of them are written through the same count / write sinks as the rows (RbCount / RbWrite below), so a length is the
+// count of the very code that later writes the bytes — except the numeric's, which has a closed form (a scale can be 16383).
+DEV uint32_t num_digit(const u8* ent, uint32_t i) { return (uint32_t)ent[8 + 2 * i] | ((uint32_t)ent[9 + 2 * i] << 8); }
+DEV uint32_t numeric_str_len(const u8* ent) {
+  const uint32_t kind = ent[0];
+  if (kind == ETLG_NUM_NAN) return 3;        // "NaN"
+  if (kind == ETLG_NUM_PINF) return 8;       // "Infinity"
+  if (kind == ETLG_NUM_NINF) return 9;       // "-Infinity"
+  const int32_t weight = (int16_t)((uint32_t)ent[2] | ((uint32_t)ent[3] << 8));
+  const uint32_t scale = (uint32_t)ent[4] | ((uint32_t)ent[5] << 8), nd = (uint32_t)ent[6] | ((uint32_t)ent[7] << 8);
+  const uint32_t frac = scale ? 1u + scale : 0u;
+  if (!nd) return 1u + frac;                 // zero keeps its display scale (:492-503)
+  uint32_t n = ent[1] ? 1u : 0u;
+  if (weight < 0) n += 1u;
+  else { const uint32_t d0 = num_digit(ent, 0); n += (d0 >= 1000 ? 4u : d0 >= 100 ? 3u : d0 >= 10 ? 2u : 1u) + 4u * (uint32_t)weight; }
+  return n + frac;
+}
+template <class S> DEV void put_4d(S& s, uint32_t v) { s.put((u8)('0' + v / 1000 % 10)); s.put((u8)('0' + v / 100 % 10)); s.put((u8)('0' + v / 10 % 10)); s.put((u8)('0' + v % 10)); }
+template <class S>
+DEV void numeric_str(S& s, const u8* ent) {
+  const uint32_t kind = ent[0];
+  if (kind != ETLG_NUM_VALUE) {
+    const char* t = kind == ETLG_NUM_NAN ? "NaN" : kind == ETLG_NUM_PINF ? "Infinity" : "-Infinity";
+    for (; *t; t++) s.put((u8)*t);
+    return;
+  }
+  const int32_t weight = (int16_t)((uint32_t)ent[2] | ((uint32_t)ent[3] << 8));
+  const uint32_t scale = (uint32_t)ent[4] | ((uint32_t)ent[5] << 8), nd = (uint32_t)ent[6] | ((uint32_t)ent[7] << 8);
+  if (!nd) {
+    s.put('0');
+    if (scale) { s.put('.'); for (uint32_t k = 0; k < scale; k++) s.put('0'); }
+    return;
+  }
+  if (ent[1]) s.put('-');
+  if (weight < 0) s.put('0');
+  else {
+    for (int32_t d = 0; d <= weight; d++) {
+      const uint32_t g = (uint32_t)d < nd ? num_digit(ent, (uint32_t)d) : 0u;
+      if (d == 0) {  // the first group without its leading zeros (:517-524)
+        if (g >= 1000) s.put((u8)('0' + g / 1000 % 10));
+        if (g >= 100) s.put((u8)('0' + g / 100 % 10));
+        if (g >= 10) s.put((u8)('0' + g / 10 % 10));
+        s.put((u8)('0' + g % 10));
+      } else put_4d(s, g);
+    }
+  }
+  if (scale) {
+    s.put('.');
+    // `let mut d = weight + 1` is i16 arithmetic in the reference (:535): at weight = i16::MAX a release build wraps to
+    // i16::MIN and prints zeros; restated as such
+    int32_t d = (int16_t)(weight + 1);
+    for (uint32_t rem = scale; rem; d++) {
+      const uint32_t g = (d >= 0 && (uint32_t)d < nd) ? num_digit(ent, (uint32_t)d) : 0u;
+      const uint32_t take = rem < 4 ? rem : 4u;
+      uint32_t div = 1000;
+      for (uint32_t k = 0; k < take; k++, div /= 10) s.put((u8)('0' + g / div % 10));
+      rem -= take;
+    }
+  }
+}
+template <class S> DEV void put_2d(S& s, uint32_t v) { s.put((u8)('0' + v / 10)); s.put((u8)('0' + v % 10)); }
+// chrono's %.f prints nothing, or 3 / 6 / 9 digits; a leap second is kept as nanos >= 10^9 on second 59 and printed as :60
+DEV uint32_t time_frac_len(uint32_t nanos) { nanos = nanos >= 1000000000u ? nanos - 1000000000u : nanos; return nanos == 0 ? 0u : nanos % 1000000u == 0 ? 4u : nanos % 1000u == 0 ? 7u : 10u; }
+template <class S> DEV void time_str(S& s, uint32_t secs, uint32_t nanos) {
+  const uint32_t leap = nanos >= 1000000000u ? 1u : 0u;
+  nanos -= leap * 1000000000u;
+  put_2d(s, secs / 3600); s.put(':'); put_2d(s, secs / 60 % 60); s.put(':'); put_2d(s, secs % 60 + leap);
+  const uint32_t frac = time_frac_len(nanos);
+  if (frac) {
+    s.put('.');
+    uint32_t v = frac == 4 ? nanos / 1000000u : frac == 7 ? nanos / 1000u : nanos, div = frac == 4 ? 100u : frac == 7 ? 100000u : 100000000u;
+    for (; div; div /= 10) s.put((u8)('0' + v / div % 10));
+  }
+}
+DEV uint32_t utc_offset_len(int32_t off) { const uint32_t a = (uint32_t)(off < 0 ? -off : off); return a % 60 ? 9u : a % 3600 ? 6u : 3u; }
+template <class S> DEV void utc_offset_str(S& s, int32_t off) {   // +HH | +HH:MM | +HH:MM:SS (write_utc_offset)
+  const uint32_t a = (uint32_t)(off < 0 ? -off : off);
+  s.put(off < 0 ? '-' : '+');
+  put_2d(s, a / 3600);
+  if (a % 60) { s.put(':'); put_2d(s, a % 3600 / 60); s.put(':'); put_2d(s, a % 60); }
+  else if (a % 3600) { s.put(':'); put_2d(s, a % 3600 / 60); }
+}
+DEV uint32_t timetz_str_len(const u8* slot) { return 8u + time_frac_len(ld32a(slot + 4)) + utc_offset_len((int32_t)ld32a(slot + 8)); }
+template <class S> DEV void timetz_str(S& s, const u8* slot) { time_str(s, ld32a(slot), ld32a(slot + 4)); utc_offset_str(s, (int32_t)ld32a(slot + 8)); }
+
+struct StrWrite { u8* p; DEV void put(u8 b) { *p++ = b; } };
+// formatted string columns (numeric, timetz), pass 2: one thread per row writes its Display string at its offset
+__global__ __launch_bounds__(256) void k_col_fmt(ColJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= j.n_rows || !j.lens[r]) return;
+  const u8* slot = j.fixed + j.row_base[r] + j.off_full;
+  StrWrite w{j.values + j.offsets[r]};
+  if (j.kind == AK_NUMERIC_STR) numeric_str(w, j.heap + ld32a(slot)); else timetz_str(w, slot);
+}
+
 // ---- ClickHouse RowBinary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83 which wire type a Cell becomes,
 // :188-283 the byte format; core.rs:96-114 the trailing CDC columns). One thread per row, run twice: lengths, then bytes.
-enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3 };
+enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3, RB_E_BQ_NUMERIC_SCALE = 4 };
 constexpr int32_t kDate32Min = -25567, kDate32Max = 120529;   // 1900-01-01 .. 2299-12-31 (encoding.rs:147-173)
 
 struct RbCount {
@@ -384,7 +487,7 @@ DEV void rb_varint(S& s, uint32_t v) {   // LEB128 (:188-199)
 }
 
 template <class S>
-DEV void rb_2d(S& s, uint32_t v) { s.put((u8)('0' + v / 10)); s.put((u8)('0' + v % 10)); }
+DEV void rb_2d(S& s, uint32_t v) { put_2d(s, v); }
 
 // One non-null value of class `cls` whose arena slot words start at `slot` (a row's slot, or the words decode_text_cell produced for
 // an array element). Returns 0, RB_E_DATE_RANGE or RB_E_HOST_CELL.
@@ -402,17 +505,12 @@ DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
       s.put32((uint32_t)days); return 0;
     }
     case ETLG_TC_TIME: {  // String(t.to_string()): chrono NaiveTime Display
-      const uint32_t secs = w0, nanos = ld32a(slot + 4);
-      const uint32_t frac = nanos == 0 ? 0u : nanos % 1000000u == 0 ? 4u : nanos % 1000u == 0 ? 7u : 10u;
-      rb_varint(s, 8 + frac);
-      rb_2d(s, secs / 3600); s.put(':'); rb_2d(s, secs / 60 % 60); s.put(':'); rb_2d(s, secs % 60);
-      if (frac) {
-        s.put('.');
-        uint32_t v = frac == 4 ? nanos / 1000000u : frac == 7 ? nanos / 1000u : nanos, div = frac == 4 ? 100u : frac == 7 ? 100000u : 100000000u;
-        for (; div; div /= 10) s.put((u8)('0' + v / div % 10));
-      }
+      const uint32_t nanos = ld32a(slot + 4);
+      rb_varint(s, 8 + time_frac_len(nanos)); time_str(s, w0, nanos);
       return 0;
     }
+    case ETLG_TC_TIMETZ: rb_varint(s, timetz_str_len(slot)); timetz_str(s, slot); return 0;   // String(t.to_string()) (encoding.rs:71)
+    case ETLG_TC_NUMERIC: if (!heap) return RB_E_HOST_CELL; { const u8* ent = heap + w0; rb_varint(s, numeric_str_len(ent)); numeric_str(s, ent); return 0; }   // String(n.to_string()) (:66)
     case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: {
       const int64_t days = (int64_t)(int32_t)w0 - kCeDays1970;
       s.put64((uint64_t)((days * 86400 + (int64_t)ld32a(slot + 4)) * 1000000 + (int64_t)(ld32a(slot + 8) / 1000u))); return 0;
@@ -422,7 +520,7 @@ DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
       return 0;
     case ETLG_TC_STRING: if (!heap) return RB_E_HOST_CELL; { const uint32_t len = ld32a(slot + 4); rb_varint(s, len); s.bytes(heap + w0, len); return 0; }
     case ETLG_TC_BYTEA: if (!heap) return RB_E_HOST_CELL; { const uint32_t len = ld32a(slot + 4); rb_varint(s, 2 * len); s.hex(heap + w0, len); return 0; }
-    default: return RB_E_HOST_CELL;   // numeric / timetz / json: Display strings the host writes
+    default: return RB_E_HOST_CELL;   // json: serde_json's normalised Display, the host writes it
   }
 }
 
@@ -514,18 +612,6 @@ template <class S> DEV void pb_date(S& s, int32_t days_ce) {
   const int64_t y = (int64_t)yoe + era * 400 + (m <= 2 ? 1 : 0);
   pb_4d(s, (uint32_t)y); s.put('-'); rb_2d(s, m); s.put('-'); rb_2d(s, d);
 }
-DEV uint32_t pb_frac_len(uint32_t nanos) { return nanos == 0 ? 0u : nanos % 1000000u == 0 ? 4u : nanos % 1000u == 0 ? 7u : 10u; }
-// "%H:%M:%S%.f" (TIME_FORMAT :17): chrono prints no fraction, or 3 / 6 / 9 digits
-template <class S> DEV void pb_time(S& s, uint32_t secs, uint32_t nanos) {
-  rb_2d(s, secs / 3600); s.put(':'); rb_2d(s, secs / 60 % 60); s.put(':'); rb_2d(s, secs % 60);
-  const uint32_t frac = pb_frac_len(nanos);
-  if (frac) {
-    s.put('.');
-    uint32_t v = frac == 4 ? nanos / 1000000u : frac == 7 ? nanos / 1000u : nanos, div = frac == 4 ? 100u : frac == 7 ? 100000u : 100000000u;
-    for (; div; div /= 10) s.put((u8)('0' + v / div % 10));
-  }
-}
-
 template <class S>
 DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
   const uint64_t base = j.row_base[r];
@@ -545,10 +631,10 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
       case ETLG_TC_F64: pb_key(s, tag, 1); s.put64(((uint64_t)ld32a(slot + 4) << 32) | w0); break;
       case ETLG_TC_STRING: case ETLG_TC_BYTEA: { const uint32_t len = ld32a(slot + 4); pb_key(s, tag, 2); s.varint64(len); s.bytes(j.heap + w0, len); break; }
       case ETLG_TC_DATE: pb_key(s, tag, 2); s.varint64(10); pb_date(s, (int32_t)w0); break;
-      case ETLG_TC_TIME: { const uint32_t ns = ld32a(slot + 4); pb_key(s, tag, 2); s.varint64(8 + pb_frac_len(ns)); pb_time(s, w0, ns); break; }
+      case ETLG_TC_TIME: { const uint32_t ns = ld32a(slot + 4); pb_key(s, tag, 2); s.varint64(8 + time_frac_len(ns)); time_str(s, w0, ns); break; }
       case ETLG_TC_TIMESTAMP: {  // "%Y-%m-%d %H:%M:%S%.f" (TIMESTAMP_FORMAT :21)
         const uint32_t secs = ld32a(slot + 4), ns = ld32a(slot + 8);
-        pb_key(s, tag, 2); s.varint64(19 + pb_frac_len(ns)); pb_date(s, (int32_t)w0); s.put(' '); pb_time(s, secs, ns); break;
+        pb_key(s, tag, 2); s.varint64(19 + time_frac_len(ns)); pb_date(s, (int32_t)w0); s.put(' '); time_str(s, secs, ns); break;
       }
       case ETLG_TC_TIMESTAMPTZ: {  // epoch microseconds as int64 (:176-179)
         const int64_t days = (int64_t)(int32_t)w0 - kCeDays1970;
@@ -562,7 +648,13 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
           s.put((u8)(h < 10 ? '0' + h : 'a' + h - 10)); s.put((u8)(l < 10 ? '0' + l : 'a' + l - 10));
         }
         break;
-      default: return (i << 8) | RB_E_HOST_CELL;   // numeric / timetz / json / arrays: host-formatted strings, host-side validation
+      case ETLG_TC_TIMETZ: pb_key(s, tag, 2); s.varint64(timetz_str_len(slot)); timetz_str(s, slot); break;   // t.to_string() (:158-161)
+      case ETLG_TC_NUMERIC: {  // n.to_string() (:146-149) behind validate_numeric_for_bigquery (bigquery/validation.rs:20-35): more than 38 decimal places would be rounded
+        const u8* ent = j.heap + w0;
+        if (ent[0] == ETLG_NUM_VALUE && ((uint32_t)ent[4] | ((uint32_t)ent[5] << 8)) > 38u) return (i << 8) | RB_E_BQ_NUMERIC_SCALE;
+        pb_key(s, tag, 2); s.varint64(numeric_str_len(ent)); numeric_str(s, ent); break;
+      }
+      default: return (i << 8) | RB_E_HOST_CELL;   // json / arrays: serde_json's Display, packed / repeated fields, host-side validation
     }
   }
   const uint64_t ev = j.row_event[r];
@@ -674,7 +766,8 @@ void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, i
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
     hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
   } else {
-    hipLaunchKernelGGL(k_col_copy, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
+    if (j.kind == AK_NUMERIC_STR || j.kind == AK_TIMETZ_STR) hipLaunchKernelGGL(k_col_fmt, dim3(nb), dim3(256), 0, st, j);
+    else hipLaunchKernelGGL(k_col_copy, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
   }
 }
 

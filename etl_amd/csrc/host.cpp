@@ -1779,7 +1779,7 @@ void etlg_batch_free(etlg_batch* b) {
 extern "C++" {
 // ---- columnar hand-off (columns.hip)
 namespace {
-struct ColPlan { uint32_t kind, vbytes; bool var; uint32_t child = 0, child_bytes = 0, elem = 0; };
+struct ColPlan { uint32_t kind, vbytes; bool var; uint32_t child = 0, child_bytes = 0, elem = 0, fmt = 0; };   // fmt: the kernels' internal kind of a formatted string column (columns.hip AK_*_STR)
 ColPlan list_plan(uint32_t elem) {  // array literals the device parses: element classes with a fixed-width value
   switch (elem) {
     case ETLG_TC_BOOL: return {ETLG_AK_LIST, 0, true, ETLG_AK_BOOLEAN, 0, elem};
@@ -1810,7 +1810,9 @@ ColPlan col_plan(uint32_t cls) {
     case ETLG_TC_UUID: return {ETLG_AK_FIXED16, 16, false};
     case ETLG_TC_STRING: return {ETLG_AK_LARGE_UTF8, 0, true};
     case ETLG_TC_BYTEA: return {ETLG_AK_LARGE_BINARY, 0, true};
-    case ETLG_TC_TIMETZ: return {ETLG_AK_NONE, 0, false};
+    // Display strings in every sink (cell_to_string, iceberg/encoding.rs:349-352; n.to_string() / t.to_string()): formatted on the device
+    case ETLG_TC_NUMERIC: return {ETLG_AK_LARGE_UTF8, 0, true, 0, 0, 0, 14u};
+    case ETLG_TC_TIMETZ: return {ETLG_AK_LARGE_UTF8, 0, true, 0, 0, 0, 15u};
     default: return {ETLG_AK_TEXT_FORM, 0, true};
   }
 }
@@ -1888,7 +1890,7 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
     ColJob& j = jobs[i];
     j = ColJob{};
     j.fixed = bv.fixed; j.heap = bv.heap; j.row_base = d_row_base; j.n_rows = n;
-    j.col_index = i; j.off_full = sh.cols[i].off_full; j.cls = sh.cols[i].type_class; j.kind = l.pl.kind;
+    j.col_index = i; j.off_full = sh.cols[i].off_full; j.cls = sh.cols[i].type_class; j.kind = l.pl.fmt ? l.pl.fmt : l.pl.kind;
     j.validity = (unsigned long long*)(A + l.validity); j.deferred = (unsigned long long*)(A + l.deferred);
     j.null_count = (unsigned long long*)(A + o_cnt + (size_t)i * 32); j.deferred_count = j.null_count + 1;
     j.child_nulls = j.null_count + 2; j.err = j.null_count + 3; j.elem_cls = l.pl.elem;
@@ -2098,7 +2100,7 @@ static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint
   for (uint32_t i = 0; i < nc; i++) {
     const uint32_t cls = sh.cols[i].type_class;
     uint32_t elem = 0;
-    bool host_class = col_plan(cls).kind == ETLG_AK_TEXT_FORM || cls == ETLG_TC_TIMETZ;   // a Display string in the reference: the host writes it
+    bool host_class = col_plan(cls).kind == ETLG_AK_TEXT_FORM;   // json (serde_json's normalised Display): the host writes it. numeric / timetz Display strings are formatted on the device
     if (format == 1 && cls == ETLG_TC_ARRAY) host_class = true;   // packed / repeated array fields + NULL-element validation: the host's
     else if (cls == ETLG_TC_ARRAY) {  // arrays of fixed-width elements are encoded on the device (Array(Nullable(T)))
       elem = (uint32_t)etlg_array_elem_class(sh.cols[i].type_oid);
@@ -2176,6 +2178,13 @@ static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint
       blk_give(c, c->gen, rb->m.d_a, rb->m.cap_a, false); rb->m.d_a = nullptr;
       *out = rb.release();
       return ETLG_OK;
+    }
+    if (code == 4) {  // BigQueryTableRow::try_from_tagged_cells (bigquery/encoding.rs:37-45) around validate_numeric_for_bigquery (validation.rs:20-35)
+      const int32_t k = lib_error(c, ETLG_UnsupportedValueInDestination, "Cell validation failed for BigQuery compatibility");
+      c->err_detail = "Cell at index " + std::to_string(col) + " failed validation";
+      c->err.detail = c->err_detail.c_str();
+      c->err.frame_index = (int64_t)ev;
+      return k;
     }
     const int32_t k = lib_error(c, ETLG_ConversionError, code == 1 ? "NULL value for non-nullable ClickHouse column" : "Date out of ClickHouse Date32 range");
     c->err.frame_index = (int64_t)ev;

@@ -23,6 +23,41 @@ def _np_from(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+def numeric_to_string(kind, sign, weight, scale, digits):
+    """`PgNumeric`'s Display (crates/etl-postgres/src/numeric.rs:460-560) for a materialised ("Numeric", ...) cell: what every
+    sink of the reference writes for it (`n.to_string()`). The integer part is groups 0..=weight (base 10000, the first one
+    without leading zeros), the fraction the next ceil(scale / 4) groups cut to `scale` digits; missing groups are zeros."""
+    if kind != 0:
+        return ("NaN", "Infinity", "-Infinity")[kind - 1]
+    if not digits:
+        return "0" + ("." + "0" * scale if scale else "")
+    nd = len(digits)
+    whole = "0" if weight < 0 else str(digits[0]) + "".join("%04d" % (digits[d] if d < nd else 0) for d in range(1, weight + 1))
+    out = ("-" if sign else "") + whole
+    if scale:
+        first = ((weight + 1 + 0x8000) & 0xFFFF) - 0x8000   # the reference computes `weight + 1` on an i16
+        groups = -(-scale // 4)
+        frac = "".join("%04d" % (digits[d] if 0 <= d < nd else 0) for d in range(first, first + groups))
+        out += "." + frac[:scale]
+    return out
+
+
+def timetz_to_string(secs, nanos, offset):
+    """`PgTimeTz`'s Display (crates/etl-postgres/src/time.rs:113-117, write_utc_offset :210-225): chrono's %H:%M:%S%.f (no
+    fraction, or 3 / 6 / 9 digits; a leap second is second 60) + the offset as +HH, +HH:MM or +HH:MM:SS."""
+    leap = nanos >= 1_000_000_000
+    ns = nanos - 1_000_000_000 if leap else nanos
+    t = "%02d:%02d:%02d" % (secs // 3600, secs // 60 % 60, secs % 60 + (1 if leap else 0))
+    if ns:
+        t += ".%03d" % (ns // 1_000_000) if ns % 1_000_000 == 0 else ".%06d" % (ns // 1000) if ns % 1000 == 0 else ".%09d" % ns
+    a = abs(offset)
+    t += ("-" if offset < 0 else "+") + "%02d" % (a // 3600)
+    if a % 60:
+        t += ":%02d:%02d" % (a % 3600 // 60, a % 60)
+    elif a % 3600:
+        t += ":%02d" % (a % 3600 // 60)
+    return t
+
 @dataclass
 class SlotCol:
     type_oid: int

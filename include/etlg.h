@@ -74,6 +74,7 @@ typedef enum etlg_error_kind {
   ETLG_SourceConnectionFailed = 8, /* wire-level parse failure: tokio_postgres::Error
                                       without SQLSTATE (error.rs:947) */
   ETLG_IoError = 9,                /* io::Error from cstr accessors (error.rs:564) */
+  ETLG_UnsupportedValueInDestination = 10, /* error.rs:136; only from etlg_batch_protobuf (bigquery/validation.rs) */
   /* library-level (no reference analog) */
   ETLG_InvalidArgument = 100,
   ETLG_DeviceError = 101,
@@ -506,13 +507,14 @@ typedef enum etlg_arrow_kind {
   ETLG_AK_FIXED16 = 9,      /* uuid: FixedSizeBinary(16) */
   ETLG_AK_LARGE_UTF8 = 10,  /* i64 offsets + bytes */
   ETLG_AK_LARGE_BINARY = 11,
-  ETLG_AK_TEXT_FORM = 12,   /* numeric / json / arrays: the cell's heap entry (etlg_numeric_hdr + digits, or
-                             * the source text), i64 offsets + bytes; the host finishes it */
+  ETLG_AK_TEXT_FORM = 12,   /* json / arrays: the cell's heap entry (the source text), i64 offsets + bytes; the host finishes it.
+                             * (numeric and timetz columns are ETLG_AK_LARGE_UTF8 of their Display strings — `n.to_string()`,
+                             * `t.to_string()`, cell_to_string encoding.rs:349-352 — formatted on the device) */
   ETLG_AK_LIST = 13,        /* only with ETLG_ROWS_PARSE_ARRAYS: arrays of bool / int2 / int4 / int8 / oid / float4 / float8 / date / time /
                              * timestamp / timestamptz / uuid / text elements parsed on the device
                              * (parse_cell_from_postgres_text_array, codec/text.rs:228-312): i64 list offsets in `offsets`,
                              * child values in `values` (child_kind layout), child validity in `child_validity` */
-  ETLG_AK_NONE = 255        /* not handed off (timetz: a display string in the reference) - no buffers */
+  ETLG_AK_NONE = 255        /* not handed off - no buffers (no class maps to it today) */
 } etlg_arrow_kind;
 
 typedef struct etlg_column {
@@ -569,9 +571,11 @@ void etlg_columns_free(etlg_columns* cols);
  * :188-283) and append_cdc_columns (clickhouse/core.rs:96-114) produce for the rows core.rs:1078-1127 collects:
  * Insert -> the row; Update -> the new row; Delete -> the old row. Rows the reference builds with extra host
  * logic (a Partial update, a Delete that carries only the key) are left out and counted in n_host_rows.
- * Columns of class numeric / timetz / json are Display strings in the reference; a slot that has one (or an array of
- * those, or of text), or a DEFERRED scalar cell / an array literal the device cannot take apart in a row, makes the call
- * return status ETLG_RB_NEEDS_HOST (no bytes). Arrays of fixed-width elements are encoded as Array(Nullable(T)). */
+ * Columns of class numeric / timetz / time are Display strings in the reference (`n.to_string()`, encoding.rs:66-71): they are
+ * formatted on the device (PgNumeric Display, crates/etl-postgres/src/numeric.rs:460-560; PgTimeTz, etl-postgres/src/time.rs:113-117,
+ * 210-225). A slot with a json column (serde_json's normalised Display) or an array of numeric / timetz / json / text elements, or
+ * a DEFERRED scalar cell / an array literal the device cannot take apart in a row, makes the call return status
+ * ETLG_RB_NEEDS_HOST (no bytes). Arrays of fixed-width elements are encoded as Array(Nullable(T)). */
 typedef enum etlg_ch_engine {
   ETLG_CH_MERGE_TREE = 0,           /* + cdc_operation String, cdc_lsn UInt64 */
   ETLG_CH_REPLACING_MERGE_TREE = 1  /* + _etl_version UInt128 (commit_lsn << 64 | tx_ordinal), _etl_deleted UInt8 */
@@ -607,8 +611,11 @@ int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_sl
  * (cell_encode_prost, crates/etl-destinations/src/bigquery/encoding.rs:120-190: field tag = column position + 1, NULL cells
  * leave nothing; then _CHANGE_TYPE = "UPSERT" and _CHANGE_SEQUENCE_NUMBER = "{commit_lsn:016x}/{tx_ordinal:016x}/{0:016x}",
  * bigquery/core.rs:978-996, 1404-1406). Updates and deletes need the reference's key-change logic (core.rs:1431-1754): they are
- * counted in n_host_rows. numeric / timetz / json / array columns (host-formatted strings, host-side validation,
- * bigquery/validation.rs) and DEFERRED cells return ETLG_RB_NEEDS_HOST. The result is an etlg_rowbinary (same view). */
+ * counted in n_host_rows. numeric / timetz cells are their Display strings, a numeric with more than 38 decimal places fails the
+ * call like validate_numeric_for_bigquery (bigquery/validation.rs:20-35: ETLG_UnsupportedValueInDestination, "Cell validation failed
+ * for BigQuery compatibility", detail "Cell at index N failed validation", frame_index = the event). json / array columns
+ * (serde_json Display, packed / repeated fields, host-side validation) and DEFERRED cells return ETLG_RB_NEEDS_HOST.
+ * The result is an etlg_rowbinary (same view). */
 int32_t etlg_batch_protobuf(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t flags, etlg_rowbinary** out);
 int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out);
 void etlg_rowbinary_free(etlg_rowbinary* rb);

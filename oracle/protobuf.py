@@ -14,7 +14,12 @@ Works on the per-cell tuples of etl_amd.view.HostBatch.materialize()."""
 import datetime as dt
 import struct
 
-from oracle.rowbinary import NeedsHost, time_string
+from oracle.display import numeric_string, time_string, timetz_string
+from oracle.rowbinary import NeedsHost
+
+
+class UnsupportedValueInDestination(Exception):
+    """validate_numeric_for_bigquery (bigquery/validation.rs:20-35) behind BigQueryTableRow::try_from_tagged_cells (encoding.rs:37-45)."""
 
 
 def varint(v):
@@ -64,6 +69,12 @@ def cell(c, tag):
         return ld(tag, (date_string(c[1]) + " " + time_string(c[2], c[3])).encode())
     if k == "TimestampTz":
         return key(tag, 0) + varint(((c[1] - 719163) * 86400 + c[2]) * 1_000_000 + c[3] // 1000)
+    if k == "TimeTz":                                # t.to_string() (encoding.rs:158-161)
+        return ld(tag, timetz_string(*c[1:]).encode())
+    if k == "Numeric":                               # validate_cell_for_bigquery, then n.to_string() (encoding.rs:146-149)
+        if c[1] == 0 and c[4] > 38:
+            raise UnsupportedValueInDestination(f"Cell at index {tag - 1} failed validation")
+        return ld(tag, numeric_string(*c[1:]).encode())
     if k == "Uuid":
         h = c[1].hex()
         return ld(tag, f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:]}".encode())

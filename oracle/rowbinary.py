@@ -9,12 +9,13 @@ and crates/etl-destinations/src/clickhouse/core.rs:
   ReplacingMergeTree: _etl_version UInt128 = commit_lsn << 64 | tx_ordinal, _etl_deleted UInt8).
 Pinned by tests/test_oracle_rowbinary.py to the byte vectors of the reference's own tests (encoding.rs:386-470).
 
-`Time` cells are strings in the reference (`t.to_string()`, encoding.rs:70): chrono 0.4's NaiveTime Display, a dependency
-that is not vendored under /root/reference — restated here from its published behaviour: %H:%M:%S, then nothing / .mmm /
-.uuuuuu / .nnnnnnnnn for whole seconds / milliseconds / microseconds / anything finer.
+`Time`, `TimeTz` and `Numeric` cells are strings in the reference (`to_string()`, encoding.rs:66-71): their Display impls are
+restated in oracle/display.py (chrono's NaiveTime Display is a dependency that is not vendored under /root/reference).
 
 Works on the per-cell tuples of etl_amd.view.HostBatch.materialize()."""
 import struct
+
+from oracle.display import numeric_string, time_string, timetz_string   # noqa: F401  (time_string is re-exported)
 
 MERGE_TREE, REPLACING_MERGE_TREE = 0, 1
 # array types whose element class the device encodes: bool int2 int4 int8 oid float4 float8 date time timestamp timestamptz uuid
@@ -28,7 +29,7 @@ class ConversionError(Exception):
 
 
 class NeedsHost(Exception):
-    """The cell has no device encoding (numeric / timetz / json / array text, or a DEFERRED cell)."""
+    """The cell has no device encoding (json / array text, or a DEFERRED cell)."""
 
 
 def varint(v):
@@ -44,18 +45,6 @@ def varint(v):
 
 def string(b):
     return varint(len(b)) + b
-
-
-def time_string(secs, nanos):
-    h, m, s = secs // 3600, secs // 60 % 60, secs % 60
-    out = f"{h:02}:{m:02}:{s:02}"
-    if nanos == 0:
-        return out
-    if nanos % 1_000_000 == 0:
-        return out + f".{nanos // 1_000_000:03}"
-    if nanos % 1_000 == 0:
-        return out + f".{nanos // 1_000:06}"
-    return out + f".{nanos:09}"
 
 
 def value(cell):
@@ -82,6 +71,10 @@ def value(cell):
         return struct.pack("<i", days)
     if k == "Time":
         return string(time_string(cell[1], cell[2]).encode())
+    if k == "TimeTz":                                  # String(t.to_string()) (encoding.rs:71)
+        return string(timetz_string(*cell[1:]).encode())
+    if k == "Numeric":                                 # String(n.to_string()) (encoding.rs:66)
+        return string(numeric_string(*cell[1:]).encode())
     if k in ("Timestamp", "TimestampTz"):
         days, secs, nanos = cell[1:]
         return struct.pack("<q", ((days - CE_DAYS_1970) * 86400 + secs) * 1_000_000 + nanos // 1000)

@@ -34,10 +34,8 @@ def test_known_answers_for_every_class():
     hb = _decode(SC.simple_table(SC.ALLTYPES), [W.insert(42, r) for r in rows])
     names = [c[0] for c in SC.ALLTYPES]
     with pytest.raises(NotImplementedError):
-        rows_to_record_batch(hb, 0, names=names)           # numeric / timetz / jsonb / array columns are text-form
-    with pytest.raises(NotImplementedError):
-        rows_to_record_batch(hb, 0, names=names, on_text="binary")   # timetz: a display string in the reference
-    keep = [i for i, n in enumerate(names) if n != "tz"]
+        rows_to_record_batch(hb, 0, names=names)           # jsonb / array columns are text-form
+    keep = list(range(len(names)))
     rb = rows_to_record_batch(hb, 0, names=names, on_text="binary", columns=keep)
     assert rb.num_rows == 3 and rb.schema.names == [names[i] for i in keep]
     col = {n: rb.column(n).to_pylist() for n in rb.schema.names}
@@ -59,6 +57,9 @@ def test_known_answers_for_every_class():
     assert typ["f4"] == pa.float32() and col["f4"] == [3.5, -0.5, None]
     assert typ["s"] == pa.string() and col["s"] == ["hello wörld", "", None]
     assert typ["by"] == pa.large_binary() and col["by"] == [b"\x01\x02\xff", b"", None]
+    # numeric / timetz: their Display strings (cell_to_string, encoding.rs:349-352)
+    assert typ["n"] == pa.string() and col["n"] == ["12345.6789", "12345.6789", None]
+    assert typ["tz"] == pa.string() and col["tz"] == ["12:30:45.123456+02", "12:30:45.123456+02", None]
     # text-form classes come back as their heap entries for the host to finish
     assert typ["j"] == pa.large_binary() and col["j"][0] == b'{"kind":"jsonb","nested":{"n":2}}' and col["j"][2] is None
     assert col["arr"][0] == b"{1,NULL,3}"
@@ -98,6 +99,8 @@ def test_agrees_with_the_per_cell_materialiser(mk):
     slot = hb.slots[0]
     for i, colspec in enumerate(slot.cols):
         if colspec.type_class == abi.TC_NUMERIC:
+            from oracle import display as D
+            assert rb.column(i).to_pylist() == [None if e["row"][i][0] == "Null" else D.numeric_string(*e["row"][i][1:]) for e in ev]
             continue
         want = [_cell_py(e["row"][i]) for e in ev]
         got = rb.column(i)

@@ -55,17 +55,20 @@ def test_every_class_known_answers():
     buf, offs = _stream([W.insert(42, r) for r in rows])
     hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
     names = [c[0] for c in SC.ALLTYPES]
-    keep = [i for i, n in enumerate(names) if n != "tz"]
     cols = b.columns(0)
     assert cols.n_rows == len(rows) and cols.view.n_cols == len(names) and not cols.view.on_device
-    assert cols.column(names.index("tz")).arrow_kind == abi.AK_NONE
+    # numeric / timetz: Display strings formatted on the device (cell_to_string, iceberg/encoding.rs:349-352)
+    assert cols.column(names.index("tz")).arrow_kind == abi.AK_LARGE_UTF8 and cols.column(names.index("n")).arrow_kind == abi.AK_LARGE_UTF8
     with pytest.raises(NotImplementedError):
-        columns_to_record_batch(cols, names=names)                       # text-form columns need on_text="binary"
-    with pytest.raises(NotImplementedError):
-        columns_to_record_batch(cols, names=names, on_text="binary")     # timetz is not handed off
-    got = columns_to_record_batch(cols, names=names, columns=keep, on_text="binary")
-    want = rows_to_record_batch(hb, 0, names=names, on_text="binary", columns=keep)
+        columns_to_record_batch(cols, names=names)                       # json / array columns need on_text="binary"
+    got = columns_to_record_batch(cols, names=names, on_text="binary")
+    want = rows_to_record_batch(hb, 0, names=names, on_text="binary")
     _same(want, got)
+    from oracle import display as D
+    ev = [e for e in hb.materialize() if e["kind"] == "I"]
+    assert got.column("n").to_pylist() == [None if e["row"][names.index("n")][0] == "Null" else D.numeric_string(*e["row"][names.index("n")][1:]) for e in ev]
+    assert got.column("tz").to_pylist() == [None if e["row"][names.index("tz")][0] == "Null" else D.timetz_string(*e["row"][names.index("tz")][1:]) for e in ev]
+    assert got.column("n").to_pylist()[:3] == ["12345.6789", "12345.6789", None] and got.column("tz").to_pylist()[0] == "12:30:45.123456+02"
     assert got.column("id").to_pylist()[:3] == [1, 2, 3] and got.column("b").to_pylist()[:3] == [True, False, None]
     assert got.column("s").to_pylist()[:3] == ["hello wörld", "", None]
     assert np.array_equal(cols.row_event(), np.flatnonzero(hb.kind == ord("I")).astype(np.uint64))

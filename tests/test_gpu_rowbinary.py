@@ -13,7 +13,7 @@ from tests import scenarios as SC
 
 pytestmark = pytest.mark.gpu
 
-RB_COLS = [c for c in SC.ALLTYPES if c[0] not in ("n", "tz", "j", "arr")]   # the classes the device encodes
+RB_COLS = [c for c in SC.ALLTYPES if c[0] not in ("j", "arr")]   # the classes the device encodes (numeric / timetz: Display strings formatted on the device)
 
 
 def _both(prime, buf, offs):
@@ -49,6 +49,16 @@ def _check(hb, b, flags, engine, identity_type="PrimaryKey"):
     return len(rows)
 
 
+# numeric / timetz texts whose Display exercises every branch of format_numeric_value (crates/etl-postgres/src/numeric.rs:478-560)
+# and write_utc_offset (etl-postgres/src/time.rs:210-225)
+NUMERICS = ["0", "0.000", "-0.00", "0e-6", "1", "-1", "9999", "10000", "10000.0001", "9999.9999", "0.0012000", "-0.5", "1e-2", "1.23e-2",
+            "123e-2", "1e10", "1.5e10", "120.00", "1200000", "-120.00", "0.00000000000000000000000000000000000001", "1e-40",
+            "123456789012345678901234567890.123456789012345678901234567890", "NaN", "Infinity", "-Infinity", "inf", "1e100", "-7e-100",
+            "0.1", "0.12", "0.123", "0.1234", "0.12345", "12345678.9", "1_000.5", "  42.50  ", "+17"]
+TIMETZS = ["12:30:00.123+02", "12:30:00-07:30", "12:30:00+07:30:15", "00:00:00+15:59:59", "23:59:59.999999-15:59:59", "01:02:03+00",
+           "01:02:03.5-00:30", "01:02:03.000001+0530", "01:02:03.123456789+05", "12:00:00-023015"]
+
+
 def _row(**kw):
     full = dict(zip([c[0] for c in SC.ALLTYPES], SC.alltypes_row(**kw)))
     return [full[c[0]] for c in RB_COLS]
@@ -61,7 +71,8 @@ def test_every_encodable_class(engine):
                          ts="1969-12-31 23:59:59.5", tstz="2026-01-02 03:04:05+02", f8="1e300", f4="-0.5", s="", by="\\x"),
             _row(id="3", d="2299-12-31", t="23:59:59.12", s="x" * 300, by="\\x" + "ab" * 200),
             [("4" if n == "id" else W.NULL) for n in names]]
-    rows += [_row(id=str(10 + i), s="y" * (i * 13 % 200), t=f"01:02:{i % 60:02}.{i:06}") for i in range(130)]
+    rows += [_row(id=str(10 + i), s="y" * (i * 13 % 200), t=f"01:02:{i % 60:02}.{i:06}", n=NUMERICS[i % len(NUMERICS)], tz=TIMETZS[i % len(TIMETZS)])
+             for i in range(130)]
     msgs = [W.insert(42, r) for r in rows] + [W.update(42, rows[1]), W.delete(42, old=rows[0])]
     buf, offs = _stream(msgs)
     hb, b, d = _both(SC.simple_table(RB_COLS), buf, offs)
@@ -94,11 +105,11 @@ def test_date_out_of_range_fails_like_the_reference():
 
 
 def test_cells_and_rows_that_stay_with_the_host():
-    # a numeric column: the whole slot is the host's
+    # a json column: the whole slot is the host's (serde_json's normalised Display)
     buf, offs = _stream([W.insert(42, SC.alltypes_row())])
     hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
     r = b.rowbinary(0, [1] * len(SC.ALLTYPES) + [0, 0])
-    assert r.status == abi.RB_NEEDS_HOST and r.n_rows == 0 and r.view.host_column == [c[0] for c in SC.ALLTYPES].index("n")
+    assert r.status == abi.RB_NEEDS_HOST and r.n_rows == 0 and r.view.host_column == [c[0] for c in SC.ALLTYPES].index("j")
     r.close(); b.close(); d.close()
     # a DEFERRED float: reported with its event and column
     cols = [("id", SC.INT8, False, 1), ("x", SC.FLOAT8, True, 0)]
@@ -109,7 +120,7 @@ def test_cells_and_rows_that_stay_with_the_host():
     r.close(); b.close(); d.close()
 
 
-@pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 1 << 20)])
+@pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 1 << 20), (synth.cfg3, 1 << 20)])   # cfg3: BASELINE's var-len schema (TEXT, NUMERIC, timestamptz, uuid)
 @pytest.mark.parametrize("engine", [abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE])
 def test_synthetic_stream(mk, nbytes, engine):
     if os.environ.get("ETLG_SIMT_RUN") == "1":
@@ -117,8 +128,8 @@ def test_synthetic_stream(mk, nbytes, engine):
     w = mk()
     buf, offs = w.fill(nbytes)
     hb, b, d = _both(w.register, buf, offs)
-    nc = len(hb.slots[0].cols)
-    assert _check(hb, b, [0] * nc + [0, 0], engine) > 100
+    flags = [1 if c.nullable else 0 for c in hb.slots[0].cols]   # Nullable() where the source column is
+    assert _check(hb, b, flags + [0, 0], engine) > 100
     b.close(); d.close()
 
 

@@ -81,5 +81,5 @@ def test_fixed_width_plans(simt_lib):
 def test_columnar_hand_off(simt_lib):
     """etlg_batch_columns / etlg_batch_rowbinary (columns.hip): the Arrow-layout buffers built by the emulated kernels against
     the host hand-off of the oracle's arena, the RowBinary bytes against oracle/rowbinary.py."""
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py"], 600)
+    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py"], 600)
     assert " passed" in tail and "failed" not in tail, tail
