@@ -36,9 +36,8 @@ constexpr int MAXC = 16;       // replicated columns per slot this kernel can ha
 // virtual columns of a tile whose widest slot has maxc columns: [0, maxc) old / key image, [maxc, 2 maxc) new image
 
 enum : uint32_t { CT_N = 0, CT_U = 1, CT_T = 2, CT_B = 3 };  // cell kind
-// classes whose heap bytes depend on the text, not only on its length (cell_heap_bytes): float, numeric, bytea, date / time
-constexpr uint32_t kScanClasses = (1u << ETLG_TC_F32) | (1u << ETLG_TC_F64) | (1u << ETLG_TC_NUMERIC) | (1u << ETLG_TC_BYTEA) | (1u << ETLG_TC_DATE) |
-                                  (1u << ETLG_TC_TIME) | (1u << ETLG_TC_TIMETZ) | (1u << ETLG_TC_TIMESTAMP) | (1u << ETLG_TC_TIMESTAMPTZ);
+// classes whose heap bytes depend on the text, not only on its length (cell_heap_bytes): float (a deferred text), numeric, bytea
+constexpr uint32_t kScanClasses = (1u << ETLG_TC_F32) | (1u << ETLG_TC_F64) | (1u << ETLG_TC_NUMERIC) | (1u << ETLG_TC_BYTEA);
 
 // The cell table of a tile, [virtual column][frame], written by the tuple walk (P1), sized by P2 / P2b, read by P3.
 // STAGED tiles keep ONE dword per cell — where the cell's tag byte sits in the LDS window (17 bits) and the cell's heap

@@ -901,6 +901,90 @@ DEV int32_t split_offset_index(const u8* s, uint32_t n, uint32_t min_index, bool
   }
   return -1;
 }
+// ---- The temporal shapes outside the fixed-layout fast paths: what the reference hands to chrono (codec/time.rs:21-55: "anything
+// else falls back to chrono's format machinery"). chrono 0.4.44 (Cargo.lock:1176) is not vendored under /root/reference; its
+// `parse_from_str` is restated here from its published behaviour for the three format strings the reference uses
+// (crates/etl-postgres/src/time.rs:13-21: "%Y-%m-%d", "%H:%M:%S%.f", "%Y-%m-%d %H:%M:%S%.f"): a numeric item first skips
+// whitespace (char::is_whitespace), then takes 1..=2 digits (%m %d %H %M %S) or 1..=4 (%Y; any count behind an explicit '+' / '-');
+// literals match exactly; the format's space matches zero or more whitespace; "%.f" is nothing, or '.' and at least one digit (nine
+// are significant, more are skipped); input left over is an error. Resolution: NaiveDate::from_ymd_opt over years
+// -262143..=262142, hour < 24, minute < 60, second <= 60 with 60 a leap second (second 59, nanos + 10^9). KATs: codec/time.rs:181-269.
+// Rare path (Postgres emits the ISO shapes): out of line, byte loads.
+#ifndef ETLG_CHRONO_CALL
+#define ETLG_CHRONO_CALL static __device__ __attribute__((noinline))
+#endif
+constexpr int32_t kChronoMinDays = -95746129, kChronoMaxDays = 95745399;   // num_days_from_ce of -262143-01-01 and 262142-12-31
+struct ChronoCur {
+  const u8* s; uint32_t n, i;
+  DEV void skip_ws() { for (;;) { const uint32_t l = ws_len_at(s + i, n - i); if (!l) break; i += l; } }
+  DEV bool lit(uint32_t c) { if (i < n && s[i] == c) { i++; return true; } return false; }
+  // 1..=maxw digits; the value saturates (a year that large fails the range check, as chrono's i64 overflow fails the parse)
+  DEV bool digits(uint32_t maxw, uint32_t& v) {
+    uint32_t k = 0; v = 0;
+    for (; i < n && k < maxw; i++, k++) { const uint32_t d = (uint32_t)s[i] - '0'; if (d > 9) break; v = v > 99999999u ? v : v * 10u + d; }
+    return k > 0;
+  }
+  DEV bool num2(uint32_t& v) { skip_ws(); return digits(2, v); }
+  DEV bool date(int32_t& days) {
+    skip_ws();
+    uint32_t y, m, d; bool neg = false, ok;
+    if (i < n && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; i++; ok = digits(0xFFFFFFFFu, y); } else ok = digits(4, y);
+    if (!ok || !lit('-') || !num2(m) || !lit('-') || !num2(d)) return false;
+    const int32_t yy = neg ? -(int32_t)y : (int32_t)y;
+    if (yy < -262143 || yy > 262142 || m < 1 || m > 12 || d < 1) return false;
+    const bool leap = (yy % 4 == 0 && yy % 100 != 0) || yy % 400 == 0;
+    const uint32_t dm = m == 2 ? (leap ? 29u : 28u) : (m == 4 || m == 6 || m == 9 || m == 11) ? 30u : 31u;
+    if (d > dm) return false;
+    const int32_t y2 = yy - (m <= 2 ? 1 : 0);
+    const int32_t era = (y2 >= 0 ? y2 : y2 - 399) / 400;
+    const uint32_t yoe = (uint32_t)(y2 - era * 400);
+    const uint32_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    days = era * 146097 + (int32_t)(yoe * 365 + yoe / 4 - yoe / 100 + doy) - 719468 + 719163;
+    return true;
+  }
+  DEV bool time(uint32_t& secs, uint32_t& nanos) {
+    uint32_t h, m, sec;
+    if (!num2(h) || !lit(':') || !num2(m) || !lit(':') || !num2(sec)) return false;
+    nanos = 0;
+    if (i < n && s[i] == '.') {
+      i++;
+      uint32_t k = 0;
+      for (; i < n; i++, k++) { const uint32_t d = (uint32_t)s[i] - '0'; if (d > 9) break; if (k < 9) nanos = nanos * 10u + d; }
+      if (!k) return false;
+      for (; k < 9; k++) nanos *= 10u;
+    }
+    if (h >= 24 || m >= 60 || sec > 60) return false;
+    if (sec == 60) { sec = 59; nanos += 1000000000u; }
+    secs = h * 3600 + m * 60 + sec;
+    return true;
+  }
+};
+// The whole of parse_postgres_{date,time,timestamp} / the timestamp and time halves of timestamptz / timetz for texts the fast
+// paths turned down. `n`: the text without its offset part (timestamptz / timetz: the caller split it off); trailing whitespace
+// is trimmed for those two (`timestamp.trim_end()`, codec/time.rs:67; `time.trim_end()`, etl-postgres/src/time.rs:123).
+// out: days (date classes), secs, nanos. Returns false for chrono's ParseError.
+ETLG_CHRONO_CALL bool chrono_fallback(uint32_t cls, const u8* s, uint32_t n, uint32_t* out3) {
+  if (cls == ETLG_TC_TIMESTAMPTZ || cls == ETLG_TC_TIMETZ) {
+    for (;;) {   // str::trim_end
+      if (!n) break;
+      uint32_t j = n - 1;
+      while (j > 0 && (s[j] & 0xC0) == 0x80) j--;
+      const uint32_t l = ws_len_at(s + j, n - j);
+      if (!l || l != n - j) break;
+      n = j;
+    }
+  }
+  ChronoCur c{s, n, 0};
+  int32_t days = 0; uint32_t secs = 0, nanos = 0;
+  bool ok = true;
+  if (cls == ETLG_TC_DATE || cls == ETLG_TC_TIMESTAMP || cls == ETLG_TC_TIMESTAMPTZ) ok = c.date(days);
+  if (ok && (cls == ETLG_TC_TIMESTAMP || cls == ETLG_TC_TIMESTAMPTZ)) c.skip_ws();
+  if (ok && cls != ETLG_TC_DATE) ok = c.time(secs, nanos);
+  if (!ok || c.i != c.n) return false;
+  out3[0] = (uint32_t)days; out3[1] = secs; out3[2] = nanos;
+  return true;
+}
+
 DEV int hexv(uint32_t c) {
   if (c - '0' < 10u) return (int)(c - '0');
   c = lower(c);
@@ -992,21 +1076,7 @@ DEV uint32_t cell_heap_bytes(uint32_t cls, const u8* d, uint32_t len, bool over 
     case ETLG_TC_BYTEA: return len >= 2 ? pad4((len - 2) >> 1) : 0;
     case ETLG_TC_F32: case ETLG_TC_F64: { uint64_t b; return parse_float_fast(d, len, cls == ETLG_TC_F32, b, over) == 1 ? pad4(len) : 0; }
     case ETLG_TC_NUMERIC: { NumShape s; return ((over && numeric_plain(d, len, s)) || numeric_scan(d, len, s, over)) ? pad4(8 + 2 * s.ngroups) : 0; }
-    case ETLG_TC_DATE: { int32_t x; return iso_date_fast(d, len, x) ? 0 : pad4(len); }
-    case ETLG_TC_TIME: { uint32_t a, b; return iso_time_fast(d, len, a, b, over) ? 0 : pad4(len); }
-    case ETLG_TC_TIMESTAMP: { int32_t x; uint32_t a, b; return iso_timestamp_fast(d, len, x, a, b, over) ? 0 : pad4(len); }
-    case ETLG_TC_TIMESTAMPTZ: {
-      int32_t idx = split_offset_index(d, len, 10, over);
-      if (idx < 0) return 0;
-      int32_t x; uint32_t a, b;
-      return iso_timestamp_fast(d, (uint32_t)idx, x, a, b, over) ? 0 : pad4(len);
-    }
-    case ETLG_TC_TIMETZ: {
-      int32_t idx = split_offset_index(d, len, 0, over);
-      if (idx < 0) return 0;
-      uint32_t a, b;
-      return iso_time_fast(d, (uint32_t)idx, a, b, over) ? 0 : pad4(len);
-    }
+    // date / time / timestamp / timestamptz / timetz: decoded on the device whatever their shape (chrono_fallback): no heap entry
     default: return 0;
   }
 }
@@ -1105,31 +1175,54 @@ DEV_DECODE uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, ui
       var(nb);
       return 0;
     }
-    case ETLG_TC_DATE: { int32_t x; if (!iso_date_fast(d, len, x)) return defer(); slot[0] = (uint32_t)x; slot[1] = 0; return 0; }
-    case ETLG_TC_TIME: { uint32_t a, b; if (!iso_time_fast(d, len, a, b, over)) return defer(); slot[0] = a; slot[1] = b; return 0; }
+    case ETLG_TC_DATE: {
+      int32_t x;
+      if (iso_date_fast(d, len, x)) { slot[0] = (uint32_t)x; slot[1] = 0; return 0; }
+      uint32_t o[3];
+      if (!chrono_fallback(cls, d, len, o)) return bad(ETLG_E_DATETIME);
+      slot[0] = o[0]; slot[1] = 0; return 0;
+    }
+    case ETLG_TC_TIME: {
+      uint32_t a, b;
+      if (iso_time_fast(d, len, a, b, over)) { slot[0] = a; slot[1] = b; return 0; }
+      uint32_t o[3];
+      if (!chrono_fallback(cls, d, len, o)) return bad(ETLG_E_DATETIME);
+      slot[0] = o[1]; slot[1] = o[2]; return 0;
+    }
     case ETLG_TC_TIMESTAMP: {
       int32_t x; uint32_t a, b;
-      if (!iso_timestamp_fast(d, len, x, a, b, over)) return defer();
-      slot[0] = (uint32_t)x; slot[1] = a; slot[2] = b;
+      if (iso_timestamp_fast(d, len, x, a, b, over)) { slot[0] = (uint32_t)x; slot[1] = a; slot[2] = b; return 0; }
+      uint32_t o[3];
+      if (!chrono_fallback(cls, d, len, o)) return bad(ETLG_E_DATETIME);
+      slot[0] = o[0]; slot[1] = o[1]; slot[2] = o[2];
       return 0;
     }
     case ETLG_TC_TIMESTAMPTZ: {  // codec/time.rs:63-71 + UTC normalisation codec/text.rs:108-111
       const int32_t idx = split_offset_index(d, len, 10, over);
       if (idx < 0) return bad(ETLG_E_DATETIME);
       int32_t x; uint32_t a, b;
-      if (!iso_timestamp_fast(d, (uint32_t)idx, x, a, b, over)) return defer();
+      if (!iso_timestamp_fast(d, (uint32_t)idx, x, a, b, over)) {
+        uint32_t o[3];
+        if (!chrono_fallback(cls, d, (uint32_t)idx, o)) return bad(ETLG_E_DATETIME);
+        x = (int32_t)o[0]; a = o[1]; b = o[2];
+      }
       int32_t off;
       if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off, over)) return bad(ETLG_E_DATETIME);
       int32_t sec = (int32_t)a - off;
       if (sec < 0) { sec += 86400; x -= 1; } else if (sec >= 86400) { sec -= 86400; x += 1; }
+      if (x < kChronoMinDays || x > kChronoMaxDays) return bad(ETLG_E_DATETIME);   // from_local_datetime(..).single() is None outside NaiveDate's range
       slot[0] = (uint32_t)x; slot[1] = (uint32_t)sec; slot[2] = b;
       return 0;
     }
-    case ETLG_TC_TIMETZ: {  // crates/etl-postgres/src/time.rs:121-127
+    case ETLG_TC_TIMETZ: {  // crates/etl-postgres/src/time.rs:121-127 (NaiveTime::parse_from_str on the trimmed time part)
       const int32_t idx = split_offset_index(d, len, 0, over);
       if (idx < 0) return bad(ETLG_E_DATETIME);
       uint32_t a, b;
-      if (!iso_time_fast(d, (uint32_t)idx, a, b, over)) return defer();
+      if (!iso_time_fast(d, (uint32_t)idx, a, b, over)) {
+        uint32_t o[3];
+        if (!chrono_fallback(cls, d, (uint32_t)idx, o)) return bad(ETLG_E_DATETIME);
+        a = o[1]; b = o[2];
+      }
       int32_t off;
       if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off, over)) return bad(ETLG_E_DATETIME);
       slot[0] = a; slot[1] = b; slot[2] = (uint32_t)off;

@@ -824,7 +824,10 @@ void build_slots(etlg_ctx* c, const std::vector<int32_t>& live, std::vector<DevS
       uint32_t ci = 0;
       for (auto& sc : s->cols) {
         const int32_t k = sc.type_class;
-        const bool heap = !(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32 || k == ETLG_TC_UUID);
+        // fixed-width classes never reach the heap — the temporal ones included: their rare non-ISO shapes are decoded on the device too
+        // (chrono_fallback, codec.hip.h). A float reaches it only as a DEFERRED text; numeric / bytea entries are sized from the text
+        const bool heap = !(k == ETLG_TC_BOOL || k == ETLG_TC_I16 || k == ETLG_TC_I32 || k == ETLG_TC_I64 || k == ETLG_TC_U32 || k == ETLG_TC_UUID ||
+                            k == ETLG_TC_DATE || k == ETLG_TC_TIME || k == ETLG_TC_TIMETZ || k == ETLG_TC_TIMESTAMP || k == ETLG_TC_TIMESTAMPTZ);
         const bool scan = heap && !(k == ETLG_TC_STRING || k == ETLG_TC_JSON || k == ETLG_TC_ARRAY);
         if (!narrow) { if (heap) d.has_var = 0xFFFFFFFFu; }
         else {

@@ -366,8 +366,11 @@ enum {
 
 /* Which cells come back DEFERRED (the same rule is implemented by the oracle's CONTRACT mode):
  *  - json / jsonb and every array type: always;
- *  - date / time / timetz / timestamp / timestamptz: when the text is not in the fixed layout of
- *    the reference's own fast paths (codec/time.rs:89-154), i.e. what the reference hands to chrono;
+ *  - date / time / timetz / timestamp / timestamptz: never. Texts in the fixed layout of the reference's fast paths
+ *    (codec/time.rs:89-154) and the shapes it hands to chrono (`parse_from_str` with "%Y-%m-%d", "%H:%M:%S%.f",
+ *    "%Y-%m-%d %H:%M:%S%.f": one-digit fields, whitespace in front of numbers, signed / long years, leap second
+ *    :60 = second 59 with nanos + 10^9, more than nine fraction digits) are both decoded on the device; a text
+ *    neither accepts is "Datetime parsing failed";
  *  - float4 / float8: decoded on the device whenever the result is certain: Clinger's exact path (mantissa
  *    <= 2^53, |exponent| <= 22: one IEEE operation), else the Eisel-Lemire algorithm on the first 19
  *    significant digits (as Rust's dec2flt does; a longer mantissa must round the same way for w and

@@ -392,39 +392,8 @@ static bool decode_text(const Ctx& c, const RCol& col, sv text, Cell& out, int32
       out.tag = cls == ETLG_TC_F32 ? Tag::F32 : Tag::F64; out.u.fbits = v.v;
       return true;
     }
-    case ETLG_TC_DATE: {
-      auto d = iso_date_fast(text);
-      if (!d) return defer();
-      out.tag = Tag::Date; out.u.t.date = *d; return true;
-    }
-    case ETLG_TC_TIME: {
-      auto t = iso_time_fast(text);
-      if (!t) return defer();
-      out.tag = Tag::Time; out.u.t.secs = t->secs; out.u.t.nanos = t->nanos; return true;
-    }
-    case ETLG_TC_TIMESTAMP: {
-      auto t = iso_timestamp_fast(text);
-      if (!t) return defer();
-      out.tag = Tag::Timestamp; out.u.t.date = t->date; out.u.t.secs = t->secs; out.u.t.nanos = t->nanos; return true;
-    }
-    case ETLG_TC_TIMESTAMPTZ: {
-      auto idx = split_offset_index(text, 10);
-      if (!idx) { err = ETLG_E_DATETIME; return false; }
-      auto t = iso_timestamp_fast(text.substr(0, *idx));
-      if (!t) return defer();
-      auto r = parse_pg_timestamptz(text);
-      if (!r.ok) { err = r.e.code; return false; }
-      out.tag = Tag::TimestampTz; out.u.t.date = r.v.date; out.u.t.secs = r.v.secs; out.u.t.nanos = r.v.nanos; return true;
-    }
-    case ETLG_TC_TIMETZ: {
-      auto idx = split_offset_index(text, 0);
-      if (!idx) { err = ETLG_E_DATETIME; return false; }
-      auto t = iso_time_fast(text.substr(0, *idx));
-      if (!t) return defer();
-      auto r = parse_pg_timetz(text);
-      if (!r.ok) { err = r.e.code; return false; }
-      out.tag = Tag::TimeTz; out.u.t.secs = r.v.secs; out.u.t.nanos = r.v.nanos; out.u.t.offset = r.v.offset; return true;
-    }
+    // date / time / timestamp / timestamptz / timetz: the device decodes every shape (fixed-layout fast paths, then the chrono
+    // grammar), so the contract is the reference's full semantics (parse_scalar_text below)
     default: {
       auto r = parse_scalar_text(cls, text);
       if (!r.ok) { err = r.e.code; return false; }

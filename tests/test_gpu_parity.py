@@ -415,6 +415,68 @@ def test_numeric_matrix(path):
     d.close()
 
 
+def _temporal_texts():
+    """(type oid, text): the reference's own temporal KATs (codec/time.rs:169-345, etl-postgres/src/time.rs:231-258 — fast-path and
+    chrono-fallback shapes, leap seconds, > 9 fraction digits, every rejected shape) plus shapes around chrono's grammar: whitespace
+    in front of numeric items, one-digit fields, signed and > 4-digit years, the year range's ends, offsets that move the date."""
+    from tests.golden import reference_kats as K
+    t = [(oid, text) for oid, text, _e in K.TIME_RS + K.PG_TIME_RS]
+    t += [(SC.DATE, x) for x in ["2023-1-1", " 2023-01-01", "2023- 1- 1", "2023-01-01 ", "+2023-01-01", "-0001-01-01", "+12023-01-01", "-262143-01-01",
+                                 "+262142-12-31", "+262143-01-01", "-262144-12-31", "0-1-1", "00000-01-01", "+0000000001-01-01", "2023-001-01", "2023-01-001",
+                                 "2023\u00a0-01-01", "\u20032023-01-01", "2023-02-29", "2024-02-29", "1900-02-29", "2000-02-29", "+99999999999999999999-01-01"]]
+    t += [(SC.TIME, x) for x in ["1:2:3", " 01:02:03", "01: 02: 03", "01:02:03 ", "01:02:03.", "01:02:03.1234567891234", "23:59:60.5", "23:60:00", "00:00:61",
+                                 "1:02:03.5", "001:02:03", "12:30", "12:30:45:10", "\u00a012:30:45"]]
+    t += [(SC.TIMESTAMP, x) for x in ["2023-1-01 1:2:3", "2023-01-01  12:30:45", "2023-01-0112:30:45", "2023-01-01 12:30:45.1234567890", "2023-12-31 23:59:60",
+                                      "+12023-01-01 00:00:00", "2023-01-01\t12:30:45", "2023-01-01 12:30:45 ", "2023-01-01", "-0044-03-15 12:00:00.25"]]
+    t += [(SC.TIMESTAMPTZ, x) for x in ["2023-1-01 1:2:3+02", "2023-01-01 12:30:45 +02", "2023-01-01 12:30:45\u00a0+02", "2023-12-31 23:59:60+00", "2023-12-31 23:59:60-05:30",
+                                        "+262142-12-31 23:59:59-01", "-262143-01-01 00:00:00+01", "+262142-12-31 23:59:59+01", "2023-01-01 12:30:45.1234567890-15:59:59",
+                                        "2023-01-01 12:30:45+", "2023-01-01 12:30:45", "0000-01-01 00:00:00+15:59:59", "2023-1-01 00:00:00+00:00:01"]]
+    t += [(SC.TIMETZ, x) for x in ["1:2:3+02", "12:30:00 +02", "12:30:00\u2003+02", " 12:30:00+02", "23:59:60+00", "12:30:00.1234567890+02", "12:30:00.+02", "12:30+02", "+02",
+                                   "12:30:00+02 ", "12-30-00"]]
+    return t
+
+
+def test_temporal_matrix(path):
+    """date / time / timestamp / timestamptz / timetz texts of every shape — the reference's fixed-layout fast paths AND what it
+    hands to chrono (codec/time.rs:21-71) — are decoded on the device: same value bytes as the oracle's full semantics, no cell
+    DEFERRED, and for rejected texts "Datetime parsing failed" (or the UTF-8 error) at the same frame, on every kernel path."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    from tests import pgwire as W
+    order = [SC.DATE, SC.TIME, SC.TIMESTAMP, SC.TIMESTAMPTZ, SC.TIMETZ]
+    cols = [("id", SC.INT8, False, 1)] + [(f"c{k}", oid, True, 0) for k, oid in enumerate(order)] + [("s", SC.TEXT, True, 0)]
+    prime = SC.simple_table(cols)
+    texts = _temporal_texts()
+    good, bad = [], []
+    for oid, text in texts:
+        (good if not oracle.parse_text_cell(oid, text).startswith("Err(") else bad).append((oid, text))
+    assert len(good) > 60 and len(bad) > 60
+
+    def row(i, oid, text):
+        r = [str(i)] + [SC.N] * len(order) + ["x" * (i % 5)]
+        r[1 + order.index(oid)] = text.encode("utf-8", "surrogatepass")
+        return r
+    o, d = oracle.Oracle(), Decoder(0)
+    prime(o); prime(d)
+    s = SC.txn([W.insert(42, row(i, oid, text)) for i, (oid, text) in enumerate(good)])
+    buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+    rb, gb = o.decode(buf, s.offsets), d.decode(buf, s.offsets)
+    assert rb.err_code == 0 and gb.rc == 0, (rb.err_code, rb.err_frame, gb.rc, gb.error)
+    hb = rb.host_batch()
+    diff = hb.diff(gb.host())
+    assert not diff, diff[:6]
+    assert all(c[0] != "Deferred" for e in hb.materialize() if e["kind"] == "I" for c in e["row"])
+    o.reset_stream_state(); d.reset_stream_state()
+    for oid, text in bad:
+        sb = SC.txn([W.insert(42, row(1, SC.DATE, "2024-02-29")), W.insert(42, row(2, oid, text))])
+        buf = np.frombuffer(sb.bytes(), dtype=np.uint8)
+        rb, gb = o.decode(buf, sb.offsets), d.decode(buf, sb.offsets)
+        assert rb.err_code != 0 and rb.err_frame == 2, (oid, text)
+        assert gb.error is not None and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame), (oid, text, gb.error)
+        o.reset_stream_state(); d.reset_stream_state()
+    d.close()
+
+
 def test_uuid_matrix(path):
     """Uuid::parse_str forms (simple, hyphenated, braced, urn) in both cases at every alignment the preceding text column
     produces, and every malformed neighbour of them (wrong hyphen, non-hex character, one character short / long)."""
