@@ -120,6 +120,102 @@ __global__ __launch_bounds__(256) void k_col_fixed(ColJob j) {
   }
 }
 
+DEV int arr_hexv(uint32_t c) { return c - '0' < 10u ? (int)(c - '0') : (c | 0x20u) - 'a' < 6u ? (int)((c | 0x20u) - 'a' + 10) : -1; }
+// serde_json 1.0.149 `from_str::<Value>` (call site codec/text.rs:126-134; features arbitrary_precision + std, crates/etl/Cargo.toml:36):
+// is the text one JSON value? RFC 8259 grammar; whitespace is space / tab / LF / CR; a number keeps its literal text, so any length
+// and exponent is fine; strings reject raw control characters, unknown escapes, a \u surrogate without its partner; an array or
+// object may be nested 127 deep (Deserializer::remaining_depth starts at 128 and entering a container that takes it to 0 is
+// RecursionLimitExceeded); anything but whitespace behind the value is an error. The text is valid UTF-8 already (the decode
+// kernels checked). Iterative: the open containers are a 128-bit stack (1 = object).
+DEV bool json_valid(const u8* s, uint32_t n) {
+  uint32_t stk[4] = {0, 0, 0, 0};
+  uint32_t depth = 0, i = 0;
+  enum : uint32_t { X_VALUE = 0, X_VALUE_OR_CLOSE = 1, X_KEY_OR_CLOSE = 2, X_KEY = 3, X_NEXT = 4 };
+  uint32_t ex = X_VALUE;
+  auto ws = [&]() { while (i < n && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) i++; };
+  auto hex4 = [&](uint32_t& v) -> bool {   // at s[i]: 'u' XXXX
+    if (n - i < 5) return false;
+    v = 0;
+    for (uint32_t k = 1; k <= 4; k++) { const int d = arr_hexv(s[i + k]); if (d < 0) return false; v = v * 16 + (uint32_t)d; }
+    i += 5;
+    return true;
+  };
+  auto string = [&]() -> bool {   // at the opening quote
+    i++;
+    while (i < n) {
+      const uint32_t c = s[i];
+      if (c == '"') { i++; return true; }
+      if (c < 0x20) return false;
+      if (c != '\\') { i++; continue; }
+      if (++i >= n) return false;
+      const uint32_t x = s[i];
+      if (x == 'u') {
+        uint32_t v, w;
+        if (!hex4(v)) return false;
+        if (v >= 0xDC00 && v <= 0xDFFF) return false;
+        if (v >= 0xD800 && v <= 0xDBFF) {
+          if (n - i < 2 || s[i] != '\\' || s[i + 1] != 'u') return false;
+          i++;
+          if (!hex4(w) || w < 0xDC00 || w > 0xDFFF) return false;
+        }
+        continue;
+      }
+      if (!(x == '"' || x == '\\' || x == '/' || x == 'b' || x == 'f' || x == 'n' || x == 'r' || x == 't')) return false;
+      i++;
+    }
+    return false;
+  };
+  auto digits = [&]() -> bool { const uint32_t i0 = i; while (i < n && s[i] - '0' < 10u) i++; return i > i0; };
+  auto word = [&](const char* l, uint32_t ln) -> bool { if (n - i < ln) return false; for (uint32_t k = 0; k < ln; k++) if (s[i + k] != (u8)l[k]) return false; i += ln; return true; };
+  for (;;) {
+    ws();
+    if (ex == X_NEXT) {
+      if (!depth) return i == n;
+      if (i >= n) return false;
+      const uint32_t c = s[i++], top = depth - 1;
+      const bool obj = (stk[top >> 5] >> (top & 31)) & 1u;
+      if (c == ',') { ex = obj ? X_KEY : X_VALUE; continue; }
+      if (c != (obj ? '}' : ']')) return false;
+      depth--;
+      continue;
+    }
+    if (i >= n) return false;
+    const uint32_t c = s[i];
+    if (ex == X_KEY_OR_CLOSE || ex == X_KEY) {
+      if (ex == X_KEY_OR_CLOSE && c == '}') { i++; depth--; ex = X_NEXT; continue; }
+      if (c != '"' || !string()) return false;
+      ws();
+      if (i >= n || s[i] != ':') return false;
+      i++;
+      ex = X_VALUE;
+      continue;
+    }
+    if (ex == X_VALUE_OR_CLOSE && c == ']') { i++; depth--; ex = X_NEXT; continue; }
+    if (c == '{' || c == '[') {
+      if (depth >= 127) return false;
+      if (c == '{') stk[depth >> 5] |= 1u << (depth & 31); else stk[depth >> 5] &= ~(1u << (depth & 31));
+      depth++; i++;
+      ex = c == '{' ? X_KEY_OR_CLOSE : X_VALUE_OR_CLOSE;
+      continue;
+    }
+    bool ok;
+    if (c == '"') ok = string();
+    else if (c == 't') ok = word("true", 4);
+    else if (c == 'f') ok = word("false", 5);
+    else if (c == 'n') ok = word("null", 4);
+    else {   // -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?
+      if (c == '-') i++;
+      if (i >= n) return false;
+      if (s[i] == '0') i++; else if (s[i] - '1' < 9u) (void)digits(); else return false;
+      ok = true;
+      if (i < n && s[i] == '.') { i++; ok = digits(); }
+      if (ok && i < n && (s[i] == 'e' || s[i] == 'E')) { i++; if (i < n && (s[i] == '+' || s[i] == '-')) i++; ok = digits(); }
+    }
+    if (!ok) return false;
+    ex = X_NEXT;
+  }
+}
+
 DEV uint32_t numeric_str_len(const u8* ent);
 DEV uint32_t timetz_str_len(const u8* slot);
 // var-len columns, pass 1: validity / deferred words + the byte length of every row's entry
@@ -132,6 +228,10 @@ __global__ __launch_bounds__(256) void k_col_lens(ColJob j) {
     st = col_state(j, b);
     // text-form columns hand over DEFERRED entries too (their heap entry is the source text)
     const bool has = st == ETLG_CELL_VALUE || (j.kind == AK_TEXT_FORM && st == ETLG_CELL_DEFERRED);
+    if (has && j.cls == ETLG_TC_JSON) {   // "JSON deserialization failed" for the first malformed cell in event order (codec/text.rs:126-134)
+      const u8* slot = j.fixed + b + j.off_full;
+      if (!json_valid(j.heap + ld32a(slot), ld32a(slot + 4))) atomicMin(j.err, (unsigned long long)((r << 8) | ETLG_E_JSON));
+    }
     if (has) {
       const u8* slot = j.fixed + b + j.off_full;
       len = j.kind == AK_NUMERIC_STR ? numeric_str_len(j.heap + ld32a(slot)) : j.kind == AK_TIMETZ_STR ? timetz_str_len(slot) : ld32a(slot + 4);
@@ -198,163 +298,6 @@ __global__ __launch_bounds__(256) void k_col_copy(ColJob j) {
   }
 }
 
-
-// ---- array literals (parse_cell_from_postgres_text_array, crates/etl/src/postgres/codec/text.rs:228-312; the dimensions
-// prefix :163-214) for the element classes with a fixed-width value: bool, int2, int4, int8, oid, float4, float8, date, time,
-// timestamp, timestamptz, uuid. One thread per row walks its
-// text twice: k_arr_count (shape errors, element parse errors, element count), then k_arr_fill behind the offsets scan.
-constexpr uint32_t kArrElemMax = 40;   // an element text longer than this is left to the host (Rust accepts any number of leading zeros)
-enum : uint32_t { ARR_HOST = 0x100 };  // not an error: the row is handed back deferred
-
-DEV uint32_t arr_strip_dims(const u8* s, uint32_t n, uint32_t& start) {   // strip_array_dimensions_prefix
-  auto at = [&](uint32_t i) -> int { return i < n ? (int)s[i] : -1; };
-  start = 0;
-  if (at(0) != '[') return 0;
-  uint32_t groups = 0, idx = 0;
-  auto skip_int = [&](uint32_t i, uint32_t& out) { if (at(i) == '-') i++; const uint32_t st = i; while (at(i) >= '0' && at(i) <= '9') i++; out = i; return i > st; };
-  while (at(idx) == '[') {
-    uint32_t a, b;
-    if (!skip_int(idx + 1, a) || at(a) != ':') return ETLG_E_ARRAY_DIMS;
-    if (!skip_int(a + 1, b) || at(b) != ']') return ETLG_E_ARRAY_DIMS;
-    idx = b + 1; groups++;
-  }
-  if (at(idx) != '=') return ETLG_E_ARRAY_DIMS;
-  if (groups > 1) return ETLG_E_ARRAY_MULTIDIM;
-  start = idx + 1;
-  return 0;
-}
-
-// Calls elem(k, is_null, value words) per element in text order; returns 0, an etlg_err_code, or ARR_HOST.
-// TEXT: string elements (ArrayCell::String: text[], varchar[], and every array type without a dedicated arm) are the unescaped
-// bytes themselves; `dst(k)` says where element k's bytes go (nullptr: they are only counted).
-template <bool TEXT, class F, class D>
-DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& count, F&& elem, D&& dst) {
-  uint32_t start;
-  count = 0;
-  if (const uint32_t e = arr_strip_dims(s0, n0, start)) return e;
-  const u8* s = s0 + start;
-  const uint32_t n = n0 - start;
-  if (n < 2) return ETLG_E_ARRAY_SHORT;
-  if (s[0] != '{' || s[n - 1] != '}') return ETLG_E_ARRAY_BRACES;
-  const u8* body = s + 1;
-  const uint32_t bn = n - 2;
-  u8 val[kArrElemMax];
-  uint32_t vl = 0, pos = 0;
-  bool in_quotes = false, in_escape = false, val_quoted = false, done = bn == 0, too_long = false;
-  u8* out = TEXT ? dst(0u) : nullptr;
-  while (!done) {
-    for (;;) {
-      if (pos >= bn) { done = true; break; }
-      const u8 c = body[pos++];
-      bool push = false;
-      if (in_escape) { push = true; in_escape = false; }
-      else if (c == '"') { if (!in_quotes) val_quoted = true; in_quotes = !in_quotes; }
-      else if (c == '\\') in_escape = true;
-      else if ((c == '{' || c == '}') && !in_quotes) return ETLG_E_ARRAY_MULTIDIM;
-      else if (c == ',' && !in_quotes) break;
-      else push = true;
-      if (push) {
-        if (vl < kArrElemMax) val[vl] = c; else too_long = true;
-        // a text element's bytes leave as they come, except the first four: an unquoted "null" is not text at all
-        if (TEXT && out && vl >= 4) { if (vl == 4) { out[0] = val[0]; out[1] = val[1]; out[2] = val[2]; out[3] = val[3]; } out[vl] = c; }
-        vl++;
-      }
-    }
-    if (in_quotes) return ETLG_E_ARRAY_QUOTE;
-    if (in_escape) return ETLG_E_ARRAY_ESCAPE;
-    if (!TEXT && too_long) return ARR_HOST;
-    const bool is_null = !val_quoted && vl == 4 && (val[0] | 0x20) == 'n' && (val[1] | 0x20) == 'u' && (val[2] | 0x20) == 'l' && (val[3] | 0x20) == 'l';
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (TEXT) {
-      if (out && !is_null && vl <= 4) for (uint32_t b = 0; b < vl; b++) out[b] = val[b];
-      w[0] = is_null ? 0u : vl;
-    } else if (!is_null) {
-      uint32_t hcur = 0, st = 0;
-      uint32_t scratch[(kArrElemMax + 7) / 4];   // where a DEFERRED element's text would go: the row is handed back whole instead
-      if (const uint32_t e = decode_text_cell<true>(elem_cls, val, vl, w, (u8*)scratch, hcur, st, false)) return e;
-      if (st != ETLG_CELL_VALUE) return ARR_HOST;   // a float text the device rule does not settle, a temporal shape outside the fast path
-    }
-    elem(count, is_null, w);
-    count++;
-    vl = 0; val_quoted = false;
-    if (TEXT) out = dst(count);
-  }
-  return 0;
-}
-
-DEV bool arr_text(const ColJob& j, uint64_t r, const u8*& s, uint32_t& n, uint32_t& st) {
-  const uint64_t b = j.row_base[r];
-  st = col_state(j, b);
-  if (st != ETLG_CELL_VALUE && st != ETLG_CELL_DEFERRED) return false;
-  const u8* slot = j.fixed + b + j.off_full;
-  s = j.heap + ld32a(slot); n = ld32a(slot + 4);
-  return true;
-}
-
-__global__ __launch_bounds__(256) void k_arr_count(ColJob j) {
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = r < j.n_rows;
-  bool valid = false, defer = false;
-  if (live) {
-    const u8* s; uint32_t n, st, cnt = 0;
-    if (arr_text(j, r, s, n, st)) {
-      auto none = [](uint32_t) -> u8* { return nullptr; };
-      auto skip = [](uint32_t, bool, const uint32_t*) {};
-      const uint32_t e = j.elem_cls == ETLG_TC_STRING ? arr_walk<true>(s, n, j.elem_cls, cnt, skip, none) : arr_walk<false>(s, n, j.elem_cls, cnt, skip, none);
-      if (e == ARR_HOST) { defer = true; cnt = 0; }
-      else if (e) { atomicMin(j.err, (unsigned long long)((r << 8) | e)); cnt = 0; }
-      else valid = true;
-    }
-    j.lens[r] = cnt;
-  }
-  const unsigned long long vm = __ballot(valid), dm = __ballot(defer), lm = __ballot(live);
-  if ((threadIdx.x & 63) == 0 && lm) {
-    j.validity[r >> 6] = vm; j.deferred[r >> 6] = dm;
-    const uint32_t nulls = (uint32_t)__builtin_popcountll(lm & ~vm), nd = (uint32_t)__builtin_popcountll(dm);
-    if (nulls) atomicAdd(j.null_count, (unsigned long long)nulls);
-    if (nd) atomicAdd(j.deferred_count, (unsigned long long)nd);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= j.n_rows || !j.lens[r]) return;
-  const u8* s; uint32_t n, st, cnt;
-  if (!arr_text(j, r, s, n, st)) return;
-  const uint64_t o = (uint64_t)j.offsets[r];
-  uint32_t nulls = 0;
-  if (j.elem_cls == ETLG_TC_STRING) {
-    // pass A (child_lens set, values not): the byte length and validity of every element; pass B (values set): the bytes
-    if (!j.values) {
-      (void)arr_walk<true>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w) {
-        const uint64_t e = o + k;
-        j.child_lens[e] = w[0];
-        if (is_null) nulls++; else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
-      }, [](uint32_t) -> u8* { return nullptr; });
-      if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
-    } else {
-      (void)arr_walk<true>(s, n, j.elem_cls, cnt, [](uint32_t, bool, const uint32_t*) {},
-                           [&](uint32_t k) -> u8* { return k < j.lens[r] ? j.values + j.child_offsets[o + k] : nullptr; });
-    }
-    return;
-  }
-  (void)arr_walk<false>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w) {
-    const uint64_t e = o + k;
-    if (is_null) { nulls++; }
-    else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
-    switch (j.kind) {   // child layout: the same conversions as k_col_fixed
-      case AK_BOOL: if (!is_null && w[0]) atomicOr(&((uint32_t*)j.values)[e >> 5], 1u << (e & 31)); break;
-      case AK_I32: case AK_F32: ((uint32_t*)j.values)[e] = w[0]; break;
-      case AK_DATE32: ((int32_t*)j.values)[e] = is_null ? 0 : (int32_t)w[0] - kCeDays1970; break;
-      case AK_TIME64: ((int64_t*)j.values)[e] = is_null ? 0 : (int64_t)w[0] * 1000000 + (int64_t)(w[1] / 1000u); break;
-      case AK_TS: case AK_TSTZ:
-        ((int64_t*)j.values)[e] = is_null ? 0 : (((int64_t)(int32_t)w[0] - kCeDays1970) * 86400 + (int64_t)w[1]) * 1000000 + (int64_t)(w[2] / 1000u); break;
-      case AK_FIXED16: ((uint4*)j.values)[e] = make_uint4(w[0], w[1], w[2], w[3]); break;
-      default: ((uint64_t*)j.values)[e] = j.elem_cls == ETLG_TC_U32 ? (uint64_t)w[0] : ((uint64_t)w[1] << 32) | w[0]; break;   // I64, U32, F64
-    }
-  }, [](uint32_t) -> u8* { return nullptr; });
-  if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
-}
 
 // ---- Display strings of the classes every sink writes as text: PgNumeric (format_numeric_value,
 // crates/etl-postgres/src/numeric.rs:460-560), PgTimeTz (etl-postgres/src/time.rs:113-117 + write_utc_offset :210-225) and
@@ -454,6 +397,203 @@ __global__ __launch_bounds__(256) void k_col_fmt(ColJob j) {
   if (j.kind == AK_NUMERIC_STR) numeric_str(w, j.heap + ld32a(slot)); else timetz_str(w, slot);
 }
 
+// ---- array literals (parse_cell_from_postgres_text_array, crates/etl/src/postgres/codec/text.rs:228-312; the dimensions
+// prefix :163-214) for the element classes with a fixed-width value: bool, int2, int4, int8, oid, float4, float8, date, time,
+// timestamp, timestamptz, uuid. One thread per row walks its
+// text twice: k_arr_count (shape errors, element parse errors, element count), then k_arr_fill behind the offsets scan.
+constexpr uint32_t kArrElemMax = 40;   // an element text longer than this is left to the host (Rust accepts any number of leading zeros)
+enum : uint32_t { ARR_HOST = 0x100 };  // not an error: the row is handed back deferred
+
+DEV uint32_t arr_strip_dims(const u8* s, uint32_t n, uint32_t& start) {   // strip_array_dimensions_prefix
+  auto at = [&](uint32_t i) -> int { return i < n ? (int)s[i] : -1; };
+  start = 0;
+  if (at(0) != '[') return 0;
+  uint32_t groups = 0, idx = 0;
+  auto skip_int = [&](uint32_t i, uint32_t& out) { if (at(i) == '-') i++; const uint32_t st = i; while (at(i) >= '0' && at(i) <= '9') i++; out = i; return i > st; };
+  while (at(idx) == '[') {
+    uint32_t a, b;
+    if (!skip_int(idx + 1, a) || at(a) != ':') return ETLG_E_ARRAY_DIMS;
+    if (!skip_int(a + 1, b) || at(b) != ']') return ETLG_E_ARRAY_DIMS;
+    idx = b + 1; groups++;
+  }
+  if (at(idx) != '=') return ETLG_E_ARRAY_DIMS;
+  if (groups > 1) return ETLG_E_ARRAY_MULTIDIM;
+  start = idx + 1;
+  return 0;
+}
+
+// Calls elem(k, is_null, value words) per element in text order; returns 0, an etlg_err_code, or ARR_HOST.
+// TEXT: string elements (ArrayCell::String: text[], varchar[], and every array type without a dedicated arm) are the unescaped
+// bytes themselves; `dst(k)` says where element k's bytes go (nullptr: they are only counted).
+// BYTEA elements (ArrayCell::Bytes, parse_bytea_hex_string per element, codec/hex.rs:11-52): TEXT walks with `hex` set — the element's
+// characters are "\x" + hex pairs, decoded as they come; w[0] = the byte count.
+template <bool TEXT, class F, class D>
+DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& count, F&& elem, D&& dst) {
+  const bool hex = TEXT && elem_cls == ETLG_TC_BYTEA;
+  bool hex_bad = false; uint32_t nib = 0;
+  uint32_t start;
+  count = 0;
+  if (const uint32_t e = arr_strip_dims(s0, n0, start)) return e;
+  const u8* s = s0 + start;
+  const uint32_t n = n0 - start;
+  if (n < 2) return ETLG_E_ARRAY_SHORT;
+  if (s[0] != '{' || s[n - 1] != '}') return ETLG_E_ARRAY_BRACES;
+  const u8* body = s + 1;
+  const uint32_t bn = n - 2;
+  u8 val[kArrElemMax];
+  uint32_t vl = 0, pos = 0;
+  bool in_quotes = false, in_escape = false, val_quoted = false, done = bn == 0, too_long = false;
+  u8* out = TEXT ? dst(0u) : nullptr;
+  while (!done) {
+    for (;;) {
+      if (pos >= bn) { done = true; break; }
+      const u8 c = body[pos++];
+      bool push = false;
+      if (in_escape) { push = true; in_escape = false; }
+      else if (c == '"') { if (!in_quotes) val_quoted = true; in_quotes = !in_quotes; }
+      else if (c == '\\') in_escape = true;
+      else if ((c == '{' || c == '}') && !in_quotes) return ETLG_E_ARRAY_MULTIDIM;
+      else if (c == ',' && !in_quotes) break;
+      else push = true;
+      if (push) {
+        if (vl < kArrElemMax) val[vl] = c; else too_long = true;
+        if (hex) {   // characters 0, 1: "\x"; then pairs (an unquoted "null" has no backslash: it never looks like bytes)
+          if (vl == 0) hex_bad |= c != '\\';
+          else if (vl == 1) hex_bad |= c != 'x';
+          else {
+            const int h = arr_hexv(c);
+            hex_bad |= h < 0;
+            if (vl & 1) { if (out) out[(vl - 3) >> 1] = (u8)((nib << 4) | (uint32_t)(h & 15)); } else nib = (uint32_t)(h & 15);
+          }
+        }
+        // a text element's bytes leave as they come, except the first four: an unquoted "null" is not text at all
+        else if (TEXT && out && vl >= 4) { if (vl == 4) { out[0] = val[0]; out[1] = val[1]; out[2] = val[2]; out[3] = val[3]; } out[vl] = c; }
+        vl++;
+      }
+    }
+    if (in_quotes) return ETLG_E_ARRAY_QUOTE;
+    if (in_escape) return ETLG_E_ARRAY_ESCAPE;
+    if (!TEXT && too_long) return ARR_HOST;
+    const bool is_null = !val_quoted && vl == 4 && (val[0] | 0x20) == 'n' && (val[1] | 0x20) == 'u' && (val[2] | 0x20) == 'l' && (val[3] | 0x20) == 'l';
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t scratch[(kArrElemMax + 7) / 4 + 2];   // a numeric element's heap entry (header + digits of <= 40 characters); a DEFERRED element's text
+    if (hex) {
+      if (!is_null) {   // "Bytea hex string conversion failed": no "\x", an odd count, a non-hex character (hex.rs:21-50)
+        if (vl < 2 || hex_bad || (vl & 1)) return ETLG_E_BYTEA;
+        w[0] = (vl - 2) >> 1;
+      }
+      hex_bad = false;
+    } else if (TEXT) {
+      if (out && !is_null && vl <= 4) for (uint32_t b = 0; b < vl; b++) out[b] = val[b];
+      w[0] = is_null ? 0u : vl;
+    } else if (!is_null) {
+      uint32_t hcur = 0, st = 0;
+      if (const uint32_t e = decode_text_cell<true>(elem_cls, val, vl, w, (u8*)scratch, hcur, st, false)) return e;
+      if (st != ETLG_CELL_VALUE) return ARR_HOST;   // a float text the device rule does not settle
+    }
+    elem(count, is_null, w, (const u8*)scratch);
+    count++;
+    vl = 0; val_quoted = false;
+    if (TEXT) out = dst(count);
+  }
+  return 0;
+}
+
+DEV bool arr_text(const ColJob& j, uint64_t r, const u8*& s, uint32_t& n, uint32_t& st) {
+  const uint64_t b = j.row_base[r];
+  st = col_state(j, b);
+  if (st != ETLG_CELL_VALUE && st != ETLG_CELL_DEFERRED) return false;
+  const u8* slot = j.fixed + b + j.off_full;
+  s = j.heap + ld32a(slot); n = ld32a(slot + 4);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_arr_count(ColJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < j.n_rows;
+  bool valid = false, defer = false;
+  if (live) {
+    const u8* s; uint32_t n, st, cnt = 0;
+    if (arr_text(j, r, s, n, st)) {
+      auto none = [](uint32_t) -> u8* { return nullptr; };
+      auto skip = [](uint32_t, bool, const uint32_t*, const u8*) {};
+      const uint32_t e = (j.elem_cls == ETLG_TC_STRING || j.elem_cls == ETLG_TC_BYTEA) ? arr_walk<true>(s, n, j.elem_cls, cnt, skip, none) : arr_walk<false>(s, n, j.elem_cls, cnt, skip, none);
+      if (e == ARR_HOST) { defer = true; cnt = 0; }
+      else if (e) { atomicMin(j.err, (unsigned long long)((r << 8) | e)); cnt = 0; }
+      else valid = true;
+    }
+    j.lens[r] = cnt;
+  }
+  const unsigned long long vm = __ballot(valid), dm = __ballot(defer), lm = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && lm) {
+    j.validity[r >> 6] = vm; j.deferred[r >> 6] = dm;
+    const uint32_t nulls = (uint32_t)__builtin_popcountll(lm & ~vm), nd = (uint32_t)__builtin_popcountll(dm);
+    if (nulls) atomicAdd(j.null_count, (unsigned long long)nulls);
+    if (nd) atomicAdd(j.deferred_count, (unsigned long long)nd);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= j.n_rows || !j.lens[r]) return;
+  const u8* s; uint32_t n, st, cnt;
+  if (!arr_text(j, r, s, n, st)) return;
+  const uint64_t o = (uint64_t)j.offsets[r];
+  uint32_t nulls = 0;
+  if (j.elem_cls == ETLG_TC_NUMERIC || j.elem_cls == ETLG_TC_TIMETZ) {
+    // ArrayCell::Numeric / TimeTz are lists of their Display strings in the sinks (iceberg/encoding.rs:902-945: `n.to_string()`,
+    // `t.to_string()`): pass A their lengths, pass B the characters. The element's value is what decode_text_cell left in the
+    // walker's scratch (a numeric heap entry) or in its slot words (timetz).
+    const bool num = j.elem_cls == ETLG_TC_NUMERIC;
+    if (!j.values) {
+      (void)arr_walk<false>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8* scratch) {
+        const uint64_t e = o + k;
+        j.child_lens[e] = is_null ? 0u : num ? numeric_str_len(scratch + w[0]) : timetz_str_len((const u8*)w);
+        if (is_null) nulls++; else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
+      }, [](uint32_t) -> u8* { return nullptr; });
+      if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
+    } else {
+      (void)arr_walk<false>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8* scratch) {
+        if (is_null) return;
+        StrWrite sw{j.values + j.child_offsets[o + k]};
+        if (num) numeric_str(sw, scratch + w[0]); else timetz_str(sw, (const u8*)w);
+      }, [](uint32_t) -> u8* { return nullptr; });
+    }
+    return;
+  }
+  if (j.elem_cls == ETLG_TC_STRING || j.elem_cls == ETLG_TC_BYTEA) {
+    // pass A (child_lens set, values not): the byte length and validity of every element; pass B (values set): the bytes
+    if (!j.values) {
+      (void)arr_walk<true>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8*) {
+        const uint64_t e = o + k;
+        j.child_lens[e] = w[0];
+        if (is_null) nulls++; else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
+      }, [](uint32_t) -> u8* { return nullptr; });
+      if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
+    } else {
+      (void)arr_walk<true>(s, n, j.elem_cls, cnt, [](uint32_t, bool, const uint32_t*, const u8*) {},
+                           [&](uint32_t k) -> u8* { return k < j.lens[r] ? j.values + j.child_offsets[o + k] : nullptr; });
+    }
+    return;
+  }
+  (void)arr_walk<false>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8*) {
+    const uint64_t e = o + k;
+    if (is_null) { nulls++; }
+    else atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
+    switch (j.kind) {   // child layout: the same conversions as k_col_fixed
+      case AK_BOOL: if (!is_null && w[0]) atomicOr(&((uint32_t*)j.values)[e >> 5], 1u << (e & 31)); break;
+      case AK_I32: case AK_F32: ((uint32_t*)j.values)[e] = w[0]; break;
+      case AK_DATE32: ((int32_t*)j.values)[e] = is_null ? 0 : (int32_t)w[0] - kCeDays1970; break;
+      case AK_TIME64: ((int64_t*)j.values)[e] = is_null ? 0 : (int64_t)w[0] * 1000000 + (int64_t)(w[1] / 1000u); break;
+      case AK_TS: case AK_TSTZ:
+        ((int64_t*)j.values)[e] = is_null ? 0 : (((int64_t)(int32_t)w[0] - kCeDays1970) * 86400 + (int64_t)w[1]) * 1000000 + (int64_t)(w[2] / 1000u); break;
+      case AK_FIXED16: ((uint4*)j.values)[e] = make_uint4(w[0], w[1], w[2], w[3]); break;
+      default: ((uint64_t*)j.values)[e] = j.elem_cls == ETLG_TC_U32 ? (uint64_t)w[0] : ((uint64_t)w[1] << 32) | w[0]; break;   // I64, U32, F64
+    }
+  }, [](uint32_t) -> u8* { return nullptr; });
+  if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
+}
+
 // ---- ClickHouse RowBinary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83 which wire type a Cell becomes,
 // :188-283 the byte format; core.rs:96-114 the trailing CDC columns). One thread per row, run twice: lengths, then bytes.
 enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3, RB_E_BQ_NUMERIC_SCALE = 4 };
@@ -550,11 +690,11 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
       const uint32_t tn = ld32a(slot + 4);
       uint32_t cnt = 0;
       auto none = [](uint32_t) -> u8* { return nullptr; };
-      if (arr_walk<false>(txt, tn, elem, cnt, [](uint32_t, bool, const uint32_t*) {}, none)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
+      if (arr_walk<false>(txt, tn, elem, cnt, [](uint32_t, bool, const uint32_t*, const u8*) {}, none)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
       if (nullable) s.put(0);
       rb_varint(s, cnt);
       uint32_t ee = 0;
-      (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w) {
+      (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w, const u8*) {
         if (is_null) { s.put(1); return; }
         s.put(0);
         const uint32_t e1 = rb_scalar(s, elem, (const u8*)w, nullptr);

@@ -1796,9 +1796,13 @@ ColPlan list_plan(uint32_t elem) {  // array literals the device parses: element
     case ETLG_TC_TIMESTAMPTZ: return {ETLG_AK_LIST, 0, true, ETLG_AK_TIMESTAMP_US_UTC, 8, elem};
     case ETLG_TC_UUID: return {ETLG_AK_LIST, 0, true, ETLG_AK_FIXED16, 16, elem};
     case ETLG_TC_STRING: return {ETLG_AK_LIST, 0, true, ETLG_AK_LARGE_UTF8, 0, elem};   // text[], varchar[], and every array type without a dedicated arm
-    default: return {ETLG_AK_TEXT_FORM, 0, true};   // numeric / bytea / json / timetz elements: the host's
+    // ArrayCell::Numeric / TimeTz: lists of Display strings (iceberg/encoding.rs:902-945); ArrayCell::Bytes: lists of the decoded bytes
+    case ETLG_TC_NUMERIC: case ETLG_TC_TIMETZ: return {ETLG_AK_LIST, 0, true, ETLG_AK_LARGE_UTF8, 0, elem};
+    case ETLG_TC_BYTEA: return {ETLG_AK_LIST, 0, true, ETLG_AK_LARGE_BINARY, 0, elem};
+    default: return {ETLG_AK_TEXT_FORM, 0, true};   // json elements: the host's
   }
 }
+bool var_child(const ColPlan& p) { return p.child == ETLG_AK_LARGE_UTF8 || p.child == ETLG_AK_LARGE_BINARY; }   // list children with offsets of their own
 ColPlan col_plan(uint32_t cls) {
   switch (cls) {
     case ETLG_TC_BOOL: return {ETLG_AK_BOOLEAN, 0, false};
@@ -1916,7 +1920,7 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   HIPCHK(c, hipStreamSynchronize(s));
   {  // a malformed array literal: the reference's error, for the first such row in event order
     uint64_t first = ~0ull;
-    for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.kind == ETLG_AK_LIST) first = std::min(first, cnt[(size_t)i * 4 + 3]);
+    for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.kind == ETLG_AK_LIST || sh.cols[i].type_class == ETLG_TC_JSON) first = std::min(first, cnt[(size_t)i * 4 + 3]);   // (a json cell that is not one JSON value: the same report)
     if (first != ~0ull) {
       uint64_t ev = 0;
       HIPCHK(c, hipMemcpy(&ev, d_row_event + (first >> 8), 8, hipMemcpyDeviceToHost));
@@ -1935,7 +1939,7 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
     vb[i] = b_bytes;
     if (lay[i].pl.kind == ETLG_AK_LIST) {
       const size_t bits = (tot + 63) / 64 * 8;
-      if (lay[i].pl.child == ETLG_AK_LARGE_UTF8) {   // child offsets first (i64), then lengths, scan scratch, validity
+      if (var_child(lay[i].pl)) {   // child offsets first (i64), then lengths, scan scratch, validity
         any_text_list = true;
         b_bytes += al((tot + 1) * 8); clen[i] = b_bytes; b_bytes += al(tot * 4); cscan[i] = b_bytes; b_bytes += al((tot / 256 + 2) * 8);
         cvb[i] = b_bytes; b_bytes += al(bits);
@@ -1952,7 +1956,7 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
     if (!lay[i].pl.var || var_total[i] <= 0) continue;
     if (lay[i].pl.kind == ETLG_AK_LIST) {
       jobs[i].child_validity = (uint32_t*)(B + cvb[i]);
-      if (lay[i].pl.child == ETLG_AK_LARGE_UTF8) {   // pass A: byte length + validity of every element, then their offsets
+      if (var_child(lay[i].pl)) {   // pass A: byte length + validity of every element, then their offsets
         jobs[i].values = nullptr; jobs[i].child_lens = (uint32_t*)(B + clen[i]); jobs[i].child_offsets = (const int64_t*)(B + vb[i]);
         HIPCHK(c, hipMemsetAsync(B + cvb[i], 0, al(((size_t)var_total[i] + 63) / 64 * 8), s));
         etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s);
@@ -1970,10 +1974,10 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
   size_t c_bytes = 0;
   if (any_text_list) {
     HIPCHK(c, hipStreamSynchronize(s));
-    for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.kind == ETLG_AK_LIST && lay[i].pl.child == ETLG_AK_LARGE_UTF8) { vc[i] = c_bytes; vbytes[i] = (size_t)text_total[i]; c_bytes += al((size_t)text_total[i]) + 64; }
+    for (uint32_t i = 0; i < nc; i++) if (lay[i].pl.kind == ETLG_AK_LIST && var_child(lay[i].pl)) { vc[i] = c_bytes; vbytes[i] = (size_t)text_total[i]; c_bytes += al((size_t)text_total[i]) + 64; }
     if (c_bytes) HIPCHK(c, blk_take(c, c_bytes + 64, false, &cs->m.d_c, &cs->m.cap_c));
     for (uint32_t i = 0; i < nc; i++)
-      if (lay[i].pl.kind == ETLG_AK_LIST && lay[i].pl.child == ETLG_AK_LARGE_UTF8 && var_total[i] > 0) { jobs[i].values = (uint8_t*)cs->m.d_c + vc[i]; etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s); }
+      if (lay[i].pl.kind == ETLG_AK_LIST && var_child(lay[i].pl) && var_total[i] > 0) { jobs[i].values = (uint8_t*)cs->m.d_c + vc[i]; etlg_k_col_list(&jobs[i], nullptr, nullptr, 1, s); }
   }
   uint8_t* Cb = (uint8_t*)cs->m.d_c;
   if (nc) HIPCHK(c, hipMemcpyAsync(cnt.data(), A + o_cnt, (size_t)nc * 32, hipMemcpyDeviceToHost, s));   // again: the child null counts
@@ -2005,7 +2009,7 @@ int32_t etlg_batch_columns(etlg_ctx* c, etlg_batch* b, int32_t slot, uint32_t ro
     if (l.pl.kind == ETLG_AK_LIST) {
       k.child_kind = l.pl.child; k.child_count = (uint64_t)var_total[i]; k.child_null_count = cnt[(size_t)i * 4 + 2];
       k.child_validity = base_b ? base_b + cvb[i] : nullptr;
-      if (l.pl.child == ETLG_AK_LARGE_UTF8) {   // element texts: offsets in block B, bytes in block C
+      if (var_child(l.pl)) {   // element texts / bytes: offsets in block B, bytes in block C
         k.child_offsets = base_b ? (const int64_t*)(base_b + vb[i]) : nullptr;
         k.values = base_c ? base_c + vc[i] : nullptr;
       }
@@ -2108,7 +2112,7 @@ static int32_t handoff_rows(etlg_ctx* c, etlg_batch* b, int32_t slot, const uint
     else if (cls == ETLG_TC_ARRAY) {  // arrays of fixed-width elements are encoded on the device (Array(Nullable(T)))
       elem = (uint32_t)etlg_array_elem_class(sh.cols[i].type_oid);
       const ColPlan lp = list_plan(elem);
-      host_class = lp.kind != ETLG_AK_LIST || lp.child == ETLG_AK_LARGE_UTF8;
+      host_class = lp.kind != ETLG_AK_LIST || var_child(lp);
     }
     if (host_class) {
       rb->v.status = ETLG_RB_NEEDS_HOST; rb->v.host_column = i;

@@ -510,13 +510,18 @@ typedef enum etlg_arrow_kind {
   ETLG_AK_FIXED16 = 9,      /* uuid: FixedSizeBinary(16) */
   ETLG_AK_LARGE_UTF8 = 10,  /* i64 offsets + bytes */
   ETLG_AK_LARGE_BINARY = 11,
-  ETLG_AK_TEXT_FORM = 12,   /* json / arrays: the cell's heap entry (the source text), i64 offsets + bytes; the host finishes it.
+  ETLG_AK_TEXT_FORM = 12,   /* json / arrays: the cell's heap entry (the source text), i64 offsets + bytes; the host finishes it. A json /
+                             * jsonb cell has been checked on the device to be one JSON value under serde_json's rules (codec/text.rs:
+                             * 126-134): a malformed one fails the call with ETLG_E_JSON at its event, so the host's parse cannot fail.
                              * (numeric and timetz columns are ETLG_AK_LARGE_UTF8 of their Display strings — `n.to_string()`,
                              * `t.to_string()`, cell_to_string encoding.rs:349-352 — formatted on the device) */
-  ETLG_AK_LIST = 13,        /* only with ETLG_ROWS_PARSE_ARRAYS: arrays of bool / int2 / int4 / int8 / oid / float4 / float8 / date / time /
-                             * timestamp / timestamptz / uuid / text elements parsed on the device
-                             * (parse_cell_from_postgres_text_array, codec/text.rs:228-312): i64 list offsets in `offsets`,
-                             * child values in `values` (child_kind layout), child validity in `child_validity` */
+  ETLG_AK_LIST = 13,        /* only with ETLG_ROWS_PARSE_ARRAYS: array literals parsed on the device (parse_cell_from_postgres_text_array,
+                             * codec/text.rs:228-312): i64 list offsets in `offsets`, child validity in `child_validity`, child values
+                             * in `values` (child_kind layout). Elements: bool / int2 / int4 / int8 / oid / float4 / float8 / date / time /
+                             * timestamp / timestamptz / uuid (fixed-width children), text and every array type without a dedicated
+                             * arm (LargeUtf8 child), numeric / timetz (LargeUtf8 child of the elements' Display strings, as the sinks
+                             * write them), bytea (LargeBinary child of the decoded bytes). Var-len children: `child_offsets`.
+                             * json[] stays ETLG_AK_TEXT_FORM */
   ETLG_AK_NONE = 255        /* not handed off - no buffers (no class maps to it today) */
 } etlg_arrow_kind;
 

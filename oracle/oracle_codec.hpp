@@ -936,7 +936,7 @@ inline Res<std::string> parse_uuid(sv s) {
 // ----------------------------------------------------------------------- json
 // serde_json 1.0.149 `from_str::<Value>` with `arbitrary_precision`: RFC 8259
 // grammar, numbers keep their literal text (any length/exponent), recursion
-// limit 128, trailing non-whitespace is an error. The oracle validates and
+// limit 128 (127 nested containers parse, the 128th is RecursionLimitExceeded), trailing non-whitespace is an error. The oracle validates and
 // keeps the raw text (Value equality is delegated to the host finish step).
 // Call site codec/text.rs:126-129; KATs :794-822.
 struct JsonScan {
@@ -1001,7 +1001,7 @@ struct JsonScan {
     if (p >= e) return false;
     char c = *p;
     if (c == '{') {
-      if (++depth > 128) return false;
+      if (++depth >= 128) return false;  // Deserializer::remaining_depth starts at 128; entering a container that takes it to 0 fails
       p++; ws();
       if (p < e && *p == '}') { p++; depth--; return true; }
       for (;;) {
@@ -1018,7 +1018,7 @@ struct JsonScan {
       }
     }
     if (c == '[') {
-      if (++depth > 128) return false;
+      if (++depth >= 128) return false;
       p++; ws();
       if (p < e && *p == ']') { p++; depth--; return true; }
       for (;;) {

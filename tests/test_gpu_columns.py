@@ -336,8 +336,10 @@ def test_float_temporal_and_uuid_arrays_on_the_device():
     hb, b, d = _both(SC.simple_table(ARR2_COLS), buf, offs)
     names = [c[0] for c in ARR2_COLS]
     cols = b.columns(0, parse_arrays=True)
-    assert [cols.column(i).arrow_kind for i in range(1, 9)] == [abi.AK_LIST] * 7 + [abi.AK_TEXT_FORM]     # numeric[] stays text
+    assert [cols.column(i).arrow_kind for i in range(1, 9)] == [abi.AK_LIST] * 8     # (numeric[]: a list of Display strings)
+    assert cols.column(8).child_kind == abi.AK_LARGE_UTF8
     rb = columns_to_record_batch(cols, names=names, on_text="binary")
+    assert rb.column(8).to_pylist()[0] == ["1.5", "NaN"]
     kinds = [pa.float64(), pa.float32(), pa.date32(), pa.time64("us"), pa.timestamp("us"), pa.timestamp("us", tz="UTC"), pa.binary(16)]
     for ci in range(1, 8):
         assert rb.schema.field(names[ci]).type == pa.large_list(kinds[ci - 1]), names[ci]
@@ -401,3 +403,102 @@ def test_text_arrays_on_the_device():
         assert rb.schema.field(ci).type == pa.large_list(pa.large_utf8())
         assert rb.column(ci).to_pylist() == [k[1] for k in kats] + [None], ci
     c.close(); b.close(); d.close()
+
+
+def _oracle_display_list(oid, text):
+    """The oracle's parse of a numeric[] / timetz[] / bytea[] literal (its repr), turned into what the sinks hand to Arrow: the
+    Display strings (oracle/display.py) / the bytes."""
+    import re
+    from oracle import display as D
+    from oracle import oracle
+    r = oracle.parse_text_cell(oid, text)
+    assert r.startswith("Array["), r
+    out = []
+    for m in re.finditer(r"NULL|Numeric\((NaN|\+Inf|-Inf|Infinity|-Infinity)\)|Numeric\(([+-]),w=(-?\d+),s=(\d+),\[([\d,]*)\]\)|TimeTz\((\d+):(\d+):(\d+)\.(\d+),(-?\d+)\)|Bytes\(([0-9a-f]*)\)", r[6:-1]):
+        t = m.group(0)
+        if t == "NULL":
+            out.append(None)
+        elif t.startswith("Numeric(") and m.group(1):
+            out.append({"NaN": "NaN", "+Inf": "Infinity", "Infinity": "Infinity", "-Inf": "-Infinity", "-Infinity": "-Infinity"}[m.group(1)])
+        elif t.startswith("Numeric("):
+            digits = tuple(int(x) for x in m.group(5).split(",")) if m.group(5) else ()
+            out.append(D.numeric_string(0, 1 if m.group(2) == "-" else 0, int(m.group(3)), int(m.group(4)), digits))
+        elif t.startswith("TimeTz("):
+            out.append(D.timetz_string(int(m.group(6)) * 3600 + int(m.group(7)) * 60 + int(m.group(8)), int(m.group(9)), int(m.group(10))))
+        else:
+            out.append(bytes.fromhex(m.group(11)))
+    return out
+
+
+def test_numeric_timetz_and_bytea_arrays_on_the_device():
+    """numeric[] / timetz[] as LargeList<LargeUtf8> of the elements' Display strings (ArrayCell::Numeric / TimeTz,
+    crates/etl-destinations/src/iceberg/encoding.rs:902-945; the reference's own expectation "12345", "-6789" at :1947-1983),
+    bytea[] as LargeList<LargeBinary> of the decoded bytes (:2001-2050) — against the oracle's parse + oracle/display.py."""
+    nums = ["{12345,-6789,NULL}", "{}", "{1.50,-0.0012000,NaN,1e3,0.000}", '{"Infinity",-Infinity}', "{123456789012345678901234567890.5}", "[2:3]={0,-0}"]
+    tzs = ["{12:30:00+02,NULL}", "{}", '{"12:30:00.123456-07:30","00:00:00+15:59:59"}', "{1:2:3+02}"]
+    bys = [r'{"\\x0102ff",NULL,"\\x"}', "{}", r'{"\\x' + "ab" * 300 + '"}', r'{"\\xDEADbeef"}']   # Postgres doubles the backslash inside the quotes
+    rows = [[str(i), nums[i % len(nums)], tzs[i % len(tzs)], bys[i % len(bys)]] for i in range(80)] + [["900", W.NULL, W.NULL, W.NULL]]
+    cols4 = [("id", SC.INT8, False, 1), ("an", 1231, True, 0), ("atz", 1270, True, 0), ("aby", 1001, True, 0)]
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(cols4), buf, offs)
+    c = b.columns(0, parse_arrays=True)
+    assert [c.column(i).arrow_kind for i in (1, 2, 3)] == [abi.AK_LIST] * 3
+    rb = columns_to_record_batch(c, names=["id", "an", "atz", "aby"])
+    assert rb.schema.field("an").type == pa.large_list(pa.large_utf8()) and rb.schema.field("aby").type == pa.large_list(pa.large_binary())
+    for ci, oid in ((1, 1231), (2, 1270), (3, 1001)):
+        want = [None if r[ci] is W.NULL else _oracle_display_list(oid, r[ci]) for r in rows]
+        assert rb.column(ci).to_pylist() == want, ci
+    assert rb.column(1).to_pylist()[0] == ["12345", "-6789", None]        # the reference's own known answer
+    c.close(); b.close(); d.close()
+    # a malformed element fails like the reference, at the first such row
+    from etl_amd.decoder import EtlError
+    for col, lit, code in ((1, "{1,abc}", abi.E_NUMERIC), (3, r'{"\\x0g"}', abi.E_BYTEA), (3, "{0102}", abi.E_BYTEA), (3, r'{"\\x012"}', abi.E_BYTEA), (2, "{12:30:00}", abi.E_DATETIME)):
+        good = ["1", "{1}", "{12:30:00+00}", r'{"\\x00"}']
+        bad = list(good); bad[0] = "2"; bad[col] = lit
+        buf, offs = _stream([W.insert(42, good), W.insert(42, bad)])
+        hb, b, d = _both(SC.simple_table(cols4), buf, offs)
+        from oracle import oracle
+        assert oracle.parse_text_cell(cols4[col][1], lit) == f"Err({code})", (lit, oracle.parse_text_cell(cols4[col][1], lit))
+        with pytest.raises(EtlError) as ei:
+            b.columns(0, parse_arrays=True)
+        assert ei.value.code == code and ei.value.frame_index == 2, lit
+        b.close(); d.close()
+
+
+JSON_GOOD = ['{"key": "value", "number": 42}', '{"value":1e309}', "null", " true ", "false", "0", "-0", "-0.5e+10", "1E-400", "123456789012345678901234567890",
+             '""', '"a\\"b\\\\c\\/d\\b\\f\\n\\r\\t"', '"\\u00e9\\uD83D\\uDE00"', "[]", "{}", "[1,[2,[3,{}]],{\"a\":[]}]", '{"a":{"b":{"c":[null,true,false]}}}',
+             "\t[ 1 , 2 ]\n", '{"k":"v","k":"dup"}', '"é中😀"', "[" * 127 + "]" * 127, '{"a":' * 126 + "1" + "}" * 126]
+JSON_BAD = ["invalid json", "", " ", "{", "}", "[1,]", "[,1]", '{"a":}', '{"a" 1}', "{a:1}", "{'a':1}", '{"a":1,}', "01", "1.", ".5", "1e", "1e+", "+1", "- 1", "0x10", "NaN", "Infinity",
+            "tru", "nul", "True", '"abc', '"a\\qb"', '"\\u12"', '"\\u12G4"', '"\\uD83D"', '"\\uD83Dx"', '"\\uDE00"', '"\\uD83D\\u0041"', '"a\tb"', '"line\nbreak"', "1 2", "[1] x",
+            "[" * 128 + "]" * 128, '{"a":' * 128 + "1" + "}" * 128, "[1 2]", '{"a":1 "b":2}', '["a" "b"]']
+
+
+def test_json_cells_are_validated_on_the_device():
+    """json / jsonb columns leave etlg_batch_columns as their source text (the sink normalises it: serde_json's Display), but only
+    after the device has checked that each cell is one JSON value under serde_json's rules (codec/text.rs:126-134; KATs :794-822):
+    a malformed cell fails the call with "JSON deserialization failed" at its event, exactly where the oracle's parse fails."""
+    from etl_amd.decoder import EtlError
+    from oracle import oracle
+    cols2 = [("id", SC.INT8, False, 1), ("j", 114, True, 0), ("jb", 3802, True, 0)]
+    for t in JSON_GOOD:
+        assert oracle.parse_text_cell(114, t).startswith("Json("), t
+    for t in JSON_BAD:
+        assert oracle.parse_text_cell(3802, t) == f"Err({abi.E_JSON})", t
+    rows = [[str(i), t, JSON_GOOD[-1 - i]] for i, t in enumerate(JSON_GOOD)] + [["999", W.NULL, W.NULL]]
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(cols2), buf, offs)
+    c = b.columns(0)
+    rb = columns_to_record_batch(c, names=["id", "j", "jb"], on_text="binary")
+    assert rb.column("j").to_pylist() == [t.encode() for t in JSON_GOOD] + [None]
+    c.close(); b.close(); d.close()
+    for k, t in enumerate(JSON_BAD):
+        good = ["1", "{}", "[]"]
+        bad = ["2", "{}", "[]"]
+        bad[1 + k % 2] = t
+        buf, offs = _stream([W.insert(42, good), W.insert(42, bad), W.insert(42, good)])
+        hb, b, d = _both(SC.simple_table(cols2), buf, offs)
+        with pytest.raises(EtlError) as ei:
+            b.columns(0)
+        assert ei.value.code == abi.E_JSON and ei.value.kind == abi.DeserializationError and ei.value.frame_index == 2, t
+        assert ei.value.description == "JSON deserialization failed"
+        b.close(); d.close()
