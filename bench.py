@@ -415,6 +415,65 @@ def leg_handoff(dev_id, dev, cap, reps):
     return out
 
 
+def leg_pcie(dev_id, dev, cap, nbatches):
+    """the end-to-end rate when the boundary hands over HOST buffers — never `value`, reported beside it.
+    `in`: pinned host input -> the library's copy stream -> decode, arena left in HBM (ETLG_F_ASYNC from host buffers: a ring of
+    three pinned buffers, the upload of batch k+1 beside the decode of batch k). `host_to_host`: the same plus the arena copied back
+    into pinned host memory per batch (etlg_batch_download), i.e. what a host-side sink consumes. cfg2 batches, offsets sidecar."""
+    import numpy as np
+    import torch
+
+    from etl_amd import abi, synth
+    from etl_amd.decoder import Decoder
+    w = synth.cfg2()
+    pool = [w.fill(cap) for _ in range(3)]
+    d = Decoder(dev_id)
+    w.register(d)
+    ring = []
+    for b, o in pool:   # each pool batch has a pinned buffer of its own: the ring of the batcher, already filled
+        hb, ho = d.host_alloc(len(b) + 64), d.host_alloc(len(o) * 4 + 64)
+        hb[:len(b)] = b
+        ho.view(np.uint32)[:len(o)] = o
+        ring.append((hb, ho, len(b), len(o) - 1))
+    flags = abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC | abi.F_NO_CONTROL
+    out = {"workload": f"{w.name}: {cap >> 20} MiB batches from a ring of {len(ring)} pinned host buffers, offsets sidecar, NO_CONTROL | ASYNC"}
+
+    def run(n, download):
+        inflight, nbytes, out_bytes = [], 0, 0
+
+        def retire():
+            nonlocal out_bytes
+            b, nb = inflight.pop(0)
+            assert b.sync() == 0, b.error
+            v = b.view()
+            out_bytes += HEADER_BYTES_PER_EVENT * v.n_events + v.fixed_bytes + v.heap_bytes
+            if download:
+                assert d.L.etlg_batch_download(d.h, b.h) == 0
+            b.close()
+        for k in range(n):
+            if len(inflight) >= len(ring) - 1:   # a buffer is reused only after its batch has been collected
+                retire()
+            hb, ho, nb, nf = ring[k % len(ring)]
+            inflight.append((d.decode_host_ptr(hb.ctypes.data, nb, ho.ctypes.data, nf, flags), nb))
+            nbytes += nb
+        while inflight:
+            retire()
+        torch.cuda.synchronize()
+        return nbytes, out_bytes
+    for name, download in (("in", False), ("host_to_host", True)):
+        run(4, download)
+        t0 = time.perf_counter()
+        nbytes, out_bytes = run(nbatches, download)
+        dt = time.perf_counter() - t0
+        out[name] = {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "batches": nbatches, "ms_per_batch": round(1e3 * dt / nbatches, 3),
+                     "arena_bytes_per_batch": int(out_bytes / nbatches)}
+    out["staged_on_copy_stream"] = d.debug_staged()
+    for hb, ho, _, _ in ring:
+        d.host_free(hb); d.host_free(ho)
+    d.close()
+    return out
+
+
 def leg_no_sidecar(dec, items, steps, check):
     """The same cfg2 batches with frame_offsets = NULL: the record-boundary scan runs on the device first (scan.hip).
     Reported beside `value`, never as `value`: the reference's host learns every frame length from its socket codec.
@@ -515,14 +574,13 @@ def leg_cfg4(dev_id, dev, world, rank, total_gib, seg_mib, gather_arenas, dist):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         frames, keep, ctrl = 0, [], []
-        for s, o, t in zip(d_segs, d_offs, d_tags):   # (1) boundaries + tags on the device, cut points on the host
+        for s, o, t in zip(d_segs, d_offs, d_tags):   # (1) boundaries + control stream on the device: per segment the host reads back a
+                                                      #     frame count and 8 bytes (control-frame count, last tag) — no segment bytes, no tags
             nf = dec.scan_boundaries_device(s.data_ptr(), s.numel(), o.data_ptr(), o.numel())
-            dec.frame_tags_device(s.data_ptr(), s.numel(), o.data_ptr(), nf, t.data_ptr())
-            tags = t[:nf].cpu().numpy()
-            assert tags[nf - 1] == ord("C"), "a segment ends after a Commit"
-            has_ctrl = np.flatnonzero((tags == ord("R")) | (tags == ord("M")))
-            if len(has_ctrl):   # rare: pull those transactions back and extract the control stream
-                ctrl.append(shard.control_stream(s.cpu().numpy(), o[:nf + 1].cpu().numpy().view(np.uint32), tags=tags))
+            cb, co, last = dec.control_stream(s.data_ptr(), s.numel(), o.data_ptr(), nf)
+            assert last == ord("C"), "a segment ends after a Commit"
+            if len(co) > 1:   # rare: the transactions that hold Relation / DDL frames, reduced to {Begin, control frames, Commit}
+                ctrl.append((cb, co))
             frames += nf
             keep.append((s, o, nf))
         if dist is not None:   # (2) control frames of earlier ranks (cfg4 has none after the schemas are primed: an empty exchange)
@@ -530,7 +588,7 @@ def leg_cfg4(dev_id, dev, world, rank, total_gib, seg_mib, gather_arenas, dist):
             shard.replay_control(dec, [x for x in shard.all_gather_control(mine_ctrl)[:rank] if len(x[1]) > 1])
         dec.reset_stream_state()
         batches = []
-        fl = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
+        fl = abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC | (abi.F_NO_CONTROL if not ctrl else 0)   # the assertion only when step (1) found no control frame
         hdrs = torch.zeros((len(keep), 8), dtype=torch.int64, device=dev)
         for i, (s, o, nf) in enumerate(keep):          # (3) decode, one batch per segment (<= 1 GiB)
             b = dec.decode_device(s.data_ptr(), s.numel(), o.data_ptr(), nf, fl)
@@ -601,7 +659,7 @@ def main():
     ap.add_argument("--batch-mib", type=int, default=64)
     ap.add_argument("--pool", type=int, default=6, help="distinct batches resident in HBM (rotated)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar,handoff,default_flags", help="extra legs on rank 0 (comma separated; empty = none)")
+    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar,handoff,default_flags,pcie,cfg4", help="extra legs on rank 0 (comma separated; empty = none)")
     ap.add_argument("--cfg4-leg", action="store_true", help="add the cfg4 leg to a cfg2 / cfg3 run")
     ap.add_argument("--cfg4-gib", type=int, default=8)
     ap.add_argument("--cfg4-seg-mib", type=int, default=1024)
@@ -799,8 +857,10 @@ def main():
             extra["copy"] = leg_copy(local_rank, dev, 400000, 8)
         if "handoff" in legs:
             extra["handoff"] = leg_handoff(local_rank, dev, cap, 5)
-    if args.cfg4_leg and world == 1:
-        extra["cfg4"] = leg_cfg4(local_rank, dev, 1, 0, args.cfg4_gib, args.cfg4_seg_mib, False, None)
+        if "pcie" in legs:
+            extra["pcie"] = leg_pcie(local_rank, dev, cap, 24)
+    if (args.cfg4_leg or "cfg4" in legs) and world == 1 and args.workload != "cfg4":
+        extra["cfg4"] = leg_cfg4(local_rank, dev, 1, 0, args.cfg4_gib if args.cfg4_leg else 2, args.cfg4_seg_mib, False, None)   # the default line: 2 GiB of the 64 GiB stream on this one GPU
 
     # ---- CPU baseline leg (rank 0, N == 1 only): the oracle on the same host cores
     cpu = None

@@ -330,6 +330,23 @@ extern "C" {
         tags_out: *mut u8,
     ) -> i32;
 
+    pub fn etlg_control_stream(
+        ctx: *mut etlg_ctx,
+        buf: *const u8,
+        len: usize,
+        frame_offsets: *const u32,
+        nframes: usize,
+        flags: u32,
+        out_bytes: *mut u8,
+        out_cap: usize,
+        out_offsets: *mut u32,
+        out_offsets_cap: usize,
+        n_bytes: *mut usize,
+        n_frames: *mut usize,
+        last_tag: *mut u32,
+    ) -> i32;
+    pub fn etlg_host_alloc(ctx: *mut etlg_ctx, bytes: usize, out: *mut *mut c_void) -> i32;
+    pub fn etlg_host_free(p: *mut c_void);
     pub fn etlg_batch_view_get(batch: *const etlg_batch, out: *mut etlg_batch_view) -> i32;
     pub fn etlg_batch_sync(ctx: *mut etlg_ctx, batch: *mut etlg_batch) -> i32;
     pub fn etlg_batch_header_to_device(ctx: *mut etlg_ctx, batch: *mut etlg_batch, dst_device_8xu64: *mut c_void) -> i32;

@@ -4,12 +4,15 @@
 //! ReplicationMessageStream ──bytes──▶ StagingBatcher ──64 MiB + sidecar──▶ GpuDecoder::decode ──arena──▶ materialize::events ──▶ EventBatch
 //! ```
 //! * [`ffi`]         raw binding of `include/etlg.h` (checked against the header by the etl-gfx950 test suite);
-//! * [`batcher`]     frames + offsets sidecar accumulation, flush policy (apply.rs:1910-1967);
+//! * [`batcher`]     frames + offsets sidecar accumulation in a ring of pinned buffers, flush policy (apply.rs:1910-1967);
+//! * [`flush`]       `last_received_lsn` / `last_commit_end_lsn` / effective flush LSN for a loop that decodes batches (apply.rs:2039-2051,
+//!                   1918-1928, 2000, 885-912);
 //! * [`materialize`] arena → `Event` / `TableRow` / `Cell`, DEFERRED cells finished with the reference's own parser;
 //! * [`GpuDecoder`]  safe wrapper of one context: side inputs mirror `SchemaStore` / `StateStore` / `SharedTableCache`
 //!                   (crates/etl/src/store/schema/base.rs:19-69, store/state/base.rs:25-139, replication/table_cache.rs:88-154).
 pub mod batcher;
 pub mod ffi;
+pub mod flush;
 pub mod materialize;
 
 use std::ffi::{CStr, CString};
@@ -103,27 +106,73 @@ impl GpuDecoder {
         unsafe { etlg_ctx_set_worker(self.ctx, kind, id, bootstrap_snapshot_lsn) };
     }
 
-    /// Decodes one staged batch into the events the apply loop would have produced message by message. On a decode error
-    /// (fail-fast, apply.rs:2475-2481) the events BEFORE the failing frame are returned with the error.
-    pub fn decode(&mut self, staged: &StagedBatch, schemas: &mut dyn materialize::SlotSchemas) -> (Vec<Event>, EtlResult<()>) {
+    /// The raw context, for `StagingBatcher::new` (its buffers are pinned through the context's device).
+    pub fn raw(&self) -> *mut etlg_ctx {
+        self.ctx
+    }
+
+    /// Enqueues one staged batch: `ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE`, host input. The library uploads the pinned buffer on its
+    /// copy stream beside the decode of the batch issued before (include/etlg.h) and returns at once; the staged buffer travels with
+    /// the handle and must not be touched until `finish` gives it back. Keep fewer than 32 batches in flight and finish them in
+    /// issue order.
+    pub fn decode_async(&mut self, staged: StagedBatch) -> Result<InFlight, (StagedBatch, EtlError)> {
         let mut batch = ptr::null_mut();
-        let flags = if staged.control_free { ETLG_F_NO_CONTROL } else { 0 };
-        let rc = unsafe {
-            etlg_decode(self.ctx, staged.frames.as_ptr(), staged.frames.len(), staged.offsets.as_ptr(), staged.meta.len(), flags, &mut batch)
-        };
+        let flags = ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE | if staged.control_free { ETLG_F_NO_CONTROL } else { 0 };
+        let rc = unsafe { etlg_decode(self.ctx, staged.frames_ptr(), staged.len, staged.offsets_ptr(), staged.nframes, flags, &mut batch) };
         if batch.is_null() {
-            return (Vec::new(), Err(self.last_error()));
+            let _ = rc;
+            let e = self.last_error();
+            return Err((staged, e));
         }
+        Ok(InFlight { batch, staged })
+    }
+
+    /// Has the batch been decoded? Never blocks... it is `finish` that waits. (The C ABI has no non-blocking probe: a loop that
+    /// wants one keeps a batch in flight for one fill period of the next buffer — by then it is done — and calls `finish`.)
+    ///
+    /// Collects a batch issued by `decode_async`: waits for it (`etlg_batch_sync`, issue order), copies the arena to the host
+    /// (`etlg_batch_download`) and materialises the events. On a decode error (fail-fast, apply.rs:2475-2481) the events BEFORE the
+    /// failing frame are returned with the error. The staged buffer comes back for `StagingBatcher::recycle`.
+    pub fn finish(&mut self, f: InFlight, schemas: &mut dyn materialize::SlotSchemas) -> (Vec<Event>, StagedBatch, EtlResult<()>) {
+        let InFlight { batch, staged } = f;
+        let rc = unsafe { etlg_batch_sync(self.ctx, batch) };
         let status = if rc == ETLG_OK { Ok(()) } else { Err(self.last_error()) };
+        if unsafe { etlg_batch_download(self.ctx, batch) } != ETLG_OK {
+            let e = self.last_error();
+            unsafe { etlg_batch_free(batch) };
+            return (Vec::new(), staged, Err(e));
+        }
         let mut view = std::mem::MaybeUninit::<etlg_batch_view>::uninit();
         unsafe { etlg_batch_view_get(batch, view.as_mut_ptr()) };
         let view = unsafe { view.assume_init() };
         let events = unsafe { materialize::events(&view, schemas) };
         unsafe { etlg_batch_free(batch) };
         match events {
-            Ok(ev) => (ev, status),
-            Err(e) => (Vec::new(), Err(e)),
+            Ok(ev) => (ev, staged, status),
+            Err(e) => (Vec::new(), staged, Err(e)),
         }
+    }
+
+    /// Synchronous form: one staged batch in, its events out (`decode_async` + `finish`).
+    pub fn decode(&mut self, staged: StagedBatch, schemas: &mut dyn materialize::SlotSchemas) -> (Vec<Event>, StagedBatch, EtlResult<()>) {
+        match self.decode_async(staged) {
+            Ok(f) => self.finish(f, schemas),
+            Err((staged, e)) => (Vec::new(), staged, Err(e)),
+        }
+    }
+}
+
+/// A batch between `decode_async` and `finish`: the library's handle plus the pinned buffer it is reading.
+pub struct InFlight {
+    batch: *mut etlg_batch,
+    staged: StagedBatch,
+}
+
+unsafe impl Send for InFlight {}
+
+impl InFlight {
+    pub fn frames(&self) -> &[crate::batcher::FrameMeta] {
+        &self.staged.meta
     }
 }
 

@@ -238,6 +238,5 @@ pub unsafe fn events(view: &etlg_batch_view, schemas: &mut dyn SlotSchemas) -> E
         };
         out.push(ev);
     }
-    let _ = Arc::strong_count; // (schemas are cheap clones: ReplicatedTableSchema holds Arcs)
     Ok(out)
 }

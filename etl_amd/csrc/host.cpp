@@ -33,6 +33,9 @@ using namespace etlg;
 
 extern "C" void etlg_k_launch(int which, const DecParams* p, hipStream_t s);
 extern "C" const char* etlg_k_name(int which);
+extern "C" void etlg_k_ctl_pick(const uint8_t* tags, uint32_t nframes, uint32_t* hdr, uint32_t* list, uint32_t cap, hipStream_t s);
+extern "C" void etlg_k_ctl_span(const uint8_t* tags, uint32_t nframes, const uint32_t* list, uint32_t n, uint32_t* span, hipStream_t s);
+extern "C" void etlg_k_ctl_gather(const uint8_t* in, const uint32_t* offs, const uint32_t* frames, uint32_t nkeep, uint32_t* lens, const uint32_t* out_offs, uint8_t* out, hipStream_t s);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_fused_set_lds(void);
 extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* cur, void* clear, uint32_t clear_words,
@@ -312,6 +315,8 @@ struct etlg_ctx {
   ScanJob scan_job;                   // ... and that scan
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
+  hipStream_t h2d_stream = nullptr;   // ASYNC batches with host input: their bytes + sidecar are uploaded here, beside the previous batch's decode
+  unsigned long long staged_async = 0;
   std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
   std::vector<std::pair<void*, size_t>> blk_dev, blk_host;  // hand-off calls (columns / RowBinary / size hints): pooled device and pinned blocks
   DevBuf d_colsel;                   // etlg_batch_columns: block counts of the row selection
@@ -389,6 +394,9 @@ struct etlg_batch {
   DecParams ctl_params{};
   DevResult* h_ctl = nullptr;      // pinned copy of the pre-pass result block
   hipEvent_t ctl_ev = nullptr;     // behind the pre-pass and its copies
+  // ASYNC with host input: the bytes and the sidecar travel to a device block of the batch's own on the copy stream
+  void* stage_blk = nullptr; size_t stage_cap = 0;
+  hipEvent_t h2d_done = nullptr;   // behind the two copies (the decode streams wait for it on the device)
 };
 
 struct HandoffBlocks {  // two device blocks (+ one pinned block when downloaded), taken from / returned to the context's pool
@@ -1064,6 +1072,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   if (c->h_ctl_stage) (void)hipHostFree(c->h_ctl_stage);
   c->d_ctl_res.release();
   if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
+  if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
   if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->tail2) (void)hipEventDestroy(c->tail2);
@@ -1190,7 +1199,17 @@ int32_t etlg_ctx_debug_paths(etlg_ctx* c, unsigned long long* out4) {
 //   (a Relation / DDL frame, or a caller without ETLG_F_NO_CONTROL on the multi-pass path)  [7] ASYNC batches re-run because their predecessor failed
 // debugging aid (not part of etlg.h): ASYNC batches that were enqueued beside their predecessor on the second decode stream
 unsigned long long etlg_ctx_debug_overlapped(etlg_ctx* c) { return c ? c->overlapped : 0; }
-unsigned long long etlg_ctx_debug_ctl_ahead(etlg_ctx* c) { return c ? c->ctl_ahead_n : 0; }   // batches whose control pre-pass ran ahead of their decode
+unsigned long long etlg_ctx_debug_ctl_ahead(etlg_ctx* c) { return c ? c->ctl_ahead_n : 0; }
+unsigned long long etlg_ctx_debug_staged(etlg_ctx* c) { return c ? c->staged_async : 0; }   // ASYNC batches whose host input was staged on the copy stream
+
+int32_t etlg_host_alloc(etlg_ctx* c, size_t bytes, void** out) {
+  if (!c || !out || !bytes) return ETLG_InvalidArgument;
+  *out = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return ETLG_OK;
+}
+void etlg_host_free(void* p) { if (p) (void)hipHostFree(p); }   // batches whose control pre-pass ran ahead of their decode
 int32_t etlg_ctx_debug_paths8(etlg_ctx* c, unsigned long long* out8) {
   if (!c || !out8) return ETLG_InvalidArgument;
   for (int i = 0; i < 8; i++) out8[i] = c->path_n[i];
@@ -1368,6 +1387,82 @@ int32_t etlg_frame_tags(etlg_ctx* c, const uint8_t* buf, size_t len, const uint3
   return ETLG_OK;
 }
 
+int32_t etlg_control_stream(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags,
+                            uint8_t* out_bytes, size_t out_cap, uint32_t* out_offsets, size_t out_offsets_cap,
+                            size_t* n_bytes, size_t* n_frames, uint32_t* last_tag) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
+  if (!c || !frame_offsets || !n_bytes || !n_frames) return ETLG_InvalidArgument;
+  clear_error(c);
+  *n_bytes = 0; *n_frames = 0;
+  if (last_tag) *last_tag = 0;
+  if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  if (!nframes) return ETLG_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; }
+  const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE;
+  hipStream_t s = c->stream;
+  DecParams p{};
+  p.in = buf; p.offs = frame_offsets;
+  if (!in_dev) {
+    HIPCHK(c, c->d_in.ensure(len + 64)); HIPCHK(c, c->d_offs.ensure((nframes + 1) * 4));
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_offs.p, frame_offsets, (nframes + 1) * 4, hipMemcpyHostToDevice, s));
+    p.in = (const uint8_t*)c->d_in.p; p.offs = (const uint32_t*)c->d_offs.p;
+  }
+  p.nframes = (uint32_t)nframes; p.nblocks = (p.nframes + kBlock - 1) / kBlock; p.in_len = len;
+  { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
+  launch(c, 0, p);   // k_classify: envelope + tag of every frame
+  constexpr uint32_t kCap = 1u << 16;   // control frames of one range the list holds
+  // scratch: hdr (2 words) | list | span (2 per frame) | keep frames (3 per frame) | lens | out offsets
+  ScratchBlk blk{c};
+  HIPCHK(c, blk_take(c, (size_t)kCap * 4 * 10 + 256, false, &blk.p, &blk.cap));
+  uint32_t* d_hdr = (uint32_t*)blk.p;
+  uint32_t* d_list = d_hdr + 16; uint32_t* d_span = d_list + kCap; uint32_t* d_keep = d_span + 2 * kCap;
+  uint32_t* d_lens = d_keep + 3 * kCap; uint32_t* d_oo = d_lens + 3 * kCap;
+  HIPCHK(c, hipMemsetAsync(d_hdr, 0, 8, s));
+  etlg_k_ctl_pick(p.f_tag, p.nframes, d_hdr, d_list, kCap, s);
+  uint32_t hdr[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(hdr, d_hdr, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (last_tag) *last_tag = hdr[1];
+  const uint32_t n = hdr[0];
+  if (!n) { if (out_offsets && out_offsets_cap) out_offsets[0] = 0; return ETLG_OK; }   // the common case: one kernel pair, one 8-byte copy
+  if (n > kCap) return lib_error(c, ETLG_Unsupported, "more than 65536 control frames in one range: extract the control stream of smaller ranges");
+  std::vector<uint32_t> list(n), span(2 * (size_t)n);
+  HIPCHK(c, hipMemcpy(list.data(), d_list, (size_t)n * 4, hipMemcpyDeviceToHost));
+  std::sort(list.begin(), list.end());   // the pick is unordered (atomics); the span kernel does not care, the stream does
+  HIPCHK(c, hipMemcpyAsync(d_list, list.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  etlg_k_ctl_span(p.f_tag, p.nframes, d_list, n, d_span, s);
+  HIPCHK(c, hipMemcpyAsync(span.data(), d_span, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  std::vector<uint32_t> keep(list);
+  for (uint32_t i = 0; i < n; i++) {
+    if (span[2 * i] == 0xFFFFFFFFu) continue;        // not inside a transaction of this range: the frame travels alone
+    keep.push_back(span[2 * i]);
+    if (span[2 * i + 1] != 0xFFFFFFFFu) keep.push_back(span[2 * i + 1]);
+  }
+  std::sort(keep.begin(), keep.end());
+  keep.erase(std::unique(keep.begin(), keep.end()), keep.end());
+  const uint32_t nk = (uint32_t)keep.size();   // <= 3 n
+  std::vector<uint32_t> lens(nk), oo((size_t)nk + 1, 0);
+  HIPCHK(c, hipMemcpyAsync(d_keep, keep.data(), (size_t)nk * 4, hipMemcpyHostToDevice, s));
+  etlg_k_ctl_gather(p.in, p.offs, d_keep, nk, d_lens, nullptr, nullptr, s);
+  HIPCHK(c, hipMemcpyAsync(lens.data(), d_lens, (size_t)nk * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (uint32_t i = 0; i < nk; i++) oo[i + 1] = oo[i] + lens[i];
+  *n_bytes = oo[nk]; *n_frames = nk;
+  if (!out_bytes || !out_offsets || out_cap < oo[nk] || out_offsets_cap < (size_t)nk + 1)
+    return lib_error(c, ETLG_InvalidArgument, "control stream does not fit the output buffers (n_bytes / n_frames hold what it needs)");
+  ScratchBlk stage{c};
+  HIPCHK(c, blk_take(c, (size_t)oo[nk] + 64, false, &stage.p, &stage.cap));
+  HIPCHK(c, hipMemcpyAsync(d_oo, oo.data(), (size_t)nk * 4, hipMemcpyHostToDevice, s));
+  etlg_k_ctl_gather(p.in, p.offs, d_keep, nk, d_lens, d_oo, (uint8_t*)stage.p, s);
+  HIPCHK(c, hipMemcpyAsync(out_bytes, stage.p, oo[nk], hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  memcpy(out_offsets, oo.data(), ((size_t)nk + 1) * 4);
+  return ETLG_OK;
+}
+
 // debugging aid (not part of etlg.h): [0] scans that needed a rerun with hints, [1] scans that fell back to the one-lane walk
 int32_t etlg_ctx_debug_scan(etlg_ctx* c, unsigned long long* out2) {
   if (!c || !out2) return ETLG_InvalidArgument;
@@ -1436,9 +1531,35 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   HIPCHK(c, hipSetDevice(c->device));
   { const int32_t rc_ = flush_deferred(c); (void)rc_; }
-  const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE, out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
+  bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE;
+  const bool out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
   const bool no_ctrl = flags & ETLG_F_NO_CONTROL;
   const bool scan = frame_offsets == nullptr;
+  // ---- ASYNC with HOST input (the staging batcher of a Rust host, crates/etl-gfx950/src/batcher.rs: pinned buffers from
+  //      etlg_host_alloc): the bytes and the sidecar are copied into a device block the batch owns, on a copy stream of their own,
+  //      and from here on the batch IS a device-input batch — it joins the chain, and its upload runs beside the decode of the batch
+  //      before it (double buffering: the caller fills its next buffer meanwhile). The caller keeps the host buffers untouched until
+  //      the batch is synced, as for every ASYNC batch (include/etlg.h).
+  void* stage_blk = nullptr; size_t stage_cap = 0; hipEvent_t h2d_done = nullptr;
+  if ((flags & ETLG_F_ASYNC) && out_dev && !in_dev && !scan && len && nframes && !c->copy.active && !c->force_multipass && len < (1ull << 31)) {
+    const size_t o_offs = (len + 16 + 255) & ~(size_t)255;   // the kernels' readers may touch up to 16 bytes past the input
+    HIPCHK(c, blk_take(c, o_offs + (nframes + 1) * 4 + 64, false, &stage_blk, &stage_cap));
+    if (!c->h2d_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
+    h2d_done = c->ev_pool.back(); c->ev_pool.pop_back();
+    HIPCHK(c, hipMemcpyAsync(stage_blk, buf, len, hipMemcpyHostToDevice, c->h2d_stream));
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)stage_blk + o_offs, frame_offsets, (nframes + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream));
+    HIPCHK(c, hipEventRecord(h2d_done, c->h2d_stream));
+    if (!c->stream2) {   // the chain may put this batch on either decode stream: both exist before anything waits
+      HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->tail2, hipEventDisableTiming));
+    }
+    for (hipStream_t w : {c->stream, c->stream2, c->ctl_stream, c->scan_stream}) if (w) HIPCHK(c, hipStreamWaitEvent(w, h2d_done, 0));
+    buf = (const uint8_t*)stage_blk; frame_offsets = (const uint32_t*)((const uint8_t*)stage_blk + o_offs);
+    in_dev = true;
+    c->staged_async++;
+  }
+  struct StageGuard { etlg_ctx* c; void*& p; size_t& cap; hipEvent_t& ev; ~StageGuard() { if (p) blk_give(c, c->gen, p, cap, false); if (ev) c->ev_pool.push_back(ev); } } stage_guard{c, stage_blk, stage_cap, h2d_done};
   // ASYNC batches are chained on the device (DecParams.carry) and may be decoded again when they are synced, so everything
   // they read must still be there then: device-resident input AND sidecar (the context's staging and scan buffers are shared
   // by all batches). Anything else is decoded synchronously; etlg_batch_sync on such a batch returns its stored result.
@@ -1463,6 +1584,8 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   b->ctx = c; b->ctx_gen = c->gen;
   BatchGuard guard{b};
   b->user_no_ctrl = no_ctrl; b->out_dev = out_dev; b->in_dev = in_dev; b->scan = scan; b->len = len;
+  b->stage_blk = stage_blk; b->stage_cap = stage_cap; b->h2d_done = h2d_done;   // the batch owns them from here (etlg_batch_free)
+  stage_blk = nullptr; h2d_done = nullptr;
   b->host_in = in_dev ? nullptr : buf; b->host_offs = (in_dev || scan) ? nullptr : h_offs; b->dev_in = in_dev ? buf : nullptr;
   b->d_in_ptr = d_in_ptr; b->user_offs = frame_offsets;
   if (scan) {
@@ -1489,6 +1612,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
       HIPCHK(c, hipStreamCreateWithFlags(&c->ctl_stream, hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&c->mp_tail, hipEventDisableTiming));
       HIPCHK(c, c->d_ctl_res.ensure(sizeof(DevResult) * etlg_ctx::kCtlRing));
+      if (b->h2d_done) HIPCHK(c, hipStreamWaitEvent(c->ctl_stream, b->h2d_done, 0));
     }
     b->nframes_in = nframes;
     b->ctl_async = true;
@@ -1764,11 +1888,15 @@ void etlg_batch_free(etlg_batch* b) {
     if (b->kdone) c->ev_pool.push_back(b->kdone);
     if (b->dev) c->out_pool.push_back(b->dev);
     if (b->scan_offs) c->offs_pool.push_back(b->scan_offs);
+    if (b->h2d_done) c->ev_pool.push_back(b->h2d_done);
+    if (b->stage_blk) blk_give(c, c->gen, b->stage_blk, b->stage_cap, false);
     if (b->h_res) c->res_pool.push_back(b->h_res);
     if (b->h_arena) c->harena_pool.emplace_back(b->h_arena, b->h_arena_cap);
   } else {  // the context is gone (its pools with it): release what the batch owns outright
     if (b->dev) { b->dev->release(); delete b->dev; }
     if (b->scan_offs) { b->scan_offs->release(); delete b->scan_offs; }
+    if (b->stage_blk) (void)hipFree(b->stage_blk);
+    if (b->h2d_done) (void)hipEventDestroy(b->h2d_done);
     if (b->done) (void)hipEventDestroy(b->done);
     if (b->kdone) (void)hipEventDestroy(b->kdone);
     if (b->ctl_ev) (void)hipEventDestroy(b->ctl_ev);

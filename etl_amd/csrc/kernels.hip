@@ -302,6 +302,38 @@ __global__ __launch_bounds__(kBlock) void k_finalize(DecParams p) {
   }
 }
 
+// ------------------------------------------------------------ control stream of a frame range (multi-GPU recipe)
+// Every shard broadcasts the transactions of its range that hold a Relation ('R') or logical-decoding Message ('M') frame,
+// reduced to {Begin, those frames, Commit}: apply.rs:2160-2276 and 2363-2440 are the only writers of the schema store and the
+// shared table cache. Three small kernels over the tags k_classify left: pick the control frames (rare: usually none, and the
+// host stops after the count), find each one's Begin / Commit, gather the kept frames' bytes.
+__global__ __launch_bounds__(kBlock) void k_ctl_pick(const u8* tags, uint32_t nframes, uint32_t* hdr /* [0] count, [1] last tag */, uint32_t* list, uint32_t cap) {
+  const uint32_t f = blockIdx.x * kBlock + threadIdx.x;
+  if (f >= nframes) return;
+  const uint32_t t = tags[f];
+  if (f == nframes - 1) hdr[1] = t;
+  if (t == 'R' || t == 'M') { const uint32_t i = atomicAdd(&hdr[0], 1u); if (i < cap) list[i] = f; }
+}
+// span[2 i] = frame of the Begin whose transaction holds control frame list[i], span[2 i + 1] = frame of that transaction's Commit
+// (0xFFFFFFFF: none — the frame stands outside a transaction of this range, or the transaction is still open at its end)
+__global__ __launch_bounds__(kBlock) void k_ctl_span(const u8* tags, uint32_t nframes, const uint32_t* list, uint32_t n, uint32_t* span) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = list[i];
+  uint32_t b = 0xFFFFFFFFu, c = 0xFFFFFFFFu;
+  for (uint32_t k = f; k-- > 0;) { const uint32_t t = tags[k]; if (t == 'B') { b = k; break; } if (t == 'C') break; }
+  if (b != 0xFFFFFFFFu) for (uint32_t k = f + 1; k < nframes; k++) if (tags[k] == 'C') { c = k; break; }
+  span[2 * i] = b; span[2 * i + 1] = c;
+}
+// one workgroup per kept frame: job[3 j] = input offset, [3 j + 1] = length, [3 j + 2] = output offset
+__global__ __launch_bounds__(kBlock) void k_ctl_gather(const u8* in, const uint32_t* offs, const uint32_t* frames, uint32_t* lens, const uint32_t* out_offs, u8* out) {
+  const uint32_t f = frames[blockIdx.x];
+  const uint32_t o0 = offs[f], len = offs[f + 1] - o0;
+  if (!out) { if (threadIdx.x == 0) lens[blockIdx.x] = len; return; }
+  const uint32_t pos = out_offs[blockIdx.x];
+  for (uint32_t k = threadIdx.x; k < len; k += kBlock) out[pos + k] = in[o0 + k];
+}
+
 // ------------------------------------------------------------------ launch
 }  // namespace etlg
 
@@ -321,6 +353,16 @@ void etlg_k_launch(int which, const DecParams* p, hipStream_t s) {
     case 6: hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, s, *p); break;
     default: break;
   }
+}
+
+void etlg_k_ctl_pick(const uint8_t* tags, uint32_t nframes, uint32_t* hdr, uint32_t* list, uint32_t cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_ctl_pick, dim3((nframes + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tags, nframes, hdr, list, cap);
+}
+void etlg_k_ctl_span(const uint8_t* tags, uint32_t nframes, const uint32_t* list, uint32_t n, uint32_t* span, hipStream_t s) {
+  hipLaunchKernelGGL(k_ctl_span, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tags, nframes, list, n, span);
+}
+void etlg_k_ctl_gather(const uint8_t* in, const uint32_t* offs, const uint32_t* frames, uint32_t nkeep, uint32_t* lens, const uint32_t* out_offs, uint8_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_ctl_gather, dim3(nkeep), dim3(kBlock), 0, s, in, offs, frames, lens, out_offs, out);
 }
 
 const char* etlg_k_name(int which) {

@@ -291,6 +291,33 @@ class Decoder:
             raise self.last_error()
         return Batch(self, out, rc, keep=(a, off))
 
+    def host_alloc(self, nbytes):
+        """Pinned host memory (etlg_host_alloc) as a writable np.uint8 array; free it with host_free(array)."""
+        p = C.c_void_p()
+        if self.L.etlg_host_alloc(self.h, nbytes, C.byref(p)) != abi.OK:
+            raise self.last_error()
+        a = np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=np.uint8)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        self.L.etlg_host_free(C.c_void_p(self._pinned.pop(a.ctypes.data)))
+
+    def decode_host_ptr(self, buf_ptr, nbytes, offs_ptr, nframes, flags):
+        """Host buffers by address (pinned staging buffers of a batcher): with abi.F_ASYNC | abi.F_OUTPUT_ON_DEVICE the upload
+        travels on the library's copy stream beside the previous batch's decode; the buffers stay untouched until the batch is synced."""
+        out = C.c_void_p()
+        rc = self.L.etlg_decode(self.h, C.c_void_p(buf_ptr), nbytes, C.c_void_p(offs_ptr), nframes, flags & ~abi.F_INPUT_ON_DEVICE, C.byref(out))
+        if not out:
+            raise self.last_error()
+        return Batch(self, out, rc)
+
+    def debug_staged(self):
+        self.L.etlg_ctx_debug_staged.restype = C.c_ulonglong
+        self.L.etlg_ctx_debug_staged.argtypes = [C.c_void_p]
+        return int(self.L.etlg_ctx_debug_staged(self.h))
+
     def decode_device(self, buf_ptr, nbytes, offs_ptr, nframes, flags=abi.F_OUTPUT_ON_DEVICE):
         """Device-resident input (raw device pointers, e.g. torch tensor .data_ptr())."""
         out = C.c_void_p()
@@ -358,6 +385,22 @@ class Decoder:
                                     abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE, C.c_void_p(out_ptr))
         if rc != 0:
             raise RuntimeError(f"etlg_frame_tags failed: {rc}")
+
+    def control_stream(self, buf_ptr, nbytes, offs_ptr, nframes, on_device=True):
+        """The control stream of a frame range, extracted on the device (etlg_control_stream): (bytes np.uint8, offsets np.uint32,
+        tag of the range's last frame). `buf_ptr` / `offs_ptr`: device pointers (or host addresses with on_device=False)."""
+        flags = abi.F_INPUT_ON_DEVICE if on_device else 0
+        nb, nf, last = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        out, offs = np.zeros(1 << 16, dtype=np.uint8), np.zeros(1 << 10, dtype=np.uint32)
+        for _ in range(2):
+            rc = self.L.etlg_control_stream(self.h, C.c_void_p(buf_ptr), nbytes, C.c_void_p(offs_ptr), nframes, flags, out.ctypes.data, out.size,
+                                            offs.ctypes.data, offs.size, C.byref(nb), C.byref(nf), C.byref(last))
+            if rc == abi.OK:
+                return out[:nb.value].copy(), offs[:nf.value + 1].copy(), int(last.value)
+            if rc != abi.InvalidArgument or (nb.value <= out.size and nf.value + 1 <= offs.size):
+                raise self.last_error()
+            out, offs = np.zeros(nb.value + 64, dtype=np.uint8), np.zeros(nf.value + 2, dtype=np.uint32)
+        raise self.last_error()
 
     def scan_boundaries_device(self, buf_ptr, nbytes, out_ptr, cap):
         """Record-boundary scan of a device-resident stream into a device array of `cap` u32 entries; returns nframes."""

@@ -275,8 +275,21 @@ enum {
                                         private stream beside the previous batch's decode and the call returns with
                                         that scan in flight (the next call on the context, or the batch's sync,
                                         enqueues the decode): the input must be COMPLETE in device memory when the
-                                        call is made (not merely enqueued on the context's stream) */
+                                        call is made (not merely enqueued on the context's stream).
+                                        With HOST input (no INPUT_ON_DEVICE) and a sidecar: the bytes and the sidecar are
+                                        uploaded into a device block the batch owns, on a private copy stream beside the
+                                        decode of the batch before it, and the batch joins the chain like a device-input
+                                        one. Truly asynchronous only from pinned memory (etlg_host_alloc); the caller must
+                                        not touch buf / frame_offsets until the batch is synced (two staging buffers in
+                                        rotation: fill one while the other is in flight). Without a sidecar a host-input
+                                        batch is decoded synchronously, as before */
 };
+
+/* Pinned (page-locked) host memory for the staging buffers of a host that feeds etlg_decode with ETLG_F_ASYNC: what the
+ * reference's apply loop accumulates per batch (EventBatch, crates/etl/src/replication/apply.rs:1918-1928) becomes two or more
+ * 64 MiB buffers of raw CopyData frames + their u32 offsets (crates/etl-gfx950/src/batcher.rs). Freed with etlg_host_free. */
+int32_t etlg_host_alloc(etlg_ctx* ctx, size_t bytes, void** out);
+void etlg_host_free(void* p);
 
 /* buf = `nframes` concatenated CopyData frames exactly as on the socket:
  *   'd' | Int32-BE length (incl. itself) | payload
@@ -333,6 +346,19 @@ int32_t etlg_scan_boundaries(etlg_ctx* ctx, const uint8_t* buf, size_t len, uint
  * flags: ETLG_F_INPUT_ON_DEVICE (buf / frame_offsets are device pointers), ETLG_F_OUTPUT_ON_DEVICE (tags_out is one). */
 int32_t etlg_frame_tags(etlg_ctx* ctx, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes,
                         uint32_t flags, uint8_t* tags_out);
+
+/* The control stream of a frame range, extracted on the device (multi-GPU recipe): for every transaction of the
+ * range that holds a Relation ('R') or logical-decoding Message ('M') frame, its Begin, those frames in order and its Commit
+ * (a control frame outside any transaction of the range travels alone). Decoding that stream on another context has the same
+ * effect on the schema store and the shared table cache as decoding the whole range (crates/etl/src/replication/apply.rs:
+ * 2160-2276, 2363-2440 are the only writers) — it is what the ranks broadcast before they decode their shards.
+ * out_bytes / out_offsets: HOST buffers for the frames and their n_frames + 1 offsets; n_bytes / n_frames are always set (a call
+ * whose buffers are too small fails with ETLG_InvalidArgument and says what it needs). last_tag: the pgoutput tag of the range's
+ * last frame ('C' when the range ends on a transaction boundary). Ranges without control frames — almost all — cost one
+ * classification pass and an 8-byte copy; nothing else of the range leaves the device. */
+int32_t etlg_control_stream(etlg_ctx* ctx, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes,
+                            uint32_t flags, uint8_t* out_bytes, size_t out_cap, uint32_t* out_offsets, size_t out_offsets_cap,
+                            size_t* n_bytes, size_t* n_frames, uint32_t* last_tag);
 
 /* ------------------------------------------------------------ batch (arena) */
 

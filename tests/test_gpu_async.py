@@ -408,3 +408,49 @@ def test_async_control_stream_with_a_ddl_message_the_host_rejects():
     assert hit
     paths = _chain_default_flags(w, pieces, warm=1, ready=False)
     assert paths["ctl_ahead"] >= 3 and paths["chain_rerun"] >= 1, paths
+
+
+@pytest.mark.parametrize("mk,no_ctrl", [(synth.cfg2, True), (synth.cfg3, True), (synth.cfg2, False)])
+def test_async_chain_from_pinned_host_buffers(mk, no_ctrl):
+    """ETLG_F_ASYNC with HOST input (the Rust batcher's staging ring, crates/etl-gfx950/src/batcher.rs): the bytes and the sidecar
+    of every batch are uploaded into a device block of its own on the library's copy stream and the batch joins the device-side
+    chain — transactions span the cuts, nothing is synced before everything is enqueued, a ring of three pinned buffers rotates
+    only as batches are collected."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = mk()
+    buf, offs = w.fill(3 << 20)
+    pieces = _cut(buf, offs, 9, seed=5)
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    cap = max(len(b) for b, _ in pieces) + 64
+    ncap = (max(len(of) for _, of in pieces) + 1) * 4
+    ring = [(d.host_alloc(cap), d.host_alloc(ncap)) for _ in range(3)]
+    flags = abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC | (abi.F_NO_CONTROL if no_ctrl else 0)
+    inflight, done = [], 0
+
+    def collect():
+        nonlocal done
+        b = inflight[done]
+        rb = o.decode(*pieces[done])
+        assert b.sync() == 0 and rb.err_code == 0, (done, b.error)
+        diff = rb.host_batch().diff(b.host())
+        assert not diff, f"batch {done}: {diff[:6]}"
+        b.close()
+        done += 1
+    for k, (pb, po) in enumerate(pieces):
+        if k - done >= len(ring):       # every buffer of the ring is in flight: collect the oldest batch, its buffer comes back
+            collect()
+        hb, ho = ring[k % len(ring)]
+        hb[:len(pb)] = pb
+        ho.view(np.uint32)[:len(po)] = po
+        inflight.append(d.decode_host_ptr(hb.ctypes.data, len(pb), ho.ctypes.data, len(po) - 1, flags))
+    while done < len(inflight):
+        collect()
+    assert d.debug_staged() == len(pieces)
+    paths = d.debug_paths()
+    assert paths["chain_rerun"] == 0 and paths["redone"] == 0, paths
+    for hb, ho in ring:
+        d.host_free(hb); d.host_free(ho)
+    d.close()

@@ -148,9 +148,69 @@ def test_constants_match_the_header():
 
 def test_other_sources_use_only_bound_symbols():
     bound = set(re.findall(r"\b(etlg_[a-z_0-9]+|ETLG_[A-Za-z0-9_]+)\b", FFI))
-    for f in ("lib.rs", "materialize.rs", "batcher.rs"):
+    for f in ("lib.rs", "materialize.rs", "batcher.rs", "flush.rs"):
         src = open(os.path.join(CRATE, "src", f)).read()
         src = re.sub(r"//[^\n]*", "", src)
         used = set(re.findall(r"\b(etlg_[a-z_0-9]+|ETLG_[A-Z][A-Za-z0-9_]+)\b", src))
         assert used <= bound, (f, sorted(used - bound))
     assert os.path.exists(os.path.join(CRATE, "Cargo.toml")) and os.path.exists(os.path.join(CRATE, "build.rs"))
+
+
+REF = "/root/reference"
+
+
+def _etl_paths():
+    """(crate, module path, item) for every `use etl::...` / `etl::a::b::Item` the shim names."""
+    out = set()
+    for f in ("lib.rs", "materialize.rs", "batcher.rs", "flush.rs"):
+        src = re.sub(r"//[^\n]*", "", open(os.path.join(CRATE, "src", f)).read())
+        for m in re.finditer(r"use (etl|etl_postgres)::([a-z_:]+)::\{([^}]+)\};", src):
+            for item in m.group(3).split(","):
+                item = item.strip().split(" as ")[0]
+                if item:
+                    out.add((m.group(1), m.group(2), item))
+        for m in re.finditer(r"use (etl|etl_postgres)::([a-z_:]+)::([A-Za-z_0-9]+);", src):
+            out.add((m.group(1), m.group(2), m.group(3)))
+        for m in re.finditer(r"use (etl)::(bail|etl_error);", src):
+            out.add((m.group(1), "", m.group(2)))
+    return sorted(out)
+
+
+def test_every_reference_path_the_shim_names_exists():
+    """grep-level check against the checkout the shim targets (it cannot be compiled here): each `etl::module::Item` resolves to a
+    module file of crates/etl (or crates/etl-postgres) that declares or re-exports an item of that name."""
+    import pytest
+    if not os.path.isdir(REF):
+        pytest.skip("the reference checkout is only present in the build container")
+    paths = _etl_paths()
+    assert len(paths) >= 15, paths
+    for crate, mod, item in paths:
+        root = os.path.join(REF, "crates", "etl" if crate == "etl" else "etl-postgres", "src")
+        if not mod:   # exported macros
+            text = "".join(open(os.path.join(dp, fn)).read() for dp, _, fns in os.walk(root) for fn in fns if fn.endswith(".rs"))
+            assert re.search(r"macro_rules!\s+" + item + r"\b", text), (crate, item)
+            continue
+        rel = mod.replace("::", "/")
+        cands = [os.path.join(root, rel + ".rs"), os.path.join(root, rel, "mod.rs")]
+        files = [c for c in cands if os.path.exists(c)]
+        assert files, (crate, mod, item, "no such module")
+        text = open(files[0]).read()
+        if os.path.isdir(os.path.join(root, rel)):   # a module directory: the item may live in a child it re-exports
+            text += "".join(open(os.path.join(root, rel, fn)).read() for fn in os.listdir(os.path.join(root, rel)) if fn.endswith(".rs"))
+        assert re.search(r"\b(struct|enum|trait|type|fn|const|static|mod)\s+" + item + r"\b|pub use [^;]*\b" + item + r"\b", text), (crate, mod, item)
+
+
+def test_the_patch_quotes_the_reference():
+    """patches/apply_rs.diff: its context lines (the ones without +/-) are lines of the reference's apply.rs."""
+    import pytest
+    if not os.path.isdir(REF):
+        pytest.skip("the reference checkout is only present in the build container")
+    ref = open(os.path.join(REF, "crates/etl/src/replication/apply.rs")).read()
+    patch = open(os.path.join(CRATE, "patches", "apply_rs.diff")).read()
+    body = patch[patch.index("--- a/crates/etl/src/replication/apply.rs"):]
+    ctx = [l[1:].strip() for l in body.split("\n") if l.startswith(" ") and l.strip()]
+    assert len(ctx) >= 8
+    for l in ctx:
+        assert l in ref, l
+    for hunk in re.findall(r"^@@ (.+)$", body, flags=re.M):
+        assert hunk.strip().split("(")[0] in ref, hunk

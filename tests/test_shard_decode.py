@@ -85,6 +85,41 @@ def test_sharded_decode_equals_single_decode_device(name, n):
         d.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(STREAMS))
+def test_control_stream_extracted_on_the_device(name):
+    """etlg_control_stream (the device-side extraction the multi-GPU bench uses: nothing of a shard but its control frames leaves
+    the device) == shard.control_stream (numpy on the host), for every shard of 1 / 3 / 8-way cuts: same frames, same bytes, and the
+    last tag of a commit-aligned range is 'C'. cfg3 has no control frame after its priming: the stream is empty."""
+    from etl_amd.decoder import Decoder
+    w, buf, offs = _stream(name)
+    d = Decoder(0)
+    seen = 0
+    for n in (1, 3, 8):
+        for f0, f1 in shard.plan_shards(buf, offs, n):
+            if f1 == f0:
+                continue
+            b, oo = shard.slice_shard(buf, offs, f0, f1)
+            b, oo = np.ascontiguousarray(b), np.ascontiguousarray(oo, dtype=np.uint32)
+            want_b, want_o = shard.control_stream(b, oo)
+            got_b, got_o, last = d.control_stream(b.ctypes.data, len(b), oo.ctypes.data, len(oo) - 1, on_device=False)
+            assert last == ord("C")
+            assert np.array_equal(got_o, want_o) and np.array_equal(got_b, want_b), (name, n, f0)
+            seen += len(got_o) - 1
+    assert (seen > 0) == (name == "cfg5")
+    # a range that starts inside a transaction and ends inside another: control frames without their Begin / Commit travel alone
+    tags = shard.frame_tags(buf, offs)
+    ctrl = np.flatnonzero((tags == ord("R")) | (tags == ord("M")))
+    if len(ctrl):
+        i = int(ctrl[len(ctrl) // 2])
+        b, oo = shard.slice_shard(buf, offs, i, min(i + 3, len(offs) - 1))
+        b, oo = np.ascontiguousarray(b), np.ascontiguousarray(oo, dtype=np.uint32)
+        want_b, want_o = shard.control_stream(b, oo)
+        got_b, got_o, _last = d.control_stream(b.ctypes.data, len(b), oo.ctypes.data, len(oo) - 1, on_device=False)
+        assert np.array_equal(got_o, want_o) and np.array_equal(got_b, want_b)
+    d.close()
+
+
 def test_control_stream_is_what_later_shards_need():
     """Without the broadcast a later shard decodes against a stale cache: the test that the test is meaningful."""
     from oracle import oracle
