@@ -463,7 +463,7 @@ DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& co
           else {
             const int h = arr_hexv(c);
             hex_bad |= h < 0;
-            if (vl & 1) { if (out) out[(vl - 3) >> 1] = (u8)((nib << 4) | (uint32_t)(h & 15)); } else nib = (uint32_t)(h & 15);
+            if (vl & 1) { if (out && !hex_bad) out[(vl - 3) >> 1] = (u8)((nib << 4) | (uint32_t)(h & 15)); } else nib = (uint32_t)(h & 15);   // (an unquoted NULL is four non-hex characters: it must not write)
           }
         }
         // a text element's bytes leave as they come, except the first four: an unquoted "null" is not text at all

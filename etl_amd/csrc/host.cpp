@@ -315,6 +315,7 @@ struct etlg_ctx {
   ScanJob scan_job;                   // ... and that scan
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
+  hipStream_t d2h_stream = nullptr;   // etlg_batch_download / host-output decodes: the arena of a finished batch travels here
   hipStream_t h2d_stream = nullptr;   // ASYNC batches with host input: their bytes + sidecar are uploaded here, beside the previous batch's decode
   unsigned long long staged_async = 0;
   std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
@@ -1073,6 +1074,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   c->d_ctl_res.release();
   if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+  if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->tail2) (void)hipEventDestroy(c->tail2);
@@ -2365,7 +2367,11 @@ namespace {
 int32_t download_batch(etlg_ctx* c, etlg_batch* b) {
   OutSet* os = b->dev;
   if (!os) return ETLG_OK;
-  hipStream_t s = c->stream;
+  // The batch is complete when this runs (its result block has been read on the host), so the copies need no ordering against
+  // the decode streams: they travel on a stream of their own and overlap the upload and decode of the batches issued after this
+  // one (PCIe is full duplex: a host-to-host pipeline costs max(upload, download) per batch, not their sum).
+  if (!c->d2h_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  hipStream_t s = c->d2h_stream;
   etlg_batch_view& v = b->v;
   const size_t n = (size_t)v.n_events;
   // layout of the pinned block: 8-byte arrays first, then 4-byte, then bytes (every part 64-byte aligned)
