@@ -269,6 +269,8 @@ struct etlg_ctx {
   static constexpr uint32_t kResRing = 32;
   uint32_t res_seq = 0;
   DevResult* h_init_ring = nullptr;
+  DevResult* d_init_ring = nullptr;   // the same, in device memory: the ring is re-initialised with a device-to-device copy (a 40 KB host-to-device
+                                      // hipMemcpyAsync made the calling thread wait for everything queued on the stream: 6.7 ms behind 15 cfg5 batches)
   CopyJob copy;        // set while etlg_copy_decode runs etlg_decode over its synthetic frames
   DevBuf d_copy_in, d_copy_offs, d_copy_out, d_copy_out_offs;
   DevBuf d_scan;       // scratch of the record-boundary scan
@@ -277,7 +279,7 @@ struct etlg_ctx {
   unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
   DevBuf d_ctrl_stage;   // bytes of a batch's Relation / DDL frames (k_ctrl_list gathers them)
   // ETLG_HOST_TIMES=1: wall-clock microseconds the host spends between marks of the control path, printed when the context goes
-  bool host_times = false; double host_us[12] = {0}; uint64_t host_n[12] = {0};
+  bool host_times = false, host_times_slow = false; double host_us[12] = {0}; uint64_t host_n[12] = {0};
   size_t ctrl_stage_cap_test = 0;
   std::chrono::steady_clock::time_point host_mark;
   DevBuf d_in, d_offs, d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_res, d_desc;
@@ -315,6 +317,7 @@ struct etlg_ctx {
   ScanJob scan_job;                   // ... and that scan
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
+  uint64_t fixed_hint = 0;            // largest fixed-arena bound seen so far, with head room (setup_outputs)
   hipStream_t d2h_stream = nullptr;   // etlg_batch_download / host-output decodes: the arena of a finished batch travels here
   hipStream_t h2d_stream = nullptr;   // ASYNC batches with host input: their bytes + sidecar are uploaded here, beside the previous batch's decode
   unsigned long long staged_async = 0;
@@ -938,11 +941,22 @@ bool plan_wanted(etlg_ctx* c, const etlg_batch* b);
 int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level);
 int32_t standard_path(etlg_ctx* c, etlg_batch* b);
 int32_t ctl_begin(etlg_ctx* c, etlg_batch* b, DecParams& p, hipStream_t s, bool ahead);
+struct SlowScope {   // ETLG_HOST_TIMES=2: names any of the instrumented calls that takes more than a millisecond
+  etlg_ctx* c; const char* what; std::chrono::steady_clock::time_point t0;
+  SlowScope(etlg_ctx* c_, const char* w) : c(c_), what(w) { if (c && c->host_times_slow) t0 = std::chrono::steady_clock::now(); }
+  ~SlowScope() {
+    if (!c || !c->host_times_slow) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (us > 1000.0) fprintf(stderr, "etlg host times: %s took %.0f us\n", what, us);
+  }
+};
 static inline void ht_start(etlg_ctx* c) { if (c->host_times) c->host_mark = std::chrono::steady_clock::now(); }
 static inline void ht_mark(etlg_ctx* c, int i) {
   if (!c->host_times) return;
   const auto t = std::chrono::steady_clock::now();
-  c->host_us[i] += std::chrono::duration<double, std::micro>(t - c->host_mark).count(); c->host_n[i]++;
+  const double us = std::chrono::duration<double, std::micro>(t - c->host_mark).count();
+  c->host_us[i] += us; c->host_n[i]++;
+  if (c->host_times_slow && us > 500.0) fprintf(stderr, "etlg host times: segment %d took %.0f us\n", i, us);   // ETLG_HOST_TIMES=2: outliers as they happen
   c->host_mark = t;
 }
 int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev);
@@ -1029,11 +1043,14 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   e = hipHostMalloc((void**)&c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipHostMallocDefault);
   if (e != hipSuccess) { snprintf(g_create_err, sizeof g_create_err, "hipHostMalloc: %s", hipGetErrorString(e)); delete c; return ETLG_DeviceError; }
   for (uint32_t i = 0; i < etlg_ctx::kResRing; i++) c->h_init_ring[i] = *c->h_init;
+  e = hipMalloc((void**)&c->d_init_ring, sizeof(DevResult) * etlg_ctx::kResRing);
+  if (e == hipSuccess) e = hipMemcpy(c->d_init_ring, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { snprintf(g_create_err, sizeof g_create_err, "hipMalloc: %s", hipGetErrorString(e)); delete c; return ETLG_DeviceError; }
   (void)etlg_k_fused_set_lds();
   (void)etlg_k_cells_set_lds();
   (void)etlg_k_copy_set_lds();
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
-  { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && ht[0] == '1'; }
+  { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && (ht[0] == '1' || ht[0] == '2'); c->host_times_slow = ht && ht[0] == '2'; }
   { const char* sc = getenv("ETLG_CTRL_STAGE_CAP"); c->ctrl_stage_cap_test = sc ? (size_t)atol(sc) : 0; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
@@ -1085,6 +1102,7 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   if (c->h_init) (void)hipHostFree(c->h_init);
   if (c->h_poison) (void)hipHostFree(c->h_poison);
   if (c->h_init_ring) (void)hipHostFree(c->h_init_ring);
+  if (c->d_init_ring) (void)hipFree(c->d_init_ring);
   for (DevResult* r : c->res_pool) (void)hipHostFree(r);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1528,6 +1546,7 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
 
 int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags, etlg_batch** out) {
   if (!c || !out) return ETLG_InvalidArgument;
+  SlowScope slow_scope_decode(c, "etlg_decode");
   *out = nullptr;
   clear_error(c);
   if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
@@ -1656,6 +1675,7 @@ namespace {
 // The decode of a batch whose boundary scan was left in flight by etlg_decode: collect the frame count, enqueue the kernels.
 // A failure here belongs to THAT batch (its sync reports it), not to the call that happens to run this.
 int32_t flush_deferred(etlg_ctx* c) {
+  SlowScope slow_scope_flush_deferred(c, "flush_deferred");
   etlg_batch* b = c ? c->deferred : nullptr;
   if (!b) return ETLG_OK;
   c->deferred = nullptr;
@@ -1685,6 +1705,7 @@ int32_t flush_deferred(etlg_ctx* c) {
 
 // Everything of etlg_decode that needs the frame count: parameters, result block, side inputs, outputs, the first kernel.
 int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev) {
+  SlowScope slow_scope_decode_tail(c, "decode_tail");
   hipStream_t s = c->stream;
   b->plan_decided = -1;
   const bool scan = b->scan, in_dev = b->in_dev, no_ctrl = b->user_no_ctrl;
@@ -1726,6 +1747,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   //      needs), side inputs unchanged (a change drains the chain), no lap boundary of the result ring. Decided before anything is
   //      enqueued for the batch; everything below then runs on the chosen stream.
   struct StreamSwitch { etlg_ctx* c; hipStream_t saved; ~StreamSwitch() { c->stream = saved; } } sw{c, c->stream};
+  SlowScope slow_scope_pre(c, "decode_tail: whole after params");
   bool beside = false;
   const bool first_try_single = p.nframes && !c->force_multipass && len < (1ull << 31) && (no_ctrl || !c->last_had_ctrl) && !b->ctl_async;
   if (async && prev && prev->pending && prev->level <= 1 && prev->used_fused && !prev->force_rerun && c->overlap_mode && first_try_single && c->res_seq != 0 && res_slot >= 2 &&
@@ -1759,6 +1781,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     HIPCHK(c, hipStreamWaitEvent(s, b->side->ready, 0));
     b->side->synced |= 1u << b->sidx;
   }
+  SlowScope slow_scope_ring(c, "decode_tail: result ring and after");
   {  // result block: next slot of a ring that is re-initialised once per lap. Slot 31 is the carry source of the batch in
      // slot 0, so it is re-initialised one batch later than the others.
     const uint32_t seq = c->res_seq++;
@@ -1767,15 +1790,18 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     // the blocks about to be re-initialised belong to batches whose result copies travel on res_stream: with two decode streams a
     // batch completes within microseconds of its predecessor, so "the copy of the batch before last is long done" no longer holds —
     // wait (on the device) for the copy of the latest batch, which is behind all the others
-    if ((slot == 0 || slot == 1) && prev && prev->pending && prev->done) HIPCHK(c, hipStreamWaitEvent(s, prev->done, 0));
-    if (seq == 0) HIPCHK(c, hipMemcpyAsync(ring, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice, s));
-    else if (slot == 0) HIPCHK(c, hipMemcpyAsync(ring, c->h_init_ring, sizeof(DevResult) * (etlg_ctx::kResRing - 1), hipMemcpyHostToDevice, s));
-    else if (slot == 1) HIPCHK(c, hipMemcpyAsync(ring + (etlg_ctx::kResRing - 1), c->h_init_ring, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    { SlowScope sw1(c, "ring: wait event");
+    if ((slot == 0 || slot == 1) && prev && prev->pending && prev->done) HIPCHK(c, hipStreamWaitEvent(s, prev->done, 0)); }
+    { SlowScope sw2(c, "ring: init copy");
+    if (seq == 0) HIPCHK(c, hipMemcpyAsync(ring, c->d_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyDeviceToDevice, s));
+    else if (slot == 0) HIPCHK(c, hipMemcpyAsync(ring, c->d_init_ring, sizeof(DevResult) * (etlg_ctx::kResRing - 1), hipMemcpyDeviceToDevice, s));
+    else if (slot == 1) HIPCHK(c, hipMemcpyAsync(ring + (etlg_ctx::kResRing - 1), c->d_init_ring, sizeof(DevResult), hipMemcpyDeviceToDevice, s)); }
     b->d_res_blk = ring + slot;
   }
   p.res = b->d_res_blk;
+  { SlowScope slow_scope_pool(c, "decode_tail: pinned result block");
   if (c->res_pool.empty()) { DevResult* r = nullptr; HIPCHK(c, hipHostMalloc((void**)&r, sizeof(DevResult), hipHostMallocDefault)); c->res_pool.push_back(r); }
-  b->h_res = c->res_pool.back(); c->res_pool.pop_back();
+  b->h_res = c->res_pool.back(); c->res_pool.pop_back(); }
   if (b->copy.active) launch_copy(c, b->copy, p);  // rows -> Insert frames (writes p.in / p.offs), row-level errors
 
   // ---- first attempt. A single-pass kernel runs OPTIMISTICALLY as if the batch held no Relation / DDL frame (they are
@@ -1797,6 +1823,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     if (rc != ETLG_OK) return rc;
   }
   if (b->n_slots_view == ~(size_t)0) b->n_slots_view = c->slots.size();
+  SlowScope slow_scope_tail(c, "decode_tail: result copy");
   if (async) {
     // the result block is copied on a second stream: on the context's stream the next batch's kernel follows this one
     // directly (a 200-byte device-to-host copy is a 4 us blit kernel plus two dispatch gaps when it sits between them)
@@ -2437,6 +2464,7 @@ int32_t setup_scratch(etlg_ctx* c, DecParams& p) {
 // create) + schema slots + the fixed-width plan's tables. Re-uploaded only when they change; a change behind pending ASYNC
 // batches finishes those first (their kernels read the old copy).
 int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec>& eps) {
+  SlowScope slow_scope_build_side_inputs(c, "build_side_inputs");
   DecParams& p = b->params;
   hipStream_t s = c->stream;
   auto point = [&](SideSet* ss, uint32_t n_tables, uint32_t n_epochs) {
@@ -2570,6 +2598,7 @@ int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec
 // Output arrays (capacity bounds: one event per frame; rows bounded by the widest slot; truncate bodies by 2x frame bytes;
 // heap by 2.5x input). Called again when the control path created wider slots.
 int32_t setup_outputs(etlg_ctx* c, etlg_batch* b) {
+  SlowScope slow_scope_setup_outputs(c, "setup_outputs");
   DecParams& p = b->params;
   if (!b->dev) b->dev = take_outset(c);
   OutSet* os = b->dev;
@@ -2581,7 +2610,13 @@ int32_t setup_outputs(etlg_ctx* c, etlg_batch* b) {
   HIPCHK(c, os->table.ensure(evcap * 4)); HIPCHK(c, os->slot.ensure(evcap * 4));
   HIPCHK(c, os->start.ensure(evcap * 8)); HIPCHK(c, os->commit.ensure(evcap * 8));
   HIPCHK(c, os->ord.ensure(evcap * 8)); HIPCHK(c, os->body.ensure(evcap * 8));
-  HIPCHK(c, os->fixed.ensure(fixed_cap)); HIPCHK(c, os->heap.ensure(heap_cap));
+  // The fixed arena's bound follows the widest slot, which a stream with DDL keeps widening (ALTER TABLE ADD COLUMN): grown to the
+  // exact bound each time, every arena of the pool was re-allocated again and again (hipFree + hipMalloc synchronise the device:
+  // 1.9 ms per cfg5 batch, ETLG_HOST_TIMES). The context remembers the largest bound it has seen with head room, and every arena
+  // that has to grow goes there at once.
+  if (fixed_cap > c->fixed_hint) c->fixed_hint = fixed_cap + fixed_cap / 2;
+  if (os->fixed.cap < fixed_cap) HIPCHK(c, os->fixed.ensure(std::max<uint64_t>(fixed_cap, c->fixed_hint)));
+  HIPCHK(c, os->heap.ensure(heap_cap));
   p.ev_kind = (uint8_t*)os->kind.p; p.ev_flags = (uint8_t*)os->flags.p; p.ev_table = (uint32_t*)os->table.p; p.ev_slot = (uint32_t*)os->slot.p;
   p.ev_start = (uint64_t*)os->start.p; p.ev_commit = (uint64_t*)os->commit.p; p.ev_ord = (uint64_t*)os->ord.p; p.ev_body = (uint64_t*)os->body.p;
   p.fixed = (uint8_t*)os->fixed.p; p.heap = (uint8_t*)os->heap.p; p.fixed_cap = fixed_cap; p.heap_cap = heap_cap;
@@ -2610,6 +2645,7 @@ hipError_t sync_decode_streams(etlg_ctx* c) {
   return e;
 }
 int32_t take_descriptors(etlg_ctx* c, size_t dbytes, uint8_t** cur_out, uint8_t** oth_out) {
+  SlowScope slow_scope_take_descriptors(c, "take_descriptors");
   hipStream_t s = c->stream;
   if (dbytes > c->desc_half) {
     const size_t half = (dbytes * 2 + 4095) & ~(size_t)4095;
@@ -2633,6 +2669,7 @@ int32_t take_descriptors(etlg_ctx* c, size_t dbytes, uint8_t** cur_out, uint8_t*
 // Enqueues ONE single-pass kernel over the batch: level 0 = the fixed-width plan (plan.hip), level 1 = the generic fused
 // kernel (fused.hip) or, for wide frames, the column-parallel one (cells.hip).
 int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
+  SlowScope slow_scope_enqueue_single(c, "enqueue_single");
   const DecParams& p = b->params;
   const uint32_t nf = p.nframes;
   const uint64_t avg = (b->len + nf - 1) / nf;
@@ -2714,6 +2751,7 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
 // sizes first (one round trip instead of three; what does not fit is fetched afterwards). `ahead`: on the control stream, beside the
 // decode of the batch before (etlg_decode); otherwise on the context's stream, collected at once (run_control_pass).
 int32_t ctl_begin(etlg_ctx* c, etlg_batch* b, DecParams& p, hipStream_t s, bool ahead) {
+  SlowScope slow_scope_ctl_begin(c, "ctl_begin");
   struct StreamSwitch { etlg_ctx* c; hipStream_t saved; ~StreamSwitch() { c->stream = saved; } } sw{c, c->stream};
   c->stream = s;
   const uint32_t nf = p.nframes;
@@ -2727,7 +2765,7 @@ int32_t ctl_begin(etlg_ctx* c, etlg_batch* b, DecParams& p, hipStream_t s, bool 
     b->h_ctl = c->res_pool.back(); c->res_pool.pop_back();
     if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
     b->ctl_ev = c->ev_pool.back(); c->ev_pool.pop_back();
-    HIPCHK(c, hipMemcpyAsync(p.res, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(p.res, c->d_init_ring, sizeof(DevResult), hipMemcpyDeviceToDevice, s));
   }
   { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
   launch(c, 0, p);
@@ -2751,6 +2789,7 @@ int32_t ctl_begin(etlg_ctx* c, etlg_batch* b, DecParams& p, hipStream_t s, bool 
 // The control pre-pass of one batch (device half above, unless it ran ahead), then the host control plane (handle_relation /
 // handle_ddl) in frame order. Fills b->ctrl / ctrl_raw, `eps`, the host error of the batch.
 int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps) {
+  SlowScope slow_scope_run_control_pass(c, "run_control_pass");
   hipStream_t s = c->stream;
   const uint32_t nf = b->params.nframes;
   ht_start(c);
@@ -2821,6 +2860,7 @@ int32_t run_control_pass(etlg_ctx* c, etlg_batch* b, std::vector<EpochRec>& eps)
 // the batch's own epochs, then the generic single-pass kernel or — forced, oversized, or behind a host error — the
 // multi-pass kernels. Synchronous callers only (immediate carry).
 int32_t standard_path(etlg_ctx* c, etlg_batch* b) {
+  SlowScope slow_scope_standard_path(c, "standard_path");
   DecParams& p = b->params;
   const uint32_t nf = p.nframes;
   std::vector<EpochRec> eps;
@@ -2852,6 +2892,7 @@ int32_t standard_path(etlg_ctx* c, etlg_batch* b) {
 
 // Finishes every pending ASYNC batch, oldest first.
 int32_t drain_pending(etlg_ctx* c) {
+  SlowScope slow_scope_drain_pending(c, "drain_pending");
   while (!c->pending.empty()) { const int32_t rc = finish_batch(c, c->pending.front()); (void)rc; }
   return ETLG_OK;
 }
@@ -2861,6 +2902,7 @@ int32_t drain_pending(etlg_ctx* c) {
 // error, commits or rolls back the control-plane state, updates the carried transaction state of the context and (for
 // host output) copies the arenas back. Batches finish in issue order.
 int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
+  SlowScope slow_scope_finish_batch(c, "finish_batch");
   hipStream_t s = c->stream;
   if (b->deferred) {  // its boundary scan is still in flight: collect it and enqueue the decode first
     const int32_t rc = flush_deferred(c);
@@ -2902,7 +2944,7 @@ int32_t finish_batch(etlg_ctx* c, etlg_batch* b) {
       FB_HIP(sync_decode_streams(c));
       for (etlg_batch* pb : c->pending) { pb->force_rerun = true; if (pb->deferred) pb->ctl_started = false; }   // (a pre-pass that ran ahead started from a state that was not final)
     }
-    FB_HIP(hipMemcpyAsync(b->d_res_blk, c->h_init, sizeof(DevResult), hipMemcpyHostToDevice, s));
+    FB_HIP(hipMemcpyAsync(b->d_res_blk, c->d_init_ring, sizeof(DevResult), hipMemcpyDeviceToDevice, s));
     if (b->copy.active) launch_copy(c, b->copy, p);
     if (ff & 8u) {  // the batch before this one failed, so this one never ran: same path again, now from the right state
       c->path_n[7]++;
