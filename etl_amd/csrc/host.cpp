@@ -1522,6 +1522,7 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
   if (nrows == 0) HIPCHK(c, hipMemsetAsync(j.d_out_offs, 0, 4, s));
   const uint64_t avg = nrows ? (len + nrows - 1) / nrows : 0;
   j.lds = (uint32_t)std::min<uint64_t>(((256 * avg * 9 / 8 + 1024) + 255) & ~255ull, 150 * 1024);
+  { const char* e = getenv("ETLG_COPY_LDS"); if (e) j.lds = (uint32_t)atoi(e); }   // measurement knob: 0 = rows read in place (no staging window, more waves per CU)
   // the rows decode inside a virtual transaction of their own; the context's stream state is left alone
   const bool sv_in = c->in_txn; const uint64_t sv_lsn = c->final_lsn, sv_ord = c->next_ord;
   c->in_txn = true; c->final_lsn = 0; c->next_ord = 0;
