@@ -30,6 +30,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import etl_amd  # noqa: E402,F401  (first thing, before torch initialises HIP: sets the process's HIP runtime defaults — hardware queues)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Algorithmic bytes of one launch: every input byte read once (frames + the 4-byte offsets sidecar per

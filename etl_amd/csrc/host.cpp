@@ -317,6 +317,7 @@ struct etlg_ctx {
   ScanJob scan_job;                   // ... and that scan
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
+  bool ring_h2d = false;              // ETLG_RING_H2D=1 (measurement / bisect knob): re-initialise the result ring from the host template
   uint64_t fixed_hint = 0;            // largest fixed-arena bound seen so far, with head room (setup_outputs)
   hipStream_t d2h_stream = nullptr;   // etlg_batch_download / host-output decodes: the arena of a finished batch travels here
   hipStream_t h2d_stream = nullptr;   // ASYNC batches with host input: their bytes + sidecar are uploaded here, beside the previous batch's decode
@@ -1004,6 +1005,12 @@ struct ScratchBlk {  // a device block for the duration of one call
   ~ScratchBlk() { if (p) blk_give(c, c->gen, p, cap, false); }
 };
 
+// A context spreads its work over up to seven HIP streams; ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware
+// queues (default 4), and two decode streams that share one queue serialise consecutive batches (etl_amd/__init__.py has the
+// measurements). The runtime reads the variable when it initialises (first HIP call of the process): a host that loads this
+// library before its first HIP call gets a workable default, an explicit setting of the caller's is respected.
+__attribute__((constructor)) static void etlg_runtime_defaults(void) { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" {
 
 uint32_t etlg_abi_version(void) { return ETLG_ABI_VERSION; }
@@ -1050,6 +1057,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   (void)etlg_k_cells_set_lds();
   (void)etlg_k_copy_set_lds();
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
+  { const char* e = getenv("ETLG_RING_H2D"); c->ring_h2d = e && e[0] == '1'; }
   { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && (ht[0] == '1' || ht[0] == '2'); c->host_times_slow = ht && ht[0] == '2'; }
   { const char* sc = getenv("ETLG_CTRL_STAGE_CAP"); c->ctrl_stage_cap_test = sc ? (size_t)atol(sc) : 0; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
@@ -1794,9 +1802,9 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     { SlowScope sw1(c, "ring: wait event");
     if ((slot == 0 || slot == 1) && prev && prev->pending && prev->done) HIPCHK(c, hipStreamWaitEvent(s, prev->done, 0)); }
     { SlowScope sw2(c, "ring: init copy");
-    if (seq == 0) HIPCHK(c, hipMemcpyAsync(ring, c->d_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyDeviceToDevice, s));
-    else if (slot == 0) HIPCHK(c, hipMemcpyAsync(ring, c->d_init_ring, sizeof(DevResult) * (etlg_ctx::kResRing - 1), hipMemcpyDeviceToDevice, s));
-    else if (slot == 1) HIPCHK(c, hipMemcpyAsync(ring + (etlg_ctx::kResRing - 1), c->d_init_ring, sizeof(DevResult), hipMemcpyDeviceToDevice, s)); }
+    if (seq == 0) HIPCHK(c, hipMemcpyAsync(ring, c->ring_h2d ? (const void*)c->h_init_ring : (const void*)c->d_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, c->ring_h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    else if (slot == 0) HIPCHK(c, hipMemcpyAsync(ring, c->ring_h2d ? (const void*)c->h_init_ring : (const void*)c->d_init_ring, sizeof(DevResult) * (etlg_ctx::kResRing - 1), c->ring_h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    else if (slot == 1) HIPCHK(c, hipMemcpyAsync(ring + (etlg_ctx::kResRing - 1), c->ring_h2d ? (const void*)c->h_init_ring : (const void*)c->d_init_ring, sizeof(DevResult), c->ring_h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s)); }
     b->d_res_blk = ring + slot;
   }
   p.res = b->d_res_blk;

@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import etl_amd  # noqa: E402,F401  (before anything initialises HIP: the package sets the process's hardware-queue default)
 
 
 def pytest_configure(config):
