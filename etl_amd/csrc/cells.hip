@@ -26,13 +26,19 @@
 #define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
 #define ETLG_DBG_WORD dbg_u   // cells_tile / k_cells keep the debug word in a scalar register of its own
 #define ETLG_TSTAMP_WHO (wave == 0 && lane == 0)   // phase clocks are taken by the tile's spine wave (its role rotates, see cells_tile)
+#include <type_traits>
 #include "lookback.hip.h"
 #include "utf8_swar.h"
 
 namespace etlg {
 
 constexpr int CF = 64;         // frames per tile
-constexpr int MAXC = 16;       // replicated columns per slot this kernel can handle (one state word per row)
+// Replicated columns per slot: two instantiations. NARROW: <= 16 columns — one 32-bit state word per row image, 16 + 16-bit column
+// masks in one register (the tuned cfg3 path; its code is what it was before WIDE existed). WIDE: <= 32 columns — two state words,
+// 32 + 32-bit masks in a 64-bit value, column masks derived from the DevCol records on the device (DevSlot keeps its 16-bit fields).
+// The host picks by the widest slot a frame of the batch can decode against: a stream whose tables outgrow 16 columns (cfg5's
+// ALTER TABLE ADD COLUMN) keeps this kernel instead of falling to k_fused/64.
+constexpr int MAXC_NARROW = 16, MAXC_WIDE = 32;
 // virtual columns of a tile whose widest slot has maxc columns: [0, maxc) old / key image, [maxc, 2 maxc) new image
 
 enum : uint32_t { CT_N = 0, CT_U = 1, CT_T = 2, CT_B = 3 };  // cell kind
@@ -162,25 +168,28 @@ struct CellsLds {
   uint64_t* fr_fx;              // fixed-arena offset of the frame's body
   uint32_t* fr_hp;              // heap offset of the frame's first entry
   uint32_t* fr_ev;              // index of the frame's event
-  uint32_t (*fr_st)[CF];        // 2-bit cell states of the old / new row (<= 16 columns)
+  uint32_t (*fr_st)[CF];        // 2-bit cell states: word (img * SW + w) of the old / new row (SW = 1, or 2 in the WIDE kernel)
   uint32_t* fr_err;             // min over (order << 8 | code)
   uint32_t* fr_toast;           // new-row columns sent as 'u'
   uint32_t* s32; uint64_t* s64;
   uint32_t* ct;                 // cell table region (CellTab)
-  uint8_t (*vlist)[32];         // virtual columns P2 ([0]) and P3 ([1]) visit
+  uint8_t (*vlist)[64];         // virtual columns P2 ([0]) and P3 ([1]) visit
 };
 
 // Everything after staging. STAGED: `base` is the LDS window holding input bytes [b0, ...), reads
 // may run up to 15 bytes past a frame; otherwise `base` is the input itself (b0 = 0).
 // `p`: parameters whose side-table pointers point at the LDS copy; `pg`: the original ones.
-template <int NW, bool STAGED>
+template <int NW, bool STAGED, bool WIDE>
 DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& q, const CellsLds& sh, const u8* base,
                     uint32_t b0, uint32_t tile, uint32_t nt) {
   uint32_t* const s_offs = sh.s_offs; int32_t* const fr_slot = sh.fr_slot; uint32_t* const fr_meta = sh.fr_meta;
   uint32_t* const fr_n = sh.fr_n; uint64_t* const fr_fx = sh.fr_fx; uint32_t* const fr_hp = sh.fr_hp; uint32_t* const fr_ev = sh.fr_ev;
   uint32_t (*const fr_st)[CF] = sh.fr_st; uint32_t* const fr_err = sh.fr_err; uint32_t* const fr_toast = sh.fr_toast;
   uint32_t* const s32 = sh.s32; uint64_t* const s64 = sh.s64;
-  uint8_t (*const vlist)[32] = sh.vlist;
+  uint8_t (*const vlist)[64] = sh.vlist;
+  constexpr int MAXC = WIDE ? MAXC_WIDE : MAXC_NARROW;   // bits per image in the column masks
+  constexpr int SW = WIDE ? 2 : 1;                       // state words per row image
+  using mask_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   // `wave` is a ROLE, not a position: role 0 is the tile's spine (P1, P2b, a look-back, P4 — about twice the instructions of
   // the other roles). The dispatcher places wave w of every 256-thread workgroup on SIMD w of its CU
@@ -206,12 +215,12 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   bool wire_ok = true, too_wide = false;
   uint32_t cnt = 0, mark = 0, seg_in = 0, pm = 0, tot_cnt = 0, tot_mark = 0;
   int my_slot = -1;
-  uint32_t heap_cols = 0;  // virtual columns of this frame whose cells reach the heap (wave 0)
+  mask_t heap_cols = 0;  // virtual columns of this frame whose cells reach the heap (wave 0)
   // The single-wave phases (P1, P2b, the look-backs, P4) are the spine of a tile: every other wave of the workgroup waits
   // for them at a barrier, while the cell phases of the other tiles on this SIMD have slack. They run at a raised issue priority.
   if (wave == 0) {
     ETLG_WAVE_PRIO(3);
-    if (lane < CF) { fr_st[0][lane] = 0; fr_st[1][lane] = 0; fr_err[lane] = 0xFFFFFFFFu; fr_toast[lane] = 0; fr_slot[lane] = -1; fr_meta[lane] = 0; fr_n[lane] = 0; }
+    if (lane < CF) { for (int w = 0; w < 2 * SW; w++) fr_st[w][lane] = 0; fr_err[lane] = 0xFFFFFFFFu; fr_toast[lane] = 0; fr_slot[lane] = -1; fr_meta[lane] = 0; fr_n[lane] = 0; }
     if (live) {
       o0 = s_offs[lane];
       const uint32_t o1 = s_offs[lane + 1];
@@ -361,35 +370,65 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     // Which virtual columns hold cells of a decodable image at all (P3 visits those), and which of them belong to a class
     // whose heap bytes depend on the text (P2 visits those; every other cell keeps the walk's pad4(len), counted in P2b
     // only where the column's class reaches the heap). Bits 0..15: old / key image, 16..31: new image.
-    uint32_t present = 0, scan = 0;
+    mask_t present = 0, scan = 0;
+    const mask_t one = 1;
     if (my_slot >= 0) {
       const DevSlot& s = p.slots[my_slot];
-      const uint32_t full = s.has_var, tag = v.tag;
-      const uint32_t po = old_kind != ETLG_OLD_NONE ? (1u << (n_old < maxc ? n_old : maxc)) - 1u : 0u;
-      const uint32_t pn = tag != 'D' ? (1u << (n_new < maxc ? n_new : maxc)) - 1u : 0u;
-      uint32_t oh = full & 0xFFFFu, os = full >> 16;                       // old image of a full row
-      if (old_kind == ETLG_OLD_KEY) {
-        if (n_old == s.n_ident) { oh = s.key_masks & 0xFFFFu; os = s.key_masks >> 16; }   // dense key tuple: cell j = identity column j
-        else { oh &= s.ident_mask; os &= s.ident_mask; }                                   // full-width key tuple: the other cells are skipped unread
+      const uint32_t tag = v.tag;
+      const mask_t po = old_kind != ETLG_OLD_NONE ? (one << (n_old < maxc ? n_old : maxc)) - one : (mask_t)0;
+      const mask_t pn = tag != 'D' ? (one << (n_new < maxc ? n_new : maxc)) - one : (mask_t)0;
+      mask_t fh, fs, oh, os;   // heap / scan columns of a full row; of this frame's old image
+      if constexpr (!WIDE) {
+        const uint32_t full = s.has_var;
+        fh = full & 0xFFFFu; fs = full >> 16;
+        oh = fh; os = fs;
+        if (old_kind == ETLG_OLD_KEY) {
+          if (n_old == s.n_ident) { oh = s.key_masks & 0xFFFFu; os = s.key_masks >> 16; }   // dense key tuple: cell j = identity column j
+          else { oh &= s.ident_mask; os &= s.ident_mask; }                                   // full-width key tuple: the other cells are skipped unread
+        }
+      } else {
+        // up to 32 columns: the masks come from the column records (DevSlot's fields hold 16 columns)
+        const DevCol* cols = p.cols + s.cols_base;
+        uint32_t h = 0, sc = 0, id = 0, kh = 0, ks = 0;
+        for (uint32_t k = 0; k < s.n_cols; k++) {
+          const DevCol cd = cols[k];
+          const uint32_t cls = cd.cls;
+          const bool heap = !(cls == ETLG_TC_BOOL || cls == ETLG_TC_I16 || cls == ETLG_TC_I32 || cls == ETLG_TC_I64 || cls == ETLG_TC_U32 || cls == ETLG_TC_UUID ||
+                              cls == ETLG_TC_DATE || cls == ETLG_TC_TIME || cls == ETLG_TC_TIMETZ || cls == ETLG_TC_TIMESTAMP || cls == ETLG_TC_TIMESTAMPTZ);
+          const bool sn = heap && ((kScanClasses >> cls) & 1u);
+          h |= heap ? 1u << k : 0u; sc |= sn ? 1u << k : 0u;
+          if (cd.identity) { id |= 1u << k; if (cd.key_index < 32) { kh |= heap ? 1u << cd.key_index : 0u; ks |= sn ? 1u << cd.key_index : 0u; } }
+        }
+        fh = h; fs = sc; oh = h; os = sc;
+        if (old_kind == ETLG_OLD_KEY) {
+          if (n_old == s.n_ident) { oh = kh; os = ks; } else { oh &= id; os &= id; }
+        }
       }
-      present = po | (pn << 16);
-      heap_cols = (oh & po) | ((full & 0xFFFFu & pn) << 16);
-      scan = (os & po) | (((full >> 16) & pn) << 16);
+      present = po | (pn << MAXC);
+      heap_cols = (oh & po) | ((fh & pn) << MAXC);
+      scan = (os & po) | ((fs & pn) << MAXC);
     }
-    present = wave_last(wave_scan_incl(present, [](uint32_t a, uint32_t b) { return a | b; }, 0u));
-    scan = wave_last(wave_scan_incl(scan, [](uint32_t a, uint32_t b) { return a | b; }, 0u));
-    const uint32_t heapy = wave_last(wave_scan_incl(heap_cols, [](uint32_t a, uint32_t b) { return a | b; }, 0u));
-    if (lane < 32) {  // the two visiting lists; P3's starts with the columns that cost most (text to copy, then text to scan),
-                      // so that the waves pulling from it finish close to each other
-      const uint32_t below = (1u << lane) - 1u, vc_of = lane < 16 ? lane : maxc + (lane - 16);
-      if ((scan >> lane) & 1u) vlist[0][__builtin_popcount(scan & below)] = (uint8_t)vc_of;
-      const uint32_t t1 = present & heapy & ~scan, t2 = present & scan, t3 = present & ~(heapy | scan);
-      const uint32_t rank = ((t1 >> lane) & 1u) ? __builtin_popcount(t1 & below)
-                          : ((t2 >> lane) & 1u) ? __builtin_popcount(t1) + __builtin_popcount(t2 & below)
-                                                : __builtin_popcount(t1 | t2) + __builtin_popcount(t3 & below);
+    auto wave_or = [](mask_t m) -> mask_t {
+      auto or32 = [](uint32_t x) { return wave_last(wave_scan_incl(x, [](uint32_t a, uint32_t b) { return a | b; }, 0u)); };
+      if constexpr (WIDE) return (mask_t)or32((uint32_t)m) | ((mask_t)or32((uint32_t)((uint64_t)m >> 32)) << 32);
+      else return (mask_t)or32((uint32_t)m);
+    };
+    auto pop = [](mask_t m) -> uint32_t { if constexpr (WIDE) return (uint32_t)__builtin_popcountll((uint64_t)m); else return (uint32_t)__builtin_popcount((uint32_t)m); };
+    present = wave_or(present);
+    scan = wave_or(scan);
+    const mask_t heapy = wave_or(heap_cols);
+    if (lane < 2u * MAXC) {  // the two visiting lists; P3's starts with the columns that cost most (text to copy, then text to scan),
+                            // so that the waves pulling from it finish close to each other
+      const mask_t below = (one << lane) - one;
+      const uint32_t vc_of = lane < (uint32_t)MAXC ? lane : maxc + (lane - MAXC);
+      if ((scan >> lane) & 1u) vlist[0][pop(scan & below)] = (uint8_t)vc_of;
+      const mask_t t1 = present & heapy & ~scan, t2 = present & scan, t3 = present & ~(heapy | scan);
+      const uint32_t rank = ((t1 >> lane) & 1u) ? pop(t1 & below)
+                          : ((t2 >> lane) & 1u) ? pop(t1) + pop(t2 & below)
+                                                : pop(t1 | t2) + pop(t3 & below);
       if ((present >> lane) & 1u) vlist[1][rank] = (uint8_t)vc_of;
     }
-    if (lane == 0) { s32[10] = (uint32_t)__builtin_popcount(scan); s32[11] = (uint32_t)__builtin_popcount(present); }
+    if (lane == 0) { s32[10] = pop(scan); s32[11] = pop(present); }
     ETLG_WAVE_PRIO(0);
   }
   __syncthreads();
@@ -475,17 +514,36 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
        // loads first (they are independent), then the running sum out of registers. Lanes without
        // a decodable row have cells = 0 and only rewrite entries nobody reads.
       const uint32_t cells_old = cells & 0xFFFFu, cells_new = cells >> 16;
-      uint32_t hh[2 * MAXC];
+      if constexpr (!WIDE) {
+        uint32_t hh[2 * MAXC];
 #pragma unroll
-      for (uint32_t i = 0; i < 2u * MAXC; i++) hh[i] = i < VC ? tab.raw(i * CF + lane) : 0u;
+        for (uint32_t i = 0; i < 2u * MAXC; i++) hh[i] = i < VC ? tab.raw(i * CF + lane) : 0u;
 #pragma unroll
-      for (uint32_t i = 0; i < 2u * MAXC; i++) {
-        if (i < VC) {  // uniform
-          const bool in_new = i >= maxc;
-          const uint32_t k = in_new ? i - maxc : i;
-          const bool take = (k < (in_new ? cells_new : cells_old)) & (((heap_cols >> (in_new ? 16u + k : k)) & 1u) != 0);
-          tab.set_heap_of(i * CF + lane, hh[i], heap);
-          heap += take ? tab.heap_of(hh[i]) : 0u;
+        for (uint32_t i = 0; i < 2u * MAXC; i++) {
+          if (i < VC) {  // uniform
+            const bool in_new = i >= maxc;
+            const uint32_t k = in_new ? i - maxc : i;
+            const bool take = (k < (in_new ? cells_new : cells_old)) & (((heap_cols >> (in_new ? 16u + k : k)) & 1u) != 0);
+            tab.set_heap_of(i * CF + lane, hh[i], heap);
+            heap += take ? tab.heap_of(hh[i]) : 0u;
+          }
+        }
+      } else {   // 64 entries in registers would cost the kernel its occupancy: four at a time
+        for (uint32_t i0 = 0; i0 < VC; i0 += 4) {
+          uint32_t hh[4];
+#pragma unroll
+          for (uint32_t u = 0; u < 4; u++) hh[u] = i0 + u < VC ? tab.raw((i0 + u) * CF + lane) : 0u;
+#pragma unroll
+          for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u;
+            if (i < VC) {
+              const bool in_new = i >= maxc;
+              const uint32_t k = in_new ? i - maxc : i;
+              const bool take = (k < (in_new ? cells_new : cells_old)) & (((heap_cols >> (in_new ? (uint32_t)MAXC + k : k)) & 1u) != 0);
+              tab.set_heap_of(i * CF + lane, hh[u], heap);
+              heap += take ? tab.heap_of(hh[u]) : 0u;
+            }
+          }
         }
       }
     }
@@ -627,7 +685,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     ETLG_WAVE_JOIN();
     if (act) {
       if (err) atomicMin(&fr_err[lane], (order << 8) | err);
-      else if (st) atomicOr(&fr_st[img][lane], st << (2 * kout));
+      else if (st) atomicOr(&fr_st[img * SW + (WIDE ? kout >> 4 : 0u)][lane], st << (2 * (WIDE ? kout & 15u : kout)));
     }
   }
   __threadfence_block();
@@ -645,7 +703,8 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     const DevCol* cols = p.cols + s.cols_base;
     u8* body = pg.fixed + fx_off;
     uint32_t flags = tag != 'I' ? old_kind : 0u;
-    uint32_t st_new = fr_st[1][lane];
+    uint32_t st_new[SW];
+    for (int w = 0; w < SW; w++) st_new[w] = fr_st[SW + w][lane];
     uint32_t toast = fr_toast[lane];
     const uint32_t e0 = fr_err[lane];
     // 'u' cells of the new row: alias the aligned old value, else MISSING (codec/event.rs:962-974)
@@ -655,21 +714,27 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       const DevCol col = cols[k];
       uint32_t* dst = (uint32_t*)(body + old_sz + col.off_full);
       const bool from_full = old_kind == ETLG_OLD_FULL, from_key = old_kind == ETLG_OLD_KEY && col.identity;
+      uint32_t cst;
       if (from_full || from_key) {
         const uint32_t* src = (const uint32_t*)(body + (from_full ? col.off_full : col.off_key));
         const uint32_t nw = slot_bytes(col.cls) >> 2;
         for (uint32_t w = 0; w < nw; w++) dst[w] = src[w];
-        const uint32_t ost = (fr_st[0][lane] >> (2 * (from_full ? k : col.key_index))) & 3u;
-        st_new |= ost << (2 * k);
+        const uint32_t oi = from_full ? k : (uint32_t)col.key_index;
+        cst = (fr_st[WIDE ? oi >> 4 : 0u][lane] >> (2 * (WIDE ? oi & 15u : oi))) & 3u;
       } else {
         slot_zero(dst, col.cls);
-        st_new |= (uint32_t)ETLG_CELL_MISSING << (2 * k);
+        cst = (uint32_t)ETLG_CELL_MISSING;
         flags |= ETLG_FLAG_PARTIAL;
       }
+      if constexpr (WIDE) { if (k >= 16) st_new[SW - 1] |= cst << (2 * (k & 15u)); else st_new[0] |= cst << (2 * k); }
+      else st_new[0] |= cst << (2 * k);
     }
     if (e0 != 0xFFFFFFFFu) { record_error(pg, f, RK_DECODE, e0 & 0xFF); return; }
-    if (old_kind != ETLG_OLD_NONE && (old_kind == ETLG_OLD_KEY ? s.st_key : s.st_full)) *(uint32_t*)body = fr_st[0][lane];
-    if (tag != 'D' && s.st_full) *(uint32_t*)(body + old_sz) = st_new;
+    {  // the 2-bit states at the head of each row image: st_key / st_full bytes (4 per 16 columns)
+      const uint32_t so = old_kind == ETLG_OLD_NONE ? 0u : old_kind == ETLG_OLD_KEY ? s.st_key : s.st_full;
+      for (uint32_t w = 0; 4 * w < so && w < (uint32_t)SW; w++) ((uint32_t*)body)[w] = fr_st[w][lane];
+      if (tag != 'D') for (uint32_t w = 0; 4 * w < s.st_full && w < (uint32_t)SW; w++) ((uint32_t*)(body + old_sz))[w] = st_new[w];
+    }
     pg.ev_kind[ev_idx] = (u8)tag;
     pg.ev_flags[ev_idx] = (u8)flags;
     pg.ev_table[ev_idx] = rel_id;
@@ -690,7 +755,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
                                  // one-dword cell table a 12-column tile is ~38 KB of LDS, so four fit; measured on cfg3: 281 us at three
                                  // workgroups (168 VGPRs, no spills), 238 us at four (profiles/r02u_cells_variants.json)
 #endif
-template <int NW>
+template <int NW, bool WIDE>
 __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecParams pg, FusedParams q) {
   ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[CF + 1];
@@ -700,12 +765,12 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   __shared__ uint64_t fr_fx[CF];     // fixed-arena offset of the frame's body
   __shared__ uint32_t fr_hp[CF];     // heap offset of the frame's first entry
   __shared__ uint32_t fr_ev[CF];     // index of the frame's event
-  __shared__ uint32_t fr_st[2][CF];  // 2-bit cell states of the old / new row (<= 16 columns)
+  __shared__ uint32_t fr_st[WIDE ? 4 : 2][CF];  // 2-bit cell states of the old / new row: one word per 16 columns and image
   __shared__ uint32_t fr_err[CF];    // min over (order << 8 | code)
   __shared__ uint32_t fr_toast[CF];  // new-row columns sent as 'u'
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
-  __shared__ uint8_t vlist[2][32];
+  __shared__ uint8_t vlist[2][64];
   const uint32_t tid = threadIdx.x;
   if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
@@ -757,8 +822,8 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   TSTAMP(1);
   const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist};
   // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
-  if (use_lds) cells_tile<NW, true>(p, pg, q, sh, stage, a0, tile, nt);
-  else cells_tile<NW, false>(p, pg, q, sh, pg.in, 0u, tile, nt);
+  if (use_lds) cells_tile<NW, true, WIDE>(p, pg, q, sh, stage, a0, tile, nt);
+  else cells_tile<NW, false, WIDE>(p, pg, q, sh, pg.in, 0u, tile, nt);
 }
 
 }  // namespace etlg
@@ -769,16 +834,19 @@ using namespace etlg;
 
 void etlg_k_launch_cells(const DecParams* p, const void* qv, hipStream_t s) {
   const FusedParams* q = (const FusedParams*)qv;
-  hipLaunchKernelGGL(k_cells<4>, dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+  if (q->maxc > (uint32_t)MAXC_NARROW) hipLaunchKernelGGL((k_cells<4, true>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+  else hipLaunchKernelGGL((k_cells<4, false>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
 }
 
 int etlg_k_cells_set_lds(void) {
-  return hipFuncSetAttribute((const void*)k_cells<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) == hipSuccess ? 0 : 1;
+  const hipError_t a = hipFuncSetAttribute((const void*)k_cells<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+  const hipError_t b = hipFuncSetAttribute((const void*)k_cells<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608);
+  return a == hipSuccess && b == hipSuccess ? 0 : 1;
 }
 
 uint32_t etlg_k_cells_table_bytes(uint32_t maxc) { return 2u * maxc * CF * 4u; }       // next to the window of a staged tile
 uint32_t etlg_k_cells_lds_floor(uint32_t maxc) { return 3u * 2u * maxc * CF * 4u; }    // table + window together: what a tile read in place needs
-uint32_t etlg_k_cells_static_lds(void) { return 3584; }  // the kernel's __shared__ arrays (3 536 bytes in the gfx950 build) + slack
-uint32_t etlg_k_cells_maxc(void) { return MAXC; }
+uint32_t etlg_k_cells_static_lds(uint32_t maxc) { return maxc > (uint32_t)MAXC_NARROW ? 4224u : 3648u; }  // the kernel's __shared__ arrays (3 600 / 4 112 bytes in the gfx950 build of the narrow / wide instantiation) + slack
+uint32_t etlg_k_cells_maxc(void) { return MAXC_WIDE; }
 
 }  // extern "C"

@@ -59,7 +59,7 @@ extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_maxc(void);
 extern "C" uint32_t etlg_k_cells_lds_floor(uint32_t maxc);
-extern "C" uint32_t etlg_k_cells_static_lds(void);
+extern "C" uint32_t etlg_k_cells_static_lds(uint32_t maxc);
 
 constexpr int kFused = 7;  // profiling slot of the fused kernel
 constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
@@ -2709,7 +2709,7 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
                         (uint64_t)p.n_slots * sizeof(DevSlot) + (uint64_t)p.n_cols * sizeof(DevCol);
   q.side_bytes = (side <= 32768 && !(c->fused_dbg & 16)) ? (uint32_t)((side + 15) & ~15ull) : 0u;
   // kernel choice: narrow frames -> one lane per frame, 256 frames per tile (k_fused); wide frames ->
-  // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 16 columns)
+  // 64 frames per tile with the waves spread over the columns (k_cells, schemas up to 32 columns: a second instantiation beyond 16)
   uint32_t widest = 1;
   for (int32_t li : c->last_live) widest = std::max<uint32_t>(widest, c->slots[(size_t)li]->desc.n_cols);
   const bool cells_ok = widest <= etlg_k_cells_maxc() && q.side_bytes != 0;  // k_cells keeps the side tables in LDS
@@ -2731,7 +2731,7 @@ int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level) {
     cap = std::max<uint64_t>(cap + etlg_k_cells_table_bytes(widest), etlg_k_cells_lds_floor(widest));
     // LDS decides how many workgroups share a CU (160 KB; the register file allows four): the window takes whatever the
     // allocation can grow by without losing one, so fewer tiles overflow it
-    const uint64_t stat = etlg_k_cells_static_lds();
+    const uint64_t stat = etlg_k_cells_static_lds(widest);
     const uint64_t wgs = std::max<uint64_t>(1, std::min<uint64_t>(4, (160 * 1024) / (cap + q.side_bytes + stat)));
     cap = std::max<uint64_t>(cap, ((160 * 1024) / wgs - 512 - stat - q.side_bytes) & ~255ull);
   }

@@ -555,6 +555,43 @@ def test_cells_tile_sizes(max_len):
             os.environ["ETLG_FUSED_KERNEL"] = saved
 
 
+def _wide_table(ncols, rel_id):
+    """A table of `ncols` columns cycling through every value class, with text / numeric / nullable columns beyond position 16."""
+    kinds = [(synth.CK_INT4, synth.INT4, {}), (synth.CK_TEXT, synth.TEXT, dict(min_len=0, max_len=40, utf8_pct=10)), (synth.CK_NUMERIC, synth.NUMERIC, {}),
+             (synth.CK_BOOL, synth.BOOL, {}), (synth.CK_TIMESTAMPTZ, synth.TIMESTAMPTZ, {}), (synth.CK_UUID, synth.UUID, {}), (synth.CK_INT2, synth.INT2, {}),
+             (synth.CK_TEXT, synth.TEXT, dict(nullable=True, null_pct=30, min_len=1, max_len=24))]
+    cols = [synth.col("id", synth.CK_INT8_SEQ, synth.INT8, pk=True)]
+    for i in range(1, ncols):
+        ck, oid, kw = kinds[i % len(kinds)]
+        cols.append(synth.col(f"c{i}", ck, oid, **kw))
+    return dict(rel_id=rel_id, name=f"wide{ncols}", cols=cols)
+
+
+@pytest.mark.parametrize("ncols", [17, 24, 32])
+def test_tables_wider_than_16_columns(ncols, path):
+    """The reference has no column limit (crates/etl/src/schema.rs:380-441). k_cells decodes tables of up to 32 replicated columns
+    (its WIDE instantiation: two state words per row image, 64-bit column masks); wider tables take k_fused/64 or the multi-pass
+    kernels (the synthetic generator stops at 32 columns; tests/scenarios.py has the hand-written wider ones). Inserts, updates with key and full old images, unchanged-toast cells (also in columns >= 16), deletes, NULLs — byte for
+    byte against the oracle on every kernel path; when k_cells is forced and the table fits, it must be the kernel that produced
+    the batch."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.Workload([_wide_table(ncols, 16600 + ncols)], 0xA11CE + ncols, rows_per_txn=23, mix=(50, 35, 15), upd_key=30, upd_toast=20, name=f"wide{ncols}")
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o); w.register(d)
+    for _ in range(2):
+        buf, offs = w.fill(1 << 20)
+        rb, gb = o.decode(buf, offs), d.decode(buf, offs)
+        assert rb.err_code == 0 and gb.rc == 0, (rb.err_code, gb.error)
+        diff = rb.host_batch().diff(gb.host())
+        assert not diff, diff[:6]
+    n = d.debug_paths()
+    d.close()
+    assert n["redone"] == 0, n
+    if path == "cells":
+        assert n["cells"] == 2, n
+
+
 @pytest.mark.parametrize("cap", [1, 150, 400, 4096])
 def test_control_frames_that_do_not_fit_the_staging_buffer(cap):
     """The control pre-pass gathers the Relation / DDL frames' bytes into one staging buffer for a single device-to-host

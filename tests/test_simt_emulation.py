@@ -51,9 +51,10 @@ def _run_gpu_file_on_emulator(simt_lib, args, timeout):
 
 
 def test_scenarios_on_every_kernel_path(simt_lib):
-    """Every scenario of tests/scenarios.py on the five device paths (default choice, k_fused 256 / 64, k_cells,
-    multi-pass), byte for byte against the oracle — the same test the GPU box runs, on emulated kernels."""
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_parity.py", "-k", "scenario_parity"], 600)
+    """Every scenario of tests/scenarios.py on the device paths (default choice, k_fused 256 / 64, k_cells, the plan kernels,
+    multi-pass), byte for byte against the oracle — the same test the GPU box runs, on emulated kernels; plus the temporal matrix
+    (fast paths + chrono grammar) and tables of 17 / 24 / 32 columns (k_cells' WIDE instantiation)."""
+    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_parity.py", "-k", "scenario_parity or temporal_matrix or wider_than_16"], 900)
     assert " passed" in tail and "failed" not in tail, tail
 
 
