@@ -14,7 +14,7 @@ SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "plan.hip", "scan.hip", "cop
 # k_cells and the rest are not
 OPT = {"fused.hip": "-Os"}
 DEFS = {}   # no per-source feature flags: one code path per kernel
-DEPS = SOURCES + ["../build.py", "dev_types.h", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "plan.hip", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
+DEPS = SOURCES + ["../build.py", "dev_types.h", "host_state.h", "host_control.inc", "host_handoff.inc", "host_orchestrate.inc", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "plan.hip", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
 
 
 def _stale(target, deps):
