@@ -59,7 +59,7 @@ void launch_copy(etlg_ctx* c, const CopyJob& j, const DecParams& p) {
   if (!j.nrows) return;
   ProfRec r; r.which = kCopy;
   if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, c->stream); }
-  etlg_k_launch_copy(j.d_rows, j.d_row_offs, j.nrows, j.rows_len, j.ncols, j.rel_id, j.d_out, j.d_out_offs, j.lds, &p, c->stream);
+  etlg_k_launch_copy(j.d_rows, j.d_row_offs, j.nrows, j.rows_len, j.ncols, j.rel_id, j.d_out, j.d_out_offs, j.lds, c->copy_lane_per_byte ? 1 : 0, &p, c->stream);
   if (c->prof) { (void)hipEventRecord(r.b, c->stream); c->prof_recs.push_back(r); }
 }
 
@@ -227,6 +227,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   (void)etlg_k_copy_set_lds();
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
   { const char* e = getenv("ETLG_RING_H2D"); c->ring_h2d = e && e[0] == '1'; }
+  { const char* e = getenv("ETLG_COPY_KERNEL"); c->copy_lane_per_byte = e && e[0] == '1'; }
   { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && (ht[0] == '1' || ht[0] == '2'); c->host_times_slow = ht && ht[0] == '2'; }
   { const char* sc = getenv("ETLG_CTRL_STAGE_CAP"); c->ctrl_stage_cap_test = sc ? (size_t)atol(sc) : 0; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }

@@ -48,7 +48,7 @@ extern "C" uint32_t etlg_k_bounds_tile_bytes(void);
 extern "C" uint32_t etlg_k_copy_bytes_per_row(uint32_t ncols);
 extern "C" int etlg_k_copy_set_lds(void);
 extern "C" void etlg_k_launch_copy(const uint8_t* rows, const uint32_t* row_offs, uint32_t nrows, uint64_t rows_len, uint32_t ncols,
-                                   uint32_t rel_id, uint8_t* out, uint32_t* out_offs, uint32_t lds_bytes, const DecParams* dec, hipStream_t s);
+                                   uint32_t rel_id, uint8_t* out, uint32_t* out_offs, uint32_t lds_bytes, int lane_per_byte, const DecParams* dec, hipStream_t s);
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_plan_set_lds(void);
@@ -321,6 +321,7 @@ struct etlg_ctx {
   ScanJob scan_job;                   // ... and that scan
   hipStream_t res_stream = nullptr;   // ASYNC batches: their result block travels to the host on this stream, so that no copy sits between two decode kernels
   hipStream_t scan_stream = nullptr;  // ASYNC batches without a sidecar: their boundary scan runs here, beside the previous batch's decode
+  bool copy_lane_per_byte = false;    // ETLG_COPY_KERNEL=1: the lane-per-byte COPY splitter (copy.hip k_copy_split) instead of the lane-per-row one
   bool ring_h2d = false;              // ETLG_RING_H2D=1 (measurement / bisect knob): re-initialise the result ring from the host template
   uint64_t fixed_hint = 0;            // largest fixed-arena bound seen so far, with head room (setup_outputs)
   hipStream_t d2h_stream = nullptr;   // etlg_batch_download / host-output decodes: the arena of a finished batch travels here

@@ -179,12 +179,14 @@ COPY_COLS = [("id", INT8, False, 1), ("a", INT4, False, 0), ("b", BOOL, False, 0
              ("f", FLOAT8, False, 0), ("by", BYTEA, False, 0)]
 
 
-def copy_rows(n, seed):
+def copy_rows(n, seed, clean=False):
     """n COPY text rows for COPY_COLS (int8, int4, bool, numeric, text, text NULLable, timestamptz, uuid, float8, bytea),
-    every backslash escape of the format included."""
+    every backslash escape of the format included; clean=True: text without any character COPY escapes."""
     import random
     rng = random.Random(seed)
     alphabet = "abcdefghij XYZ\t\n\\\r\x08\x0c\x0b\u00e9\u4e2d\U0001F600,;{}\"'"
+    if clean:
+        alphabet = "abcdefghijklmnopqrstuvwxyz ABCDEFGHIJ0123456789,;.-\u00e9"
     esc_map = {"\t": "\\t", "\n": "\\n", "\\": "\\\\", "\r": "\\r", "\x08": "\\b", "\x0c": "\\f", "\x0b": "\\v"}
 
     def esc(s):

@@ -115,3 +115,94 @@ def test_copy_device_resident_rows():
     assert gb.rc == 0 and gb.view().on_device == 1
     assert not o.copy_decode(so, buf, offs).host_batch().diff(gb.host())
     d.close()
+
+
+def _fuzz_rows(seed, n):
+    """Two text columns whose rows stress the splitter's step boundaries: field lengths around multiples of 64, runs of backslashes
+    of every parity in front of separators, NULL markers at every alignment, escaped multi-byte characters, rows of several KB
+    (longer than the 4 KB block), one-byte and empty fields."""
+    rng = random.Random(seed)
+    pieces = ["a", "xy", "\\\\", "\\t", "\\n", "\\N", "\\\\\\\\", "é", "\\é", "中", "😀", "\\😀", "\\q", " ", "\\b\\f\\r\\v"]
+
+    def field(target):
+        s = ""
+        while len(s.encode()) < target:
+            s += rng.choice(pieces)
+        return s
+    rows = []
+    for i in range(n):
+        k = rng.random()
+        if k < 0.1:
+            a, b = "\\N", field(rng.randrange(0, 140))
+        elif k < 0.2:
+            a, b = field(rng.choice([61, 62, 63, 64, 65, 127, 128, 129])), "\\N"
+        elif k < 0.25:
+            a, b = field(rng.randrange(3000, 9000)), field(rng.randrange(0, 70))
+        elif k < 0.3:
+            a, b = "", ""
+        else:
+            a, b = field(rng.randrange(0, 200)), field(rng.randrange(0, 200))
+        rows.append((a + "\t" + b + "\n").encode())
+    return rows
+
+
+@pytest.fixture(params=["lane_per_row", "lane_per_byte"])
+def splitter(request):
+    """Both COPY splitters of copy.hip: the default (one lane per row) and the data-parallel one (ETLG_COPY_KERNEL=1, read when the
+    context is created)."""
+    import os
+    saved = os.environ.pop("ETLG_COPY_KERNEL", None)
+    if request.param == "lane_per_byte":
+        os.environ["ETLG_COPY_KERNEL"] = "1"
+    yield request.param
+    os.environ.pop("ETLG_COPY_KERNEL", None)
+    if saved is not None:
+        os.environ["ETLG_COPY_KERNEL"] = saved
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_copy_splitter_step_boundaries(seed, splitter):
+    cols = [("a", K.TEXT, True, 0), ("b", K.TEXT, True, 0)]
+    rows = _fuzz_rows(seed, 700)
+    o, d, rb, gb = both(cols, rows)
+    assert rb.err_code == 0, (rb.err_desc, rb.err_frame)
+    assert_same(rb, gb)
+    d.close()
+
+
+@pytest.mark.parametrize("kind", ["utf8_cut_at_row_end", "utf8_overlong", "cont_at_row_start", "unterminated", "more", "fewer", "trailing_backslash",
+                                  "empty_row", "dangling_after_newline", "escaped_tab_before_sep"])
+def test_copy_splitter_row_errors(kind, splitter):
+    """One bad (or odd) row between good ones, at several positions of the 64-byte step: the first error and everything before it
+    as the oracle has them (rows are independent: a sequence cut off by a row's end is that row's error, not its neighbour's)."""
+    cols = [("a", K.TEXT, True, 0), ("b", K.TEXT, True, 0)]
+    bad = {"utf8_cut_at_row_end": b"abc\txy\xe4\xb8\n"[:-1] + b"",           # a 3-byte sequence cut off (and no terminator)
+           "utf8_overlong": b"a\xc0\xafb\tc\n", "cont_at_row_start": b"\xa0bc\td\n",
+           "unterminated": b"abc\tdef", "more": b"a\tb\tc\n", "fewer": b"abc\n", "trailing_backslash": b"a\tb\\",
+           "empty_row": b"", "dangling_after_newline": b"a\tb\nrest", "escaped_tab_before_sep": b"a\\\t\tb\n"}[kind]
+    for pad in (0, 5, 57, 60, 62, 63, 64, 120):
+        good1 = ("g" * pad + "\tq\n").encode()
+        rows = [good1, bad, b"\xb8tail\tz\n" if kind == "utf8_cut_at_row_end" else b"x\ty\n", b"k\tl\n"]
+        o, d, rb, gb = both(cols, rows)
+        assert_same(rb, gb)
+        d.close()
+
+
+def test_copy_generated_rows_lane_per_byte(splitter):
+    """The generated rows of bench.py's copy leg (every escape of the format, NULLs, all ten classes) and the reference's known-answer
+    rows through both splitters."""
+    rows = _gen_rows(3000, 17)
+    o, d, rb, gb = both(GEN_COLS, rows)
+    assert rb.err_code == 0
+    assert_same(rb, gb)
+    d.close()
+    for cols, row, _want in K.OK:
+        o, d, rb, gb = both(cols, [bytes(row)])
+        assert_same(rb, gb)
+        d.close()
+    for cols, row, code in K.ERR:
+        good = {len(K.BASIC): b"1\tx\tt\n", 1: (b"7\n" if cols[0][1] == K.INT4 else b"ok\n")}[len(cols)]
+        o, d, rb, gb = both(cols, [good, bytes(row)])
+        assert rb.err_code == code
+        assert_same(rb, gb)
+        d.close()
