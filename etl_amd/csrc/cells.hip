@@ -51,9 +51,15 @@ constexpr uint32_t kScanClasses = (1u << ETLG_TC_F32) | (1u << ETLG_TC_F64) | (1
 // at 12 bytes per cell the table of a 12-column schema was 18 KB of a 47 KB tile and capped a CU at three workgroups.
 // A tile read in place has no window; it keeps (32-bit offset, length | kind << 30, heap bytes) per cell in the space the
 // window would have taken.
+// The sizing pass (P2) has to parse a float cell to know whether it is handed back DEFERRED (a heap entry) or not; P3 used to parse it
+// again (~37 k cycles per column and tile on the table-copy bench rows, profiles/r03ad_copy_direct.txt). The first kFloatCache
+// scan columns of a tile keep their parsed values in LDS instead: [scan rank][frame] bits + one ballot of the lanes that hold a value.
+constexpr uint32_t kFloatCache = 4;
 constexpr uint32_t kWinMax = 120u * 1024u;   // staged bytes of a tile: tag positions fit 17 bits, a frame's heap bytes fit 15 bits of dwords
-template <bool STAGED> struct CellTab;
-template <> struct CellTab<true> {
+// A tile of table-copy rows (k_copy_cells) has no cell headers in its window: (window offset 17 bits | heap dwords 15 bits,
+// length | kind << 30) per cell.
+template <int TAB> struct CellTab;   // 0: tile read in place, 1: staged WAL tile, 2: staged table-copy tile
+template <> struct CellTab<1> {
   uint32_t* e;
   // the heap field starts out as what a class that copies its text takes (String, wholesale-deferred): pad4(len)
   DEV void put(uint32_t i, uint32_t tagpos, uint32_t len, uint32_t kind) const { e[i] = (tagpos << 15) | (kind == CT_T ? (len + 3u) >> 2 : 0u); }
@@ -72,7 +78,7 @@ template <> struct CellTab<true> {
   DEV uint32_t raw(uint32_t i) const { return e[i]; }
   DEV void set_heap_of(uint32_t i, uint32_t w, uint32_t h) const { e[i] = (w & ~0x7FFFu) | (h >> 2); }  // w: what get() / raw() returned; h: a multiple of 4 below 128 KiB
 };
-template <> struct CellTab<false> {
+template <> struct CellTab<0> {
   uint2* pl; uint32_t* h;
   DEV void put(uint32_t i, uint32_t tagpos, uint32_t len, uint32_t kind) const { pl[i] = make_uint2(tagpos + 5, len | (kind << 30)); h[i] = kind == CT_T ? pad4(len) : 0u; }
   DEV uint32_t get(uint32_t i, const u8*, uint32_t& pos, uint32_t& len, uint32_t& kind) const {
@@ -83,6 +89,18 @@ template <> struct CellTab<false> {
   DEV uint32_t heap_of(uint32_t w) const { return w; }
   DEV uint32_t raw(uint32_t i) const { return h[i]; }
   DEV void set_heap_of(uint32_t i, uint32_t, uint32_t v) const { h[i] = v; }
+};
+template <> struct CellTab<2> {
+  uint2* e;
+  DEV void put(uint32_t i, uint32_t pos, uint32_t len, uint32_t kind) const { e[i] = make_uint2(pos | ((kind == CT_T ? (len + 3u) >> 2 : 0u) << 17), len | (kind << 30)); }
+  DEV uint32_t get(uint32_t i, const u8*, uint32_t& pos, uint32_t& len, uint32_t& kind) const {
+    const uint2 v = e[i];
+    pos = v.x & 0x1FFFFu; len = v.y & 0x3FFFFFFFu; kind = v.y >> 30;
+    return v.x;
+  }
+  DEV uint32_t heap_of(uint32_t w) const { return (w >> 17) << 2; }
+  DEV uint32_t raw(uint32_t i) const { return e[i].x; }
+  DEV void set_heap_of(uint32_t i, uint32_t w, uint32_t h) const { e[i].x = (w & 0x1FFFFu) | ((h >> 2) << 17); }
 };
 
 // frame meta word: tag (8) | old_kind (2) << 8 | wire_ok << 10 | emit << 11 | too_wide << 12
@@ -174,19 +192,25 @@ struct CellsLds {
   uint32_t* s32; uint64_t* s64;
   uint32_t* ct;                 // cell table region (CellTab)
   uint8_t (*vlist)[64];         // virtual columns P2 ([0]) and P3 ([1]) visit
+  const uint32_t* bm_sep; const uint32_t* bm_bs; const uint32_t* bm_nl;   // table-copy tiles, one bit per window byte: unescaped tabs / newlines, backslashes, newlines
+  uint32_t* cxm;                // table-copy tiles: the columns of each row whose field holds a backslash
+  uint64_t (*fcache)[CF]; uint64_t* fc_ok; uint8_t* vinv;   // float4 / float8 cells parsed by the sizing pass, for P3 (see kFloatCache)   // table-copy tiles: where the window's tabs / newlines / backslashes are (one bit per byte)
 };
 
 // Everything after staging. STAGED: `base` is the LDS window holding input bytes [b0, ...), reads
 // may run up to 15 bytes past a frame; otherwise `base` is the input itself (b0 = 0).
 // `p`: parameters whose side-table pointers point at the LDS copy; `pg`: the original ones.
-template <int NW, bool STAGED, bool WIDE>
+template <int NW, int TAB, bool WIDE>
 DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& q, const CellsLds& sh, const u8* base,
-                    uint32_t b0, uint32_t tile, uint32_t nt) {
+                    uint32_t b0, uint32_t tile, uint32_t nt, uint32_t copy_bad = 0) {
+  constexpr bool STAGED = TAB != 0;
+  constexpr bool COPY = TAB == 2;   // table-copy rows: the window holds COPY text rows, P1 is the field splitter (copy_walk below)
   uint32_t* const s_offs = sh.s_offs; int32_t* const fr_slot = sh.fr_slot; uint32_t* const fr_meta = sh.fr_meta;
   uint32_t* const fr_n = sh.fr_n; uint64_t* const fr_fx = sh.fr_fx; uint32_t* const fr_hp = sh.fr_hp; uint32_t* const fr_ev = sh.fr_ev;
   uint32_t (*const fr_st)[CF] = sh.fr_st; uint32_t* const fr_err = sh.fr_err; uint32_t* const fr_toast = sh.fr_toast;
   uint32_t* const s32 = sh.s32; uint64_t* const s64 = sh.s64;
   uint8_t (*const vlist)[64] = sh.vlist;
+  uint64_t (*const fcache)[CF] = sh.fcache; uint64_t* const fc_ok = sh.fc_ok; uint8_t* const vinv = sh.vinv;
   constexpr int MAXC = WIDE ? MAXC_WIDE : MAXC_NARROW;   // bits per image in the column masks
   constexpr int SW = WIDE ? 2 : 1;                       // state words per row image
   using mask_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
@@ -203,8 +227,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   const uint32_t VC = 2 * maxc;
   const uint32_t f0 = tile * CF;
   constexpr bool use_lds = STAGED;
-  CellTab<STAGED> tab;
-  if constexpr (STAGED) tab.e = sh.ct; else { tab.pl = (uint2*)sh.ct; tab.h = sh.ct + 2 * VC * CF; }
+  CellTab<TAB> tab;
+  if constexpr (COPY) tab.e = (uint2*)sh.ct;
+  else if constexpr (STAGED) tab.e = sh.ct;
+  else { tab.pl = (uint2*)sh.ct; tab.h = sh.ct + 2 * VC * CF; }
   uint32_t* fail = &pg.res->fused_fail;
 
   // ================= P1 (wave 0): slice frames into cells, transaction scan, slots
@@ -221,103 +247,167 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   if (wave == 0) {
     ETLG_WAVE_PRIO(3);
     if (lane < CF) { for (int w = 0; w < 2 * SW; w++) fr_st[w][lane] = 0; fr_err[lane] = 0xFFFFFFFFu; fr_toast[lane] = 0; fr_slot[lane] = -1; fr_meta[lane] = 0; fr_n[lane] = 0; }
-    if (live) {
-      o0 = s_offs[lane];
-      const uint32_t o1 = s_offs[lane + 1];
-      if (o1 > o0 && o1 <= pg.in_len) {
-        v.fr = base + (o0 - b0);
-        v.e = base + (o1 - b0);
-        v.tag = classify_ptr(v.fr, o1 - o0);
-      }
-      const uint32_t tag = v.tag;
-      if (!(tag == 'I' || tag == 'U' || tag == 'D')) {
-        RowMsg dummy;
-        wire_ok = frame_structure(v, dummy);
-      }
-      if (consumes_ordinal(tag)) cnt = 1;
-      if (tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
-      if (tag == 'C') mark = (o0 + 1) << 1;
-    }
-    TSTAMP(11);
-    // parse_row_msg + walk_tuple for the I / U / D frames, recording every cell, with 32-bit offsets into `base`.
-    // This wave runs alone while the others wait and a lone wave issues an instruction every 5-8 cycles, so the
-    // walk is priced per instruction: a frame is at most (image header, cells) twice, and the two kinds of item
-    // get their own wave-level steps — one header step per pass, then a cell loop whose body is a dozen VALU
-    // operations (no data-dependent branches: bitwise predicates and selects).
-    {
-      // Loop-carried state is kept in integers (st: 0 idle, 1 in front of an image header, 2 inside an image; bad / wide:
-      // error flags): as `bool`s they live in lane-mask SGPR pairs and every trip paid ~30 scalar instructions merging them.
-      const uint32_t tag = v.tag;
-      const uint32_t upd = tag == 'U' ? 1u : 0u;
-      const uint32_t maxc_u = maxc;
-      uint32_t c = 0, e = 0, img = tag == 'I' ? 1u : 0u, k = 0, n = 0, st = 0, bad = 0, wide = 0;
-      if (live && (tag == 'I' || tag == 'U' || tag == 'D')) {
-        c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
-        wire_ok = e >= c + 5;
-        if (wire_ok) { rel_id = ld_be32(base + c); c += 4; st = 1; }
-      }
-      // the next 8 bytes of a lane: item tag + i16 count (header) or item tag + i32 length (cell)
-      auto next8 = [&](bool on) -> uint64_t {
-        if (STAGED) return ldu64(base + c);  // the window has 16 spare bytes past any frame
-        uint64_t head = 0;
-        if (on) for (uint32_t i = 0; i < 5 && c + i < e; i++) head |= (uint64_t)base[c + i] << (8 * i);
-        return head;
-      };
-      // One loop over "steps": a header step whenever some lane stands in front of an image header (the first trip for
-      // everybody, later the frames that go on from an old / key image to the new one), then a cell step for every lane
-      // inside an image. A tile finishes in (cells of its longest frame) + 1 or 2 trips.
-      for (;;) {
-        const unsigned long long wh = __ballot(st == 1);
-        if (!(wh | __ballot(st == 2))) break;
-        if (wh) {  // image header: 'K' | 'O' | 'N', i16 column count
-          const bool on = st == 1;
-          const uint64_t head = next8(on);
-          const uint32_t t = (uint32_t)head & 0xFFu;
-          const uint32_t room = e - c;  // c <= e holds for a lane that is still going
-          const bool is_old = (t == 'K') | (t == 'O');
-          const uint32_t img_h = ((img == 0) & !is_old & (upd != 0)) ? 1u : img;  // update without an old image
-          const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
-          const bool hdr_ok = (room >= 3) & (img_h == 0 ? is_old : t == 'N') & !(cnt16 & 0x8000u);
-          const bool go = on & hdr_ok;
-          bad |= (on & !hdr_ok) ? 1u : 0u;
-          wide |= (go & (cnt16 > maxc_u)) ? 1u : 0u;
-          c += go ? 3u : 0u;
-          const bool first = go & (img_h == 0);
-          old_kind = first ? (t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL) : old_kind;
-          n_old = first ? cnt16 : n_old;
-          n_new = (go & (img_h != 0)) ? cnt16 : n_new;
-          n = go ? cnt16 : n;
-          k = go ? 0u : k;
-          const bool again = go & (cnt16 == 0) & (img_h == 0) & (upd != 0);  // an image without cells is complete at once
-          img = go ? (again ? 1u : img_h) : img;
-          st = on ? (go ? (cnt16 == 0 ? (again ? 1u : 0u) : 2u) : 0u) : st;
-          if (!__ballot(st == 2)) continue;
+    if constexpr (COPY) {
+      // parse_table_row_from_postgres_copy_bytes (codec/table_row.rs:47-254), lane = row: the row's fields are what lies between its
+      // separators, and the bitmaps of the window (k_cells<.., COPYK>: unescaped tabs / newlines, backslashes, newlines) are read
+      // eight words at a time into registers, so the walk from separator to separator is register arithmetic (ctz, masks) without
+      // a memory round trip per field. Every field gets its cell record (raw text); the fields that hold a backslash are noted
+      // in a column mask and finished by all waves afterwards (copy_fix below: the NULL marker, the escapes). Anything else than
+      // ncols fields closed by tabs and one final newline — a stray newline, more / fewer columns, a missing terminator, a dangling
+      // backslash (it escapes the newline), and for the whole tile invalid UTF-8 (copy_bad) — marks the row as a wire error: the
+      // batch then fails and the host decodes it again through the row -> frame rewrite (copy.hip), which knows the reference's
+      // error order.
+      uint32_t bad = copy_bad, cxm = 0;
+      if (live) {
+        o0 = s_offs[lane];
+        const uint32_t n = s_offs[lane + 1] - o0;   // (the window vote checked the offsets)
+        const uint32_t ro = o0 - b0;
+        v.fr = base + ro; v.e = base + ro + n; v.tag = 'I';
+        cnt = 1;
+        rel_id = q.copy_rel;
+        const uint32_t ncols = p.slots[pg.copy_slot].n_cols;
+        n_new = ncols;
+        bad |= n == 0 ? 1u : 0u;
+        if (!bad) {
+          const uint32_t* const bm_sep = sh.bm_sep; const uint32_t* const bm_bs = sh.bm_bs; const uint32_t* const bm_nl = sh.bm_nl;
+          const uint32_t endb = ro + n - 1;   // the row's last byte
+          const uint32_t w0 = ro >> 5, w1 = endb >> 5;
+          uint32_t k = 0, fs = ro, carry = 0;
+          for (uint32_t ws = w0; ws <= w1; ws += 8) {
+            uint32_t ms[8], bsw[8], nlw[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+              const uint32_t w = ws + u < w1 ? ws + u : w1;   // (words past the row are read as its last word and masked off below)
+              ms[u] = bm_sep[w]; bsw[u] = bm_bs[w]; nlw[u] = bm_nl[w];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+              const uint32_t w = ws + u;
+              uint32_t rng = w > w1 ? 0u : ~0u;
+              rng &= w == w0 ? ~0u << (ro & 31u) : ~0u;
+              rng &= w == w1 ? ~0u >> (31u - (endb & 31u)) : ~0u;
+              uint32_t m = ms[u] & rng;
+              const uint32_t b_ = bsw[u] & rng;
+              bad |= (m & nlw[u]) != (w == w1 ? 1u << (endb & 31u) : 0u) ? 1u : 0u;   // the only separator that is a newline is the row's last byte
+              uint32_t lo = 0;   // first bit of this word that belongs to the current field
+              while (m) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                m &= m - 1u;
+                const uint32_t below = (bit ? ~0u >> (32u - bit) : 0u) & (~0u << lo);   // lo <= bit <= 31
+                const uint32_t pos = (w << 5) + bit;
+                if (k < maxc) tab.put((maxc + k) * CF + lane, fs, pos - fs, (uint32_t)CT_T);
+                cxm |= (carry | (b_ & below)) ? 1u << (k & 31u) : 0u;
+                vbytes += pos - fs;
+                k++; fs = pos + 1u; carry = 0; lo = bit + 1u;
+              }
+              carry |= lo < 32u ? b_ & (~0u << lo) : 0u;
+            }
+          }
+          bad |= (k != ncols || fs != ro + n || k > maxc) ? 1u : 0u;
         }
-        {  // cells: 'n' | 'u' | ('t' | 'b') i32 len bytes
-          const bool on = st == 2;
-          const uint64_t head = next8(on);
-          const uint32_t t = (uint32_t)head & 0xFFu;
-          const uint32_t room = e - c;
-          const bool is_val = (t == 't') | (t == 'b');
-          const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
-          const uint32_t kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
-          const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
-          const bool go = on & cell_ok;
-          if (go & (k < maxc_u)) tab.put((img * maxc_u + k) * CF + lane, c, len, kind);
-          bad |= (on & !cell_ok) ? 1u : 0u;
-          wide |= (go & (len > 0x3FFFFFFFu)) ? 1u : 0u;
-          vbytes += go ? len : 0u;
-          c += go ? (is_val ? 5u + len : 1u) : 0u;
-          k += go ? 1u : 0u;
-          // image complete: an update goes on to its new image (a header step), everything else is finished
-          const bool done_img = go & (k == n);
-          const bool again = done_img & (img == 0) & (upd != 0);
-          img = again ? 1u : img;
-          st = on ? (go ? (done_img ? (again ? 1u : 0u) : 2u) : 0u) : st;
-        }
+        wire_ok = bad == 0;
       }
-      wire_ok = wire_ok & (bad == 0);
-      too_wide |= wide != 0;
+      if (lane < CF) sh.cxm[lane] = (live && !bad) ? cxm : 0u;
+      TSTAMP(11);
+    } else {
+      if (live) {
+        o0 = s_offs[lane];
+        const uint32_t o1 = s_offs[lane + 1];
+        if (o1 > o0 && o1 <= pg.in_len) {
+          v.fr = base + (o0 - b0);
+          v.e = base + (o1 - b0);
+          v.tag = classify_ptr(v.fr, o1 - o0);
+        }
+        const uint32_t tag = v.tag;
+        if (!(tag == 'I' || tag == 'U' || tag == 'D')) {
+          RowMsg dummy;
+          wire_ok = frame_structure(v, dummy);
+        }
+        if (consumes_ordinal(tag)) cnt = 1;
+        if (tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
+        if (tag == 'C') mark = (o0 + 1) << 1;
+      }
+      TSTAMP(11);
+      // parse_row_msg + walk_tuple for the I / U / D frames, recording every cell, with 32-bit offsets into `base`.
+      // This wave runs alone while the others wait and a lone wave issues an instruction every 5-8 cycles, so the
+      // walk is priced per instruction: a frame is at most (image header, cells) twice, and the two kinds of item
+      // get their own wave-level steps — one header step per pass, then a cell loop whose body is a dozen VALU
+      // operations (no data-dependent branches: bitwise predicates and selects).
+      {
+        // Loop-carried state is kept in integers (st: 0 idle, 1 in front of an image header, 2 inside an image; bad / wide:
+        // error flags): as `bool`s they live in lane-mask SGPR pairs and every trip paid ~30 scalar instructions merging them.
+        const uint32_t tag = v.tag;
+        const uint32_t upd = tag == 'U' ? 1u : 0u;
+        const uint32_t maxc_u = maxc;
+        uint32_t c = 0, e = 0, img = tag == 'I' ? 1u : 0u, k = 0, n = 0, st = 0, bad = 0, wide = 0;
+        if (live && (tag == 'I' || tag == 'U' || tag == 'D')) {
+          c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
+          wire_ok = e >= c + 5;
+          if (wire_ok) { rel_id = ld_be32(base + c); c += 4; st = 1; }
+        }
+        // the next 8 bytes of a lane: item tag + i16 count (header) or item tag + i32 length (cell)
+        auto next8 = [&](bool on) -> uint64_t {
+          if (STAGED) return ldu64(base + c);  // the window has 16 spare bytes past any frame
+          uint64_t head = 0;
+          if (on) for (uint32_t i = 0; i < 5 && c + i < e; i++) head |= (uint64_t)base[c + i] << (8 * i);
+          return head;
+        };
+        // One loop over "steps": a header step whenever some lane stands in front of an image header (the first trip for
+        // everybody, later the frames that go on from an old / key image to the new one), then a cell step for every lane
+        // inside an image. A tile finishes in (cells of its longest frame) + 1 or 2 trips.
+        for (;;) {
+          const unsigned long long wh = __ballot(st == 1);
+          if (!(wh | __ballot(st == 2))) break;
+          if (wh) {  // image header: 'K' | 'O' | 'N', i16 column count
+            const bool on = st == 1;
+            const uint64_t head = next8(on);
+            const uint32_t t = (uint32_t)head & 0xFFu;
+            const uint32_t room = e - c;  // c <= e holds for a lane that is still going
+            const bool is_old = (t == 'K') | (t == 'O');
+            const uint32_t img_h = ((img == 0) & !is_old & (upd != 0)) ? 1u : img;  // update without an old image
+            const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
+            const bool hdr_ok = (room >= 3) & (img_h == 0 ? is_old : t == 'N') & !(cnt16 & 0x8000u);
+            const bool go = on & hdr_ok;
+            bad |= (on & !hdr_ok) ? 1u : 0u;
+            wide |= (go & (cnt16 > maxc_u)) ? 1u : 0u;
+            c += go ? 3u : 0u;
+            const bool first = go & (img_h == 0);
+            old_kind = first ? (t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL) : old_kind;
+            n_old = first ? cnt16 : n_old;
+            n_new = (go & (img_h != 0)) ? cnt16 : n_new;
+            n = go ? cnt16 : n;
+            k = go ? 0u : k;
+            const bool again = go & (cnt16 == 0) & (img_h == 0) & (upd != 0);  // an image without cells is complete at once
+            img = go ? (again ? 1u : img_h) : img;
+            st = on ? (go ? (cnt16 == 0 ? (again ? 1u : 0u) : 2u) : 0u) : st;
+            if (!__ballot(st == 2)) continue;
+          }
+          {  // cells: 'n' | 'u' | ('t' | 'b') i32 len bytes
+            const bool on = st == 2;
+            const uint64_t head = next8(on);
+            const uint32_t t = (uint32_t)head & 0xFFu;
+            const uint32_t room = e - c;
+            const bool is_val = (t == 't') | (t == 'b');
+            const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
+            const uint32_t kind = t == 't' ? (uint32_t)CT_T : t == 'b' ? (uint32_t)CT_B : t == 'u' ? (uint32_t)CT_U : (uint32_t)CT_N;
+            const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
+            const bool go = on & cell_ok;
+            if (go & (k < maxc_u)) tab.put((img * maxc_u + k) * CF + lane, c, len, kind);
+            bad |= (on & !cell_ok) ? 1u : 0u;
+            wide |= (go & (len > 0x3FFFFFFFu)) ? 1u : 0u;
+            vbytes += go ? len : 0u;
+            c += go ? (is_val ? 5u + len : 1u) : 0u;
+            k += go ? 1u : 0u;
+            // image complete: an update goes on to its new image (a header step), everything else is finished
+            const bool done_img = go & (k == n);
+            const bool again = done_img & (img == 0) & (upd != 0);
+            img = again ? 1u : img;
+            st = on ? (go ? (done_img ? (again ? 1u : 0u) : 2u) : 0u) : st;
+          }
+        }
+        wire_ok = wire_ok & (bad == 0);
+        too_wide |= wide != 0;
+      }
     }
     TSTAMP(9);
     // wave-level transaction scan (no barrier: a tile's frames live in one wave)
@@ -421,7 +511,8 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
                             // so that the waves pulling from it finish close to each other
       const mask_t below = (one << lane) - one;
       const uint32_t vc_of = lane < (uint32_t)MAXC ? lane : maxc + (lane - MAXC);
-      if ((scan >> lane) & 1u) vlist[0][pop(scan & below)] = (uint8_t)vc_of;
+      if ((scan >> lane) & 1u) { const uint32_t rk = pop(scan & below); vlist[0][rk] = (uint8_t)vc_of; vinv[vc_of] = (uint8_t)rk; }
+      else vinv[vc_of] = 0xFF;
       const mask_t t1 = present & heapy & ~scan, t2 = present & scan, t3 = present & ~(heapy | scan);
       const uint32_t rank = ((t1 >> lane) & 1u) ? pop(t1 & below)
                           : ((t2 >> lane) & 1u) ? pop(t1) + pop(t2 & below)
@@ -432,6 +523,62 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     ETLG_WAVE_PRIO(0);
   }
   __syncthreads();
+  if constexpr (COPY) {
+    // copy_fix: the fields that hold a backslash, one per lane (wave = column, lane = row). A field that is exactly `\N` on the raw
+    // bytes is NULL (table_row.rs:199); in every other one the escapes are undone IN PLACE (:129-176; unescaping only shrinks, so
+    // the text is rewritten from the field's first byte and the cell record keeps its position). A backslash is never the
+    // field's last byte: the separator behind it would have been an escaped character (k_cells<.., COPYK>).
+    const uint32_t ncols = p.slots[pg.copy_slot].n_cols;
+    const uint32_t* const bm_bs = sh.bm_bs;
+    u8* const win = const_cast<u8*>(base);
+    auto next_bs = [&](uint32_t from, uint32_t lim) -> uint32_t {   // next backslash in [from, lim), or lim
+      while (from < lim) {
+        const uint32_t m = bm_bs[from >> 5] >> (from & 31u);
+        if (m) { const uint32_t q2 = from + (uint32_t)__builtin_ctz(m); return q2 < lim ? q2 : lim; }
+        from = (from | 31u) + 1u;
+      }
+      return lim;
+    };
+    for (uint32_t k = (uint32_t)wave; k < ncols && k < maxc; k += NW) {
+      if (lane < nt && ((sh.cxm[lane] >> k) & 1u)) {
+        uint32_t start, raw_len, kind0;
+        tab.get((maxc + k) * CF + lane, base, start, raw_len, kind0);
+        const uint32_t pk = start + raw_len;
+        uint32_t nb = next_bs(start, pk);
+        if (raw_len == 2 && nb == start && win[start + 1] == 'N') tab.put((maxc + k) * CF + lane, start, 0u, (uint32_t)CT_N);
+        else {
+          uint32_t pos = start, w_ = start;
+          for (;;) {
+            const uint32_t run = nb - pos;
+            if (w_ != pos) {
+              uint32_t j = 0;
+              for (; j + 8 <= run; j += 8) {
+                const uint64_t x = ldu64(win + pos + j);
+#pragma unroll
+                for (uint32_t b2 = 0; b2 < 8; b2++) win[w_ + j + b2] = (u8)(x >> (8 * b2));
+              }
+              for (; j < run; j++) win[w_ + j] = win[pos + j];
+            }
+            w_ += run; pos = nb;
+            if (pos >= pk) break;
+            const uint32_t e = win[pos + 1];
+            if (e < 0x80u) {
+              const uint32_t ch = e == 'b' ? 8u : e == 'f' ? 12u : e == 'n' ? (uint32_t)'\n' : e == 'r' ? (uint32_t)'\r' : e == 't' ? (uint32_t)'\t' : e == 'v' ? 11u : e;
+              win[w_++] = (u8)ch;
+              pos += 2;
+            } else {  // a whole multi-byte character (the window is valid UTF-8)
+              const uint32_t l = e >= 0xF0u ? 4u : e >= 0xE0u ? 3u : 2u;
+              for (uint32_t t2 = 0; t2 < l; t2++) win[w_ + t2] = win[pos + 1 + t2];
+              w_ += l; pos += 1 + l;
+            }
+            nb = next_bs(pos, pk);
+          }
+          tab.put((maxc + k) * CF + lane, start, w_ - start, (uint32_t)CT_T);
+        }
+      }
+    }
+    __syncthreads();
+  }
   TSTAMP(2);
 
   // ================= P2: heap bytes per cell; waves pull virtual columns from a queue
@@ -444,6 +591,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     const uint32_t vc = vlist[0][vj];
     const int slot = fr_slot[lane];
     const uint32_t meta = fr_meta[lane];
+    uint64_t fbits = 0; bool fok = false;
     const uint32_t img = vc >= maxc, k = vc - img * maxc;
     const uint32_t n = img ? (fr_n[lane] >> 16) : (fr_n[lane] & 0xFFFF);
     const uint32_t tag = meta_tag(meta);
@@ -456,18 +604,35 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       uint32_t pos, len, kind;
       const uint32_t ent = tab.get(vc * CF + lane, base, pos, len, kind);
       const uint32_t cls = ci >= 0 ? (uint32_t)cols[ci].cls : 0u;
-      if (ci >= 0 && kind == CT_T && ((kScanClasses >> cls) & 1u)) {
+      bool sized = ci >= 0 && kind == CT_T && ((kScanClasses >> cls) & 1u);
+      if (dbg_u >> 17) {  // profiling ablation (results are wrong): leave one class unsized
+        const uint32_t fam = cls == ETLG_TC_NUMERIC ? 1u : cls == ETLG_TC_BYTEA ? 4u : 2u;
+        if ((dbg_u >> 17) & fam) sized = false;
+      }
+      if (sized) {
         const u8* d = base + pos;
         uint32_t h = 0;
         bool done = false;
         while (!done) {  // one pass per distinct class among the active lanes, scalar dispatch inside
           const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
-          if (cls == u) { h = cell_heap_bytes(u, d, len, use_lds); done = true; }
+          if (cls == u) {
+            if (u == ETLG_TC_F32 || u == ETLG_TC_F64) {  // parsed once: P3 takes the value from the cache
+              const int r = parse_float_fast(d, len, u == ETLG_TC_F32, fbits, use_lds);
+              h = r == 1 ? pad4(len) : 0u;
+              fok = r == 0;
+            } else h = cell_heap_bytes(u, d, len, use_lds);
+            done = true;
+          }
         }
         tab.set_heap_of(vc * CF + lane, ent, h);
       }
     }
     ETLG_WAVE_JOIN();
+    if (vj < kFloatCache) {
+      const unsigned long long okm = __ballot(fok);
+      if (fok) fcache[vj][lane] = fbits;
+      if (lane == 0) fc_ok[vj] = okm;
+    }
   }
   __syncthreads();
   TSTAMP(3);
@@ -520,7 +685,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         for (uint32_t i = 0; i < 2u * MAXC; i++) hh[i] = i < VC ? tab.raw(i * CF + lane) : 0u;
 #pragma unroll
         for (uint32_t i = 0; i < 2u * MAXC; i++) {
-          if (i < VC) {  // uniform
+          if (i < VC && !(COPY && i < maxc)) {  // uniform (a table-copy tile has no old / key image)
             const bool in_new = i >= maxc;
             const uint32_t k = in_new ? i - maxc : i;
             const bool take = (k < (in_new ? cells_new : cells_old)) & (((heap_cols >> (in_new ? 16u + k : k)) & 1u) != 0);
@@ -667,6 +832,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         if (bad_utf8) err = ETLG_E_UTF8;
       }
     }
+    if (textual && !coop && (cls == ETLG_TC_F32 || cls == ETLG_TC_F64)) {  // a float the sizing pass has parsed
+      const uint32_t rk = vinv[vc];
+      if (rk < kFloatCache && ((fc_ok[rk] >> lane) & 1ull)) { st64(slotp, fcache[rk][lane]); st = ETLG_CELL_VALUE; textual = false; }
+    }
     if (textual && !coop) {
       bool done = false;
       while (!done) {  // waterfall over the distinct classes of this wave's cells
@@ -739,7 +908,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     pg.ev_flags[ev_idx] = (u8)flags;
     pg.ev_table[ev_idx] = rel_id;
     pg.ev_slot[ev_idx] = s.host_id;
-    pg.ev_start[ev_idx] = ld_be64(v.fr + 6);
+    pg.ev_start[ev_idx] = COPY ? 0ull : ld_be64(v.fr + 6);   // (the Insert frames of the row -> frame rewrite carry a zero WAL position)
     pg.ev_commit[ev_idx] = tx.final_lsn;
     pg.ev_ord[ev_idx] = tx.ord;
     pg.ev_body[ev_idx] = fx_off;
@@ -755,7 +924,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
                                  // one-dword cell table a 12-column tile is ~38 KB of LDS, so four fit; measured on cfg3: 281 us at three
                                  // workgroups (168 VGPRs, no spills), 238 us at four (profiles/r02u_cells_variants.json)
 #endif
-template <int NW, bool WIDE>
+// COPYK: the tiles are 64 table-copy rows each (etlg_copy_decode): `pg.in` / `pg.offs` are the COPY text rows and their offsets, the
+// cell table has two dwords per cell, and the splitter of cells_tile<.., 2, ..> takes P1's place — the rows reach the arena in one
+// kernel, without being rewritten as Insert frames first (copy.hip stays as the path for batches with a malformed row).
+template <int NW, bool WIDE, bool COPYK>
 __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecParams pg, FusedParams q) {
   ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[CF + 1];
@@ -771,6 +943,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
   __shared__ uint8_t vlist[2][64];
+  __shared__ uint64_t fcache[kFloatCache][CF];
+  __shared__ uint64_t fc_ok[kFloatCache];
+  __shared__ uint8_t vinv[64];
+  __shared__ uint32_t cxm[CF];
   const uint32_t tid = threadIdx.x;
   if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
@@ -790,8 +966,8 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   // dynamic LDS: side tables | cell table (one dword per cell) | staging window; a tile read in place spreads its
   // three-dword cells over table + window (the host sizes the allocation for that, etlg_k_cells_lds_floor)
   uint32_t* ct = (uint32_t*)(smem + q.side_bytes);  // side_bytes is a multiple of 16
-  u8* stage = (u8*)(ct + VC * CF);
-  const uint32_t table_bytes = VC * CF * 4;
+  const uint32_t table_bytes = VC * CF * (COPYK ? 8u : 4u);
+  u8* stage = (u8*)ct + table_bytes;
   const uint32_t tile = blockIdx.x;
   const uint32_t lane = tid & 63;
   const int wave = (int)(((tid >> 6) + ((dbg_u & 0x10000u) ? 0u : tile)) & (uint32_t)(NW - 1));   // role of this wave in the tile (cells_tile)
@@ -802,8 +978,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
   const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
-  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len && span1 - a0 + 16 <= kWinMax &&
-                         (uint64_t)(span1 - a0) + 16 + table_bytes <= q.lds_bytes - q.side_bytes;
+  // (table-copy tiles keep three bitmaps of the window behind it, 3/8 of its bytes: etlg_k_copy_cells_lds)
+  const uint32_t avail = q.lds_bytes - q.side_bytes;
+  const uint32_t wcap = COPYK ? (avail > table_bytes + 128 ? (((avail - table_bytes - 128) / 11) * 8) & ~15u : 0u) : (avail > table_bytes ? avail - table_bytes : 0u);
+  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len && span1 - a0 + 16 <= kWinMax && (uint64_t)(span1 - a0) + 16 <= wcap;
   if (window_ok) {
     const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
     stage_chunks<NW * 64>(pg.in, stage, a0, full_end, tid);
@@ -816,14 +994,71 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   bool lane_ok = true;
   if (tid < nt) {
     const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
-    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
+    lane_ok = COPYK ? (o1 >= o0 && o0 >= span0 && o1 <= span1) : (o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1));
   }
   const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
   TSTAMP(1);
-  const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist};
-  // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
-  if (use_lds) cells_tile<NW, true, WIDE>(p, pg, q, sh, stage, a0, tile, nt);
-  else cells_tile<NW, false, WIDE>(p, pg, q, sh, pg.in, 0u, tile, nt);
+  if constexpr (COPYK) {
+    // table_row.rs:51 validates a row as UTF-8 before anything else. Every row that decodes here ends in a newline, so the rows of the
+    // tile are valid exactly when the tile's bytes are, and those are checked four at a time by the whole workgroup (position-wise
+    // rule, utf8_swar.h). A tile that fails — or whose rows do not fit the window — marks all its rows (cells_tile).
+    uint32_t bad8 = use_lds ? 0u : 1u;
+    uint32_t* const bm_sep = (uint32_t*)(stage + wcap);
+    uint32_t* const bm_bs = bm_sep + (wcap / 32 + 2);
+    uint32_t* const bm_nl = bm_bs + (wcap / 32 + 2);
+    const uint32_t nchunks = use_lds ? (span1 - a0 + 15) / 16 + 2 : 0u;   // (+2: look-aheads read one word past the last row)
+    if (use_lds) {
+      // where the special bytes are: one bit per window byte, 16 bytes per thread and step
+      for (uint32_t ci = tid; ci < nchunks; ci += NW * 64) {
+        const uint4 x4 = *(const uint4*)(stage + 16 * ci);
+        const uint32_t xs[4] = {x4.x, x4.y, x4.z, x4.w};
+        uint32_t sep16 = 0, bs16 = 0, nl16 = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          auto eq = [](uint32_t v4, uint32_t c) { const uint32_t t = v4 ^ (c * 0x01010101u); return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u; };   // bit 7 of every byte equal to c (exact)
+          auto nib = [](uint32_t m) { return (((m >> 7) * 0x01020408u) >> 24) & 0xFu; };   // those four bits side by side
+          const uint32_t b = eq(xs[u], '\\'), nl = eq(xs[u], '\n'), sp = nl | eq(xs[u], '\t');
+          sep16 |= nib(sp) << (4 * u); bs16 |= nib(b) << (4 * u); nl16 |= nib(nl) << (4 * u);
+        }
+        ((uint16_t*)bm_sep)[ci] = (uint16_t)sep16;
+        ((uint16_t*)bm_bs)[ci] = (uint16_t)bs16;
+        ((uint16_t*)bm_nl)[ci] = (uint16_t)nl16;
+      }
+      __syncthreads();
+      // a tab / newline behind an odd run of backslashes is an escaped character, not a separator (the run cannot reach back into
+      // the row before: a row that decodes here ends in a newline)
+      for (uint32_t w = tid; 2 * w < nchunks; w += NW * 64) {
+        uint32_t esc = bm_sep[w] & ((bm_bs[w] << 1) | (w ? bm_bs[w - 1] >> 31 : 0u));
+        uint32_t clear = 0;
+        while (esc) {
+          const uint32_t bit = (uint32_t)__builtin_ctz(esc);
+          esc &= esc - 1u;
+          uint32_t qb = (w << 5) + bit, run = 0;   // count the backslashes that end at qb - 1
+          while (qb > 0 && ((bm_bs[(qb - 1) >> 5] >> ((qb - 1) & 31u)) & 1u)) { run++; qb--; }
+          if (run & 1u) clear |= 1u << bit;
+        }
+        if (clear) bm_sep[w] &= ~clear;
+      }
+      const u8* wp = stage + (span0 - a0);
+      const uint32_t nb = span1 - span0;
+      for (uint32_t d = tid; 4 * d < nb; d += NW * 64) {
+        const uint32_t rem = nb - 4 * d;
+        uint32_t cur = ldu32(wp + 4 * d);
+        if (rem < 4) cur &= (1u << (8 * rem)) - 1u;
+        const uint32_t prev = d ? ldu32(wp + 4 * d - 4) : 0u;
+        if (((cur | prev) & 0x80808080u) && utf8_dword_bad(prev, cur, rem == 4)) bad8 = 1;
+      }
+    }
+    const uint32_t copy_bad = __syncthreads_and(bad8 ? 0 : 1) ? 0u : 1u;
+    const CellsLds shc{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, bm_sep, bm_bs, bm_nl, cxm, fcache, fc_ok, vinv};
+    cells_tile<NW, 2, WIDE>(p, pg, q, shc, stage, a0, tile, nt, copy_bad);
+  }
+  if constexpr (!COPYK) {
+    const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, nullptr, nullptr, nullptr, cxm, fcache, fc_ok, vinv};
+    // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
+    if (use_lds) cells_tile<NW, 1, WIDE>(p, pg, q, sh, stage, a0, tile, nt);
+    else cells_tile<NW, 0, WIDE>(p, pg, q, sh, pg.in, 0u, tile, nt);
+  }
 }
 
 }  // namespace etlg
@@ -834,19 +1069,31 @@ using namespace etlg;
 
 void etlg_k_launch_cells(const DecParams* p, const void* qv, hipStream_t s) {
   const FusedParams* q = (const FusedParams*)qv;
-  if (q->maxc > (uint32_t)MAXC_NARROW) hipLaunchKernelGGL((k_cells<4, true>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
-  else hipLaunchKernelGGL((k_cells<4, false>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+  if (q->maxc > (uint32_t)MAXC_NARROW) hipLaunchKernelGGL((k_cells<4, true, false>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+  else hipLaunchKernelGGL((k_cells<4, false, false>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+}
+
+// table-copy rows straight into the arena (p->in / p->offs: the rows and their offsets; q->copy_rel: the table's id)
+void etlg_k_launch_copy_cells(const DecParams* p, const void* qv, hipStream_t s) {
+  const FusedParams* q = (const FusedParams*)qv;
+  if (q->maxc > (uint32_t)MAXC_NARROW) hipLaunchKernelGGL((k_cells<4, true, true>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
+  else hipLaunchKernelGGL((k_cells<4, false, true>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
 }
 
 int etlg_k_cells_set_lds(void) {
-  const hipError_t a = hipFuncSetAttribute((const void*)k_cells<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-  const hipError_t b = hipFuncSetAttribute((const void*)k_cells<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608);
-  return a == hipSuccess && b == hipSuccess ? 0 : 1;
+  const hipError_t a = hipFuncSetAttribute((const void*)k_cells<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144);
+  const hipError_t b = hipFuncSetAttribute((const void*)k_cells<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6656);
+  const hipError_t a2 = hipFuncSetAttribute((const void*)k_cells<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144);
+  const hipError_t b2 = hipFuncSetAttribute((const void*)k_cells<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6656);
+  return a == hipSuccess && b == hipSuccess && a2 == hipSuccess && b2 == hipSuccess ? 0 : 1;
 }
 
 uint32_t etlg_k_cells_table_bytes(uint32_t maxc) { return 2u * maxc * CF * 4u; }       // next to the window of a staged tile
+uint32_t etlg_k_copy_cells_table_bytes(uint32_t maxc) { return 2u * maxc * CF * 8u; }  // ... of a tile of table-copy rows
+// dynamic LDS of a table-copy tile whose window holds `window` bytes: cell table, window, three bitmaps of the window (k_cells<.., COPYK>)
+uint32_t etlg_k_copy_cells_lds(uint32_t maxc, uint32_t window) { return 2u * maxc * CF * 8u + ((window + 15u) & ~15u) / 8u * 11u + 192u; }
 uint32_t etlg_k_cells_lds_floor(uint32_t maxc) { return 3u * 2u * maxc * CF * 4u; }    // table + window together: what a tile read in place needs
-uint32_t etlg_k_cells_static_lds(uint32_t maxc) { return maxc > (uint32_t)MAXC_NARROW ? 4224u : 3648u; }  // the kernel's __shared__ arrays (3 600 / 4 112 bytes in the gfx950 build of the narrow / wide instantiation) + slack
+uint32_t etlg_k_cells_static_lds(uint32_t maxc) { return (maxc > (uint32_t)MAXC_NARROW ? 4224u : 3648u) + kFloatCache * (CF + 1) * 8u + 64u; }  // the kernel's __shared__ arrays (5 744 / 6 256 bytes in the gfx950 build of the narrow / wide instantiation) + slack
 uint32_t etlg_k_cells_maxc(void) { return MAXC_WIDE; }
 
 }  // extern "C"

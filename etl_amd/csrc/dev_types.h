@@ -101,6 +101,7 @@ struct FusedParams {
   uint32_t maxc;               // k_cells: widest schema slot of the batch (columns)
   uint32_t clear_words;        // 64-bit words of d_clear this launch zeroes (the descriptor buffer of the NEXT batch)
   unsigned long long* d_clear;
+  uint32_t copy_rel;           // k_copy_cells: the table id the rows' Insert events carry
 };
 
 constexpr unsigned long long kNoErr = ~0ull;

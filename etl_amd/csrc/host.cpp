@@ -39,6 +39,7 @@ void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
   if (which == kFused) etlg_k_launch_fused((int)c->fq.blk, &p, &c->fq, c->stream);
   else if (which == kPlan) etlg_k_launch_plan(&p, &c->pq, c->stream);
   else if (which == kCells) etlg_k_launch_cells(&p, &c->fq, c->stream);
+  else if (which == kCopyCells) etlg_k_launch_copy_cells(&p, &c->fq, c->stream);
   else etlg_k_launch(which, &p, c->stream);
 }
 
@@ -61,6 +62,20 @@ void launch_copy(etlg_ctx* c, const CopyJob& j, const DecParams& p) {
   if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, c->stream); }
   etlg_k_launch_copy(j.d_rows, j.d_row_offs, j.nrows, j.rows_len, j.ncols, j.rel_id, j.d_out, j.d_out_offs, j.lds, c->copy_lane_per_byte ? 1 : 0, &p, c->stream);
   if (c->prof) { (void)hipEventRecord(r.b, c->stream); c->prof_recs.push_back(r); }
+}
+
+// A table-copy batch whose first attempt was (or would have been) the rows -> arena kernel goes on as a batch of Insert frames:
+// the rows are rewritten (copy.hip, with the reference's row-level errors) and every parameter that named the rows names the frames.
+int32_t copy_use_frames(etlg_ctx* c, etlg_batch* b) {
+  CopyJob& j = b->copy;
+  HIPCHK(c, c->d_copy_out.ensure(j.syn_len + 64)); HIPCHK(c, c->d_copy_out_offs.ensure(((size_t)j.nrows + 1) * 4));
+  j.d_out = (uint8_t*)c->d_copy_out.p; j.d_out_offs = (uint32_t*)c->d_copy_out_offs.p;
+  j.direct = false;
+  DecParams& p = b->params;
+  p.in = j.d_out; p.offs = j.d_out_offs; p.in_len = j.syn_len;
+  b->len = (size_t)j.syn_len; b->d_in_ptr = j.d_out; b->dev_in = j.d_out; b->user_offs = j.d_out_offs;
+  launch_copy(c, j, p);
+  return ETLG_OK;
 }
 
 // The multi-pass pipeline (also the exact first-error path).
@@ -222,12 +237,15 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   e = hipMalloc((void**)&c->d_init_ring, sizeof(DevResult) * etlg_ctx::kResRing);
   if (e == hipSuccess) e = hipMemcpy(c->d_init_ring, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice);
   if (e != hipSuccess) { snprintf(g_create_err, sizeof g_create_err, "hipMalloc: %s", hipGetErrorString(e)); delete c; return ETLG_DeviceError; }
-  (void)etlg_k_fused_set_lds();
-  (void)etlg_k_cells_set_lds();
-  (void)etlg_k_copy_set_lds();
+  // (a kernel whose static + dynamic LDS request exceeds a CU's 160 KB is refused here, not at its first launch)
+  if (etlg_k_fused_set_lds() || etlg_k_cells_set_lds() || etlg_k_copy_set_lds()) {
+    snprintf(g_create_err, sizeof g_create_err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) refused a kernel's LDS request");
+    delete c; return ETLG_DeviceError;
+  }
   { const char* fm = getenv("ETLG_FORCE_MULTIPASS"); c->force_multipass = fm && fm[0] == '1'; }
   { const char* e = getenv("ETLG_RING_H2D"); c->ring_h2d = e && e[0] == '1'; }
   { const char* e = getenv("ETLG_COPY_KERNEL"); c->copy_lane_per_byte = e && e[0] == '1'; }
+  { const char* e = getenv("ETLG_COPY_DIRECT"); c->copy_direct = !(e && e[0] == '0'); }
   { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && (ht[0] == '1' || ht[0] == '2'); c->host_times_slow = ht && ht[0] == '2'; }
   { const char* sc = getenv("ETLG_CTRL_STAGE_CAP"); c->ctrl_stage_cap_test = sc ? (size_t)atol(sc) : 0; }
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
@@ -432,7 +450,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : i == kCopyCells ? "k_copy_cells" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }
@@ -668,6 +686,13 @@ int32_t etlg_ctx_debug_scan(etlg_ctx* c, unsigned long long* out2) {
   return ETLG_OK;
 }
 
+// debugging aid (not part of etlg.h): table-copy batches [0] produced by the rows -> arena kernel, [1] decoded through the row -> frame rewrite
+int32_t etlg_ctx_debug_copy(etlg_ctx* c, unsigned long long* out2) {
+  if (!c || !out2) return ETLG_InvalidArgument;
+  out2[0] = c->copy_n[0]; out2[1] = c->copy_n[1];
+  return ETLG_OK;
+}
+
 int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, size_t len, const uint32_t* row_offsets, size_t nrows,
                          uint32_t flags, etlg_batch** out) {
   { const int32_t rc_ = flush_deferred(c); (void)rc_; }
@@ -695,9 +720,15 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
     HIPCHK(c, hipMemcpyAsync(c->d_copy_offs.p, row_offsets, (nrows + 1) * 4, hipMemcpyHostToDevice, s));
     j.d_rows = (const uint8_t*)c->d_copy_in.p; j.d_row_offs = (const uint32_t*)c->d_copy_offs.p;
   }
-  HIPCHK(c, c->d_copy_out.ensure(syn_len + 64)); HIPCHK(c, c->d_copy_out_offs.ensure((nrows + 1) * 4));
-  j.d_out = (uint8_t*)c->d_copy_out.p; j.d_out_offs = (uint32_t*)c->d_copy_out_offs.p;
-  if (nrows == 0) HIPCHK(c, hipMemsetAsync(j.d_out_offs, 0, 4, s));
+  j.syn_len = syn_len;
+  // first attempt: the rows go straight into the arena (k_copy_cells, cells.hip); a batch with anything unusual in it — a malformed
+  // row, rows that do not fit a tile's window — fails there and is decoded again through the row -> frame rewrite below
+  j.direct = c->copy_direct && nrows != 0 && len < (1ull << 31) && !c->force_multipass && ncols <= etlg_k_cells_maxc();
+  if (!j.direct) {
+    HIPCHK(c, c->d_copy_out.ensure(syn_len + 64)); HIPCHK(c, c->d_copy_out_offs.ensure((nrows + 1) * 4));
+    j.d_out = (uint8_t*)c->d_copy_out.p; j.d_out_offs = (uint32_t*)c->d_copy_out_offs.p;
+    if (nrows == 0) HIPCHK(c, hipMemsetAsync(j.d_out_offs, 0, 4, s));
+  }
   const uint64_t avg = nrows ? (len + nrows - 1) / nrows : 0;
   j.lds = (uint32_t)std::min<uint64_t>(((256 * avg * 9 / 8 + 1024) + 255) & ~255ull, 150 * 1024);
   { const char* e = getenv("ETLG_COPY_LDS"); if (e) j.lds = (uint32_t)atoi(e); }   // measurement knob: 0 = rows read in place (no staging window, more waves per CU)
@@ -705,8 +736,9 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
   const bool sv_in = c->in_txn; const uint64_t sv_lsn = c->final_lsn, sv_ord = c->next_ord;
   c->in_txn = true; c->final_lsn = 0; c->next_ord = 0;
   c->copy = j;
-  const int32_t rc = etlg_decode(c, j.d_out, (size_t)syn_len, j.d_out_offs, nrows,
-                                 (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL, out);
+  const int32_t rc = j.direct ? etlg_decode(c, j.d_rows, len, j.d_row_offs, nrows, (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL, out)
+                              : etlg_decode(c, j.d_out, (size_t)syn_len, j.d_out_offs, nrows,
+                                            (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL, out);
   c->copy = CopyJob{};
   c->in_txn = sv_in; c->final_lsn = sv_lsn; c->next_ord = sv_ord;
   if (*out) {
@@ -981,7 +1013,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   { SlowScope slow_scope_pool(c, "decode_tail: pinned result block");
   if (c->res_pool.empty()) { DevResult* r = nullptr; HIPCHK(c, hipHostMalloc((void**)&r, sizeof(DevResult), hipHostMallocDefault)); c->res_pool.push_back(r); }
   b->h_res = c->res_pool.back(); c->res_pool.pop_back(); }
-  if (b->copy.active) launch_copy(c, b->copy, p);  // rows -> Insert frames (writes p.in / p.offs), row-level errors
+  if (b->copy.active && !b->copy.direct) launch_copy(c, b->copy, p);  // rows -> Insert frames (writes p.in / p.offs), row-level errors
 
   // ---- first attempt. A single-pass kernel runs OPTIMISTICALLY as if the batch held no Relation / DDL frame (they are
   //      <0.1 % of frames and absent from almost every batch): no classify / control-list kernels, no host round trip. A

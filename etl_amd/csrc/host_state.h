@@ -61,6 +61,9 @@ extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64
 extern "C" void etlg_k_col_var(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
+extern "C" uint32_t etlg_k_copy_cells_table_bytes(uint32_t maxc);
+extern "C" uint32_t etlg_k_copy_cells_lds(uint32_t maxc, uint32_t window);
+extern "C" void etlg_k_launch_copy_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" uint32_t etlg_k_cells_maxc(void);
 extern "C" uint32_t etlg_k_cells_lds_floor(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_static_lds(uint32_t maxc);
@@ -70,7 +73,8 @@ constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)
 constexpr int kBounds = 9; // ... of the record-boundary scan (scan.hip)
 constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
 constexpr int kPlan = 11;  // ... of the fixed-width plan (plan.hip)
-constexpr int kProfSlots = 12;
+constexpr int kCopyCells = 12;  // ... of the table-copy rows -> arena kernel (cells.hip, k_cells<.., COPYK>)
+constexpr int kProfSlots = 13;
 
 namespace {
 
@@ -221,6 +225,8 @@ struct CopyJob {
   uint32_t nrows = 0, ncols = 0, rel_id = 0, lds = 0;
   uint64_t rows_len = 0;
   uint8_t* d_out = nullptr; uint32_t* d_out_offs = nullptr;
+  bool direct = false;      // first attempt: rows -> arena in one kernel (k_copy_cells); a batch that fails there is decoded again through the frames
+  uint64_t syn_len = 0;     // bytes of the Insert frames the rows rewrite to (sizes d_out and the arenas)
 };
 
 // One uploaded copy of the side inputs (table states + cache timeline, schema slots + columns, the fixed-width plan's tables):
@@ -339,6 +345,8 @@ struct etlg_ctx {
   bool force_multipass = false;  // ETLG_FORCE_MULTIPASS=1 (tests exercise both paths)
   unsigned long long last_dbg[12] = {0};
   unsigned long long path_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long copy_n[2] = {0, 0};   // table-copy batches produced by k_copy_cells / decoded through the row -> frame rewrite
+  bool copy_direct = true;                 // ETLG_COPY_DIRECT=0: always the row -> frame rewrite
   int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells, 3 k_plan whenever eligible (default: plan, else by frame size)
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;

@@ -368,6 +368,13 @@ class Decoder:
         self.L.etlg_ctx_debug_paths8(self.h, out)
         return dict(zip(("fused", "cells", "multipass", "redone", "plan", "plan_redone", "control", "chain_rerun"), [int(x) for x in out]))
 
+    def debug_copy(self):
+        """Table-copy batches by path (debugging aid, not in etlg.h): 'direct' = produced by the rows -> arena kernel (k_copy_cells),
+        'frames' = decoded through the row -> frame rewrite (a malformed row, rows wider than a tile's window, ETLG_COPY_DIRECT=0)."""
+        out = (C.c_ulonglong * 2)()
+        self.L.etlg_ctx_debug_copy(self.h, out)
+        return {"direct": int(out[0]), "frames": int(out[1])}
+
     def frame_tags(self, buf, offsets):
         """pgoutput tag of every frame (np.uint8; 0 = malformed), classified on the device (etlg_frame_tags)."""
         import numpy as np

@@ -146,18 +146,22 @@ def _fuzz_rows(seed, n):
     return rows
 
 
-@pytest.fixture(params=["lane_per_row", "lane_per_byte"])
+@pytest.fixture(params=["direct", "lane_per_row", "lane_per_byte"])
 def splitter(request):
-    """Both COPY splitters of copy.hip: the default (one lane per row) and the data-parallel one (ETLG_COPY_KERNEL=1, read when the
-    context is created)."""
+    """The three COPY front ends: rows -> arena in one kernel (k_copy_cells, the default; a batch with a malformed row is decoded
+    again through the frames), and the two row -> frame splitters of copy.hip on their own (ETLG_COPY_DIRECT=0: one lane per row, and
+    with ETLG_COPY_KERNEL=1 the data-parallel one). The knobs are read when the context is created."""
     import os
-    saved = os.environ.pop("ETLG_COPY_KERNEL", None)
+    saved = {k: os.environ.pop(k, None) for k in ("ETLG_COPY_KERNEL", "ETLG_COPY_DIRECT")}
+    if request.param != "direct":
+        os.environ["ETLG_COPY_DIRECT"] = "0"
     if request.param == "lane_per_byte":
         os.environ["ETLG_COPY_KERNEL"] = "1"
     yield request.param
-    os.environ.pop("ETLG_COPY_KERNEL", None)
-    if saved is not None:
-        os.environ["ETLG_COPY_KERNEL"] = saved
+    for k, v in saved.items():
+        os.environ.pop(k, None)
+        if v is not None:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -167,7 +171,17 @@ def test_copy_splitter_step_boundaries(seed, splitter):
     o, d, rb, gb = both(cols, rows)
     assert rb.err_code == 0, (rb.err_desc, rb.err_frame)
     assert_same(rb, gb)
+    # (rows of several KB: a tile of 64 of them can outgrow the LDS window — such a batch takes the frames even by default)
+    dc = d.debug_copy()
+    assert dc["direct"] + dc["frames"] == 1 and (splitter == "direct" or dc["frames"] == 1)
     d.close()
+    if splitter == "direct":   # the same kinds of rows without the multi-KB ones stay in the one-kernel path
+        short = [r for r in rows if len(r) < 600]
+        o, d, rb, gb = both(cols, short)
+        assert rb.err_code == 0
+        assert_same(rb, gb)
+        assert d.debug_copy() == {"direct": 1, "frames": 0}
+        d.close()
 
 
 @pytest.mark.parametrize("kind", ["utf8_cut_at_row_end", "utf8_overlong", "cont_at_row_start", "unterminated", "more", "fewer", "trailing_backslash",
@@ -185,6 +199,8 @@ def test_copy_splitter_row_errors(kind, splitter):
         rows = [good1, bad, b"\xb8tail\tz\n" if kind == "utf8_cut_at_row_end" else b"x\ty\n", b"k\tl\n"]
         o, d, rb, gb = both(cols, rows)
         assert_same(rb, gb)
+        if kind not in ("escaped_tab_before_sep",):   # a malformed row: whatever ran first, the frames decided
+            assert d.debug_copy() == {"direct": 0, "frames": 1}, (kind, pad)
         d.close()
 
 
@@ -195,6 +211,8 @@ def test_copy_generated_rows_lane_per_byte(splitter):
     o, d, rb, gb = both(GEN_COLS, rows)
     assert rb.err_code == 0
     assert_same(rb, gb)
+    assert d.debug_copy() == ({"direct": 1, "frames": 0} if splitter == "direct" else {"direct": 0, "frames": 1})
+    assert d.debug_paths()["redone"] == 0
     d.close()
     for cols, row, _want in K.OK:
         o, d, rb, gb = both(cols, [bytes(row)])
@@ -206,3 +224,62 @@ def test_copy_generated_rows_lane_per_byte(splitter):
         assert rb.err_code == code
         assert_same(rb, gb)
         d.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_copy_field_tasks_fuzz(seed):
+    """The rows -> arena kernel's per-field tasks (cells.hip): four text columns of pieces chosen to confuse a splitter that works from
+    bitmaps — escaped tabs and newlines as raw bytes behind backslash runs of every parity, `\\N` as a whole field / as a prefix / behind
+    an escaped backslash, fields that end in an escaped backslash right before the separator, empty fields, multi-byte characters
+    behind a backslash, rows from 5 bytes to a few hundred so that rows and fields start at every bit of the bitmap words."""
+    rng = random.Random(seed)
+    pieces = ["a", "bc", "\\\\", "\\\t", "\\\n", "\\N", "\\\\\\\\", "\\\\\\\t", "é", "\\é", "😀", "\\😀", "\\q", "N", "\\b", " ", "0123456789" * 3]
+    cols = [(c, K.TEXT, True, 0) for c in "abcd"]
+
+    def field():
+        k = rng.random()
+        if k < 0.12:
+            return "\\N"
+        if k < 0.2:
+            return ""
+        if k < 0.25:
+            return "\\\\N"          # an escaped backslash, then N: the text `\N`, not NULL
+        if k < 0.3:
+            return "\\N" + rng.choice(pieces)
+        return "".join(rng.choice(pieces) for _ in range(rng.randrange(1, rng.choice([3, 8, 25]))))
+    rows = [("\t".join(field() for _ in range(4)) + "\n").encode() for _ in range(900)]
+    o, d, rb, gb = both(cols, rows)
+    assert rb.err_code == 0, (rb.err_desc, rb.err_frame)
+    assert_same(rb, gb)
+    assert d.debug_copy() == {"direct": 1, "frames": 0}
+    d.close()
+    # the same rows with one malformed row in the middle of a tile: the batch is decoded again through the frames, up to that row
+    bad = rows[:500] + [b"a\tb\tc\n"] + rows[500:]
+    o, d, rb, gb = both(cols, bad)
+    assert rb.err_frame == 500 and rb.err_code != 0
+    assert_same(rb, gb)
+    assert d.debug_copy() == {"direct": 0, "frames": 1}
+    d.close()
+
+
+def test_copy_long_rows_take_the_row_walk():
+    """Rows longer than the per-field tasks take (4 KB) are split by the lane-per-row walk inside the same kernel; short rows of the
+    same tile by the tasks."""
+    rng = random.Random(5)
+    cols = [("a", K.TEXT, True, 0), ("b", K.TEXT, True, 0), ("c", K.INT4, True, 0)]
+    pieces = ["abc", "\\\\", "\\t", "\\\t", "é", "\\é", "x" * 40, "\\N", " "]
+    rows = []
+    for i in range(24):
+        if i % 5 == 2:
+            a = "".join(rng.choice(pieces) for _ in range(400))          # ~5 KB
+            while len(a.encode()) < 4200:
+                a += rng.choice(pieces)
+        else:
+            a = "".join(rng.choice(pieces) for _ in range(rng.randrange(0, 6)))
+        b = "\\N" if i % 3 == 0 else "".join(rng.choice(pieces) for _ in range(rng.randrange(0, 4)))
+        rows.append((a + "\t" + b + "\t" + ("\\N" if i % 4 == 1 else str(i - 7)) + "\n").encode())
+    o, d, rb, gb = both(cols, rows)
+    assert rb.err_code == 0, (rb.err_desc, rb.err_frame)
+    assert_same(rb, gb)
+    assert d.debug_copy() == {"direct": 1, "frames": 0}
+    d.close()
