@@ -211,6 +211,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   uint32_t* const s32 = sh.s32; uint64_t* const s64 = sh.s64;
   uint8_t (*const vlist)[64] = sh.vlist;
   uint64_t (*const fcache)[CF] = sh.fcache; uint64_t* const fc_ok = sh.fc_ok; uint8_t* const vinv = sh.vinv;
+  constexpr uint32_t FC = COPY ? kFloatCache : 0u;   // the float cache exists in table-copy tiles only (WAL tiles keep their LDS for the window)
   constexpr int MAXC = WIDE ? MAXC_WIDE : MAXC_NARROW;   // bits per image in the column masks
   constexpr int SW = WIDE ? 2 : 1;                       // state words per row image
   using mask_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
@@ -511,8 +512,8 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
                             // so that the waves pulling from it finish close to each other
       const mask_t below = (one << lane) - one;
       const uint32_t vc_of = lane < (uint32_t)MAXC ? lane : maxc + (lane - MAXC);
-      if ((scan >> lane) & 1u) { const uint32_t rk = pop(scan & below); vlist[0][rk] = (uint8_t)vc_of; vinv[vc_of] = (uint8_t)rk; }
-      else vinv[vc_of] = 0xFF;
+      if ((scan >> lane) & 1u) { const uint32_t rk = pop(scan & below); vlist[0][rk] = (uint8_t)vc_of; if constexpr (FC != 0) vinv[vc_of] = (uint8_t)rk; }
+      else if constexpr (FC != 0) vinv[vc_of] = 0xFF;
       const mask_t t1 = present & heapy & ~scan, t2 = present & scan, t3 = present & ~(heapy | scan);
       const uint32_t rank = ((t1 >> lane) & 1u) ? pop(t1 & below)
                           : ((t2 >> lane) & 1u) ? pop(t1) + pop(t2 & below)
@@ -604,19 +605,14 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       uint32_t pos, len, kind;
       const uint32_t ent = tab.get(vc * CF + lane, base, pos, len, kind);
       const uint32_t cls = ci >= 0 ? (uint32_t)cols[ci].cls : 0u;
-      bool sized = ci >= 0 && kind == CT_T && ((kScanClasses >> cls) & 1u);
-      if (dbg_u >> 17) {  // profiling ablation (results are wrong): leave one class unsized
-        const uint32_t fam = cls == ETLG_TC_NUMERIC ? 1u : cls == ETLG_TC_BYTEA ? 4u : 2u;
-        if ((dbg_u >> 17) & fam) sized = false;
-      }
-      if (sized) {
+      if (ci >= 0 && kind == CT_T && ((kScanClasses >> cls) & 1u)) {
         const u8* d = base + pos;
         uint32_t h = 0;
         bool done = false;
         while (!done) {  // one pass per distinct class among the active lanes, scalar dispatch inside
           const uint32_t u = __builtin_amdgcn_readfirstlane(cls);
           if (cls == u) {
-            if (u == ETLG_TC_F32 || u == ETLG_TC_F64) {  // parsed once: P3 takes the value from the cache
+            if (FC != 0 && (u == ETLG_TC_F32 || u == ETLG_TC_F64)) {  // parsed once: P3 takes the value from the cache
               const int r = parse_float_fast(d, len, u == ETLG_TC_F32, fbits, use_lds);
               h = r == 1 ? pad4(len) : 0u;
               fok = r == 0;
@@ -628,7 +624,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       }
     }
     ETLG_WAVE_JOIN();
-    if (vj < kFloatCache) {
+    if (FC != 0 && vj < FC) {
       const unsigned long long okm = __ballot(fok);
       if (fok) fcache[vj][lane] = fbits;
       if (lane == 0) fc_ok[vj] = okm;
@@ -832,9 +828,9 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
         if (bad_utf8) err = ETLG_E_UTF8;
       }
     }
-    if (textual && !coop && (cls == ETLG_TC_F32 || cls == ETLG_TC_F64)) {  // a float the sizing pass has parsed
+    if (FC != 0 && textual && !coop && (cls == ETLG_TC_F32 || cls == ETLG_TC_F64)) {  // a float the sizing pass has parsed
       const uint32_t rk = vinv[vc];
-      if (rk < kFloatCache && ((fc_ok[rk] >> lane) & 1ull)) { st64(slotp, fcache[rk][lane]); st = ETLG_CELL_VALUE; textual = false; }
+      if (rk < FC && ((fc_ok[rk] >> lane) & 1ull)) { st64(slotp, fcache[rk][lane]); st = ETLG_CELL_VALUE; textual = false; }
     }
     if (textual && !coop) {
       bool done = false;
@@ -943,10 +939,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[8];
   __shared__ uint8_t vlist[2][64];
-  __shared__ uint64_t fcache[kFloatCache][CF];
-  __shared__ uint64_t fc_ok[kFloatCache];
-  __shared__ uint8_t vinv[64];
-  __shared__ uint32_t cxm[CF];
+  __shared__ uint64_t fcache[COPYK ? kFloatCache : 1][COPYK ? CF : 1];   // (table-copy tiles only)
+  __shared__ uint64_t fc_ok[COPYK ? kFloatCache : 1];
+  __shared__ uint8_t vinv[COPYK ? 64 : 1];
+  __shared__ uint32_t cxm[COPYK ? CF : 1];
   const uint32_t tid = threadIdx.x;
   if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
@@ -1054,7 +1050,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
     cells_tile<NW, 2, WIDE>(p, pg, q, shc, stage, a0, tile, nt, copy_bad);
   }
   if constexpr (!COPYK) {
-    const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, nullptr, nullptr, nullptr, cxm, fcache, fc_ok, vinv};
+    const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
     if (use_lds) cells_tile<NW, 1, WIDE>(p, pg, q, sh, stage, a0, tile, nt);
     else cells_tile<NW, 0, WIDE>(p, pg, q, sh, pg.in, 0u, tile, nt);
@@ -1093,7 +1089,8 @@ uint32_t etlg_k_copy_cells_table_bytes(uint32_t maxc) { return 2u * maxc * CF * 
 // dynamic LDS of a table-copy tile whose window holds `window` bytes: cell table, window, three bitmaps of the window (k_cells<.., COPYK>)
 uint32_t etlg_k_copy_cells_lds(uint32_t maxc, uint32_t window) { return 2u * maxc * CF * 8u + ((window + 15u) & ~15u) / 8u * 11u + 192u; }
 uint32_t etlg_k_cells_lds_floor(uint32_t maxc) { return 3u * 2u * maxc * CF * 4u; }    // table + window together: what a tile read in place needs
-uint32_t etlg_k_cells_static_lds(uint32_t maxc) { return (maxc > (uint32_t)MAXC_NARROW ? 4224u : 3648u) + kFloatCache * (CF + 1) * 8u + 64u; }  // the kernel's __shared__ arrays (5 744 / 6 256 bytes in the gfx950 build of the narrow / wide instantiation) + slack
+uint32_t etlg_k_cells_static_lds(uint32_t maxc) { return maxc > (uint32_t)MAXC_NARROW ? 4224u : 3648u; }  // the kernel's __shared__ arrays (WAL tiles: 3 6xx / 4 1xx bytes in the gfx950 build of the narrow / wide instantiation) + slack
+uint32_t etlg_k_copy_cells_static_lds(uint32_t maxc) { return (maxc > (uint32_t)MAXC_NARROW ? 4224u : 3648u) + kFloatCache * (CF + 1) * 8u + 64u + 256u + 64u; }  // ... of a table-copy tile (+ float cache, column masks)
 uint32_t etlg_k_cells_maxc(void) { return MAXC_WIDE; }
 
 }  // extern "C"

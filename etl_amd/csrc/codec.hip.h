@@ -1060,6 +1060,11 @@ DEV bool parse_uuid(const u8* s, uint32_t n, uint32_t* out4, bool over = false) 
 #define ETLG_FLOAT_CALL DEV
 #endif
 ETLG_FLOAT_CALL int parse_float_fast(const u8* s, uint32_t n, bool is32, uint64_t& out, bool over) {
+  if (over && n <= 24) {  // up to 24 bytes: three loads, then register arithmetic without a per-character loop (float_fast.h, parse_float_swar)
+    const uint64_t x0 = ldu64(s), x1 = n > 8 ? ldu64(s + 8) : 0ull, x2 = n > 16 ? ldu64(s + 16) : 0ull;
+    const int r = parse_float_swar(x0, x1, x2, n, is32, out);
+    if (r != 3) return r;
+  }
   ByteWin bw{s, over};
   return parse_float_fast_t([&](uint32_t i) { return bw.at(i); }, n, is32, out);
 }

@@ -67,6 +67,7 @@ extern "C" void etlg_k_launch_copy_cells(const DecParams* p, const void* q, hipS
 extern "C" uint32_t etlg_k_cells_maxc(void);
 extern "C" uint32_t etlg_k_cells_lds_floor(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_static_lds(uint32_t maxc);
+extern "C" uint32_t etlg_k_copy_cells_static_lds(uint32_t maxc);
 
 constexpr int kFused = 7;  // profiling slot of the fused kernel
 constexpr int kCells = 8;  // ... of the column-parallel kernel (cells.hip)

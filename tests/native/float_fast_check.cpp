@@ -32,12 +32,25 @@ static bool grammar(const std::string& s, bool& special) {
   return i == s.size();
 }
 
-static unsigned long long cases = 0, values = 0, deferred = 0, bad = 0, mism = 0;
+static unsigned long long cases = 0, values = 0, deferred = 0, bad = 0, mism = 0, swar_taken = 0, swar_left = 0;
 
 static void check(const std::string& s) {
   for (int is32 = 0; is32 < 2; is32++) {
     uint64_t out = 0;
     const int r = etlg::parse_float_fast_t([&](uint32_t i) { return (uint32_t)(unsigned char)s[i]; }, (uint32_t)s.size(), is32 != 0, out);
+    {  // the register front end (parse_float_swar) must agree with the loop on every text it takes: same return code, same bits;
+       // the bytes behind the text are garbage, as they are on the device
+      unsigned char raw[24];
+      for (int k = 0; k < 24; k++) raw[k] = k < (int)s.size() ? (unsigned char)s[k] : (unsigned char)(rand() & 0xFF);
+      uint64_t x[3]; memcpy(x, raw, 24);
+      uint64_t out2 = 0;
+      const int r2 = etlg::parse_float_swar(x[0], x[1], x[2], (uint32_t)s.size(), is32 != 0, out2);
+      if (r2 == 3) swar_left++;
+      else {
+        swar_taken++;
+        if (r2 != r || (r == 0 && out2 != out)) { if (mism++ < 10) printf("register front end differs for '%s' (%s): %d %llx vs %d %llx\n", s.c_str(), is32 ? "f32" : "f64", r2, (unsigned long long)out2, r, (unsigned long long)out); }
+      }
+    }
     bool special;
     const bool ok = grammar(s, special);
     cases++;
@@ -107,6 +120,24 @@ int main() {
     snprintf(buf, sizeof buf, "%.17g", mid); check(buf);
     snprintf(buf, sizeof buf, "%.9g", a); check(buf);
   }
-  printf("cases %llu values %llu deferred %llu malformed %llu mismatches %llu\n", cases, values, deferred, bad, mism);
-  return mism != 0 || values < cases / 4;
+  // texts as PostgreSQL prints float8 / float4 (shortest round-trip digits, exponents as e+NN / e-NN) and a dense sweep of short ones
+  for (long it = 0; it < 1500000; it++) {
+    char buf[64];
+    uint64_t bits = ((uint64_t)rand() << 42) ^ ((uint64_t)rand() << 21) ^ (uint64_t)rand();
+    double d; memcpy(&d, &bits, 8);
+    if (d != d) continue;
+    if (it % 3 == 0) snprintf(buf, sizeof buf, "%.17g", d);
+    else if (it % 3 == 1) snprintf(buf, sizeof buf, "%.9g", (double)(float)d);
+    else snprintf(buf, sizeof buf, "%.*g", 1 + rand() % 17, d / (1 + rand() % 1000));
+    check(buf);
+  }
+  const char* alpha = "0123456789.eE+-0000";
+  for (long it = 0; it < 1500000; it++) {
+    std::string s;
+    const int len = 1 + rand() % 10;
+    for (int i = 0; i < len; i++) s += alpha[rand() % 19];
+    check(s);
+  }
+  printf("cases %llu values %llu deferred %llu malformed %llu mismatches %llu (register front end: took %llu, left %llu to the loop)\n", cases, values, deferred, bad, mism, swar_taken, swar_left);
+  return mism != 0 || values < cases / 4 || swar_taken < cases / 2;
 }

@@ -283,3 +283,36 @@ def test_copy_long_rows_take_the_row_walk():
     assert_same(rb, gb)
     assert d.debug_copy() == {"direct": 1, "frames": 0}
     d.close()
+
+
+def test_copy_utf8_in_the_direct_kernel():
+    """Row validity as UTF-8 (table_row.rs:51) is checked on the tile's bytes sixteen at a time while the bitmaps are built: multi-byte
+    characters across every chunk and tile boundary pass; one broken byte anywhere — the first / last row of a tile, the first /
+    last byte of a row, inside a sequence that straddles a 16-byte chunk — fails the batch at that row, as the oracle has it."""
+    rng = random.Random(3)
+    cols = [("a", K.TEXT, True, 0), ("b", K.TEXT, True, 0)]
+    chars = ["a", "é", "中", "😀", "z", "ß", "ࠀ", "\U00010000"]
+    rows = [("".join(rng.choice(chars) for _ in range(rng.randrange(0, 30))) + "\t" +
+             "".join(rng.choice(chars) for _ in range(rng.randrange(0, 12))) + "\n").encode() for _ in range(150)]
+    o, d, rb, gb = both(cols, rows)
+    assert rb.err_code == 0
+    assert_same(rb, gb)
+    assert d.debug_copy() == {"direct": 1, "frames": 0}
+    d.close()
+    for r in (0, 1, 63, 64, 65, 127, 128, 149):
+        row = rows[r]
+        multi = [i for i, c in enumerate(row) if c >= 0x80]
+        if not multi:
+            continue
+        for pos, repl in ((multi[0], b"A"), (multi[-1], b"\xff"), (multi[len(multi) // 2], b"\xc0"), (multi[0], b"")):
+            broken = row[:pos] + repl + row[pos + 1:]
+            try:
+                broken.decode()
+                continue   # (dropping that byte happened to leave valid text)
+            except UnicodeDecodeError:
+                pass
+            rs = rows[:r] + [broken] + rows[r + 1:]
+            o, d, rb, gb = both(cols, rs)
+            assert rb.err_frame == r and rb.err_code != 0
+            assert_same(rb, gb)
+            d.close()

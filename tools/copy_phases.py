@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from etl_amd import synth
 from etl_amd.decoder import Decoder
 
-names = {0: "P0 stage+side+offsets", 1: "window vote", 11: "P1 classify / copy split", 9: "P1 walk", 10: "P1 txn scan(+seq lookback)", 2: "P1 ownership/slot + barrier",
+names = {0: "P0 stage+side+offsets", 1: "window vote", 11: "P1 classify / copy split", 9: "P1 walk", 10: "P1 txn scan(+seq lookback)", 2: "P1 ownership/slot + barrier (+ copy_fix)",
          3: "P2 heap sizing", 4: "P2b shapes/prefix/scan", 5: "look-back", 6: "ctx/prefix distribution", 7: "P3 decode+write", 8: "P4 headers/states"}
 for clean in (True, False):
     rows = synth.copy_rows(20000, 1, clean=clean) * 20
