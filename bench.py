@@ -327,7 +327,9 @@ def leg_cfg5(dev_id, dev, cap, npool, passes):
 
 
 def leg_copy(dev_id, dev, nrows, reps):
-    """SURVEY §8(f)#1: table-copy rows (COPY text format) -> the Insert arena."""
+    """table-copy rows (COPY text format) -> the Insert arena (rows -> arena in one kernel, k_copy_cells; `paths` says how
+    many of the timed batches took it and how many fell back to the row -> frame rewrite). `value` is quoted on escape-heavy rows, the
+    same table with text that needs no escapes is reported beside it (`ordinary_text`)."""
     import numpy as np
     import torch
 
@@ -372,13 +374,13 @@ def _leg_copy_rows(dev_id, dev, base, nrows, reps, what, clean=None):
     torch.cuda.synchronize()
     kern = kernel_table(d.profile_read())
     d.profile(False)
+    paths = d.debug_copy()
     d.close()
-    # algorithmic bytes: the rows + their offsets read once, the arena written once. The synthetic Insert frames the splitter writes and
-    # the decode kernel reads back (2 x (rows + 88 bytes per row)) are implementation traffic, not counted
+    # algorithmic bytes: the rows + their offsets read once, the arena written once
     alg = len(buf) + 4 * len(rows) + ob / reps
     out = {"value": round(reps * len(buf) / dt / 1e9, 3), "unit": "GB/s", "rows_per_s": round(reps * len(rows) / dt, 1),
            "workload": f"{len(rows)} COPY text rows of a 10-column mixed table ({len(buf)} bytes), {what}, device-resident, synchronous",
-           "roofline": roofline_of(kern, alg)}
+           "paths": paths, "roofline": roofline_of(kern, alg)}
     if clean is not None:
         out["ordinary_text"] = clean   # the same table with text that needs no escapes: what COPY output mostly looks like
     return out

@@ -23,6 +23,10 @@
 // occupancy is NW waves per tile instead of one. A tile whose bytes do not fit the LDS window
 // reads the input in place. Schemas wider than MAXC columns and every error fall back to the
 // multi-pass kernels (kernels.hip).
+//
+// Table-copy rows (etlg_copy_decode) run through the same tile: k_cells<.., COPYK> stages 64 COPY text
+// rows instead of 64 frames and cells_tile<.., 2, ..> replaces P1's tuple walk by the COPY field splitter
+// (window bitmaps -> row walk in registers -> the fields with backslashes finished by all waves).
 #define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
 #define ETLG_DBG_WORD dbg_u   // cells_tile / k_cells keep the debug word in a scalar register of its own
 #define ETLG_TSTAMP_WHO (wave == 0 && lane == 0)   // phase clocks are taken by the tile's spine wave (its role rotates, see cells_tile)

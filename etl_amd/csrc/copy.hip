@@ -1,6 +1,11 @@
 // Table-copy rows for gfx950 (include/etlg.h, etlg_copy_decode): COPY ... TO STDOUT text rows ->
 // the same arena the Insert path produces, through the same value codec.
 //
+// Since round 3 a batch of rows first goes through k_copy_cells (cells.hip: rows -> arena in one kernel).
+// This file is the path behind it — batches with a malformed row (the reference's error order is
+// decided here), rows that do not fit a tile's LDS window, tables wider than k_cells takes,
+// ETLG_COPY_DIRECT=0 — and the reference point the one-kernel path is tested against.
+//
 // parse_table_row_from_postgres_copy_bytes (crates/etl/src/postgres/codec/table_row.rs:47-254) is
 // a field splitter + unescaper in front of parse_cell_from_postgres_text. This kernel is that
 // front end: one lane per row (256 rows per workgroup, the rows staged into LDS with coalesced

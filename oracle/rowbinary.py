@@ -6,7 +6,9 @@ Follows crates/etl-destinations/src/clickhouse/encoding.rs:
   rb_varint :188-199 | rb_encode_nullable :202-211 | rb_encode_value :214-255 | encode_to_row_binary :259-283
 and crates/etl-destinations/src/clickhouse/core.rs:
   which events become rows :1078-1127 | append_cdc_columns :96-114 (MergeTree: cdc_operation String + cdc_lsn UInt64;
-  ReplacingMergeTree: _etl_version UInt128 = commit_lsn << 64 | tx_ordinal, _etl_deleted UInt8).
+  ReplacingMergeTree: _etl_version UInt128 = commit_lsn << 64 | tx_ordinal, _etl_deleted UInt8) |
+  expand_key_row :1437-1472 + default_cell :1481-1517 (the tombstone row of a Delete that carries only the key; default_cell pinned
+  by the reference's default_cell_string_mapped_values_are_strings :1930-1937 in tests/test_oracle_rowbinary.py).
 Pinned by tests/test_oracle_rowbinary.py to the byte vectors of the reference's own tests (encoding.rs:386-470).
 
 `Time`, `TimeTz` and `Numeric` cells are strings in the reference (`to_string()`, encoding.rs:66-71): their Display impls are
@@ -87,6 +89,8 @@ def value(cell):
         return string(cell[1])
     if k == "Deferred" and cell[1] in ARRAY_OIDS:   # array columns keep their literal in the arena
         return array(cell[1], cell[2])
+    if k == "EmptyArray":                            # default_cell of an array column: varint count 0 (encoding.rs:249-254)
+        return varint(0)
     raise NeedsHost(k)
 
 
@@ -162,8 +166,94 @@ def cdc_columns(op, commit_lsn, tx_ordinal, engine):
     return struct.pack("<QQ", tx_ordinal, commit_lsn) + bytes([1 if op == "D" else 0])   # u128 LE: low half first
 
 
-def encode_events(events, slot_index, types_by_col, nullable_flags, engine, identity_type="PrimaryKey"):
-    """Rows of the events the device emitter takes (Insert; non-partial Update -> new row; Delete with a full old row).
+# type OIDs default_cell names (clickhouse/core.rs:1481-1517)
+_OID = {"BOOL": 16, "INT2": 21, "INT4": 23, "INT8": 20, "OID": 26, "FLOAT4": 700, "FLOAT8": 701, "DATE": 1082, "TIMESTAMP": 1114,
+        "TIMESTAMPTZ": 1184, "UUID": 2950}
+_EPOCH = CE_DAYS_1970
+
+
+TC_STRING, TC_ARRAY = 0, 17                      # etlg_type_class values (include/etlg.h)
+TEXT_OIDS = {25, 1043, 1042, 19, 18}             # text varchar bpchar name "char": the scalar types whose cells are Strings
+# array types the value codec has no arm for (their cells decode as Strings) but is_array_type still calls arrays; the names the
+# reference's own tests use (type_utils.rs:26-60, clickhouse/core.rs:1930-1937): _char _name _bpchar _money _interval ...
+EXTRA_ARRAY_OIDS = {1002, 1003, 1014, 791, 1187, 1561, 1563, 1040, 1041, 651, 775}
+
+
+def class_of(oid):
+    from oracle import oracle
+    return oracle.lib().oracle_class_of_oid(oid)
+
+
+def is_array_oid(oid):
+    """is_array_type (crates/etl-postgres/src/type_utils.rs:14-18): array kind and an underscore-prefixed name."""
+    return class_of(oid) == TC_ARRAY or oid in EXTRA_ARRAY_OIDS
+
+
+def key_rows_on_device(schema_cols):
+    """The device's contract for key-only Deletes (include/etlg.h, etlg_batch_rowbinary): it builds the tombstone unless a nullable
+    non-key column has a type outside the value codec's table (a String cell that may or may not be an array type to
+    is_array_type: NULL or an empty array) — those slots' key-only Deletes stay with the host."""
+    for _name, oid, nullable, pk in schema_cols:
+        if not pk and nullable and class_of(oid) == TC_STRING and oid not in TEXT_OIDS:
+            return False
+    return True
+
+
+def default_cell(oid):
+    """default_cell (clickhouse/core.rs:1481-1517): the zero value of a non-key column in a key-only DELETE tombstone. Array types ->
+    an empty array; date / timestamp / uuid -> typed zeros; every other non-primitive type -> an empty String."""
+    if oid == _OID["BOOL"]:
+        return ("Bool", False)
+    if oid == _OID["INT2"]:
+        return ("I16", 0)
+    if oid == _OID["INT4"]:
+        return ("I32", 0)
+    if oid == _OID["INT8"]:
+        return ("I64", 0)
+    if oid == _OID["OID"]:
+        return ("U32", 0)
+    if oid == _OID["FLOAT4"]:
+        return ("F32", 0)
+    if oid == _OID["FLOAT8"]:
+        return ("F64", 0)
+    if oid == _OID["DATE"]:
+        return ("Date", _EPOCH)
+    if oid in (_OID["TIMESTAMP"], _OID["TIMESTAMPTZ"]):
+        return ("Timestamp", _EPOCH, 0, 0)
+    if oid == _OID["UUID"]:
+        return ("Uuid", bytes(16))
+    if is_array_oid(oid):
+        return ("EmptyArray",)
+    return ("String", b"")
+
+
+def expand_key_row(key_cells, schema_cols, identity_type):
+    """expand_key_row (clickhouse/core.rs:1437-1472). schema_cols: (name, type oid, nullable, primary key) of the slot's replicated
+    columns. Returns the full-width cells, or raises HostRow when the reference raises (the host reports it)."""
+    n_pk = sum(1 for c in schema_cols if c[3])
+    if len(key_cells) != n_pk:
+        raise HostRow("ClickHouse key image does not match the source primary key")
+    if identity_type not in ("PrimaryKey", "Full"):
+        raise HostRow("ClickHouse requires primary-key or full replica identity")
+    it = iter(key_cells)
+    out = []
+    for _name, oid, nullable, pk in schema_cols:
+        if pk:
+            out.append(next(it, ("Null",)))
+        elif nullable and not is_array_oid(oid):
+            out.append(("Null",))
+        else:
+            out.append(default_cell(oid))
+    return out
+
+
+class HostRow(Exception):
+    """The reference raises for this row (a replica-identity error): the device leaves it to the host."""
+
+
+def encode_events(events, slot_index, types_by_col, nullable_flags, engine, identity_type="PrimaryKey", schema_cols=None):
+    """Rows of the events the device emitter takes (Insert; non-partial Update -> new row; Delete with a full old row; with
+    `schema_cols` also a Delete that carries only the key, as the tombstone expand_key_row builds).
     `types_by_col`: type classes (only their count is used here: text-form classes raise NeedsHost from value()).
     `identity_type`: ReplicatedTableSchema::identity_type of the slot; under ReplacingMergeTree the reference refuses Update
     events unless it is PrimaryKey or Full (clickhouse_update_row, clickhouse/core.rs:1359-1382) — the emitter leaves those
@@ -178,7 +268,7 @@ def encode_events(events, slot_index, types_by_col, nullable_flags, engine, iden
         if e["kind"] not in "IUD" or e.get("schema_slot") != slot_index:
             continue
         if e["kind"] == "U" and (e["partial"] or not updates_ok) or e["kind"] == "D" and e["old_kind"] != "Full":
-            continue
+            continue   # (a key row holds identity columns only; its dates are range-checked below with the row)
         for c in (e["old_row"] if e["kind"] == "D" else e["row"]):
             try:
                 if c[0] == "Date":
@@ -200,10 +290,17 @@ def encode_events(events, slot_index, types_by_col, nullable_flags, engine, iden
                 continue
             cells = e["row"]
         else:
-            if e["old_kind"] != "Full":
+            if e["old_kind"] == "Key" and schema_cols is not None and key_rows_on_device(schema_cols):
+                try:
+                    cells = expand_key_row(e["old_row"], schema_cols, identity_type)
+                except HostRow:
+                    host += 1
+                    continue
+            elif e["old_kind"] != "Full":
                 host += 1
                 continue
-            cells = e["old_row"]
+            else:
+                cells = e["old_row"]
         assert len(cells) == n_user
         body = row(cells, nullable_flags[:n_user])
         tail = cdc_columns(e["kind"], e["commit_lsn"], e["tx_ordinal"], engine)

@@ -228,7 +228,7 @@ def test_copy_generated_rows_lane_per_byte(splitter):
 
 @pytest.mark.parametrize("seed", [11, 12, 13, 14])
 def test_copy_field_tasks_fuzz(seed):
-    """The rows -> arena kernel's per-field tasks (cells.hip): four text columns of pieces chosen to confuse a splitter that works from
+    """The rows -> arena kernel's splitter (cells.hip): four text columns of pieces chosen to confuse a splitter that works from
     bitmaps — escaped tabs and newlines as raw bytes behind backslash runs of every parity, `\\N` as a whole field / as a prefix / behind
     an escaped backslash, fields that end in an escaped backslash right before the separator, empty fields, multi-byte characters
     behind a backslash, rows from 5 bytes to a few hundred so that rows and fields start at every bit of the bitmap words."""
@@ -262,9 +262,9 @@ def test_copy_field_tasks_fuzz(seed):
     d.close()
 
 
-def test_copy_long_rows_take_the_row_walk():
-    """Rows longer than the per-field tasks take (4 KB) are split by the lane-per-row walk inside the same kernel; short rows of the
-    same tile by the tasks."""
+def test_copy_rows_of_several_kb():
+    """Rows of several KB beside short ones in one tile: the row walk takes the bitmap words eight at a time (256 bytes per batch of
+    loads), so long rows take several batches while their neighbours are done after one."""
     rng = random.Random(5)
     cols = [("a", K.TEXT, True, 0), ("b", K.TEXT, True, 0), ("c", K.INT4, True, 0)]
     pieces = ["abc", "\\\\", "\\t", "\\\t", "é", "\\é", "x" * 40, "\\N", " "]
