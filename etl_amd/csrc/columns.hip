@@ -25,6 +25,7 @@ DEV bool col_selected(const ColSel& s, uint64_t i, uint64_t& base) {
     return true;
   }
   if (k == 'D' && (s.kinds & 4u) && (fl & 3u) == ETLG_OLD_FULL) return true;
+  if (k == 'D' && (s.kinds & 8u) && (fl & 3u) == ETLG_OLD_KEY) return true;   // the key row: RowBinary expands it into the tombstone (rb_row)
   return false;
 }
 
@@ -671,10 +672,35 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
   // row that meets a cell without an encoding goes on looking for a date out of range; k_rb_lens ranks range errors first across rows.
   const uint64_t base = j.row_base[r];
   uint32_t err0 = 0;
+  // A Delete that carries only the key becomes the tombstone expand_key_row builds (clickhouse/core.rs:1437-1472): the key cells in
+  // the primary-key columns, NULL in every other column that is nullable at the source and not an array, default_cell's zero value
+  // (:1481-1517) in the rest. The host selects such rows only where the reference accepts them (host_handoff.inc).
+  const bool keyrow = j.kcols && j.ev_kind[j.row_event[r]] == 'D' && (j.ev_flags[j.row_event[r]] & 3u) == ETLG_OLD_KEY;
   for (uint32_t i = 0; i < j.n_cols; i++) {
-    const uint32_t cd = j.cols[i], cls = cd & 0xFF, off = cd >> 16;
+    const uint32_t cd = j.cols[i], cls = cd & 0xFF;
+    uint32_t off = cd >> 16, sti = i;
     const bool nullable = (cd >> 8) & 1;
-    const uint32_t st = (j.fixed[base + i / 4] >> (2 * (i % 4))) & 3u;
+    if (keyrow) {
+      const uint32_t kc = j.kcols[i];
+      if (kc & 1u) { off = kc >> 16; sti = (kc >> 8) & 0xFFu; }   // an identity column: its cell sits in the key layout
+      else if ((kc & 2u) && cls != ETLG_TC_ARRAY) {                // Cell::Null
+        if (!nullable) { if (!err0) err0 = (i << 8) | RB_E_NULL; continue; }
+        s.put(1);
+        continue;
+      } else {                                                    // default_cell(typ)
+        if (nullable) s.put(0);
+        switch (cls) {
+          case ETLG_TC_BOOL: s.put(0); break;
+          case ETLG_TC_I16: s.put(0); s.put(0); break;
+          case ETLG_TC_I32: case ETLG_TC_U32: case ETLG_TC_F32: case ETLG_TC_DATE: s.put32(0); break;   // Date32: 1970-01-01 is day 0
+          case ETLG_TC_I64: case ETLG_TC_F64: case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: s.put64(0); break;   // DateTime64: the epoch
+          case ETLG_TC_UUID: s.put64(0); s.put64(0); break;   // Uuid::nil()
+          default: s.put(0); break;   // an empty Array (varint count 0) / an empty String (numeric, time, timetz, interval, bytea, text ...)
+        }
+        continue;
+      }
+    }
+    const uint32_t st = (j.fixed[base + sti / 4] >> (2 * (sti % 4))) & 3u;
     if (st == ETLG_CELL_NULL) {
       if (!nullable) { if (!err0) err0 = (i << 8) | RB_E_NULL; continue; }   // "NULL value for non-nullable ClickHouse column" (:217-225)
       s.put(1);

@@ -194,7 +194,7 @@ struct PlanParams {
 struct ColSel {            // which events are rows of the hand-off
   const uint8_t* ev_kind; const uint8_t* ev_flags; const uint32_t* ev_slot; const uint64_t* ev_body;
   uint64_t n_events;
-  uint32_t slot, kinds;    // kinds: bit 0 inserts, bit 1 new rows of non-partial updates, bit 2 full old rows of deletes
+  uint32_t slot, kinds;    // kinds: bit 0 inserts, bit 1 new rows of non-partial updates, bit 2 full old rows of deletes, bit 3 key rows of deletes
   unsigned long long* host_rows;  // optional: I/U/D events of the slot the selection leaves out (partial updates, key-only deletes)
   uint32_t row_full, row_key;
   uint32_t* blk;           // per-block counts -> exclusive prefix; blk[nblocks] = total
@@ -234,6 +234,8 @@ struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
   uint32_t cdc_nullable;           // bit 0 / 1: the first / second trailing CDC column is Nullable() in the destination
   uint32_t format;                 // 0 ClickHouse RowBinary, 1 BigQuery protobuf (Insert rows, prost wire format)
   const uint32_t* cols;            // per replicated column: cls | nullable << 8 | off_full << 16
+  const uint32_t* kcols;           // per replicated column, for key-only Deletes: identity | source nullable << 1 | key_index << 8 | off_key << 16
+  const uint8_t* ev_flags;
   uint32_t* lens; const int64_t* offsets; uint8_t* out;
   unsigned long long* err;         // min over failing cells of (row << 24 | column << 8 | code); ~0 = none
 };

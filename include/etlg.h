@@ -603,8 +603,12 @@ void etlg_columns_free(etlg_columns* cols);
 /* ClickHouse RowBinary rows for ONE schema slot of a decoded batch, encoded on the device: what
  * cell_to_clickhouse_value + encode_to_row_binary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83,
  * :188-283) and append_cdc_columns (clickhouse/core.rs:96-114) produce for the rows core.rs:1078-1127 collects:
- * Insert -> the row; Update -> the new row; Delete -> the old row. Rows the reference builds with extra host
- * logic (a Partial update, a Delete that carries only the key) are left out and counted in n_host_rows.
+ * Insert -> the row; Update -> the new row; Delete -> the old row, and for a Delete that carries only the key the tombstone row
+ * expand_key_row builds (core.rs:1437-1472: the key cells in the primary-key columns, NULL in every other column that is nullable
+ * at the source and not an array, default_cell's zero value (:1481-1517) in the rest) when the slot's replica identity is the primary
+ * key or Full (ensure_clickhouse_key_identity_is_primary_key, :1404-1427) and no nullable non-key column has a type outside the value
+ * codec's table (is_array_type decides NULL or empty array there; only the host knows every array type). Events the reference
+ * refuses or the device does not build (a Partial update, key-only Deletes of other slots) are left out and counted in n_host_rows.
  * Columns of class numeric / timetz / time are Display strings in the reference (`n.to_string()`, encoding.rs:66-71): they are
  * formatted on the device (PgNumeric Display, crates/etl-postgres/src/numeric.rs:460-560; PgTimeTz, etl-postgres/src/time.rs:113-117,
  * 210-225). A slot with a json column (serde_json's normalised Display) or an array of numeric / timetz / json / text elements, or

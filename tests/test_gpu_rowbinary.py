@@ -34,10 +34,11 @@ def _stream(msgs):
     return np.frombuffer(s.bytes(), dtype=np.uint8), s.offsets
 
 
-def _check(hb, b, flags, engine, identity_type="PrimaryKey"):
+def _check(hb, b, flags, engine, identity_type="PrimaryKey", schema_cols=None):
+    """schema_cols: the table's (name, oid, nullable, pk) columns — with them the oracle builds the tombstone rows of key-only Deletes."""
     from oracle import rowbinary as RB
     slot = hb.slots[0]
-    rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in slot.cols], list(flags), engine, identity_type)
+    rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in slot.cols], list(flags), engine, identity_type, schema_cols)
     r = b.rowbinary(0, flags, engine)
     assert r.status == abi.RB_OK
     assert r.n_rows == len(rows) and int(r.view.n_host_rows) == host
@@ -129,13 +130,13 @@ def test_synthetic_stream(mk, nbytes, engine):
     buf, offs = w.fill(nbytes)
     hb, b, d = _both(w.register, buf, offs)
     flags = [1 if c.nullable else 0 for c in hb.slots[0].cols]   # Nullable() where the source column is
-    assert _check(hb, b, flags + [0, 0], engine) > 100
+    assert _check(hb, b, flags + [0, 0], engine, schema_cols=w.schema_cols(w.tables[0])) > 100   # (cfg3 carries key-only deletes: tombstone rows)
     b.close(); d.close()
 
 
 def test_updates_deletes_and_host_rows():
-    """cfg3-like traffic on a table the device encodes: updates (new row), deletes with a full old row; key-only deletes and
-    partial updates are counted, not encoded."""
+    """cfg3-like traffic on a table the device encodes: updates (new row), deletes with a full old row, key-only deletes as
+    tombstone rows (expand_key_row); partial updates are counted, not encoded."""
     cols = [("id", SC.INT8, False, 1), ("v", SC.INT4, True, 0), ("s", 25, True, 0)]
     msgs = []
     for i in range(300):
@@ -146,13 +147,64 @@ def test_updates_deletes_and_host_rows():
         if i % 5 == 0:
             msgs.append(W.update(42, [str(i), "1", W.TOAST]))                   # partial: host
         if i % 7 == 0:
-            msgs.append(W.delete(42, key=[str(i), W.NULL, W.NULL]))              # key only: host
+            msgs.append(W.delete(42, key=[str(i), W.NULL, W.NULL]))              # key only: the tombstone row
         if i % 11 == 0:
             msgs.append(W.delete(42, old=r))                                     # full old row
     buf, offs = _stream(msgs)
     hb, b, d = _both(SC.simple_table(cols), buf, offs)
     for engine in (abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE):
-        _check(hb, b, [0, 1, 1, 0, 0], engine)
+        n = _check(hb, b, [0, 1, 1, 0, 0], engine, schema_cols=cols)
+        assert n == 300 + 100 + 43 + 28 and b.rowbinary(0, [0, 1, 1, 0, 0], engine).view.n_host_rows == 60
+    b.close(); d.close()
+
+
+def test_key_only_deletes_become_tombstone_rows():
+    """expand_key_row + default_cell (clickhouse/core.rs:1437-1517) on every class: a two-column primary key in the middle of the
+    table, nullable and non-nullable columns of every class beside it (NULL where the source column is nullable and not an array,
+    the zero value otherwise: typed zeros for date / timestamp / uuid, empty arrays, empty Strings for numeric / time / timetz / bytea /
+    text), both engines, Nullable() and plain destination columns. Then the slots whose key-only Deletes stay with the host: another
+    replica identity, and a nullable column of a type the value codec has no arm for."""
+    from etl_amd.schema import infer_identity_type
+    base = [c for c in SC.ALLTYPES if c[0] not in ("j", "arr")]
+    cols = []
+    for k, c in enumerate(base):                       # every class twice: NOT NULL and nullable
+        cols.append((c[0] + "_nn", c[1], False, 0))
+        cols.append((c[0] + "_n", c[1], True, 0))
+    cols.insert(5, ("k1", SC.INT8, False, 1))
+    cols.insert(9, ("k2", 25, False, 1))
+    cols.append(("ia_nn", 1007, False, 0))             # int4[]: arrays are never NULL in the tombstone
+    cols.append(("ia_n", 1007, True, 0))
+    ident = [1 if c[3] else 0 for c in cols]
+    assert infer_identity_type(cols, [1] * len(cols), ident) == "PrimaryKey"
+    msgs = [W.delete(42, key=[("%d" % i) if c[3] and c[1] == SC.INT8 else ("key-%d" % i) if c[3] else W.NULL for c in cols]) for i in range(70)]
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(cols, ident=ident), buf, offs)
+    for engine in (abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE):
+        for dest_nullable in (0, 1):
+            flags = [dest_nullable if c[2] else 0 for c in cols] + [0, dest_nullable]
+            if not dest_nullable:
+                # the tombstone's NULLs meet non-nullable destination columns: the reference's encoder error, on the first row
+                from etl_amd.decoder import EtlError
+                with pytest.raises(EtlError) as ei:
+                    b.rowbinary(0, flags, engine)
+                assert ei.value.description == "NULL value for non-nullable ClickHouse column" and ei.value.frame_index == 1
+                continue
+            assert _check(hb, b, flags, engine, schema_cols=cols) == 70
+    b.close(); d.close()
+    # the same deletes under REPLICA IDENTITY USING INDEX on a non-PK column: expand_key_row refuses them (ensure_clickhouse_key_identity_
+    # is_primary_key) -> host rows; and with a nullable `money` column (a String cell; is_array_type is the host's to answer): host rows
+    cols2 = [("id", SC.INT8, False, 1), ("k", SC.INT4, False, 0), ("s", 25, True, 0)]
+    msgs2 = [W.insert(42, ["1", "2", "x"]), W.delete(42, key=[W.NULL, "2", W.NULL])]
+    buf, offs = _stream(msgs2)
+    hb, b, d = _both(SC.simple_table(cols2, ident=[0, 1, 0]), buf, offs)
+    assert _check(hb, b, [0, 0, 1, 0, 0], abi.CH_MERGE_TREE, "AlternativeKey", schema_cols=cols2) == 1
+    assert b.rowbinary(0, [0, 0, 1, 0, 0], abi.CH_MERGE_TREE).view.n_host_rows == 1
+    b.close(); d.close()
+    cols3 = [("id", SC.INT8, False, 1), ("m", 790, True, 0)]
+    buf, offs = _stream([W.insert(42, ["1", "$2.00"]), W.delete(42, key=["1", W.NULL])])
+    hb, b, d = _both(SC.simple_table(cols3), buf, offs)
+    assert _check(hb, b, [0, 1, 0, 0], abi.CH_MERGE_TREE, schema_cols=cols3) == 1
+    assert b.rowbinary(0, [0, 1, 0, 0], abi.CH_MERGE_TREE).view.n_host_rows == 1
     b.close(); d.close()
 
 

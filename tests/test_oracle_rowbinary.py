@@ -59,3 +59,27 @@ def test_time_display():
     assert RB.time_string(45045, 120_000_000) == "12:30:45.120"
     assert RB.time_string(45045, 123_456_000) == "12:30:45.123456"
     assert RB.time_string(0, 1) == "00:00:00.000000001"
+
+
+def test_reference_default_cell_and_key_row_expansion():
+    """default_cell_string_mapped_values_are_strings (clickhouse/core.rs:1930-1937): money / timetz / interval default to an empty
+    String, their array types to an empty array; expand_key_row_rejects_short_key_payload_before_identity_checks (:1719-1726): a key
+    image of the wrong width is refused before the identity check. Then the tombstone row itself (:1437-1472): key cells in the
+    primary-key columns, NULL where the source column is nullable and not an array, the zero value otherwise."""
+    import pytest
+    MONEY, TIMETZ, INTERVAL, MONEY_A, TIMETZ_A, INTERVAL_A = 790, 1266, 1186, 791, 1270, 1187
+    for oid in (MONEY, TIMETZ, INTERVAL):
+        assert RB.default_cell(oid) == ("String", b"")
+    for oid in (MONEY_A, TIMETZ_A, INTERVAL_A):
+        assert RB.default_cell(oid) == ("EmptyArray",)
+    with pytest.raises(RB.HostRow, match="does not match the source primary key"):
+        RB.expand_key_row([], [("id", 23, False, 1), ("name", 25, True, 0)], "AlternativeKey")
+    with pytest.raises(RB.HostRow, match="primary-key or full replica identity"):
+        RB.expand_key_row([("I32", 1)], [("id", 23, False, 1), ("name", 25, True, 0)], "AlternativeKey")
+    cols = [("a", 25, True, 0), ("id", 23, False, 1), ("b", 25, False, 0), ("c", 1007, True, 0), ("d", 1184, False, 0),
+            ("e", 2950, False, 0), ("f", 1082, False, 0), ("g", 16, False, 0), ("h", 1700, False, 0)]
+    row = RB.expand_key_row([("I32", 7)], cols, "PrimaryKey")
+    assert row == [("Null",), ("I32", 7), ("String", b""), ("EmptyArray",), ("Timestamp", RB.CE_DAYS_1970, 0, 0), ("Uuid", bytes(16)),
+                   ("Date", RB.CE_DAYS_1970), ("Bool", False), ("String", b"")]
+    # as bytes: Nullable(String) NULL, Int32 7, String "", Array() , DateTime64 0, UUID nil, Date32 0, Bool false, String ""
+    assert RB.row(row, [1, 0, 0, 0, 0, 0, 0, 0, 0]) == b"\x01" + b"\x07\0\0\0" + b"\0" + b"\0" + bytes(8) + bytes(16) + bytes(4) + b"\0" + b"\0"
