@@ -29,11 +29,66 @@ DEV bool col_selected(const ColSel& s, uint64_t i, uint64_t& base) {
   return false;
 }
 
+// ---- BigQuery: which rows an event becomes (bigquery/core.rs:978-1036, 1425-1476, 1557-1645)
+// Did the update change the primary key (bigquery_primary_key_changed)? 0 no, 1 yes, 2 a cell the device does not compare.
+DEV uint32_t pb_pk_changed(const ColSel& s, uint64_t oldb, uint64_t newb, bool key) {
+  for (uint32_t i = 0; i < s.n_cols; i++) {
+    const uint32_t kc = s.kcols[i];
+    if (!(kc & 4u)) continue;
+    const uint32_t cd = s.cols[i], cls = cd & 0xFFu;
+    const uint32_t oi = key ? (kc >> 8) & 0xFFu : i, ooff = key ? kc >> 16 : cd >> 16;
+    const uint32_t so = (s.fixed[oldb + oi / 4] >> (2 * (oi % 4))) & 3u, sn = (s.fixed[newb + i / 4] >> (2 * (i % 4))) & 3u;
+    if ((so != ETLG_CELL_NULL && so != ETLG_CELL_VALUE) || (sn != ETLG_CELL_NULL && sn != ETLG_CELL_VALUE)) return 2;
+    if (so != sn) return 1;
+    if (so == ETLG_CELL_NULL) continue;
+    const u8* a = s.fixed + oldb + ooff; const u8* b = s.fixed + newb + (cd >> 16);
+    if (cls == ETLG_TC_STRING || cls == ETLG_TC_BYTEA) {
+      const uint32_t la = *(const uint32_t*)(a + 4), lb = *(const uint32_t*)(b + 4);
+      if (la != lb) return 1;
+      const u8* ha = s.heap + *(const uint32_t*)a; const u8* hb = s.heap + *(const uint32_t*)b;
+      for (uint32_t k = 0; k < la; k++) if (ha[k] != hb[k]) return 1;
+    } else {
+      const uint32_t nw = slot_bytes(cls) >> 2;
+      for (uint32_t w = 0; w < nw; w++) if (((const uint32_t*)a)[w] != ((const uint32_t*)b)[w]) return 1;
+    }
+  }
+  return 0;
+}
+// -> number of rows (0: the event stays with the host — the reference refuses it, or the device cannot decide), their bases
+DEV uint32_t pb_selected(const ColSel& s, uint64_t i, unsigned long long* bases) {
+  if (i >= s.n_events || s.ev_slot[i] != s.slot) return 0;
+  const uint32_t k = s.ev_kind[i], fl = s.ev_flags[i], ok = fl & 3u;
+  const uint64_t base = s.ev_body[i];
+  if (k == 'I') { bases[0] = base; return 1; }
+  if (k == 'D') {  // bigquery_delete_row: the old image's primary-key cells (a key image only under primary-key identity, :1540-1555)
+    if (ok == ETLG_OLD_FULL) { bases[0] = base | kPbDelete; return 1; }
+    if (ok == ETLG_OLD_KEY && s.identity_pk) { bases[0] = base | kPbDelete | kPbKey; return 1; }
+    return 0;
+  }
+  if (k != 'U' || (fl & ETLG_FLAG_PARTIAL)) return 0;   // bigquery_update_new_row refuses partial rows (:1478-1494)
+  const uint64_t newb = base + (ok == ETLG_OLD_FULL ? s.row_full : ok == ETLG_OLD_KEY ? s.row_key : 0u);
+  if (ok == ETLG_OLD_NONE) {  // ensure_bigquery_update_without_old_row_can_skip_delete (:1515-1536)
+    if (!s.identity_pk) return 0;
+    bases[0] = newb; return 1;
+  }
+  if ((ok == ETLG_OLD_KEY && !s.identity_pk) || !s.pk_comparable) return 0;
+  const uint32_t ch = pb_pk_changed(s, base, newb, ok == ETLG_OLD_KEY);
+  if (ch == 2) return 0;
+  if (ch == 1) {  // the old key goes first, the new row follows with the next ordinal (:1446-1474)
+    bases[0] = base | kPbDelete | (ok == ETLG_OLD_KEY ? kPbKey : 0ull);
+    bases[1] = newb | kPbSecond;
+    return 2;
+  }
+  bases[0] = newb;
+  return 1;
+}
+
 __global__ __launch_bounds__(256) void k_col_count(ColSel s) {
   __shared__ uint32_t lds[8];
   uint64_t base;
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t sel = col_selected(s, i, base) ? 1u : 0u;
+  unsigned long long pbb[2];
+  const uint32_t sel = s.pb ? pb_selected(s, i, pbb) : col_selected(s, i, base) ? 1u : 0u;
   if (s.host_rows) {  // row events of the slot that are not handed off
     bool left = false;
     if (!sel && i < s.n_events && s.ev_slot[i] == s.slot) { const uint32_t k = s.ev_kind[i]; left = k == 'I' || k == 'U' || k == 'D'; }
@@ -64,9 +119,14 @@ __global__ __launch_bounds__(256) void k_col_rows(ColSel s) {
   __shared__ uint32_t lds[8];
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t base = 0;
-  const uint32_t sel = col_selected(s, i, base) ? 1u : 0u;
+  unsigned long long pbb[2] = {0, 0};
+  const uint32_t sel = s.pb ? pb_selected(s, i, pbb) : col_selected(s, i, base) ? 1u : 0u;
   const uint32_t inc = block_scan_incl<0>(sel, lds, nullptr);
-  if (sel) { const uint32_t r = s.blk[blockIdx.x] + inc - 1; s.row_event[r] = i; s.row_base[r] = base; }
+  if (sel) {
+    const uint32_t r = s.blk[blockIdx.x] + inc - sel;
+    s.row_event[r] = i; s.row_base[r] = s.pb ? pbb[0] : base;
+    if (sel == 2) { s.row_event[r + 1] = i; s.row_base[r + 1] = pbb[1]; }
+  }
 }
 
 enum : uint32_t { AK_BOOL = 0, AK_I32 = 1, AK_I64 = 2, AK_F32 = 3, AK_F64 = 4, AK_DATE32 = 5, AK_TIME64 = 6, AK_TS = 7, AK_TSTZ = 8, AK_FIXED16 = 9,
@@ -780,10 +840,19 @@ template <class S> DEV void pb_date(S& s, int32_t days_ce) {
 }
 template <class S>
 DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
-  const uint64_t base = j.row_base[r];
+  // (the row's kind sits in the top bits of its base: ColSel / pb_selected)
+  const unsigned long long rbase = j.row_base[r];
+  const bool del = (rbase & kPbDelete) != 0, keyimg = (rbase & kPbKey) != 0;
+  const uint64_t base = rbase & kPbBase;
   for (uint32_t i = 0; i < j.n_cols; i++) {
-    const uint32_t cd = j.cols[i], cls = cd & 0xFF, off = cd >> 16, tag = i + 1;
-    const uint32_t st = (j.fixed[base + i / 4] >> (2 * (i % 4))) & 3u;
+    const uint32_t cd = j.cols[i], cls = cd & 0xFF, tag = i + 1;
+    uint32_t off = cd >> 16, sti = i;
+    if (del) {  // bigquery_delete_row (core.rs:1742-1754): only the primary-key cells of the old image, under their column tags
+      const uint32_t kc = j.kcols[i];
+      if (!(kc & 4u)) continue;
+      if (keyimg) { off = kc >> 16; sti = (kc >> 8) & 0xFFu; }
+    }
+    const uint32_t st = (j.fixed[base + sti / 4] >> (2 * (sti % 4))) & 3u;
     if (st == ETLG_CELL_NULL) continue;                       // Cell::Null => {}
     if (st != ETLG_CELL_VALUE) return (i << 8) | RB_E_HOST_CELL;
     const u8* slot = j.fixed + base + off;
@@ -825,9 +894,9 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
   }
   const uint64_t ev = j.row_event[r];
   pb_key(s, j.n_cols + 1, 2); s.varint64(6);
-  { const char* op = "UPSERT"; for (int k = 0; k < 6; k++) s.put((u8)op[k]); }
+  { const char* op = del ? "DELETE" : "UPSERT"; for (int k = 0; k < 6; k++) s.put((u8)op[k]); }
   pb_key(s, j.n_cols + 2, 2); s.varint64(50);
-  pb_hex16(s, j.ev_commit[ev]); s.put('/'); pb_hex16(s, j.ev_ord[ev]); s.put('/'); pb_hex16(s, 0);
+  pb_hex16(s, j.ev_commit[ev]); s.put('/'); pb_hex16(s, j.ev_ord[ev]); s.put('/'); pb_hex16(s, (rbase & kPbSecond) ? 1 : 0);   // bigquery_sequence_key (:1405-1407)
   return 0;
 }
 

@@ -200,7 +200,16 @@ struct ColSel {            // which events are rows of the hand-off
   uint32_t* blk;           // per-block counts -> exclusive prefix; blk[nblocks] = total
   uint32_t nblocks;
   uint64_t* row_event; uint64_t* row_base;   // outputs of k_col_rows
+  // BigQuery rows (pb != 0; bigquery/core.rs:978-1036): an event becomes 0, 1 or 2 rows, and a row's base carries what it is in its
+  // top bits (kPbDelete: the sparse DELETE row of an old image; kPbKey: that image has the key layout; kPbSecond: sequence ordinal 1)
+  uint32_t pb, n_cols;
+  uint32_t identity_pk;    // the slot's replica identity is the primary key
+  uint32_t pk_comparable;  // every primary-key column is of a class whose Cell equality is equality of the arena's words / bytes
+  const uint8_t* fixed; const uint8_t* heap;
+  const uint32_t* cols;    // per replicated column: cls | .. | off_full << 16 (RbJob.cols)
+  const uint32_t* kcols;   // identity | source nullable << 1 | primary key << 2 | key_index << 8 | off_key << 16 (RbJob.kcols)
 };
+constexpr unsigned long long kPbDelete = 1ull << 63, kPbKey = 1ull << 62, kPbSecond = 1ull << 61, kPbBase = (1ull << 61) - 1;
 
 struct ColJob {
   const uint8_t* fixed; const uint8_t* heap; const uint64_t* row_base;
@@ -234,7 +243,7 @@ struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
   uint32_t cdc_nullable;           // bit 0 / 1: the first / second trailing CDC column is Nullable() in the destination
   uint32_t format;                 // 0 ClickHouse RowBinary, 1 BigQuery protobuf (Insert rows, prost wire format)
   const uint32_t* cols;            // per replicated column: cls | nullable << 8 | off_full << 16
-  const uint32_t* kcols;           // per replicated column, for key-only Deletes: identity | source nullable << 1 | key_index << 8 | off_key << 16
+  const uint32_t* kcols;           // per replicated column, for key images: identity | source nullable << 1 | primary key << 2 | key_index << 8 | off_key << 16
   const uint8_t* ev_flags;
   uint32_t* lens; const int64_t* offsets; uint8_t* out;
   unsigned long long* err;         // min over failing cells of (row << 24 | column << 8 | code); ~0 = none

@@ -181,6 +181,7 @@ using SchemaPtr = std::shared_ptr<const StoredSchema>;
 struct SlotHost {  // one ReplicatedTableSchema instance
   etlg_slot_desc desc;
   std::vector<etlg_slot_col> cols;
+  std::vector<uint8_t> pk;   // per replicated column: a primary-key column of the stored schema (ColumnSchema::primary_key)
   int identity_type = 0;   // ReplicatedTableSchema::infer_identity_type (schema.rs:686-721): 0 Missing, 1 PrimaryKey, 2 Full, 3 AlternativeKey
 };
 

@@ -645,15 +645,24 @@ typedef struct etlg_rowbinary etlg_rowbinary;
  * the description, frame_index = the event index). Same batch requirements as etlg_batch_columns. */
 int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, const uint8_t* nullable_flags,
                              uint32_t n_flags, int32_t engine, uint32_t flags, etlg_rowbinary** out);
-/* BigQuery Storage Write rows for ONE schema slot: the protobuf bytes BigQueryTableRow holds for every Insert event
- * (cell_encode_prost, crates/etl-destinations/src/bigquery/encoding.rs:120-190: field tag = column position + 1, NULL cells
- * leave nothing; then _CHANGE_TYPE = "UPSERT" and _CHANGE_SEQUENCE_NUMBER = "{commit_lsn:016x}/{tx_ordinal:016x}/{0:016x}",
- * bigquery/core.rs:978-996, 1404-1406). Updates and deletes need the reference's key-change logic (core.rs:1431-1754): they are
- * counted in n_host_rows. numeric / timetz cells are their Display strings, a numeric with more than 38 decimal places fails the
+/* BigQuery Storage Write rows for ONE schema slot: the protobuf bytes of the BigQueryTableRows the sink builds for the slot's events
+ * (crates/etl-destinations/src/bigquery/core.rs:978-1036; cell_encode_prost, bigquery/encoding.rs:120-190: field tag = column position
+ * + 1, NULL cells leave nothing), every row closed by _CHANGE_TYPE and _CHANGE_SEQUENCE_NUMBER =
+ * "{commit_lsn:016x}/{tx_ordinal:016x}/{ordinal:016x}" (core.rs:1405-1407):
+ *   Insert -> one UPSERT row (ordinal 0);
+ *   Update -> the new row as UPSERT; when the update changed the primary key — the old image's primary-key cells (key image or full
+ *             old row) against the new row's, bigquery_primary_key_changed :1557-1645 — a sparse DELETE row of the OLD key goes first
+ *             (ordinal 0) and the UPSERT takes ordinal 1 (:1425-1476): such an event is two consecutive rows with the same row_event;
+ *   Delete -> the sparse DELETE row: the old image's primary-key cells under their column tags (bigquery_delete_row :1742-1754).
+ * Events the reference refuses are left out and counted in n_host_rows (the host raises the reference's error when it meets the first):
+ * a partial update, a delete without an old row, a key image or an update without an old row under a replica identity other than the
+ * primary key (:1497-1555). So are updates that carry an old row when a primary-key column is of a class whose Cell equality is not
+ * equality of the arena's words / bytes (float4 / float8, numeric, timetz), or a primary-key cell is DEFERRED.
+ * numeric / timetz cells are their Display strings, a numeric with more than 38 decimal places fails the
  * call like validate_numeric_for_bigquery (bigquery/validation.rs:20-35: ETLG_UnsupportedValueInDestination, "Cell validation failed
  * for BigQuery compatibility", detail "Cell at index N failed validation", frame_index = the event). json / array columns
  * (serde_json Display, packed / repeated fields, host-side validation) and DEFERRED cells return ETLG_RB_NEEDS_HOST.
- * The result is an etlg_rowbinary (same view). */
+ * The result is an etlg_rowbinary (same view; n_rows can exceed the number of events). */
 int32_t etlg_batch_protobuf(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t flags, etlg_rowbinary** out);
 int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out);
 void etlg_rowbinary_free(etlg_rowbinary* rb);

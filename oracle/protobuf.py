@@ -2,8 +2,10 @@
 (etl_amd/csrc/columns.hip). Never imported by the product path.
 
 Follows crates/etl-destinations/src/bigquery/encoding.rs: cell_encode_prost :120-190 (which protobuf field type every Cell
-becomes), BigQueryTableRow::try_from :54-66 (tags = position + 1), and bigquery/core.rs:978-996 + 1404-1406 (the Insert row's two
-trailing cells: "UPSERT" and the sequence key), crates/etl/src/event.rs:346-351 (EventSequenceKey Display).
+becomes), BigQueryTableRow::try_from :54-66 (tags = position + 1), and bigquery/core.rs:978-1036 + 1404-1754 (which rows an event
+becomes: Insert -> one UPSERT row; Update -> the new row as UPSERT, behind a sparse DELETE row of the old primary key when the update
+changed it; Delete -> a sparse DELETE row of the old primary key; the sequence key's trailing ordinal), crates/etl/src/event.rs:346-351
+(EventSequenceKey Display). The row decisions are pinned by the reference's own tests (core.rs:2422-2600) in tests/test_oracle_protobuf.py.
 
 PARITY UNPINNED: the reference's tests compare against prost's own output, never against literal bytes, and prost is an
 un-vendored dependency — the wire rules below are the protobuf encoding specification (varint keys, wire types 0 / 1 / 2 / 5,
@@ -81,18 +83,84 @@ def cell(c, tag):
     raise NeedsHost(k)
 
 
-def insert_rows(events, slot_index):
-    """(list of row bytes, event indices, events of the slot left to the host)."""
+# classes whose Cell equality is the equality of the arena's words / bytes (bigquery_primary_key_changed compares Cells: float
+# NaN != NaN and 0.0 == -0.0, numeric / timetz / json / array cells are compared as parsed values): updates of a table whose
+# primary key has a column of another class stay with the host when they carry an old row
+PK_COMPARABLE = {"Bool", "I16", "I32", "I64", "U32", "Date", "Time", "Timestamp", "TimestampTz", "Uuid", "String", "Bytes", "Null"}
+
+
+def seq(e, ordinal):
+    return f"{e['commit_lsn']:016x}/{e['tx_ordinal']:016x}/{ordinal:016x}".encode()
+
+
+def upsert_row(e, cells, ordinal):
+    n = len(cells)
+    return b"".join(cell(c, t + 1) for t, c in enumerate(cells)) + ld(n + 1, b"UPSERT") + ld(n + 2, seq(e, ordinal))
+
+
+def delete_row(e, tagged, n_cols, ordinal):
+    """bigquery_delete_row (core.rs:1742-1754): the primary-key cells under their column tags, then DELETE and the sequence key."""
+    return b"".join(cell(c, t) for t, c in tagged) + ld(n_cols + 1, b"DELETE") + ld(n_cols + 2, seq(e, ordinal))
+
+
+def pk_tagged(old_kind, old_row, schema_cols):
+    """bigquery_primary_key_tagged_cells_from_old_row (:1647-1739) for a key image / a full old row of the right width."""
+    pk = [i for i, c in enumerate(schema_cols) if c[3]]
+    if old_kind == "Key":
+        return [(i + 1, old_row[k]) for k, i in enumerate(pk)]
+    return [(i + 1, old_row[i]) for i in pk]
+
+
+def event_rows(events, slot_index, schema_cols=None, identity_type="PrimaryKey"):
+    """(list of row bytes, event index of every row, events of the slot left to the host). Without `schema_cols`: Insert rows only
+    (the round-2 contract). With them: what bigquery/core.rs:978-1036 builds for every Insert / Update / Delete event the reference
+    accepts; an event it refuses (a partial update, a delete without an old row, a key image under another replica identity, an
+    update without an old row under another replica identity) — and an update with an old row whose primary key has a column of a
+    class outside PK_COMPARABLE, or a cell of it DEFERRED — stays with the host."""
     rows, idx, host = [], [], 0
     for i, e in enumerate(events):
         if e["kind"] not in "IUD" or e.get("schema_slot") != slot_index:
             continue
-        if e["kind"] != "I":
+        if e["kind"] == "I":
+            rows.append(upsert_row(e, e["row"], 0)); idx.append(i)
+            continue
+        if schema_cols is None:
             host += 1
             continue
-        body = b"".join(cell(c, t + 1) for t, c in enumerate(e["row"]))
-        n = len(e["row"])
-        body += ld(n + 1, b"UPSERT") + ld(n + 2, f"{e['commit_lsn']:016x}/{e['tx_ordinal']:016x}/{0:016x}".encode())
-        rows.append(body)
-        idx.append(i)
+        n = len(schema_cols)
+        n_pk = sum(1 for c in schema_cols if c[3])
+        ok, old = e["old_kind"], e.get("old_row")
+        if e["kind"] == "D":
+            if ok == "Full" or (ok == "Key" and identity_type == "PrimaryKey" and len(old) == n_pk):
+                rows.append(delete_row(e, pk_tagged(ok, old, schema_cols), n, 0)); idx.append(i)
+            else:
+                host += 1
+            continue
+        if e["partial"]:
+            host += 1
+            continue
+        new = e["row"]
+        if ok == "None":   # ensure_bigquery_update_without_old_row_can_skip_delete (:1515-1536)
+            if identity_type != "PrimaryKey":
+                host += 1
+                continue
+            rows.append(upsert_row(e, new, 0)); idx.append(i)
+            continue
+        if ok == "Key" and (identity_type != "PrimaryKey" or len(old) != n_pk):
+            host += 1
+            continue
+        pairs = [(c, new[t - 1]) for t, c in pk_tagged(ok, old, schema_cols)]
+        if any(a[0] not in PK_COMPARABLE or b[0] not in PK_COMPARABLE for a, b in pairs):
+            host += 1
+            continue
+        if any(a != b for a, b in pairs):   # bigquery_primary_key_changed (:1557-1645)
+            rows.append(delete_row(e, pk_tagged(ok, old, schema_cols), n, 0)); idx.append(i)
+            rows.append(upsert_row(e, new, 1)); idx.append(i)
+        else:
+            rows.append(upsert_row(e, new, 0)); idx.append(i)
     return rows, idx, host
+
+
+def insert_rows(events, slot_index):
+    """(list of row bytes, event indices, events of the slot left to the host)."""
+    return event_rows(events, slot_index)

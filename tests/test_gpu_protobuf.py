@@ -15,9 +15,10 @@ from tests.test_gpu_rowbinary import NUMERICS, RB_COLS, TIMETZS, _both, _row, _s
 pytestmark = pytest.mark.gpu
 
 
-def _check(hb, b):
+def _check(hb, b, schema_cols=None, identity_type="PrimaryKey"):
+    """schema_cols: the table's (name, oid, nullable, pk) columns — with them the oracle builds the rows of updates and deletes."""
     from oracle import protobuf as PB
-    rows, idx, host = PB.insert_rows(hb.materialize(), 0)
+    rows, idx, host = PB.event_rows(hb.materialize(), 0, schema_cols, identity_type)
     r = b.protobuf(0)
     assert r.status == abi.RB_OK and r.n_rows == len(rows) and int(r.view.n_host_rows) == host
     assert np.array_equal(r.row_event(), np.array(idx, dtype=np.uint64))
@@ -40,7 +41,7 @@ def test_every_encodable_class():
     msgs = [W.insert(42, r) for r in rows] + [W.update(42, rows[1]), W.delete(42, old=rows[0])]
     buf, offs = _stream(msgs)
     hb, b, d = _both(SC.simple_table(RB_COLS), buf, offs)
-    assert _check(hb, b) == len(rows)
+    assert _check(hb, b, RB_COLS) == len(rows) + 2          # + the update's UPSERT row and the delete's sparse DELETE row
     b.close(); d.close()
 
 
@@ -63,7 +64,80 @@ def test_synthetic_stream(mk):
     w = mk()
     buf, offs = w.fill((128 << 10) if os.environ.get("ETLG_SIMT_RUN") == "1" else (1 << 20))
     hb, b, d = _both(w.register, buf, offs)
-    assert _check(hb, b) > 100
+    assert _check(hb, b, w.schema_cols(w.tables[0])) > 100   # (cfg3: updates with key / full old rows, key-only deletes)
+    b.close(); d.close()
+
+
+def test_updates_and_deletes():
+    """bigquery/core.rs:978-1036 + 1425-1754 on the device: an update is its new row as UPSERT — behind a sparse DELETE row of the OLD
+    primary key (sequence ordinal 0, the UPSERT then 1) when the update changed the key, judged by comparing the old image's
+    primary-key cells (key image or full old row) with the new row's; a delete is the sparse DELETE row of its old image's primary
+    key; two-column keys (int8 + text), NULL in a key column, keys that differ only in the text column's last byte / its length.
+    The events the reference refuses stay with the host: partial updates, deletes without an old row."""
+    cols = [("a", SC.INT4, True, 0), ("k1", SC.INT8, False, 1), ("s", 25, True, 0), ("k2", 25, False, 1), ("u", SC.UUID, True, 0)]
+    ident = [0, 1, 0, 1, 0]
+    U1 = "123e4567-e89b-12d3-a456-426614174000"
+    msgs = []
+    for i in range(120):
+        k1, k2 = str(i), "key-%03d" % i
+        row = [str(i * 2), k1, "text %d" % i, k2, U1]
+        msgs.append(W.insert(42, row))
+        m = i % 12
+        if m == 0:
+            msgs.append(W.update(42, [W.NULL, k1, "changed", k2, W.NULL]))                              # no old image: key unchanged
+        elif m == 1:
+            msgs.append(W.update(42, ["1", k1, "x", k2, U1], key=[W.NULL, k1, W.NULL, k2, W.NULL]))      # key image, same key
+        elif m == 2:
+            msgs.append(W.update(42, ["1", str(i + 1000), "x", k2, U1], key=[W.NULL, k1, W.NULL, k2, W.NULL]))   # k1 changed
+        elif m == 3:
+            msgs.append(W.update(42, ["1", k1, "x", k2[:-1] + "X", U1], key=[W.NULL, k1, W.NULL, k2, W.NULL]))   # k2: last byte
+        elif m == 4:
+            msgs.append(W.update(42, ["1", k1, "x", k2 + "+", U1], key=[W.NULL, k1, W.NULL, k2, W.NULL]))        # k2: length
+        elif m == 5:
+            msgs.append(W.update(42, ["1", k1, W.TOAST, k2, U1]))                                        # partial: host
+        elif m == 6:
+            msgs.append(W.delete(42, key=[W.NULL, k1, W.NULL, k2, W.NULL]))
+        elif m == 7:
+            msgs.append(W.delete(42, old=row))
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(cols, ident=ident), buf, offs)
+    n = _check(hb, b, cols)
+    assert n == 120 + 10 * 5 + 10 * 3 + 10 * 2 and b.protobuf(0).view.n_host_rows == 10
+    b.close(); d.close()
+    # REPLICA IDENTITY FULL: old rows are full images; the primary key is still (k1, k2)
+    msgs = []
+    for i in range(40):
+        row = [str(i), str(i), "t", "k%d" % i, U1]
+        msgs.append(W.insert(42, row))
+        if i % 4 == 0:
+            msgs.append(W.update(42, [str(i + 1), str(i), "t2", "k%d" % i, U1], old=row))               # other columns changed only
+        elif i % 4 == 1:
+            msgs.append(W.update(42, [str(i), str(i), "t", "K%d" % i, U1], old=row))                     # key changed
+        elif i % 4 == 2:
+            msgs.append(W.delete(42, old=row))
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(cols, ident=[1] * 5), buf, offs)
+    assert _check(hb, b, cols, "Full") == 40 + 10 + 20 + 10
+    b.close(); d.close()
+
+
+def test_events_bigquery_refuses_stay_with_the_host():
+    """A key image / an update without an old row under a replica identity that is not the primary key
+    (ensure_bigquery_key_image_matches_primary_key, ensure_bigquery_update_without_old_row_can_skip_delete: core.rs:1515-1555), a
+    delete without an old row (bigquery_delete_old_row :1497-1511); and updates of a table whose primary key has a float column
+    (Cell equality is not bit equality there) when they carry an old row."""
+    cols = [("id", SC.INT8, False, 1), ("k", SC.INT4, False, 0), ("s", 25, True, 0)]
+    msgs = [W.insert(42, ["1", "2", "x"]), W.update(42, ["1", "2", "y"]), W.update(42, ["1", "3", "y"], key=[W.NULL, "2", W.NULL]),
+            W.delete(42, key=[W.NULL, "3", W.NULL])]
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(cols, ident=[0, 1, 0]), buf, offs)
+    assert _check(hb, b, cols, "AlternativeKey") == 1 and b.protobuf(0).view.n_host_rows == 3
+    b.close(); d.close()
+    cols = [("f", SC.FLOAT8, False, 1), ("s", 25, True, 0)]
+    msgs = [W.insert(42, ["1.5", "x"]), W.update(42, ["1.5", "y"]), W.update(42, ["2.5", "y"], key=["1.5", W.NULL]), W.delete(42, key=["2.5", W.NULL])]
+    buf, offs = _stream(msgs)
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    assert _check(hb, b, cols) == 3 and b.protobuf(0).view.n_host_rows == 1
     b.close(); d.close()
 
 
