@@ -56,6 +56,14 @@ impl PinnedBuf {
         debug_assert!(at + len <= self.cap);
         unsafe { std::slice::from_raw_parts_mut(self.ptr.add(at), len) }
     }
+    /// (for the crate's other staging buffers: copy.rs)
+    pub(crate) fn bytes_mut(&mut self, at: usize, len: usize) -> &mut [u8] {
+        self.slice_mut(at, len)
+    }
+    pub(crate) fn bytes(&self, at: usize, len: usize) -> &[u8] {
+        debug_assert!(at + len <= self.cap);
+        unsafe { std::slice::from_raw_parts(self.ptr.add(at), len) }
+    }
 }
 
 impl Drop for PinnedBuf {

@@ -5,12 +5,14 @@
 //! ```
 //! * [`ffi`]         raw binding of `include/etlg.h` (checked against the header by the etl-gfx950 test suite);
 //! * [`batcher`]     frames + offsets sidecar accumulation in a ring of pinned buffers, flush policy (apply.rs:1910-1967);
+//! * [`copy`]        table copy: `CopyOutStream` items staged as bytes, `GpuDecoder::copy_decode` → `Vec<TableRow>` (table_copy.rs:70-103);
 //! * [`flush`]       `last_received_lsn` / `last_commit_end_lsn` / effective flush LSN for a loop that decodes batches (apply.rs:2039-2051,
 //!                   1918-1928, 2000, 885-912);
 //! * [`materialize`] arena → `Event` / `TableRow` / `Cell`, DEFERRED cells finished with the reference's own parser;
 //! * [`GpuDecoder`]  safe wrapper of one context: side inputs mirror `SchemaStore` / `StateStore` / `SharedTableCache`
 //!                   (crates/etl/src/store/schema/base.rs:19-69, store/state/base.rs:25-139, replication/table_cache.rs:88-154).
 pub mod batcher;
+pub mod copy;
 pub mod ffi;
 pub mod flush;
 pub mod materialize;

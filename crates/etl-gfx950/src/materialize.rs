@@ -164,6 +164,27 @@ fn full(r: RowImage) -> EtlResult<TableRow> {
     }
 }
 
+/// The rows of a table-copy batch (`etlg_copy_decode`: one Insert-shaped event per COPY row, in row order) — what
+/// `TableCopyStream` yields item by item (crates/etl/src/postgres/stream/table_copy.rs:84-92).
+///
+/// SAFETY: `view` must describe a batch whose arrays are in host memory and stay alive for the call.
+pub unsafe fn table_rows(view: &etlg_batch_view) -> EtlResult<Vec<TableRow>> {
+    let a = Arena::new(view);
+    let n = view.n_events as usize;
+    let kind = std::slice::from_raw_parts(view.ev_kind, n);
+    let slot = std::slice::from_raw_parts(view.ev_schema_slot, n);
+    let body = std::slice::from_raw_parts(view.ev_body_off, n);
+    let slots = std::slice::from_raw_parts(view.slots, view.n_slots as usize);
+    let mut out = Vec::with_capacity(n);
+    for i in 0..n {
+        if kind[i] != ETLG_EV_INSERT {
+            bail!(ErrorKind::InvalidState, "Table-copy batch holds an event that is not a row", kind[i]);
+        }
+        out.push(full(row(&a, &slots[slot[i] as usize], body[i] as usize, false)?)?);
+    }
+    Ok(out)
+}
+
 /// The events of one decoded batch, in stream order — what `EventBatch` would have received message by message.
 ///
 /// SAFETY: `view` must describe a batch whose arrays are in host memory and stay alive for the call.

@@ -201,16 +201,17 @@ def test_every_reference_path_the_shim_names_exists():
 
 
 def test_the_patch_quotes_the_reference():
-    """patches/apply_rs.diff: its context lines (the ones without +/-) are lines of the reference's apply.rs."""
+    """patches/*.diff: their context lines (the ones without +/-) are lines of the reference file they patch."""
     import pytest
     if not os.path.isdir(REF):
         pytest.skip("the reference checkout is only present in the build container")
-    ref = open(os.path.join(REF, "crates/etl/src/replication/apply.rs")).read()
-    patch = open(os.path.join(CRATE, "patches", "apply_rs.diff")).read()
-    body = patch[patch.index("--- a/crates/etl/src/replication/apply.rs"):]
-    ctx = [l[1:].strip() for l in body.split("\n") if l.startswith(" ") and l.strip()]
-    assert len(ctx) >= 8
-    for l in ctx:
-        assert l in ref, l
-    for hunk in re.findall(r"^@@ (.+)$", body, flags=re.M):
-        assert hunk.strip().split("(")[0] in ref, hunk
+    for name, target in (("apply_rs.diff", "crates/etl/src/replication/apply.rs"), ("table_copy_rs.diff", "crates/etl/src/postgres/stream/table_copy.rs")):
+        ref = open(os.path.join(REF, target)).read()
+        patch = open(os.path.join(CRATE, "patches", name)).read()
+        body = patch[patch.index("--- a/" + target):]
+        ctx = [l[1:].strip() for l in body.split("\n") if l.startswith(" ") and l.strip()]
+        assert len(ctx) >= 8, name
+        for l in ctx:
+            assert l in ref, (name, l)
+        for hunk in re.findall(r"^@@ (.+)$", body, flags=re.M):
+            assert hunk.strip().split("(")[0] in ref, (name, hunk)
