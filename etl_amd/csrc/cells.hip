@@ -565,7 +565,10 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
               for (; j < run; j++) win[w_ + j] = win[pos + j];
             }
             w_ += run; pos = nb;
-            if (pos >= pk) break;
+            if (pos + 1 >= pk) break;   // the field is done. (A backslash as its LAST byte cannot occur in a row that decodes; it can in a
+                                        // tile whose bitmaps were built across a malformed row — a row without its newline that ends in
+                                        // backslashes, in front of one that starts with some: the batch fails on that row, and nothing
+                                        // here reads or writes outside the field.)
             const uint32_t e = win[pos + 1];
             if (e < 0x80u) {
               const uint32_t ch = e == 'b' ? 8u : e == 'f' ? 12u : e == 'n' ? (uint32_t)'\n' : e == 'r' ? (uint32_t)'\r' : e == 't' ? (uint32_t)'\t' : e == 'v' ? 11u : e;
@@ -576,6 +579,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
               for (uint32_t t2 = 0; t2 < l; t2++) win[w_ + t2] = win[pos + 1 + t2];
               w_ += l; pos += 1 + l;
             }
+            if (pos > pk) pos = pk;   // (only behind a mis-split field, see above)
             nb = next_bs(pos, pk);
           }
           tab.put((maxc + k) * CF + lane, start, w_ - start, (uint32_t)CT_T);

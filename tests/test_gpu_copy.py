@@ -316,3 +316,17 @@ def test_copy_utf8_in_the_direct_kernel():
             assert rb.err_frame == r and rb.err_code != 0
             assert_same(rb, gb)
             d.close()
+
+
+def test_copy_backslash_run_across_a_malformed_row_boundary():
+    """A row without its newline that ends in backslashes, in front of a row that starts with backslashes (found by tools/copy_fuzz.py):
+    inside the tile the two runs are one, so the second row's separators are judged by the wrong parity — the batch fails on the first
+    row anyway, but the kernel must stay inside its fields while it works on the second (it once did not)."""
+    cols = [("a", K.TEXT, True, 0), ("b", K.TEXT, True, 0), ("c", K.TEXT, True, 0)]
+    for tail in (b"\\", b"\\\\", b"\\\\\\"):
+        for head in range(1, 12):
+            rows = [b"good\tx\ty\n", b"bbbbbbbb\t         \t" + tail, b"\\" * head + b"\tNNN\t\n", b"k\tl\tm\n"]
+            o, d, rb, gb = both(cols, rows)
+            assert rb.err_code != 0 and rb.err_frame == 1
+            assert_same(rb, gb)
+            d.close()
