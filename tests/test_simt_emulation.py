@@ -84,3 +84,14 @@ def test_columnar_hand_off(simt_lib):
     the host hand-off of the oracle's arena, the RowBinary bytes against oracle/rowbinary.py."""
     tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py"], 600)
     assert " passed" in tail and "failed" not in tail, tail
+
+
+def test_copy_mutation_fuzz(simt_lib):
+    """tools/copy_fuzz.py on the emulated kernels: generated COPY rows with a few mutated bytes (specials, invalid UTF-8, deletions) or
+    many benign escape insertions, table-copy path against the oracle — same error, same row, same arena before it; a batch the
+    reference rejects never comes out of the one-kernel path. (It found the out-of-field copy loop behind a malformed row boundary.)"""
+    env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="600")
+    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_COPY_DIRECT", "ETLG_COPY_KERNEL"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=660)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]

@@ -18,7 +18,16 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = random.Random(seed)
 TABLES = [(synth.COPY_COLS, lambda n, s: synth.copy_rows(n, s)),
-          ([(c, K.TEXT, True, 0) for c in "abc"], lambda n, s: [("\t".join("".join(random.Random(s * 977 + i * 3 + j).choice("ab\\\\\\tN \\n é中") for _ in range(random.Random(s + i + j).randrange(0, 12))) for j in range(3)) + "\n").encode() for i in range(n)])]
+          ([(c, K.TEXT, True, 0) for c in "abc"], lambda n, s: text_rows(n, s))]
+TOKENS = ["a", "b", "\\\\", "\\t", "\\n", "\\N", "é", "中", " ", "\\\t", "\\\n", "N", "xyz" * 5]   # every token is a whole character or a whole escape
+
+
+def text_rows(n, s):
+    r = random.Random(s)
+    return [("\t".join(r.choice(["\\N", "", "".join(r.choice(TOKENS) for _ in range(r.randrange(1, 14)))]) if r.random() < 0.25
+                       else "".join(r.choice(TOKENS) for _ in range(r.randrange(0, 14))) for _ in range(3)) + "\n").encode() for _ in range(n)]
+
+
 SPECIALS = [b"\t", b"\n", b"\\", b"\\N", b"\\\\", b"\xff", b"\xc3", b"\xa9", b"", b"N", b"\\\t", b"\\\n", b"\xe4\xb8", b"0", b"x"]
 bad = 0
 direct = frames = 0
