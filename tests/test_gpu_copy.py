@@ -330,3 +330,26 @@ def test_copy_backslash_run_across_a_malformed_row_boundary():
             assert rb.err_code != 0 and rb.err_frame == 1
             assert_same(rb, gb)
             d.close()
+
+
+@pytest.mark.parametrize("ncols", [17, 24, 32])
+def test_copy_wide_tables(ncols):
+    """Tables of more than 16 columns take the WIDE instantiation of the rows -> arena kernel (two state words per row, 64-bit column
+    masks, the splitter's column mask of the fields with backslashes up to bit 31): every class, NULLs and escapes in every column
+    position, rows that span several bitmap batches."""
+    rng = random.Random(ncols)
+    kinds = [(K.INT4, lambda: str(rng.randrange(-10**9, 10**9))), (K.TEXT, lambda: "".join(rng.choice(["a", "é", "\\\\", "\\t", "x y", "\\N", ""]) for _ in range(rng.randrange(0, 9)))),
+             (20, lambda: str(rng.randrange(-2**62, 2**62))), (16, lambda: rng.choice("tf")), (1700, lambda: rng.choice(["0", "-12.5", "1e5", "NaN", "123456.789"])),
+             (701, lambda: rng.choice(["1.5", "-0.25", "1e300", "nan", "3.141592653589793"])), (17, lambda: "\\\\x" + "".join("%02x" % rng.randrange(256) for _ in range(rng.randrange(0, 6)))),
+             (2950, lambda: "%08x-1111-2222-3333-%012x" % (rng.getrandbits(32), rng.getrandbits(48))), (1184, lambda: "2024-0%d-1%d 0%d:30:15.%06d+0%d" % (rng.randrange(1, 10), rng.randrange(10), rng.randrange(10), rng.randrange(10**6), rng.randrange(10)))]
+    cols, gens = [], []
+    for i in range(ncols):
+        oid, g = kinds[(i * 5 + 3) % len(kinds)]
+        cols.append(("c%d" % i, oid, True, 1 if i == 0 else 0))
+        gens.append(g)
+    rows = [("\t".join(("\\N" if rng.random() < 0.15 else g()) for g in gens) + "\n").encode() for _ in range(300)]
+    o, d, rb, gb = both(cols, rows)
+    assert rb.err_code == 0, (rb.err_desc, rb.err_frame)
+    assert_same(rb, gb)
+    assert d.debug_copy() == {"direct": 1, "frames": 0}
+    d.close()

@@ -18,14 +18,15 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = random.Random(seed)
 TABLES = [(synth.COPY_COLS, lambda n, s: synth.copy_rows(n, s)),
-          ([(c, K.TEXT, True, 0) for c in "abc"], lambda n, s: text_rows(n, s))]
+          ([(c, K.TEXT, True, 0) for c in "abc"], lambda n, s: text_rows(n, s)),
+          ([("c%d" % i, K.TEXT, True, 0) for i in range(20)], lambda n, s: text_rows(n, s, 20))]   # more than 16 columns: the WIDE instantiation
 TOKENS = ["a", "b", "\\\\", "\\t", "\\n", "\\N", "é", "中", " ", "\\\t", "\\\n", "N", "xyz" * 5]   # every token is a whole character or a whole escape
 
 
-def text_rows(n, s):
+def text_rows(n, s, nf=3):
     r = random.Random(s)
     return [("\t".join(r.choice(["\\N", "", "".join(r.choice(TOKENS) for _ in range(r.randrange(1, 14)))]) if r.random() < 0.25
-                       else "".join(r.choice(TOKENS) for _ in range(r.randrange(0, 14))) for _ in range(3)) + "\n").encode() for _ in range(n)]
+                       else "".join(r.choice(TOKENS) for _ in range(r.randrange(0, 14))) for _ in range(nf)) + "\n").encode() for _ in range(n)]
 
 
 SPECIALS = [b"\t", b"\n", b"\\", b"\\N", b"\\\\", b"\xff", b"\xc3", b"\xa9", b"", b"N", b"\\\t", b"\\\n", b"\xe4\xb8", b"0", b"x"]
@@ -34,7 +35,7 @@ direct = frames = 0
 for it in range(iters):
     cols, gen = TABLES[it % len(TABLES)]
     rows = list(gen(rng.randrange(1, 200), rng.randrange(1 << 20)))
-    benign = it % 2 == 1 and it % 4 == 1   # every other batch of the all-text table: insertions that keep the rows valid (pairs that
+    benign = it % len(TABLES) != 0 and it % 2 == 1   # every other batch of the all-text table: insertions that keep the rows valid (pairs that
                                             # start with a backslash, plain and multi-byte characters), many of them — batches the one-kernel path keeps
     if benign:
         for _ in range(rng.randrange(1, 60)):
