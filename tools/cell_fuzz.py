@@ -1,0 +1,118 @@
+"""Differential fuzz of single-cell value codecs, emulated (or real) kernels against the oracle: python tools/cell_fuzz.py [batches] [seed]
+For every class a batch of Insert frames with one mutated text each is decoded by both; the first error (code, frame) and the arena of the
+rows before it must agree, and — for the classes whose hand-off writes Display strings — the RowBinary bytes as well. Exemplars are
+mutated character-wise (digits, separators, signs, zone suffixes, exponent forms, brackets, escapes), so most texts sit near the
+edges of the grammars (chrono's parse_from_str shapes, serde_json's validity, numeric's and float's forms, array literals)."""
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from etl_amd import abi
+from etl_amd.decoder import Decoder
+from oracle import oracle
+from oracle import rowbinary as RB
+from tests import pgwire as W
+from tests import scenarios as SC
+
+CLASSES = {
+    "timestamptz": (1184, ["2024-02-29 12:30:45.123456+02", "1999-12-31 23:59:60+00", "0001-01-01 00:00:00+00:00:00", "2024-1-2 3:4:5+5", "2024-01-02T03:04:05Z",
+                           "2024-01-02 03:04:05.1234567-07:30", "2024-01-02 03:04:05 BC", "infinity", "-infinity", "294276-12-31 23:59:59.999999+00"],
+                    "0123456789-+:. TZBCinfty"),
+    "timestamp": (1114, ["2024-02-29 12:30:45.123456", "1999-12-31 23:59:60", "2024-1-2 3:4:5", "2024-01-02T03:04:05", "0001-01-01 00:00:00.5", "infinity"], "0123456789-+:. TBCinf"),
+    "date": (1082, ["2024-02-29", "0001-01-01", "9999-12-31", "2023-02-29", "2024-1-2", "10000-01-01", "infinity", "0044-03-15 BC"], "0123456789- BCinf"),
+    "time": (1083, ["12:30:45.123456", "23:59:60", "00:00:00", "24:00:00", "1:2:3", "12:30", "12:30:45.1234567890"], "0123456789:. "),
+    "timetz": (1266, ["12:30:45.123456+02", "23:59:59-07:30", "00:00:00+15:59:59", "12:30:45+0530", "12:30:45Z", "24:00:00-00"], "0123456789:.+- Z"),
+    "jsonb": (3802, ['{"a":1,"b":[true,false,null],"c":{"d":"e\\u00e9\\n"}}', '[1,2.5e-3,-0,"x"]', '"\\ud83d\\ude00"', '{"a":{"a":{"a":[[[[1]]]]}}}', "1e999", '{"k":"v"}   ', "[]", "nul"],
+              '{}[]":,\\u0123456789abcdefADtrenlsu-+.E '),
+    "numeric": (1700, ["0", "-12.5", "123456789.000100", "NaN", "1e5", "0.000012", "1234567890123456789012345678901234567890.12345", "-0.00", "1e-40", "Infinity", "+17", " 42.50 ", "1_000.5", ".5", "5."],
+                "0123456789.+-eE_ NaInfity"),
+    "float8": (701, ["1.5", "-0.25", "1e300", "3.141592653589793", "12345678901234567890123", "nan", "Infinity", "1e-400", "0x10", ".5e1", "9007199254740993"], "0123456789.+-eEnaifty x"),
+    "int4[]": (1007, ["{1,2,3}", "{}", "{NULL,-5}", "{{1,2},{3,4}}", '{"1",2}', "[0:2]={1,2,3}", "{ 1 , 2 }"], "0123456789{},\"NUL -[]:= "),
+    "text[]": (1009, ['{a,b,"c d"}', '{"x\\"y",NULL,"NULL"}', "{}", '{"\\\\"}', "{a b,c}", '{"é",中}'], '{}",\\NULabc é'),
+    "bytea": (17, ["\\x0102ff", "\\x", "\\xABcd", "\\x0", "abc", "\\\\000\\\\001", "\\xzz"], "\\x0123456789abcdefABzZ"),
+    "uuid": (2950, ["123e4567-e89b-12d3-a456-426614174000", "{123e4567-e89b-12d3-a456-426614174000}", "123e4567e89b12d3a456426614174000", "urn:uuid:123e4567-e89b-12d3-a456-426614174000", "123E4567-E89B-12D3-A456-42661417400"],
+             "0123456789abcdefABCDEF-{}urn:id"),
+}
+
+
+def mutate(rng, s, alphabet):
+    s = list(s)
+    for _ in range(rng.choice([0, 1, 1, 1, 2, 3])):
+        k = rng.random()
+        pos = rng.randrange(len(s) + 1)
+        if k < 0.4 and s:
+            s[min(pos, len(s) - 1)] = rng.choice(alphabet)
+        elif k < 0.7:
+            s.insert(pos, rng.choice(alphabet))
+        elif k < 0.9 and s:
+            del s[min(pos, len(s) - 1)]
+        elif s:
+            a = min(pos, len(s) - 1)
+            s[a:a] = s[a:a + rng.randrange(1, 4)]
+    return "".join(s)
+
+
+def main():
+    batches = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = random.Random(seed)
+    bad = cells = 0
+    for bi in range(batches):
+        for name, (oid, exemplars, alphabet) in CLASSES.items():
+            cols = [("id", SC.INT8, False, 1), ("v", oid, True, 0)]
+            texts = [mutate(rng, rng.choice(exemplars), alphabet) for _ in range(60)]
+            s = SC.txn([W.insert(42, [str(i), t]) for i, t in enumerate(texts)])
+            buf, offs = np.frombuffer(s.bytes(), dtype=np.uint8), s.offsets
+            # the kernel path alternates: the default choice (k_fused for these narrow frames), k_cells, the multi-pass kernels
+            os.environ.pop("ETLG_FUSED_KERNEL", None); os.environ.pop("ETLG_FORCE_MULTIPASS", None)
+            if bi % 3 == 1:
+                os.environ["ETLG_FUSED_KERNEL"] = "2"
+            elif bi % 3 == 2:
+                os.environ["ETLG_FORCE_MULTIPASS"] = "1"
+            o, d = oracle.Oracle(), Decoder(0)
+            prime = SC.simple_table(cols)
+            prime(o); prime(d)
+            rb = o.decode(buf, offs)
+            b = d.decode(buf, offs, flags=abi.F_OUTPUT_ON_DEVICE)
+            e = b.error
+            got = (e.code, e.frame_index) if e else (0, -1)
+            want = (rb.err_code, rb.err_frame)
+            hb = rb.host_batch()
+            got_rb = None
+            if want[0] == 0 and got[0] == 0:   # (before the arena is downloaded: the hand-off calls take a device-resident batch)
+                try:
+                    r = b.rowbinary(0, [0, 1, 0, 0])
+                    got_rb = ("host", None) if r.status == abi.RB_NEEDS_HOST else ("ok", r.bytes().tobytes())
+                    r.close()
+                except Exception as ex:
+                    got_rb = ("err", getattr(ex, "description", str(ex)))
+            diff = hb.diff(b.host())
+            ok = got == want and not diff
+            if ok and name in ("numeric", "timetz", "time", "timestamptz", "timestamp", "date", "float8", "uuid", "bytea", "int4[]") and want[0] == 0:
+                # the hand-off of the same arena (Display strings, Date32 range, arrays): RowBinary bytes against the oracle's encoder
+                try:
+                    rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in hb.slots[0].cols], [0, 1, 0, 0], abi.CH_MERGE_TREE)
+                    want_rb = ("ok", b"".join(rows))
+                except RB.ConversionError as ce:
+                    want_rb = ("err", str(ce))
+                except RB.NeedsHost:
+                    want_rb = ("host", None)
+                if want_rb != got_rb:
+                    ok = False
+                    diff = ["rowbinary", want_rb[0], got_rb[0], (want_rb[1] or b"")[:60], (got_rb[1] or b"")[:60]]
+            cells += len(texts)
+            if not ok:
+                bad += 1
+                bad_i = want[1] if want[1] >= 0 else -1
+                print("MISMATCH", name, "want", want, "got", got, "diff", diff[:4], "text", repr(texts[bad_i - 1]) if bad_i > 0 else "")
+                open("/tmp/cell_fuzz_%s_%d.txt" % (name.replace("[]", "_a"), bi), "w").write(repr(texts))
+            b.close(); d.close()
+    print("batches", batches, "cells", cells, "mismatching batches", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
