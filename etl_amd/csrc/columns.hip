@@ -579,8 +579,12 @@ __global__ __launch_bounds__(256) void k_arr_count(ColJob j) {
       auto none = [](uint32_t) -> u8* { return nullptr; };
       auto skip = [](uint32_t, bool, const uint32_t*, const u8*) {};
       const uint32_t e = (j.elem_cls == ETLG_TC_STRING || j.elem_cls == ETLG_TC_BYTEA) ? arr_walk<true>(s, n, j.elem_cls, cnt, skip, none) : arr_walk<false>(s, n, j.elem_cls, cnt, skip, none);
-      if (e == ARR_HOST) { defer = true; cnt = 0; }
-      else if (e) { atomicMin(j.err, (unsigned long long)((r << 8) | e)); cnt = 0; }
+      // A row handed back (ARR_HOST) is the host's to finish, and it may turn out to be the batch's first malformed literal. So the call
+      // only fails for a malformed row when no handed-back row precedes it (the host compares the two minima: code 0xFF marks a
+      // hand-back); otherwise the malformed rows are handed back as well, and the consumer — finishing deferred rows in event
+      // order — meets the first problem first, like parse_cell_from_postgres_text at decode time.
+      if (e == ARR_HOST) { defer = true; cnt = 0; atomicMin(j.err, (unsigned long long)((r << 8) | 0xFFu)); }
+      else if (e) { atomicMin(j.err, (unsigned long long)((r << 8) | e)); cnt = 0; defer = true; }
       else valid = true;
     }
     j.lens[r] = cnt;

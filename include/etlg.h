@@ -538,7 +538,8 @@ typedef enum etlg_arrow_kind {
   ETLG_AK_LARGE_BINARY = 11,
   ETLG_AK_TEXT_FORM = 12,   /* json / arrays: the cell's heap entry (the source text), i64 offsets + bytes; the host finishes it. A json /
                              * jsonb cell has been checked on the device to be one JSON value under serde_json's rules (codec/text.rs:
-                             * 126-134): a malformed one fails the call with ETLG_E_JSON at its event, so the host's parse cannot fail.
+                             * 126-134): a malformed one fails the call with ETLG_E_JSON at its event, so the host's parse cannot fail (except behind a list
+                             * row handed back DEFERRED, see ETLG_ROWS_PARSE_ARRAYS: then the host meets it in event order).
                              * (numeric and timetz columns are ETLG_AK_LARGE_UTF8 of their Display strings — `n.to_string()`,
                              * `t.to_string()`, cell_to_string encoding.rs:349-352 — formatted on the device) */
   ETLG_AK_LIST = 13,        /* only with ETLG_ROWS_PARSE_ARRAYS: array literals parsed on the device (parse_cell_from_postgres_text_array,
@@ -589,7 +590,11 @@ typedef struct etlg_columns etlg_columns;
 #define ETLG_ROWS_UPDATE 2u  /* the new row of non-partial Updates */
 #define ETLG_ROWS_PARSE_ARRAYS 4u /* array columns of a fixed-width element class become ETLG_AK_LIST; a malformed literal
                                    * fails the call with the reference's error (ETLG_E_ARRAY_* / the element's parse error,
-                                   * frame_index = the event index), as parse_cell_from_postgres_text does at decode time */
+                                   * frame_index = the event index), as parse_cell_from_postgres_text does at decode time — unless
+                                   * a row the device hands back DEFERRED (an element of more than 40 characters, a float text its
+                                   * rule does not settle) precedes the first malformed one: then the call succeeds and the
+                                   * malformed rows are handed back too, so that the consumer, finishing the deferred rows in event
+                                   * order, meets the first problem first */
 
 /* `batch` must be device-resident (decoded with ETLG_F_OUTPUT_ON_DEVICE, not downloaded) and finished
  * (an ETLG_F_ASYNC batch is synced first). flags: ETLG_F_OUTPUT_ON_DEVICE keeps the buffers in HBM, otherwise

@@ -377,6 +377,30 @@ def test_array_elements_outside_the_fast_paths_hand_the_row_back():
     c.close(); b.close(); d.close()
 
 
+def test_a_handed_back_row_in_front_of_a_malformed_literal():
+    """The first problem of a batch in event order is what the reference reports. A row the device hands back DEFERRED (an element of
+    more than 40 characters — here one that is itself malformed) may be that problem, so a malformed literal BEHIND it does not fail
+    the call: it is handed back as well, and the host, finishing deferred rows in order, raises the right error. Without a handed-back
+    row in front, the malformed literal fails the call as before."""
+    from etl_amd.decoder import EtlError
+    cols2 = [("id", SC.INT8, False, 1), ("a", 1016, True, 0)]
+    long_bad = "{92x337203685477-5807N-9223372036854775808}"      # 42 characters in one element, not an integer: Err at decode time
+    rows = [["1", "{1,2}"], ["2", long_bad], ["3", "=NU\"L}"], ["4", "{7}"]]
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(cols2), buf, offs)
+    c = b.columns(0, parse_arrays=True)
+    rb = columns_to_record_batch(c, names=["id", "a"])
+    assert rb.column(1).to_pylist() == [[1, 2], None, None, [7]]
+    assert list(np.unpackbits(c.host_arrays(1)[1], bitorder="little")[:4]) == [0, 1, 1, 0] and c.column(1).deferred_count == 2
+    c.close(); b.close(); d.close()
+    buf, offs = _stream([W.insert(42, r) for r in (rows[0], rows[2], rows[1])])   # the malformed one first: the call fails on it
+    hb, b, d = _both(SC.simple_table(cols2), buf, offs)
+    with pytest.raises(EtlError) as ei:
+        b.columns(0, parse_arrays=True)
+    assert ei.value.frame_index == 2 and ei.value.description == "Array input missing braces"
+    b.close(); d.close()
+
+
 def test_text_arrays_on_the_device():
     """text[] (and every array type without a dedicated element arm: ArrayCell::String) as LargeList<LargeUtf8>: quotes, escapes,
     NULL vs "NULL", braces inside quotes, empty strings, multi-byte text — the known answers of the reference's own tests
