@@ -94,6 +94,21 @@ def value(cell):
     raise NeedsHost(k)
 
 
+def _ce_days(datestr):
+    """days from 0001-01-01 = 1 (chrono's num_days_from_ce) of the oracle's `[-]Y-MM-DD` repr, years before 1 and beyond 9999 included
+    (datetime.date covers 1..9999 only)."""
+    neg = datestr.startswith("-")
+    y, m, d = (datestr[1:] if neg or datestr.startswith("+") else datestr).split("-")
+    y = -int(y) if neg else int(y)
+    m, d = int(m), int(d)
+    y -= m <= 2
+    era = (y if y >= 0 else y - 399) // 400
+    yoe = y - era * 400
+    doy = (153 * (m + (-3 if m > 2 else 9)) + 2) // 5 + d - 1
+    doe = yoe * 365 + yoe // 4 - yoe // 100 + doy
+    return era * 146097 + doe - 719468 + CE_DAYS_1970   # days since 1970-01-01 -> from CE
+
+
 def array_elements(type_oid, text):
     """The elements of an array literal as the cell tuples value() takes, through the C++ oracle's parser
     (parse_array_text, oracle_codec.hpp — codec/text.rs:228-312) and its repr. Only for element classes whose repr is unambiguous
@@ -119,7 +134,7 @@ def array_elements(type_oid, text):
                 raise NeedsHost("NaN bits are not in the repr")
             out.append((k, int(v, 16)))
         elif k == "Date":
-            out.append(("Date", dt.date.fromisoformat(v).toordinal()))
+            out.append(("Date", _ce_days(v)))
         elif k == "Time":
             h, m, rest = v.split(":")
             sec, ns = rest.split(".")
@@ -128,7 +143,7 @@ def array_elements(type_oid, text):
             d, t = v.split(" ")
             h, m, rest = t.split(":")
             sec, ns = rest.split(".")
-            out.append((k, dt.date.fromisoformat(d).toordinal(), int(h) * 3600 + int(m) * 60 + int(sec), int(ns)))
+            out.append((k, _ce_days(d), int(h) * 3600 + int(m) * 60 + int(sec), int(ns)))
         elif k == "Uuid":
             out.append(("Uuid", bytes.fromhex(v)))
         else:

@@ -32,6 +32,11 @@ CLASSES = {
     "float8": (701, ["1.5", "-0.25", "1e300", "3.141592653589793", "12345678901234567890123", "nan", "Infinity", "1e-400", "0x10", ".5e1", "9007199254740993"], "0123456789.+-eEnaifty x"),
     "int4[]": (1007, ["{1,2,3}", "{}", "{NULL,-5}", "{{1,2},{3,4}}", '{"1",2}', "[0:2]={1,2,3}", "{ 1 , 2 }"], "0123456789{},\"NUL -[]:= "),
     "text[]": (1009, ['{a,b,"c d"}', '{"x\\"y",NULL,"NULL"}', "{}", '{"\\\\"}', "{a b,c}", '{"é",中}'], '{}",\\NULabc é'),
+    "float8[]": (1022, ["{1.5,-0.25,NULL}", "{1e300,nan}", "{}", '{"3.14"}', "{Infinity,-inf}", "{12345678901234567890123}"], '0123456789{},".NULnaifty+-eE '),
+    "date[]": (1182, ["{2024-02-29,NULL}", "{0001-01-01}", "{1899-12-31}", "{2300-01-01,2024-1-2}", "{}", '{"2024-01-02"}', "{infinity}"], '0123456789{},"-NULinfty BC'),
+    "timestamptz[]": (1185, ['{"2024-01-02 03:04:05+00",NULL}', '{"2024-01-02 03:04:05.123456+05:30"}', "{}", '{"1999-12-31 23:59:60+00"}'], '0123456789{},"-+:. NULZT'),
+    "time[]": (1183, ["{12:30:45.123456,NULL}", "{23:59:60}", "{}", "{1:2:3}"], '0123456789{},":.NUL '),
+    "uuid[]": (2951, ["{123e4567-e89b-12d3-a456-426614174000,NULL}", "{}", "{123e4567e89b12d3a456426614174000}"], '0123456789abcdefABCDEF{},"-NUL'),
     "bytea": (17, ["\\x0102ff", "\\x", "\\xABcd", "\\x0", "abc", "\\\\000\\\\001", "\\xzz"], "\\x0123456789abcdefABzZ"),
     "uuid": (2950, ["123e4567-e89b-12d3-a456-426614174000", "{123e4567-e89b-12d3-a456-426614174000}", "123e4567e89b12d3a456426614174000", "urn:uuid:123e4567-e89b-12d3-a456-426614174000", "123E4567-E89B-12D3-A456-42661417400"],
              "0123456789abcdefABCDEF-{}urn:id"),
@@ -160,7 +165,7 @@ def main():
                     got_rb = ("err", getattr(ex, "description", str(ex)))
             diff = hb.diff(b.host())
             ok = got == want and not diff
-            if ok and name in ("numeric", "timetz", "time", "timestamptz", "timestamp", "date", "float8", "uuid", "bytea", "int4[]") and want[0] == 0:
+            if ok and name in ("numeric", "timetz", "time", "timestamptz", "timestamp", "date", "float8", "uuid", "bytea", "int4[]", "float8[]", "date[]", "timestamptz[]", "time[]", "uuid[]") and want[0] == 0:
                 # the hand-off of the same arena (Display strings, Date32 range, arrays): RowBinary bytes against the oracle's encoder
                 try:
                     rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in hb.slots[0].cols], [0, 1, 0, 0], abi.CH_MERGE_TREE)
