@@ -163,8 +163,29 @@ def main():
                     r.close()
                 except Exception as ex:
                     got_rb = ("err", getattr(ex, "description", str(ex)))
+            got_pb = None
+            if want[0] == 0 and got[0] == 0:
+                try:
+                    r = b.protobuf(0)
+                    got_pb = ("host", None) if r.status == abi.RB_NEEDS_HOST else ("ok", r.bytes().tobytes())
+                    r.close()
+                except Exception as ex:
+                    got_pb = ("err", getattr(ex, "detail", None) or getattr(ex, "description", str(ex)))
             diff = hb.diff(b.host())
             ok = got == want and not diff
+            if ok and want[0] == 0 and "[" not in name:
+                # BigQuery rows of the same arena (cell_encode_prost; numeric scale validation)
+                from oracle import protobuf as PB
+                try:
+                    rows, idx, host = PB.event_rows(hb.materialize(), 0, cols, "PrimaryKey")
+                    want_pb = ("ok", b"".join(rows))
+                except PB.UnsupportedValueInDestination as ue:
+                    want_pb = ("err", str(ue))
+                except RB.NeedsHost:
+                    want_pb = ("host", None)
+                if want_pb != got_pb:
+                    ok = False
+                    diff = ["protobuf", want_pb[0], got_pb[0] if got_pb else None, (want_pb[1] or b"")[:80], (got_pb[1] or b"")[:80] if got_pb else None]
             if ok and name in ("numeric", "timetz", "time", "timestamptz", "timestamp", "date", "float8", "uuid", "bytea", "int4[]", "float8[]", "date[]", "timestamptz[]", "time[]", "uuid[]") and want[0] == 0:
                 # the hand-off of the same arena (Display strings, Date32 range, arrays): RowBinary bytes against the oracle's encoder
                 try:
