@@ -95,3 +95,14 @@ def test_copy_mutation_fuzz(simt_lib):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=660)
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+def test_value_codec_fuzz(simt_lib):
+    """tools/cell_fuzz.py on the emulated kernels: mutated texts of every value class (temporal shapes around chrono's grammar, json
+    validity, numeric / float forms, array literals, bytea, uuid) through the decode kernels on three kernel paths, and the decoded
+    arena through the Arrow columns, RowBinary and BigQuery rows — against the oracle and its hand-off restatements."""
+    env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="600")
+    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cell_fuzz.py"), "3", "7"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=660)
+    assert out.returncode == 0 and "mismatching batches 0" in out.stdout and "MISMATCH" not in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]

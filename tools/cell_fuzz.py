@@ -163,6 +163,15 @@ def main():
                     r.close()
                 except Exception as ex:
                     got_rb = ("err", getattr(ex, "description", str(ex)))
+            got_cols = None
+            if want[0] == 0 and got[0] == 0:   # Arrow-layout columns of the same arena (before it is downloaded)
+                try:
+                    from etl_amd.arrow import columns_to_record_batch
+                    cc = b.columns(0)
+                    got_cols = columns_to_record_batch(cc, names=["id", "v"], on_text="binary")
+                    cc.close()
+                except Exception as ex:
+                    got_cols = ("err", getattr(ex, "code", None), getattr(ex, "frame_index", None))
             got_pb = None
             if want[0] == 0 and got[0] == 0:
                 try:
@@ -173,6 +182,25 @@ def main():
                     got_pb = ("err", getattr(ex, "detail", None) or getattr(ex, "description", str(ex)))
             diff = hb.diff(b.host())
             ok = got == want and not diff
+            if ok and want[0] == 0:
+                from etl_amd.arrow import rows_to_record_batch
+                from tests.test_gpu_columns import _same
+                want_cols = rows_to_record_batch(hb, 0, names=["id", "v"], on_text="binary")
+                if name == "jsonb":   # json cells are validated by the hand-off call (serde_json's grammar): the first cell that is not one JSON value fails it
+                    verdicts = [oracle.parse_text_cell(oid, t) for t in texts]
+                    firstbad = next((i for i, v in enumerate(verdicts) if v.startswith("Err(")), None)
+                    if firstbad is not None:
+                        want_cols = ("err", int(verdicts[firstbad][4:-1]), firstbad + 1)
+                if isinstance(want_cols, tuple) or isinstance(got_cols, tuple):
+                    if want_cols != got_cols:
+                        ok = False
+                        diff = ["columns", str(want_cols)[:80], str(got_cols)[:80]]
+                else:
+                    try:
+                        _same(want_cols, got_cols)
+                    except AssertionError as ae:
+                        ok = False
+                        diff = ["columns", str(ae)[:200]]
             if ok and want[0] == 0 and "[" not in name:
                 # BigQuery rows of the same arena (cell_encode_prost; numeric scale validation)
                 from oracle import protobuf as PB
