@@ -163,6 +163,13 @@ def main():
                     r.close()
                 except Exception as ex:
                     got_rb = ("err", getattr(ex, "description", str(ex)))
+            got_hints = None
+            if want[0] == 0 and got[0] == 0:   # Event::size_hint per event, computed on the device from the arena
+                from oracle import size_hint as SH
+                sm = abi.SizeModel()
+                for kk, vv in SH.MODEL.items():
+                    setattr(sm, kk, vv)
+                got_hints = b.size_hints(sm)
             got_cols = None
             if want[0] == 0 and got[0] == 0:   # Arrow-layout columns of the same arena (before it is downloaded)
                 try:
@@ -182,6 +189,13 @@ def main():
                     got_pb = ("err", getattr(ex, "detail", None) or getattr(ex, "description", str(ex)))
             diff = hb.diff(b.host())
             ok = got == want and not diff
+            if ok and want[0] == 0:
+                from oracle import size_hint as SH
+                want_hints = np.array([SH.event_hint(e, hb.slots, SH.MODEL) for e in hb.materialize()], dtype=np.uint64)
+                if not np.array_equal(want_hints, got_hints):
+                    ok = False
+                    w = np.flatnonzero(want_hints != got_hints)[:3]
+                    diff = ["size_hints", [(int(i), int(want_hints[i]), int(got_hints[i])) for i in w]]
             if ok and want[0] == 0:
                 from etl_amd.arrow import rows_to_record_batch
                 from tests.test_gpu_columns import _same
