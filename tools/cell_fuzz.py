@@ -65,10 +65,18 @@ ARRAYS = {1007: ["{1,NULL,3}", "{}", "[1:2]={1,2}", '{"1",2}', "{+5,-0}", "{-214
           1000: ["{t,f,NULL}", "{}", '{"t"}', "{true}"], 1028: ["{0,4294967295}", "{NULL,7}", "{}"]}
 
 
+VAR_ARRAYS = {1231: ["{0,-12.5,NULL}", "{123456789.000100,NaN}", "{1e5,0.000012}", "{}", '{"1.5"}', "{Infinity,-inf}", "{1_000.5, 42 }"],
+              1001: ['{"\\\\x0102ff",NULL}', '{"\\\\x"}', "{}", '{"\\\\xABcd","\\\\x00"}', "{\\\\x41}"],
+              1270: ["{12:30:45.123456+02,NULL}", "{23:59:59-07:30}", "{}", '{"00:00:00+15:59:59"}']}
+
+
 def oracle_list(oid, text):
     r = oracle.parse_text_cell(oid, text)
     if not r.startswith("Array["):
         return r
+    if oid in VAR_ARRAYS:   # numeric[] / bytea[] / timetz[]: what the sinks hand to Arrow (Display strings, decoded bytes)
+        from tests.test_gpu_columns import _oracle_display_list
+        return _oracle_display_list(oid, text)
     body = r[6:-1]
     out = []
     for e in ([] if not body else body.split(",")):
@@ -83,9 +91,9 @@ def fuzz_arrays(rng, batches):
     from etl_amd.decoder import EtlError
     bad = cells = 0
     for bi in range(batches):
-        for oid, exemplars in ARRAYS.items():
+        for oid, exemplars in list(ARRAYS.items()) + list(VAR_ARRAYS.items()):
             cols = [("id", SC.INT8, False, 1), ("v", oid, True, 0)]
-            texts = [mutate(rng, rng.choice(exemplars), '0123456789{},"NULnul -+[]:=tf\\ ') for _ in range(40)]
+            texts = [mutate(rng, rng.choice(exemplars), '0123456789{},"NULnul -+[]:=tf\\ .eExabcdINy_') for _ in range(40)]
             s = SC.txn([W.insert(42, [str(i), t]) for i, t in enumerate(texts)])
             buf, offs = np.frombuffer(s.bytes(), dtype=np.uint8), s.offsets
             d = Decoder(0)
