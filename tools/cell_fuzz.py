@@ -67,13 +67,17 @@ ARRAYS = {1007: ["{1,NULL,3}", "{}", "[1:2]={1,2}", '{"1",2}', "{+5,-0}", "{-214
 
 VAR_ARRAYS = {1231: ["{0,-12.5,NULL}", "{123456789.000100,NaN}", "{1e5,0.000012}", "{}", '{"1.5"}', "{Infinity,-inf}", "{1_000.5, 42 }"],
               1001: ['{"\\\\x0102ff",NULL}', '{"\\\\x"}', "{}", '{"\\\\xABcd","\\\\x00"}', "{\\\\x41}"],
-              1270: ["{12:30:45.123456+02,NULL}", "{23:59:59-07:30}", "{}", '{"00:00:00+15:59:59"}']}
+              1270: ["{12:30:45.123456+02,NULL}", "{23:59:59-07:30}", "{}", '{"00:00:00+15:59:59"}'],
+              1009: ['{a,"b c",NULL,"null",nUlL}', '{"x\\"y","a,b","{}"}', '{é,"\\\\"}', "{ a , b }", '{"",x}', "{abcd,abcde,nulls,null}", "[0:1]={x,y}", "{}"]}
 
 
 def oracle_list(oid, text):
     r = oracle.parse_text_cell(oid, text)
     if not r.startswith("Array["):
         return r
+    if oid == 1009:          # text[]: the repr is String("...") | NULL; unambiguous as long as no text holds `")` (the alphabet has no parenthesis)
+        import re
+        return [None if m.group(0) == "NULL" else m.group(1) for m in re.finditer(r'NULL(?=,|\])|String\("(.*?)"\)(?=,|\]$)', r[6:], flags=re.S)]
     if oid in VAR_ARRAYS:   # numeric[] / bytea[] / timetz[]: what the sinks hand to Arrow (Display strings, decoded bytes)
         from tests.test_gpu_columns import _oracle_display_list
         return _oracle_display_list(oid, text)
