@@ -12,6 +12,7 @@
 #include <vector>
 
 namespace simt {
+static std::vector<uint32_t> g_order;   // lane order of the current scheduling round (ETLG_SIMT_ORDER)
 
 namespace {
 
@@ -144,9 +145,21 @@ void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void
       makecontext(&L.ctx, tramp, 0);
     }
     for (;;) {
-      // run every runnable lane to its next rendezvous (or to the end of the kernel)
+      // run every runnable lane to its next rendezvous (or to the end of the kernel). The order in which the lanes of a workgroup
+      // run between two rendezvous is not defined on the GPU; ETLG_SIMT_ORDER=reverse | shuffle makes the emulator take another
+      // one than 0, 1, 2, ... (a kernel whose result depends on it has a race: the bytea[] walker of round 3 had one that only
+      // the MI355X showed). Workgroups stay in blockIdx order: the look-back kernels wait for their predecessors.
       bool ran = false;
-      for (uint32_t t = 0; t < block; t++) {
+      static const char* order_env = getenv("ETLG_SIMT_ORDER");
+      static uint64_t order_rng = 0x9E3779B97F4A7C15ull;
+      std::vector<uint32_t>& ord = g_order;
+      if (ord.size() != block) { ord.resize(block); for (uint32_t t = 0; t < block; t++) ord[t] = t; }
+      if (order_env && order_env[0] == 'r') { for (uint32_t t = 0; t < block; t++) ord[t] = block - 1 - t; }
+      else if (order_env && order_env[0] == 's') {
+        for (uint32_t t = block; t > 1; t--) { order_rng = order_rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(ord[t - 1], ord[(uint32_t)((order_rng >> 33) % t)]); }
+      }
+      for (uint32_t ti = 0; ti < block; ti++) {
+        const uint32_t t = ord[ti];
         Lane& L = g_lanes[t];
         if (L.state != RUN) continue;
         g_cur = &L; g_view = &L.view;
