@@ -670,6 +670,7 @@ struct RbCount {
   DEV void varint64(uint64_t v) { do { n++; v >>= 7; } while (v); }
   DEV void put32(uint32_t) { n += 4; }
   DEV void put64(uint64_t) { n += 8; }
+  DEV void zeros(uint32_t k) { n += k; }
   DEV void bytes(const u8*, uint32_t len) { n += len; }
   DEV void hex(const u8*, uint32_t len) { n += 2 * len; }
 };
@@ -679,6 +680,7 @@ struct RbWrite {
   DEV void varint64(uint64_t v) { while (v >= 0x80) { *p++ = (u8)(v | 0x80); v >>= 7; } *p++ = (u8)v; }
   DEV void put32(uint32_t v) { for (int k = 0; k < 4; k++) *p++ = (u8)(v >> (8 * k)); }
   DEV void put64(uint64_t v) { for (int k = 0; k < 8; k++) *p++ = (u8)(v >> (8 * k)); }
+  DEV void zeros(uint32_t k) { for (uint32_t i = 0; i < k; i++) p[i] = 0; p += k; }
   DEV void bytes(const u8* s, uint32_t len) { for (uint32_t k = 0; k < len; k++) *p++ = s[k]; }
   DEV void hex(const u8* s, uint32_t len) {   // bytes_to_hex, lowercase (:176-185)
     for (uint32_t k = 0; k < len; k++) { const uint32_t b = s[k], h = b >> 4, l = b & 15; *p++ = (u8)(h < 10 ? '0' + h : 'a' + h - 10); *p++ = (u8)(l < 10 ? '0' + l : 'a' + l - 10); }
@@ -729,6 +731,20 @@ DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
   }
 }
 
+// default_cell(typ) (clickhouse/core.rs:1481-1517) in RowBinary is a run of zero bytes: the type's width for the fixed-width classes
+// (false, 0, 0.0, Date32 day 0 = 1970-01-01, DateTime64 0 = the epoch, Uuid::nil()), the varint 0 of an empty Array / an empty String
+// (numeric, time, timetz, interval, bytea, text ...) for the rest. One length + one zero run instead of a switch over put32 / put64 /
+// put64 x 2: hipcc (ROCm 7.2) compiled that switch inside rb_row's column loop with the output pointer left undefined behind the
+// TIMESTAMP / TIMESTAMPTZ arm (k_rb_rows wrote through a stale register on the MI355X; profiles/r04_rowbinary_tombstone_fault.txt).
+DEV uint32_t rb_default_zero_bytes(uint32_t cls) {
+  uint32_t n = 1;                                                                                          // BOOL, and every String / Array class
+  if (cls == ETLG_TC_I16) n = 2;
+  if (cls == ETLG_TC_I32 || cls == ETLG_TC_U32 || cls == ETLG_TC_F32 || cls == ETLG_TC_DATE) n = 4;
+  if (cls == ETLG_TC_I64 || cls == ETLG_TC_F64 || cls == ETLG_TC_TIMESTAMP || cls == ETLG_TC_TIMESTAMPTZ) n = 8;
+  if (cls == ETLG_TC_UUID) n = 16;
+  return n;
+}
+
 template <class S>
 DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or column << 8 | code of the cell that fails the row
   // The reference converts every cell of every pending row first (cell_to_clickhouse_value, clickhouse/core.rs:1193-1203: Date32
@@ -753,14 +769,7 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
         continue;
       } else {                                                    // default_cell(typ)
         if (nullable) s.put(0);
-        switch (cls) {
-          case ETLG_TC_BOOL: s.put(0); break;
-          case ETLG_TC_I16: s.put(0); s.put(0); break;
-          case ETLG_TC_I32: case ETLG_TC_U32: case ETLG_TC_F32: case ETLG_TC_DATE: s.put32(0); break;   // Date32: 1970-01-01 is day 0
-          case ETLG_TC_I64: case ETLG_TC_F64: case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: s.put64(0); break;   // DateTime64: the epoch
-          case ETLG_TC_UUID: s.put64(0); s.put64(0); break;   // Uuid::nil()
-          default: s.put(0); break;   // an empty Array (varint count 0) / an empty String (numeric, time, timetz, interval, bytea, text ...)
-        }
+        s.zeros(rb_default_zero_bytes(cls));
         continue;
       }
     }

@@ -629,9 +629,11 @@ int32_t etlg_control_stream(etlg_ctx* c, const uint8_t* buf, size_t len, const u
   { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
   launch(c, 0, p);   // k_classify: envelope + tag of every frame
   constexpr uint32_t kCap = 1u << 16;   // control frames of one range the list holds
-  // scratch: hdr (2 words) | list | span (2 per frame) | keep frames (3 per frame) | lens | out offsets
+  // scratch: hdr (16 words) | list (kCap) | span (2 per frame) | keep frames (<= 3 per frame: the frame, its Begin, its Commit) |
+  // lens (3 per frame) | out offsets (3 per frame + 1): 16 + 12 kCap + 1 words
   ScratchBlk blk{c};
-  HIPCHK(c, blk_take(c, (size_t)kCap * 4 * 10 + 256, false, &blk.p, &blk.cap));
+  constexpr size_t kCtlWords = 16 + 12 * (size_t)kCap + 1;
+  HIPCHK(c, blk_take(c, kCtlWords * 4 + 256, false, &blk.p, &blk.cap));
   uint32_t* d_hdr = (uint32_t*)blk.p;
   uint32_t* d_list = d_hdr + 16; uint32_t* d_span = d_list + kCap; uint32_t* d_keep = d_span + 2 * kCap;
   uint32_t* d_lens = d_keep + 3 * kCap; uint32_t* d_oo = d_lens + 3 * kCap;
@@ -660,6 +662,7 @@ int32_t etlg_control_stream(etlg_ctx* c, const uint8_t* buf, size_t len, const u
   std::sort(keep.begin(), keep.end());
   keep.erase(std::unique(keep.begin(), keep.end()), keep.end());
   const uint32_t nk = (uint32_t)keep.size();   // <= 3 n
+  if ((size_t)nk > 3 * (size_t)kCap) return lib_error(c, ETLG_Unsupported, "control stream of this range holds more frames than its scratch block");
   std::vector<uint32_t> lens(nk), oo((size_t)nk + 1, 0);
   HIPCHK(c, hipMemcpyAsync(d_keep, keep.data(), (size_t)nk * 4, hipMemcpyHostToDevice, s));
   etlg_k_ctl_gather(p.in, p.offs, d_keep, nk, d_lens, nullptr, nullptr, s);
@@ -773,6 +776,8 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   //      before it (double buffering: the caller fills its next buffer meanwhile). The caller keeps the host buffers untouched until
   //      the batch is synced, as for every ASYNC batch (include/etlg.h).
   void* stage_blk = nullptr; size_t stage_cap = 0; hipEvent_t h2d_done = nullptr;
+  // (in place before the first HIP call below: an early return gives the block and the event back)
+  struct StageGuard { etlg_ctx* c; void*& p; size_t& cap; hipEvent_t& ev; ~StageGuard() { if (p) blk_give(c, c->gen, p, cap, false); if (ev) c->ev_pool.push_back(ev); } } stage_guard{c, stage_blk, stage_cap, h2d_done};
   if ((flags & ETLG_F_ASYNC) && out_dev && !in_dev && !scan && len && nframes && !c->copy.active && !c->force_multipass && len < (1ull << 31)) {
     const size_t o_offs = (len + 16 + 255) & ~(size_t)255;   // the kernels' readers may touch up to 16 bytes past the input
     HIPCHK(c, blk_take(c, o_offs + (nframes + 1) * 4 + 64, false, &stage_blk, &stage_cap));
@@ -791,7 +796,6 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     in_dev = true;
     c->staged_async++;
   }
-  struct StageGuard { etlg_ctx* c; void*& p; size_t& cap; hipEvent_t& ev; ~StageGuard() { if (p) blk_give(c, c->gen, p, cap, false); if (ev) c->ev_pool.push_back(ev); } } stage_guard{c, stage_blk, stage_cap, h2d_done};
   // ASYNC batches are chained on the device (DecParams.carry) and may be decoded again when they are synced, so everything
   // they read must still be there then: device-resident input AND sidecar (the context's staging and scan buffers are shared
   // by all batches). Anything else is decoded synchronously; etlg_batch_sync on such a batch returns its stored result.
