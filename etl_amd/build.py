@@ -14,7 +14,10 @@ SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "plan.hip", "scan.hip", "cop
 # k_cells and the rest are not
 OPT = {"fused.hip": "-Os"}
 DEFS = {}   # no per-source feature flags: one code path per kernel
-DEPS = SOURCES + ["../build.py", "dev_types.h", "host_state.h", "host_control.inc", "host_handoff.inc", "host_orchestrate.inc", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "plan.hip", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
+# what every object depends on beside its own source (the shared headers); host.cpp also on its parts
+COMMON = ["../build.py", "dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
+EXTRA = {"fused.hip": ["fixed_tile.hip.h"], "host.cpp": ["host_state.h", "host_control.inc", "host_handoff.inc", "host_orchestrate.inc"]}
+DEPS = SOURCES + COMMON + [d for v in EXTRA.values() for d in v]   # (the library as a whole)
 
 
 def _stale(target, deps):
@@ -31,7 +34,7 @@ def build_native(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        if force or _stale(obj, deps):
+        if force or _stale(obj, [os.path.join(CSRC, d) for d in [src] + COMMON + EXTRA.get(src, [])]):
             cmd = [HIPCC, "--offload-arch=gfx950", OPT.get(src, "-O3"), "-std=c++17", "-fPIC", "-Wall",
                    "-Wno-unused-function"] + DEFS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
             if src.endswith(".cpp"):
