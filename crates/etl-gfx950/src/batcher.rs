@@ -139,6 +139,13 @@ impl StagingBatcher {
         self.cur.room_for(payload.len())
     }
 
+    /// Could the payload be staged at all — does it fit an EMPTY buffer of the ring? A single XLogData message may be larger than
+    /// any staging buffer (a pgoutput tuple can approach 1 GB; the ring holds 64 MiB buffers): such a message never goes through
+    /// `push_xlog_data`; the caller drains the GPU stage and hands it to the reference's own per-message path.
+    pub fn can_stage(&self, payload: &[u8]) -> bool {
+        payload.len() + 5 <= self.cap_bytes
+    }
+
     /// Stages the payload of one CopyData message (`payload[0] == b'w'` for XLogData; keepalives stay with the caller).
     /// Re-creates the 5-byte CopyData header tokio-postgres stripped. An XLogData message is at least its 25-byte header
     /// plus the pgoutput tag (postgres-replication: `XLogDataBody`, call site apply.rs:2037-2051).

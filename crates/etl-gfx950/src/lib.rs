@@ -126,7 +126,7 @@ impl GpuDecoder {
             let e = self.last_error();
             return Err((staged, e));
         }
-        Ok(InFlight { batch, staged })
+        Ok(InFlight { ctx: self.ctx, batch, staged: Some(staged) })
     }
 
     /// Has the batch been decoded? Never blocks... it is `finish` that waits. (The C ABI has no non-blocking probe: a loop that
@@ -136,7 +136,8 @@ impl GpuDecoder {
     /// (`etlg_batch_download`) and materialises the events. On a decode error (fail-fast, apply.rs:2475-2481) the events BEFORE the
     /// failing frame are returned with the error. The staged buffer comes back for `StagingBatcher::recycle`.
     pub fn finish(&mut self, f: InFlight, schemas: &mut dyn materialize::SlotSchemas) -> (Vec<Event>, StagedBatch, EtlResult<()>) {
-        let InFlight { batch, staged } = f;
+        let mut f = f;
+        let (batch, staged) = f.take();
         let rc = unsafe { etlg_batch_sync(self.ctx, batch) };
         let status = if rc == ETLG_OK { Ok(()) } else { Err(self.last_error()) };
         if unsafe { etlg_batch_download(self.ctx, batch) } != ETLG_OK {
@@ -166,15 +167,38 @@ impl GpuDecoder {
 
 /// A batch between `decode_async` and `finish`: the library's handle plus the pinned buffer it is reading.
 pub struct InFlight {
+    ctx: *mut etlg_ctx,
     batch: *mut etlg_batch,
-    staged: StagedBatch,
+    staged: Option<StagedBatch>,
 }
 
 unsafe impl Send for InFlight {}
 
 impl InFlight {
     pub fn frames(&self) -> &[crate::batcher::FrameMeta] {
-        &self.staged.meta
+        &self.staged.as_ref().expect("batch already collected").meta
+    }
+
+    /// Takes the handle and the staged buffer out (for `finish`); what is left drops as a no-op.
+    fn take(&mut self) -> (*mut etlg_batch, StagedBatch) {
+        (std::mem::replace(&mut self.batch, ptr::null_mut()), self.staged.take().expect("batch already collected"))
+    }
+}
+
+/// A batch that is dropped without `finish` — an apply loop that bails out with batches still queued (`status?` in gpu_collect) — must
+/// not release its pinned buffer while the library's upload or kernels may still be reading it, and must not leave the context's
+/// ASYNC chain with an unfinished link: the batch is waited for and freed FIRST, the staged buffer (hipHostFree) goes after it.
+/// The decoder has to outlive its in-flight batches (drop the queue before the `GpuDecoder`).
+impl Drop for InFlight {
+    fn drop(&mut self) {
+        if !self.batch.is_null() {
+            unsafe {
+                let _ = etlg_batch_sync(self.ctx, self.batch);
+                etlg_batch_free(self.batch);
+            }
+            self.batch = ptr::null_mut();
+        }
+        // self.staged drops here, after the library is done with it
     }
 }
 

@@ -401,6 +401,29 @@ def test_a_handed_back_row_in_front_of_a_malformed_literal():
     b.close(); d.close()
 
 
+def test_hand_back_and_malformed_literal_in_one_row():
+    """Inside one row the reference parses the columns in order (convert_tuple_to_row): a cell the device hands back DEFERRED in an EARLIER
+    column of a row ranks before a malformed literal in a LATER column of the same row — the call succeeds and both are the host's; the
+    other way round (the malformed literal in the earlier column) the call fails with the literal's error."""
+    from etl_amd.decoder import EtlError
+    cols3 = [("id", SC.INT8, False, 1), ("a", 1016, True, 0), ("b", 1016, True, 0)]
+    long_el = "{" + "0" * 41 + "7}"          # one element of 42 characters: handed back (the host accepts it: leading zeros)
+    bad = "=NU\"L}"                          # "Array input missing braces"
+    buf, offs = _stream([W.insert(42, ["1", "{1}", "{2}"]), W.insert(42, ["2", long_el, bad]), W.insert(42, ["3", "{5}", "{6}"])])
+    hb, b, d = _both(SC.simple_table(cols3), buf, offs)
+    c = b.columns(0, parse_arrays=True)
+    rb = columns_to_record_batch(c, names=["id", "a", "b"])
+    assert rb.column(1).to_pylist() == [[1], None, [5]] and rb.column(2).to_pylist() == [[2], None, [6]]
+    assert c.column(1).deferred_count == 1 and c.column(2).deferred_count == 1
+    c.close(); b.close(); d.close()
+    buf, offs = _stream([W.insert(42, ["1", "{1}", "{2}"]), W.insert(42, ["2", bad, long_el])])
+    hb, b, d = _both(SC.simple_table(cols3), buf, offs)
+    with pytest.raises(EtlError) as ei:
+        b.columns(0, parse_arrays=True)
+    assert ei.value.frame_index == 2 and ei.value.description == "Array input missing braces"
+    b.close(); d.close()
+
+
 def test_text_arrays_on_the_device():
     """text[] (and every array type without a dedicated element arm: ArrayCell::String) as LargeList<LargeUtf8>: quotes, escapes,
     NULL vs "NULL", braces inside quotes, empty strings, multi-byte text — the known answers of the reference's own tests
