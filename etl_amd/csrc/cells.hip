@@ -957,6 +957,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
     for (uint32_t i = tid; i < per; i += NW * 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
   if (!(pg.flags & 16u) && !load_carry(pg)) return;  // ASYNC chain: the state the batch before this one left (flags bit 4: read late, by the tiles that need it — txn_lookback)
+  if constexpr (COPYK) { if (blockIdx.x == 0 && tid == 0) pg.res->copy_span = pg.offs[pg.nframes] - pg.offs[0]; }
   DecParams p = pg;
   uint32_t dbg_u;
   ETLG_SCALAR_COPY(dbg_u, q.dbg);

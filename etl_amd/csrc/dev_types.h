@@ -82,7 +82,8 @@ struct DevResult {
   unsigned long long pay_shard[32][3];
   // plan.hip: set (release) by the batch's last tile once out_in_txn / out_final_lsn / out_next_ord above are written: a batch that runs
   // beside this one on the second stream (DecParams.flags bit 4) polls it before it reads them
-  uint32_t carry_ready, _pad_ready;
+  uint32_t carry_ready;
+  uint32_t copy_span;   // k_copy_cells: offs[nrows] - offs[0], the bytes of the rows (TableCopyPayloadMetadata) — travels with the result block instead of two 4-byte copies
 };
 
 // Side arguments of the fused single-pass kernel (fused.hip).

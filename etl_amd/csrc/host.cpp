@@ -749,7 +749,8 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
     etlg_batch* b = *out;
     const uint64_t done = b->v.n_frames;
     uint32_t o[2] = {0, 0};
-    if (in_dev) {
+    if (rc == ETLG_OK && j.direct && b->copy.direct && done == nrows && b->used_cells && b->copy_span) { o[1] = b->copy_span; }   // the rows -> arena kernel measured them (no device round trips here)
+    else if (in_dev) {
       (void)hipMemcpy(&o[0], row_offsets, 4, hipMemcpyDeviceToHost);
       (void)hipMemcpy(&o[1], row_offsets + done, 4, hipMemcpyDeviceToHost);
     } else { o[0] = row_offsets[0]; o[1] = row_offsets[done]; }

@@ -392,6 +392,7 @@ struct etlg_batch {
   hipEvent_t done = nullptr;  // recorded behind the copy of the result block: syncing a batch waits for IT, not for the whole stream
   DevResult* h_res = nullptr;  // pinned, from the context's pool
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
+  uint32_t copy_span = 0;  // table-copy batch decoded by k_copy_cells: the bytes of its rows (DevResult.copy_span)
   DevResult* d_res_blk = nullptr;  // this batch's result block on the device
   bool used_cells = false; // ... and it was k_cells
   bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
