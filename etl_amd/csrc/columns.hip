@@ -280,7 +280,9 @@ DEV bool json_valid(const u8* s, uint32_t n) {
 DEV uint32_t numeric_str_len(const u8* ent);
 DEV uint32_t timetz_str_len(const u8* slot);
 // var-len columns, pass 1: validity / deferred words + the byte length of every row's entry
-__global__ __launch_bounds__(256) void k_col_lens(ColJob j) {
+// (blk: the block's sum of lengths, for the offsets scan — a launch of its own, k_col_len_blocks, for the callers that have no such pass)
+__global__ __launch_bounds__(256) void k_col_lens(ColJob j, unsigned long long* blk) {
+  __shared__ uint64_t lds_sum[4];
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = r < j.n_rows;
   uint32_t st = ETLG_CELL_NULL, len = 0;
@@ -308,6 +310,8 @@ __global__ __launch_bounds__(256) void k_col_lens(ColJob j) {
     if (nulls) atomicAdd(j.null_count, (unsigned long long)nulls);
     if (nd) atomicAdd(j.deferred_count, (unsigned long long)nd);
   }
+  const uint64_t t = block_sum64(len, lds_sum);
+  if (threadIdx.x == 0) blk[blockIdx.x] = t;
 }
 
 // lens (u32) -> offsets (i64), three steps like k_col_count / k_col_scan / k_col_rows
@@ -340,22 +344,27 @@ __global__ __launch_bounds__(256) void k_col_offsets(const uint32_t* lens, uint6
 // var-len columns, pass 2: one wave per 64 rows; the wave moves one row at a time, 4 bytes per lane per step where both ends
 // allow it (heap entries start 4-byte aligned; the destination is wherever the previous row ended)
 __global__ __launch_bounds__(256) void k_col_copy(ColJob j) {
+  // A wave takes 64 consecutive rows (their bytes are consecutive in `values`): eight lanes per row, eight rows at a time, eight bytes
+  // per lane and step. (One row at a time with a byte per lane was a load and a store instruction per row of up to 64 bytes: 44 us per
+  // text column of a cfg3 batch, profiles/r04q.)
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   if (r0 >= j.n_rows) return;
   const uint64_t r = r0 + lane;
   uint32_t len = 0, src = 0; int64_t dst = 0;
   if (r < j.n_rows) { len = j.lens[r]; dst = j.offsets[r]; if (len) src = ld32a(j.fixed + j.row_base[r] + j.off_full); }
-  const uint32_t nrow = j.n_rows - r0 < 64 ? (uint32_t)(j.n_rows - r0) : 64u;
-  for (uint32_t k = 0; k < nrow; k++) {
-    const uint32_t l_u = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)k);
-    if (!l_u) continue;
-    const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)k);
-    const uint64_t d_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)dst >> 32), (int)k) << 32) |
-                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dst, (int)k);
-    const u8* sp = j.heap + s_u;
-    u8* dp = j.values + d_u;
-    for (uint32_t b = lane; b < l_u; b += 64) dp[b] = sp[b];
+  const uint32_t sub = lane & 7u, grp = lane >> 3;
+  for (uint32_t it = 0; it < 8; it++) {
+    const int k = (int)(it * 8u + grp);
+    const uint32_t l_k = (uint32_t)__shfl((int)len, k, 64);
+    const uint32_t s_k = (uint32_t)__shfl((int)src, k, 64);
+    const uint64_t d_k = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)dst >> 32), k, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)dst, k, 64);
+    const u8* sp = j.heap + s_k;
+    u8* dp = j.values + d_k;
+    for (uint32_t b = sub * 8u; b < l_k; b += 64u) {
+      if (b + 8u <= l_k) { uint64_t v; __builtin_memcpy(&v, sp + b, 8); __builtin_memcpy(dp + b, &v, 8); }
+      else for (uint32_t t = b; t < l_k; t++) dp[t] = sp[t];
+    }
   }
 }
 
@@ -674,17 +683,46 @@ struct RbCount {
   DEV void bytes(const u8*, uint32_t len) { n += len; }
   DEV void hex(const u8*, uint32_t len) { n += 2 * len; }
 };
+// The byte pass of a row. One thread writes one row, so a byte store per put() was one write request per BYTE at the L2 (64 lanes,
+// 64 different lines per instruction): k_rb_rows took 469 us for the 47 MB of a cfg3 batch's rows (profiles/r04q). The bytes are
+// collected in a 64-bit accumulator instead and leave eight at a time (unaligned 8-byte stores are fine in global memory); finish()
+// writes the last 1-7 bytes one by one — the next row's first bytes belong to another thread.
 struct RbWrite {
-  u8* p;
-  DEV void put(u8 b) { *p++ = b; }
-  DEV void varint64(uint64_t v) { while (v >= 0x80) { *p++ = (u8)(v | 0x80); v >>= 7; } *p++ = (u8)v; }
-  DEV void put32(uint32_t v) { for (int k = 0; k < 4; k++) *p++ = (u8)(v >> (8 * k)); }
-  DEV void put64(uint64_t v) { for (int k = 0; k < 8; k++) *p++ = (u8)(v >> (8 * k)); }
-  DEV void zeros(uint32_t k) { for (uint32_t i = 0; i < k; i++) p[i] = 0; p += k; }
-  DEV void bytes(const u8* s, uint32_t len) { for (uint32_t k = 0; k < len; k++) *p++ = s[k]; }
-  DEV void hex(const u8* s, uint32_t len) {   // bytes_to_hex, lowercase (:176-185)
-    for (uint32_t k = 0; k < len; k++) { const uint32_t b = s[k], h = b >> 4, l = b & 15; *p++ = (u8)(h < 10 ? '0' + h : 'a' + h - 10); *p++ = (u8)(l < 10 ? '0' + l : 'a' + l - 10); }
+  u8* p;                // where the accumulator's first byte goes
+  uint64_t acc = 0;
+  uint32_t n = 0;       // bytes in acc (0..7)
+  DEV void store8(uint64_t v) { __builtin_memcpy(p, &v, 8); p += 8; }
+  // appends the low k bytes of v (1 <= k <= 8; the bytes above them are zero)
+  DEV void append(uint64_t v, uint32_t k) {
+    acc |= v << (8u * n);
+    const uint32_t m = n + k;
+    if (m >= 8u) {
+      store8(acc);
+      acc = n ? v >> (8u * (8u - n)) : 0ull;   // what did not fit (n = 0: k = 8, nothing is left)
+      n = m - 8u;
+    } else n = m;
   }
+  DEV void put(u8 b) { append(b, 1); }
+  DEV void varint64(uint64_t v) { while (v >= 0x80) { put((u8)(v | 0x80)); v >>= 7; } put((u8)v); }
+  DEV void put32(uint32_t v) { append(v, 4); }
+  DEV void put64(uint64_t v) { append(v, 8); }
+  DEV void zeros(uint32_t k) { while (k >= 8u) { append(0ull, 8); k -= 8u; } if (k) append(0ull, k); }
+  DEV void bytes(const u8* s, uint32_t len) {
+    uint32_t k = 0;
+    for (; k + 8u <= len; k += 8u) { uint64_t v; __builtin_memcpy(&v, s + k, 8); append(v, 8); }
+    if (k < len) { uint64_t v = 0; for (uint32_t b = 0; k + b < len; b++) v |= (uint64_t)s[k + b] << (8u * b); append(v, len - k); }
+  }
+  DEV void hex(const u8* s, uint32_t len) {   // bytes_to_hex, lowercase (:176-185)
+    auto h1 = [](uint32_t d) -> uint64_t { return d < 10 ? '0' + d : 'a' + d - 10; };
+    uint32_t k = 0;
+    for (; k + 4u <= len; k += 4u) {   // four bytes -> eight digits
+      uint64_t v = 0;
+      for (uint32_t b = 0; b < 4; b++) { const uint32_t x = s[k + b]; v |= (h1(x >> 4) | (h1(x & 15u) << 8)) << (16u * b); }
+      append(v, 8);
+    }
+    for (; k < len; k++) { const uint32_t x = s[k]; append(h1(x >> 4) | (h1(x & 15u) << 8), 2); }
+  }
+  DEV void finish() { for (uint32_t b = 0; b < n; b++) p[b] = (u8)(acc >> (8u * b)); p += n; n = 0; acc = 0; }
 };
 
 template <class S>
@@ -913,14 +951,18 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
   return 0;
 }
 
-__global__ __launch_bounds__(256) void k_rb_lens(RbJob j) {
+__global__ __launch_bounds__(256) void k_rb_lens(RbJob j, unsigned long long* blk) {
+  __shared__ uint64_t lds_sum[4];
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= j.n_rows) return;
   RbCount c;
-  const uint32_t e = j.format ? pb_row(j, r, c) : rb_row(j, r, c);
-  // first failing row in event order, rows with a date out of range before all others (bit 62 clear)
-  if (e) { atomicMin(j.err, (((e & 0xFFu) == RB_E_DATE_RANGE || j.format) ? 0ull : 1ull << 62) | (unsigned long long)((r << 24) | e)); c.n = 0; }
-  j.lens[r] = c.n;
+  if (r < j.n_rows) {
+    const uint32_t e = j.format ? pb_row(j, r, c) : rb_row(j, r, c);
+    // first failing row in event order, rows with a date out of range before all others (bit 62 clear)
+    if (e) { atomicMin(j.err, (((e & 0xFFu) == RB_E_DATE_RANGE || j.format) ? 0ull : 1ull << 62) | (unsigned long long)((r << 24) | e)); c.n = 0; }
+    j.lens[r] = c.n;
+  }
+  const uint64_t t = block_sum64(c.n, lds_sum);   // (the block's sum for the offsets scan)
+  if (threadIdx.x == 0) blk[blockIdx.x] = t;
 }
 
 __global__ __launch_bounds__(256) void k_rb_rows(RbJob j) {
@@ -928,6 +970,7 @@ __global__ __launch_bounds__(256) void k_rb_rows(RbJob j) {
   if (r >= j.n_rows || !j.lens[r]) return;
   RbWrite w{j.out + j.offsets[r]};
   if (j.format) (void)pb_row(j, r, w); else (void)rb_row(j, r, w);
+  w.finish();
 }
 
 
@@ -1009,8 +1052,7 @@ void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, i
   if (!j.n_rows) return;
   const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
   if (step == 0) {
-    hipLaunchKernelGGL(k_col_lens, dim3(nb), dim3(256), 0, st, j);
-    hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, blk);
+    hipLaunchKernelGGL(k_col_lens, dim3(nb), dim3(256), 0, st, j, blk);
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
     hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
   } else {
@@ -1049,8 +1091,7 @@ void etlg_k_rowbinary(const void* jv, unsigned long long* blk, int64_t* offsets,
   if (!j.n_rows) return;
   const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
   if (step == 0) {
-    hipLaunchKernelGGL(k_rb_lens, dim3(nb), dim3(256), 0, st, j);
-    hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, blk);
+    hipLaunchKernelGGL(k_rb_lens, dim3(nb), dim3(256), 0, st, j, blk);
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
     hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
   } else {
