@@ -484,6 +484,11 @@ hipError_t scan_launch(etlg_ctx* c, ScanJob& j, bool sequential) {
   uint8_t* oth = base + (size_t)(c->scan_cur ^ 1) * half;
   c->h_scan[0] = 0; c->h_scan[1] = 0;
   const bool dbg = getenv("ETLG_SCAN_DBG") != nullptr;
+  // The one-lane fallback (k_bounds_seq) has no clearing loop: the OTHER buffer — dirtied by the run before this one, the next run's
+  // look-back words — is zeroed here. (It used to be marked clean all the same: the scan AFTER a fallback then met the descriptors of
+  // an earlier run wherever a tile looked before its predecessor had published — wrong boundaries on the MI355X, never on the emulator,
+  // whose workgroups run in order; found by running tools/simt_fuzz.py's boundary-scan worker against the real library, round 4.)
+  if (sequential && c->scan_dirty[c->scan_cur ^ 1]) { e = hipMemsetAsync(oth, 0, c->scan_dirty[c->scan_cur ^ 1] * 8, s); if (e != hipSuccess) return e; }
   ProfRec r; r.which = kBounds;
   if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
   etlg_k_launch_bounds(j.d_in, len, (uint32_t*)j.offs->p, (uint32_t)std::min<size_t>(j.cap + 2, 0xFFFFFFFFu), j.cur, oth, (uint32_t)c->scan_dirty[c->scan_cur ^ 1],

@@ -95,6 +95,52 @@ def test_scan_payload_that_mimics_frames(dec):
     assert reruns >= 1 and seq == 0
 
 
+def _byte_soup(seed):
+    """One buffer of tools/simt_fuzz.py's boundary-scan worker: frames whose bodies are random bytes, header look-alikes or whole fake
+    frame chains, some of them truncated."""
+    import random
+    rng = random.Random(seed)
+
+    def payload(n):
+        k = rng.random()
+        if k < 0.3:
+            return bytes(rng.getrandbits(8) for _ in range(n))
+        if k < 0.6:
+            return bytes(rng.choice(b"d\x00\x00\x01\x10w") for _ in range(n))
+        return (b"d" + struct.pack(">I", rng.choice([4, 5, 17, 60, 200, 4000])) + b"w") * (n // 6 + 1)
+    parts, size, total = [], 0, rng.choice([40000, 150000])
+    while size < total:
+        n = rng.choice([108, 500, 3000, 9000, 20000, 70000])
+        body = payload(n)[:n]
+        fr = b"d" + struct.pack(">I", len(body) + 4) + body
+        if rng.random() < 0.05:
+            fr = fr[:rng.randrange(1, len(fr) + 1)]
+        parts.append(fr)
+        size += len(fr)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8)
+
+
+def test_scan_after_a_one_lane_fallback(dec):
+    """A scan that ends in the one-lane fallback (four runs of wrong guesses) must leave the look-back buffers clean for the scan
+    after it. It did not (round 4, found by running the fuzzer's boundary-scan worker against the real library): k_bounds_seq has no
+    clearing loop, the host marked the other buffer clean all the same, and on the MI355X — where a tile may look at a descriptor
+    before its predecessor has published — the NEXT scan took stale words for published ones: wrong boundaries for ~30 % of the
+    scans behind a fallback. (The emulator runs workgroups in order and never sees it.)"""
+    soup = _byte_soup(7)
+    w = synth.cfg3()
+    good, offs = w.fill(1 << 20)
+    fake = b"d" + struct.pack(">I", 22) + b"k" + bytes(17)
+    s = SC.txn([W.insert(42, ["1", fake * 3000]), W.insert(42, ["2", "plain"]), W.insert(42, ["3", fake * 2500]), W.insert(42, ["4", "tail"])])
+    mimic = np.frombuffer(s.bytes(), dtype=np.uint8)
+    seq0 = dec.debug_scan()[1]
+    for rep in range(24):
+        _check(dec, soup)                                   # ends in the fallback ...
+        assert dec.debug_scan()[1] == seq0 + rep + 1
+        got = dec.scan_boundaries(good if rep % 2 else mimic)   # ... and the scan behind it is still right
+        want = offs if rep % 2 else ref_scan(mimic)
+        assert np.array_equal(got, np.asarray(want, dtype=np.uint32)), rep
+
+
 def test_decode_without_sidecar_device_input(dec):
     """etlg_decode(frame_offsets = NULL) on HBM-resident input: boundaries come from the device scan."""
     import torch

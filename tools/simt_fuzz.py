@@ -136,7 +136,7 @@ def main():
     t_end = time.time() + seconds
     total = bad = 0
     procs = []
-    nproc = max(1, (os.cpu_count() or 2) - 1)
+    nproc = int(os.environ.get("ETLG_FUZZ_PROCS", 0)) or max(1, (os.cpu_count() or 2) - 1)   # (on a GPU box with the gfx950 library as ETLG_SIMT_FUZZ_LIB: a handful of contexts, not one per core)
     while time.time() < t_end or procs:
         while time.time() < t_end and len(procs) < nproc:
             env = dict(os.environ, ETLG_LIB_PATH=lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="120", **PATHS[seed % len(PATHS)])
