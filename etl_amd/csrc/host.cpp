@@ -809,7 +809,14 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   // DDL frames (a control frame then fails the batch with a hint and finish_batch takes the control path); on a stream that does
   // carry them (last_had_ctrl) the control pre-pass runs ahead on its own stream (ctl_begin) — that needs the sidecar.
   const bool async_ok = (flags & ETLG_F_ASYNC) && out_dev && in_dev && !c->copy.active && !c->force_multipass && len < (1ull << 31);
-  const bool ctl_ahead = async_ok && !no_ctrl && c->last_had_ctrl && !scan && nframes && c->ctl_async_mode;
+  // (the pre-pass + host control plane of this batch may only run ahead of batches that are themselves on the control path: each of
+  // those holds a snapshot of the control state it started from. An OPTIMISTIC batch still pending — enqueued before the context knew
+  // the stream carries Relation / DDL frames — may have to be decoded again when it is synced, against the schemas of ITS position in
+  // the stream; a control plane that had run ahead of it had changed them under it: rows decoded against the table's next schema,
+  // found by tools/async_fuzz.py. Such a batch waits for the chain to drain first — once per stream, at the transition.)
+  bool pending_optimistic = false;
+  for (const etlg_batch* pb : c->pending) if (pb->pending && !pb->ctl_async) pending_optimistic = true;
+  const bool ctl_ahead = async_ok && !no_ctrl && c->last_had_ctrl && !scan && nframes && c->ctl_async_mode && !pending_optimistic;
   const bool async = async_ok && (no_ctrl || !c->last_had_ctrl || ctl_ahead);
   hipStream_t s = c->stream;
   if (!async) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
@@ -903,6 +910,7 @@ int32_t flush_deferred(etlg_ctx* c) {
   b->deferred = false;
   size_t nframes = 0;
   int32_t rc = ETLG_OK;
+  const bool pre_pass_ahead = b->defer_ctl;
   if (b->defer_ctl) { b->defer_ctl = false; nframes = b->nframes_in; }   // its control pre-pass ran ahead: decode_tail collects it (standard_path -> ctl_finish)
   else {
     const hipError_t e = scan_collect(c, c->scan_job, &nframes);
@@ -910,6 +918,12 @@ int32_t flush_deferred(etlg_ctx* c) {
     else if (nframes >= (1u << 30)) rc = lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   }
   if (rc == ETLG_OK) {
+    // A batch whose boundary scan was deferred joined the chain when the stream had shown no Relation / DDL frame. If it has by now (a
+    // batch before this one was synced in between), this batch takes the control path — which starts from the HOST's carried state and
+    // control plane: everything before it is finished first. (It used to run its control pass from the state of the last SYNCED batch
+    // with the batches in between still pending: rows decoded against missing table state — found by tools/async_fuzz.py, round 4.)
+    if (!pre_pass_ahead && !b->user_no_ctrl && c->last_had_ctrl)
+      while (!c->pending.empty() && c->pending.front() != b) (void)finish_batch(c, c->pending.front());
     etlg_batch* prev = nullptr;   // the batch issued just before this one, if it is still in flight
     for (size_t i = 0; i < c->pending.size(); i++) if (c->pending[i] == b && i > 0) prev = c->pending[i - 1];
     rc = decode_tail(c, b, nframes, true, prev);

@@ -80,6 +80,92 @@ def _run_chain(w, pieces, expect_path=None, sidecar=True):
     return paths
 
 
+def async_fuzz_round(seed):
+    """One round of tools/async_fuzz.py: a synthetic stream (cfg2 / cfg3 / cfg5, sometimes started inside the stream, sometimes with a
+    few damaged bytes), cut into 2-40 batches at arbitrary frame boundaries, enqueued ETLG_F_ASYNC with a random window of batches in
+    flight, with or without the offsets sidecar and the caller's no-control assertion, synced in issue order; every batch against the
+    oracle. Returns (batches checked, list of mismatch descriptions)."""
+    import random
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    rng = random.Random(seed)
+    mk = rng.choice([synth.cfg2, synth.cfg2, synth.cfg3, synth.cfg5])
+    w = mk()
+    for _ in range(rng.randrange(3)):
+        w.fill(rng.choice([1 << 16, 1 << 18]))          # start somewhere inside the stream
+    buf, offs = w.fill(rng.choice([1 << 19, 1 << 20, 3 << 20]))
+    buf = buf.copy()
+    damage = rng.random() < 0.35
+    if damage:
+        for _ in range(rng.randrange(1, 4)):
+            f = rng.randrange(len(offs) - 1)
+            lo, hi = int(offs[f]), int(offs[f + 1])
+            pos = rng.randrange(lo + 30, hi) if hi - lo > 31 else lo
+            buf[pos] = rng.choice([0, 0x2D, 0x41, 0xFF, 0x6E, 0x75, 0x74])
+    nparts = rng.randrange(3, 41)
+    if nparts >= len(offs) - 1:
+        nparts = 2
+    pieces = _cut(buf, offs, nparts, seed=seed)
+    no_ctrl = mk is not synth.cfg5 and rng.random() < 0.6
+    sidecar = rng.random() < 0.75
+    window = rng.choice([1, 2, 3, 8, 24])
+    flags = abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC | (abi.F_NO_CONTROL if no_ctrl else 0)
+    o, d = oracle.Oracle(), Decoder(0)
+    ready = not w.cfg.emit_relations
+    w.register(o, ready=ready)
+    w.register(d, ready=ready)
+    dev = DevBufs(pieces)
+    what = f"seed {seed} {mk.__name__} parts {nparts} window {window} sidecar {sidecar} no_ctrl {no_ctrl} damaged {damage}"
+    st = {"done": 0, "stop": False, "bad": []}
+    inflight = []
+
+    def collect():
+        k = st["done"]
+        b = inflight[k]
+        rb = o.decode(*pieces[k])
+        rc = b.sync()
+        ok = (rb.err_code != 0) == (rc != 0)
+        if ok and rb.err_code:
+            ok = (b.error.code, b.error.frame_index) == (rb.err_code, rb.err_frame)
+        diff = rb.host_batch().diff(b.host()) if ok else ["error: oracle %s vs rc %s %s" % (rb.err_code, rc, b.error)]
+        if diff:
+            st["bad"].append(f"{what} batch {k}: {diff[:3]}")
+            st["stop"] = True
+        if rb.err_code:
+            st["stop"] = True      # the reference's apply loop exits on a decode error (apply.rs:2475-2481): the chain ends here
+        b.close()
+        st["done"] += 1
+
+    for (p, n, po, nf) in dev.items:
+        if st["stop"]:
+            break
+        inflight.append(d.decode_device(p, n, po if sidecar else None, nf if sidecar else 0, flags))
+        while not st["stop"] and len(inflight) - st["done"] >= window:
+            collect()
+    checked = 0
+    while st["done"] < len(inflight):
+        if st["stop"]:
+            inflight[st["done"]].sync()
+            inflight[st["done"]].close()
+            st["done"] += 1
+        else:
+            collect()
+    checked = st["done"]
+    d.close()
+    return checked, st["bad"]
+
+
+@pytest.mark.parametrize("seed", [61, 106, 226, 261, 7, 19, 42])
+def test_async_fuzz_rounds(seed):
+    """Rounds of tools/async_fuzz.py that found defects in round 4, plus a few more. 61 / 106: optimistic batches queued behind the
+    batch that carries the stream's first Relation frames listed no schema slots in their views. 226: the control pre-pass (and host
+    control plane) of a later batch ran ahead of optimistic batches that were still pending and had to be decoded again — against the
+    table's NEXT schema. 261: a batch whose boundary scan was deferred took the control path from the state of the last synced batch
+    while the batches in between were pending."""
+    checked, bad = async_fuzz_round(seed)
+    assert checked >= 1 and not bad, bad
+
+
 @pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 3 << 20), (synth.cfg3, 3 << 20)])
 def test_async_chain_carries_transaction_state(mk, nbytes):
     w = mk()
@@ -365,6 +451,18 @@ def test_async_control_stream_runs_its_pre_pass_ahead():
     pieces = _cut(buf, offs, 9, seed=13)
     paths = _chain_default_flags(w, pieces, warm=1, ready=False)
     assert paths["ctl_ahead"] == 8 and paths["control"] >= 9 and paths["chain_rerun"] == 0, paths
+
+
+def test_async_cold_start_on_a_stream_that_begins_with_its_relation_frames():
+    """No warm-up: every batch of a cfg5 stream enqueued before the first is synced. The first batch carries the stream's Relation
+    frames, so its optimistic attempt ends with the control hint, it takes the control path when it is synced, and the batches behind
+    it — enqueued when the context had no schema slot at all — are decoded again from the state it leaves. Their views list the
+    slots their events name (they listed none: found by tools/async_fuzz.py, round 4)."""
+    w = synth.cfg5()
+    buf, offs = w.fill(1 << 20)
+    pieces = _cut(buf, offs, 6, seed=5)
+    paths = _chain_default_flags(w, pieces, warm=0, ready=False)
+    assert paths["chain_rerun"] >= 1 and paths["control"] >= 1, paths
 
 
 def test_async_control_stream_with_an_error_in_the_middle():
