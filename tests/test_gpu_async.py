@@ -109,13 +109,20 @@ def async_fuzz_round(seed):
     no_ctrl = mk is not synth.cfg5 and rng.random() < 0.6
     sidecar = rng.random() < 0.75
     window = rng.choice([1, 2, 3, 8, 24])
-    flags = abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC | (abi.F_NO_CONTROL if no_ctrl else 0)
+    # (drawn after everything above, so that the rounds of earlier seeds stay what they were)
+    host_in = rng.random() < 0.25          # host buffers: with a sidecar they are staged on the copy stream, without one decoded synchronously
+    side_calls = rng.random() < 0.3        # other calls of the ABI between the batches of the chain
+    flags = (0 if host_in else abi.F_INPUT_ON_DEVICE) | abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC | (abi.F_NO_CONTROL if no_ctrl else 0)
     o, d = oracle.Oracle(), Decoder(0)
     ready = not w.cfg.emit_relations
     w.register(o, ready=ready)
     w.register(d, ready=ready)
     dev = DevBufs(pieces)
-    what = f"seed {seed} {mk.__name__} parts {nparts} window {window} sidecar {sidecar} no_ctrl {no_ctrl} damaged {damage}"
+    if host_in:
+        keep = [(np.ascontiguousarray(pb), np.ascontiguousarray(po.astype(np.uint32))) for pb, po in pieces]
+        dev.keep.append(keep)
+        dev.items = [(pb.ctypes.data, len(pb), po.ctypes.data, len(po) - 1) for pb, po in keep]
+    what = f"seed {seed} {mk.__name__} parts {nparts} window {window} sidecar {sidecar} no_ctrl {no_ctrl} damaged {damage} host_in {host_in} side_calls {side_calls}"
     st = {"done": 0, "stop": False, "bad": []}
     inflight = []
 
@@ -136,10 +143,22 @@ def async_fuzz_round(seed):
         b.close()
         st["done"] += 1
 
-    for (p, n, po, nf) in dev.items:
+    for kk, (p, n, po, nf) in enumerate(dev.items):
         if st["stop"]:
             break
         inflight.append(d.decode_device(p, n, po if sidecar else None, nf if sidecar else 0, flags))
+        if side_calls and not damage and rng.random() < 0.4:   # a boundary scan / a tag pass of some piece in the middle of the chain: right answers, chain undisturbed
+            j = rng.randrange(len(pieces))
+            pb, po = pieces[j]
+            if rng.random() < 0.5:
+                got = d.scan_boundaries(pb)
+                if not np.array_equal(got, po.astype(np.uint32)):
+                    st["bad"].append(f"{what}: scan_boundaries of piece {j} between batches {kk} and {kk + 1}")
+            elif len(po) > 1:
+                tags = d.frame_tags(pb, po)
+                want = np.array([pb[int(x) + 5] if pb[int(x) + 5] == ord("k") else pb[int(x) + 30] for x in po[:-1]], dtype=np.uint8)   # keepalives: 'k'
+                if not np.array_equal(np.asarray(tags, dtype=np.uint8), want):
+                    st["bad"].append(f"{what}: frame_tags of piece {j} between batches {kk} and {kk + 1}")
         while not st["stop"] and len(inflight) - st["done"] >= window:
             collect()
     checked = 0
