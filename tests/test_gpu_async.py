@@ -123,6 +123,8 @@ def async_fuzz_round(seed):
         dev.keep.append(keep)
         dev.items = [(pb.ctypes.data, len(pb), po.ctypes.data, len(po) - 1) for pb, po in keep]
     what = f"seed {seed} {mk.__name__} parts {nparts} window {window} sidecar {sidecar} no_ctrl {no_ctrl} damaged {damage} host_in {host_in} side_calls {side_calls}"
+    if os.environ.get("ETLG_FUZZ_VERBOSE"):
+        print(what, flush=True)
     st = {"done": 0, "stop": False, "bad": []}
     inflight = []
 
@@ -146,7 +148,8 @@ def async_fuzz_round(seed):
     for kk, (p, n, po, nf) in enumerate(dev.items):
         if st["stop"]:
             break
-        inflight.append(d.decode_device(p, n, po if sidecar else None, nf if sidecar else 0, flags))
+        enqueue = d.decode_host_ptr if host_in else d.decode_device
+        inflight.append(enqueue(p, n, po if sidecar else None, nf if sidecar else 0, flags))
         if side_calls and not damage and rng.random() < 0.4:   # a boundary scan / a tag pass of some piece in the middle of the chain: right answers, chain undisturbed
             j = rng.randrange(len(pieces))
             pb, po = pieces[j]

@@ -17,6 +17,8 @@ t_end = time.time() + seconds
 rounds = batches = bad = 0
 seed = seed0
 while time.time() < t_end or rounds == 0:
+    if os.environ.get("ETLG_FUZZ_VERBOSE"):
+        print("round", seed, flush=True)   # (a crash names its seed)
     n, problems = async_fuzz_round(seed)
     for line in problems:
         print("MISMATCH", line, flush=True)
