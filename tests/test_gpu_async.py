@@ -145,9 +145,30 @@ def async_fuzz_round(seed):
         b.close()
         st["done"] += 1
 
+    # table-state changes between batches (the apply loop sees its state store change between messages: a table finishes its copy —
+    # SyncDone(lsn): owned from that LSN on, decided per transaction, the kernels' seq_lookback mode —, errors out, comes back): the
+    # library finishes the chain before it takes the change, so the round does the same with the oracle
+    state_changes = {}
+    if rng.random() < 0.3 and not no_ctrl:
+        begins = [int.from_bytes(bytes(buf[int(x) + 31:int(x) + 39]), "big") for x in offs[:-1] if buf[int(x) + 5] == ord("w") and buf[int(x) + 30] == ord("B")]
+        for _ in range(rng.randrange(1, 4)):
+            at = rng.randrange(1, len(pieces))
+            t = rng.choice(w.tables)
+            kind = rng.choice([abi.TS_READY, abi.TS_SYNC_DONE, abi.TS_SYNC_DONE, abi.TS_OTHER, abi.TS_ABSENT])
+            lsn = (rng.choice(begins) + rng.choice([-1, 0, 1])) if begins and kind == abi.TS_SYNC_DONE else 0
+            state_changes.setdefault(at, []).append((t["rel_id"], kind, max(lsn, 0)))
+        what += f" state_changes {sorted(state_changes)}"
     for kk, (p, n, po, nf) in enumerate(dev.items):
         if st["stop"]:
             break
+        if kk in state_changes:
+            while not st["stop"] and st["done"] < len(inflight):
+                collect()
+            if st["stop"]:
+                break
+            for rel, kind, lsn in state_changes[kk]:
+                o.table_state(rel, kind, lsn)
+                d.table_state(rel, kind, lsn)
         enqueue = d.decode_host_ptr if host_in else d.decode_device
         inflight.append(enqueue(p, n, po if sidecar else None, nf if sidecar else 0, flags))
         if side_calls and not damage and rng.random() < 0.4:   # a boundary scan / a tag pass of some piece in the middle of the chain: right answers, chain undisturbed
