@@ -428,8 +428,8 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   TxnCtx tx{true, 0, 0};
   uint32_t bc = 0, bm = 0;
   uint64_t carried_lsn = 0, start_ord = 0;   // wave 0, from the transaction look-back: final_lsn of the Begin `bm` names, the ordinal the batch starts from
-  auto make_tx = [&]() {
-    bc = s32[12]; bm = s32[13]; carried_lsn = s64[6]; start_ord = s64[3];
+  auto make_tx = [&](const TxnStart& t) {
+    bc = t.seg; bm = t.mark; carried_lsn = t.lsn; start_ord = t.ord;
     const uint32_t seg = seg_combine(bc, seg_in);
     const uint32_t last = bm > pm ? bm : pm;
     tx.in_txn = (last & 1u) != 0;
@@ -440,8 +440,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   };
   if (wave == 0) {
     if (seq_lb) {
-      txn_lookback(pg, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64);
-      make_tx();   // (the wave reads back what its first lane just wrote: LDS operations of a wave are ordered)
+      make_tx(txn_lookback(pg, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64));   // (in registers: no barrier between the look-back and here)
     }
     TSTAMP(10);
     if (live && too_wide) atomicOr(fail, 4u);
@@ -748,7 +747,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   // the 64-bit values the allocator spilled to scratch)
   if (wave == 0) {
     if (!seq_lb) {
-      make_tx();
+      make_tx(TxnStart{s32[12], s32[13], s64[6], s64[3]});   // written by the look-back wave before the barrier above
       if (live && wire_ok) txn_check_frame(pg, v, tx);
     }
     const uint64_t ev_idx = pre_ev + x_ev;

@@ -255,6 +255,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_MARGIN")) c->plan_margin_pct = (uint32_t)atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_DBG")) c->plan_dbg = (uint32_t)atoi(pm);
+  { const char* e = getenv("ETLG_CTL_OVERLAP"); c->ctl_overlap_mode = !(e && e[0] == '0'); }   // 0: batches on the control path stay on one decode stream
   if (const char* pm = getenv("ETLG_OVERLAP")) c->overlap_mode = atoi(pm);
   if (const char* pm = getenv("ETLG_CTL_ASYNC")) c->ctl_async_mode = atoi(pm);
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && ncu > 0) c->n_cus = ncu; }
@@ -993,6 +994,14 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     { const int32_t rc = setup_outputs(c, b); if (rc != ETLG_OK) return rc; }
     b->plan_decided = plan_wanted(c, b) ? 1 : 0;
     beside = true;   // (a look-back buffer that has to grow synchronises both streams: take_descriptors)
+  }
+  // Batches on the pipelined control path (their pre-pass ran ahead, ctl_async) alternate between the two decode streams as well
+  // (round 4): the decode kernel of batch k+1 — enqueued by standard_path below, behind its own control pass, side-input set and
+  // outputs, all of which go to the stream chosen here — starts beside the tail of batch k's; it reads the carried transaction state
+  // late like every batch that runs beside its predecessor (flags bit 4). cfg5: the decode kernels were a single-stream chain.
+  else if (async && prev && prev->pending && prev->ctl_async && b->ctl_async && prev->level <= 1 && prev->used_fused && !prev->force_rerun && c->overlap_mode &&
+           c->ctl_overlap_mode && p.nframes && !c->force_multipass && len < (1ull << 31) && c->res_seq != 0 && res_slot >= 2 && !b->copy.active && !c->prof_serial) {
+    beside = true;
   }
   if (beside) {
     if (!c->stream2) {

@@ -305,6 +305,7 @@ struct etlg_ctx {
   bool plan_covers_all = false;
   int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
   uint32_t plan_margin_pct = 4;  // ETLG_PLAN_MARGIN: LDS window per tile = 64 average frames + this margin (a tile that does not fit is read in place)
+  bool ctl_overlap_mode = true;  // ETLG_CTL_OVERLAP
   uint32_t plan_dbg = 0;         // ETLG_PLAN_DBG: bit 0 = no LDS staging (tests of the in-place reader)
   int n_cus = 256;
   uint32_t plan_skip = 0, plan_penalty = 4, plan_streak = 0;

@@ -174,8 +174,12 @@ DEV uint64_t final_lsn_of_mark(const DecParams& p, uint32_t mark) {
 // bit 4 the batch before this one may still be running on the other decode stream: such a tile then waits for that batch's last
 // tile to have written its totals (carry_ready); every other tile of the batch never looks at the predecessor at all. Results
 // for the workgroup, written by the wave's first lane: s32[12] segment count, s32[13] mark, s64[6] final_lsn of the Begin the
-// mark names (0 when it names none), s64[3] the ordinal the batch starts from.
-DEV void txn_lookback(const DecParams& pg, unsigned long long* d_txn, uint32_t ntiles, uint32_t tile, uint64_t txn_agg, uint32_t* fail,
+// mark names (0 when it names none), s64[3] the ordinal the batch starts from. The same four values come back in registers (wave
+// uniform) for a caller whose wave goes on with them at once: reading the LDS slots back without a barrier in between leaves the
+// order of lane 0's stores and the other lanes' loads to the compiler (round 4: k_cells' sequential look-back read stale slots on the
+// MI355X; a workgroup barrier sits between the stores and the loads everywhere else).
+struct TxnStart { uint32_t seg, mark; uint64_t lsn, ord; };
+DEV TxnStart txn_lookback(const DecParams& pg, unsigned long long* d_txn, uint32_t ntiles, uint32_t tile, uint64_t txn_agg, uint32_t* fail,
                       uint32_t* s32, uint64_t* s64) {
   const uint64_t ex = lookback<OpTxn>(d_txn, d_txn + ntiles, tile, txn_agg, 0ull, fail);
   const uint32_t seg = seg_unpack30((uint32_t)(ex >> 32));
@@ -193,12 +197,12 @@ DEV void txn_lookback(const DecParams& pg, unsigned long long* d_txn, uint32_t n
     next_ord = __hip_atomic_load(&pg.carry->out_next_ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (mark == 0u && in_txn) mark = 1u;   // virtual Begin before frame 0
-  if ((threadIdx.x & 63) == 0) {
-    s32[12] = seg; s32[13] = mark;
-    s64[6] = (mark & 1u) ? (mark == 1u ? final_lsn : ld_be64(pg.in + ((mark >> 1) - 1) + kBodyOff)) : 0ull;
-    s64[3] = next_ord;
-  }
-  ETLG_WAVE_JOIN();   // (the wave may read these back at once: its LDS operations are ordered)
+  TxnStart t;
+  t.seg = seg; t.mark = mark; t.ord = next_ord;
+  t.lsn = (mark & 1u) ? (mark == 1u ? final_lsn : ld_be64(pg.in + ((mark >> 1) - 1) + kBodyOff)) : 0ull;   // (one address for the wave)
+  if ((threadIdx.x & 63) == 0) { s32[12] = t.seg; s32[13] = t.mark; s64[6] = t.lsn; s64[3] = t.ord; }
+  ETLG_WAVE_JOIN();
+  return t;
 }
 // the last tile of a single-pass kernel has written the batch's totals: the batch behind it may be waiting for them
 DEV void carry_publish(DevResult* r) { __hip_atomic_store(&r->carry_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
