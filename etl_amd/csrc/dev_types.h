@@ -189,6 +189,14 @@ struct PlanParams {
                                // bit 1 stop after staging, bit 2 stop after the message heads, bit 3 no cell decode / row stores, bit 4 no event header stores
                                // bit 5: phase clocks into DevResult.dbg_t; bit 9: one tile per wave (k_plan) even when two would do
   uint32_t max_row_dw;         // dwords of the widest planned row (k_plan2 / k_plan3 keep a row of up to 6 / 8 dwords in registers)
+  // Tile prefixes from the sidecar pre-pass (k_plan_pre, plan.hip), or null: the decode kernel then runs the look-back itself.
+  // pre[2 * tile] = {last Begin / Commit mark before the tile : 30 | fixed-arena dwords before it : 32}, pre[2 * tile + 1] = LSN of the
+  // Begin that is open when the tile starts — what plan_resolve2 would hand the tile.
+  const unsigned long long* pre;
+  unsigned long long* pre_out; // ... as the pre-pass writes it
+  uint32_t* pre_ticket;        // the pre-pass's arrival counter (zero between launches)
+  uint32_t pre_tag;            // 1..3, changes with every use of a buffer: the status of this launch's group words
+  uint32_t pre_row_dw;         // the row dwords every planned table shares (the pre-pass prices a frame without reading it)
 };
 
 // ---- columnar hand-off (columns.hip)

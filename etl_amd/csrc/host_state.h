@@ -51,6 +51,7 @@ extern "C" void etlg_k_launch_copy(const uint8_t* rows, const uint32_t* row_offs
                                    uint32_t rel_id, uint8_t* out, uint32_t* out_offs, uint32_t lds_bytes, int lane_per_byte, const DecParams* dec, hipStream_t s);
 extern "C" void etlg_k_launch_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" void etlg_k_launch_plan(const DecParams* p, const void* q, hipStream_t s);
+extern "C" void etlg_k_launch_plan_pre(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_plan_set_lds(void);
 extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
 extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
@@ -75,7 +76,8 @@ constexpr int kBounds = 9; // ... of the record-boundary scan (scan.hip)
 constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
 constexpr int kPlan = 11;  // ... of the fixed-width plan (plan.hip)
 constexpr int kCopyCells = 12;  // ... of the table-copy rows -> arena kernel (cells.hip, k_cells<.., COPYK>)
-constexpr int kProfSlots = 13;
+constexpr int kPlanPre = 13;    // ... of the plan's sidecar pre-pass (plan.hip, k_plan_pre)
+constexpr int kProfSlots = 14;
 
 namespace {
 
@@ -264,6 +266,9 @@ struct etlg_ctx {
   // device scratch (grow-only)
   // look-back descriptors are double buffered: each single-pass launch zeroes the buffer of the next one
   size_t desc_half = 0;          // bytes per buffer
+  // the plan's sidecar pre-pass (k_plan_pre): tile prefixes of a batch, four buffers in rotation (like the look-back descriptors)
+  static constexpr uint32_t kPreBufs = 4;
+  DevBuf d_pre; size_t pre_half = 0; uint32_t pre_seq = 0;
   size_t desc_dirty[4] = {0, 0, 0, 0}; // bytes at the head of each buffer that may be non-zero
   uint32_t desc_cur = 0;
   // Two decode streams: consecutive ASYNC batches of the fixed-width plan alternate between them, so the tail of batch k (its last
@@ -304,6 +309,8 @@ struct etlg_ctx {
   uint32_t n_plan_tabs = 0, plan_max_row = 16;
   bool plan_covers_all = false;
   int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
+  int plan_pre = 1;              // ETLG_PLAN_PRE: 0 = the plan kernel runs its look-back itself; 1 = tile prefixes from the sidecar pre-pass (k_plan_pre), one tile per wave; 2 = ... two tiles per wave
+  uint32_t plan_uniform_dw = 0;  // row dwords shared by every planned table (0: they differ — no pre-pass)
   uint32_t plan_margin_pct = 4;  // ETLG_PLAN_MARGIN: LDS window per tile = 64 average frames + this margin (a tile that does not fit is read in place)
   bool ctl_overlap_mode = true;  // ETLG_CTL_OVERLAP
   uint32_t plan_dbg = 0;         // ETLG_PLAN_DBG: bit 0 = no LDS staging (tests of the in-place reader)

@@ -146,6 +146,9 @@ DEV int plan_find(const PlanParams& q, uint32_t rel_u) {
 // The transaction state carried into the batch is NOT part of the fold (virtual group -1 holds the identity): a tile whose
 // prefix holds no mark patches it in afterwards (plan_resolve) — so only the first tiles of a batch depend on the batch before
 // it, and consecutive ASYNC batches can run side by side (DecParams.flags bit 4, host.cpp "two streams").
+constexpr uint32_t kPreBeginLen = kBodyOff + 20u, kPreCommitLen = kBodyOff + 25u;   // CopyData + XLogData head + tag, then lsn:8 ts:8 xid:4 (Begin) / flags:1 lsn:8 end:8 ts:8 (Commit): 51 and 56 bytes
+constexpr int kPreTilesPerWave = 16, kPreWaves = 16;   // the pre-pass: tiles a wave takes, waves of a workgroup
+constexpr uint32_t kPreGroupLog = 8;                   // ... tiles per group = kPreTilesPerWave * kPreWaves = 1 << kPreGroupLog
 constexpr uint32_t kPlanMaxPolls = 1u << 15;   // bounded spin (tens of milliseconds): a give-up sends the batch to the generic kernels
 
 struct PlanPre2 { unsigned long long a0 = 0, l0 = 0, a1 = 0, l1 = 0; bool valid = false; };
@@ -329,8 +332,13 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
   const uint64_t agg = ((uint64_t)tot_mark << 32) | tot_fx;
   const bool early = (tile & 63u) == 63u;   // the group's folder: the groups behind it wait for what it publishes next
   uint64_t ex = 0, ex_lsn = 0;
-  plan_publish2(q.desc, tile, agg, tile_lsn);
-  if (early) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, agg, tile_lsn, failp, PlanPre2(), ex, ex_lsn);
+  // With the sidecar pre-pass (q.pre) the tile's prefix is a record in memory: nothing is published, nothing resolved. What the
+  // pre-pass assumed about a frame it never read — a Begin is 51 bytes, a Commit 56, everything else a row of pre_row_dw dwords —
+  // is checked here against the frame itself; a frame that breaks it sends the batch to the generic kernels like any other
+  // shape the plan does not cover.
+  if (q.pre) bad |= (uint32_t)((isB && flen != kPreBeginLen) || (isC && flen != kPreCommitLen) || (isI && ti >= 0 && row_dw != q.pre_row_dw));
+  else plan_publish2(q.desc, tile, agg, tile_lsn);
+  if (early && !q.pre) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, agg, tile_lsn, failp, PlanPre2(), ex, ex_lsn);
   {
     const uint64_t h0 = rd64(m, fr);        // 'd' | len:4 | 'w' | 2 bytes of wal_start
     const uint32_t len = __builtin_bswap32((uint32_t)(h0 >> 8));
@@ -435,8 +443,21 @@ DEV void plan_late_carry(DecParams& p, uint32_t* failp) {
 // Finish, part 1: everything that LOADS — the look-back's answer, with it the open Begin's LSN — and the transaction context. A wave
 // runs this for both of its tiles before it stores anything: memory operations of a wave return in order, so a descriptor load issued
 // behind a tile's row / header stores waits for those stores to be acknowledged first.
+// The two words the sidecar pre-pass left for a tile — its prefix inside its group of 64, the group's prefix — through scalar loads
+// (one address per wave; written by the kernels before this one on the stream), requested before the tile's bytes are.
+struct PlanPreWords { unsigned long long g0 = 0, g1 = 0, t0 = 0, t1 = 0; };
+DEV PlanPreWords plan_pre_load(const PlanParams& q, uint32_t tile) {
+  PlanPreWords w;
+  if (q.pre && tile < q.ntiles) {
+    const ETLG_CONST_AS unsigned long long* dt = (const ETLG_CONST_AS unsigned long long*)(uintptr_t)(q.pre + 2 * (size_t)tile);
+    const ETLG_CONST_AS unsigned long long* dg = (const ETLG_CONST_AS unsigned long long*)(uintptr_t)(q.pre + 2 * ((size_t)q.ntiles + (tile >> kPreGroupLog)));
+    w.t0 = dt[0]; w.t1 = dt[1]; w.g0 = dg[0]; w.g1 = dg[1];
+  }
+  return w;
+}
+
 template <int RD>
-DEV void plan_resolve(DecParams& p, const PlanParams& q, uint32_t tile, PlanLocal<RD>& L, unsigned long long& tprev, const PlanPre2& pre = PlanPre2()) {
+DEV void plan_resolve(DecParams& p, const PlanParams& q, uint32_t tile, PlanLocal<RD>& L, unsigned long long& tprev, const PlanPre2& pre = PlanPre2(), const PlanPreWords& pw = PlanPreWords()) {
   if (L.done) return;
   const uint32_t lane = threadIdx.x;
   const uint32_t f = tile * 64u + lane;
@@ -448,7 +469,11 @@ DEV void plan_resolve(DecParams& p, const PlanParams& q, uint32_t tile, PlanLoca
   uint64_t ex = L.ex, ex_lsn = L.ex_lsn;
 
   // ---- (3) the look-back's answer
-  if (!L.early) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, L.agg, L.tile_lsn, failp, pre, ex, ex_lsn);
+  if (q.pre) {   // the pre-pass left the tile's prefix inside its group and the group's prefix: asked for at the kernel's start (plan_pre_load)
+    const PlanFold r = fold_f(fold_of(pw.g0, pw.g1), fold_of(pw.t0, pw.t1));
+    ex = fold_agg(r); ex_lsn = fold_lsn(r);
+  }
+  else if (!L.early) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, L.agg, L.tile_lsn, failp, pre, ex, ex_lsn);
   PSTAMP(7);
   uint32_t pre_mark = (uint32_t)(ex >> 32);
   if (pre_mark == 0) {   // no Begin / Commit before this tile in the batch: the state the batch started from decides (virtual Begin before frame 0)
@@ -609,6 +634,7 @@ DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
   if (!(p.flags & 16u) && !load_carry(p)) return;
   const uint32_t t0 = TWO ? 2u * blockIdx.x : blockIdx.x;
   const TileSpan sa = plan_span(p, t0);
+  const PlanPreWords pwa = plan_pre_load(q, t0), pwb = TWO ? plan_pre_load(q, t0 + 1u) : PlanPreWords();
   TileSpan sb = sa;
   if (TWO && t0 + 1u < q.ntiles) sb = plan_span(p, t0 + 1u);   // B's offsets travel while A is worked on
   PlanLocal<RD> A;
@@ -624,16 +650,139 @@ DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
     }
     // both tiles' first look-back words are requested before the first wait: one round trip instead of two
     PlanPre2 preA, preB;
-    if (!A.done && !A.early) preA = plan_prefetch2(q.desc, q.desc + 2 * (size_t)q.ntiles, t0);
-    if (!B.done && !B.early) preB = plan_prefetch2(q.desc, q.desc + 2 * (size_t)q.ntiles, t1);
-    plan_resolve(p, q, t0, A, tprev, preA);
-    plan_resolve(p, q, t1, B, tprev, preB);
+    if (!A.done && !A.early && !q.pre) preA = plan_prefetch2(q.desc, q.desc + 2 * (size_t)q.ntiles, t0);
+    if (!B.done && !B.early && !q.pre) preB = plan_prefetch2(q.desc, q.desc + 2 * (size_t)q.ntiles, t1);
+    plan_resolve(p, q, t0, A, tprev, preA, pwa);
+    plan_resolve(p, q, t1, B, tprev, preB, pwb);
     plan_store<true>(p, q, t0, A, tprev);
     plan_store<false>(p, q, t1, B, tprev);
   } else {
-    plan_resolve(p, q, t0, A, tprev);
+    plan_resolve(p, q, t0, A, tprev, PlanPre2(), pwa);
     plan_store<false>(p, q, t0, A, tprev);
   }
+}
+
+// ---- the sidecar pre-pass ----------------------------------------------------------------------------------------------------
+// The look-back is what makes a plan tile wait: two or three dependent round trips past the L2s (1.5-2 us each) in the middle of
+// every tile, ~10 of the kernel's 51 us on cfg2, and the reason the batch runs as one lock-step round (profiles/r04ad: the same
+// kernel with its prefixes given is 37 us, one tile per wave). But what a plan tile needs from its predecessors — fixed-arena dwords,
+// the last Begin / Commit, the open Begin's LSN — is a function of WHICH frames are Begins and Commits, and when every planned table
+// has the same row size that can be read off the offsets sidecar: pgoutput's Begin is kPreBeginLen bytes on the wire, its Commit
+// kPreCommitLen, and a frame of another length is priced as a row. So a small kernel runs the look-back AHEAD of the decode — one wave
+// per tile over the sidecar (3.5 % of the input's bytes; the tag byte is read only for the frames of those two lengths, the LSN
+// only for Begins), same descriptors, same fold — and leaves every tile's exclusive prefix in memory; the decode kernel picks its
+// record up with the tile's offsets and never talks to another tile. It also runs beside the decode of the batch BEFORE it (the two
+// decode streams): its cost leaves the chain's critical path. The decode kernel verifies what the pre-pass assumed frame by frame
+// (plan_local): a stream that breaks it — a Begin with trailing bytes, a row of another table size, anything that is not B / C / I —
+// gives the batch up to the generic kernels exactly like today.
+// k_plan_pre: one workgroup of sixteen waves per GROUP of 256 tiles, a wave takes 16 consecutive tiles (lane = frame, tile after tile; the
+// offsets of all 16 are requested before the first is looked at). Leaves desc[tile] = the tile's exclusive prefix INSIDE its group and,
+// behind them, gdesc[group] = the exclusive prefix of the group: every workgroup stores its group's
+// aggregate (16-byte word, this launch's status tag in both halves) and takes a ticket; the LAST one to arrive turns the aggregates
+// into exclusive prefixes in place — one wave, 64 groups per trip, the fold carried from trip to trip, a word that has not landed yet
+// polled like a look-back word (no fences: status and payload travel in one store). A decode tile folds the two words it owns: two
+// scalar loads, no other tile.
+__global__ __launch_bounds__(kPreWaves * 64) void k_plan_pre(DecParams p, PlanParams q) {
+  __shared__ unsigned long long s_wagg[kPreWaves][2];
+  const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), g = blockIdx.x;
+  const uint32_t t0 = (g << kPreGroupLog) + wave * (uint32_t)kPreTilesPerWave;
+  // offsets: lane l of iteration i owns frame (t0 + i) * 64 + l; its end is the next lane's start (the next iteration's lane 0 for lane 63)
+  uint32_t o[kPreTilesPerWave + 1];
+#pragma unroll
+  for (int i = 0; i <= kPreTilesPerWave; i++) {
+    const uint64_t f = (uint64_t)(t0 + (uint32_t)i) * 64u + lane;
+    o[i] = p.offs[f < p.nframes ? f : p.nframes];
+  }
+  // the frames of a Begin's or a Commit's length: their tag byte and the eight bytes behind it, all 16 tiles' requests in flight at once
+  // (one round trip; a wave meets a handful of such frames, and waiting for each tile's on its own was most of this kernel)
+  uint32_t cand_m = 0;          // bit i: this lane's frame of tile i is such a frame
+  uint32_t tagv[kPreTilesPerWave];
+  uint64_t lsnv[kPreTilesPerWave];
+#pragma unroll
+  for (int i = 0; i < kPreTilesPerWave; i++) {
+    const uint64_t f = (uint64_t)(t0 + (uint32_t)i) * 64u + lane;
+    const uint32_t o0 = o[i];
+    const uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)o[i + 1]);   // lane 0 of the next tile
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp((int)nxt, (int)o0, 0x130, 0xF, 0xF, false);  // wave_shl:1 — the next lane's offset
+    const uint32_t flen = o1 - o0;
+    const bool cand = f < p.nframes && o1 > o0 && o1 <= p.in_len && (flen == kPreBeginLen || flen == kPreCommitLen);
+    tagv[i] = 0; lsnv[i] = 0;
+    if (cand) { cand_m |= 1u << i; tagv[i] = p.in[o0 + 30] | (flen << 8); lsnv[i] = ld_be64(p.in + o0 + 31); }   // (a Commit's bytes there are its flags and seven of its LSN: unused)
+  }
+  PlanFold run = fold_id();     // fold of this wave's tiles so far (wave-uniform)
+  PlanFold keep = fold_id();    // lane i: the exclusive prefix of tile t0 + i inside the wave
+#pragma unroll
+  for (int i = 0; i < kPreTilesPerWave; i++) {
+    const uint32_t tile = t0 + (uint32_t)i;
+    const uint64_t f = (uint64_t)tile * 64u + lane;
+    const bool live = f < p.nframes;
+    const bool cand = (cand_m >> i) & 1u;
+    const uint32_t tag = tagv[i] & 0xFFu, flen = tagv[i] >> 8;
+    const uint64_t lsn = lsnv[i];
+    const bool isB = cand && flen == kPreBeginLen && tag == 'B', isC = cand && flen == kPreCommitLen && tag == 'C';
+    const uint32_t fixed_dw = !live ? 0u : isB ? 2u : isC ? 4u : q.pre_row_dw;
+    const uint32_t mark = isB ? ((((uint32_t)f + 1u) << 1) | 1u) : isC ? (((uint32_t)f + 1u) << 1) : 0u;
+    const uint32_t tot_mark = wave_last(wave_scan_max(mark)), tot_fx = wave_last(wave_scan_add(fixed_dw));
+    uint64_t tile_lsn = 0;
+    if (tot_mark & 1u) {
+      const int src = (int)((tot_mark >> 1) - 1u - tile * 64u);
+      tile_lsn = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(lsn >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lsn, src);
+      tile_lsn &= ~(3ull << 62);   // (an LSN with those bits set fails the decode kernel's own check)
+    }
+    if (lane == (uint32_t)i) keep = run;
+    run = fold_f(run, PlanFold{tot_fx, tot_mark, (uint32_t)tile_lsn, (uint32_t)(tile_lsn >> 32)});
+  }
+  if (lane == 0) { s_wagg[wave][0] = fold_agg(run); s_wagg[wave][1] = fold_lsn(run); }
+  __syncthreads();
+  // the waves of this group in front of this one: every wave scans the sixteen aggregates (lane = wave) and reads its own prefix off
+  const PlanFold winc = fold_scan(lane < (uint32_t)kPreWaves ? fold_of(s_wagg[lane][0], s_wagg[lane][1]) : fold_id());
+  PlanFold before = fold_id();
+  if (wave) {
+    const int src = (int)wave - 1;
+    before = PlanFold{(uint32_t)__builtin_amdgcn_readlane((int)winc.fx, src), (uint32_t)__builtin_amdgcn_readlane((int)winc.mk, src),
+                      (uint32_t)__builtin_amdgcn_readlane((int)winc.l0, src), (uint32_t)__builtin_amdgcn_readlane((int)winc.l1, src)};
+  }
+  if (lane < (uint32_t)kPreTilesPerWave && t0 + lane < q.ntiles) {
+    const PlanFold r = fold_f(before, keep);
+    unsigned long long* d = q.pre_out + 2 * (size_t)(t0 + lane);
+    d[0] = fold_agg(r); d[1] = fold_lsn(r);
+  }
+  if (wave != (uint32_t)kPreWaves - 1u) return;
+  // ---- the group's aggregate, a ticket, and (the last group to arrive) the scan over all of them
+  const uint32_t ng = (q.ntiles + (1u << kPreGroupLog) - 1u) >> kPreGroupLog;
+  unsigned long long* gd = q.pre_out + 2 * (size_t)q.ntiles;
+  const unsigned long long tagbits = (unsigned long long)q.pre_tag << 62;
+  uint32_t ticket = 0;
+  if (lane == 0) {
+    const PlanFold all = fold_f(before, run);
+    ETLG_ST_PAIR(gd + 2 * (size_t)g, tagbits | fold_agg(all), tagbits | fold_lsn(all));
+    ticket = atomicAdd(q.pre_ticket, 1u);
+  }
+  ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+  if (ticket != ng - 1u) return;
+  PlanFold carry = fold_id();
+  unsigned long long na = 0, nl = 0;   // the next trip's words, requested a trip ahead
+  if (lane < ng) ETLG_LD_PAIR(gd + 2 * (size_t)lane, na, nl);
+  for (uint32_t base = 0; base < ng; base += 64u) {
+    const uint32_t gi = base + lane;
+    unsigned long long a = gi < ng ? na : tagbits, l = gi < ng ? nl : tagbits;   // lanes past the last group: the identity, present
+    if (gi + 64u < ng) ETLG_LD_PAIR(gd + 2 * (size_t)(gi + 64u), na, nl);
+    bool have = pair_state(a, l) == tagbits;
+    for (uint32_t polls = 0;; polls++) {
+      if (!have) { ETLG_LD_PAIR(gd + 2 * (size_t)gi, a, l); have = pair_state(a, l) == tagbits; }
+      if (!__ballot(!have)) break;
+      if (polls > kPlanMaxPolls) { if (lane == 0) atomicOr(&p.res->fused_fail, 1u); break; }   // (the decode kernel's result is discarded with it)
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const PlanFold inc = fold_scan(gi < ng ? fold_of(a, l) : fold_id());
+    PlanFold exc;   // previous lane's inclusive value (wave_shr:1), the identity into lane 0
+    exc.fx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.fx, 0x138, 0xF, 0xF, false); exc.mk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.mk, 0x138, 0xF, 0xF, false);
+    exc.l0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.l0, 0x138, 0xF, 0xF, false); exc.l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.l1, 0x138, 0xF, 0xF, false);
+    const PlanFold r = fold_f(carry, exc);
+    if (gi < ng) { gd[2 * (size_t)gi] = fold_agg(r); gd[2 * (size_t)gi + 1] = fold_lsn(r); }   // (status 0: never this or a later launch's tag)
+    carry = fold_f(carry, fold_lane63(inc));
+  }
+  if (lane == 0) __hip_atomic_store(q.pre_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next user of the buffer expects it
 }
 
 __global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan(DecParams p, PlanParams q) {
@@ -652,6 +801,11 @@ __global__ __launch_bounds__(64, ETLG_PLAN_MINWAVES) void k_plan2(DecParams p, P
 extern "C" {
 
 using namespace etlg;
+
+void etlg_k_launch_plan_pre(const DecParams* p, const void* qv, hipStream_t s) {
+  const PlanParams* q = (const PlanParams*)qv;
+  hipLaunchKernelGGL(k_plan_pre, dim3((q->ntiles + (1u << kPreGroupLog) - 1u) >> kPreGroupLog), dim3(kPreWaves * 64), 0, s, *p, *q);
+}
 
 void etlg_k_launch_plan(const DecParams* p, const void* qv, hipStream_t s) {
   const PlanParams* q = (const PlanParams*)qv;

@@ -16,7 +16,7 @@ from etl_amd.decoder import Decoder
 
 DEFAULT = ["two_streams:", "one_stream:ETLG_OVERLAP=0", "one_tile_per_wave:ETLG_PLAN_DBG=512", "two_streams_again:"]
 variants = sys.argv[1:] or DEFAULT
-KNOBS = ("ETLG_PLAN_DBG", "ETLG_OVERLAP", "ETLG_PLAN_MARGIN")
+KNOBS = ("ETLG_PLAN_DBG", "ETLG_OVERLAP", "ETLG_PLAN_MARGIN", "ETLG_PLAN_PRE")
 w = synth.cfg2()
 pool = []
 for k in range(6):
@@ -33,29 +33,36 @@ for v in variants:
         os.environ[a] = b
     d = Decoder(0)
     synth.cfg2().register(d)
-    d.profile(True)
+    PROF = os.environ.get("PROBE_PROF", "1") != "0"
+    d.profile(PROF)
     base = {}
+    t_enq = 0.0
     import time
     t0 = 0.0
     for it in range(6 + 24):
         if it == 6:
-            base = d.profile_read()
+            base = d.profile_read() if PROF else {}
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         keep = []
+        te = time.perf_counter()
         for k in range(6):
             tb, to, nb, nf = pool[k]
             keep.append(d.decode_device(tb.data_ptr(), nb, to.data_ptr(), nf, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC))
+        if it >= 6:
+            t_enq += time.perf_counter() - te
         for b in keep:
             b.sync()
             assert b.rc == 0, b.error
             b.close()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    prof = d.profile_read()
-    row = {"variant": name, "env": envs, "paths": d.debug_paths(), "overlapped": d.debug_overlapped(), "wall_us_per_batch": round(1e6 * wall / (24 * 6), 2),
+    prof = d.profile_read() if PROF else {}
+    row = {"variant": name, "host_enqueue_us_per_batch": round(1e6 * t_enq / (24 * 6), 2), "env": envs, "paths": d.debug_paths(), "overlapped": d.debug_overlapped(), "wall_us_per_batch": round(1e6 * wall / (24 * 6), 2),
            "GBps": round(24 * 6 * (64 << 20) / wall / 1e9, 1)}
-    for kn in ("k_plan",):
+    for kn in ("k_plan", "k_plan_pre"):
+        if kn not in prof or not PROF:
+            continue
         n, ms = prof[kn][0] - base.get(kn, (0, 0))[0], prof[kn][1] - base.get(kn, (0, 0.0))[1]
         if n:
             row[kn + "_us"] = round(1e3 * ms / n, 2)
