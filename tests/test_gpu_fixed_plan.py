@@ -1,7 +1,9 @@
 """Fixed-width decode plans against the oracle, through the C ABI.
 
 k_plan (etl_amd/csrc/plan.hip): whole batches of Begin / Commit / Insert frames into Ready tables of bool / integer
-columns, one wave per tile; anything else makes the kernel give the batch up and the generic kernel decodes it.
+columns, one wave per tile; anything else makes the kernel give the batch up and the generic kernel decodes it. A tile's
+prefix comes from the sidecar pre-pass (k_plan_pre: frames priced by their length) when every planned table has the same row
+size, from the kernel's own look-back otherwise (ETLG_PLAN_PRE=0 forces that).
 The plan of k_fused (etl_amd/csrc/fixed_tile.hip.h): tiles that conform take schema-constant sizing, every other tile
 of the same launch takes the generic body, and the arena must not show the seam.
 Every case runs on both (`fused` fixture: k_fused with 256 / 64 frames per tile forced, k_plan forced, k_plan reading the
@@ -18,19 +20,25 @@ from etl_amd import synth
 pytestmark = pytest.mark.gpu
 
 EXPECT = True
-_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG")
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE")
 
 
-@pytest.fixture(params=["fused256", "fused64", "plan", "plan_one", "plan_inplace"])
+@pytest.fixture(params=["fused256", "fused64", "plan", "plan_one", "plan_inplace", "plan_lookback", "plan_pre_two", "plan_pre_inplace"])
 def fused(request):
     """Yields the frames per tile of the forced k_fused instance, or 0 when k_plan is forced."""
     saved = {k: os.environ.pop(k, None) for k in _KNOBS}
     if request.param.startswith("plan"):
         os.environ["ETLG_FUSED_KERNEL"] = "3"
-        if request.param == "plan_inplace":
+        # plan: the default (sidecar pre-pass, one tile per wave). The look-back kernels: plan_lookback (two tiles per wave, k_plan2),
+        # plan_one (one tile per wave), plan_inplace (tiles read in place instead of through the LDS window)
+        if request.param in ("plan_one", "plan_inplace", "plan_lookback"):
+            os.environ["ETLG_PLAN_PRE"] = "0"
+        if request.param in ("plan_inplace", "plan_pre_inplace"):
             os.environ["ETLG_PLAN_DBG"] = "1"
         if request.param == "plan_one":
             os.environ["ETLG_PLAN_DBG"] = "512"   # one tile per wave (k_plan) instead of two (k_plan2)
+        if request.param == "plan_pre_two":
+            os.environ["ETLG_PLAN_PRE"] = "2"     # the pre-pass in front of the two-tiles-per-wave kernel
     else:
         os.environ["ETLG_FUSED_KERNEL"] = "0" if request.param == "fused256" else "1"
         os.environ["ETLG_FUSED_DBG"] = "64"   # k_fused only: count the tiles that took the plan (DevResult.dbg_t[11])
@@ -347,3 +355,147 @@ def test_k_plan_gives_up_and_the_generic_kernel_answers(what):
             os.environ.pop(k, None)
             if saved[k] is not None:
                 os.environ[k] = saved[k]
+
+
+# ---- the sidecar pre-pass (k_plan_pre): frames priced by their length ------------------------------------------------------------
+def _one_narrow_table(t):
+    t.schema_put(43, 0, NARROW, name="t43")
+    t.table_state(43, 1)
+    t.table_ready(43, 0, [1] * len(NARROW), [1 if c[3] else 0 for c in NARROW])
+
+
+def _pre_pair():
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    d, o = Decoder(0), oracle.Oracle()
+    _one_narrow_table(d); _one_narrow_table(o)
+    return d, o
+
+
+@pytest.mark.parametrize("pre", ["1", "2", "0"])
+def test_prepass_rows_as_long_as_a_begin_or_a_commit(pre):
+    """pgoutput's Begin is 51 bytes on the wire, its Commit 56 — and so is an Insert into a two-column table whose values have three
+    (eight) characters together. The pre-pass reads the tag of every frame of those two lengths, so such rows are priced as rows: the
+    plan is taken, nothing is decoded again, and the arena is the oracle's. (pre = 0: the same stream through the look-back kernel.)"""
+    import random
+    saved = {k: os.environ.pop(k, None) for k in _KNOBS}
+    os.environ["ETLG_FUSED_KERNEL"] = "3"
+    os.environ["ETLG_PLAN_PRE"] = pre
+    try:
+        d, o = _pre_pair()
+        rng = random.Random(5156)
+        for rep in range(3):
+            s = W.Stream()
+            lsn = 0x7000 + 0x10000 * rep
+            n = 0
+            for t in range(60):
+                lsn += 0x100
+                s.add(W.begin(lsn, ts=10 + t, xid=900 + t))
+                for r in range(rng.randrange(0, 90)):
+                    kind = rng.randrange(4)
+                    if kind == 0:
+                        row = [str(rng.randrange(10, 100)), str(rng.randrange(10))]               # 38 + (5 + 2) + (5 + 1) = 51 bytes
+                    elif kind == 1:
+                        row = [str(rng.randrange(1000, 10000)), str(rng.randrange(1000, 10000))]   # 38 + 9 + 9 = 56 bytes
+                    elif kind == 2:
+                        row = [str(rng.randrange(10)), W.NULL]
+                    else:
+                        row = [str(rng.randrange(-2**31, 2**31)), str(rng.randrange(-10**15, 10**15))]
+                    s.add(W.insert(43, row))
+                    n += 1
+                s.add(W.commit(lsn, lsn + 8, ts=20 + t, flags=0))
+            buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+            lens = np.diff(np.asarray(s.offsets))
+            tags = np.asarray([buf[int(x) + 30] for x in s.offsets[:-1]])
+            assert ((lens == 51) & (tags == ord("I"))).any() and ((lens == 56) & (tags == ord("I"))).any()
+            assert _agree(d, o, buf, s.offsets) == 0
+        p = d.debug_paths()
+        assert p["plan"] == 3 and p["plan_redone"] == 0 and p["redone"] == 0, p
+        d.close()
+    finally:
+        for k in _KNOBS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("what", ["begin_with_a_trailing_byte", "commit_with_trailing_bytes", "keepalive_as_long_as_a_begin"])
+def test_prepass_assumption_broken_by_the_stream(what):
+    """The pre-pass takes a Begin for 51 bytes and a Commit for 56. A stream that pads them (the wire parser ignores bytes behind a
+    message), or carries another kind of frame of such a length, breaks what the pre-pass assumed about a frame it never read: the
+    decode kernel notices (every frame is checked against the assumption), the batch is given up, and the generic kernel answers."""
+    saved = {k: os.environ.pop(k, None) for k in _KNOBS}
+    os.environ["ETLG_FUSED_KERNEL"] = "3"
+    try:
+        d, o = _pre_pair()
+        s = W.Stream()
+        lsn = 0x8000
+        for t in range(12):
+            lsn += 0x100
+            pad_b = b"\x00" if (what == "begin_with_a_trailing_byte" and t == 7) else b""
+            pad_c = b"\x00\x00\x00" if (what == "commit_with_trailing_bytes" and t == 5) else b""
+            s.add(W.begin(lsn, ts=10 + t, xid=900 + t) + pad_b)
+            for r in range(40):
+                s.add(W.insert(43, [str(t * 100 + r), str(r)]))
+                if what == "keepalive_as_long_as_a_begin" and t == 6 and r == 20:
+                    s.add_payload(W.keepalive(0x9999) + b"\x00" * (51 - 5 - len(W.keepalive(0x9999))))
+            s.add(W.commit(lsn, lsn + 8, ts=20 + t, flags=0) + pad_c)
+        buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+        _agree(d, o, buf, s.offsets)   # (whatever the oracle makes of the padding, the device makes the same)
+        p = d.debug_paths()
+        assert p["plan"] == 0 and p["plan_redone"] == 1, p
+        d.close()
+    finally:
+        for k in _KNOBS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+def test_prepass_buffers_through_their_rotation():
+    """Fourteen batches of very different sizes through one context: the pre-pass's buffers rotate (four), its status tag cycles
+    (three), and a word a larger batch left in a buffer must never be taken for a smaller one's (the ticket sits at a fixed place,
+    group words carry the launch's tag, prefixes none)."""
+    w = synth.cfg2()
+    d, o = _pair(w)
+    for k, kb in enumerate((4096, 120, 2300, 115, 6000, 130, 130, 2500, 120, 4500, 125, 250, 120, 2100)):   # 1 .. 4 groups of 256 tiles
+        buf, offs = w.fill(kb << 10)
+        assert len(offs) > 1
+        assert _agree(d, o, buf, offs) == 0, (k, kb)
+    p = d.debug_paths()
+    assert p["plan"] == 14 and p["plan_redone"] == 0 and p["redone"] == 0, p
+    d.close()
+
+
+@pytest.mark.skipif(os.environ.get("ETLG_SIMT_RUN") == "1", reason="1.1 M frames: minutes on the emulator")
+def test_prepass_more_than_64_groups():
+    """130 MiB of cfg2 in one batch: 18 k tiles are 71 groups of 256, so the last group to arrive scans the group aggregates in two
+    trips with the fold carried over; size-independent checks on the whole arena, the oracle on its head and tail."""
+    from etl_amd.decoder import Decoder
+    w = synth.cfg2()
+    d = Decoder(0)
+    w.register(d, ready=True)
+    buf, offs = w.fill(130 << 20)
+    nf = len(offs) - 1
+    assert (nf + 63) // 64 > 64 * 256
+    b = d.decode(buf, offs)
+    assert b.error is None
+    h = b.host()
+    assert h.n_events == nf and d.debug_paths()["plan"] == 1 and d.debug_paths()["plan_redone"] == 0
+    tags = buf[offs[:-1].astype(np.int64) + 30]
+    fixed_dw = np.where(tags == ord("B"), 2, np.where(tags == ord("C"), 4, 6)).astype(np.int64)
+    want_body = np.concatenate([[0], np.cumsum(fixed_dw)[:-1]]) * 4
+    assert np.array_equal(np.asarray(h.body_off, dtype=np.int64), want_body)          # every tile's prefix, all 71 groups
+    assert len(h.fixed) == int(fixed_dw.sum()) * 4
+    assert np.array_equal(np.asarray(h.kind), tags)
+    # commit_lsn of every row = final_lsn of the Begin that opened its transaction (the LSN the pre-pass folds across tiles and groups)
+    is_b = tags == ord("B")
+    b_lsn = np.zeros(nf, dtype=np.uint64)
+    pos = offs[:-1].astype(np.int64)[is_b] + 31
+    raw = np.stack([buf[pos + i] for i in range(8)], axis=1).astype(np.uint64)
+    b_lsn[is_b] = sum(raw[:, i] << np.uint64(8 * (7 - i)) for i in range(8))
+    last_b = np.maximum.accumulate(np.where(is_b, np.arange(nf), -1))
+    rows = tags == ord("I")
+    assert (last_b[rows] >= 0).all()
+    assert np.array_equal(np.asarray(h.commit_lsn, dtype=np.uint64)[rows], b_lsn[last_b[rows]])
+    d.close()

@@ -18,13 +18,14 @@ PATHS = {
     "fused256": {"ETLG_FUSED_KERNEL": "0"},   # k_fused, 256 frames per tile
     "fused64": {"ETLG_FUSED_KERNEL": "1"},    # k_fused, 64 frames per tile
     "cells": {"ETLG_FUSED_KERNEL": "2"},      # k_cells (column-parallel)
-    "plan": {"ETLG_FUSED_KERNEL": "3"},       # the fixed-width plan whenever the batch is eligible, no back-off (k_plan2: two tiles per wave)
-    "plan_one": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_DBG": "512"},     # ... one tile per wave (k_plan, the kernel wide rows take)
+    "plan": {"ETLG_FUSED_KERNEL": "3"},       # the fixed-width plan whenever the batch is eligible, no back-off (tile prefixes from the sidecar pre-pass where the tables allow it)
+    "plan_lookback": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0"},   # ... with the kernel's own look-back (k_plan2: two tiles per wave)
+    "plan_one": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0", "ETLG_PLAN_DBG": "512"},     # ... one tile per wave (k_plan, the kernel wide rows take)
     "plan_inplace": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_DBG": "1"},   # ... reading the input in place instead of the LDS window
     "noplan": {"ETLG_PLAN": "0"},             # the default choice without the plan
     "multipass": {"ETLG_FORCE_MULTIPASS": "1"},
 }
-_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG")
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE")
 
 
 @pytest.fixture(params=sorted(PATHS))
@@ -89,7 +90,7 @@ def test_large_batch_parity(mk, nbytes, path):
     d.close()
     assert n["redone"] == 0, n
     want = {"fused256": "fused", "fused64": "fused", "cells": "cells", "multipass": "multipass"}.get(path)
-    if path in ("plan", "plan_one", "plan_inplace", "default") and mk is synth.cfg2:
+    if path in ("plan", "plan_lookback", "plan_one", "plan_inplace", "default") and mk is synth.cfg2:
         want = "plan"   # cfg2 is what the fixed-width plan is for
     if want:
         assert n[want] == 2, n

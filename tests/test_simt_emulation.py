@@ -44,7 +44,7 @@ def _run_gpu_file_on_emulator(simt_lib, args, timeout, order=None):
     env.pop("ETLG_SIMT_ORDER", None)
     if order:
         env["ETLG_SIMT_ORDER"] = order   # the lanes of a workgroup run in another order than 0, 1, 2, ... between rendezvous (tests/simt/simt.cpp)
-    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG"):
+    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args,
                          capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout + 60)
