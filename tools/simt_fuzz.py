@@ -125,7 +125,8 @@ dec.close()
 print("DONE seed", seed, "scan", "iterations", it, "mismatches", bad, flush=True)
 '''
 
-PATHS = [{}, {"ETLG_FUSED_KERNEL": "0"}, {"ETLG_FUSED_KERNEL": "1"}, {"ETLG_FUSED_KERNEL": "2"}, {"ETLG_FORCE_MULTIPASS": "1"}]
+PATHS = [{}, {"ETLG_FUSED_KERNEL": "0"}, {"ETLG_FUSED_KERNEL": "1"}, {"ETLG_FUSED_KERNEL": "2"}, {"ETLG_FORCE_MULTIPASS": "1"},
+         {"ETLG_FUSED_KERNEL": "3"}, {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0"}]   # ... the plan forced: behind its sidecar pre-pass, with its own look-back
 
 
 def main():
