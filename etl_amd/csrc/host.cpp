@@ -122,7 +122,7 @@ struct BatchGuard {  // an etlg_decode that fails half way returns what the batc
 };
 int32_t build_side_inputs(etlg_ctx* c, etlg_batch* b, const std::vector<EpochRec>& eps);
 int32_t setup_outputs(etlg_ctx* c, etlg_batch* b);
-int32_t setup_scratch(etlg_ctx* c, DecParams& p);
+int32_t setup_scratch(etlg_ctx* c, DecParams& p, int set = 0);
 bool plan_wanted(etlg_ctx* c, const etlg_batch* b);
 int32_t enqueue_single(etlg_ctx* c, etlg_batch* b, int level);
 int32_t standard_path(etlg_ctx* c, etlg_batch* b);
@@ -255,6 +255,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   (void)etlg_k_plan_set_lds();
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_PRE")) c->plan_pre = atoi(pm);
+  if (const char* pm = getenv("ETLG_CTL_HOLD")) c->ctl_hold_mode = atoi(pm) != 0;
   if (const char* pm = getenv("ETLG_PLAN_MARGIN")) c->plan_margin_pct = (uint32_t)atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_DBG")) c->plan_dbg = (uint32_t)atoi(pm);
   { const char* e = getenv("ETLG_CTL_OVERLAP"); c->ctl_overlap_mode = !(e && e[0] == '0'); }   // 0: batches on the control path stay on one decode stream
@@ -287,6 +288,9 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   if (c->mp_tail) (void)hipEventDestroy(c->mp_tail);
   if (c->h_ctl_list) (void)hipHostFree(c->h_ctl_list);
   if (c->h_ctl_stage) (void)hipHostFree(c->h_ctl_stage);
+  if (c->ctl_alt.h_ctl_list) (void)hipHostFree(c->ctl_alt.h_ctl_list);
+  if (c->ctl_alt.h_ctl_stage) (void)hipHostFree(c->ctl_alt.h_ctl_stage);
+  for (DevBuf* b : {&c->ctl_alt.d_tag, &c->ctl_alt.d_emit, &c->ctl_alt.d_ffixed, &c->ctl_alt.d_fheap, &c->ctl_alt.d_blk32, &c->ctl_alt.d_blk64, &c->ctl_alt.d_ctrl, &c->ctl_alt.d_ctrl_stage}) b->release();
   c->d_ctl_res.release();
   if (c->scan_stream) (void)hipStreamDestroy(c->scan_stream);
   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
@@ -775,7 +779,8 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   clear_error(c);
   if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
   HIPCHK(c, hipSetDevice(c->device));
-  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
+  // (the batch a call left deferred — a boundary scan in flight, a control pre-pass running ahead — is flushed below, once this call
+  // knows whether it is itself a batch of the pipelined control path: such a batch sends its own pre-pass out FIRST)
   bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE;
   const bool out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
   const bool no_ctrl = flags & ETLG_F_NO_CONTROL;
@@ -822,6 +827,14 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   for (const etlg_batch* pb : c->pending) if (pb->pending && !pb->ctl_async) pending_optimistic = true;
   const bool ctl_ahead = async_ok && !no_ctrl && c->last_had_ctrl && !scan && nframes && c->ctl_async_mode && !pending_optimistic;
   const bool async = async_ok && (no_ctrl || !c->last_had_ctrl || ctl_ahead);
+  // The pipelined control path, one step deeper (round 4): when the batch held back by the previous call is on that path too, THIS
+  // batch's pre-pass goes out before the held one is flushed — i.e. before the host waits for the held batch's pre-pass, runs its
+  // control plane (~120 us of host work per 64 MiB of cfg5) and enqueues its decode. The pre-pass of batch k + 1 then runs while the
+  // host works on batch k instead of beside batch k's decode kernel (where its small kernels only get going as that one drains, and
+  // the host's wait for them was 130 us per batch). The pre-pass kernels read the input and the transaction state the pre-pass before
+  // them left on the device — nothing the host control plane of the held batch changes. Two pre-passes in flight: two sets of buffers.
+  const bool hold = ctl_ahead && c->ctl_hold_mode && c->deferred && c->deferred->defer_ctl;
+  if (!hold) { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   hipStream_t s = c->stream;
   if (!async) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
 
@@ -881,8 +894,10 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
       else if (prev->kdone) { HIPCHK(c, hipStreamWaitEvent(c->ctl_stream, prev->kdone, 0)); cp.carry = prev->d_res_blk; }   // an optimistic batch: its decode result
       else { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; cp.in_txn = c->in_txn; cp.final_lsn = c->final_lsn; cp.next_ord = c->next_ord; }
     }
+    b->ctl_set = (int)(c->ctl_seq & 1u);   // (the held batch's pre-pass wrote the other set)
     cp.res = (DevResult*)c->d_ctl_res.p + (c->ctl_seq++ % etlg_ctx::kCtlRing);
-    { const int32_t rc = ctl_begin(c, b, cp, c->ctl_stream, true); if (rc != ETLG_OK) return rc; }
+    { const int32_t rc = ctl_begin(c, b, cp, c->ctl_stream, true); if (rc != ETLG_OK) { if (hold) { const int32_t rc_ = flush_deferred(c); (void)rc_; } return rc; } }
+    if (hold) { const int32_t rc_ = flush_deferred(c); (void)rc_; }   // now the held batch: its pre-pass result, its control plane, its decode
     b->deferred = true; b->defer_ctl = true; b->pending = true; b->v.on_device = 1;
     c->deferred = b; c->pending.push_back(b);
     c->ctl_ahead_n++;

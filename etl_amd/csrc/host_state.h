@@ -327,6 +327,11 @@ struct etlg_ctx {
   DevBuf d_ctl_res;                   // ring of kCtlRing pre-pass result blocks (the pre-passes chain their transaction state through them)
   static constexpr uint32_t kCtlRing = 4, kCtlListCap = 4096, kCtlStageCap = 512u << 10;
   uint32_t ctl_seq = 0;
+  // A second set of everything a control pre-pass writes (per-frame scratch, the control list, the gathered bytes and their pinned
+  // heads): the pre-pass of batch k + 1 goes out BEFORE the host control plane of batch k has read batch k's (etlg_decode), so two
+  // are in flight and take turns (etlg_batch::ctl_set).
+  struct CtlAlt { DevBuf d_tag, d_emit, d_ffixed, d_fheap, d_blk32, d_blk64, d_ctrl, d_ctrl_stage; CtrlFrame* h_ctl_list = nullptr; uint8_t* h_ctl_stage = nullptr; } ctl_alt;
+  bool ctl_hold_mode = true;          // ETLG_CTL_HOLD=0: the held batch is flushed before the next pre-pass goes out (round 3's order)
   CtrlFrame* h_ctl_list = nullptr;    // pinned: the first kCtlListCap entries of the control list ...
   uint8_t* h_ctl_stage = nullptr;     // ... and the first kCtlStageCap gathered bytes, copied behind the pre-pass without asking for their sizes
   hipEvent_t mp_tail = nullptr; bool mp_tail_set = false;   // behind the last multi-pass launch (it shares the per-frame scratch with the pre-pass)
@@ -395,6 +400,7 @@ struct etlg_batch {
   DevBuf* scan_offs = nullptr;  // ASYNC without a sidecar: the batch's own offsets (from the context's pool)
   int plan_decided = -1;      // decode_tail: -1 not decided yet, 0 / 1 = the first attempt is the generic kernel / the fixed-width plan
   int sidx = 0;               // decode stream the batch's first attempt was enqueued on (0: etlg_ctx::stream, 1: stream2)
+  int ctl_set = 0;            // which set of control pre-pass buffers its pre-pass wrote (etlg_ctx::ctl_alt is set 1)
   bool force_rerun = false;   // a batch of the chain before this one had to be decoded again: whatever this one produced started from the wrong state
   hipEvent_t kdone = nullptr; // ASYNC: recorded behind the batch's kernels on its decode stream (the result copy waits for it)
   hipEvent_t done = nullptr;  // recorded behind the copy of the result block: syncing a batch waits for IT, not for the whole stream
