@@ -14,7 +14,10 @@
 //   3. sizes are schema constants, so ONE 64-bit look-back descriptor per tile carries everything a tile needs from
 //      its predecessors: {last Begin/Commit mark : 30, fixed-arena dwords : 32}. Events are one per frame (the event
 //      prefix is the frame index), the heap is empty, ordinals follow from frame indexes (every frame of a
-//      conforming batch consumes one: apply.rs:2284-2292, 2339, 2457),
+//      conforming batch consumes one: apply.rs:2284-2292, 2339, 2457). When every planned table has the same row size
+//      even that is known before a frame is read — a Begin is 51 bytes on the wire, a Commit 56, every other frame a
+//      row — and a pre-pass over the offsets sidecar (k_plan_pre, below) hands every tile its prefix: the decode kernel
+//      then has no look-back at all and its tiles are independent (what was assumed is verified frame by frame),
 //   4. integers are parsed from a right-aligned 12- or 20-byte field, four digits per 32-bit word (SWAR).
 //
 // Anything else — another tag, a table that is not eligible, a NULL in a NOT NULL column, text the lean parser does
