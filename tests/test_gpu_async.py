@@ -113,7 +113,20 @@ def async_fuzz_round(seed):
     host_in = rng.random() < 0.25          # host buffers: with a sidecar they are staged on the copy stream, without one decoded synchronously
     side_calls = rng.random() < 0.3        # other calls of the ABI between the batches of the chain
     flags = (0 if host_in else abi.F_INPUT_ON_DEVICE) | abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC | (abi.F_NO_CONTROL if no_ctrl else 0)
-    o, d = oracle.Oracle(), Decoder(0)
+    # library knobs read when the context is created (drawn from a generator of their own: the rounds stay what they were): the plan's
+    # sidecar pre-pass on / off / in front of two tiles per wave, the order of the pipelined control path
+    krng = random.Random(seed * 7919 + 13)
+    knobs = {"ETLG_PLAN_PRE": krng.choice(["1", "1", "0", "2"]), "ETLG_CTL_HOLD": krng.choice(["1", "1", "0"])}
+    saved_knobs = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        o, d = oracle.Oracle(), Decoder(0)
+    finally:
+        for k, v in saved_knobs.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     ready = not w.cfg.emit_relations
     w.register(o, ready=ready)
     w.register(d, ready=ready)
