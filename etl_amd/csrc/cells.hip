@@ -733,9 +733,20 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   }
   __syncthreads();
   TSTAMP(4);
+#ifdef ETLG_CELLS_NOLB_ABLATION
+  // measurement build only (tools/build_variant.py ... -DETLG_CELLS_NOLB_ABLATION, results are wrong; not a runtime bit: a branch here cost
+  // the shipped kernel its spill-free register allocation): with ETLG_FUSED_DBG bit 17 no look-back at all — made-up prefixes of a
+  // plausible size, no descriptor traffic: what a tile would cost if its prefixes were given (the question the plan kernel's pre-pass
+  // answered)
+  if (dbg_u & 0x20000u) {
+    if (wave == 0 && lane == 0) { s64[4] = ((uint64_t)(tile * 64u) << 32) | (tile * 64u * 48u); s64[5] = (uint64_t)tile * 64u * 40u; s32[12] = 0; s32[13] = 1u; s64[6] = pg.final_lsn; s64[3] = pg.next_ord; }
+  } else
+#endif
+  {
   if (wave == 0) { const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, s64[0], 0, fail); if (lane == 0) s64[4] = a; }
   if (wave == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
   if (wave == 2 % NW && NW > 2 && !seq_lb) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
+  }
   if (NW <= 2 && wave == 0) {
     if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
     if (!seq_lb) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);

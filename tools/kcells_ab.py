@@ -37,7 +37,7 @@ for it in range(4 + 16):
     if it == 4:
         base = d.profile_read()
     b = d.decode_device(tb.data_ptr(), tb.numel(), to.data_ptr(), len(offs) - 1, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
-    assert b.rc == 0, b.error
+    assert b.rc == 0 or os.environ.get("PROBE_NO_ASSERT"), b.error
     b.close()
 row["cfg3"] = per_launch(d.profile_read(), base)
 d.close()
@@ -53,7 +53,7 @@ for it, (tb, to, _) in enumerate(batches):
     if it == 2:
         base = d.profile_read()
     b = d.decode_device(tb.data_ptr(), tb.numel(), to.data_ptr(), to.numel() - 1, abi.F_OUTPUT_ON_DEVICE)
-    assert b.rc == 0, b.error
+    assert b.rc == 0 or os.environ.get("PROBE_NO_ASSERT"), b.error
     b.close()
 row["cfg5"] = per_launch(d.profile_read(), base)
 row["cfg5_paths"] = d.debug_paths()
