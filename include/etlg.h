@@ -297,7 +297,9 @@ void etlg_host_free(void* p);
  *         | keepalive 'k' | u64 wal_end | i64 ts | u8 reply
  * frame_offsets: optional sidecar of nframes+1 byte offsets (the host learns
  * each frame length on receipt); NULL = the device scans record boundaries
- * itself and nframes is ignored.
+ * itself and nframes is ignored. (The sidecar is also what lets fixed-width
+ * batches skip every inter-tile dependency: frames are priced by their length
+ * before they are read — DESIGN.md 3.0, k_plan_pre. Results do not depend on it.)
  * Returns 0, or the etlg_error_kind of the first failing frame (the batch is
  * still returned and holds every event before it). */
 int32_t etlg_decode(etlg_ctx* ctx, const uint8_t* buf, size_t len,
