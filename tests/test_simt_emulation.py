@@ -39,83 +39,112 @@ def test_product_loader_refuses_the_emulator_build(simt_lib):
     assert "refused" in out.stdout, out.stdout + out.stderr
 
 
-def _run_gpu_file_on_emulator(simt_lib, args, timeout, order=None):
+def _emu_env(simt_lib, timeout, order=None, drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE")):
     env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG=str(timeout))
     env.pop("ETLG_SIMT_ORDER", None)
     if order:
         env["ETLG_SIMT_ORDER"] = order   # the lanes of a workgroup run in another order than 0, 1, 2, ... between rendezvous (tests/simt/simt.cpp)
-    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE"):
+    for k in drop:
         env.pop(k, None)
-    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args,
-                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout + 60)
-    tail = out.stdout[-3000:] + out.stderr[-1000:]
-    assert out.returncode == 0, tail
+    return env
+
+
+def _pytest_job(args, timeout, order=None):
+    return dict(cmd=[sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, timeout=timeout, order=order, drop=None)
+
+
+# Every emulated run of this file is a subprocess of its own (the parity files pick the library up from the environment); they are all
+# started when the first of them is asked for and run side by side — the suite's wall time is the longest of them, not their sum.
+_JOBS = {
+    "scenarios": _pytest_job(["tests/test_gpu_parity.py", "-k", "scenario_parity or temporal_matrix or wider_than_16"], 900),
+    "shard_async": _pytest_job(["tests/test_shard_decode.py", "tests/test_gpu_async.py", "-k", "not 8-"], 900),
+    "copy_scan": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k", "not device_resident and not device_input and not 16777216"], 600),
+    "plans": _pytest_job(["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or k_plan or prepass or (cfg2 and default)"], 900),
+    "hand_off": _pytest_job(["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py"], 600),
+    "lane_order": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_protobuf.py",
+                               "-k", "not device_resident and not device_input and not 16777216 and not synthetic and not kat_ and not random"], 600, order="shuffle"),
+    "copy_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], timeout=600, order=None,
+                      drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_COPY_DIRECT", "ETLG_COPY_KERNEL")),
+    "cell_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "cell_fuzz.py"), "3", "7"], timeout=600, order=None,
+                      drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG")),
+}
+
+
+@pytest.fixture(scope="module")
+def emu_jobs(simt_lib):
+    procs = {}
+    for name, j in _JOBS.items():
+        env = _emu_env(simt_lib, j["timeout"], j["order"]) if j["drop"] is None else _emu_env(simt_lib, j["timeout"], j["order"], j["drop"])
+        procs[name] = subprocess.Popen(j["cmd"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+    yield procs
+    for pr in procs.values():
+        if pr.poll() is None:
+            pr.kill()
+
+
+def _result(emu_jobs, name):
+    """(return code, stdout, stderr) of one of the emulated runs."""
+    out, err = emu_jobs[name].communicate(timeout=_JOBS[name]["timeout"] + 120)
+    return emu_jobs[name].returncode, out, err
+
+
+def _passed(emu_jobs, name):
+    rc, out, err = _result(emu_jobs, name)
+    tail = out[-3000:] + err[-1000:]
+    assert rc == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
     return tail
 
 
-def test_scenarios_on_every_kernel_path(simt_lib):
+def test_scenarios_on_every_kernel_path(emu_jobs):
     """Every scenario of tests/scenarios.py on the device paths (default choice, k_fused 256 / 64, k_cells, the plan kernels,
     multi-pass), byte for byte against the oracle — the same test the GPU box runs, on emulated kernels; plus the temporal matrix
     (fast paths + chrono grammar) and tables of 17 / 24 / 32 columns (k_cells' WIDE instantiation)."""
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_parity.py", "-k", "scenario_parity or temporal_matrix or wider_than_16"], 900)
-    assert " passed" in tail and "failed" not in tail, tail
+    _passed(emu_jobs, "scenarios")
 
 
-def test_sharded_decode_and_async_chain(simt_lib):
+def test_sharded_decode_and_async_chain(emu_jobs):
     """The multi-GPU recipe (cut after Commit, broadcast control frames, decode per shard, concatenate) and the ASYNC batch
     chain (device-side carried transaction state, poisoned successors), through the C ABI and the emulated kernels."""
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_shard_decode.py", "tests/test_gpu_async.py", "-k", "not 8-"], 900)
-    assert " passed" in tail and "failed" not in tail, tail
+    _passed(emu_jobs, "shard_async")
 
 
-def test_copy_rows_and_boundary_scan(simt_lib):
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k",
-                                                "not device_resident and not device_input and not 16777216"], 600)
-    assert " passed" in tail and "failed" not in tail, tail
+def test_copy_rows_and_boundary_scan(emu_jobs):
+    _passed(emu_jobs, "copy_scan")
 
 
-def test_fixed_width_plans(simt_lib):
+def test_fixed_width_plans(emu_jobs):
     """k_plan (plan.hip) and the fixed-width plan of k_fused (fixed_tile.hip.h): their own parity file with the demand that
     conforming streams really take the plan, and the cfg2 mutation fuzz on the default path (k_plan first, the generic kernel
     behind it)."""
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or k_plan or (cfg2 and default)"], 900)
-    assert " passed" in tail and "failed" not in tail, tail
+    _passed(emu_jobs, "plans")
 
 
-def test_columnar_hand_off(simt_lib):
+def test_columnar_hand_off(emu_jobs):
     """etlg_batch_columns / etlg_batch_rowbinary (columns.hip): the Arrow-layout buffers built by the emulated kernels against
     the host hand-off of the oracle's arena, the RowBinary bytes against oracle/rowbinary.py."""
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py"], 600)
-    assert " passed" in tail and "failed" not in tail, tail
+    _passed(emu_jobs, "hand_off")
 
 
-def test_copy_mutation_fuzz(simt_lib):
+def test_copy_mutation_fuzz(emu_jobs):
     """tools/copy_fuzz.py on the emulated kernels: generated COPY rows with a few mutated bytes (specials, invalid UTF-8, deletions) or
     many benign escape insertions, table-copy path against the oracle — same error, same row, same arena before it; a batch the
     reference rejects never comes out of the one-kernel path. (It found the out-of-field copy loop behind a malformed row boundary.)"""
-    env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="600")
-    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_COPY_DIRECT", "ETLG_COPY_KERNEL"):
-        env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=660)
-    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+    rc, out, err = _result(emu_jobs, "copy_fuzz")
+    assert rc == 0 and "mismatches 0" in out, out[-2000:] + err[-1000:]
 
 
-def test_value_codec_fuzz(simt_lib):
+def test_value_codec_fuzz(emu_jobs):
     """tools/cell_fuzz.py on the emulated kernels: mutated texts of every value class (temporal shapes around chrono's grammar, json
     validity, numeric / float forms, array literals, bytea, uuid) through the decode kernels on three kernel paths, and the decoded
     arena through the Arrow columns, RowBinary and BigQuery rows — against the oracle and its hand-off restatements."""
-    env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG="600")
-    for k in ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG"):
-        env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cell_fuzz.py"), "3", "7"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=660)
-    assert out.returncode == 0 and "mismatching batches 0" in out.stdout and "MISMATCH" not in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+    rc, out, err = _result(emu_jobs, "cell_fuzz")
+    assert rc == 0 and "mismatching batches 0" in out and "MISMATCH" not in out, out[-2000:] + err[-1000:]
 
 
-def test_results_do_not_depend_on_the_lane_order(simt_lib):
+def test_results_do_not_depend_on_the_lane_order(emu_jobs):
     """Between two rendezvous the GPU runs the lanes of a workgroup in no particular order; the emulator's default is 0, 1, 2, ...,
     which hides races (round 3's bytea[] walker had one that only the MI355X showed). The table-copy and hand-off tests again with
     the lanes shuffled at every scheduling round. (The whole GPU suite passes that way too — 1418 tests, a nine-minute run that is
     not part of this suite: ETLG_SIMT_ORDER=shuffle with the recipe of DESIGN §6 'Kernel logic without a GPU'.)"""
-    tail = _run_gpu_file_on_emulator(simt_lib, ["tests/test_gpu_copy.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_protobuf.py",
-                                                "-k", "not device_resident and not device_input and not 16777216 and not synthetic and not kat_ and not random"], 600, order="shuffle")
-    assert " passed" in tail and "failed" not in tail, tail
+    _passed(emu_jobs, "lane_order")
