@@ -63,6 +63,7 @@ _JOBS = {
     "hand_off": _pytest_job(["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py"], 600),
     "lane_order": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_protobuf.py",
                                "-k", "not device_resident and not device_input and not 16777216 and not synthetic and not kat_ and not random"], 600, order="shuffle"),
+    "plans_shuffled": _pytest_job(["tests/test_gpu_fixed_plan.py", "-k", "prepass or conforming or mix_in_one_launch"], 900, order="shuffle"),
     "copy_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], timeout=600, order=None,
                       drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_COPY_DIRECT", "ETLG_COPY_KERNEL")),
     "cell_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "cell_fuzz.py"), "3", "7"], timeout=600, order=None,
@@ -118,6 +119,12 @@ def test_fixed_width_plans(emu_jobs):
     conforming streams really take the plan, and the cfg2 mutation fuzz on the default path (k_plan first, the generic kernel
     behind it)."""
     _passed(emu_jobs, "plans")
+
+
+def test_fixed_width_plans_with_the_lanes_shuffled(emu_jobs):
+    """The plan kernels and the sidecar pre-pass (workgroups of sixteen waves, LDS hand-over of the waves' aggregates, a ticket, the last
+    group's scan) with the lanes of a workgroup run in a shuffled order between rendezvous: results must not depend on it."""
+    _passed(emu_jobs, "plans_shuffled")
 
 
 def test_columnar_hand_off(emu_jobs):
