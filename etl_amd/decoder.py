@@ -353,9 +353,9 @@ class Decoder:
         return self.L.etlg_ctx_profile(self.h, 2 if enable == 2 else 1 if enable else 0)
 
     def profile_read(self):
-        arr = (abi.KernelStat * 16)()
+        arr = (abi.KernelStat * 24)()
         n = C.c_uint32()
-        self.L.etlg_ctx_profile_read(self.h, arr, 16, C.byref(n))
+        self.L.etlg_ctx_profile_read(self.h, arr, 24, C.byref(n))
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
 
     def debug_paths(self):

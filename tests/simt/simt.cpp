@@ -128,6 +128,11 @@ void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void
     g_lds = (uint8_t*)aligned_alloc(64, 160 * 1024 + 4096);
     g_trace = getenv("ETLG_SIMT_TRACE") != nullptr;
     if (const char* wd = getenv("ETLG_SIMT_WATCHDOG")) { signal(SIGALRM, watchdog); alarm((unsigned)atoi(wd)); }
+    if (getenv("ETLG_SIMT_SEGV")) {   // a fault inside an emulated kernel: where every lane stands + a backtrace (on a stack of its own: the lanes' stacks are small)
+      static char alt[1 << 16];
+      stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof(alt); ss.ss_flags = 0; sigaltstack(&ss, nullptr);
+      struct sigaction sa; memset(&sa, 0, sizeof(sa)); sa.sa_handler = watchdog; sa.sa_flags = SA_ONSTACK; sigaction(SIGSEGV, &sa, nullptr);
+    }
   }
   (void)lds_bytes;
   g_body = body; g_arg = arg; g_block = block;
