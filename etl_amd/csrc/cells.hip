@@ -31,7 +31,6 @@
 #define ETLG_DBG_WORD dbg_u   // cells_tile / k_cells keep the debug word in a scalar register of its own
 #define ETLG_TSTAMP_WHO (wave == 0 && lane == 0)   // phase clocks are taken by the tile's spine wave (its role rotates, see cells_tile)
 #include <type_traits>
-#include <cstdio>
 #include "lookback.hip.h"
 #include "utf8_swar.h"
 
@@ -200,28 +199,15 @@ struct CellsLds {
   const uint32_t* bm_sep; const uint32_t* bm_bs; const uint32_t* bm_nl;   // table-copy tiles, one bit per window byte: unescaped tabs / newlines, backslashes, newlines
   uint32_t* cxm;                // table-copy tiles: the columns of each row whose field holds a backslash
   uint64_t (*fcache)[CF]; uint64_t* fc_ok; uint8_t* vinv;   // float4 / float8 cells parsed by the sizing pass, for P3 (see kFloatCache)   // table-copy tiles: where the window's tabs / newlines / backslashes are (one bit per byte)
-  uint64_t* fr_lsn; uint64_t* fr_ord;   // body kernel of the split (PART 2): the transaction context of each frame as the spine kernel left it
 };
-
-// ---- the split form of the tile (k_cells_spine -> k_cells_body): what the spine phases (P1 .. prefix distribution) leave for the cell
-// phases (P3, P4) in memory, one record per tile, in dwords:
-//   [0] number of virtual columns P3 visits  [1] form of the cell table (the spine's TAB)  [16..31] P3's visiting list (64 bytes)
-//   [32 ..)   twelve arrays of CF dwords: slot, meta, n, heap offset, event index, error word, fixed offset lo / hi,
-//             final_lsn lo / hi, ordinal lo / hi of each frame
-//   [32 + 12 CF ..)  the cell table as it stood in LDS: VC x CF dwords (form 1) or 3 x VC x CF (form 0: a tile read in place)
-constexpr uint32_t kHandHdr = 32, kHandFr = 12 * CF;
-constexpr uint32_t hand_stride_dw(uint32_t maxc) { return kHandHdr + kHandFr + 3u * 2u * maxc * CF; }
 
 // Everything after staging. STAGED: `base` is the LDS window holding input bytes [b0, ...), reads
 // may run up to 15 bytes past a frame; otherwise `base` is the input itself (b0 = 0).
 // `p`: parameters whose side-table pointers point at the LDS copy; `pg`: the original ones.
-// PART: 0 the whole tile in one kernel (k_cells); 1 the spine phases only, their results go to the tile's hand-off record `hand`
-// (k_cells_spine); 2 the cell phases only, from the record the kernel head has loaded into LDS (k_cells_body).
-template <int NW, int TAB, bool WIDE, int PART = 0>
+template <int NW, int TAB, bool WIDE>
 DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& q, const CellsLds& sh, const u8* base,
-                    uint32_t b0, uint32_t tile, uint32_t nt, uint32_t copy_bad = 0, uint32_t* hand = nullptr) {
+                    uint32_t b0, uint32_t tile, uint32_t nt, uint32_t copy_bad = 0) {
   constexpr bool STAGED = TAB != 0;
-  constexpr bool SPINE = PART != 2, BODY = PART != 1;   // which phases this instance holds
   constexpr bool COPY = TAB == 2;   // table-copy rows: the window holds COPY text rows, P1 is the field splitter (copy_walk below)
   uint32_t* const s_offs = sh.s_offs; int32_t* const fr_slot = sh.fr_slot; uint32_t* const fr_meta = sh.fr_meta;
   uint32_t* const fr_n = sh.fr_n; uint64_t* const fr_fx = sh.fr_fx; uint32_t* const fr_hp = sh.fr_hp; uint32_t* const fr_ev = sh.fr_ev;
@@ -263,8 +249,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   mask_t heap_cols = 0;  // virtual columns of this frame whose cells reach the heap (wave 0)
   // The single-wave phases (P1, P2b, the look-backs, P4) are the spine of a tile: every other wave of the workgroup waits
   // for them at a barrier, while the cell phases of the other tiles on this SIMD have slack. They run at a raised issue priority.
-  static_assert(!(COPY && PART != 0), "table-copy tiles are not split");
-  if constexpr (SPINE) if (wave == 0) {
+  if (wave == 0) {
     ETLG_WAVE_PRIO(3);
     if (lane < CF) { for (int w = 0; w < 2 * SW; w++) fr_st[w][lane] = 0; fr_err[lane] = 0xFFFFFFFFu; fr_toast[lane] = 0; fr_slot[lane] = -1; fr_meta[lane] = 0; fr_n[lane] = 0; }
     if constexpr (COPY) {
@@ -453,7 +438,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     const uint64_t c = seg & 0x7FFFFFFFu;
     tx.ord = (seg & 0x80000000u) ? c - 1 : start_ord + c - 1;
   };
-  if constexpr (SPINE) if (wave == 0) {
+  if (wave == 0) {
     if (seq_lb) {
       make_tx(txn_lookback(pg, q.d_txn, q.ntiles, tile, txn_agg, fail, s32, s64));   // (in registers: no barrier between the look-back and here)
     }
@@ -541,7 +526,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     if (lane == 0) { s32[10] = pop(scan); s32[11] = pop(present); }
     ETLG_WAVE_PRIO(0);
   }
-  if constexpr (SPINE) __syncthreads();
+  __syncthreads();
   if constexpr (COPY) {
     // copy_fix: the fields that hold a backslash, one per lane (wave = column, lane = row). A field that is exactly `\N` on the raw
     // bytes is NULL (table_row.rs:199); in every other one the escapes are undone IN PLACE (:129-176; unescaping only shrinks, so
@@ -605,8 +590,8 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   TSTAMP(2);
 
   // ================= P2: heap bytes per cell; waves pull virtual columns from a queue
-  const uint32_t n_scan = SPINE ? s32[10] : 0u, n_present = s32[11];
-  if constexpr (SPINE) for (;;) {
+  const uint32_t n_scan = s32[10], n_present = s32[11];
+  for (;;) {
     uint32_t vj = 0;
     if (lane == 0) vj = atomicAdd(&s32[8], 1u);
     vj = __builtin_amdgcn_readfirstlane(vj);
@@ -652,17 +637,15 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
       if (lane == 0) fc_ok[vj] = okm;
     }
   }
-  if constexpr (SPINE) {
   __syncthreads();
   TSTAMP(3);
   ETLG_WAVE_PRIO(3);   // P2b on wave 0, then one look-back per wave
-  }
 
   // ================= P2b (wave 0): shapes, per-frame heap prefix, sizes, look-back
   uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_ev = 0, x_fx = 0, x_hp = 0, cells = 0;
   uint64_t pay[3] = {0, 0, 0};
   int row_slot = -1;
-  if constexpr (SPINE) if (wave == 0) {
+  if (wave == 0) {
     if (live) {
       const uint32_t tag = v.tag;
       if (tag == 'I' || tag == 'U' || tag == 'D') {
@@ -748,7 +731,6 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     }
     x_ev = ie - emit; x_fx = ifx - (fixed >> 2); x_hp = ih - (heap >> 2);  // exclusive, inside the tile
   }
-  if constexpr (SPINE) {
   __syncthreads();
   TSTAMP(4);
 #ifdef ETLG_CELLS_NOLB_ABLATION
@@ -803,33 +785,12 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     fr_hp[lane] = (uint32_t)hp_off;
     fr_ev[lane] = (uint32_t)ev_idx;  // a batch has fewer than 2^32 frames
     if (live) fr_meta[lane] |= (emit ? 1u : 0u) << 11;
-    if constexpr (PART == 1) {   // the frame's transaction context, for the body kernel's P4 (emitted frames only read it)
-      uint32_t* const hf = hand + kHandHdr;
-      hf[8 * CF + lane] = (uint32_t)tx.final_lsn; hf[9 * CF + lane] = (uint32_t)(tx.final_lsn >> 32);
-      hf[10 * CF + lane] = (uint32_t)tx.ord; hf[11 * CF + lane] = (uint32_t)(tx.ord >> 32);
-    }
   }
   ETLG_WAVE_PRIO(0);
   __syncthreads();
   TSTAMP(6);
-  }  // SPINE
-  if constexpr (PART == 1) {
-    // ---- hand-off: the frame arrays, P3's visiting list and the cell table leave LDS as they stand (all waves, coalesced dwords)
-    uint32_t* const hf = hand + kHandHdr;
-    for (uint32_t i = tid; i < (uint32_t)CF; i += NW * 64) {
-      hf[i] = (uint32_t)fr_slot[i]; hf[CF + i] = fr_meta[i]; hf[2 * CF + i] = fr_n[i]; hf[3 * CF + i] = fr_hp[i]; hf[4 * CF + i] = fr_ev[i];
-      hf[5 * CF + i] = fr_err[i]; hf[6 * CF + i] = (uint32_t)fr_fx[i]; hf[7 * CF + i] = (uint32_t)(fr_fx[i] >> 32);
-    }
-    if (tid < 16) hand[16 + tid] = ((const uint32_t*)vlist[1])[tid];
-    if (tid == 0) { hand[0] = n_present; hand[1] = (uint32_t)TAB; }
-    const uint32_t nw = (STAGED ? 1u : 3u) * VC * CF;
-    uint32_t* const ht = hf + kHandFr;
-    if (sh.ct != ht) for (uint32_t i = tid; i < nw; i += NW * 64) ht[i] = sh.ct[i];   // (k_cells_spine1 keeps the table of a tile read in place there from the start)
-    return;
-  }
 
   // ================= P3: decode cells; waves pull virtual columns from a queue
-  if constexpr (BODY) {
   for (;;) {
     uint32_t vj = 0;
     if (lane == 0) vj = atomicAdd(&s32[9], 1u);
@@ -915,24 +876,6 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
   TSTAMP(7);
 
   // ================= P4 (wave 0): finish rows, event headers
-  if constexpr (PART == 2) {   // what the spine wave of k_cells still holds in registers here comes back from the hand-off record
-    if (wave == 0 && lane < nt) {
-      const uint32_t meta = fr_meta[lane];
-      emit = (meta >> 11) & 1u;
-      old_kind = meta_old(meta);
-      v.tag = meta_tag(meta);
-      if (emit) {   // (an emitted frame passed the envelope checks: its offsets are in range)
-        v.fr = base + (s_offs[lane] - b0); v.e = base + (s_offs[lane + 1] - b0);
-        row_slot = fr_slot[lane];
-        if (v.tag == 'I' || v.tag == 'U' || v.tag == 'D') {
-          rel_id = ld_be32(v.fr + kBodyOff);
-          const DevSlot& s = p.slots[row_slot];
-          old_sz = old_kind == ETLG_OLD_FULL ? s.row_full : old_kind == ETLG_OLD_KEY ? s.row_key : 0u;
-        }
-        tx.final_lsn = sh.fr_lsn[lane]; tx.ord = sh.fr_ord[lane];
-      }
-    }
-  }
   if (wave != 0 || !emit) return;
   if (dbg_u & 2) return;
   ETLG_WAVE_PRIO(3);
@@ -988,7 +931,6 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
     write_frame(p, v, tx, dummy, -1, ev_idx, fx_off, hp_off, nullptr, use_lds);
   }
   TSTAMP(8);
-  }  // BODY
 }
 
 #ifndef ETLG_CELLS_MINBLOCKS
@@ -999,9 +941,7 @@ DEV void cells_tile(const DecParams& p, const DecParams& pg, const FusedParams& 
 // COPYK: the tiles are 64 table-copy rows each (etlg_copy_decode): `pg.in` / `pg.offs` are the COPY text rows and their offsets, the
 // cell table has two dwords per cell, and the splitter of cells_tile<.., 2, ..> takes P1's place — the rows reach the arena in one
 // kernel, without being rewritten as Insert frames first (copy.hip stays as the path for batches with a malformed row).
-// PART (see cells_tile): 0 = k_cells, the whole tile; 1 = k_cells_spine, 2 = k_cells_body — the same tile as two kernels, the second
-// of which has no single-wave phase in front of its cell work and no look-back.
-template <int NW, bool WIDE, bool COPYK, int PART = 0>
+template <int NW, bool WIDE, bool COPYK>
 __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecParams pg, FusedParams q) {
   ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[CF + 1];
@@ -1021,22 +961,12 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   __shared__ uint64_t fc_ok[COPYK ? kFloatCache : 1];
   __shared__ uint8_t vinv[COPYK ? 64 : 1];
   __shared__ uint32_t cxm[COPYK ? CF : 1];
-  __shared__ uint64_t fr_lsn[PART == 2 ? CF : 1];
-  __shared__ uint64_t fr_ord[PART == 2 ? CF : 1];
   const uint32_t tid = threadIdx.x;
-  if constexpr (PART != 2) {
   if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
     const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
     for (uint32_t i = tid; i < per; i += NW * 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
   }
   if (!(pg.flags & 16u) && !load_carry(pg)) return;  // ASYNC chain: the state the batch before this one left (flags bit 4: read late, by the tiles that need it — txn_lookback)
-  } else {
-    // the spine kernel did not run (the batch before this one failed), gave a look-back up, or met an error: the batch is decoded again
-    // on another path whatever this kernel writes (finish_batch), and the hand-off records may not be whole
-    const DevResult* r = pg.res;
-    if (__hip_atomic_load(&r->fused_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-        __hip_atomic_load(&r->first_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kNoErr) return;
-  }
   if constexpr (COPYK) { if (blockIdx.x == 0 && tid == 0) pg.res->copy_span = pg.offs[pg.nframes] - pg.offs[0]; }
   DecParams p = pg;
   uint32_t dbg_u;
@@ -1044,7 +974,6 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   if ((dbg_u & 8) && ((tid >> 6) + ((dbg_u & 0x10000u) ? 0u : blockIdx.x)) % NW == 0 && (tid & 63) == 0) s64[7] = clock64();
   if (tid < 3) s64[tid] = 0;
   if (tid < 2) s32[8 + tid] = 0;  // column queues of P2 / P3
-  uint32_t* const hand = PART != 0 ? q.hand + (size_t)blockIdx.x * q.hand_stride : nullptr;   // this tile's hand-off record
   // ---- P0: side tables, offsets, staging
   SideRegs side;  // variant head (lookback.hip.h): one round trip for all four tables, LDS stores after the staging loads
   side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
@@ -1075,24 +1004,6 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
   }
   side_store<NW * 64>((uint32_t*)smem, tid, side);
   if (tid <= nt) s_offs[tid] = my_o;  // CF + 1 <= NW * 64 entries
-  uint32_t hand_form = 1;
-  if constexpr (PART == 2) {   // the spine kernel's results for this tile: frame arrays, P3's visiting list, the cell table
-    const uint32_t* const hf = hand + kHandHdr;
-    hand_form = hand[1];
-    for (uint32_t i = tid; i < (uint32_t)CF; i += NW * 64) {
-      fr_slot[i] = (int32_t)hf[i]; fr_meta[i] = hf[CF + i]; fr_n[i] = hf[2 * CF + i]; fr_hp[i] = hf[3 * CF + i]; fr_ev[i] = hf[4 * CF + i];
-      fr_err[i] = hf[5 * CF + i]; fr_fx[i] = hf[6 * CF + i] | ((uint64_t)hf[7 * CF + i] << 32);
-      fr_lsn[i] = hf[8 * CF + i] | ((uint64_t)hf[9 * CF + i] << 32); fr_ord[i] = hf[10 * CF + i] | ((uint64_t)hf[11 * CF + i] << 32);
-      fr_toast[i] = 0;
-      for (int w = 0; w < (WIDE ? 4 : 2); w++) fr_st[w][i] = 0;
-    }
-    if (tid < 16) ((uint32_t*)vlist[1])[tid] = hand[16 + tid];
-    if (tid == 0) s32[11] = hand[0];
-    const uint32_t nw = (hand_form ? 1u : 3u) * VC * CF;
-    const uint32_t* const ht = hf + kHandFr;
-    if (!hand_form) __syncthreads();   // (rare) the three-dword table of a tile read in place takes the window's room: behind the staging stores
-    for (uint32_t i = tid; i < nw; i += NW * 64) ct[i] = ht[i];
-  }
   __syncthreads();
   TSTAMP(0);
   bool lane_ok = true;
@@ -1100,7 +1011,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
     const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
     lane_ok = COPYK ? (o1 >= o0 && o0 >= span0 && o1 <= span1) : (o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1));
   }
-  const bool use_lds = PART == 2 ? hand_form != 0 : __syncthreads_and(lane_ok ? 1 : 0) && window_ok;   // (the body kernel follows the spine's choice: the cell table is in that form)
+  const bool use_lds = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
   TSTAMP(1);
   if constexpr (COPYK) {
     // table_row.rs:51 validates a row as UTF-8 before anything else. Every row that decodes here ends in a newline, so the rows of the
@@ -1154,87 +1065,14 @@ __global__ __launch_bounds__(NW * 64, ETLG_CELLS_MINBLOCKS) void k_cells(DecPara
       }
     }
     const uint32_t copy_bad = __syncthreads_and(bad8 ? 0 : 1) ? 0u : 1u;
-    const CellsLds shc{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, bm_sep, bm_bs, bm_nl, cxm, fcache, fc_ok, vinv, nullptr, nullptr};
+    const CellsLds shc{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, bm_sep, bm_bs, bm_nl, cxm, fcache, fc_ok, vinv};
     cells_tile<NW, 2, WIDE>(p, pg, q, shc, stage, a0, tile, nt, copy_bad);
   }
   if constexpr (!COPYK) {
-    const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, fr_lsn, fr_ord};
+    const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // frames are addressed as base + (offset - b0): the LDS window, or (tiles that do not fit) the input itself
-    if (PART == 2 && use_lds && !window_ok) cells_tile<NW, 1, WIDE, PART>(p, pg, q, sh, pg.in + a0, a0, tile, nt, 0u, hand);   // (the spine read the input in place with the window's addressing: k_cells_spine1)
-    else if (use_lds) cells_tile<NW, 1, WIDE, PART>(p, pg, q, sh, stage, a0, tile, nt, 0u, hand);
-    else cells_tile<NW, 0, WIDE, PART>(p, pg, q, sh, pg.in, 0u, tile, nt, 0u, hand);
-  }
-}
-
-// The spine phases with ONE wave per tile and no staging window: the walk and the sizing pass read the input in place — with the
-// window's addressing (tag positions relative to the tile's 16-byte aligned start), so that the cell table is the one-dword form the
-// body kernel's staged tile reads — and the only LDS a tile takes is its cell table and the side tables: sixteen and more tiles per
-// CU, every one of them a chain of dependent loads that the others hide. A tile whose bytes end within 16 bytes of the input's end
-// (the window form reads up to 11 bytes past a frame), or whose span does not fit 17-bit tag positions, is read with the guarded
-// in-place reader and keeps its three-dword table in its hand-off record from the start.
-#ifndef ETLG_SPINE_MINWAVES
-#define ETLG_SPINE_MINWAVES 4
-#endif
-template <bool WIDE>
-__global__ __launch_bounds__(64, ETLG_SPINE_MINWAVES) void k_cells_spine1(DecParams pg, FusedParams q) {
-  ETLG_DYNAMIC_LDS(smem);
-  __shared__ uint32_t s_offs[CF + 1];
-  __shared__ int32_t fr_slot[CF];
-  __shared__ uint32_t fr_meta[CF];
-  __shared__ uint32_t fr_n[CF];
-  __shared__ uint64_t fr_fx[CF];
-  __shared__ uint32_t fr_hp[CF];
-  __shared__ uint32_t fr_ev[CF];
-  __shared__ uint32_t fr_st[WIDE ? 4 : 2][CF];
-  __shared__ uint32_t fr_err[CF];
-  __shared__ uint32_t fr_toast[CF];
-  __shared__ uint32_t s32[16];
-  __shared__ uint64_t s64[8];
-  __shared__ uint8_t vlist[2][64];
-  const uint32_t tid = threadIdx.x, lane = tid;
-  constexpr int wave = 0;
-  if (q.clear_words) {
-    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
-    for (uint32_t i = tid; i < per; i += 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
-  }
-  if (!(pg.flags & 16u) && !load_carry(pg)) return;
-  DecParams p = pg;
-  uint32_t dbg_u;
-  ETLG_SCALAR_COPY(dbg_u, q.dbg);
-  if ((dbg_u & 8) && lane == 0) s64[7] = clock64();
-  if (tid < 3) s64[tid] = 0;
-  if (tid < 2) s32[8 + tid] = 0;
-  SideRegs side;
-  side_load<64>(p, true, (uint32_t*)smem, tid, side);
-  const uint32_t tile = blockIdx.x, f0 = tile * CF;
-  const uint32_t nt = pg.nframes - f0 < (uint32_t)CF ? pg.nframes - f0 : (uint32_t)CF;
-  const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)pg.offs;
-  const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
-  const uint32_t my_o = tid < nt ? pg.offs[f0 + tid] : 0u;
-  const uint32_t a0 = span0 & ~15u;
-  side_store<64>((uint32_t*)smem, tid, side);
-  if (tid < nt) s_offs[tid] = my_o;
-  if (tid == 0) s_offs[nt] = span1;
-  __syncthreads();
-  TSTAMP(0);
-  bool lane_ok = true;
-  if (tid < nt) {
-    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
-    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
-  }
-  const bool form1 = __syncthreads_and(lane_ok ? 1 : 0) && span1 > span0 && (uint64_t)span1 + 16 <= pg.in_len && span1 - a0 + 16 <= kWinMax;
-  TSTAMP(1);
-#ifdef ETLG_SIMT
-  if (!form1 && tid == 0 && getenv("ETLG_SPINE_DBG")) fprintf(stderr, "spine1 tile %u form0: span %u..%u a0 %u in_len %llu nt %u\n", blockIdx.x, span0, span1, a0, (unsigned long long)pg.in_len, nt);
-#endif
-  uint32_t* const hand = q.hand + (size_t)blockIdx.x * q.hand_stride;
-  uint32_t* const ct = (uint32_t*)(smem + q.side_bytes);
-  if (form1) {
-    const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, ct, vlist, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    cells_tile<1, 1, WIDE, 1>(p, pg, q, sh, pg.in + a0, a0, tile, nt, 0u, hand);
-  } else {
-    const CellsLds sh{s_offs, fr_slot, fr_meta, fr_n, fr_fx, fr_hp, fr_ev, fr_st, fr_err, fr_toast, s32, s64, hand + kHandHdr + kHandFr, vlist, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    cells_tile<1, 0, WIDE, 1>(p, pg, q, sh, pg.in, 0u, tile, nt, 0u, hand);
+    if (use_lds) cells_tile<NW, 1, WIDE>(p, pg, q, sh, stage, a0, tile, nt);
+    else cells_tile<NW, 0, WIDE>(p, pg, q, sh, pg.in, 0u, tile, nt);
   }
 }
 
@@ -1250,25 +1088,6 @@ void etlg_k_launch_cells(const DecParams* p, const void* qv, hipStream_t s) {
   else hipLaunchKernelGGL((k_cells<4, false, false>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
 }
 
-// the same tile as two kernels (q->hand: one hand-off record of q->hand_stride dwords per tile)
-void etlg_k_launch_cells_spine(const DecParams* p, const void* qv, hipStream_t s) {
-  const FusedParams* q = (const FusedParams*)qv;
-  if (q->maxc > (uint32_t)MAXC_NARROW) hipLaunchKernelGGL((k_cells<4, true, false, 1>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
-  else hipLaunchKernelGGL((k_cells<4, false, false, 1>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
-}
-void etlg_k_launch_cells_body(const DecParams* p, const void* qv, hipStream_t s) {
-  const FusedParams* q = (const FusedParams*)qv;
-  if (q->maxc > (uint32_t)MAXC_NARROW) hipLaunchKernelGGL((k_cells<4, true, false, 2>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
-  else hipLaunchKernelGGL((k_cells<4, false, false, 2>), dim3(q->ntiles), dim3(256), q->lds_bytes, s, *p, *q);
-}
-// ... the spine with one wave per tile, reading the input in place (lds: side tables + the one-dword cell table)
-void etlg_k_launch_cells_spine1(const DecParams* p, const void* qv, uint32_t lds, hipStream_t s) {
-  const FusedParams* q = (const FusedParams*)qv;
-  if (q->maxc > (uint32_t)MAXC_NARROW) hipLaunchKernelGGL((k_cells_spine1<true>), dim3(q->ntiles), dim3(64), lds, s, *p, *q);
-  else hipLaunchKernelGGL((k_cells_spine1<false>), dim3(q->ntiles), dim3(64), lds, s, *p, *q);
-}
-uint32_t etlg_k_cells_hand_stride(uint32_t maxc) { return hand_stride_dw(maxc); }   // dwords per tile
-
 // table-copy rows straight into the arena (p->in / p->offs: the rows and their offsets; q->copy_rel: the table's id)
 void etlg_k_launch_copy_cells(const DecParams* p, const void* qv, hipStream_t s) {
   const FusedParams* q = (const FusedParams*)qv;
@@ -1281,11 +1100,6 @@ int etlg_k_cells_set_lds(void) {
   const hipError_t b = hipFuncSetAttribute((const void*)k_cells<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6656);
   const hipError_t a2 = hipFuncSetAttribute((const void*)k_cells<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144);
   const hipError_t b2 = hipFuncSetAttribute((const void*)k_cells<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6656);
-  const hipError_t c1 = hipFuncSetAttribute((const void*)k_cells<4, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144);
-  const hipError_t c2 = hipFuncSetAttribute((const void*)k_cells<4, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6656);
-  const hipError_t d1 = hipFuncSetAttribute((const void*)k_cells<4, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 7168);
-  const hipError_t d2 = hipFuncSetAttribute((const void*)k_cells<4, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 7680);
-  if (c1 != hipSuccess || c2 != hipSuccess || d1 != hipSuccess || d2 != hipSuccess) return 1;
   return a == hipSuccess && b == hipSuccess && a2 == hipSuccess && b2 == hipSuccess ? 0 : 1;
 }
 

@@ -103,8 +103,6 @@ struct FusedParams {
   uint32_t clear_words;        // 64-bit words of d_clear this launch zeroes (the descriptor buffer of the NEXT batch)
   unsigned long long* d_clear;
   uint32_t copy_rel;           // k_copy_cells: the table id the rows' Insert events carry
-  uint32_t hand_stride;        // k_cells_spine / k_cells_body: dwords per tile of `hand`
-  uint32_t* hand;              // ... the hand-off records between the two kernels (cells.hip: kHandHdr)
 };
 
 constexpr unsigned long long kNoErr = ~0ull;

@@ -40,9 +40,6 @@ void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
   else if (which == kPlan) etlg_k_launch_plan(&p, &c->pq, c->stream);
   else if (which == kPlanPre) etlg_k_launch_plan_pre(&p, &c->pq, c->stream);
   else if (which == kCells) etlg_k_launch_cells(&p, &c->fq, c->stream);
-  else if (which == kCellsSpine && c->cells_split == 2) etlg_k_launch_cells_spine1(&p, &c->fq, c->fq.side_bytes + etlg_k_cells_table_bytes(c->fq.maxc), c->stream);
-  else if (which == kCellsSpine) etlg_k_launch_cells_spine(&p, &c->fq, c->stream);
-  else if (which == kCellsBody) etlg_k_launch_cells_body(&p, &c->fq, c->stream);
   else if (which == kCopyCells) etlg_k_launch_copy_cells(&p, &c->fq, c->stream);
   else etlg_k_launch(which, &p, c->stream);
 }
@@ -258,7 +255,6 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   (void)etlg_k_plan_set_lds();
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_PRE")) c->plan_pre = atoi(pm);
-  if (const char* pm = getenv("ETLG_CELLS_SPLIT")) c->cells_split = atoi(pm);
   if (const char* pm = getenv("ETLG_CTL_HOLD")) c->ctl_hold_mode = atoi(pm) != 0;
   if (const char* pm = getenv("ETLG_PLAN_MARGIN")) c->plan_margin_pct = (uint32_t)atoi(pm);
   if (const char* pm = getenv("ETLG_PLAN_DBG")) c->plan_dbg = (uint32_t)atoi(pm);
@@ -302,7 +298,6 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   c->d_pre.release();
-  c->d_hand.release();
   if (c->tail2) (void)hipEventDestroy(c->tail2);
   if (c->fence_ev) (void)hipEventDestroy(c->fence_ev);
   for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -463,7 +458,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kPlanPre ? "k_plan_pre" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kCellsSpine ? "k_cells_spine" : i == kCellsBody ? "k_cells_body" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : i == kCopyCells ? "k_copy_cells" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kPlanPre ? "k_plan_pre" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : i == kCopyCells ? "k_copy_cells" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }

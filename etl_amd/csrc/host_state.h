@@ -61,10 +61,6 @@ extern "C" void etlg_k_size_hints(const void* job, hipStream_t s);
 extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" void etlg_k_col_var(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" int etlg_k_cells_set_lds(void);
-extern "C" void etlg_k_launch_cells_spine(const DecParams* p, const void* q, hipStream_t s);
-extern "C" void etlg_k_launch_cells_body(const DecParams* p, const void* q, hipStream_t s);
-extern "C" void etlg_k_launch_cells_spine1(const DecParams* p, const void* q, uint32_t lds, hipStream_t s);
-extern "C" uint32_t etlg_k_cells_hand_stride(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
 extern "C" uint32_t etlg_k_copy_cells_table_bytes(uint32_t maxc);
 extern "C" uint32_t etlg_k_copy_cells_lds(uint32_t maxc, uint32_t window);
@@ -81,9 +77,7 @@ constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
 constexpr int kPlan = 11;  // ... of the fixed-width plan (plan.hip)
 constexpr int kCopyCells = 12;  // ... of the table-copy rows -> arena kernel (cells.hip, k_cells<.., COPYK>)
 constexpr int kPlanPre = 13;    // ... of the plan's sidecar pre-pass (plan.hip, k_plan_pre)
-constexpr int kCellsSpine = 14; // ... of the spine half of the split k_cells (cells.hip, k_cells<.., 1>)
-constexpr int kCellsBody = 15;  // ... of its cell half (k_cells<.., 2>)
-constexpr int kProfSlots = 16;
+constexpr int kProfSlots = 14;
 
 namespace {
 
@@ -275,9 +269,6 @@ struct etlg_ctx {
   // the plan's sidecar pre-pass (k_plan_pre): tile prefixes of a batch, four buffers in rotation (like the look-back descriptors)
   static constexpr uint32_t kPreBufs = 4;
   DevBuf d_pre; size_t pre_half = 0; uint32_t pre_seq = 0;
-  // the split k_cells: hand-off records between the spine and the body kernel of a batch, four buffers in rotation (batch k + 1 may run
-  // beside batch k on the other decode stream; batch k - 2 is complete before k starts, as for the descriptors)
-  DevBuf d_hand; size_t hand_half = 0; uint32_t hand_seq = 0;
   size_t desc_dirty[4] = {0, 0, 0, 0}; // bytes at the head of each buffer that may be non-zero
   uint32_t desc_cur = 0;
   // Two decode streams: consecutive ASYNC batches of the fixed-width plan alternate between them, so the tail of batch k (its last
@@ -318,7 +309,6 @@ struct etlg_ctx {
   uint32_t n_plan_tabs = 0, plan_max_row = 16;
   bool plan_covers_all = false;
   int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
- int cells_split = 1;          // ETLG_CELLS_SPLIT: 0 = k_cells as one kernel; 1 = spine kernel + body kernel (WAL tiles; table-copy tiles stay one kernel)
   int plan_pre = 1;              // ETLG_PLAN_PRE: 0 = the plan kernel runs its look-back itself; 1 = tile prefixes from the sidecar pre-pass (k_plan_pre), one tile per wave; 2 = ... two tiles per wave
   uint32_t plan_uniform_dw = 0;  // row dwords shared by every planned table (0: they differ — no pre-pass)
   uint32_t plan_margin_pct = 4;  // ETLG_PLAN_MARGIN: LDS window per tile = 64 average frames + this margin (a tile that does not fit is read in place)

@@ -94,6 +94,8 @@ void resolve_wave(Lane* wave0, const std::vector<int>& grp) {
         else if (ctrl == 0x130) { if (l <= 62) src = l + 1; }                                                         // wave_shl:1
         else if (ctrl == 0x142) { if (row >= 1) src = (row - 1) * 16 + 15; }                                          // row_bcast:15
         else if (ctrl == 0x143) { if (row >= 2) src = 31; }                                                           // row_bcast:31
+        else if (ctrl >= 0x150 && ctrl <= 0x15F) src = row * 16 + (int)(ctrl - 0x150);                                 // row_newbcast:n (gfx90a+)
+        else if (ctrl >= 0x121 && ctrl <= 0x12F) src = row * 16 + (((l & 15) - (int)(ctrl - 0x120)) & 15);             // row_ror:n
         else { fprintf(stderr, "simt: DPP control 0x%x is not modelled\n", ctrl); abort(); }
         if (ctrl == 0x142 && row == 0) write = false;
         if (ctrl == 0x143 && row < 2) write = false;

@@ -17,8 +17,7 @@ PATHS = {
     "default": {},
     "fused256": {"ETLG_FUSED_KERNEL": "0"},   # k_fused, 256 frames per tile
     "fused64": {"ETLG_FUSED_KERNEL": "1"},    # k_fused, 64 frames per tile
-    "cells": {"ETLG_FUSED_KERNEL": "2"},      # k_cells (column-parallel), as shipped: spine kernel + body kernel
-    "cells_one": {"ETLG_FUSED_KERNEL": "2", "ETLG_CELLS_SPLIT": "0"},   # ... the whole tile in one kernel
+    "cells": {"ETLG_FUSED_KERNEL": "2"},      # k_cells (column-parallel)
     "plan": {"ETLG_FUSED_KERNEL": "3"},       # the fixed-width plan whenever the batch is eligible, no back-off (tile prefixes from the sidecar pre-pass where the tables allow it)
     "plan_lookback": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0"},   # ... with the kernel's own look-back (k_plan2: two tiles per wave)
     "plan_one": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0", "ETLG_PLAN_DBG": "512"},     # ... one tile per wave (k_plan, the kernel wide rows take)
@@ -26,7 +25,7 @@ PATHS = {
     "noplan": {"ETLG_PLAN": "0"},             # the default choice without the plan
     "multipass": {"ETLG_FORCE_MULTIPASS": "1"},
 }
-_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE", "ETLG_CELLS_SPLIT")
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE")
 
 
 @pytest.fixture(params=sorted(PATHS))
@@ -34,8 +33,6 @@ def path(request):
     import os
     saved = {k: os.environ.pop(k, None) for k in _KNOBS}
     os.environ.update(PATHS[request.param])
-    if "ETLG_CELLS_SPLIT" not in PATHS[request.param] and os.environ.get("ETLG_TEST_CELLS_SPLIT"):
-        os.environ["ETLG_CELLS_SPLIT"] = os.environ["ETLG_TEST_CELLS_SPLIT"]   # development runs: the whole file on another form of the split
     yield request.param
     for k in _KNOBS:
         os.environ.pop(k, None)
@@ -92,7 +89,7 @@ def test_large_batch_parity(mk, nbytes, path):
     n = d.debug_paths()
     d.close()
     assert n["redone"] == 0, n
-    want = {"fused256": "fused", "fused64": "fused", "cells": "cells", "cells_one": "cells", "multipass": "multipass"}.get(path)
+    want = {"fused256": "fused", "fused64": "fused", "cells": "cells", "multipass": "multipass"}.get(path)
     if path in ("plan", "plan_lookback", "plan_one", "plan_inplace", "default") and mk is synth.cfg2:
         want = "plan"   # cfg2 is what the fixed-width plan is for
     if want:
