@@ -785,6 +785,12 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   const bool out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
   const bool no_ctrl = flags & ETLG_F_NO_CONTROL;
   const bool scan = frame_offsets == nullptr;
+  // Can this call turn out to be one that HOLDS the deferred batch (sends its own control pre-pass out first, see `hold` below)? If not,
+  // the deferred batch is flushed right here, before this batch's upload is put in front of the decode streams: its control pass and
+  // decode kernels must not queue behind the copy of the batch after it (the upload / decode overlap the staging exists for).
+  const bool may_hold = (flags & ETLG_F_ASYNC) && out_dev && !no_ctrl && !scan && nframes && c->ctl_hold_mode && c->ctl_async_mode && c->last_had_ctrl &&
+                        c->deferred && c->deferred->defer_ctl;
+  if (!may_hold) { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   // ---- ASYNC with HOST input (the staging batcher of a Rust host, crates/etl-gfx950/src/batcher.rs: pinned buffers from
   //      etlg_host_alloc): the bytes and the sidecar are copied into a device block the batch owns, on a copy stream of their own,
   //      and from here on the batch IS a device-input batch — it joins the chain, and its upload runs beside the decode of the batch
@@ -806,7 +812,9 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
       HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&c->tail2, hipEventDisableTiming));
     }
-    for (hipStream_t w : {c->stream, c->stream2, c->ctl_stream, c->scan_stream}) if (w) HIPCHK(c, hipStreamWaitEvent(w, h2d_done, 0));
+    // (a call that may hold the deferred batch lets only the control stream wait now — its pre-pass reads the upload; the decode streams
+    // get their wait once the held batch has been enqueued on them, below)
+    for (hipStream_t w : {may_hold ? (hipStream_t) nullptr : c->stream, may_hold ? (hipStream_t) nullptr : c->stream2, c->ctl_stream, c->scan_stream}) if (w) HIPCHK(c, hipStreamWaitEvent(w, h2d_done, 0));
     buf = (const uint8_t*)stage_blk; frame_offsets = (const uint32_t*)((const uint8_t*)stage_blk + o_offs);
     in_dev = true;
     c->staged_async++;
@@ -834,7 +842,10 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   // the host's wait for them was 130 us per batch). The pre-pass kernels read the input and the transaction state the pre-pass before
   // them left on the device — nothing the host control plane of the held batch changes. Two pre-passes in flight: two sets of buffers.
   const bool hold = ctl_ahead && c->ctl_hold_mode && c->deferred && c->deferred->defer_ctl;
-  if (!hold) { const int32_t rc_ = flush_deferred(c); (void)rc_; }
+  if (!hold) {
+    const int32_t rc_ = flush_deferred(c); (void)rc_;
+    if (may_hold && h2d_done) for (hipStream_t w : {c->stream, c->stream2}) if (w) HIPCHK(c, hipStreamWaitEvent(w, h2d_done, 0));
+  }
   hipStream_t s = c->stream;
   if (!async) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
 
@@ -897,7 +908,13 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     b->ctl_set = (int)(c->ctl_seq & 1u);   // (the held batch's pre-pass wrote the other set)
     cp.res = (DevResult*)c->d_ctl_res.p + (c->ctl_seq++ % etlg_ctx::kCtlRing);
     { const int32_t rc = ctl_begin(c, b, cp, c->ctl_stream, true); if (rc != ETLG_OK) { if (hold) { const int32_t rc_ = flush_deferred(c); (void)rc_; } return rc; } }
-    if (hold) { const int32_t rc_ = flush_deferred(c); (void)rc_; }   // now the held batch: its pre-pass result, its control plane, its decode
+    if (hold) {   // now the held batch: its pre-pass result, its control plane, its decode
+      const int32_t rc_ = flush_deferred(c);
+      // (the held batch could not be enqueued: this batch's pre-pass was chained to a control result that will never be the state the
+      // decode before it leaves — it starts again from the host's state when it is flushed)
+      if (rc_ != ETLG_OK) { b->force_rerun = true; b->ctl_started = false; }
+      if (b->h2d_done) for (hipStream_t w : {c->stream, c->stream2}) if (w) HIPCHK(c, hipStreamWaitEvent(w, b->h2d_done, 0));
+    }
     b->deferred = true; b->defer_ctl = true; b->pending = true; b->v.on_device = 1;
     c->deferred = b; c->pending.push_back(b);
     c->ctl_ahead_n++;

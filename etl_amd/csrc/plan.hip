@@ -446,7 +446,7 @@ DEV void plan_late_carry(DecParams& p, uint32_t* failp) {
 // Finish, part 1: everything that LOADS — the look-back's answer, with it the open Begin's LSN — and the transaction context. A wave
 // runs this for both of its tiles before it stores anything: memory operations of a wave return in order, so a descriptor load issued
 // behind a tile's row / header stores waits for those stores to be acknowledged first.
-// The two words the sidecar pre-pass left for a tile — its prefix inside its group of 64, the group's prefix — through scalar loads
+// The two words the sidecar pre-pass left for a tile — its prefix inside its group of 256 (kPreGroupLog), the group's prefix — through scalar loads
 // (one address per wave; written by the kernels before this one on the stream), requested before the tile's bytes are.
 struct PlanPreWords { unsigned long long g0 = 0, g1 = 0, t0 = 0, t1 = 0; };
 DEV PlanPreWords plan_pre_load(const PlanParams& q, uint32_t tile) {
@@ -771,10 +771,11 @@ __global__ __launch_bounds__(kPreWaves * 64) void k_plan_pre(DecParams p, PlanPa
     unsigned long long a = gi < ng ? na : tagbits, l = gi < ng ? nl : tagbits;   // lanes past the last group: the identity, present
     if (gi + 64u < ng) ETLG_LD_PAIR(gd + 2 * (size_t)(gi + 64u), na, nl);
     bool have = pair_state(a, l) == tagbits;
+    bool gave_up = false;
     for (uint32_t polls = 0;; polls++) {
       if (!have) { ETLG_LD_PAIR(gd + 2 * (size_t)gi, a, l); have = pair_state(a, l) == tagbits; }
       if (!__ballot(!have)) break;
-      if (polls > kPlanMaxPolls) { if (lane == 0) atomicOr(&p.res->fused_fail, 1u); break; }   // (the decode kernel's result is discarded with it)
+      if (polls > kPlanMaxPolls) { if (lane == 0) atomicOr(&p.res->fused_fail, 1u); gave_up = true; break; }   // (the decode kernel's result is discarded with it)
       __builtin_amdgcn_s_sleep(2);
     }
     const PlanFold inc = fold_scan(gi < ng ? fold_of(a, l) : fold_id());
@@ -782,7 +783,9 @@ __global__ __launch_bounds__(kPreWaves * 64) void k_plan_pre(DecParams p, PlanPa
     exc.fx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.fx, 0x138, 0xF, 0xF, false); exc.mk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.mk, 0x138, 0xF, 0xF, false);
     exc.l0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.l0, 0x138, 0xF, 0xF, false); exc.l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.l1, 0x138, 0xF, 0xF, false);
     const PlanFold r = fold_f(carry, exc);
-    if (gi < ng) { gd[2 * (size_t)gi] = fold_agg(r); gd[2 * (size_t)gi + 1] = fold_lsn(r); }   // (status 0: never this or a later launch's tag)
+    // (status 0: never this or a later launch's tag. After a give-up nothing is rewritten: the words keep this launch's tag, which no
+    // later use of the buffer before the tag's next turn takes for its own, and the batch is decoded again anyway)
+    if (gi < ng && !gave_up) { gd[2 * (size_t)gi] = fold_agg(r); gd[2 * (size_t)gi + 1] = fold_lsn(r); }
     carry = fold_f(carry, fold_lane63(inc));
   }
   if (lane == 0) __hip_atomic_store(q.pre_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next user of the buffer expects it

@@ -567,6 +567,74 @@ def test_async_control_stream_with_a_ddl_message_the_host_rejects():
     assert paths["ctl_ahead"] >= 3 and paths["chain_rerun"] >= 1, paths
 
 
+@pytest.mark.parametrize("hold", ["1", "0"])
+def test_control_stream_one_batch_deep_with_a_ddl_message_the_host_rejects(hold):
+    """The pipelining depth the Rust batcher runs at (issue k + 1, then collect k) on a stream with control frames, ETLG_CTL_HOLD on and
+    off: batch k + 1's control pre-pass goes out before the held batch k is flushed. When k's host control plane rejects a DDL message
+    and every batch before k has been collected, k goes to the multi-pass kernels at once — on the decode stream, with the per-frame
+    scratch a pre-pass running ahead may be writing (the two were unordered). Error, frame, the events before it and the
+    batches behind it must be the oracle's on every rotation of the two scratch sets: the rejected message is tried in batch 3, 4 and 5."""
+    import os
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    saved = os.environ.get("ETLG_CTL_HOLD")
+    os.environ["ETLG_CTL_HOLD"] = hold
+    try:
+        for target in (3, 4, 5):
+            w = synth.cfg5()
+            buf, offs = w.fill(3 << 20)
+            pieces = _cut(buf, offs, 8, seed=41)
+            bb, oo = pieces[target]
+            hit = False
+            for fi in range(len(oo) - 1):
+                k = int(oo[fi])
+                if bb[k + 30] == ord("M"):
+                    j = bytes(bb[k:int(oo[fi + 1])]).find(b"{")
+                    assert j > 0
+                    bb[k + j] = ord("x")
+                    hit = True
+                    break
+            if not hit:
+                continue
+            o, d = oracle.Oracle(), Decoder(0)
+            w.register(o, ready=False)
+            w.register(d, ready=False)
+            dev = DevBufs(pieces)
+            want = []
+            for pb, pf in pieces:
+                rb = o.decode(pb, pf)
+                want.append((rb, rb.host_batch()))
+                if rb.err_code:
+                    break
+
+            def check(k, b):
+                rc = b.sync()
+                rb, hb = want[k]
+                assert (rb.err_code != 0) == (rc != 0), f"target {target} batch {k}: oracle error {rb.err_code} vs rc {rc} ({b.error})"
+                if rb.err_code:
+                    assert (b.error.code, b.error.frame_index) == (rb.err_code, rb.err_frame), f"target {target} batch {k}"
+                diff = hb.diff(b.host())
+                assert not diff, f"target {target} batch {k}: {diff[:6]}"
+                b.close()
+
+            n = len(want)       # the stream ends at the rejected message (errors are fatal to the apply loop)
+            infl = None
+            for k in range(n + 1):
+                nxt = d.decode_device(*dev.items[k], FLAGS_DEFAULT) if k < len(pieces) else None   # (one batch behind the failing one is issued: its pre-pass is the one that runs ahead)
+                if infl is not None:
+                    check(k - 1, infl)
+                infl = nxt
+                if k == n and infl is not None:
+                    infl.sync(); infl.close()      # behind the error: whatever it says, it must not hang or crash
+            assert want[-1][0].err_code != 0, "the mutated DDL message was meant to fail"
+            d.close()
+    finally:
+        if saved is None:
+            os.environ.pop("ETLG_CTL_HOLD", None)
+        else:
+            os.environ["ETLG_CTL_HOLD"] = saved
+
+
 @pytest.mark.parametrize("mk,no_ctrl", [(synth.cfg2, True), (synth.cfg3, True), (synth.cfg2, False)])
 def test_async_chain_from_pinned_host_buffers(mk, no_ctrl):
     """ETLG_F_ASYNC with HOST input (the Rust batcher's staging ring, crates/etl-gfx950/src/batcher.rs): the bytes and the sidecar
