@@ -679,7 +679,10 @@ void etlg_rowbinary_free(etlg_rowbinary* rb);
 /* Event::size_hint (crates/etl/src/event.rs:295-320) for every event of a batch, computed on the device from the
  * arena: what EventBatch::push adds up to decide batch cut points (replication/apply.rs:656-657, 1932-1935).
  * The estimate is built from `size_of::<T>()` of the reference's own types (data/table_row.rs:248-384), whose
- * layouts are not ABI-stable: the Rust shim fills this model once (crates/etl-gfx950/src/lib.rs). */
+ * layouts are not ABI-stable: the Rust shim fills this model once (crates/etl-gfx950/src/lib.rs).
+ * What is tested: the reference holds no test that states a size hint as a number, so there is nothing to pin the FORMULA's
+ * restatement to — tests/test_gpu_size_hints.py checks the device against oracle/size_hint.py, a second restatement of the same
+ * reading of event.rs / table_row.rs by the same hands. That is self-consistency, not parity with the reference. */
 typedef struct etlg_size_model {
   uint32_t begin_event;             /* size_of::<BeginEvent>() ... (event.rs:297-316) */
   uint32_t commit_event;

@@ -7,10 +7,14 @@ becomes: Insert -> one UPSERT row; Update -> the new row as UPSERT, behind a spa
 changed it; Delete -> a sparse DELETE row of the old primary key; the sequence key's trailing ordinal), crates/etl/src/event.rs:346-351
 (EventSequenceKey Display). The row decisions are pinned by the reference's own tests (core.rs:2422-2600) in tests/test_oracle_protobuf.py.
 
-PARITY UNPINNED: the reference's tests compare against prost's own output, never against literal bytes, and prost is an
-un-vendored dependency — the wire rules below are the protobuf encoding specification (varint keys, wire types 0 / 1 / 2 / 5,
-int32 / int64 as sign-extended 64-bit varints), which prost implements. Date / time strings: chrono's %Y-%m-%d, %H:%M:%S%.f
-(etl-postgres/src/time.rs:13-21; %.f prints nothing, or 3 / 6 / 9 digits).
+PINNED by the reference's own tests, transcribed in tests/golden/bigquery_kats.py and checked by tests/test_oracle_protobuf.py: TimestampTz
+cells are int64 epoch-microsecond varints and TimestampTz arrays the PACKED form of the same (encoding.rs:451-480); the numeric scale rule
+(38 decimal places pass, 39 fail: validation.rs:20-35, encoding.rs:483-496) incl. inside arrays with the element's index (:385-404); the
+JSON integer-precision rule (:343-360, validation.rs:44-93); NULL elements of arrays (:372-383); which rows an event becomes (core.rs,
+see above). UNPINNED, because the reference compares against prost's own output and prost is an un-vendored dependency: the byte forms of
+the remaining classes — bool / int32 / uint32 varints, float / double fixed words, length-delimited strings — which are the protobuf
+encoding specification (varint keys, wire types 0 / 1 / 2 / 5, int32 / int64 as sign-extended 64-bit varints). Date / time strings:
+chrono's %Y-%m-%d, %H:%M:%S%.f (etl-postgres/src/time.rs:13-21; %.f prints nothing, or 3 / 6 / 9 digits).
 
 Works on the per-cell tuples of etl_amd.view.HostBatch.materialize()."""
 import datetime as dt
@@ -70,7 +74,7 @@ def cell(c, tag):
     if k == "Timestamp":
         return ld(tag, (date_string(c[1]) + " " + time_string(c[2], c[3])).encode())
     if k == "TimestampTz":
-        return key(tag, 0) + varint(((c[1] - 719163) * 86400 + c[2]) * 1_000_000 + c[3] // 1000)
+        return key(tag, 0) + varint(tstz_micros(c))
     if k == "TimeTz":                                # t.to_string() (encoding.rs:158-161)
         return ld(tag, timetz_string(*c[1:]).encode())
     if k == "Numeric":                               # validate_cell_for_bigquery, then n.to_string() (encoding.rs:146-149)
@@ -81,6 +85,48 @@ def cell(c, tag):
         h = c[1].hex()
         return ld(tag, f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:]}".encode())
     raise NeedsHost(k)
+
+
+class NullValuesNotSupportedInArrayInDestination(Exception):
+    """reject_nulls (bigquery/validation.rs:126-141)."""
+
+
+def packed_int64(tag, values):
+    """prost::encoding::int64::encode_packed (encoding.rs:212-260 use it for the integer / TimestampTz arrays): one length-delimited
+    field holding the varints back to back; nothing at all for an empty array."""
+    if not values:
+        return b""
+    return ld(tag, b"".join(varint(v) for v in values))
+
+
+def tstz_micros(c):
+    return ((c[1] - 719163) * 86400 + c[2]) * 1_000_000 + c[3] // 1000
+
+
+def validate_json_for_bigquery(text):
+    """validate_json_for_bigquery / validate_json_number_for_bigquery (bigquery/validation.rs:44-93) on the cell's JSON text (the
+    reference parses with serde_json's arbitrary_precision: a number keeps its literal): an integer literal — no '.', 'e', 'E' —
+    outside i64 (when negative) / u64 would be stored as FLOAT64 and is refused; everything else is left to BigQuery."""
+    import json
+
+    def integer(lit):
+        v = int(lit)
+        if (lit.startswith("-") and not (-(1 << 63) <= v < (1 << 63))) or (not lit.startswith("-") and not (0 <= v < (1 << 64))):
+            raise UnsupportedValueInDestination("JSON integer would lose precision in BigQuery")
+        return v
+    json.loads(text, parse_int=integer, parse_float=lambda lit: lit, parse_constant=lambda lit: lit)
+
+
+def validate_array_for_bigquery(elem_kind, elems, cell_index=0):
+    """validate_array_cell_for_bigquery (validation.rs:119-190) behind try_from_tagged_cells (encoding.rs:37-45: the cell's index goes
+    into the detail). elems: Python values or None; numeric elements as (kind, neg, weight, scale, digits) tuples like materialize()'s."""
+    nulls = sum(1 for e in elems if e is None)
+    if nulls:
+        raise NullValuesNotSupportedInArrayInDestination(f"Cell at index {cell_index} failed validation")
+    if elem_kind == "Numeric":
+        for i, e in enumerate(elems):
+            if e[0] == 0 and e[3] > 38:
+                raise UnsupportedValueInDestination(f"Cell at index {cell_index} failed validation: Element at index {i} would be rounded by BigQuery")
 
 
 # classes whose Cell equality is the equality of the arena's words / bytes (bigquery_primary_key_changed compares Cells: float

@@ -166,6 +166,39 @@ def test_numeric_with_more_than_38_decimal_places_fails_like_the_reference():
     b.close(); d.close()
 
 
+def test_reference_pinned_cell_encodings_on_the_device():
+    """The vectors the reference's own tests hold (tests/golden/bigquery_kats.py, encoding.rs:451-496) through etlg_batch_protobuf, against
+    LITERAL bytes: a timestamptz cell is the int64 varint of its epoch microseconds; a numeric with 38 decimal places is its text, one with
+    39 fails the batch with the reference's kind and detail. (Arrays and json leave the device as NEEDS_HOST: their packed / validated forms
+    are pinned on the oracle only.)"""
+    from etl_amd.decoder import EtlError
+    from tests.golden import bigquery_kats as K
+    cols = [("ts", SC.TIMESTAMPTZ, False, 1), ("v", SC.NUMERIC, True, 0)]
+    buf, offs = _stream([W.insert(42, ["2026-01-02 03:04:05+00", K.NUMERIC_AT_SCALE])])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    r = b.protobuf(0)
+    assert r.status == abi.RB_OK and r.n_rows == 1
+    row = r.bytes().tobytes()
+    want = K.TSTZ_SCALAR_BYTES + bytes([0x12, len(K.NUMERIC_AT_SCALE)]) + K.NUMERIC_AT_SCALE.encode()     # field 1: int64 varint; field 2: string
+    assert row.startswith(want), (row[:len(want)].hex(), want.hex())
+    ev = hb.materialize()
+    ins = [e for e in ev if e["kind"] == "I"][0]
+    assert row == want + bytes([0x1A, 6]) + b"UPSERT" + bytes([0x22, 50]) + f"{ins['commit_lsn']:016x}/{ins['tx_ordinal']:016x}/{0:016x}".encode()
+    r.close(); b.close(); d.close()
+    buf, offs = _stream([W.insert(42, ["2026-01-02 03:04:05+00", K.NUMERIC_OVER_SCALE])])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    with pytest.raises(EtlError) as ei:
+        b.protobuf(0)
+    assert ei.value.kind == abi.UnsupportedValueInDestination and ei.value.detail == "Cell at index 1 failed validation"
+    b.close(); d.close()
+    for col, text in ((("a", SC.INT4_A, True, 0), "{1,NULL,3}"), (("j", SC.JSONB, True, 0), K.JSON_REFUSED[0])):
+        buf, offs = _stream([W.insert(42, ["1", text])])
+        hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), col]), buf, offs)
+        r = b.protobuf(0)
+        assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == 1
+        r.close(); b.close(); d.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_update_delete_streams(seed):
     """Random I / U / D traffic on a table with a three-column primary key (int4, text, uuid) scattered among nullable columns, under

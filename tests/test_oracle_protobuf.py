@@ -59,3 +59,64 @@ def test_events_the_reference_refuses():                                        
            _ev("U", row=[("I32", 1), ("String", b"x")])]                                                     # ensure_bigquery_update_without_old_row (AlternativeKey)
     rows, idx, host = PB.event_rows(evs, 0, TWO, "AlternativeKey")
     assert rows == [] and host == 4
+
+
+# ---- cell encodings and validation rules the reference's tests pin (tests/golden/bigquery_kats.py) ----------------------------------
+from tests.golden import bigquery_kats as K   # noqa: E402
+
+
+def test_timestamptz_is_an_int64_of_epoch_microseconds_scalar_and_packed():     # encoding.rs:451-480
+    import datetime as dt
+    assert K.TSTZ_MICROS == int(dt.datetime(2026, 1, 2, 3, 4, 5, tzinfo=dt.timezone.utc).timestamp()) * 1_000_000   # chrono's timestamp_micros()
+    assert PB.tstz_micros(K.TSTZ_CELL) == K.TSTZ_MICROS
+    assert PB.cell(K.TSTZ_CELL, 1) == K.TSTZ_SCALAR_BYTES
+    assert PB.packed_int64(1, [PB.tstz_micros(K.TSTZ_CELL)]) == K.TSTZ_PACKED_BYTES
+    assert PB.packed_int64(1, []) == b""
+
+
+def _numeric_cell(text):
+    """("Numeric", kind, sign, weight, scale, digits) of a plain decimal, the way the arena holds it (base-10000 groups)."""
+    neg = text.startswith("-")
+    t = text.lstrip("+-")
+    ip, _, fp = t.partition(".")
+    scale = len(fp)
+    ip = ip.lstrip("0")
+    ipad = "0" * ((-len(ip)) % 4) + ip
+    fpad = fp + "0" * ((-len(fp)) % 4)
+    groups = [int(ipad[i:i + 4]) for i in range(0, len(ipad), 4)] + [int(fpad[i:i + 4]) for i in range(0, len(fpad), 4)]
+    weight = len(ipad) // 4 - 1
+    while groups and groups[0] == 0:
+        groups.pop(0); weight -= 1
+    while groups and groups[-1] == 0:
+        groups.pop()
+    return ("Numeric", 0, 1 if neg else 0, weight if groups else 0, scale, groups)
+
+
+def test_numeric_scale_rule_38_passes_39_fails():                                   # encoding.rs:483-496, validation.rs:20-35 / 213-229
+    import pytest
+    assert PB.cell(_numeric_cell(K.NUMERIC_AT_SCALE), 1) == PB.ld(1, K.NUMERIC_AT_SCALE.encode())
+    with pytest.raises(PB.UnsupportedValueInDestination):
+        PB.cell(_numeric_cell(K.NUMERIC_OVER_SCALE), 1)
+    with pytest.raises(PB.UnsupportedValueInDestination) as e:                      # first failing cell wins (:420-438): tag 1 = cell index 0
+        PB.upsert_row({"commit_lsn": 1, "tx_ordinal": 0}, [_numeric_cell(K.NUMERIC_OVER_SCALE), _numeric_cell("0.5")], 0)
+    assert "Cell at index 0" in str(e.value)
+
+
+def test_arrays_null_elements_and_numeric_rounding_inside_an_array():             # encoding.rs:372-418
+    import pytest
+    with pytest.raises(PB.NullValuesNotSupportedInArrayInDestination) as e:
+        PB.validate_array_for_bigquery("I32", K.ARRAY_WITH_NULLS)
+    assert "Cell at index 0 failed validation" in str(e.value)
+    PB.validate_array_for_bigquery("I32", K.ARRAY_VALID)
+    with pytest.raises(PB.UnsupportedValueInDestination) as e:
+        PB.validate_array_for_bigquery("Numeric", [_numeric_cell(t)[1:] for t in K.NUMERIC_ARRAY_ROUNDING])
+    assert "Cell at index 0" in str(e.value) and "Element at index 1" in str(e.value)
+
+
+def test_json_integer_precision_rule():                                            # encoding.rs:343-360, validation.rs:44-93
+    import pytest
+    for t in K.JSON_ACCEPTED:
+        PB.validate_json_for_bigquery(t)
+    for t in K.JSON_REFUSED:
+        with pytest.raises(PB.UnsupportedValueInDestination):
+            PB.validate_json_for_bigquery(t)
