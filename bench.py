@@ -326,6 +326,120 @@ def leg_cfg5(dev_id, dev, cap, npool, passes):
             "batches": npool, "paths": paths, "roofline": roofline_of(kern, alg)}
 
 
+def leg_cfg1(dev_id, dev, cap, cpu_seconds):
+    """BASELINE configs[0], the reference's own CPU-runnable case (crates/etl-benchmarks/src/table_streaming.rs:140-267 drives a
+    MemoryDestination with one apply worker): the 1 M-row INSERT-only stream of synth.cfg1 — 1 000 transactions of 1 000 rows of the
+    five-int4 table, with its Relation frames — decoded once through the device path (default flags + ASYNC, 64 MiB batches,
+    device-resident in / out) and once by the CPU port of the reference's decoder on ONE thread (the single apply worker). Events/s is
+    the figure the config is about; the whole stream is the sample."""
+    import torch
+
+    from etl_amd import abi, synth
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    import numpy as np
+    w = synth.cfg1()
+    buf, offs = w.fill(160 << 20, max_txns=1000)     # the whole stream (113 MB), then cut behind Commits into batches of <= cap
+    tags = np.where(buf[offs[:-1] + 5] == ord("w"), buf[offs[:-1] + 30], 0)
+    rows = int((tags == ord("I")).sum())
+    assert rows == 1_000_000 and int((tags == ord("B")).sum()) == 1000, rows
+    commits = np.nonzero(tags == ord("C"))[0]
+    pieces, f0 = [], 0
+    while f0 < len(offs) - 1:
+        ends = commits[(commits >= f0) & (offs[commits + 1] - offs[f0] <= cap)]
+        f1 = int(ends[-1]) + 1
+        pieces.append((np.ascontiguousarray(buf[offs[f0]:offs[f1]]), (offs[f0:f1 + 1] - offs[f0]).astype(np.uint32)))
+        f0 = f1
+    items = to_device(pieces, dev)
+    tot_bytes = sum(len(b) for b, _ in pieces)
+    tot_frames = sum(len(o) - 1 for _, o in pieces)
+    dec = Decoder(dev_id)
+    FL = abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC
+    best, events, paths = None, 0, {}
+    for rep in range(4):
+        for t in w.tables:
+            dec.table_forget(t["rel_id"])
+        dec.reset_stream_state()
+        w.register(dec, ready=False)
+        n0 = dec.debug_paths()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pl = Pipeline(dec, items, FL, True)
+        for _ in range(len(items)):
+            pl.issue()
+        pl.drain()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rep > 0:
+            best = dt if best is None else min(best, dt)
+            n1 = dec.debug_paths()
+            paths = {k: n1[k] - n0[k] for k in n1}
+        events = pl.events
+    dec.close()
+    secs, passes, cpu_events, cpu_best = 0.0, 0, 0, None
+    while secs < cpu_seconds or passes == 0:
+        o = oracle.Oracle(mode=oracle.MODE_FULL)    # a fresh context per pass: the stream registers its own tables (Relation frames)
+        w.register(o, ready=False)
+        ps, cpu_events = 0.0, 0
+        for buf, offs in pieces:
+            s_, ne, nf, ec = o.decode_timed(buf, offs)
+            assert ec == 0 and nf == len(offs) - 1
+            ps += s_
+            cpu_events += ne
+        o.close()
+        secs += ps
+        passes += 1
+        cpu_best = ps if cpu_best is None else min(cpu_best, ps)
+    assert cpu_events == events, (cpu_events, events)
+    return {"workload": f"{w.name}: 1 000 000 INSERT rows in 1 000 transactions with their Relation frames ({tot_bytes} bytes, {tot_frames} frames, {len(pieces)} batches of <= {cap >> 20} MiB)",
+            "rows": rows, "events": events,
+            "gpu": {"events_per_s": round(events / best, 1), "value": round(tot_bytes / best / 1e9, 3), "unit": "GB/s", "seconds": round(best, 6), "paths": paths,
+                    "how": "default flags + ASYNC, device-resident in / out, best of 3 passes over the whole stream"},
+            "cpu_baseline": {"events_per_s": round(events / cpu_best, 1), "value": round(tot_bytes / cpu_best / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                             "seconds": round(cpu_best, 4), "sample": f"the whole stream, best of {passes} passes, single thread (the reference's one apply worker), oracle FULL mode"}}
+
+
+def leg_wide70(dev_id, dev, nrows, reps):
+    """The reference's type-matrix table (crates/etl/tests/replication_stream.rs:184-268): 68 replicated columns, wider than k_cells'
+    column masks — which kernel takes it and at what rate. Inserts with every fifth row an Update by key and every eleventh a Delete."""
+    import torch
+
+    from etl_amd import abi, synth
+    from etl_amd.decoder import Decoder
+    buf, offs = synth.type_matrix_stream(nrows, mix=True)
+    items = to_device([(buf, offs)], dev)
+    dec = Decoder(dev_id)
+    synth.type_matrix_register(dec)
+    FL = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
+    pl = Pipeline(dec, items, FL, True)
+    for _ in range(WINDOW + 2):
+        pl.issue()
+    pl.drain()
+    torch.cuda.synchronize()
+    pl = Pipeline(dec, items, FL, True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pl.issue()
+    pl.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dec.profile(2)
+    q = Pipeline(dec, items, FL, True)
+    for _ in range(8):
+        q.issue()
+    q.drain()
+    torch.cuda.synchronize()
+    kern = kernel_table(dec.profile_read())
+    dec.profile(False)
+    paths = dec.debug_paths()
+    dec.close()
+    alg = (q.bytes + SIDECAR_BYTES_PER_FRAME * q.frames + q.out_bytes) / 8
+    return {"value": round(pl.bytes / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(pl.events / dt, 1),
+            "workload": f"type-matrix table, {len(synth.TYPE_MATRIX)} columns (every scalar class, 31 array columns, json): one batch of {len(buf)} bytes / {len(offs) - 1} frames "
+                        f"(avg {len(buf) // (len(offs) - 1)} B), I / U(key) / D(key), NO_CONTROL | ASYNC, device-resident in / out",
+            "batches": reps, "paths": paths, "roofline": roofline_of(kern, alg)}
+
+
 def leg_copy(dev_id, dev, nrows, reps):
     """table-copy rows (COPY text format) -> the Insert arena (rows -> arena in one kernel, k_copy_cells; `paths` says how
     many of the timed batches took it and how many fell back to the row -> frame rewrite). `value` is quoted on escape-heavy rows, the
@@ -691,7 +805,7 @@ def main():
     ap.add_argument("--batch-mib", type=int, default=64)
     ap.add_argument("--pool", type=int, default=6, help="distinct batches resident in HBM (rotated)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--legs", default="cfg3,cfg5,copy,no_sidecar,handoff,default_flags,pcie,cfg4", help="extra legs on rank 0 (comma separated; empty = none)")
+    ap.add_argument("--legs", default="cfg1,cfg3,cfg5,wide70,copy,no_sidecar,handoff,default_flags,pcie,cfg4", help="extra legs on rank 0 (comma separated; empty = none)")
     ap.add_argument("--cfg4-leg", action="store_true", help="add the cfg4 leg to a cfg2 / cfg3 run")
     ap.add_argument("--cfg4-gib", type=int, default=8)
     ap.add_argument("--cfg4-seg-mib", type=int, default=1024)
@@ -885,6 +999,10 @@ def main():
             extra["default_flags"]["kernels_us"] = d["roofline"]["pipeline_kernels_us"]
         if "cfg5" in legs:
             extra["cfg5"] = leg_cfg5(local_rank, dev, cap, 16, 2)
+        if "cfg1" in legs:
+            extra["cfg1"] = leg_cfg1(local_rank, dev, cap, 4.0)
+        if "wide70" in legs:
+            extra["wide70"] = leg_wide70(local_rank, dev, 24000, 40)
         if "copy" in legs:
             extra["copy"] = leg_copy(local_rank, dev, 400000, 8)
         if "handoff" in legs:

@@ -204,3 +204,97 @@ def copy_rows(n, seed, clean=False):
              "\\\\x" + "".join("%02x" % rng.getrandbits(8) for _ in range(rng.randint(0, 20)))]
         rows.append(("\t".join(f) + "\n").encode())
     return rows
+
+
+# ---- the reference's type-matrix table (crates/etl/tests/replication_stream.rs:184-268, the row of :303-400): one column of every type
+#      the reference's parser has an arm for, every array form, and the types it hands on as text — 68 replicated columns, i.e. a table
+#      wider than any kernel's column masks. The cell texts are PostgreSQL's text output of the values that test inserts.
+MATRIX_UUID = "a0eebc99-9c0b-4ef8-bb6d-6bb9bd380a11"
+TYPE_MATRIX = [   # (name, type oid, nullable, text of the test's value; None = NULL)
+    ("id", 20, False, "1"), ("bool_col", 16, False, "t"), ("char_col", 18, False, "x"), ("bpchar_col", 1042, False, "ab "),
+    ("varchar_col", 1043, False, "varchar"), ("name_col", 19, False, "pg_name"), ("text_col", 25, False, "hello world"),
+    ("text_null_col", 25, True, None), ("text_null_marker_literal_col", 25, False, "\\N"), ("text_embedded_null_marker_col", 25, False, "value\\Ntail"),
+    ("money_col", 790, False, "$12.34"), ("int2_col", 21, False, "-123"), ("int4_col", 23, False, "456"), ("int8_col", 20, False, "7890123456"),
+    ("oid_col", 26, False, "42"), ("float4_col", 700, False, "3.5"), ("float8_col", 701, False, "-7.25"), ("numeric_col", 1700, False, "12345.6789"),
+    ("bytea_col", 17, False, "\\x0102ff"), ("date_col", 1082, False, "2026-01-02"), ("time_col", 1083, False, "12:30:45.123456"),
+    ("timetz_col", 1266, False, "12:30:45.123456+02"), ("timestamp_col", 1114, False, "2026-01-02 03:04:05.123456"),
+    ("timestamptz_col", 1184, False, "2026-01-02 03:04:05.123456+00"), ("uuid_col", 2950, False, MATRIX_UUID),
+    ("json_col", 114, False, '{"kind":"json","n":1}'), ("jsonb_col", 3802, False, '{"kind": "jsonb", "nested": {"n": 2}}'),
+    ("bool_arr", 1000, False, "{t,f,NULL}"), ("char_arr", 1002, False, "{a,NULL,b}"), ("bpchar_arr", 1014, False, '{"ab ",NULL,"cd "}'),
+    ("varchar_arr", 1015, False, "{left,NULL,right}"), ("name_arr", 1003, False, "{alpha,NULL,beta}"), ("text_arr", 1009, False, "{hello,NULL,world}"),
+    ("money_arr", 791, False, "{$12.34,NULL,-$0.01}"), ("int2_arr", 1005, False, "{-123,NULL,321}"), ("int4_arr", 1007, False, "{456,NULL,-654}"),
+    ("int8_arr", 1016, False, "{7890123456,NULL,-9876543210}"), ("oid_arr", 1028, False, "{42,NULL,43}"), ("float4_arr", 1021, False, "{3.5,NULL,-1.25}"),
+    ("float8_arr", 1022, False, "{-7.25,NULL,8.5}"), ("numeric_arr", 1231, False, "{12345.6789,NULL,-0.5}"),
+    ("bytea_arr", 1001, False, '{"\\\\x00",NULL,"\\\\x0102"}'), ("date_arr", 1182, False, "{2026-01-02,NULL,2026-01-03}"),
+    ("time_arr", 1183, False, "{12:30:45.123456,NULL,23:59:59}"), ("timetz_arr", 1270, False, "{12:30:45.123456+02,NULL,23:59:59-07:30}"),
+    ("timestamp_arr", 1115, False, '{"2026-01-02 03:04:05.123456",NULL,"2026-01-03 04:05:06"}'),
+    ("timestamptz_arr", 1185, False, '{"2026-01-02 03:04:05.123456+00",NULL,"2026-01-03 04:05:06+00"}'),
+    ("uuid_arr", 2951, False, "{" + MATRIX_UUID + ",NULL,00000000-0000-0000-0000-000000000000}"),
+    ("json_arr", 199, False, '{"{\\"a\\":1}",NULL,"{\\"b\\":2}"}'), ("jsonb_arr", 3807, False, '{"{\\"a\\": 1}",NULL,"{\\"b\\": 2}"}'),
+    ("interval_col", 1186, False, "1 day 02:03:04"), ("interval_arr", 1187, False, '{"1 day",NULL,02:00:00}'),
+    ("inet_col", 869, False, "192.0.2.1"), ("inet_arr", 1041, False, "{192.0.2.1,NULL,2001:db8::1}"),
+    ("cidr_col", 650, False, "192.0.2.0/24"), ("cidr_arr", 651, False, "{192.0.2.0/24,NULL,2001:db8::/32}"),
+    ("macaddr_col", 829, False, "aa:bb:cc:dd:ee:ff"), ("macaddr_arr", 1040, False, "{aa:bb:cc:dd:ee:ff,NULL,00:11:22:33:44:55}"),
+    ("macaddr8_col", 774, False, "08:00:2b:01:02:03:04:05"), ("macaddr8_arr", 775, False, "{08:00:2b:01:02:03:04:05,NULL,02:03:04:05:06:07:08:09}"),
+    ("xml_col", 142, False, '<root a="1"/>'), ("xml_arr", 143, False, "{<left/>,NULL,<right/>}"),
+    ("int4_range_col", 3904, False, "[1,5)"), ("int4_range_arr", 3905, False, '{"[1,5)",NULL,"[10,20)"}'),
+    ("num_multirange_col", 4532, False, "{[1.0,2.0)}"), ("num_multirange_arr", 6151, False, '{"{[1.0,2.0)}",NULL,"{[3.0,4.0)}"}'),
+    ("int2_vector_col", 22, False, "1 2 3"), ("oid_vector_col", 30, False, "10 20"),
+]
+TYPE_MATRIX_COLS = [(n, oid, nullable, 1 if n == "id" else 0) for n, oid, nullable, _ in TYPE_MATRIX]
+TYPE_MATRIX_REL = 16500
+
+
+def type_matrix_stream(nrows, rows_per_txn=200, start_lsn=0x2000000, mix=False):
+    """CopyData-framed pgoutput of `nrows` changes of the type-matrix table (ids 1, 2, ...): Begin / rows / Commit per transaction.
+    mix: every fifth row an Update with a key image, every eleventh a Delete by key. Returns (np.uint8 bytes, np.uint32 offsets)."""
+    import struct
+
+    def tup(cells):
+        out = [struct.pack(">h", len(cells))]
+        for c in cells:
+            if c is None:
+                out.append(b"n")
+            else:
+                b = c.encode()
+                out.append(b"t" + struct.pack(">i", len(b)) + b)
+        return b"".join(out)
+
+    tail = tup([t for _, _, _, t in TYPE_MATRIX[1:]])[2:]       # the cells behind the id (the count travels with the first)
+    ncol = struct.pack(">h", len(TYPE_MATRIX))
+    buf = bytearray()
+    offs = [0]
+    lsn = start_lsn
+
+    def put(msg):
+        nonlocal lsn
+        lsn += 8
+        payload = b"w" + struct.pack(">QQq", lsn, lsn, 0) + msg
+        buf.extend(b"d" + struct.pack(">I", len(payload) + 4) + payload)
+        offs.append(len(buf))
+
+    i = 0
+    while i < nrows:
+        n = min(rows_per_txn, nrows - i)
+        final = lsn + 8 * (n + 2)
+        put(b"B" + struct.pack(">QqI", final, 0, 700 + i // rows_per_txn))
+        for k in range(i, i + n):
+            idt = str(k + 1).encode()
+            cell0 = b"t" + struct.pack(">i", len(idt)) + idt
+            row = ncol + cell0 + tail
+            if mix and k % 11 == 10:
+                put(b"D" + struct.pack(">I", TYPE_MATRIX_REL) + b"K" + struct.pack(">h", 1) + cell0)
+            elif mix and k % 5 == 4:
+                put(b"U" + struct.pack(">I", TYPE_MATRIX_REL) + b"K" + struct.pack(">h", 1) + cell0 + b"N" + row)
+            else:
+                put(b"I" + struct.pack(">I", TYPE_MATRIX_REL) + b"N" + row)
+        put(b"C" + struct.pack(">bQQq", 0, final, final + 8, 0))
+        i += n
+    return np.frombuffer(bytes(buf), dtype=np.uint8), np.array(offs, dtype=np.uint32)
+
+
+def type_matrix_register(target):
+    target.schema_put(TYPE_MATRIX_REL, 0, TYPE_MATRIX_COLS, name="type_matrix")
+    target.table_state(TYPE_MATRIX_REL, abi.TS_READY)
+    n = len(TYPE_MATRIX_COLS)
+    target.table_ready(TYPE_MATRIX_REL, 0, [1] * n, [1] + [0] * (n - 1))

@@ -117,6 +117,51 @@ def test_full_size_parity(mk):
     assert n["redone"] == 0 and n["multipass"] == 0, n
 
 
+@pytest.mark.parametrize("mix", [False, True])
+def test_type_matrix_table_of_68_columns(mix):
+    """The reference's own type-matrix table (crates/etl/tests/replication_stream.rs:184-268, the row of :303-400): 68 replicated
+    columns — one of every type the parser has an arm for, every array form, the types it hands on as text. Wider than k_cells' 32-column
+    masks: the batch must be decoded by k_fused / 64 (no limit on the column count), byte for byte like the oracle, without a redo;
+    inserts only, and with key-image updates and key deletes mixed in. Arrays and json stay DEFERRED source text in the arena (§4)
+    and the columnar hand-off parses every array class of the row on the device."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    buf, offs = synth.type_matrix_stream(1500, mix=mix)
+    o, d = oracle.Oracle(), Decoder(0)
+    synth.type_matrix_register(o)
+    synth.type_matrix_register(d)
+    rb = o.decode(buf, offs)
+    gb = d.decode(buf, offs, flags=abi.F_NO_CONTROL)
+    assert rb.err_code == 0 and gb.rc == 0, (rb.err_code, gb.rc, gb.error)
+    hb = rb.host_batch()
+    diff = hb.diff(gb.host())
+    assert not diff, diff[:6]
+    ev = hb.materialize()
+    row = [e for e in ev if e["kind"] == "I"][0]["row"]
+    assert len(row) == 68 and row[7] == ("Null",) and row[8] == ("String", b"\\N") and row[17][0] == "Numeric" and row[27][0] == "Deferred"
+    n = d.debug_paths()
+    assert n["fused"] == 1 and n["cells"] == 0 and n["redone"] == 0 and n["multipass"] == 0, n
+    if not mix:
+        # the hand-off of the same batch: 29 of the 31 array columns come back as list columns parsed on the device (json[] / jsonb[]
+        # stay text: their elements are the host's), with the values the reference's test asserts (replication_stream.rs:613-856)
+        from etl_amd.arrow import columns_to_record_batch
+        gd = d.decode(buf, offs, flags=abi.F_NO_CONTROL | abi.F_OUTPUT_ON_DEVICE)
+        names = [c[0] for c in synth.TYPE_MATRIX_COLS]
+        cols = gd.columns(0, parse_arrays=True)
+        kinds = {names[i]: cols.column(i).arrow_kind for i in range(len(names))}
+        assert [k for k in names if k.endswith("_arr") and kinds[k] != abi.AK_LIST] == ["json_arr", "jsonb_arr"]
+        rec = columns_to_record_batch(cols, names=names, on_text="binary")
+        assert rec.num_rows == 1500
+        want = {"bool_arr": [True, False, None], "int4_arr": [456, None, -654], "int8_arr": [7890123456, None, -9876543210], "text_arr": ["hello", None, "world"],
+                "bpchar_arr": ["ab ", None, "cd "], "numeric_arr": ["12345.6789", None, "-0.5"], "timetz_arr": ["12:30:45.123456+02", None, "23:59:59-07:30"],
+                "bytea_arr": [b"\x00", None, b"\x01\x02"], "money_arr": ["$12.34", None, "-$0.01"], "float8_arr": [-7.25, None, 8.5],
+                "num_multirange_arr": ["{[1.0,2.0)}", None, "{[3.0,4.0)}"], "inet_arr": ["192.0.2.1", None, "2001:db8::1"]}
+        for k, v in want.items():
+            assert rec.column(k)[0].as_py() == v and rec.column(k)[1499].as_py() == v, k
+        cols.close(); gd.close()
+    d.close()
+
+
 def test_full_size_parity_cfg5_control_path():
     """BASELINE configs[4] at the BASELINE batch size: 64 MiB of the cfg5 stream (Relation / DDL messages, Type / Origin noise,
     keepalives, 3 tables) with DEFAULT flags — the optimistic kernel, then the control path — byte for byte, two batches in a
