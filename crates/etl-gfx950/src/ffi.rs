@@ -345,6 +345,17 @@ extern "C" {
         n_frames: *mut usize,
         last_tag: *mut u32,
     ) -> i32;
+    pub fn etlg_shard_plan(
+        ctx: *mut etlg_ctx,
+        buf: *const u8,
+        len: usize,
+        frame_offsets: *const u32,
+        nframes: usize,
+        n_shards: u32,
+        flags: u32,
+        cuts_out: *mut u64,
+    ) -> i32;
+    pub fn etlg_shard_replay(ctx: *mut etlg_ctx, buf: *const u8, len: usize, frame_offsets: *const u32, nframes: usize) -> i32;
     pub fn etlg_host_alloc(ctx: *mut etlg_ctx, bytes: usize, out: *mut *mut c_void) -> i32;
     pub fn etlg_host_free(p: *mut c_void);
     pub fn etlg_batch_view_get(batch: *const etlg_batch, out: *mut etlg_batch_view) -> i32;

@@ -236,6 +236,52 @@ impl GpuDecoder {
     }
 }
 
+/// The multi-GPU recipe (one `GpuDecoder` per device, one process or task per GPU — the reference itself has a single
+/// apply task, apply.rs:1210-1336, so this is an extension a host opts into): `shard_plan` cuts a staged stream behind Commit frames,
+/// every rank extracts the control stream of its own range (`control_stream`), the ranks exchange those few hundred bytes, every rank
+/// replays the streams of the ranks before it (`shard_replay`, rank order) and then decodes its own range. Python twin with the
+/// collectives: etl_amd/shard.py; the C entry points are the ones tests/test_shard_decode.py compares against that model.
+impl GpuDecoder {
+    /// Commit-aligned, byte-balanced frame ranges `[cuts[k], cuts[k + 1])` of a staged batch (etlg_shard_plan).
+    pub fn shard_plan(&mut self, staged: &StagedBatch, n_shards: u32) -> EtlResult<Vec<u64>> {
+        let mut cuts = vec![0u64; n_shards as usize + 1];
+        let rc = unsafe { etlg_shard_plan(self.ctx, staged.frames_ptr(), staged.len, staged.offsets_ptr(), staged.nframes, n_shards, 0, cuts.as_mut_ptr()) };
+        if rc == ETLG_OK { Ok(cuts) } else { Err(self.last_error()) }
+    }
+
+    /// The Relation / DDL-message transactions of a frame range of a staged batch, reduced to {Begin, control frames, Commit}
+    /// (etlg_control_stream): what this rank broadcasts. Returns (bytes, offsets).
+    pub fn control_stream(&mut self, staged: &StagedBatch, f0: usize, f1: usize) -> EtlResult<(Vec<u8>, Vec<u32>)> {
+        let offs = unsafe { std::slice::from_raw_parts(staged.offsets_ptr(), staged.nframes + 1) };
+        let (b0, b1) = (offs[f0] as usize, offs[f1] as usize);
+        let rel: Vec<u32> = offs[f0..=f1].iter().map(|o| o - offs[f0]).collect();
+        let (mut bytes, mut out_offs) = (vec![0u8; 1 << 16], vec![0u32; 1 << 10]);
+        loop {
+            let (mut nb, mut nf, mut last) = (0usize, 0usize, 0u32);
+            let rc = unsafe {
+                etlg_control_stream(self.ctx, staged.frames_ptr().add(b0), b1 - b0, rel.as_ptr(), f1 - f0, 0, bytes.as_mut_ptr(), bytes.len(),
+                                    out_offs.as_mut_ptr(), out_offs.len(), &mut nb, &mut nf, &mut last)
+            };
+            if rc == ETLG_OK {
+                bytes.truncate(nb);
+                out_offs.truncate(nf + 1);
+                return Ok((bytes, out_offs));
+            }
+            if nb <= bytes.len() && nf + 1 <= out_offs.len() { return Err(self.last_error()); }
+            bytes = vec![0u8; nb + 64];
+            out_offs = vec![0u32; nf + 2];
+        }
+    }
+
+    /// Applies the control stream of an EARLIER rank's range (etlg_shard_replay): same schema slots in the same order on every rank;
+    /// leaves the context outside any transaction, where a commit-aligned shard starts.
+    pub fn shard_replay(&mut self, bytes: &[u8], offsets: &[u32]) -> EtlResult<()> {
+        let nframes = offsets.len().saturating_sub(1);
+        let rc = unsafe { etlg_shard_replay(self.ctx, if nframes == 0 { ptr::null() } else { bytes.as_ptr() }, bytes.len(), offsets.as_ptr(), nframes) };
+        if rc == ETLG_OK { Ok(()) } else { Err(self.last_error()) }
+    }
+}
+
 impl Drop for GpuDecoder {
     fn drop(&mut self) {
         unsafe { etlg_ctx_destroy(self.ctx) };

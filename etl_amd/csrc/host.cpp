@@ -616,6 +616,55 @@ int32_t etlg_frame_tags(etlg_ctx* c, const uint8_t* buf, size_t len, const uint3
   return ETLG_OK;
 }
 
+int32_t etlg_shard_plan(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t n_shards,
+                        uint32_t flags, uint64_t* cuts_out) {
+  { const int32_t rc_ = flush_deferred(c); (void)rc_; }
+  if (!c || !frame_offsets || !cuts_out || !n_shards || n_shards > 4096) return ETLG_InvalidArgument;
+  clear_error(c);
+  if (len > 0xFFFFFFFFull - 16 || nframes >= (1u << 30)) return lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+  cuts_out[0] = 0;
+  for (uint32_t k = 1; k <= n_shards; k++) cuts_out[k] = nframes;
+  if (!nframes) { for (uint32_t k = 1; k < n_shards; k++) cuts_out[k] = 0; return ETLG_OK; }
+  if (n_shards == 1) return ETLG_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; }
+  const bool in_dev = flags & ETLG_F_INPUT_ON_DEVICE;
+  hipStream_t s = c->stream;
+  DecParams p{};
+  p.in = buf; p.offs = frame_offsets;
+  if (!in_dev) {
+    HIPCHK(c, c->d_in.ensure(len + 64)); HIPCHK(c, c->d_offs.ensure((nframes + 1) * 4));
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_in.p, buf, len, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_offs.p, frame_offsets, (nframes + 1) * 4, hipMemcpyHostToDevice, s));
+    p.in = (const uint8_t*)c->d_in.p; p.offs = (const uint32_t*)c->d_offs.p;
+  }
+  p.nframes = (uint32_t)nframes; p.nblocks = (p.nframes + kBlock - 1) / kBlock; p.in_len = len;
+  { const int32_t rc = setup_scratch(c, p); if (rc != ETLG_OK) return rc; }
+  launch(c, 0, p);   // k_classify: the tags stay on the device
+  HIPCHK(c, c->d_colsel.ensure((size_t)n_shards * 4 + 64));
+  uint32_t* d_cuts = (uint32_t*)c->d_colsel.p;
+  etlg_k_shard_cuts(p.f_tag, p.offs, p.nframes, n_shards, d_cuts, s);
+  std::vector<uint32_t> h(n_shards - 1);
+  HIPCHK(c, hipMemcpyAsync(h.data(), d_cuts, (size_t)(n_shards - 1) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (uint32_t k = 1; k < n_shards; k++) cuts_out[k] = std::max<uint64_t>(h[k - 1], cuts_out[k - 1]);   // (cuts never go back: a shard may be empty)
+  return ETLG_OK;
+}
+
+int32_t etlg_shard_replay(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes) {
+  if (!c) return ETLG_InvalidArgument;
+  int32_t rc = ETLG_OK;
+  if (nframes) {
+    if (!buf || !frame_offsets) return ETLG_InvalidArgument;
+    etlg_batch* b = nullptr;
+    rc = etlg_decode(c, buf, len, frame_offsets, nframes, ETLG_F_OUTPUT_ON_DEVICE, &b);   // the control path: default flags, synchronous; the events are dropped
+    const etlg_error saved = c->err; const std::string detail = c->err_detail;
+    if (b) etlg_batch_free(b);
+    if (rc != ETLG_OK) { c->err = saved; c->err_detail = detail; c->err.detail = c->err_detail.empty() ? nullptr : c->err_detail.c_str(); return rc; }
+  }
+  return etlg_ctx_reset_stream_state(c);   // the shard behind starts outside any transaction, at ordinal 0 (its first frame follows a Commit)
+}
+
 int32_t etlg_control_stream(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags,
                             uint8_t* out_bytes, size_t out_cap, uint32_t* out_offsets, size_t out_offsets_cap,
                             size_t* n_bytes, size_t* n_frames, uint32_t* last_tag) {

@@ -355,6 +355,25 @@ void etlg_k_launch(int which, const DecParams* p, hipStream_t s) {
   }
 }
 
+// Commit-aligned shard cuts (etlg_shard_plan): lane k finds the k-th interior cut of an n-way split balanced by bytes — the first frame
+// index e with tags[e - 1] == 'C' whose byte offset reaches total * k / n, or the last such index when no Commit lies behind that point
+// (0 when the range has no Commit at all). The caller makes the list monotonic. One transaction's worth of tags per lane: a serial scan.
+__global__ __launch_bounds__(64) void k_shard_cuts(const u8* tags, const uint32_t* offs, uint32_t nframes, uint32_t n_shards, uint32_t* cuts) {
+  const uint32_t k = blockIdx.x * 64 + threadIdx.x + 1;
+  if (k >= n_shards) return;
+  const uint64_t total = offs[nframes];
+  const uint64_t target = total * k / n_shards;
+  uint32_t lo = 0, hi = nframes;   // smallest i in [0, nframes] with offs[i] >= target
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if ((uint64_t)offs[mid] >= target) hi = mid; else lo = mid + 1; }
+  uint32_t e = lo ? lo : 1u, cut = 0;
+  for (; e <= nframes; e++) if (tags[e - 1] == 'C') { cut = e; break; }
+  if (!cut) for (e = lo; e >= 1; e--) if (tags[e - 1] == 'C') { cut = e; break; }
+  cuts[k - 1] = cut;
+}
+void etlg_k_shard_cuts(const uint8_t* tags, const uint32_t* offs, uint32_t nframes, uint32_t n_shards, uint32_t* cuts, hipStream_t s) {
+  hipLaunchKernelGGL(k_shard_cuts, dim3((n_shards + 63) / 64), dim3(64), 0, s, tags, offs, nframes, n_shards, cuts);
+}
+
 void etlg_k_ctl_pick(const uint8_t* tags, uint32_t nframes, uint32_t* hdr, uint32_t* list, uint32_t cap, hipStream_t s) {
   hipLaunchKernelGGL(k_ctl_pick, dim3((nframes + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tags, nframes, hdr, list, cap);
 }

@@ -393,6 +393,31 @@ class Decoder:
         if rc != 0:
             raise RuntimeError(f"etlg_frame_tags failed: {rc}")
 
+    def shard_plan(self, buf, offsets, n_shards):
+        """[(f0, f1)] commit-aligned, byte-balanced frame ranges of a HOST stream (etlg_shard_plan: classified and cut on the device)."""
+        a = np.ascontiguousarray(buf, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint32)
+        return self._shard_plan(a.ctypes.data, len(a), o.ctypes.data, len(o) - 1, n_shards, 0)
+
+    def shard_plan_device(self, buf_ptr, nbytes, offs_ptr, nframes, n_shards):
+        """... of a device-resident stream (raw device pointers)."""
+        return self._shard_plan(buf_ptr, nbytes, offs_ptr, nframes, n_shards, abi.F_INPUT_ON_DEVICE)
+
+    def _shard_plan(self, buf_ptr, nbytes, offs_ptr, nframes, n_shards, flags):
+        cuts = np.zeros(n_shards + 1, dtype=np.uint64)
+        rc = self.L.etlg_shard_plan(self.h, C.c_void_p(buf_ptr), nbytes, C.c_void_p(offs_ptr), nframes, n_shards, flags, cuts.ctypes.data)
+        if rc != abi.OK:
+            raise self.last_error()
+        return [(int(cuts[k]), int(cuts[k + 1])) for k in range(n_shards)]
+
+    def shard_replay(self, buf, offsets):
+        """Applies the control stream of an EARLIER shard to this context and leaves it outside any transaction (etlg_shard_replay)."""
+        a = np.ascontiguousarray(buf, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint32)
+        rc = self.L.etlg_shard_replay(self.h, a.ctypes.data if len(a) else None, len(a), o.ctypes.data, len(o) - 1)
+        if rc != abi.OK:
+            raise self.last_error()
+
     def control_stream(self, buf_ptr, nbytes, offs_ptr, nframes, on_device=True):
         """The control stream of a frame range, extracted on the device (etlg_control_stream): (bytes np.uint8, offsets np.uint32,
         tag of the range's last frame). `buf_ptr` / `offs_ptr`: device pointers (or host addresses with on_device=False)."""

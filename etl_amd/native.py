@@ -19,7 +19,7 @@ EXPORTS = [
     "etlg_table_state", "etlg_table_ready", "etlg_ctx_reset_stream_state", "etlg_decode", "etlg_last_error",
     "etlg_batch_view_get", "etlg_batch_sync", "etlg_batch_download", "etlg_batch_header_to_device", "etlg_ctx_fence", "etlg_batch_free", "etlg_ctx_slots", "etlg_ctx_profile",
     "etlg_ctx_profile_read", "etlg_scan_boundaries", "etlg_copy_decode", "etlg_frame_tags",
-    "etlg_table_forget", "etlg_table_cache_get", "etlg_host_alloc", "etlg_host_free", "etlg_control_stream",
+    "etlg_table_forget", "etlg_table_cache_get", "etlg_host_alloc", "etlg_host_free", "etlg_control_stream", "etlg_shard_plan", "etlg_shard_replay",
     "etlg_batch_columns", "etlg_columns_view_get", "etlg_columns_free",
     "etlg_batch_rowbinary", "etlg_batch_protobuf", "etlg_rowbinary_view_get", "etlg_rowbinary_free", "etlg_batch_size_hints",
 ]
@@ -103,6 +103,10 @@ def lib():
     L.etlg_rowbinary_free.restype = None
     L.etlg_batch_size_hints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.etlg_table_cache_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    L.etlg_shard_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.etlg_shard_plan.restype = C.c_int32
+    L.etlg_shard_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.etlg_shard_replay.restype = C.c_int32
     L.etlg_control_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
     L.etlg_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]

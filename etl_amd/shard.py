@@ -41,10 +41,14 @@ def frame_tags(buf, offsets):
     return tags
 
 
-def plan_shards(buf, offsets, n_shards, tags=None):
+def plan_shards(buf, offsets, n_shards, tags=None, decoder=None):
     """Cut frames [0, nframes) into n_shards contiguous ranges that end right after a
     Commit ('C') frame, balanced by bytes. Returns [(f0, f1)] (f1 exclusive).
+    `decoder` (an etl_amd.Decoder): the cut is made by the library — etlg_shard_plan, what a non-Python host calls; the numpy code below is
+    its model (the oracle tier of the tests has no library context) and the two are compared in tests/test_shard_decode.py.
     `tags`: the frames' pgoutput tags if the caller already has them (etlg_frame_tags); `buf` may then be None."""
+    if decoder is not None and hasattr(decoder, "shard_plan"):
+        return decoder.shard_plan(buf, offsets, n_shards)
     offsets = np.asarray(offsets, dtype=np.int64)
     nfr = len(offsets) - 1
     if nfr == 0:
@@ -115,6 +119,11 @@ def control_stream(buf, offsets, f0=0, f1=None, tags=None):
 def replay_control(decoder, streams):
     """Applies the control streams of the shards BEFORE this one (in rank order) to `decoder` — a Decoder or anything with
     its decode() — and drops the events. Raises if a replay fails: the shard that owns those frames reports the error."""
+    if hasattr(decoder, "shard_replay"):    # the library's own entry point (etlg_shard_replay): what a non-Python host calls
+        for buf, offs in streams:
+            if len(offs) > 1:
+                decoder.shard_replay(buf, offs)
+        return
     for buf, offs in streams:
         if len(offs) <= 1:
             continue
@@ -191,11 +200,12 @@ def decode_sharded(make_context, buf, offsets, n_shards, tags=None):
     Returns the list of per-shard batches, in LSN order."""
     if tags is None:
         tags = frame_tags(buf, offsets)
-    ranges = plan_shards(buf, offsets, n_shards, tags=tags)
+    first = make_context()
+    ranges = plan_shards(buf, offsets, n_shards, tags=tags, decoder=first)   # (a Decoder plans through the C ABI: etlg_shard_plan)
     ctrl = [control_stream(buf, offsets, f0, f1, tags=tags) for f0, f1 in ranges]
     out = []
     for k, (f0, f1) in enumerate(ranges):
-        ctx = make_context()
+        ctx = first if k == 0 else make_context()
         replay_control(ctx, ctrl[:k])
         ctx.reset_stream_state()
         b, o = slice_shard(buf, offsets, f0, f1)

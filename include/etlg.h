@@ -349,6 +349,24 @@ int32_t etlg_scan_boundaries(etlg_ctx* ctx, const uint8_t* buf, size_t len, uint
 int32_t etlg_frame_tags(etlg_ctx* ctx, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes,
                         uint32_t flags, uint8_t* tags_out);
 
+/* Commit-aligned shard cuts of a staged stream (multi-GPU recipe): frames [0, nframes) as n_shards contiguous
+ * ranges balanced by bytes, every interior cut right after a Commit ('C') frame — the transaction state (commit_lsn, next ordinal:
+ * crates/etl/src/replication/apply.rs:942-963) is then shard-local. The frames are classified and the cuts found on the device; only
+ * the n_shards - 1 cut indexes come back. cuts_out (HOST, n_shards + 1 entries): shard k = frames [cuts_out[k], cuts_out[k + 1]);
+ * cuts_out[0] = 0, cuts_out[n_shards] = nframes; a stream with fewer Commits than shards leaves some ranges empty (cuts never go back).
+ * The reference has no counterpart: it decodes one ordered stream in one task (apply.rs:1210-1336).
+ * flags: ETLG_F_INPUT_ON_DEVICE (buf / frame_offsets are device pointers). n_shards <= 4096. */
+int32_t etlg_shard_plan(etlg_ctx* ctx, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t n_shards,
+                        uint32_t flags, uint64_t* cuts_out);
+
+/* Step 3 of the recipe: apply the control stream of a shard BEFORE this context's own (etlg_control_stream of that range, as the ranks
+ * exchanged it) — its Relation and DDL-message frames update the schema store and the shared table cache exactly as in place
+ * (apply.rs:2160-2276, 2363-2440) — drop the events it decodes to, and leave the context outside any transaction at ordinal 0, which is
+ * where a commit-aligned shard starts. Call once per earlier shard, in rank order, then decode the own shard. HOST buffers; nframes = 0
+ * only resets the transaction state. An error (a Relation frame the reference would reject) is the error of the shard that owns the
+ * frame: it is returned here, and that shard's own decode reports it with its frame index. */
+int32_t etlg_shard_replay(etlg_ctx* ctx, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes);
+
 /* The control stream of a frame range, extracted on the device (multi-GPU recipe): for every transaction of the
  * range that holds a Relation ('R') or logical-decoding Message ('M') frame, its Begin, those frames in order and its Commit
  * (a control frame outside any transaction of the range travels alone). Decoding that stream on another context has the same

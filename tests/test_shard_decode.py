@@ -81,6 +81,19 @@ def test_sharded_decode_equals_single_decode_device(name, n):
     _check(mk, w, buf, offs, n)
     tags = made[0].frame_tags(buf, offs)   # the device classification plans the same cuts
     assert shard.plan_shards(None, offs, n, tags=tags) == shard.plan_shards(buf, offs, n)
+    # ... and so does the library's own planner (etlg_shard_plan: classification + cut search on the device), for every shard count —
+    # incl. more shards than the stream has Commits (empty ranges, cuts that never go back)
+    for m in (1, 2, 3, 5, 8, 64, 1000):
+        assert made[0].shard_plan(buf, offs, m) == shard.plan_shards(buf, offs, m), m
+    few, fo = shard.slice_shard(buf, offs, 0, 40)          # a stream that ends inside a transaction, and one without any Commit
+    few, fo = np.ascontiguousarray(few), np.ascontiguousarray(fo)
+    for m in (2, 7):
+        assert made[0].shard_plan(few, fo, m) == shard.plan_shards(few, fo, m), m
+    t = shard.frame_tags(few, fo)
+    k = int(np.flatnonzero(t == ord("B"))[0])
+    j = k + 1 + int(np.flatnonzero(t[k + 1:] == ord("C"))[0]) if np.any(t[k + 1:] == ord("C")) else len(t)
+    nob, noo = shard.slice_shard(few, fo, k, j)
+    assert made[0].shard_plan(np.ascontiguousarray(nob), np.ascontiguousarray(noo), 3) == shard.plan_shards(nob, noo, 3) == [(0, 0), (0, 0), (0, j - k)]
     for d in made:
         d.close()
 
