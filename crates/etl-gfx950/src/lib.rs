@@ -9,6 +9,11 @@
 //! * [`flush`]       `last_received_lsn` / `last_commit_end_lsn` / effective flush LSN for a loop that decodes batches (apply.rs:2039-2051,
 //!                   1918-1928, 2000, 885-912);
 //! * [`materialize`] arena → `Event` / `TableRow` / `Cell`, DEFERRED cells finished with the reference's own parser;
+//!
+//! None of this has met a Rust compiler (the etl-gfx950 image has none). What HAS been executed is the twin of the call sequence in C++
+//! through the same C ABI — tests/native/shim_twin.cpp, run by tests/test_shim_twin.py on the MI355X against the oracle's events and a
+//! model of the reference's LSN rules: `StagingBatcher` (ring of pinned buffers, `push_xlog_data`, `take` / `recycle`), `decode_async` /
+//! `finish`, `decode_unstaged`, `FlushTracker`, `InFlight`'s drop order. A change here wants the same change there.
 //! * [`GpuDecoder`]  safe wrapper of one context: side inputs mirror `SchemaStore` / `StateStore` / `SharedTableCache`
 //!                   (crates/etl/src/store/schema/base.rs:19-69, store/state/base.rs:25-139, replication/table_cache.rs:88-154).
 pub mod batcher;
@@ -153,6 +158,39 @@ impl GpuDecoder {
         match events {
             Ok(ev) => (ev, staged, status),
             Err(e) => (Vec::new(), staged, Err(e)),
+        }
+    }
+
+    /// One message that does not fit a staging buffer (`StagingBatcher::can_stage` says no: a pgoutput tuple may approach 1 GB), decoded by
+    /// itself: re-framed into an ordinary (unpinned) buffer and handed to the library synchronously. Call it with nothing in flight
+    /// (dispatch and collect first — the event order holds, and the context carries `remote_final_lsn` / the next ordinal from the
+    /// batches before into this one and on into the batches behind). Twin: tests/native/shim_twin.cpp, the `!can_stage` branch.
+    pub fn decode_unstaged(&mut self, payload: &[u8], schemas: &mut dyn materialize::SlotSchemas) -> (Vec<Event>, EtlResult<()>) {
+        let mut framed = Vec::with_capacity(payload.len() + 5 + 64);
+        framed.push(b'd');
+        framed.extend_from_slice(&((payload.len() as u32 + 4).to_be_bytes()));
+        framed.extend_from_slice(payload);
+        let offs = [0u32, framed.len() as u32];
+        framed.resize(framed.len() + 64, 0);            // (head room the library's staging copy does not need; kept for symmetry with the ring)
+        let mut batch = ptr::null_mut();
+        let rc = unsafe { etlg_decode(self.ctx, framed.as_ptr(), offs[1] as usize, offs.as_ptr(), 1, ETLG_F_OUTPUT_ON_DEVICE, &mut batch) };
+        if batch.is_null() {
+            return (Vec::new(), Err(self.last_error()));
+        }
+        let status = if rc == ETLG_OK { Ok(()) } else { Err(self.last_error()) };
+        if unsafe { etlg_batch_download(self.ctx, batch) } != ETLG_OK {
+            let e = self.last_error();
+            unsafe { etlg_batch_free(batch) };
+            return (Vec::new(), Err(e));
+        }
+        let mut view = std::mem::MaybeUninit::<etlg_batch_view>::uninit();
+        unsafe { etlg_batch_view_get(batch, view.as_mut_ptr()) };
+        let view = unsafe { view.assume_init() };
+        let events = unsafe { materialize::events(&view, schemas) };
+        unsafe { etlg_batch_free(batch) };
+        match events {
+            Ok(ev) => (ev, status),
+            Err(e) => (Vec::new(), Err(e)),
         }
     }
 
