@@ -471,39 +471,27 @@ hipError_t scan_launch(etlg_ctx* c, ScanJob& j, bool sequential) {
   const size_t len = j.len;
   hipStream_t s = j.s;
   const size_t tb = etlg_k_bounds_tile_bytes();
-  const size_t ntiles = (len + tb - 1) / tb, ngroups = (ntiles + 63) / 64;
-  // scratch: two descriptor buffers (result block of 64 bytes + look-back words) | hints. Each run zeroes the buffer the next
-  // run will use, the result travels through pinned host memory: a scan is ONE kernel on the stream, no memset, no copy.
-  const size_t words = 8 + ntiles + ngroups;                       // 8-byte words of one descriptor buffer that this run dirties
+  const size_t ntiles = (len + tb - 1) / tb;
+  // scratch: result block | tile summaries | base indexes | the tiles' scratch rows, and the hints behind them. A run writes everything it
+  // reads (no descriptor to clear, no memset on the stream); the result travels through pinned host memory.
   if (!c->h_scan) { hipError_t e = hipHostMalloc((void**)&c->h_scan, 64); if (e != hipSuccess) return e; }
-  if (ntiles > c->scan_tiles_cap) {  // (re)allocation: the layout is by capacity, everything is initialised once
+  if (ntiles > c->scan_tiles_cap) {  // (re)allocation: the layout is by capacity; only the hints need initialising
     const size_t tcap = ntiles + ntiles / 4 + 64;
-    const size_t half = ((8 + tcap + tcap / 64 + 2) * 8 + 63) & ~(size_t)63;
-    const size_t need = 2 * half + ((tcap * 4 + 63) & ~(size_t)63) + 64;
+    const size_t body = (etlg_k_bounds_scratch_bytes(tcap) + 63) & ~(size_t)63;
+    const size_t need = body + ((tcap * 4 + 63) & ~(size_t)63) + 64;
     hipError_t e = c->d_scan.ensure(need); if (e != hipSuccess) return e;
-    e = hipMemsetAsync(c->d_scan.p, 0, 2 * half, s); if (e != hipSuccess) return e;
-    e = hipMemsetAsync((uint8_t*)c->d_scan.p + 2 * half, 0xFF, tcap * 4, s); if (e != hipSuccess) return e;
-    c->scan_tiles_cap = tcap; c->scan_half = half; c->scan_cur = 0; c->scan_dirty[0] = c->scan_dirty[1] = 0;
+    e = hipMemsetAsync((uint8_t*)c->d_scan.p + body, 0xFF, tcap * 4, s); if (e != hipSuccess) return e;
+    c->scan_tiles_cap = tcap; c->scan_half = body;
   }
-  const size_t half = c->scan_half;
   uint8_t* base = (uint8_t*)c->d_scan.p;
   hipError_t e = j.offs->ensure((j.cap + 2) * 4); if (e != hipSuccess) return e;
-  j.cur = base + (size_t)c->scan_cur * half;
-  uint8_t* oth = base + (size_t)(c->scan_cur ^ 1) * half;
+  j.cur = base;
   c->h_scan[0] = 0; c->h_scan[1] = 0;
-  const bool dbg = getenv("ETLG_SCAN_DBG") != nullptr;
-  // The one-lane fallback (k_bounds_seq) has no clearing loop: the OTHER buffer — dirtied by the run before this one, the next run's
-  // look-back words — is zeroed here. (It used to be marked clean all the same: the scan AFTER a fallback then met the descriptors of
-  // an earlier run wherever a tile looked before its predecessor had published — wrong boundaries on the MI355X, never on the emulator,
-  // whose workgroups run in order; found by running tools/simt_fuzz.py's boundary-scan worker against the real library, round 4.)
-  if (sequential && c->scan_dirty[c->scan_cur ^ 1]) { e = hipMemsetAsync(oth, 0, c->scan_dirty[c->scan_cur ^ 1] * 8, s); if (e != hipSuccess) return e; }
   ProfRec r; r.which = kBounds;
   if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
-  etlg_k_launch_bounds(j.d_in, len, (uint32_t*)j.offs->p, (uint32_t)std::min<size_t>(j.cap + 2, 0xFFFFFFFFu), j.cur, oth, (uint32_t)c->scan_dirty[c->scan_cur ^ 1],
-                       (uint32_t*)(base + 2 * half), c->h_scan, (sequential ? 1 : 0) | (dbg ? 2 : 0), s);
+  etlg_k_launch_bounds(j.d_in, len, (uint32_t*)j.offs->p, (uint32_t)std::min<size_t>(j.cap + 2, 0xFFFFFFFFu), base, (uint32_t*)(base + c->scan_half), c->h_scan,
+                       sequential ? 1 : 0, s);
   if (c->prof) { (void)hipEventRecord(r.b, s); c->prof_recs.push_back(r); }
-  c->scan_dirty[c->scan_cur] = words; c->scan_dirty[c->scan_cur ^ 1] = 0;
-  c->scan_cur ^= 1;
   return hipSuccess;
 }
 
@@ -525,26 +513,25 @@ hipError_t scan_collect(etlg_ctx* c, ScanJob& j, size_t* nframes_out) {
   hipStream_t s = j.s;
   const size_t tb = etlg_k_bounds_tile_bytes();
   const size_t ntiles = (len + tb - 1) / tb;
-  const bool dbg = getenv("ETLG_SCAN_DBG") != nullptr;
-  bool used_hints = false, hints_set = false;
+  bool used_hints = false, hints_set = false, overflow = false;
   hipError_t rc = hipSuccess;
   for (int run = 0;; run++) {
     const bool sequential = run >= 4;
     hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
     uint32_t nf = c->h_scan[0], flags = 0, nbad = 0;
-    if (c->h_scan[1] || dbg) {  // some tile failed: the details are in the device result block
+    if (c->h_scan[1]) {  // the run did not hold: the details are in the device result block
       uint32_t res[16];
       e = hipMemcpy(res, j.cur, 64, hipMemcpyDeviceToHost); if (e != hipSuccess) return e;
       nf = res[0]; flags = res[1]; nbad = res[2];
-      if (dbg) { fprintf(stderr, "k_bounds tiles %zu phase cycles/tile:", ntiles); for (int k = 4; k < 11; k++) fprintf(stderr, " %u", (unsigned)(res[k] / std::max<size_t>(1, ntiles / 64))); fprintf(stderr, "\n"); }
       if (nbad) hints_set = true;
+      if (flags & 4u) overflow = true;   // a tile with more frames than its scratch row holds (malformed input): hints do not help, one lane does
     }
     bool again_same = false;
     if (flags & 2u) {  // offsets buffer too small
       if (j.cap >= len / 5 + 2) { rc = hipErrorOutOfMemory; break; }
       j.cap = len / 5 + 2;
       run--; again_same = true;
-    } else if (sequential || (!(flags & 1u) && nbad == 0)) {
+    } else if (sequential || (!(flags & 4u) && nbad == 0)) {
       if (used_hints) c->scan_reruns++;
       if (sequential) c->scan_seq++;
       *nframes_out = nf;
@@ -552,9 +539,10 @@ hipError_t scan_collect(etlg_ctx* c, ScanJob& j, size_t* nframes_out) {
     } else {
       used_hints = true;  // some tiles guessed wrong (their hints are set now), or a spin gave up: run again
     }
+    if (overflow && !again_same) run = 3;   // (the next run is the one-lane one)
     e = scan_launch(c, j, again_same ? sequential : run + 1 >= 4); if (e != hipSuccess) return e;
   }
-  if (hints_set) { const hipError_t e = hipMemsetAsync((uint8_t*)c->d_scan.p + 2 * c->scan_half, 0xFF, ntiles * 4, s); if (e != hipSuccess) return e; }   // rare: leave the hints clean for the next scan
+  if (hints_set) { const hipError_t e = hipMemsetAsync((uint8_t*)c->d_scan.p + c->scan_half, 0xFF, ntiles * 4, s); if (e != hipSuccess) return e; }   // rare: leave the hints clean for the next scan
   return rc;
 }
 

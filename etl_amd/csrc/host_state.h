@@ -43,8 +43,9 @@ extern "C" void etlg_k_ctl_span(const uint8_t* tags, uint32_t nframes, const uin
 extern "C" void etlg_k_ctl_gather(const uint8_t* in, const uint32_t* offs, const uint32_t* frames, uint32_t nkeep, uint32_t* lens, const uint32_t* out_offs, uint8_t* out, hipStream_t s);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_fused_set_lds(void);
-extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* cur, void* clear, uint32_t clear_words,
-                                     uint32_t* hints, uint32_t* result, int sequential, hipStream_t s);
+extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* scratch, uint32_t* hints, uint32_t* hflag,
+                                     int sequential, hipStream_t s);
+extern "C" size_t etlg_k_bounds_scratch_bytes(size_t ntiles);
 extern "C" uint32_t etlg_k_bounds_tile_bytes(void);
 extern "C" uint32_t etlg_k_copy_bytes_per_row(uint32_t ncols);
 extern "C" int etlg_k_copy_set_lds(void);
@@ -293,7 +294,7 @@ struct etlg_ctx {
   DevBuf d_copy_in, d_copy_offs, d_copy_out, d_copy_out_offs;
   DevBuf d_scan;       // scratch of the record-boundary scan
   uint32_t* h_scan = nullptr;  // pinned: its 4-word result
-  size_t scan_half = 0, scan_tiles_cap = 0, scan_dirty[2] = {0, 0}; int scan_cur = 0;  // double-buffered scan descriptors: bytes per buffer, dirty 8-byte words, the one the next run uses
+  size_t scan_half = 0, scan_tiles_cap = 0;  // scan scratch: bytes in front of the hints, tiles it is laid out for
   unsigned long long scan_reruns = 0, scan_seq = 0;  // debugging aid: batches that needed hints / the one-lane walk
   DevBuf d_ctrl_stage;   // bytes of a batch's Relation / DDL frames (k_ctrl_list gathers them)
   // ETLG_HOST_TIMES=1: wall-clock microseconds the host spends between marks of the control path, printed when the context goes

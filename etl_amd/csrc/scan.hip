@@ -4,28 +4,34 @@
 //
 // Frames are a linked list through the buffer — the frame at p is 'd' | Int32-BE length L and the
 // next one starts at p + 1 + L — so which boundaries lie in a tile of bytes depends on where the
-// chain enters it. The kernel is optimistic and verifies itself:
+// chain enters it. The scan is optimistic and verifies itself, in THREE kernels on one stream and
+// without a word exchanged between workgroups of one launch (round 5; rounds 2-4 carried the tile
+// aggregates through a decoupled look-back inside one kernel — the scan's only source of defects
+// that the emulator could not see, and two or three dependent round trips in every tile's path):
 //
-//   1. one wave stages its tile (TB bytes + a header's worth of halo) into LDS;
-//   2. every lane GUESSES an entry into its own 128 bytes — the first position holding a
-//      well-formed XLogData / keepalive frame header whose successor holds one too — and walks the
-//      chain to the end of its 128 bytes; the lanes are then stitched (the exit of one must be the
-//      guess of the lane it lands in), which yields the tile's frames and exit offset from the
-//      first guess on (tile 0 knows its entry: offset 0). A tile whose lanes do not stitch walks
-//      the chain with one lane instead;
-//   3. ONE two-level decoupled look-back carries (frames so far: sum, furthest exit so far: max):
-//      the sum is the base index of the tile's offsets, the max must be exactly the tile's
-//      guessed entry (or lie beyond the tile when it found nothing);
-//   4. offsets go straight to their final indexes.
+//   k_bounds_local    one wave per tile of TB bytes: stage the tile (+ a header's worth of halo) into
+//                     LDS; every lane GUESSES an entry into its own 128 bytes — the first position
+//                     holding a well-formed XLogData / keepalive frame header whose successor holds one
+//                     too — and walks the chain to the end of its 128 bytes; the lanes are stitched (the
+//                     exit of one must be the guess of the lane it lands in), which yields the tile's
+//                     frames and exit offset from the first guess on (tile 0 knows its entry: offset 0;
+//                     a tile whose lanes do not stitch walks the chain with one lane). The tile's frame
+//                     starts go to a scratch row of its own (16-bit offsets inside the tile), its
+//                     {entry, frames, exit} to a summary table.
+//   k_bounds_resolve  the summary table is scanned (frames: sum, exit: max), one thread per tile, blocks of 256:
+//                     every tile's prefix inside its block, every block's aggregate.
+//   k_bounds_write    every workgroup folds the block aggregates in front of its block; the sum is the base
+//                     index of a tile's offsets, the max must be exactly the tile's guessed entry (or lie
+//                     beyond the tile when it found nothing); the scratch rows go to their final indexes.
 //
 // If every tile passes its check, the guesses ARE the chain (induction from tile 0). A tile that
 // fails — payload bytes that look like two consecutive headers right at a tile start, or a
-// malformed frame — records the entry it should have used as a hint and raises a counter; the
-// host reruns the kernel with the hints (each run fixes every tile flagged by the one before,
-// and every tile under a frame found to cover a flagged tile) and, after a few runs, lets one
-// lane follow the chain (k_bounds_seq). Wrong guesses need
-// non-text bytes that mimic a frame AND its successor within the ~100 bytes before the first
-// real frame of a tile, so reruns are rare; malformed input (an error anyway) costs one.
+// malformed frame — gets the entry it should have used as a hint; the host reruns the kernels with
+// the hints (each run fixes every tile flagged by the one before, and every tile under a frame
+// found to cover a flagged tile) and, after a few runs, lets one lane follow the chain
+// (k_bounds_seq). Wrong guesses need non-text bytes that mimic a frame AND its successor within the
+// ~100 bytes before the first real frame of a tile, so reruns are rare; malformed input (an error
+// anyway) costs one.
 //
 // The result is exactly the sequential rule  p -> p + 1 + L  while buf[p] == 'd', L >= 4 and
 // the frame fits; else the rest of the buffer is one last (malformed) frame  — the rule of the
@@ -38,20 +44,26 @@ constexpr uint32_t TB = 8192;          // bytes per tile
 constexpr uint32_t HALO = 32;          // a header (and the bytes the guess inspects) may straddle the tile end
 constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
 
+constexpr uint32_t CAP = 360;          // frame starts a tile's scratch row holds: the shortest message the server sends is a 23-byte keepalive (8192 / 23 = 356);
+                                       // a tile with more (a stream of malformed 5-byte frames) sends the scan to the one-lane fallback
+
+struct TileSum { uint32_t entry, n, e, flags; };   // flags: 1 the chain enters this tile (entry valid), 2 more than CAP frames
+struct TilePre { uint32_t n, e; };                 // frames / furthest exit of a block's tiles before this one; block aggregates use the same pair
+
 struct BoundsParams {
   const u8* in;
   uint64_t len;
   uint32_t* offs;              // out: nframes + 1 offsets
   uint32_t offs_cap;           // entries available in offs
   uint32_t ntiles;
-  unsigned long long* d_clear; // the OTHER descriptor buffer (result block + look-back words of the next run), zeroed by this launch
-  uint32_t clear_words;        // ... its extent in 8-byte words
-  uint32_t* hflag;             // pinned host memory: [0] nframes (last tile), [1] set to 1 by any tile that fails — the host reads the device
-                               // result block only then
-  unsigned long long* ndesc;   // [ntiles + ngroups] look-back of (frames: sum, exit: max)   (zeroed)
+  uint32_t* hflag;             // pinned host memory: [0] nframes, [1] set to 1 when the run did not produce the offsets — the host reads the
+                               // device result block only then
+  TileSum* sum;                // [ntiles]
+  TilePre* pre;                // [ntiles] the tile's prefix inside its block of RB tiles (k_bounds_resolve)
+  TilePre* blk;                // [ceil(ntiles / RB)] block aggregates
+  uint16_t* rows;              // [ntiles][CAP] frame starts of the tile, relative to its first byte
   uint32_t* hints;             // [ntiles] entry to use instead of guessing, NO_ENTRY = guess (kept across reruns)
-  uint32_t dbg;                // 1: per-phase shader-clock sums into result[4..11] (profiling only)
-  uint32_t* result;            // [0] nframes  [1] failure flags (1 spin gave up, 2 offs_cap too small)  [2] tiles that failed their check
+  uint32_t* result;            // [0] nframes  [1] failure flags (2 offs_cap too small, 4 a tile with more than CAP frames)  [2] tiles that failed their check
 };
 
 // Is there a well-formed frame header at absolute offset p? If so `next` = start of the following
@@ -90,17 +102,17 @@ DEV void walk(const u8* st, uint32_t* out, uint32_t lo, uint32_t stop, uint64_t 
   exit_off = p;
 }
 
-// look-back payload: frames so far (30 bits, summed) | furthest exit so far (32 bits, max)
-struct OpCountExit {
-  DEV static uint64_t id() { return 0; }
-  DEV static uint64_t f(uint64_t a, uint64_t b) {
-    const uint32_t ea = (uint32_t)a, eb = (uint32_t)b;
-    return ((((a >> 32) + (b >> 32)) & 0x3FFFFFFFull) << 32) | (ea > eb ? ea : eb);
+// ... the same walk, writing the frame starts relative to `lo` as 16-bit values (a tile's scratch row)
+DEV void walk16(const u8* st, uint16_t* out, uint32_t lo, uint32_t stop, uint64_t len, uint32_t p) {
+  uint32_t n = 0;
+  while (p < stop) {
+    uint32_t nx;
+    out[n++] = (uint16_t)(p - lo);
+    p = header_at(st, lo, len, p, nx) ? nx : (uint32_t)len;
   }
-};
+}
 
 constexpr uint32_t SUB = TB / 64;  // bytes of the tile each lane looks at (128)
-#define STAMP(k) do { if (q.dbg && threadIdx.x == 0 && (blockIdx.x & 31) == 5) { const unsigned long long _t = clock64(); atomicAdd(&q.result[4 + (k)], (uint32_t)(_t - t_prev)); t_prev = _t; } } while (0)
 
 // What a tile knows after its local phase (registers; the LDS window is free again)
 struct TileLocal {
@@ -110,8 +122,8 @@ struct TileLocal {
   bool has, stitched, mine;
 };
 
-// ---- local phase of one tile: stage, guess, walk, stitch. Ends with the tile's aggregate published to the look-back.
-DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t, unsigned long long& t_prev) {
+// ---- local phase of one tile: stage, guess, walk, stitch.
+DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t) {
   const uint32_t lane = threadIdx.x;
   const uint64_t lo64 = (uint64_t)tile * TB;
   const uint32_t lo = (uint32_t)lo64;
@@ -145,7 +157,6 @@ DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t
     }
   }
   __syncthreads();
-  STAMP(0);
   // ---- every lane guesses an entry into ITS 128 bytes: the first position holding a plausible frame
   //      whose successor is plausible too (or lies outside the tile). 'd' bytes are found 4 at a time.
   const uint32_t a = lo + lane * SUB, a_end = a + SUB < hi ? a + SUB : hi;
@@ -186,7 +197,6 @@ DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t
       }
     }
   }
-  STAMP(1);
   // the tile's own entry: known (tile 0), hinted by an earlier run, or the first lane's guess
   const uint32_t hint = q.hints[tile];
   uint32_t entry = NO_ENTRY;
@@ -201,7 +211,6 @@ DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t
   // local walks: from the lane's guess to the end of its 128 bytes
   uint32_t n_l = 0, e_l = 0;
   if (s_l != NO_ENTRY) walk(st, nullptr, lo, a_end, q.len, s_l, n_l, e_l);
-  STAMP(2);
   // ---- stitch the lanes. The chain passes through every guessing lane from the entry lane on iff each
   //      of them starts exactly where the furthest walk before it ended (walks of on-chain lanes end
   //      further and further), and every lane without a guess lies under a frame. One prefix-max scan.
@@ -220,93 +229,105 @@ DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t
     inc = wave_scan_add(mine ? n_l : 0u);  // inclusive prefix of the on-chain lanes' frame counts
     n = wave_last(inc);
   }
-  STAMP(3);
   if (has && !stitched) {
     // the lanes do not agree (bytes that mimic a frame inside a value, a malformed header ...): one lane
     // walks the tile; it walks again (out of global memory) to write the offsets once their base index is known
     if (lane == 0) walk(st, nullptr, lo, hi, q.len, entry, n, e);
     n = (uint32_t)__shfl(n, 0, 64); e = (uint32_t)__shfl(e, 0, 64);
   }
-  STAMP(4);
   t.entry = entry; t.n = n; t.e = e; t.s_l = s_l; t.n_l = n_l; t.inc = inc; t.has = has; t.stitched = stitched; t.mine = mine;
-  // the aggregate is published NOW; the prefix is fetched after the wave's second tile has done its local work, so the look-back's
-  // round trips (half of a tile's time when waited for at once) are covered by work
-  lookback_publish(q.ndesc, tile, ((uint64_t)n << 32) | e);
 }
 
-// ---- second phase: the look-back gives the frames before this tile and how far the chain has come; check the guess, write the
-//      offsets. The LDS window may hold another tile by now: the short re-walks read the input itself.
-DEV void bounds_finish(const BoundsParams& q, uint32_t tile, const TileLocal& t, uint32_t* lfail, unsigned long long& t_prev) {
-  const uint32_t lane = threadIdx.x;
-  const uint32_t hi = t.hi, n = t.n, entry = t.entry;
-  const bool has = t.has;
-  const uint64_t pre = lookback_resolve<OpCountExit>(q.ndesc, q.ndesc + q.ntiles, tile, ((uint64_t)n << 32) | t.e, 0, lfail);
-  const uint64_t N = pre >> 32;
-  if (*lfail) { if (lane == 0) { atomicOr(&q.result[1], 1u); q.hflag[1] = 1u; } }
-  STAMP(5);
-  if (tile > 0) {
+// One wave = one tile: local phase, then the tile's frame starts (out of the LDS window: no second look at the input) into its scratch
+// row and its {entry, frames, exit} into the summary table. Nothing here depends on another tile.
+__global__ __launch_bounds__(64) void k_bounds_local(BoundsParams q) {
+  __shared__ __attribute__((aligned(16))) u8 st[TB + HALO + 16];
+  const uint32_t lane = threadIdx.x, tile = blockIdx.x;
+  TileLocal t;
+  bounds_local(q, st, tile, t);
+  uint32_t flags = t.has ? 1u : 0u;
+  if (t.has) {
+    uint16_t* const row = q.rows + (size_t)tile * CAP;
+    if (t.n > CAP) flags |= 2u;
+    else if (t.stitched) { if (t.mine) walk16(st, row + (t.inc - t.n_l), t.lo, t.a_end, q.len, t.s_l); }   // consecutive lanes write consecutive entries
+    else if (lane == 0) walk16(st, row, t.lo, t.hi, q.len, t.entry);
+  }
+  if (lane == 0) q.sum[tile] = TileSum{t.entry, t.n, t.e, flags};
+}
+
+// The exclusive scan of (frames: sum, exit: max) over the summary table, two levels. Level one: a workgroup takes RB consecutive tiles,
+// one per thread (coalesced 16-byte loads: ONE workgroup walking the whole table was 15 us of a 45 us scan — every lane on a line of
+// its own through one CU's memory pipeline), and leaves every tile's prefix inside its block and the block's aggregate.
+constexpr int RB = 256;
+__global__ __launch_bounds__(RB) void k_bounds_resolve(BoundsParams q) {
+  __shared__ uint32_t s_n[RB / 64], s_e[RB / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t t = blockIdx.x * RB + tid;
+  if (blockIdx.x == 0 && tid == 0) { q.result[1] = 0; q.result[2] = 0; }   // (the write kernel behind this one raises them)
+  TileSum v{NO_ENTRY, 0, 0, 0};
+  if (t < q.ntiles) v = q.sum[t];
+  const uint32_t in_n = wave_scan_add(v.n), in_e = wave_scan_max(v.e);
+  if (lane == 63) { s_n[wave] = in_n; s_e[wave] = in_e; }
+  __syncthreads();
+  uint32_t N = in_n - v.n;
+  uint32_t E = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)in_e, 0x138, 0xF, 0xF, false);   // the lanes before this one (0 into lane 0)
+  for (uint32_t w = 0; w < wave; w++) { N += s_n[w]; E = s_e[w] > E ? s_e[w] : E; }
+  if (t < q.ntiles) q.pre[t] = TilePre{N, E};
+  if (tid == RB - 1) q.blk[blockIdx.x] = TilePre{N + v.n, v.e > E ? v.e : E};
+}
+
+// Level two + the check + the offsets, one WAVE per tile (four tiles per workgroup: the copy wants the whole chip, 32 workgroups of 256
+// tiles took 34 us): the wave folds the block aggregates in front of its tile's block (a 64 MiB batch has 32 of them, 4 GiB 2 048: a few
+// trips of 64), checks the tile's guess against the chain so far and copies the scratch row to its final indexes. A tile whose guess
+// does not hold leaves its hint and raises the run's flags: the host runs the kernels again and ignores what the others wrote (their
+// base indexes are wrong behind the first bad tile anyway).
+__global__ __launch_bounds__(256) void k_bounds_write(BoundsParams q) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= q.ntiles) return;
+  const uint32_t nb = t / RB;   // blocks in front of this tile's
+  uint32_t bn = 0, be = 0;
+  for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+    const uint32_t b = b0 + lane;
+    TilePre a{0, 0};
+    if (b < nb) a = q.blk[b];
+    bn += wave_last(wave_scan_add(a.n));
+    const uint32_t m = wave_last(wave_scan_max(a.e));
+    be = m > be ? m : be;
+  }
+  const TileSum v = q.sum[t];
+  const TilePre pr = q.pre[t];
+  const uint32_t N = bn + pr.n, E = be > pr.e ? be : pr.e;
+  uint32_t fl = (v.flags & 2u) ? 4u : 0u;
+  if (t > 0) {
     // If every tile passes this check the guesses are the chain: by induction the exits of the older
     // tiles are the true ones and grow with the tile index, so their maximum is where the chain enters.
-    const uint32_t e_prev = (uint32_t)pre;
-    const bool ok = has ? e_prev == entry : e_prev >= hi;
+    const uint64_t hi64 = ((uint64_t)t + 1) * TB;
+    const uint32_t hi = (uint32_t)(hi64 < q.len ? hi64 : q.len);
+    const bool ok = (v.flags & 1u) ? E == v.entry : E >= hi;
     if (!ok) {
       if (lane == 0) {
-        q.hints[tile] = e_prev;  // what this tile should have started from (>= hi: nothing starts here)
+        q.hints[t] = E;   // what this tile should have started from (>= hi: nothing starts here)
         atomicAdd(&q.result[2], 1u);
         q.hflag[1] = 1u;
       }
       // a frame that runs past this tile also covers every tile up to its end: tell them all now (tiles
       // inside one long value that mimics frames agree with each other and would otherwise be found
       // one per run)
-      if (e_prev >= hi) {
-        const uint64_t last = (uint64_t)e_prev / TB;  // tiles tile+1 .. last-1 end at or before e_prev
-        for (uint64_t tt = (uint64_t)tile + 1 + lane; tt < last && tt < q.ntiles; tt += 64) q.hints[tt] = e_prev;
-      }
+      if (E >= hi) { const uint64_t last = (uint64_t)E / TB; for (uint64_t tt = (uint64_t)t + 1 + lane; tt < last && tt < q.ntiles; tt += 64) q.hints[tt] = E; }
     }
   }
-  // ---- offsets at their final indexes: every on-chain lane repeats its short walk (consecutive lanes
-  //      write consecutive entries)
-  if (N + n + 1 > q.offs_cap) { if (lane == 0) { atomicOr(&q.result[1], 2u); q.hflag[1] = 1u; } return; }
-  if (has && t.stitched) {
-    if (t.mine) { uint32_t n2, e2; walk(q.in, q.offs + N + (t.inc - t.n_l), 0u, t.a_end, q.len, t.s_l, n2, e2); }
-  } else if (has && lane == 0) {
-    uint32_t n2, e2;
-    walk(q.in, q.offs + N, 0u, hi, q.len, entry, n2, e2);
+  const uint64_t total_here = (uint64_t)N + v.n;
+  if (total_here + 1 > q.offs_cap) fl |= 2u;
+  if (fl && lane == 0) { atomicOr(&q.result[1], fl); q.hflag[1] = 1u; }
+  if (t == q.ntiles - 1 && lane == 0) {
+    q.result[0] = (uint32_t)total_here; q.hflag[0] = (uint32_t)total_here;
+    if (!(fl & 2u)) q.offs[total_here] = (uint32_t)q.len;
   }
-  if (tile == q.ntiles - 1 && lane == 0) {
-    q.offs[N + n] = (uint32_t)q.len;
-    q.result[0] = (uint32_t)(N + n);
-    q.hflag[0] = (uint32_t)(N + n);
-  }
-  STAMP(6);
-}
-
-// One wave = TWO consecutive tiles through ONE LDS window: local(A), local(B), finish(A), finish(B). Half as many waves as tiles:
-// a 64 MiB batch (8 192 tiles) is one round of the chip instead of 1.7, and each look-back is resolved a tile's work after it
-// was published.
-__global__ __launch_bounds__(64) void k_bounds(BoundsParams q) {
-  __shared__ __attribute__((aligned(16))) u8 st[TB + HALO + 16];
-  __shared__ uint32_t lfail;   // failure bit of THIS wave's look-backs (1 spin gave up)
-  const uint32_t lane = threadIdx.x;
-  if (lane == 0) lfail = 0;
-  unsigned long long t_prev = q.dbg ? clock64() : 0;
-  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next run will use
-    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
-    for (uint32_t i = lane; i < per; i += 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
-  }
-  const uint32_t t0 = 2 * blockIdx.x, t1 = t0 + 1;
-  TileLocal A, B;
-  bounds_local(q, st, t0, A, t_prev);
-  const bool two = t1 < q.ntiles;
-  if (two) {
-    __syncthreads();   // every lane is done with tile A's bytes
-    bounds_local(q, st, t1, B, t_prev);
-  }
-  // B first: the last tile of a group (always a B) publishes the group's aggregate as soon as it has folded the group's tile words,
-  // before it waits for the older groups itself — resolving A first would put A's wait for the older groups in front of that
-  // publication and chain the groups one round trip after the other
-  if (two) bounds_finish(q, t1, B, &lfail, t_prev);
-  bounds_finish(q, t0, A, &lfail, t_prev);
+  if ((v.flags & 3u) != 1u || (fl & 2u)) return;   // nothing starts here, or the row overflowed, or the offsets do not fit
+  const uint16_t* const row = q.rows + (size_t)t * CAP;
+  const uint32_t lo = t * TB;
+  for (uint32_t i = lane; i < v.n; i += 64) q.offs[N + i] = lo + row[i];   // consecutive lanes write consecutive entries
 }
 
 // Cold fallback: one lane follows the whole chain out of global memory.
@@ -339,19 +360,26 @@ using namespace etlg;
 
 uint32_t etlg_k_bounds_tile_bytes(void) { return TB; }
 
-// Scratch (device, caller-owned): two descriptor buffers, each = result block (16 u32, first) | ndesc [ntiles + ngroups] u64, zero when a
-// run starts — every run zeroes the OTHER buffer (`clear`, `clear_words`) — and hints [ntiles] u32, 0xFF-filled (refilled by the
-// caller after a run that set any). hflag: 2 u32 of pinned host memory, zeroed by the caller.
-void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* cur, void* clear, uint32_t clear_words,
-                          uint32_t* hints, uint32_t* hflag, int sequential, hipStream_t s) {
+// Scratch (device, caller-owned), for ntiles = ceil(len / tile bytes): result block (64 bytes) | TileSum[ntiles] | TilePre[ntiles] |
+// TilePre[ntiles / 256 + 1] | rows u16[ntiles][CAP]. Nothing in it needs initialising: every run writes what it reads. hints: u32[ntiles], 0xFF-filled (refilled by
+// the caller after a run that set any). hflag: 2 u32 of pinned host memory.
+size_t etlg_k_bounds_scratch_bytes(size_t ntiles) {
+  return 64 + ntiles * sizeof(TileSum) + ntiles * sizeof(TilePre) + (((ntiles / RB + 2) * sizeof(TilePre) + 63) & ~(size_t)63) + ntiles * CAP * 2 + 64;
+}
+
+void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* scratch, uint32_t* hints, uint32_t* hflag, int sequential, hipStream_t s) {
   BoundsParams q;
-  q.dbg = (sequential & 2) ? 1u : 0u; sequential &= 1;
   q.in = in; q.len = len; q.offs = offs; q.offs_cap = offs_cap;
   q.ntiles = (uint32_t)((len + TB - 1) / TB);
-  q.result = (uint32_t*)cur; q.ndesc = (unsigned long long*)cur + 8; q.hints = hints; q.hflag = hflag;
-  q.d_clear = (unsigned long long*)clear; q.clear_words = clear_words;
-  if (sequential) hipLaunchKernelGGL(k_bounds_seq, dim3(1), dim3(64), 0, s, q);
-  else hipLaunchKernelGGL(k_bounds, dim3((q.ntiles + 1) / 2), dim3(64), 0, s, q);
+  q.result = (uint32_t*)scratch; q.sum = (TileSum*)((uint8_t*)scratch + 64);
+  q.pre = (TilePre*)(q.sum + q.ntiles);
+  q.blk = q.pre + q.ntiles;
+  q.rows = (uint16_t*)((uint8_t*)q.blk + ((((size_t)q.ntiles / RB + 2) * sizeof(TilePre) + 63) & ~(size_t)63));
+  q.hints = hints; q.hflag = hflag;
+  if (sequential) { hipLaunchKernelGGL(k_bounds_seq, dim3(1), dim3(64), 0, s, q); return; }
+  hipLaunchKernelGGL(k_bounds_local, dim3(q.ntiles), dim3(64), 0, s, q);
+  hipLaunchKernelGGL(k_bounds_resolve, dim3((q.ntiles + RB - 1) / RB), dim3(RB), 0, s, q);
+  hipLaunchKernelGGL(k_bounds_write, dim3((q.ntiles + 3) / 4), dim3(256), 0, s, q);
 }
 
 }  // extern "C"
