@@ -56,7 +56,8 @@ def _pytest_job(args, timeout, order=None):
 # Every emulated run of this file is a subprocess of its own (the parity files pick the library up from the environment); they are all
 # started when the first of them is asked for and run side by side — the suite's wall time is the longest of them, not their sum.
 _JOBS = {
-    "scenarios": _pytest_job(["tests/test_gpu_parity.py", "-k", "scenario_parity or temporal_matrix or wider_than_16"], 900),
+    "scenarios": _pytest_job(["tests/test_gpu_parity.py", "-k", "scenario_parity or temporal_matrix or wider_than_16 or type_matrix"], 900),
+    "shim_twin": _pytest_job(["tests/test_shim_twin.py"], 600),
     "shard_async": _pytest_job(["tests/test_shard_decode.py", "tests/test_gpu_async.py", "-k", "not 8-"], 900),
     "copy_scan": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k", "not device_resident and not device_input and not 16777216"], 600),
     "plans": _pytest_job(["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or k_plan or prepass or (cfg2 and default)"], 900),
@@ -102,6 +103,13 @@ def test_scenarios_on_every_kernel_path(emu_jobs):
     multi-pass), byte for byte against the oracle — the same test the GPU box runs, on emulated kernels; plus the temporal matrix
     (fast paths + chrono grammar) and tables of 17 / 24 / 32 columns (k_cells' WIDE instantiation)."""
     _passed(emu_jobs, "scenarios")
+
+
+def test_rust_shim_twin(emu_jobs):
+    """tests/native/shim_twin.cpp — the Rust crate's call sequence (ring of pinned buffers, decode_async / finish, the oversize-message
+    path, FlushTracker, InFlight's drop order) through the C ABI — over fuzzed streams on the emulated library: events against the
+    oracle's, LSN bookkeeping against the reference's per-message rules."""
+    _passed(emu_jobs, "shim_twin")
 
 
 def test_sharded_decode_and_async_chain(emu_jobs):
