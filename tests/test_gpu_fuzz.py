@@ -61,3 +61,108 @@ def test_mutations_agree_with_oracle(mk, path):
         n_err += rb.err_code != 0
         d.close()
     assert n_err > 5   # the mutations do hit the error paths
+
+
+# ---- what only the hardware can show: the kernels that talk between workgroups of one launch (the look-backs of k_fused / k_cells /
+#      k_plan2, the pre-pass's ticket) on batches of hundreds to thousands of tiles, and the boundary scan on byte soup. The SIMT emulator
+#      runs workgroups in order and sees none of it (a stale-descriptor defect lived two rounds behind a green emulator suite);
+#      the long runs of tools/ are outside the driver's view, so a bounded share of them lives here.
+import os  # noqa: E402
+import time  # noqa: E402
+
+_HW = os.environ.get("ETLG_SIMT_RUN") != "1"
+BIG_PATHS = {"default": {}, "fused256": {"ETLG_FUSED_KERNEL": "0"}, "fused64": {"ETLG_FUSED_KERNEL": "1"}, "cells": {"ETLG_FUSED_KERNEL": "2"},
+             "plan_lookback": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0"}, "plan_pre": {"ETLG_FUSED_KERNEL": "3"}}
+
+
+@pytest.mark.skipif(not _HW, reason="inter-workgroup behaviour: the emulator runs workgroups in order")
+@pytest.mark.parametrize("big_path", sorted(BIG_PATHS))
+@pytest.mark.parametrize("mk", [synth.cfg2, synth.cfg3, synth.cfg5])
+def test_many_tile_batches_mutated_on_hardware(mk, big_path):
+    """4 MiB batches (cfg2: 37 000 frames, 580 tiles of 64 / 145 of 256 — several groups of the two-level look-back, several rounds of
+    the chip's wave slots), one to three mutations each, eight batches back to back on ONE context per kernel path (descriptor buffers
+    rotate, a failed batch is redone by the multi-pass kernels and the next one reuses its buffers): error and every byte of the arena
+    before it as the oracle has them."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    import zlib
+    knobs = ("ETLG_FUSED_KERNEL", "ETLG_PLAN_PRE", "ETLG_FORCE_MULTIPASS", "ETLG_PLAN", "ETLG_FUSED_DBG", "ETLG_PLAN_DBG")
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    os.environ.update(BIG_PATHS[big_path])
+    try:
+        rng = random.Random(zlib.crc32(f"big/{mk.__name__}/{big_path}".encode()))
+        w = mk()
+        buf, offs = w.fill(4 << 20)
+        d = Decoder(0)
+        w.register(d, ready=not w.cfg.emit_relations)
+        n_err = 0
+        for it in range(8):
+            mb, mo = buf, offs
+            for _ in range(rng.choice([0, 1, 1, 2, 3])):
+                mb, mo = _mutate(rng, mb, mo)
+            o = oracle.Oracle()
+            w.register(o, ready=not w.cfg.emit_relations)
+            if w.cfg.emit_relations:     # the stream registers its tables itself: a fresh device context per batch as well
+                d.close(); d = Decoder(0); w.register(d, ready=False)
+            else:
+                d.reset_stream_state()
+            rb, gb = o.decode(mb, mo), d.decode(mb, mo)
+            e = gb.error
+            got = (e.code, e.kind, e.description, e.frame_index) if e else (0, 0, "", -1)
+            assert (rb.err_code, rb.err_kind, rb.err_desc, rb.err_frame) == got, (it, got)
+            diff = rb.host_batch().diff(gb.host())
+            assert not diff, (it, diff[:4])
+            n_err += rb.err_code != 0
+        d.close()
+        assert n_err >= 1
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_boundary_scan_byte_soup(seed):
+    """tools/scan_hunt.py's generator for a bounded time (12 s per seed on the hardware, 150 inputs on the emulator): frames with random,
+    header-look-alike and frame-in-frame payloads, truncated / mis-tagged / mis-sized frames, random cuts — the three scan kernels (and
+    their hinted reruns and one-lane fallback) against the sequential rule."""
+    import struct as S
+    from etl_amd.decoder import Decoder
+    from tests.test_gpu_scan import ref_scan
+    rng = random.Random(seed)
+    dec = Decoder(0)
+
+    def payload(n):
+        k = rng.random()
+        if k < 0.3:
+            return bytes(rng.getrandbits(8) for _ in range(n))
+        if k < 0.6:
+            return bytes(rng.choice(b"d\x00\x00\x01\x10w") for _ in range(n))
+        return (b"d" + S.pack(">I", rng.choice([4, 5, 17, 60, 200, 4000])) + b"w") * (n // 6 + 1)
+
+    t0, it = time.time(), 0
+    while (time.time() - t0 < 12.0) if _HW else (it < 150):
+        parts, size = [], 0
+        total = rng.choice([0, 1, 4, 5, 300, 5000, 9000, 40000, 150000])
+        while size < total:
+            n = rng.choice([0, 1, 20, 108, 108, 108, 500, 3000, 9000, 20000, 70000])
+            body = payload(n)[:n]
+            fr = b"d" + S.pack(">I", len(body) + 4) + body
+            k = rng.random()
+            if k < 0.03:
+                fr = fr[:rng.randrange(1, len(fr) + 1)]
+            elif k < 0.05:
+                fr = bytes([rng.getrandbits(8)]) + fr[1:]
+            elif k < 0.07:
+                fr = fr[:1] + S.pack(">I", rng.choice([0, 3, 2**31, 2**32 - 1, len(body) + 5])) + fr[5:]
+            parts.append(fr)
+            size += len(fr)
+        buf = np.frombuffer(b"".join(parts), dtype=np.uint8)
+        if rng.random() < 0.3 and len(buf) > 3:
+            buf = buf[:rng.randrange(len(buf))]
+        got, want = dec.scan_boundaries(buf), ref_scan(buf)
+        assert len(got) == len(want) and np.array_equal(got, want), (seed, it, len(buf))
+        it += 1
+    dec.close()
+    assert it >= 100
