@@ -984,33 +984,50 @@ def main():
         paths = dec.debug_paths()
 
     extra = {}
+    _leg_t = [time.perf_counter()]
+
+    def _leg_done(name):   # wall time of every leg, to stderr (the JSON line stays the only stdout)
+        t = time.perf_counter()
+        print(f"[bench] {name}: {t - _leg_t[0]:.1f} s", file=sys.stderr, flush=True)
+        _leg_t[0] = t
+    _leg_done("headline + roofline leg")
     if rank == 0:
         extra["deferred_cells"] = deferred_cells(dec, items[0])
         if "no_sidecar" in legs and args.workload == "cfg2":
             extra["no_sidecar"] = leg_no_sidecar(dec, items, 80, check)
+            _leg_done("no_sidecar")
         if "cfg3" in legs and args.workload != "cfg3":
             extra["cfg3"] = leg_async(synth.cfg3, local_rank, dev, cap, 4, 60, flags, check,
                                       os.path.join(ROOT, "profiles", "traffic_cfg3.json"))[0]
+            _leg_done("cfg3")
         if "default_flags" in legs and args.workload == "cfg2":
             # the headline workload WITHOUT the caller's no-control assertion: the optimistic path (first kernel as if there were
             # no Relation / DDL frame, ETLG_E_CTRL_HINT otherwise), ASYNC chain as with the assertion
             d = leg_async(synth.cfg2, local_rank, dev, cap, 6, 200, abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC, check)[0]   # the headline's pool and batch count
             extra["default_flags"] = {k: d[k] for k in ("value", "unit", "workload", "batches", "paths")}
             extra["default_flags"]["kernels_us"] = d["roofline"]["pipeline_kernels_us"]
+            _leg_done("default_flags")
         if "cfg5" in legs:
             extra["cfg5"] = leg_cfg5(local_rank, dev, cap, 16, 2)
+            _leg_done("cfg5")
         if "cfg1" in legs:
             extra["cfg1"] = leg_cfg1(local_rank, dev, cap, 4.0)
+            _leg_done("cfg1")
         if "wide70" in legs:
             extra["wide70"] = leg_wide70(local_rank, dev, 24000, 40)
+            _leg_done("wide70")
         if "copy" in legs:
             extra["copy"] = leg_copy(local_rank, dev, 400000, 8)
+            _leg_done("copy")
         if "handoff" in legs:
             extra["handoff"] = leg_handoff(local_rank, dev, cap, 5)
+            _leg_done("handoff")
         if "pcie" in legs:
             extra["pcie"] = leg_pcie(local_rank, dev, cap, 24)
+            _leg_done("pcie")
     if (args.cfg4_leg or "cfg4" in legs) and world == 1 and args.workload != "cfg4":
         extra["cfg4"] = leg_cfg4(local_rank, dev, 1, 0, args.cfg4_gib if args.cfg4_leg else 2, args.cfg4_seg_mib, False, None)   # the default line: 2 GiB of the 64 GiB stream on this one GPU
+        _leg_done("cfg4")
 
     # ---- CPU baseline leg (rank 0, N == 1 only): the oracle on the same host cores
     cpu = None
@@ -1038,6 +1055,7 @@ def main():
         nthr = cpu_threads(args.cpu_threads)
         if nthr > 1:
             cpu["all_cores"] = cpu_baseline_threads(w, pool, nthr, args.cpu_threads_seconds)
+        _leg_done("cpu_baseline")
 
     if rank == 0:
         value = all_bytes / elapsed / 1e9
