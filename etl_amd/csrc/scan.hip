@@ -163,35 +163,38 @@ DEV void bounds_local(const BoundsParams& q, u8* st, uint32_t tile, TileLocal& t
   t.a_end = a_end;
   uint32_t s_l = NO_ENTRY;
   if (a < hi) {
-    // all 128 bytes at once (8 independent 16-byte LDS reads): one bit per byte that is 'd', one per
-    // byte that is 0. A guess is only tried where 'd' is followed by a zero byte, i.e. at frames
-    // shorter than 16 MiB (text is full of 'd's; a longer frame is simply never guessed and costs
-    // the tile a hinted rerun).
-    unsigned long long dmask[2] = {0, 0}, zmask[2] = {0, 0};
+    // all 128 bytes at once (8 independent 16-byte LDS reads + the dword behind them). A guess is only tried where 'd' is followed by a
+    // zero byte, i.e. at frames shorter than 16 MiB (text is full of 'd's; a longer frame is simply never guessed and costs the tile
+    // a hinted rerun). The flags stay where their bytes are (bit 7 of each byte: 'd' here AND zero in the byte behind, which for a
+    // dword's last byte is the next dword's first) and only WHICH dwords hold a candidate is collected in a 32-bit mask: packing two
+    // 128-bit byte masks per lane was 900 of the kernel's ~1 300 instructions, for the one or two candidates a lane has.
+    uint32_t w[33];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const uint4 v = *(const uint4*)(st + (a - lo) + 16 * k);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t x = w[j] ^ 0x64646464u;                                                  // 'd' -> 0
-        const uint32_t zd = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);              // 0x80 where the byte was 'd'
-        const uint32_t y = w[j];
-        const uint32_t zz = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);              // 0x80 where the byte was 0
-        const uint32_t bd = ((zd >> 7) & 1u) | ((zd >> 14) & 2u) | ((zd >> 21) & 4u) | ((zd >> 28) & 8u);
-        const uint32_t bz = ((zz >> 7) & 1u) | ((zz >> 14) & 2u) | ((zz >> 21) & 4u) | ((zz >> 28) & 8u);
-        dmask[k >> 2] |= (unsigned long long)bd << (16 * (k & 3) + 4 * j);
-        zmask[k >> 2] |= (unsigned long long)bz << (16 * (k & 3) + 4 * j);
-      }
+      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
     }
-    const unsigned long long znext = st[(a - lo) + SUB] == 0 ? 1ull : 0ull;  // the byte after this lane's range
-    dmask[0] &= (zmask[0] >> 1) | (zmask[1] << 63);
-    dmask[1] &= (zmask[1] >> 1) | (znext << 63);
-    for (int half = 0; half < 2 && s_l == NO_ENTRY; half++) {
-      unsigned long long m = dmask[half];
-      while (m && s_l == NO_ENTRY) {
-        const uint32_t p = a + 64 * half + (uint32_t)__builtin_ctzll(m);
-        m &= m - 1;
+    w[32] = *(const uint32_t*)(st + (a - lo) + SUB);   // (the window has a halo: readable for every lane)
+    auto zero_flags = [](uint32_t y) { return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); };   // 0x80 where the byte is 0 (exact)
+    uint32_t dwords = 0;   // bit j: dword j of this lane's 128 bytes holds a candidate
+    uint32_t zz_next = zero_flags(w[32]);
+#pragma unroll
+    for (int j = 31; j >= 0; j--) {
+      const uint32_t zz = zero_flags(w[j]);
+      const uint32_t zd = zero_flags(w[j] ^ 0x64646464u);                            // 0x80 where the byte is 'd'
+      const uint32_t cand = zd & __builtin_amdgcn_alignbit(zz_next, zz, 8);           // ... and the byte behind it is 0
+      dwords |= cand ? 1u << j : 0u;
+      zz_next = zz;
+    }
+    while (dwords && s_l == NO_ENTRY) {
+      const uint32_t j = (uint32_t)__builtin_ctz(dwords);
+      dwords &= dwords - 1u;
+      const u8* const at = st + (a - lo) + 4u * j;
+      const uint32_t x = *(const uint32_t*)at, nx_dw = *(const uint32_t*)(at + 4);
+      uint32_t cand = zero_flags(x ^ 0x64646464u) & __builtin_amdgcn_alignbit(zero_flags(nx_dw), zero_flags(x), 8);
+      while (cand && s_l == NO_ENTRY) {
+        const uint32_t p = a + 4u * j + ((uint32_t)__builtin_ctz(cand) >> 3);
+        cand &= cand - 1u;
         uint32_t nx, nx2;
         if (p < a_end && plausible_at(st, lo, q.len, p, nx) && (nx >= hi || plausible_at(st, lo, q.len, nx, nx2))) s_l = p;
       }

@@ -133,6 +133,9 @@ template <class T> static inline T c_shfl_xor(const void* id, T v, int m, int = 
 static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3u)));
 }
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u));
+}
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline unsigned long long clock64() { return simt::ticks(); }
 static inline unsigned long long wall_clock64() { return simt::ticks(); }
