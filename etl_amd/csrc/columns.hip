@@ -137,8 +137,8 @@ DEV uint32_t col_state(const ColJob& j, uint64_t base) { return (j.fixed[base + 
 DEV uint32_t ld32a(const u8* p) { return *(const uint32_t*)p; }   // row slots are 4-byte aligned
 
 // One thread per row: state, value, validity / deferred words through wave ballots.
-__global__ __launch_bounds__(256) void k_col_fixed(ColJob j) {
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+DEV void col_fixed_body(const ColJob& j, uint32_t bx) {
+  const uint64_t r = (uint64_t)bx * 256 + threadIdx.x;
   const bool live = r < j.n_rows;
   uint32_t st = ETLG_CELL_NULL;
   const u8* slot = nullptr;
@@ -180,6 +180,15 @@ __global__ __launch_bounds__(256) void k_col_fixed(ColJob j) {
     default: break;
   }
 }
+
+__global__ __launch_bounds__(256) void k_col_fixed(ColJob j) { col_fixed_body(j, blockIdx.x); }
+
+// Several columns of one hand-off in ONE launch (blockIdx.y = column): a cfg3 batch's Arrow columns were ~30 launches of 3-30 us each,
+// and a third of the call was the gaps between them. The jobs travel in the kernel's argument block (a ColJob is 152 bytes, the
+// block holds 4 KB): tables of more columns take several packs.
+constexpr int kPack = 20;
+struct ColPack { ColJob j[kPack]; unsigned long long* blk[kPack]; int64_t* offs[kPack]; unsigned long long* tot[kPack]; };   // tot: where the column's byte total goes (one read-back for all)
+__global__ __launch_bounds__(256) void k_col_fixed_pack(ColPack p) { col_fixed_body(p.j[blockIdx.y], blockIdx.x); }
 
 DEV int arr_hexv(uint32_t c) { return c - '0' < 10u ? (int)(c - '0') : (c | 0x20u) - 'a' < 6u ? (int)((c | 0x20u) - 'a' + 10) : -1; }
 // serde_json 1.0.149 `from_str::<Value>` (call site codec/text.rs:126-134; features arbitrary_precision + std, crates/etl/Cargo.toml:36):
@@ -281,9 +290,8 @@ DEV uint32_t numeric_str_len(const u8* ent);
 DEV uint32_t timetz_str_len(const u8* slot);
 // var-len columns, pass 1: validity / deferred words + the byte length of every row's entry
 // (blk: the block's sum of lengths, for the offsets scan — a launch of its own, k_col_len_blocks, for the callers that have no such pass)
-__global__ __launch_bounds__(256) void k_col_lens(ColJob j, unsigned long long* blk) {
-  __shared__ uint64_t lds_sum[4];
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+DEV void col_lens_body(const ColJob& j, unsigned long long* blk, uint32_t bx, uint64_t* lds_sum) {
+  const uint64_t r = (uint64_t)bx * 256 + threadIdx.x;
   const bool live = r < j.n_rows;
   uint32_t st = ETLG_CELL_NULL, len = 0;
   if (live) {
@@ -311,7 +319,15 @@ __global__ __launch_bounds__(256) void k_col_lens(ColJob j, unsigned long long* 
     if (nd) atomicAdd(j.deferred_count, (unsigned long long)nd);
   }
   const uint64_t t = block_sum64(len, lds_sum);
-  if (threadIdx.x == 0) blk[blockIdx.x] = t;
+  if (threadIdx.x == 0) blk[bx] = t;
+}
+__global__ __launch_bounds__(256) void k_col_lens(ColJob j, unsigned long long* blk) {
+  __shared__ uint64_t lds_sum[4];
+  col_lens_body(j, blk, blockIdx.x, lds_sum);
+}
+__global__ __launch_bounds__(256) void k_col_lens_pack(ColPack p) {
+  __shared__ uint64_t lds_sum[4];
+  col_lens_body(p.j[blockIdx.y], p.blk[blockIdx.y], blockIdx.x, lds_sum);
 }
 
 // lens (u32) -> offsets (i64), three steps like k_col_count / k_col_scan / k_col_rows
@@ -321,8 +337,7 @@ __global__ __launch_bounds__(256) void k_col_len_blocks(const uint32_t* lens, ui
   const uint64_t t = block_sum64(i < n ? lens[i] : 0u, lds);
   if (threadIdx.x == 0) blk[blockIdx.x] = t;
 }
-__global__ __launch_bounds__(256) void k_col_len_scan(unsigned long long* blk, uint32_t n) {
-  __shared__ uint64_t lds[4];
+DEV void col_len_scan_body(unsigned long long* blk, uint32_t n, uint64_t* lds) {
   uint64_t run = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += 256) {
     const uint32_t i = b0 + threadIdx.x;
@@ -333,22 +348,38 @@ __global__ __launch_bounds__(256) void k_col_len_scan(unsigned long long* blk, u
   }
   if (threadIdx.x == 0) blk[n] = run;
 }
-__global__ __launch_bounds__(256) void k_col_offsets(const uint32_t* lens, uint64_t n, const unsigned long long* blk, int64_t* offsets) {
+__global__ __launch_bounds__(256) void k_col_len_scan(unsigned long long* blk, uint32_t n) {
   __shared__ uint64_t lds[4];
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  col_len_scan_body(blk, n, lds);
+}
+__global__ __launch_bounds__(256) void k_col_len_scan_pack(ColPack p, uint32_t n) {   // one workgroup per column
+  __shared__ uint64_t lds[4];
+  col_len_scan_body(p.blk[blockIdx.x], n, lds);
+}
+DEV void col_offsets_body(const uint32_t* lens, uint64_t n, const unsigned long long* blk, int64_t* offsets, uint32_t bx, uint64_t* lds, unsigned long long* tot = nullptr) {
+  const uint64_t i = (uint64_t)bx * 256 + threadIdx.x;
   const uint64_t ex = block_scan_excl64(i < n ? lens[i] : 0u, lds, nullptr);
-  if (i < n) offsets[i] = (int64_t)(blk[blockIdx.x] + ex);
-  if (i == n - 1) offsets[n] = (int64_t)(blk[blockIdx.x] + ex + lens[i]);
+  if (i < n) offsets[i] = (int64_t)(blk[bx] + ex);
+  if (i == n - 1) { offsets[n] = (int64_t)(blk[bx] + ex + lens[i]); if (tot) *tot = blk[bx] + ex + lens[i]; }
+}
+__global__ __launch_bounds__(256) void k_col_offsets(const uint32_t* lens, uint64_t n, const unsigned long long* blk, int64_t* offsets, unsigned long long* tot = nullptr) {
+  __shared__ uint64_t lds[4];
+  col_offsets_body(lens, n, blk, offsets, blockIdx.x, lds, tot);
+}
+__global__ __launch_bounds__(256) void k_col_offsets_pack(ColPack p) {
+  __shared__ uint64_t lds[4];
+  const ColJob& j = p.j[blockIdx.y];
+  col_offsets_body(j.lens, j.n_rows, p.blk[blockIdx.y], p.offs[blockIdx.y], blockIdx.x, lds, p.tot[blockIdx.y]);
 }
 
 // var-len columns, pass 2: one wave per 64 rows; the wave moves one row at a time, 4 bytes per lane per step where both ends
 // allow it (heap entries start 4-byte aligned; the destination is wherever the previous row ended)
-__global__ __launch_bounds__(256) void k_col_copy(ColJob j) {
+DEV void col_copy_body(const ColJob& j, uint32_t bx) {
   // A wave takes 64 consecutive rows (their bytes are consecutive in `values`): eight lanes per row, eight rows at a time, eight bytes
   // per lane and step. (One row at a time with a byte per lane was a load and a store instruction per row of up to 64 bytes: 44 us per
   // text column of a cfg3 batch, profiles/r04q.)
   const uint32_t lane = threadIdx.x & 63;
-  const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const uint64_t r0 = ((uint64_t)bx * 4 + (threadIdx.x >> 6)) * 64;
   if (r0 >= j.n_rows) return;
   const uint64_t r = r0 + lane;
   uint32_t len = 0, src = 0; int64_t dst = 0;
@@ -367,6 +398,7 @@ __global__ __launch_bounds__(256) void k_col_copy(ColJob j) {
     }
   }
 }
+__global__ __launch_bounds__(256) void k_col_copy(ColJob j) { col_copy_body(j, blockIdx.x); }
 
 
 // ---- Display strings of the classes every sink writes as text: PgNumeric (format_numeric_value,
@@ -459,12 +491,18 @@ template <class S> DEV void timetz_str(S& s, const u8* slot) { time_str(s, ld32a
 
 struct StrWrite { u8* p; DEV void put(u8 b) { *p++ = b; } };
 // formatted string columns (numeric, timetz), pass 2: one thread per row writes its Display string at its offset
-__global__ __launch_bounds__(256) void k_col_fmt(ColJob j) {
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+DEV void col_fmt_body(const ColJob& j, uint32_t bx) {
+  const uint64_t r = (uint64_t)bx * 256 + threadIdx.x;
   if (r >= j.n_rows || !j.lens[r]) return;
   const u8* slot = j.fixed + j.row_base[r] + j.off_full;
   StrWrite w{j.values + j.offsets[r]};
   if (j.kind == AK_NUMERIC_STR) numeric_str(w, j.heap + ld32a(slot)); else timetz_str(w, slot);
+}
+__global__ __launch_bounds__(256) void k_col_fmt(ColJob j) { col_fmt_body(j, blockIdx.x); }
+// pass 2 of several var-len columns in one launch: a column is copied or formatted by what it is (uniform per blockIdx.y)
+__global__ __launch_bounds__(256) void k_col_var2_pack(ColPack p) {
+  const ColJob& j = p.j[blockIdx.y];
+  if (j.kind == AK_NUMERIC_STR || j.kind == AK_TIMETZ_STR) col_fmt_body(j, blockIdx.x); else col_copy_body(j, blockIdx.x);
 }
 
 // ---- array literals (parse_cell_from_postgres_text_array, crates/etl/src/postgres/codec/text.rs:228-312; the dimensions
@@ -1046,6 +1084,32 @@ void etlg_k_col_fixed(const void* jv, hipStream_t st) {
   if (j.n_rows) hipLaunchKernelGGL(k_col_fixed, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
 }
 
+// Packed forms (jobs: n <= etlg_k_col_pack_max() ColJob records of ONE hand-off, all with the same n_rows): every fixed-width column /
+// pass 1 of every var-len column (lens -> block sums -> offsets; blk[i] / offs[i]: the column's scan scratch and offsets) / pass 2.
+uint32_t etlg_k_col_pack_max(void) { return kPack; }
+static void fill_pack(ColPack& p, const ColJob* jobs, uint32_t n, unsigned long long* const* blk, int64_t* const* offs, unsigned long long* const* tot = nullptr) {
+  for (uint32_t i = 0; i < n; i++) { p.j[i] = jobs[i]; p.blk[i] = blk ? blk[i] : nullptr; p.offs[i] = offs ? offs[i] : nullptr; p.tot[i] = tot ? tot[i] : nullptr; }
+}
+void etlg_k_col_fixed_pack(const void* jobs, uint32_t n, hipStream_t st) {
+  const ColJob* j = (const ColJob*)jobs;
+  if (!n || !j[0].n_rows) return;
+  ColPack p; fill_pack(p, j, n, nullptr, nullptr);
+  hipLaunchKernelGGL(k_col_fixed_pack, dim3((uint32_t)((j[0].n_rows + 255) / 256), n), dim3(256), 0, st, p);
+}
+void etlg_k_col_var_pack(const void* jobs, uint32_t n, unsigned long long* const* blk, int64_t* const* offs, unsigned long long* const* tot, int step, hipStream_t st) {
+  const ColJob* j = (const ColJob*)jobs;
+  if (!n || !j[0].n_rows) return;
+  const uint32_t nb = (uint32_t)((j[0].n_rows + 255) / 256);
+  ColPack p; fill_pack(p, j, n, blk, offs, tot);
+  if (step == 0) {
+    hipLaunchKernelGGL(k_col_lens_pack, dim3(nb, n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_col_len_scan_pack, dim3(n), dim3(256), 0, st, p, nb);
+    hipLaunchKernelGGL(k_col_offsets_pack, dim3(nb, n), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(k_col_var2_pack, dim3(nb, n), dim3(256), 0, st, p);
+  }
+}
+
 // blk: (nblocks + 1) x u64 scratch
 void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st) {
   const ColJob j = *(const ColJob*)jv;
@@ -1054,7 +1118,7 @@ void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, i
   if (step == 0) {
     hipLaunchKernelGGL(k_col_lens, dim3(nb), dim3(256), 0, st, j, blk);
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
-    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
+    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets, (unsigned long long*)nullptr);
   } else {
     if (j.kind == AK_NUMERIC_STR || j.kind == AK_TIMETZ_STR) hipLaunchKernelGGL(k_col_fmt, dim3(nb), dim3(256), 0, st, j);
     else hipLaunchKernelGGL(k_col_copy, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
@@ -1067,7 +1131,7 @@ void etlg_k_scan_lens(const uint32_t* lens, uint64_t n, unsigned long long* blk,
   const uint32_t nb = (uint32_t)((n + 255) / 256);
   hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, lens, n, blk);
   hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
-  hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, lens, n, (const unsigned long long*)blk, offsets);
+  hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, lens, n, (const unsigned long long*)blk, offsets, (unsigned long long*)nullptr);
 }
 
 // list columns: step 0 = element counts + list offsets, step 1 = child values / validity
@@ -1079,21 +1143,21 @@ void etlg_k_col_list(const void* jv, unsigned long long* blk, int64_t* offsets, 
     hipLaunchKernelGGL(k_arr_count, dim3(nb), dim3(256), 0, st, j);
     hipLaunchKernelGGL(k_col_len_blocks, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, blk);
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
-    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
+    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets, (unsigned long long*)nullptr);
   } else {
     hipLaunchKernelGGL(k_arr_fill, dim3(nb), dim3(256), 0, st, j);
   }
 }
 
 // step 0: lengths + offsets (blk: (nblocks + 1) x u64 scratch); step 1: the bytes
-void etlg_k_rowbinary(const void* jv, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st) {
+void etlg_k_rowbinary(const void* jv, unsigned long long* blk, int64_t* offsets, unsigned long long* tot, int step, hipStream_t st) {
   const RbJob j = *(const RbJob*)jv;
   if (!j.n_rows) return;
   const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
   if (step == 0) {
     hipLaunchKernelGGL(k_rb_lens, dim3(nb), dim3(256), 0, st, j, blk);
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
-    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets);
+    hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets, tot);
   } else {
     hipLaunchKernelGGL(k_rb_rows, dim3(nb), dim3(256), 0, st, j);
   }

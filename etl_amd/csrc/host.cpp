@@ -286,6 +286,8 @@ void etlg_ctx_destroy(etlg_ctx* c) {
   for (auto& b : c->blk_host) (void)hipHostFree(b.first);
   if (c->ctl_stream) (void)hipStreamDestroy(c->ctl_stream);
   if (c->mp_tail) (void)hipEventDestroy(c->mp_tail);
+  if (c->h_cnt_init) (void)hipHostFree(c->h_cnt_init);
+  if (c->h_hand) (void)hipHostFree(c->h_hand);
   if (c->h_ctl_list) (void)hipHostFree(c->h_ctl_list);
   if (c->h_ctl_stage) (void)hipHostFree(c->h_ctl_stage);
   if (c->ctl_alt.h_ctl_list) (void)hipHostFree(c->ctl_alt.h_ctl_list);

@@ -57,10 +57,13 @@ extern "C" void etlg_k_launch_plan_pre(const DecParams* p, const void* q, hipStr
 extern "C" int etlg_k_plan_set_lds(void);
 extern "C" void etlg_k_col_select(const void* sel, hipStream_t s);
 extern "C" void etlg_k_col_fixed(const void* job, hipStream_t s);
+extern "C" uint32_t etlg_k_col_pack_max(void);
+extern "C" void etlg_k_col_fixed_pack(const void* jobs, uint32_t n, hipStream_t s);
+extern "C" void etlg_k_col_var_pack(const void* jobs, uint32_t n, unsigned long long* const* blk, int64_t* const* offs, unsigned long long* const* tot, int step, hipStream_t s);
 extern "C" void etlg_k_scan_lens(const uint32_t* lens, uint64_t n, unsigned long long* blk, int64_t* offsets, hipStream_t s);
 extern "C" void etlg_k_col_list(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" void etlg_k_size_hints(const void* job, hipStream_t s);
-extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
+extern "C" void etlg_k_rowbinary(const void* job, unsigned long long* blk, int64_t* offsets, unsigned long long* tot, int step, hipStream_t s);
 extern "C" void etlg_k_col_var(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t s);
 extern "C" int etlg_k_cells_set_lds(void);
 extern "C" uint32_t etlg_k_cells_table_bytes(uint32_t maxc);
@@ -353,6 +356,8 @@ struct etlg_ctx {
   std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
   std::vector<std::pair<void*, size_t>> blk_dev, blk_host;  // hand-off calls (columns / RowBinary / size hints): pooled device and pinned blocks
   DevBuf d_colsel;                   // etlg_batch_columns: block counts of the row selection
+  uint8_t* h_hand = nullptr; size_t h_hand_cap = 0;   // pinned: the row formats' small uploads (initial counters + column words, one copy) and read-backs (row count; totals + counters, one copy each)
+  unsigned long long* h_cnt_init = nullptr; size_t h_cnt_init_cols = 0;   // pinned {0, 0, 0, ~0} per column: the hand-off's counters start from it (an asynchronous copy; the content never changes)
   std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order
   std::vector<hipEvent_t> ev_pool;   // "result block copied back" events of finished batches
   std::vector<int32_t> last_live;      // slots whose columns d_cols currently holds

@@ -123,7 +123,8 @@ uint64_t collective(int op, uint64_t a, uint64_t b, uint64_t c, const void* site
   return L->out;
 }
 
-void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg) {
+void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg, uint32_t gx) {
+  if (!gx) gx = grid ? grid : 1;
   if (block > kMaxLanes) { fprintf(stderr, "simt: block of %u lanes\n", block); abort(); }
   if (!g_stacks) {
     g_stacks = (char*)mmap(nullptr, kStack * kMaxLanes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -143,7 +144,7 @@ void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void
   for (uint32_t bid = 0; bid < grid; bid++) {
     for (uint32_t t = 0; t < block; t++) {
       Lane& L = g_lanes[t];
-      L.view = LaneView{t, bid, block, grid};
+      L.view = LaneView{t, bid, block, grid, gx};
       L.state = RUN;
       getcontext(&L.ctx);
       L.ctx.uc_stack.ss_sp = g_stacks + (size_t)t * kStack;

@@ -53,24 +53,24 @@ namespace simt {
 enum Op : int { OP_BAR = 1, OP_JOIN, OP_BALLOT, OP_ALL, OP_ANY, OP_READFIRST, OP_READLANE, OP_SHFL, OP_SHFL_UP, OP_SHFL_XOR, OP_DPP, OP_FENCE };
 
 struct Idx { uint32_t x, y, z; };
-struct LaneView { uint32_t tid, bid, bdim, gdim; };
+struct LaneView { uint32_t tid, bid, bdim, gdim, gx; };   // bid: linear workgroup index over a grid of gx columns (blockIdx.x) x gdim / gx rows (blockIdx.y)
 extern LaneView* g_view;   // the lane that is running
 uint8_t* dyn_lds();
 // rendezvous of the running lane; returns the lane's result
 uint64_t collective(int op, uint64_t a, uint64_t b, uint64_t c, const void* site);
-void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg);
+void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg, uint32_t gx = 0);
 uint64_t ticks();
 
 static inline Idx tidx() { return Idx{g_view->tid, 0, 0}; }
-static inline Idx bidx() { return Idx{g_view->bid, 0, 0}; }
+static inline Idx bidx() { return Idx{g_view->bid % g_view->gx, g_view->bid / g_view->gx, 0}; }
 static inline Idx bdim() { return Idx{g_view->bdim, 1, 1}; }
-static inline Idx gdim() { return Idx{g_view->gdim, 1, 1}; }
+static inline Idx gdim() { return Idx{g_view->gx, g_view->gdim / g_view->gx, 1}; }
 
 template <class... KArgs, class... Args>
 void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t lds, Args&&... args) {
   std::tuple<std::decay_t<KArgs>...> tup(std::forward<Args>(args)...);
   struct Ctx { void (*k)(KArgs...); std::tuple<std::decay_t<KArgs>...>* t; } ctx{k, &tup};
-  run_grid(g.x, b.x, lds, [](void* p) { Ctx* c = (Ctx*)p; std::apply(c->k, *c->t); }, &ctx);
+  run_grid(g.x * g.y, b.x, lds, [](void* p) { Ctx* c = (Ctx*)p; std::apply(c->k, *c->t); }, &ctx, g.x);
 }
 
 }  // namespace simt
