@@ -245,6 +245,7 @@ pub struct etlg_rowbinary {
 pub const ETLG_ROWS_INSERT: u32 = 1;
 pub const ETLG_ROWS_UPDATE: u32 = 2;
 pub const ETLG_ROWS_PARSE_ARRAYS: u32 = 4;
+pub const ETLG_ROWS_FORMAT_JSON: u32 = 8;
 pub const ETLG_CH_MERGE_TREE: i32 = 0;
 pub const ETLG_CH_REPLACING_MERGE_TREE: i32 = 1;
 pub const ETLG_RB_OK: u32 = 0;

@@ -127,7 +127,7 @@ RB_OK, RB_NEEDS_HOST = 0, 3
 (AK_BOOLEAN, AK_INT32, AK_INT64, AK_FLOAT32, AK_FLOAT64, AK_DATE32, AK_TIME64_US, AK_TIMESTAMP_US, AK_TIMESTAMP_US_UTC, AK_FIXED16,
  AK_LARGE_UTF8, AK_LARGE_BINARY, AK_TEXT_FORM, AK_LIST) = range(14)
 AK_NONE = 255
-ROWS_INSERT, ROWS_UPDATE, ROWS_PARSE_ARRAYS = 1, 2, 4
+ROWS_INSERT, ROWS_UPDATE, ROWS_PARSE_ARRAYS, ROWS_FORMAT_JSON = 1, 2, 4, 8
 
 
 class KernelStat(C.Structure):

@@ -11,6 +11,7 @@
 // A cell the decode kernels handed back DEFERRED is null in `validity` and set in the column's `deferred` bitmap: the consumer
 // finishes it from the arena (row_event names the event). Integer / byte work, HBM-bound: no MFMA.
 #include "codec.hip.h"
+#include <type_traits>
 
 namespace etlg {
 
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void k_col_rows(ColSel s) {
 }
 
 enum : uint32_t { AK_BOOL = 0, AK_I32 = 1, AK_I64 = 2, AK_F32 = 3, AK_F64 = 4, AK_DATE32 = 5, AK_TIME64 = 6, AK_TS = 7, AK_TSTZ = 8, AK_FIXED16 = 9,
-                  AK_UTF8 = 10, AK_BINARY = 11, AK_TEXT_FORM = 12, AK_NUMERIC_STR = 14, AK_TIMETZ_STR = 15, AK_NONE = 255 };   // 14 / 15: internal (host.cpp ColPlan.fmt), LargeUtf8 to the caller
+                  AK_UTF8 = 10, AK_BINARY = 11, AK_TEXT_FORM = 12, AK_NUMERIC_STR = 14, AK_TIMETZ_STR = 15, AK_JSON_STR = 16, AK_NONE = 255 };   // 14 / 15 / 16: internal (host.cpp ColPlan.fmt), LargeUtf8 to the caller
 constexpr int32_t kCeDays1970 = 719163;  // chrono num_days_from_ce of 1970-01-01
 
 DEV uint32_t col_state(const ColJob& j, uint64_t base) { return (j.fixed[base + j.col_index / 4] >> (2 * (j.col_index % 4))) & 3u; }
@@ -286,10 +287,185 @@ DEV bool json_valid(const u8* s, uint32_t n) {
   }
 }
 
+
+// ---- serde_json 1.0.149 `Value::to_string()` of a json / jsonb cell (the sinks' `j.to_string()`: clickhouse/encoding.rs:73,
+// bigquery/encoding.rs:173-176, iceberg/encoding.rs:356) from the cell's source text, which json_valid() has accepted. What the parse +
+// Display round trip changes (features arbitrary_precision + std, no preserve_order: crates/etl/Cargo.toml:36):
+//   * whitespace between tokens goes; the output is compact ("," and ":" without blanks);
+//   * an object is a BTreeMap<String, Value>: members leave in the byte order of their DECODED keys, a repeated key keeps its last value;
+//   * strings are decoded and written again with serde_json's escapes: \" \\ \b \f \n \r \t, \u00xx (lowercase) for the other bytes
+//     below 0x20, everything else raw (so "é" -> the two UTF-8 bytes, "\/" -> "/", a surrogate pair -> four bytes, 0x7f raw);
+//   * a number keeps its literal (arbitrary_precision), except: an exponent without a sign gets '+' ("1e309" -> "1e+309": pinned by
+//     the reference's own test, codec/text.rs:812-815), and an integer literal that fits u64 / i64 goes through the integer and back
+//     (parse_any_number tries buf.parse() first), which only changes "-0" -> "0" (restated from serde_json's source; unpinned).
+// Sorting is by selection: one pass over the object's members per member written (keys compared as decoded byte streams, no copy), so an
+// object of k members costs k scans of its text. Returns 0; JD_HOST when the cell is beyond what a lane does here (nesting deeper than
+// kJsonDepth, an object of more than kJsonMembers members, serde_json's private number token as a key) — the caller hands the cell
+// back, as before; JD_BQ_INT when `bq` is set and a number that is WRITTEN (the value of a repeated key that lost is not in the parsed
+// Value either) is an integer literal outside u64 / i64 (validate_json_number_for_bigquery, bigquery/validation.rs:64-85).
+constexpr uint32_t kJsonDepth = 16, kJsonMembers = 64;
+enum : uint32_t { JD_OK = 0, JD_HOST = 1, JD_BQ_INT = 2 };
+struct JsIter { uint32_t i, pend, npend; };   // a cursor over a string's decoded bytes (i: behind the opening quote)
+DEV int js_next(const u8* s, JsIter& k) {     // the next decoded byte, -1 at the closing quote
+  if (k.npend) { const int b = (int)(k.pend & 0xFFu); k.pend >>= 8; k.npend--; return b; }
+  const uint32_t c = s[k.i];
+  if (c == '"') return -1;
+  if (c != '\\') { k.i++; return (int)c; }
+  const uint32_t x = s[k.i + 1];
+  if (x != 'u') {
+    k.i += 2;
+    return x == 'b' ? 8 : x == 'f' ? 12 : x == 'n' ? 10 : x == 'r' ? 13 : x == 't' ? 9 : (int)x;   // \" \\ \/ are themselves
+  }
+  auto h4 = [&](uint32_t at) { uint32_t v = 0; for (uint32_t q = 0; q < 4; q++) v = v * 16 + (uint32_t)arr_hexv(s[at + q]); return v; };
+  uint32_t cp = h4(k.i + 2);
+  k.i += 6;
+  if (cp >= 0xD800 && cp <= 0xDBFF) { cp = 0x10000 + ((cp - 0xD800) << 10) + (h4(k.i + 2) - 0xDC00); k.i += 6; }
+  if (cp < 0x80) return (int)cp;
+  if (cp < 0x800) { k.pend = 0x80 | (cp & 63); k.npend = 1; return (int)(0xC0 | (cp >> 6)); }
+  if (cp < 0x10000) { k.pend = (0x80 | ((cp >> 6) & 63)) | ((0x80 | (cp & 63)) << 8); k.npend = 2; return (int)(0xE0 | (cp >> 12)); }
+  k.pend = (0x80 | ((cp >> 12) & 63)) | ((0x80 | ((cp >> 6) & 63)) << 8) | ((0x80 | (cp & 63)) << 16); k.npend = 3;
+  return (int)(0xF0 | (cp >> 18));
+}
+DEV int js_cmp(const u8* s, uint32_t a, uint32_t b) {   // the decoded strings at the opening quotes a and b: <0, 0, >0
+  JsIter x{a + 1, 0, 0}, y{b + 1, 0, 0};
+  for (;;) {
+    const int p = js_next(s, x), q = js_next(s, y);
+    if (p != q) return p - q;      // (-1, the end, sorts first: a prefix is smaller)
+    if (p < 0) return 0;
+  }
+}
+DEV uint32_t js_skip_string(const u8* s, uint32_t i) {   // from the opening quote to behind the closing one
+  for (i++;; i++) { if (s[i] == '"') return i + 1; if (s[i] == '\\') i++; }
+}
+DEV uint32_t js_ws(const u8* s, uint32_t i, uint32_t n) { while (i < n && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) i++; return i; }
+DEV uint32_t js_skip_value(const u8* s, uint32_t i, uint32_t n) {   // from a value's first byte to behind it
+  const uint32_t c = s[i];
+  if (c == '"') return js_skip_string(s, i);
+  if (c == '{' || c == '[') {
+    uint32_t d = 0;
+    for (;;) {
+      const uint32_t x = s[i];
+      if (x == '"') { i = js_skip_string(s, i); continue; }
+      if (x == '{' || x == '[') d++;
+      else if (x == '}' || x == ']') { if (!--d) return i + 1; }
+      i++;
+    }
+  }
+  while (i < n && s[i] != ',' && s[i] != '}' && s[i] != ']' && s[i] != ' ' && s[i] != '\t' && s[i] != '\n' && s[i] != '\r') i++;
+  return i;
+}
+template <class S>
+DEV uint32_t js_put_string(S& out, const u8* s, uint32_t i) {   // the string at the opening quote i, escaped again; returns behind it
+  JsIter k{i + 1, 0, 0};
+  out.put('"');
+  for (;;) {
+    const int b = js_next(s, k);
+    if (b < 0) break;
+    if (b == '"' || b == '\\') { out.put('\\'); out.put((u8)b); }
+    else if (b >= 0x20) out.put((u8)b);
+    else {
+      out.put('\\');
+      if (b == 8) out.put('b'); else if (b == 12) out.put('f'); else if (b == 10) out.put('n'); else if (b == 13) out.put('r'); else if (b == 9) out.put('t');
+      else { out.put('u'); out.put('0'); out.put('0'); out.put((u8)('0' + (b >> 4))); out.put((u8)((b & 15) < 10 ? '0' + (b & 15) : 'a' + (b & 15) - 10)); }
+    }
+  }
+  out.put('"');
+  return k.i + 1;
+}
+template <class S>
+DEV uint32_t json_display(S& out, const u8* s, uint32_t n, bool bq) {
+  uint32_t f_start[kJsonDepth], f_last[kJsonDepth], f_end[kJsonDepth];   // objects: behind '{', the last key written, behind '}'
+  uint32_t is_obj = 0, depth = 0;
+  uint32_t i = js_ws(s, 0, n);
+  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  for (;;) {
+    // ---- one value at i
+    bool opened = false;
+    {
+      const uint32_t c = s[i];
+      if (c == '"') i = js_put_string(out, s, i);
+      else if (c == '{' || c == '[') {
+        if (depth >= kJsonDepth) return JD_HOST;
+        out.put((u8)c);
+        if (c == '{') { is_obj |= 1u << depth; f_start[depth] = i + 1; f_last[depth] = NONE; f_end[depth] = 0; }
+        else {
+          is_obj &= ~(1u << depth);
+          i = js_ws(s, i + 1, n);
+          if (s[i] == ']') { out.put(']'); i++; goto after_value; }   // (depth not raised: an empty array is a value like any other)
+          opened = true;
+        }
+        depth++;
+        if (opened) continue;   // the array's first element sits at i
+      } else if (c == 't' || c == 'f' || c == 'n') { const uint32_t e = js_skip_value(s, i, n); for (; i < e; i++) out.put(s[i]); }
+      else {   // a number
+        const uint32_t e = js_skip_value(s, i, n);
+        bool integer = true;
+        for (uint32_t q = i; q < e; q++) if (s[q] == '.' || s[q] == 'e' || s[q] == 'E') integer = false;
+        if (integer && bq) {   // number.parse::<i64>() / ::<u64>() must succeed
+          const bool neg = s[i] == '-';
+          const uint32_t d0 = i + (neg ? 1 : 0), nd = e - d0;
+          const char* lim = neg ? "9223372036854775808" : "18446744073709551615";
+          const uint32_t nl = neg ? 19 : 20;
+          bool over = nd > nl;
+          if (nd == nl) { for (uint32_t q = 0; q < nl; q++) { if (s[d0 + q] != (u8)lim[q]) { over = s[d0 + q] > (u8)lim[q]; break; } } }
+          if (over) return JD_BQ_INT;
+        }
+        if (e - i == 2 && s[i] == '-' && s[i + 1] == '0') { out.put('0'); i = e; }
+        else for (; i < e; i++) { out.put(s[i]); if ((s[i] == 'e' || s[i] == 'E') && s[i + 1] != '+' && s[i + 1] != '-') out.put('+'); }
+      }
+    }
+    // ---- behind a value (or inside a fresh object): what the innermost open container wants next
+  after_value:
+    for (;;) {
+      if (!depth) return JD_OK;
+      const uint32_t t = depth - 1;
+      if (!((is_obj >> t) & 1u)) {   // array: the text goes on in order
+        i = js_ws(s, i, n);
+        if (s[i] == ',') { out.put(','); i = js_ws(s, i + 1, n); break; }
+        out.put(']'); i++; depth--;
+        continue;
+      }
+      // object: the smallest key above the last one written; of equal keys the last
+      uint32_t p = js_ws(s, f_start[t], n), best = NONE, bestv = 0, members = 0;
+      const uint32_t last = f_last[t];
+      while (s[p] != '}') {
+        if (s[p] == ',') p = js_ws(s, p + 1, n);
+        const uint32_t kq = p;
+        p = js_ws(s, js_skip_string(s, p), n) + 1;   // behind ':'
+        p = js_ws(s, p, n);
+        const uint32_t v = p;
+        p = js_ws(s, js_skip_value(s, p, n), n);
+        if (++members > kJsonMembers) return JD_HOST;
+        if (last == NONE) {   // the first round also looks for the private token ("$serde_json::private::Number" as a key makes from_str read a number)
+          const char* tok = "$serde_json::private::";
+          JsIter it{kq + 1, 0, 0};
+          bool is_tok = true;
+          for (uint32_t q = 0; q < 22 && is_tok; q++) is_tok = js_next(s, it) == (int)tok[q];
+          if (is_tok) return JD_HOST;
+        }
+        if (last != NONE && js_cmp(s, kq, last) <= 0) continue;
+        if (best == NONE || js_cmp(s, kq, best) <= 0) { best = kq; bestv = v; }
+      }
+      f_end[t] = p + 1;
+      if (best == NONE) { out.put('}'); i = f_end[t]; depth--; continue; }
+      if (last != NONE) out.put(',');
+      f_last[t] = best;
+      (void)js_put_string(out, s, best);
+      out.put(':');
+      i = bestv;
+      break;
+    }
+  }
+}
+struct JsCount { uint32_t n = 0; DEV void put(u8) { n++; } };
+
 DEV uint32_t numeric_str_len(const u8* ent);
 DEV uint32_t timetz_str_len(const u8* slot);
 // var-len columns, pass 1: validity / deferred words + the byte length of every row's entry
 // (blk: the block's sum of lengths, for the offsets scan — a launch of its own, k_col_len_blocks, for the callers that have no such pass)
+// JS: the launch has a json column that leaves as its Display string (a kernel of its own: json_display's registers would cost every
+// other table two waves per SIMD)
+template <bool JS>
 DEV void col_lens_body(const ColJob& j, unsigned long long* blk, uint32_t bx, uint64_t* lds_sum) {
   const uint64_t r = (uint64_t)bx * 256 + threadIdx.x;
   const bool live = r < j.n_rows;
@@ -298,18 +474,25 @@ DEV void col_lens_body(const ColJob& j, unsigned long long* blk, uint32_t bx, ui
     const uint64_t b = j.row_base[r];
     st = col_state(j, b);
     // text-form columns hand over DEFERRED entries too (their heap entry is the source text)
-    const bool has = st == ETLG_CELL_VALUE || (j.kind == AK_TEXT_FORM && st == ETLG_CELL_DEFERRED);
+    const bool text_form = j.kind == AK_TEXT_FORM || j.kind == AK_JSON_STR;
+    const bool has = st == ETLG_CELL_VALUE || (text_form && st == ETLG_CELL_DEFERRED);
+    bool json_ok = true;
     if (has && j.cls == ETLG_TC_JSON) {   // "JSON deserialization failed" for the first malformed cell in event order (codec/text.rs:126-134)
       const u8* slot = j.fixed + b + j.off_full;
-      if (!json_valid(j.heap + ld32a(slot), ld32a(slot + 4))) atomicMin(j.err, (unsigned long long)((r << 8) | ETLG_E_JSON));
+      json_ok = json_valid(j.heap + ld32a(slot), ld32a(slot + 4));
+      if (!json_ok) atomicMin(j.err, (unsigned long long)((r << 8) | ETLG_E_JSON));
     }
     if (has) {
       const u8* slot = j.fixed + b + j.off_full;
       len = j.kind == AK_NUMERIC_STR ? numeric_str_len(j.heap + ld32a(slot)) : j.kind == AK_TIMETZ_STR ? timetz_str_len(slot) : ld32a(slot + 4);
+      if (JS && j.kind == AK_JSON_STR && json_ok) {   // the Display string where a lane writes it, the source text handed back DEFERRED where not
+        JsCount c;
+        if (json_display(c, j.heap + ld32a(slot), len, false) == JD_OK) { len = c.n; st = ETLG_CELL_VALUE; }
+      }
     }
     j.lens[r] = len;
   }
-  const bool valid = live && (st == ETLG_CELL_VALUE || (j.kind == AK_TEXT_FORM && st == ETLG_CELL_DEFERRED));
+  const bool valid = live && (st == ETLG_CELL_VALUE || ((j.kind == AK_TEXT_FORM || j.kind == AK_JSON_STR) && st == ETLG_CELL_DEFERRED));
   const bool defer = live && st == ETLG_CELL_DEFERRED;
   const unsigned long long vm = __ballot(valid), dm = __ballot(defer), lm = __ballot(live);
   if ((threadIdx.x & 63) == 0 && lm) {
@@ -321,13 +504,15 @@ DEV void col_lens_body(const ColJob& j, unsigned long long* blk, uint32_t bx, ui
   const uint64_t t = block_sum64(len, lds_sum);
   if (threadIdx.x == 0) blk[bx] = t;
 }
+template <bool JS>
 __global__ __launch_bounds__(256) void k_col_lens(ColJob j, unsigned long long* blk) {
   __shared__ uint64_t lds_sum[4];
-  col_lens_body(j, blk, blockIdx.x, lds_sum);
+  col_lens_body<JS>(j, blk, blockIdx.x, lds_sum);
 }
+template <bool JS>
 __global__ __launch_bounds__(256) void k_col_lens_pack(ColPack p) {
   __shared__ uint64_t lds_sum[4];
-  col_lens_body(p.j[blockIdx.y], p.blk[blockIdx.y], blockIdx.x, lds_sum);
+  col_lens_body<JS>(p.j[blockIdx.y], p.blk[blockIdx.y], blockIdx.x, lds_sum);
 }
 
 // lens (u32) -> offsets (i64), three steps like k_col_count / k_col_scan / k_col_rows
@@ -489,20 +674,76 @@ template <class S> DEV void utc_offset_str(S& s, int32_t off) {   // +HH | +HH:M
 DEV uint32_t timetz_str_len(const u8* slot) { return 8u + time_frac_len(ld32a(slot + 4)) + utc_offset_len((int32_t)ld32a(slot + 8)); }
 template <class S> DEV void timetz_str(S& s, const u8* slot) { time_str(s, ld32a(slot), ld32a(slot + 4)); utc_offset_str(s, (int32_t)ld32a(slot + 8)); }
 
+// The byte pass of a row. One thread writes one row, so a byte store per put() was one write request per BYTE at the L2 (64 lanes,
+// 64 different lines per instruction): k_rb_rows took 469 us for the 47 MB of a cfg3 batch's rows (profiles/r04q). The bytes are
+// collected in a 64-bit accumulator instead and leave eight at a time (unaligned 8-byte stores are fine in global memory); finish()
+// writes the last 1-7 bytes one by one — the next row's first bytes belong to another thread.
+struct RbWrite {
+  u8* p;                // where the accumulator's first byte goes
+  uint64_t acc = 0;
+  uint32_t n = 0;       // bytes in acc (0..7)
+  DEV void store8(uint64_t v) { __builtin_memcpy(p, &v, 8); p += 8; }
+  // appends the low k bytes of v (1 <= k <= 8; the bytes above them are zero)
+  DEV void append(uint64_t v, uint32_t k) {
+    acc |= v << (8u * n);
+    const uint32_t m = n + k;
+    if (m >= 8u) {
+      store8(acc);
+      acc = n ? v >> (8u * (8u - n)) : 0ull;   // what did not fit (n = 0: k = 8, nothing is left)
+      n = m - 8u;
+    } else n = m;
+  }
+  DEV void put(u8 b) { append(b, 1); }
+  DEV void varint64(uint64_t v) { while (v >= 0x80) { put((u8)(v | 0x80)); v >>= 7; } put((u8)v); }
+  DEV void put32(uint32_t v) { append(v, 4); }
+  DEV void put64(uint64_t v) { append(v, 8); }
+  DEV void zeros(uint32_t k) { while (k >= 8u) { append(0ull, 8); k -= 8u; } if (k) append(0ull, k); }
+  DEV void bytes(const u8* s, uint32_t len) {
+    uint32_t k = 0;
+    for (; k + 8u <= len; k += 8u) { uint64_t v; __builtin_memcpy(&v, s + k, 8); append(v, 8); }
+    if (k < len) { uint64_t v = 0; for (uint32_t b = 0; k + b < len; b++) v |= (uint64_t)s[k + b] << (8u * b); append(v, len - k); }
+  }
+  DEV void hex(const u8* s, uint32_t len) {   // bytes_to_hex, lowercase (:176-185)
+    auto h1 = [](uint32_t d) -> uint64_t { return d < 10 ? '0' + d : 'a' + d - 10; };
+    uint32_t k = 0;
+    for (; k + 4u <= len; k += 4u) {   // four bytes -> eight digits
+      uint64_t v = 0;
+      for (uint32_t b = 0; b < 4; b++) { const uint32_t x = s[k + b]; v |= (h1(x >> 4) | (h1(x & 15u) << 8)) << (16u * b); }
+      append(v, 8);
+    }
+    for (; k < len; k++) { const uint32_t x = s[k]; append(h1(x >> 4) | (h1(x & 15u) << 8), 2); }
+  }
+  DEV void finish() { for (uint32_t b = 0; b < n; b++) p[b] = (u8)(acc >> (8u * b)); p += n; n = 0; acc = 0; }
+};
 struct StrWrite { u8* p; DEV void put(u8 b) { *p++ = b; } };
 // formatted string columns (numeric, timetz), pass 2: one thread per row writes its Display string at its offset
+template <bool JS>
 DEV void col_fmt_body(const ColJob& j, uint32_t bx) {
   const uint64_t r = (uint64_t)bx * 256 + threadIdx.x;
   if (r >= j.n_rows || !j.lens[r]) return;
   const u8* slot = j.fixed + j.row_base[r] + j.off_full;
   StrWrite w{j.values + j.offsets[r]};
-  if (j.kind == AK_NUMERIC_STR) numeric_str(w, j.heap + ld32a(slot)); else timetz_str(w, slot);
+  if (j.kind == AK_NUMERIC_STR) numeric_str(w, j.heap + ld32a(slot));
+  else if (j.kind == AK_TIMETZ_STR) timetz_str(w, slot);
+  else if (JS) {   // json: the Display string, or (the rows pass 1 marked DEFERRED) the source text as it is
+    const u8* t = j.heap + ld32a(slot);
+    if ((j.deferred[r >> 6] >> (r & 63)) & 1ull) { for (uint32_t k = 0; k < j.lens[r]; k++) w.put(t[k]); }
+    else {   // through the row formats' writer (eight bytes per store). With StrWrite's byte stores this instantiation faulted on the
+             // MI355X — a store address with its low or high half replaced — while the same function under a bounds-checked byte
+             // writer, under RbWrite in k_rb_rows and on the emulator was right (profiles/r05x_json_arrow_fault.txt): not pursued further.
+      RbWrite rw{w.p};
+      (void)json_display(rw, t, ld32a(slot + 4), false);
+      rw.finish();
+    }
+  }
 }
-__global__ __launch_bounds__(256) void k_col_fmt(ColJob j) { col_fmt_body(j, blockIdx.x); }
+template <bool JS>
+__global__ __launch_bounds__(256) void k_col_fmt(ColJob j) { col_fmt_body<JS>(j, blockIdx.x); }
 // pass 2 of several var-len columns in one launch: a column is copied or formatted by what it is (uniform per blockIdx.y)
+template <bool JS>
 __global__ __launch_bounds__(256) void k_col_var2_pack(ColPack p) {
   const ColJob& j = p.j[blockIdx.y];
-  if (j.kind == AK_NUMERIC_STR || j.kind == AK_TIMETZ_STR) col_fmt_body(j, blockIdx.x); else col_copy_body(j, blockIdx.x);
+  if (j.kind == AK_NUMERIC_STR || j.kind == AK_TIMETZ_STR || j.kind == AK_JSON_STR) col_fmt_body<JS>(j, blockIdx.x); else col_copy_body(j, blockIdx.x);
 }
 
 // ---- array literals (parse_cell_from_postgres_text_array, crates/etl/src/postgres/codec/text.rs:228-312; the dimensions
@@ -708,7 +949,7 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
 
 // ---- ClickHouse RowBinary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83 which wire type a Cell becomes,
 // :188-283 the byte format; core.rs:96-114 the trailing CDC columns). One thread per row, run twice: lengths, then bytes.
-enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3, RB_E_BQ_NUMERIC_SCALE = 4 };
+enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3, RB_E_BQ_NUMERIC_SCALE = 4 /* and the json integer rule: one report */, RB_E_JSON = 5 };
 constexpr int32_t kDate32Min = -25567, kDate32Max = 120529;   // 1900-01-01 .. 2299-12-31 (encoding.rs:147-173)
 
 struct RbCount {
@@ -721,47 +962,6 @@ struct RbCount {
   DEV void bytes(const u8*, uint32_t len) { n += len; }
   DEV void hex(const u8*, uint32_t len) { n += 2 * len; }
 };
-// The byte pass of a row. One thread writes one row, so a byte store per put() was one write request per BYTE at the L2 (64 lanes,
-// 64 different lines per instruction): k_rb_rows took 469 us for the 47 MB of a cfg3 batch's rows (profiles/r04q). The bytes are
-// collected in a 64-bit accumulator instead and leave eight at a time (unaligned 8-byte stores are fine in global memory); finish()
-// writes the last 1-7 bytes one by one — the next row's first bytes belong to another thread.
-struct RbWrite {
-  u8* p;                // where the accumulator's first byte goes
-  uint64_t acc = 0;
-  uint32_t n = 0;       // bytes in acc (0..7)
-  DEV void store8(uint64_t v) { __builtin_memcpy(p, &v, 8); p += 8; }
-  // appends the low k bytes of v (1 <= k <= 8; the bytes above them are zero)
-  DEV void append(uint64_t v, uint32_t k) {
-    acc |= v << (8u * n);
-    const uint32_t m = n + k;
-    if (m >= 8u) {
-      store8(acc);
-      acc = n ? v >> (8u * (8u - n)) : 0ull;   // what did not fit (n = 0: k = 8, nothing is left)
-      n = m - 8u;
-    } else n = m;
-  }
-  DEV void put(u8 b) { append(b, 1); }
-  DEV void varint64(uint64_t v) { while (v >= 0x80) { put((u8)(v | 0x80)); v >>= 7; } put((u8)v); }
-  DEV void put32(uint32_t v) { append(v, 4); }
-  DEV void put64(uint64_t v) { append(v, 8); }
-  DEV void zeros(uint32_t k) { while (k >= 8u) { append(0ull, 8); k -= 8u; } if (k) append(0ull, k); }
-  DEV void bytes(const u8* s, uint32_t len) {
-    uint32_t k = 0;
-    for (; k + 8u <= len; k += 8u) { uint64_t v; __builtin_memcpy(&v, s + k, 8); append(v, 8); }
-    if (k < len) { uint64_t v = 0; for (uint32_t b = 0; k + b < len; b++) v |= (uint64_t)s[k + b] << (8u * b); append(v, len - k); }
-  }
-  DEV void hex(const u8* s, uint32_t len) {   // bytes_to_hex, lowercase (:176-185)
-    auto h1 = [](uint32_t d) -> uint64_t { return d < 10 ? '0' + d : 'a' + d - 10; };
-    uint32_t k = 0;
-    for (; k + 4u <= len; k += 4u) {   // four bytes -> eight digits
-      uint64_t v = 0;
-      for (uint32_t b = 0; b < 4; b++) { const uint32_t x = s[k + b]; v |= (h1(x >> 4) | (h1(x & 15u) << 8)) << (16u * b); }
-      append(v, 8);
-    }
-    for (; k < len; k++) { const uint32_t x = s[k]; append(h1(x >> 4) | (h1(x & 15u) << 8), 2); }
-  }
-  DEV void finish() { for (uint32_t b = 0; b < n; b++) p[b] = (u8)(acc >> (8u * b)); p += n; n = 0; acc = 0; }
-};
 
 template <class S>
 DEV void rb_varint(S& s, uint32_t v) {   // LEB128 (:188-199)
@@ -772,9 +972,23 @@ DEV void rb_varint(S& s, uint32_t v) {   // LEB128 (:188-199)
 template <class S>
 DEV void rb_2d(S& s, uint32_t v) { put_2d(s, v); }
 
+// A json cell as the sinks' `j.to_string()`: `head(len)` writes what goes in front of the string (its varint length). The text is
+// checked in the counting pass only (a row that fails has length 0 and is not written). Returns 0, RB_E_JSON (not one JSON value: the
+// reference fails at decode time, codec/text.rs:126-134), RB_E_HOST_CELL (json_display leaves it to the host), RB_E_BQ_NUMERIC_SCALE.
+template <class S, class H>
+DEV uint32_t rb_json(S& s, const u8* t, uint32_t tn, bool bq, H head) {
+  if (std::is_same<S, RbCount>::value && !json_valid(t, tn)) return RB_E_JSON;
+  JsCount c;
+  const uint32_t e = json_display(c, t, tn, bq);
+  if (e) return e == JD_BQ_INT ? RB_E_BQ_NUMERIC_SCALE : RB_E_HOST_CELL;
+  head(c.n);
+  if (std::is_same<S, RbCount>::value) s.zeros(c.n); else (void)json_display(s, t, tn, false);
+  return 0;
+}
+
 // One non-null value of class `cls` whose arena slot words start at `slot` (a row's slot, or the words decode_text_cell produced for
 // an array element). Returns 0, RB_E_DATE_RANGE or RB_E_HOST_CELL.
-template <class S>
+template <bool JS = false, class S>
 DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
   const uint32_t w0 = ld32a(slot);
   switch (cls) {
@@ -803,7 +1017,8 @@ DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
       return 0;
     case ETLG_TC_STRING: if (!heap) return RB_E_HOST_CELL; { const uint32_t len = ld32a(slot + 4); rb_varint(s, len); s.bytes(heap + w0, len); return 0; }
     case ETLG_TC_BYTEA: if (!heap) return RB_E_HOST_CELL; { const uint32_t len = ld32a(slot + 4); rb_varint(s, 2 * len); s.hex(heap + w0, len); return 0; }
-    default: return RB_E_HOST_CELL;   // json: serde_json's normalised Display, the host writes it
+    case ETLG_TC_JSON: if (!JS || !heap) return RB_E_HOST_CELL; return rb_json(s, heap + w0, ld32a(slot + 4), false, [&](uint32_t len) { rb_varint(s, len); });   // String(j.to_string()) (:73)
+    default: return RB_E_HOST_CELL;
   }
 }
 
@@ -821,13 +1036,14 @@ DEV uint32_t rb_default_zero_bytes(uint32_t cls) {
   return n;
 }
 
-template <class S>
+template <bool JS, class S>
 DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or column << 8 | code of the cell that fails the row
   // The reference converts every cell of every pending row first (cell_to_clickhouse_value, clickhouse/core.rs:1193-1203: Date32
   // range errors) and only then encodes the rows (NULL in a non-nullable column): a range error anywhere beats a NULL error. So a
   // row that meets a cell without an encoding goes on looking for a date out of range; k_rb_lens ranks range errors first across rows.
+  // A json cell that is not one JSON value fails earlier still — at decode time in the reference — so it beats both.
   const uint64_t base = j.row_base[r];
-  uint32_t err0 = 0;
+  uint32_t err0 = 0, errd = 0;
   // A Delete that carries only the key becomes the tombstone expand_key_row builds (clickhouse/core.rs:1437-1472): the key cells in
   // the primary-key columns, NULL in every other column that is nullable at the source and not an array, default_cell's zero value
   // (:1481-1517) in the rest. The host selects such rows only where the reference accepts them (host_handoff.inc).
@@ -875,17 +1091,19 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
         const uint32_t e1 = rb_scalar(s, elem, (const u8*)w, nullptr);
         if (e1 && !ee) ee = e1;
       }, none);
-      if (ee == RB_E_DATE_RANGE) return (i << 8) | ee;
-      if (ee && !err0) err0 = (i << 8) | ee;
+      if (ee == RB_E_DATE_RANGE) { if (!errd) errd = (i << 8) | ee; }
+      else if (ee && !err0) err0 = (i << 8) | ee;
       continue;
     }
-    if (st != ETLG_CELL_VALUE) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
+    if (st != ETLG_CELL_VALUE && !(cls == ETLG_TC_JSON && st == ETLG_CELL_DEFERRED)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }   // (json cells are source text in the arena: DEFERRED)
     if (nullable) s.put(0);
-    if (const uint32_t e = rb_scalar(s, cls, slot, j.heap)) {
-      if (e == RB_E_DATE_RANGE) return (i << 8) | e;
-      if (!err0) err0 = (i << 8) | e;
+    if (const uint32_t e = rb_scalar<JS>(s, cls, slot, j.heap)) {
+      if (e == RB_E_JSON) return (i << 8) | e;
+      if (e == RB_E_DATE_RANGE) { if (!errd) errd = (i << 8) | e; }
+      else if (!err0) err0 = (i << 8) | e;
     }
   }
+  if (errd) return errd;
   if (err0) return err0;
   // trailing CDC columns (core.rs:96-114); never NULL, a Nullable() destination column still takes its marker byte
   const uint64_t ev = j.row_event[r];
@@ -927,12 +1145,13 @@ template <class S> DEV void pb_date(S& s, int32_t days_ce) {
   const int64_t y = (int64_t)yoe + era * 400 + (m <= 2 ? 1 : 0);
   pb_4d(s, (uint32_t)y); s.put('-'); rb_2d(s, m); s.put('-'); rb_2d(s, d);
 }
-template <class S>
+template <bool JS, class S>
 DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
   // (the row's kind sits in the top bits of its base: ColSel / pb_selected)
   const unsigned long long rbase = j.row_base[r];
   const bool del = (rbase & kPbDelete) != 0, keyimg = (rbase & kPbKey) != 0;
   const uint64_t base = rbase & kPbBase;
+  uint32_t err0 = 0;
   for (uint32_t i = 0; i < j.n_cols; i++) {
     const uint32_t cd = j.cols[i], cls = cd & 0xFF, tag = i + 1;
     uint32_t off = cd >> 16, sti = i;
@@ -943,7 +1162,7 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
     }
     const uint32_t st = (j.fixed[base + sti / 4] >> (2 * (sti % 4))) & 3u;
     if (st == ETLG_CELL_NULL) continue;                       // Cell::Null => {}
-    if (st != ETLG_CELL_VALUE) return (i << 8) | RB_E_HOST_CELL;
+    if (st != ETLG_CELL_VALUE && !(cls == ETLG_TC_JSON && st == ETLG_CELL_DEFERRED)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
     const u8* slot = j.fixed + base + off;
     const uint32_t w0 = ld32a(slot);
     switch (cls) {
@@ -975,12 +1194,21 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
       case ETLG_TC_TIMETZ: pb_key(s, tag, 2); s.varint64(timetz_str_len(slot)); timetz_str(s, slot); break;   // t.to_string() (:158-161)
       case ETLG_TC_NUMERIC: {  // n.to_string() (:146-149) behind validate_numeric_for_bigquery (bigquery/validation.rs:20-35): more than 38 decimal places would be rounded
         const u8* ent = j.heap + w0;
-        if (ent[0] == ETLG_NUM_VALUE && ((uint32_t)ent[4] | ((uint32_t)ent[5] << 8)) > 38u) return (i << 8) | RB_E_BQ_NUMERIC_SCALE;
+        if (ent[0] == ETLG_NUM_VALUE && ((uint32_t)ent[4] | ((uint32_t)ent[5] << 8)) > 38u) { if (!err0) err0 = (i << 8) | RB_E_BQ_NUMERIC_SCALE; break; }
         pb_key(s, tag, 2); s.varint64(numeric_str_len(ent)); numeric_str(s, ent); break;
       }
-      default: return (i << 8) | RB_E_HOST_CELL;   // json / arrays: serde_json's Display, packed / repeated fields, host-side validation
+      case ETLG_TC_JSON: {  // j.to_string() (:173-176) behind validate_json_for_bigquery (bigquery/validation.rs:47-85)
+        if (!JS) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; break; }
+        if (const uint32_t e = rb_json(s, j.heap + w0, ld32a(slot + 4), true, [&](uint32_t len) { pb_key(s, tag, 2); s.varint64(len); })) {
+          if (e == RB_E_JSON) return (i << 8) | e;   // (the reference's decode fails before the sink validates anything: it beats an earlier cell's report)
+          if (!err0) err0 = (i << 8) | e;
+        }
+        break;
+      }
+      default: if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; break;   // arrays: packed / repeated fields, host-side validation
     }
   }
+  if (err0) return err0;
   const uint64_t ev = j.row_event[r];
   pb_key(s, j.n_cols + 1, 2); s.varint64(6);
   { const char* op = del ? "DELETE" : "UPSERT"; for (int k = 0; k < 6; k++) s.put((u8)op[k]); }
@@ -989,25 +1217,32 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
   return 0;
 }
 
+// JS: the table has a json column (kernels of their own, as for the Arrow columns)
+template <bool JS>
 __global__ __launch_bounds__(256) void k_rb_lens(RbJob j, unsigned long long* blk) {
   __shared__ uint64_t lds_sum[4];
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   RbCount c;
   if (r < j.n_rows) {
-    const uint32_t e = j.format ? pb_row(j, r, c) : rb_row(j, r, c);
+    const uint32_t e = j.format ? pb_row<JS>(j, r, c) : rb_row<JS>(j, r, c);
     // first failing row in event order, rows with a date out of range before all others (bit 62 clear)
-    if (e) { atomicMin(j.err, (((e & 0xFFu) == RB_E_DATE_RANGE || j.format) ? 0ull : 1ull << 62) | (unsigned long long)((r << 24) | e)); c.n = 0; }
+    // (and a json cell that is not JSON before those: the reference's decode fails before any sink sees a row)
+    if (e) {
+      const unsigned long long rank = (e & 0xFFu) == RB_E_JSON ? 0ull : ((e & 0xFFu) == RB_E_DATE_RANGE || j.format) ? 1ull << 61 : 1ull << 62;
+      atomicMin(j.err, rank | (unsigned long long)((r << 24) | e)); c.n = 0;
+    }
     j.lens[r] = c.n;
   }
   const uint64_t t = block_sum64(c.n, lds_sum);   // (the block's sum for the offsets scan)
   if (threadIdx.x == 0) blk[blockIdx.x] = t;
 }
 
+template <bool JS>
 __global__ __launch_bounds__(256) void k_rb_rows(RbJob j) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= j.n_rows || !j.lens[r]) return;
   RbWrite w{j.out + j.offsets[r]};
-  if (j.format) (void)pb_row(j, r, w); else (void)rb_row(j, r, w);
+  if (j.format) (void)pb_row<JS>(j, r, w); else (void)rb_row<JS>(j, r, w);
   w.finish();
 }
 
@@ -1101,12 +1336,14 @@ void etlg_k_col_var_pack(const void* jobs, uint32_t n, unsigned long long* const
   if (!n || !j[0].n_rows) return;
   const uint32_t nb = (uint32_t)((j[0].n_rows + 255) / 256);
   ColPack p; fill_pack(p, j, n, blk, offs, tot);
+  bool js = false;
+  for (uint32_t i = 0; i < n; i++) js |= j[i].kind == AK_JSON_STR;
   if (step == 0) {
-    hipLaunchKernelGGL(k_col_lens_pack, dim3(nb, n), dim3(256), 0, st, p);
+    if (js) hipLaunchKernelGGL(k_col_lens_pack<true>, dim3(nb, n), dim3(256), 0, st, p); else hipLaunchKernelGGL(k_col_lens_pack<false>, dim3(nb, n), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_col_len_scan_pack, dim3(n), dim3(256), 0, st, p, nb);
     hipLaunchKernelGGL(k_col_offsets_pack, dim3(nb, n), dim3(256), 0, st, p);
   } else {
-    hipLaunchKernelGGL(k_col_var2_pack, dim3(nb, n), dim3(256), 0, st, p);
+    if (js) hipLaunchKernelGGL(k_col_var2_pack<true>, dim3(nb, n), dim3(256), 0, st, p); else hipLaunchKernelGGL(k_col_var2_pack<false>, dim3(nb, n), dim3(256), 0, st, p);
   }
 }
 
@@ -1116,11 +1353,12 @@ void etlg_k_col_var(const void* jv, unsigned long long* blk, int64_t* offsets, i
   if (!j.n_rows) return;
   const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
   if (step == 0) {
-    hipLaunchKernelGGL(k_col_lens, dim3(nb), dim3(256), 0, st, j, blk);
+    if (j.kind == AK_JSON_STR) hipLaunchKernelGGL(k_col_lens<true>, dim3(nb), dim3(256), 0, st, j, blk); else hipLaunchKernelGGL(k_col_lens<false>, dim3(nb), dim3(256), 0, st, j, blk);
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
     hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets, (unsigned long long*)nullptr);
   } else {
-    if (j.kind == AK_NUMERIC_STR || j.kind == AK_TIMETZ_STR) hipLaunchKernelGGL(k_col_fmt, dim3(nb), dim3(256), 0, st, j);
+    if (j.kind == AK_JSON_STR) hipLaunchKernelGGL(k_col_fmt<true>, dim3(nb), dim3(256), 0, st, j);
+    else if (j.kind == AK_NUMERIC_STR || j.kind == AK_TIMETZ_STR) hipLaunchKernelGGL(k_col_fmt<false>, dim3(nb), dim3(256), 0, st, j);
     else hipLaunchKernelGGL(k_col_copy, dim3((uint32_t)((j.n_rows + 255) / 256)), dim3(256), 0, st, j);
   }
 }
@@ -1155,11 +1393,11 @@ void etlg_k_rowbinary(const void* jv, unsigned long long* blk, int64_t* offsets,
   if (!j.n_rows) return;
   const uint32_t nb = (uint32_t)((j.n_rows + 255) / 256);
   if (step == 0) {
-    hipLaunchKernelGGL(k_rb_lens, dim3(nb), dim3(256), 0, st, j, blk);
+    if (j.has_json) hipLaunchKernelGGL(k_rb_lens<true>, dim3(nb), dim3(256), 0, st, j, blk); else hipLaunchKernelGGL(k_rb_lens<false>, dim3(nb), dim3(256), 0, st, j, blk);
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
     hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets, tot);
   } else {
-    hipLaunchKernelGGL(k_rb_rows, dim3(nb), dim3(256), 0, st, j);
+    if (j.has_json) hipLaunchKernelGGL(k_rb_rows<true>, dim3(nb), dim3(256), 0, st, j); else hipLaunchKernelGGL(k_rb_rows<false>, dim3(nb), dim3(256), 0, st, j);
   }
 }
 

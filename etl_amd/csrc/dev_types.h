@@ -256,6 +256,7 @@ struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
   const uint8_t* ev_flags;
   uint32_t* lens; const int64_t* offsets; uint8_t* out;
   unsigned long long* err;         // min over failing cells of (row << 24 | column << 8 | code); ~0 = none
+  uint32_t has_json;               // the table has a json / jsonb column: the kernels that carry json_display
 };
 
 

@@ -60,11 +60,13 @@ class Batch:
             v = self.view()
         return HostBatch.from_view(v)
 
-    def columns(self, slot, kinds=("I",), on_device=False, parse_arrays=False):
+    def columns(self, slot, kinds=("I",), on_device=False, parse_arrays=False, format_json=False):
         """Arrow-layout column buffers of the rows decoded against schema slot `slot`, built on the device
         (etlg_batch_columns). The batch must still be device-resident. parse_arrays: bool / int2 / int4 / int8 / oid array
-        columns are parsed on the device into list columns (abi.AK_LIST); a malformed literal raises the reference's error."""
-        rk = (abi.ROWS_INSERT if "I" in kinds else 0) | (abi.ROWS_UPDATE if "U" in kinds else 0) | (abi.ROWS_PARSE_ARRAYS if parse_arrays else 0)
+        columns are parsed on the device into list columns (abi.AK_LIST); a malformed literal raises the reference's error.
+        format_json: json / jsonb columns leave as LargeUtf8 of serde_json's `Value::to_string()` (abi.ROWS_FORMAT_JSON)."""
+        rk = ((abi.ROWS_INSERT if "I" in kinds else 0) | (abi.ROWS_UPDATE if "U" in kinds else 0) | (abi.ROWS_PARSE_ARRAYS if parse_arrays else 0)
+              | (abi.ROWS_FORMAT_JSON if format_json else 0))
         out = C.c_void_p()
         rc = self.dec.L.etlg_batch_columns(self.dec.h, self.h, slot, rk, abi.F_OUTPUT_ON_DEVICE if on_device else 0, C.byref(out))
         if rc != abi.OK or not out:

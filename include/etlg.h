@@ -615,6 +615,14 @@ typedef struct etlg_columns etlg_columns;
                                    * rule does not settle) precedes the first malformed one: then the call succeeds and the
                                    * malformed rows are handed back too, so that the consumer, finishing the deferred rows in event
                                    * order, meets the first problem first */
+#define ETLG_ROWS_FORMAT_JSON 8u  /* json / jsonb columns become ETLG_AK_LARGE_UTF8 of serde_json's `Value::to_string()` — what the sinks
+                                   * write (`Cell::Json(j) => j.to_string()`: iceberg/encoding.rs:356, ducklake/encoding.rs:173): compact,
+                                   * object members in the byte order of their decoded keys with the last of repeated keys, strings escaped
+                                   * again, number literals kept (an unsigned exponent gains '+': codec/text.rs:812-815). A cell beyond what
+                                   * a lane does (nesting deeper than 16, an object of more than 64 members) keeps its source text and its
+                                   * bit in `deferred`, like every cell of an ETLG_AK_TEXT_FORM column; a cell that is not one JSON value
+                                   * fails the call with ETLG_E_JSON as without the flag. etlg_batch_rowbinary / _protobuf always write
+                                   * the Display string (and report such a cell as host_event / host_column). */
 
 /* `batch` must be device-resident (decoded with ETLG_F_OUTPUT_ON_DEVICE, not downloaded) and finished
  * (an ETLG_F_ASYNC batch is synced first). flags: ETLG_F_OUTPUT_ON_DEVICE keeps the buffers in HBM, otherwise
@@ -636,9 +644,11 @@ void etlg_columns_free(etlg_columns* cols);
  * refuses or the device does not build (a Partial update, key-only Deletes of other slots) are left out and counted in n_host_rows.
  * Columns of class numeric / timetz / time are Display strings in the reference (`n.to_string()`, encoding.rs:66-71): they are
  * formatted on the device (PgNumeric Display, crates/etl-postgres/src/numeric.rs:460-560; PgTimeTz, etl-postgres/src/time.rs:113-117,
- * 210-225). A slot with a json column (serde_json's normalised Display) or an array of numeric / timetz / json / text elements, or
- * a DEFERRED scalar cell / an array literal the device cannot take apart in a row, makes the call return status
- * ETLG_RB_NEEDS_HOST (no bytes). Arrays of fixed-width elements are encoded as Array(Nullable(T)). */
+ * 210-225); so is a json / jsonb cell (`j.to_string()`, encoding.rs:73: serde_json's Display, see ETLG_ROWS_FORMAT_JSON — a cell that
+ * is not one JSON value fails the call with ETLG_E_JSON at its event, the reference's decode error, before any report of the sink's own).
+ * A slot with an array of numeric / timetz / json / text elements, or a DEFERRED scalar cell / an array literal the device cannot take
+ * apart / a json cell beyond json_display's limits in a row, makes the call return status ETLG_RB_NEEDS_HOST (no bytes; host_event /
+ * host_column name the first such cell). Arrays of fixed-width elements are encoded as Array(Nullable(T)). */
 typedef enum etlg_ch_engine {
   ETLG_CH_MERGE_TREE = 0,           /* + cdc_operation String, cdc_lsn UInt64 */
   ETLG_CH_REPLACING_MERGE_TREE = 1  /* + _etl_version UInt128 (commit_lsn << 64 | tx_ordinal), _etl_deleted UInt8 */
@@ -685,8 +695,11 @@ int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_sl
  * equality of the arena's words / bytes (float4 / float8, numeric, timetz), or a primary-key cell is DEFERRED.
  * numeric / timetz cells are their Display strings, a numeric with more than 38 decimal places fails the
  * call like validate_numeric_for_bigquery (bigquery/validation.rs:20-35: ETLG_UnsupportedValueInDestination, "Cell validation failed
- * for BigQuery compatibility", detail "Cell at index N failed validation", frame_index = the event). json / array columns
- * (serde_json Display, packed / repeated fields, host-side validation) and DEFERRED cells return ETLG_RB_NEEDS_HOST.
+ * for BigQuery compatibility", detail "Cell at index N failed validation", frame_index = the event). A json / jsonb cell is its
+ * serde_json Display string (encoding.rs:173-176) behind validate_json_for_bigquery (validation.rs:47-85): an integer literal of the
+ * parsed value outside u64 / i64 fails the call the same way; a cell that is not one JSON value fails it with ETLG_E_JSON. Array
+ * columns (packed / repeated fields, host-side validation), DEFERRED cells and json cells beyond json_display's limits return
+ * ETLG_RB_NEEDS_HOST.
  * The result is an etlg_rowbinary (same view; n_rows can exceed the number of events). */
 int32_t etlg_batch_protobuf(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t flags, etlg_rowbinary** out);
 int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out);

@@ -84,6 +84,15 @@ def cell(c, tag):
     if k == "Uuid":
         h = c[1].hex()
         return ld(tag, f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:]}".encode())
+    if k == "Deferred" and c[1] in (114, 3802):      # validate_json_for_bigquery, then j.to_string() (encoding.rs:173-176)
+        from oracle import json_display
+        if not json_display.device_limits_ok(c[2]):
+            raise NeedsHost("json beyond json_display's limits")
+        try:
+            validate_json_for_bigquery(c[2])
+        except UnsupportedValueInDestination:
+            raise UnsupportedValueInDestination(f"Cell at index {tag - 1} failed validation") from None
+        return ld(tag, json_display.display(c[2]))
     raise NeedsHost(k)
 
 
@@ -107,14 +116,12 @@ def validate_json_for_bigquery(text):
     """validate_json_for_bigquery / validate_json_number_for_bigquery (bigquery/validation.rs:44-93) on the cell's JSON text (the
     reference parses with serde_json's arbitrary_precision: a number keeps its literal): an integer literal — no '.', 'e', 'E' —
     outside i64 (when negative) / u64 would be stored as FLOAT64 and is refused; everything else is left to BigQuery."""
-    import json
-
-    def integer(lit):
-        v = int(lit)
-        if (lit.startswith("-") and not (-(1 << 63) <= v < (1 << 63))) or (not lit.startswith("-") and not (0 <= v < (1 << 64))):
-            raise UnsupportedValueInDestination("JSON integer would lose precision in BigQuery")
-        return v
-    json.loads(text, parse_int=integer, parse_float=lambda lit: lit, parse_constant=lambda lit: lit)
+    from oracle import json_display
+    for lit in json_display.numbers(json_display.parse(text)):   # the PARSED value: what a repeated key lost is not looked at
+        if not any(ch in lit for ch in ".eE"):
+            v = int(lit)
+            if (lit.startswith("-") and not (-(1 << 63) <= v < (1 << 63))) or (not lit.startswith("-") and not (0 <= v < (1 << 64))):
+                raise UnsupportedValueInDestination("JSON integer would lose precision in BigQuery")
 
 
 def validate_array_for_bigquery(elem_kind, elems, cell_index=0):

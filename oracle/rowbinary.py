@@ -22,6 +22,7 @@ from oracle.display import numeric_string, time_string, timetz_string   # noqa: 
 MERGE_TREE, REPLACING_MERGE_TREE = 0, 1
 # array types whose element class the device encodes: bool int2 int4 int8 oid float4 float8 date time timestamp timestamptz uuid
 ARRAY_OIDS = {1000, 1005, 1007, 1016, 1028, 1021, 1022, 1182, 1183, 1115, 1185, 2951}
+JSON_OIDS = {114, 3802}
 CE_DAYS_1970 = 719163
 DATE32_MIN, DATE32_MAX = -25567, 120529        # 1900-01-01, 2299-12-31 as days since 1970-01-01
 
@@ -87,6 +88,11 @@ def value(cell):
         return string(cell[1].hex().encode())
     if k == "String":
         return string(cell[1])
+    if k == "Deferred" and cell[1] in JSON_OIDS:    # json cells keep their text in the arena: String(j.to_string()) (encoding.rs:73)
+        from oracle import json_display
+        if not json_display.device_limits_ok(cell[2]):
+            raise NeedsHost("json beyond json_display's limits")
+        return string(json_display.display(cell[2]))
     if k == "Deferred" and cell[1] in ARRAY_OIDS:   # array columns keep their literal in the arena
         return array(cell[1], cell[2])
     if k == "EmptyArray":                            # default_cell of an array column: varint count 0 (encoding.rs:249-254)

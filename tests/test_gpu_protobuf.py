@@ -49,7 +49,7 @@ def test_host_only_classes_and_deferred_cells():
     buf, offs = _stream([W.insert(42, SC.alltypes_row())])
     hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
     r = b.protobuf(0)
-    assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == [c[0] for c in SC.ALLTYPES].index("j")
+    assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == [c[0] for c in SC.ALLTYPES].index("arr")   # (the json column is written on the device: tests/test_gpu_json_display.py)
     r.close(); b.close(); d.close()
     cols = [("id", SC.INT8, False, 1), ("x", SC.FLOAT8, True, 0)]
     buf, offs = _stream([W.insert(42, ["1", "1.5"]), W.insert(42, ["2", "50537618.817359292015891086651596749e82"])])
@@ -169,8 +169,8 @@ def test_numeric_with_more_than_38_decimal_places_fails_like_the_reference():
 def test_reference_pinned_cell_encodings_on_the_device():
     """The vectors the reference's own tests hold (tests/golden/bigquery_kats.py, encoding.rs:451-496) through etlg_batch_protobuf, against
     LITERAL bytes: a timestamptz cell is the int64 varint of its epoch microseconds; a numeric with 38 decimal places is its text, one with
-    39 fails the batch with the reference's kind and detail. (Arrays and json leave the device as NEEDS_HOST: their packed / validated forms
-    are pinned on the oracle only.)"""
+    39 fails the batch with the reference's kind and detail; a json integer literal outside u64 fails the same way. (Arrays leave the
+    device as NEEDS_HOST: their packed forms are pinned on the oracle only.)"""
     from etl_amd.decoder import EtlError
     from tests.golden import bigquery_kats as K
     cols = [("ts", SC.TIMESTAMPTZ, False, 1), ("v", SC.NUMERIC, True, 0)]
@@ -191,12 +191,23 @@ def test_reference_pinned_cell_encodings_on_the_device():
         b.protobuf(0)
     assert ei.value.kind == abi.UnsupportedValueInDestination and ei.value.detail == "Cell at index 1 failed validation"
     b.close(); d.close()
-    for col, text in ((("a", SC.INT4_A, True, 0), "{1,NULL,3}"), (("j", SC.JSONB, True, 0), K.JSON_REFUSED[0])):
+    buf, offs = _stream([W.insert(42, ["1", "{1,NULL,3}"])])
+    hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", SC.INT4_A, True, 0)]), buf, offs)
+    r = b.protobuf(0)
+    assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == 1
+    r.close(); b.close(); d.close()
+    for text in K.JSON_REFUSED:                        # encoding.rs:353-360
         buf, offs = _stream([W.insert(42, ["1", text])])
-        hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), col]), buf, offs)
-        r = b.protobuf(0)
-        assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == 1
-        r.close(); b.close(); d.close()
+        hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("j", SC.JSONB, True, 0)]), buf, offs)
+        with pytest.raises(EtlError) as ei:
+            b.protobuf(0)
+        assert ei.value.kind == abi.UnsupportedValueInDestination and ei.value.detail == "Cell at index 1 failed validation"
+        b.close(); d.close()
+    buf, offs = _stream([W.insert(42, ["1", K.JSON_ACCEPTED[0]])])      # encoding.rs:344-351: {"value":1e309} is BigQuery's to judge
+    hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("j", SC.JSONB, True, 0)]), buf, offs)
+    r = b.protobuf(0)
+    assert r.status == abi.RB_OK and r.bytes().tobytes().startswith(bytes([0x08, 1, 0x12, 16]) + b'{"value":1e+309}')   # (Display as codec/text.rs:812-815 has it)
+    r.close(); b.close(); d.close()
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

@@ -106,11 +106,16 @@ def test_date_out_of_range_fails_like_the_reference():
 
 
 def test_cells_and_rows_that_stay_with_the_host():
-    # a json column: the whole slot is the host's (serde_json's normalised Display)
+    # every class of the all-types table is written on the device — the json cell as serde_json's Display (tests/test_gpu_json_display.py) ...
     buf, offs = _stream([W.insert(42, SC.alltypes_row())])
     hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
+    assert _check(hb, b, [1] * len(SC.ALLTYPES) + [0, 0], abi.CH_MERGE_TREE) == 1
+    b.close(); d.close()
+    # ... but a json cell nested deeper than a lane follows stays with the host, reported with its event and column
+    buf, offs = _stream([W.insert(42, SC.alltypes_row()), W.insert(42, SC.alltypes_row(id="2", j="[" * 17 + "]" * 17))])
+    hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
     r = b.rowbinary(0, [1] * len(SC.ALLTYPES) + [0, 0])
-    assert r.status == abi.RB_NEEDS_HOST and r.n_rows == 0 and r.view.host_column == [c[0] for c in SC.ALLTYPES].index("j")
+    assert r.status == abi.RB_NEEDS_HOST and r.n_rows == 0 and (int(r.view.host_event), r.view.host_column) == (2, [c[0] for c in SC.ALLTYPES].index("j"))
     r.close(); b.close(); d.close()
     # a DEFERRED float: reported with its event and column
     cols = [("id", SC.INT8, False, 1), ("x", SC.FLOAT8, True, 0)]

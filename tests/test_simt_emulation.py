@@ -61,7 +61,7 @@ _JOBS = {
     "shard_async": _pytest_job(["tests/test_shard_decode.py", "tests/test_gpu_async.py", "-k", "not 8-"], 900),
     "copy_scan": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k", "not device_resident and not device_input and not 16777216"], 600),
     "plans": _pytest_job(["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or k_plan or prepass or (cfg2 and default)"], 900),
-    "hand_off": _pytest_job(["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py"], 600),
+    "hand_off": _pytest_job(["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py", "tests/test_gpu_json_display.py"], 600),
     "lane_order": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_protobuf.py",
                                "-k", "not device_resident and not device_input and not 16777216 and not synthetic and not kat_ and not random"], 600, order="shuffle"),
     "plans_shuffled": _pytest_job(["tests/test_gpu_fixed_plan.py", "-k", "prepass or conforming or mix_in_one_launch"], 900, order="shuffle"),

@@ -191,6 +191,16 @@ def main():
                     cc.close()
                 except Exception as ex:
                     got_cols = ("err", getattr(ex, "code", None), getattr(ex, "frame_index", None))
+            got_json = None
+            if name == "jsonb" and want[0] == 0 and got[0] == 0:   # the json column as serde_json's Display strings (ETLG_ROWS_FORMAT_JSON)
+                try:
+                    cc = b.columns(0, format_json=True)
+                    _v, dfr, vals, oo = cc.host_arrays(1)
+                    data = vals.tobytes()
+                    got_json = ("ok", [data[oo[k]:oo[k + 1]] for k in range(len(texts))], list(np.unpackbits(dfr, bitorder="little")[:len(texts)]))
+                    cc.close()
+                except Exception as ex:
+                    got_json = ("err", getattr(ex, "code", None), getattr(ex, "frame_index", None))
             got_pb = None
             if want[0] == 0 and got[0] == 0:
                 try:
@@ -217,6 +227,16 @@ def main():
                     firstbad = next((i for i, v in enumerate(verdicts) if v.startswith("Err(")), None)
                     if firstbad is not None:
                         want_cols = ("err", int(verdicts[firstbad][4:-1]), firstbad + 1)
+                if name == "jsonb":
+                    from oracle import json_display as JD
+                    if firstbad is not None:
+                        want_json = want_cols
+                    else:
+                        lim = [JD.device_limits_ok(t) for t in texts]
+                        want_json = ("ok", [JD.display(t) if k else t.encode() for t, k in zip(texts, lim)], [0 if k else 1 for k in lim])
+                    if want_json != got_json:
+                        ok = False
+                        diff = ["json columns", str(want_json)[:300], str(got_json)[:300]]
                 if isinstance(want_cols, tuple) or isinstance(got_cols, tuple):
                     if want_cols != got_cols:
                         ok = False
@@ -231,6 +251,8 @@ def main():
                 # BigQuery rows of the same arena (cell_encode_prost; numeric scale validation)
                 from oracle import protobuf as PB
                 try:
+                    if name == "jsonb" and firstbad is not None:
+                        raise PB.UnsupportedValueInDestination("JSON deserialization failed")   # (the decode error, as the device words it)
                     rows, idx, host = PB.event_rows(hb.materialize(), 0, cols, "PrimaryKey")
                     want_pb = ("ok", b"".join(rows))
                 except PB.UnsupportedValueInDestination as ue:
@@ -240,9 +262,11 @@ def main():
                 if want_pb != got_pb:
                     ok = False
                     diff = ["protobuf", want_pb[0], got_pb[0] if got_pb else None, (want_pb[1] or b"")[:80], (got_pb[1] or b"")[:80] if got_pb else None]
-            if ok and name in ("numeric", "timetz", "time", "timestamptz", "timestamp", "date", "float8", "uuid", "bytea", "int4[]", "float8[]", "date[]", "timestamptz[]", "time[]", "uuid[]") and want[0] == 0:
+            if ok and name in ("jsonb", "numeric", "timetz", "time", "timestamptz", "timestamp", "date", "float8", "uuid", "bytea", "int4[]", "float8[]", "date[]", "timestamptz[]", "time[]", "uuid[]") and want[0] == 0:
                 # the hand-off of the same arena (Display strings, Date32 range, arrays): RowBinary bytes against the oracle's encoder
                 try:
+                    if name == "jsonb" and firstbad is not None:
+                        raise RB.ConversionError("JSON deserialization failed")
                     rows, idx, host = RB.encode_events(hb.materialize(), 0, [c.type_class for c in hb.slots[0].cols], [0, 1, 0, 0], abi.CH_MERGE_TREE)
                     want_rb = ("ok", b"".join(rows))
                 except RB.ConversionError as ce:
