@@ -678,10 +678,11 @@ template <class S> DEV void timetz_str(S& s, const u8* slot) { time_str(s, ld32a
 // 64 different lines per instruction): k_rb_rows took 469 us for the 47 MB of a cfg3 batch's rows (profiles/r04q). The bytes are
 // collected in a 64-bit accumulator instead and leave eight at a time (unaligned 8-byte stores are fine in global memory); finish()
 // writes the last 1-7 bytes one by one — the next row's first bytes belong to another thread.
-struct RbWrite {
+struct RbGlobalSink {
   u8* p;                // where the accumulator's first byte goes
   uint64_t acc = 0;
   uint32_t n = 0;       // bytes in acc (0..7)
+  DEV explicit RbGlobalSink(u8* q) : p(q) {}
   DEV void store8(uint64_t v) { __builtin_memcpy(p, &v, 8); p += 8; }
   // appends the low k bytes of v (1 <= k <= 8; the bytes above them are zero)
   DEV void append(uint64_t v, uint32_t k) {
@@ -693,6 +694,27 @@ struct RbWrite {
       n = m - 8u;
     } else n = m;
   }
+  DEV void finish() { for (uint32_t b = 0; b < n; b++) p[b] = (u8)(acc >> (8u * b)); p += n; n = 0; acc = 0; }
+};
+// The same bytes into a ZEROED image of the output in LDS (k_rb_rows): whole words are OR-ed in (ds_or_b32), so the first and the last
+// word of a part may be shared with its neighbours; the image leaves for global memory in 16-byte stores of the whole workgroup.
+struct RbLdsSink {
+  uint32_t* w;          // the word the accumulator's first byte belongs to
+  uint64_t acc = 0;
+  uint32_t n;           // bytes in acc (0..3 between calls), counting the bytes of *w in front of this part
+  DEV RbLdsSink(uint32_t* word, uint32_t lead) : w(word), n(lead) {}
+  DEV void app4(uint32_t v, uint32_t k) {   // 1 <= k <= 4
+    acc |= (uint64_t)v << (8u * n);
+    n += k;
+    if (n >= 4u) { atomicOr(w++, (uint32_t)acc); acc >>= 32; n -= 4u; }
+  }
+  DEV void append(uint64_t v, uint32_t k) { if (k > 4u) { app4((uint32_t)v, 4u); app4((uint32_t)(v >> 32), k - 4u); } else app4((uint32_t)v, k); }
+  DEV void finish() { if (n && (uint32_t)acc) atomicOr(w, (uint32_t)acc); n = 0; acc = 0; }
+};
+template <class B>
+struct RbWriterT : B {
+  using B::B;
+  using B::append;
   DEV void put(u8 b) { append(b, 1); }
   DEV void varint64(uint64_t v) { while (v >= 0x80) { put((u8)(v | 0x80)); v >>= 7; } put((u8)v); }
   DEV void put32(uint32_t v) { append(v, 4); }
@@ -700,6 +722,7 @@ struct RbWrite {
   DEV void zeros(uint32_t k) { while (k >= 8u) { append(0ull, 8); k -= 8u; } if (k) append(0ull, k); }
   DEV void bytes(const u8* s, uint32_t len) {
     uint32_t k = 0;
+    for (; k + 16u <= len; k += 16u) { uint64_t v[2]; __builtin_memcpy(v, s + k, 16); append(v[0], 8); append(v[1], 8); }   // (one request per 16 bytes of a long text)
     for (; k + 8u <= len; k += 8u) { uint64_t v; __builtin_memcpy(&v, s + k, 8); append(v, 8); }
     if (k < len) { uint64_t v = 0; for (uint32_t b = 0; k + b < len; b++) v |= (uint64_t)s[k + b] << (8u * b); append(v, len - k); }
   }
@@ -713,8 +736,9 @@ struct RbWrite {
     }
     for (; k < len; k++) { const uint32_t x = s[k]; append(h1(x >> 4) | (h1(x & 15u) << 8), 2); }
   }
-  DEV void finish() { for (uint32_t b = 0; b < n; b++) p[b] = (u8)(acc >> (8u * b)); p += n; n = 0; acc = 0; }
 };
+using RbWrite = RbWriterT<RbGlobalSink>;
+using RbLdsWrite = RbWriterT<RbLdsSink>;
 struct StrWrite { u8* p; DEV void put(u8 b) { *p++ = b; } };
 // formatted string columns (numeric, timetz), pass 2: one thread per row writes its Display string at its offset
 template <bool JS>
@@ -988,6 +1012,10 @@ DEV uint32_t rb_json(S& s, const u8* t, uint32_t tn, bool bq, H head) {
 
 // One non-null value of class `cls` whose arena slot words start at `slot` (a row's slot, or the words decode_text_cell produced for
 // an array element). Returns 0, RB_E_DATE_RANGE or RB_E_HOST_CELL.
+// The counting pass notes where the row's `qparts` pieces (4, or 2 / 1 for narrow tables) begin; the byte pass writes a row with
+// parts <= qparts lanes (1, 2 or 4 — chosen when the bytes per row are known), a lane taking qparts / parts pieces.
+DEV uint32_t rb_part_col(const RbJob& j, uint32_t q) { return q * j.n_cols / j.qparts; }   // the first column of piece q
+
 template <bool JS = false, class S>
 DEV uint32_t rb_scalar(S& s, uint32_t cls, const u8* slot, const u8* heap) {
   const uint32_t w0 = ld32a(slot);
@@ -1036,8 +1064,10 @@ DEV uint32_t rb_default_zero_bytes(uint32_t cls) {
   return n;
 }
 
-template <bool JS, class S>
-DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or column << 8 | code of the cell that fails the row
+// [c_lo, c_hi): the columns this call writes (the byte pass splits a row among several lanes, k_rb_rows; the trailing columns go with
+// the last part); mark(i) is called in front of column i (the counting pass notes where the parts begin).
+template <bool JS, class S, class M>
+DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s, uint32_t c_lo, uint32_t c_hi, M&& mark) {   // returns 0, or column << 8 | code of the cell that fails the row
   // The reference converts every cell of every pending row first (cell_to_clickhouse_value, clickhouse/core.rs:1193-1203: Date32
   // range errors) and only then encodes the rows (NULL in a non-nullable column): a range error anywhere beats a NULL error. So a
   // row that meets a cell without an encoding goes on looking for a date out of range; k_rb_lens ranks range errors first across rows.
@@ -1048,7 +1078,8 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
   // the primary-key columns, NULL in every other column that is nullable at the source and not an array, default_cell's zero value
   // (:1481-1517) in the rest. The host selects such rows only where the reference accepts them (host_handoff.inc).
   const bool keyrow = j.kcols && j.ev_kind[j.row_event[r]] == 'D' && (j.ev_flags[j.row_event[r]] & 3u) == ETLG_OLD_KEY;
-  for (uint32_t i = 0; i < j.n_cols; i++) {
+  for (uint32_t i = c_lo; i < c_hi; i++) {
+    mark(i);
     const uint32_t cd = j.cols[i], cls = cd & 0xFF;
     uint32_t off = cd >> 16, sti = i;
     const bool nullable = (cd >> 8) & 1;
@@ -1105,6 +1136,7 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s) {   // returns 0, or colum
   }
   if (errd) return errd;
   if (err0) return err0;
+  if (c_hi != j.n_cols) return 0;
   // trailing CDC columns (core.rs:96-114); never NULL, a Nullable() destination column still takes its marker byte
   const uint64_t ev = j.row_event[r];
   const uint32_t kind = j.ev_kind[ev];
@@ -1145,14 +1177,15 @@ template <class S> DEV void pb_date(S& s, int32_t days_ce) {
   const int64_t y = (int64_t)yoe + era * 400 + (m <= 2 ? 1 : 0);
   pb_4d(s, (uint32_t)y); s.put('-'); rb_2d(s, m); s.put('-'); rb_2d(s, d);
 }
-template <bool JS, class S>
-DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
+template <bool JS, class S, class M>
+DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s, uint32_t c_lo, uint32_t c_hi, M&& mark) {
   // (the row's kind sits in the top bits of its base: ColSel / pb_selected)
   const unsigned long long rbase = j.row_base[r];
   const bool del = (rbase & kPbDelete) != 0, keyimg = (rbase & kPbKey) != 0;
   const uint64_t base = rbase & kPbBase;
   uint32_t err0 = 0;
-  for (uint32_t i = 0; i < j.n_cols; i++) {
+  for (uint32_t i = c_lo; i < c_hi; i++) {
+    mark(i);
     const uint32_t cd = j.cols[i], cls = cd & 0xFF, tag = i + 1;
     uint32_t off = cd >> 16, sti = i;
     if (del) {  // bigquery_delete_row (core.rs:1742-1754): only the primary-key cells of the old image, under their column tags
@@ -1209,6 +1242,7 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s) {
     }
   }
   if (err0) return err0;
+  if (c_hi != j.n_cols) return 0;
   const uint64_t ev = j.row_event[r];
   pb_key(s, j.n_cols + 1, 2); s.varint64(6);
   { const char* op = del ? "DELETE" : "UPSERT"; for (int k = 0; k < 6; k++) s.put((u8)op[k]); }
@@ -1224,7 +1258,12 @@ __global__ __launch_bounds__(256) void k_rb_lens(RbJob j, unsigned long long* bl
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   RbCount c;
   if (r < j.n_rows) {
-    const uint32_t e = j.format ? pb_row<JS>(j, r, c) : rb_row<JS>(j, r, c);
+    // (where pieces 1 .. qparts-1 of the row begin, for the byte pass: piece q starts at column q * n_cols / qparts)
+    uint32_t next = 1;
+    auto mark = [&](uint32_t i) {
+      while (next < j.qparts && i == rb_part_col(j, next)) { j.part_off[(uint64_t)(next - 1) * j.n_rows + r] = c.n; next++; }
+    };
+    const uint32_t e = j.format ? pb_row<JS>(j, r, c, 0, j.n_cols, mark) : rb_row<JS>(j, r, c, 0, j.n_cols, mark);
     // first failing row in event order, rows with a date out of range before all others (bit 62 clear)
     // (and a json cell that is not JSON before those: the reference's decode fails before any sink sees a row)
     if (e) {
@@ -1237,13 +1276,56 @@ __global__ __launch_bounds__(256) void k_rb_lens(RbJob j, unsigned long long* bl
   if (threadIdx.x == 0) blk[blockIdx.x] = t;
 }
 
+// The byte pass. One lane per row is few waves for what each has to do — a 64 MiB cfg3 batch is 175 000 rows of 270 bytes: 2.7 waves per
+// SIMD, each a serial chain of loads and stores (132 us; profiles/r05v_rb_rows_ablation.txt) — so a row is split among `parts` lanes
+// (1-4, the host picks it from the row count), each writing the columns [part * n / parts, (part + 1) * n / parts) from the byte offset
+// the counting pass noted. A wave holds 64 (128, 256) consecutive rows of ONE part — the lanes walk the same columns — and the parts of
+// a row sit in ONE workgroup: with a part per workgroup (blockIdx.y) every cache line of the output was written from several XCDs, and
+// the kernel got slower, not faster (186 us against 134; profiles/r05y_rb_rows_parts.txt).
+DEV uint32_t rb_rows_per_block(uint32_t parts) { return parts == 1 ? 256u : parts == 2 ? 128u : 64u; }
+// ... and the lanes do not store to global memory themselves: 64 lanes x 8 bytes at a stride of a row is 64 write requests per
+// instruction (the request rate, not the bytes, bounded the kernel). The workgroup's rows are one contiguous piece of the output: when it
+// fits kRbLds, the lanes build it in LDS and the whole workgroup stores it in 16-byte pieces; a piece that does not fit (rows of more
+// than ~500 bytes on average) is written directly as before.
+constexpr uint32_t kRbLds = 32 * 1024;
 template <bool JS>
 __global__ __launch_bounds__(256) void k_rb_rows(RbJob j) {
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= j.n_rows || !j.lens[r]) return;
-  RbWrite w{j.out + j.offsets[r]};
-  if (j.format) (void)pb_row<JS>(j, r, w); else (void)rb_row<JS>(j, r, w);
-  w.finish();
+  __shared__ uint4 img[kRbLds / 16 + 2];
+  const uint32_t rpb = rb_rows_per_block(j.parts), part = threadIdx.x / rpb;
+  const uint64_t r0 = (uint64_t)blockIdx.x * rpb, r = r0 + threadIdx.x % rpb;
+  const uint64_t r1 = r0 + rpb < j.n_rows ? r0 + rpb : j.n_rows;
+  const uint64_t g0 = (uint64_t)j.offsets[r0], g1 = (uint64_t)j.offsets[r1];
+  const uint32_t pad = (uint32_t)((uintptr_t)(j.out + g0) & 15u);   // the image starts at the 16-byte line the piece starts in
+  const bool staged = g1 - g0 + pad <= kRbLds;                      // (uniform in the workgroup)
+  const bool active = part < j.parts && r < j.n_rows && j.lens[r];
+  const uint32_t q = part * (j.qparts / j.parts);   // the lane's first piece
+  const uint32_t c_lo = rb_part_col(j, q), c_hi = part + 1 >= j.parts ? j.n_cols : rb_part_col(j, q + j.qparts / j.parts);
+  const uint32_t po = active && q ? j.part_off[(uint64_t)(q - 1) * j.n_rows + r] : 0u;
+  auto none = [](uint32_t) {};
+  if (!staged) {
+    if (active) {
+      RbWrite w(j.out + j.offsets[r] + po);
+      if (j.format) (void)pb_row<JS>(j, r, w, c_lo, c_hi, none); else (void)rb_row<JS>(j, r, w, c_lo, c_hi, none);
+      w.finish();
+    }
+    return;
+  }
+  const uint32_t total = pad + (uint32_t)(g1 - g0), nch = (total + 15u) / 16u;
+  for (uint32_t k = threadIdx.x; k < nch; k += 256) img[k] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (active) {
+    const uint32_t o = pad + (uint32_t)((uint64_t)j.offsets[r] - g0) + po;
+    RbLdsWrite w((uint32_t*)img + (o >> 2), o & 3u);
+    if (j.format) (void)pb_row<JS>(j, r, w, c_lo, c_hi, none); else (void)rb_row<JS>(j, r, w, c_lo, c_hi, none);
+    w.finish();
+  }
+  __syncthreads();
+  u8* gb = j.out + g0 - pad;
+  for (uint32_t k = threadIdx.x; k < nch; k += 256) {
+    const uint32_t b0 = k * 16u;
+    if (b0 >= pad && b0 + 16u <= total) *(uint4*)(gb + b0) = img[k];
+    else for (uint32_t b = b0 < pad ? pad : b0; b < b0 + 16u && b < total; b++) gb[b] = ((const u8*)img)[b];   // the first / last line: the bytes outside belong to the neighbours
+  }
 }
 
 
@@ -1397,7 +1479,8 @@ void etlg_k_rowbinary(const void* jv, unsigned long long* blk, int64_t* offsets,
     hipLaunchKernelGGL(k_col_len_scan, dim3(1), dim3(256), 0, st, blk, nb);
     hipLaunchKernelGGL(k_col_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)j.lens, j.n_rows, (const unsigned long long*)blk, offsets, tot);
   } else {
-    if (j.has_json) hipLaunchKernelGGL(k_rb_rows<true>, dim3(nb), dim3(256), 0, st, j); else hipLaunchKernelGGL(k_rb_rows<false>, dim3(nb), dim3(256), 0, st, j);
+    const uint32_t rpb = j.parts == 1 ? 256u : j.parts == 2 ? 128u : 64u, nbw = (uint32_t)((j.n_rows + rpb - 1) / rpb);
+    if (j.has_json) hipLaunchKernelGGL(k_rb_rows<true>, dim3(nbw), dim3(256), 0, st, j); else hipLaunchKernelGGL(k_rb_rows<false>, dim3(nbw), dim3(256), 0, st, j);
   }
 }
 

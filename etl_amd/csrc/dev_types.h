@@ -257,6 +257,8 @@ struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
   uint32_t* lens; const int64_t* offsets; uint8_t* out;
   unsigned long long* err;         // min over failing cells of (row << 24 | column << 8 | code); ~0 = none
   uint32_t has_json;               // the table has a json / jsonb column: the kernels that carry json_display
+  uint32_t qparts, parts;          // the counting pass notes where the row's qparts pieces begin (4; 2 / 1 for narrow tables); the byte pass writes a row with parts lanes (1, 2, 4 <= qparts)
+  uint32_t* part_off;              // [(qparts - 1) x n_rows]: where pieces 1 .. of a row begin, in bytes from the row's start
 };
 
 

@@ -249,6 +249,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* e = getenv("ETLG_COPY_DIRECT"); c->copy_direct = !(e && e[0] == '0'); }
   { const char* ht = getenv("ETLG_HOST_TIMES"); c->host_times = ht && (ht[0] == '1' || ht[0] == '2'); c->host_times_slow = ht && ht[0] == '2'; }
   { const char* sc = getenv("ETLG_CTRL_STAGE_CAP"); c->ctrl_stage_cap_test = sc ? (size_t)atol(sc) : 0; }
+  { const char* rp = getenv("ETLG_RB_PARTS"); c->rb_parts_test = rp ? (uint32_t)atoi(rp) : 0; }   // tests: lanes per row in k_rb_rows (1-4) instead of the choice by row count
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
   clear_error(c);

@@ -356,6 +356,7 @@ struct etlg_ctx {
   std::vector<DevBuf*> offs_pool;     // ... into an offsets buffer the batch owns
   std::vector<std::pair<void*, size_t>> blk_dev, blk_host;  // hand-off calls (columns / RowBinary / size hints): pooled device and pinned blocks
   DevBuf d_colsel;                   // etlg_batch_columns: block counts of the row selection
+  uint32_t rb_parts_test = 0;        // ETLG_RB_PARTS (tests)
   uint8_t* h_hand = nullptr; size_t h_hand_cap = 0;   // pinned: the row formats' small uploads (initial counters + column words, one copy) and read-backs (row count; totals + counters, one copy each)
   unsigned long long* h_cnt_init = nullptr; size_t h_cnt_init_cols = 0;   // pinned {0, 0, 0, ~0} per column: the hand-off's counters start from it (an asynchronous copy; the content never changes)
   std::vector<etlg_batch*> pending;  // ASYNC batches not finished yet, in issue order

@@ -126,6 +126,39 @@ def test_cells_and_rows_that_stay_with_the_host():
     r.close(); b.close(); d.close()
 
 
+@pytest.mark.parametrize("parts", [1, 2, 4])
+def test_rows_split_among_lanes(parts):
+    """k_rb_rows writes a row with 1-4 lanes (the host picks by the row count: four for the small batches of this file): the other
+    splits, forced, on the 17-column all-classes table and on cfg3 — RowBinary and protobuf rows as the oracle has them."""
+    from tests.test_gpu_protobuf import _check as _check_pb
+    os.environ["ETLG_RB_PARTS"] = str(parts)
+    try:
+        rows = [_row(id=str(i), s="y" * (i * 13 % 200), n=NUMERICS[i % len(NUMERICS)], tz=TIMETZS[i % len(TIMETZS)]) for i in range(70)]
+        rows[5] = [("5" if c[0] == "id" else W.NULL) for c in RB_COLS]
+        buf, offs = _stream([W.insert(42, r) for r in rows] + [W.update(42, rows[1]), W.delete(42, old=rows[0])])
+        hb, b, d = _both(SC.simple_table(RB_COLS), buf, offs)
+        nullable = [0 if c[0] == "id" else 1 for c in RB_COLS]
+        for engine in (abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE):
+            assert _check(hb, b, nullable + [1, 0], engine) >= len(rows)
+        b.close(); d.close()
+        # rows too long for the workgroup's LDS image (64 rows of ~1.5 KB): the lanes write to global memory themselves; a mix of both in one call
+        big = [_row(id=str(i), s="z" * (1500 + i if i < 80 else i % 7)) for i in range(200)]
+        buf, offs = _stream([W.insert(42, r) for r in big])
+        hb, b, d = _both(SC.simple_table(RB_COLS), buf, offs)
+        assert _check(hb, b, nullable + [0, 0], abi.CH_MERGE_TREE) == len(big)
+        assert _check_pb(hb, b, RB_COLS) == len(big)
+        b.close(); d.close()
+        w = synth.cfg3()
+        buf, offs = w.fill(96 << 10)
+        hb, b, d = _both(w.register, buf, offs)
+        flags = [1 if c.nullable else 0 for c in hb.slots[0].cols]
+        assert _check(hb, b, flags + [0, 0], abi.CH_MERGE_TREE, schema_cols=w.schema_cols(w.tables[0])) > 50
+        assert _check_pb(hb, b, w.schema_cols(w.tables[0])) > 50
+        b.close(); d.close()
+    finally:
+        os.environ.pop("ETLG_RB_PARTS", None)
+
+
 @pytest.mark.parametrize("mk,nbytes", [(synth.cfg2, 1 << 20), (synth.cfg3, 1 << 20)])   # cfg3: BASELINE's var-len schema (TEXT, NUMERIC, timestamptz, uuid)
 @pytest.mark.parametrize("engine", [abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE])
 def test_synthetic_stream(mk, nbytes, engine):
