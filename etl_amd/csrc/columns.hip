@@ -746,20 +746,19 @@ DEV void col_fmt_body(const ColJob& j, uint32_t bx) {
   const uint64_t r = (uint64_t)bx * 256 + threadIdx.x;
   if (r >= j.n_rows || !j.lens[r]) return;
   const u8* slot = j.fixed + j.row_base[r] + j.off_full;
-  StrWrite w{j.values + j.offsets[r]};
+  // through the row formats' writer: eight bytes per store (a store per byte was a write request per byte and lane). For json the byte
+  // writer did worse than that: its instantiation faulted on the MI355X — a store address with its low or high half replaced — while
+  // the same function under a bounds-checked byte writer, under RbWrite in k_rb_rows and on the emulator was right
+  // (profiles/r05x_json_arrow_fault.txt; not pursued further).
+  RbWrite w(j.values + j.offsets[r]);
   if (j.kind == AK_NUMERIC_STR) numeric_str(w, j.heap + ld32a(slot));
   else if (j.kind == AK_TIMETZ_STR) timetz_str(w, slot);
   else if (JS) {   // json: the Display string, or (the rows pass 1 marked DEFERRED) the source text as it is
     const u8* t = j.heap + ld32a(slot);
-    if ((j.deferred[r >> 6] >> (r & 63)) & 1ull) { for (uint32_t k = 0; k < j.lens[r]; k++) w.put(t[k]); }
-    else {   // through the row formats' writer (eight bytes per store). With StrWrite's byte stores this instantiation faulted on the
-             // MI355X — a store address with its low or high half replaced — while the same function under a bounds-checked byte
-             // writer, under RbWrite in k_rb_rows and on the emulator was right (profiles/r05x_json_arrow_fault.txt): not pursued further.
-      RbWrite rw{w.p};
-      (void)json_display(rw, t, ld32a(slot + 4), false);
-      rw.finish();
-    }
+    if ((j.deferred[r >> 6] >> (r & 63)) & 1ull) w.bytes(t, j.lens[r]);
+    else (void)json_display(w, t, ld32a(slot + 4), false);
   }
+  w.finish();
 }
 template <bool JS>
 __global__ __launch_bounds__(256) void k_col_fmt(ColJob j) { col_fmt_body<JS>(j, blockIdx.x); }
