@@ -739,7 +739,6 @@ struct RbWriterT : B {
 };
 using RbWrite = RbWriterT<RbGlobalSink>;
 using RbLdsWrite = RbWriterT<RbLdsSink>;
-struct StrWrite { u8* p; DEV void put(u8 b) { *p++ = b; } };
 // formatted string columns (numeric, timetz), pass 2: one thread per row writes its Display string at its offset
 template <bool JS>
 DEV void col_fmt_body(const ColJob& j, uint32_t bx) {
@@ -931,8 +930,9 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
     } else {
       (void)arr_walk<false>(s, n, j.elem_cls, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8* scratch) {
         if (is_null) return;
-        StrWrite sw{j.values + j.child_offsets[o + k]};
+        RbWrite sw(j.values + j.child_offsets[o + k]);
         if (num) numeric_str(sw, scratch + w[0]); else timetz_str(sw, (const u8*)w);
+        sw.finish();
       }, [](uint32_t) -> u8* { return nullptr; });
     }
     return;
