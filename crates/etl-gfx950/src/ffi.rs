@@ -28,6 +28,7 @@ pub const ETLG_DeserializationError: i32 = 7;
 pub const ETLG_SourceConnectionFailed: i32 = 8;
 pub const ETLG_IoError: i32 = 9;
 pub const ETLG_UnsupportedValueInDestination: i32 = 10;
+pub const ETLG_NullValuesNotSupportedInArrayInDestination: i32 = 11;
 pub const ETLG_InvalidArgument: i32 = 100;
 pub const ETLG_DeviceError: i32 = 101;
 pub const ETLG_Unsupported: i32 = 102;

@@ -46,6 +46,7 @@ fn kind_of(k: i32) -> ErrorKind {
         ETLG_SourceConnectionFailed => ErrorKind::SourceConnectionFailed,
         ETLG_IoError => ErrorKind::IoError,
         ETLG_UnsupportedValueInDestination => ErrorKind::UnsupportedValueInDestination,
+        ETLG_NullValuesNotSupportedInArrayInDestination => ErrorKind::NullValuesNotSupportedInArrayInDestination,
         _ => ErrorKind::Unknown,
     }
 }

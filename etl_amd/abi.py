@@ -20,6 +20,7 @@ DeserializationError = 7
 SourceConnectionFailed = 8
 IoError = 9
 UnsupportedValueInDestination = 10
+NullValuesNotSupportedInArrayInDestination = 11
 InvalidArgument = 100
 DeviceError = 101
 Unsupported = 102
@@ -29,7 +30,7 @@ KIND_NAMES = {
     ValidationError: "ValidationError", InvalidState: "InvalidState",
     MissingTableSchema: "MissingTableSchema", CorruptedTableSchema: "CorruptedTableSchema",
     DeserializationError: "DeserializationError", SourceConnectionFailed: "SourceConnectionFailed",
-    IoError: "IoError", UnsupportedValueInDestination: "UnsupportedValueInDestination", InvalidArgument: "InvalidArgument", DeviceError: "DeviceError",
+    IoError: "IoError", UnsupportedValueInDestination: "UnsupportedValueInDestination", NullValuesNotSupportedInArrayInDestination: "NullValuesNotSupportedInArrayInDestination", InvalidArgument: "InvalidArgument", DeviceError: "DeviceError",
     Unsupported: "Unsupported",
 }
 

@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
 
 // ---- ClickHouse RowBinary (crates/etl-destinations/src/clickhouse/encoding.rs:58-83 which wire type a Cell becomes,
 // :188-283 the byte format; core.rs:96-114 the trailing CDC columns). One thread per row, run twice: lengths, then bytes.
-enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3, RB_E_BQ_NUMERIC_SCALE = 4 /* and the json integer rule: one report */, RB_E_JSON = 5 };
+enum : uint32_t { RB_E_NULL = 1, RB_E_DATE_RANGE = 2, RB_E_HOST_CELL = 3, RB_E_BQ_NUMERIC_SCALE = 4 /* and the json integer rule: one report */, RB_E_JSON = 5, RB_E_BQ_ARRAY_NULL = 6 };
 constexpr int32_t kDate32Min = -25567, kDate32Max = 120529;   // 1900-01-01 .. 2299-12-31 (encoding.rs:147-173)
 
 struct RbCount {
@@ -1176,6 +1176,57 @@ template <class S> DEV void pb_date(S& s, int32_t days_ce) {
   const int64_t y = (int64_t)yoe + era * 400 + (m <= 2 ? 1 : 0);
   pb_4d(s, (uint32_t)y); s.put('-'); rb_2d(s, m); s.put('-'); rb_2d(s, d);
 }
+// An array cell (array_cell_encode_prost, bigquery/encoding.rs:203-290) behind validate_array_cell_for_bigquery (validation.rs:125-190:
+// a NULL element fails the row). Element classes with a fixed-width value, as in RowBinary: bool / int2 / int4 / oid / int8 / float4 /
+// float8 and timestamptz (epoch microseconds) leave PACKED — one length-delimited field of the values back to back (varints, or 4- / 8-
+// byte words), nothing at all for an empty array; date / time / timestamp / uuid leave as one string field per element. The literal is
+// walked once for the element count, the NULLs and the packed length, once for the bytes. A literal the device does not take apart
+// (malformed: the reference's decode error, which the host raises; an element of more than 40 characters) is RB_E_HOST_CELL.
+template <class S>
+DEV uint32_t pb_array(S& s, uint32_t tag, uint32_t elem, const u8* txt, uint32_t tn) {
+  if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA || elem == ETLG_TC_NUMERIC || elem == ETLG_TC_JSON || elem == ETLG_TC_TIMETZ) return RB_E_HOST_CELL;
+  const bool packed = elem == ETLG_TC_BOOL || elem == ETLG_TC_I16 || elem == ETLG_TC_I32 || elem == ETLG_TC_U32 || elem == ETLG_TC_I64 ||
+                      elem == ETLG_TC_F32 || elem == ETLG_TC_F64 || elem == ETLG_TC_TIMESTAMPTZ;
+  auto none = [](uint32_t) -> u8* { return nullptr; };
+  auto value64 = [&](const uint32_t* w) -> uint64_t {   // what the varint of an element holds
+    if (elem == ETLG_TC_I16 || elem == ETLG_TC_I32) return (uint64_t)(int64_t)(int32_t)w[0];
+    if (elem == ETLG_TC_I64) return ((uint64_t)w[1] << 32) | w[0];
+    if (elem == ETLG_TC_TIMESTAMPTZ) return (uint64_t)((((int64_t)(int32_t)w[0] - kCeDays1970) * 86400 + (int64_t)w[1]) * 1000000 + (int64_t)(w[2] / 1000u));
+    return (uint64_t)w[0];   // bool, oid
+  };
+  uint32_t cnt = 0, nulls = 0, plen = 0;
+  if (arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w, const u8*) {
+        if (is_null) { nulls++; return; }
+        if (elem == ETLG_TC_F32) plen += 4; else if (elem == ETLG_TC_F64) plen += 8; else if (elem == ETLG_TC_BOOL) plen += 1;
+        else if (packed) { uint64_t v = value64(w); do { plen++; v >>= 7; } while (v); }
+      }, none)) return RB_E_HOST_CELL;
+  if (nulls) return RB_E_BQ_ARRAY_NULL;
+  if (!cnt) return 0;
+  if (packed) { pb_key(s, tag, 2); s.varint64(plen); }
+  (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool, const uint32_t* w, const u8*) {
+    switch (elem) {
+      case ETLG_TC_BOOL: s.put(w[0] ? 1 : 0); break;
+      case ETLG_TC_F32: s.put32(w[0]); break;
+      case ETLG_TC_F64: s.put64(((uint64_t)w[1] << 32) | w[0]); break;
+      case ETLG_TC_DATE: pb_key(s, tag, 2); s.varint64(10); pb_date(s, (int32_t)w[0]); break;
+      case ETLG_TC_TIME: pb_key(s, tag, 2); s.varint64(8 + time_frac_len(w[1])); time_str(s, w[0], w[1]); break;
+      case ETLG_TC_TIMESTAMP: pb_key(s, tag, 2); s.varint64(19 + time_frac_len(w[2])); pb_date(s, (int32_t)w[0]); s.put(' '); time_str(s, w[1], w[2]); break;
+      case ETLG_TC_UUID: {
+        const u8* b16 = (const u8*)w;
+        pb_key(s, tag, 2); s.varint64(36);
+        for (int k = 0; k < 16; k++) {
+          const uint32_t b = b16[k], h = b >> 4, l = b & 15;
+          if (k == 4 || k == 6 || k == 8 || k == 10) s.put('-');
+          s.put((u8)(h < 10 ? '0' + h : 'a' + h - 10)); s.put((u8)(l < 10 ? '0' + l : 'a' + l - 10));
+        }
+        break;
+      }
+      default: s.varint64(value64(w)); break;
+    }
+  }, none);
+  return 0;
+}
+
 template <bool JS, class S, class M>
 DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s, uint32_t c_lo, uint32_t c_hi, M&& mark) {
   // (the row's kind sits in the top bits of its base: ColSel / pb_selected)
@@ -1194,9 +1245,13 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s, uint32_t c_lo, uint32_t c_
     }
     const uint32_t st = (j.fixed[base + sti / 4] >> (2 * (sti % 4))) & 3u;
     if (st == ETLG_CELL_NULL) continue;                       // Cell::Null => {}
-    if (st != ETLG_CELL_VALUE && !(cls == ETLG_TC_JSON && st == ETLG_CELL_DEFERRED)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
+    if (st != ETLG_CELL_VALUE && !((cls == ETLG_TC_JSON || cls == ETLG_TC_ARRAY) && st == ETLG_CELL_DEFERRED)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
     const u8* slot = j.fixed + base + off;
     const uint32_t w0 = ld32a(slot);
+    if (cls == ETLG_TC_ARRAY) {
+      if (const uint32_t e = pb_array(s, tag, (cd >> 9) & 0x7Fu, j.heap + w0, ld32a(slot + 4))) { if (!err0) err0 = (i << 8) | e; }
+      continue;
+    }
     switch (cls) {
       case ETLG_TC_BOOL: pb_key(s, tag, 0); s.put(w0 ? 1 : 0); break;
       case ETLG_TC_I16: case ETLG_TC_I32: pb_key(s, tag, 0); s.varint64((uint64_t)(int64_t)(int32_t)w0); break;

@@ -75,6 +75,7 @@ typedef enum etlg_error_kind {
                                       without SQLSTATE (error.rs:947) */
   ETLG_IoError = 9,                /* io::Error from cstr accessors (error.rs:564) */
   ETLG_UnsupportedValueInDestination = 10, /* error.rs:136; only from etlg_batch_protobuf (bigquery/validation.rs) */
+  ETLG_NullValuesNotSupportedInArrayInDestination = 11, /* error.rs:134; only from etlg_batch_protobuf (reject_nulls, bigquery/validation.rs:127-141) */
   /* library-level (no reference analog) */
   ETLG_InvalidArgument = 100,
   ETLG_DeviceError = 101,
@@ -698,7 +699,10 @@ int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_sl
  * for BigQuery compatibility", detail "Cell at index N failed validation", frame_index = the event). A json / jsonb cell is its
  * serde_json Display string (encoding.rs:173-176) behind validate_json_for_bigquery (validation.rs:47-85): an integer literal of the
  * parsed value outside u64 / i64 fails the call the same way; a cell that is not one JSON value fails it with ETLG_E_JSON. Array
- * columns (packed / repeated fields, host-side validation), DEFERRED cells and json cells beyond json_display's limits return
+ * cells of a fixed-width element class (array_cell_encode_prost, encoding.rs:203-290): bool / int2 / int4 / oid / int8 / float4 / float8 /
+ * timestamptz packed, date / time / timestamp / uuid one string field per element, an empty array nothing; a NULL element fails the
+ * call with ETLG_NullValuesNotSupportedInArrayInDestination (same description and detail). Arrays of text / numeric / timetz / bytea /
+ * json elements, a literal the device cannot take apart, DEFERRED cells and json cells beyond json_display's limits return
  * ETLG_RB_NEEDS_HOST.
  * The result is an etlg_rowbinary (same view; n_rows can exceed the number of events). */
 int32_t etlg_batch_protobuf(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t flags, etlg_rowbinary** out);

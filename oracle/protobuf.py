@@ -21,7 +21,7 @@ import datetime as dt
 import struct
 
 from oracle.display import numeric_string, time_string, timetz_string
-from oracle.rowbinary import NeedsHost
+from oracle.rowbinary import ARRAY_OIDS, NeedsHost
 
 
 class UnsupportedValueInDestination(Exception):
@@ -84,6 +84,8 @@ def cell(c, tag):
     if k == "Uuid":
         h = c[1].hex()
         return ld(tag, f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:]}".encode())
+    if k == "Deferred" and c[1] in ARRAY_OIDS:        # validate_array_cell_for_bigquery, then array_cell_encode_prost (encoding.rs:203-290)
+        return array_cell(c[1], c[2], tag)
     if k == "Deferred" and c[1] in (114, 3802):      # validate_json_for_bigquery, then j.to_string() (encoding.rs:173-176)
         from oracle import json_display
         if not json_display.device_limits_ok(c[2]):
@@ -98,6 +100,30 @@ def cell(c, tag):
 
 class NullValuesNotSupportedInArrayInDestination(Exception):
     """reject_nulls (bigquery/validation.rs:126-141)."""
+
+
+def array_cell(type_oid, text, tag):
+    """An array cell of a fixed-width element class (the ones the device encodes): reject_nulls (validation.rs:127-141, wrapped by
+    try_from_tagged_cells with the cell's index), then bool / int32 / uint32 / int64 / float / double / timestamptz PACKED
+    (prost::encoding::*::encode_packed: nothing for an empty array) and date / time / timestamp / uuid as one string field per element."""
+    from oracle.rowbinary import array_elements
+    elems = array_elements(type_oid, text)             # raises NeedsHost for what the device hands back
+    if any(e[0] == "Null" for e in elems):
+        raise NullValuesNotSupportedInArrayInDestination(f"Cell at index {tag - 1} failed validation")
+    if not elems:
+        return b""
+    k = elems[0][0]
+    if k == "Bool":
+        return ld(tag, bytes(1 if e[1] else 0 for e in elems))
+    if k in ("I16", "I32", "I64", "U32"):
+        return ld(tag, b"".join(varint(e[1]) for e in elems))
+    if k == "F32":
+        return ld(tag, b"".join(struct.pack("<I", e[1]) for e in elems))
+    if k == "F64":
+        return ld(tag, b"".join(struct.pack("<Q", e[1]) for e in elems))
+    if k == "TimestampTz":
+        return packed_int64(tag, [tstz_micros(e) for e in elems])
+    return b"".join(cell(e, tag) for e in elems)     # Date / Time / Timestamp / Uuid: the scalar's string field, repeated
 
 
 def packed_int64(tag, values):

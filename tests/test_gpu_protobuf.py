@@ -46,11 +46,19 @@ def test_every_encodable_class():
 
 
 def test_host_only_classes_and_deferred_cells():
+    from etl_amd.decoder import EtlError
+    # the all-classes table: every class is written on the device (json: tests/test_gpu_json_display.py; int4[]: below) ...
+    buf, offs = _stream([W.insert(42, SC.alltypes_row(arr="{1,2,3}")), W.insert(42, SC.alltypes_row(id="2", arr="{}"))])
+    hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
+    assert _check(hb, b, SC.ALLTYPES) == 2
+    b.close(); d.close()
+    # ... and its default row carries {1,NULL,3}: BigQuery takes no NULL inside an array (reject_nulls, validation.rs:127-141)
     buf, offs = _stream([W.insert(42, SC.alltypes_row())])
     hb, b, d = _both(SC.simple_table(SC.ALLTYPES), buf, offs)
-    r = b.protobuf(0)
-    assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == [c[0] for c in SC.ALLTYPES].index("arr")   # (the json column is written on the device: tests/test_gpu_json_display.py)
-    r.close(); b.close(); d.close()
+    with pytest.raises(EtlError) as ei:
+        b.protobuf(0)
+    assert ei.value.kind == abi.NullValuesNotSupportedInArrayInDestination and ei.value.detail == f"Cell at index {[c[0] for c in SC.ALLTYPES].index('arr')} failed validation"
+    b.close(); d.close()
     cols = [("id", SC.INT8, False, 1), ("x", SC.FLOAT8, True, 0)]
     buf, offs = _stream([W.insert(42, ["1", "1.5"]), W.insert(42, ["2", "50537618.817359292015891086651596749e82"])])
     hb, b, d = _both(SC.simple_table(cols), buf, offs)
@@ -169,8 +177,8 @@ def test_numeric_with_more_than_38_decimal_places_fails_like_the_reference():
 def test_reference_pinned_cell_encodings_on_the_device():
     """The vectors the reference's own tests hold (tests/golden/bigquery_kats.py, encoding.rs:451-496) through etlg_batch_protobuf, against
     LITERAL bytes: a timestamptz cell is the int64 varint of its epoch microseconds; a numeric with 38 decimal places is its text, one with
-    39 fails the batch with the reference's kind and detail; a json integer literal outside u64 fails the same way. (Arrays leave the
-    device as NEEDS_HOST: their packed forms are pinned on the oracle only.)"""
+    39 fails the batch with the reference's kind and detail; a json integer literal outside u64 fails the same way; an int4[] with a
+    NULL element fails with the reference's kind and detail (arrays: test_arrays_of_fixed_width_elements)."""
     from etl_amd.decoder import EtlError
     from tests.golden import bigquery_kats as K
     cols = [("ts", SC.TIMESTAMPTZ, False, 1), ("v", SC.NUMERIC, True, 0)]
@@ -191,11 +199,12 @@ def test_reference_pinned_cell_encodings_on_the_device():
         b.protobuf(0)
     assert ei.value.kind == abi.UnsupportedValueInDestination and ei.value.detail == "Cell at index 1 failed validation"
     b.close(); d.close()
-    buf, offs = _stream([W.insert(42, ["1", "{1,NULL,3}"])])
-    hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", SC.INT4_A, True, 0)]), buf, offs)
-    r = b.protobuf(0)
-    assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == 1
-    r.close(); b.close(); d.close()
+    buf, offs = _stream([W.insert(42, ["1", "{" + ",".join("NULL" if v is None else str(v) for v in K.ARRAY_WITH_NULLS) + "}"])])   # encoding.rs:372-383
+    hb, b, d = _both(SC.simple_table([("a", SC.INT4_A, True, 1)]), *_stream([W.insert(42, ["{1,NULL,3}"])]))
+    with pytest.raises(EtlError) as ei:
+        b.protobuf(0)
+    assert ei.value.kind == abi.NullValuesNotSupportedInArrayInDestination and ei.value.detail == "Cell at index 0 failed validation"
+    b.close(); d.close()
     for text in K.JSON_REFUSED:                        # encoding.rs:353-360
         buf, offs = _stream([W.insert(42, ["1", text])])
         hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("j", SC.JSONB, True, 0)]), buf, offs)
@@ -207,6 +216,59 @@ def test_reference_pinned_cell_encodings_on_the_device():
     hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("j", SC.JSONB, True, 0)]), buf, offs)
     r = b.protobuf(0)
     assert r.status == abi.RB_OK and r.bytes().tobytes().startswith(bytes([0x08, 1, 0x12, 16]) + b'{"value":1e+309}')   # (Display as codec/text.rs:812-815 has it)
+    r.close(); b.close(); d.close()
+
+
+# array type OIDs of the element classes the device encodes (tests/scenarios.py names only int4[])
+ARRAYS = {"bool": 1000, "int2": 1005, "int4": 1007, "int8": 1016, "oid": 1028, "float4": 1021, "float8": 1022,
+          "date": 1182, "time": 1183, "timestamp": 1115, "timestamptz": 1185, "uuid": 2951}
+
+
+def test_arrays_of_fixed_width_elements():
+    """array_cell_encode_prost (bigquery/encoding.rs:203-290) on the device: bool / int2 / int4 / oid / int8 / float4 / float8 / timestamptz
+    arrays PACKED, date / time / timestamp / uuid arrays one string field per element, empty arrays nothing, quoted elements and a
+    dimensions prefix; the timestamptz array of the reference's own test against its LITERAL bytes (encoding.rs:451-480); a NULL element
+    fails the batch like reject_nulls (validation.rs:127-141; encoding.rs:372-383); arrays of var-len elements stay with the host."""
+    from etl_amd.decoder import EtlError
+    from tests.golden import bigquery_kats as K
+    lits = {"bool": ["{t,f,t}", "{}", "{f}"], "int2": ["{1,-2,32767}", "{-32768}", "{}"], "int4": ["{1,2,3}", "{-1,2147483647,-2147483648}", "[0:2]={7,8,9}"],
+            "int8": ["{9223372036854775807,-9223372036854775808,0}", "{}", "{1}"], "oid": ["{0,4294967295}", "{42}", "{}"],
+            "float4": ["{1.5,-0.25,3e10}", "{}", "{0}"], "float8": ["{1.5,-2.25e-300,1e300}", "{0.1}", "{}"],
+            "date": ["{2026-01-02,0001-01-01}", "{}", '{"9999-12-31"}'], "time": ["{12:30:45.123456,00:00:00}", "{23:59:59.5}", "{}"],
+            "timestamp": ['{"2026-01-02 03:04:05.123456","1969-12-31 23:59:59.5"}', "{}", '{"2000-01-01 00:00:00"}'],
+            "timestamptz": ['{"2026-01-02 03:04:05+00"}', '{"1969-12-31 23:59:59.5+00","2026-01-02 05:04:05.000001+02"}', "{}"],
+            "uuid": ["{123e4567-e89b-12d3-a456-426614174000,00000000-0000-0000-0000-000000000000}", "{}", "{FFFFFFFF-FFFF-FFFF-FFFF-FFFFFFFFFFFF}"]}
+    names = sorted(ARRAYS)
+    cols = [("id", SC.INT8, False, 1)] + [(n, ARRAYS[n], True, 0) for n in names]
+    rows = [[str(k)] + [lits[n][k] for n in names] for k in range(3)] + [["3"] + [W.NULL] * len(names)]
+    buf, offs = _stream([W.insert(42, r) for r in rows] + [W.update(42, rows[1]), W.delete(42, old=rows[0])])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    assert _check(hb, b, cols) == len(rows) + 2
+    r = b.protobuf(0)     # row 0: id = 0 (field 1 varint), then the arrays in column order; the timestamptz array is field 1 + its position
+    tag = 2 + names.index("timestamptz")
+    assert bytes([tag << 3 | 2, len(K.TSTZ_VARINT)]) + K.TSTZ_VARINT in r.bytes().tobytes()[:int(r.row_offsets()[1])]
+    r.close(); b.close(); d.close()
+    assert K.TSTZ_PACKED_BYTES == bytes([1 << 3 | 2, len(K.TSTZ_VARINT)]) + K.TSTZ_VARINT       # (the same field under the test's tag 1)
+    for n in names:                                                                              # a NULL element, in every class
+        lit = "{" + ",".join(['"' + e + '"' for e in lits[n][0][1:-1].split(",")][:1] + ["NULL"]) + "}"
+        buf, offs = _stream([W.insert(42, ["1", lits[n][0]]), W.insert(42, ["2", lit])])
+        hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", ARRAYS[n], True, 0)]), buf, offs)
+        with pytest.raises(EtlError) as ei:
+            b.protobuf(0)
+        assert ei.value.kind == abi.NullValuesNotSupportedInArrayInDestination and ei.value.description == "Cell validation failed for BigQuery compatibility", n
+        assert ei.value.detail == "Cell at index 1 failed validation" and ei.value.frame_index == 2
+        b.close(); d.close()
+    for oid, lit in ((1009, "{a,b}"), (1231, "{1.5}"), (1001, '{"\\x01"}'), (3807, '{"{}"}'), (1270, "{12:00:00+02}")):   # text[] numeric[] bytea[] jsonb[] timetz[]
+        buf, offs = _stream([W.insert(42, ["1", lit])])
+        hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", oid, True, 0)]), buf, offs)
+        r = b.protobuf(0)
+        assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == 1, oid
+        r.close(); b.close(); d.close()
+    # a malformed literal is the host's to report (the reference fails at decode time): handed back with its event and column
+    buf, offs = _stream([W.insert(42, ["1", "{1,2}"]), W.insert(42, ["2", "{1,x}"])])
+    hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", 1007, True, 0)]), buf, offs)
+    r = b.protobuf(0)
+    assert r.status == abi.RB_NEEDS_HOST and (int(r.view.host_event), r.view.host_column) == (2, 1)
     r.close(); b.close(); d.close()
 
 

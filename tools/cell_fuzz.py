@@ -131,6 +131,29 @@ def fuzz_arrays(rng, batches):
                 if not ok and first_err is not None and any(longish[:e.frame_index - 1]):
                     ok = True   # (a possible hand-back in front: its own verdict decides, which this harness does not restate)
                 what = ("error", e.code, e.frame_index, first_err, want[first_err] if first_err is not None else None)
+            if ok and oid in ARRAYS and not any(longish):
+                # the same cells as BigQuery rows (packed fields; a NULL element fails the batch; a malformed literal is handed back): the
+                # first row that is not plain decides, on both sides
+                from oracle import protobuf as PB
+                o = oracle.Oracle()
+                SC.simple_table(cols)(o)
+                hbo = o.decode(buf, offs).host_batch()
+                try:
+                    prow, _idx, _host = PB.event_rows(hbo.materialize(), 0, cols, "PrimaryKey")
+                    want_pb = ("ok", b"".join(prow))
+                except PB.NullValuesNotSupportedInArrayInDestination as ex:
+                    want_pb = ("null", str(ex))
+                except RB.NeedsHost:
+                    want_pb = ("host",)
+                try:
+                    r = b.protobuf(0)
+                    got_pb = ("host",) if r.status == abi.RB_NEEDS_HOST else ("ok", r.bytes().tobytes())
+                    r.close()
+                except EtlError as e:
+                    got_pb = ("null", e.detail) if e.kind == abi.NullValuesNotSupportedInArrayInDestination else ("err", e.description)
+                if want_pb != got_pb:
+                    ok = False
+                    what = ("protobuf", want_pb[0], got_pb[0], str(want_pb[1:])[:80], str(got_pb[1:])[:80])
             cells += len(texts)
             if not ok:
                 bad += 1
