@@ -870,6 +870,61 @@ DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& co
   return 0;
 }
 
+// The same walk for the row formats' text-like elements (ArrayCell::String / Bytes), which need an element's LENGTH in front of its
+// bytes: elem(k, is_null, p0, p1, ulen) gets the element's source characters s0[p0 .. p1) — quotes and backslashes included — and its
+// unescaped length; arr_unescape() then replays the span. Same checks, same NULL rule (an unquoted, unescaped "null" of any case).
+template <class F>
+DEV uint32_t arr_spans(const u8* s0, uint32_t n0, uint32_t& count, F&& elem) {
+  uint32_t start;
+  count = 0;
+  if (const uint32_t e = arr_strip_dims(s0, n0, start)) return e;
+  const uint32_t n = n0 - start;
+  if (n < 2) return ETLG_E_ARRAY_SHORT;
+  if (s0[start] != '{' || s0[start + n - 1] != '}') return ETLG_E_ARRAY_BRACES;
+  const uint32_t b0 = start + 1, b1 = start + n - 1;   // the body
+  uint32_t pos = b0;
+  bool done = b1 == b0;
+  while (!done) {
+    const uint32_t p0 = pos;
+    uint32_t p1 = b1, vl = 0, low4 = 0;
+    bool in_quotes = false, in_escape = false, val_quoted = false, escaped = false;
+    for (;;) {
+      if (pos >= b1) { done = true; p1 = b1; break; }
+      const u8 c = s0[pos++];
+      bool push = false;
+      if (in_escape) { push = true; in_escape = false; }
+      else if (c == '"') { if (!in_quotes) val_quoted = true; in_quotes = !in_quotes; }
+      else if (c == '\\') { in_escape = true; escaped = true; }
+      else if ((c == '{' || c == '}') && !in_quotes) return ETLG_E_ARRAY_MULTIDIM;
+      else if (c == ',' && !in_quotes) { p1 = pos - 1; break; }
+      else push = true;
+      if (push) { if (vl < 4) low4 |= (uint32_t)(c | 0x20) << (8 * vl); vl++; }
+    }
+    if (in_quotes) return ETLG_E_ARRAY_QUOTE;
+    if (in_escape) return ETLG_E_ARRAY_ESCAPE;
+    const bool is_null = !val_quoted && vl == 4 && low4 == 0x6C6C756Eu;   // "null" (an escaped n\ull is "null" too: the reference compares the unescaped value)
+    (void)escaped;
+    elem(count, is_null, p0, p1, vl);
+    count++;
+  }
+  return 0;
+}
+template <class E>
+DEV void arr_unescape(const u8* s0, uint32_t p0, uint32_t p1, E&& emit) {
+  bool esc = false;
+  for (uint32_t p = p0; p < p1; p++) {
+    const u8 c = s0[p];
+    if (esc) { emit(c); esc = false; } else if (c == '\\') esc = true; else if (c != '"') emit(c);
+  }
+}
+// a bytea element's unescaped text: "\x" + hex pairs (parse_bytea_hex_string, codec/hex.rs:11-52)? Returns the byte count, or ~0u.
+DEV uint32_t arr_bytea_len(const u8* s0, uint32_t p0, uint32_t p1, uint32_t ulen) {
+  if (ulen < 2 || (ulen & 1)) return ~0u;
+  uint32_t k = 0; bool bad = false;
+  arr_unescape(s0, p0, p1, [&](u8 c) { if (k == 0) bad |= c != '\\'; else if (k == 1) bad |= c != 'x'; else bad |= arr_hexv(c) < 0; k++; });
+  return bad ? ~0u : (ulen - 2) >> 1;
+}
+
 DEV bool arr_text(const ColJob& j, uint64_t r, const u8*& s, uint32_t& n, uint32_t& st) {
   const uint64_t b = j.row_base[r];
   st = col_state(j, b);
@@ -995,6 +1050,7 @@ DEV void rb_varint(S& s, uint32_t v) {   // LEB128 (:188-199)
 template <class S>
 DEV void rb_2d(S& s, uint32_t v) { put_2d(s, v); }
 
+constexpr uint32_t kJsonElemMax = 256;   // a json[] element longer than this (unescaped) is left to the host: a lane unescapes it into private memory
 // A json cell as the sinks' `j.to_string()`: `head(len)` writes what goes in front of the string (its varint length). The text is
 // checked in the counting pass only (a row that fails has length 0 and is not written). Returns 0, RB_E_JSON (not one JSON value: the
 // reference fails at decode time, codec/text.rs:126-134), RB_E_HOST_CELL (json_display leaves it to the host), RB_E_BQ_NUMERIC_SCALE.
@@ -1106,19 +1162,68 @@ DEV uint32_t rb_row(const RbJob& j, uint64_t r, S& s, uint32_t c_lo, uint32_t c_
       // Array(Nullable(T)) (:249-254): varint count, then every element with its null marker. The literal (kept as text in the
       // arena) is walked twice: count, then encode. A literal the device cannot take apart is the host's (it raises the exact error).
       const uint32_t elem = (cd >> 9) & 0x7Fu;
-      if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA || elem == ETLG_TC_NUMERIC || elem == ETLG_TC_JSON || elem == ETLG_TC_TIMETZ) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
+      if (elem == ETLG_TC_JSON && !JS) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
       const u8* txt = j.heap + ld32a(slot);
       const uint32_t tn = ld32a(slot + 4);
+      if (JS && elem == ETLG_TC_JSON) {
+        // json[] / jsonb[]: String(j.to_string()) per element (encoding.rs:109). An element is unescaped into private memory (json_display
+        // walks its text back and forth); one that is not JSON is the reference's decode error, as for a scalar cell.
+        u8 tmp[kJsonElemMax];
+        uint32_t cnt = 0, bad = 0;
+        bool too_long = false, bad_json = false, limit = false;   // (an element too long to look at may not be JSON at all: the cell is the host's before anything else)
+        if (arr_spans(txt, tn, cnt, [&](uint32_t, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+              if (is_null) return;
+              if (ulen > kJsonElemMax) { too_long = true; return; }
+              uint32_t k = 0;
+              arr_unescape(txt, p0, p1, [&](u8 c) { tmp[k++] = c; });
+              if (std::is_same<S, RbCount>::value && !json_valid(tmp, ulen)) { bad_json = true; return; }
+              JsCount c;
+              if (json_display(c, tmp, ulen, false)) limit = true;
+            })) too_long = true;
+        bad = too_long ? RB_E_HOST_CELL : bad_json ? RB_E_JSON : limit ? RB_E_HOST_CELL : 0u;
+        if (bad == RB_E_JSON) return (i << 8) | bad;
+        if (bad) { if (!err0) err0 = (i << 8) | bad; continue; }
+        if (nullable) s.put(0);
+        rb_varint(s, cnt);
+        (void)arr_spans(txt, tn, cnt, [&](uint32_t, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+          if (is_null) { s.put(1); return; }
+          s.put(0);
+          uint32_t k = 0;
+          arr_unescape(txt, p0, p1, [&](u8 c) { tmp[k++] = c; });
+          JsCount c;
+          (void)json_display(c, tmp, ulen, false);
+          rb_varint(s, c.n);
+          if (std::is_same<S, RbCount>::value) s.zeros(c.n); else (void)json_display(s, tmp, ulen, false);
+        });
+        continue;
+      }
+      if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA) {
+        // text-like elements are String(the unescaped bytes), bytea elements String(bytes_to_hex(..)) (array_cell_to_clickhouse_values,
+        // encoding.rs:89-111): the lowercase hex digits of the element's own "\x.." text
+        uint32_t cnt = 0; bool bad = false;
+        if (arr_spans(txt, tn, cnt, [&](uint32_t, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+              if (elem == ETLG_TC_BYTEA && !is_null && arr_bytea_len(txt, p0, p1, ulen) == ~0u) bad = true;
+            }) || bad) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
+        if (nullable) s.put(0);
+        rb_varint(s, cnt);
+        (void)arr_spans(txt, tn, cnt, [&](uint32_t, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+          if (is_null) { s.put(1); return; }
+          s.put(0);
+          if (elem == ETLG_TC_STRING) { rb_varint(s, ulen); arr_unescape(txt, p0, p1, [&](u8 c) { s.put(c); }); }
+          else { uint32_t k = 0; rb_varint(s, ulen - 2); arr_unescape(txt, p0, p1, [&](u8 c) { if (k++ >= 2) s.put((u8)(c - 'A' < 6u ? c | 0x20 : c)); }); }
+        });
+        continue;
+      }
       uint32_t cnt = 0;
       auto none = [](uint32_t) -> u8* { return nullptr; };
       if (arr_walk<false>(txt, tn, elem, cnt, [](uint32_t, bool, const uint32_t*, const u8*) {}, none)) { if (!err0) err0 = (i << 8) | RB_E_HOST_CELL; continue; }
       if (nullable) s.put(0);
       rb_varint(s, cnt);
       uint32_t ee = 0;
-      (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w, const u8*) {
+      (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w, const u8* scratch) {
         if (is_null) { s.put(1); return; }
         s.put(0);
-        const uint32_t e1 = rb_scalar(s, elem, (const u8*)w, nullptr);
+        const uint32_t e1 = rb_scalar(s, elem, (const u8*)w, scratch);   // (a numeric element's entry sits in the walk's scratch: String(n.to_string()); timetz: String(t.to_string()))
         if (e1 && !ee) ee = e1;
       }, none);
       if (ee == RB_E_DATE_RANGE) { if (!errd) errd = (i << 8) | ee; }
@@ -1182,9 +1287,46 @@ template <class S> DEV void pb_date(S& s, int32_t days_ce) {
 // byte words), nothing at all for an empty array; date / time / timestamp / uuid leave as one string field per element. The literal is
 // walked once for the element count, the NULLs and the packed length, once for the bytes. A literal the device does not take apart
 // (malformed: the reference's decode error, which the host raises; an element of more than 40 characters) is RB_E_HOST_CELL.
-template <class S>
+template <bool JS, class S>
 DEV uint32_t pb_array(S& s, uint32_t tag, uint32_t elem, const u8* txt, uint32_t tn) {
-  if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA || elem == ETLG_TC_NUMERIC || elem == ETLG_TC_JSON || elem == ETLG_TC_TIMETZ) return RB_E_HOST_CELL;
+  if (elem == ETLG_TC_JSON && !JS) return RB_E_HOST_CELL;
+  if (JS && elem == ETLG_TC_JSON) {   // one string field per element: j.to_string() behind reject_nulls and validate_elements(validate_json_for_bigquery) (validation.rs:185-188)
+    // Which report a cell with several problems gets: an element too long to look at makes the cell the host's (it may not even be JSON);
+    // then the decode error (an element that is not JSON); then the sink's own, in the reference's order — reject_nulls over the whole
+    // array, validate_elements after it; an element beyond json_display's limits last (it could only add the integer rule's report).
+    u8 tmp[kJsonElemMax];
+    uint32_t cnt = 0;
+    bool too_long = false, bad_json = false, has_null = false, bq = false, limit = false;
+    if (arr_spans(txt, tn, cnt, [&](uint32_t, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+          if (is_null) { has_null = true; return; }
+          if (ulen > kJsonElemMax) { too_long = true; return; }
+          uint32_t k = 0;
+          arr_unescape(txt, p0, p1, [&](u8 c) { tmp[k++] = c; });
+          if (std::is_same<S, RbCount>::value && !json_valid(tmp, ulen)) { bad_json = true; return; }
+          JsCount c;
+          const uint32_t e = json_display(c, tmp, ulen, true);
+          if (e) { if (e == JD_BQ_INT) bq = true; else limit = true; return; }
+          if (too_long | bad_json | has_null | bq | limit) return;   // (nothing of this row will be kept)
+          pb_key(s, tag, 2); s.varint64(c.n);
+          if (std::is_same<S, RbCount>::value) s.zeros(c.n); else (void)json_display(s, tmp, ulen, false);
+        })) return RB_E_HOST_CELL;
+    return too_long ? RB_E_HOST_CELL : bad_json ? RB_E_JSON : has_null ? RB_E_BQ_ARRAY_NULL : bq ? RB_E_BQ_NUMERIC_SCALE : limit ? RB_E_HOST_CELL : 0u;
+  }
+  if (elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA) {   // one string / bytes field per element: the unescaped bytes / the decoded bytes
+    uint32_t cnt = 0;
+    bool has_null = false, bad = false;   // (a bytea element that is not "\x" + hex pairs is the reference's decode error — the host raises it — and comes before the sink's NULL rule)
+    if (arr_spans(txt, tn, cnt, [&](uint32_t, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+          if (is_null) { has_null = true; return; }
+          if (elem == ETLG_TC_STRING) { if (!has_null) { pb_key(s, tag, 2); s.varint64(ulen); arr_unescape(txt, p0, p1, [&](u8 c) { s.put(c); }); } return; }
+          const uint32_t nb = arr_bytea_len(txt, p0, p1, ulen);
+          if (nb == ~0u) { bad = true; return; }
+          if (has_null | bad) return;
+          pb_key(s, tag, 2); s.varint64(nb);
+          uint32_t k = 0, hi = 0;
+          arr_unescape(txt, p0, p1, [&](u8 c) { if (k >= 2) { const uint32_t h = (uint32_t)arr_hexv(c); if (k & 1) s.put((u8)((hi << 4) | h)); else hi = h; } k++; });
+        })) return RB_E_HOST_CELL;
+    return bad ? RB_E_HOST_CELL : has_null ? RB_E_BQ_ARRAY_NULL : 0u;
+  }
   const bool packed = elem == ETLG_TC_BOOL || elem == ETLG_TC_I16 || elem == ETLG_TC_I32 || elem == ETLG_TC_U32 || elem == ETLG_TC_I64 ||
                       elem == ETLG_TC_F32 || elem == ETLG_TC_F64 || elem == ETLG_TC_TIMESTAMPTZ;
   auto none = [](uint32_t) -> u8* { return nullptr; };
@@ -1195,16 +1337,24 @@ DEV uint32_t pb_array(S& s, uint32_t tag, uint32_t elem, const u8* txt, uint32_t
     return (uint64_t)w[0];   // bool, oid
   };
   uint32_t cnt = 0, nulls = 0, plen = 0;
-  if (arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w, const u8*) {
+  bool scale_bad = false;
+  if (arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w, const u8* scratch) {
         if (is_null) { nulls++; return; }
         if (elem == ETLG_TC_F32) plen += 4; else if (elem == ETLG_TC_F64) plen += 8; else if (elem == ETLG_TC_BOOL) plen += 1;
         else if (packed) { uint64_t v = value64(w); do { plen++; v >>= 7; } while (v); }
+        else if (elem == ETLG_TC_NUMERIC) {   // validate_elements(validate_numeric_for_bigquery) behind reject_nulls (validation.rs:169-172)
+          const u8* ent = scratch + w[0];
+          if (ent[0] == ETLG_NUM_VALUE && ((uint32_t)ent[4] | ((uint32_t)ent[5] << 8)) > 38u) scale_bad = true;
+        }
       }, none)) return RB_E_HOST_CELL;
   if (nulls) return RB_E_BQ_ARRAY_NULL;
+  if (scale_bad) return RB_E_BQ_NUMERIC_SCALE;
   if (!cnt) return 0;
   if (packed) { pb_key(s, tag, 2); s.varint64(plen); }
-  (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool, const uint32_t* w, const u8*) {
+  (void)arr_walk<false>(txt, tn, elem, cnt, [&](uint32_t, bool, const uint32_t* w, const u8* scratch) {
     switch (elem) {
+      case ETLG_TC_NUMERIC: { const u8* ent = scratch + w[0]; pb_key(s, tag, 2); s.varint64(numeric_str_len(ent)); numeric_str(s, ent); break; }
+      case ETLG_TC_TIMETZ: pb_key(s, tag, 2); s.varint64(timetz_str_len((const u8*)w)); timetz_str(s, (const u8*)w); break;
       case ETLG_TC_BOOL: s.put(w[0] ? 1 : 0); break;
       case ETLG_TC_F32: s.put32(w[0]); break;
       case ETLG_TC_F64: s.put64(((uint64_t)w[1] << 32) | w[0]); break;
@@ -1249,7 +1399,10 @@ DEV uint32_t pb_row(const RbJob& j, uint64_t r, S& s, uint32_t c_lo, uint32_t c_
     const u8* slot = j.fixed + base + off;
     const uint32_t w0 = ld32a(slot);
     if (cls == ETLG_TC_ARRAY) {
-      if (const uint32_t e = pb_array(s, tag, (cd >> 9) & 0x7Fu, j.heap + w0, ld32a(slot + 4))) { if (!err0) err0 = (i << 8) | e; }
+      if (const uint32_t e = pb_array<JS>(s, tag, (cd >> 9) & 0x7Fu, j.heap + w0, ld32a(slot + 4))) {
+        if (e == RB_E_JSON) return (i << 8) | e;
+        if (!err0) err0 = (i << 8) | e;
+      }
       continue;
     }
     switch (cls) {

@@ -647,9 +647,11 @@ void etlg_columns_free(etlg_columns* cols);
  * formatted on the device (PgNumeric Display, crates/etl-postgres/src/numeric.rs:460-560; PgTimeTz, etl-postgres/src/time.rs:113-117,
  * 210-225); so is a json / jsonb cell (`j.to_string()`, encoding.rs:73: serde_json's Display, see ETLG_ROWS_FORMAT_JSON — a cell that
  * is not one JSON value fails the call with ETLG_E_JSON at its event, the reference's decode error, before any report of the sink's own).
- * A slot with an array of numeric / timetz / json / text elements, or a DEFERRED scalar cell / an array literal the device cannot take
- * apart / a json cell beyond json_display's limits in a row, makes the call return status ETLG_RB_NEEDS_HOST (no bytes; host_event /
- * host_column name the first such cell). Arrays of fixed-width elements are encoded as Array(Nullable(T)). */
+ * Arrays of every element class leave as Array(Nullable(T)) (array_cell_to_clickhouse_values, encoding.rs:86-111): fixed-width values,
+ * text-like elements as the unescaped text, numeric / timetz / json elements as their Display strings, bytea elements as bytes_to_hex.
+ * A DEFERRED scalar cell / an array literal the device cannot take apart (malformed: the host raises the reference's decode error; a
+ * numeric / timetz element of more than 40 characters, a json element of more than 256 bytes) / a json cell beyond json_display's
+ * limits in a row makes the call return status ETLG_RB_NEEDS_HOST (no bytes; host_event / host_column name the first such cell). Arrays of fixed-width elements are encoded as Array(Nullable(T)). */
 typedef enum etlg_ch_engine {
   ETLG_CH_MERGE_TREE = 0,           /* + cdc_operation String, cdc_lsn UInt64 */
   ETLG_CH_REPLACING_MERGE_TREE = 1  /* + _etl_version UInt128 (commit_lsn << 64 | tx_ordinal), _etl_deleted UInt8 */
@@ -699,11 +701,12 @@ int32_t etlg_batch_rowbinary(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_sl
  * for BigQuery compatibility", detail "Cell at index N failed validation", frame_index = the event). A json / jsonb cell is its
  * serde_json Display string (encoding.rs:173-176) behind validate_json_for_bigquery (validation.rs:47-85): an integer literal of the
  * parsed value outside u64 / i64 fails the call the same way; a cell that is not one JSON value fails it with ETLG_E_JSON. Array
- * cells of a fixed-width element class (array_cell_encode_prost, encoding.rs:203-290): bool / int2 / int4 / oid / int8 / float4 / float8 /
- * timestamptz packed, date / time / timestamp / uuid one string field per element, an empty array nothing; a NULL element fails the
- * call with ETLG_NullValuesNotSupportedInArrayInDestination (same description and detail). Arrays of text / numeric / timetz / bytea /
- * json elements, a literal the device cannot take apart, DEFERRED cells and json cells beyond json_display's limits return
- * ETLG_RB_NEEDS_HOST.
+ * cells (array_cell_encode_prost, encoding.rs:203-290): bool / int2 / int4 / oid / int8 / float4 / float8 / timestamptz packed; date /
+ * time / timestamp / uuid, text-like, numeric, timetz and json elements one string field per element, bytea elements one bytes field;
+ * an empty array nothing; a NULL element fails the call with ETLG_NullValuesNotSupportedInArrayInDestination (same description and
+ * detail), a numeric element of more than 38 decimal places / a json element's integer outside u64 / i64 with
+ * ETLG_UnsupportedValueInDestination (validate_elements, validation.rs:143-188). A literal the device cannot take apart (see
+ * etlg_batch_rowbinary), DEFERRED cells and json cells beyond json_display's limits return ETLG_RB_NEEDS_HOST.
  * The result is an etlg_rowbinary (same view; n_rows can exceed the number of events). */
 int32_t etlg_batch_protobuf(etlg_ctx* ctx, etlg_batch* batch, int32_t schema_slot, uint32_t flags, etlg_rowbinary** out);
 int32_t etlg_rowbinary_view_get(const etlg_rowbinary* rb, etlg_rowbinary_view* out);

@@ -86,6 +86,31 @@ def cell(c, tag):
         return ld(tag, f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:]}".encode())
     if k == "Deferred" and c[1] in ARRAY_OIDS:        # validate_array_cell_for_bigquery, then array_cell_encode_prost (encoding.rs:203-290)
         return array_cell(c[1], c[2], tag)
+    if k == "Deferred" and c[1] not in (114, 3802):
+        from oracle import arrays
+        if c[1] in arrays.JSON_ARRAY_OIDS:           # json[]: reject_nulls, validate_elements(validate_json_for_bigquery), one string field per element
+            from oracle import json_display as J
+            els = arrays.split_literal(c[1], c[2])
+            if any(e is not None and len(e) > arrays.JSON_ELEM_MAX for e in els):   # (the device does not look at such an element: the host's)
+                raise NeedsHost("a json element too long for the device")
+            if any(e is None for e in els):
+                raise NullValuesNotSupportedInArrayInDestination(f"Cell at index {tag - 1} failed validation")
+            inside = [e for e in els if J.device_limits_ok(e)]
+            for e in inside:
+                try:
+                    validate_json_for_bigquery(e)
+                except UnsupportedValueInDestination:
+                    raise UnsupportedValueInDestination(f"Cell at index {tag - 1} failed validation") from None
+            if len(inside) != len(els):
+                raise NeedsHost("a json element beyond json_display's limits")
+            return b"".join(ld(tag, J.display(e)) for e in els)
+        if c[1] in arrays.VAR_ARRAY_OIDS or arrays.is_string_array(c[1], c[2]):            # one string / bytes field per element (encoding.rs:215-219, 244-249, 262-267, 285-289)
+            items = arrays.elements(c[1], c[2])
+            if any(e is None for e, _ in items):
+                raise NullValuesNotSupportedInArrayInDestination(f"Cell at index {tag - 1} failed validation")
+            if any(sc is not None and sc > 38 for _, sc in items):   # validate_elements(validate_numeric_for_bigquery)
+                raise UnsupportedValueInDestination(f"Cell at index {tag - 1} failed validation")
+            return b"".join(ld(tag, e) for e, _ in items)
     if k == "Deferred" and c[1] in (114, 3802):      # validate_json_for_bigquery, then j.to_string() (encoding.rs:173-176)
         from oracle import json_display
         if not json_display.device_limits_ok(c[2]):

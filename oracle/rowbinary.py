@@ -95,6 +95,12 @@ def value(cell):
         return string(json_display.display(cell[2]))
     if k == "Deferred" and cell[1] in ARRAY_OIDS:   # array columns keep their literal in the arena
         return array(cell[1], cell[2])
+    if k == "Deferred":                              # text-like / numeric / timetz / bytea elements: String(..) each (encoding.rs:89-111; bytea: String(bytes_to_hex))
+        from oracle import arrays
+        if cell[1] in arrays.VAR_ARRAY_OIDS or (cell[1] not in JSON_OIDS and arrays.is_string_array(cell[1], cell[2])):
+            items = arrays.elements(cell[1], cell[2])
+            hexed = cell[1] == arrays.BYTEA_A
+            return varint(len(items)) + b"".join(b"\x01" if e is None else b"\x00" + string(e.hex().encode() if hexed else e) for e, _ in items)
     if k == "EmptyArray":                            # default_cell of an array column: varint count 0 (encoding.rs:249-254)
         return varint(0)
     raise NeedsHost(k)

@@ -221,3 +221,58 @@ def test_bigquery_integer_rule_on_the_device():
         r = b.rowbinary(0, [0, 1, 0, 0], abi.CH_MERGE_TREE)
         assert r.status == abi.RB_OK and r.n_rows == 3
         r.close(); b.close(); d.close()
+
+
+def test_json_arrays_in_the_row_formats():
+    """json[] / jsonb[] cells: String(j.to_string()) per element in RowBinary (clickhouse/encoding.rs:109), one string field per element
+    in protobuf (bigquery/encoding.rs:279-284) behind reject_nulls and validate_elements(validate_json_for_bigquery) — quoting and
+    escapes of the array literal undone first; an element that is not JSON is the decode error; elements beyond a lane's limits
+    (longer than 256 bytes, nested deeper than 16) are handed back."""
+    from etl_amd.decoder import EtlError
+    from oracle import protobuf as PB
+    from oracle import rowbinary as RB
+    q = lambda t: '"' + t.replace("\\", "\\\\").replace('"', '\\"') + '"'     # noqa: E731  (an element as Postgres writes it inside an array literal)
+    docs = [src for src, _ in K.PINNED + K.RESTATED if "123456789012345678901234567890" not in src]
+    lits = ["{" + ",".join(q(t) for t in docs[k:k + 3]) + "}" for k in range(0, len(docs), 3)] + ["{}", "{1,2.50,true,null}", "{NULL," + q('{"b":1,"a":2}') + "}"]
+    cols = [("id", SC.INT8, False, 1), ("ja", 199, True, 0), ("jb", 3807, True, 0)]
+    rows = [[str(i), t, lits[-1 - i]] for i, t in enumerate(lits)] + [[str(len(lits)), W.NULL, W.NULL]]
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    ev = hb.materialize()
+    rrows, idx, host = RB.encode_events(ev, 0, [k.type_class for k in hb.slots[0].cols], [0, 1, 1, 0, 0], abi.CH_MERGE_TREE, "PrimaryKey", None)
+    r = b.rowbinary(0, [0, 1, 1, 0, 0], abi.CH_MERGE_TREE)
+    assert r.status == abi.RB_OK and r.n_rows == len(rows) and r.bytes().tobytes() == b"".join(rrows)
+    r.close()
+    with pytest.raises(EtlError) as ei:                 # the last literals hold a NULL element (the unquoted null, NULL)
+        b.protobuf(0)
+    assert ei.value.kind == abi.NullValuesNotSupportedInArrayInDestination
+    b.close(); d.close()
+    keep = [t for t in lits if "null" not in t.lower().replace('\\"', "")] or lits[:1]
+    rows = [[str(i), t, keep[-1 - i]] for i, t in enumerate(keep)]
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    prow, idx, host = PB.event_rows(hb.materialize(), 0, cols, "PrimaryKey")
+    r = b.protobuf(0)
+    assert r.status == abi.RB_OK and r.n_rows == len(rows) and r.bytes().tobytes() == b"".join(prow)
+    r.close(); b.close(); d.close()
+    for lit, what in (("{" + q("{") + "}", "json"), ("{1," + q("[1,]") + "}", "json"), ("{" + q("[" * 17 + "]" * 17) + "}", "host"), ("{" + q('"' + "x" * 260 + '"') + "}", "host"),
+                      ("{" + q('{"n":18446744073709551616}') + "}", "bq")):
+        buf, offs = _stream([W.insert(42, ["1", "{}", "{}"]), W.insert(42, ["2", lit, "{}"])])
+        hb, b, d = _both(SC.simple_table(cols), buf, offs)
+        for call, fmt in ((lambda: b.rowbinary(0, [0, 1, 1, 0, 0], abi.CH_MERGE_TREE), "rb"), (lambda: b.protobuf(0), "pb")):
+            if what == "json":
+                with pytest.raises(EtlError) as ei:
+                    call()
+                assert ei.value.code == abi.E_JSON and ei.value.frame_index == 2, (lit, fmt)
+            elif what == "bq" and fmt == "pb":
+                with pytest.raises(EtlError) as ei:
+                    call()
+                assert ei.value.kind == abi.UnsupportedValueInDestination and ei.value.detail == "Cell at index 1 failed validation"
+            else:
+                r = call()
+                if what == "host":
+                    assert r.status == abi.RB_NEEDS_HOST and (int(r.view.host_event), r.view.host_column) == (2, 1), (lit, fmt)
+                else:
+                    assert r.status == abi.RB_OK
+                r.close()
+        b.close(); d.close()

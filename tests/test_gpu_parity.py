@@ -143,7 +143,7 @@ def test_type_matrix_table_of_68_columns(mix):
     assert n["fused"] == 1 and n["cells"] == 0 and n["redone"] == 0 and n["multipass"] == 0, n
     if not mix:
         # the hand-off of the same batch: 29 of the 31 array columns come back as list columns parsed on the device (json[] / jsonb[]
-        # stay text: their elements are the host's), with the values the reference's test asserts (replication_stream.rs:613-856)
+        # stay text in the Arrow form), with the values the reference's test asserts (replication_stream.rs:613-856)
         from etl_amd.arrow import columns_to_record_batch
         gd = d.decode(buf, offs, flags=abi.F_NO_CONTROL | abi.F_OUTPUT_ON_DEVICE)
         names = [c[0] for c in synth.TYPE_MATRIX_COLS]
@@ -158,7 +158,25 @@ def test_type_matrix_table_of_68_columns(mix):
                 "num_multirange_arr": ["{[1.0,2.0)}", None, "{[3.0,4.0)}"], "inet_arr": ["192.0.2.1", None, "2001:db8::1"]}
         for k, v in want.items():
             assert rec.column(k)[0].as_py() == v and rec.column(k)[1499].as_py() == v, k
-        cols.close(); gd.close()
+        cols.close()
+        # ... and the whole table as ClickHouse rows: every one of the 68 columns — the 31 array columns (Array(Nullable(T)); text-like,
+        # numeric, timetz, bytea and json elements as strings), json as serde_json's Display — written on the device, byte for byte
+        from oracle import protobuf as PB
+        from oracle import rowbinary as RB
+        flags = [1 if c.nullable else 0 for c in hb.slots[0].cols] + [0, 0]
+        rrows, idx, host = RB.encode_events(ev, 0, [c.type_class for c in hb.slots[0].cols], flags, abi.CH_MERGE_TREE, "PrimaryKey", None)
+        r = gd.rowbinary(0, flags, abi.CH_MERGE_TREE)
+        assert r.status == abi.RB_OK and r.n_rows == len(rrows) == 1500 and host == 0
+        assert r.bytes().tobytes() == b"".join(rrows)
+        r.close()
+        # BigQuery takes no NULL inside an array (the row's arrays hold one): the reference's error for the first such cell of the first row
+        from etl_amd.decoder import EtlError
+        with pytest.raises(PB.NullValuesNotSupportedInArrayInDestination) as oi:
+            PB.event_rows(ev, 0, synth.TYPE_MATRIX_COLS, "PrimaryKey")
+        with pytest.raises(EtlError) as ei:
+            gd.protobuf(0)
+        assert ei.value.kind == abi.NullValuesNotSupportedInArrayInDestination and ei.value.detail == str(oi.value) and ei.value.frame_index == 1
+        gd.close()
     d.close()
 
 

@@ -228,7 +228,8 @@ def test_arrays_of_fixed_width_elements():
     """array_cell_encode_prost (bigquery/encoding.rs:203-290) on the device: bool / int2 / int4 / oid / int8 / float4 / float8 / timestamptz
     arrays PACKED, date / time / timestamp / uuid arrays one string field per element, empty arrays nothing, quoted elements and a
     dimensions prefix; the timestamptz array of the reference's own test against its LITERAL bytes (encoding.rs:451-480); a NULL element
-    fails the batch like reject_nulls (validation.rs:127-141; encoding.rs:372-383); arrays of var-len elements stay with the host."""
+    fails the batch like reject_nulls (validation.rs:127-141; encoding.rs:372-383); text-like / numeric / timetz / bytea elements as one
+    string (bytes) field each, the numeric scale rule inside arrays (encoding.rs:385-404)."""
     from etl_amd.decoder import EtlError
     from tests.golden import bigquery_kats as K
     lits = {"bool": ["{t,f,t}", "{}", "{f}"], "int2": ["{1,-2,32767}", "{-32768}", "{}"], "int4": ["{1,2,3}", "{-1,2147483647,-2147483648}", "[0:2]={7,8,9}"],
@@ -258,7 +259,27 @@ def test_arrays_of_fixed_width_elements():
         assert ei.value.kind == abi.NullValuesNotSupportedInArrayInDestination and ei.value.description == "Cell validation failed for BigQuery compatibility", n
         assert ei.value.detail == "Cell at index 1 failed validation" and ei.value.frame_index == 2
         b.close(); d.close()
-    for oid, lit in ((1009, "{a,b}"), (1231, "{1.5}"), (1001, '{"\\x01"}'), (3807, '{"{}"}'), (1270, "{12:00:00+02}")):   # text[] numeric[] bytea[] jsonb[] timetz[]
+    # text-like / numeric / timetz / bytea elements: one string (bytes) field per element, against oracle/arrays.py
+    from tests.test_gpu_rowbinary import VAR_ARRAY_LITS
+    onames = sorted(VAR_ARRAY_LITS)
+    vcols = [("id", SC.INT8, False, 1)] + [(f"a{o}", o, True, 0) for o in onames]
+    plain = {o: [t for t in VAR_ARRAY_LITS[o] if "null" not in t.lower().replace("\\", "")] for o in onames}     # (no NULL elements)
+    nr = max(len(v) for v in plain.values())
+    vrows = [[str(k)] + [plain[o][k % len(plain[o])] for o in onames] for k in range(nr)] + [[str(nr)] + [W.NULL] * len(onames)]
+    buf, offs = _stream([W.insert(42, r) for r in vrows])
+    hb, b, d = _both(SC.simple_table(vcols), buf, offs)
+    assert _check(hb, b, vcols) == len(vrows)
+    b.close(); d.close()
+    for oid, lit, kind in ((1009, "{a,NULL}", abi.NullValuesNotSupportedInArrayInDestination), (1001, "{NULL}", abi.NullValuesNotSupportedInArrayInDestination),
+                           (1231, "{1.5,nUlL}", abi.NullValuesNotSupportedInArrayInDestination), (1231, "{123.456,1e-39,789.012}", abi.UnsupportedValueInDestination)):
+        buf, offs = _stream([W.insert(42, ["1", "{}"]), W.insert(42, ["2", lit])])          # (the last: encoding.rs:385-404 with the 39 decimal places written short)
+        hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", oid, True, 0)]), buf, offs)
+        with pytest.raises(EtlError) as ei:
+            b.protobuf(0)
+        assert ei.value.kind == kind and ei.value.detail == "Cell at index 1 failed validation" and ei.value.frame_index == 2, (oid, lit)
+        b.close(); d.close()
+    # (the reference's own vector writes the element out — 41 characters, one more than the device parses inside an array: handed back, the host raises)
+    for oid, lit in ((1009, '{a,"b}'), (1001, "{abc}"), (1231, "{" + ",".join(K.NUMERIC_ARRAY_ROUNDING) + "}")):   # malformed literals: handed back (json[]: tests/test_gpu_json_display.py)
         buf, offs = _stream([W.insert(42, ["1", lit])])
         hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", oid, True, 0)]), buf, offs)
         r = b.protobuf(0)

@@ -126,6 +126,38 @@ def test_cells_and_rows_that_stay_with_the_host():
     r.close(); b.close(); d.close()
 
 
+VAR_ARRAY_LITS = {
+    1009: ['{a,"b c",NULL,"null",nUlL}', '{"x\\"y","a,b","{}"}', '{é,"\\\\"}', "{ a , b }", '{"",x}', "{abcd,abcde,nulls,null}", "[0:1]={x,y}", "{}", "{\\n\\ull,n\\ul}",
+           '{"' + "z" * 300 + '",q}'],
+    1015: ["{v1,v2}", "{}"], 1014: ['{"ab  ","c"}'], 1002: ["{a,b}"], 1003: ["{pg_catalog,public}"],
+    1231: ["{12345,-6789,NULL}", "{}", "{1.50,-0.0012000,NaN,1e3,0.000}", '{"Infinity",-Infinity}', "{123456789012345678901234567890.5}", "[2:3]={0,-0}"],
+    1270: ["{12:30:00+02,NULL}", "{}", '{"12:30:00.123456-07:30","00:00:00+15:59:59"}', "{1:2:3+02}"],
+    1001: ['{"\\\\x0102ff",NULL,"\\\\x"}', "{}", '{"\\\\x' + "ab" * 300 + '"}', '{"\\\\xDEADbeef"}'],
+}
+
+
+def test_arrays_of_var_len_elements():
+    """text-like / numeric / timetz / bytea arrays as Array(Nullable(String)) (array_cell_to_clickhouse_values, encoding.rs:89-111: the
+    unescaped text, `n.to_string()`, `t.to_string()`, bytes_to_hex of the decoded bytes): quoting, escapes, the NULL rule (unquoted,
+    unescaped-to "null" of any case), elements longer than anything fixed, the dimensions prefix — against oracle/arrays.py; malformed
+    literals stay with the host (json[]: tests/test_gpu_json_display.py)."""
+    names = sorted(VAR_ARRAY_LITS)
+    cols = [("id", SC.INT8, False, 1)] + [(f"a{o}", o, True, 0) for o in names]
+    n = max(len(v) for v in VAR_ARRAY_LITS.values())
+    rows = [[str(k)] + [VAR_ARRAY_LITS[o][k % len(VAR_ARRAY_LITS[o])] for o in names] for k in range(n)] + [[str(n)] + [W.NULL] * len(names)]
+    buf, offs = _stream([W.insert(42, r) for r in rows] + [W.update(42, rows[1])])
+    hb, b, d = _both(SC.simple_table(cols), buf, offs)
+    for engine in (abi.CH_MERGE_TREE, abi.CH_REPLACING_MERGE_TREE):
+        assert _check(hb, b, [0] + [1] * len(names) + [0, 0], engine) == len(rows) + 1
+    b.close(); d.close()
+    for oid, lit in ((1009, '{a,"b}'), (1009, "{a,{b}}"), (1001, '{"\\\\x0g"}'), (1001, "{abc}"), (1231, "{1.5,x}"), (1231, "{" + "1" * 41 + "}")):
+        buf, offs = _stream([W.insert(42, ["1", "{}"]), W.insert(42, ["2", lit])])
+        hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("a", oid, True, 0)]), buf, offs)
+        r = b.rowbinary(0, [0, 1, 0, 0])
+        assert r.status == abi.RB_NEEDS_HOST and (int(r.view.host_event), r.view.host_column) == (2, 1), (oid, lit)
+        r.close(); b.close(); d.close()
+
+
 @pytest.mark.parametrize("parts", [1, 2, 4])
 def test_rows_split_among_lanes(parts):
     """k_rb_rows writes a row with 1-4 lanes (the host picks by the row count: four for the small batches of this file): the other
@@ -272,11 +304,6 @@ def test_arrays_of_fixed_width_elements():
     hb, b, d = _both(SC.simple_table(cols), buf, offs)
     r = b.rowbinary(0, [0] + [1] * 7 + [0, 0])
     assert r.status == abi.RB_NEEDS_HOST and (int(r.view.host_event), r.view.host_column) == (1, 1)
-    r.close(); b.close(); d.close()
-    buf, offs = _stream([W.insert(42, ["1", "{a}"])])
-    hb, b, d = _both(SC.simple_table([("id", SC.INT8, False, 1), ("t", 1009, True, 0)]), buf, offs)
-    r = b.rowbinary(0, [0, 1, 0, 0])
-    assert r.status == abi.RB_NEEDS_HOST and r.view.host_column == 1
     r.close(); b.close(); d.close()
 
 

@@ -32,3 +32,17 @@ def test_device_limits_model():
     assert J.device_limits_ok("{" + ",".join(f'"k{i}":1' for i in range(64)) + "}")
     assert not J.device_limits_ok("{" + ",".join(f'"k":{i}' for i in range(65)) + "}")       # repeated keys count: the text is what a lane scans
     assert not J.device_limits_ok('[{"\\u0024serde_json::private::Number":"1"}]')
+
+
+def test_json_array_elements():
+    from etl_amd import abi
+    from oracle import arrays as A
+    from oracle.rowbinary import NeedsHost
+    assert A.E_JSON == abi.E_JSON
+    assert A.elements(199, b'{"{\\"b\\":1,\\"a\\":2}",NULL,"[1, 2]",1e5}') == [(b'{"a":2,"b":1}', None), (None, None), (b"[1,2]", None), (b"1e+5", None)]
+    with pytest.raises(A.JsonDecodeError):
+        A.elements(3807, b'{"{"}')
+    with pytest.raises(NeedsHost):
+        A.elements(3807, b'{"' + b"[" * 17 + b"]" * 17 + b'"}')
+    with pytest.raises(NeedsHost):
+        A.elements(199, b'{"\\"' + b"x" * 260 + b'\\""}')
