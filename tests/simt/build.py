@@ -15,7 +15,7 @@ DEPS = KERNEL_SOURCES + ["dev_types.h", "host_state.h", "host_control.inc", "hos
 CXX = os.environ.get("CXX", "g++")
 sys.path.insert(0, ROOT)
 from etl_amd.build import DEFS as PRODUCT_DEFS  # noqa: E402
-FLAGS = ["-std=c++17", "-O1", "-g", "-fPIC", "-fno-strict-aliasing", "-Wno-unknown-pragmas", "-Wno-attributes",
+FLAGS = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-fno-strict-aliasing", "-Wno-unknown-pragmas", "-Wno-attributes",
          "-I", os.path.join(HERE, "include"), "-x", "c++"]
 
 
@@ -45,7 +45,7 @@ def build(force=False, extra_flags=(), lib=LIB):
 
     with ThreadPoolExecutor(4) as ex:
         objs = list(ex.map(one, KERNEL_SOURCES + ["simt.cpp"]))
-    subprocess.check_call([CXX, "-shared", "-o", lib] + objs)
+    subprocess.check_call([CXX, "-shared", "-pthread", "-o", lib] + objs)
     return lib
 
 

@@ -9,10 +9,12 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace simt {
-static std::vector<uint32_t> g_order;   // lane order of the current scheduling round (ETLG_SIMT_ORDER)
 
 namespace {
 
@@ -29,24 +31,41 @@ struct Lane {
   const void* site;
 };
 
-Lane g_lanes[kMaxLanes];
-ucontext_t g_sched;
+// Everything one RESIDENT workgroup owns: its lanes (fibers + their stacks), its LDS, the context of its scheduler loop. The default
+// run has one (workgroups one after the other on the calling thread); ETLG_SIMT_GRID=<n> keeps n of them resident, one per worker
+// thread (see Pool below) — the kernels' `__shared__` arrays are thread_local statics, so each resident workgroup has its own.
+struct BlockCtx {
+  Lane* lanes = nullptr;
+  char* stacks = nullptr;
+  uint8_t* lds = nullptr;
+  ucontext_t sched;
+  std::vector<uint32_t> order;   // lane order of the current scheduling round (ETLG_SIMT_ORDER)
+  uint32_t bid = 0;
+  void alloc() {
+    if (lanes) return;
+    lanes = new Lane[kMaxLanes];
+    stacks = (char*)mmap(nullptr, kStack * kMaxLanes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    lds = (uint8_t*)aligned_alloc(64, 160 * 1024 + 4096);
+  }
+};
+
+BlockCtx g_main;            // the calling thread's workgroup (default mode)
+BlockCtx* g_b = nullptr;    // the workgroup that is running (exactly one thread runs at any time)
 Lane* g_cur = nullptr;
-char* g_stacks = nullptr;
-uint8_t* g_lds = nullptr;
 void (*g_body)(void*) = nullptr;
 void* g_arg = nullptr;
 uint64_t g_ticks = 0;
 bool g_trace = false;
+bool g_multi = false;       // a launch with several resident workgroups is running: s_sleep is a scheduling point
 
-uint32_t g_block = 0;
+uint32_t g_block = 0, g_grid = 0, g_gx = 0;
 
 // ETLG_SIMT_WATCHDOG=<seconds>: a lane that never reaches a rendezvous (a spin on a flag another lane would set)
 // hangs the emulator; the alarm reports where every lane is and aborts.
 void watchdog(int) {
   fprintf(stderr, "simt: watchdog — running lane %u of block %u; lanes waiting (tid: op @line):", g_cur ? g_cur->view.tid : ~0u, g_cur ? g_cur->view.bid : ~0u);
-  for (uint32_t t = 0; t < g_block; t++) {
-    const Lane& L = g_lanes[t];
+  for (uint32_t t = 0; g_b && t < g_block; t++) {
+    const Lane& L = g_b->lanes[t];
     if (L.state == WAIT && (L.op != OP_BAR || t % 64 == 0)) fprintf(stderr, " %u:%d@%u(a=%llx)", t, L.op, (unsigned)((uintptr_t)L.site & 0xFFFFFFFFu), (unsigned long long)L.a);
   }
   fprintf(stderr, "\n");
@@ -59,7 +78,7 @@ void watchdog(int) {
 void tramp() {
   g_body(g_arg);
   g_cur->state = DONE;
-  swapcontext(&g_cur->ctx, &g_sched);
+  swapcontext(&g_cur->ctx, &g_b->sched);
 }
 
 // Resolves one wave-level collective for the lanes `grp` (all of one wave, all at the same site and op).
@@ -113,23 +132,232 @@ void resolve_wave(Lane* wave0, const std::vector<int>& grp) {
 }  // namespace
 
 LaneView* g_view = nullptr;
-uint8_t* dyn_lds() { return g_lds; }
+uint8_t* dyn_lds() { return g_b->lds; }
 uint64_t ticks() { return ++g_ticks; }
 
 uint64_t collective(int op, uint64_t a, uint64_t b, uint64_t c, const void* site) {
   Lane* L = g_cur;
   L->op = op; L->a = a; L->b = b; L->c = c; L->site = site; L->state = WAIT;
-  swapcontext(&L->ctx, &g_sched);
+  swapcontext(&L->ctx, &g_b->sched);
   return L->out;
 }
+
+// s_sleep: the body of every poll loop (look-back words, late carries). With several workgroups resident it hands the processor to
+// another workgroup — the one that is being waited for must get to run; on its own (default mode) there is nobody to wait for.
+void yield_hint() { if (g_multi) collective(OP_YIELD, 0, 0, 0, nullptr); }
+
+namespace {
+
+void init_block(BlockCtx& B, uint32_t bid) {
+  B.alloc();
+  B.bid = bid;
+  for (uint32_t t = 0; t < g_block; t++) {
+    Lane& L = B.lanes[t];
+    L.view = LaneView{t, bid, g_block, g_grid, g_gx};
+    L.state = RUN;
+    getcontext(&L.ctx);
+    L.ctx.uc_stack.ss_sp = B.stacks + (size_t)t * kStack;
+    L.ctx.uc_stack.ss_size = kStack;
+    L.ctx.uc_link = nullptr;
+    makecontext(&L.ctx, tramp, 0);
+  }
+}
+
+// One scheduling round of the running workgroup (g_b == &B): every runnable lane to its next rendezvous (or to the end of the kernel),
+// then one round of releases. Returns false once every lane is done. *yielded: a lane asked for another workgroup to run (yield_hint).
+bool step_block(BlockCtx& B, bool* yielded) {
+  const uint32_t block = g_block, bid = B.bid;
+  const uint32_t nwaves = (block + 63) / 64;
+  Lane* const lanes = B.lanes;
+  // The order in which the lanes of a workgroup run between two rendezvous is not defined on the GPU; ETLG_SIMT_ORDER=reverse | shuffle
+  // makes the emulator take another one than 0, 1, 2, ... (a kernel whose result depends on it has a race: the bytea[] walker of
+  // round 3 had one that only the MI355X showed).
+  bool ran = false;
+  static const char* order_env = getenv("ETLG_SIMT_ORDER");
+  static uint64_t order_rng = 0x9E3779B97F4A7C15ull;
+  std::vector<uint32_t>& ord = B.order;
+  if (ord.size() != block) { ord.resize(block); for (uint32_t t = 0; t < block; t++) ord[t] = t; }
+  if (order_env && order_env[0] == 'r') { for (uint32_t t = 0; t < block; t++) ord[t] = block - 1 - t; }
+  else if (order_env && order_env[0] == 's') {
+    for (uint32_t t = block; t > 1; t--) { order_rng = order_rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(ord[t - 1], ord[(uint32_t)((order_rng >> 33) % t)]); }
+  }
+  for (uint32_t ti = 0; ti < block; ti++) {
+    const uint32_t t = ord[ti];
+    Lane& L = lanes[t];
+    if (L.state != RUN) continue;
+    g_cur = &L; g_view = &L.view;
+    swapcontext(&B.sched, &L.ctx);
+    ran = true;
+  }
+  // lanes inside a poll loop: they go on in the next round (no release in this one — the rest of their wave may be parked at a
+  // collective these lanes have yet to reach), after the workgroups they wait for have had the processor
+  bool any_yield = false;
+  for (uint32_t t = 0; t < block; t++) if (lanes[t].state == WAIT && lanes[t].op == OP_YIELD) { lanes[t].state = RUN; lanes[t].out = 0; any_yield = true; }
+  if (any_yield) { if (yielded) *yielded = true; return true; }
+  uint32_t live = 0, at_bar = 0;
+  for (uint32_t t = 0; t < block; t++) { live += lanes[t].state != DONE; at_bar += lanes[t].state == WAIT && lanes[t].op == OP_BAR; }
+  if (!live) return false;
+  // wave-level rendezvous: a group = the waiting lanes of one wave at one call site. When a wave has
+  // several groups (divergent control flow) the one whose site comes first in the source goes first.
+  bool released = false;
+  std::vector<int> grp;
+  for (uint32_t w = 0; w < nwaves; w++) {
+    Lane* wave0 = lanes + 64 * w;
+    const uint32_t n = std::min<uint32_t>(64, block - 64 * w);
+    // regular collectives first (lowest source site), then — once no lane of the wave is inside a divergent
+    // region any more — the lanes parked at a reconvergence point (ETLG_WAVE_JOIN)
+    const void* best = nullptr;
+    for (int pass = 0; pass < 2 && !best; pass++)
+      for (uint32_t l = 0; l < n; l++) {
+        const Lane& L = wave0[l];
+        if (L.state == WAIT && L.op != OP_BAR && (L.op == OP_JOIN) == (pass == 1) && (!best || L.site < best)) best = L.site;
+      }
+    if (!best) continue;
+    grp.clear();
+    for (uint32_t l = 0; l < n; l++) if (wave0[l].state == WAIT && wave0[l].op != OP_BAR && wave0[l].site == best) grp.push_back((int)l);
+    if (g_trace && wave0[grp[0]].op != OP_JOIN) {
+      uint32_t waiting = 0;
+      for (uint32_t l = 0; l < n; l++) waiting += wave0[l].state == WAIT && wave0[l].op != OP_BAR && wave0[l].op != OP_JOIN;
+      if (waiting != grp.size()) fprintf(stderr, "simt: block %u wave %u: divergent rendezvous, %zu of %u lanes at line %u (op %d)\n", bid, w, grp.size(), waiting, (unsigned)((uintptr_t)best & 0xFFFFFFFFu), wave0[grp[0]].op);
+    }
+    if (wave0[grp[0]].op == OP_JOIN) { for (int l : grp) { wave0[l].out = 0; wave0[l].state = RUN; } released = true; continue; }
+    resolve_wave(wave0, grp);
+    released = true;
+  }
+  if (released) return true;
+  // no wave-level rendezvous pending: everybody alive must be at the workgroup barrier
+  if (at_bar == live) {
+    uint64_t all = 1;
+    for (uint32_t t = 0; t < block; t++) if (lanes[t].state == WAIT) all &= lanes[t].a;
+    for (uint32_t t = 0; t < block; t++) if (lanes[t].state == WAIT) { lanes[t].out = all; lanes[t].state = RUN; }
+    return true;
+  }
+  if (!ran) { fprintf(stderr, "simt: deadlock in block %u (%u live, %u at the barrier)\n", bid, live, at_bar); abort(); }
+  return true;
+}
+
+// ---- several workgroups resident (ETLG_SIMT_GRID=<n>, n >= 2; ETLG_SIMT_GRID_ORDER=shuffle (default) | reverse; ETLG_SIMT_SEED)
+// The GPU keeps many workgroups of a launch resident and runs them in no particular order: a tile of a look-back kernel reads words
+// its predecessors have NOT written yet (what the buffer held before — another launch's words), folds aggregates instead of inclusive
+// prefixes, polls. One workgroup after the other in blockIdx order shows none of that (a stale-descriptor defect of the
+// boundary scan lived through two rounds of green emulator runs). Here n worker threads hold one resident workgroup each; workgroups
+// become resident in blockIdx order (as the dispatcher issues them), exactly ONE thread runs at any time (the emulated memory model
+// stays sequential: no fences are modelled), and the processor changes hands where a workgroup polls (s_sleep), where it ends and —
+// in shuffle order — after a random number of scheduling rounds. reverse: the newest resident workgroup that is not waiting runs
+// first, so every look-back finds its predecessors as late as the protocol allows. A workgroup that polled runs again only after
+// another one has made progress; when all are waiting the oldest one runs (everything before it has completed).
+struct Worker {
+  std::thread th;
+  BlockCtx bc;
+  bool has_block = false, started = false, skip = false;
+};
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<Worker*> w;
+  int turn = -1;          // index of the worker that runs; -1: the launching thread
+  uint32_t next_bid = 0, done = 0;
+  bool reverse = false;
+  uint64_t rng = 0x2545F4914F6CDD1Dull;
+  uint64_t switches = 0, polls = 0, launches = 0;
+  uint32_t draw(uint32_t n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)((rng >> 20) % n); }
+  int pick() {   // (lock held)
+    int best = -1, oldest = -1;
+    uint32_t cands = 0;
+    for (size_t i = 0; i < w.size(); i++) {
+      if (!w[i]->has_block) continue;
+      if (oldest < 0 || w[i]->bc.bid < w[oldest]->bc.bid) oldest = (int)i;
+      if (w[i]->skip) continue;
+      cands++;
+      if (reverse) { if (best < 0 || w[i]->bc.bid > w[best]->bc.bid) best = (int)i; }
+      else if (draw(cands) == 0) best = (int)i;   // reservoir: uniform over the candidates
+    }
+    if (best >= 0) return best;
+    if (oldest < 0) return -1;   // nothing left: back to the launching thread
+    for (Worker* x : w) x->skip = false;
+    return oldest;
+  }
+};
+Pool* g_pool = nullptr;
+
+void worker_main(Pool* P, int idx) {
+  Worker& me = *P->w[(size_t)idx];
+  for (;;) {
+    std::unique_lock<std::mutex> lk(P->m);
+    P->cv.wait(lk, [&] { return P->turn == idx; });
+    lk.unlock();
+    g_b = &me.bc;
+    if (!me.started) { init_block(me.bc, me.bc.bid); me.started = true; }
+    const uint32_t quantum = P->reverse ? 0u : 1u + P->draw(24);
+    bool alive = true, yielded = false;
+    for (uint32_t r = 0;; r++) {
+      alive = step_block(me.bc, &yielded);
+      if (!alive || yielded) break;
+      if (quantum && r + 1 >= quantum) break;
+    }
+    lk.lock();
+    if (!alive) {
+      P->done++;
+      for (Worker* x : P->w) x->skip = false;
+      if (P->next_bid < g_grid) { me.bc.bid = P->next_bid++; me.started = false; }
+      else me.has_block = false;
+    } else if (yielded) { me.skip = true; P->polls++; }
+    else for (Worker* x : P->w) x->skip = false;
+    P->switches++;
+    P->turn = P->pick();
+    lk.unlock();
+    P->cv.notify_all();
+  }
+}
+
+void run_grid_resident(uint32_t nres) {
+  if (!g_pool) {
+    g_pool = new Pool();
+    const char* o = getenv("ETLG_SIMT_GRID_ORDER");
+    g_pool->reverse = o && o[0] == 'r';
+    if (const char* sd = getenv("ETLG_SIMT_SEED")) g_pool->rng ^= (uint64_t)strtoull(sd, nullptr, 0) * 0x9E3779B97F4A7C15ull;
+    if (getenv("ETLG_SIMT_GRID_STATS"))   // how much interleaving a run saw: launches with several resident workgroups, hand-overs, polls that found nothing
+      atexit([] { fprintf(stderr, "simt: %llu launches with resident workgroups, %llu hand-overs, %llu after a poll\n", (unsigned long long)g_pool->launches, (unsigned long long)g_pool->switches, (unsigned long long)g_pool->polls); });
+  }
+  Pool* P = g_pool;
+  {
+    std::unique_lock<std::mutex> lk(P->m);
+    while (P->w.size() < nres) {
+      Worker* x = new Worker();
+      P->w.push_back(x);
+      x->th = std::thread(worker_main, P, (int)P->w.size() - 1);
+      x->th.detach();
+    }
+    P->next_bid = 0; P->done = 0; P->launches++;
+    for (size_t i = 0; i < P->w.size(); i++) {
+      Worker& x = *P->w[i];
+      x.skip = false; x.started = false;
+      x.has_block = i < nres && P->next_bid < g_grid;
+      if (x.has_block) x.bc.bid = P->next_bid++;
+    }
+    g_multi = true;
+    P->turn = P->pick();
+  }
+  P->cv.notify_all();
+  {
+    std::unique_lock<std::mutex> lk(P->m);
+    P->cv.wait(lk, [&] { return P->turn == -1; });
+    g_multi = false;
+    if (P->done != g_grid) { fprintf(stderr, "simt: %u of %u workgroups ran\n", P->done, g_grid); abort(); }
+  }
+}
+
+}  // namespace
 
 void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg, uint32_t gx) {
   if (!gx) gx = grid ? grid : 1;
   if (block > kMaxLanes) { fprintf(stderr, "simt: block of %u lanes\n", block); abort(); }
-  if (!g_stacks) {
-    g_stacks = (char*)mmap(nullptr, kStack * kMaxLanes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    g_lds = (uint8_t*)aligned_alloc(64, 160 * 1024 + 4096);
+  static bool inited = false;
+  static uint32_t resident = 1;
+  if (!inited) {
+    inited = true;
     g_trace = getenv("ETLG_SIMT_TRACE") != nullptr;
+    if (const char* g = getenv("ETLG_SIMT_GRID")) resident = (uint32_t)std::max(1, atoi(g));
     if (const char* wd = getenv("ETLG_SIMT_WATCHDOG")) { signal(SIGALRM, watchdog); alarm((unsigned)atoi(wd)); }
     if (getenv("ETLG_SIMT_SEGV")) {   // a fault inside an emulated kernel: where every lane stands + a backtrace (on a stack of its own: the lanes' stacks are small)
       static char alt[1 << 16];
@@ -138,83 +366,17 @@ void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void
     }
   }
   (void)lds_bytes;
-  g_body = body; g_arg = arg; g_block = block;
-  const uint32_t nwaves = (block + 63) / 64;
-  std::vector<int> grp;
-  for (uint32_t bid = 0; bid < grid; bid++) {
-    for (uint32_t t = 0; t < block; t++) {
-      Lane& L = g_lanes[t];
-      L.view = LaneView{t, bid, block, grid, gx};
-      L.state = RUN;
-      getcontext(&L.ctx);
-      L.ctx.uc_stack.ss_sp = g_stacks + (size_t)t * kStack;
-      L.ctx.uc_stack.ss_size = kStack;
-      L.ctx.uc_link = nullptr;
-      makecontext(&L.ctx, tramp, 0);
-    }
-    for (;;) {
-      // run every runnable lane to its next rendezvous (or to the end of the kernel). The order in which the lanes of a workgroup
-      // run between two rendezvous is not defined on the GPU; ETLG_SIMT_ORDER=reverse | shuffle makes the emulator take another
-      // one than 0, 1, 2, ... (a kernel whose result depends on it has a race: the bytea[] walker of round 3 had one that only
-      // the MI355X showed). Workgroups stay in blockIdx order: the look-back kernels wait for their predecessors.
-      bool ran = false;
-      static const char* order_env = getenv("ETLG_SIMT_ORDER");
-      static uint64_t order_rng = 0x9E3779B97F4A7C15ull;
-      std::vector<uint32_t>& ord = g_order;
-      if (ord.size() != block) { ord.resize(block); for (uint32_t t = 0; t < block; t++) ord[t] = t; }
-      if (order_env && order_env[0] == 'r') { for (uint32_t t = 0; t < block; t++) ord[t] = block - 1 - t; }
-      else if (order_env && order_env[0] == 's') {
-        for (uint32_t t = block; t > 1; t--) { order_rng = order_rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(ord[t - 1], ord[(uint32_t)((order_rng >> 33) % t)]); }
-      }
-      for (uint32_t ti = 0; ti < block; ti++) {
-        const uint32_t t = ord[ti];
-        Lane& L = g_lanes[t];
-        if (L.state != RUN) continue;
-        g_cur = &L; g_view = &L.view;
-        swapcontext(&g_sched, &L.ctx);
-        ran = true;
-      }
-      uint32_t live = 0, at_bar = 0;
-      for (uint32_t t = 0; t < block; t++) { live += g_lanes[t].state != DONE; at_bar += g_lanes[t].state == WAIT && g_lanes[t].op == OP_BAR; }
-      if (!live) break;
-      // wave-level rendezvous: a group = the waiting lanes of one wave at one call site. When a wave has
-      // several groups (divergent control flow) the one whose site comes first in the source goes first.
-      bool released = false;
-      for (uint32_t w = 0; w < nwaves; w++) {
-        Lane* wave0 = g_lanes + 64 * w;
-        const uint32_t n = std::min<uint32_t>(64, block - 64 * w);
-        // regular collectives first (lowest source site), then — once no lane of the wave is inside a divergent
-        // region any more — the lanes parked at a reconvergence point (ETLG_WAVE_JOIN)
-        const void* best = nullptr;
-        for (int pass = 0; pass < 2 && !best; pass++)
-          for (uint32_t l = 0; l < n; l++) {
-            const Lane& L = wave0[l];
-            if (L.state == WAIT && L.op != OP_BAR && (L.op == OP_JOIN) == (pass == 1) && (!best || L.site < best)) best = L.site;
-          }
-        if (!best) continue;
-        grp.clear();
-        for (uint32_t l = 0; l < n; l++) if (wave0[l].state == WAIT && wave0[l].op != OP_BAR && wave0[l].site == best) grp.push_back((int)l);
-        if (g_trace && wave0[grp[0]].op != OP_JOIN) {
-          uint32_t waiting = 0;
-          for (uint32_t l = 0; l < n; l++) waiting += wave0[l].state == WAIT && wave0[l].op != OP_BAR && wave0[l].op != OP_JOIN;
-          if (waiting != grp.size()) fprintf(stderr, "simt: block %u wave %u: divergent rendezvous, %zu of %u lanes at line %u (op %d)\n", bid, w, grp.size(), waiting, (unsigned)((uintptr_t)best & 0xFFFFFFFFu), wave0[grp[0]].op);
-        }
-        if (wave0[grp[0]].op == OP_JOIN) { for (int l : grp) { wave0[l].out = 0; wave0[l].state = RUN; } released = true; continue; }
-        resolve_wave(wave0, grp);
-        released = true;
-      }
-      if (released) continue;
-      // no wave-level rendezvous pending: everybody alive must be at the workgroup barrier
-      if (at_bar == live) {
-        uint64_t all = 1;
-        for (uint32_t t = 0; t < block; t++) if (g_lanes[t].state == WAIT) all &= g_lanes[t].a;
-        for (uint32_t t = 0; t < block; t++) if (g_lanes[t].state == WAIT) { g_lanes[t].out = all; g_lanes[t].state = RUN; }
-        continue;
-      }
-      if (!ran) { fprintf(stderr, "simt: deadlock in block %u (%u live, %u at the barrier)\n", bid, live, at_bar); abort(); }
+  g_body = body; g_arg = arg; g_block = block; g_grid = grid; g_gx = gx;
+  if (resident >= 2 && grid >= 2) run_grid_resident(std::min(resident, grid));
+  else {
+    // workgroups one after the other, in blockIdx order, on the calling thread
+    g_b = &g_main;
+    for (uint32_t bid = 0; bid < grid; bid++) {
+      init_block(g_main, bid);
+      while (step_block(g_main, nullptr)) {}
     }
   }
-  g_cur = nullptr; g_view = nullptr;
+  g_cur = nullptr; g_view = nullptr; g_b = nullptr;
 }
 
 }  // namespace simt

@@ -4,7 +4,8 @@
 // the CPU of a box without a GPU, so that the logic of a kernel change can be checked against the oracle
 // before it costs GPU minutes. The sources are compiled with g++ against this header instead of
 // <hip/hip_runtime.h>; every lane of a workgroup is a fiber (ucontext), workgroups run one after the
-// other in blockIdx order, and wave / workgroup collectives (__syncthreads, __ballot, __shfl*, DPP,
+// other in blockIdx order — or, with ETLG_SIMT_GRID=<n>, n of them resident at a time and interleaved
+// (simt.cpp: what the look-back kernels need to be tested at all) —, and wave / workgroup collectives (__syncthreads, __ballot, __shfl*, DPP,
 // readlane, readfirstlane) are rendezvous points resolved by the scheduler in simt.cpp.
 //
 // What it is NOT: it is not a backend of the product. libetl_gfx950.so never contains it,
@@ -29,7 +30,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local   /* one copy per resident workgroup (simt.cpp: a worker thread each with ETLG_SIMT_GRID) */
 #define DEV_NOINLINE static __attribute__((noinline))
 #define ETLG_DYNAMIC_LDS(name) uint8_t* const name = simt::dyn_lds()
 #define ETLG_CONST_AS   /* one address space on the host */
@@ -50,7 +51,7 @@ struct dim3 { uint32_t x, y, z; dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t 
 
 namespace simt {
 
-enum Op : int { OP_BAR = 1, OP_JOIN, OP_BALLOT, OP_ALL, OP_ANY, OP_READFIRST, OP_READLANE, OP_SHFL, OP_SHFL_UP, OP_SHFL_XOR, OP_DPP, OP_FENCE };
+enum Op : int { OP_BAR = 1, OP_JOIN, OP_BALLOT, OP_ALL, OP_ANY, OP_READFIRST, OP_READLANE, OP_SHFL, OP_SHFL_UP, OP_SHFL_XOR, OP_DPP, OP_FENCE, OP_YIELD };
 
 struct Idx { uint32_t x, y, z; };
 struct LaneView { uint32_t tid, bid, bdim, gdim, gx; };   // bid: linear workgroup index over a grid of gx columns (blockIdx.x) x gdim / gx rows (blockIdx.y)
@@ -60,6 +61,7 @@ uint8_t* dyn_lds();
 uint64_t collective(int op, uint64_t a, uint64_t b, uint64_t c, const void* site);
 void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg, uint32_t gx = 0);
 uint64_t ticks();
+void yield_hint();   // a poll loop's s_sleep: lets another resident workgroup run (ETLG_SIMT_GRID)
 
 static inline Idx tidx() { return Idx{g_view->tid, 0, 0}; }
 static inline Idx bidx() { return Idx{g_view->bid % g_view->gx, g_view->bid / g_view->gx, 0}; }
@@ -136,7 +138,7 @@ static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u));
 }
-static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) { simt::yield_hint(); }
 static inline unsigned long long clock64() { return simt::ticks(); }
 static inline unsigned long long wall_clock64() { return simt::ticks(); }
 template <class T, class U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }

@@ -71,11 +71,13 @@ import os  # noqa: E402
 import time  # noqa: E402
 
 _HW = os.environ.get("ETLG_SIMT_RUN") != "1"
+_EMU_RESIDENT = not _HW and int(os.environ.get("ETLG_SIMT_GRID", "1")) >= 2   # the emulator with several workgroups resident and interleaved (tests/simt/simt.cpp)
+_BIG = (4 << 20) if _HW else int(os.environ.get("ETLG_SIMT_BIG_BYTES", str(1 << 20)))
 BIG_PATHS = {"default": {}, "fused256": {"ETLG_FUSED_KERNEL": "0"}, "fused64": {"ETLG_FUSED_KERNEL": "1"}, "cells": {"ETLG_FUSED_KERNEL": "2"},
              "plan_lookback": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0"}, "plan_pre": {"ETLG_FUSED_KERNEL": "3"}}
 
 
-@pytest.mark.skipif(not _HW, reason="inter-workgroup behaviour: the emulator runs workgroups in order")
+@pytest.mark.skipif(not (_HW or _EMU_RESIDENT), reason="inter-workgroup behaviour: the emulator runs workgroups in order unless ETLG_SIMT_GRID keeps several resident")
 @pytest.mark.parametrize("big_path", sorted(BIG_PATHS))
 @pytest.mark.parametrize("mk", [synth.cfg2, synth.cfg3, synth.cfg5])
 def test_many_tile_batches_mutated_on_hardware(mk, big_path):
@@ -92,12 +94,14 @@ def test_many_tile_batches_mutated_on_hardware(mk, big_path):
     try:
         rng = random.Random(zlib.crc32(f"big/{mk.__name__}/{big_path}".encode()))
         w = mk()
-        buf, offs = w.fill(4 << 20)
+        # three base batches of different streams and sizes in rotation: a look-back word left over from an earlier launch (the descriptor
+        # buffers rotate by four) is then a WRONG word, not the same aggregate again
+        bases = [w.fill(_BIG)] + [mk(seed=0xE71F000 + 97 * k).fill(_BIG * (4 - k) // 4) for k in (1, 2)]
         d = Decoder(0)
         w.register(d, ready=not w.cfg.emit_relations)
         n_err = 0
-        for it in range(8):
-            mb, mo = buf, offs
+        for it in range(9):
+            mb, mo = bases[it % 3]
             for _ in range(rng.choice([0, 1, 1, 2, 3])):
                 mb, mo = _mutate(rng, mb, mo)
             o = oracle.Oracle()
@@ -115,6 +119,44 @@ def test_many_tile_batches_mutated_on_hardware(mk, big_path):
             n_err += rb.err_code != 0
         d.close()
         assert n_err >= 1
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.skipif(not (_HW or _EMU_RESIDENT), reason="inter-workgroup behaviour: the emulator runs workgroups in order unless ETLG_SIMT_GRID keeps several resident")
+@pytest.mark.parametrize("big_path", sorted(BIG_PATHS))
+@pytest.mark.parametrize("mk", [synth.cfg2, synth.cfg3])
+def test_many_tile_batches_back_to_back(mk, big_path):
+    """Clean batches of DIFFERENT streams and sizes back to back on one context, per kernel path: every one of them is decoded by the
+    single-pass kernel alone (no error, no rerun), so a look-back word, ticket or pre-pass prefix that survived from an earlier launch in
+    a rotating buffer — or was read before its tile wrote it — shows up as a wrong offset, ordinal or transaction field against the oracle
+    (the mutated batches above mostly end in the exact-error rerun, which forgives the first attempt)."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    knobs = ("ETLG_FUSED_KERNEL", "ETLG_PLAN_PRE", "ETLG_FORCE_MULTIPASS", "ETLG_PLAN", "ETLG_FUSED_DBG", "ETLG_PLAN_DBG")
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    os.environ.update(BIG_PATHS[big_path])
+    try:
+        # (sizes grow at distance two: launch k + 2 is the one that clears launch k's descriptor buffer for launch k + 4 — orchestrate's
+        # take_descriptors —, and only a clear that covers all of launch k's words is left to the kernel alone)
+        sizes = [_BIG // 2, _BIG // 3, _BIG * 3 // 4, _BIG // 2, _BIG, _BIG * 3 // 4, _BIG, _BIG, _BIG // 5, _BIG]
+        d = Decoder(0)
+        w0 = mk()
+        w0.register(d)
+        for it in range(10 if _HW else 8):
+            w = mk(seed=0xE72A000 + 131 * it)
+            mb, mo = w.fill(sizes[it % len(sizes)])
+            o = oracle.Oracle()
+            w.register(o)
+            d.reset_stream_state()
+            rb, gb = o.decode(mb, mo), d.decode(mb, mo)
+            assert rb.err_code == 0 and gb.error is None, (it, rb.err_code, gb.error)
+            diff = rb.host_batch().diff(gb.host())
+            assert not diff, (it, diff[:4])
+        d.close()
     finally:
         for k in knobs:
             os.environ.pop(k, None)
