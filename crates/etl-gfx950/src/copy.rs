@@ -94,4 +94,68 @@ impl GpuDecoder {
             Err(e) => (Vec::new(), Err(e)),
         }
     }
+
+    /// The ASYNC form: enqueues the staged rows (`ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE`, host input — the library uploads the pinned
+    /// buffers on its copy stream beside the decode of the batch before, include/etlg.h) and returns at once, so that the stream keeps
+    /// filling the next `CopyStaging` while this one decodes (two or three in rotation, like the WAL batcher's ring). The staging
+    /// travels with the handle and comes back from `copy_finish`. Fewer than 32 in flight, finished in issue order.
+    /// Python twin of the call sequence: tests/test_gpu_copy.py::test_copy_async_batches_from_host_buffers.
+    pub fn copy_decode_async(&mut self, schema_slot: u32, staged: CopyStaging) -> Result<CopyInFlight, (CopyStaging, etl::error::EtlError)> {
+        let mut batch = std::ptr::null_mut();
+        let rc = unsafe {
+            etlg_copy_decode(self.ctx, schema_slot as i32, staged.rows.as_ptr(), staged.len, staged.offsets.as_ptr() as *const u32, staged.nrows,
+                             ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE, &mut batch)
+        };
+        if batch.is_null() {
+            let _ = rc;
+            let e = self.last_error();
+            return Err((staged, e));
+        }
+        Ok(CopyInFlight { ctx: self.ctx, batch, staged: Some(staged) })
+    }
+
+    /// Collects a batch issued by `copy_decode_async`: waits for it (`etlg_batch_sync`), copies the arena to the host and materialises
+    /// the rows. Fail-fast like the stream (table_copy.rs:88-92): on a bad row the rows BEFORE it come back with the reference's error;
+    /// the batches behind it are not affected (table-copy batches share no state).
+    pub fn copy_finish(&mut self, f: CopyInFlight) -> (Vec<TableRow>, CopyStaging, EtlResult<()>) {
+        let mut f = f;
+        let batch = std::mem::replace(&mut f.batch, std::ptr::null_mut());
+        let staged = f.staged.take().expect("a batch in flight holds its staging");
+        let rc = unsafe { etlg_batch_sync(self.ctx, batch) };
+        let status = if rc == ETLG_OK { Ok(()) } else { Err(self.last_error()) };
+        if unsafe { etlg_batch_download(self.ctx, batch) } != ETLG_OK {
+            let e = self.last_error();
+            unsafe { etlg_batch_free(batch) };
+            return (Vec::new(), staged, Err(e));
+        }
+        let mut view = std::mem::MaybeUninit::<etlg_batch_view>::uninit();
+        unsafe { etlg_batch_view_get(batch, view.as_mut_ptr()) };
+        let view = unsafe { view.assume_init() };
+        let rows = unsafe { materialize::table_rows(&view) };
+        unsafe { etlg_batch_free(batch) };
+        match rows {
+            Ok(r) => (r, staged, status),
+            Err(e) => (Vec::new(), staged, Err(e)),
+        }
+    }
+}
+
+/// A table-copy batch in flight. Dropping it without `copy_finish` frees the batch FIRST (the library waits for its kernels and its
+/// upload: `etlg_batch_free` finishes a pending batch) and only then the pinned staging — the order `InFlight` keeps for WAL batches
+/// (lib.rs; exercised by tests/native/shim_twin.cpp).
+pub struct CopyInFlight {
+    ctx: *mut etlg_ctx,
+    batch: *mut etlg_batch,
+    staged: Option<CopyStaging>,
+}
+
+impl Drop for CopyInFlight {
+    fn drop(&mut self) {
+        let _ = self.ctx;
+        if !self.batch.is_null() {
+            unsafe { etlg_batch_free(self.batch) };
+            self.batch = std::ptr::null_mut();
+        }
+        self.staged.take();
+    }
 }

@@ -69,6 +69,9 @@ void launch_copy(etlg_ctx* c, const CopyJob& j, const DecParams& p) {
 // the rows are rewritten (copy.hip, with the reference's row-level errors) and every parameter that named the rows names the frames.
 int32_t copy_use_frames(etlg_ctx* c, etlg_batch* b) {
   CopyJob& j = b->copy;
+  // the frame buffers are the context's own: an ASYNC batch that needs them (k_cells cannot take its schema, or a kernel is forced) lets
+  // everything enqueued before it finish — an earlier batch may still be reading them
+  if (j.async) HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, c->d_copy_out.ensure(j.syn_len + 64)); HIPCHK(c, c->d_copy_out_offs.ensure(((size_t)j.nrows + 1) * 4));
   j.d_out = (uint8_t*)c->d_copy_out.p; j.d_out_offs = (uint32_t*)c->d_copy_out_offs.p;
   j.direct = false;
@@ -754,9 +757,6 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
   { const int32_t rc_ = flush_deferred(c); (void)rc_; }
   if (!c || !out || !row_offsets) return ETLG_InvalidArgument;
   *out = nullptr;
-  // ASYNC batches still in flight finish first: finish_batch writes the stream state they leave into the context, and the
-  // rows below decode inside a virtual transaction that must neither see that state nor be overwritten by it
-  { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; }
   clear_error(c);
   if (schema_slot < 0 || (size_t)schema_slot >= c->slots.size()) return lib_error(c, ETLG_InvalidArgument, "unknown schema slot");
   const SlotHost& sh = *c->slots[(size_t)schema_slot];
@@ -769,17 +769,44 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
   hipStream_t s = c->stream;
   CopyJob j;
   j.active = true; j.slot = schema_slot; j.nrows = (uint32_t)nrows; j.ncols = ncols; j.rel_id = sh.desc.table_id; j.rows_len = len;
+  j.syn_len = syn_len;
+  // first attempt: the rows go straight into the arena (k_copy_cells, cells.hip); a batch with anything unusual in it — a malformed
+  // row, rows that do not fit a tile's window — fails there and is decoded again through the row -> frame rewrite below
+  j.direct = c->copy_direct && nrows != 0 && len < (1ull << 31) && !c->force_multipass && ncols <= etlg_k_cells_maxc();
+  // ASYNC (the reference's caller streams rows continuously, postgres/stream/table_copy.rs:78-99): the batch is enqueued behind the
+  // table-copy batches already in flight — they share nothing but the stream: every batch decodes inside a virtual transaction of its
+  // own — and etlg_batch_sync finishes it. Only the rows -> arena kernel is enqueued that way; what it leaves to the frame rewrite
+  // (the context's shared buffers) is done when the batch is synced.
+  j.async = (flags & ETLG_F_ASYNC) && (flags & ETLG_F_OUTPUT_ON_DEVICE) && j.direct;
+  // Batches of the OTHER kind still in flight finish first: finish_batch writes the stream state a WAL batch leaves into the context,
+  // and the rows below must neither see that state nor be chained to it. (A synchronous call finishes everything, as before.)
+  bool drain = !j.async;
+  for (const etlg_batch* pb : c->pending) if (!pb->copy.active) drain = true;
+  if (drain) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
+  // (a staging block / event `j` still holds when the call returns — an early return, or a decode that failed before there was a batch
+  // to adopt them — goes back to the pools)
+  struct StageGuard { etlg_ctx* c; CopyJob& j; ~StageGuard() { if (j.stage_blk) blk_give(c, c->gen, j.stage_blk, j.stage_cap, false); if (j.h2d_done) c->ev_pool.push_back(j.h2d_done); } } stage_guard{c, j};
   if (in_dev) { j.d_rows = buf; j.d_row_offs = row_offsets; }
-  else {
+  else if (j.async) {
+    // host rows: uploaded into a device block the batch owns, on the copy stream, beside the decode of the batch before it (the caller
+    // keeps buf / row_offsets untouched until the batch is synced, as for every ASYNC batch: include/etlg.h)
+    const size_t o_offs = (len + 16 + 255) & ~(size_t)255;
+    HIPCHK(c, blk_take(c, o_offs + (nrows + 1) * 4 + 64, false, &j.stage_blk, &j.stage_cap));
+    if (!c->h2d_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+    if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
+    j.h2d_done = c->ev_pool.back(); c->ev_pool.pop_back();
+    if (len) HIPCHK(c, hipMemcpyAsync(j.stage_blk, buf, len, hipMemcpyHostToDevice, c->h2d_stream));
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)j.stage_blk + o_offs, row_offsets, (nrows + 1) * 4, hipMemcpyHostToDevice, c->h2d_stream));
+    HIPCHK(c, hipEventRecord(j.h2d_done, c->h2d_stream));
+    HIPCHK(c, hipStreamWaitEvent(s, j.h2d_done, 0));
+    j.d_rows = (const uint8_t*)j.stage_blk; j.d_row_offs = (const uint32_t*)((const uint8_t*)j.stage_blk + o_offs);
+    c->staged_async++;
+  } else {
     HIPCHK(c, c->d_copy_in.ensure(len + 64)); HIPCHK(c, c->d_copy_offs.ensure((nrows + 1) * 4));
     if (len) HIPCHK(c, hipMemcpyAsync(c->d_copy_in.p, buf, len, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_copy_offs.p, row_offsets, (nrows + 1) * 4, hipMemcpyHostToDevice, s));
     j.d_rows = (const uint8_t*)c->d_copy_in.p; j.d_row_offs = (const uint32_t*)c->d_copy_offs.p;
   }
-  j.syn_len = syn_len;
-  // first attempt: the rows go straight into the arena (k_copy_cells, cells.hip); a batch with anything unusual in it — a malformed
-  // row, rows that do not fit a tile's window — fails there and is decoded again through the row -> frame rewrite below
-  j.direct = c->copy_direct && nrows != 0 && len < (1ull << 31) && !c->force_multipass && ncols <= etlg_k_cells_maxc();
   if (!j.direct) {
     HIPCHK(c, c->d_copy_out.ensure(syn_len + 64)); HIPCHK(c, c->d_copy_out_offs.ensure((nrows + 1) * 4));
     j.d_out = (uint8_t*)c->d_copy_out.p; j.d_out_offs = (uint32_t*)c->d_copy_out_offs.p;
@@ -788,27 +815,17 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
   const uint64_t avg = nrows ? (len + nrows - 1) / nrows : 0;
   j.lds = (uint32_t)std::min<uint64_t>(((256 * avg * 9 / 8 + 1024) + 255) & ~255ull, 150 * 1024);
   { const char* e = getenv("ETLG_COPY_LDS"); if (e) j.lds = (uint32_t)atoi(e); }   // measurement knob: 0 = rows read in place (no staging window, more waves per CU)
-  // the rows decode inside a virtual transaction of their own; the context's stream state is left alone
+  // the rows decode inside a virtual transaction of their own; the context's stream state is left alone (finish_batch keeps it
+  // that way for a batch that is finished later)
   const bool sv_in = c->in_txn; const uint64_t sv_lsn = c->final_lsn, sv_ord = c->next_ord;
   c->in_txn = true; c->final_lsn = 0; c->next_ord = 0;
   c->copy = j;
-  const int32_t rc = j.direct ? etlg_decode(c, j.d_rows, len, j.d_row_offs, nrows, (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL, out)
-                              : etlg_decode(c, j.d_out, (size_t)syn_len, j.d_out_offs, nrows,
-                                            (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL, out);
+  const uint32_t dflags = (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL | (j.async ? (uint32_t)ETLG_F_ASYNC : 0u);
+  const int32_t rc = j.direct ? etlg_decode(c, j.d_rows, len, j.d_row_offs, nrows, dflags, out)
+                              : etlg_decode(c, j.d_out, (size_t)syn_len, j.d_out_offs, nrows, dflags, out);
+  j.stage_blk = c->copy.stage_blk; j.h2d_done = c->copy.h2d_done;   // (nullptr once the batch has adopted them: etlg_decode)
   c->copy = CopyJob{};
   c->in_txn = sv_in; c->final_lsn = sv_lsn; c->next_ord = sv_ord;
-  if (*out) {
-    // TableCopyPayloadMetadata: the bytes of the rows that were decoded
-    etlg_batch* b = *out;
-    const uint64_t done = b->v.n_frames;
-    uint32_t o[2] = {0, 0};
-    if (rc == ETLG_OK && j.direct && b->copy.direct && done == nrows && b->used_cells && b->copy_span) { o[1] = b->copy_span; }   // the rows -> arena kernel measured them (no device round trips here)
-    else if (in_dev) {
-      (void)hipMemcpy(&o[0], row_offsets, 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&o[1], row_offsets + done, 4, hipMemcpyDeviceToHost);
-    } else { o[0] = row_offsets[0]; o[1] = row_offsets[done]; }
-    b->v.payload_bytes[0] = o[1] - o[0]; b->v.payload_bytes[1] = 0; b->v.payload_bytes[2] = 0;
-  }
   return rc;
 }
 
@@ -825,6 +842,9 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   const bool out_dev = flags & ETLG_F_OUTPUT_ON_DEVICE;
   const bool no_ctrl = flags & ETLG_F_NO_CONTROL;
   const bool scan = frame_offsets == nullptr;
+  // ASYNC table-copy batches still in flight (etlg_copy_decode) finish before a WAL batch is taken: a chained batch would read the state
+  // the last of them leaves — the end of a virtual transaction — as its carried transaction state
+  if (!c->copy.active) for (const etlg_batch* pb : c->pending) if (pb->copy.active) { const int32_t rc_ = flush_deferred(c); (void)rc_; const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); break; }
   // Can this call turn out to be one that HOLDS the deferred batch (sends its own control pre-pass out first, see `hold` below)? If not,
   // the deferred batch is flushed right here, before this batch's upload is put in front of the decode streams: its control pass and
   // decode kernels must not queue behind the copy of the batch after it (the upload / decode overlap the staging exists for).
@@ -865,7 +885,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   // Without the caller's no-control assertion the first attempt is optimistic as long as the stream has not been carrying Relation /
   // DDL frames (a control frame then fails the batch with a hint and finish_batch takes the control path); on a stream that does
   // carry them (last_had_ctrl) the control pre-pass runs ahead on its own stream (ctl_begin) — that needs the sidecar.
-  const bool async_ok = (flags & ETLG_F_ASYNC) && out_dev && in_dev && !c->copy.active && !c->force_multipass && len < (1ull << 31);
+  const bool async_ok = (flags & ETLG_F_ASYNC) && out_dev && in_dev && (!c->copy.active || c->copy.async) && !c->force_multipass && len < (1ull << 31);
   // (the pre-pass + host control plane of this batch may only run ahead of batches that are themselves on the control path: each of
   // those holds a snapshot of the control state it started from. An OPTIMISTIC batch still pending — enqueued before the context knew
   // the stream carries Relation / DDL frames — may have to be decoded again when it is synced, against the schemas of ITS position in
@@ -903,6 +923,10 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   b->user_no_ctrl = no_ctrl; b->out_dev = out_dev; b->in_dev = in_dev; b->scan = scan; b->len = len;
   b->stage_blk = stage_blk; b->stage_cap = stage_cap; b->h2d_done = h2d_done;   // the batch owns them from here (etlg_batch_free)
   stage_blk = nullptr; h2d_done = nullptr;
+  if (c->copy.active && c->copy.stage_blk) {   // an ASYNC table-copy batch whose rows were staged by etlg_copy_decode: likewise
+    b->stage_blk = c->copy.stage_blk; b->stage_cap = c->copy.stage_cap; b->h2d_done = c->copy.h2d_done;
+    c->copy.stage_blk = nullptr; c->copy.h2d_done = nullptr;
+  }
   b->host_in = in_dev ? nullptr : buf; b->host_offs = (in_dev || scan) ? nullptr : h_offs; b->dev_in = in_dev ? buf : nullptr;
   b->d_in_ptr = d_in_ptr; b->user_offs = frame_offsets;
   if (scan) {
@@ -1044,7 +1068,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   // carried transaction state: the host's (every earlier batch is finished), or — behind pending ASYNC batches — whatever the
   // batch issued just before this one leaves in its result block
   p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
-  p.carry = (async && prev) ? prev->d_res_blk : nullptr;
+  p.carry = (async && prev && !c->copy.active) ? prev->d_res_blk : nullptr;   // (table-copy batches: a virtual transaction each, nothing carried)
 
   HIPCHK(c, c->d_res.ensure(sizeof(DevResult) * etlg_ctx::kResRing));
   const uint32_t res_slot = c->res_seq % etlg_ctx::kResRing;

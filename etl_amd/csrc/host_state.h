@@ -236,6 +236,10 @@ struct CopyJob {
   uint8_t* d_out = nullptr; uint32_t* d_out_offs = nullptr;
   bool direct = false;      // first attempt: rows -> arena in one kernel (k_copy_cells); a batch that fails there is decoded again through the frames
   uint64_t syn_len = 0;     // bytes of the Insert frames the rows rewrite to (sizes d_out and the arenas)
+  bool async = false;       // etlg_copy_decode with ETLG_F_ASYNC: enqueued only, finished by etlg_batch_sync (rows -> arena kernel only)
+  // ASYNC with host input: the rows and their offsets were uploaded into a device block of the batch's own, on the copy stream; the
+  // batch adopts both in etlg_decode (whatever is still set afterwards is given back by etlg_copy_decode)
+  void* stage_blk = nullptr; size_t stage_cap = 0; hipEvent_t h2d_done = nullptr;
 };
 
 // One uploaded copy of the side inputs (table states + cache timeline, schema slots + columns, the fixed-width plan's tables):

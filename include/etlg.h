@@ -324,7 +324,17 @@ const etlg_error* etlg_last_error(const etlg_ctx* ctx);
  * nullability, as in the reference. Fail-fast: the first bad row ends the batch with the
  * reference's error; rows before it are valid. The stream state of the context
  * (transaction carry) is not touched.
- * flags: ETLG_F_INPUT_ON_DEVICE, ETLG_F_OUTPUT_ON_DEVICE. */
+ * flags: ETLG_F_INPUT_ON_DEVICE, ETLG_F_OUTPUT_ON_DEVICE, ETLG_F_ASYNC.
+ * ETLG_F_ASYNC (with ETLG_F_OUTPUT_ON_DEVICE): enqueue only — the reference's caller streams rows continuously
+ * (crates/etl/src/postgres/stream/table_copy.rs:78-99; the table-sync worker batches them, crates/etl/src/replication/table_sync/copy.rs) and
+ * the next batch can be handed over while this one decodes. The call returns with the batch in flight; etlg_batch_sync finishes it
+ * (counts, error, payload_bytes become valid then). Batches are synced in issue order, fewer than 32 in flight per context, as for
+ * etlg_decode. Table-copy batches are independent of each other (a virtual transaction each): a batch that ends in an error does not
+ * touch the batches behind it. Host rows are uploaded into a device block the batch owns, on a copy stream beside the decode of the
+ * batch before it — truly asynchronous only from pinned memory (etlg_host_alloc); the caller keeps buf / row_offsets untouched (and
+ * device-resident input alive) until the batch is synced. What the rows -> arena kernel leaves to the frame rewrite (a malformed row,
+ * rows wider than a tile's window) is redone when the batch is synced. Mixing kinds on one context is allowed and serialises: a WAL
+ * batch (etlg_decode) finishes the table-copy batches in flight first, and the other way round. */
 int32_t etlg_copy_decode(etlg_ctx* ctx, int32_t schema_slot, const uint8_t* buf, size_t len,
                          const uint32_t* row_offsets, size_t nrows, uint32_t flags, etlg_batch** out);
 

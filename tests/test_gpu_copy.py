@@ -353,3 +353,114 @@ def test_copy_wide_tables(ncols):
     assert_same(rb, gb)
     assert d.debug_copy() == {"direct": 1, "frames": 0}
     d.close()
+
+
+# ---- the ASYNC form (etlg_copy_decode with ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE): the reference's caller streams rows continuously
+#      (crates/etl/src/postgres/stream/table_copy.rs:78-99); batches are enqueued back to back and finished by etlg_batch_sync
+def _copy_ctx(cols=GEN_COLS):
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    o, d = oracle.Oracle(), Decoder(0)
+    for t in (o, d):
+        t.schema_put(42, 0, cols)
+    so = o.table_ready(42, 0, [1] * len(cols), [1 if c[3] else 0 for c in cols])
+    sd = d.table_ready(42, 0, [1] * len(cols), [1 if c[3] else 0 for c in cols])
+    assert so == sd >= 0
+    return o, d, so, sd
+
+
+def _rows_np(rows):
+    return np.frombuffer(b"".join(rows), dtype=np.uint8), np.cumsum([0] + [len(r) for r in rows]).astype(np.uint32)
+
+
+ASYNC = abi.F_ASYNC | abi.F_OUTPUT_ON_DEVICE
+
+
+def test_copy_async_batches_from_host_buffers():
+    """Six batches of different sizes enqueued without a sync in between (host rows: each is uploaded into a block of its own beside the
+    decode of the batch before it), the third with a malformed row, synced in issue order: every batch as the oracle has it — the bad
+    one ends at its row with the reference's error and does not disturb the batches behind it —, payload metadata included."""
+    o, d, so, sd = _copy_ctx()
+    batches = []
+    for k, n in enumerate([700, 64, 1500, 1, 333, 900]):
+        rows = _gen_rows(n, 100 + k)
+        if k == 2:
+            rows[1234] = rows[1234].replace(b"\t", b"\t\t", 1)
+        batches.append(_rows_np(rows))
+    staged0 = d.debug_staged()
+    inflight = [d.copy_decode(sd, buf, offs, flags=ASYNC) for buf, offs in batches]
+    assert all(g.rc == 0 for g in inflight)                      # enqueued only
+    assert d.debug_staged() - staged0 == len(batches)
+    for k, ((buf, offs), g) in enumerate(zip(batches, inflight)):
+        rb = o.copy_decode(so, buf, offs)
+        g.sync()
+        assert (g.rc != 0) == (k == 2)
+        assert_same(rb, g)
+        assert g.view().payload_bytes[0] == (int(offs[1234]) if k == 2 else len(buf))
+    assert d.debug_copy()["direct"] == len(batches) - 1 and d.debug_paths()["chain_rerun"] == 0
+    d.close()
+
+
+def test_copy_async_leaves_the_stream_state_alone():
+    """WAL batches and ASYNC table-copy batches on one context: a transaction left open by a WAL batch is still open — same commit LSN,
+    next ordinal — after copy batches were enqueued and finished in between, and a WAL batch issued while copy batches are in flight
+    finishes them first instead of chaining to their virtual transaction."""
+    from tests import pgwire as W
+    o, d, so, sd = _copy_ctx()
+    for t in (o, d):
+        t.table_state(42, abi.TS_READY)
+    vals = [r.decode() for r in [b"1", b"2", b"t", b"1", b"x", b"y", b"2024-01-01 00:00:00+00", b"123e4567-e89b-12d3-a456-426614174000", b"1.5", b"\\x00"]]
+    s = SC.txn([W.insert(42, vals), W.insert(42, vals)])
+    whole = np.frombuffer(s.bytes(), dtype=np.uint8)
+    offs = np.asarray(s.offsets, dtype=np.uint32)
+    cut = 2                                                       # Begin + first Insert | second Insert + Commit
+    a, ao = whole[:offs[cut]], offs[:cut + 1]
+    b, bo = whole[offs[cut]:], offs[cut:] - offs[cut]
+    r1, g1 = o.decode(a, ao), d.decode(a, ao)
+    assert r1.err_code == 0 and g1.rc == 0 and not r1.host_batch().diff(g1.host())
+    cb = [_rows_np(_gen_rows(n, 7 + n)) for n in (400, 90)]
+    inflight = [d.copy_decode(sd, x, xo, flags=ASYNC) for x, xo in cb]
+    g2 = d.decode(b, bo)                                          # finishes the copy batches first
+    r2 = o.decode(b, bo)
+    assert r2.err_code == 0 and g2.rc == 0 and not r2.host_batch().diff(g2.host())
+    for (x, xo), g in zip(cb, inflight):
+        assert g.sync() == 0
+        assert_same(o.copy_decode(so, x, xo), g)
+    d.close()
+
+
+def test_copy_async_rows_the_direct_kernel_leaves_to_the_frame_path():
+    """An ASYNC batch whose rows the rows -> arena kernel hands back (a row of several KB beside short ones: the tile's window) is redone
+    through the frame rewrite when it is synced — the context's shared frame buffers — while the batches behind it stay in flight."""
+    cols = [("a", 25, -1, False), ("b", 25, -1, False)]
+    o, d, so, sd = _copy_ctx(cols)
+    sets = [_fuzz_rows(31, 300), _fuzz_rows(32, 50), _fuzz_rows(33, 700)]
+    sets[1][7] = sets[1][7][:-1] + b"\\\n"                         # a trailing backslash: a row-level error of the frame path
+    batches = [_rows_np(r) for r in sets]
+    inflight = [d.copy_decode(sd, buf, offs, flags=ASYNC) for buf, offs in batches]
+    for (buf, offs), g in zip(batches, inflight):
+        rb = o.copy_decode(so, buf, offs)
+        g.sync()
+        assert_same(rb, g)
+    assert d.debug_copy()["frames"] >= 1
+    d.close()
+
+
+def test_copy_async_device_resident_rows():
+    import torch
+    o, d, so, sd = _copy_ctx()
+    keep, inflight, want = [], [], []
+    for k, n in enumerate([3000, 10, 1200, 2500]):
+        buf, offs = _rows_np(_gen_rows(n, 40 + k))
+        tb = torch.from_numpy(buf.copy()).cuda()
+        to = torch.from_numpy(offs.view(np.int32).copy()).cuda()
+        keep.append((tb, to))
+        want.append((buf, offs))
+    torch.cuda.synchronize()
+    for (tb, to), (buf, offs) in zip(keep, want):
+        inflight.append(d.copy_decode_device(sd, tb.data_ptr(), tb.numel(), to.data_ptr(), len(offs) - 1, flags=ASYNC))
+    for (buf, offs), g in zip(want, inflight):
+        assert g.sync() == 0 and g.view().payload_bytes[0] == len(buf)
+        assert not o.copy_decode(so, buf, offs).host_batch().diff(g.host())
+    assert d.debug_copy()["direct"] == 4
+    d.close()
