@@ -72,6 +72,7 @@ static void check_lookback(const char* name, uint32_t tile, int incl_group /* ne
   }
   uint32_t fail = 0; uint64_t out = ~0ull;
   hipLaunchKernelGGL(k_lookback<Op>, dim3(1), dim3(64), 0, 0, desc.data(), gdesc.data(), tile, agg[tile], carry, &fail, &out);
+  (void)hipStreamSynchronize(0);
   CHECK(fail == 0, "%s tile %u: gave up", name, tile);
   CHECK(out == want, "%s tile %u incl_group %d: %llx != %llx", name, tile, incl_group, (unsigned long long)out, (unsigned long long)want);
   CHECK(desc[tile] == (ST_AGG | agg[tile]), "%s tile %u: own aggregate not published", name, tile);
@@ -101,6 +102,7 @@ int main() {
   uint64_t r = 88172645463325252ull;
   for (auto& x : in) { r ^= r << 13; r ^= r >> 7; r ^= r << 17; x = (uint32_t)r; }
   hipLaunchKernelGGL(k_scans, dim3(G), dim3(B), 0, 0, in.data(), a.data(), m.data(), s.data(), blk.data(), tot.data());
+  (void)hipStreamSynchronize(0);
   for (uint32_t w = 0; w < N / 64; w++) {
     uint32_t acc = 0, mx = 0, seg = 0;
     for (uint32_t l = 0; l < 64; l++) {
@@ -119,6 +121,7 @@ int main() {
   }
   std::vector<uint32_t> o(4 * 128);
   hipLaunchKernelGGL(k_misc, dim3(1), dim3(128), 0, 0, o.data());
+  (void)hipStreamSynchronize(0);
   for (uint32_t t = 0; t < 128; t++) {
     const uint32_t lane = t & 63, w0 = t & ~63u;
     unsigned long long b = 0; for (int l = 0; l < 64; l++) if (l % 3 == 0) b |= 1ull << l;

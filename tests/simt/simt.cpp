@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -144,7 +146,8 @@ uint64_t collective(int op, uint64_t a, uint64_t b, uint64_t c, const void* site
 
 // s_sleep: the body of every poll loop (look-back words, late carries). With several workgroups resident it hands the processor to
 // another workgroup — the one that is being waited for must get to run; on its own (default mode) there is nobody to wait for.
-void yield_hint() { if (g_multi) collective(OP_YIELD, 0, 0, 0, nullptr); }
+namespace { bool lazy_poll_wanted(); }
+void yield_hint() { if (g_multi || lazy_poll_wanted()) collective(OP_YIELD, 0, 0, 0, nullptr); }
 
 namespace {
 
@@ -349,6 +352,8 @@ void run_grid_resident(uint32_t nres) {
 
 }  // namespace
 
+namespace { void lazy_poll_progress(); extern uint32_t g_depth; extern bool g_resident_mode; BlockCtx* depth_ctx(); }
+
 void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void*), void* arg, uint32_t gx) {
   if (!gx) gx = grid ? grid : 1;
   if (block > kMaxLanes) { fprintf(stderr, "simt: block of %u lanes\n", block); abort(); }
@@ -358,6 +363,7 @@ void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void
     inited = true;
     g_trace = getenv("ETLG_SIMT_TRACE") != nullptr;
     if (const char* g = getenv("ETLG_SIMT_GRID")) resident = (uint32_t)std::max(1, atoi(g));
+    g_resident_mode = resident >= 2;
     if (const char* wd = getenv("ETLG_SIMT_WATCHDOG")) { signal(SIGALRM, watchdog); alarm((unsigned)atoi(wd)); }
     if (getenv("ETLG_SIMT_SEGV")) {   // a fault inside an emulated kernel: where every lane stands + a backtrace (on a stack of its own: the lanes' stacks are small)
       static char alt[1 << 16];
@@ -367,16 +373,224 @@ void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void
   }
   (void)lds_bytes;
   g_body = body; g_arg = arg; g_block = block; g_grid = grid; g_gx = gx;
-  if (resident >= 2 && grid >= 2) run_grid_resident(std::min(resident, grid));
+  if (resident >= 2 && grid >= 2 && g_depth == 0) run_grid_resident(std::min(resident, grid));
   else {
-    // workgroups one after the other, in blockIdx order, on the calling thread
-    g_b = &g_main;
+    // workgroups one after the other, in blockIdx order, on the thread that runs this launch (the calling thread; a helper thread for a
+    // launch that runs while another one is suspended in a poll: lazy streams, below)
+    BlockCtx& B = *depth_ctx();
+    g_b = &B;
     for (uint32_t bid = 0; bid < grid; bid++) {
-      init_block(g_main, bid);
-      while (step_block(g_main, nullptr)) {}
+      init_block(B, bid);
+      bool polled = false;
+      while (step_block(B, &polled)) {
+        if (polled) { polled = false; lazy_poll_progress(); g_b = &B; }
+      }
     }
   }
   g_cur = nullptr; g_view = nullptr; g_b = nullptr;
+}
+
+// ---------------------------------------------------------------- streams and events (see simt.h)
+namespace {
+struct StreamQ;
+struct QOp { void (*fn)(void*); void* arg; void (*drop)(void*); StreamQ* wait_s; uint64_t wait_seq; };   // wait_s: the operation is a wait for wait_s to complete wait_seq operations
+struct StreamQ {
+  std::deque<QOp> q;
+  uint64_t enq = 0, completed = 0;   // operations enqueued / completed so far
+  bool running = false;              // an operation of this stream is executing (or suspended in a poll): the next one must not start
+};
+struct Ev { StreamQ* s = nullptr; uint64_t seq = 0; };
+std::map<void*, StreamQ*> g_streams;   // by hipStream_t (nullptr = the null stream)
+std::vector<StreamQ*> g_all;           // every queue ever made (handles of destroyed streams are forgotten, their queues stay: events point at them)
+std::map<uintptr_t, size_t> g_pinned;  // hipHostMalloc blocks: start -> bytes
+uint64_t g_lazy_ops = 0, g_forced_by_wait = 0, g_poll_progress = 0;
+uint32_t g_depth = 0;                  // launches suspended in a poll below the one that is running
+bool g_resident_mode = false;
+size_t g_rr = 0;
+
+bool lazy_mode() {
+  static const bool on = [] {
+    const char* e = getenv("ETLG_SIMT_STREAMS");
+    const bool l = e && e[0] == 'l';
+    if (l && getenv("ETLG_SIMT_GRID_STATS"))
+      atexit([] { fprintf(stderr, "simt: %llu operations ran deferred, %llu forced by another stream's wait, %llu while a kernel of another stream polled\n",
+                          (unsigned long long)g_lazy_ops, (unsigned long long)g_forced_by_wait, (unsigned long long)g_poll_progress); });
+    return l;
+  }();
+  return on;
+}
+StreamQ* sq(void* stream) {
+  auto it = g_streams.find(stream);
+  if (it != g_streams.end()) return it->second;
+  StreamQ* S = new StreamQ();
+  g_all.push_back(S);
+  return g_streams[stream] = S;
+}
+
+// A launch that runs while others are suspended needs lanes, stacks, LDS and `__shared__` arrays of its own: depth d > 0 runs on helper
+// thread d (thread_local statics) with block context d. One thread runs at any time.
+struct Helper {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  void (*fn)(void*) = nullptr; void* arg = nullptr;
+  bool busy = false;
+  BlockCtx bc;
+};
+std::vector<Helper*> g_helpers;   // [depth]; [0] only lends its block context to the calling thread
+BlockCtx* depth_ctx() {
+  if (g_depth == 0) return &g_main;
+  return &g_helpers[g_depth]->bc;
+}
+void helper_main(Helper* h) {
+  for (;;) {
+    std::unique_lock<std::mutex> lk(h->m);
+    h->cv.wait(lk, [&] { return h->busy; });
+    lk.unlock();
+    h->fn(h->arg);
+    lk.lock();
+    h->busy = false;
+    lk.unlock();
+    h->cv.notify_all();
+  }
+}
+void exec_on_depth(void (*fn)(void*), void* arg) {
+  if (g_depth == 0) { fn(arg); return; }
+  while (g_helpers.size() <= g_depth) {
+    Helper* h = new Helper();
+    g_helpers.push_back(h);
+    if (g_helpers.size() > 1) { h->th = std::thread(helper_main, h); h->th.detach(); }
+  }
+  Helper* h = g_helpers[g_depth];
+  { std::unique_lock<std::mutex> lk(h->m); h->fn = fn; h->arg = arg; h->busy = true; }
+  h->cv.notify_all();
+  std::unique_lock<std::mutex> lk(h->m);
+  h->cv.wait(lk, [&] { return !h->busy; });
+}
+
+bool force(StreamQ* S, uint64_t n);
+// Runs the oldest operation of T if it can run now. false: T is empty, busy, or its oldest operation waits for a stream that is busy.
+bool try_run_front(StreamQ* T) {
+  if (T->running || T->q.empty()) return false;
+  QOp op = T->q.front();
+  if (op.wait_s) {
+    if (op.wait_s->completed < op.wait_seq) {
+      if (op.wait_s->running) return false;
+      g_forced_by_wait++;
+      T->running = true;
+      const bool ok = force(op.wait_s, op.wait_seq);
+      T->running = false;
+      if (!ok) return false;
+    }
+    T->q.pop_front();
+    T->completed++;
+    return true;
+  }
+  T->q.pop_front();
+  T->running = true;
+  g_lazy_ops++;
+  exec_on_depth(op.fn, op.arg);
+  if (op.drop) op.drop(op.arg);
+  T->running = false;
+  T->completed++;
+  return true;
+}
+// Runs S until it has completed n operations. false: it cannot get there now (S or something it waits for is busy further up the stack).
+bool force(StreamQ* S, uint64_t n) {
+  while (S->completed < n) if (!try_run_front(S)) return false;
+  return true;
+}
+void force_or_die(StreamQ* S, uint64_t n, const char* what) {
+  if (force(S, n)) return;
+  fprintf(stderr, "simt: %s cannot complete: the stream (or one it waits for) is busy — a cycle of waits, or a synchronisation from inside a kernel\n", what);
+  abort();
+}
+
+bool lazy_poll_wanted() {
+  if (!lazy_mode() || g_resident_mode) return false;
+  for (StreamQ* T : g_all) if (!T->running && !T->q.empty()) return true;
+  return false;
+}
+// A kernel polls for something another stream's work produces (the late carry of a batch that runs BESIDE its predecessor, plan.hip /
+// lookback.hip.h): whatever is enqueued on the other streams may legally run now. One operation of one of them, round robin.
+void lazy_poll_progress() {
+  if (!lazy_mode() || g_resident_mode || g_all.empty()) return;
+  void (*sv_body)(void*) = g_body; void* sv_arg = g_arg;
+  const uint32_t sv_block = g_block, sv_grid = g_grid, sv_gx = g_gx;
+  BlockCtx* sv_b = g_b; Lane* sv_cur = g_cur; LaneView* sv_view = g_view;
+  g_depth++;
+  for (size_t k = 0; k < g_all.size(); k++) {
+    StreamQ* T = g_all[(g_rr + k) % g_all.size()];
+    if (try_run_front(T)) { g_rr = (g_rr + k + 1) % g_all.size(); g_poll_progress++; break; }
+  }
+  g_depth--;
+  g_body = sv_body; g_arg = sv_arg; g_block = sv_block; g_grid = sv_grid; g_gx = sv_gx; g_b = sv_b; g_cur = sv_cur; g_view = sv_view;
+}
+}  // namespace
+
+bool streams_lazy() { return lazy_mode(); }
+
+void stream_enqueue(void* stream, void (*fn)(void*), void* arg, void (*drop)(void*)) {
+  if (!lazy_mode()) { fn(arg); if (drop) drop(arg); return; }
+  StreamQ* S = sq(stream);
+  S->q.push_back(QOp{fn, arg, drop, nullptr, 0});
+  S->enq++;
+}
+void stream_sync(void* stream) { if (lazy_mode()) { StreamQ* S = sq(stream); force_or_die(S, S->enq, "hipStreamSynchronize"); } }
+void stream_destroy(void* stream) {
+  if (!lazy_mode()) return;
+  auto it = g_streams.find(stream);
+  if (it == g_streams.end()) return;
+  force_or_die(it->second, it->second->enq, "hipStreamDestroy");   // (hipStreamDestroy lets the queued work finish)
+  g_streams.erase(it);
+}
+void device_sync() {
+  if (!lazy_mode()) return;
+  for (size_t i = 0; i < g_all.size(); i++) force_or_die(g_all[i], g_all[i]->enq, "a device synchronisation (hipFree / hipHostFree)");
+}
+void* event_create() { return new Ev(); }
+void event_destroy(void* ev) { delete (Ev*)ev; }
+void event_record(void* ev, void* stream) {
+  if (!ev) return;
+  Ev* e = (Ev*)ev;
+  if (!lazy_mode()) { e->s = nullptr; return; }
+  e->s = sq(stream); e->seq = e->s->enq;   // complete once everything enqueued on the stream so far has run
+}
+void event_sync(void* ev) { if (lazy_mode() && ev && ((Ev*)ev)->s) force_or_die(((Ev*)ev)->s, ((Ev*)ev)->seq, "hipEventSynchronize"); }
+void stream_wait_event(void* stream, void* ev) {
+  if (!lazy_mode() || !ev) return;
+  Ev* e = (Ev*)ev;
+  if (!e->s) return;   // never recorded: no dependency (HIP's rule)
+  StreamQ* S = sq(stream);
+  if (S == e->s) return;   // (its own earlier work: stream order already says so)
+  // the wait refers to the record that was LAST made when the wait is enqueued, not to later ones
+  S->q.push_back(QOp{nullptr, nullptr, nullptr, e->s, e->seq});
+  S->enq++;
+}
+void host_register(void* p, size_t n) { g_pinned[(uintptr_t)p] = n; }
+void host_unregister(void* p) { g_pinned.erase((uintptr_t)p); }
+bool host_is_pinned(const void* p) {
+  auto it = g_pinned.upper_bound((uintptr_t)p);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  return (uintptr_t)p < it->first + it->second;
+}
+// Copies. A copy between device memory and PINNED host memory is asynchronous in earnest: it reads its source when it runs. From
+// PAGEABLE host memory the runtime stages the bytes before the call returns (the caller may reuse the buffer at once), and a copy INTO
+// pageable memory returns only when it is complete — the emulator cannot tell device from pageable host memory by address, so the
+// direction comes from `kind` (1 = host to device, 2 = device to host).
+void memcpy_async(void* d, const void* s, size_t n, int kind, void* stream) {
+  if (!lazy_mode() || !n) { if (n) memmove(d, s, n); return; }
+  struct C { void* d; const void* s; size_t n; void* staged; };
+  C* c = new C{d, s, n, nullptr};
+  if (kind == 1 && !host_is_pinned(s)) { c->staged = malloc(n); memcpy(c->staged, s, n); c->s = c->staged; }
+  stream_enqueue(stream, [](void* p) { C* c = (C*)p; memmove(c->d, c->s, c->n); }, c, [](void* p) { C* c = (C*)p; free(c->staged); delete c; });
+  if (kind == 2 && !host_is_pinned(d)) stream_sync(stream);
+}
+void memset_async(void* d, int v, size_t n, void* stream) {
+  if (!lazy_mode()) { memset(d, v, n); return; }
+  struct M { void* d; int v; size_t n; };
+  stream_enqueue(stream, [](void* p) { M* m = (M*)p; memset(m->d, m->v, m->n); }, new M{d, v, n}, [](void* p) { delete (M*)p; });
 }
 
 }  // namespace simt

@@ -68,11 +68,37 @@ static inline Idx bidx() { return Idx{g_view->bid % g_view->gx, g_view->bid / g_
 static inline Idx bdim() { return Idx{g_view->bdim, 1, 1}; }
 static inline Idx gdim() { return Idx{g_view->gx, g_view->gdim / g_view->gx, 1}; }
 
+// ---- streams (simt.cpp). Default: every enqueued operation runs at once, in program order (what the emulator always did).
+// ETLG_SIMT_STREAMS=lazy: the operations of a stream — kernel launches, asynchronous copies, memsets — run as LATE as the HIP ordering rules
+// allow: when the host synchronises with the stream or with an event recorded behind them, or when another stream that is being run
+// reaches a wait for such an event. Work that the host code forgot to order (a kernel reading an upload on another stream without a
+// wait for it, a buffer handed to a second batch while the first one's kernel is still queued, a result read before its copy was waited
+// for) then really happens in the wrong order and shows up as a wrong result, instead of being hidden by immediate execution.
+struct Stream;
+struct Event;
+bool streams_lazy();
+void stream_enqueue(void* stream, void (*fn)(void*), void* arg, void (*drop)(void*));   // fn(arg) in stream order; drop(arg) frees the closure
+void stream_sync(void* stream);
+void stream_destroy(void* stream);
+void device_sync();                               // every stream (hipFree / hipHostFree / hipDeviceSynchronize)
+void* event_create();
+void event_destroy(void* ev);
+void event_record(void* ev, void* stream);
+void event_sync(void* ev);
+void stream_wait_event(void* stream, void* ev);
+void host_register(void* p, size_t n);            // pinned host memory: copies to / from it are truly asynchronous
+void host_unregister(void* p);
+bool host_is_pinned(const void* p);
+void memcpy_async(void* d, const void* s, size_t n, int kind, void* stream);
+void memset_async(void* d, int v, size_t n, void* stream);
+
 template <class... KArgs, class... Args>
-void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t lds, Args&&... args) {
-  std::tuple<std::decay_t<KArgs>...> tup(std::forward<Args>(args)...);
-  struct Ctx { void (*k)(KArgs...); std::tuple<std::decay_t<KArgs>...>* t; } ctx{k, &tup};
-  run_grid(g.x * g.y, b.x, lds, [](void* p) { Ctx* c = (Ctx*)p; std::apply(c->k, *c->t); }, &ctx, g.x);
+void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t lds, void* stream, Args&&... args) {
+  using Tup = std::tuple<std::decay_t<KArgs>...>;
+  struct Ctx { void (*k)(KArgs...); Tup t; uint32_t grid, block, gx; size_t lds; };
+  Ctx* c = new Ctx{k, Tup(std::forward<Args>(args)...), g.x * g.y, b.x, g.x, lds};   // the arguments are captured by value at launch, as on the GPU
+  stream_enqueue(stream, [](void* p) { Ctx* c = (Ctx*)p; run_grid(c->grid, c->block, c->lds, [](void* q) { Ctx* c2 = (Ctx*)q; std::apply(c2->k, c2->t); }, c, c->gx); },
+                 c, [](void* p) { delete (Ctx*)p; });
 }
 
 }  // namespace simt
@@ -81,7 +107,7 @@ void launch(void (*k)(KArgs...), dim3 g, dim3 b, size_t lds, Args&&... args) {
 #define blockIdx (simt::bidx())
 #define blockDim (simt::bdim())
 #define gridDim (simt::gdim())
-#define hipLaunchKernelGGL(k, g, b, lds, stream, ...) simt::launch(k, g, b, lds, __VA_ARGS__)
+#define hipLaunchKernelGGL(k, g, b, lds, stream, ...) simt::launch(k, g, b, lds, (void*)(stream), __VA_ARGS__)
 
 // ---------------------------------------------------------------- collectives
 // Every collective is a function-like macro that stamps its expansion with __COUNTER__: the rendezvous is keyed
@@ -166,23 +192,24 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 #define SIMT_MALLOC_SLACK 256   /* the sanitizer build (tools/simt_sanitize.py) allocates exactly what was asked for */
 #endif
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n + SIMT_MALLOC_SLACK); return *p ? hipSuccess : hipErrorOutOfMemory; }
-static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = calloc(1, n + (SIMT_MALLOC_SLACK ? 64 : 0)); return *p ? hipSuccess : hipErrorOutOfMemory; }
-static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipFree(void* p) { simt::device_sync(); free(p); return hipSuccess; }   // (hipFree synchronises the device)
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = calloc(1, n + (SIMT_MALLOC_SLACK ? 64 : 0)); if (*p) simt::host_register(*p, n + (SIMT_MALLOC_SLACK ? 64 : 0)); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void* p) { simt::device_sync(); simt::host_unregister(p); free(p); return hipSuccess; }
+// hipMemcpy: the copy runs on the null stream and the host waits for it (the library's streams are non-blocking: nothing else is waited for)
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { simt::memcpy_async(d, s, n, (int)k, nullptr); simt::stream_sync(nullptr); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr) { simt::memcpy_async(d, s, n, (int)k, (void*)st); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr) { simt::memset_async(d, v, n, (void*)st); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, 8); return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { simt::stream_destroy((void*)s); free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { simt::stream_sync((void*)s); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)simt::event_create(); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr) { simt::event_record((void*)e, (void*)s); return hipSuccess; }
 enum { hipEventDisableTiming = 2 };
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)calloc(1, 8); return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)simt::event_create(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t e) { simt::event_sync((void*)e); return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { simt::stream_wait_event((void*)s, (void*)e); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { simt::event_destroy((void*)e); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
