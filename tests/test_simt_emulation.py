@@ -39,10 +39,12 @@ def test_product_loader_refuses_the_emulator_build(simt_lib):
     assert "refused" in out.stdout, out.stdout + out.stderr
 
 
-def _emu_env(simt_lib, timeout, order=None, drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE"), grid=None):
+def _emu_env(simt_lib, timeout, order=None, drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE"), grid=None, streams=None):
     env = dict(os.environ, ETLG_LIB_PATH=simt_lib, ETLG_SIMT_RUN="1", ETLG_SIMT_WATCHDOG=str(timeout))
-    for k in ("ETLG_SIMT_ORDER", "ETLG_SIMT_GRID", "ETLG_SIMT_GRID_ORDER", "ETLG_SIMT_SEED", "ETLG_SIMT_BIG_BYTES"):
+    for k in ("ETLG_SIMT_ORDER", "ETLG_SIMT_GRID", "ETLG_SIMT_GRID_ORDER", "ETLG_SIMT_SEED", "ETLG_SIMT_BIG_BYTES", "ETLG_SIMT_STREAMS"):
         env.pop(k, None)
+    if streams:   # "lazy": enqueued work runs as late as the HIP ordering rules allow (tests/simt/simt.h)
+        env["ETLG_SIMT_STREAMS"] = streams
     if grid:   # several workgroups resident and interleaved: (how many, "shuffle" | "reverse") — tests/simt/simt.cpp
         env["ETLG_SIMT_GRID"], env["ETLG_SIMT_GRID_ORDER"] = str(grid[0]), grid[1]
     if order:
@@ -52,8 +54,8 @@ def _emu_env(simt_lib, timeout, order=None, drop=("ETLG_FUSED_KERNEL", "ETLG_FOR
     return env
 
 
-def _pytest_job(args, timeout, order=None, grid=None):
-    return dict(cmd=[sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, timeout=timeout, order=order, drop=None, grid=grid)
+def _pytest_job(args, timeout, order=None, grid=None, streams=None):
+    return dict(cmd=[sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, timeout=timeout, order=order, drop=None, grid=grid, streams=streams)
 
 
 # Every emulated run of this file is a subprocess of its own (the parity files pick the library up from the environment); they are all
@@ -70,6 +72,8 @@ _JOBS = {
     "plans_shuffled": _pytest_job(["tests/test_gpu_fixed_plan.py", "-k", "prepass or conforming or mix_in_one_launch"], 900, order="shuffle"),
     "resident_shuffle": _pytest_job(["tests/test_gpu_fuzz.py", "-k", "back_to_back"], 900, grid=(8, "shuffle")),
     "resident_reverse": _pytest_job(["tests/test_gpu_fuzz.py", "-k", "many_tile and not cfg2"], 900, grid=(8, "reverse")),
+    "lazy_streams": _pytest_job(["tests/test_gpu_async.py", "tests/test_shim_twin.py", "tests/test_gpu_copy.py", "-k",
+                                 "(async or shim or twin or chain or copy_generated) and not device_resident and not device_input and not 16777216"], 900, streams="lazy"),
     "copy_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], timeout=600, order=None,
                       drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_COPY_DIRECT", "ETLG_COPY_KERNEL")),
     "cell_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "cell_fuzz.py"), "3", "7"], timeout=600, order=None,
@@ -81,7 +85,7 @@ _JOBS = {
 def emu_jobs(simt_lib):
     procs = {}
     for name, j in _JOBS.items():
-        env = _emu_env(simt_lib, j["timeout"], j["order"], grid=j.get("grid")) if j["drop"] is None else _emu_env(simt_lib, j["timeout"], j["order"], j["drop"])
+        env = _emu_env(simt_lib, j["timeout"], j["order"], grid=j.get("grid"), streams=j.get("streams")) if j["drop"] is None else _emu_env(simt_lib, j["timeout"], j["order"], j["drop"])
         procs[name] = subprocess.Popen(j["cmd"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
     yield procs
     for pr in procs.values():
@@ -157,6 +161,19 @@ def test_look_back_kernels_newest_workgroup_first(emu_jobs):
     many-tile batches of the variable-length and the DDL workloads (error cut, rerun by the multi-pass kernels, the next batch reusing
     the buffers) on every kernel path."""
     _passed(emu_jobs, "resident_reverse")
+
+
+def test_host_orchestration_with_lazy_streams(emu_jobs):
+    """The library's stream plumbing (two decode streams, control / copy / result / scan streams, events between them) under the
+    emulator's LAZY stream model: every enqueued kernel, copy and memset runs as late as the HIP ordering rules allow — when the host
+    synchronises with its stream or event, or when a stream that is being run reaches a wait for it; copies from pageable memory are
+    staged at the call, copies into pageable memory complete at the call, pinned memory is read and written when the copy runs; a kernel
+    that polls for another stream's result (the late carry of a batch decoded BESIDE its predecessor) lets the other streams' work run.
+    Work the host code forgot to order then happens in the wrong order and the arenas differ from the oracle's. The ASYNC chains
+    (device-chained state, ring laps, reruns, the pipelined control path, pinned host input), the Rust shim's twin and the ASYNC table
+    copy. (With the decode streams' wait for a batch's upload taken out, these tests pass under immediate execution and fail here;
+    the whole -m gpu suite passes this way — 1 635 tests)"""
+    _passed(emu_jobs, "lazy_streams")
 
 
 def test_columnar_hand_off(emu_jobs):
