@@ -408,10 +408,14 @@ uint32_t g_depth = 0;                  // launches suspended in a poll below the
 bool g_resident_mode = false;
 size_t g_rr = 0;
 
+bool g_random_streams = false;   // ETLG_SIMT_STREAMS=random: lazy, plus — at every enqueue — a few operations of randomly chosen streams run early
+uint64_t g_srng = 0x853C49E6748FEA9Bull;
 bool lazy_mode() {
   static const bool on = [] {
     const char* e = getenv("ETLG_SIMT_STREAMS");
-    const bool l = e && e[0] == 'l';
+    const bool l = e && (e[0] == 'l' || e[0] == 'r');
+    g_random_streams = e && e[0] == 'r';
+    if (const char* sd = getenv("ETLG_SIMT_SEED")) g_srng ^= (uint64_t)strtoull(sd, nullptr, 0) * 0x9E3779B97F4A7C15ull;
     if (l && getenv("ETLG_SIMT_GRID_STATS"))
       atexit([] { fprintf(stderr, "simt: %llu operations ran deferred, %llu forced by another stream's wait, %llu while a kernel of another stream polled\n",
                           (unsigned long long)g_lazy_ops, (unsigned long long)g_forced_by_wait, (unsigned long long)g_poll_progress); });
@@ -535,6 +539,10 @@ void stream_enqueue(void* stream, void (*fn)(void*), void* arg, void (*drop)(voi
   StreamQ* S = sq(stream);
   S->q.push_back(QOp{fn, arg, drop, nullptr, 0});
   S->enq++;
+  if (g_random_streams && g_depth == 0) {   // any schedule between "at once" and "as late as possible": some of what is queued runs now
+    auto draw = [] { g_srng ^= g_srng << 13; g_srng ^= g_srng >> 7; g_srng ^= g_srng << 17; return (uint32_t)(g_srng >> 24); };
+    for (uint32_t k = draw() % 4; k > 0 && !g_all.empty(); k--) (void)try_run_front(g_all[draw() % g_all.size()]);
+  }
 }
 void stream_sync(void* stream) { if (lazy_mode()) { StreamQ* S = sq(stream); force_or_die(S, S->enq, "hipStreamSynchronize"); } }
 void stream_destroy(void* stream) {
