@@ -99,7 +99,7 @@ impl GpuDecoder {
     /// buffers on its copy stream beside the decode of the batch before, include/etlg.h) and returns at once, so that the stream keeps
     /// filling the next `CopyStaging` while this one decodes (two or three in rotation, like the WAL batcher's ring). The staging
     /// travels with the handle and comes back from `copy_finish`. Fewer than 32 in flight, finished in issue order.
-    /// Python twin of the call sequence: tests/test_gpu_copy.py::test_copy_async_batches_from_host_buffers.
+    /// Twin: tests/native/shim_twin.cpp `twin_copy_run` (tests/test_shim_twin.py: rows against the oracle's, fail-fast, drop order).
     pub fn copy_decode_async(&mut self, schema_slot: u32, staged: CopyStaging) -> Result<CopyInFlight, (CopyStaging, etl::error::EtlError)> {
         let mut batch = std::ptr::null_mut();
         let rc = unsafe {
@@ -142,7 +142,7 @@ impl GpuDecoder {
 
 /// A table-copy batch in flight. Dropping it without `copy_finish` frees the batch FIRST (the library waits for its kernels and its
 /// upload: `etlg_batch_free` finishes a pending batch) and only then the pinned staging — the order `InFlight` keeps for WAL batches
-/// (lib.rs; exercised by tests/native/shim_twin.cpp).
+/// (lib.rs; both exercised by tests/native/shim_twin.cpp).
 pub struct CopyInFlight {
     ctx: *mut etlg_ctx,
     batch: *mut etlg_batch,

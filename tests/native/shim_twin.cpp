@@ -7,6 +7,7 @@
 //   lib.rs       GpuDecoder::decode_async / finish / decode_unstaged, InFlight (+ its Drop)
 //   flush.rs     FlushTracker
 //   patches/apply_rs.diff   the seam in handle_replication_message_and_flush: gpu_dispatch / gpu_collect -> twin_run's loop
+//   copy.rs      CopyStaging, GpuDecoder::copy_decode_async / copy_finish, CopyInFlight (+ its Drop) -> twin_copy_run
 //
 // The library is whatever the process has loaded (the path comes from the caller: the product build on a GPU box, the emulator build in
 // the CPU suite). Every function is looked up by name: a symbol the shim binds and the library lacks fails the run.
@@ -31,13 +32,14 @@ struct Api {
   int32_t (*batch_view_get)(const etlg_batch*, etlg_batch_view*);
   void (*batch_free)(etlg_batch*);
   const etlg_error* (*last_error)(const etlg_ctx*);
+  int32_t (*copy_decode)(etlg_ctx*, int32_t, const uint8_t*, size_t, const uint32_t*, size_t, uint32_t, etlg_batch**);
   bool load(const char* path) {
     void* h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     if (!h) return false;
 #define SYM(field, name) field = (decltype(field))dlsym(h, name); if (!field) return false;
     SYM(host_alloc, "etlg_host_alloc") SYM(host_free, "etlg_host_free") SYM(decode, "etlg_decode") SYM(batch_sync, "etlg_batch_sync")
     SYM(batch_download, "etlg_batch_download") SYM(batch_view_get, "etlg_batch_view_get") SYM(batch_free, "etlg_batch_free")
-    SYM(last_error, "etlg_last_error")
+    SYM(last_error, "etlg_last_error") SYM(copy_decode, "etlg_copy_decode")
 #undef SYM
     return true;
   }
@@ -253,6 +255,93 @@ int32_t twin_run(const char* libpath, etlg_ctx* ctx, const uint8_t* stream, cons
   *ntrace = nt;
   batcher.release();      // (PinnedBuf's Drop: only after every batch that read the buffers is gone)
   return fail == 1 ? 0 : fail;   // a decode error is a result (reported through the callback), not a failure of the twin
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- copy.rs
+namespace {
+struct CopyStaging {   // copy.rs: CopyStaging::new / fits / push / clear
+  PinnedBuf rows, offsets;
+  size_t len = 0, nrows = 0;
+  bool create(etlg_ctx* ctx, size_t cap_bytes) {
+    const size_t max_rows = cap_bytes / 2 + 2;
+    if (!rows.alloc(ctx, cap_bytes) || !offsets.alloc(ctx, (max_rows + 1) * 4)) return false;
+    set_offset(0, 0);
+    return true;
+  }
+  void set_offset(size_t i, uint32_t v) { memcpy(offsets.ptr + i * 4, &v, 4); }
+  bool fits(size_t n) const { return len + n <= rows.cap && (nrows + 2) * 4 <= offsets.cap && len + n < 0xFFFFFFFFull; }
+  bool push(const uint8_t* row, size_t n) {
+    if (!fits(n)) return false;
+    memcpy(rows.ptr + len, row, n);
+    len += n; nrows += 1;
+    set_offset(nrows, (uint32_t)len);
+    return true;
+  }
+  void clear() { len = 0; nrows = 0; }
+  void release() { rows.release(); offsets.release(); }
+};
+struct CopyInFlight { etlg_batch* batch; CopyStaging* staged; };
+}  // namespace
+
+extern "C" {
+
+// The table-copy seam (patches/table_copy_rs.diff) with the ASYNC pair of copy.rs: the items of a CopyOutStream (`rows` / `offs`: one
+// COPY text row per item) are staged into a ring of `ring` pinned CopyStaging buffers of `cap_bytes`; a full one is enqueued
+// (copy_decode_async) and the oldest batch in flight is collected (copy_finish) once `ring - 1` are out — the stream never waits for a
+// decode it does not need. Fail-fast like the stream (table_copy.rs:88-92): the first bad row ends the run after the rows before it were
+// delivered; the batches still in flight are dropped — batch first, then its pinned staging (CopyInFlight's Drop).
+// cb: per collected batch, the host view, the rows the batch held, status.
+int32_t twin_copy_run(const char* libpath, etlg_ctx* ctx, int32_t schema_slot, const uint8_t* rows, const uint32_t* offs, uint32_t nitems,
+                      uint32_t ring, uint32_t cap_bytes, twin_on_batch cb, void* user, uint64_t* rows_delivered) {
+  if (!A.load(libpath)) return 100;
+  if (ring < 2) return 101;
+  std::vector<CopyStaging*> free_;
+  for (uint32_t i = 0; i < ring; i++) { auto* st = new CopyStaging(); if (!st->create(ctx, cap_bytes)) return 102; free_.push_back(st); }
+  CopyStaging* cur = free_.back(); free_.pop_back();
+  std::deque<CopyInFlight> in_flight;
+  int32_t fail = 0;
+  uint64_t delivered = 0;
+  auto finish = [&]() {   // GpuDecoder::copy_finish on the oldest batch
+    CopyInFlight f = in_flight.front(); in_flight.pop_front();
+    const int32_t rc = A.batch_sync(ctx, f.batch);
+    int32_t code = 0; int64_t frame = -1;
+    if (rc != ETLG_OK) { const etlg_error* e = A.last_error(ctx); if (e) { code = e->code; frame = e->frame_index; } }
+    if (A.batch_download(ctx, f.batch) != ETLG_OK) { A.batch_free(f.batch); f.staged->clear(); free_.push_back(f.staged); fail = 110; return; }
+    etlg_batch_view v; memset(&v, 0, sizeof(v));
+    A.batch_view_get(f.batch, &v);
+    delivered += v.n_events;
+    if (cb) cb(user, &v, f.staged->nrows, rc, code, frame);
+    A.batch_free(f.batch);
+    f.staged->clear(); free_.push_back(f.staged);   // the staging comes back only now
+    if (rc != ETLG_OK) fail = 1;
+  };
+  auto dispatch = [&]() {   // GpuDecoder::copy_decode_async
+    if (cur->nrows == 0) return;
+    while (free_.empty() && !fail) finish();
+    if (fail) return;
+    etlg_batch* b = nullptr;
+    (void)A.copy_decode(ctx, schema_slot, cur->rows.ptr, cur->len, (const uint32_t*)cur->offsets.ptr, cur->nrows, ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE, &b);
+    if (!b) { fail = 120; return; }
+    in_flight.push_back(CopyInFlight{b, cur});
+    cur = free_.back(); free_.pop_back();
+  };
+  for (uint32_t i = 0; i < nitems && !fail; i++) {
+    const uint8_t* row = rows + offs[i];
+    const size_t n = offs[i + 1] - offs[i];
+    if (!cur->fits(n)) { dispatch(); if (fail) break; }
+    if (!cur->push(row, n)) { fail = 140; break; }   // (a row larger than a whole staging buffer: the caller sizes the ring for its rows)
+  }
+  if (!fail) dispatch();
+  while (!in_flight.empty() && fail != 110) {
+    if (fail) { CopyInFlight f = in_flight.front(); in_flight.pop_front(); A.batch_free(f.batch); f.staged->clear(); free_.push_back(f.staged); }   // Drop for CopyInFlight: the batch (the library finishes it), THEN the staging
+    else finish();
+  }
+  *rows_delivered = delivered;
+  cur->release(); delete cur;
+  for (auto* st : free_) { st->release(); delete st; }
+  return fail == 1 ? 0 : fail;
 }
 
 }  // extern "C"

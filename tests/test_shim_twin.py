@@ -180,3 +180,68 @@ def test_twin_stops_at_a_decode_error_like_the_loop(twin, seed):
     diff = ref.diff(got)
     assert not diff, diff[:6]
     assert rows[-1].kind == 2 and rows[-1].in_flight == 0
+
+
+# ---- copy.rs: CopyStaging ring, copy_decode_async / copy_finish, CopyInFlight's drop order (twin_copy_run)
+def _copy_run(twin, rows, ring, cap):
+    from etl_amd.decoder import Decoder
+    from etl_amd.synth import COPY_COLS
+    d = Decoder(0)
+    d.schema_put(42, 0, COPY_COLS)
+    slot = d.table_ready(42, 0, [1] * len(COPY_COLS), [1 if c[3] else 0 for c in COPY_COLS])
+    buf = np.frombuffer(b"".join(rows), dtype=np.uint8).copy()
+    offs = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint32)
+    parts, status = [], []
+
+    @C.CFUNCTYPE(None, C.c_void_p, C.POINTER(abi.BatchView), C.c_uint64, C.c_int32, C.c_int32, C.c_int64)
+    def on_batch(_user, view, nrows, rc, code, frame):
+        parts.append(HostBatch.from_view(view.contents))
+        status.append((int(nrows), int(rc), int(code), int(frame), int(view.contents.payload_bytes[0])))
+
+    delivered = C.c_uint64()
+    twin.twin_copy_run.restype = C.c_int32
+    rc = twin.twin_copy_run(native.LIB_PATH.encode(), C.c_void_p(d.h.value if hasattr(d.h, "value") else d.h), C.c_int32(slot), C.c_void_p(buf.ctypes.data),
+                            C.c_void_p(offs.ctypes.data), C.c_uint32(len(rows)), C.c_uint32(ring), C.c_uint32(cap), on_batch, None, C.byref(delivered))
+    paths = d.debug_copy()
+    d.close()
+    return rc, parts, status, int(delivered.value), slot, buf, offs, paths
+
+
+@pytest.mark.parametrize("seed,ring,cap", [(1, 2, 64 << 10), (2, 3, 200 << 10), (3, 4, 32 << 10)])
+def test_copy_twin_streams_rows_through_a_ring_of_pinned_stagings(twin, seed, ring, cap):
+    """The rows of a table copy go through `ring` pinned staging buffers, `ring - 1` batches in flight at most, each collected in issue
+    order: the rows delivered, batch after batch, are the oracle's rows of the whole stream, and every batch's payload metadata is the
+    byte length of its rows (TableCopyPayloadMetadata, table_copy.rs:84)."""
+    from etl_amd.synth import COPY_COLS, copy_rows
+    from oracle import oracle
+    rows = copy_rows(6000, 70 + seed)
+    rc, parts, status, delivered, slot, buf, offs, paths = _copy_run(twin, rows, ring, cap)
+    assert rc == 0 and delivered == len(rows) and all(st[1] == 0 for st in status), (rc, delivered, status[:4])
+    assert len(status) >= 6 and sum(st[0] for st in status) == len(rows)
+    at = 0
+    for nrows, _rc, _code, _frame, payload in status:          # per batch: its rows' bytes
+        assert payload == int(offs[at + nrows]) - int(offs[at])
+        at += nrows
+    o = oracle.Oracle()
+    o.schema_put(42, 0, COPY_COLS)
+    so = o.table_ready(42, 0, [1] * len(COPY_COLS), [1 if c[3] else 0 for c in COPY_COLS])
+    ref = o.copy_decode(so, buf, offs).host_batch()
+    got = HostBatch.concat(parts)
+    got.tx_ordinal = ref.tx_ordinal                          # (the ordinal of a copied row is its index in ITS batch)
+    got.n_frames, got.payload_bytes = ref.n_frames, ref.payload_bytes
+    diff = ref.diff(got)
+    assert not diff, diff[:6]
+    assert paths["frames"] == 0
+
+
+def test_copy_twin_stops_at_a_bad_row_and_drops_what_is_in_flight(twin):
+    from etl_amd.synth import copy_rows
+    rows = copy_rows(5000, 91)
+    bad = 3333
+    rows[bad] = rows[bad].replace(b"\t", b"\t\t", 1)          # one field too many
+    rc, parts, status, delivered, slot, buf, offs, _paths = _copy_run(twin, rows, 3, 48 << 10)
+    assert rc == 0
+    failing = [k for k, st in enumerate(status) if st[1] != 0]
+    assert len(failing) == 1 and failing[0] == len(status) - 1, status      # fail-fast: nothing is delivered behind the failing batch
+    before = sum(st[0] for st in status[:-1])
+    assert before + status[-1][3] == bad and delivered == bad               # the rows in front of the bad one, no more
