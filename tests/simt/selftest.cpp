@@ -96,6 +96,72 @@ static void lookback_tests() {
   }
 }
 
+// ---- the lazy stream model (ETLG_SIMT_STREAMS=lazy; under immediate execution the same checks hold trivially, except the "stale" ones)
+__global__ void k_fill(uint32_t* dst, uint32_t v, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = v; }
+__global__ void k_sum(const uint32_t* src, uint32_t n, uint32_t* out) {
+  uint32_t acc = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += src[i];
+  atomicAdd(out, acc);
+}
+__global__ void k_wait_flag(volatile uint32_t* flag, uint32_t* out) {   // polls like a late carry: s_sleep is where another stream's work may run
+  uint32_t polls = 0;
+  while (*flag == 0 && polls < 100000) { polls++; __builtin_amdgcn_s_sleep(2); }
+  if (threadIdx.x == 0) *out = *flag ? 1u : 2u;
+}
+
+static void stream_tests() {
+  const bool lazy = simt::streams_lazy();
+  hipStream_t a, b;
+  hipEvent_t ev;
+  (void)hipStreamCreateWithFlags(&a, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  uint32_t *buf = nullptr, *out = nullptr, *pinned = nullptr;
+  (void)hipMalloc((void**)&buf, 1024 * 4); (void)hipMalloc((void**)&out, 64);
+  (void)hipHostMalloc((void**)&pinned, 64);
+  // 1. producer on a, consumer on b behind a wait for the producer's event: the consumer sees the producer's values
+  hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, a, buf, 3u, 1024u);
+  (void)hipEventRecord(ev, a);
+  (void)hipStreamWaitEvent(b, ev, 0);
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(64), 0, b, (const uint32_t*)buf, 1024u, out);
+  (void)hipStreamSynchronize(b);
+  CHECK(out[0] == 3 * 1024, "ordered by an event: %u", out[0]);
+  // 2. the same WITHOUT the wait: under the lazy model the consumer runs first (nothing forces the producer) and sums the old values
+  out[1] = 0;
+  hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, a, buf, 5u, 1024u);
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(64), 0, b, (const uint32_t*)buf, 1024u, out + 1);
+  (void)hipStreamSynchronize(b);
+  CHECK(out[1] == (lazy ? 3u : 5u) * 1024, "unordered: %u (lazy %d)", out[1], (int)lazy);
+  (void)hipStreamSynchronize(a);
+  CHECK(buf[7] == 5, "the producer ran once its stream was synchronised");
+  // 3. copies: from pageable memory the bytes are taken at the call; from pinned memory when the copy runs; into pageable memory the
+  //    call completes the copy (and everything before it on the stream)
+  uint32_t pageable[4] = {11, 12, 13, 14};
+  pinned[0] = 21;
+  (void)hipMemcpyAsync(buf, pageable, 16, hipMemcpyHostToDevice, a);
+  (void)hipMemcpyAsync(buf + 4, pinned, 4, hipMemcpyHostToDevice, a);
+  pageable[0] = 99; pinned[0] = 77;                 // the caller reuses both buffers before any synchronisation
+  (void)hipStreamSynchronize(a);
+  CHECK(buf[0] == 11, "pageable source staged at the call: %u", buf[0]);
+  CHECK(buf[4] == (lazy ? 77u : 21u), "pinned source read when the copy runs: %u", buf[4]);
+  uint32_t back = 0;
+  hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, a, buf, 8u, 16u);
+  (void)hipMemcpyAsync(&back, buf, 4, hipMemcpyDeviceToHost, a);   // pageable destination: complete on return
+  CHECK(back == 8, "copy into pageable memory completes at the call: %u", back);
+  // 4. a kernel that polls for another stream's result: the other stream's queued work runs while it polls
+  uint32_t* flag = buf + 512;
+  *flag = 0; out[2] = 0;
+  hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, a, flag, 1u, 1u);          // queued on a, not forced by anything ...
+  hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, b, (volatile uint32_t*)flag, out + 2);
+  (void)hipStreamSynchronize(b);                                              // ... except by the poll of the kernel on b
+  CHECK(out[2] == 1, "a polling kernel lets the other stream run: %u", out[2]);
+  (void)hipStreamSynchronize(a);
+  // 5. hipFree drains: nothing queued may touch the block afterwards
+  hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, a, buf, 1u, 1024u);
+  (void)hipFree(buf);
+  (void)hipFree(out); (void)hipHostFree(pinned);
+  (void)hipEventDestroy(ev); (void)hipStreamDestroy(a); (void)hipStreamDestroy(b);
+}
+
 int main() {
   const uint32_t B = 256, G = 3, N = B * G;
   std::vector<uint32_t> in(N), a(N), m(N), s(N), blk(N), tot(G);
@@ -133,6 +199,7 @@ int main() {
     CHECK(o[t * 4 + 3] == x + (w0 + 63 - lane), "partial ballot / shfl t%u: %u", t, o[t * 4 + 3]);
   }
   lookback_tests();
+  stream_tests();
   printf(g_fail ? "simt selftest: %d failures\n" : "simt selftest ok\n", g_fail);
   return g_fail != 0;
 }

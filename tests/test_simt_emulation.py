@@ -29,6 +29,11 @@ def test_emulator_primitives_against_scalar_loops(tmp_path):
     subprocess.check_call(["g++"] + CXXFLAGS + [os.path.join(SIMT, "selftest.cpp"), os.path.join(SIMT, "simt.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout[-2000:]
+    # the same binary with the scheduling models on: several workgroups resident, lazy streams (selftest.cpp's stream_tests: event order,
+    # the stale read of an unordered consumer, pageable / pinned copy semantics, a polling kernel, hipFree draining)
+    for extra in ({"ETLG_SIMT_GRID": "3"}, {"ETLG_SIMT_STREAMS": "lazy"}, {"ETLG_SIMT_STREAMS": "random", "ETLG_SIMT_SEED": "5"}):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, **extra))
+        assert out.returncode == 0, (extra, out.stdout[-2000:])
 
 
 def test_product_loader_refuses_the_emulator_build(simt_lib):
