@@ -533,6 +533,7 @@ void lazy_poll_progress() {
 }  // namespace
 
 bool streams_lazy() { return lazy_mode(); }
+int streams_mode() { return !lazy_mode() ? 0 : g_random_streams ? 2 : 1; }
 
 void stream_enqueue(void* stream, void (*fn)(void*), void* arg, void (*drop)(void*)) {
   if (!lazy_mode()) { fn(arg); if (drop) drop(arg); return; }

@@ -77,6 +77,7 @@ static inline Idx gdim() { return Idx{g_view->gx, g_view->gdim / g_view->gx, 1};
 struct Stream;
 struct Event;
 bool streams_lazy();
+int streams_mode();                               // 0 immediate, 1 lazy, 2 random
 void stream_enqueue(void* stream, void (*fn)(void*), void* arg, void (*drop)(void*));   // fn(arg) in stream order; drop(arg) frees the closure
 void stream_sync(void* stream);
 void stream_destroy(void* stream);
