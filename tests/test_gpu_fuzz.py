@@ -64,9 +64,11 @@ def test_mutations_agree_with_oracle(mk, path):
 
 
 # ---- what only the hardware can show: the kernels that talk between workgroups of one launch (the look-backs of k_fused / k_cells /
-#      k_plan2, the pre-pass's ticket) on batches of hundreds to thousands of tiles, and the boundary scan on byte soup. The SIMT emulator
-#      runs workgroups in order and sees none of it (a stale-descriptor defect lived two rounds behind a green emulator suite);
-#      the long runs of tools/ are outside the driver's view, so a bounded share of them lives here.
+#      k_plan2, the pre-pass's ticket) on batches of hundreds to thousands of tiles, and the boundary scan on byte soup. The SIMT emulator's
+#      default — workgroups one after the other — sees none of it (a stale-descriptor defect lived two rounds behind a green
+#      emulator suite); with ETLG_SIMT_GRID it keeps several workgroups resident and interleaved, and these tests then run there too
+#      (smaller batches; tests/test_simt_emulation.py). The long runs of tools/ are outside the driver's view, so a bounded share of them
+#      lives here.
 import os  # noqa: E402
 import time  # noqa: E402
 
