@@ -79,6 +79,7 @@ _JOBS = {
     "resident_reverse": _pytest_job(["tests/test_gpu_fuzz.py", "-k", "many_tile and not cfg2"], 900, grid=(8, "reverse")),
     "lazy_streams": _pytest_job(["tests/test_gpu_async.py", "tests/test_shim_twin.py", "tests/test_gpu_copy.py", "-k",
                                  "(async or shim or twin or chain or copy_generated) and not device_resident and not device_input and not 16777216"], 900, streams="lazy"),
+    "other_compiler": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "simt_other_compiler.py")], timeout=900, order=None, drop=None),
     "copy_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], timeout=600, order=None,
                       drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_COPY_DIRECT", "ETLG_COPY_KERNEL")),
     "cell_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "cell_fuzz.py"), "3", "7"], timeout=600, order=None,
@@ -179,6 +180,16 @@ def test_host_orchestration_with_lazy_streams(emu_jobs):
     copy. (With the decode streams' wait for a batch's upload taken out, these tests pass under immediate execution and fail here;
     the whole -m gpu suite passes this way — 1 635 tests)"""
     _passed(emu_jobs, "lazy_streams")
+
+
+def test_scenarios_on_the_library_built_by_rocm_clang(emu_jobs):
+    """tools/simt_other_compiler.py: the emulated library built by ROCm's clang++ -O2 (hipcc's front and middle end) instead of g++ -O1,
+    every scenario on every kernel path against the oracle. Skipped where that compiler is not installed."""
+    rc, out, err = _result(emu_jobs, "other_compiler")
+    if rc == 77:
+        pytest.skip("no ROCm clang++ in this image")
+    tail = out[-3000:] + err[-1000:]
+    assert rc == 0 and " passed" in tail and "failed" not in tail, tail
 
 
 def test_columnar_hand_off(emu_jobs):
