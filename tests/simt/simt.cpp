@@ -283,8 +283,8 @@ struct Pool {
 };
 Pool* g_pool = nullptr;
 
-void worker_main(Pool* P, int idx) {
-  Worker& me = *P->w[(size_t)idx];
+void worker_main(Pool* P, Worker* self, int idx) {
+  Worker& me = *self;   // (not P->w[idx]: the vector may be growing while this thread starts)
   for (;;) {
     std::unique_lock<std::mutex> lk(P->m);
     P->cv.wait(lk, [&] { return P->turn == idx; });
@@ -328,7 +328,7 @@ void run_grid_resident(uint32_t nres) {
     while (P->w.size() < nres) {
       Worker* x = new Worker();
       P->w.push_back(x);
-      x->th = std::thread(worker_main, P, (int)P->w.size() - 1);
+      x->th = std::thread(worker_main, P, x, (int)P->w.size() - 1);
       x->th.detach();
     }
     P->next_bid = 0; P->done = 0; P->launches++;
