@@ -752,6 +752,14 @@ int32_t etlg_ctx_debug_copy(etlg_ctx* c, unsigned long long* out2) {
   return ETLG_OK;
 }
 
+// debugging aid (not part of etlg.h): [0] result blocks cleared again after a second attempt behind their lap's re-initialisation,
+// [1] chains finished early because their last batch was marked for a second attempt
+int32_t etlg_ctx_debug_ring(etlg_ctx* c, unsigned long long* out1) {
+  if (!c || !out1) return ETLG_InvalidArgument;
+  out1[0] = c->ring_recleared; out1[1] = c->chain_healed;
+  return ETLG_OK;
+}
+
 int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, size_t len, const uint32_t* row_offsets, size_t nrows,
                          uint32_t flags, etlg_batch** out) {
   { const int32_t rc_ = flush_deferred(c); (void)rc_; }
@@ -986,6 +994,12 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
     *out = b;
     return ETLG_OK;
   }
+  // A chain behind a batch that has to be decoded again does not heal by itself: every batch enqueued behind one that is marked for a
+  // second attempt starts from that batch's unusable result, refuses to run, and is itself decoded again — synchronously — when it is
+  // synced; with the caller keeping its window full that went on for the rest of the stream (one fixed-width batch with an UPDATE in it,
+  // and every later batch was a poisoned first attempt plus a synchronous second one). The batches in flight are finished first, once;
+  // this batch then starts a fresh chain from the host's exact state.
+  if (async && !c->pending.empty() && c->pending.back()->force_rerun) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); c->chain_healed++; }
   {
     const int32_t rc = decode_tail(c, b, nframes, async, (async && !c->pending.empty()) ? c->pending.back() : nullptr);
     if (rc != ETLG_OK) return rc;
@@ -1026,6 +1040,11 @@ int32_t flush_deferred(etlg_ctx* c) {
       while (!c->pending.empty() && c->pending.front() != b) (void)finish_batch(c, c->pending.front());
     etlg_batch* prev = nullptr;   // the batch issued just before this one, if it is still in flight
     for (size_t i = 0; i < c->pending.size(); i++) if (c->pending[i] == b && i > 0) prev = c->pending[i - 1];
+    if (prev && prev->force_rerun) {   // (as in etlg_decode: a chain behind a batch that is decoded again is finished first, once)
+      while (!c->pending.empty() && c->pending.front() != b) (void)finish_batch(c, c->pending.front());
+      prev = nullptr;
+      c->chain_healed++;
+    }
     rc = decode_tail(c, b, nframes, true, prev);
   }
   if (rc != ETLG_OK) {  // nothing was enqueued for it: it is finished, with this error
@@ -1140,6 +1159,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
     else if (slot == 0) HIPCHK(c, hipMemcpyAsync(ring, c->ring_h2d ? (const void*)c->h_init_ring : (const void*)c->d_init_ring, sizeof(DevResult) * (etlg_ctx::kResRing - 1), c->ring_h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
     else if (slot == 1) HIPCHK(c, hipMemcpyAsync(ring + (etlg_ctx::kResRing - 1), c->ring_h2d ? (const void*)c->h_init_ring : (const void*)c->d_init_ring, sizeof(DevResult), c->ring_h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s)); }
     b->d_res_blk = ring + slot;
+    b->res_seq_no = seq;
   }
   p.res = b->d_res_blk;
   { SlowScope slow_scope_pool(c, "decode_tail: pinned result block");

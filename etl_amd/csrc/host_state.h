@@ -293,6 +293,8 @@ struct etlg_ctx {
   unsigned long long overlapped = 0;   // debugging aid: batches launched beside their predecessor
   // result blocks: a ring re-initialised once per lap with one copy
   static constexpr uint32_t kResRing = 32;
+  uint64_t chain_healed = 0;     // ASYNC chains finished early because their last batch was marked for a second attempt (etlg_decode)
+  uint64_t ring_recleared = 0;   // result blocks cleared again after a second attempt behind their lap's re-initialisation (finish_batch)
   uint32_t res_seq = 0;
   DevResult* h_init_ring = nullptr;
   DevResult* d_init_ring = nullptr;   // the same, in device memory: the ring is re-initialised with a device-to-device copy (a 40 KB host-to-device
@@ -420,6 +422,7 @@ struct etlg_batch {
   CopyJob copy;            // table-copy batch: the splitter has to run again before a multi-pass redo
   uint32_t copy_span = 0;  // table-copy batch decoded by k_copy_cells: the bytes of its rows (DevResult.copy_span)
   DevResult* d_res_blk = nullptr;  // this batch's result block on the device
+  uint32_t res_seq_no = 0;         // ... and the batch's number in the ring's sequence (finish_batch: has the slot's next re-initialisation been issued?)
   bool used_cells = false; // ... and it was k_cells
   bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
   DecParams params{};

@@ -393,7 +393,7 @@ void run_grid(uint32_t grid, uint32_t block, size_t lds_bytes, void (*body)(void
 // ---------------------------------------------------------------- streams and events (see simt.h)
 namespace {
 struct StreamQ;
-struct QOp { void (*fn)(void*); void* arg; void (*drop)(void*); StreamQ* wait_s; uint64_t wait_seq; };   // wait_s: the operation is a wait for wait_s to complete wait_seq operations
+struct QOp { void (*fn)(void*); void* arg; void (*drop)(void*); StreamQ* wait_s; uint64_t wait_seq; uint64_t ordinal; };   // wait_s: the operation is a wait for wait_s to complete wait_seq operations
 struct StreamQ {
   std::deque<QOp> q;
   uint64_t enq = 0, completed = 0;   // operations enqueued / completed so far
@@ -403,13 +403,24 @@ struct Ev { StreamQ* s = nullptr; uint64_t seq = 0; };
 std::map<void*, StreamQ*> g_streams;   // by hipStream_t (nullptr = the null stream)
 std::vector<StreamQ*> g_all;           // every queue ever made (handles of destroyed streams are forgotten, their queues stay: events point at them)
 std::map<uintptr_t, size_t> g_pinned;  // hipHostMalloc blocks: start -> bytes
-uint64_t g_lazy_ops = 0, g_forced_by_wait = 0, g_poll_progress = 0;
+uint64_t g_lazy_ops = 0, g_forced_by_wait = 0, g_poll_progress = 0, g_ordinal = 0, g_running_ordinal = 0;
 uint32_t g_depth = 0;                  // launches suspended in a poll below the one that is running
 bool g_resident_mode = false;
 size_t g_rr = 0;
 
 bool g_random_streams = false;   // ETLG_SIMT_STREAMS=random: lazy, plus — at every enqueue — a few operations of randomly chosen streams run early
 uint64_t g_srng = 0x853C49E6748FEA9Bull;
+// debugging aid: a region of "device" memory whose content is compared after every operation the emulator executes (simt_watch below)
+const uint8_t* g_watch = nullptr; size_t g_watch_n = 0; std::vector<uint8_t> g_watch_last;
+void watch_check(const char* what, const void* fn) {
+  if (!g_watch) return;
+  if (memcmp(g_watch, g_watch_last.data(), g_watch_n) != 0) {
+    fprintf(stderr, "simt: watched region %p changed by %s", (const void*)g_watch, what);
+    if (fn) { void* a[1] = {(void*)fn}; char** sy = backtrace_symbols(a, 1); if (sy) { fprintf(stderr, " %s", sy[0]); free(sy); } }
+    fprintf(stderr, " (first qword now %llu; operation number %llu)\n", (unsigned long long)*(const unsigned long long*)g_watch, (unsigned long long)g_running_ordinal);
+    memcpy(g_watch_last.data(), g_watch, g_watch_n);
+  }
+}
 bool lazy_mode() {
   static const bool on = [] {
     const char* e = getenv("ETLG_SIMT_STREAMS");
@@ -493,7 +504,9 @@ bool try_run_front(StreamQ* T) {
   T->q.pop_front();
   T->running = true;
   g_lazy_ops++;
+  g_running_ordinal = op.ordinal;
   exec_on_depth(op.fn, op.arg);
+  watch_check("a queued operation", (const void*)op.fn);
   if (op.drop) op.drop(op.arg);
   T->running = false;
   T->completed++;
@@ -536,9 +549,9 @@ bool streams_lazy() { return lazy_mode(); }
 int streams_mode() { return !lazy_mode() ? 0 : g_random_streams ? 2 : 1; }
 
 void stream_enqueue(void* stream, void (*fn)(void*), void* arg, void (*drop)(void*)) {
-  if (!lazy_mode()) { fn(arg); if (drop) drop(arg); return; }
+  if (!lazy_mode()) { fn(arg); watch_check("an operation", (const void*)fn); if (drop) drop(arg); return; }
   StreamQ* S = sq(stream);
-  S->q.push_back(QOp{fn, arg, drop, nullptr, 0});
+  S->q.push_back(QOp{fn, arg, drop, nullptr, 0, ++g_ordinal});
   S->enq++;
   if (g_random_streams && g_depth == 0) {   // any schedule between "at once" and "as late as possible": some of what is queued runs now
     auto draw = [] { g_srng ^= g_srng << 13; g_srng ^= g_srng >> 7; g_srng ^= g_srng << 17; return (uint32_t)(g_srng >> 24); };
@@ -573,7 +586,7 @@ void stream_wait_event(void* stream, void* ev) {
   StreamQ* S = sq(stream);
   if (S == e->s) return;   // (its own earlier work: stream order already says so)
   // the wait refers to the record that was LAST made when the wait is enqueued, not to later ones
-  S->q.push_back(QOp{nullptr, nullptr, nullptr, e->s, e->seq});
+  S->q.push_back(QOp{nullptr, nullptr, nullptr, e->s, e->seq, ++g_ordinal});
   S->enq++;
 }
 void host_register(void* p, size_t n) { g_pinned[(uintptr_t)p] = n; }
@@ -605,3 +618,9 @@ void memset_async(void* d, int v, size_t n, void* stream) {
 }  // namespace simt
 
 extern "C" int etlg_simt_marker(void) { return 1; }
+// debugging aid for a host-side probe (never called by the product sources): report every executed operation that changes [p, p + n)
+extern "C" unsigned long long simt_op_ordinal(void) { return simt::g_ordinal; }   // number of the operation enqueued last (lazy streams)
+extern "C" void simt_watch(const void* p, size_t n) {
+  simt::g_watch = (const uint8_t*)p; simt::g_watch_n = p ? n : 0;
+  simt::g_watch_last.assign((const uint8_t*)p, (const uint8_t*)p + simt::g_watch_n);
+}

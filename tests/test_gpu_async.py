@@ -309,6 +309,52 @@ def test_async_chain_when_the_plan_does_not_cover_a_batch():
     assert paths["plan_redone"] >= 1 and paths["redone"] == 0, paths
 
 
+def test_async_chain_second_attempts_across_a_ring_lap():
+    """70 cfg2 batches, six in flight; batch 30 holds an UPDATE the fixed-width plan does not cover. It is decoded again when it is
+    synced — and with it the batches queued behind it — AFTER batch 32 (result block 0) has sent out the ring's re-initialisation for the
+    next lap: what the second attempts leave in blocks 30 and 31 must not meet batches 62 and 63 (payload shards are added to, give-up
+    and error words or-ed / min-ed into, carry_ready polled by the batch that runs beside). Every batch of the chain against the oracle."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    from tests import pgwire as W
+    w = synth.cfg2()
+    buf, offs = w.fill(6 << 20)
+    pieces = _cut(buf, offs, 70, seed=29)
+    b1, o1 = pieces[30]
+    at = (len(o1) - 1) // 2
+    while b1[int(o1[at]) + 30] != ord("I") or b1[int(o1[at - 1]) + 30] != ord("I"):
+        at += 1
+    rel = int.from_bytes(b1[int(o1[at]) + 31:int(o1[at]) + 35].tobytes(), "big")
+    lsn = int.from_bytes(b1[int(o1[at]) + 6:int(o1[at]) + 14].tobytes(), "big")
+    upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"])))
+    cut = int(o1[at])
+    pieces[30] = (np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]]),
+                  np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32))
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    dev = DevBufs(pieces)
+    inflight = []
+    done = 0
+    for k, (p, n, po, nf) in enumerate(dev.items):
+        inflight.append(d.decode_device(p, n, po, nf, FLAGS))
+        while len(inflight) - done > 6 or (k == len(dev.items) - 1 and done < len(inflight)):
+            b = inflight[done]
+            rb = o.decode(*pieces[done])
+            assert b.sync() == 0 and rb.err_code == 0, (done, b.error)
+            diff = rb.host_batch().diff(b.host())
+            assert not diff, f"batch {done}: {diff[:6]}"
+            b.close()
+            done += 1
+    paths = d.debug_paths()
+    assert paths["plan_redone"] >= 1 and 1 <= paths["chain_rerun"] <= 6, paths   # the six batches that were in flight behind batch 30, and no more:
+    assert d.debug_chains_healed() == 1                    # ... the chain was finished once and started afresh (it used to stay poisoned: every
+                                                           # later batch a refused first attempt plus a synchronous second one, chain_rerun 39)
+    assert d.debug_ring_recleared() >= 2                   # blocks 30 and 31 (block 31's re-initialisation went out with batch 33)
+    assert paths["plan"] >= 60, paths
+    d.close()
+
+
 def test_async_chain_without_a_sidecar():
     """frame_offsets = NULL + ASYNC: every batch scans its own record boundaries (on the scan stream, into an offsets buffer the
     batch owns) and is chained on the device like the others; an error in the middle still re-runs the batches behind it."""

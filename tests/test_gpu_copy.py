@@ -464,3 +464,45 @@ def test_copy_async_device_resident_rows():
         assert not o.copy_decode(so, buf, offs).host_batch().diff(g.host())
     assert d.debug_copy()["direct"] == 4
     d.close()
+
+
+def test_copy_async_second_attempt_behind_the_ring_lap_leaves_no_residue():
+    """The result ring (32 blocks) is re-initialised when the batch that takes block 0 is issued. A table-copy batch of the old lap that
+    is still in flight then, and is decoded again when it is synced (its rows go through the frame rewrite), writes its block AFTER that
+    re-initialisation; the block's next user, 32 batches later, must not inherit what the second attempt left (payload shards are
+    added to, error / give-up words are min-ed / or-ed into). Found by tools/copy_async_fuzz.py: a transaction's payload_bytes 489
+    instead of 71. Sequence: 30 batches; A (block 30, redone at its sync), B (31), C (block 0: the lap's re-initialisation goes out with
+    A in flight); 29 more batches; then a WAL transaction lands on block 30."""
+    from tests import pgwire as W
+    cols = [("a", 25, -1, False), ("b", 25, -1, False)]
+    o, d, so, sd = _copy_ctx(cols)
+    for t in (o, d):
+        t.table_state(42, abi.TS_READY)
+    small = _rows_np(_fuzz_rows(5, 20))
+
+    def plain(n):
+        for _ in range(n):
+            g = d.copy_decode(sd, *small)
+            assert g.rc == 0
+            g.close()
+    plain(30)                                                        # blocks 0 .. 29
+    heavy = _rows_np([("x" * 4000 + "\t" + "y" * (k % 17) + "\n").encode() for k in range(80)] + _fuzz_rows(31, 40))   # 64 rows of 4 KB do not fit a tile's window: the direct kernel hands the batch back
+    frames0 = d.debug_copy()["frames"]
+    a = d.copy_decode(sd, *heavy, flags=ASYNC)                       # block 30
+    b = d.copy_decode(sd, *small, flags=ASYNC)                       # block 31
+    c = d.copy_decode(sd, *small, flags=ASYNC)                       # block 0: re-initialises 0 .. 30 with A still in flight
+    for g, (buf, offs) in ((a, heavy), (b, small), (c, small)):
+        rb = o.copy_decode(so, buf, offs)
+        g.sync()
+        assert_same(rb, g)
+        g.close()
+    assert d.debug_copy()["frames"] == frames0 + 1                   # A was decoded again, through the frame rewrite
+    assert d.debug_ring_recleared() == 1                             # ... and its block cleared behind it
+    plain(29)                                                        # blocks 1 .. 29
+    s = SC.txn([W.insert(42, ["x" * 30, "y" * 41])])
+    wb = np.frombuffer(s.bytes(), dtype=np.uint8)
+    r2, g2 = o.decode(wb, s.offsets), d.decode(wb, s.offsets)        # block 30
+    assert r2.err_code == 0 and g2.rc == 0
+    assert not r2.host_batch().diff(g2.host())
+    assert g2.view().payload_bytes[0] == 71
+    d.close()

@@ -82,9 +82,10 @@ while time.time() - t0 < seconds and bad < 5:
             lsn += 0x1000
             wb = np.frombuffer(s.bytes(), dtype=np.uint8)
             r2, g2 = o.decode(wb, s.offsets), d.decode(wb, s.offsets)
-            if r2.err_code != 0 or g2.rc != 0 or r2.host_batch().diff(g2.host()):
+            wd = r2.host_batch().diff(g2.host()) if (r2.err_code == 0 and g2.rc == 0) else []
+            if r2.err_code != 0 or g2.rc != 0 or wd:
                 bad += 1
-                print("MISMATCH (WAL batch between copy batches) round", rounds, flush=True)
+                print("MISMATCH (WAL batch between copy batches) round", rounds, "k", k, "of", len(todo), "oracle", r2.err_code, r2.err_desc, "device", g2.rc, g2.error.description if g2.error else "", wd[:4], flush=True)
             wal += 1
         inflight.append(d.copy_decode(slot, buf, offs, flags=ASYNC))
     for k, ((buf, offs), g) in enumerate(zip(todo, inflight)):
