@@ -80,6 +80,8 @@ _JOBS = {
     "lazy_streams": _pytest_job(["tests/test_gpu_async.py", "tests/test_shim_twin.py", "tests/test_gpu_copy.py", "-k",
                                  "(async or shim or twin or chain or copy_generated) and not device_resident and not device_input and not 16777216"], 900, streams="lazy"),
     "other_compiler": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "simt_other_compiler.py")], timeout=900, order=None, drop=None),
+    "long_chains": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "async_long_fuzz.py"), "45", "21"], timeout=600, order=None,
+                        drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE", "ETLG_OVERLAP")),
     "copy_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "copy_fuzz.py"), "160", "101"], timeout=600, order=None,
                       drop=("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_COPY_DIRECT", "ETLG_COPY_KERNEL")),
     "cell_fuzz": dict(cmd=[sys.executable, os.path.join(ROOT, "tools", "cell_fuzz.py"), "3", "7"], timeout=600, order=None,
@@ -196,6 +198,15 @@ def test_columnar_hand_off(emu_jobs):
     """etlg_batch_columns / etlg_batch_rowbinary (columns.hip): the Arrow-layout buffers built by the emulated kernels against
     the host hand-off of the oracle's arena, the RowBinary bytes against oracle/rowbinary.py."""
     _passed(emu_jobs, "hand_off")
+
+
+def test_long_async_chains_with_second_attempts(emu_jobs):
+    """tools/async_long_fuzz.py: chains of 80-200 cfg2 batches on ONE context (the result ring laps several times), a random window in
+    flight, an UPDATE the fixed-width plan does not cover in a few batches (decoded again at their sync, with the batches behind them):
+    every batch against the oracle, and the chain has to heal — second attempts within a window's worth per such batch. Against the
+    host code before round 5's second session every chain reports CHAIN DID NOT HEAL."""
+    rc, out, err = _result(emu_jobs, "long_chains")
+    assert rc == 0 and " 0 problems" in out, out[-2000:] + err[-1000:]
 
 
 def test_copy_mutation_fuzz(emu_jobs):

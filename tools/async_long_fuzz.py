@@ -1,0 +1,75 @@
+"""Long ASYNC chains on ONE context against the oracle (emulator or GPU): python tools/async_long_fuzz.py [seconds=120] [seed=1]
+What tools/async_fuzz.py does not reach: its rounds use a fresh context for at most 40 batches, so the result ring (32 blocks) barely
+laps and a batch that is decoded again never meets a re-used block. Here a round is 80-200 cfg2 batches cut at arbitrary frames on one
+context, a random window of them in flight, and in a few of them an UPDATE the fixed-width plan does not cover (the batch is decoded
+again by the generic kernel when it is synced, and so are the batches that were in flight behind it); every batch against the oracle,
+every field — and the chain has to heal: second attempts stay within a window's worth per spliced batch.
+(Found-by-design targets: the two defects of round 5's second session)"""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from etl_amd import synth
+from etl_amd.decoder import Decoder
+from oracle import oracle
+from tests import pgwire as W
+from tests.test_gpu_async import FLAGS, DevBufs, _cut
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + seconds
+rounds = batches = bad = spliced_total = 0
+while time.time() < t_end or rounds == 0:
+    rng = random.Random(seed + rounds)
+    w = synth.cfg2(seed=0xE7A0000 + seed * 1000 + rounds)
+    n = rng.randrange(80, 200)
+    buf, offs = w.fill(rng.choice([2, 3, 5]) << 20)
+    pieces = _cut(buf, offs, n, seed=seed * 7919 + rounds)
+    spliced = sorted(rng.sample(range(3, len(pieces)), rng.choice([1, 1, 2, 3, 5])))
+    for k in spliced:
+        b1, o1 = pieces[k]
+        at = None
+        for cand in range(1, len(o1) - 1):
+            if b1[int(o1[cand]) + 30] == ord("I") and b1[int(o1[cand - 1]) + 30] == ord("I"):
+                at = cand
+                break
+        if at is None:
+            continue
+        rel = int.from_bytes(b1[int(o1[at]) + 31:int(o1[at]) + 35].tobytes(), "big")
+        lsn = int.from_bytes(b1[int(o1[at]) + 6:int(o1[at]) + 14].tobytes(), "big")
+        upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"])))
+        cut = int(o1[at])
+        pieces[k] = (np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]]),
+                     np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32))
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    dev = DevBufs(pieces)
+    window = rng.choice([1, 2, 3, 6, 12, 20, 30])
+    inflight, done = [], 0
+    for k, (p, nbytes, po, nf) in enumerate(dev.items):
+        inflight.append(d.decode_device(p, nbytes, po, nf, FLAGS))
+        while len(inflight) - done > window or (k == len(dev.items) - 1 and done < len(inflight)):
+            b = inflight[done]
+            rb = o.decode(*pieces[done])
+            rc = b.sync()
+            diff = [] if (rc != 0 or rb.err_code != 0) else rb.host_batch().diff(b.host())
+            if rc != 0 or rb.err_code != 0 or diff:
+                bad += 1
+                print("MISMATCH seed", seed, "round", rounds, "batch", done, "of", len(pieces), "window", window, "spliced", spliced, "rc", rc, rb.err_code, diff[:4], flush=True)
+            b.close()
+            done += 1
+            batches += 1
+    paths = d.debug_paths()
+    if paths["chain_rerun"] > (window + 1) * len(spliced) or paths["redone"]:
+        bad += 1
+        print("CHAIN DID NOT HEAL seed", seed, "round", rounds, "window", window, "spliced", spliced, paths, flush=True)
+    spliced_total += len(spliced)
+    d.close()
+    rounds += 1
+print(f"async long fuzz: {rounds} chains, {batches} batches checked, {spliced_total} batches with an UPDATE, {bad} problems, seeds {seed}..{seed + rounds - 1}")
+sys.exit(1 if bad else 0)
