@@ -21,6 +21,41 @@ from tests.test_gpu_async import FLAGS, DevBufs, _cut
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = sys.argv[3] if len(sys.argv) > 3 else "cfg2"    # "cfg5": the DDL workload with default flags — the pipelined control path (pre-pass ring, two scratch sets) over many laps
+if mode == "cfg5":
+    from tests.test_gpu_async import FLAGS_DEFAULT
+    t_end = time.time() + seconds
+    rounds = batches = bad = 0
+    while time.time() < t_end or rounds == 0:
+        rng = random.Random(seed + rounds)
+        w = synth.cfg5(seed=0xE7B0000 + seed * 1000 + rounds)
+        buf, offs = w.fill(rng.choice([2, 3, 4]) << 20)
+        pieces = _cut(buf, offs, rng.randrange(80, 160), seed=seed * 104729 + rounds)
+        o, d = oracle.Oracle(), Decoder(0)
+        w.register(o, ready=not w.cfg.emit_relations)
+        w.register(d, ready=not w.cfg.emit_relations)
+        dev = DevBufs(pieces)
+        window = rng.choice([1, 2, 3, 6, 12, 20])
+        inflight, done = [], 0
+        for k, (p, nbytes, po, nf) in enumerate(dev.items):
+            inflight.append(d.decode_device(p, nbytes, po, nf, FLAGS_DEFAULT))
+            while len(inflight) - done > window or (k == len(dev.items) - 1 and done < len(inflight)):
+                b = inflight[done]
+                rb = o.decode(*pieces[done])
+                rc = b.sync()
+                diff = [] if (rc != 0 or rb.err_code != 0) else rb.host_batch().diff(b.host())
+                if rc != 0 or rb.err_code != 0 or diff:
+                    bad += 1
+                    print("MISMATCH cfg5 seed", seed, "round", rounds, "batch", done, "of", len(pieces), "window", window, "rc", rc, b.error.description if b.error else "", rb.err_code, diff[:4], flush=True)
+                b.close()
+                done += 1
+                batches += 1
+        paths = d.debug_paths()
+        d.close()
+        rounds += 1
+        print("round", rounds, "window", window, "batches", len(pieces), paths, flush=True)
+    print(f"async long fuzz (cfg5, default flags): {rounds} chains, {batches} batches checked, {bad} problems, seeds {seed}..{seed + rounds - 1}")
+    sys.exit(1 if bad else 0)
 t_end = time.time() + seconds
 rounds = batches = bad = spliced_total = 0
 while time.time() < t_end or rounds == 0:
