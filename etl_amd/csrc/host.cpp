@@ -1045,6 +1045,10 @@ int32_t flush_deferred(etlg_ctx* c) {
       prev = nullptr;
       c->chain_healed++;
     }
+    // This batch was in flight (its scan) when a batch before it was marked for a second attempt, and was marked with it; but its
+    // DECODE goes out only now. With nothing in flight in front of it, it starts from the final state: one attempt is enough. (Left
+    // marked, it was decoded again at its sync and marked everything behind it in turn: a chain without a sidecar never healed.)
+    if (!prev && !pre_pass_ahead) b->force_rerun = false;
     rc = decode_tail(c, b, nframes, true, prev);
   }
   if (rc != ETLG_OK) {  // nothing was enqueued for it: it is finished, with this error

@@ -21,7 +21,7 @@ from tests.test_gpu_async import FLAGS, DevBufs, _cut
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-mode = sys.argv[3] if len(sys.argv) > 3 else "cfg2"    # "cfg5": the DDL workload with default flags — the pipelined control path (pre-pass ring, two scratch sets) over many laps
+mode = sys.argv[3] if len(sys.argv) > 3 else "cfg2"    # "nosidecar" / "mixed": (some) batches without the offsets sidecar; "cfg5": the DDL workload with default flags — the pipelined control path (pre-pass ring, two scratch sets) over many laps
 if mode == "cfg5":
     from tests.test_gpu_async import FLAGS_DEFAULT
     t_end = time.time() + seconds
@@ -87,7 +87,8 @@ while time.time() < t_end or rounds == 0:
     window = rng.choice([1, 2, 3, 6, 12, 20, 30])
     inflight, done = [], 0
     for k, (p, nbytes, po, nf) in enumerate(dev.items):
-        inflight.append(d.decode_device(p, nbytes, po, nf, FLAGS))
+        sidecar = mode != "nosidecar" and not (mode == "mixed" and rng.random() < 0.5)   # without one: the boundary scan of the batch runs ahead, its decode is enqueued by the next call
+        inflight.append(d.decode_device(p, nbytes, po if sidecar else None, nf if sidecar else 0, FLAGS))
         while len(inflight) - done > window or (k == len(dev.items) - 1 and done < len(inflight)):
             b = inflight[done]
             rb = o.decode(*pieces[done])
