@@ -80,6 +80,15 @@ while time.time() < t_end or rounds == 0:
         cut = int(o1[at])
         pieces[k] = (np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]]),
                      np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32))
+    broken = []
+    if mode == "errors":   # a malformed integer in a few batches: the batch ends there with the reference's error, the context keeps the state before
+        for k in sorted(rng.sample(range(3, len(pieces)), rng.choice([1, 2, 3]))):   # the failing frame, and the chain goes on from it (both sides alike)
+            b2, o2 = pieces[k]
+            for cand in range(len(o2) - 1):
+                if b2[int(o2[cand]) + 30] == ord("I"):
+                    b2[int(o2[cand]) + 43 + 3] = ord("x")
+                    broken.append(k)
+                    break
     o, d = oracle.Oracle(), Decoder(0)
     w.register(o)
     w.register(d)
@@ -93,15 +102,23 @@ while time.time() < t_end or rounds == 0:
             b = inflight[done]
             rb = o.decode(*pieces[done])
             rc = b.sync()
-            diff = [] if (rc != 0 or rb.err_code != 0) else rb.host_batch().diff(b.host())
-            if rc != 0 or rb.err_code != 0 or diff:
+            if mode == "errors":
+                e = b.error
+                got = (e.code, e.frame_index) if e else (0, -1)
+                same_err = got == (rb.err_code, rb.err_frame)
+                diff = rb.host_batch().diff(b.host()) if same_err else ["error %s, oracle (%d, %d)" % (got, rb.err_code, rb.err_frame)]
+                rc_bad = False
+            else:
+                diff = [] if (rc != 0 or rb.err_code != 0) else rb.host_batch().diff(b.host())
+                rc_bad = rc != 0 or rb.err_code != 0
+            if rc_bad or diff:
                 bad += 1
-                print("MISMATCH seed", seed, "round", rounds, "batch", done, "of", len(pieces), "window", window, "spliced", spliced, "rc", rc, rb.err_code, diff[:4], flush=True)
+                print("MISMATCH seed", seed, "round", rounds, "batch", done, "of", len(pieces), "window", window, "spliced", spliced, "broken", broken, "rc", rc, rb.err_code, diff[:4], flush=True)
             b.close()
             done += 1
             batches += 1
     paths = d.debug_paths()
-    if paths["chain_rerun"] > (window + 1) * len(spliced) or paths["redone"]:
+    if mode != "errors" and (paths["chain_rerun"] > (window + 1) * len(spliced) or paths["redone"]):
         bad += 1
         print("CHAIN DID NOT HEAL seed", seed, "round", rounds, "window", window, "spliced", spliced, paths, flush=True)
     spliced_total += len(spliced)
