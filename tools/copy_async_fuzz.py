@@ -87,7 +87,8 @@ while time.time() - t0 < seconds and bad < 5:
                 bad += 1
                 print("MISMATCH (WAL batch between copy batches) round", rounds, "k", k, "of", len(todo), "oracle", r2.err_code, r2.err_desc, "device", g2.rc, g2.error.description if g2.error else "", wd[:4], flush=True)
             wal += 1
-        inflight.append(d.copy_decode(slot, buf, offs, flags=ASYNC))
+        # (one call in six is synchronous: it finishes the batches in flight first and comes back finished itself)
+        inflight.append(d.copy_decode(slot, buf, offs, flags=ASYNC if rng.random() < 0.84 else 0))
     for k, ((buf, offs), g) in enumerate(zip(todo, inflight)):
         rb = o.copy_decode(slot, buf, offs)
         g.sync()
