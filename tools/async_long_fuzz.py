@@ -22,14 +22,19 @@ from tests.test_gpu_async import FLAGS, DevBufs, _cut
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 mode = sys.argv[3] if len(sys.argv) > 3 else "cfg2"    # "nosidecar" / "mixed": (some) batches without the offsets sidecar; "cfg5": the DDL workload with default flags — the pipelined control path (pre-pass ring, two scratch sets) over many laps
-if mode == "cfg5":
+if mode in ("cfg5", "ddl"):
     from tests.test_gpu_async import FLAGS_DEFAULT
     t_end = time.time() + seconds
     rounds = batches = bad = 0
     while time.time() < t_end or rounds == 0:
         rng = random.Random(seed + rounds)
-        w = synth.cfg5(seed=0xE7B0000 + seed * 1000 + rounds)
-        buf, offs = w.fill(rng.choice([2, 3, 4]) << 20)
+        if mode == "ddl":   # DDL message -> Relation every few transactions: EVERY batch carries control frames, the chain stays on the pipelined control path
+            w = synth.Workload([synth.table_fixed(), synth.table_w8(), synth.table_mixed()], 0xE7D0000 + seed * 1000 + rounds, rows_per_txn=rng.choice([3, 5, 12]),
+                               mix=(60, 30, 10), upd_key=10, upd_toast=5, emit_relations=1, emit_origin=1, ddl_every=rng.choice([2, 3, 7]), type_msg_pct=10,
+                               keepalive_every=97, name="ddl_dense")
+        else:
+            w = synth.cfg5(seed=0xE7B0000 + seed * 1000 + rounds)
+        buf, offs = w.fill((rng.choice([2, 3, 4]) << 20) if mode == "cfg5" else (rng.choice([1, 2]) << 20))
         pieces = _cut(buf, offs, rng.randrange(80, 160), seed=seed * 104729 + rounds)
         o, d = oracle.Oracle(), Decoder(0)
         w.register(o, ready=not w.cfg.emit_relations)
