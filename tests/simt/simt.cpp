@@ -154,6 +154,14 @@ namespace {
 void init_block(BlockCtx& B, uint32_t bid) {
   B.alloc();
   B.bid = bid;
+  // ETLG_SIMT_LDS_POISON=1: a workgroup starts with garbage in its dynamic LDS, as on the GPU (the emulator's buffer otherwise holds what
+  // the previous workgroup left — often exactly the values a kernel that forgot to initialise something hopes for)
+  static const bool poison = getenv("ETLG_SIMT_LDS_POISON") != nullptr;
+  if (poison) {
+    static uint64_t r = 0xD1B54A32D192ED03ull;
+    uint64_t* w = (uint64_t*)B.lds;
+    for (size_t i = 0; i < (160 * 1024) / 8; i++) { r ^= r << 13; r ^= r >> 7; r ^= r << 17; w[i] = r; }
+  }
   for (uint32_t t = 0; t < g_block; t++) {
     Lane& L = B.lanes[t];
     L.view = LaneView{t, bid, g_block, g_grid, g_gx};
