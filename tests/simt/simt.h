@@ -192,7 +192,14 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 #ifndef SIMT_MALLOC_SLACK
 #define SIMT_MALLOC_SLACK 256   /* the sanitizer build (tools/simt_sanitize.py) allocates exactly what was asked for */
 #endif
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n + SIMT_MALLOC_SLACK); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// (ETLG_SIMT_MALLOC_POISON=1: device memory starts as 0xCD bytes instead of zeros — hipMalloc promises nothing, and a pool that hands a block
+// to its second user certainly holds old data)
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  static const bool poison = getenv("ETLG_SIMT_MALLOC_POISON") != nullptr;
+  *p = poison ? malloc(n + SIMT_MALLOC_SLACK) : calloc(1, n + SIMT_MALLOC_SLACK);
+  if (*p && poison) memset(*p, 0xCD, n + SIMT_MALLOC_SLACK);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 static inline hipError_t hipFree(void* p) { simt::device_sync(); free(p); return hipSuccess; }   // (hipFree synchronises the device)
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = calloc(1, n + (SIMT_MALLOC_SLACK ? 64 : 0)); if (*p) simt::host_register(*p, n + (SIMT_MALLOC_SLACK ? 64 : 0)); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { simt::device_sync(); simt::host_unregister(p); free(p); return hipSuccess; }
