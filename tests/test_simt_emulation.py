@@ -50,6 +50,8 @@ def _emu_env(simt_lib, timeout, order=None, drop=("ETLG_FUSED_KERNEL", "ETLG_FOR
         env.pop(k, None)
     if streams:   # "lazy": enqueued work runs as late as the HIP ordering rules allow (tests/simt/simt.h)
         env["ETLG_SIMT_STREAMS"] = streams
+    if grid or streams:   # these runs also start every workgroup's dynamic LDS and every device allocation as garbage, as the GPU may
+        env["ETLG_SIMT_LDS_POISON"] = env["ETLG_SIMT_MALLOC_POISON"] = "1"
     if grid:   # several workgroups resident and interleaved: (how many, "shuffle" | "reverse") — tests/simt/simt.cpp
         env["ETLG_SIMT_GRID"], env["ETLG_SIMT_GRID_ORDER"] = str(grid[0]), grid[1]
     if order:
