@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libetl_gfx950.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "plan.hip", "scan.hip", "copy.hip", "columns.hip", "host.cpp"]
+SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "rows.hip", "plan.hip", "scan.hip", "copy.hip", "columns.hip", "host.cpp"]
 # per-source optimisation level: k_fused is measurably faster built for size (88 vs 93 us on cfg2, tools/variants.sh);
 # k_cells and the rest are not
 OPT = {"fused.hip": "-Os"}

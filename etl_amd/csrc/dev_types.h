@@ -14,11 +14,12 @@ struct DevCol {
   uint8_t cls;       // etlg_type_class
   uint8_t nullable;
   uint8_t identity;
-  uint8_t _pad;
+  uint8_t key_col;   // (k_rows) the column whose key_index is THIS record's index: cell j of a dense key tuple decodes against column key_col of record j
   uint16_t off_full; // byte offset inside a full-layout row
   uint16_t off_key;  // byte offset inside a key-layout row
   uint16_t key_index;
-  uint16_t _pad2;
+  uint16_t hr;       // (k_rows) heap rank: bits 0..7 among the columns of a full row whose class can reach the heap, bits 8..15 among the identity
+                     // columns in key_index order; 0xFF = the class never reaches the heap
 };
 
 // A ReplicatedTableSchema instance (reference: crates/etl/src/schema.rs:380-441).
@@ -103,6 +104,8 @@ struct FusedParams {
   uint32_t clear_words;        // 64-bit words of d_clear this launch zeroes (the descriptor buffer of the NEXT batch)
   unsigned long long* d_clear;
   uint32_t copy_rel;           // k_copy_cells: the table id the rows' Insert events carry
+  uint32_t rows_img;           // k_rows: bytes of the tile's image of the fixed arena in LDS (multiple of 16, < 64 KiB)
+  uint32_t rows_maxh;          // k_rows: most heap-class columns in one slot (rows per image of the heap-cell table)
 };
 
 constexpr unsigned long long kNoErr = ~0ull;

@@ -41,6 +41,7 @@ void launch_raw(etlg_ctx* c, int which, const DecParams& p) {
   else if (which == kPlanPre) etlg_k_launch_plan_pre(&p, &c->pq, c->stream);
   else if (which == kCells) etlg_k_launch_cells(&p, &c->fq, c->stream);
   else if (which == kCopyCells) etlg_k_launch_copy_cells(&p, &c->fq, c->stream);
+  else if (which == kRows) etlg_k_launch_rows(&p, &c->fq, c->stream);
   else etlg_k_launch(which, &p, c->stream);
 }
 
@@ -242,7 +243,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   if (e == hipSuccess) e = hipMemcpy(c->d_init_ring, c->h_init_ring, sizeof(DevResult) * etlg_ctx::kResRing, hipMemcpyHostToDevice);
   if (e != hipSuccess) { snprintf(g_create_err, sizeof g_create_err, "hipMalloc: %s", hipGetErrorString(e)); delete c; return ETLG_DeviceError; }
   // (a kernel whose static + dynamic LDS request exceeds a CU's 160 KB is refused here, not at its first launch)
-  if (etlg_k_fused_set_lds() || etlg_k_cells_set_lds() || etlg_k_copy_set_lds()) {
+  if (etlg_k_fused_set_lds() || etlg_k_cells_set_lds() || etlg_k_copy_set_lds() || etlg_k_rows_set_lds()) {
     snprintf(g_create_err, sizeof g_create_err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) refused a kernel's LDS request");
     delete c; return ETLG_DeviceError;
   }
@@ -255,6 +256,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* rp = getenv("ETLG_RB_PARTS"); c->rb_parts_test = rp ? (uint32_t)atoi(rp) : 0; }   // tests: lanes per row in k_rb_rows (1-4) instead of the choice by row count
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
+  { const char* rm = getenv("ETLG_ROWS"); if (rm) c->rows_mode = atoi(rm); }
   clear_error(c);
   (void)etlg_k_plan_set_lds();
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
@@ -440,6 +442,12 @@ int32_t etlg_host_alloc(etlg_ctx* c, size_t bytes, void** out) {
   return ETLG_OK;
 }
 void etlg_host_free(void* p) { if (p) (void)hipHostFree(p); }   // batches whose control pre-pass ran ahead of their decode
+// debugging aid (not part of etlg.h): [0] batches k_rows produced, [1] batches it handed back to k_cells / k_fused
+int32_t etlg_ctx_debug_rows(etlg_ctx* c, unsigned long long* out2) {
+  if (!c || !out2) return ETLG_InvalidArgument;
+  out2[0] = c->rows_n; out2[1] = c->rows_redone;
+  return ETLG_OK;
+}
 int32_t etlg_ctx_debug_paths8(etlg_ctx* c, unsigned long long* out8) {
   if (!c || !out8) return ETLG_InvalidArgument;
   for (int i = 0; i < 8; i++) out8[i] = c->path_n[i];
@@ -464,7 +472,7 @@ int32_t etlg_ctx_profile_read(etlg_ctx* c, etlg_kernel_stat* out, uint32_t cap, 
   }
   c->prof_recs.clear();
   uint32_t k = 0;
-  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kPlanPre ? "k_plan_pre" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : i == kCopyCells ? "k_copy_cells" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
+  for (int i = 0; i < kProfSlots && k < cap; i++) { out[k].name = i == kPlan ? "k_plan" : i == kPlanPre ? "k_plan_pre" : i == kFused ? "k_fused" : i == kCells ? "k_cells" : i == kBounds ? "k_bounds" : i == kCopy ? "k_copy_frames" : i == kCopyCells ? "k_copy_cells" : i == kRows ? "k_rows" : etlg_k_name(i); out[k].launches = c->prof_n[i]; out[k].total_ms = c->prof_ms[i]; k++; }
   *n = k;
   return ETLG_OK;
 }

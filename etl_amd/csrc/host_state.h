@@ -71,6 +71,12 @@ extern "C" uint32_t etlg_k_copy_cells_table_bytes(uint32_t maxc);
 extern "C" uint32_t etlg_k_copy_cells_lds(uint32_t maxc, uint32_t window);
 extern "C" void etlg_k_launch_copy_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" uint32_t etlg_k_cells_maxc(void);
+extern "C" void etlg_k_launch_rows(const DecParams* p, const void* q, hipStream_t s);
+extern "C" int etlg_k_rows_set_lds(void);
+extern "C" uint32_t etlg_k_rows_table_bytes(uint32_t maxh, uint32_t cf);
+extern "C" uint32_t etlg_k_rows_static_lds(void);
+extern "C" uint32_t etlg_k_rows_max_cols(void);
+extern "C" uint32_t etlg_k_rows_max_heap_cols(void);
 extern "C" uint32_t etlg_k_cells_lds_floor(uint32_t maxc);
 extern "C" uint32_t etlg_k_cells_static_lds(uint32_t maxc);
 extern "C" uint32_t etlg_k_copy_cells_static_lds(uint32_t maxc);
@@ -82,7 +88,8 @@ constexpr int kCopy = 10;  // ... of the table-copy row splitter (copy.hip)
 constexpr int kPlan = 11;  // ... of the fixed-width plan (plan.hip)
 constexpr int kCopyCells = 12;  // ... of the table-copy rows -> arena kernel (cells.hip, k_cells<.., COPYK>)
 constexpr int kPlanPre = 13;    // ... of the plan's sidecar pre-pass (plan.hip, k_plan_pre)
-constexpr int kProfSlots = 14;
+constexpr int kRows = 14;       // ... of the row-synchronous kernel (rows.hip)
+constexpr int kProfSlots = 15;
 
 namespace {
 
@@ -327,6 +334,10 @@ struct etlg_ctx {
   uint32_t plan_dbg = 0;         // ETLG_PLAN_DBG: bit 0 = no LDS staging (tests of the in-place reader)
   int n_cus = 256;
   uint32_t plan_skip = 0, plan_penalty = 4, plan_streak = 0;
+  // k_rows (rows.hip) hands a batch back when a tile does not fit its LDS window / image: the batches behind it skip the kernel for a while
+  uint32_t rows_skip = 0, rows_penalty = 4, rows_streak = 0;
+  int rows_mode = 1;             // ETLG_ROWS: 0 never, 1 wherever k_cells / k_fused-64 would run and the batch is eligible
+  unsigned long long rows_n = 0, rows_redone = 0;   // batches k_rows produced / handed back
   bool side_dirty = true;            // table states / the shared table cache changed since the side inputs were last built
   bool last_any_sync_done = false;
   bool last_had_ctrl = false;        // the last finished batch took the control path and did hold Relation / DDL frames
@@ -376,7 +387,7 @@ struct etlg_ctx {
   unsigned long long path_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long copy_n[2] = {0, 0};   // table-copy batches produced by k_copy_cells / decoded through the row -> frame rewrite
   bool copy_direct = true;                 // ETLG_COPY_DIRECT=0: always the row -> frame rewrite
-  int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells, 3 k_plan whenever eligible (default: plan, else by frame size)
+  int fused_kernel = -1;         // ETLG_FUSED_KERNEL: 0 k_fused/256, 1 k_fused/64, 2 k_cells, 3 k_plan whenever eligible, 4 k_rows whenever eligible (default: plan, else by frame size)
   uint32_t fused_dbg = 0;        // ETLG_FUSED_DBG: ablation bits for profiling only (results are wrong)
   std::vector<OutSet*> out_pool;
   DevResult* h_init = nullptr;              // pinned, constant: the cleared result block
@@ -424,6 +435,8 @@ struct etlg_batch {
   DevResult* d_res_blk = nullptr;  // this batch's result block on the device
   uint32_t res_seq_no = 0;         // ... and the batch's number in the ring's sequence (finish_batch: has the slot's next re-initialisation been issued?)
   bool used_cells = false; // ... and it was k_cells
+  bool used_rows = false;  // ... and it was k_rows
+  bool no_rows = false;    // k_rows handed this batch back: the second attempt takes k_cells / k_fused
   bool used_fused = false; // the fused kernel produced this batch; errors re-run the multi-pass kernels
   DecParams params{};
   SideSet* side = nullptr;   // the side inputs its kernels read (released when the batch is finished)

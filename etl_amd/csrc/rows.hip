@@ -1,0 +1,608 @@
+// Row-synchronous single-pass decode kernel for gfx950 — the variable-length path since round 6.
+//
+// k_cells (cells.hip) slices a tile's tuples into a cell table and then visits the table column by column with four
+// waves: ~25 k instructions per 64-frame tile, a third of them the per-visit skeleton (frame state, slot / column records,
+// arena addresses per LANE), and a sizing pass that parses numerics a second time. Here the same tile is ONE walk:
+//
+//   P0  all waves: stage the tile's bytes + side tables into LDS, zero the tile's image of the fixed arena
+//   P1  spine wave, lane = frame: envelope, tag, transaction scan, ownership + schema slot, FIXED-arena size per frame
+//       (it depends on the message heads only) -> wave scan -> every frame knows where its rows sit in the LDS image;
+//       the fixed-arena and transaction aggregates are published at once and resolved by two other waves while the
+//       spine walks
+//   P2  spine wave: the frames of one (schema slot, image kind, cell count) walk their tuples IN STEP — in trip k every
+//       active lane stands in front of cell k of the same column, so the column record is wave-uniform (scalar loads, a
+//       scalar class switch: the per-schema program the host would otherwise have to compile) and the value codec runs on
+//       up to 64 cells of one class. Fixed-width values go straight into the LDS image; cells that reach the heap
+//       (text, numeric, bytea, deferred classes) are sized on the spot — the running sum IS the cell's heap offset inside
+//       its frame — and noted in a small table [heap rank][frame]
+//   P3  spine: wave scan of (events, heap dwords), look-back; then numerics / bytea are emitted at their final heap
+//       positions, heap references patched into the image, toast cells aliased, event headers stored
+//   P4  the other waves, as soon as the heap prefix is known: the text of String / deferred cells is copied by 16-byte
+//       chunks dealt out densely over the lanes (a chunk's owner cell by binary search over the row's chunk prefix sums),
+//       validated as UTF-8 on the way; finally all waves copy the image to the fixed arena — one contiguous block
+//
+// What the kernel does not cover it hands back (DevResult.fused_fail bit 4, "rows gave up": the host decodes the batch
+// again with k_cells / k_fused): a tile whose bytes do not fit its LDS window, a tile whose rows outgrow the image, a
+// frame with more than 32 KiB of heap entries. Errors are recorded at their frame like everywhere else and send the batch
+// to the multi-pass kernels for the exact cut (the code recorded here only has to be SOME error of that frame).
+#define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
+#define ETLG_DBG_WORD dbg_u
+#define ETLG_TSTAMP_WHO (spine && lane == 0)
+#include "lookback.hip.h"
+#include "utf8_swar.h"
+
+namespace etlg {
+
+constexpr int RNW = 4;          // waves per tile
+constexpr uint32_t kRowsGaveUp = 16u;
+// heap-cell table entry: window position of the text (17 bits) | heap offset inside the frame, dwords (13 bits) | kind (2 bits)
+enum : uint32_t { HK_NONE = 0, HK_COPY = 1, HK_NUMERIC = 2, HK_BYTEA = 3 };
+constexpr uint32_t kRowsHeapMaxDw = 0x1FFFu;
+
+DEV bool rows_heap_class(uint32_t cls) {
+  return !(cls == ETLG_TC_BOOL || cls == ETLG_TC_I16 || cls == ETLG_TC_I32 || cls == ETLG_TC_I64 || cls == ETLG_TC_U32 || cls == ETLG_TC_UUID ||
+           cls == ETLG_TC_DATE || cls == ETLG_TC_TIME || cls == ETLG_TC_TIMETZ || cls == ETLG_TC_TIMESTAMP || cls == ETLG_TC_TIMESTAMPTZ);
+}
+
+#ifndef ETLG_ROWS_MINBLOCKS
+#define ETLG_ROWS_MINBLOCKS 3
+#endif
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams pg, FusedParams q) {
+  ETLG_DYNAMIC_LDS(smem);
+  __shared__ uint32_t s_offs[64 + 1];
+  __shared__ uint32_t fr_hp[64];     // heap offset of the frame's first entry (absolute, bytes)
+  __shared__ uint32_t s32[16];
+  __shared__ uint64_t s64[12];
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  if (q.clear_words) {  // descriptors are double buffered: this launch clears the buffer the next batch will use
+    const uint32_t per = (q.clear_words + gridDim.x - 1) / gridDim.x;
+    for (uint32_t i = tid; i < per; i += NW * 64) { const uint32_t w = blockIdx.x * per + i; if (w < q.clear_words) q.d_clear[w] = 0; }
+  }
+  if (!(pg.flags & 16u) && !load_carry(pg)) return;  // ASYNC chain: the state the batch before this one left (flags bit 4: read late, by the tiles that need it)
+  DecParams p = pg;
+  uint32_t dbg_u, cf;
+  ETLG_SCALAR_COPY(dbg_u, q.dbg); ETLG_SCALAR_COPY(cf, q.blk);
+  const uint32_t tile = blockIdx.x;
+  const bool spine = (((tid >> 6) + tile) & (uint32_t)(NW - 1)) == 0;   // the role rotates with the tile (see cells.hip: wave w of a workgroup sits on SIMD w)
+  const uint32_t role = ((tid >> 6) + tile) & (uint32_t)(NW - 1);
+  if ((dbg_u & 8) && spine && lane == 0) s64[7] = clock64();
+  uint32_t* fail = &pg.res->fused_fail;
+  // ---- P0: side tables, offsets, staging
+  SideRegs side;
+  side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
+  const uint32_t maxh = q.rows_maxh, R = 2 * maxh;
+  // dynamic LDS: side tables | heap-cell table (u32 [R][cf]) | slot offsets (u16 [R][cf]) | image of the fixed arena | staging window
+  uint32_t* const tabw = (uint32_t*)(smem + q.side_bytes);
+  uint16_t* const tabs = (uint16_t*)(tabw + R * cf);
+  const uint32_t tab_bytes = (R * cf * 6u + 15u) & ~15u;
+  u8* const img = (u8*)tabw + tab_bytes;
+  u8* const stage = img + q.rows_img;
+  const uint32_t f0 = tile * cf;
+  const uint32_t nt = pg.nframes - f0 < cf ? pg.nframes - f0 : cf;
+  const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)pg.offs;
+  const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
+  const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
+  const uint32_t a0 = span0 & ~15u;
+  const uint32_t used = q.side_bytes + tab_bytes + q.rows_img;
+  const uint32_t wcap = q.lds_bytes > used ? q.lds_bytes - used : 0u;
+  const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len && span1 - a0 + 16 <= (1u << 17) && (uint64_t)(span1 - a0) + 16 <= wcap;
+  if (window_ok) {
+    const uint32_t full_end = a0 + ((span1 - a0) & ~15u);
+    stage_chunks<NW * 64>(pg.in, stage, a0, full_end, tid);
+    for (uint32_t c = full_end + tid; c < span1; c += NW * 64) stage[c - a0] = pg.in[c];
+  }
+  side_store<NW * 64>((uint32_t*)smem, tid, side);
+  if (tid <= nt) s_offs[tid] = my_o;
+  {  // the table starts empty, the image as zeros (NULL slots, padding and VALUE states are never written)
+    uint4* z = (uint4*)tabw;
+    const uint32_t n16 = (tab_bytes + q.rows_img) >> 4;
+    for (uint32_t i = tid; i < n16; i += NW * 64) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  TSTAMP(0);
+  bool lane_ok = true;
+  if (tid < nt) {
+    const uint32_t o0 = s_offs[tid], o1 = s_offs[tid + 1];
+    lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
+  }
+  const bool tile_ok = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
+  if (!tile_ok && tid == 0) atomicOr(fail, kRowsGaveUp);   // (the tile still takes part in the look-backs, with nothing to report)
+  TSTAMP(1);
+  const u8* const base = stage;
+  const uint32_t b0 = a0;
+
+  // ================= P1 (spine): heads, transaction scan, slots, fixed sizes
+  const bool live = spine && lane < nt && tile_ok;
+  const uint32_t f = f0 + lane;
+  FrameView v{f, 0, base, base};
+  uint32_t rel_id = 0, old_kind = ETLG_OLD_NONE, n_old = 0, n_new = 0, vbytes = 0, o0 = 0;
+  uint32_t c = 0, e = 0;          // walk cursor / frame end, as window offsets
+  uint32_t ph = 0;                // 0 nothing to walk, 1 in front of the old / key image's cells, 2 in front of the new image's cells
+  bool wire_ok = true, isrow = false, derr = false, gave = false;
+  uint32_t cnt = 0, mark = 0, seg_in = 0, pm = 0, tot_cnt = 0, tot_mark = 0;
+  int slot = -1;
+  uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_fx = 0;
+  uint64_t pay[3] = {0, 0, 0};
+  uint64_t toast = 0;             // new-image columns sent as 'u' (resolved after the heap references are final)
+  uint64_t rows_old = 0, rows_new = 0;   // wave-uniform: rows of the heap-cell table that hold an entry
+  TxnCtx tx{true, 0, 0};
+  uint32_t bc = 0, bm = 0;
+  uint64_t carried_lsn = 0, start_ord = 0;
+  uint32_t tot_f = 0;
+  if (spine) {
+    ETLG_WAVE_PRIO(3);
+    if (live) {
+      o0 = s_offs[lane];
+      const uint32_t o1 = s_offs[lane + 1];
+      if (o1 > o0 && o1 <= pg.in_len) {
+        v.fr = base + (o0 - b0);
+        v.e = base + (o1 - b0);
+        v.tag = classify_ptr(v.fr, o1 - o0);
+      }
+      const uint32_t tag = v.tag;
+      isrow = tag == 'I' || tag == 'U' || tag == 'D';
+      if (!isrow) {
+        RowMsg dummy;
+        wire_ok = frame_structure(v, dummy, true);
+      } else {
+        c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
+        wire_ok = e >= c + 5;
+        if (wire_ok) {
+          rel_id = ld_be32(base + c); c += 4;
+          // the first image header: 'K' | 'O' | 'N', i16 column count
+          const uint64_t head = ldu64(base + c);
+          const uint32_t t = (uint32_t)head & 0xFFu;
+          const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
+          const bool is_old = (t == 'K') | (t == 'O');
+          const bool hdr_ok = (e - c >= 3) & !(cnt16 & 0x8000u) & (tag == 'I' ? t == 'N' : tag == 'D' ? is_old : (is_old | (t == 'N')));
+          wire_ok = hdr_ok;
+          if (hdr_ok) {
+            c += 3;
+            if (is_old) { old_kind = t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL; n_old = cnt16; ph = 1; }
+            else { n_new = cnt16; ph = 2; }
+          }
+        }
+      }
+      if (consumes_ordinal(tag)) cnt = 1;
+      if (tag == 'B') { cnt |= 0x80000000u; mark = ((o0 + 1) << 1) | 1; }
+      if (tag == 'C') mark = (o0 + 1) << 1;
+    }
+    {  // wave-level transaction scan (a tile's frames live in one wave)
+      const uint32_t ic = wave_scan_incl(cnt, [](uint32_t a, uint32_t b) { return seg_combine(a, b); }, 0u);
+      const uint32_t im = wave_scan_max(mark);
+      pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)im, 0x138, 0xF, 0xF, false);  // previous lane's value, 0 into lane 0
+      seg_in = ic;
+      tot_cnt = wave_last(ic); tot_mark = wave_last(im);
+    }
+    // ownership + schema slot, fixed-arena bytes of the frame
+    if (isrow && wire_ok) {
+      const int ti = find_table(p, rel_id);
+      if (should_apply(p, ti, rel_id, 0)) {   // (no table is in SyncDone state on this path: the host sends those batches to k_cells)
+        slot = cache_slot_before(p, ti, f);
+        if (slot < 0) { record_error(pg, f, RK_SCHEMA, (uint32_t)(-slot)); slot = -1; derr = true; }
+        else if (p.slots[slot].n_cols > q.maxc) { gave = true; slot = -1; }
+      }
+      if (slot >= 0) {
+        const DevSlot& s = p.slots[slot];
+        emit = 1;
+        if (old_kind != ETLG_OLD_NONE) { old_sz = old_kind == ETLG_OLD_KEY ? s.row_key : s.row_full; fixed = old_sz; }
+        if (v.tag != 'D') fixed += s.row_full;
+      }
+    } else if (live && !isrow) {
+      RowMsg dummy{};
+      int rs = -1;
+      size_frame(p, v, tx, wire_ok, dummy, emit, fixed, heap, pay, rs, false, true);   // (records the wire error of a malformed frame)
+    }
+    if (isrow && !wire_ok) { record_error(pg, f, RK_WIRE, ETLG_E_WIRE); ph = 0; }
+    const uint32_t ifx = wave_scan_add(fixed >> 2);
+    tot_f = wave_last(ifx);
+    x_fx = ifx - (fixed >> 2);
+    if ((uint64_t)tot_f * 4u > q.rows_img) {   // the tile's rows do not fit the image: nothing of this tile is written
+      gave = true; tot_f = 0; emit = 0; fixed = 0; ph = 0; x_fx = 0;
+    }
+    if (lane == 0) { s64[1] = tot_f; s64[2] = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark; }
+    ETLG_WAVE_PRIO(0);
+  }
+  __syncthreads();
+  TSTAMP(2);
+  // the two look-backs whose aggregates are known from the heads alone run beside the walk
+  if (role == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
+  if (role == 2 % NW && NW > 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
+
+  uint32_t x_ev = 0, x_hp = 0;
+  if (spine) {
+    if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
+    if (NW <= 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
+    // ================= P2 (spine): the walk. Begin / Commit bodies first (field copies)
+    const uint32_t rowb = x_fx << 2;   // the frame's body inside the image
+    if (emit && v.tag == 'B') st64((uint32_t*)(img + rowb), ld_be64(v.fr + kBodyOff + 8));
+    if (emit && v.tag == 'C') { st64((uint32_t*)(img + rowb), ld_be64(v.fr + kBodyOff + 9)); st64((uint32_t*)(img + rowb) + 2, ld_be64(v.fr + kBodyOff + 17)); }
+    uint32_t hp = 0;   // heap bytes of the frame so far = heap offset of its next entry
+    // One image of one group of frames: `in` = the lanes of the group, all in front of cell 0 of an image with n_u cells that decodes
+    // against slot slot_u (~0: nobody decodes it, the walk is structural); kmode 0 full row / update row, 1 dense key tuple,
+    // 2 full-width key tuple; img1: the new image.
+    auto walk_image = [&](bool in, uint32_t slot_u, uint32_t kmode, uint32_t n_u, bool img1) {
+      const ETLG_CONST_AS uint32_t* cw = nullptr;
+      if (slot_u != ~0u) {
+        const ETLG_CONST_AS uint32_t* sw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.slots + slot_u);
+        static_assert(sizeof(DevSlot) == 44 && sizeof(DevCol) == 12, "descriptor words below");
+        cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + sw[6]);   // DevSlot.cols_base
+      }
+      u8* const rowp = img + rowb + (img1 ? old_sz : 0u);
+      const bool upd = img1 && v.tag == 'U';
+      bool on = in;
+      unsigned long long tprev = 0;
+      const bool tclk = (dbg_u & 32u) && img1 && (blockIdx.x & 15) == 3;
+      if (tclk) tprev = clock64();
+      for (uint32_t k = 0; k < n_u; k++) {
+        if (tclk && k) { const unsigned long long tn = clock64(); if (lane == 0) atomicAdd(&pg.res->dbg_t[(k - 1) % 12], tn - tprev); tprev = tn; }
+        // the column record (wave-uniform): -1 = the cell is walked, not decoded
+        int ci = -1;
+        uint32_t w0 = 0, w1 = 0, w2 = 0;
+        if (cw) {
+          ci = (int)k;
+          if (kmode == 1) ci = (int)(cw[3 * k] >> 24);                    // DevCol.key_col of record k
+          w0 = cw[3 * ci]; w1 = cw[3 * ci + 1]; w2 = cw[3 * ci + 2];
+          if (kmode == 2 && !((w0 >> 16) & 0xFFu)) ci = -1;              // full-width key tuple: only the identity columns are read
+        }
+        const uint32_t cls = w0 & 0xFFu, nullable = (w0 >> 8) & 0xFFu;
+        const uint32_t off = kmode ? (w1 >> 16) : (w1 & 0xFFFFu);
+        const uint32_t kout = kmode ? (w2 & 0xFFFFu) : (uint32_t)ci;
+        const uint32_t hr = kmode ? (w2 >> 24) : ((w2 >> 16) & 0xFFu);
+        // the cell head: 'n' | 'u' | ('t' | 'b') i32 len bytes
+        const uint64_t head = ldu64(base + c);  // the window has 16 spare bytes past any frame
+        const uint32_t t = (uint32_t)head & 0xFFu;
+        const uint32_t room = e - c;
+        const bool is_val = (t == 't') | (t == 'b');
+        const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
+        const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
+        if (on & !cell_ok) wire_ok = false;
+        on = on & cell_ok;
+        const uint32_t pos = c + 5;
+        if (on) { vbytes += len; c += is_val ? 5u + len : 1u; }
+        if (ci < 0) continue;
+        uint32_t* const slotp = (uint32_t*)(rowp + off);
+        uint32_t st = ETLG_CELL_VALUE;
+        if (on && t == 't') {
+          const u8* d = base + pos;
+          if (rows_heap_class(cls)) {
+            uint32_t hb, kind = HK_COPY, nbytes = len;
+            if (cls == ETLG_TC_NUMERIC) {
+              NumShape ns;
+              const bool okn = numeric_plain(d, len, ns) || numeric_scan(d, len, ns, true);
+              if (!okn) derr = true;
+              nbytes = 8 + 2 * ns.ngroups; kind = HK_NUMERIC;
+              if (!okn) nbytes = 0;
+            } else if (cls == ETLG_TC_BYTEA) {
+              if (len < 2) derr = true;
+              nbytes = len >= 2 ? (len - 2) >> 1 : 0u; kind = HK_BYTEA;
+            } else if (cls == ETLG_TC_F32 || cls == ETLG_TC_F64) {
+              uint64_t bits = 0;
+              const int r = parse_float_fast(d, len, cls == ETLG_TC_F32, bits, true);
+              if (r == 2) derr = true;
+              if (r == 0) { st64(slotp, bits); kind = HK_NONE; nbytes = 0; }
+              else st = ETLG_CELL_DEFERRED;
+            } else if (cls != ETLG_TC_STRING) st = ETLG_CELL_DEFERRED;   // json / arrays / classes without a codec: the source text
+            hb = pad4(nbytes);
+            if (kind != HK_NONE) {
+              if ((hp >> 2) > kRowsHeapMaxDw || pos >= (1u << 17)) gave = true;
+              else {
+                const uint32_t r = (img1 ? maxh : 0u) + hr;
+                tabw[r * cf + lane] = pos | ((hp >> 2) << 17) | (kind << 30);
+                tabs[r * cf + lane] = (uint16_t)((u8*)slotp - img);
+                slotp[1] = nbytes;
+                hp += hb;
+              }
+            }
+          } else {
+            uint32_t tmp[4] = {0, 0, 0, 0};
+            uint32_t hdummy = 0;
+            const uint32_t err = decode_text_cell<false>(cls, d, len, tmp, nullptr, hdummy, st, true);
+            if (err) derr = true;
+            else {
+              const uint32_t nw = slot_bytes(cls) >> 2;
+              slotp[0] = tmp[0];
+              if (nw > 1) slotp[1] = tmp[1];
+              if (nw > 2) slotp[2] = tmp[2];
+              if (nw > 3) slotp[3] = tmp[3];
+            }
+          }
+        } else if (on && t == 'n') {
+          if (!nullable) derr = true;   // Required column missing from tuple (codec/event.rs:945-961)
+          st = ETLG_CELL_NULL;
+        } else if (on && t == 'u') {
+          if (upd) toast |= 1ull << k;   // resolved once the old image's heap references are final
+          else derr = true;              // a full row / key image cannot miss a value
+        } else if (on) {
+          derr = true;                   // binary format
+        }
+        if (on && st) atomicOr((uint32_t*)rowp + (kout >> 4), st << (2 * (kout & 15u)));
+        // which rows of the table hold entries (wave-uniform: any lane of the group)
+        if (rows_heap_class(cls) && hr != 0xFFu && __ballot(on && t == 't')) { if (img1) rows_new |= 1ull << hr; else rows_old |= 1ull << hr; }
+      }
+    };
+    // Shape of an image against its slot (convert_tuple_to_row / normalize_key_tuple_to_row, codec/event.rs:559-565, 889-922): 0 full /
+    // update row, 1 dense key tuple, 2 full-width key tuple, 3 = a shape error
+    auto image_mode = [&](uint32_t slot_u, bool key, uint32_t n_u) -> uint32_t {
+      const ETLG_CONST_AS uint32_t* sw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.slots + slot_u);
+      const uint32_t n_cols = sw[0], n_ident = sw[1];
+      if (!key) return n_u == n_cols ? 0u : 3u;
+      if (n_ident == 0) return 3u;
+      return n_u == n_ident ? 1u : n_u == n_cols ? 2u : 3u;
+    };
+    // ---- old / key images, one group per (slot, kind, cell count)
+    for (;;) {
+      const unsigned long long pend = __ballot(ph == 1);
+      if (!pend) break;
+      const int leader = __builtin_ctzll(pend);
+      const uint32_t slot_u = (uint32_t)__builtin_amdgcn_readlane(slot, leader);
+      const uint32_t kind_u = (uint32_t)__builtin_amdgcn_readlane((int)old_kind, leader);
+      const uint32_t n_u = (uint32_t)__builtin_amdgcn_readlane((int)n_old, leader);
+      const bool in = ph == 1 && (uint32_t)slot == slot_u && old_kind == kind_u && n_old == n_u;
+      uint32_t mode = 0;
+      if (slot_u != ~0u) {
+        mode = image_mode(slot_u, kind_u == ETLG_OLD_KEY, n_u);
+        if (mode == 3) { if (in) { derr = true; ph = 0; } continue; }   // (the frame fails whatever its cells hold)
+      }
+      walk_image(in, slot_u, mode, n_u, false);
+      if (in) {
+        ph = 0;
+        if (v.tag == 'U' && wire_ok) {   // the new image's header
+          const uint64_t head = ldu64(base + c);
+          const uint32_t t = (uint32_t)head & 0xFFu;
+          const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
+          const bool hdr_ok = (e - c >= 3) & (t == 'N') & !(cnt16 & 0x8000u);
+          if (hdr_ok) { c += 3; n_new = cnt16; ph = 2; } else wire_ok = false;
+        }
+      }
+    }
+    // ---- new images, one group per (slot, cell count)
+    for (;;) {
+      const unsigned long long pend = __ballot(ph == 2);
+      if (!pend) break;
+      const int leader = __builtin_ctzll(pend);
+      const uint32_t slot_u = (uint32_t)__builtin_amdgcn_readlane(slot, leader);
+      const uint32_t n_u = (uint32_t)__builtin_amdgcn_readlane((int)n_new, leader);
+      const bool in = ph == 2 && (uint32_t)slot == slot_u && n_new == n_u;
+      if (slot_u != ~0u && image_mode(slot_u, false, n_u) == 3) { if (in) { derr = true; ph = 0; } continue; }
+      walk_image(in, slot_u, 0u, n_u, true);
+      if (in) ph = 0;
+    }
+    TSTAMP(3);
+    if (live && isrow) {
+      if (!wire_ok) record_error(pg, f, RK_WIRE, ETLG_E_WIRE);
+      else if (derr) record_error(pg, f, RK_DECODE, ETLG_E_WIRE);
+      pay[v.tag == 'I' ? 0 : v.tag == 'U' ? 1 : 2] = vbytes;
+      if (slot >= 0) heap = hp;
+    }
+    if (__ballot(gave)) { if (lane == 0) atomicOr(fail, kRowsGaveUp); }
+    // wave scan of (events, heap dwords), payload counters
+    const uint32_t ie = wave_scan_add(emit), ih = wave_scan_add(heap >> 2);
+    const uint32_t tot_e = wave_last(ie), tot_h = wave_last(ih);
+    const uint32_t a0p = wave_last(wave_scan_add((uint32_t)pay[0])), a1p = wave_last(wave_scan_add((uint32_t)pay[1])),
+                   a2p = wave_last(wave_scan_add((uint32_t)pay[2]));
+    if (lane == 0) {
+      if (a0p) atomicAdd(&pg.res->pay_shard[tile & 31][0], (unsigned long long)a0p);
+      if (a1p) atomicAdd(&pg.res->pay_shard[tile & 31][1], (unsigned long long)a1p);
+      if (a2p) atomicAdd(&pg.res->pay_shard[tile & 31][2], (unsigned long long)a2p);
+    }
+    x_ev = ie - emit; x_hp = ih - (heap >> 2);
+    const uint64_t agg = ((uint64_t)tot_e << 32) | tot_h;
+    const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg, 0, fail);
+    const uint64_t pre_hp = (uint64_t)(uint32_t)a << 2;
+    const bool heap_fits = pre_hp + ((uint64_t)tot_h << 2) <= pg.heap_cap && pre_hp + ((uint64_t)tot_h << 2) <= 0xFFFFFFFFull;
+    if (lane < cf) fr_hp[lane] = (uint32_t)(pre_hp + ((uint64_t)x_hp << 2));
+    if (lane == 0) { s64[0] = agg; s64[4] = a; s64[8] = rows_old; s64[9] = rows_new; s32[0] = heap_fits ? 1u : 0u; }
+  }
+  __syncthreads();
+  TSTAMP(4);
+  const uint64_t pre_ev = s64[4] >> 32, pre_fx = s64[5] << 2;
+  const bool heap_fits = s32[0] != 0;
+  const uint64_t m_old = s64[8], m_new = s64[9];
+
+  if (!spine) {
+    // ================= P4 (the other waves): text of String / deferred cells -> heap, 16 bytes per lane and step
+    const uint32_t cw_rank = role - 1, ncw = NW - 1;
+    for (uint32_t half = 0; half < 2 && heap_fits; half++) {
+      uint64_t m = half ? m_new : m_old;
+      while (m) {
+        const uint32_t hr = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t r = half * maxh + hr;
+        const uint32_t w = lane < nt ? tabw[r * cf + lane] : 0u;
+        const bool act = (w >> 30) == HK_COPY;
+        const uint32_t pos = w & 0x1FFFFu;
+        const uint32_t len = act ? __builtin_bswap32(ldu32(base + pos - 4)) : 0u;
+        const uint32_t dst = act ? fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2) : 0u;
+        const uint32_t nch = (len + 15u) >> 4;
+        const uint32_t incl = wave_scan_add(nch);
+        const uint32_t T = wave_last(incl);
+        const uint32_t excl = incl - nch;
+        for (uint32_t t0 = cw_rank * 64u; t0 < T; t0 += ncw * 64u) {
+          const uint32_t x = t0 + lane;
+          // the chunk's cell: the number of lanes whose inclusive sum is <= x
+          uint32_t lo = 0;
+#pragma unroll
+          for (uint32_t step = 32; step; step >>= 1) {
+            const uint32_t probe = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), 64);
+            if (probe <= x) lo += step;
+          }
+          const uint32_t owner = lo < 63u ? lo : 63u;
+          const uint32_t o_pos = (uint32_t)__shfl((int)pos, (int)owner, 64), o_len = (uint32_t)__shfl((int)len, (int)owner, 64);
+          const uint32_t o_dst = (uint32_t)__shfl((int)dst, (int)owner, 64), o_excl = (uint32_t)__shfl((int)excl, (int)owner, 64);
+          if (x < T) {
+            const uint32_t boff = (x - o_excl) << 4;
+            const uint32_t rem = o_len - boff;                 // >= 1
+            const u8* src = base + o_pos + boff;
+            const uint32_t sh = (uint32_t)(uintptr_t)src & 3u;
+            const uint32_t* qd = (const uint32_t*)(src - sh);
+            const uint32_t need = sh + (rem < 16u ? rem : 16u);   // bytes from qd[0] on
+            uint32_t wv[5];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; j++) wv[j] = 4 * j < need ? qd[j] : 0u;
+            uint32_t prev = boff ? __builtin_amdgcn_alignbyte(qd[0], qd[-1], sh) : 0u;
+            uint32_t* out = (uint32_t*)(pg.heap + o_dst + boff);
+            bool bad = false;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+              if (4 * j < rem) {
+                const uint32_t rj = rem - 4 * j;
+                uint32_t xw = __builtin_amdgcn_alignbyte(wv[j + 1], wv[j], sh);
+                if (rj < 4) xw &= (1u << (8 * rj)) - 1u;
+                out[j] = xw;
+                if ((xw | prev) & 0x80808080u) bad |= utf8_dword_bad(prev, xw, rj == 4);
+                prev = xw;
+              }
+            }
+            if (bad) record_error(pg, f0 + owner, RK_DECODE, ETLG_E_UTF8);
+          }
+        }
+      }
+    }
+  } else {
+    // ================= P3 (spine): transaction context, numerics / bytea, heap references, toast, event headers
+    ETLG_WAVE_PRIO(3);
+    {
+      const TxnStart ts{s32[12], s32[13], s64[6], s64[3]};
+      bc = ts.seg; bm = ts.mark; carried_lsn = ts.lsn; start_ord = ts.ord;
+      const uint32_t seg = seg_combine(bc, seg_in);
+      const uint32_t last = bm > pm ? bm : pm;
+      tx.in_txn = (last & 1u) != 0;
+      tx.final_lsn = !tx.in_txn ? 0 : last == bm ? carried_lsn : ld_be64(base + (((last >> 1) - 1) - b0) + kBodyOff);
+      const uint64_t cc = seg & 0x7FFFFFFFu;
+      tx.ord = (seg & 0x80000000u) ? cc - 1 : start_ord + cc - 1;
+      if (live && wire_ok) txn_check_frame(pg, v, tx);
+    }
+    const uint64_t ev_idx = pre_ev + x_ev;
+    const uint64_t fx_off = pre_fx + ((uint64_t)x_fx << 2);
+    if (lane == 0 && tile == q.ntiles - 1) {
+      DevResult* r = pg.res;
+      r->n_events = pre_ev + (s64[0] >> 32); r->fixed_bytes = pre_fx + (s64[1] << 2); r->heap_bytes = ((uint64_t)(uint32_t)s64[4] << 2) + ((uint64_t)(uint32_t)s64[0] << 2);
+      r->n_frames = pg.nframes;
+      const uint32_t sg = seg_combine(bc, tot_cnt);
+      const uint32_t lm = bm > tot_mark ? bm : tot_mark;
+      const bool it = (lm & 1u) != 0;
+      r->out_in_txn = it;
+      r->out_final_lsn = it ? (lm == bm ? carried_lsn : final_lsn_of_mark(pg, lm)) : 0;
+      const uint64_t cc = sg & 0x7FFFFFFFu;
+      r->out_next_ord = (sg & 0x80000000u) ? cc : start_ord + cc;
+      carry_publish(r);
+    }
+    const bool fixed_fits = pre_fx + ((uint64_t)tot_f << 2) <= pg.fixed_cap;
+    if (!(heap_fits && fixed_fits)) { if (emit) record_error(pg, f, RK_DECODE, ETLG_E_WIRE); emit = 0; }
+    if (lane == 0) s32[1] = (heap_fits && fixed_fits) ? 1u : 0u;
+    // numerics / bytea at their final heap positions; every heap cell's slot gets its heap reference
+    for (uint32_t half = 0; half < 2 && heap_fits; half++) {
+      uint64_t m = half ? m_new : m_old;
+      while (m) {
+        const uint32_t hr = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t r = half * maxh + hr;
+        const uint32_t w = lane < nt ? tabw[r * cf + lane] : 0u;
+        const uint32_t kind = w >> 30;
+        if (kind != HK_NONE) {
+          const uint32_t pos = w & 0x1FFFFu;
+          uint32_t hcur = fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2);
+          uint32_t* const slotp = (uint32_t*)(img + tabs[r * cf + lane]);
+          slotp[0] = hcur;
+          if (kind != HK_COPY) {
+            const uint32_t len = __builtin_bswap32(ldu32(base + pos - 4));
+            uint32_t tmp[4] = {0, 0, 0, 0}, st = 0;
+            const uint32_t err = decode_text_cell<false>(kind == HK_NUMERIC ? (uint32_t)ETLG_TC_NUMERIC : (uint32_t)ETLG_TC_BYTEA, base + pos, len, tmp, pg.heap, hcur, st, true);
+            if (err) record_error(pg, f, RK_DECODE, err);
+            else slotp[1] = tmp[1];
+          }
+        }
+      }
+    }
+    // 'u' cells of the new row: alias the aligned old value, else MISSING (codec/event.rs:962-974)
+    uint32_t flags = (isrow && v.tag != 'I') ? old_kind : 0u;
+    if (emit && isrow && toast) {
+      const DevSlot& s = p.slots[slot];
+      const DevCol* cols = p.cols + s.cols_base;
+      u8* const body = img + (x_fx << 2);
+      while (toast) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(toast);
+        toast &= toast - 1;
+        const DevCol col = cols[k];
+        uint32_t* dst = (uint32_t*)(body + old_sz + col.off_full);
+        const bool from_full = old_kind == ETLG_OLD_FULL, from_key = old_kind == ETLG_OLD_KEY && col.identity;
+        uint32_t cst;
+        if (from_full || from_key) {
+          const uint32_t* src = (const uint32_t*)(body + (from_full ? col.off_full : col.off_key));
+          const uint32_t nw = slot_bytes(col.cls) >> 2;
+          for (uint32_t w = 0; w < nw; w++) dst[w] = src[w];
+          const uint32_t oi = from_full ? k : (uint32_t)col.key_index;
+          cst = (((const uint32_t*)body)[oi >> 4] >> (2 * (oi & 15u))) & 3u;
+        } else {
+          cst = (uint32_t)ETLG_CELL_MISSING;
+          flags |= ETLG_FLAG_PARTIAL;
+        }
+        if (cst) ((uint32_t*)(body + old_sz))[k >> 4] |= cst << (2 * (k & 15u));
+      }
+    }
+    // event headers
+    if (emit) {
+      const uint32_t tag = v.tag;
+      if (isrow || tag == 'B' || tag == 'C') {
+        const u8* b = v.fr + kBodyOff;
+        uint32_t table = rel_id, slot_id = 0;
+        uint64_t commit_lsn = tx.final_lsn;
+        if (isrow) slot_id = p.slots[slot].host_id;
+        else if (tag == 'B') { commit_lsn = ld_be64(b); table = ld_be32(b + 16); }
+        else { flags = b[0]; commit_lsn = ld_be64(b + 1); table = 0; }
+        pg.ev_kind[ev_idx] = (u8)tag;
+        pg.ev_flags[ev_idx] = (u8)flags;
+        pg.ev_table[ev_idx] = table;
+        pg.ev_slot[ev_idx] = slot_id;
+        pg.ev_start[ev_idx] = ld_be64(v.fr + 6);
+        pg.ev_commit[ev_idx] = commit_lsn;
+        pg.ev_ord[ev_idx] = tx.ord;
+        pg.ev_body[ev_idx] = fx_off;
+      } else {
+        // Truncate / Relation events (rare): the generic writer, into the image
+        DecParams pl = p;
+        pl.fixed = img;
+        RowMsg dummy{};
+        write_frame(pl, v, tx, dummy, -1, ev_idx, (uint64_t)x_fx << 2, 0, nullptr, true);
+        pg.ev_body[ev_idx] = fx_off;
+      }
+    }
+    ETLG_WAVE_PRIO(0);
+  }
+  __threadfence_block();
+  __syncthreads();
+  TSTAMP(5);
+  // ================= all waves: the image -> the fixed arena, one contiguous block
+  if (s32[1]) {
+    const uint32_t ndw = (uint32_t)s64[1];
+    uint32_t* out = (uint32_t*)(pg.fixed + pre_fx);
+    const uint32_t* in32 = (const uint32_t*)img;
+    for (uint32_t i = tid; i < ndw; i += NW * 64) out[i] = in32[i];
+  }
+  TSTAMP(6);
+}
+
+}  // namespace etlg
+
+extern "C" {
+
+using namespace etlg;
+
+void etlg_k_launch_rows(const DecParams* p, const void* qv, hipStream_t s) {
+  const FusedParams* q = (const FusedParams*)qv;
+  hipLaunchKernelGGL((k_rows<RNW>), dim3(q->ntiles), dim3(RNW * 64), q->lds_bytes, s, *p, *q);
+}
+
+int etlg_k_rows_set_lds(void) {
+  return hipFuncSetAttribute((const void*)k_rows<RNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) == hipSuccess ? 0 : 1;
+}
+
+uint32_t etlg_k_rows_table_bytes(uint32_t maxh, uint32_t cf) { return (2u * maxh * cf * 6u + 15u) & ~15u; }
+uint32_t etlg_k_rows_static_lds(void) { return 1024u; }   // the kernel's __shared__ arrays (s_offs, fr_hp, s32, s64) + slack
+uint32_t etlg_k_rows_max_cols(void) { return 64u; }       // toast mask: one bit per column of the new image
+uint32_t etlg_k_rows_max_heap_cols(void) { return 64u; }  // rows per image of the heap-cell table (one 64-bit presence mask per image)
+
+}  // extern "C"

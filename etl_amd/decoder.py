@@ -370,6 +370,13 @@ class Decoder:
         self.L.etlg_ctx_debug_paths8(self.h, out)
         return dict(zip(("fused", "cells", "multipass", "redone", "plan", "plan_redone", "control", "chain_rerun"), [int(x) for x in out]))
 
+    def debug_rows(self):
+        """Batches by the row-synchronous kernel (debugging aid, not in etlg.h): 'rows' = produced by k_rows, 'rows_redone' = handed back by it
+        (a tile that did not fit its LDS window / image) and decoded again by k_cells / k_fused."""
+        out = (C.c_ulonglong * 2)()
+        self.L.etlg_ctx_debug_rows(self.h, out)
+        return {"rows": int(out[0]), "rows_redone": int(out[1])}
+
     def debug_copy(self):
         """Table-copy batches by path (debugging aid, not in etlg.h): 'direct' = produced by the rows -> arena kernel (k_copy_cells),
         'frames' = decoded through the row -> frame rewrite (a malformed row, rows wider than a tile's window, ETLG_COPY_DIRECT=0)."""

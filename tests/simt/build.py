@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "etl_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libetlg_simt.so")
-KERNEL_SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "plan.hip", "scan.hip", "copy.hip", "columns.hip", "host.cpp"]
+KERNEL_SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "rows.hip", "plan.hip", "scan.hip", "copy.hip", "columns.hip", "host.cpp"]
 DEPS = KERNEL_SOURCES + ["dev_types.h", "host_state.h", "host_control.inc", "host_handoff.inc", "host_orchestrate.inc", "codec.hip.h", "lookback.hip.h", "fixed_tile.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h"]
 CXX = os.environ.get("CXX", "g++")
 sys.path.insert(0, ROOT)

@@ -18,6 +18,8 @@ PATHS = {
     "fused256": {"ETLG_FUSED_KERNEL": "0"},   # k_fused, 256 frames per tile
     "fused64": {"ETLG_FUSED_KERNEL": "1"},    # k_fused, 64 frames per tile
     "cells": {"ETLG_FUSED_KERNEL": "2"},      # k_cells (column-parallel)
+    "rows": {"ETLG_FUSED_KERNEL": "4"},       # k_rows (row-synchronous walk, rows.hip) wherever a batch is eligible
+    "norows": {"ETLG_ROWS": "0"},             # the default choice without k_rows (k_cells / k_fused as before round 6)
     "plan": {"ETLG_FUSED_KERNEL": "3"},       # the fixed-width plan whenever the batch is eligible, no back-off (tile prefixes from the sidecar pre-pass where the tables allow it)
     "plan_lookback": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0"},   # ... with the kernel's own look-back (k_plan2: two tiles per wave)
     "plan_one": {"ETLG_FUSED_KERNEL": "3", "ETLG_PLAN_PRE": "0", "ETLG_PLAN_DBG": "512"},     # ... one tile per wave (k_plan, the kernel wide rows take)
@@ -25,7 +27,7 @@ PATHS = {
     "noplan": {"ETLG_PLAN": "0"},             # the default choice without the plan
     "multipass": {"ETLG_FORCE_MULTIPASS": "1"},
 }
-_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE")
+_KNOBS = ("ETLG_FUSED_KERNEL", "ETLG_FORCE_MULTIPASS", "ETLG_FUSED_DBG", "ETLG_PLAN", "ETLG_PLAN_DBG", "ETLG_PLAN_PRE", "ETLG_ROWS")
 
 
 @pytest.fixture(params=sorted(PATHS))
@@ -87,9 +89,10 @@ def test_large_batch_parity(mk, nbytes, path):
         diff = rb.host_batch().diff(gb.host())
         assert not diff, diff[:6]
     n = d.debug_paths()
+    n.update(d.debug_rows())
     d.close()
-    assert n["redone"] == 0, n
-    want = {"fused256": "fused", "fused64": "fused", "cells": "cells", "multipass": "multipass"}.get(path)
+    assert n["redone"] == 0 and n["rows_redone"] == 0, n
+    want = {"fused256": "fused", "fused64": "fused", "cells": "cells", "multipass": "multipass", "rows": "rows"}.get(path)
     if path in ("plan", "plan_lookback", "plan_one", "plan_inplace", "default") and mk is synth.cfg2:
         want = "plan"   # cfg2 is what the fixed-width plan is for
     if want:
