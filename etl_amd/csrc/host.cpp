@@ -443,9 +443,9 @@ int32_t etlg_host_alloc(etlg_ctx* c, size_t bytes, void** out) {
 }
 void etlg_host_free(void* p) { if (p) (void)hipHostFree(p); }   // batches whose control pre-pass ran ahead of their decode
 // debugging aid (not part of etlg.h): [0] batches k_rows produced, [1] batches it handed back to k_cells / k_fused
-int32_t etlg_ctx_debug_rows(etlg_ctx* c, unsigned long long* out2) {
+int32_t etlg_ctx_debug_rows(etlg_ctx* c, unsigned long long* out2) {   // (three words)
   if (!c || !out2) return ETLG_InvalidArgument;
-  out2[0] = c->rows_n; out2[1] = c->rows_redone;
+  out2[0] = c->rows_n; out2[1] = c->rows_redone; out2[2] = c->rows_resized;
   return ETLG_OK;
 }
 int32_t etlg_ctx_debug_paths8(etlg_ctx* c, unsigned long long* out8) {

@@ -1,30 +1,33 @@
 // Row-synchronous single-pass decode kernel for gfx950 — the variable-length path since round 6.
 //
-// k_cells (cells.hip) slices a tile's tuples into a cell table and then visits the table column by column with four
-// waves: ~25 k instructions per 64-frame tile, a third of them the per-visit skeleton (frame state, slot / column records,
-// arena addresses per LANE), and a sizing pass that parses numerics a second time. Here the same tile is ONE walk:
+// k_cells (cells.hip) slices a tile's tuples into a cell table and then visits the table column by column: ~25 k
+// instructions per 64-frame tile, a third of them the per-visit skeleton (frame state, slot / column records, arena
+// addresses looked up per LANE), a sizing pass that parses numerics a second time, a per-frame prefix over all virtual
+// columns, and text moved four bytes per lane. Here a tile is:
 //
 //   P0  all waves: stage the tile's bytes + side tables into LDS, zero the tile's image of the fixed arena
-//   P1  spine wave, lane = frame: envelope, tag, transaction scan, ownership + schema slot, FIXED-arena size per frame
-//       (it depends on the message heads only) -> wave scan -> every frame knows where its rows sit in the LDS image;
-//       the fixed-arena and transaction aggregates are published at once and resolved by two other waves while the
-//       spine walks
-//   P2  spine wave: the frames of one (schema slot, image kind, cell count) walk their tuples IN STEP — in trip k every
-//       active lane stands in front of cell k of the same column, so the column record is wave-uniform (scalar loads, a
-//       scalar class switch: the per-schema program the host would otherwise have to compile) and the value codec runs on
-//       up to 64 cells of one class. Fixed-width values go straight into the LDS image; cells that reach the heap
-//       (text, numeric, bytea, deferred classes) are sized on the spot — the running sum IS the cell's heap offset inside
-//       its frame — and noted in a small table [heap rank][frame]
-//   P3  spine: wave scan of (events, heap dwords), look-back; then numerics / bytea are emitted at their final heap
-//       positions, heap references patched into the image, toast cells aliased, event headers stored
-//   P4  the other waves, as soon as the heap prefix is known: the text of String / deferred cells is copied by 16-byte
-//       chunks dealt out densely over the lanes (a chunk's owner cell by binary search over the row's chunk prefix sums),
-//       validated as UTF-8 on the way; finally all waves copy the image to the fixed arena — one contiguous block
+//   P1  spine wave, lane = frame: envelope, tag, transaction scan, ownership + schema slot, FIXED-arena bytes per frame
+//       (they depend on the message heads only) -> wave scan -> every frame knows where its rows sit in the LDS image;
+//       the fixed-arena and transaction aggregates are published at once and resolved by two other waves during W
+//   W   spine wave: a lean structural walk (tag, length, bounds; ~35 instructions per step) that leaves the position of
+//       every cell in a 16-bit table [virtual column][frame]; then the frames are sorted into GROUPS of one (schema slot,
+//       image kind, cell count): inside a group, cell k of every frame belongs to the same column
+//   D   all waves pull (group, column) tasks: the column record is wave-uniform (scalar loads, a scalar class switch — the
+//       per-schema program the host would otherwise have to compile), lanes = the group's frames. Fixed-width values go
+//       straight into the LDS image; cells that reach the heap (text, numeric, bytea, deferred classes) are sized and
+//       noted in a small table [heap rank][frame]
+//   S   spine: per-frame prefix over its heap cells (heap rows only), wave scan of (events, heap dwords), look-back
+//   H   spine: numerics / bytea emitted at their final heap positions, heap references patched into the image, toast
+//       cells aliased, event headers stored —
+//   C   — while the other waves copy the text of String / deferred cells by 16-byte chunks dealt out densely over the
+//       lanes (a chunk's owner cell by binary search over the row's chunk prefix sums), validated as UTF-8 on the way;
+//       finally all waves copy the image to the fixed arena: one contiguous block
 //
 // What the kernel does not cover it hands back (DevResult.fused_fail bit 4, "rows gave up": the host decodes the batch
 // again with k_cells / k_fused): a tile whose bytes do not fit its LDS window, a tile whose rows outgrow the image, a
-// frame with more than 32 KiB of heap entries. Errors are recorded at their frame like everywhere else and send the batch
-// to the multi-pass kernels for the exact cut (the code recorded here only has to be SOME error of that frame).
+// frame with more than 32 KiB of heap entries or longer than 64 KiB, more than 16 groups in one tile. Errors are recorded
+// at their frame like everywhere else and send the batch to the multi-pass kernels for the exact cut (the code recorded
+// here only has to be SOME error of that frame).
 #define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
 #define ETLG_DBG_WORD dbg_u
 #define ETLG_TSTAMP_WHO (spine && lane == 0)
@@ -35,7 +38,8 @@ namespace etlg {
 
 constexpr int RNW = 4;          // waves per tile
 constexpr uint32_t kRowsGaveUp = 16u;
-// heap-cell table entry: window position of the text (17 bits) | heap offset inside the frame, dwords (13 bits) | kind (2 bits)
+constexpr uint32_t kRowsMaxGroups = 16;
+// heap-cell table entry: window position of the text (17 bits) | heap dwords of the cell, later its heap offset inside the frame (13 bits) | kind (2 bits)
 enum : uint32_t { HK_NONE = 0, HK_COPY = 1, HK_NUMERIC = 2, HK_BYTEA = 3 };
 constexpr uint32_t kRowsHeapMaxDw = 0x1FFFu;
 
@@ -52,7 +56,13 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams pg, FusedParams q) {
   ETLG_DYNAMIC_LDS(smem);
   __shared__ uint32_t s_offs[64 + 1];
-  __shared__ uint32_t fr_hp[64];     // heap offset of the frame's first entry (absolute, bytes)
+  __shared__ uint32_t fr_hp[64];      // heap offset of the frame's first entry (absolute, bytes)
+  __shared__ uint32_t fr_base[64];    // window offset of the frame's first byte
+  __shared__ uint32_t fr_row[64];     // the frame's body inside the image (bits 0..15) | bytes of its old / key row (16..31)
+  __shared__ uint32_t fr_flags[64];   // bit 0: a cell failed to decode; bit 1: the frame is an Update; bit 2: beyond what the kernel covers
+  __shared__ uint32_t fr_toast[2][64];   // new-image columns sent as 'u'
+  __shared__ uint32_t g_slot[kRowsMaxGroups], g_info[kRowsMaxGroups], g_cb[kRowsMaxGroups], g_task0[kRowsMaxGroups];
+  __shared__ uint64_t g_mem[kRowsMaxGroups];
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[12];
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -62,22 +72,24 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   }
   if (!(pg.flags & 16u) && !load_carry(pg)) return;  // ASYNC chain: the state the batch before this one left (flags bit 4: read late, by the tiles that need it)
   DecParams p = pg;
-  uint32_t dbg_u, cf;
-  ETLG_SCALAR_COPY(dbg_u, q.dbg); ETLG_SCALAR_COPY(cf, q.blk);
+  uint32_t dbg_u, cf, maxc;
+  ETLG_SCALAR_COPY(dbg_u, q.dbg); ETLG_SCALAR_COPY(cf, q.blk); ETLG_SCALAR_COPY(maxc, q.maxc);
   const uint32_t tile = blockIdx.x;
-  const bool spine = (((tid >> 6) + tile) & (uint32_t)(NW - 1)) == 0;   // the role rotates with the tile (see cells.hip: wave w of a workgroup sits on SIMD w)
-  const uint32_t role = ((tid >> 6) + tile) & (uint32_t)(NW - 1);
+  const uint32_t role = ((tid >> 6) + tile) & (uint32_t)(NW - 1);   // the roles rotate with the tile (see cells.hip: wave w of a workgroup sits on SIMD w)
+  const bool spine = role == 0;
   if ((dbg_u & 8) && spine && lane == 0) s64[7] = clock64();
   uint32_t* fail = &pg.res->fused_fail;
   // ---- P0: side tables, offsets, staging
   SideRegs side;
   side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
   const uint32_t maxh = q.rows_maxh, R = 2 * maxh;
-  // dynamic LDS: side tables | heap-cell table (u32 [R][cf]) | slot offsets (u16 [R][cf]) | image of the fixed arena | staging window
-  uint32_t* const tabw = (uint32_t*)(smem + q.side_bytes);
-  uint16_t* const tabs = (uint16_t*)(tabw + R * cf);
-  const uint32_t tab_bytes = (R * cf * 6u + 15u) & ~15u;
-  u8* const img = (u8*)tabw + tab_bytes;
+  // dynamic LDS: side tables | heap-cell table (u32 [R][cf]) | its slot offsets (u16 [R][cf]) | cell positions (u16 [2 maxc][cf]) | image of the fixed arena | staging window
+  uint32_t* const htab = (uint32_t*)(smem + q.side_bytes);
+  uint16_t* const hslot = (uint16_t*)(htab + R * cf);
+  const uint32_t htab_bytes = (R * cf * 6u + 15u) & ~15u;
+  uint16_t* const ctab = (uint16_t*)((u8*)htab + htab_bytes);
+  const uint32_t ctab_bytes = (2u * maxc * cf * 2u + 15u) & ~15u;
+  u8* const img = (u8*)ctab + ctab_bytes;
   u8* const stage = img + q.rows_img;
   const uint32_t f0 = tile * cf;
   const uint32_t nt = pg.nframes - f0 < cf ? pg.nframes - f0 : cf;
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
   const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
-  const uint32_t used = q.side_bytes + tab_bytes + q.rows_img;
+  const uint32_t used = q.side_bytes + htab_bytes + ctab_bytes + q.rows_img;
   const uint32_t wcap = q.lds_bytes > used ? q.lds_bytes - used : 0u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len && span1 - a0 + 16 <= (1u << 17) && (uint64_t)(span1 - a0) + 16 <= wcap;
   if (window_ok) {
@@ -95,11 +107,16 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   }
   side_store<NW * 64>((uint32_t*)smem, tid, side);
   if (tid <= nt) s_offs[tid] = my_o;
-  {  // the table starts empty, the image as zeros (NULL slots, padding and VALUE states are never written)
-    uint4* z = (uint4*)tabw;
-    const uint32_t n16 = (tab_bytes + q.rows_img) >> 4;
+  {  // the heap-cell table starts empty, the image as zeros (NULL slots, padding and VALUE states are never written)
+    uint4* z = (uint4*)htab;
+    const uint32_t n16 = htab_bytes >> 4;
     for (uint32_t i = tid; i < n16; i += NW * 64) z[i] = make_uint4(0, 0, 0, 0);
+    uint4* zi = (uint4*)img;
+    const uint32_t i16 = q.rows_img >> 4;
+    for (uint32_t i = tid; i < i16; i += NW * 64) zi[i] = make_uint4(0, 0, 0, 0);
   }
+  if (tid < 64) { fr_toast[0][tid] = 0; fr_toast[1][tid] = 0; fr_flags[tid] = 0; }
+  if (tid == 0) { s64[8] = 0; s64[9] = 0; s32[2] = 0; s32[3] = 0; s32[4] = 0; }
   __syncthreads();
   TSTAMP(0);
   bool lane_ok = true;
@@ -108,8 +125,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     lane_ok = o1 <= o0 || o1 > pg.in_len || (o0 >= span0 && o1 <= span1);
   }
   const bool tile_ok = __syncthreads_and(lane_ok ? 1 : 0) && window_ok;
-  if (!tile_ok && tid == 0) atomicOr(fail, kRowsGaveUp);   // (the tile still takes part in the look-backs, with nothing to report)
-  TSTAMP(1);
+  if (!tile_ok && tid == 0) {   // (the tile still takes part in the look-backs, with nothing to report)
+    atomicOr(fail, kRowsGaveUp | 0x100u);
+    atomicMax(&pg.res->dbg_t[11], (unsigned long long)(span1 - a0) + 32ull);   // what its window would have had to hold: the host sizes the next attempt by it
+  }
   const u8* const base = stage;
   const uint32_t b0 = a0;
 
@@ -118,15 +137,15 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   const uint32_t f = f0 + lane;
   FrameView v{f, 0, base, base};
   uint32_t rel_id = 0, old_kind = ETLG_OLD_NONE, n_old = 0, n_new = 0, vbytes = 0, o0 = 0;
-  uint32_t c = 0, e = 0;          // walk cursor / frame end, as window offsets
-  uint32_t ph = 0;                // 0 nothing to walk, 1 in front of the old / key image's cells, 2 in front of the new image's cells
-  bool wire_ok = true, isrow = false, derr = false, gave = false;
+  uint32_t c = 0, e = 0, fb = 0;  // walk cursor / frame end / frame start, as window offsets
+  uint32_t ok = 0;                // 1: a row frame that is still well formed
+  uint32_t derr = 0, gave = 0;
+  bool wire_ok = true, isrow = false;
   uint32_t cnt = 0, mark = 0, seg_in = 0, pm = 0, tot_cnt = 0, tot_mark = 0;
   int slot = -1;
+  uint32_t s_ncols = 0, s_nident = 0, s_cb = 0;
   uint32_t emit = 0, fixed = 0, heap = 0, old_sz = 0, x_fx = 0;
   uint64_t pay[3] = {0, 0, 0};
-  uint64_t toast = 0;             // new-image columns sent as 'u' (resolved after the heap references are final)
-  uint64_t rows_old = 0, rows_new = 0;   // wave-uniform: rows of the heap-cell table that hold an entry
   TxnCtx tx{true, 0, 0};
   uint32_t bc = 0, bm = 0;
   uint64_t carried_lsn = 0, start_ord = 0;
@@ -147,7 +166,9 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         RowMsg dummy;
         wire_ok = frame_structure(v, dummy, true);
       } else {
-        c = (uint32_t)(v.fr - base) + kBodyOff; e = (uint32_t)(v.e - base);
+        fb = (uint32_t)(v.fr - base);
+        c = fb + kBodyOff; e = (uint32_t)(v.e - base);
+        if (e - fb > 0xFFFFu) gave = 0x400;   // cell positions are 16-bit offsets from the frame's first byte
         wire_ok = e >= c + 5;
         if (wire_ok) {
           rel_id = ld_be32(base + c); c += 4;
@@ -159,9 +180,9 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
           const bool hdr_ok = (e - c >= 3) & !(cnt16 & 0x8000u) & (tag == 'I' ? t == 'N' : tag == 'D' ? is_old : (is_old | (t == 'N')));
           wire_ok = hdr_ok;
           if (hdr_ok) {
-            c += 3;
-            if (is_old) { old_kind = t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL; n_old = cnt16; ph = 1; }
-            else { n_new = cnt16; ph = 2; }
+            c += 3; ok = gave ? 0u : 1u;
+            if (is_old) { old_kind = t == 'K' ? (uint32_t)ETLG_OLD_KEY : (uint32_t)ETLG_OLD_FULL; n_old = cnt16; }
+            else n_new = cnt16;
           }
         }
       }
@@ -181,11 +202,12 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
       const int ti = find_table(p, rel_id);
       if (should_apply(p, ti, rel_id, 0)) {   // (no table is in SyncDone state on this path: the host sends those batches to k_cells)
         slot = cache_slot_before(p, ti, f);
-        if (slot < 0) { record_error(pg, f, RK_SCHEMA, (uint32_t)(-slot)); slot = -1; derr = true; }
-        else if (p.slots[slot].n_cols > q.maxc) { gave = true; slot = -1; }
+        if (slot < 0) { record_error(pg, f, RK_SCHEMA, (uint32_t)(-slot)); slot = -1; derr = 1; }
+        else if (p.slots[slot].n_cols > maxc) { gave = 0x800; slot = -1; }
       }
       if (slot >= 0) {
         const DevSlot& s = p.slots[slot];
+        s_ncols = s.n_cols; s_nident = s.n_ident; s_cb = s.cols_base;
         emit = 1;
         if (old_kind != ETLG_OLD_NONE) { old_sz = old_kind == ETLG_OLD_KEY ? s.row_key : s.row_full; fixed = old_sz; }
         if (v.tag != 'D') fixed += s.row_full;
@@ -195,190 +217,228 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
       int rs = -1;
       size_frame(p, v, tx, wire_ok, dummy, emit, fixed, heap, pay, rs, false, true);   // (records the wire error of a malformed frame)
     }
-    if (isrow && !wire_ok) { record_error(pg, f, RK_WIRE, ETLG_E_WIRE); ph = 0; }
     const uint32_t ifx = wave_scan_add(fixed >> 2);
     tot_f = wave_last(ifx);
     x_fx = ifx - (fixed >> 2);
     if ((uint64_t)tot_f * 4u > q.rows_img) {   // the tile's rows do not fit the image: nothing of this tile is written
-      gave = true; tot_f = 0; emit = 0; fixed = 0; ph = 0; x_fx = 0;
+      if (lane == 0) atomicMax(&pg.res->dbg_t[10], (unsigned long long)tot_f * 4ull);
+      gave = 0x200; tot_f = 0; emit = 0; fixed = 0; ok = 0; x_fx = 0; slot = -1;
     }
+    if (lane < cf) { fr_base[lane] = fb; fr_row[lane] = (x_fx << 2) | (old_sz << 16); if (isrow && v.tag == 'U') fr_flags[lane] = 2u; }
     if (lane == 0) { s64[1] = tot_f; s64[2] = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark; }
     ETLG_WAVE_PRIO(0);
   }
   __syncthreads();
-  TSTAMP(2);
+  TSTAMP(1);
   // the two look-backs whose aggregates are known from the heads alone run beside the walk
   if (role == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
   if (role == 2 % NW && NW > 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
 
-  uint32_t x_ev = 0, x_hp = 0;
   if (spine) {
     if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
     if (NW <= 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
-    // ================= P2 (spine): the walk. Begin / Commit bodies first (field copies)
-    const uint32_t rowb = x_fx << 2;   // the frame's body inside the image
+    // ================= W (spine): Begin / Commit bodies (field copies), then the structural walk
+    ETLG_WAVE_PRIO(3);
+    const uint32_t rowb = x_fx << 2;
     if (emit && v.tag == 'B') st64((uint32_t*)(img + rowb), ld_be64(v.fr + kBodyOff + 8));
     if (emit && v.tag == 'C') { st64((uint32_t*)(img + rowb), ld_be64(v.fr + kBodyOff + 9)); st64((uint32_t*)(img + rowb) + 2, ld_be64(v.fr + kBodyOff + 17)); }
-    uint32_t hp = 0;   // heap bytes of the frame so far = heap offset of its next entry
-    // One image of one group of frames: `in` = the lanes of the group, all in front of cell 0 of an image with n_u cells that decodes
-    // against slot slot_u (~0: nobody decodes it, the walk is structural); kmode 0 full row / update row, 1 dense key tuple,
-    // 2 full-width key tuple; img1: the new image.
-    auto walk_image = [&](bool in, uint32_t slot_u, uint32_t kmode, uint32_t n_u, bool img1) {
-      const ETLG_CONST_AS uint32_t* cw = nullptr;
-      if (slot_u != ~0u) {
-        const ETLG_CONST_AS uint32_t* sw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.slots + slot_u);
-        static_assert(sizeof(DevSlot) == 44 && sizeof(DevCol) == 12, "descriptor words below");
-        cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + sw[6]);   // DevSlot.cols_base
-      }
-      u8* const rowp = img + rowb + (img1 ? old_sz : 0u);
-      const bool upd = img1 && v.tag == 'U';
-      bool on = in;
-      unsigned long long tprev = 0;
-      const bool tclk = (dbg_u & 32u) && img1 && (blockIdx.x & 15) == 3;
-      if (tclk) tprev = clock64();
-      for (uint32_t k = 0; k < n_u; k++) {
-        if (tclk && k) { const unsigned long long tn = clock64(); if (lane == 0) atomicAdd(&pg.res->dbg_t[(k - 1) % 12], tn - tprev); tprev = tn; }
-        // the column record (wave-uniform): -1 = the cell is walked, not decoded
-        int ci = -1;
-        uint32_t w0 = 0, w1 = 0, w2 = 0;
-        if (cw) {
-          ci = (int)k;
-          if (kmode == 1) ci = (int)(cw[3 * k] >> 24);                    // DevCol.key_col of record k
-          w0 = cw[3 * ci]; w1 = cw[3 * ci + 1]; w2 = cw[3 * ci + 2];
-          if (kmode == 2 && !((w0 >> 16) & 0xFFu)) ci = -1;              // full-width key tuple: only the identity columns are read
-        }
-        const uint32_t cls = w0 & 0xFFu, nullable = (w0 >> 8) & 0xFFu;
-        const uint32_t off = kmode ? (w1 >> 16) : (w1 & 0xFFFFu);
-        const uint32_t kout = kmode ? (w2 & 0xFFFFu) : (uint32_t)ci;
-        const uint32_t hr = kmode ? (w2 >> 24) : ((w2 >> 16) & 0xFFu);
-        // the cell head: 'n' | 'u' | ('t' | 'b') i32 len bytes
+    // `lim` cells of image `vimg` (0 old / key, 1 new) for every lane that is still going: 'n' | 'u' | ('t' | 'b') i32 len bytes.
+    // One step per cell index, no data-dependent branches; a lane that meets a malformed cell stops (ok = 0).
+    auto walk_cells = [&](uint32_t lim, uint32_t vimg) {
+      for (uint32_t k = 0;; k++) {
+        const bool act = (k < lim) & (ok != 0);
+        if (!__ballot(act)) break;
         const uint64_t head = ldu64(base + c);  // the window has 16 spare bytes past any frame
         const uint32_t t = (uint32_t)head & 0xFFu;
         const uint32_t room = e - c;
         const bool is_val = (t == 't') | (t == 'b');
         const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
         const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
-        if (on & !cell_ok) wire_ok = false;
-        on = on & cell_ok;
-        const uint32_t pos = c + 5;
-        if (on) { vbytes += len; c += is_val ? 5u + len : 1u; }
-        if (ci < 0) continue;
-        uint32_t* const slotp = (uint32_t*)(rowp + off);
-        uint32_t st = ETLG_CELL_VALUE;
-        if (on && t == 't') {
-          const u8* d = base + pos;
-          if (rows_heap_class(cls)) {
-            uint32_t hb, kind = HK_COPY, nbytes = len;
-            if (cls == ETLG_TC_NUMERIC) {
-              NumShape ns;
-              const bool okn = numeric_plain(d, len, ns) || numeric_scan(d, len, ns, true);
-              if (!okn) derr = true;
-              nbytes = 8 + 2 * ns.ngroups; kind = HK_NUMERIC;
-              if (!okn) nbytes = 0;
-            } else if (cls == ETLG_TC_BYTEA) {
-              if (len < 2) derr = true;
-              nbytes = len >= 2 ? (len - 2) >> 1 : 0u; kind = HK_BYTEA;
-            } else if (cls == ETLG_TC_F32 || cls == ETLG_TC_F64) {
-              uint64_t bits = 0;
-              const int r = parse_float_fast(d, len, cls == ETLG_TC_F32, bits, true);
-              if (r == 2) derr = true;
-              if (r == 0) { st64(slotp, bits); kind = HK_NONE; nbytes = 0; }
-              else st = ETLG_CELL_DEFERRED;
-            } else if (cls != ETLG_TC_STRING) st = ETLG_CELL_DEFERRED;   // json / arrays / classes without a codec: the source text
-            hb = pad4(nbytes);
-            if (kind != HK_NONE) {
-              if ((hp >> 2) > kRowsHeapMaxDw || pos >= (1u << 17)) gave = true;
-              else {
-                const uint32_t r = (img1 ? maxh : 0u) + hr;
-                tabw[r * cf + lane] = pos | ((hp >> 2) << 17) | (kind << 30);
-                tabs[r * cf + lane] = (uint16_t)((u8*)slotp - img);
-                slotp[1] = nbytes;
-                hp += hb;
-              }
-            }
-          } else {
-            uint32_t tmp[4] = {0, 0, 0, 0};
-            uint32_t hdummy = 0;
-            const uint32_t err = decode_text_cell<false>(cls, d, len, tmp, nullptr, hdummy, st, true);
-            if (err) derr = true;
+        const bool go = act & cell_ok;
+        if (go & (k < maxc)) ctab[(vimg * maxc + k) * cf + lane] = (uint16_t)(c - fb);
+        ok = (act & !cell_ok) ? 0u : ok;
+        vbytes += go ? len : 0u;
+        c += go ? (is_val ? 5u + len : 1u) : 0u;
+      }
+    };
+    walk_cells(old_kind != ETLG_OLD_NONE ? n_old : 0u, 0u);
+    {  // an Update goes on to its new image's header
+      const bool need = (ok != 0) & (v.tag == 'U') & (old_kind != ETLG_OLD_NONE);
+      const uint64_t head = ldu64(base + c);
+      const uint32_t t = (uint32_t)head & 0xFFu;
+      const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
+      const bool hdr_ok = (e - c >= 3) & (t == 'N') & !(cnt16 & 0x8000u);
+      if (need) { if (hdr_ok) { c += 3; n_new = cnt16; } else ok = 0; }
+    }
+    walk_cells(v.tag != 'D' ? n_new : 0u, 1u);
+    if (isrow) wire_ok = ok != 0;
+    if (live && isrow && !wire_ok) record_error(pg, f, RK_WIRE, ETLG_E_WIRE);
+    TSTAMP(2);
+    // ---- groups: frames of one (slot, image shape, cell count); convert_tuple_to_row / normalize_key_tuple_to_row's shape checks
+    //      (codec/event.rs:559-565, 889-922) per frame: 0 full / update row, 1 dense key tuple, 2 full-width key tuple, 3 = a shape error
+    const uint32_t mo = old_kind == ETLG_OLD_KEY ? (s_nident == 0 ? 3u : n_old == s_nident ? 1u : n_old == s_ncols ? 2u : 3u) : (n_old == s_ncols ? 0u : 3u);
+    const uint32_t mn = n_new == s_ncols ? 0u : 3u;
+    uint32_t ng = 0, ntasks = 0;
+    for (uint32_t img1 = 0; img1 < 2; img1++) {
+      const uint32_t myn = img1 ? n_new : n_old, mym = img1 ? mn : mo;
+      uint32_t pend = (ok != 0 && slot >= 0 && !derr && (img1 ? v.tag != 'D' : old_kind != ETLG_OLD_NONE)) ? 1u : 0u;
+      for (;;) {
+        const unsigned long long m = __ballot(pend != 0);
+        if (!m) break;
+        const int leader = __builtin_ctzll(m);
+        const uint32_t slot_u = (uint32_t)__builtin_amdgcn_readlane(slot, leader);
+        const uint32_t n_u = (uint32_t)__builtin_amdgcn_readlane((int)myn, leader);
+        const uint32_t mode_u = (uint32_t)__builtin_amdgcn_readlane((int)mym, leader);
+        const uint32_t cb_u = (uint32_t)__builtin_amdgcn_readlane((int)s_cb, leader);
+        const bool in = pend && (uint32_t)slot == slot_u && myn == n_u && mym == mode_u;
+        const unsigned long long mem = __ballot(in);
+        if (mode_u == 3) { if (in) derr = 1; }   // (the frame fails whatever its cells hold)
+        else if (n_u != 0) {
+          if (ng < kRowsMaxGroups) {
+            if (lane == 0) { g_slot[ng] = slot_u; g_info[ng] = mode_u | (img1 << 8) | (n_u << 16); g_cb[ng] = cb_u; g_task0[ng] = ntasks; g_mem[ng] = mem; }
+            ng++; ntasks += n_u;
+          } else if (in) gave = 0x1000;
+        }
+        if (in) pend = 0;
+      }
+    }
+    if (lane == 0) { s32[2] = ntasks; s32[3] = ng; }
+    ETLG_WAVE_PRIO(0);
+  }
+  __syncthreads();
+  TSTAMP(3);
+
+  // ================= D (all waves): (group, column) tasks
+  {
+    const uint32_t ntasks = s32[2], ng = s32[3];
+    const uint32_t my_t0 = lane < ng ? g_task0[lane] : 0xFFFFFFFFu;
+    for (;;) {
+      uint32_t tk = 0;
+      if (lane == 0) tk = atomicAdd(&s32[4], 1u);
+      tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+      if (tk >= ntasks) break;
+      const uint32_t g = (uint32_t)__builtin_popcountll(__ballot(my_t0 <= tk)) - 1u;
+      const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_info[g]);
+      const uint32_t cb_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_cb[g]);
+      const uint32_t k = tk - (uint32_t)__builtin_amdgcn_readfirstlane((int)g_task0[g]);
+      const uint64_t mem = g_mem[g];
+      const uint32_t kmode = info & 0xFFu;
+      const bool img1 = ((info >> 8) & 1u) != 0;
+      // the column record (wave-uniform; ci < 0: the cell is not decoded)
+      const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + cb_u);
+      static_assert(sizeof(DevCol) == 12, "descriptor words below");
+      int ci = (int)k;
+      if (kmode == 1) ci = (int)(cw[3 * k] >> 24);                     // DevCol.key_col of record k: cell k of a dense key tuple
+      const uint32_t w0 = cw[3 * ci], w1 = cw[3 * ci + 1], w2 = cw[3 * ci + 2];
+      if (kmode == 2 && !((w0 >> 16) & 0xFFu)) ci = -1;               // full-width key tuple: only the identity columns are read
+      if (ci < 0) continue;
+      const uint32_t cls = w0 & 0xFFu, nullable = (w0 >> 8) & 0xFFu;
+      const uint32_t off = kmode ? (w1 >> 16) : (w1 & 0xFFFFu);
+      const uint32_t kout = kmode ? (w2 & 0xFFFFu) : (uint32_t)ci;
+      const uint32_t hr = kmode ? (w2 >> 24) : ((w2 >> 16) & 0xFFu);
+      const bool on = ((mem >> lane) & 1ull) != 0;
+      const uint32_t pos0 = on ? fr_base[lane] + ctab[((img1 ? maxc : 0u) + k) * cf + lane] : 0u;
+      const uint32_t frow = fr_row[lane];
+      u8* const rowp = img + (frow & 0xFFFFu) + (img1 ? frow >> 16 : 0u);
+      uint32_t* const slotp = (uint32_t*)(rowp + off);
+      const uint64_t head = ldu64(base + pos0);
+      const uint32_t t = (uint32_t)head & 0xFFu;
+      const uint32_t len = __builtin_bswap32((uint32_t)(head >> 8));
+      const uint32_t pos = pos0 + 5;
+      uint32_t st = ETLG_CELL_VALUE, bad = 0;
+      bool entry = false;
+      if (on && t == 't') {
+        const u8* d = base + pos;
+        if (rows_heap_class(cls)) {
+          uint32_t kind = HK_COPY, nbytes = len;
+          if (cls == ETLG_TC_NUMERIC) {
+            NumShape ns;
+            const bool okn = numeric_plain(d, len, ns) || numeric_scan(d, len, ns, true);
+            kind = HK_NUMERIC;
+            nbytes = okn ? 8 + 2 * ns.ngroups : 0u;
+            if (!okn) bad = 1;
+          } else if (cls == ETLG_TC_BYTEA) {
+            if (len < 2) bad = 1;
+            nbytes = len >= 2 ? (len - 2) >> 1 : 0u; kind = HK_BYTEA;
+          } else if (cls == ETLG_TC_F32 || cls == ETLG_TC_F64) {
+            uint64_t bits = 0;
+            const int r = parse_float_fast(d, len, cls == ETLG_TC_F32, bits, true);
+            if (r == 2) bad = 1;
+            if (r == 0) { st64(slotp, bits); kind = HK_NONE; nbytes = 0; }
+            else st = ETLG_CELL_DEFERRED;
+          } else if (cls != ETLG_TC_STRING) st = ETLG_CELL_DEFERRED;   // json / arrays / classes without a codec: the source text
+          const uint32_t hdw = (nbytes + 3u) >> 2;
+          if (kind != HK_NONE && !bad) {
+            if (hdw > kRowsHeapMaxDw) bad = 4;
             else {
-              const uint32_t nw = slot_bytes(cls) >> 2;
-              slotp[0] = tmp[0];
-              if (nw > 1) slotp[1] = tmp[1];
-              if (nw > 2) slotp[2] = tmp[2];
-              if (nw > 3) slotp[3] = tmp[3];
+              const uint32_t r = (img1 ? maxh : 0u) + hr;
+              htab[r * cf + lane] = pos | (hdw << 17) | (kind << 30);
+              hslot[r * cf + lane] = (uint16_t)((u8*)slotp - img);
+              slotp[1] = nbytes;
+              entry = true;
             }
           }
-        } else if (on && t == 'n') {
-          if (!nullable) derr = true;   // Required column missing from tuple (codec/event.rs:945-961)
-          st = ETLG_CELL_NULL;
-        } else if (on && t == 'u') {
-          if (upd) toast |= 1ull << k;   // resolved once the old image's heap references are final
-          else derr = true;              // a full row / key image cannot miss a value
-        } else if (on) {
-          derr = true;                   // binary format
+        } else {
+          uint32_t tmp[4] = {0, 0, 0, 0};
+          uint32_t hdummy = 0;
+          const uint32_t err = decode_text_cell<false>(cls, d, len, tmp, nullptr, hdummy, st, true);
+          if (err) bad = 1;
+          else {
+            const uint32_t nw = slot_bytes(cls) >> 2;
+            slotp[0] = tmp[0];
+            if (nw > 1) slotp[1] = tmp[1];
+            if (nw > 2) slotp[2] = tmp[2];
+            if (nw > 3) slotp[3] = tmp[3];
+          }
         }
-        if (on && st) atomicOr((uint32_t*)rowp + (kout >> 4), st << (2 * (kout & 15u)));
-        // which rows of the table hold entries (wave-uniform: any lane of the group)
-        if (rows_heap_class(cls) && hr != 0xFFu && __ballot(on && t == 't')) { if (img1) rows_new |= 1ull << hr; else rows_old |= 1ull << hr; }
+      } else if (on && t == 'n') {
+        if (!nullable) bad = 1;   // Required column missing from tuple (codec/event.rs:945-961)
+        st = ETLG_CELL_NULL;
+      } else if (on && t == 'u') {
+        if (img1 && (fr_flags[lane] & 2u)) { atomicOr(&fr_toast[k >> 5][lane], 1u << (k & 31u)); }   // resolved once the old image's heap references are final
+        else bad = 1;              // a full row / key image cannot miss a value
+      } else if (on) {
+        bad = 1;                   // binary format
       }
-    };
-    // Shape of an image against its slot (convert_tuple_to_row / normalize_key_tuple_to_row, codec/event.rs:559-565, 889-922): 0 full /
-    // update row, 1 dense key tuple, 2 full-width key tuple, 3 = a shape error
-    auto image_mode = [&](uint32_t slot_u, bool key, uint32_t n_u) -> uint32_t {
-      const ETLG_CONST_AS uint32_t* sw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.slots + slot_u);
-      const uint32_t n_cols = sw[0], n_ident = sw[1];
-      if (!key) return n_u == n_cols ? 0u : 3u;
-      if (n_ident == 0) return 3u;
-      return n_u == n_ident ? 1u : n_u == n_cols ? 2u : 3u;
-    };
-    // ---- old / key images, one group per (slot, kind, cell count)
-    for (;;) {
-      const unsigned long long pend = __ballot(ph == 1);
-      if (!pend) break;
-      const int leader = __builtin_ctzll(pend);
-      const uint32_t slot_u = (uint32_t)__builtin_amdgcn_readlane(slot, leader);
-      const uint32_t kind_u = (uint32_t)__builtin_amdgcn_readlane((int)old_kind, leader);
-      const uint32_t n_u = (uint32_t)__builtin_amdgcn_readlane((int)n_old, leader);
-      const bool in = ph == 1 && (uint32_t)slot == slot_u && old_kind == kind_u && n_old == n_u;
-      uint32_t mode = 0;
-      if (slot_u != ~0u) {
-        mode = image_mode(slot_u, kind_u == ETLG_OLD_KEY, n_u);
-        if (mode == 3) { if (in) { derr = true; ph = 0; } continue; }   // (the frame fails whatever its cells hold)
-      }
-      walk_image(in, slot_u, mode, n_u, false);
-      if (in) {
-        ph = 0;
-        if (v.tag == 'U' && wire_ok) {   // the new image's header
-          const uint64_t head = ldu64(base + c);
-          const uint32_t t = (uint32_t)head & 0xFFu;
-          const uint32_t cnt16 = (((uint32_t)head >> 8) & 0xFFu) << 8 | (((uint32_t)head >> 16) & 0xFFu);
-          const bool hdr_ok = (e - c >= 3) & (t == 'N') & !(cnt16 & 0x8000u);
-          if (hdr_ok) { c += 3; n_new = cnt16; ph = 2; } else wire_ok = false;
+      if (on && st && !bad) atomicOr((uint32_t*)rowp + (kout >> 4), st << (2 * (kout & 15u)));
+      if (bad) atomicOr(&fr_flags[lane], bad);
+      if (__ballot(entry) && lane == 0) atomicOr((unsigned long long*)&s64[img1 ? 9 : 8], 1ull << hr);
+    }
+  }
+  __syncthreads();
+  TSTAMP(4);
+
+  uint32_t x_ev = 0, x_hp = 0;
+  if (spine) {
+    // ================= S (spine): per-frame prefix over its heap cells, wave scans, look-back
+    ETLG_WAVE_PRIO(3);
+    const uint64_t m_old = s64[8], m_new = s64[9];
+    {
+      const uint32_t fl = lane < cf ? fr_flags[lane] : 0u;
+      if (fl & 1u) derr = 1;
+      if (fl & 4u) gave = 0x2000;
+    }
+    uint32_t hdw = 0;
+    for (uint32_t half = 0; half < 2; half++) {
+      uint64_t m = half ? m_new : m_old;
+      while (m) {
+        const uint32_t hr = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t idx = (half * maxh + hr) * cf + (lane < cf ? lane : 0u);
+        const uint32_t w = htab[idx];
+        if ((w >> 30) != HK_NONE && lane < cf) {
+          htab[idx] = (w & ~(kRowsHeapMaxDw << 17)) | ((hdw & kRowsHeapMaxDw) << 17);
+          if (hdw > kRowsHeapMaxDw) gave = 0x4000;
+          hdw += (w >> 17) & kRowsHeapMaxDw;
         }
       }
     }
-    // ---- new images, one group per (slot, cell count)
-    for (;;) {
-      const unsigned long long pend = __ballot(ph == 2);
-      if (!pend) break;
-      const int leader = __builtin_ctzll(pend);
-      const uint32_t slot_u = (uint32_t)__builtin_amdgcn_readlane(slot, leader);
-      const uint32_t n_u = (uint32_t)__builtin_amdgcn_readlane((int)n_new, leader);
-      const bool in = ph == 2 && (uint32_t)slot == slot_u && n_new == n_u;
-      if (slot_u != ~0u && image_mode(slot_u, false, n_u) == 3) { if (in) { derr = true; ph = 0; } continue; }
-      walk_image(in, slot_u, 0u, n_u, true);
-      if (in) ph = 0;
-    }
-    TSTAMP(3);
     if (live && isrow) {
-      if (!wire_ok) record_error(pg, f, RK_WIRE, ETLG_E_WIRE);
-      else if (derr) record_error(pg, f, RK_DECODE, ETLG_E_WIRE);
+      if (wire_ok && derr) record_error(pg, f, RK_DECODE, ETLG_E_WIRE);
       pay[v.tag == 'I' ? 0 : v.tag == 'U' ? 1 : 2] = vbytes;
-      if (slot >= 0) heap = hp;
+      if (slot >= 0) heap = hdw << 2;
     }
-    if (__ballot(gave)) { if (lane == 0) atomicOr(fail, kRowsGaveUp); }
-    // wave scan of (events, heap dwords), payload counters
+    { const uint32_t why = wave_last(wave_scan_incl(gave, [](uint32_t a, uint32_t b) { return a | b; }, 0u)); if (why && lane == 0) atomicOr(fail, kRowsGaveUp | why); }   // bits 8..: why (debugging aid)
     const uint32_t ie = wave_scan_add(emit), ih = wave_scan_add(heap >> 2);
     const uint32_t tot_e = wave_last(ie), tot_h = wave_last(ih);
     const uint32_t a0p = wave_last(wave_scan_add((uint32_t)pay[0])), a1p = wave_last(wave_scan_add((uint32_t)pay[1])),
@@ -392,18 +452,19 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     const uint64_t agg = ((uint64_t)tot_e << 32) | tot_h;
     const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg, 0, fail);
     const uint64_t pre_hp = (uint64_t)(uint32_t)a << 2;
-    const bool heap_fits = pre_hp + ((uint64_t)tot_h << 2) <= pg.heap_cap && pre_hp + ((uint64_t)tot_h << 2) <= 0xFFFFFFFFull;
+    const bool hf = pre_hp + ((uint64_t)tot_h << 2) <= pg.heap_cap && pre_hp + ((uint64_t)tot_h << 2) <= 0xFFFFFFFFull;
     if (lane < cf) fr_hp[lane] = (uint32_t)(pre_hp + ((uint64_t)x_hp << 2));
-    if (lane == 0) { s64[0] = agg; s64[4] = a; s64[8] = rows_old; s64[9] = rows_new; s32[0] = heap_fits ? 1u : 0u; }
+    if (lane == 0) { s64[0] = agg; s64[4] = a; s32[0] = hf ? 1u : 0u; }
+    ETLG_WAVE_PRIO(0);
   }
   __syncthreads();
-  TSTAMP(4);
+  TSTAMP(5);
   const uint64_t pre_ev = s64[4] >> 32, pre_fx = s64[5] << 2;
   const bool heap_fits = s32[0] != 0;
   const uint64_t m_old = s64[8], m_new = s64[9];
 
   if (!spine) {
-    // ================= P4 (the other waves): text of String / deferred cells -> heap, 16 bytes per lane and step
+    // ================= C (the other waves): text of String / deferred cells -> heap, 16 bytes per lane and step
     const uint32_t cw_rank = role - 1, ncw = NW - 1;
     for (uint32_t half = 0; half < 2 && heap_fits; half++) {
       uint64_t m = half ? m_new : m_old;
@@ -411,7 +472,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         const uint32_t hr = (uint32_t)__builtin_ctzll(m);
         m &= m - 1;
         const uint32_t r = half * maxh + hr;
-        const uint32_t w = lane < nt ? tabw[r * cf + lane] : 0u;
+        const uint32_t w = lane < nt ? htab[r * cf + lane] : 0u;
         const bool act = (w >> 30) == HK_COPY;
         const uint32_t pos = w & 0x1FFFFu;
         const uint32_t len = act ? __builtin_bswap32(ldu32(base + pos - 4)) : 0u;
@@ -462,7 +523,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
       }
     }
   } else {
-    // ================= P3 (spine): transaction context, numerics / bytea, heap references, toast, event headers
+    // ================= H (spine): transaction context, numerics / bytea, heap references, toast, event headers
     ETLG_WAVE_PRIO(3);
     {
       const TxnStart ts{s32[12], s32[13], s64[6], s64[3]};
@@ -500,12 +561,12 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         const uint32_t hr = (uint32_t)__builtin_ctzll(m);
         m &= m - 1;
         const uint32_t r = half * maxh + hr;
-        const uint32_t w = lane < nt ? tabw[r * cf + lane] : 0u;
+        const uint32_t w = lane < nt ? htab[r * cf + lane] : 0u;
         const uint32_t kind = w >> 30;
         if (kind != HK_NONE) {
           const uint32_t pos = w & 0x1FFFFu;
           uint32_t hcur = fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2);
-          uint32_t* const slotp = (uint32_t*)(img + tabs[r * cf + lane]);
+          uint32_t* const slotp = (uint32_t*)(img + hslot[r * cf + lane]);
           slotp[0] = hcur;
           if (kind != HK_COPY) {
             const uint32_t len = __builtin_bswap32(ldu32(base + pos - 4));
@@ -519,6 +580,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     }
     // 'u' cells of the new row: alias the aligned old value, else MISSING (codec/event.rs:962-974)
     uint32_t flags = (isrow && v.tag != 'I') ? old_kind : 0u;
+    uint64_t toast = lane < cf ? ((uint64_t)fr_toast[0][lane] | ((uint64_t)fr_toast[1][lane] << 32)) : 0ull;
     if (emit && isrow && toast) {
       const DevSlot& s = p.slots[slot];
       const DevCol* cols = p.cols + s.cols_base;
@@ -574,7 +636,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   }
   __threadfence_block();
   __syncthreads();
-  TSTAMP(5);
+  TSTAMP(6);
   // ================= all waves: the image -> the fixed arena, one contiguous block
   if (s32[1]) {
     const uint32_t ndw = (uint32_t)s64[1];
@@ -582,7 +644,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     const uint32_t* in32 = (const uint32_t*)img;
     for (uint32_t i = tid; i < ndw; i += NW * 64) out[i] = in32[i];
   }
-  TSTAMP(6);
+  TSTAMP(7);
 }
 
 }  // namespace etlg
@@ -597,11 +659,12 @@ void etlg_k_launch_rows(const DecParams* p, const void* qv, hipStream_t s) {
 }
 
 int etlg_k_rows_set_lds(void) {
-  return hipFuncSetAttribute((const void*)k_rows<RNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) == hipSuccess ? 0 : 1;
+  return hipFuncSetAttribute((const void*)k_rows<RNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) == hipSuccess ? 0 : 1;
 }
 
-uint32_t etlg_k_rows_table_bytes(uint32_t maxh, uint32_t cf) { return (2u * maxh * cf * 6u + 15u) & ~15u; }
-uint32_t etlg_k_rows_static_lds(void) { return 1024u; }   // the kernel's __shared__ arrays (s_offs, fr_hp, s32, s64) + slack
+// heap-cell table + cell positions next to the image and the window
+uint32_t etlg_k_rows_table_bytes(uint32_t maxh, uint32_t maxc, uint32_t cf) { return ((2u * maxh * cf * 6u + 15u) & ~15u) + ((2u * maxc * cf * 2u + 15u) & ~15u); }
+uint32_t etlg_k_rows_static_lds(void) { return 2816u; }   // the kernel's __shared__ arrays + slack
 uint32_t etlg_k_rows_max_cols(void) { return 64u; }       // toast mask: one bit per column of the new image
 uint32_t etlg_k_rows_max_heap_cols(void) { return 64u; }  // rows per image of the heap-cell table (one 64-bit presence mask per image)
 

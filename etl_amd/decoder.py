@@ -373,9 +373,9 @@ class Decoder:
     def debug_rows(self):
         """Batches by the row-synchronous kernel (debugging aid, not in etlg.h): 'rows' = produced by k_rows, 'rows_redone' = handed back by it
         (a tile that did not fit its LDS window / image) and decoded again by k_cells / k_fused."""
-        out = (C.c_ulonglong * 2)()
+        out = (C.c_ulonglong * 3)()
         self.L.etlg_ctx_debug_rows(self.h, out)
-        return {"rows": int(out[0]), "rows_redone": int(out[1])}
+        return {"rows": int(out[0]), "rows_redone": int(out[1]), "rows_resized": int(out[2])}
 
     def debug_copy(self):
         """Table-copy batches by path (debugging aid, not in etlg.h): 'direct' = produced by the rows -> arena kernel (k_copy_cells),

@@ -171,6 +171,7 @@ static inline unsigned long long wall_clock64() { return simt::ticks(); }
 template <class T, class U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
 template <class T, class U> static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
 template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T, class U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
