@@ -866,6 +866,72 @@ DEV bool iso_timestamp_fast(const u8* s, uint32_t n, int32_t& days, uint32_t& se
   if (n < 19 || s[10] != ' ') return false;
   return iso_date_fast(s, 10, days) && iso_time_fast(s + 11, n - 11, secs, nanos, over);
 }
+// (the register-only temporal parsers below are compiled into the kernels that ask for them — rows.hip; k_cells / k_fused keep the code their
+// register allocation was tuned for: with these inlined k_cells spills 16-21 VGPRs)
+#ifndef ETLG_TEMPORAL_SWAR
+#define ETLG_TEMPORAL_SWAR 0
+#endif
+// parse_iso_timestamp_fast once more, for staged text (the loads may run past the text inside the window's slack): the 19..29 bytes
+// come in as eight dwords, separators are compared in place, every two-digit field is validated and converted with the packed
+// digit test of digits4, the fraction is right-padded with '0' by masks. No byte loads, no character loop. Accepts exactly what
+// iso_timestamp_fast accepts and returns the same values (tests/test_gpu_parity.py::test_temporal_matrix runs both ends of every
+// branch); false = "not this shape": the caller goes on with the byte-wise path.
+DEV bool iso_timestamp_swar(const u8* s, uint32_t n, int32_t& days, uint32_t& secs, uint32_t& nanos) {
+  if (n < 19u || n == 20u || n > 29u) return false;
+  const uint32_t sh = (uint32_t)(uintptr_t)s & 3u;
+  const uint32_t* q = (const uint32_t*)(s - sh);
+  const uint32_t need = sh + n;
+  uint32_t r[9], w[8];
+#pragma unroll
+  for (uint32_t j = 0; j < 9; j++) r[j] = 4 * j < need ? q[j] : 0u;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; j++) w[j] = __builtin_amdgcn_alignbyte(r[j + 1], r[j], sh);
+  const bool frac = n > 19u;
+  bool sep = (w[1] & 0xFF0000FFu) == 0x2D00002Du && (w[2] & 0x00FF0000u) == 0x00200000u && (w[3] & 0x0000FF00u) == 0x00003A00u &&
+             (w[4] & 0xFFu) == 0x3Au && (!frac || (w[4] >> 24) == 0x2Eu);
+  if (!sep) return false;
+  uint32_t badm = 0;
+  auto two = [&](uint32_t x) -> uint32_t {   // two ASCII digits in bits 0..15, first digit in the low byte
+    const uint32_t t = x - 0x3030u;
+    badm |= ((x + 0x4646u) | t) & 0x8080u;
+    return (t & 0xFu) * 10u + ((t >> 8) & 0xFu);
+  };
+  bool okd = true;
+  const uint32_t year = digits4(w[0], okd);
+  const uint32_t mon = two((w[1] >> 8) & 0xFFFFu), day = two(w[2] & 0xFFFFu);
+  const uint32_t hh = two((w[2] >> 24) | ((w[3] & 0xFFu) << 8)), mi = two(w[3] >> 16), ss = two((w[4] >> 8) & 0xFFFFu);
+  uint32_t nn = 0;
+  if (frac) {
+    const uint32_t fl = n - 20u;   // 1..9
+    const uint32_t ka = fl >= 4u ? 0xFFFFFFFFu : (1u << (8u * fl)) - 1u;
+    const uint32_t flb = fl > 4u ? fl - 4u : 0u;
+    const uint32_t kb = flb >= 4u ? 0xFFFFFFFFu : (1u << (8u * flb)) - 1u;
+    const uint32_t a = (w[5] & ka) | (0x30303030u & ~ka), b = (w[6] & kb) | (0x30303030u & ~kb);
+    const uint32_t c9 = fl == 9u ? (w[7] & 0xFFu) : 0x30u;
+    if (c9 - 0x30u > 9u) return false;
+    nn = digits4(a, okd) * 100000u + digits4(b, okd) * 10u + (c9 - 0x30u);
+  }
+  if (!okd || badm || hh >= 24u || mi >= 60u || ss >= 60u) return false;
+  if (!ymd_to_ce_days(year, mon, day, days)) return false;
+  secs = hh * 3600u + mi * 60u + ss;
+  nanos = nn;
+  return true;
+}
+// split_timestamp_offset + parse_postgres_utc_offset for the shape Postgres prints for whole-hour zones, `...+HH` / `...-HH`, staged
+// text: the index of the sign and the offset in seconds; false = another shape (the caller goes on with the general functions).
+DEV bool tz_hours_swar(const u8* s, uint32_t n, uint32_t min_index, uint32_t& idx, int32_t& off) {
+  if (n < min_index + 4u) return false;   // the sign must lie beyond min_index
+  const uint32_t x = ldu32(s + n - 3u);
+  const uint32_t sg = x & 0xFFu;
+  if (sg != '+' && sg != '-') return false;
+  const uint32_t d2 = (x >> 8) & 0xFFFFu, t = d2 - 0x3030u;
+  if (((d2 + 0x4646u) | t) & 0x8080u) return false;
+  const uint32_t h = (t & 0xFu) * 10u + ((t >> 8) & 0xFu);
+  if (h >= 16u) return false;
+  idx = n - 3u;
+  off = sg == '-' ? -(int32_t)(h * 3600u) : (int32_t)(h * 3600u);
+  return true;
+}
 // parse_postgres_utc_offset, crates/etl-postgres/src/time.rs:143-207
 DEV bool parse_utc_offset(const u8* s, uint32_t n, int32_t& out, bool over = false) {
   if (n == 0) return false;
@@ -1196,23 +1262,28 @@ DEV_DECODE uint32_t decode_text_cell(uint32_t cls, const u8* d, uint32_t len, ui
     }
     case ETLG_TC_TIMESTAMP: {
       int32_t x; uint32_t a, b;
-      if (iso_timestamp_fast(d, len, x, a, b, over)) { slot[0] = (uint32_t)x; slot[1] = a; slot[2] = b; return 0; }
+      if ((ETLG_TEMPORAL_SWAR && over && iso_timestamp_swar(d, len, x, a, b)) || iso_timestamp_fast(d, len, x, a, b, over)) { slot[0] = (uint32_t)x; slot[1] = a; slot[2] = b; return 0; }
       uint32_t o[3];
       if (!chrono_fallback(cls, d, len, o)) return bad(ETLG_E_DATETIME);
       slot[0] = o[0]; slot[1] = o[1]; slot[2] = o[2];
       return 0;
     }
     case ETLG_TC_TIMESTAMPTZ: {  // codec/time.rs:63-71 + UTC normalisation codec/text.rs:108-111
+      int32_t x; uint32_t a, b;
+      int32_t off;
+      uint32_t fidx;
+      if (ETLG_TEMPORAL_SWAR && over && tz_hours_swar(d, len, 10, fidx, off) && iso_timestamp_swar(d, fidx, x, a, b)) {
+        // (the shape Postgres prints: both halves decided without a byte load)
+      } else {
       const int32_t idx = split_offset_index(d, len, 10, over);
       if (idx < 0) return bad(ETLG_E_DATETIME);
-      int32_t x; uint32_t a, b;
       if (!iso_timestamp_fast(d, (uint32_t)idx, x, a, b, over)) {
         uint32_t o[3];
         if (!chrono_fallback(cls, d, (uint32_t)idx, o)) return bad(ETLG_E_DATETIME);
         x = (int32_t)o[0]; a = o[1]; b = o[2];
       }
-      int32_t off;
       if (!parse_utc_offset(d + idx, len - (uint32_t)idx, off, over)) return bad(ETLG_E_DATETIME);
+      }
       int32_t sec = (int32_t)a - off;
       if (sec < 0) { sec += 86400; x -= 1; } else if (sec >= 86400) { sec -= 86400; x += 1; }
       if (x < kChronoMinDays || x > kChronoMaxDays) return bad(ETLG_E_DATETIME);   // from_local_datetime(..).single() is None outside NaiveDate's range

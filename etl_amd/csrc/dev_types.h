@@ -104,8 +104,8 @@ struct FusedParams {
   uint32_t clear_words;        // 64-bit words of d_clear this launch zeroes (the descriptor buffer of the NEXT batch)
   unsigned long long* d_clear;
   uint32_t copy_rel;           // k_copy_cells: the table id the rows' Insert events carry
-  uint32_t rows_img;           // k_rows: bytes of the tile's image of the fixed arena in LDS (multiple of 16, < 64 KiB)
-  uint32_t rows_maxh;          // k_rows: most heap-class columns in one slot (rows per image of the heap-cell table)
+  uint32_t rows_maxh_old;      // k_rows: most heap-class IDENTITY columns in one slot (rows of the heap-cell table for key / old images)
+  uint32_t rows_maxh;          // k_rows: most heap-class columns in one slot (rows for new images)
 };
 
 constexpr unsigned long long kNoErr = ~0ull;

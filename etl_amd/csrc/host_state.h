@@ -73,7 +73,8 @@ extern "C" void etlg_k_launch_copy_cells(const DecParams* p, const void* q, hipS
 extern "C" uint32_t etlg_k_cells_maxc(void);
 extern "C" void etlg_k_launch_rows(const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_rows_set_lds(void);
-extern "C" uint32_t etlg_k_rows_table_bytes(uint32_t maxh, uint32_t maxc, uint32_t cf);
+extern "C" int etlg_k_rows_occupancy(uint32_t lds_bytes);
+extern "C" uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc, uint32_t cf);
 extern "C" uint32_t etlg_k_rows_static_lds(void);
 extern "C" uint32_t etlg_k_rows_max_cols(void);
 extern "C" uint32_t etlg_k_rows_max_heap_cols(void);
@@ -336,7 +337,7 @@ struct etlg_ctx {
   uint32_t plan_skip = 0, plan_penalty = 4, plan_streak = 0;
   // k_rows (rows.hip) hands a batch back when a tile does not fit its LDS window / image: the batches behind it skip the kernel for a while
   uint32_t rows_skip = 0, rows_penalty = 4, rows_streak = 0;
-  uint64_t rows_win_min = 0, rows_img_min = 0;   // bytes a 64-frame tile's window / image had to hold when k_rows last handed a batch back for that reason
+  uint64_t rows_win_min = 0;   // bytes a 64-frame tile's window had to hold when k_rows last handed a batch back for that reason
   unsigned long long rows_resized = 0;            // batches k_rows took again with a larger window / image
   int rows_mode = 1;             // ETLG_ROWS: 0 never, 1 wherever k_cells / k_fused-64 would run and the batch is eligible
   unsigned long long rows_n = 0, rows_redone = 0;   // batches k_rows produced / handed back

@@ -5,32 +5,32 @@
 // addresses looked up per LANE), a sizing pass that parses numerics a second time, a per-frame prefix over all virtual
 // columns, and text moved four bytes per lane. Here a tile is:
 //
-//   P0  all waves: stage the tile's bytes + side tables into LDS, zero the tile's image of the fixed arena
+//   P0  all waves: stage the tile's bytes + side tables into LDS
 //   P1  spine wave, lane = frame: envelope, tag, transaction scan, ownership + schema slot, FIXED-arena bytes per frame
-//       (they depend on the message heads only) -> wave scan -> every frame knows where its rows sit in the LDS image;
-//       the fixed-arena and transaction aggregates are published at once and resolved by two other waves during W
+//       (they depend on the message heads only) -> wave scan; the fixed-arena and transaction aggregates are published at
+//       once and resolved by two other waves during W, so that D knows every row's final place in the arena
 //   W   spine wave: a lean structural walk (tag, length, bounds; ~35 instructions per step) that leaves the position of
 //       every cell in a 16-bit table [virtual column][frame]; then the frames are sorted into GROUPS of one (schema slot,
 //       image kind, cell count): inside a group, cell k of every frame belongs to the same column
 //   D   all waves pull (group, column) tasks: the column record is wave-uniform (scalar loads, a scalar class switch — the
-//       per-schema program the host would otherwise have to compile), lanes = the group's frames. Fixed-width values go
-//       straight into the LDS image; cells that reach the heap (text, numeric, bytea, deferred classes) are sized and
-//       noted in a small table [heap rank][frame]
+//       per-schema program the host would otherwise have to compile), lanes = the group's frames, heaviest classes first.
+//       Fixed-width values go straight to their arena slots; cells that reach the heap (text, numeric, bytea, deferred
+//       classes) are sized and noted in a small table [heap rank][frame]; 2-bit cell states collect in LDS
 //   S   spine: per-frame prefix over its heap cells (heap rows only), wave scan of (events, heap dwords), look-back
-//   H   spine: numerics / bytea emitted at their final heap positions, heap references patched into the image, toast
-//       cells aliased, event headers stored —
+//   H   spine: numerics / bytea emitted at their final heap positions, heap references patched into the slots, toast
+//       cells aliased, row state words and event headers stored —
 //   C   — while the other waves copy the text of String / deferred cells by 16-byte chunks dealt out densely over the
-//       lanes (a chunk's owner cell by binary search over the row's chunk prefix sums), validated as UTF-8 on the way;
-//       finally all waves copy the image to the fixed arena: one contiguous block
+//       lanes (a chunk's owner cell by binary search over the row's chunk prefix sums), validated as UTF-8 on the way
 //
 // What the kernel does not cover it hands back (DevResult.fused_fail bit 4, "rows gave up": the host decodes the batch
-// again with k_cells / k_fused): a tile whose bytes do not fit its LDS window, a tile whose rows outgrow the image, a
+// again with k_cells / k_fused): a tile whose bytes do not fit its LDS window, a
 // frame with more than 32 KiB of heap entries or longer than 64 KiB, more than 16 groups in one tile. Errors are recorded
 // at their frame like everywhere else and send the batch to the multi-pass kernels for the exact cut (the code recorded
 // here only has to be SOME error of that frame).
 #define ETLG_FLOAT_CALL static __device__ __attribute__((noinline))
 #define ETLG_DBG_WORD dbg_u
 #define ETLG_TSTAMP_WHO (spine && lane == 0)
+#define ETLG_TEMPORAL_SWAR 1   // timestamps / whole-hour offsets decided from registers (codec.hip.h)
 #include "lookback.hip.h"
 #include "utf8_swar.h"
 
@@ -39,6 +39,7 @@ namespace etlg {
 constexpr int RNW = 4;          // waves per tile
 constexpr uint32_t kRowsGaveUp = 16u;
 constexpr uint32_t kRowsMaxGroups = 16;
+constexpr uint32_t kRowsMaxTasks = 96;
 // heap-cell table entry: window position of the text (17 bits) | heap dwords of the cell, later its heap offset inside the frame (13 bits) | kind (2 bits)
 enum : uint32_t { HK_NONE = 0, HK_COPY = 1, HK_NUMERIC = 2, HK_BYTEA = 3 };
 constexpr uint32_t kRowsHeapMaxDw = 0x1FFFu;
@@ -49,7 +50,7 @@ DEV bool rows_heap_class(uint32_t cls) {
 }
 
 #ifndef ETLG_ROWS_MINBLOCKS
-#define ETLG_ROWS_MINBLOCKS 3
+#define ETLG_ROWS_MINBLOCKS 4
 #endif
 
 template <int NW>
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   __shared__ uint32_t s_offs[64 + 1];
   __shared__ uint32_t fr_hp[64];      // heap offset of the frame's first entry (absolute, bytes)
   __shared__ uint32_t fr_base[64];    // window offset of the frame's first byte
-  __shared__ uint32_t fr_row[64];     // the frame's body inside the image (bits 0..15) | bytes of its old / key row (16..31)
+  __shared__ uint32_t fr_row[64];     // the frame's body inside the tile's piece of the fixed arena, bytes
+  __shared__ uint32_t fr_osz[64];     // bytes of its old / key row
+  __shared__ uint4 tasks[kRowsMaxTasks];   // {cell index | group << 8 | image shape << 12 | new image << 14, the column's DevCol record}: heavy classes first inside a group
+  __shared__ uint8_t own_mark[NW][64];     // text copy: which cell starts at a chunk position of the current step
   __shared__ uint32_t fr_flags[64];   // bit 0: a cell failed to decode; bit 1: the frame is an Update; bit 2: beyond what the kernel covers
   __shared__ uint32_t fr_toast[2][64];   // new-image columns sent as 'u'
   __shared__ uint32_t g_slot[kRowsMaxGroups], g_info[kRowsMaxGroups], g_cb[kRowsMaxGroups], g_task0[kRowsMaxGroups];
@@ -82,22 +86,26 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   // ---- P0: side tables, offsets, staging
   SideRegs side;
   side_load<NW * 64>(p, true, (uint32_t*)smem, tid, side);
-  const uint32_t maxh = q.rows_maxh, R = 2 * maxh;
-  // dynamic LDS: side tables | heap-cell table (u32 [R][cf]) | its slot offsets (u16 [R][cf]) | cell positions (u16 [2 maxc][cf]) | image of the fixed arena | staging window
+  // rows of the heap-cell table: the heap-class columns a key / old image can hold (identity columns), then those of a full row
+  const uint32_t maxh = q.rows_maxh, maxh_old = q.rows_maxh_old, R = maxh_old + maxh;
+  // dynamic LDS: side tables | heap-cell table (u32 [R][cf]) | its slots (u16 [R][cf]: dword offsets inside the tile's piece of the fixed arena)
+  //              | 2-bit cell states (u32 [2 SW][cf]: one word per 16 columns and image) | cell positions (u16 [2 maxc][cf]) | staging window
+  const uint32_t SW = (maxc + 15u) >> 4;
   uint32_t* const htab = (uint32_t*)(smem + q.side_bytes);
   uint16_t* const hslot = (uint16_t*)(htab + R * cf);
   const uint32_t htab_bytes = (R * cf * 6u + 15u) & ~15u;
-  uint16_t* const ctab = (uint16_t*)((u8*)htab + htab_bytes);
+  uint32_t* const sttab = (uint32_t*)((u8*)htab + htab_bytes);
+  const uint32_t st_bytes = (2u * SW * cf * 4u + 15u) & ~15u;
+  uint16_t* const ctab = (uint16_t*)((u8*)sttab + st_bytes);
   const uint32_t ctab_bytes = (2u * maxc * cf * 2u + 15u) & ~15u;
-  u8* const img = (u8*)ctab + ctab_bytes;
-  u8* const stage = img + q.rows_img;
+  u8* const stage = (u8*)ctab + ctab_bytes;
   const uint32_t f0 = tile * cf;
   const uint32_t nt = pg.nframes - f0 < cf ? pg.nframes - f0 : cf;
   const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)pg.offs;
   const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
   const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
-  const uint32_t used = q.side_bytes + htab_bytes + ctab_bytes + q.rows_img;
+  const uint32_t used = q.side_bytes + htab_bytes + st_bytes + ctab_bytes;
   const uint32_t wcap = q.lds_bytes > used ? q.lds_bytes - used : 0u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len && span1 - a0 + 16 <= (1u << 17) && (uint64_t)(span1 - a0) + 16 <= wcap;
   if (window_ok) {
@@ -107,13 +115,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   }
   side_store<NW * 64>((uint32_t*)smem, tid, side);
   if (tid <= nt) s_offs[tid] = my_o;
-  {  // the heap-cell table starts empty, the image as zeros (NULL slots, padding and VALUE states are never written)
+  {  // the heap-cell table starts empty, the cell states as VALUE
     uint4* z = (uint4*)htab;
-    const uint32_t n16 = htab_bytes >> 4;
+    const uint32_t n16 = (htab_bytes + st_bytes) >> 4;
     for (uint32_t i = tid; i < n16; i += NW * 64) z[i] = make_uint4(0, 0, 0, 0);
-    uint4* zi = (uint4*)img;
-    const uint32_t i16 = q.rows_img >> 4;
-    for (uint32_t i = tid; i < i16; i += NW * 64) zi[i] = make_uint4(0, 0, 0, 0);
   }
   if (tid < 64) { fr_toast[0][tid] = 0; fr_toast[1][tid] = 0; fr_flags[tid] = 0; }
   if (tid == 0) { s64[8] = 0; s64[9] = 0; s32[2] = 0; s32[3] = 0; s32[4] = 0; }
@@ -220,11 +225,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     const uint32_t ifx = wave_scan_add(fixed >> 2);
     tot_f = wave_last(ifx);
     x_fx = ifx - (fixed >> 2);
-    if ((uint64_t)tot_f * 4u > q.rows_img) {   // the tile's rows do not fit the image: nothing of this tile is written
-      if (lane == 0) atomicMax(&pg.res->dbg_t[10], (unsigned long long)tot_f * 4ull);
+    if (tot_f > 0xFFFFu) {   // heap cells name their slots by 16-bit dword offsets inside the tile's piece of the arena
       gave = 0x200; tot_f = 0; emit = 0; fixed = 0; ok = 0; x_fx = 0; slot = -1;
     }
-    if (lane < cf) { fr_base[lane] = fb; fr_row[lane] = (x_fx << 2) | (old_sz << 16); if (isrow && v.tag == 'U') fr_flags[lane] = 2u; }
+    if (lane < cf) { fr_base[lane] = fb; fr_row[lane] = x_fx << 2; fr_osz[lane] = old_sz; if (isrow && v.tag == 'U') fr_flags[lane] = 2u; }
     if (lane == 0) { s64[1] = tot_f; s64[2] = ((uint64_t)seg_pack30(tot_cnt) << 32) | tot_mark; }
     ETLG_WAVE_PRIO(0);
   }
@@ -237,11 +241,8 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   if (spine) {
     if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
     if (NW <= 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
-    // ================= W (spine): Begin / Commit bodies (field copies), then the structural walk
+    // ================= W (spine): the structural walk
     ETLG_WAVE_PRIO(3);
-    const uint32_t rowb = x_fx << 2;
-    if (emit && v.tag == 'B') st64((uint32_t*)(img + rowb), ld_be64(v.fr + kBodyOff + 8));
-    if (emit && v.tag == 'C') { st64((uint32_t*)(img + rowb), ld_be64(v.fr + kBodyOff + 9)); st64((uint32_t*)(img + rowb) + 2, ld_be64(v.fr + kBodyOff + 17)); }
     // `lim` cells of image `vimg` (0 old / key, 1 new) for every lane that is still going: 'n' | 'u' | ('t' | 'b') i32 len bytes.
     // One step per cell index, no data-dependent branches; a lane that meets a malformed cell stops (ok = 0).
     auto walk_cells = [&](uint32_t lim, uint32_t vimg) {
@@ -302,45 +303,69 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         if (in) pend = 0;
       }
     }
-    if (lane == 0) { s32[2] = ntasks; s32[3] = ng; }
+    // the task list: inside every group the heavy classes first (temporal / uuid / numeric / float), so that the waves pulling from it finish
+    // close to each other
+    uint32_t nq = 0;
+    if (ntasks > kRowsMaxTasks) { gave = 0x1000; ng = 0; }
+    for (uint32_t g = 0; g < ng; g++) {
+      const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_info[g]);
+      const uint32_t cb_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_cb[g]);
+      const uint32_t kmode = info & 0xFFu, n_u = info >> 16;
+      const uint32_t tag16 = (g << 8) | (kmode << 12) | (((info >> 8) & 1u) << 14);
+      for (uint32_t k0 = 0; k0 < n_u; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        uint32_t heavy = 0, light = 0;
+        uint4 ent = make_uint4(0, 0, 0, 0);
+        if (k < n_u) {
+          const uint32_t* cw = (const uint32_t*)(p.cols + cb_u);   // (the LDS copy of the column records)
+          static_assert(sizeof(DevCol) == 12, "descriptor words below");
+          const uint32_t ci = kmode == 1 ? cw[3 * k] >> 24 : k;   // DevCol.key_col of record k: cell k of a dense key tuple
+          ent = make_uint4(k | tag16, cw[3 * ci], cw[3 * ci + 1], cw[3 * ci + 2]);
+          const uint32_t cls = ent.y & 0xFFu;
+          const bool hv = (cls >= ETLG_TC_DATE && cls <= ETLG_TC_UUID) || cls == ETLG_TC_NUMERIC || cls == ETLG_TC_F32 || cls == ETLG_TC_F64;
+          const bool take = !(kmode == 2 && !((ent.y >> 16) & 0xFFu));   // (full-width key tuple: only the identity columns are read)
+          heavy = (take && hv) ? 1u : 0u; light = (take && !hv) ? 1u : 0u;
+        }
+        const unsigned long long mh = __ballot(heavy != 0), ml = __ballot(light != 0);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t nh = (uint32_t)__builtin_popcountll(mh);
+        if (heavy) tasks[nq + (uint32_t)__builtin_popcountll(mh & lt)] = ent;
+        if (light) tasks[nq + nh + (uint32_t)__builtin_popcountll(ml & lt)] = ent;
+        nq += nh + (uint32_t)__builtin_popcountll(ml);
+      }
+    }
+    TSTAMP(9);
+    if (lane == 0) { s32[2] = nq; s32[3] = ng; }
     ETLG_WAVE_PRIO(0);
   }
   __syncthreads();
   TSTAMP(3);
 
   // ================= D (all waves): (group, column) tasks
+  const uint64_t pre_fx = s64[5] << 2;   // (resolved beside the walk)
+  const bool fixed_fits = pre_fx + (s64[1] << 2) <= pg.fixed_cap;
   {
-    const uint32_t ntasks = s32[2], ng = s32[3];
-    const uint32_t my_t0 = lane < ng ? g_task0[lane] : 0xFFFFFFFFu;
-    for (;;) {
-      uint32_t tk = 0;
-      if (lane == 0) tk = atomicAdd(&s32[4], 1u);
-      tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-      if (tk >= ntasks) break;
-      const uint32_t g = (uint32_t)__builtin_popcountll(__ballot(my_t0 <= tk)) - 1u;
-      const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_info[g]);
-      const uint32_t cb_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_cb[g]);
-      const uint32_t k = tk - (uint32_t)__builtin_amdgcn_readfirstlane((int)g_task0[g]);
+    const uint32_t ntasks = fixed_fits ? s32[2] : 0u;
+    // (the frame's constants once per wave; the tasks are dealt out round robin — they were ordered heavy first — so that a wave knows its
+    // next task without asking: one LDS round trip per task for the record instead of an atomic, a list entry, three group words and two
+    // dependent scalar loads from global memory)
+    const uint32_t my_base = fr_base[lane], my_row = fr_row[lane], my_osz = fr_osz[lane], my_upd = fr_flags[lane] & 2u;
+    for (uint32_t tk = tid >> 6; tk < ntasks; tk += NW) {
+      const uint4 ent = tasks[tk];
+      const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.x);
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.y), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.z),
+                     w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.w);
+      const uint32_t k = e0 & 0xFFu, g = (e0 >> 8) & 0xFu, kmode = (e0 >> 12) & 3u;
+      const bool img1 = ((e0 >> 14) & 1u) != 0;
       const uint64_t mem = g_mem[g];
-      const uint32_t kmode = info & 0xFFu;
-      const bool img1 = ((info >> 8) & 1u) != 0;
-      // the column record (wave-uniform; ci < 0: the cell is not decoded)
-      const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(pg.cols + cb_u);
-      static_assert(sizeof(DevCol) == 12, "descriptor words below");
-      int ci = (int)k;
-      if (kmode == 1) ci = (int)(cw[3 * k] >> 24);                     // DevCol.key_col of record k: cell k of a dense key tuple
-      const uint32_t w0 = cw[3 * ci], w1 = cw[3 * ci + 1], w2 = cw[3 * ci + 2];
-      if (kmode == 2 && !((w0 >> 16) & 0xFFu)) ci = -1;               // full-width key tuple: only the identity columns are read
-      if (ci < 0) continue;
       const uint32_t cls = w0 & 0xFFu, nullable = (w0 >> 8) & 0xFFu;
       const uint32_t off = kmode ? (w1 >> 16) : (w1 & 0xFFFFu);
-      const uint32_t kout = kmode ? (w2 & 0xFFFFu) : (uint32_t)ci;
+      const uint32_t kout = kmode ? (w2 & 0xFFFFu) : k;
       const uint32_t hr = kmode ? (w2 >> 24) : ((w2 >> 16) & 0xFFu);
       const bool on = ((mem >> lane) & 1ull) != 0;
-      const uint32_t pos0 = on ? fr_base[lane] + ctab[((img1 ? maxc : 0u) + k) * cf + lane] : 0u;
-      const uint32_t frow = fr_row[lane];
-      u8* const rowp = img + (frow & 0xFFFFu) + (img1 ? frow >> 16 : 0u);
-      uint32_t* const slotp = (uint32_t*)(rowp + off);
+      const uint32_t pos0 = on ? my_base + ctab[((img1 ? maxc : 0u) + k) * cf + lane] : 0u;
+      const uint32_t soff = my_row + (img1 ? my_osz : 0u) + off;   // the slot inside the tile's piece of the fixed arena
+      uint32_t* const slotp = (uint32_t*)(pg.fixed + pre_fx + soff);
       const uint64_t head = ldu64(base + pos0);
       const uint32_t t = (uint32_t)head & 0xFFu;
       const uint32_t len = __builtin_bswap32((uint32_t)(head >> 8));
@@ -369,11 +394,11 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
           } else if (cls != ETLG_TC_STRING) st = ETLG_CELL_DEFERRED;   // json / arrays / classes without a codec: the source text
           const uint32_t hdw = (nbytes + 3u) >> 2;
           if (kind != HK_NONE && !bad) {
-            if (hdw > kRowsHeapMaxDw) bad = 4;
+            if (hdw > kRowsHeapMaxDw || hr >= (img1 ? maxh : maxh_old)) bad = 4;   // (a full old image of a table whose replica identity is not FULL: no rows were set aside)
             else {
-              const uint32_t r = (img1 ? maxh : 0u) + hr;
+              const uint32_t r = (img1 ? maxh_old : 0u) + hr;
               htab[r * cf + lane] = pos | (hdw << 17) | (kind << 30);
-              hslot[r * cf + lane] = (uint16_t)((u8*)slotp - img);
+              hslot[r * cf + lane] = (uint16_t)(soff >> 2);
               slotp[1] = nbytes;
               entry = true;
             }
@@ -393,14 +418,15 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         }
       } else if (on && t == 'n') {
         if (!nullable) bad = 1;   // Required column missing from tuple (codec/event.rs:945-961)
+        else slot_zero(slotp, cls);
         st = ETLG_CELL_NULL;
       } else if (on && t == 'u') {
-        if (img1 && (fr_flags[lane] & 2u)) { atomicOr(&fr_toast[k >> 5][lane], 1u << (k & 31u)); }   // resolved once the old image's heap references are final
+        if (img1 && my_upd) { atomicOr(&fr_toast[k >> 5][lane], 1u << (k & 31u)); }   // resolved once the old image's heap references are final
         else bad = 1;              // a full row / key image cannot miss a value
       } else if (on) {
         bad = 1;                   // binary format
       }
-      if (on && st && !bad) atomicOr((uint32_t*)rowp + (kout >> 4), st << (2 * (kout & 15u)));
+      if (on && st && !bad) atomicOr(&sttab[((img1 ? SW : 0u) + (kout >> 4)) * cf + lane], st << (2 * (kout & 15u)));
       if (bad) atomicOr(&fr_flags[lane], bad);
       if (__ballot(entry) && lane == 0) atomicOr((unsigned long long*)&s64[img1 ? 9 : 8], 1ull << hr);
     }
@@ -424,7 +450,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
       while (m) {
         const uint32_t hr = (uint32_t)__builtin_ctzll(m);
         m &= m - 1;
-        const uint32_t idx = (half * maxh + hr) * cf + (lane < cf ? lane : 0u);
+        const uint32_t idx = ((half ? maxh_old : 0u) + hr) * cf + (lane < cf ? lane : 0u);
         const uint32_t w = htab[idx];
         if ((w >> 30) != HK_NONE && lane < cf) {
           htab[idx] = (w & ~(kRowsHeapMaxDw << 17)) | ((hdw & kRowsHeapMaxDw) << 17);
@@ -459,39 +485,61 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   }
   __syncthreads();
   TSTAMP(5);
-  const uint64_t pre_ev = s64[4] >> 32, pre_fx = s64[5] << 2;
+  const uint64_t pre_ev = s64[4] >> 32;
   const bool heap_fits = s32[0] != 0;
   const uint64_t m_old = s64[8], m_new = s64[9];
 
   if (!spine) {
     // ================= C (the other waves): text of String / deferred cells -> heap, 16 bytes per lane and step
     const uint32_t cw_rank = role - 1, ncw = NW - 1;
-    for (uint32_t half = 0; half < 2 && heap_fits; half++) {
+    const bool cclk = (dbg_u & 8) && role == 1 && lane == 0 && (blockIdx.x & 15) == 3;
+    const unsigned long long c_t0 = cclk ? clock64() : 0ull;
+    for (uint32_t half = 0; half < 2 && heap_fits && fixed_fits; half++) {
       uint64_t m = half ? m_new : m_old;
-      while (m) {
+      for (uint32_t ri = 0; m; ri++) {
         const uint32_t hr = (uint32_t)__builtin_ctzll(m);
         m &= m - 1;
-        const uint32_t r = half * maxh + hr;
+        const uint32_t r = (half ? maxh_old : 0u) + hr;
         const uint32_t w = lane < nt ? htab[r * cf + lane] : 0u;
-        const bool act = (w >> 30) == HK_COPY;
+        const uint32_t kind = w >> 30;
+        const bool act = kind == HK_COPY;
         const uint32_t pos = w & 0x1FFFFu;
-        const uint32_t len = act ? __builtin_bswap32(ldu32(base + pos - 4)) : 0u;
-        const uint32_t dst = act ? fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2) : 0u;
-        const uint32_t nch = (len + 15u) >> 4;
+        const uint32_t len = kind != HK_NONE ? __builtin_bswap32(ldu32(base + pos - 4)) : 0u;
+        const uint32_t dst = kind != HK_NONE ? fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2) : 0u;
+        // one of the copying waves per row: every heap cell's slot gets its heap reference; numerics / bytea are emitted at their final place
+        if (ri % ncw == cw_rank && kind != HK_NONE) {
+          uint32_t* const slotp = (uint32_t*)(pg.fixed + pre_fx + ((uint32_t)hslot[r * cf + lane] << 2));
+          slotp[0] = dst;
+          if (kind != HK_COPY) {
+            uint32_t tmp[4] = {0, 0, 0, 0}, st = 0, hcur = dst;
+            const uint32_t err = decode_text_cell<false>(kind == HK_NUMERIC ? (uint32_t)ETLG_TC_NUMERIC : (uint32_t)ETLG_TC_BYTEA, base + pos, len, tmp, pg.heap, hcur, st, true);
+            if (err) record_error(pg, f0 + lane, RK_DECODE, err);
+            else slotp[1] = tmp[1];
+          }
+        }
+        const uint32_t clen = act ? len : 0u;
+        const uint32_t nch = (clen + 15u) >> 4;
         const uint32_t incl = wave_scan_add(nch);
         const uint32_t T = wave_last(incl);
         const uint32_t excl = incl - nch;
+        volatile uint8_t* const marks = own_mark[tid >> 6];
         for (uint32_t t0 = cw_rank * 64u; t0 < T; t0 += ncw * 64u) {
           const uint32_t x = t0 + lane;
-          // the chunk's cell: the number of lanes whose inclusive sum is <= x
-          uint32_t lo = 0;
-#pragma unroll
-          for (uint32_t step = 32; step; step >>= 1) {
-            const uint32_t probe = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), 64);
-            if (probe <= x) lo += step;
-          }
-          const uint32_t owner = lo < 63u ? lo : 63u;
-          const uint32_t o_pos = (uint32_t)__shfl((int)pos, (int)owner, 64), o_len = (uint32_t)__shfl((int)len, (int)owner, 64);
+          // The chunk's cell. Cells lie in lane order, so the cell of chunk x is the last one that starts at or before x: every cell whose
+          // first chunk falls into this step leaves its lane number at that position of a 64-byte scratch row, the cell still going when
+          // the step begins comes in at position 0, and a running maximum over the positions (DPP) spreads the owners. One LDS round trip
+          // and a scan instead of a six-step binary search through ds_bpermute (six dependent round trips).
+          marks[lane] = 0;
+          ETLG_WAVE_JOIN();
+          const uint32_t s_i = excl - t0;
+          if (nch != 0 && s_i < 64u) marks[s_i] = (uint8_t)(lane + 1u);
+          const unsigned long long before = __ballot(nch != 0 && excl < t0);
+          const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+          uint32_t mk = marks[lane];
+          if (lane == 0 && mk == 0) mk = carry;
+          const uint32_t own1 = wave_scan_max(mk);
+          const uint32_t owner = own1 ? own1 - 1u : 0u;
+          const uint32_t o_pos = (uint32_t)__shfl((int)pos, (int)owner, 64), o_len = (uint32_t)__shfl((int)clen, (int)owner, 64);
           const uint32_t o_dst = (uint32_t)__shfl((int)dst, (int)owner, 64), o_excl = (uint32_t)__shfl((int)excl, (int)owner, 64);
           if (x < T) {
             const uint32_t boff = (x - o_excl) << 4;
@@ -522,6 +570,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         }
       }
     }
+    if (cclk) atomicAdd(&pg.res->dbg_t[8], clock64() - c_t0);   // (phase clocks: the text copy as one of its waves sees it)
   } else {
     // ================= H (spine): transaction context, numerics / bytea, heap references, toast, event headers
     ETLG_WAVE_PRIO(3);
@@ -551,40 +600,15 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
       r->out_next_ord = (sg & 0x80000000u) ? cc : start_ord + cc;
       carry_publish(r);
     }
-    const bool fixed_fits = pre_fx + ((uint64_t)tot_f << 2) <= pg.fixed_cap;
     if (!(heap_fits && fixed_fits)) { if (emit) record_error(pg, f, RK_DECODE, ETLG_E_WIRE); emit = 0; }
-    if (lane == 0) s32[1] = (heap_fits && fixed_fits) ? 1u : 0u;
-    // numerics / bytea at their final heap positions; every heap cell's slot gets its heap reference
-    for (uint32_t half = 0; half < 2 && heap_fits; half++) {
-      uint64_t m = half ? m_new : m_old;
-      while (m) {
-        const uint32_t hr = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t r = half * maxh + hr;
-        const uint32_t w = lane < nt ? htab[r * cf + lane] : 0u;
-        const uint32_t kind = w >> 30;
-        if (kind != HK_NONE) {
-          const uint32_t pos = w & 0x1FFFFu;
-          uint32_t hcur = fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2);
-          uint32_t* const slotp = (uint32_t*)(img + hslot[r * cf + lane]);
-          slotp[0] = hcur;
-          if (kind != HK_COPY) {
-            const uint32_t len = __builtin_bswap32(ldu32(base + pos - 4));
-            uint32_t tmp[4] = {0, 0, 0, 0}, st = 0;
-            const uint32_t err = decode_text_cell<false>(kind == HK_NUMERIC ? (uint32_t)ETLG_TC_NUMERIC : (uint32_t)ETLG_TC_BYTEA, base + pos, len, tmp, pg.heap, hcur, st, true);
-            if (err) record_error(pg, f, RK_DECODE, err);
-            else slotp[1] = tmp[1];
-          }
-        }
-      }
-    }
-    // 'u' cells of the new row: alias the aligned old value, else MISSING (codec/event.rs:962-974)
+    u8* const body = pg.fixed + fx_off;
+    // 'u' cells of the new row: alias the aligned old value, else MISSING (codec/event.rs:962-974). The old row's slots were stored by
+    // other waves of this workgroup before the barriers above and are read back past the L1 (agent scope).
     uint32_t flags = (isrow && v.tag != 'I') ? old_kind : 0u;
     uint64_t toast = lane < cf ? ((uint64_t)fr_toast[0][lane] | ((uint64_t)fr_toast[1][lane] << 32)) : 0ull;
     if (emit && isrow && toast) {
       const DevSlot& s = p.slots[slot];
       const DevCol* cols = p.cols + s.cols_base;
-      u8* const body = img + (x_fx << 2);
       while (toast) {
         const uint32_t k = (uint32_t)__builtin_ctzll(toast);
         toast &= toast - 1;
@@ -592,29 +616,48 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         uint32_t* dst = (uint32_t*)(body + old_sz + col.off_full);
         const bool from_full = old_kind == ETLG_OLD_FULL, from_key = old_kind == ETLG_OLD_KEY && col.identity;
         uint32_t cst;
+        const uint32_t nw = slot_bytes(col.cls) >> 2;
         if (from_full || from_key) {
-          const uint32_t* src = (const uint32_t*)(body + (from_full ? col.off_full : col.off_key));
-          const uint32_t nw = slot_bytes(col.cls) >> 2;
-          for (uint32_t w = 0; w < nw; w++) dst[w] = src[w];
+          uint32_t* src = (uint32_t*)(body + (from_full ? col.off_full : col.off_key));
+          for (uint32_t w = 0; w < nw; w++) dst[w] = __hip_atomic_load(&src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint32_t oi = from_full ? k : (uint32_t)col.key_index;
-          cst = (((const uint32_t*)body)[oi >> 4] >> (2 * (oi & 15u))) & 3u;
+          cst = (sttab[(oi >> 4) * cf + lane] >> (2 * (oi & 15u))) & 3u;
+          // an aliased cell that lives on the heap: its reference is being patched into the OLD slot by one of the copying waves right
+          // now — the same value is computed here from the table instead of waiting for that store
+          const uint32_t ohr = from_full ? (col.hr & 0xFFu) : (uint32_t)(col.hr >> 8);
+          if (rows_heap_class(col.cls) && ohr != 0xFFu) {
+            const uint32_t hw = htab[ohr * cf + lane];
+            if ((hw >> 30) != HK_NONE) dst[0] = fr_hp[lane] + (((hw >> 17) & kRowsHeapMaxDw) << 2);
+          }
         } else {
+          for (uint32_t w = 0; w < nw; w++) dst[w] = 0;
           cst = (uint32_t)ETLG_CELL_MISSING;
           flags |= ETLG_FLAG_PARTIAL;
         }
-        if (cst) ((uint32_t*)(body + old_sz))[k >> 4] |= cst << (2 * (k & 15u));
+        if (cst) sttab[(SW + (k >> 4)) * cf + lane] |= cst << (2 * (k & 15u));
       }
     }
-    // event headers
+    // row state words, Begin / Commit bodies, event headers
     if (emit) {
       const uint32_t tag = v.tag;
       if (isrow || tag == 'B' || tag == 'C') {
         const u8* b = v.fr + kBodyOff;
         uint32_t table = rel_id, slot_id = 0;
         uint64_t commit_lsn = tx.final_lsn;
-        if (isrow) slot_id = p.slots[slot].host_id;
-        else if (tag == 'B') { commit_lsn = ld_be64(b); table = ld_be32(b + 16); }
-        else { flags = b[0]; commit_lsn = ld_be64(b + 1); table = 0; }
+        if (isrow) {
+          const DevSlot& s = p.slots[slot];
+          slot_id = s.host_id;
+          // the 2-bit states at the head of each row image: st_key / st_full bytes (4 per 16 columns)
+          const uint32_t so = old_kind == ETLG_OLD_NONE ? 0u : old_kind == ETLG_OLD_KEY ? s.st_key : s.st_full;
+          for (uint32_t w = 0; 4 * w < so && w < SW; w++) ((uint32_t*)body)[w] = sttab[w * cf + lane];
+          if (tag != 'D') for (uint32_t w = 0; 4 * w < s.st_full && w < SW; w++) ((uint32_t*)(body + old_sz))[w] = sttab[(SW + w) * cf + lane];
+        } else if (tag == 'B') {   // parse_event_from_begin_message, codec/event.rs:303-316
+          commit_lsn = ld_be64(b); table = ld_be32(b + 16);
+          st64((uint32_t*)body, ld_be64(b + 8));
+        } else {                   // parse_event_from_commit_message, codec/event.rs:322-336
+          flags = b[0]; commit_lsn = ld_be64(b + 1); table = 0;
+          st64((uint32_t*)body, ld_be64(b + 9)); st64((uint32_t*)body + 2, ld_be64(b + 17));
+        }
         pg.ev_kind[ev_idx] = (u8)tag;
         pg.ev_flags[ev_idx] = (u8)flags;
         pg.ev_table[ev_idx] = table;
@@ -624,27 +667,14 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         pg.ev_ord[ev_idx] = tx.ord;
         pg.ev_body[ev_idx] = fx_off;
       } else {
-        // Truncate / Relation events (rare): the generic writer, into the image
-        DecParams pl = p;
-        pl.fixed = img;
+        // Truncate / Relation events (rare): the generic writer
         RowMsg dummy{};
-        write_frame(pl, v, tx, dummy, -1, ev_idx, (uint64_t)x_fx << 2, 0, nullptr, true);
-        pg.ev_body[ev_idx] = fx_off;
+        write_frame(p, v, tx, dummy, -1, ev_idx, fx_off, 0, nullptr, true);
       }
     }
     ETLG_WAVE_PRIO(0);
   }
-  __threadfence_block();
-  __syncthreads();
   TSTAMP(6);
-  // ================= all waves: the image -> the fixed arena, one contiguous block
-  if (s32[1]) {
-    const uint32_t ndw = (uint32_t)s64[1];
-    uint32_t* out = (uint32_t*)(pg.fixed + pre_fx);
-    const uint32_t* in32 = (const uint32_t*)img;
-    for (uint32_t i = tid; i < ndw; i += NW * 64) out[i] = in32[i];
-  }
-  TSTAMP(7);
 }
 
 }  // namespace etlg
@@ -659,12 +689,19 @@ void etlg_k_launch_rows(const DecParams* p, const void* qv, hipStream_t s) {
 }
 
 int etlg_k_rows_set_lds(void) {
-  return hipFuncSetAttribute((const void*)k_rows<RNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) == hipSuccess ? 0 : 1;
+  return hipFuncSetAttribute((const void*)k_rows<RNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144) == hipSuccess ? 0 : 1;
 }
 
 // heap-cell table + cell positions next to the image and the window
-uint32_t etlg_k_rows_table_bytes(uint32_t maxh, uint32_t maxc, uint32_t cf) { return ((2u * maxh * cf * 6u + 15u) & ~15u) + ((2u * maxc * cf * 2u + 15u) & ~15u); }
-uint32_t etlg_k_rows_static_lds(void) { return 2816u; }   // the kernel's __shared__ arrays + slack
+uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc, uint32_t cf) {
+  return (((maxh_old + maxh) * cf * 6u + 15u) & ~15u) + ((2u * ((maxc + 15u) >> 4) * cf * 4u + 15u) & ~15u) + ((2u * maxc * cf * 2u + 15u) & ~15u);
+}
+uint32_t etlg_k_rows_static_lds(void) { return 4864u; }   // the kernel's __shared__ arrays + slack
+int etlg_k_rows_occupancy(uint32_t lds_bytes) {   // workgroups of k_rows that fit a CU with that much dynamic LDS (debugging aid)
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_rows<RNW>, RNW * 64, lds_bytes) != hipSuccess) return -1;
+  return n;
+}
 uint32_t etlg_k_rows_max_cols(void) { return 64u; }       // toast mask: one bit per column of the new image
 uint32_t etlg_k_rows_max_heap_cols(void) { return 64u; }  // rows per image of the heap-cell table (one 64-bit presence mask per image)
 

@@ -222,3 +222,4 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigne
 static inline hipError_t hipEventDestroy(hipEvent_t e) { simt::event_destroy((void*)e); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return hipSuccess; }

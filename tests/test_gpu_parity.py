@@ -498,6 +498,15 @@ def _temporal_texts():
     t += [(SC.TIMESTAMPTZ, x) for x in ["2023-1-01 1:2:3+02", "2023-01-01 12:30:45 +02", "2023-01-01 12:30:45\u00a0+02", "2023-12-31 23:59:60+00", "2023-12-31 23:59:60-05:30",
                                         "+262142-12-31 23:59:59-01", "-262143-01-01 00:00:00+01", "+262142-12-31 23:59:59+01", "2023-01-01 12:30:45.1234567890-15:59:59",
                                         "2023-01-01 12:30:45+", "2023-01-01 12:30:45", "0000-01-01 00:00:00+15:59:59", "2023-1-01 00:00:00+00:00:01"]]
+    # around the register-only fast path (iso_timestamp_swar / tz_hours_swar, codec.hip.h): every fraction length, a non-digit in every field,
+    # the range limits of every field, whole-hour offsets up to the 16-hour bound, the separators one by one
+    swar = ["2023-06-15 12:30:45"] + ["2023-06-15 12:30:45." + "123456789"[:k] for k in range(1, 10)] + ["2023-06-15 12:30:45." + "000000001"[:k] for k in (1, 5, 9)]
+    swar += ["2023-06-15 12:30:45.12345678x", "2023-06-15 12:30:45.x", "2023-06-15 12:30:45.1234x678", "2023-06-15 12:30:45.", "2023-06-15 12:30:45.1234567890"]
+    swar += ["2023-06-15 24:00:00", "2023-06-15 23:60:00", "2023-06-15 23:59:60", "2023-06-15 23:59:59.999999999", "2023-13-01 00:00:00", "2023-00-10 00:00:00",
+             "2023-02-29 00:00:00", "2024-02-29 00:00:00", "2023-04-31 00:00:00", "0000-01-01 00:00:00", "9999-12-31 23:59:59.999999"]
+    swar += ["2023-06-15 12:30:45"[:i] + ch + "2023-06-15 12:30:45"[i + 1:] for i in range(19) for ch in ("x", "/", "\u00e9")[:2]]
+    t += [(SC.TIMESTAMP, x) for x in swar]
+    t += [(SC.TIMESTAMPTZ, x + z) for x in swar[:24] for z in ("+00", "-00", "+15", "-15", "+16", "-16", "+1x", "+05:30", "-0530", "+9")]
     t += [(SC.TIMETZ, x) for x in ["1:2:3+02", "12:30:00 +02", "12:30:00\u2003+02", " 12:30:00+02", "23:59:60+00", "12:30:00.1234567890+02", "12:30:00.+02", "12:30+02", "+02",
                                    "12:30:00+02 ", "12-30-00"]]
     return t
