@@ -236,11 +236,14 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   TSTAMP(1);
   // the two look-backs whose aggregates are known from the heads alone run beside the walk
   if (role == 1 % NW && NW > 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
-  if (role == 2 % NW && NW > 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
+  // (the transaction fold only: what it needs of the state carried into the batch is fetched at the very end of the tile — H — because
+  // with ETLG_F_ASYNC on two streams that state may have to be waited for, and a tile that waits before it has published its event /
+  // heap aggregate would stall every tile behind it while the batch before still needs their CU slots)
+  if (role == 2 % NW && NW > 2) { const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], 0ull, fail); if (lane == 0) s64[10] = ex; }
 
   if (spine) {
     if (NW == 1) { const uint64_t b = lookback<OpAdd>(q.d_outb, q.d_outb + q.ntiles, tile, s64[1], 0, fail); if (lane == 0) s64[5] = b; }
-    if (NW <= 2) txn_lookback(pg, q.d_txn, q.ntiles, tile, s64[2], fail, s32, s64);
+    if (NW <= 2) { const uint64_t ex = lookback<OpTxn>(q.d_txn, q.d_txn + q.ntiles, tile, s64[2], 0ull, fail); if (lane == 0) s64[10] = ex; }
     // ================= W (spine): the structural walk
     ETLG_WAVE_PRIO(3);
     // `lim` cells of image `vimg` (0 old / key, 1 new) for every lane that is still going: 'n' | 'u' | ('t' | 'b') i32 len bytes.
@@ -467,6 +470,9 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     { const uint32_t why = wave_last(wave_scan_incl(gave, [](uint32_t a, uint32_t b) { return a | b; }, 0u)); if (why && lane == 0) atomicOr(fail, kRowsGaveUp | why); }   // bits 8..: why (debugging aid)
     const uint32_t ie = wave_scan_add(emit), ih = wave_scan_add(heap >> 2);
     const uint32_t tot_e = wave_last(ie), tot_h = wave_last(ih);
+    x_ev = ie - emit; x_hp = ih - (heap >> 2);
+    const uint64_t agg = ((uint64_t)tot_e << 32) | tot_h;
+    lookback_publish(q.d_outa, tile, agg);   // (at once: the tiles behind this one wait for it; the payload counters come after)
     const uint32_t a0p = wave_last(wave_scan_add((uint32_t)pay[0])), a1p = wave_last(wave_scan_add((uint32_t)pay[1])),
                    a2p = wave_last(wave_scan_add((uint32_t)pay[2]));
     if (lane == 0) {
@@ -474,9 +480,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
       if (a1p) atomicAdd(&pg.res->pay_shard[tile & 31][1], (unsigned long long)a1p);
       if (a2p) atomicAdd(&pg.res->pay_shard[tile & 31][2], (unsigned long long)a2p);
     }
-    x_ev = ie - emit; x_hp = ih - (heap >> 2);
-    const uint64_t agg = ((uint64_t)tot_e << 32) | tot_h;
-    const uint64_t a = lookback<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg, 0, fail);
+    const uint64_t a = lookback_resolve<OpAdd2>(q.d_outa, q.d_outa + q.ntiles, tile, agg, 0, fail);
     const uint64_t pre_hp = (uint64_t)(uint32_t)a << 2;
     const bool hf = pre_hp + ((uint64_t)tot_h << 2) <= pg.heap_cap && pre_hp + ((uint64_t)tot_h << 2) <= 0xFFFFFFFFull;
     if (lane < cf) fr_hp[lane] = (uint32_t)(pre_hp + ((uint64_t)x_hp << 2));
@@ -575,7 +579,28 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     // ================= H (spine): transaction context, numerics / bytea, heap references, toast, event headers
     ETLG_WAVE_PRIO(3);
     {
-      const TxnStart ts{s32[12], s32[13], s64[6], s64[3]};
+      // the second half of txn_lookback (lookback.hip.h): the state carried into the batch is not part of the fold; only a tile whose
+      // prefix needs it reads it, and with DecParams.flags bit 4 (the batch before may still be running on the other decode stream)
+      // waits for that batch's last tile first
+      const uint64_t ex = s64[10];
+      TxnStart ts;
+      ts.seg = seg_unpack30((uint32_t)(ex >> 32));
+      ts.mark = (uint32_t)ex;
+      uint32_t c_in_txn = pg.in_txn;
+      uint64_t c_final_lsn = pg.final_lsn;
+      ts.ord = pg.next_ord;
+      if ((pg.flags & 16u) && pg.carry && (ts.mark == 0u || !(ts.seg & 0x80000000u))) {   // wave-uniform
+        for (uint32_t polls = 0;; polls++) {
+          if (__hip_atomic_load(&pg.carry->carry_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
+          if (polls > (1u << 15)) { if (lane == 0) atomicOr(fail, 1u); break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        c_in_txn = __hip_atomic_load(&pg.carry->out_in_txn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c_final_lsn = __hip_atomic_load(&pg.carry->out_final_lsn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ts.ord = __hip_atomic_load(&pg.carry->out_next_ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (ts.mark == 0u && c_in_txn) ts.mark = 1u;   // virtual Begin before frame 0
+      ts.lsn = (ts.mark & 1u) ? (ts.mark == 1u ? c_final_lsn : ld_be64(pg.in + ((ts.mark >> 1) - 1) + kBodyOff)) : 0ull;
       bc = ts.seg; bm = ts.mark; carried_lsn = ts.lsn; start_ord = ts.ord;
       const uint32_t seg = seg_combine(bc, seg_in);
       const uint32_t last = bm > pm ? bm : pm;

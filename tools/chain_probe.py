@@ -18,7 +18,7 @@ FL = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
 rows = []
 for v in variants:
     name, _, envs = v.partition(":")
-    for k in ("ETLG_OVERLAP", "ETLG_FUSED_KERNEL", "ETLG_PLAN"):
+    for k in ("ETLG_OVERLAP", "ETLG_FUSED_KERNEL", "ETLG_PLAN", "ETLG_ROWS"):
         os.environ.pop(k, None)
     for kv in filter(None, envs.split(",")):
         a, b = kv.split("=")
@@ -40,7 +40,7 @@ for v in variants:
     for rep in range(3):
         t0 = time.perf_counter(); run(120); torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / 120)
-    row = {"workload": wl, "variant": name, "env": envs, "us_per_batch": round(best * 1e6, 1), "GBps": round((64 << 20) / best / 1e9, 1), "paths": d.debug_paths(), "overlapped": d.debug_overlapped()}
+    row = {"workload": wl, "variant": name, "env": envs, "us_per_batch": round(best * 1e6, 1), "GBps": round((64 << 20) / best / 1e9, 1), "paths": {**d.debug_paths(), **d.debug_rows()}, "overlapped": d.debug_overlapped()}
     print(json.dumps(row), flush=True)
     rows.append(row)
     d.close()
