@@ -39,7 +39,6 @@ namespace etlg {
 constexpr int RNW = 4;          // waves per tile
 constexpr uint32_t kRowsGaveUp = 16u;
 constexpr uint32_t kRowsMaxGroups = 16;
-constexpr uint32_t kRowsMaxTasks = 96;
 // heap-cell table entry: window position of the text (17 bits) | heap dwords of the cell, later its heap offset inside the frame (13 bits) | kind (2 bits)
 enum : uint32_t { HK_NONE = 0, HK_COPY = 1, HK_NUMERIC = 2, HK_BYTEA = 3 };
 constexpr uint32_t kRowsHeapMaxDw = 0x1FFFu;
@@ -61,10 +60,10 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   __shared__ uint32_t fr_base[64];    // window offset of the frame's first byte
   __shared__ uint32_t fr_row[64];     // the frame's body inside the tile's piece of the fixed arena, bytes
   __shared__ uint32_t fr_osz[64];     // bytes of its old / key row
-  __shared__ uint4 tasks[kRowsMaxTasks];   // {cell index | group << 8 | image shape << 12 | new image << 14, the column's DevCol record}: heavy classes first inside a group
+  __shared__ uint32_t row_next[128];       // ... and the next unclaimed step (chunk index) of every row
+  __shared__ uint32_t row_chunks[128];     // 16-byte chunks of text to copy per row of the heap-cell table (D adds them up, C deals the rows out by them)
   __shared__ uint8_t own_mark[NW][64];     // text copy: which cell starts at a chunk position of the current step
   __shared__ uint32_t fr_flags[64];   // bit 0: a cell failed to decode; bit 1: the frame is an Update; bit 2: beyond what the kernel covers
-  __shared__ uint32_t fr_toast[2][64];   // new-image columns sent as 'u'
   __shared__ uint32_t g_slot[kRowsMaxGroups], g_info[kRowsMaxGroups], g_cb[kRowsMaxGroups], g_task0[kRowsMaxGroups];
   __shared__ uint64_t g_mem[kRowsMaxGroups];
   __shared__ uint32_t s32[16];
@@ -89,23 +88,29 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   // rows of the heap-cell table: the heap-class columns a key / old image can hold (identity columns), then those of a full row
   const uint32_t maxh = q.rows_maxh, maxh_old = q.rows_maxh_old, R = maxh_old + maxh;
   // dynamic LDS: side tables | heap-cell table (u32 [R][cf]) | its slots (u16 [R][cf]: dword offsets inside the tile's piece of the fixed arena)
-  //              | 2-bit cell states (u32 [2 SW][cf]: one word per 16 columns and image) | cell positions (u16 [2 maxc][cf]) | staging window
+  //              | 2-bit cell states (u32 [2 SW][cf]: one word per 16 columns and image) | toast masks | cell positions (u16 [2 maxc][cf]) | task list | staging window
   const uint32_t SW = (maxc + 15u) >> 4;
   uint32_t* const htab = (uint32_t*)(smem + q.side_bytes);
   uint16_t* const hslot = (uint16_t*)(htab + R * cf);
   const uint32_t htab_bytes = (R * cf * 6u + 15u) & ~15u;
   uint32_t* const sttab = (uint32_t*)((u8*)htab + htab_bytes);
   const uint32_t st_bytes = (2u * SW * cf * 4u + 15u) & ~15u;
-  uint16_t* const ctab = (uint16_t*)((u8*)sttab + st_bytes);
+  const uint32_t TW = (maxc + 31u) >> 5;
+  uint32_t* const toast = (uint32_t*)((u8*)sttab + st_bytes);   // new-image columns sent as 'u': u32 [TW][cf]
+  const uint32_t toast_bytes = (TW * cf * 4u + 15u) & ~15u;
+  uint16_t* const ctab = (uint16_t*)((u8*)toast + toast_bytes);
   const uint32_t ctab_bytes = (2u * maxc * cf * 2u + 15u) & ~15u;
-  u8* const stage = (u8*)ctab + ctab_bytes;
+  // the task list: {cell index | group << 8 | image shape << 12 | new image << 14, the column's DevCol record}, heavy classes first inside a group
+  uint4* const tasks = (uint4*)((u8*)ctab + ctab_bytes);
+  const uint32_t max_tasks = 4u * maxc + 32u;   // (a tile usually holds one or two groups; one that needs more tasks is handed back)
+  u8* const stage = (u8*)tasks + max_tasks * 16u;
   const uint32_t f0 = tile * cf;
   const uint32_t nt = pg.nframes - f0 < cf ? pg.nframes - f0 : cf;
   const ETLG_CONST_AS uint32_t* offs_c = (const ETLG_CONST_AS uint32_t*)(uintptr_t)pg.offs;
   const uint32_t span0 = offs_c[f0], span1 = offs_c[f0 + nt];
   const uint32_t my_o = tid <= nt ? pg.offs[f0 + tid] : 0u;
   const uint32_t a0 = span0 & ~15u;
-  const uint32_t used = q.side_bytes + htab_bytes + st_bytes + ctab_bytes;
+  const uint32_t used = q.side_bytes + htab_bytes + st_bytes + toast_bytes + ctab_bytes + max_tasks * 16u;
   const uint32_t wcap = q.lds_bytes > used ? q.lds_bytes - used : 0u;
   const bool window_ok = q.in_aligned && span1 > span0 && span1 <= pg.in_len && span1 - a0 + 16 <= (1u << 17) && (uint64_t)(span1 - a0) + 16 <= wcap;
   if (window_ok) {
@@ -115,12 +120,13 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   }
   side_store<NW * 64>((uint32_t*)smem, tid, side);
   if (tid <= nt) s_offs[tid] = my_o;
-  {  // the heap-cell table starts empty, the cell states as VALUE
+  {  // the heap-cell table starts empty, the cell states as VALUE, no cell as toast
     uint4* z = (uint4*)htab;
-    const uint32_t n16 = (htab_bytes + st_bytes) >> 4;
+    const uint32_t n16 = (htab_bytes + st_bytes + toast_bytes) >> 4;
     for (uint32_t i = tid; i < n16; i += NW * 64) z[i] = make_uint4(0, 0, 0, 0);
   }
-  if (tid < 64) { fr_toast[0][tid] = 0; fr_toast[1][tid] = 0; fr_flags[tid] = 0; }
+  if (tid < 64) fr_flags[tid] = 0;
+  if (tid < 128) { row_chunks[tid] = 0; row_next[tid] = 0; }
   if (tid == 0) { s64[8] = 0; s64[9] = 0; s32[2] = 0; s32[3] = 0; s32[4] = 0; }
   __syncthreads();
   TSTAMP(0);
@@ -249,20 +255,27 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     // `lim` cells of image `vimg` (0 old / key, 1 new) for every lane that is still going: 'n' | 'u' | ('t' | 'b') i32 len bytes.
     // One step per cell index, no data-dependent branches; a lane that meets a malformed cell stops (ok = 0).
     auto walk_cells = [&](uint32_t lim, uint32_t vimg) {
+      // (integer flags and one table lookup for the four cell tags: as predicates every test lived in a lane-mask register pair and the
+      // loop spent a third of its instructions combining those)
+      constexpr uint32_t kValid = (1u << ('b' - 'b')) | (1u << ('n' - 'b')) | (1u << ('t' - 'b')) | (1u << ('u' - 'b'));
+      constexpr uint32_t kValue = (1u << ('b' - 'b')) | (1u << ('t' - 'b'));
+      uint16_t* const row0 = ctab + vimg * maxc * cf + lane;
+      const uint32_t lim_k = lim < maxc ? lim : maxc;   // cells beyond the widest slot are walked, not noted (their frame decodes against no slot)
       for (uint32_t k = 0;; k++) {
-        const bool act = (k < lim) & (ok != 0);
-        if (!__ballot(act)) break;
+        const uint32_t act = (k < lim) ? ok : 0u;
+        if (!__ballot(act != 0)) break;
         const uint64_t head = ldu64(base + c);  // the window has 16 spare bytes past any frame
-        const uint32_t t = (uint32_t)head & 0xFFu;
+        const uint32_t ti = ((uint32_t)head & 0xFFu) - 'b';
+        const uint32_t sh5 = ti < 32u ? ti : 31u;
+        const uint32_t valid = (kValid >> sh5) & (ti < 32u ? 1u : 0u), is_val = (kValue >> sh5) & valid;
+        const uint32_t len = __builtin_bswap32((uint32_t)(head >> 8)) & (0u - is_val);
         const uint32_t room = e - c;
-        const bool is_val = (t == 't') | (t == 'b');
-        const uint32_t len = is_val ? __builtin_bswap32((uint32_t)(head >> 8)) : 0u;
-        const bool cell_ok = (room >= 1) & (is_val | (t == 'n') | (t == 'u')) & (!is_val | ((room >= 5) & (len <= room - 5)));
-        const bool go = act & cell_ok;
-        if (go & (k < maxc)) ctab[(vimg * maxc + k) * cf + lane] = (uint16_t)(c - fb);
-        ok = (act & !cell_ok) ? 0u : ok;
-        vbytes += go ? len : 0u;
-        c += go ? (is_val ? 5u + len : 1u) : 0u;
+        const uint32_t need = 1u + (is_val << 2) + len;                       // the bytes the cell takes
+        const uint32_t go = (valid & act & (len <= room ? 1u : 0u)) & (need <= room ? 1u : 0u);   // (len first: need may wrap for a length near 2^32)
+        if (go && k < lim_k) row0[k * cf] = (uint16_t)(c - fb);
+        ok = act & (go ^ 1u) ? 0u : ok;
+        vbytes += len & (0u - go);
+        c += need & (0u - go);
       }
     };
     walk_cells(old_kind != ETLG_OLD_NONE ? n_old : 0u, 0u);
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     // the task list: inside every group the heavy classes first (temporal / uuid / numeric / float), so that the waves pulling from it finish
     // close to each other
     uint32_t nq = 0;
-    if (ntasks > kRowsMaxTasks) { gave = 0x1000; ng = 0; }
+    if (ntasks > max_tasks) { gave = 0x1000; ng = 0; }
     for (uint32_t g = 0; g < ng; g++) {
       const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_info[g]);
       const uint32_t cb_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_cb[g]);
@@ -375,6 +388,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
       const uint32_t pos = pos0 + 5;
       uint32_t st = ETLG_CELL_VALUE, bad = 0;
       bool entry = false;
+      uint32_t cchunks = 0;   // 16-byte chunks of text the copy phase will move for this cell
       if (on && t == 't') {
         const u8* d = base + pos;
         if (rows_heap_class(cls)) {
@@ -404,6 +418,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
               hslot[r * cf + lane] = (uint16_t)(soff >> 2);
               slotp[1] = nbytes;
               entry = true;
+              if (kind == HK_COPY) cchunks = (len + 15u) >> 4;
             }
           }
         } else {
@@ -424,14 +439,18 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         else slot_zero(slotp, cls);
         st = ETLG_CELL_NULL;
       } else if (on && t == 'u') {
-        if (img1 && my_upd) { atomicOr(&fr_toast[k >> 5][lane], 1u << (k & 31u)); }   // resolved once the old image's heap references are final
+        if (img1 && my_upd) { atomicOr(&toast[(k >> 5) * cf + lane], 1u << (k & 31u)); }   // resolved once the old image's heap references are final
         else bad = 1;              // a full row / key image cannot miss a value
       } else if (on) {
         bad = 1;                   // binary format
       }
       if (on && st && !bad) atomicOr(&sttab[((img1 ? SW : 0u) + (kout >> 4)) * cf + lane], st << (2 * (kout & 15u)));
       if (bad) atomicOr(&fr_flags[lane], bad);
-      if (__ballot(entry) && lane == 0) atomicOr((unsigned long long*)&s64[img1 ? 9 : 8], 1ull << hr);
+      if (__ballot(entry)) {
+        // (wave-uniform: some lane of the group left an entry) the row is marked present and its text chunks are added up
+        const uint32_t tot = wave_last(wave_scan_add(cchunks));
+        if (lane == 0) { atomicOr((unsigned long long*)&s64[img1 ? 9 : 8], 1ull << hr); if (tot) atomicAdd(&row_chunks[(img1 ? maxh_old : 0u) + hr], tot); }
+      }
     }
   }
   __syncthreads();
@@ -493,89 +512,7 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   const bool heap_fits = s32[0] != 0;
   const uint64_t m_old = s64[8], m_new = s64[9];
 
-  if (!spine) {
-    // ================= C (the other waves): text of String / deferred cells -> heap, 16 bytes per lane and step
-    const uint32_t cw_rank = role - 1, ncw = NW - 1;
-    const bool cclk = (dbg_u & 8) && role == 1 && lane == 0 && (blockIdx.x & 15) == 3;
-    const unsigned long long c_t0 = cclk ? clock64() : 0ull;
-    for (uint32_t half = 0; half < 2 && heap_fits && fixed_fits; half++) {
-      uint64_t m = half ? m_new : m_old;
-      for (uint32_t ri = 0; m; ri++) {
-        const uint32_t hr = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t r = (half ? maxh_old : 0u) + hr;
-        const uint32_t w = lane < nt ? htab[r * cf + lane] : 0u;
-        const uint32_t kind = w >> 30;
-        const bool act = kind == HK_COPY;
-        const uint32_t pos = w & 0x1FFFFu;
-        const uint32_t len = kind != HK_NONE ? __builtin_bswap32(ldu32(base + pos - 4)) : 0u;
-        const uint32_t dst = kind != HK_NONE ? fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2) : 0u;
-        // one of the copying waves per row: every heap cell's slot gets its heap reference; numerics / bytea are emitted at their final place
-        if (ri % ncw == cw_rank && kind != HK_NONE) {
-          uint32_t* const slotp = (uint32_t*)(pg.fixed + pre_fx + ((uint32_t)hslot[r * cf + lane] << 2));
-          slotp[0] = dst;
-          if (kind != HK_COPY) {
-            uint32_t tmp[4] = {0, 0, 0, 0}, st = 0, hcur = dst;
-            const uint32_t err = decode_text_cell<false>(kind == HK_NUMERIC ? (uint32_t)ETLG_TC_NUMERIC : (uint32_t)ETLG_TC_BYTEA, base + pos, len, tmp, pg.heap, hcur, st, true);
-            if (err) record_error(pg, f0 + lane, RK_DECODE, err);
-            else slotp[1] = tmp[1];
-          }
-        }
-        const uint32_t clen = act ? len : 0u;
-        const uint32_t nch = (clen + 15u) >> 4;
-        const uint32_t incl = wave_scan_add(nch);
-        const uint32_t T = wave_last(incl);
-        const uint32_t excl = incl - nch;
-        volatile uint8_t* const marks = own_mark[tid >> 6];
-        for (uint32_t t0 = cw_rank * 64u; t0 < T; t0 += ncw * 64u) {
-          const uint32_t x = t0 + lane;
-          // The chunk's cell. Cells lie in lane order, so the cell of chunk x is the last one that starts at or before x: every cell whose
-          // first chunk falls into this step leaves its lane number at that position of a 64-byte scratch row, the cell still going when
-          // the step begins comes in at position 0, and a running maximum over the positions (DPP) spreads the owners. One LDS round trip
-          // and a scan instead of a six-step binary search through ds_bpermute (six dependent round trips).
-          marks[lane] = 0;
-          ETLG_WAVE_JOIN();
-          const uint32_t s_i = excl - t0;
-          if (nch != 0 && s_i < 64u) marks[s_i] = (uint8_t)(lane + 1u);
-          const unsigned long long before = __ballot(nch != 0 && excl < t0);
-          const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
-          uint32_t mk = marks[lane];
-          if (lane == 0 && mk == 0) mk = carry;
-          const uint32_t own1 = wave_scan_max(mk);
-          const uint32_t owner = own1 ? own1 - 1u : 0u;
-          const uint32_t o_pos = (uint32_t)__shfl((int)pos, (int)owner, 64), o_len = (uint32_t)__shfl((int)clen, (int)owner, 64);
-          const uint32_t o_dst = (uint32_t)__shfl((int)dst, (int)owner, 64), o_excl = (uint32_t)__shfl((int)excl, (int)owner, 64);
-          if (x < T) {
-            const uint32_t boff = (x - o_excl) << 4;
-            const uint32_t rem = o_len - boff;                 // >= 1
-            const u8* src = base + o_pos + boff;
-            const uint32_t sh = (uint32_t)(uintptr_t)src & 3u;
-            const uint32_t* qd = (const uint32_t*)(src - sh);
-            const uint32_t need = sh + (rem < 16u ? rem : 16u);   // bytes from qd[0] on
-            uint32_t wv[5];
-#pragma unroll
-            for (uint32_t j = 0; j < 5; j++) wv[j] = 4 * j < need ? qd[j] : 0u;
-            uint32_t prev = boff ? __builtin_amdgcn_alignbyte(qd[0], qd[-1], sh) : 0u;
-            uint32_t* out = (uint32_t*)(pg.heap + o_dst + boff);
-            bool bad = false;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-              if (4 * j < rem) {
-                const uint32_t rj = rem - 4 * j;
-                uint32_t xw = __builtin_amdgcn_alignbyte(wv[j + 1], wv[j], sh);
-                if (rj < 4) xw &= (1u << (8 * rj)) - 1u;
-                out[j] = xw;
-                if ((xw | prev) & 0x80808080u) bad |= utf8_dword_bad(prev, xw, rj == 4);
-                prev = xw;
-              }
-            }
-            if (bad) record_error(pg, f0 + owner, RK_DECODE, ETLG_E_UTF8);
-          }
-        }
-      }
-    }
-    if (cclk) atomicAdd(&pg.res->dbg_t[8], clock64() - c_t0);   // (phase clocks: the text copy as one of its waves sees it)
-  } else {
+  if (spine) {
     // ================= H (spine): transaction context, numerics / bytea, heap references, toast, event headers
     ETLG_WAVE_PRIO(3);
     {
@@ -630,13 +567,14 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     // 'u' cells of the new row: alias the aligned old value, else MISSING (codec/event.rs:962-974). The old row's slots were stored by
     // other waves of this workgroup before the barriers above and are read back past the L1 (agent scope).
     uint32_t flags = (isrow && v.tag != 'I') ? old_kind : 0u;
-    uint64_t toast = lane < cf ? ((uint64_t)fr_toast[0][lane] | ((uint64_t)fr_toast[1][lane] << 32)) : 0ull;
-    if (emit && isrow && toast) {
+    for (uint32_t tw = 0; tw < TW; tw++) {
+      uint32_t tbits = (emit && isrow && lane < cf) ? toast[tw * cf + lane] : 0u;
+      if (!tbits) continue;
       const DevSlot& s = p.slots[slot];
       const DevCol* cols = p.cols + s.cols_base;
-      while (toast) {
-        const uint32_t k = (uint32_t)__builtin_ctzll(toast);
-        toast &= toast - 1;
+      while (tbits) {
+        const uint32_t k = tw * 32u + (uint32_t)__builtin_ctz(tbits);
+        tbits &= tbits - 1;
         const DevCol col = cols[k];
         uint32_t* dst = (uint32_t*)(body + old_sz + col.off_full);
         const bool from_full = old_kind == ETLG_OLD_FULL, from_key = old_kind == ETLG_OLD_KEY && col.identity;
@@ -699,6 +637,105 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     }
     ETLG_WAVE_PRIO(0);
   }
+  TSTAMP(10);
+  {
+    // ================= C (all waves; the spine joins when H is done): text of String / deferred cells -> heap, 16 bytes per lane and step.
+    // Work is claimed, not dealt out: a row with little text whole (the first wave to ask gets it, references and all), a long row step by
+    // step — so the waves finish together whenever they arrive.
+    const bool cclk = (dbg_u & 8) && role == 1 && lane == 0 && (blockIdx.x & 15) == 3;
+    const unsigned long long c_t0 = cclk ? clock64() : 0ull;
+    for (uint32_t half = 0; half < 2 && heap_fits && fixed_fits; half++) {
+      uint64_t m = half ? m_new : m_old;
+      while (m) {
+        const uint32_t hr = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t r = (half ? maxh_old : 0u) + hr;
+        // a row with little text (two steps' worth or less) is one wave's from the references to the last byte; a long one is split by steps
+        const uint32_t Trow = row_chunks[r];
+        const bool solo = Trow <= 128u;
+        if (!solo && (uint32_t)__builtin_amdgcn_readfirstlane((int)row_next[r]) >= Trow) continue;   // (every step of it has been claimed; one lane's reading for the whole wave)
+        if (solo) {
+          uint32_t cl = 0;
+          if (lane == 0) cl = atomicAdd(&row_next[r], 1u);
+          if (__builtin_amdgcn_readfirstlane((int)cl) != 0) continue;
+        }
+        const uint32_t w = lane < nt ? htab[r * cf + lane] : 0u;
+        const uint32_t kind = w >> 30;
+        const bool act = kind == HK_COPY;
+        const uint32_t pos = w & 0x1FFFFu;
+        const uint32_t len = kind != HK_NONE ? __builtin_bswap32(ldu32(base + pos - 4)) : 0u;
+        const uint32_t dst = kind != HK_NONE ? fr_hp[lane] + (((w >> 17) & kRowsHeapMaxDw) << 2) : 0u;
+        // one wave per row (the owner of a short row, the claimant of a long row's first step): every heap cell's slot gets its heap
+        // reference; numerics / bytea are emitted at their final place
+        uint32_t t0 = 0;
+        if (!solo) { uint32_t cl = 0; if (lane == 0) cl = atomicAdd(&row_next[r], 64u); t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl); }
+        if (t0 == 0 && kind != HK_NONE) {
+          uint32_t* const slotp = (uint32_t*)(pg.fixed + pre_fx + ((uint32_t)hslot[r * cf + lane] << 2));
+          slotp[0] = dst;
+          if (kind != HK_COPY) {
+            uint32_t tmp[4] = {0, 0, 0, 0}, st = 0, hcur = dst;
+            const uint32_t err = decode_text_cell<false>(kind == HK_NUMERIC ? (uint32_t)ETLG_TC_NUMERIC : (uint32_t)ETLG_TC_BYTEA, base + pos, len, tmp, pg.heap, hcur, st, true);
+            if (err) record_error(pg, f0 + lane, RK_DECODE, err);
+            else slotp[1] = tmp[1];
+          }
+        }
+        const uint32_t clen = act ? len : 0u;
+        const uint32_t nch = (clen + 15u) >> 4;
+        const uint32_t incl = wave_scan_add(nch);
+        const uint32_t T = wave_last(incl);
+        const uint32_t excl = incl - nch;
+        volatile uint8_t* const marks = own_mark[tid >> 6];
+        for (; t0 < T;) {
+          const uint32_t x = t0 + lane;
+          // The chunk's cell. Cells lie in lane order, so the cell of chunk x is the last one that starts at or before x: every cell whose
+          // first chunk falls into this step leaves its lane number at that position of a 64-byte scratch row, the cell still going when
+          // the step begins comes in at position 0, and a running maximum over the positions (DPP) spreads the owners. One LDS round trip
+          // and a scan instead of a six-step binary search through ds_bpermute (six dependent round trips).
+          marks[lane] = 0;
+          ETLG_WAVE_JOIN();
+          const uint32_t s_i = excl - t0;
+          if (nch != 0 && s_i < 64u) marks[s_i] = (uint8_t)(lane + 1u);
+          const unsigned long long before = __ballot(nch != 0 && excl < t0);
+          const uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+          uint32_t mk = marks[lane];
+          if (lane == 0 && mk == 0) mk = carry;
+          const uint32_t own1 = wave_scan_max(mk);
+          const uint32_t owner = own1 ? own1 - 1u : 0u;
+          const uint32_t o_pos = (uint32_t)__shfl((int)pos, (int)owner, 64), o_len = (uint32_t)__shfl((int)clen, (int)owner, 64);
+          const uint32_t o_dst = (uint32_t)__shfl((int)dst, (int)owner, 64), o_excl = (uint32_t)__shfl((int)excl, (int)owner, 64);
+          if (x < T) {
+            const uint32_t boff = (x - o_excl) << 4;
+            const uint32_t rem = o_len - boff;                 // >= 1
+            const u8* src = base + o_pos + boff;
+            const uint32_t sh = (uint32_t)(uintptr_t)src & 3u;
+            const uint32_t* qd = (const uint32_t*)(src - sh);
+            const uint32_t need = sh + (rem < 16u ? rem : 16u);   // bytes from qd[0] on
+            uint32_t wv[5];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; j++) wv[j] = 4 * j < need ? qd[j] : 0u;
+            uint32_t prev = boff ? __builtin_amdgcn_alignbyte(qd[0], qd[-1], sh) : 0u;
+            uint32_t* out = (uint32_t*)(pg.heap + o_dst + boff);
+            bool bad = false;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+              if (4 * j < rem) {
+                const uint32_t rj = rem - 4 * j;
+                uint32_t xw = __builtin_amdgcn_alignbyte(wv[j + 1], wv[j], sh);
+                if (rj < 4) xw &= (1u << (8 * rj)) - 1u;
+                out[j] = xw;
+                if ((xw | prev) & 0x80808080u) bad |= utf8_dword_bad(prev, xw, rj == 4);
+                prev = xw;
+              }
+            }
+            if (bad) record_error(pg, f0 + owner, RK_DECODE, ETLG_E_UTF8);
+          }
+          if (solo) t0 += 64u;
+          else { uint32_t cl = 0; if (lane == 0) cl = atomicAdd(&row_next[r], 64u); t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl); }
+        }
+      }
+    }
+    if (cclk) atomicAdd(&pg.res->dbg_t[8], clock64() - c_t0);   // (phase clocks: the text copy as one of its waves sees it)
+  }
   TSTAMP(6);
 }
 
@@ -719,15 +756,16 @@ int etlg_k_rows_set_lds(void) {
 
 // heap-cell table + cell positions next to the image and the window
 uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc, uint32_t cf) {
-  return (((maxh_old + maxh) * cf * 6u + 15u) & ~15u) + ((2u * ((maxc + 15u) >> 4) * cf * 4u + 15u) & ~15u) + ((2u * maxc * cf * 2u + 15u) & ~15u);
+  return (((maxh_old + maxh) * cf * 6u + 15u) & ~15u) + ((2u * ((maxc + 15u) >> 4) * cf * 4u + 15u) & ~15u) + ((((maxc + 31u) >> 5) * cf * 4u + 15u) & ~15u) +
+         ((2u * maxc * cf * 2u + 15u) & ~15u) + (4u * maxc + 32u) * 16u;
 }
-uint32_t etlg_k_rows_static_lds(void) { return 4864u; }   // the kernel's __shared__ arrays + slack
+uint32_t etlg_k_rows_static_lds(void) { return 3840u; }   // the kernel's __shared__ arrays + slack
 int etlg_k_rows_occupancy(uint32_t lds_bytes) {   // workgroups of k_rows that fit a CU with that much dynamic LDS (debugging aid)
   int n = -1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_rows<RNW>, RNW * 64, lds_bytes) != hipSuccess) return -1;
   return n;
 }
-uint32_t etlg_k_rows_max_cols(void) { return 64u; }       // toast mask: one bit per column of the new image
+uint32_t etlg_k_rows_max_cols(void) { return 128u; }      // (a task names its cell index in 8 bits, a cell position its frame offset in 16)
 uint32_t etlg_k_rows_max_heap_cols(void) { return 64u; }  // rows per image of the heap-cell table (one 64-bit presence mask per image)
 
 }  // extern "C"

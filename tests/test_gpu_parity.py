@@ -120,11 +120,38 @@ def test_full_size_parity(mk):
     assert n["redone"] == 0 and n["multipass"] == 0, n
 
 
+def test_type_matrix_table_without_k_rows():
+    """... and the same table with the row-synchronous kernel switched off: k_fused / 64, byte for byte, without a redo."""
+    import os
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    saved = os.environ.get("ETLG_ROWS")
+    os.environ["ETLG_ROWS"] = "0"
+    try:
+        buf, offs = synth.type_matrix_stream(600, mix=True)
+        o, d = oracle.Oracle(), Decoder(0)
+        synth.type_matrix_register(o)
+        synth.type_matrix_register(d)
+        rb, gb = o.decode(buf, offs), d.decode(buf, offs, flags=abi.F_NO_CONTROL)
+        assert rb.err_code == 0 and gb.rc == 0, (rb.err_code, gb.rc, gb.error)
+        diff = rb.host_batch().diff(gb.host())
+        assert not diff, diff[:6]
+        n = d.debug_paths()
+        n.update(d.debug_rows())
+        d.close()
+        assert n["fused"] == 1 and n["rows"] == 0 and n["redone"] == 0 and n["multipass"] == 0, n
+    finally:
+        if saved is None:
+            os.environ.pop("ETLG_ROWS", None)
+        else:
+            os.environ["ETLG_ROWS"] = saved
+
+
 @pytest.mark.parametrize("mix", [False, True])
 def test_type_matrix_table_of_68_columns(mix):
     """The reference's own type-matrix table (crates/etl/tests/replication_stream.rs:184-268, the row of :303-400): 68 replicated
     columns — one of every type the parser has an arm for, every array form, the types it hands on as text. Wider than k_cells' 32-column
-    masks: the batch must be decoded by k_fused / 64 (no limit on the column count), byte for byte like the oracle, without a redo;
+    masks: the batch must be decoded by k_rows (and, with ETLG_ROWS=0, by k_fused / 64: no limit on the column count), byte for byte like the oracle, without a redo;
     inserts only, and with key-image updates and key deletes mixed in. Arrays and json stay DEFERRED source text in the arena (§4)
     and the columnar hand-off parses every array class of the row on the device."""
     from etl_amd.decoder import Decoder
@@ -143,7 +170,9 @@ def test_type_matrix_table_of_68_columns(mix):
     row = [e for e in ev if e["kind"] == "I"][0]["row"]
     assert len(row) == 68 and row[7] == ("Null",) and row[8] == ("String", b"\\N") and row[17][0] == "Numeric" and row[27][0] == "Deferred"
     n = d.debug_paths()
-    assert n["fused"] == 1 and n["cells"] == 0 and n["redone"] == 0 and n["multipass"] == 0, n
+    n.update(d.debug_rows())
+    # (since round 6 the row-synchronous kernel takes tables of up to 128 columns; k_fused / 64 remains the path behind it: ETLG_ROWS=0 below)
+    assert n["rows"] == 1 and n["fused"] == 0 and n["cells"] == 0 and n["redone"] == 0 and n["multipass"] == 0 and n["rows_redone"] == 0, n
     if not mix:
         # the hand-off of the same batch: 29 of the 31 array columns come back as list columns parsed on the device (json[] / jsonb[]
         # stay text in the Arrow form), with the values the reference's test asserts (replication_stream.rs:613-856)
