@@ -83,6 +83,24 @@ int32_t copy_use_frames(etlg_ctx* c, etlg_batch* b) {
   return ETLG_OK;
 }
 
+// A batch on the frame path that is decoded AGAIN (finish_batch: its rows go through the rewrite once more): the context's frame buffers may
+// have been re-allocated since its first attempt — a later, larger ASYNC batch grew them (DevBuf::ensure frees the old allocation) — and
+// what they hold now is a later batch's frames. Every name the batch holds for them is refreshed first; the streams are idle here (the
+// first attempt and everything queued behind it have been waited for), so growing them again is safe too. (the stale pointers
+// were a device use-after-free on the bad-row path of an ASYNC frames-at-enqueue batch.)
+int32_t copy_repoint_frames(etlg_ctx* c, etlg_batch* b) {
+  CopyJob& j = b->copy;
+  if (!j.active || j.direct) return ETLG_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, c->d_copy_out.ensure(j.syn_len + 64)); HIPCHK(c, c->d_copy_out_offs.ensure(((size_t)j.nrows + 1) * 4));
+  j.d_out = (uint8_t*)c->d_copy_out.p; j.d_out_offs = (uint32_t*)c->d_copy_out_offs.p;
+  DecParams& p = b->params;
+  p.in = j.d_out; p.offs = j.d_out_offs; p.in_len = j.syn_len;
+  b->d_in_ptr = j.d_out; b->dev_in = j.d_out; b->user_offs = j.d_out_offs;
+  return ETLG_OK;
+}
+
 // The multi-pass pipeline (also the exact first-error path).
 void launch_multipass(etlg_ctx* c, const DecParams& p, bool classify_done) {
   if (!classify_done) { if (p.nframes) launch(c, 0, p); launch(c, 1, p); }

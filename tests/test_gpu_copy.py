@@ -446,6 +446,30 @@ def test_copy_async_rows_the_direct_kernel_leaves_to_the_frame_path():
     d.close()
 
 
+def test_copy_async_frame_path_second_attempt_behind_a_larger_batch(monkeypatch):
+    """ASYNC table-copy batches that take the frame path at enqueue (a kernel is forced) share the context's frame buffers, and
+    a later, larger batch re-allocates them. The earlier batch — a small one with a malformed row, so that it needs a second attempt (the
+    multi-pass kernels, for the exact error cut) when it is synced — must decode through the buffers of NOW, not through the pointers of
+    its first attempt (a device use-after-free before the fix): its error, its rows before the error and the batches behind it are the
+    oracle's."""
+    monkeypatch.setenv("ETLG_FUSED_KERNEL", "1")
+    o, d, so, sd = _copy_ctx()
+    small = _gen_rows(40, 901)
+    small[17] = small[17].replace(b"\t", b"\t\t", 1)               # one column too many: a row-level error
+    big = _gen_rows(9000, 902)                                       # ~200 x the small batch: the shared buffers grow
+    mid = _gen_rows(700, 903)
+    batches = [_rows_np(small), _rows_np(big), _rows_np(mid)]
+    frames0 = d.debug_copy()["frames"]
+    inflight = [d.copy_decode(sd, buf, offs, flags=ASYNC) for buf, offs in batches]
+    for k, ((buf, offs), g) in enumerate(zip(batches, inflight)):
+        rb = o.copy_decode(so, buf, offs)
+        g.sync()
+        assert (g.rc != 0) == (k == 0)
+        assert_same(rb, g)
+    assert d.debug_copy()["frames"] - frames0 == 3
+    d.close()
+
+
 def test_copy_async_device_resident_rows():
     import torch
     o, d, so, sd = _copy_ctx()
