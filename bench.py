@@ -155,17 +155,54 @@ def kernel_table(prof):
     return {k: {"launches": n, "avg_us": 1000.0 * ms / n} for k, (n, ms) in prof.items() if n}
 
 
-def roofline_of(kern, alg_bytes_per_launch, traffic=None):
+def roofline_of(kern, alg_bytes_per_launch, traffic=None, kern_as_run=None):
+    """`kern`: every kernel timed ALONE (the chain kept on one stream); `kern_as_run`: the same launches in the mode the timed region runs
+    in (two decode streams: consecutive batches overlap, a launch reads longer — what `rocprofv3 --kernel-trace --stats` of this command
+    averages over). `achieved` / `frac` are priced on the as-run duration when there is one (the line must follow from the
+    rocprof summary, not from the kernel's best case); the alone figure stays beside it (`alone_us`, `frac_alone`)."""
     dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
-    ach = alg_bytes_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
+    alone_us = kern[dom]["avg_us"]
+    run_us = max(alone_us, kern_as_run[dom]["avg_us"]) if kern_as_run and dom in kern_as_run else alone_us
+    ach = alg_bytes_per_launch / (run_us * 1e-6) / 1e9
     per_batch = {k: v["avg_us"] * v["launches"] / kern[dom]["launches"] for k, v in kern.items()}
     pipe_us = sum(per_batch.values())
     return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "alg_bytes_per_launch": int(alg_bytes_per_launch), "kernel_avg_us": round(kern[dom]["avg_us"], 2),
+            "alg_bytes_per_launch": int(alg_bytes_per_launch), "kernel_avg_us": round(run_us, 2),
+            "alone_us": round(alone_us, 2), "frac_alone": round(alg_bytes_per_launch / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
             "pipeline_kernels_us": {k: round(v, 2) for k, v in per_batch.items()},
             "pipeline_sum_us": round(pipe_us, 2),
             "pipeline_frac": round(alg_bytes_per_launch / (pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+def kernel_sources_sha():
+    """Hash of the kernel sources: a traffic file (tools/traffic.sh) names the sources its counters were taken with, and a file whose
+    hash is not this one is not quoted (`roofline.traffic` must not come from an earlier build)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "etl_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(n.encode()); h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_of(path, kernel, batch_mib=None):
+    """hbm_bytes_per_launch of a traffic file if it was taken for THIS kernel with THESE sources, else None."""
+    if not path or not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("kernel") != kernel or t.get("sources_sha") != kernel_sources_sha():
+        return None
+    if batch_mib is not None and t.get("batch_mib") not in (None, batch_mib):
+        return None
+    return t.get("hbm_bytes_per_launch")
+
+
+def roofline_with_traffic(kern, alg, name):
+    """roofline of a side leg, with the HBM traffic of profiles/traffic_<name>.json when that file was taken for this kernel and this build."""
+    dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+    return roofline_of(kern, alg, traffic_of(os.path.join(ROOT, "profiles", f"traffic_{name}.json"), dom))
 
 
 def to_device(pool, dev):
@@ -248,15 +285,13 @@ def leg_async(mk, dev_id, dev, cap, npool, nbatches, flags, check, traffic_file=
     kern2 = kernel_table(dec.profile_read())
     dec.profile(False)
     alg = (q.bytes + SIDECAR_BYTES_PER_FRAME * q.frames + q.out_bytes) / nprof
-    traffic = None
-    if traffic_file and os.path.exists(traffic_file):
-        t = json.load(open(traffic_file))
-        traffic = t.get("hbm_bytes_per_launch")
+    dom0 = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+    traffic = traffic_of(traffic_file, dom0)
     out = {"value": round(p.bytes / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(p.events / dt, 1),
            "hbm_read_frac": round(p.bytes / dt / 1e9 / HBM_PEAK_GBPS, 5),
            "workload": f"{w.name}: {cap >> 20} MiB batches, device-resident in / out, offsets sidecar, " + ("NO_CONTROL | ASYNC" if flags & abi.F_NO_CONTROL else "default control flags + ASYNC (the caller asserts nothing about Relation / DDL frames: optimistic first attempt, chained on the device like NO_CONTROL batches)"),
-           "batches": nbatches, "frames_per_batch": int(p.frames / nbatches), "paths": dec.debug_paths(),
-           "roofline": roofline_of(kern, alg, traffic), "deferred_cells": deferred_cells(dec, items[0])}
+           "batches": nbatches, "frames_per_batch": int(p.frames / nbatches), "paths": {**dec.debug_paths(), **dec.debug_rows()},
+           "roofline": roofline_of(kern, alg, traffic, kern2), "deferred_cells": deferred_cells(dec, items[0])}
     dom = out["roofline"]["kernel"]
     interval_us = 1e6 * dt / nbatches
     out["roofline"]["two_streams"] = {"kernel_avg_us_overlapped": round(kern2[dom]["avg_us"], 2) if dom in kern2 else None,
@@ -297,7 +332,7 @@ def leg_cfg5(dev_id, dev, cap, npool, passes):
         w.register(dec, ready=False)
         if rep == passes + 1:
             dec.profile(2)   # every kernel timed alone (the pre-pass of batch k+1 otherwise runs beside the decode of batch k)
-        n0 = dec.debug_paths()
+        n0 = {**dec.debug_paths(), **dec.debug_rows()}
         a0 = dec.debug_ctl_ahead()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -313,7 +348,7 @@ def leg_cfg5(dev_id, dev, cap, npool, passes):
             kern = kernel_table(dec.profile_read())
         elif rep > 0:
             best = dt if best is None else min(best, dt)
-            n1 = dec.debug_paths()
+            n1 = {**dec.debug_paths(), **dec.debug_rows()}
             paths = {k: n1[k] - n0[k] for k in n1}
             paths["pre_pass_ahead"] = dec.debug_ctl_ahead() - a0
         out_bytes, events = pl.out_bytes, pl.events
@@ -324,7 +359,72 @@ def leg_cfg5(dev_id, dev, cap, npool, passes):
             "hbm_read_frac": round(tot_bytes / best / 1e9 / HBM_PEAK_GBPS, 5),
             "workload": f"{w.name}: {npool} consecutive {cap >> 20} MiB batches of one stream, device-resident in / out, offsets sidecar, "
                         "default flags + ASYNC (Relation / DDL frames handled by the host control plane; control pre-pass of batch k+1 beside the decode of batch k)",
-            "batches": npool, "paths": paths, "roofline": roofline_of(kern, alg)}
+            "batches": npool, "paths": paths, "roofline": roofline_with_traffic(kern, alg, "cfg5")}
+
+
+def leg_cfg2_mixed(dev_id, dev, cap, npool, nbatches):
+    """The fixed-width plan off its insert-only diet: the cfg2 stream with ONE Update in (a) every batch, (b) every 10th batch
+    — an Insert frame's tag byte rewritten to 'U': an Update without an old image has the Insert's layout, and since round 6 the plan
+    decodes it itself (round 5: the batch was decoded again by the generic kernel and the ASYNC chain behind it started over) — and
+    (c) one Delete by key in every 10th batch, a shape the plan still gives up on: the give-up path (second attempt on the generic
+    kernel, the batches in flight behind it enqueued again, chained to the new result). ASYNC chain of `nbatches` 64 MiB batches,
+    NO_CONTROL, device-resident in / out."""
+    import numpy as np
+    import torch
+
+    from etl_amd import abi, synth
+    from etl_amd.decoder import Decoder
+    w = synth.cfg2()
+    pool = [w.fill(cap) for _ in range(npool)]
+    out = {}
+    FL = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
+    def with_delete(buf, offs, f):
+        """frame f (an Insert) replaced by a Delete of the same row by its key: 'D' rel 'K' 1 column — a shape the plan gives up on"""
+        fr = bytes(buf[offs[f]:offs[f + 1]])
+        cell_len = int.from_bytes(fr[39:43], "big")            # the first cell: 't' len bytes at offset 38
+        body = b"D" + fr[31:35] + b"K" + (1).to_bytes(2, "big") + fr[38:43 + cell_len]
+        nf = b"d" + (4 + 25 + len(body)).to_bytes(4, "big") + fr[5:30] + body
+        nb = np.concatenate([buf[:offs[f]], np.frombuffer(nf, dtype=np.uint8), buf[offs[f + 1]:]])
+        no = offs.astype(np.int64).copy()
+        no[f + 1:] += len(nf) - len(fr)
+        return nb, no.astype(np.uint32)
+
+    for name, every, how in (("update_in_every_batch", 1, "U"), ("update_in_every_10th_batch", 10, "U"), ("delete_in_every_10th_batch", 10, "D")):
+        mixed = []
+        for k, (buf, offs) in enumerate(pool):
+            b2, o2 = buf.copy(), offs
+            if k % every == 0:
+                tags = b2[offs[:-1] + 30]
+                f = int(np.nonzero(tags == ord("I"))[0][len(offs) // 2])   # an Insert in the middle of the batch
+                if how == "U":
+                    b2[offs[f] + 30] = ord("U")
+                else:
+                    b2, o2 = with_delete(b2, offs, f)
+            mixed.append((b2, o2))
+        items = to_device(mixed, dev)
+        dec = Decoder(dev_id)
+        synth.cfg2().register(dec)
+        pl = Pipeline(dec, items, FL, True)
+        for _ in range(WINDOW + 2):
+            pl.issue()
+        pl.drain()
+        torch.cuda.synchronize()
+        n0 = {**dec.debug_paths(), **dec.debug_rows()}
+        pl = Pipeline(dec, items, FL, True)
+        t0 = time.perf_counter()
+        for _ in range(nbatches):
+            pl.issue()
+        pl.drain()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n1 = {**dec.debug_paths(), **dec.debug_rows()}
+        n1["chain_reissued"] = dec.debug_chain_reissued(); n0.setdefault("chain_reissued", 0)
+        dec.close()
+        out[name] = {"value": round(pl.bytes / dt / 1e9, 3), "unit": "GB/s", "us_per_batch": round(1e6 * dt / nbatches, 1), "batches": nbatches,
+                     "paths": {k: n1[k] - n0[k] for k in n1 if n1[k] - n0[k]}}
+        del items
+    out["workload"] = f"cfg2 stream, {cap >> 20} MiB batches, one Insert of the named batches rewritten as an Update without an old image / replaced by a Delete by key; pool of {npool} batches, ASYNC | NO_CONTROL, chain of {nbatches}"
+    return out
 
 
 def leg_cfg1(dev_id, dev, cap, cpu_seconds):
@@ -357,25 +457,33 @@ def leg_cfg1(dev_id, dev, cap, cpu_seconds):
     dec = Decoder(dev_id)
     FL = abi.F_OUTPUT_ON_DEVICE | abi.F_ASYNC
     best, events, paths = None, 0, {}
-    for rep in range(4):
+    # One decode of the stream is half a millisecond — a latency, not a rate: a timed pass is LOOPS decodes of the whole
+    # stream back to back on one context (each starts with the stream's Relation frames again, as after a reconnect: the control path
+    # every time; a pass ends behind a Commit), sized so that it lasts >= 100 ms.
+    loops = 1
+    for rep in range(5):
         for t in w.tables:
             dec.table_forget(t["rel_id"])
         dec.reset_stream_state()
         w.register(dec, ready=False)
-        n0 = dec.debug_paths()
+        n0 = {**dec.debug_paths(), **dec.debug_rows()}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pl = Pipeline(dec, items, FL, True)
-        for _ in range(len(items)):
+        for _ in range(len(items) * loops):
             pl.issue()
         pl.drain()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if rep > 0:
-            best = dt if best is None else min(best, dt)
-            n1 = dec.debug_paths()
-            paths = {k: n1[k] - n0[k] for k in n1}
-        events = pl.events
+        if rep == 0:
+            loops = max(1, int(0.12 / max(dt, 1e-5)) + 1)   # (the first pass also warms the pools)
+            continue
+        per = dt / loops
+        best = per if best is None else min(best, per)
+        n1 = {**dec.debug_paths(), **dec.debug_rows()}
+        paths = {k: n1[k] - n0[k] for k in n1}
+        paths["stream_decodes_per_timed_pass"] = loops
+        events = pl.events // loops
     dec.close()
     secs, passes, cpu_events, cpu_best = 0.0, 0, 0, None
     while secs < cpu_seconds or passes == 0:
@@ -395,7 +503,7 @@ def leg_cfg1(dev_id, dev, cap, cpu_seconds):
     return {"workload": f"{w.name}: 1 000 000 INSERT rows in 1 000 transactions with their Relation frames ({tot_bytes} bytes, {tot_frames} frames, {len(pieces)} batches of <= {cap >> 20} MiB)",
             "rows": rows, "events": events,
             "gpu": {"events_per_s": round(events / best, 1), "value": round(tot_bytes / best / 1e9, 3), "unit": "GB/s", "seconds": round(best, 6), "paths": paths,
-                    "how": "default flags + ASYNC, device-resident in / out, best of 3 passes over the whole stream"},
+                    "how": "default flags + ASYNC, device-resident in / out; a timed pass decodes the whole stream `stream_decodes_per_timed_pass` times back to back (>= 100 ms), best of 4 passes, per decode of the stream"},
             "cpu_baseline": {"events_per_s": round(events / cpu_best, 1), "value": round(tot_bytes / cpu_best / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
                              "seconds": round(cpu_best, 4), "sample": f"the whole stream, best of {passes} passes, single thread (the reference's one apply worker), oracle FULL mode"}}
 
@@ -432,13 +540,13 @@ def leg_wide70(dev_id, dev, nrows, reps):
     torch.cuda.synchronize()
     kern = kernel_table(dec.profile_read())
     dec.profile(False)
-    paths = dec.debug_paths()
+    paths = {**dec.debug_paths(), **dec.debug_rows()}
     dec.close()
     alg = (q.bytes + SIDECAR_BYTES_PER_FRAME * q.frames + q.out_bytes) / 8
     return {"value": round(pl.bytes / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(pl.events / dt, 1),
             "workload": f"type-matrix table, {len(synth.TYPE_MATRIX)} columns (every scalar class, 31 array columns, json): one batch of {len(buf)} bytes / {len(offs) - 1} frames "
                         f"(avg {len(buf) // (len(offs) - 1)} B), I / U(key) / D(key), NO_CONTROL | ASYNC, device-resident in / out",
-            "batches": reps, "paths": paths, "roofline": roofline_of(kern, alg)}
+            "batches": reps, "paths": paths, "roofline": roofline_with_traffic(kern, alg, "wide70")}
 
 
 def leg_copy(dev_id, dev, nrows, reps):
@@ -519,7 +627,7 @@ def _leg_copy_rows(dev_id, dev, base, nrows, reps, what, clean=None):
     alg = len(buf) + 4 * len(rows) + ob / reps
     out = {"value": round(reps * len(buf) / dt / 1e9, 3), "unit": "GB/s", "rows_per_s": round(reps * len(rows) / dt, 1),
            "workload": f"{len(rows)} COPY text rows of a 10-column mixed table ({len(buf)} bytes), {what}, device-resident, synchronous",
-           "paths": paths, "roofline": roofline_of(kern, alg), "async": asy}
+           "paths": paths, "roofline": roofline_with_traffic(kern, alg, "copy_clean" if clean is None and "ordinary" in what else "copy"), "async": asy}
     if clean is not None:
         out["ordinary_text"] = clean   # the same table with text that needs no escapes: what COPY output mostly looks like
     return out
@@ -830,7 +938,7 @@ def main():
     ap.add_argument("--batch-mib", type=int, default=64)
     ap.add_argument("--pool", type=int, default=6, help="distinct batches resident in HBM (rotated)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--legs", default="cfg1,cfg3,cfg5,wide70,copy,no_sidecar,handoff,default_flags,pcie,cfg4", help="extra legs on rank 0 (comma separated; empty = none)")
+    ap.add_argument("--legs", default="cfg1,cfg3,cfg5,wide70,copy,no_sidecar,handoff,default_flags,cfg2_mixed,pcie,cfg4", help="extra legs on rank 0 (comma separated; empty = none)")
     ap.add_argument("--cfg4-leg", action="store_true", help="add the cfg4 leg to a cfg2 / cfg3 run")
     ap.add_argument("--cfg4-gib", type=int, default=8)
     ap.add_argument("--cfg4-seg-mib", type=int, default=1024)
@@ -992,21 +1100,17 @@ def main():
         alg_bytes = (q.bytes + SIDECAR_BYTES_PER_FRAME * q.frames + q.out_bytes) / nprof
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this same command
         # (tools/traffic.sh writes the file; FETCH_SIZE doubled per MI355X_MICROARCH.md, gfx950 note)
-        traffic = None
         tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
-        if os.path.exists(tf):
-            t = json.load(open(tf))
-            if t.get("kernel") == dom and t.get("batch_mib") == args.batch_mib:
-                traffic = t["hbm_bytes_per_launch"]
-        roof = roofline_of(kern, alg_bytes, traffic)
+        traffic = traffic_of(tf, dom, args.batch_mib)
+        roof = roofline_of(kern, alg_bytes, traffic, kern2)
         interval_us = 1e6 * elapsed / (args.steps * inner)
         roof["two_streams"] = {"batches_beside_their_predecessor": dec.debug_overlapped(),
                                "kernel_avg_us_overlapped": round(kern2[dom]["avg_us"], 2) if dom in kern2 else None,
                                "launch_interval_us": round(interval_us, 2),
                                "effective_GBps": round(alg_bytes / (interval_us * 1e-6) / 1e9, 1),
                                "effective_frac": round(alg_bytes / (interval_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
-        paths = dec.debug_paths()
+        paths = {**dec.debug_paths(), **dec.debug_rows()}
 
     extra = {}
     _leg_t = [time.perf_counter()]
@@ -1033,6 +1137,9 @@ def main():
             extra["default_flags"] = {k: d[k] for k in ("value", "unit", "workload", "batches", "paths")}
             extra["default_flags"]["kernels_us"] = d["roofline"]["pipeline_kernels_us"]
             _leg_done("default_flags")
+        if "cfg2_mixed" in legs and args.workload == "cfg2":
+            extra["cfg2_mixed"] = leg_cfg2_mixed(local_rank, dev, cap, 10, 240)
+            _leg_done("cfg2_mixed")
         if "cfg5" in legs:
             extra["cfg5"] = leg_cfg5(local_rank, dev, cap, 16, 2)
             _leg_done("cfg5")

@@ -275,6 +275,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* fd = getenv("ETLG_FUSED_DBG"); c->fused_dbg = fd ? (uint32_t)atoi(fd) : 0; }
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
   { const char* rm = getenv("ETLG_ROWS"); if (rm) c->rows_mode = atoi(rm); }
+  { const char* cr = getenv("ETLG_CHAIN_REISSUE"); if (cr) c->chain_reissue = atoi(cr) != 0; }
   clear_error(c);
   (void)etlg_k_plan_set_lds();
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
@@ -782,7 +783,7 @@ int32_t etlg_ctx_debug_copy(etlg_ctx* c, unsigned long long* out2) {
 // [1] chains finished early because their last batch was marked for a second attempt
 int32_t etlg_ctx_debug_ring(etlg_ctx* c, unsigned long long* out1) {
   if (!c || !out1) return ETLG_InvalidArgument;
-  out1[0] = c->ring_recleared; out1[1] = c->chain_healed;
+  out1[0] = c->ring_recleared; out1[1] = c->chain_healed; out1[2] = c->chain_reissued;
   return ETLG_OK;
 }
 

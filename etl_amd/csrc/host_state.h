@@ -301,6 +301,10 @@ struct etlg_ctx {
   unsigned long long overlapped = 0;   // debugging aid: batches launched beside their predecessor
   // result blocks: a ring re-initialised once per lap with one copy
   static constexpr uint32_t kResRing = 32;
+  uint64_t chain_reissued = 0;   // ASYNC batches enqueued again behind a batch that was decoded again (finish_batch, reissue_successors)
+  bool chain_reissue = false;    // ETLG_CHAIN_REISSUE=1: the successors of a batch that was decoded again are enqueued again, chained to its new result
+                                 // (reissue_successors). Built and measured in round 6 — it LOST on the delete-in-every-10th-batch leg (548 against 905 GB/s:
+                                 // every give-up re-runs the whole window on one stream) — so the default stays each successor decoded again at its own sync
   uint64_t chain_healed = 0;     // ASYNC chains finished early because their last batch was marked for a second attempt (etlg_decode)
   uint64_t ring_recleared = 0;   // result blocks cleared again after a second attempt behind their lap's re-initialisation (finish_batch)
   uint32_t res_seq = 0;

@@ -288,8 +288,12 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
   const uint32_t tag = (uint32_t)(h30 & 0xFF);
   const uint32_t rel = __builtin_bswap32((uint32_t)(h30 >> 8));
   const uint32_t ncols = ((uint32_t)(h30 >> 48) & 0xFFu) << 8 | (uint32_t)(h30 >> 56);
-  bad |= sane & (uint32_t)(tag != 'I' && tag != 'B' && tag != 'C');
-  const bool isI = sane && tag == 'I', isB = sane && tag == 'B', isC = sane && tag == 'C';
+  bad |= sane & (uint32_t)(tag != 'I' && tag != 'U' && tag != 'B' && tag != 'C');
+  // (round 6) an Update WITHOUT an old image — what pgoutput sends for a table under its default replica identity whenever the key did not
+  // change — has the Insert's layout: rel | 'N' | tuple. Its new row is a full row (an unchanged-toast cell, 'u', is not the plan's:
+  // it gives the batch up below like every cell that is neither 't' nor 'n'), its event differs in the kind byte and in the payload
+  // counter it adds to. An Update that carries 'K' / 'O' fails the shape test ('N' behind the relation id) and goes the generic way.
+  const bool isI = sane && (tag == 'I' || tag == 'U'), isB = sane && tag == 'B', isC = sane && tag == 'C';
   // table of every Insert lane: one scalar lookup per distinct table of the wave (descriptors through the scalar cache)
   int ti = -1;
   uint32_t row_dw = 0, slot_id = 0, want_cols = 0;
@@ -346,7 +350,7 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
     const uint64_t h0 = rd64(m, fr);        // 'd' | len:4 | 'w' | 2 bytes of wal_start
     const uint32_t len = __builtin_bswap32((uint32_t)(h0 >> 8));
     const uint32_t env = ((uint32_t)(h0 & 0xFF) == 'd') & (len + 1u == flen) & ((uint32_t)((h0 >> 40) & 0xFF) == 'w');
-    const uint32_t shape = tag == 'I' ? (uint32_t)((uint32_t)((h30 >> 40) & 0xFF) == 'N')
+    const uint32_t shape = (tag == 'I' || tag == 'U') ? (uint32_t)((uint32_t)((h30 >> 40) & 0xFF) == 'N')
                          : tag == 'B' ? (uint32_t)(flen >= kBodyOff + 20) : (uint32_t)(flen >= kBodyOff + 25);
     bad |= sane & ((env & shape) ^ 1u);
   }
@@ -569,9 +573,14 @@ DEV void plan_store(DecParams& p, const PlanParams& q, uint32_t tile, const Plan
   }
   PSTAMP(6);
   WSTAMP(5);
-  // payload bytes of the tile's inserts (A3), one atomic per wave into a shard
-  const uint32_t pay = wave_last(wave_scan_add(vbytes));
+  // payload bytes of the tile's inserts / updates (A3), one atomic per wave into a shard
+  const bool is_upd = (L.tagf & 0xFFu) == 'U';
+  const uint32_t pay = wave_last(wave_scan_add(is_upd ? 0u : vbytes));
   if (lane == 0 && pay) atomicAdd(&p.res->pay_shard[tile & 31][0], (unsigned long long)pay);
+  if (__ballot(is_upd && vbytes != 0)) {
+    const uint32_t payu = wave_last(wave_scan_add(is_upd ? vbytes : 0u));
+    if (lane == 0 && payu) atomicAdd(&p.res->pay_shard[tile & 31][1], (unsigned long long)payu);
+  }
   if ((any_bad || !cap_ok) && lane == 0) atomicOr(failp, 2u);
 }
 

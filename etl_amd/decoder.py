@@ -386,15 +386,21 @@ class Decoder:
 
     def debug_ring_recleared(self):
         """Result blocks cleared again after a second attempt behind their lap's re-initialisation (debugging aid, not in etlg.h)."""
-        out = (C.c_ulonglong * 2)()
+        out = (C.c_ulonglong * 3)()
         self.L.etlg_ctx_debug_ring(self.h, out)
         return int(out[0])
 
     def debug_chains_healed(self):
         """ASYNC chains that were finished early because their last batch was marked for a second attempt (debugging aid)."""
-        out = (C.c_ulonglong * 2)()
+        out = (C.c_ulonglong * 3)()
         self.L.etlg_ctx_debug_ring(self.h, out)
         return int(out[1])
+
+    def debug_chain_reissued(self):
+        """ASYNC batches enqueued again — chained to the new result — behind a batch that was decoded again (debugging aid)."""
+        out = (C.c_ulonglong * 3)()
+        self.L.etlg_ctx_debug_ring(self.h, out)
+        return int(out[2])
 
     def frame_tags(self, buf, offsets):
         """pgoutput tag of every frame (np.uint8; 0 = malformed), classified on the device (etlg_frame_tags)."""

@@ -286,8 +286,8 @@ def test_async_chain_survives_an_error_in_the_middle():
 
 
 def test_async_chain_when_the_plan_does_not_cover_a_batch():
-    """An UPDATE in a stream of fixed-width inserts: k_plan gives the batch up, the generic kernel decodes it, and the
-    batches queued behind it run again from the right state."""
+    """An UPDATE that carries a key image (an Update without an old image is the plan's own since round 6) in a stream of fixed-width
+    inserts: k_plan gives the batch up, the generic kernel decodes it, and the batches queued behind it run again from the right state."""
     from tests import pgwire as W
     w = synth.cfg2()
     buf, offs = w.fill(1 << 20)
@@ -300,7 +300,7 @@ def test_async_chain_when_the_plan_does_not_cover_a_batch():
         at += 1
     rel = int.from_bytes(b1[int(o1[at]) + 31:int(o1[at]) + 35].tobytes(), "big")
     lsn = int.from_bytes(b1[int(o1[at]) + 6:int(o1[at]) + 14].tobytes(), "big")
-    upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"])))
+    upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"], key=["4"])))
     cut = int(o1[at])
     nb = np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]])
     no = np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32)
@@ -310,7 +310,7 @@ def test_async_chain_when_the_plan_does_not_cover_a_batch():
 
 
 def test_async_chain_second_attempts_across_a_ring_lap():
-    """70 cfg2 batches, six in flight; batch 30 holds an UPDATE the fixed-width plan does not cover. It is decoded again when it is
+    """70 cfg2 batches, six in flight; batch 30 holds an UPDATE with a key image, which the fixed-width plan does not cover. It is decoded again when it is
     synced — and with it the batches queued behind it — AFTER batch 32 (result block 0) has sent out the ring's re-initialisation for the
     next lap: what the second attempts leave in blocks 30 and 31 must not meet batches 62 and 63 (payload shards are added to, give-up
     and error words or-ed / min-ed into, carry_ready polled by the batch that runs beside). Every batch of the chain against the oracle."""
@@ -326,7 +326,7 @@ def test_async_chain_second_attempts_across_a_ring_lap():
         at += 1
     rel = int.from_bytes(b1[int(o1[at]) + 31:int(o1[at]) + 35].tobytes(), "big")
     lsn = int.from_bytes(b1[int(o1[at]) + 6:int(o1[at]) + 14].tobytes(), "big")
-    upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"])))
+    upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"], key=["4"])))
     cut = int(o1[at])
     pieces[30] = (np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]]),
                   np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32))
@@ -534,6 +534,7 @@ def _chain_default_flags(w, pieces, warm, ready=True):
     paths = d.debug_paths()
     paths["overlapped"] = d.debug_overlapped()
     paths["ctl_ahead"] = d.debug_ctl_ahead()
+    paths["chain_reissued"] = d.debug_chain_reissued()
     d.close()
     return paths
 
@@ -561,13 +562,14 @@ def test_async_control_stream_runs_its_pre_pass_ahead():
 def test_async_cold_start_on_a_stream_that_begins_with_its_relation_frames():
     """No warm-up: every batch of a cfg5 stream enqueued before the first is synced. The first batch carries the stream's Relation
     frames, so its optimistic attempt ends with the control hint, it takes the control path when it is synced, and the batches behind
-    it — enqueued when the context had no schema slot at all — are decoded again from the state it leaves. Their views list the
-    slots their events name (they listed none: found by tools/async_fuzz.py, round 4)."""
+    it — enqueued when the context had no schema slot at all — are decoded again from the state it leaves (since round 6: enqueued
+    again behind it, chained to its new result, instead of one synchronous second attempt each). Their views list the slots their
+    events name (they listed none: found by tools/async_fuzz.py, round 4)."""
     w = synth.cfg5()
     buf, offs = w.fill(1 << 20)
     pieces = _cut(buf, offs, 6, seed=5)
     paths = _chain_default_flags(w, pieces, warm=0, ready=False)
-    assert paths["chain_rerun"] >= 1 and paths["control"] >= 1, paths
+    assert paths["chain_rerun"] + paths["chain_reissued"] >= 1 and paths["control"] >= 1, paths
 
 
 def test_async_control_stream_with_an_error_in_the_middle():

@@ -81,7 +81,7 @@ while time.time() < t_end or rounds == 0:
             continue
         rel = int.from_bytes(b1[int(o1[at]) + 31:int(o1[at]) + 35].tobytes(), "big")
         lsn = int.from_bytes(b1[int(o1[at]) + 6:int(o1[at]) + 14].tobytes(), "big")
-        upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"])))
+        upd = W.frame(W.xlog(lsn - 1, W.update(rel, ["5", "6", "7", "8", "9"], key=["4"])))
         cut = int(o1[at])
         pieces[k] = (np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]]),
                      np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32))
