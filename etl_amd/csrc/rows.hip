@@ -64,7 +64,6 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
   __shared__ uint32_t row_chunks[128];     // 16-byte chunks of text to copy per row of the heap-cell table (D adds them up, C deals the rows out by them)
   __shared__ uint8_t own_mark[NW][64];     // text copy: which cell starts at a chunk position of the current step
   __shared__ uint32_t fr_flags[64];   // bit 0: a cell failed to decode; bit 1: the frame is an Update; bit 2: beyond what the kernel covers
-  __shared__ uint32_t g_slot[kRowsMaxGroups], g_info[kRowsMaxGroups], g_cb[kRowsMaxGroups], g_task0[kRowsMaxGroups];
   __shared__ uint64_t g_mem[kRowsMaxGroups];
   __shared__ uint32_t s32[16];
   __shared__ uint64_t s64[12];
@@ -295,7 +294,9 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
     //      (codec/event.rs:559-565, 889-922) per frame: 0 full / update row, 1 dense key tuple, 2 full-width key tuple, 3 = a shape error
     const uint32_t mo = old_kind == ETLG_OLD_KEY ? (s_nident == 0 ? 3u : n_old == s_nident ? 1u : n_old == s_ncols ? 2u : 3u) : (n_old == s_ncols ? 0u : 3u);
     const uint32_t mn = n_new == s_ncols ? 0u : 3u;
-    uint32_t ng = 0, ntasks = 0;
+    // ... and, group by group, the task list: inside every group the heavy classes first (temporal / uuid / numeric / float), so that the
+    // waves dealing the list out among themselves finish close to each other. An entry carries the column's record.
+    uint32_t ng = 0, nq = 0;
     for (uint32_t img1 = 0; img1 < 2; img1++) {
       const uint32_t myn = img1 ? n_new : n_old, mym = img1 ? mn : mo;
       uint32_t pend = (ok != 0 && slot >= 0 && !derr && (img1 ? v.tag != 'D' : old_kind != ETLG_OLD_NONE)) ? 1u : 0u;
@@ -309,45 +310,34 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
         const uint32_t cb_u = (uint32_t)__builtin_amdgcn_readlane((int)s_cb, leader);
         const bool in = pend && (uint32_t)slot == slot_u && myn == n_u && mym == mode_u;
         const unsigned long long mem = __ballot(in);
-        if (mode_u == 3) { if (in) derr = 1; }   // (the frame fails whatever its cells hold)
-        else if (n_u != 0) {
-          if (ng < kRowsMaxGroups) {
-            if (lane == 0) { g_slot[ng] = slot_u; g_info[ng] = mode_u | (img1 << 8) | (n_u << 16); g_cb[ng] = cb_u; g_task0[ng] = ntasks; g_mem[ng] = mem; }
-            ng++; ntasks += n_u;
-          } else if (in) gave = 0x1000;
-        }
         if (in) pend = 0;
-      }
-    }
-    // the task list: inside every group the heavy classes first (temporal / uuid / numeric / float), so that the waves pulling from it finish
-    // close to each other
-    uint32_t nq = 0;
-    if (ntasks > max_tasks) { gave = 0x1000; ng = 0; }
-    for (uint32_t g = 0; g < ng; g++) {
-      const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_info[g]);
-      const uint32_t cb_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_cb[g]);
-      const uint32_t kmode = info & 0xFFu, n_u = info >> 16;
-      const uint32_t tag16 = (g << 8) | (kmode << 12) | (((info >> 8) & 1u) << 14);
-      for (uint32_t k0 = 0; k0 < n_u; k0 += 64) {
-        const uint32_t k = k0 + lane;
-        uint32_t heavy = 0, light = 0;
-        uint4 ent = make_uint4(0, 0, 0, 0);
-        if (k < n_u) {
-          const uint32_t* cw = (const uint32_t*)(p.cols + cb_u);   // (the LDS copy of the column records)
-          static_assert(sizeof(DevCol) == 12, "descriptor words below");
-          const uint32_t ci = kmode == 1 ? cw[3 * k] >> 24 : k;   // DevCol.key_col of record k: cell k of a dense key tuple
-          ent = make_uint4(k | tag16, cw[3 * ci], cw[3 * ci + 1], cw[3 * ci + 2]);
-          const uint32_t cls = ent.y & 0xFFu;
-          const bool hv = (cls >= ETLG_TC_DATE && cls <= ETLG_TC_UUID) || cls == ETLG_TC_NUMERIC || cls == ETLG_TC_F32 || cls == ETLG_TC_F64;
-          const bool take = !(kmode == 2 && !((ent.y >> 16) & 0xFFu));   // (full-width key tuple: only the identity columns are read)
-          heavy = (take && hv) ? 1u : 0u; light = (take && !hv) ? 1u : 0u;
+        if (mode_u == 3) { if (in) derr = 1; continue; }   // (the frame fails whatever its cells hold)
+        if (n_u == 0) continue;
+        if (ng >= kRowsMaxGroups || nq + n_u > max_tasks) { if (in) gave = 0x1000; continue; }
+        if (lane == 0) g_mem[ng] = mem;
+        const uint32_t tag16 = (ng << 8) | (mode_u << 12) | (img1 << 14);
+        for (uint32_t k0 = 0; k0 < n_u; k0 += 64) {
+          const uint32_t k = k0 + lane;
+          uint32_t heavy = 0, light = 0;
+          uint4 ent = make_uint4(0, 0, 0, 0);
+          if (k < n_u) {
+            const uint32_t* cw = (const uint32_t*)(p.cols + cb_u);   // (the LDS copy of the column records)
+            static_assert(sizeof(DevCol) == 12, "descriptor words below");
+            const uint32_t ci = mode_u == 1 ? cw[3 * k] >> 24 : k;   // DevCol.key_col of record k: cell k of a dense key tuple
+            ent = make_uint4(k | tag16, cw[3 * ci], cw[3 * ci + 1], cw[3 * ci + 2]);
+            const uint32_t cls = ent.y & 0xFFu;
+            const bool hv = (cls >= ETLG_TC_DATE && cls <= ETLG_TC_UUID) || cls == ETLG_TC_NUMERIC || cls == ETLG_TC_F32 || cls == ETLG_TC_F64;
+            const bool take = !(mode_u == 2 && !((ent.y >> 16) & 0xFFu));   // (full-width key tuple: only the identity columns are read)
+            heavy = (take && hv) ? 1u : 0u; light = (take && !hv) ? 1u : 0u;
+          }
+          const unsigned long long mh = __ballot(heavy != 0), ml = __ballot(light != 0);
+          const unsigned long long lt = (1ull << lane) - 1ull;
+          const uint32_t nh = (uint32_t)__builtin_popcountll(mh);
+          if (heavy) tasks[nq + (uint32_t)__builtin_popcountll(mh & lt)] = ent;
+          if (light) tasks[nq + nh + (uint32_t)__builtin_popcountll(ml & lt)] = ent;
+          nq += nh + (uint32_t)__builtin_popcountll(ml);
         }
-        const unsigned long long mh = __ballot(heavy != 0), ml = __ballot(light != 0);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const uint32_t nh = (uint32_t)__builtin_popcountll(mh);
-        if (heavy) tasks[nq + (uint32_t)__builtin_popcountll(mh & lt)] = ent;
-        if (light) tasks[nq + nh + (uint32_t)__builtin_popcountll(ml & lt)] = ent;
-        nq += nh + (uint32_t)__builtin_popcountll(ml);
+        ng++;
       }
     }
     TSTAMP(9);
@@ -716,16 +706,22 @@ __global__ __launch_bounds__(NW * 64, ETLG_ROWS_MINBLOCKS) void k_rows(DecParams
             uint32_t prev = boff ? __builtin_amdgcn_alignbyte(qd[0], qd[-1], sh) : 0u;
             uint32_t* out = (uint32_t*)(pg.heap + o_dst + boff);
             bool bad = false;
+            uint32_t xs[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
               if (4 * j < rem) {
                 const uint32_t rj = rem - 4 * j;
                 uint32_t xw = __builtin_amdgcn_alignbyte(wv[j + 1], wv[j], sh);
                 if (rj < 4) xw &= (1u << (8 * rj)) - 1u;
-                out[j] = xw;
+                xs[j] = xw;
                 if ((xw | prev) & 0x80808080u) bad |= utf8_dword_bad(prev, xw, rj == 4);
                 prev = xw;
               }
+            }
+            if (rem > 12u) __builtin_memcpy(out, xs, 16);   // all four dwords are the cell's (the last one zero padded): one 16-byte store (4-byte aligned)
+            else {
+#pragma unroll
+              for (uint32_t j = 0; j < 3; j++) if (4 * j < rem) out[j] = xs[j];
             }
             if (bad) record_error(pg, f0 + owner, RK_DECODE, ETLG_E_UTF8);
           }

@@ -1,7 +1,6 @@
-python bench.py --legs=cfg2_mixed --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-r=json.loads(sys.stdin.read()); print(r['value']); print(json.dumps(r['cfg2_mixed'], indent=0))" > gpurun_out/r06p_mixed.txt 2>&1
-ETLG_CHAIN_REISSUE=0 python bench.py --legs=cfg2_mixed --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-r=json.loads(sys.stdin.read()); print('reissue off', r['value']); print(json.dumps(r['cfg2_mixed'], indent=0))" >> gpurun_out/r06p_mixed.txt 2>&1
-timeout 900 python -m pytest tests/test_gpu_async.py tests/test_gpu_fixed_plan.py tests/test_gpu_copy.py tests/test_shim_twin.py -x -q 2>&1 | tail -3 >> gpurun_out/r06p_mixed.txt
+python tools/wide_ab.py rows > gpurun_out/r06l_wide.txt 2>&1
+python tools/rows_ab.py rows > gpurun_out/r06_ab.txt 2>&1
+ETLG_ROWS=0 python tools/rows_ab.py cells >> gpurun_out/r06_ab.txt 2>&1
+ETLG_FUSED_DBG=8 python tools/rows_ab.py rows_phases >> gpurun_out/r06_ab.txt 2>&1
+timeout 600 python tools/chain_probe.py cfg3 rows_two: 2>&1 | grep workload >> gpurun_out/r06l_wide.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -4 > gpurun_out/r06l_tests.txt
