@@ -166,6 +166,10 @@ struct DecParams {
   // ETLG_F_ASYNC chains batches on the device: when set, the carried transaction state (in_txn / final_lsn / next_ord above)
   // is read from the result block of the batch issued just before this one on the same stream, not from these host values
   const DevResult* carry;
+  // ETLG_F_ASYNC without a sidecar, fixed-width plan (round 6): the record-boundary scan of THIS batch is still in flight when the decode is
+  // enqueued behind it. `nframes` above is then an upper bound the grids were sized by; the kernels read the count the scan left on the
+  // device — words [0] frames, [1] flags, [2] tiles that guessed wrong (either non-zero: the scan did not hold) — and take it for nframes (plan.hip, plan_frames_from_device)
+  const uint32_t* nframes_dev;
 };
 
 // The fixed-width decode plan (plan.hip): the eligible tables of a batch, sorted by rel_id, and their columns.

@@ -276,6 +276,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
   { const char* rm = getenv("ETLG_ROWS"); if (rm) c->rows_mode = atoi(rm); }
   { const char* cr = getenv("ETLG_CHAIN_REISSUE"); if (cr) c->chain_reissue = atoi(cr) != 0; }
+  { const char* sc = getenv("ETLG_SCAN_CHAIN"); if (sc) c->scan_chain_mode = atoi(sc) != 0; }
   clear_error(c);
   (void)etlg_k_plan_set_lds();
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
@@ -518,19 +519,19 @@ hipError_t scan_launch(etlg_ctx* c, ScanJob& j, bool sequential) {
   }
   uint8_t* base = (uint8_t*)c->d_scan.p;
   hipError_t e = j.offs->ensure((j.cap + 2) * 4); if (e != hipSuccess) return e;
-  j.cur = base;
+  j.cur = j.res ? (uint8_t*)j.res : base;
   c->h_scan[0] = 0; c->h_scan[1] = 0;
   ProfRec r; r.which = kBounds;
   if (c->prof) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, s); }
-  etlg_k_launch_bounds(j.d_in, len, (uint32_t*)j.offs->p, (uint32_t)std::min<size_t>(j.cap + 2, 0xFFFFFFFFu), base, (uint32_t*)(base + c->scan_half), c->h_scan,
+  etlg_k_launch_bounds(j.d_in, len, (uint32_t*)j.offs->p, (uint32_t)std::min<size_t>(j.cap + 2, 0xFFFFFFFFu), base, j.res, (uint32_t*)(base + c->scan_half), c->h_scan,
                        sequential ? 1 : 0, s);
   if (c->prof) { (void)hipEventRecord(r.b, s); c->prof_recs.push_back(r); }
   return hipSuccess;
 }
 
-hipError_t scan_begin(etlg_ctx* c, ScanJob& j, const uint8_t* d_in, size_t len, hipStream_t s, DevBuf& offs) {
+hipError_t scan_begin(etlg_ctx* c, ScanJob& j, const uint8_t* d_in, size_t len, hipStream_t s, DevBuf& offs, uint32_t* res = nullptr) {
   j = ScanJob{};
-  j.d_in = d_in; j.len = len; j.s = s; j.offs = &offs;
+  j.d_in = d_in; j.len = len; j.s = s; j.offs = &offs; j.res = res;
   j.cap = len / 24 + 1024;  // frames the offsets buffer can take; grown to the worst case (5-byte frames) on demand
   if (len == 0) {
     hipError_t e = offs.ensure(64); if (e != hipSuccess) return e;
@@ -783,7 +784,7 @@ int32_t etlg_ctx_debug_copy(etlg_ctx* c, unsigned long long* out2) {
 // [1] chains finished early because their last batch was marked for a second attempt
 int32_t etlg_ctx_debug_ring(etlg_ctx* c, unsigned long long* out1) {
   if (!c || !out1) return ETLG_InvalidArgument;
-  out1[0] = c->ring_recleared; out1[1] = c->chain_healed; out1[2] = c->chain_reissued;
+  out1[0] = c->ring_recleared; out1[1] = c->chain_healed; out1[2] = c->chain_reissued; out1[3] = c->scan_chained_n; out1[4] = c->scan_chain_redone;
   return ETLG_OK;
 }
 
@@ -965,13 +966,57 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   b->host_in = in_dev ? nullptr : buf; b->host_offs = (in_dev || scan) ? nullptr : h_offs; b->dev_in = in_dev ? buf : nullptr;
   b->d_in_ptr = d_in_ptr; b->user_offs = frame_offsets;
   if (scan) {
+    // Round 6: when the batch will be decoded by the fixed-width plan behind its sidecar pre-pass (the cfg2 shape) and the stream has
+    // shown how many frames a batch of this size holds, the decode is enqueued AT ONCE behind the scan: the grids are sized by a bound,
+    // the kernels read the count the scan leaves on the device (DecParams.nframes_dev), and the host never waits between a scan and
+    // the decode behind it. A scan that did not hold, or a batch beyond the bound, comes back with fused_fail bit 5
+    // and takes the round-5 route when it is finished (finish_batch). ASYNC: the scan on its own stream, the decode streams wait for
+    // its event; otherwise scan and decode follow each other on the context's stream and the call waits once, at its end.
+    const size_t offs_cap = len / 24 + 1024;
+    // (the estimate: this batch's bytes at the bytes per frame of the last scanned batch of the stream; the bound: a quarter above it)
+    const uint64_t nf_est = c->scan_last_len ? std::max<uint64_t>(1, (uint64_t)((unsigned __int128)len * c->scan_last_nf / c->scan_last_len)) : 0;
+    const uint64_t bound = std::min<uint64_t>(offs_cap, nf_est + nf_est / 4 + 4096);
+    const bool chain_scan = c->scan_chain_mode && c->scan_last_nf && len && no_ctrl && c->worker == ETLG_WORKER_APPLY && !c->copy.active && !c->prof_serial &&
+                            c->plan_mode != 0 && (c->fused_kernel < 0 || c->fused_kernel == 3) && c->n_plan_tabs && c->plan_covers_all && c->plan_pre != 0 &&
+                            c->plan_uniform_dw != 0 && !c->plan_skip && c->plan_max_row <= 512 && !c->fused_dbg && c->side_valid && !c->side_dirty && !c->slots_dirty &&
+                            c->last_epochs.empty() && bound < (1u << 29) && !(async && !c->pending.empty() && c->pending.back()->force_rerun);
+    if (async || chain_scan) {
+      if (c->offs_pool.empty()) c->offs_pool.push_back(new DevBuf());
+      b->scan_offs = c->offs_pool.back(); c->offs_pool.pop_back();
+    }
+    if (chain_scan) {
+      if (async && !c->scan_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
+      b->scan_s = async ? c->scan_stream : s;
+      HIPCHK(c, b->scan_offs->ensure((offs_cap + 2) * 4 + 128));
+      b->d_scan_res = (uint32_t*)((uint8_t*)b->scan_offs->p + (((offs_cap + 2) * 4 + 63) & ~(size_t)63));   // (the scan's result words live with the batch: no copy behind the scan)
+      HIPCHK(c, scan_begin(c, c->scan_job, d_in_ptr, len, b->scan_s, *b->scan_offs, b->d_scan_res));
+      b->nf_est = nf_est;
+      if (async) {
+        if (c->ev_pool.empty()) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_pool.push_back(e); }
+        hipEvent_t sev = c->ev_pool.back(); c->ev_pool.pop_back();
+        HIPCHK(c, hipEventRecord(sev, c->scan_stream));
+        if (!c->stream2) {
+          HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+          HIPCHK(c, hipEventCreateWithFlags(&c->tail2, hipEventDisableTiming));
+        }
+        for (hipStream_t w : {c->stream, c->stream2}) HIPCHK(c, hipStreamWaitEvent(w, sev, 0));
+        c->ev_pool.push_back(sev);   // (recorded and waited for: the waits keep their own reference to this recording)
+      }
+      b->scan_chained = true;
+      c->scan_chained_n++;
+      const int32_t rc = decode_tail(c, b, (size_t)bound, async, (async && !c->pending.empty()) ? c->pending.back() : nullptr);
+      if (rc != ETLG_OK) return rc;
+      guard.b = nullptr;
+      *out = b;
+      if (!async) return finish_batch(c, b);
+      b->pending = true; b->v.on_device = 1; fill_view_common(b); c->pending.push_back(b);
+      return ETLG_OK;
+    }
     if (async) {
       // The scan of THIS batch runs on its own stream while the previous batch is still being decoded on the context's, and
       // nobody waits for it here: the call returns with the scan in flight and the NEXT call (or the batch's sync) collects
       // the frame count and enqueues the decode. The input must be complete when the call is made (include/etlg.h).
       if (!c->scan_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
-      if (c->offs_pool.empty()) c->offs_pool.push_back(new DevBuf());
-      b->scan_offs = c->offs_pool.back(); c->offs_pool.pop_back();
       HIPCHK(c, scan_begin(c, c->scan_job, d_in_ptr, len, c->scan_stream, *b->scan_offs));
       b->deferred = true; b->pending = true; b->v.on_device = 1;
       c->deferred = b; c->pending.push_back(b);
@@ -1057,6 +1102,7 @@ int32_t flush_deferred(etlg_ctx* c) {
     const hipError_t e = scan_collect(c, c->scan_job, &nframes);
     if (e != hipSuccess) rc = lib_error(c, ETLG_DeviceError, hipGetErrorString(e));
     else if (nframes >= (1u << 30)) rc = lib_error(c, ETLG_InvalidArgument, "batch too large (max 4 GiB, 2^30 frames)");
+    else { c->scan_last_nf = nframes; c->scan_last_len = b->len; }
   }
   if (rc == ETLG_OK) {
     // A batch whose boundary scan was deferred joined the chain when the stream had shown no Relation / DDL frame. If it has by now (a
@@ -1119,6 +1165,7 @@ int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg
   // batch issued just before this one leaves in its result block
   p.in_txn = c->in_txn; p.final_lsn = c->final_lsn; p.next_ord = c->next_ord;
   p.carry = (async && prev && !c->copy.active) ? prev->d_res_blk : nullptr;   // (table-copy batches: a virtual transaction each, nothing carried)
+  p.nframes_dev = b->scan_chained ? b->d_scan_res : nullptr;
 
   HIPCHK(c, c->d_res.ensure(sizeof(DevResult) * etlg_ctx::kResRing));
   const uint32_t res_slot = c->res_seq % etlg_ctx::kResRing;

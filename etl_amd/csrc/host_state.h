@@ -43,7 +43,7 @@ extern "C" void etlg_k_ctl_span(const uint8_t* tags, uint32_t nframes, const uin
 extern "C" void etlg_k_ctl_gather(const uint8_t* in, const uint32_t* offs, const uint32_t* frames, uint32_t nkeep, uint32_t* lens, const uint32_t* out_offs, uint8_t* out, hipStream_t s);
 extern "C" void etlg_k_launch_fused(int blk, const DecParams* p, const void* q, hipStream_t s);
 extern "C" int etlg_k_fused_set_lds(void);
-extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* scratch, uint32_t* hints, uint32_t* hflag,
+extern "C" void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* scratch, uint32_t* result, uint32_t* hints, uint32_t* hflag,
                                      int sequential, hipStream_t s);
 extern "C" size_t etlg_k_bounds_scratch_bytes(size_t ntiles);
 extern "C" uint32_t etlg_k_bounds_tile_bytes(void);
@@ -230,7 +230,7 @@ struct OutSet {  // device output arrays of one batch
 };
 
 struct ProfRec { int which; hipEvent_t a, b; };
-struct ScanJob { const uint8_t* d_in = nullptr; size_t len = 0; hipStream_t s = nullptr; DevBuf* offs = nullptr; size_t cap = 0; uint8_t* cur = nullptr; };
+struct ScanJob { const uint8_t* d_in = nullptr; size_t len = 0; hipStream_t s = nullptr; DevBuf* offs = nullptr; size_t cap = 0; uint8_t* cur = nullptr; uint32_t* res = nullptr; };
 struct HostErr { int32_t code = 0; uint32_t rank = 0; };
 struct EpochRec { uint32_t table_id; DevEpoch ep; };
 
@@ -301,6 +301,9 @@ struct etlg_ctx {
   unsigned long long overlapped = 0;   // debugging aid: batches launched beside their predecessor
   // result blocks: a ring re-initialised once per lap with one copy
   static constexpr uint32_t kResRing = 32;
+  uint64_t scan_last_nf = 0, scan_last_len = 0;   // frames and bytes of the last batch whose boundaries were scanned on the device: the next one's grids are sized by its bytes per frame (+ 25 %)
+  bool scan_chain_mode = true;   // ETLG_SCAN_CHAIN=0: a batch without a sidecar always waits for its frame count on the host before its decode is enqueued (round 5)
+  uint64_t scan_chained_n = 0, scan_chain_redone = 0;
   uint64_t chain_reissued = 0;   // ASYNC batches enqueued again behind a batch that was decoded again (finish_batch, reissue_successors)
   bool chain_reissue = false;    // ETLG_CHAIN_REISSUE=1: the successors of a batch that was decoded again are enqueued again, chained to its new result
                                  // (reissue_successors). Built and measured in round 6 — it LOST on the delete-in-every-10th-batch leg (548 against 905 GB/s:
@@ -430,6 +433,10 @@ struct etlg_batch {
   bool deferred = false;        // ASYNC without a sidecar: scan in flight, decode not enqueued yet (etlg_ctx::deferred)
   const uint8_t* d_in_ptr = nullptr; const uint32_t* user_offs = nullptr;
   DevBuf* scan_offs = nullptr;  // ASYNC without a sidecar: the batch's own offsets (from the context's pool)
+  bool scan_chained = false;    // ... and its decode (the fixed-width plan) was enqueued BEHIND the scan, with the frame count read on the device (DecParams.nframes_dev)
+  uint32_t* d_scan_res = nullptr;   // the scan's result words, behind the batch's offsets
+  hipStream_t scan_s = nullptr;     // ... the stream that scan runs on (ASYNC: the context's scan stream; otherwise the decode stream itself)
+  uint64_t nf_est = 0;              // ... the frame count the stream has shown (params.nframes is the bound the grids are sized by; LDS windows are sized by this)
   int plan_decided = -1;      // decode_tail: -1 not decided yet, 0 / 1 = the first attempt is the generic kernel / the fixed-width plan
   int sidx = 0;               // decode stream the batch's first attempt was enqueued on (0: etlg_ctx::stream, 1: stream2)
   int ctl_set = 0;            // which set of control pre-pass buffers its pre-pass wrote (etlg_ctx::ctl_alt is set 1)

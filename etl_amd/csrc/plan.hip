@@ -628,11 +628,32 @@ DEV void plan_stage_local(DecParams& p, const PlanParams& q, u8* smem, uint32_t 
   }
 }
 
+// A batch whose record-boundary scan was still running when this launch was enqueued (DecParams.nframes_dev): the frame count is read from
+// the device now; p.nframes / q.ntiles were the bound the grid was sized by. Returns false when there is nothing to do here — the scan did
+// not hold, the batch is empty or larger than the bound (DevResult.fused_fail bit 5: the host collects the scan and decodes the batch again
+// with the count in hand) — after letting a batch that may be polling for this one's carried state go on (it is decoded again as well).
+DEV bool plan_frames_from_device(DecParams& p, PlanParams& q) {
+  if (!p.nframes_dev) return true;
+  const ETLG_CONST_AS uint32_t* r = (const ETLG_CONST_AS uint32_t*)(uintptr_t)p.nframes_dev;
+  const uint32_t nf = r[0], flags = r[1] | r[2];   // ([2]: tiles of the scan whose guess did not hold — the boundaries are not the chain's)
+  if (flags != 0 || nf == 0 || nf > p.nframes) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      atomicOr(&p.res->fused_fail, 32u);
+      __hip_atomic_store(&p.res->carry_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return false;
+  }
+  p.nframes = nf;
+  q.ntiles = (nf + 63u) >> 6;
+  return true;
+}
+
 // TWO: a wave takes two consecutive tiles through ONE LDS window — local(A), local(B), finish(A), finish(B): half as many waves
 // as tiles (a 64 MiB cfg2 batch is 4 645 waves: one round of the chip's ~5 100 slots instead of 1.8), and A's look-back is resolved
 // a whole tile's work after it was published. Only for rows of up to 8 dwords (A's image waits in registers).
 template <bool TWO, int RD>
-DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
+DEV void plan_kernel(DecParams& p, const PlanParams& q_in, u8* smem) {
+  PlanParams q = q_in;
   const uint32_t lane = threadIdx.x;
   unsigned long long tprev = (q.dbg & 32u) ? clock64() : 0ull;
   const uint32_t tile = blockIdx.x;   // (the timeline's slot)
@@ -644,7 +665,9 @@ DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
   // ASYNC chain: the state the batch before this one left on the device — read now (that batch has finished: same stream), or, for
   // a batch the host put on the second stream, by the few tiles that need it, when they need it (plan_late_carry)
   if (!(p.flags & 16u) && !load_carry(p)) return;
+  if (!plan_frames_from_device(p, q)) return;
   const uint32_t t0 = TWO ? 2u * blockIdx.x : blockIdx.x;
+  if (t0 >= q.ntiles) return;   // (a grid sized by a bound)
   const TileSpan sa = plan_span(p, t0);
   const PlanPreWords pwa = plan_pre_load(q, t0), pwb = TWO ? plan_pre_load(q, t0 + 1u) : PlanPreWords();
   TileSpan sb = sa;
@@ -696,6 +719,8 @@ DEV void plan_kernel(DecParams& p, const PlanParams& q, u8* smem) {
 // scalar loads, no other tile.
 __global__ __launch_bounds__(kPreWaves * 64) void k_plan_pre(DecParams p, PlanParams q) {
   __shared__ unsigned long long s_wagg[kPreWaves][2];
+  if (!plan_frames_from_device(p, q)) return;   // (the decode kernel behind this one reports it)
+  if (blockIdx.x >= ((q.ntiles + (1u << kPreGroupLog) - 1u) >> kPreGroupLog)) return;
   const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), g = blockIdx.x;
   const uint32_t t0 = (g << kPreGroupLog) + wave * (uint32_t)kPreTilesPerWave;
   // offsets: lane l of iteration i owns frame (t0 + i) * 64 + l; its end is the next lane's start (the next iteration's lane 0 for lane 63)

@@ -370,11 +370,12 @@ size_t etlg_k_bounds_scratch_bytes(size_t ntiles) {
   return 64 + ntiles * sizeof(TileSum) + ntiles * sizeof(TilePre) + (((ntiles / RB + 2) * sizeof(TilePre) + 63) & ~(size_t)63) + ntiles * CAP * 2 + 64;
 }
 
-void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* scratch, uint32_t* hints, uint32_t* hflag, int sequential, hipStream_t s) {
+void etlg_k_launch_bounds(const uint8_t* in, uint64_t len, uint32_t* offs, uint32_t offs_cap, void* scratch, uint32_t* result, uint32_t* hints, uint32_t* hflag, int sequential, hipStream_t s) {
   BoundsParams q;
   q.in = in; q.len = len; q.offs = offs; q.offs_cap = offs_cap;
   q.ntiles = (uint32_t)((len + TB - 1) / TB);
-  q.result = (uint32_t*)scratch; q.sum = (TileSum*)((uint8_t*)scratch + 64);
+  q.result = result ? result : (uint32_t*)scratch;   // (a batch decoded behind its scan keeps the result words in a block of its own, host.cpp)
+  q.sum = (TileSum*)((uint8_t*)scratch + 64);
   q.pre = (TilePre*)(q.sum + q.ntiles);
   q.blk = q.pre + q.ntiles;
   q.rows = (uint16_t*)((uint8_t*)q.blk + ((((size_t)q.ntiles / RB + 2) * sizeof(TilePre) + 63) & ~(size_t)63));

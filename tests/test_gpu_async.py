@@ -374,6 +374,61 @@ def test_async_chain_without_a_sidecar():
     paths = _run_chain(w, pieces, sidecar=False)
 
 
+@pytest.mark.parametrize("asynchronous", [True, False])
+def test_decode_enqueued_behind_its_boundary_scan(asynchronous):
+    """frame_offsets = NULL on a fixed-width stream: from the second batch on the decode is enqueued BEHIND the batch's boundary scan —
+    grids sized by a bound taken from the bytes per frame of the batch before, the frame count read on the device
+    (DecParams.nframes_dev, plan.hip). Batches of very different sizes; a batch of one-row transactions right after batches of
+    1000-row ones (half again as many frames per byte: beyond the bound, decoded again with the count in hand); a batch whose bytes
+    stop being frames in the middle (the scan's malformed-header rule: the rest is one frame, which the decoder rejects — and the
+    scan's tiles behind it guessed wrong, which the decode kernels must notice on the device). ASYNC and one finished batch per
+    call; every batch against the oracle."""
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    w = synth.cfg2()
+    w2 = synth.Workload([synth.table_fixed()], 0xE71B0B, rows_per_txn=1, start_lsn=0x9000000, name="one_row_transactions")
+
+    def cut(buf, offs, edges):
+        out = []
+        for a, b in zip(edges[:-1], edges[1:]):
+            o = offs[a:b + 1].astype(np.int64)
+            out.append((buf[int(o[0]):int(o[-1])].copy(), (o - o[0]).astype(np.uint32)))
+        return out
+    buf, offs = w.fill(2 << 20)
+    nf = len(offs) - 1
+    pieces = cut(buf, offs, [0, nf // 64, nf // 32, nf])
+    buf, offs = w2.fill(3 << 20)
+    pieces.append((buf.copy(), offs.astype(np.uint32)))           # batch 3: beyond the bound
+    buf, offs = w2.fill(3 << 19)
+    nf = len(offs) - 1
+    pieces += cut(buf, offs, [0, 700, nf // 2, nf])                # batches 4 (tiny), 5 (damaged below), 6
+    b5, o5 = pieces[5]
+    k = len(o5) // 2
+    b5[int(o5[k])] = 0x00
+    pieces[5] = (b5, np.concatenate([o5[:k + 1], o5[-1:]]).astype(np.uint32))
+    o, d = oracle.Oracle(), Decoder(0)
+    w.register(o)
+    w.register(d)
+    dev = DevBufs(pieces)
+    fl = abi.F_INPUT_ON_DEVICE | abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | (abi.F_ASYNC if asynchronous else 0)
+    got = []
+    for (p, n, po, nfr) in dev.items:
+        got.append(d.decode_device(p, n, None, 0, fl))
+    for i, ((pb, po), b) in enumerate(zip(pieces, got)):
+        rb = o.decode(pb, po)
+        rc = b.sync() if asynchronous else b.rc
+        assert (rb.err_code != 0) == (rc != 0), f"batch {i}: oracle error {rb.err_code} vs rc {rc} ({b.error})"
+        if rb.err_code:
+            assert (b.error.code, b.error.frame_index) == (rb.err_code, rb.err_frame), f"batch {i}"
+        diff = rb.host_batch().diff(b.host())
+        assert not diff, f"batch {i}: {diff[:6]}"
+        b.close()
+    chained, redone = d.debug_scan_chained()
+    d.close()
+    if os.environ.get("ETLG_SCAN_CHAIN", "1") != "0":
+        assert chained >= 4 and redone >= 1, (chained, redone)
+
+
 def test_deferred_scan_is_collected_by_whatever_comes_next():
     """An ASYNC batch without a sidecar returns with its boundary scan in flight; the decode is enqueued by the next call on the
     context — another decode, a control-plane call, a frame-tag query, the batch's own sync, its free, or the context's destroy —

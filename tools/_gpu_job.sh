@@ -1,6 +1,5 @@
-python tools/wide_ab.py rows > gpurun_out/r06l_wide.txt 2>&1
-python tools/rows_ab.py rows > gpurun_out/r06_ab.txt 2>&1
-ETLG_ROWS=0 python tools/rows_ab.py cells >> gpurun_out/r06_ab.txt 2>&1
-ETLG_FUSED_DBG=8 python tools/rows_ab.py rows_phases >> gpurun_out/r06_ab.txt 2>&1
-timeout 600 python tools/chain_probe.py cfg3 rows_two: 2>&1 | grep workload >> gpurun_out/r06l_wide.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -4 > gpurun_out/r06l_tests.txt
+O=gpurun_out
+( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $O/r06v_tests.log 2>&1; tail -n 4 $O/r06v_tests.log
+python tools/nosidecar_probe.py chained:ETLG_SCAN_CHAIN=1 host_count:ETLG_SCAN_CHAIN=0 > $O/r06v_nosidecar_probe.txt 2>&1
+for m in nosidecar mixed cfg2; do timeout 200 python tools/async_long_fuzz.py 45 6 $m 2>&1 | tail -2 >> $O/r06v_long_fuzz.txt; done
+( time timeout 900 python bench.py > $O/r06v_bench.json 2> $O/r06v_bench.err ); tail -c 300 $O/r06v_bench.json
