@@ -213,7 +213,7 @@ def to_device(pool, dev):
     return d
 
 
-def deferred_cells(dec, item):
+def deferred_cells(dec, item, extra_flags=0):
     """Share of the row cells of one batch that the kernels hand back DEFERRED (the host finishes them: json, arrays, the
     float / temporal texts the device rule does not settle) — counted from the arena's 2-bit cell states, outside any timed
     region (VERDICT r01 #9: "the deferred fraction is reported in the bench line")."""
@@ -221,7 +221,7 @@ def deferred_cells(dec, item):
 
     from etl_amd import abi
     tb, to, nbytes, nfr = item
-    b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL)
+    b = dec.decode_device(tb.data_ptr(), nbytes, to.data_ptr(), nfr, abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | extra_flags)
     hb = b.host()
     b.close()
     cells = deferred = 0
@@ -541,9 +541,29 @@ def leg_wide70(dev_id, dev, nrows, reps):
     kern = kernel_table(dec.profile_read())
     dec.profile(False)
     paths = {**dec.debug_paths(), **dec.debug_rows()}
+    # the same chain with ETLG_F_FINISH_CELLS: every batch's array cells typed and float cells settled on the device when it is synced
+    # (etlg_batch_finish_cells: two more kernels over the arena and two stops per batch) — what a consumer of Cell::Array pays instead of
+    # re-parsing 31 of the 68 cells of every row on the host
+    dfrac = deferred_cells(dec, items[0])
+    dfrac_fin = deferred_cells(dec, items[0], abi.F_FINISH_CELLS)
+    pf = Pipeline(dec, items, FL | abi.F_FINISH_CELLS, True)
+    for _ in range(4):
+        pf.issue()
+    pf.drain()
+    torch.cuda.synchronize()
+    pf = Pipeline(dec, items, FL | abi.F_FINISH_CELLS, True)
+    t0 = time.perf_counter()
+    for _ in range(max(8, reps // 2)):
+        pf.issue()
+    pf.drain()
+    torch.cuda.synchronize()
+    dtf = time.perf_counter() - t0
     dec.close()
     alg = (q.bytes + SIDECAR_BYTES_PER_FRAME * q.frames + q.out_bytes) / 8
     return {"value": round(pl.bytes / dt / 1e9, 3), "unit": "GB/s", "events_per_s": round(pl.events / dt, 1),
+            "deferred_cells": dfrac,
+            "finish_cells": {"value": round(pf.bytes / dtf / 1e9, 3), "unit": "GB/s", "deferred_cells": dfrac_fin,
+                             "note": "ETLG_F_FINISH_CELLS: arrays typed (etlg_array_hdr entries) and floats settled in the arena on the device; what is left DEFERRED is json / jsonb and json arrays"},
             "workload": f"type-matrix table, {len(synth.TYPE_MATRIX)} columns (every scalar class, 31 array columns, json): one batch of {len(buf)} bytes / {len(offs) - 1} frames "
                         f"(avg {len(buf) // (len(offs) - 1)} B), I / U(key) / D(key), NO_CONTROL | ASYNC, device-resident in / out",
             "batches": reps, "paths": paths, "roofline": roofline_with_traffic(kern, alg, "wide70")}

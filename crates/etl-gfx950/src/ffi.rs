@@ -91,6 +91,9 @@ pub const ETLG_F_INPUT_ON_DEVICE: u32 = 1 << 0;
 pub const ETLG_F_OUTPUT_ON_DEVICE: u32 = 1 << 1;
 pub const ETLG_F_NO_CONTROL: u32 = 1 << 2;
 pub const ETLG_F_ASYNC: u32 = 1 << 3;
+pub const ETLG_F_FINISH_CELLS: u32 = 1 << 4;
+pub const ETLG_FINISH_ARRAYS: u32 = 1;
+pub const ETLG_FINISH_FLOATS: u32 = 2;
 
 // ---- batch (arena)
 pub const ETLG_EV_BEGIN: u8 = b'B';
@@ -232,6 +235,24 @@ pub struct etlg_size_model {
 }
 
 pub const ETLG_SIZE_HINT_INCOMPLETE: u64 = 1 << 63;
+
+/// A typed array in the heap (include/etlg.h: the finish pass).
+#[repr(C)]
+pub struct etlg_array_hdr {
+    pub n_elems: u32,
+    pub elem_class: u8,
+    pub elem_bytes: u8,
+    pub reserved: u16,
+}
+
+#[repr(C)]
+pub struct etlg_finish_stats {
+    pub deferred_seen: u64,
+    pub arrays_typed: u64,
+    pub floats_settled: u64,
+    pub left_deferred: u64,
+    pub heap_bytes_added: u64,
+}
 
 #[repr(C)]
 pub struct etlg_columns {
@@ -383,6 +404,7 @@ extern "C" {
     pub fn etlg_rowbinary_view_get(rb: *const etlg_rowbinary, out: *mut etlg_rowbinary_view) -> i32;
     pub fn etlg_rowbinary_free(rb: *mut etlg_rowbinary);
     pub fn etlg_batch_size_hints(ctx: *mut etlg_ctx, batch: *mut etlg_batch, model: *const etlg_size_model, flags: u32, out: *mut u64) -> i32;
+    pub fn etlg_batch_finish_cells(ctx: *mut etlg_ctx, batch: *mut etlg_batch, what: u32, stats: *mut etlg_finish_stats) -> i32;
     pub fn etlg_ctx_slots(ctx: *const etlg_ctx, n_slots: *mut u32, slots: *mut *const etlg_slot_desc) -> i32;
 
     pub fn etlg_ctx_profile(ctx: *mut etlg_ctx, enable: i32) -> i32;

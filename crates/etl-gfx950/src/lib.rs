@@ -125,7 +125,8 @@ impl GpuDecoder {
     /// issue order.
     pub fn decode_async(&mut self, staged: StagedBatch) -> Result<InFlight, (StagedBatch, EtlError)> {
         let mut batch = ptr::null_mut();
-        let flags = ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE | if staged.control_free { ETLG_F_NO_CONTROL } else { 0 };
+        // (ETLG_F_FINISH_CELLS: arrays arrive typed and floats exact — materialize.rs then parses no array text on the host)
+        let flags = ETLG_F_ASYNC | ETLG_F_OUTPUT_ON_DEVICE | ETLG_F_FINISH_CELLS | if staged.control_free { ETLG_F_NO_CONTROL } else { 0 };
         let rc = unsafe { etlg_decode(self.ctx, staged.frames_ptr(), staged.len, staged.offsets_ptr(), staged.nframes, flags, &mut batch) };
         if batch.is_null() {
             let _ = rc;

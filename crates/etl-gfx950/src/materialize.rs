@@ -1,7 +1,9 @@
 //! Arena → `Vec<Event>`: rebuilds the values the apply loop pushes into `EventBatch` (crates/etl/src/replication/apply.rs:
 //! 1918-1928) from the columnar batch `etlg_decode` returns (`include/etlg.h`, "batch (arena)"). Every `Cell` variant of
-//! crates/etl/src/data/cell.rs:19-57 is covered; a cell the device handed back DEFERRED (json / jsonb, arrays, chrono's
-//! fallback grammars, the rare inconclusive float) is finished HERE with the reference's own
+//! crates/etl/src/data/cell.rs:19-57 is covered. With `ETLG_F_FINISH_CELLS` (round 6) arrays arrive TYPED (`array_of` below reads
+//! the entry the device wrote: no text is parsed on the host) and no float arrives DEFERRED; what the device still hands back
+//! DEFERRED (json / jsonb, json arrays, a literal the reference rejects — and, without the flag, every array and the rare
+//! inconclusive float) is finished HERE with the reference's own
 //! `parse_cell_from_postgres_text` (crates/etl/src/postgres/codec/text.rs:32-153) on the validated source text the arena
 //! carries, so such cells cannot differ from the CPU decoder by construction.
 //!
@@ -10,7 +12,7 @@
 use std::sync::Arc;
 
 use chrono::{DateTime, NaiveDate, NaiveDateTime, NaiveTime, TimeZone, Utc};
-use etl::data::{Cell, OldTableRow, PartialTableRow, TableRow, UpdatedTableRow};
+use etl::data::{ArrayCell, Cell, OldTableRow, PartialTableRow, TableRow, UpdatedTableRow};
 use etl::error::{ErrorKind, EtlResult};
 use etl::event::{BeginEvent, CommitEvent, DeleteEvent, Event, InsertEvent, RelationEvent, TruncateEvent, UpdateEvent};
 use etl::postgres::codec::text::parse_cell_from_postgres_text;
@@ -121,10 +123,86 @@ fn cell(a: &Arena<'_>, col: &etlg_slot_col, state: u8, at: usize) -> EtlResult<O
                 },
             })
         }
-        // ETLG_TC_STRING; json / arrays never arrive as VALUE (always DEFERRED)
+        // an array the finish pass typed on the device (ETLG_F_FINISH_CELLS / etlg_batch_finish_cells): no text is parsed here
+        ETLG_TC_ARRAY => Cell::Array(array_of(a.heap_ref(at))?),
+        // ETLG_TC_STRING; json never arrives as VALUE (always DEFERRED)
         _ => Cell::String(unsafe { String::from_utf8_unchecked(a.heap_ref(at).to_vec()) }),
     };
     Ok(Some(c))
+}
+
+/// A typed array entry (etlg_array_hdr, include/etlg.h) -> ArrayCell (crates/etl/src/data/cell.rs:98-134): header, validity words,
+/// then element slots (laid out like row slots of the element class) or end offsets + bytes.
+fn array_of(raw: &[u8]) -> EtlResult<ArrayCell> {
+    let u32_at = |o: usize| u32::from_le_bytes(raw[o..o + 4].try_into().unwrap());
+    let u64_at = |o: usize| u64::from_le_bytes(raw[o..o + 8].try_into().unwrap());
+    let n = u32_at(0) as usize;
+    let (elem, eb) = (raw[4] as i32, raw[5] as usize);
+    let vw = (n + 31) / 32;
+    let valid = |k: usize| (u32_at(8 + 4 * (k / 32)) >> (k % 32)) & 1 != 0;
+    let at0 = 8 + 4 * vw;
+    macro_rules! fixed {
+        ($variant:ident, $f:expr) => {{
+            let mut v = Vec::with_capacity(n);
+            for k in 0..n {
+                let o = at0 + k * eb;
+                v.push(if valid(k) { Some($f(o)?) } else { None });
+            }
+            ArrayCell::$variant(v)
+        }};
+    }
+    let ok = |x| -> EtlResult<_> { Ok(x) };
+    Ok(match elem {
+        ETLG_TC_BOOL => fixed!(Bool, |o| ok(u32_at(o) != 0)),
+        ETLG_TC_I16 => fixed!(I16, |o| ok(u32_at(o) as i32 as i16)),
+        ETLG_TC_I32 => fixed!(I32, |o| ok(u32_at(o) as i32)),
+        ETLG_TC_U32 => fixed!(U32, |o| ok(u32_at(o))),
+        ETLG_TC_I64 => fixed!(I64, |o| ok(u64_at(o) as i64)),
+        ETLG_TC_F32 => fixed!(F32, |o| ok(f32::from_bits(u32_at(o)))),
+        ETLG_TC_F64 => fixed!(F64, |o| ok(f64::from_bits(u64_at(o)))),
+        ETLG_TC_DATE => fixed!(Date, |o| date_of(u32_at(o) as i32)),
+        ETLG_TC_TIME => fixed!(Time, |o| time_of(u32_at(o), u32_at(o + 4))),
+        ETLG_TC_TIMESTAMP => fixed!(Timestamp, |o| Ok::<_, etl::error::EtlError>(NaiveDateTime::new(date_of(u32_at(o) as i32)?, time_of(u32_at(o + 4), u32_at(o + 8))?))),
+        ETLG_TC_TIMESTAMPTZ => fixed!(TimestampTz, |o| Ok::<_, etl::error::EtlError>(Utc.from_utc_datetime(&NaiveDateTime::new(date_of(u32_at(o) as i32)?, time_of(u32_at(o + 4), u32_at(o + 8))?)))),
+        ETLG_TC_TIMETZ => fixed!(TimeTz, |o| {
+            let offset = chrono::FixedOffset::east_opt(u32_at(o + 8) as i32)
+                .ok_or_else(|| etl_error!(ErrorKind::ConversionError, "Datetime parsing failed", "UTC offset out of range in decoded arena"))?;
+            Ok::<_, etl::error::EtlError>(PgTimeTz::new(time_of(u32_at(o), u32_at(o + 4))?, offset))
+        }),
+        ETLG_TC_UUID => fixed!(Uuid, |o| ok(Uuid::from_bytes(raw[o..o + 16].try_into().unwrap()))),
+        _ => {
+            // var-len elements: end offsets, then the data
+            let data0 = at0 + 4 * n;
+            let piece = |k: usize| {
+                let lo = if k == 0 { 0 } else { u32_at(at0 + 4 * (k - 1)) as usize };
+                &raw[data0 + lo..data0 + u32_at(at0 + 4 * k) as usize]
+            };
+            match elem {
+                ETLG_TC_BYTEA => ArrayCell::Bytes((0..n).map(|k| valid(k).then(|| piece(k).to_vec())).collect()),
+                ETLG_TC_NUMERIC => ArrayCell::Numeric((0..n).map(|k| valid(k).then(|| numeric_of(piece(k)))).collect()),
+                _ => ArrayCell::String((0..n).map(|k| valid(k).then(|| unsafe { String::from_utf8_unchecked(piece(k).to_vec()) })).collect()),
+            }
+        }
+    })
+}
+
+/// A numeric heap entry (etlg_numeric_hdr + base-10000 digits) -> PgNumeric (crates/etl-postgres/src/numeric.rs:75-96).
+fn numeric_of(raw: &[u8]) -> PgNumeric {
+    let (kind, sign) = (raw[0], raw[1]);
+    let weight = i16::from_le_bytes([raw[2], raw[3]]);
+    let scale = u16::from_le_bytes([raw[4], raw[5]]);
+    let nd = u16::from_le_bytes([raw[6], raw[7]]) as usize;
+    match kind {
+        ETLG_NUM_NAN => PgNumeric::NaN,
+        ETLG_NUM_PINF => PgNumeric::PositiveInfinity,
+        ETLG_NUM_NINF => PgNumeric::NegativeInfinity,
+        _ => PgNumeric::Value {
+            sign: if sign == 0 { Sign::Positive } else { Sign::Negative },
+            weight,
+            scale,
+            digits: (0..nd).map(|i| i16::from_le_bytes([raw[8 + 2 * i], raw[9 + 2 * i]])).collect(),
+        },
+    }
 }
 
 enum RowImage {

@@ -54,6 +54,8 @@ F_INPUT_ON_DEVICE = 1 << 0
 F_OUTPUT_ON_DEVICE = 1 << 1
 F_NO_CONTROL = 1 << 2
 F_ASYNC = 1 << 3
+F_FINISH_CELLS = 1 << 4
+FINISH_ARRAYS, FINISH_FLOATS = 1, 2
 
 OLD_NONE, OLD_FULL, OLD_KEY, FLAG_PARTIAL = 0, 1, 2, 4
 CELL_VALUE, CELL_NULL, CELL_MISSING, CELL_DEFERRED = range(4)
@@ -120,6 +122,10 @@ class RowBinaryView(C.Structure):   # etlg_rowbinary_view
 class SizeModel(C.Structure):   # etlg_size_model
     _fields_ = [(n, C.c_uint32) for n in ("begin_event", "commit_event", "insert_event", "update_event", "delete_event", "truncate_event",
                                           "relation_event", "replicated_table_schema", "table_row", "cell")] + [("_reserved", C.c_uint32 * 2)]
+
+
+class FinishStats(C.Structure):   # etlg_finish_stats
+    _fields_ = [(n, C.c_uint64) for n in ("deferred_seen", "arrays_typed", "floats_settled", "left_deferred", "heap_bytes_added")]
 
 
 SIZE_HINT_INCOMPLETE = 1 << 63

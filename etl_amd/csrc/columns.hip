@@ -11,6 +11,7 @@
 // A cell the decode kernels handed back DEFERRED is null in `validity` and set in the column's `deferred` bitmap: the consumer
 // finishes it from the arena (row_event names the event). Integer / byte work, HBM-bound: no MFMA.
 #include "codec.hip.h"
+#include "float_slow.h"
 #include <type_traits>
 
 namespace etlg {
@@ -799,7 +800,7 @@ DEV uint32_t arr_strip_dims(const u8* s, uint32_t n, uint32_t& start) {   // str
 // BYTEA elements (ArrayCell::Bytes, parse_bytea_hex_string per element, codec/hex.rs:11-52): TEXT walks with `hex` set — the element's
 // characters are "\x" + hex pairs, decoded as they come; w[0] = the byte count.
 template <bool TEXT, class F, class D>
-DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& count, F&& elem, D&& dst) {
+DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& count, F&& elem, D&& dst, bool exact_floats = false) {
   const bool hex = TEXT && elem_cls == ETLG_TC_BYTEA;
   bool hex_bad = false; uint32_t nib = 0;
   uint32_t start;
@@ -860,7 +861,11 @@ DEV uint32_t arr_walk(const u8* s0, uint32_t n0, uint32_t elem_cls, uint32_t& co
     } else if (!is_null) {
       uint32_t hcur = 0, st = 0;
       if (const uint32_t e = decode_text_cell<true>(elem_cls, val, vl, w, (u8*)scratch, hcur, st, false)) return e;
-      if (st != ETLG_CELL_VALUE) return ARR_HOST;   // a float text the device rule does not settle
+      if (st != ETLG_CELL_VALUE) {   // a float text the fast rule does not settle: the exact conversion (finish pass), else the host's
+        if (!exact_floats || !(elem_cls == ETLG_TC_F32 || elem_cls == ETLG_TC_F64)) return ARR_HOST;
+        const uint64_t bits = parse_float_exact_t([&](uint32_t i) { return (uint32_t)val[i]; }, vl, elem_cls == ETLG_TC_F32);
+        w[0] = (uint32_t)bits; w[1] = (uint32_t)(bits >> 32);
+      }
     }
     elem(count, is_null, w, (const u8*)scratch);
     count++;
@@ -1589,6 +1594,164 @@ __global__ __launch_bounds__(256) void k_size_hints(HintJob j) {
   j.out[i] = v | (inc ? (1ull << 63) : 0ull);
 }
 
+// ---- the finish pass (etlg_batch_finish_cells, include/etlg.h): cells a decode left ETLG_CELL_DEFERRED are settled in the arena itself.
+// Array literals (parse_cell_from_postgres_text_array, crates/etl/src/postgres/codec/text.rs:163-312) become typed heap entries — header,
+// validity bits, element slots or end offsets + bytes (include/etlg.h: etlg_array_hdr) — appended behind the batch's heap; float texts the
+// fast rule could not decide get their exactly rounded bits (float_slow.h). One thread per (event, row image, finishable column); a cell
+// the device does not settle (a malformed literal, a json element, a numeric element of more than 40 characters) stays DEFERRED for the
+// host, exactly as before. Two walks of the text like k_arr_count / k_arr_fill: sizes -> exclusive scan -> entries.
+enum : uint32_t { FIN_ARRAYS = 1u, FIN_FLOATS = 2u };
+
+struct FinCell { bool on; uint32_t cls, elem; u8* slot; uint32_t* stw; uint32_t stsh; };
+DEV FinCell fin_cell(const FinJob& j, uint64_t t) {
+  FinCell c{false, 0, 0, nullptr, nullptr, 0};
+  const uint32_t K = 2u * j.maxfin;
+  const uint64_t ev = t / K;
+  const uint32_t r = (uint32_t)(t % K), img = r / j.maxfin, q = r % j.maxfin;
+  if (ev >= j.n_events) return c;
+  const uint32_t kind = j.ev_kind[ev];
+  if (!(kind == 'I' || kind == 'U' || kind == 'D')) return c;
+  const uint32_t s = j.ev_slot[ev];
+  if (s >= j.n_slots) return c;
+  const uint32_t* sl = j.slots + 7 * s;
+  if (q >= sl[6]) return c;
+  const uint32_t col = j.fin[sl[5] + q];
+  const uint32_t* cd = j.cols + 3 * (size_t)(sl[4] + col);
+  const uint32_t ok = kind == 'I' ? 0u : (uint32_t)j.ev_flags[ev] & 3u;
+  uint64_t base = j.ev_body[ev];
+  uint32_t pos = col, off = cd[1] & 0xFFFFu;
+  if (img == 0) {
+    if (ok == ETLG_OLD_NONE) return c;
+    if (ok == ETLG_OLD_KEY) { if (!((cd[0] >> 8) & 1u)) return c; pos = cd[2]; off = cd[1] >> 16; }
+  } else {
+    if (kind == 'D') return c;
+    base += ok == ETLG_OLD_KEY ? sl[3] : ok == ETLG_OLD_FULL ? sl[2] : 0u;
+  }
+  u8* stb = j.fixed + base + pos / 4;
+  const uint32_t st = (*stb >> (2 * (pos % 4))) & 3u;
+  if (st != ETLG_CELL_DEFERRED) return c;
+  c.on = true; c.cls = cd[0] & 0xFFu; c.elem = (cd[0] >> 16) & 0xFFu;
+  c.slot = j.fixed + base + off;
+  c.stw = (uint32_t*)((uintptr_t)stb & ~(uintptr_t)3);
+  c.stsh = 8u * (uint32_t)((uintptr_t)stb & 3u) + 2u * (pos % 4);
+  return c;
+}
+DEV bool fin_elem_fixed(uint32_t e) { return e == ETLG_TC_BOOL || e == ETLG_TC_I16 || e == ETLG_TC_I32 || e == ETLG_TC_I64 || e == ETLG_TC_U32 || e == ETLG_TC_F32 || e == ETLG_TC_F64 ||
+                                             e == ETLG_TC_DATE || e == ETLG_TC_TIME || e == ETLG_TC_TIMETZ || e == ETLG_TC_TIMESTAMP || e == ETLG_TC_TIMESTAMPTZ || e == ETLG_TC_UUID; }
+DEV bool fin_elem_var(uint32_t e) { return e == ETLG_TC_STRING || e == ETLG_TC_BYTEA || e == ETLG_TC_NUMERIC; }
+
+// bytes of the typed entry of one array literal, 0 = not settled here
+DEV uint32_t fin_array_bytes(const u8* s, uint32_t n, uint32_t elem, bool exact, uint32_t& cnt) {
+  cnt = 0;
+  uint64_t data = 0;
+  auto none = [](uint32_t) -> u8* { return nullptr; };
+  uint32_t e;
+  if (fin_elem_fixed(elem)) e = arr_walk<false>(s, n, elem, cnt, [](uint32_t, bool, const uint32_t*, const u8*) {}, none, exact);
+  else if (elem == ETLG_TC_NUMERIC) e = arr_walk<false>(s, n, elem, cnt, [&](uint32_t, bool is_null, const uint32_t* w, const u8*) { if (!is_null) data += pad4(w[1]); }, none);
+  else if (fin_elem_var(elem)) e = arr_walk<true>(s, n, elem, cnt, [&](uint32_t, bool, const uint32_t* w, const u8*) { data += w[0]; }, none);
+  else return 0;
+  if (e) return 0;
+  const uint64_t tot = 8ull + 4ull * ((cnt + 31u) >> 5) + (fin_elem_fixed(elem) ? (uint64_t)cnt * slot_bytes(elem) : 4ull * cnt + ((data + 3ull) & ~3ull));
+  return tot > 0x7FFFFFF0ull ? 0u : (uint32_t)tot;
+}
+
+// Thread u of the grid takes cell t = event * K + row, with u = row * n_events + event: the lanes of a wave hold the SAME column of
+// consecutive events (one element class, one code path: with t = u every lane of a wave decoded another class, 31 paths one after the
+// other — 7.2 ms for the fill of a 30 MB type-matrix batch), while sizes and entries stay in (event, image, column) order.
+DEV uint64_t fin_thread_cell(const FinJob& j, uint64_t u) {
+  const uint64_t K = 2ull * j.maxfin;
+  return (u % j.n_events) * K + u / j.n_events;
+}
+
+__global__ __launch_bounds__(256) void k_fin_count(FinJob j) {
+  const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= j.n_events * 2ull * j.maxfin) return;
+  const uint64_t t = fin_thread_cell(j, u);
+  const FinCell c = fin_cell(j, t);
+  uint32_t len = 0;
+  uint32_t cnt = 0;
+  if (c.on && c.cls == ETLG_TC_ARRAY && (j.what & FIN_ARRAYS)) len = fin_array_bytes(j.heap + ld32a(c.slot), ld32a(c.slot + 4), c.elem, (j.what & FIN_FLOATS) != 0, cnt);
+  j.lens[t] = len;
+  if (len) j.counts[t] = cnt;
+}
+
+DEV void fin_tally(const FinJob& j, bool seen, bool arr, bool flt, bool left) {   // one atomic per wave and counter
+  const unsigned long long ms = __ballot(seen), ma = __ballot(arr), mf = __ballot(flt), ml = __ballot(left);
+  if ((threadIdx.x & 63u) == 0) {
+    if (ms) atomicAdd(&j.stats[0], (unsigned long long)__builtin_popcountll(ms));
+    if (ma) atomicAdd(&j.stats[1], (unsigned long long)__builtin_popcountll(ma));
+    if (mf) atomicAdd(&j.stats[2], (unsigned long long)__builtin_popcountll(mf));
+    if (ml) atomicAdd(&j.stats[3], (unsigned long long)__builtin_popcountll(ml));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fin_fill(FinJob j) {
+  const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool in_grid = u < j.n_events * 2ull * j.maxfin;
+  const uint64_t t = in_grid ? fin_thread_cell(j, u) : 0;
+  FinCell c{false, 0, 0, nullptr, nullptr, 0};
+  if (in_grid) c = fin_cell(j, t);
+  bool settled = false, was_arr = false, was_flt = false;
+  if (c.on) {
+  const u8* s = j.heap + ld32a(c.slot);
+  const uint32_t n = ld32a(c.slot + 4);
+  if ((c.cls == ETLG_TC_F32 || c.cls == ETLG_TC_F64) && (j.what & FIN_FLOATS)) {
+    // (the decode validated the grammar: only texts parse_float_fast calls inconclusive are DEFERRED)
+    const uint64_t bits = parse_float_exact_t([&](uint32_t i) { return (uint32_t)s[i]; }, n, c.cls == ETLG_TC_F32);
+    ((uint32_t*)c.slot)[0] = (uint32_t)bits; ((uint32_t*)c.slot)[1] = (uint32_t)(bits >> 32);
+    settled = true; was_flt = true;
+  } else if (c.cls == ETLG_TC_ARRAY && (j.what & FIN_ARRAYS) && j.lens && j.lens[t]) {
+    const uint32_t bytes = j.lens[t], elem = c.elem;
+    const uint64_t at = j.heap_base + (uint64_t)j.offsets[t];
+    uint32_t* const e32 = (uint32_t*)(j.heap + at);
+    uint32_t cnt = j.counts[t];   // (from the count pass: the header and the validity words come before the elements)
+    auto none = [](uint32_t) -> u8* { return nullptr; };
+    const bool fixed = fin_elem_fixed(elem), exact = (j.what & FIN_FLOATS) != 0;
+    const uint32_t total = cnt, vw = (total + 31u) >> 5, sb = fixed ? slot_bytes(elem) : 0u;
+    e32[0] = total; e32[1] = elem | (sb << 8);
+    for (uint32_t i = 0; i < vw; i++) e32[2 + i] = 0;
+    uint32_t* const valid = e32 + 2;
+    if (fixed) {
+      uint32_t* const vals = e32 + 2 + vw;
+      (void)arr_walk<false>(s, n, elem, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8*) {
+        uint32_t* d = vals + (size_t)k * (sb >> 2);
+        for (uint32_t q = 0; q < (sb >> 2); q++) d[q] = is_null ? 0u : w[q];
+        if (!is_null) valid[k >> 5] |= 1u << (k & 31u);
+      }, none, exact);
+    } else {
+      uint32_t* const ends = e32 + 2 + vw;
+      u8* const data = (u8*)(ends + total);
+      uint32_t run = 0;
+      if (elem == ETLG_TC_NUMERIC) {
+        (void)arr_walk<false>(s, n, elem, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8* scratch) {
+          if (!is_null) {
+            const uint32_t nb = pad4(w[1]);
+            heap_copy(data + run, scratch + w[0], w[1]);
+            run += nb;
+            valid[k >> 5] |= 1u << (k & 31u);
+          }
+          ends[k] = run;
+        }, none);
+      } else {
+        // text / bytea elements: their bytes leave as the walk unescapes them; element k starts where element k - 1 ended
+        uint32_t lens_run = 0;
+        (void)arr_walk<true>(s, n, elem, cnt, [&](uint32_t k, bool is_null, const uint32_t* w, const u8*) {
+          lens_run += w[0];
+          ends[k] = lens_run;
+          if (!is_null) valid[k >> 5] |= 1u << (k & 31u);
+        }, [&](uint32_t) -> u8* { return data + lens_run; });
+        run = lens_run;
+        while (run & 3u) data[run++] = 0;
+      }
+    }
+    ((uint32_t*)c.slot)[0] = (uint32_t)at; ((uint32_t*)c.slot)[1] = bytes;
+    settled = true; was_arr = true;
+  }
+  if (settled) atomicAnd(c.stw, ~(3u << c.stsh));   // DEFERRED (3) -> VALUE (0); the other cells of the row share the word
+  }
+  fin_tally(j, c.on, was_arr, was_flt, c.on && !settled);
+}
+
 }  // namespace etlg
 
 extern "C" {
@@ -1695,5 +1858,19 @@ void etlg_k_size_hints(const void* jv, hipStream_t st) {
   const HintJob j = *(const HintJob*)jv;
   if (j.n_events) hipLaunchKernelGGL(k_size_hints, dim3((uint32_t)((j.n_events + 255) / 256)), dim3(256), 0, st, j);
 }
+
+// the finish pass: step 0 = entry sizes of every (event, image, finishable column) + their exclusive scan (blk: (ceil(n / 256) + 1) x u64
+// scratch, offsets: n + 1 x i64), step 1 = the entries, the slots and the cell states
+void etlg_k_finish(const void* jv, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st) {
+  const FinJob j = *(const FinJob*)jv;
+  const uint64_t n = j.n_events * 2ull * j.maxfin;
+  if (!n) return;
+  const uint32_t nb = (uint32_t)((n + 255) / 256);
+  if (step == 0) {
+    hipLaunchKernelGGL(k_fin_count, dim3(nb), dim3(256), 0, st, j);
+    etlg_k_scan_lens(j.lens, n, blk, offsets, st);
+  } else hipLaunchKernelGGL(k_fin_fill, dim3(nb), dim3(256), 0, st, j);
+}
+uint32_t etlg_k_finish_job_bytes(void) { return (uint32_t)sizeof(FinJob); }
 
 }  // extern "C"

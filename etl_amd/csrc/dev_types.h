@@ -251,6 +251,20 @@ struct HintJob {           // Event::size_hint per event (k_size_hints)
   unsigned long long* out;
 };
 
+struct FinJob {            // the finish pass (k_fin_count / k_fin_fill, columns.hip)
+  const uint8_t* ev_kind; const uint8_t* ev_flags; const uint32_t* ev_slot; const uint64_t* ev_body;
+  uint8_t* fixed; uint8_t* heap;
+  uint64_t n_events;
+  const uint32_t* slots;   // per host slot: n_cols, n_ident, row_full, row_key, cols_base, fin_base, n_fin
+  const uint32_t* cols;    // per column: cls | identity << 8 | elem_cls << 16, off_full | off_key << 16, key_index
+  const uint32_t* fin;     // the finishable columns of every slot (indexes into the slot's columns)
+  uint32_t n_slots, maxfin, what;
+  uint32_t* lens; const int64_t* offsets;
+  uint32_t* counts;        // elements of every array the count pass sized (the fill pass lays the entry out without another walk)
+  uint64_t heap_base;      // where the appended entries start
+  unsigned long long* stats;   // [0] deferred cells examined, [1] arrays typed, [2] floats settled, [3] left deferred
+};
+
 struct RbJob {             // ClickHouse RowBinary rows (k_rb_rows)
   const uint8_t* fixed; const uint8_t* heap; const uint64_t* row_event; const uint64_t* row_base;
   const uint8_t* ev_kind; const uint64_t* ev_commit; const uint64_t* ev_ord;

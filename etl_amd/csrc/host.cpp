@@ -136,6 +136,7 @@ void fill_view_common(etlg_batch* b) {
 // Reads the result block, resolves device vs host error, commits or rolls back
 // the control-plane state and (for host output) copies the arenas back.
 int32_t finish_batch(etlg_ctx* c, etlg_batch* b);
+extern "C" int32_t finish_cells(etlg_ctx* c, etlg_batch* b, uint32_t what, etlg_finish_stats* stats);   // (host_handoff.inc)
 int32_t drain_pending(etlg_ctx* c);
 int32_t download_batch(etlg_ctx* c, etlg_batch* b);
 struct BatchGuard {  // an etlg_decode that fails half way returns what the batch took from the context's pools
@@ -856,7 +857,7 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
   const bool sv_in = c->in_txn; const uint64_t sv_lsn = c->final_lsn, sv_ord = c->next_ord;
   c->in_txn = true; c->final_lsn = 0; c->next_ord = 0;
   c->copy = j;
-  const uint32_t dflags = (flags & ETLG_F_OUTPUT_ON_DEVICE) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL | (j.async ? (uint32_t)ETLG_F_ASYNC : 0u);
+  const uint32_t dflags = (flags & (ETLG_F_OUTPUT_ON_DEVICE | ETLG_F_FINISH_CELLS)) | ETLG_F_INPUT_ON_DEVICE | ETLG_F_NO_CONTROL | (j.async ? (uint32_t)ETLG_F_ASYNC : 0u);
   const int32_t rc = j.direct ? etlg_decode(c, j.d_rows, len, j.d_row_offs, nrows, dflags, out)
                               : etlg_decode(c, j.d_out, (size_t)syn_len, j.d_out_offs, nrows, dflags, out);
   j.stage_blk = c->copy.stage_blk; j.h2d_done = c->copy.h2d_done;   // (nullptr once the batch has adopted them: etlg_decode)
@@ -957,6 +958,7 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   b->ctx = c; b->ctx_gen = c->gen;
   BatchGuard guard{b};
   b->user_no_ctrl = no_ctrl; b->out_dev = out_dev; b->in_dev = in_dev; b->scan = scan; b->len = len;
+  b->finish_what = (flags & ETLG_F_FINISH_CELLS) ? (uint32_t)(ETLG_FINISH_ARRAYS | ETLG_FINISH_FLOATS) : 0u;
   b->stage_blk = stage_blk; b->stage_cap = stage_cap; b->h2d_done = h2d_done;   // the batch owns them from here (etlg_batch_free)
   stage_blk = nullptr; h2d_done = nullptr;
   if (c->copy.active && c->copy.stage_blk) {   // an ASYNC table-copy batch whose rows were staged by etlg_copy_decode: likewise

@@ -72,7 +72,9 @@ extern "C" uint32_t etlg_k_copy_cells_lds(uint32_t maxc, uint32_t window);
 extern "C" void etlg_k_launch_copy_cells(const DecParams* p, const void* q, hipStream_t s);
 extern "C" uint32_t etlg_k_cells_maxc(void);
 extern "C" void etlg_k_launch_rows(const DecParams* p, const void* q, hipStream_t s);
+extern "C" void etlg_k_finish(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st);
 extern "C" int etlg_k_rows_set_lds(void);
+extern "C" int etlg_k_rows_waves(void);
 extern "C" int etlg_k_rows_occupancy(uint32_t lds_bytes);
 extern "C" uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc, uint32_t cf);
 extern "C" uint32_t etlg_k_rows_static_lds(void);
@@ -433,6 +435,7 @@ struct etlg_batch {
   bool deferred = false;        // ASYNC without a sidecar: scan in flight, decode not enqueued yet (etlg_ctx::deferred)
   const uint8_t* d_in_ptr = nullptr; const uint32_t* user_offs = nullptr;
   DevBuf* scan_offs = nullptr;  // ASYNC without a sidecar: the batch's own offsets (from the context's pool)
+  uint32_t finish_what = 0;     // ETLG_F_FINISH_CELLS: the ETLG_FINISH_* bits finish_batch applies before the batch is handed over
   bool scan_chained = false;    // ... and its decode (the fixed-width plan) was enqueued BEHIND the scan, with the frame count read on the device (DecParams.nframes_dev)
   uint32_t* d_scan_res = nullptr;   // the scan's result words, behind the batch's offsets
   hipStream_t scan_s = nullptr;     // ... the stream that scan runs on (ASYNC: the context's scan stream; otherwise the decode stream itself)

@@ -741,14 +741,23 @@ extern "C" {
 
 using namespace etlg;
 
+static int rows_nw() {   // waves per tile: ETLG_ROWS_NW = 2 | 4 (experiments; the shipped value is RNW)
+  static const int nw = [] { const char* e = getenv("ETLG_ROWS_NW"); const int v = e ? atoi(e) : RNW; return v == 2 ? 2 : 4; }();
+  return nw;
+}
+
 void etlg_k_launch_rows(const DecParams* p, const void* qv, hipStream_t s) {
   const FusedParams* q = (const FusedParams*)qv;
-  hipLaunchKernelGGL((k_rows<RNW>), dim3(q->ntiles), dim3(RNW * 64), q->lds_bytes, s, *p, *q);
+  if (rows_nw() == 2) hipLaunchKernelGGL((k_rows<2>), dim3(q->ntiles), dim3(2 * 64), q->lds_bytes, s, *p, *q);
+  else hipLaunchKernelGGL((k_rows<4>), dim3(q->ntiles), dim3(4 * 64), q->lds_bytes, s, *p, *q);
 }
 
 int etlg_k_rows_set_lds(void) {
-  return hipFuncSetAttribute((const void*)k_rows<RNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144) == hipSuccess ? 0 : 1;
+  const int a = hipFuncSetAttribute((const void*)k_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144) == hipSuccess ? 0 : 1;
+  const int b = hipFuncSetAttribute((const void*)k_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144) == hipSuccess ? 0 : 1;
+  return a | b;
 }
+int etlg_k_rows_waves(void) { return rows_nw(); }
 
 // heap-cell table + cell positions next to the image and the window
 uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc, uint32_t cf) {
@@ -758,7 +767,8 @@ uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc
 uint32_t etlg_k_rows_static_lds(void) { return 3840u; }   // the kernel's __shared__ arrays + slack
 int etlg_k_rows_occupancy(uint32_t lds_bytes) {   // workgroups of k_rows that fit a CU with that much dynamic LDS (debugging aid)
   int n = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_rows<RNW>, RNW * 64, lds_bytes) != hipSuccess) return -1;
+  const hipError_t e = rows_nw() == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_rows<2>, 2 * 64, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_rows<4>, 4 * 64, lds_bytes);
+  if (e != hipSuccess) return -1;
   return n;
 }
 uint32_t etlg_k_rows_max_cols(void) { return 128u; }      // (a task names its cell index in 8 bits, a cell position its frame offset in 16)

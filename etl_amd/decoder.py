@@ -73,6 +73,14 @@ class Batch:
             raise self.dec.last_error()
         return Columns(self.dec, out)
 
+    def finish_cells(self, what=abi.FINISH_ARRAYS | abi.FINISH_FLOATS):
+        """Typed arrays / exact floats in the arena, on the device (etlg_batch_finish_cells). Returns abi.FinishStats."""
+        st = abi.FinishStats()
+        rc = self.dec.L.etlg_batch_finish_cells(self.dec.h, self.h, what, C.byref(st))
+        if rc != abi.OK:
+            raise self.dec.last_error()
+        return st
+
     def size_hints(self, model):
         """Event::size_hint per event (np.uint64; bit 63 = abi.SIZE_HINT_INCOMPLETE), computed on the device
         (etlg_batch_size_hints). `model`: abi.SizeModel — the reference's size_of constants."""

@@ -22,6 +22,7 @@ EXPORTS = [
     "etlg_table_forget", "etlg_table_cache_get", "etlg_host_alloc", "etlg_host_free", "etlg_control_stream", "etlg_shard_plan", "etlg_shard_replay",
     "etlg_batch_columns", "etlg_columns_view_get", "etlg_columns_free",
     "etlg_batch_rowbinary", "etlg_batch_protobuf", "etlg_rowbinary_view_get", "etlg_rowbinary_free", "etlg_batch_size_hints",
+    "etlg_batch_finish_cells",
 ]
 
 _LIB = None
@@ -102,6 +103,7 @@ def lib():
     L.etlg_rowbinary_free.argtypes = [C.c_void_p]
     L.etlg_rowbinary_free.restype = None
     L.etlg_batch_size_hints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.etlg_batch_finish_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.etlg_table_cache_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     L.etlg_shard_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
     L.etlg_shard_plan.restype = C.c_int32

@@ -267,6 +267,8 @@ class HostBatch:
             return ("Uuid", bytes(slot_bytes[:16]))
         off, ln = struct.unpack_from("<II", slot_bytes, 0)
         raw = self._heap(off, ln)
+        if tc == abi.TC_ARRAY:
+            return self._array(raw)
         if tc == abi.TC_NUMERIC:
             kind, sign, weight, scale, nd = struct.unpack_from("<BBhHH", raw, 0)
             digits = struct.unpack_from(f"<{(ln - 8) // 2}h", raw, 8)
@@ -274,6 +276,40 @@ class HostBatch:
         if tc == abi.TC_BYTEA:
             return ("Bytes", raw)
         return ("String", raw)
+
+    _ELEM_NAMES = {abi.TC_BOOL: "Bool", abi.TC_I16: "I16", abi.TC_I32: "I32", abi.TC_U32: "U32", abi.TC_I64: "I64", abi.TC_F32: "F32", abi.TC_F64: "F64",
+                   abi.TC_DATE: "Date", abi.TC_TIME: "Time", abi.TC_TIMESTAMP: "Timestamp", abi.TC_TIMESTAMPTZ: "TimestampTz", abi.TC_TIMETZ: "TimeTz",
+                   abi.TC_UUID: "Uuid", abi.TC_NUMERIC: "Numeric", abi.TC_BYTEA: "Bytes", abi.TC_STRING: "String"}
+
+    def _array(self, raw):
+        """A typed array entry (etlg_array_hdr, include/etlg.h) -> ("Array", element class name, [element cells | ("Null",)])."""
+        n, ecls, ebytes, _ = struct.unpack_from("<IBBH", raw, 0)
+        vw = (n + 31) // 32
+        valid = struct.unpack_from(f"<{vw}I", raw, 8) if vw else ()
+        at = 8 + 4 * vw
+        col = type("ElemCol", (), {"type_class": ecls, "type_oid": 0})
+        out = []
+        if ebytes:
+            for k in range(n):
+                if not (valid[k >> 5] >> (k & 31)) & 1:
+                    out.append(("Null",))
+                else:
+                    out.append(self._cell(col, abi.CELL_VALUE, raw[at + k * ebytes:at + k * ebytes + 16].ljust(16, b"\0")))
+        else:
+            ends = struct.unpack_from(f"<{n}I", raw, at) if n else ()
+            data = raw[at + 4 * n:]
+            prev = 0
+            for k in range(n):
+                piece = data[prev:ends[k]]
+                prev = ends[k]
+                if not (valid[k >> 5] >> (k & 31)) & 1:
+                    out.append(("Null",))
+                elif ecls == abi.TC_NUMERIC:
+                    kind, sign, weight, scale, nd = struct.unpack_from("<BBhHH", piece, 0)
+                    out.append(("Numeric", kind, sign, weight, scale, struct.unpack_from(f"<{nd}h", piece, 8)))
+                else:
+                    out.append(("Bytes" if ecls == abi.TC_BYTEA else "String", piece))
+        return ("Array", self._ELEM_NAMES.get(ecls, str(ecls)), out)
 
     def _row(self, slot, base, key_layout):
         cols = slot.key_cols() if key_layout else slot.cols

@@ -264,7 +264,7 @@ enum {
   ETLG_F_OUTPUT_ON_DEVICE = 1u << 1, /* do not copy the arenas to the host; view holds device pointers */
   ETLG_F_NO_CONTROL = 1u << 2,       /* caller asserts: no R/M/T frame in this batch (skips the
                                         control-plane round trip; verified on device) */
-  ETLG_F_ASYNC = 1u << 3             /* with OUTPUT_ON_DEVICE | NO_CONTROL: enqueue only, do not synchronize;
+  ETLG_F_ASYNC = 1u << 3,            /* with OUTPUT_ON_DEVICE | NO_CONTROL: enqueue only, do not synchronize;
                                         counts become valid after etlg_batch_sync. The input must be COMPLETE in
                                         device memory when the call is made: the batch may be decoded on a private
                                         stream beside its predecessor, not behind work enqueued on the context's
@@ -284,6 +284,10 @@ enum {
                                         not touch buf / frame_offsets until the batch is synced (two staging buffers in
                                         rotation: fill one while the other is in flight). Without a sidecar a host-input
                                         batch is decoded synchronously, as before */
+  ETLG_F_FINISH_CELLS = 1u << 4      /* round 6: run etlg_batch_finish_cells(ETLG_FINISH_ARRAYS | ETLG_FINISH_FLOATS) on the batch
+                                        before it is handed over (an ASYNC batch: when it is synced; a host-output batch: before
+                                        the download): array cells come back TYPED (etlg_array_hdr entries) and no float cell
+                                        comes back DEFERRED. Also honoured by etlg_copy_decode */
 };
 
 /* Pinned (page-locked) host memory for the staging buffers of a host that feeds etlg_decode with ETLG_F_ASYNC: what the
@@ -436,6 +440,54 @@ enum {
  *    DEFERRED. The rule is etl_amd/csrc/float_fast.h; the oracle evaluates the same header for the
  *    DECISION and glibc strtod / strtof for the value. Malformed text is the reference's
  *    "Float parsing failed". */
+
+/* ---- the finish pass (round 6): typed arrays and exact floats in the arena itself.
+ *
+ * The reference decodes an array cell to Cell::Array(ArrayCell::*) at decode time (parse_cell_from_postgres_text_array,
+ * crates/etl/src/postgres/codec/text.rs:163-312) and every float text with Rust's correctly rounded str::parse (:52-59).
+ * etlg_decode leaves array cells — and the rare float text its fast rule cannot decide — ETLG_CELL_DEFERRED (above);
+ * etlg_batch_finish_cells settles them on the device, in place:
+ *  - ETLG_FINISH_ARRAYS: every DEFERRED cell of an array column whose element class is bool / int2 / int4 / int8 / oid /
+ *    float4 / float8 / date / time / timetz / timestamp / timestamptz / uuid / numeric / bytea / text-like
+ *    (etlg_array_elem_class) and whose literal the reference accepts becomes ETLG_CELL_VALUE; its slot then holds
+ *    (heap_off, bytes) of an etlg_array_hdr entry appended behind the batch's heap (heap_bytes grows; the source text
+ *    stays where it was). NULL elements, quoting, escapes, the optional dimensions prefix, the unquoted-NULL rule:
+ *    exactly the reference's state machine. A literal the reference REJECTS (unbalanced quotes, a multidimensional
+ *    array, an element its type's parser refuses ...), a json / jsonb element, or a numeric / timetz element of more
+ *    than 40 characters is left DEFERRED: the host's parse_cell_from_postgres_text then raises the reference's own
+ *    error (or finishes the cell), as before.
+ *  - ETLG_FINISH_FLOATS: every DEFERRED float4 / float8 cell gets its correctly rounded bits (the conversion Rust's
+ *    dec2flt falls back to: 768 decimal digits shifted into place, core::num::dec2flt::slow) and becomes
+ *    ETLG_CELL_VALUE; float elements of arrays likewise. With both bits set the only DEFERRED cells left in a batch
+ *    are json / jsonb, json arrays and literals the reference rejects.
+ * The batch must be device-resident and finished (an ASYNC batch is synced first). Events, row blocks and every
+ * heap reference that existed stay where they are. */
+enum { ETLG_FINISH_ARRAYS = 1u, ETLG_FINISH_FLOATS = 2u };
+
+/* A typed array in the heap (4-byte aligned, a multiple of 4 bytes long):
+ *   etlg_array_hdr
+ *   uint32_t validity[(n_elems + 31) / 32]      bit k set: element k is a value (clear: NULL)
+ *   elem_bytes != 0:  n_elems slots of elem_bytes bytes, each laid out like a row slot of elem_class (NULL: zeros)
+ *   elem_bytes == 0:  uint32_t end[n_elems] — element k is data[end[k-1] .. end[k]) (end[-1] = 0) — then the data,
+ *                     zero padded to 4 bytes: String / Bytes elements are their unescaped bytes; a Numeric element is an
+ *                     etlg_numeric_hdr + digits, padded to 4 bytes (its end offset includes the padding) */
+typedef struct etlg_array_hdr {
+  uint32_t n_elems;
+  uint8_t elem_class; /* etlg_type_class of the elements */
+  uint8_t elem_bytes; /* etlg_slot_bytes(elem_class) for fixed-width elements, 0 for String / Bytes / Numeric */
+  uint16_t reserved;  /* 0 */
+} etlg_array_hdr;
+
+typedef struct etlg_finish_stats {
+  uint64_t deferred_seen;  /* DEFERRED cells of array / float columns the pass looked at */
+  uint64_t arrays_typed;
+  uint64_t floats_settled;
+  uint64_t left_deferred;  /* of deferred_seen: still DEFERRED (the host finishes them) */
+  uint64_t heap_bytes_added;
+} etlg_finish_stats;
+
+/* what: ETLG_FINISH_* bits. stats may be NULL. Idempotent (a second call finds nothing it can settle). */
+int32_t etlg_batch_finish_cells(etlg_ctx* ctx, etlg_batch* batch, uint32_t what, etlg_finish_stats* stats);
 
 /* Numeric heap entry header (followed by ndigits little-endian i16 base-10000
  * digits): mirrors PgNumeric (crates/etl-postgres/src/numeric.rs:75-96). */

@@ -1319,6 +1319,152 @@ int32_t oracle_batch_view(oracle_batch* ob, etlg_batch_view* v) {
   return 0;
 }
 
+// The finish pass of include/etlg.h (etlg_batch_finish_cells) on the canonical arena, restated: cells left DEFERRED are settled in
+// (event, image, column) order — an array literal through parse_array_text (the FULL-mode parser above: text.rs:228-312), a float
+// through glibc's correctly rounded strtod / strtof — and the typed entries are appended to the heap in that order. What the device
+// contract leaves to the host stays DEFERRED here too: a literal the reference rejects, json elements, a non-text element of more
+// than 40 unescaped characters. what: ETLG_FINISH_* bits. Returns the number of cells settled, -1 when there is no arena.
+static bool fin_elem_supported(int32_t e) {
+  switch (e) {
+    case ETLG_TC_BOOL: case ETLG_TC_I16: case ETLG_TC_I32: case ETLG_TC_I64: case ETLG_TC_U32: case ETLG_TC_F32: case ETLG_TC_F64: case ETLG_TC_DATE: case ETLG_TC_TIME:
+    case ETLG_TC_TIMETZ: case ETLG_TC_TIMESTAMP: case ETLG_TC_TIMESTAMPTZ: case ETLG_TC_UUID: case ETLG_TC_NUMERIC: case ETLG_TC_BYTEA: case ETLG_TC_STRING: return true;
+    default: return false;
+  }
+}
+// the longest unescaped element of a literal parse_array_text accepted (same state machine, lengths only); float_rule: some float element
+// is one the device's fast rule calls inconclusive
+static void fin_scan_elems(sv str, int32_t elem_class, size_t& longest, bool& float_inconclusive) {
+  longest = 0; float_inconclusive = false;
+  auto st = strip_array_dims(str);
+  str = st.v;
+  sv body = str.substr(1, str.size() - 2);
+  std::string val;
+  bool in_quotes = false, in_escape = false, val_quoted = false;
+  size_t pos = 0;
+  bool done = body.empty();
+  while (!done) {
+    for (;;) {
+      if (pos >= body.size()) { done = true; break; }
+      char c = body[pos++];
+      if (in_escape) { val.push_back(c); in_escape = false; }
+      else if (c == '"') { if (!in_quotes) val_quoted = true; in_quotes = !in_quotes; }
+      else if (c == '\\') in_escape = true;
+      else if (c == ',' && !in_quotes) break;
+      else val.push_back(c);
+    }
+    longest = std::max(longest, val.size());
+    const bool is_null = !val_quoted && eq_ignore_ascii_case(val, "null");
+    if (!is_null && (elem_class == ETLG_TC_F32 || elem_class == ETLG_TC_F64) && float_device_rule(val, elem_class == ETLG_TC_F32) == 1) float_inconclusive = true;
+    val.clear(); val_quoted = false;
+  }
+}
+static void fin_put_slot(std::vector<u8>& out, size_t at, const Cell& c) {
+  auto p32 = [&](size_t o, uint32_t x) { memcpy(out.data() + o, &x, 4); };
+  auto p64 = [&](size_t o, uint64_t x) { memcpy(out.data() + o, &x, 8); };
+  switch (c.tag) {
+    case Tag::Bool: p32(at, c.u.b ? 1 : 0); break;
+    case Tag::I16: case Tag::I32: p32(at, (uint32_t)(int32_t)c.u.i); break;
+    case Tag::U32: p32(at, (uint32_t)c.u.i); break;
+    case Tag::I64: p64(at, (uint64_t)c.u.i); break;
+    case Tag::F32: p32(at, (uint32_t)c.u.fbits); break;
+    case Tag::F64: p64(at, c.u.fbits); break;
+    case Tag::Date: p32(at, (uint32_t)c.u.t.date); break;
+    case Tag::Time: p32(at, c.u.t.secs); p32(at + 4, c.u.t.nanos); break;
+    case Tag::Timestamp: case Tag::TimestampTz: p32(at, (uint32_t)c.u.t.date); p32(at + 4, c.u.t.secs); p32(at + 8, c.u.t.nanos); break;
+    case Tag::TimeTz: p32(at, c.u.t.secs); p32(at + 4, c.u.t.nanos); p32(at + 8, (uint32_t)c.u.t.offset); break;
+    case Tag::Uuid: memcpy(out.data() + at, c.u.uuid, 16); break;
+    default: break;
+  }
+}
+int64_t oracle_batch_finish(oracle_batch* ob, uint32_t what) {
+  Batch& b = ob->b;
+  const Ctx& c = *ob->ctx;
+  if (!build_arena(c, b)) return -1;
+  int64_t settled = 0;
+  for (size_t i = 0; i < b.events.size(); i++) {
+    const u8 kind = b.kind[i];
+    if (!(kind == 'I' || kind == 'U' || kind == 'D')) continue;
+    const Slot& s = *c.slots[b.slot[i]];
+    const int ok = kind == 'I' ? 0 : (b.flags[i] & 3);
+    for (int img = 0; img < 2; img++) {
+      if (img == 0 && ok == ETLG_OLD_NONE) continue;
+      if (img == 1 && kind == 'D') continue;
+      const bool key = img == 0 && ok == ETLG_OLD_KEY;
+      const size_t base = (size_t)b.body_off[i] + (img == 1 ? (ok == ETLG_OLD_KEY ? s.row_key : ok == ETLG_OLD_FULL ? s.row_full : 0) : 0);
+      for (size_t ci = 0; ci < s.cols.size(); ci++) {
+        const RCol& col = s.cols[ci];
+        size_t pos = ci, off = col.off_full;
+        if (key) {
+          size_t k = 0; bool found = false;
+          for (; k < s.ident_idx.size(); k++) if ((size_t)s.ident_idx[k] == ci) { found = true; break; }
+          if (!found) continue;
+          pos = k; off = col.off_key;
+        }
+        const u8 st = (b.fixed[base + pos / 4] >> (2 * (pos % 4))) & 3;
+        if (st != ETLG_CELL_DEFERRED) continue;
+        uint32_t toff, tlen;
+        memcpy(&toff, b.fixed.data() + base + off, 4); memcpy(&tlen, b.fixed.data() + base + off + 4, 4);
+        const std::string text((const char*)b.heap.data() + toff, tlen);   // (a copy: the heap grows below)
+        bool done = false;
+        if ((col.cls == ETLG_TC_F32 || col.cls == ETLG_TC_F64) && (what & ETLG_FINISH_FLOATS)) {
+          auto v = col.cls == ETLG_TC_F32 ? parse_f32_bits(text) : parse_f64_bits(text);
+          uint64_t bits = v.v;
+          memcpy(b.fixed.data() + base + off, &bits, 8);
+          done = true;
+        } else if (col.cls == ETLG_TC_ARRAY && (what & ETLG_FINISH_ARRAYS)) {
+          const int32_t elem = array_elem_class(col.type_oid);
+          if (!fin_elem_supported(elem)) continue;
+          auto r = parse_array_text(elem, text);
+          if (!r.ok) continue;
+          size_t longest; bool finc;
+          fin_scan_elems(text, elem, longest, finc);
+          const bool textlike = elem == ETLG_TC_STRING || elem == ETLG_TC_BYTEA;
+          if (!textlike && longest > 40) continue;                  // kArrElemMax: handed back
+          if (finc && !(what & ETLG_FINISH_FLOATS)) continue;       // a float element only the exact conversion settles
+          const Arr& a = *r.v.u.arr;
+          const size_t n = a.elems.size(), vw = (n + 31) / 32;
+          const bool fixed = !(textlike || elem == ETLG_TC_NUMERIC);
+          const uint32_t sb = fixed ? slot_bytes(elem) : 0;
+          std::vector<u8> e(8 + 4 * vw + (fixed ? n * sb : 4 * n), 0);
+          const uint32_t n32 = (uint32_t)n;
+          memcpy(e.data(), &n32, 4); e[4] = (u8)elem; e[5] = (u8)sb;
+          std::vector<u8> data;
+          for (size_t k = 0; k < n; k++) {
+            const Cell& ec = a.elems[k];
+            const bool is_null = ec.tag == Tag::Null;
+            if (!is_null) e[8 + 4 * (k / 32) + (k % 32) / 8] |= (u8)(1u << (k % 8));
+            if (fixed) { if (!is_null) fin_put_slot(e, 8 + 4 * vw + k * sb, ec); }
+            else {
+              if (!is_null) {
+                if (ec.tag == Tag::Numeric) {
+                  const NumBlock* nb = ec.u.num;
+                  etlg_numeric_hdr h{nb->kind, nb->sign, nb->weight, nb->scale, (uint16_t)nb->ndigits};
+                  const size_t at = data.size();
+                  data.resize(at + 8 + 2 * (size_t)nb->ndigits);
+                  memcpy(data.data() + at, &h, 8);
+                  if (nb->ndigits) memcpy(data.data() + at + 8, nb->digits, 2 * (size_t)nb->ndigits);
+                  while (data.size() % 4) data.push_back(0);
+                } else data.insert(data.end(), (const u8*)ec.u.s.p, (const u8*)ec.u.s.p + ec.u.s.len);
+              }
+              const uint32_t end = (uint32_t)data.size();
+              memcpy(e.data() + 8 + 4 * vw + 4 * k, &end, 4);
+            }
+          }
+          e.insert(e.end(), data.begin(), data.end());
+          while (e.size() % 4) e.push_back(0);
+          while (b.heap.size() % 4) b.heap.push_back(0);
+          const uint32_t at = (uint32_t)b.heap.size(), bytes = (uint32_t)e.size();
+          b.heap.insert(b.heap.end(), e.begin(), e.end());
+          memcpy(b.fixed.data() + base + off, &at, 4); memcpy(b.fixed.data() + base + off + 4, &bytes, 4);
+          done = true;
+        }
+        if (done) { b.fixed[base + pos / 4] &= (u8)~(3u << (2 * (pos % 4))); settled++; }
+      }
+    }
+  }
+  return settled;
+}
+
 uint64_t oracle_batch_n_events(const oracle_batch* ob) { return ob->b.events.size(); }
 void oracle_batch_free(oracle_batch* ob) { delete ob; }
 

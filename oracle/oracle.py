@@ -189,6 +189,15 @@ class OracleBatch:
             raise RuntimeError("oracle arena is only defined for CONTRACT-mode batches")
         return HostBatch.from_view(v)
 
+    def finish(self, what=3):
+        """The finish pass of include/etlg.h on the canonical arena (typed arrays, exact floats): oracle_batch_finish. Returns the cells settled."""
+        self.orc.L.oracle_batch_finish.restype = C.c_int64
+        self.orc.L.oracle_batch_finish.argtypes = [C.c_void_p, C.c_uint32]
+        n = self.orc.L.oracle_batch_finish(self.h, what)
+        if n < 0:
+            raise RuntimeError("oracle arena is only defined for CONTRACT-mode batches")
+        return n
+
     def event_repr(self, i):
         return self.orc.L.oracle_event_repr(self.h, i).decode("utf-8", "replace")
 

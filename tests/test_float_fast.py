@@ -26,3 +26,15 @@ def test_oracle_states_the_deferral_rule_independently(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "mismatches 0" in out.stdout
+
+
+def test_float_exact_fallback_matches_strtod(tmp_path):
+    """etl_amd/csrc/float_slow.h — the finish pass's exact decimal -> binary conversion (Rust dec2flt's slow path, core::num::dec2flt::slow) —
+    against glibc on 4 million texts: random decimals, the exact half-way points of both widths with their neighbours, mantissas beyond
+    768 digits, and 260 k texts the fast path calls inconclusive."""
+    exe = str(tmp_path / "float_slow_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "etl_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "float_slow_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "mismatches 0" in out.stdout

@@ -73,6 +73,7 @@ _JOBS = {
     "shard_async": _pytest_job(["tests/test_shard_decode.py", "tests/test_gpu_async.py", "-k", "not 8-"], 900),
     "copy_scan": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k", "not device_resident and not device_input and not 16777216"], 600),
     "plans": _pytest_job(["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or k_plan or prepass or (cfg2 and default)"], 900),
+    "finish_pass": _pytest_job(["tests/test_gpu_finish.py"], 600),
     "hand_off": _pytest_job(["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py", "tests/test_gpu_json_display.py"], 600),
     "lane_order": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_protobuf.py",
                                "-k", "not device_resident and not device_input and not 16777216 and not synthetic and not kat_ and not random"], 600, order="shuffle"),
@@ -200,6 +201,12 @@ def test_columnar_hand_off(emu_jobs):
     """etlg_batch_columns / etlg_batch_rowbinary (columns.hip): the Arrow-layout buffers built by the emulated kernels against
     the host hand-off of the oracle's arena, the RowBinary bytes against oracle/rowbinary.py."""
     _passed(emu_jobs, "hand_off")
+
+
+def test_finish_pass_typed_arrays_and_exact_floats(emu_jobs):
+    """etlg_batch_finish_cells / ETLG_F_FINISH_CELLS (columns.hip: k_fin_count / k_fin_fill, float_slow.h): the reference's array vectors
+    through the emulated kernels, the type-matrix table, fuzzed literals in every image, the float matrix — tests/test_gpu_finish.py."""
+    _passed(emu_jobs, "finish_pass")
 
 
 def test_long_async_chains_with_second_attempts(emu_jobs):

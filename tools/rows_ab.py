@@ -8,7 +8,7 @@ from etl_amd import abi, synth
 from etl_amd.decoder import Decoder
 
 label = sys.argv[1] if len(sys.argv) > 1 else "default"
-row = {"label": label, "env": {k: os.environ[k] for k in ("ETLG_ROWS", "ETLG_FUSED_KERNEL", "ETLG_FUSED_DBG") if k in os.environ}}
+row = {"label": label, "env": {k: os.environ[k] for k in ("ETLG_ROWS", "ETLG_FUSED_KERNEL", "ETLG_FUSED_DBG", "ETLG_ROWS_NW", "ETLG_ROWS_CF") if k in os.environ}}
 
 
 def dev(buf, offs):
