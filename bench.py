@@ -1183,7 +1183,7 @@ def main():
             extra["cfg1"] = leg_cfg1(local_rank, dev, cap, 4.0)
             _leg_done("cfg1")
         if "wide70" in legs:
-            extra["wide70"] = leg_wide70(local_rank, dev, 24000, 40)
+            extra["wide70"] = leg_wide70(local_rank, dev, 44000, 40)   # (~64 MiB per batch, like the other legs; 24 000 rows = 36 MB until round 5)
             _leg_done("wide70")
         if "copy" in legs:
             extra["copy"] = leg_copy(local_rank, dev, 400000, 8)

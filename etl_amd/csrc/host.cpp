@@ -945,6 +945,10 @@ int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t*
   }
   hipStream_t s = c->stream;
   if (!async) { const int32_t rc = drain_pending(c); if (rc != ETLG_OK) return rc; clear_error(c); }
+  // The result blocks live in a ring of kResRing: include/etlg.h asks for fewer than 32 batches in flight, and a caller that keeps more
+  // (etlg_copy_decode(ASYNC) queues batches back to back too) must not get a block that a batch in flight — or one being decoded again —
+  // still writes: the oldest batches are finished first. They stay the caller's: their sync returns what was found here.
+  while (c->pending.size() >= etlg_ctx::kResRing - 2) { const int32_t rc = finish_batch(c, c->pending.front()); (void)rc; }
 
   // ---- record boundaries: the caller's sidecar, or the device scan (scan.hip)
   const uint32_t* h_offs = frame_offsets;

@@ -35,7 +35,7 @@
 //
 // The result is exactly the sequential rule  p -> p + 1 + L  while buf[p] == 'd', L >= 4 and
 // the frame fits; else the rest of the buffer is one last (malformed) frame  — the rule of the
-// oracle and of the host fallback in host.cpp.
+// oracle (there is no host-side scan: when the tiles' guesses do not settle the one-lane kernel k_bounds_seq walks the chain).
 #include "lookback.hip.h"
 
 namespace etlg {

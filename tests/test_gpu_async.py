@@ -429,6 +429,26 @@ def test_decode_enqueued_behind_its_boundary_scan(asynchronous):
         assert chained >= 4 and redone >= 1, (chained, redone)
 
 
+def test_more_batches_in_flight_than_the_result_ring_holds():
+    """The contract asks for fewer than 32 ASYNC batches in flight per context (their result blocks live in a ring of 32). A caller that
+    queues 75 before its first sync still gets every batch right: the library finishes the oldest ones itself when the ring is about to
+    lap (nothing enforced the limit; a slot's next user could run on a block a batch in flight still wrote)."""
+    w = synth.cfg2()
+    buf, offs = w.fill(3 << 20)
+    pieces = _cut(buf, offs, 75, seed=41)
+    paths = _run_chain(w, pieces)
+    assert paths["plan"] >= 75 and paths["redone"] == 0, paths
+    w = synth.cfg3()
+    buf, offs = w.fill(3 << 20)
+    pieces = _cut(buf, offs, 70, seed=43)
+    b2, o2 = pieces[40]
+    k = int(o2[len(o2) // 2])
+    while b2[k + 30] != ord("I"):
+        k = int(o2[np.searchsorted(o2, k, side="right")])
+    b2[k + 31:k + 35] = 0xEE     # an Insert for a relation id nobody registered: an error in the middle, the batches behind it decoded again
+    _run_chain(w, pieces)
+
+
 def test_deferred_scan_is_collected_by_whatever_comes_next():
     """An ASYNC batch without a sidecar returns with its boundary scan in flight; the decode is enqueued by the next call on the
     context — another decode, a control-plane call, a frame-tag query, the batch's own sync, its free, or the context's destroy —

@@ -1,6 +1,3 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python tools/finish_probe.py 2>&1 | tail -2 > gpurun_out/r06za_finish_probe.txt
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06z_prof -o p -- python tools/finish_probe.py > /dev/null 2>&1
-f=$(ls gpurun_out/r06z_prof/*kernel_stats.csv | head -1); head -4 $f | cut -c1-160 >> gpurun_out/r06za_finish_probe.txt
-rm -rf gpurun_out/r06z_prof
-timeout 900 python -m pytest tests/test_gpu_finish.py -q -x 2>&1 | tail -2 >> gpurun_out/r06za_finish_probe.txt
+O=gpurun_out
+( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $O/r06zc_tests.log 2>&1; tail -n 4 $O/r06zc_tests.log
+( time timeout 900 python bench.py > $O/r06zc_bench.json 2> $O/r06zc_bench.err ); tail -c 200 $O/r06zc_bench.json
