@@ -38,7 +38,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # cfg2: 113 + 4 + 42 + 24 = 183 bytes per row.
 SIDECAR_BYTES_PER_FRAME = 4
 HEADER_BYTES_PER_EVENT = 42     # kind 1, flags 1, table 4, slot 4, start 8, commit 8, ordinal 8, body offset 8
-WINDOW = 24                     # ASYNC batches in flight per context (the library's result ring holds 32)
+WINDOW = int(os.environ.get("ETLG_BENCH_WINDOW", "24"))   # ASYNC batches in flight per context (the library's result ring holds 32)
 
 
 def cpu_threads(requested):
@@ -773,14 +773,19 @@ def leg_pcie(dev_id, dev, cap, nbatches):
     return out
 
 
-def leg_no_sidecar(dec, items, steps, check):
+def leg_no_sidecar(dev_id, items, steps, check):
     """The same cfg2 batches with frame_offsets = NULL: the record-boundary scan runs on the device first (scan.hip).
     Reported beside `value`, never as `value`: the reference's host learns every frame length from its socket codec.
     `value`: ASYNC — the scan of batch k+1 runs on its own stream while batch k is decoded, the host only waits for the frame
     count; `sync_value`: one batch at a time, every call returns a finished batch."""
     import torch
 
-    from etl_amd import abi
+    from etl_amd import abi, synth
+    from etl_amd.decoder import Decoder
+    # a context of its own, like the other legs (the headline's context keeps 24 output sets of its chain in its pools; on it this leg
+    # read 700-810 GB/s where a fresh context reads 1 200: gpurun_out/r06zc, r06v against tools/nosidecar_probe.py)
+    dec = Decoder(dev_id)
+    synth.cfg2().register(dec)
     out = {}
     for mode, fl in (("sync", abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL), ("async", abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC)):
         depth = 8 if mode == "async" else 1
@@ -828,10 +833,12 @@ def leg_no_sidecar(dec, items, steps, check):
         out[mode] = (nb / (t1 - t0) / 1e9, kern)
     kern = out["async"][1]
     kb = kern.get("k_bounds", {"launches": 0, "avg_us": 0.0})
+    chained = dec.debug_scan_chained()
+    dec.close()
     return {"value": round(out["async"][0], 3), "unit": "GB/s", "sync_value": round(out["sync"][0], 3),
             "k_bounds_avg_us": round(kb["avg_us"], 2), "k_bounds_launches_per_batch": round(kb["launches"] / steps, 2),
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
-            "decodes_enqueued_behind_their_scan": dec.debug_scan_chained()[0], "decoded_again_with_the_count": dec.debug_scan_chained()[1],
+            "decodes_enqueued_behind_their_scan": chained[0], "decoded_again_with_the_count": chained[1],
             "note": "frame_offsets = NULL: device record-boundary scan + decode. The decode is enqueued behind the scan, grids sized by a bound, "
                     "the frame count read on the device (no host wait between scan and decode). value = ASYNC (scan on its own stream beside "
                     "the decode of the batch before); sync_value = one finished batch per call (scan and decode back to back on one stream); "
@@ -1159,7 +1166,7 @@ def main():
     if rank == 0:
         extra["deferred_cells"] = deferred_cells(dec, items[0])
         if "no_sidecar" in legs and args.workload == "cfg2":
-            extra["no_sidecar"] = leg_no_sidecar(dec, items, 160, check)
+            extra["no_sidecar"] = leg_no_sidecar(local_rank, items, 160, check)
             _leg_done("no_sidecar")
         if "cfg3" in legs and args.workload != "cfg3":
             # (400 batches: a 60-batch region is 8 ms, and one scheduling hiccup of the host moved the figure by a third from call to call)
