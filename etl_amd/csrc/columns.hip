@@ -939,6 +939,29 @@ DEV bool arr_text(const ColJob& j, uint64_t r, const u8*& s, uint32_t& n, uint32
   return true;
 }
 
+// json[] / jsonb[] as a list of `j.to_string()` strings (ArrayCell::Json, iceberg/encoding.rs:577, 964): the literal's elements one by
+// one — unescaped into private memory (json_display walks its text back and forth), checked as ONE JSON value (an element that is not
+// is the reference's decode error, codec/text.rs:126-134, like a scalar json cell), sized. An element of more than kJsonElemMax bytes
+// or beyond json_display's limits (depth 16, 64 members) hands the row back (ARR_HOST). kJsonElemMax is defined with the row formats below.
+constexpr uint32_t kJsonListElemMax = 256;
+DEV uint32_t arr_json_check(const u8* s, uint32_t n, uint32_t& cnt) {
+  u8 tmp[kJsonListElemMax];
+  bool too_long = false, bad_json = false, limit = false;
+  const uint32_t e = arr_spans(s, n, cnt, [&](uint32_t, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+    if (is_null || too_long || bad_json) return;
+    if (ulen > kJsonListElemMax) { too_long = true; return; }
+    uint32_t k = 0;
+    arr_unescape(s, p0, p1, [&](u8 c) { tmp[k++] = c; });
+    if (!json_valid(tmp, ulen)) { bad_json = true; return; }
+    JsCount c;
+    if (json_display(c, tmp, ulen, false)) limit = true;
+  });
+  if (e) return e;
+  if (too_long) return ARR_HOST;          // (an element too long to look at may not be JSON at all: the row is the host's before anything else)
+  if (bad_json) return ETLG_E_JSON;
+  return limit ? (uint32_t)ARR_HOST : 0u;
+}
+
 __global__ __launch_bounds__(256) void k_arr_count(ColJob j) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = r < j.n_rows;
@@ -948,7 +971,8 @@ __global__ __launch_bounds__(256) void k_arr_count(ColJob j) {
     if (arr_text(j, r, s, n, st)) {
       auto none = [](uint32_t) -> u8* { return nullptr; };
       auto skip = [](uint32_t, bool, const uint32_t*, const u8*) {};
-      const uint32_t e = (j.elem_cls == ETLG_TC_STRING || j.elem_cls == ETLG_TC_BYTEA) ? arr_walk<true>(s, n, j.elem_cls, cnt, skip, none) : arr_walk<false>(s, n, j.elem_cls, cnt, skip, none);
+      const uint32_t e = j.elem_cls == ETLG_TC_JSON ? arr_json_check(s, n, cnt)
+                       : (j.elem_cls == ETLG_TC_STRING || j.elem_cls == ETLG_TC_BYTEA) ? arr_walk<true>(s, n, j.elem_cls, cnt, skip, none) : arr_walk<false>(s, n, j.elem_cls, cnt, skip, none);
       // A row handed back (ARR_HOST) is the host's to finish, and it may turn out to be the batch's first malformed literal. So the call
       // only fails for a malformed row when no handed-back row precedes it (the host compares the two minima: code 0xFF marks a
       // hand-back); otherwise the malformed rows are handed back as well, and the consumer — finishing deferred rows in event
@@ -975,6 +999,36 @@ __global__ __launch_bounds__(256) void k_arr_fill(ColJob j) {
   if (!arr_text(j, r, s, n, st)) return;
   const uint64_t o = (uint64_t)j.offsets[r];
   uint32_t nulls = 0;
+  if (j.elem_cls == ETLG_TC_JSON) {
+    // pass A (values not set): the Display length and validity of every element; pass B: the characters
+    u8 tmp[kJsonListElemMax];
+    if (!j.values) {
+      (void)arr_spans(s, n, cnt, [&](uint32_t k, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+        const uint64_t e = o + k;
+        uint32_t len = 0;
+        if (!is_null) {
+          uint32_t q = 0;
+          arr_unescape(s, p0, p1, [&](u8 c) { tmp[q++] = c; });
+          JsCount c;
+          (void)json_display(c, tmp, ulen, false);
+          len = c.n;
+          atomicOr(&j.child_validity[e >> 5], 1u << (e & 31));
+        } else nulls++;
+        j.child_lens[e] = len;
+      });
+      if (nulls) atomicAdd(j.child_nulls, (unsigned long long)nulls);
+    } else {
+      (void)arr_spans(s, n, cnt, [&](uint32_t k, bool is_null, uint32_t p0, uint32_t p1, uint32_t ulen) {
+        if (is_null) return;
+        uint32_t q = 0;
+        arr_unescape(s, p0, p1, [&](u8 c) { tmp[q++] = c; });
+        RbWrite sw(j.values + j.child_offsets[o + k]);
+        (void)json_display(sw, tmp, ulen, false);
+        sw.finish();
+      });
+    }
+    return;
+  }
   if (j.elem_cls == ETLG_TC_NUMERIC || j.elem_cls == ETLG_TC_TIMETZ) {
     // ArrayCell::Numeric / TimeTz are lists of their Display strings in the sinks (iceberg/encoding.rs:902-945: `n.to_string()`,
     // `t.to_string()`): pass A their lengths, pass B the characters. The element's value is what decode_text_cell left in the

@@ -631,7 +631,9 @@ typedef enum etlg_arrow_kind {
                              * timestamp / timestamptz / uuid (fixed-width children), text and every array type without a dedicated
                              * arm (LargeUtf8 child), numeric / timetz (LargeUtf8 child of the elements' Display strings, as the sinks
                              * write them), bytea (LargeBinary child of the decoded bytes). Var-len children: `child_offsets`.
-                             * json[] stays ETLG_AK_TEXT_FORM */
+                             * json[] / jsonb[] (round 6): LargeUtf8 child of `j.to_string()` per element (ArrayCell::Json,
+                             * iceberg/encoding.rs:577-585); an element of more than 256 bytes or beyond the json writer's limits
+                             * (depth 16, 64 members) hands its row back (`deferred`), one that is not JSON is ETLG_E_JSON */
   ETLG_AK_NONE = 255        /* not handed off - no buffers (no class maps to it today) */
 } etlg_arrow_kind;
 

@@ -512,6 +512,54 @@ def test_numeric_timetz_and_bytea_arrays_on_the_device():
         b.close(); d.close()
 
 
+def test_json_arrays_as_lists_of_display_strings():
+    """json[] / jsonb[] as LargeList<LargeUtf8> of `j.to_string()` per element (ArrayCell::Json, crates/etl-destinations/src/iceberg/
+    encoding.rs:577-585, 964-971; the element strings are serde_json's Display: oracle/json_display.py through oracle/arrays.py). NULL
+    elements, escapes inside the quoted elements, key order, number forms; an element of more than 256 bytes or beyond json_display's
+    limits hands its row back; an element that is not JSON is the reference's decode error (codec/text.rs:126-134) at its row."""
+    from oracle import arrays as OA
+
+    def q(js):   # a JSON text as a quoted array element (Postgres escapes the quotes and the backslashes)
+        return '"' + js.replace("\\", "\\\\").replace('"', '\\"') + '"'
+    good = ['{"b":1,"a":[true,null,1.50,"x\\ny"]}', "[1,2,{\"k\":\"v\"}]", '"text"', "1e5", "-0.0", "null", '{"z":{"y":{"x":[]}}}', '{"dup":1,"dup":2}', "  [ 1 , 2 ]  "]
+    lits = ["{" + ",".join(q(j) for j in good[:3]) + "}", "{" + q(good[3]) + ",NULL," + q(good[4]) + "}", "{}", "{NULL}", "{" + q(good[5]) + "," + q(good[6]) + "}",
+            "[2:3]={" + q(good[7]) + "," + q(good[8]) + "}", "{" + q('{"big":"' + "x" * 300 + '"}') + "}", "{" + q("[" * 20 + "]" * 20) + "}"]
+    rows = [[str(i), lits[i % len(lits)], lits[(i + 3) % len(lits)]] for i in range(40)] + [["900", W.NULL, W.NULL]]
+    cols3 = [("id", SC.INT8, False, 1), ("j", 199, True, 0), ("jb", 3807, True, 0)]
+    buf, offs = _stream([W.insert(42, r) for r in rows])
+    hb, b, d = _both(SC.simple_table(cols3), buf, offs)
+    c = b.columns(0, parse_arrays=True)
+    assert [c.column(i).arrow_kind for i in (1, 2)] == [abi.AK_LIST] * 2
+    rb = columns_to_record_batch(c, names=["id", "j", "jb"])
+    assert rb.schema.field("j").type == pa.large_list(pa.large_utf8())
+    n_back = 0
+    for ci, oid in ((1, 199), (2, 3807)):
+        got = rb.column(ci).to_pylist()
+        deferred = np.unpackbits(c.host_arrays(ci)[1], bitorder="little")[:len(rows)]
+        for r, g, df in zip(rows, got, deferred):
+            if r[ci] is W.NULL:
+                assert g is None and not df
+                continue
+            try:
+                want = [None if e is None else e.decode() for e, _ in OA.elements(oid, r[ci].encode())]
+            except OA.NeedsHost:
+                assert g is None and df, r[ci][:60]
+                n_back += 1
+                continue
+            assert g == want and not df, (r[ci][:80], g, want)
+    assert n_back >= 8
+    assert rb.column(1).to_pylist()[0] == ['{"a":[true,null,1.50,"x\\ny"],"b":1}', '[1,2,{"k":"v"}]', '"text"']   # (sorted keys; the number keeps its literal: arbitrary_precision)
+    c.close(); b.close(); d.close()
+    from etl_amd.decoder import EtlError
+    for lit in ['{"{\\"a\\":}"}', "{abc}", '{"1 2"}']:
+        buf, offs = _stream([W.insert(42, ["1", "{1}", "{2}"]), W.insert(42, ["2", lit, "{3}"])])
+        hb, b, d = _both(SC.simple_table(cols3), buf, offs)
+        with pytest.raises(EtlError) as ei:
+            b.columns(0, parse_arrays=True)
+        assert ei.value.code == abi.E_JSON and ei.value.frame_index == 2, lit
+        b.close(); d.close()
+
+
 JSON_GOOD = ['{"key": "value", "number": 42}', '{"value":1e309}', "null", " true ", "false", "0", "-0", "-0.5e+10", "1E-400", "123456789012345678901234567890",
              '""', '"a\\"b\\\\c\\/d\\b\\f\\n\\r\\t"', '"\\u00e9\\uD83D\\uDE00"', "[]", "{}", "[1,[2,[3,{}]],{\"a\":[]}]", '{"a":{"b":{"c":[null,true,false]}}}',
              "\t[ 1 , 2 ]\n", '{"k":"v","k":"dup"}', '"é中😀"', "[" * 127 + "]" * 127, '{"a":' * 126 + "1" + "}" * 126]

@@ -181,13 +181,14 @@ def test_type_matrix_table_of_68_columns(mix):
         names = [c[0] for c in synth.TYPE_MATRIX_COLS]
         cols = gd.columns(0, parse_arrays=True)
         kinds = {names[i]: cols.column(i).arrow_kind for i in range(len(names))}
-        assert [k for k in names if k.endswith("_arr") and kinds[k] != abi.AK_LIST] == ["json_arr", "jsonb_arr"]
+        assert [k for k in names if k.endswith("_arr") and kinds[k] != abi.AK_LIST] == []   # (round 6: json[] / jsonb[] as lists of `j.to_string()` too)
         rec = columns_to_record_batch(cols, names=names, on_text="binary")
         assert rec.num_rows == 1500
         want = {"bool_arr": [True, False, None], "int4_arr": [456, None, -654], "int8_arr": [7890123456, None, -9876543210], "text_arr": ["hello", None, "world"],
                 "bpchar_arr": ["ab ", None, "cd "], "numeric_arr": ["12345.6789", None, "-0.5"], "timetz_arr": ["12:30:45.123456+02", None, "23:59:59-07:30"],
                 "bytea_arr": [b"\x00", None, b"\x01\x02"], "money_arr": ["$12.34", None, "-$0.01"], "float8_arr": [-7.25, None, 8.5],
-                "num_multirange_arr": ["{[1.0,2.0)}", None, "{[3.0,4.0)}"], "inet_arr": ["192.0.2.1", None, "2001:db8::1"]}
+                "num_multirange_arr": ["{[1.0,2.0)}", None, "{[3.0,4.0)}"], "inet_arr": ["192.0.2.1", None, "2001:db8::1"],
+                "json_arr": ['{"a":1}', None, '{"b":2}'], "jsonb_arr": ['{"a":1}', None, '{"b":2}']}
         for k, v in want.items():
             assert rec.column(k)[0].as_py() == v and rec.column(k)[1499].as_py() == v, k
         cols.close()
