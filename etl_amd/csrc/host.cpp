@@ -170,6 +170,8 @@ static inline void ht_mark(etlg_ctx* c, int i) {
 }
 int32_t decode_tail(etlg_ctx* c, etlg_batch* b, size_t nframes, bool async, etlg_batch* prev);
 int32_t flush_deferred(etlg_ctx* c);
+void check_invariants(etlg_ctx* c, const char* where);
+struct InvariantScope { etlg_ctx* c; const char* where; ~InvariantScope() { if (c && c->debug_invariants) check_invariants(c, where); } };
 hipError_t sync_decode_streams(etlg_ctx* c);
 
 }  // namespace
@@ -278,6 +280,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* rm = getenv("ETLG_ROWS"); if (rm) c->rows_mode = atoi(rm); }
   { const char* cr = getenv("ETLG_CHAIN_REISSUE"); if (cr) c->chain_reissue = atoi(cr) != 0; }
   { const char* sc = getenv("ETLG_SCAN_CHAIN"); if (sc) c->scan_chain_mode = atoi(sc) != 0; }
+  { const char* di = getenv("ETLG_DEBUG_INVARIANTS"); if (di) c->debug_invariants = atoi(di) != 0; }
   clear_error(c);
   (void)etlg_k_plan_set_lds();
   if (const char* pm = getenv("ETLG_PLAN")) c->plan_mode = atoi(pm);
@@ -868,6 +871,7 @@ int32_t etlg_copy_decode(etlg_ctx* c, int32_t schema_slot, const uint8_t* buf, s
 
 int32_t etlg_decode(etlg_ctx* c, const uint8_t* buf, size_t len, const uint32_t* frame_offsets, size_t nframes, uint32_t flags, etlg_batch** out) {
   if (!c || !out) return ETLG_InvalidArgument;
+  InvariantScope inv_scope{c, "etlg_decode"};
   SlowScope slow_scope_decode(c, "etlg_decode");
   *out = nullptr;
   clear_error(c);
@@ -1301,6 +1305,7 @@ extern "C" {
 
 int32_t etlg_batch_sync(etlg_ctx* c, etlg_batch* b) {
   if (!c || !b) return ETLG_InvalidArgument;
+  InvariantScope inv_scope{c, "etlg_batch_sync"};
   if (b->pending) {
     // batches finish in issue order: the carried transaction state of the context is the state after the LAST finished one
     while (b->pending && !c->pending.empty()) { const int32_t rc = finish_batch(c, c->pending.front()); (void)rc; }

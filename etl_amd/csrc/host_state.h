@@ -299,6 +299,7 @@ struct etlg_ctx {
   hipEvent_t fence_ev = nullptr; // etlg_ctx_fence: recorded behind the header copies on res_stream
   bool hdr_in_flight = false;
   int overlap_mode = 1;          // ETLG_OVERLAP=0: one stream, as in round 2
+  bool debug_invariants = false;  // ETLG_DEBUG_INVARIANTS=1: check_invariants (host_orchestrate.inc) at every entry point, abort on a violation
   bool prof_serial = false;      // etlg_ctx_profile(ctx, 2): kernels timed one at a time (no second stream), for per-kernel durations
   unsigned long long overlapped = 0;   // debugging aid: batches launched beside their predecessor
   // result blocks: a ring re-initialised once per lap with one copy

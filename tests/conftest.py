@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 import etl_amd  # noqa: E402,F401  (before anything initialises HIP: the package sets the process's hardware-queue default)
 
 
+# Every context the suites create checks the batch-state invariants of the ASYNC chain at its entry points (host_orchestrate.inc:
+# check_invariants aborts the process with the violated rule): on the MI355X and under the CPU emulator alike. bench.py does not set it.
+os.environ.setdefault("ETLG_DEBUG_INVARIANTS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
