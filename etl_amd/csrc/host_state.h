@@ -75,6 +75,7 @@ extern "C" void etlg_k_launch_rows(const DecParams* p, const void* q, hipStream_
 extern "C" void etlg_k_finish(const void* job, unsigned long long* blk, int64_t* offsets, int step, hipStream_t st);
 extern "C" int etlg_k_rows_set_lds(void);
 extern "C" int etlg_k_rows_waves(void);
+extern "C" int etlg_k_rows_waves_per_simd(void);
 extern "C" int etlg_k_rows_occupancy(uint32_t lds_bytes);
 extern "C" uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc, uint32_t cf);
 extern "C" uint32_t etlg_k_rows_static_lds(void);

@@ -758,6 +758,7 @@ int etlg_k_rows_set_lds(void) {
   return a | b;
 }
 int etlg_k_rows_waves(void) { return rows_nw(); }
+int etlg_k_rows_waves_per_simd(void) { return ETLG_ROWS_MINBLOCKS; }
 
 // heap-cell table + cell positions next to the image and the window
 uint32_t etlg_k_rows_table_bytes(uint32_t maxh_old, uint32_t maxh, uint32_t maxc, uint32_t cf) {
