@@ -313,3 +313,47 @@ def test_heap_grows_for_wide_arrays_and_sharded_header_follows():
     assert not hb.diff(gh)
     assert gh.materialize()[1]["row"][1][2][2999] == ("I64", 9)
     d.close()
+
+
+def test_finish_on_table_copy_rows_and_on_a_batch_that_ends_in_an_error():
+    """(1) etlg_copy_decode honours ETLG_F_FINISH_CELLS: COPY text rows of a table with array and float columns (the row's escapes are
+    undone before the literal is seen: a backslash in the COPY form is two in the array literal) come back with typed arrays, arena =
+    the oracle's copy_decode + finish. (2) A WAL batch whose 40th row has a malformed int: the events before it are finished like any
+    other (the reference's consumer gets a valid prefix, fail-fast), the error and its frame are the oracle's."""
+    o, d = _pair()
+    cols = [("id", SC.INT8, False, 1), ("a", K.INT4_A, True, 0), ("t", K.TEXT_A, True, 0), ("f", SC.FLOAT8, True, 0), ("n", K.NUMERIC_A, True, 0)]
+    for t in (o, d):
+        t.schema_put(42, 0, cols)
+    so, sd = o.table_ready(42, 0, [1] * 5, [1, 0, 0, 0, 0]), d.table_ready(42, 0, [1] * 5, [1, 0, 0, 0, 0])
+    rng = random.Random(5)
+    rows = []
+    for i in range(300):
+        arr = _fuzz_literal(rng, "int")
+        txt = _fuzz_literal(rng, "text").replace("\\", "\\\\").replace("\t", "\\t").replace("\n", "\\n")   # the COPY form of the literal
+        flt = rng.choice(["9007199254740993", "0.1", "1.00000000000000011102230246251565404236316680908203125", "\\N"])
+        num = _fuzz_literal(rng, "numeric")
+        rows.append(("\t".join([str(i), arr if rng.random() > 0.1 else "\\N", txt, flt, num]) + "\n").encode())
+    buf = np.frombuffer(b"".join(rows), dtype=np.uint8)
+    offs = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint32)
+    rb = o.copy_decode(so, buf, offs)
+    gb = d.copy_decode(sd, buf, offs, flags=FIN)
+    assert rb.err_code == 0 and gb.rc == 0, (rb.err_code, gb.error)
+    assert rb.finish() > 300
+    diff = rb.host_batch().diff(gb.host())
+    assert not diff, diff[:6]
+    d.close()
+    # (2)
+    o, d = _pair()
+    prime = SC.simple_table([("id", SC.INT8, False, 1), ("a", K.INT8_A, True, 0), ("v", SC.INT4, False, 0), ("f", SC.FLOAT4, False, 0)])
+    prime(o); prime(d)
+    msgs = [W.insert(42, [str(i), "{%d,NULL,%d}" % (i, -i), "7" if i != 40 else "7x", "16777217.5"]) for i in range(80)]
+    s = SC.txn(msgs)
+    buf = np.frombuffer(s.bytes(), dtype=np.uint8)
+    rb = o.decode(buf, s.offsets)
+    gb = d.decode(buf, s.offsets, flags=FIN)
+    assert rb.err_code != 0 and gb.rc != 0 and (gb.error.code, gb.error.frame_index) == (rb.err_code, rb.err_frame)
+    assert rb.finish() == 40
+    hb, gh = rb.host_batch(), gb.host()
+    assert not hb.diff(gh)
+    assert [e for e in gh.materialize() if e["kind"] == "I"][39]["row"][1] == ("Array", "I64", [("I64", 39), ("Null",), ("I64", -39)])
+    d.close()
