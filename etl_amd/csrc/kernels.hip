@@ -355,23 +355,32 @@ void etlg_k_launch(int which, const DecParams* p, hipStream_t s) {
   }
 }
 
-// Commit-aligned shard cuts (etlg_shard_plan): lane k finds the k-th interior cut of an n-way split balanced by bytes — the first frame
+// Commit-aligned shard cuts (etlg_shard_plan): WAVE k finds the k-th interior cut of an n-way split balanced by bytes — the first frame
 // index e with tags[e - 1] == 'C' whose byte offset reaches total * k / n, or the last such index when no Commit lies behind that point
-// (0 when the range has no Commit at all). The caller makes the list monotonic. One transaction's worth of tags per lane: a serial scan.
+// (0 when the range has no Commit at all). The caller makes the list monotonic. The wave looks at 64 tags per step (ballot): a stream
+// with few or no Commits costs nframes / 64 steps per cut instead of one lane walking every tag.
 __global__ __launch_bounds__(64) void k_shard_cuts(const u8* tags, const uint32_t* offs, uint32_t nframes, uint32_t n_shards, uint32_t* cuts) {
-  const uint32_t k = blockIdx.x * 64 + threadIdx.x + 1;
+  const uint32_t k = blockIdx.x + 1, lane = threadIdx.x;
   if (k >= n_shards) return;
   const uint64_t total = offs[nframes];
   const uint64_t target = total * k / n_shards;
   uint32_t lo = 0, hi = nframes;   // smallest i in [0, nframes] with offs[i] >= target
   while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if ((uint64_t)offs[mid] >= target) hi = mid; else lo = mid + 1; }
-  uint32_t e = lo ? lo : 1u, cut = 0;
-  for (; e <= nframes; e++) if (tags[e - 1] == 'C') { cut = e; break; }
-  if (!cut) for (e = lo; e >= 1; e--) if (tags[e - 1] == 'C') { cut = e; break; }
-  cuts[k - 1] = cut;
+  uint32_t cut = 0;
+  for (uint64_t e0 = lo ? lo : 1u; e0 <= nframes && !cut; e0 += 64) {   // forward: the first e >= max(lo, 1) with a Commit in front of it
+    const uint64_t e = e0 + lane;
+    const unsigned long long m = __ballot(e <= nframes && tags[e - 1] == 'C');
+    if (m) cut = (uint32_t)(e0 + (uint32_t)__builtin_ctzll(m));
+  }
+  for (int64_t e1 = lo; e1 >= 1 && !cut; e1 -= 64) {                   // none behind the target: the last one at or before it
+    const int64_t e = e1 - (int64_t)lane;
+    const unsigned long long m = __ballot(e >= 1 && tags[e - 1] == 'C');
+    if (m) cut = (uint32_t)(e1 - (int64_t)__builtin_ctzll(m));
+  }
+  if (lane == 0) cuts[k - 1] = cut;
 }
 void etlg_k_shard_cuts(const uint8_t* tags, const uint32_t* offs, uint32_t nframes, uint32_t n_shards, uint32_t* cuts, hipStream_t s) {
-  hipLaunchKernelGGL(k_shard_cuts, dim3((n_shards + 63) / 64), dim3(64), 0, s, tags, offs, nframes, n_shards, cuts);
+  if (n_shards > 1) hipLaunchKernelGGL(k_shard_cuts, dim3(n_shards - 1), dim3(64), 0, s, tags, offs, nframes, n_shards, cuts);
 }
 
 void etlg_k_ctl_pick(const uint8_t* tags, uint32_t nframes, uint32_t* hdr, uint32_t* list, uint32_t cap, hipStream_t s) {
