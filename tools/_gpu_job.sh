@@ -1,3 +1,2 @@
-timeout 400 python tools/finish_fuzz.py 240 1000 2>&1 | tail -3 > gpurun_out/r06zp_finish_fuzz.txt
-timeout 300 python tools/async_fuzz.py 2>&1 | tail -1 >> gpurun_out/r06zp_finish_fuzz.txt
-timeout 300 python tools/scan_hunt.py 2>&1 | tail -2 >> gpurun_out/r06zp_finish_fuzz.txt
+mkdir -p gpurun_out/r06g
+( time timeout 900 python bench.py > gpurun_out/r06g/bench3.json 2> gpurun_out/r06g/bench3.err ); tail -c 100 gpurun_out/r06g/bench3.json
