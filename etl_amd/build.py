@@ -15,7 +15,7 @@ SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "rows.hip", "plan.hip", "sca
 OPT = {"fused.hip": "-Os"}
 DEFS = {}   # no per-source feature flags: one code path per kernel
 # what every object depends on beside its own source (the shared headers); host.cpp also on its parts
-COMMON = ["../build.py", "dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
+COMMON = ["../build.py", "dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", "float_slow.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]
 EXTRA = {"fused.hip": ["fixed_tile.hip.h"], "host.cpp": ["host_state.h", "host_control.inc", "host_handoff.inc", "host_orchestrate.inc"]}
 DEPS = SOURCES + COMMON + [d for v in EXTRA.values() for d in v]   # (the library as a whole)
 
