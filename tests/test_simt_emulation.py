@@ -74,6 +74,7 @@ _JOBS = {
     "copy_scan": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_scan.py", "-k", "not device_resident and not device_input and not 16777216"], 600),
     "plans": _pytest_job(["tests/test_gpu_fixed_plan.py", "tests/test_gpu_fuzz.py", "-k", "fixed_plan or k_plan or prepass or (cfg2 and default)"], 900),
     "finish_pass": _pytest_job(["tests/test_gpu_finish.py"], 600),
+    "round6_lazy_streams": _pytest_job(["tests/test_gpu_finish.py", "tests/test_gpu_async.py", "-k", "finish or behind_its_boundary_scan or without_a_sidecar or result_ring"], 900, streams="lazy"),
     "hand_off": _pytest_job(["tests/test_gpu_columns.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_size_hints.py", "tests/test_gpu_protobuf.py", "tests/test_arrow_kats.py", "tests/test_gpu_json_display.py"], 600),
     "lane_order": _pytest_job(["tests/test_gpu_copy.py", "tests/test_gpu_rowbinary.py", "tests/test_gpu_protobuf.py",
                                "-k", "not device_resident and not device_input and not 16777216 and not synthetic and not kat_ and not random"], 600, order="shuffle"),
@@ -207,6 +208,12 @@ def test_finish_pass_typed_arrays_and_exact_floats(emu_jobs):
     """etlg_batch_finish_cells / ETLG_F_FINISH_CELLS (columns.hip: k_fin_count / k_fin_fill, float_slow.h): the reference's array vectors
     through the emulated kernels, the type-matrix table, fuzzed literals in every image, the float matrix — tests/test_gpu_finish.py."""
     _passed(emu_jobs, "finish_pass")
+
+
+def test_round6_paths_with_lazy_streams_and_poisoned_memory(emu_jobs):
+    """The finish pass, the decode enqueued behind its boundary scan and the guarded result ring with enqueued work running as late as the
+    HIP ordering rules allow, LDS and device allocations starting as garbage: a missing event / a read of something never written shows."""
+    _passed(emu_jobs, "round6_lazy_streams")
 
 
 def test_long_async_chains_with_second_attempts(emu_jobs):
