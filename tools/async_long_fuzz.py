@@ -22,7 +22,7 @@ from tests.test_gpu_async import FLAGS, DevBufs, _cut
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 mode = sys.argv[3] if len(sys.argv) > 3 else "cfg2"    # "nosidecar" / "mixed": (some) batches without the offsets sidecar; "cfg5": the DDL workload with default flags — the pipelined control path (pre-pass ring, two scratch sets) over many laps
-if mode in ("cfg5", "ddl"):
+if mode in ("cfg5", "ddl", "ddl_fixed"):
     from tests.test_gpu_async import FLAGS_DEFAULT
     t_end = time.time() + seconds
     rounds = batches = bad = 0
@@ -32,6 +32,11 @@ if mode in ("cfg5", "ddl"):
             w = synth.Workload([synth.table_fixed(), synth.table_w8(), synth.table_mixed()], 0xE7D0000 + seed * 1000 + rounds, rows_per_txn=rng.choice([3, 5, 12]),
                                mix=(60, 30, 10), upd_key=10, upd_toast=5, emit_relations=1, emit_origin=1, ddl_every=rng.choice([2, 3, 7]), type_msg_pct=10,
                                keepalive_every=97, name="ddl_dense")
+        elif mode == "ddl_fixed":   # fixed-width tables only, a DDL message -> Relation now and then, default flags: batches WITHOUT a control frame behind one that had
+            # some take the plan kernel behind their control pass (standard_path, round 6); Updates by key / Deletes hand those back to the generic kernel
+            w = synth.Workload([synth.table_fixed(), synth.table_fixed(16390, "bench_fixed_b")], 0xE7F0000 + seed * 1000 + rounds, rows_per_txn=rng.choice([5, 12, 40]),
+                               mix=rng.choice([(100, 0, 0), (90, 10, 0), (60, 30, 10)]), upd_key=rng.choice([0, 0, 10]), emit_relations=1, emit_origin=1,
+                               ddl_every=rng.choice([3, 7, 40, 200]), keepalive_every=rng.choice([0, 997]), name="ddl_fixed")
         else:
             w = synth.cfg5(seed=0xE7B0000 + seed * 1000 + rounds)
         buf, offs = w.fill((rng.choice([2, 3, 4]) << 20) if mode == "cfg5" else (rng.choice([1, 2]) << 20))
@@ -59,7 +64,7 @@ if mode in ("cfg5", "ddl"):
         d.close()
         rounds += 1
         print("round", rounds, "window", window, "batches", len(pieces), paths, flush=True)
-    print(f"async long fuzz (cfg5, default flags): {rounds} chains, {batches} batches checked, {bad} problems, seeds {seed}..{seed + rounds - 1}")
+    print(f"async long fuzz ({mode}, default flags): {rounds} chains, {batches} batches checked, {bad} problems, seeds {seed}..{seed + rounds - 1}")
     sys.exit(1 if bad else 0)
 t_end = time.time() + seconds
 rounds = batches = bad = spliced_total = 0
