@@ -530,46 +530,3 @@ def test_prepass_more_than_64_groups():
     assert np.array_equal(np.asarray(h.commit_lsn, dtype=np.uint64)[rows], b_lsn[last_b[rows]])
     d.close()
 
-
-# ---- the plan kernel behind a control pass (round 6, standard_path) ---------------------------------------------------------------
-@pytest.mark.parametrize("what", ["conforming", "delete_in_the_second_batch"])
-def test_k_plan_behind_the_control_pass(what):
-    """Default flags (the caller asserts nothing about Relation / DDL frames), a stream that starts with its Relation frame (synth.cfg1:
-    BASELINE configs[0]): batch 0 takes the control path and a generic kernel; batch 1 comes behind a batch that HAD control frames, so its
-    control pass runs first — it finds none, and since round 6 the fixed-width plan decodes it (it used to be k_fused's only because of
-    its predecessor); batch 2 is optimistic again. A Delete in batch 1 hands it back to the generic kernel as on the optimistic route.
-    (ETLG_PLAN_BEHIND_CONTROL=0, read once per process, restores the old choice: the counters below follow whichever is in force.)"""
-    from etl_amd.decoder import Decoder
-    from oracle import oracle
-    w = synth.cfg1()
-    buf, offs = w.fill(1 << 20, max_txns=9)
-    tags = np.where(buf[offs[:-1] + 5] == ord("w"), buf[offs[:-1] + 30], 0)
-    commits = np.nonzero(tags == ord("C"))[0]
-    cuts = [0, int(commits[2]) + 1, int(commits[5]) + 1, len(offs) - 1]
-    pieces = [(np.ascontiguousarray(buf[offs[a]:offs[b]]), (offs[a:b + 1] - offs[a]).astype(np.uint32)) for a, b in zip(cuts, cuts[1:])]
-    assert (tags[:cuts[1]] == ord("R")).any() and not (tags[cuts[1]:] == ord("R")).any()
-    if what == "delete_in_the_second_batch":
-        b1, o1 = pieces[1]
-        at = next(k for k in range(1, len(o1) - 1) if b1[int(o1[k]) + 30] == ord("I") and b1[int(o1[k - 1]) + 30] == ord("I"))
-        lsn = int.from_bytes(b1[int(o1[at]) + 6:int(o1[at]) + 14].tobytes(), "big")
-        dele = W.frame(W.xlog(lsn - 1, W.delete(w.tables[0]["rel_id"], key=["4"])))
-        cut = int(o1[at])
-        pieces[1] = (np.concatenate([b1[:cut], np.frombuffer(dele, dtype=np.uint8), b1[cut:]]),
-                     np.concatenate([o1[:at + 1], o1[at:] + len(dele)]).astype(np.uint32))
-    d, o = Decoder(0), oracle.Oracle()
-    w.register(d, ready=False)
-    w.register(o, ready=False)
-    seen = []
-    for pb, po in pieces:
-        assert _agree(d, o, pb, po) == 0
-        seen.append(d.debug_paths())
-    on = os.environ.get("ETLG_PLAN_BEHIND_CONTROL", "1") != "0"
-    p = seen[-1]
-    assert seen[0]["control"] == 1 and seen[0]["plan"] == 0, seen
-    assert seen[1]["control"] == 2, seen            # batch 1: behind a batch with control frames, its control pass runs
-    if what == "delete_in_the_second_batch":
-        assert seen[1]["plan"] == 0 and seen[1]["plan_redone"] == (1 if on else 0), seen
-    else:
-        assert seen[1]["plan"] == (1 if on else 0) and seen[1]["plan_redone"] == 0, seen
-    assert p["redone"] == 0 and p["multipass"] == 0, seen
-    d.close()

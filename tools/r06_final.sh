@@ -31,6 +31,6 @@ for wl in cfg5 wide70 copy copy_clean nosidecar finish; do
   f=$(ls $O/prof_$wl/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && { cp $f $O/${wl}_kernel_stats.csv; head -n 3 $f | cut -c1-160; }
   rm -rf $O/prof_$wl
 done
-for m in nosidecar mixed cfg2 cfg5; do timeout 200 python tools/async_long_fuzz.py 40 11 $m 2>&1 | tail -1 >> $O/long_fuzz.txt; done
+for m in nosidecar mixed cfg2 cfg5 ddl_fixed; do timeout 200 python tools/async_long_fuzz.py 40 11 $m 2>&1 | tail -1 >> $O/long_fuzz.txt; done
 timeout 300 python tools/cell_fuzz.py 60 2>&1 | tail -2 >> $O/long_fuzz.txt
 rm -rf gpurun_out/traffic_*_FETCH_SIZE gpurun_out/traffic_*_WRITE_SIZE
