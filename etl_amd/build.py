@@ -12,7 +12,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["kernels.hip", "fused.hip", "cells.hip", "rows.hip", "plan.hip", "scan.hip", "copy.hip", "columns.hip", "host.cpp"]
 # per-source optimisation level: k_fused is measurably faster built for size (88 vs 93 us on cfg2, tools/variants.sh);
 # k_cells and the rest are not
-OPT = {"fused.hip": "-Os"}
+# (round 6: so is k_copy_cells — cells.hip at -Os 468 / 304 us against 482-486 / 313-317 on the two table-copy workloads, same box;
+# -O2, -fno-unroll-loops and the scheduler strategies move nothing on rows.hip / plan.hip: profiles/r06zv_compile_flag_sweep.txt)
+OPT = {"fused.hip": "-Os", "cells.hip": "-Os"}
 DEFS = {}   # no per-source feature flags: one code path per kernel
 # what every object depends on beside its own source (the shared headers); host.cpp also on its parts
 COMMON = ["../build.py", "dev_types.h", "codec.hip.h", "lookback.hip.h", "utf8_swar.h", "float_fast.h", "float_slow.h", "pow5_table.h", os.path.join("..", "..", "include", "etlg.h")]

@@ -148,7 +148,10 @@ DEV void record_error(const DecParams& p, uint32_t frame, uint32_t rank, uint32_
 // this one must not run either — the host decodes both again, in order, when they are synced (DevResult.fused_fail bit 3).
 DEV bool load_carry(DecParams& p) {
   if (!p.carry) return true;
-  const bool ok = p.carry->fused_fail == 0 && p.carry->first_err == kNoErr;
+  // (bit 1 alone — a fixed-width plan that gave its batch up over a shape it does not cover — is not a reason to stop: that kernel has
+  // published the three words from the Begin / Commit frames it read. The host keeps this batch's result only if the second attempt at
+  // that batch leaves the same words: finish_batch, `spare`; otherwise this batch is decoded again as it always was.)
+  const bool ok = (p.carry->fused_fail & ~2u) == 0 && p.carry->first_err == kNoErr;
   p.in_txn = p.carry->out_in_txn; p.final_lsn = p.carry->out_final_lsn; p.next_ord = p.carry->out_next_ord;
   if (!ok && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&p.res->fused_fail, 8u);
   return ok;

@@ -279,6 +279,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* fk = getenv("ETLG_FUSED_KERNEL"); c->fused_kernel = fk ? atoi(fk) : -1; }
   { const char* rm = getenv("ETLG_ROWS"); if (rm) c->rows_mode = atoi(rm); }
   { const char* cr = getenv("ETLG_CHAIN_REISSUE"); if (cr) c->chain_reissue = atoi(cr) != 0; }
+  { const char* cs = getenv("ETLG_CHAIN_SPARE"); if (cs) c->chain_spare = atoi(cs) != 0; }
   { const char* sc = getenv("ETLG_SCAN_CHAIN"); if (sc) c->scan_chain_mode = atoi(sc) != 0; }
   { const char* di = getenv("ETLG_DEBUG_INVARIANTS"); if (di) c->debug_invariants = atoi(di) != 0; }
   clear_error(c);
@@ -788,7 +789,7 @@ int32_t etlg_ctx_debug_copy(etlg_ctx* c, unsigned long long* out2) {
 // [1] chains finished early because their last batch was marked for a second attempt
 int32_t etlg_ctx_debug_ring(etlg_ctx* c, unsigned long long* out1) {
   if (!c || !out1) return ETLG_InvalidArgument;
-  out1[0] = c->ring_recleared; out1[1] = c->chain_healed; out1[2] = c->chain_reissued; out1[3] = c->scan_chained_n; out1[4] = c->scan_chain_redone;
+  out1[0] = c->ring_recleared; out1[1] = c->chain_healed; out1[2] = c->chain_reissued; out1[3] = c->scan_chained_n; out1[4] = c->scan_chain_redone; out1[5] = c->chain_spared;   // (callers pass eight words)
   return ETLG_OK;
 }
 

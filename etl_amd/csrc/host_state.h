@@ -312,6 +312,8 @@ struct etlg_ctx {
   bool chain_reissue = false;    // ETLG_CHAIN_REISSUE=1: the successors of a batch that was decoded again are enqueued again, chained to its new result
                                  // (reissue_successors). Built and measured in round 6 — it LOST on the delete-in-every-10th-batch leg (548 against 905 GB/s:
                                  // every give-up re-runs the whole window on one stream) — so the default stays each successor decoded again at its own sync
+  bool chain_spare = true;       // ETLG_CHAIN_SPARE=0: the batches behind a plan batch that was decoded again are always decoded again (the rule before round 6's last session)
+  uint64_t chain_spared = 0;     // second attempts of a plan batch that left the carried state its first attempt had published: the batches behind it stood (finish_batch)
   uint64_t chain_healed = 0;     // ASYNC chains finished early because their last batch was marked for a second attempt (etlg_decode)
   uint64_t ring_recleared = 0;   // result blocks cleared again after a second attempt behind their lap's re-initialisation (finish_batch)
   uint32_t res_seq = 0;

@@ -394,26 +394,33 @@ class Decoder:
 
     def debug_ring_recleared(self):
         """Result blocks cleared again after a second attempt behind their lap's re-initialisation (debugging aid, not in etlg.h)."""
-        out = (C.c_ulonglong * 5)()
+        out = (C.c_ulonglong * 8)()
         self.L.etlg_ctx_debug_ring(self.h, out)
         return int(out[0])
 
     def debug_chains_healed(self):
         """ASYNC chains that were finished early because their last batch was marked for a second attempt (debugging aid)."""
-        out = (C.c_ulonglong * 5)()
+        out = (C.c_ulonglong * 8)()
         self.L.etlg_ctx_debug_ring(self.h, out)
         return int(out[1])
+
+    def debug_chains_spared(self):
+        """Second attempts of a fixed-width-plan batch that left the carried transaction state its first attempt had published: the batches
+        in flight behind it were NOT decoded again (debugging aid)."""
+        out = (C.c_ulonglong * 8)()
+        self.L.etlg_ctx_debug_ring(self.h, out)
+        return int(out[5])
 
     def debug_scan_chained(self):
         """(batches whose decode was enqueued behind their boundary scan with the frame count read on the device, those of them that
         had to be decoded again with the count in hand) — debugging aid."""
-        out = (C.c_ulonglong * 5)()
+        out = (C.c_ulonglong * 8)()
         self.L.etlg_ctx_debug_ring(self.h, out)
         return int(out[3]), int(out[4])
 
     def debug_chain_reissued(self):
         """ASYNC batches enqueued again — chained to the new result — behind a batch that was decoded again (debugging aid)."""
-        out = (C.c_ulonglong * 5)()
+        out = (C.c_ulonglong * 8)()
         self.L.etlg_ctx_debug_ring(self.h, out)
         return int(out[2])
 

@@ -309,12 +309,17 @@ def test_async_chain_when_the_plan_does_not_cover_a_batch():
     assert paths["plan_redone"] >= 1 and paths["redone"] == 0, paths
 
 
-def test_async_chain_second_attempts_across_a_ring_lap():
+@pytest.mark.parametrize("spare", [True, False])
+def test_async_chain_second_attempts_across_a_ring_lap(spare, monkeypatch):
     """70 cfg2 batches, six in flight; batch 30 holds an UPDATE with a key image, which the fixed-width plan does not cover. It is decoded again when it is
     synced — and with it the batches queued behind it — AFTER batch 32 (result block 0) has sent out the ring's re-initialisation for the
     next lap: what the second attempts leave in blocks 30 and 31 must not meet batches 62 and 63 (payload shards are added to, give-up
-    and error words or-ed / min-ed into, carry_ready polled by the batch that runs beside). Every batch of the chain against the oracle."""
+    and error words or-ed / min-ed into, carry_ready polled by the batch that runs beside). Every batch of the chain against the oracle.
+    `spare` (the default since round 6's last session): the generic kernel's second attempt at batch 30 leaves the carried transaction
+    state the plan had published before it gave up, so the batches behind it STAND — one second attempt, no chain to heal; with
+    ETLG_CHAIN_SPARE=0 they are decoded again as before."""
     from etl_amd.decoder import Decoder
+    monkeypatch.setenv("ETLG_CHAIN_SPARE", "1" if spare else "0")
     from oracle import oracle
     from tests import pgwire as W
     w = synth.cfg2()
@@ -347,11 +352,16 @@ def test_async_chain_second_attempts_across_a_ring_lap():
             b.close()
             done += 1
     paths = d.debug_paths()
-    assert paths["plan_redone"] >= 1 and 1 <= paths["chain_rerun"] <= 6, paths   # the six batches that were in flight behind batch 30, and no more:
-    assert d.debug_chains_healed() == 1                    # ... the chain was finished once and started afresh (it used to stay poisoned: every
-                                                           # later batch a refused first attempt plus a synchronous second one, chain_rerun 39)
-    assert d.debug_ring_recleared() >= 2                   # blocks 30 and 31 (block 31's re-initialisation went out with batch 33)
-    assert paths["plan"] >= 60, paths
+    if spare:
+        assert paths["plan_redone"] == 1 and paths["chain_rerun"] == 0 and d.debug_chains_spared() == 1, paths
+        assert d.debug_chains_healed() == 0 and d.debug_ring_recleared() >= 1    # block 30
+        assert paths["plan"] == 69, paths
+    else:
+        assert paths["plan_redone"] >= 1 and 1 <= paths["chain_rerun"] <= 6, paths   # the six batches that were in flight behind batch 30, and no more:
+        assert d.debug_chains_healed() == 1                    # ... the chain was finished once and started afresh (it used to stay poisoned: every
+                                                               # later batch a refused first attempt plus a synchronous second one, chain_rerun 39)
+        assert d.debug_ring_recleared() >= 2                   # blocks 30 and 31 (block 31's re-initialisation went out with batch 33)
+        assert paths["plan"] >= 60, paths
     d.close()
 
 
