@@ -369,9 +369,11 @@ def leg_cfg2_mixed(dev_id, dev, cap, npool, nbatches):
     """The fixed-width plan off its insert-only diet: the cfg2 stream with ONE Update in (a) every batch, (b) every 10th batch
     — an Insert frame's tag byte rewritten to 'U': an Update without an old image has the Insert's layout, and since round 6 the plan
     decodes it itself (round 5: the batch was decoded again by the generic kernel and the ASYNC chain behind it started over) — and
-    (c) one Delete by key in every 10th batch, a shape the plan still gives up on: the give-up path (second attempt on the generic
-    kernel, the batches in flight behind it enqueued again, chained to the new result). ASYNC chain of `nbatches` 64 MiB batches,
-    NO_CONTROL, device-resident in / out."""
+    (c) one Delete by key in every 10th batch (the plan's own since round 6's last session: the key-layout row, priced by the pre-pass
+    by its length), (d) one Update WITH a key image in every 10th batch, a shape the plan still gives up on: the give-up path — a
+    second attempt on the generic kernel; the batches in flight behind it stand when that attempt leaves the carried transaction state
+    the plan had published (`chain_rerun` counts the ones that do not). ASYNC chain of `nbatches` 64 MiB batches, NO_CONTROL,
+    device-resident in / out."""
     import numpy as np
     import torch
 
@@ -382,7 +384,7 @@ def leg_cfg2_mixed(dev_id, dev, cap, npool, nbatches):
     out = {}
     FL = abi.F_OUTPUT_ON_DEVICE | abi.F_NO_CONTROL | abi.F_ASYNC
     def with_delete(buf, offs, f):
-        """frame f (an Insert) replaced by a Delete of the same row by its key: 'D' rel 'K' 1 column — a shape the plan gives up on"""
+        """frame f (an Insert) replaced by a Delete of the same row by its key: 'D' rel 'K' 1 column"""
         fr = bytes(buf[offs[f]:offs[f + 1]])
         cell_len = int.from_bytes(fr[39:43], "big")            # the first cell: 't' len bytes at offset 38
         body = b"D" + fr[31:35] + b"K" + (1).to_bytes(2, "big") + fr[38:43 + cell_len]
@@ -392,7 +394,19 @@ def leg_cfg2_mixed(dev_id, dev, cap, npool, nbatches):
         no[f + 1:] += len(nf) - len(fr)
         return nb, no.astype(np.uint32)
 
-    for name, every, how in (("update_in_every_batch", 1, "U"), ("update_in_every_10th_batch", 10, "U"), ("delete_in_every_10th_batch", 10, "D")):
+    def with_update_key(buf, offs, f):
+        """frame f (an Insert) replaced by an Update of the same row that carries its key image: 'U' rel 'K' 1 column 'N' row — a shape the plan gives up on"""
+        fr = bytes(buf[offs[f]:offs[f + 1]])
+        cell_len = int.from_bytes(fr[39:43], "big")
+        body = b"U" + fr[31:35] + b"K" + (1).to_bytes(2, "big") + fr[38:43 + cell_len] + b"N" + fr[36:]
+        nf = b"d" + (4 + 25 + len(body)).to_bytes(4, "big") + fr[5:30] + body
+        nb = np.concatenate([buf[:offs[f]], np.frombuffer(nf, dtype=np.uint8), buf[offs[f + 1]:]])
+        no = offs.astype(np.int64).copy()
+        no[f + 1:] += len(nf) - len(fr)
+        return nb, no.astype(np.uint32)
+
+    for name, every, how in (("update_in_every_batch", 1, "U"), ("update_in_every_10th_batch", 10, "U"), ("delete_in_every_10th_batch", 10, "D"),
+                             ("update_with_key_in_every_10th_batch", 10, "UK")):
         mixed = []
         for k, (buf, offs) in enumerate(pool):
             b2, o2 = buf.copy(), offs
@@ -401,8 +415,10 @@ def leg_cfg2_mixed(dev_id, dev, cap, npool, nbatches):
                 f = int(np.nonzero(tags == ord("I"))[0][len(offs) // 2])   # an Insert in the middle of the batch
                 if how == "U":
                     b2[offs[f] + 30] = ord("U")
-                else:
+                elif how == "D":
                     b2, o2 = with_delete(b2, offs, f)
+                else:
+                    b2, o2 = with_update_key(b2, offs, f)
             mixed.append((b2, o2))
         items = to_device(mixed, dev)
         dec = Decoder(dev_id)
@@ -412,7 +428,7 @@ def leg_cfg2_mixed(dev_id, dev, cap, npool, nbatches):
             pl.issue()
         pl.drain()
         torch.cuda.synchronize()
-        n0 = {**dec.debug_paths(), **dec.debug_rows()}
+        n0 = {**dec.debug_paths(), **dec.debug_rows(), "chain_spared": dec.debug_chains_spared()}
         pl = Pipeline(dec, items, FL, True)
         t0 = time.perf_counter()
         for _ in range(nbatches):
@@ -422,11 +438,12 @@ def leg_cfg2_mixed(dev_id, dev, cap, npool, nbatches):
         dt = time.perf_counter() - t0
         n1 = {**dec.debug_paths(), **dec.debug_rows()}
         n1["chain_reissued"] = dec.debug_chain_reissued(); n0.setdefault("chain_reissued", 0)
+        n1["chain_spared"] = dec.debug_chains_spared()
         dec.close()
         out[name] = {"value": round(pl.bytes / dt / 1e9, 3), "unit": "GB/s", "us_per_batch": round(1e6 * dt / nbatches, 1), "batches": nbatches,
                      "paths": {k: n1[k] - n0[k] for k in n1 if n1[k] - n0[k]}}
         del items
-    out["workload"] = f"cfg2 stream, {cap >> 20} MiB batches, one Insert of the named batches rewritten as an Update without an old image / replaced by a Delete by key; pool of {npool} batches, ASYNC | NO_CONTROL, chain of {nbatches}"
+    out["workload"] = f"cfg2 stream, {cap >> 20} MiB batches, one Insert of the named batches rewritten as an Update without an old image / replaced by a Delete by key / by an Update with its key image; pool of {npool} batches, ASYNC | NO_CONTROL, chain of {nbatches}"
     return out
 
 

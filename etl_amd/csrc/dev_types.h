@@ -179,8 +179,12 @@ struct PlanTab {
   uint32_t n_cols;
   uint32_t row_dwords;  // full-layout row block, dwords
   uint32_t cols_base;   // index of the table's first column word
+  uint32_t key_dwords;  // key-layout row block, dwords; 0: the plan does not take this table's Deletes (no identity column)
+  uint32_t n_ident;
+  uint32_t keys_base;   // index of the table's first key word (n_cols of them, behind the column words)
 };
 // one word per column: cls | nullable << 8 | off_full << 16
+// one key word per column (Deletes by key, round 6): identity | key_index << 8 | off_key (dwords) << 24
 
 struct PlanParams {
   unsigned long long* desc;    // look-back words (plan.hip): desc[ntiles] | gdesc[ceil(ntiles / 64)] | dlsn[ntiles]
@@ -204,6 +208,11 @@ struct PlanParams {
   uint32_t* pre_ticket;        // the pre-pass's arrival counter (zero between launches)
   uint32_t pre_tag;            // 1..3, changes with every use of a buffer: the status of this launch's group words
   uint32_t pre_row_dw;         // the row dwords every planned table shares (the pre-pass prices a frame without reading it)
+  uint32_t pre_key_dw;         // ... and the key-row dwords they share, with
+  uint32_t pre_key_below;      // the length below which a frame that is no Begin / Commit is priced as a Delete by key: the shortest row frame any
+                               // planned table can send (38 + 6 per NOT NULL column + 1 per nullable one). 0: every such frame is a row (Deletes give the batch up)
+  uint32_t pre_key_max;        // the longest Delete by key the pre-pass still recognises: a frame of pre_key_below .. pre_key_max bytes has its tag byte read
+                               // (like the frames of a Begin's / Commit's length) and is priced as a key row when that is 'D'
 };
 
 // ---- columnar hand-off (columns.hip)

@@ -280,6 +280,7 @@ int32_t etlg_ctx_create(int32_t hip_device, etlg_ctx** out) {
   { const char* rm = getenv("ETLG_ROWS"); if (rm) c->rows_mode = atoi(rm); }
   { const char* cr = getenv("ETLG_CHAIN_REISSUE"); if (cr) c->chain_reissue = atoi(cr) != 0; }
   { const char* cs = getenv("ETLG_CHAIN_SPARE"); if (cs) c->chain_spare = atoi(cs) != 0; }
+  { const char* pd = getenv("ETLG_PLAN_DELETES"); if (pd) c->plan_deletes = atoi(pd) != 0; }
   { const char* sc = getenv("ETLG_SCAN_CHAIN"); if (sc) c->scan_chain_mode = atoi(sc) != 0; }
   { const char* di = getenv("ETLG_DEBUG_INVARIANTS"); if (di) c->debug_invariants = atoi(di) != 0; }
   clear_error(c);

@@ -342,6 +342,9 @@ struct etlg_ctx {
   bool plan_covers_all = false;
   int plan_mode = 1;             // ETLG_PLAN=0 switches the plan off
   int plan_pre = 1;              // ETLG_PLAN_PRE: 0 = the plan kernel runs its look-back itself; 1 = tile prefixes from the sidecar pre-pass (k_plan_pre), one tile per wave; 2 = ... two tiles per wave
+  uint32_t plan_key_max = 0;     // the longest Delete by key a planned table sends in canonical form (no leading zeros / plus signs, 'n' at the other positions of a full-width tuple)
+  uint32_t plan_uniform_key_dw = 0, plan_key_below = 0;   // key-row dwords shared by every planned table; the shortest row frame one of them can send (the pre-pass prices a shorter frame as a Delete by key)
+  bool plan_deletes = true;      // ETLG_PLAN_DELETES=0: a Delete gives the batch up to the generic kernels, as before round 6's last session
   uint32_t plan_uniform_dw = 0;  // row dwords shared by every planned table (0: they differ — no pre-pass)
   uint32_t plan_margin_pct = 4;  // ETLG_PLAN_MARGIN: LDS window per tile = 64 average frames + this margin (a tile that does not fit is read in place)
   bool ctl_overlap_mode = true;  // ETLG_CTL_OVERLAP

@@ -288,35 +288,40 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
   const uint32_t tag = (uint32_t)(h30 & 0xFF);
   const uint32_t rel = __builtin_bswap32((uint32_t)(h30 >> 8));
   const uint32_t ncols = ((uint32_t)(h30 >> 48) & 0xFFu) << 8 | (uint32_t)(h30 >> 56);
-  bad |= sane & (uint32_t)(tag != 'I' && tag != 'U' && tag != 'B' && tag != 'C');
+  bad |= sane & (uint32_t)(tag != 'I' && tag != 'U' && tag != 'D' && tag != 'B' && tag != 'C');
   // (round 6) an Update WITHOUT an old image — what pgoutput sends for a table under its default replica identity whenever the key did not
   // change — has the Insert's layout: rel | 'N' | tuple. Its new row is a full row (an unchanged-toast cell, 'u', is not the plan's:
   // it gives the batch up below like every cell that is neither 't' nor 'n'), its event differs in the kind byte and in the payload
   // counter it adds to. An Update that carries 'K' / 'O' fails the shape test ('N' behind the relation id) and goes the generic way.
+  // (round 6, last session) a Delete BY KEY — rel | 'K' | tuple, what pgoutput sends under the default replica identity — decodes to the
+  // table's key-layout row (normalize_key_tuple_to_row, codec/event.rs:795-923: a dense tuple of the identity columns, or a full-width
+  // one whose other positions are skipped unread). 'O' (REPLICA IDENTITY FULL) and a table without identity columns go the generic way.
+  const bool isD = sane && tag == 'D';
   const bool isI = sane && (tag == 'I' || tag == 'U'), isB = sane && tag == 'B', isC = sane && tag == 'C';
   // table of every Insert lane: one scalar lookup per distinct table of the wave (descriptors through the scalar cache)
   int ti = -1;
-  uint32_t row_dw = 0, slot_id = 0, want_cols = 0;
+  uint32_t row_dw = 0, slot_id = 0, want_cols = 0, key_dw = 0, n_ident = 0;
   {
-    unsigned long long todo = __ballot(isI);
+    unsigned long long todo = __ballot(isI || isD);
     while (todo) {
       const int leader = __builtin_ctzll(todo);
       const uint32_t rel_u = (uint32_t)__builtin_amdgcn_readlane((int)rel, leader);
       const int t_u = plan_find(q, rel_u);
-      const bool mine = isI && rel == rel_u;
+      const bool mine = (isI || isD) && rel == rel_u;
       if (t_u >= 0) {
         const ETLG_CONST_AS uint32_t* tw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(q.tabs + t_u);
-        const uint32_t s_u = tw[1], n_u = tw[2], r_u = tw[3];
-        if (mine) { ti = t_u; slot_id = s_u; want_cols = n_u; row_dw = r_u; }
+        const uint32_t s_u = tw[1], n_u = tw[2], r_u = tw[3], k_u = tw[5], i_u = tw[6];
+        if (mine) { ti = t_u; slot_id = s_u; want_cols = n_u; row_dw = r_u; key_dw = k_u; n_ident = i_u; }
       }
       todo &= ~__ballot(mine);
     }
   }
   bad |= (uint32_t)(isI && (ti < 0 || ncols != want_cols));  // "Tuple data field count does not match schema" is the generic path's to report
+  bad |= (uint32_t)(isD && (ti < 0 || key_dw == 0 || (ncols != n_ident && ncols != want_cols)));   // ("Replica-identity tuple shape does not match schema": likewise)
   uint64_t b_lsn = 0;  // Begin: final_lsn; Commit: commit_lsn
   if (isB) b_lsn = bswap64(rd64(m, fr + 31));
   if (isC) b_lsn = bswap64(rd64(m, fr + 32));
-  const uint32_t fixed_dw = isI ? row_dw : isB ? 2u : isC ? 4u : 0u;
+  const uint32_t fixed_dw = isI ? row_dw : isD ? key_dw : isB ? 2u : isC ? 4u : 0u;
   const uint32_t mark = isB ? (((f + 1) << 1) | 1u) : isC ? ((f + 1) << 1) : 0u;
   const uint32_t im = wave_scan_max(mark);
   const uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)im, 0x138, 0xF, 0xF, false);  // wave_shr:1: exclusive running max
@@ -343,7 +348,10 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
   // pre-pass assumed about a frame it never read — a Begin is 51 bytes, a Commit 56, everything else a row of pre_row_dw dwords —
   // is checked here against the frame itself; a frame that breaks it sends the batch to the generic kernels like any other
   // shape the plan does not cover.
-  if (q.pre) bad |= (uint32_t)((isB && flen != kPreBeginLen) || (isC && flen != kPreCommitLen) || (isI && ti >= 0 && row_dw != q.pre_row_dw));
+  // (a Delete by key was priced as one when it is shorter than any row frame can be, q.pre_key_below, or no longer than q.pre_key_max — its tag
+  // was read then —, and as a row otherwise)
+  if (q.pre) bad |= (uint32_t)((isB && flen != kPreBeginLen) || (isC && flen != kPreCommitLen) || (isI && ti >= 0 && (row_dw != q.pre_row_dw || flen < q.pre_key_below)) ||
+                               (isD && ti >= 0 && (key_dw != q.pre_key_dw || (flen >= q.pre_key_below && flen > q.pre_key_max))));
   else plan_publish2(q.desc, tile, agg, tile_lsn);
   if (early && !q.pre) plan_resolve2(q.desc, q.desc + 2 * (size_t)q.ntiles, tile, agg, tile_lsn, failp, PlanPre2(), ex, ex_lsn);
   {
@@ -351,6 +359,7 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
     const uint32_t len = __builtin_bswap32((uint32_t)(h0 >> 8));
     const uint32_t env = ((uint32_t)(h0 & 0xFF) == 'd') & (len + 1u == flen) & ((uint32_t)((h0 >> 40) & 0xFF) == 'w');
     const uint32_t shape = (tag == 'I' || tag == 'U') ? (uint32_t)((uint32_t)((h30 >> 40) & 0xFF) == 'N')
+                         : tag == 'D' ? (uint32_t)((uint32_t)((h30 >> 40) & 0xFF) == 'K')
                          : tag == 'B' ? (uint32_t)(flen >= kBodyOff + 20) : (uint32_t)(flen >= kBodyOff + 25);
     bad |= sane & ((env & shape) ^ 1u);
   }
@@ -416,13 +425,67 @@ DEV void plan_local(const DecParams& p, const PlanParams& q, const M& m, u8* row
       }
       todo &= ~__ballot(mine);
     }
+    // Deletes by key (rare: the loop body is skipped when the tile has none). The loop runs over the SCHEMA's columns, wave-uniform; a lane
+    // reads a cell at a column when its tuple has one there — every column of a full-width tuple, the identity columns of a dense one.
+    unsigned long long todo_d = __ballot(isD && !bad);
+    while (todo_d) {
+      const int leader = __builtin_ctzll(todo_d);
+      const int t_u = __builtin_amdgcn_readlane(ti, leader);
+      const bool mine = isD && !bad && ti == t_u;
+      const ETLG_CONST_AS uint32_t* tw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(q.tabs + t_u);
+      const uint32_t n_u = tw[2], cb_u = tw[4], ni_u = tw[6], kb_u = tw[7];
+      const ETLG_CONST_AS uint32_t* cw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(q.cols + cb_u);
+      const ETLG_CONST_AS uint32_t* kw = (const ETLG_CONST_AS uint32_t*)(uintptr_t)(q.cols + kb_u);
+      if (mine) {
+        const bool dense = ncols != n_u;   // (ncols == n_ident; a table whose every column is an identity column reads the same either way)
+        uint32_t cur = fr + 38;
+        const uint32_t e = fr + flen;
+        uint32_t acc = 0, cbad = 0;
+        for (uint32_t i = 0; i < n_u; i++) {
+          const uint32_t cd = cw[i], kd = kw[i];
+          const uint32_t ident = kd & 1u;
+          if (!ident && dense) continue;            // a dense tuple has no cell for this column (wave-uniform per group of like tuples; lanes of the other kind go on)
+          const uint32_t cls = cd & 0xFFu;
+          const uint32_t rc = cur < e ? cur : fr;
+          const uint64_t ch = rd64(m, rc);
+          const uint32_t kind = (uint32_t)(ch & 0xFF);
+          const uint32_t len = __builtin_bswap32((uint32_t)(ch >> 8));
+          const uint32_t c0 = (uint32_t)(ch >> 40) & 0xFFu;
+          const uint32_t is_t = kind == 't', is_n = kind == 'n';
+          const uint32_t fits = (cur < e) & (is_n | (is_t & (rc + 5 <= e) & (len <= e - rc - 5)));
+          const uint32_t tl = (is_t & fits) ? len : 0u;
+          if (ident) {
+            uint32_t okv;
+            uint64_t v;
+            if (cls == ETLG_TC_BOOL) { okv = (tl == 1u) & ((c0 == 't') | (c0 == 'f')); v = c0 == 't'; }
+            else v = plan_int(m, rc + 5, tl, c0, cls, okv);
+            const uint32_t good = fits & ((is_n & ((cd >> 8) & 1u)) | (is_t & okv));   // ('u' in a key tuple is "missing source value": the generic path's to report)
+            cbad |= good ^ 1u;
+            const uint64_t val = is_t ? v : 0ull;
+            uint32_t* slot = rimg + (kd >> 24);
+            const uint32_t k = (kd >> 8) & 0xFFFFu;
+            slot[0] = (uint32_t)val;
+            if (cls == ETLG_TC_I64) slot[1] = (uint32_t)(val >> 32);
+            acc |= (is_n ? (uint32_t)ETLG_CELL_NULL : (uint32_t)ETLG_CELL_VALUE) << (2 * (k & 15));
+            if ((k & 15) == 15 || k + 1 == ni_u) { rimg[k >> 4] = acc; acc = 0; }
+          } else {
+            cbad |= fits ^ 1u;   // a position the key row does not take: skipped unread, its bytes still count (calculate_tuple_bytes)
+          }
+          vbytes += tl;
+          cur = rc + (is_t ? 5u + tl : 1u);
+        }
+        bad |= cbad;
+      }
+      todo_d &= ~__ballot(mine);
+    }
   }
   PSTAMP(3);
   WSTAMP(3);
   // (storing the header columns that do not depend on the look-back here, early, was tried: the descriptor loads of the finish
   // phase then queue behind those stores — memory operations of a wave return in order — and the kernel got 4 us slower)
-  L.tbl = isB ? b_xid : isI ? rel : 0u; L.slot_id = isI ? slot_id : 0u; L.pm = pm; L.x_fx = x_fx; L.fixed_dw = fixed_dw; L.vbytes = vbytes; L.bad = bad;
-  L.tagf = tag | (c_flags << 8) | ((isI ? 1u : 0u) << 16) | ((isB ? 1u : 0u) << 17) | ((isC ? 1u : 0u) << 18) | ((live ? 1u : 0u) << 19);
+  L.tbl = isB ? b_xid : (isI || isD) ? rel : 0u; L.slot_id = (isI || isD) ? slot_id : 0u; L.pm = pm; L.x_fx = x_fx; L.fixed_dw = fixed_dw; L.vbytes = vbytes; L.bad = bad;
+  if (isD) c_flags = ETLG_OLD_KEY;   // the event's flags column: which old row a Delete carries (write_frame, codec.hip.h)
+  L.tagf = tag | (c_flags << 8) | (((isI || isD) ? 1u : 0u) << 16) | ((isB ? 1u : 0u) << 17) | ((isC ? 1u : 0u) << 18) | ((live ? 1u : 0u) << 19);
   L.wal_start = wal_start; L.b_lsn = b_lsn; L.rimg = rimg;
   if (keep) {
 #pragma unroll
@@ -574,12 +637,16 @@ DEV void plan_store(DecParams& p, const PlanParams& q, uint32_t tile, const Plan
   PSTAMP(6);
   WSTAMP(5);
   // payload bytes of the tile's inserts / updates (A3), one atomic per wave into a shard
-  const bool is_upd = (L.tagf & 0xFFu) == 'U';
-  const uint32_t pay = wave_last(wave_scan_add(is_upd ? 0u : vbytes));
+  const bool is_upd = (L.tagf & 0xFFu) == 'U', is_del = (L.tagf & 0xFFu) == 'D';
+  const uint32_t pay = wave_last(wave_scan_add((is_upd || is_del) ? 0u : vbytes));
   if (lane == 0 && pay) atomicAdd(&p.res->pay_shard[tile & 31][0], (unsigned long long)pay);
   if (__ballot(is_upd && vbytes != 0)) {
     const uint32_t payu = wave_last(wave_scan_add(is_upd ? vbytes : 0u));
     if (lane == 0 && payu) atomicAdd(&p.res->pay_shard[tile & 31][1], (unsigned long long)payu);
+  }
+  if (__ballot(is_del && vbytes != 0)) {
+    const uint32_t payd = wave_last(wave_scan_add(is_del ? vbytes : 0u));
+    if (lane == 0 && payd) atomicAdd(&p.res->pay_shard[tile & 31][2], (unsigned long long)payd);
   }
   if ((any_bad || !cap_ok) && lane == 0) atomicOr(failp, 2u);
 }
@@ -733,6 +800,7 @@ __global__ __launch_bounds__(kPreWaves * 64) void k_plan_pre(DecParams p, PlanPa
   // the frames of a Begin's or a Commit's length: their tag byte and the eight bytes behind it, all 16 tiles' requests in flight at once
   // (one round trip; a wave meets a handful of such frames, and waiting for each tile's on its own was most of this kernel)
   uint32_t cand_m = 0;          // bit i: this lane's frame of tile i is such a frame
+  uint32_t short_m = 0;         // bit i: ... is shorter than a row frame can be
   uint32_t tagv[kPreTilesPerWave];
   uint64_t lsnv[kPreTilesPerWave];
 #pragma unroll
@@ -742,9 +810,10 @@ __global__ __launch_bounds__(kPreWaves * 64) void k_plan_pre(DecParams p, PlanPa
     const uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)o[i + 1]);   // lane 0 of the next tile
     const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp((int)nxt, (int)o0, 0x130, 0xF, 0xF, false);  // wave_shl:1 — the next lane's offset
     const uint32_t flen = o1 - o0;
-    const bool cand = f < p.nframes && o1 > o0 && o1 <= p.in_len && (flen == kPreBeginLen || flen == kPreCommitLen);
+    const bool cand = f < p.nframes && o1 > o0 && o1 <= p.in_len && (flen == kPreBeginLen || flen == kPreCommitLen || (flen >= q.pre_key_below && flen <= q.pre_key_max));
     tagv[i] = 0; lsnv[i] = 0;
     if (cand) { cand_m |= 1u << i; tagv[i] = p.in[o0 + 30] | (flen << 8); lsnv[i] = ld_be64(p.in + o0 + 31); }   // (a Commit's bytes there are its flags and seven of its LSN: unused)
+    if (flen < q.pre_key_below) short_m |= 1u << i;   // shorter than any row frame: a Delete by key, unless it is a Begin / Commit (the decode kernel checks each)
   }
   PlanFold run = fold_id();     // fold of this wave's tiles so far (wave-uniform)
   PlanFold keep = fold_id();    // lane i: the exclusive prefix of tile t0 + i inside the wave
@@ -757,7 +826,8 @@ __global__ __launch_bounds__(kPreWaves * 64) void k_plan_pre(DecParams p, PlanPa
     const uint32_t tag = tagv[i] & 0xFFu, flen = tagv[i] >> 8;
     const uint64_t lsn = lsnv[i];
     const bool isB = cand && flen == kPreBeginLen && tag == 'B', isC = cand && flen == kPreCommitLen && tag == 'C';
-    const uint32_t fixed_dw = !live ? 0u : isB ? 2u : isC ? 4u : q.pre_row_dw;
+    const bool isDel = ((short_m >> i) & 1u) || (cand && tag == 'D' && flen <= q.pre_key_max);   // (pre_key_max 0: never)
+    const uint32_t fixed_dw = !live ? 0u : isB ? 2u : isC ? 4u : isDel ? q.pre_key_dw : q.pre_row_dw;
     const uint32_t mark = isB ? ((((uint32_t)f + 1u) << 1) | 1u) : isC ? (((uint32_t)f + 1u) << 1) : 0u;
     const uint32_t tot_mark = wave_last(wave_scan_max(mark)), tot_fx = wave_last(wave_scan_add(fixed_dw));
     uint64_t tile_lsn = 0;

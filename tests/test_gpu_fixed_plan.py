@@ -302,8 +302,8 @@ def test_k_plan_two_tables_wide_rows_nulls_and_boundary_values(inplace):
                 os.environ[k] = saved[k]
 
 
-@pytest.mark.parametrize("what", ["long_leading_zeros", "null_in_required", "oid_minus_zero", "int2_overflow", "update_with_key", "update_toast", "delete",
-                                  "truncate", "keepalive", "unknown_table", "lsn_top_bits"])
+@pytest.mark.parametrize("what", ["long_leading_zeros", "null_in_required", "oid_minus_zero", "int2_overflow", "update_with_key", "update_toast", "delete_full",
+                                  "delete_key_shape", "delete_key_toast", "truncate", "keepalive", "unknown_table", "lsn_top_bits"])
 def test_k_plan_gives_up_and_the_generic_kernel_answers(what):
     """Shapes k_plan does not take. Legal ones (a value with twenty leading zeros, an Update, a keepalive ...) must come out
     exactly as the oracle has them, produced by the generic kernel ('plan_redone'); illegal ones must report the oracle's error."""
@@ -321,7 +321,9 @@ def test_k_plan_gives_up_and_the_generic_kernel_answers(what):
             "int2_overflow": W.insert(42, ["1"] + ["0", "0", "32768", "t", "0"] + ["0", "0", "0", "t", "0", "0", "0", "0"]),
             "update_with_key": W.update(43, ["5", "6"], key=["4"]),   # (an Update WITHOUT an old image is the plan's own since round 6: test_k_plan_takes_updates_without_an_old_image)
             "update_toast": W.update(43, ["5", W.TOAST]),
-            "delete": W.delete(43, key=["5"]),
+            "delete_full": W.delete(43, old=["5", "6"]),          # REPLICA IDENTITY FULL: 'O' (a Delete BY KEY is the plan's own since round 6: test_k_plan_takes_deletes_by_key)
+            "delete_key_shape": W.delete(43, key=["5", "6", "7"]),   # neither the identity columns nor the full width
+            "delete_key_toast": W.delete(43, key=[W.TOAST]),
             "truncate": W.truncate([43], 1),
             "keepalive": None,
             "unknown_table": W.insert(4242, ["1"]),
@@ -346,7 +348,7 @@ def test_k_plan_gives_up_and_the_generic_kernel_answers(what):
         err = _agree(d, o, buf, s.offsets)
         p = d.debug_paths()
         assert p["plan"] == 0 and p["plan_redone"] == 1, p
-        legal = what in ("long_leading_zeros", "update_with_key", "update_toast", "delete", "truncate", "keepalive", "lsn_top_bits", "unknown_table")   # a table without a state is not owned: its rows are skipped
+        legal = what in ("long_leading_zeros", "update_with_key", "update_toast", "delete_full", "truncate", "keepalive", "lsn_top_bits", "unknown_table")   # a table without a state is not owned: its rows are skipped
         assert (err == 0) == legal, (what, err)
         if not legal:
             assert p["redone"] == 1, p
@@ -379,6 +381,67 @@ def test_k_plan_takes_updates_without_an_old_image(pre):
             assert _agree(d, o, buf, st.offsets) == 0
         p = d.debug_paths()
         assert p["plan"] == 2 and p["plan_redone"] == 0 and p["redone"] == 0, p
+        d.close()
+    finally:
+        for k in _KNOBS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("tables", ["narrow_prepass", "narrow_lookback", "two_tables"])
+def test_k_plan_takes_deletes_by_key(tables):
+    """A Delete BY KEY (rel | 'K' | tuple: what pgoutput sends under the default replica identity) decodes to the table's key-layout row
+    (normalize_key_tuple_to_row, codec/event.rs:795-923). Since round 6's last session the fixed-width plan takes it: the dense form (the
+    identity columns only), the full-width form ('n' — or a value that is skipped unread — at the other positions), keys at the integer
+    limits. Behind the sidecar pre-pass a Delete is priced by its length — shorter than any row frame can be, or, in the range where rows
+    and Deletes overlap, by its tag byte — and a Delete the pre-pass priced as a row (a key with leading zeros beyond that range) gives
+    the batch up like every broken assumption. Every event against the oracle; the plan must have been the kernel."""
+    import random
+    from etl_amd.decoder import Decoder
+    from oracle import oracle
+    saved = {k: os.environ.pop(k, None) for k in _KNOBS}
+    os.environ["ETLG_FUSED_KERNEL"] = "3"
+    if tables == "narrow_lookback":
+        os.environ["ETLG_PLAN_PRE"] = "0"
+    try:
+        if tables == "two_tables":
+            d, o = Decoder(0), oracle.Oracle()
+            _two_tables(d); _two_tables(o)
+        else:
+            d, o = _pre_pair()
+        rng = random.Random(11)
+        forms43 = [lambda k: W.delete(43, key=[k]), lambda k: W.delete(43, key=[k, W.NULL]), lambda k: W.delete(43, key=[k[:3], "77"])]   # (a value at a position the key row skips makes the frame longer than the pre-pass looks for when the key is long too: short keys here)
+        keys = ["5", "0", "-12", "2147483647", "-2147483648", "+7", "007", "123456"]
+        for rnd in range(2):
+            s = W.Stream()
+            lsn, n, nd = 0x7000 + rnd * 0x10000, 0, 0
+            for t in range(9):
+                lsn += 0x100
+                s.add(W.begin(lsn, ts=1000 + t, xid=70 + t))
+                for r in range(41):
+                    if tables == "two_tables" and rng.random() < 0.4:
+                        s.add(W.insert(42, _wide_row(rng, n)))
+                    else:
+                        s.add(W.insert(43, [str(n), W.NULL if rng.random() < 0.3 else str(rng.randint(-10**12, 10**12))]))
+                    if n % 5 == 3:
+                        if tables == "two_tables" and nd % 3 == 2:
+                            s.add(W.delete(42, key=[str(n)]) if nd % 2 else W.delete(42, key=[str(-n)] + [W.NULL] * 13))
+                        else:
+                            s.add(forms43[nd % 3](keys[nd % len(keys)]))
+                        nd += 1
+                    n += 1
+                s.add(W.commit(lsn, lsn + 8, ts=2000 + t, flags=0))
+            buf = np.frombuffer(s.bytes(), dtype=np.uint8).copy()
+            assert _agree(d, o, buf, s.offsets) == 0
+            assert nd > 60
+        p = d.debug_paths()
+        assert p["plan"] == 2 and p["plan_redone"] == 0 and p["redone"] == 0, p
+        if tables == "narrow_prepass":   # a key with more leading zeros than the pre-pass looks for: priced as a row, found out by the decode kernel, decoded by the generic one
+            s = _plan_stream(3, 4, 30, odd=(17, W.delete(43, key=["0" * 30 + "9"])))
+            buf = np.frombuffer(s.bytes(), dtype=np.uint8).copy()
+            # (_plan_stream writes table 42 as well, which this pair does not know: rows of a table without a state are skipped — by the generic kernel)
+            assert _agree(d, o, buf, s.offsets) == 0
         d.close()
     finally:
         for k in _KNOBS:

@@ -90,6 +90,24 @@ while time.time() < t_end or rounds == 0:
         cut = int(o1[at])
         pieces[k] = (np.concatenate([b1[:cut], np.frombuffer(upd, dtype=np.uint8), b1[cut:]]),
                      np.concatenate([o1[:at + 1], o1[at:] + len(upd)]).astype(np.uint32))
+    # Deletes by key in a third of the batches (round 6, last session: the fixed-width plan decodes them itself — dense and full-width key tuples): an
+    # Insert replaced by the Delete of its row, same LSN
+    for k in range(len(pieces)):
+        if k in spliced or rng.random() > 0.33:
+            continue
+        b1, o1 = pieces[k]
+        ins = [f for f in range(len(o1) - 1) if b1[int(o1[f]) + 30] == ord("I")]
+        for f in sorted(rng.sample(ins, min(len(ins), rng.choice([1, 1, 2, 5]))), reverse=True):
+            fr = bytes(b1[int(o1[f]):int(o1[f + 1])])
+            cl = int.from_bytes(fr[39:43], "big")
+            cells = fr[38:43 + cl] + (b"n" * 4 if rng.random() < 0.5 else b"")
+            body = b"D" + fr[31:35] + b"K" + (5 if len(cells) > 5 + cl else 1).to_bytes(2, "big") + cells
+            nf = b"d" + (4 + 25 + len(body)).to_bytes(4, "big") + fr[5:30] + body
+            b1 = np.concatenate([b1[:int(o1[f])], np.frombuffer(nf, dtype=np.uint8), b1[int(o1[f + 1]):]])
+            o1 = o1.astype(np.int64).copy()
+            o1[f + 1:] += len(nf) - len(fr)
+            o1 = o1.astype(np.uint32)
+        pieces[k] = (b1, o1)
     broken = []
     if mode == "errors":   # a malformed integer in a few batches: the batch ends there with the reference's error, the context keeps the state before
         for k in sorted(rng.sample(range(3, len(pieces)), rng.choice([1, 2, 3]))):   # the failing frame, and the chain goes on from it (both sides alike)
@@ -128,7 +146,7 @@ while time.time() < t_end or rounds == 0:
             done += 1
             batches += 1
     paths = d.debug_paths()
-    if mode != "errors" and (paths["chain_rerun"] > (window + 1) * len(spliced) or paths["redone"]):
+    if mode != "errors" and os.environ.get("ETLG_PLAN_DELETES", "1") != "0" and (paths["chain_rerun"] > (window + 1) * len(spliced) or paths["redone"]):
         bad += 1
         print("CHAIN DID NOT HEAL seed", seed, "round", rounds, "window", window, "spliced", spliced, paths, flush=True)
     spliced_total += len(spliced)
